@@ -1,0 +1,168 @@
+// C-ABI: runtime init, raw network taps, numerics probe.
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "capi_common.h"
+#include "plans_embedded.inc"
+
+namespace ocr {
+
+static thread_local std::string g_last_error;
+void set_last_error(const std::string& msg) { g_last_error = msg; }
+int fail(int code, const std::string& msg) {
+  g_last_error = msg;
+  return code;
+}
+
+const char* embedded_plan(const char* kind) {
+  if (!strcmp(kind, "det")) return kPlanDet;
+  if (!strcmp(kind, "cls")) return kPlanCls;
+  if (!strcmp(kind, "rec")) return kPlanRec;
+  return nullptr;
+}
+
+bool load_model_dir(const std::string& model_dir, const char* weights_override, WeightMap& w, std::string& err) {
+  std::string model;
+  for (const char* n : {"/inference.pdmodel", "/model.pdmodel"})
+    if (file_exists(model_dir + n)) { model = model_dir + n; break; }
+  if (model.empty()) { err = "No valid model file found in " + model_dir; return false; }
+  std::string params;
+  if (weights_override) params = weights_override;
+  else
+    for (const char* n : {"/inference.pdiparams", "/model.pdiparams", "/synthetic.pdiparams"})
+      if (file_exists(model_dir + n)) { params = model_dir + n; break; }
+  if (params.empty() || !file_exists(params)) { err = "No parameter file found in " + model_dir; return false; }
+  std::vector<std::string> names;
+  if (!pdmodel_persistable_names(model, names, err)) return false;
+  return pdiparams_read(params, names, w, err);
+}
+
+}  // namespace ocr
+
+using namespace ocr;
+
+struct ocr_net {
+  Net net;
+  hipStream_t stream = nullptr;
+  float* x_dev = nullptr;
+  size_t x_cap = 0;
+  int device = 0;
+};
+
+extern "C" {
+
+const char* ocr_last_error(void) { return ocr::g_last_error.c_str(); }
+
+int ocr_rt_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int ocr_rt_init(int device_id) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) return fail(OCR_ERR_DEVICE, "no HIP device visible: this library has no CPU fallback");
+  if (device_id < 0 || device_id >= n) return fail(OCR_ERR_ARG, "device_id out of range");
+  CAPI_HIP(hipSetDevice(device_id));
+  hipDeviceProp_t prop;
+  CAPI_HIP(hipGetDeviceProperties(&prop, device_id));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(OCR_ERR_DEVICE, std::string("device is ") + prop.gcnArchName + ", this build targets gfx950 (MI355X) only");
+  return OCR_OK;
+}
+
+int ocr_net_create(const char* kind, const char* model_dir, const char* weights, int device_id, ocr_net** out) {
+  if (!kind || !model_dir || !out) return fail(OCR_ERR_ARG, "null argument");
+  const char* plan = embedded_plan(kind);
+  if (!plan) return fail(OCR_ERR_ARG, "kind must be det, cls or rec");
+  int rc = ocr_rt_init(device_id);
+  if (rc) return rc;
+  WeightMap w;
+  std::string err;
+  if (!load_model_dir(model_dir, weights, w, err)) return fail(OCR_ERR_MODEL, err);
+  std::unique_ptr<ocr_net> h(new ocr_net());
+  h->device = device_id;
+  if (!h->net.load(plan, w, err)) return fail(OCR_ERR_MODEL, err);
+  CAPI_HIP(hipStreamCreate(&h->stream));
+  *out = h.release();
+  return OCR_OK;
+}
+
+void ocr_net_destroy(ocr_net* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  if (h->x_dev) (void)hipFree(h->x_dev);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+int ocr_net_forward(ocr_net* h, const float* x, int N, int H, int W, int keep_all) {
+  if (!h || !x || N <= 0 || H <= 0 || W <= 0) return fail(OCR_ERR_ARG, "bad argument");
+  CAPI_HIP(hipSetDevice(h->device));
+  const size_t n = (size_t)N * H * W * 3;
+  if (n > h->x_cap) {
+    if (h->x_dev) (void)hipFree(h->x_dev);
+    h->x_dev = nullptr;
+    h->x_cap = 0;
+    CAPI_HIP(hipMalloc(&h->x_dev, n * sizeof(float)));
+    h->x_cap = n;
+  }
+  CAPI_HIP(hipMemcpyAsync(h->x_dev, x, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  h->net.set_keep_all(keep_all != 0);
+  std::string err;
+  if (!h->net.run(h->x_dev, N, H, W, h->stream, err)) return fail(OCR_ERR_DEVICE, err);
+  CAPI_HIP(hipStreamSynchronize(h->stream));
+  h->net.collect_timings();
+  return OCR_OK;
+}
+
+int ocr_net_num_tensors(ocr_net* h) { return h ? h->net.ntensors() : 0; }
+
+int ocr_net_fetch(ocr_net* h, int tid, float* out, size_t cap_floats, int dims[4]) {
+  if (!h || !out || !dims) return fail(OCR_ERR_ARG, "null argument");
+  CAPI_HIP(hipSetDevice(h->device));
+  std::vector<float> host;
+  std::string err;
+  if (!h->net.fetch_logical(tid, host, dims, h->stream, err)) return fail(OCR_ERR_DEVICE, err);
+  if (host.size() > cap_floats) return fail(OCR_ERR_CAPACITY, "output buffer too small");
+  memcpy(out, host.data(), host.size() * sizeof(float));
+  return OCR_OK;
+}
+
+int ocr_net_timing(ocr_net* h, int enable) {
+  if (!h) return fail(OCR_ERR_ARG, "null handle");
+  h->net.enable_timing(enable != 0);
+  h->net.reset_timings();
+  return OCR_OK;
+}
+
+int ocr_net_timing_report(ocr_net* h, char* buf, size_t cap) {
+  if (!h || !buf) return fail(OCR_ERR_ARG, "null argument");
+  size_t off = 0;
+  for (auto& kv : h->net.timings()) {
+    int n = snprintf(buf + off, cap > off ? cap - off : 0, "%s %.6f %ld %.0f %.0f\n", kv.first.c_str(), kv.second.ms,
+                     kv.second.count, kv.second.flops, kv.second.bytes);
+    if (n < 0 || off + n >= cap) return fail(OCR_ERR_CAPACITY, "report buffer too small");
+    off += n;
+  }
+  if (off < cap) buf[off] = 0;
+  return OCR_OK;
+}
+
+int ocr_probe(const float* a, const float* b, float* out, int n) {
+  if (!a || !b || !out || n <= 0) return fail(OCR_ERR_ARG, "bad argument");
+  float *da = nullptr, *db = nullptr, *dout = nullptr;
+  CAPI_HIP(hipMalloc(&da, n * sizeof(float)));
+  CAPI_HIP(hipMalloc(&db, n * sizeof(float)));
+  CAPI_HIP(hipMalloc(&dout, 6 * (size_t)n * sizeof(float)));
+  CAPI_HIP(hipMemcpy(da, a, n * sizeof(float), hipMemcpyHostToDevice));
+  CAPI_HIP(hipMemcpy(db, b, n * sizeof(float), hipMemcpyHostToDevice));
+  launch_probe(da, db, dout, n, nullptr);
+  CAPI_HIP(hipMemcpy(out, dout, 6 * (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+  (void)hipFree(da); (void)hipFree(db); (void)hipFree(dout);
+  return OCR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,96 @@
+// Host-visible launch interface of kernels_net.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "ocr_common.h"
+
+namespace ocr {
+
+enum : int { OUT_C8I = 0, OUT_PLAIN = 1, OUT_DECONV = 2 };
+
+struct ConvArgs {
+  const float* in;   // [N,H,W,Cs_in] C8I
+  float* out;
+  const float* wfrag;  // [tap][C8][NTtot][64 lanes][4]
+  long M;              // N*OH*OW GEMM rows
+  int N, H, W, Cs_in, C8;
+  int OH, OW, Cs_out;
+  int Cout;        // logical channels per quadrant (columns >= Cout inside CoutPadded store 0)
+  int CoutPadded;  // deconv: column = q*CoutPadded + ch
+  int ColsStore;   // GEMM columns that are stored
+  int NTtot;       // 32-wide column tiles in the fragment image
+  int KH, KW, PH, PW;
+  int out_mode;
+  int need_nyx;
+};
+void launch_conv_mfma(const ConvArgs& a, const Epilogue& ep, int nt, hipStream_t s);
+
+struct StemArgs {
+  const float* in;  // [N,H,W,3] plain
+  float* out;       // [N,OH,OW,Cs_out] C8I
+  const float* w;   // [KH*KW*3][Cs_out] physical order
+  long M;
+  int N, H, W, OH, OW, Cs_out, KH, KW, SH, SW, PH, PW;
+};
+void launch_stem(const StemArgs& a, const Epilogue& ep, hipStream_t s);
+
+struct DwArgs {
+  const float* in;
+  float* out;
+  const float* w;  // [K*K][Cs] physical order
+  long M;
+  int N, H, W, OH, OW, Cs, K, SH, SW, PH, PW;
+};
+void launch_dw(const DwArgs& a, const Epilogue& ep, hipStream_t s);
+
+void launch_ew(const float* in, float* out, long M, int H, int W, int Cs, const Epilogue& ep, hipStream_t s);
+void launch_gap(const float* in, float* part, float* out, int N, int H, int W, int Cs, hipStream_t s);
+
+struct SeArgs {
+  const float* in;  // [N][Cs]
+  float* out;       // [N][Cs]
+  const float *w1, *b1, *w2, *b2;  // logical: w1 [R][C], w2 [C][R]
+  int C, Cs, R;
+  float slope, offset;
+};
+void launch_sefc(const SeArgs& a, int N, hipStream_t s);
+
+struct ConcatArgs {
+  const float* src[4];
+  float* out;
+  long M;
+  int H, W, Cs, nsrc;
+  int coff[4], scs[4], up[4];
+};
+void launch_concat(const ConcatArgs& a, hipStream_t s);
+
+struct PoolArgs {
+  const float* in;
+  float* out;
+  long M;
+  int N, H, W, OH, OW, Cs, KH, KW, SH, SW, is_max;
+};
+void launch_pool(const PoolArgs& a, hipStream_t s);
+
+void launch_ln(const float* in, float* out, long rows, int C, int Cs, float eps, const float* g, const float* b,
+               hipStream_t s);
+void launch_attn(const float* qkv, float* out, int N, int T, int heads, int hd, int Cs_in, int Cs_out, float scale,
+                 hipStream_t s);
+void launch_softmax_argmax(const float* logits, float* probs, int* amax, float* pmax, long rows, int C, hipStream_t s);
+
+struct DetTailArgs {
+  const float* in;  // [N,H,W,Cs] C8I
+  float* prob;      // [N,2H,2W]
+  uint8_t* bitmap;  // [N,2H,2W] {0,1} or null
+  const float* w;   // [C][4] (dy*2+dx)
+  long M;
+  int N, H, W, C, Cs;
+  float bias;
+  int ithresh;  // floor(det_db_thresh*255): bit = trunc(p*255) > ithresh
+};
+void launch_det_tail(const DetTailArgs& a, hipStream_t s);
+
+void launch_c8i_to_plain(const float* in, float* out, long M, int C, int Cs, hipStream_t s);
+void launch_probe(const float* a, const float* b, float* out, int n, hipStream_t s);
+
+}  // namespace ocr

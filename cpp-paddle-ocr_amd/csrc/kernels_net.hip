@@ -1,0 +1,662 @@
+// Network kernels for gfx950 (MI355X).  f32 storage, f32 MFMA (`v_mfma_f32_32x32x2_f32`), every
+// contraction a single ascending-k fmaf chain — see ocr_common.h for the layout argument and
+// DESIGN.md §4 for the arithmetic contract these kernels implement bit for bit.
+//
+// Replaces the `Predictor::Run()` calls of the reference
+// (/root/reference/src/ocr_det.cpp:122, ocr_cls.cpp:74, ocr_rec.cpp:81).
+#include <hip/hip_runtime.h>
+
+#include "kernels_net.h"
+
+namespace ocr {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ void decompose(long m, int hw, int w, int& n, int& y, int& x) {
+  n = (int)(m / hw);
+  int r = (int)(m - (long)n * hw);
+  y = r / w;
+  x = r - y * w;
+}
+
+// ---- scalar epilogue for one value at (n, y, x, physical channel pc); oidx = its NHWC offset ----
+__device__ __forceinline__ float apply_epilogue(const Epilogue& ep, float v, int pc, int n, int y, int x, long oidx,
+                                                int cs) {
+  for (int s = 0; s < ep.n; ++s) {
+    const EpStage& st = ep.st[s];
+    switch (st.kind) {
+      case EP_BIAS: v = v + st.v0[pc]; break;
+      case EP_SMUL: v = st.p0 * v; break;
+      case EP_SADD: v = v + st.p0; break;
+      case EP_BN: { float t = v * st.v0[pc]; v = t + st.v1[pc]; } break;
+      case EP_ACT: v = ocr_act(st.act, st.p0, st.p1, v); break;
+      case EP_MULC: v = v * st.v0[(long)n * cs + pc]; break;
+      case EP_ADDT: v = v + st.v0[oidx]; break;
+      case EP_ADDUP: {
+        int sy = y / st.a0, sx = x / st.a0;
+        v = v + st.v0[(((long)n * st.a2 + sy) * st.a1 + sx) * cs + pc];
+      } break;
+    }
+  }
+  return v;
+}
+
+// 4 consecutive physical channels
+__device__ __forceinline__ float4 apply_epilogue4(const Epilogue& ep, float4 v, int pc, int n, int y, int x, long oidx,
+                                                  int cs) {
+  for (int s = 0; s < ep.n; ++s) {
+    const EpStage& st = ep.st[s];
+    switch (st.kind) {
+      case EP_BIAS: { float4 b = *(const float4*)(st.v0 + pc); v.x = v.x + b.x; v.y = v.y + b.y; v.z = v.z + b.z; v.w = v.w + b.w; } break;
+      case EP_SMUL: v.x = st.p0 * v.x; v.y = st.p0 * v.y; v.z = st.p0 * v.z; v.w = st.p0 * v.w; break;
+      case EP_SADD: v.x = v.x + st.p0; v.y = v.y + st.p0; v.z = v.z + st.p0; v.w = v.w + st.p0; break;
+      case EP_BN: {
+        float4 sc = *(const float4*)(st.v0 + pc), sh = *(const float4*)(st.v1 + pc);
+        float t;
+        t = v.x * sc.x; v.x = t + sh.x;
+        t = v.y * sc.y; v.y = t + sh.y;
+        t = v.z * sc.z; v.z = t + sh.z;
+        t = v.w * sc.w; v.w = t + sh.w;
+      } break;
+      case EP_ACT:
+        v.x = ocr_act(st.act, st.p0, st.p1, v.x); v.y = ocr_act(st.act, st.p0, st.p1, v.y);
+        v.z = ocr_act(st.act, st.p0, st.p1, v.z); v.w = ocr_act(st.act, st.p0, st.p1, v.w);
+        break;
+      case EP_MULC: { float4 g = *(const float4*)(st.v0 + (long)n * cs + pc); v.x = v.x * g.x; v.y = v.y * g.y; v.z = v.z * g.z; v.w = v.w * g.w; } break;
+      case EP_ADDT: { float4 g = *(const float4*)(st.v0 + oidx); v.x = v.x + g.x; v.y = v.y + g.y; v.z = v.z + g.z; v.w = v.w + g.w; } break;
+      case EP_ADDUP: {
+        int sy = y / st.a0, sx = x / st.a0;
+        float4 g = *(const float4*)(st.v0 + (((long)n * st.a2 + sy) * st.a1 + sx) * cs + pc);
+        v.x = v.x + g.x; v.y = v.y + g.y; v.z = v.z + g.z; v.w = v.w + g.w;
+      } break;
+    }
+  }
+  return v;
+}
+
+// Epilogue of one 32x32 accumulator tile.  Stage loop outside, the 16 rows unrolled inside each
+// stage, so the accumulator is only ever indexed statically (stays in registers).  Conv epilogues
+// on this path carry per-channel / scalar stages and same-shape residual adds only (the plan
+// generator never fuses MULC/ADDUP into a conv; the host checks).
+__device__ __forceinline__ void conv_epilogue_tile(const ConvArgs& a, const Epilogue& ep, const floatx16& accv, int nt,
+                                                   long m0, int p, int h, int hw) {
+  const int co = nt * 32 + p;  // logical column of the GEMM
+  if (nt >= a.NTtot || co >= a.ColsStore) return;
+  int ch = co, q = 0;  // channel for per-channel params; deconv quadrant
+  if (a.out_mode == OUT_DECONV) { q = co / a.CoutPadded; ch = co - q * a.CoutPadded; }
+  const int pc = (a.out_mode == OUT_PLAIN) ? ch : c8i_phys(ch);
+  const bool is_pad = ch >= a.Cout;
+  const long mb = m0 + 4 * h;  // row(r) = mb + (r&3) + 8*(r>>2)
+  float val[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) val[r] = accv[r];
+  for (int s = 0; s < ep.n; ++s) {
+    const EpStage& st = ep.st[s];
+    switch (st.kind) {
+      case EP_BIAS: { const float b = st.v0[pc];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) val[r] = val[r] + b; } break;
+      case EP_SMUL:
+#pragma unroll
+        for (int r = 0; r < 16; ++r) val[r] = st.p0 * val[r];
+        break;
+      case EP_SADD:
+#pragma unroll
+        for (int r = 0; r < 16; ++r) val[r] = val[r] + st.p0;
+        break;
+      case EP_BN: { const float sc = st.v0[pc], sh = st.v1[pc];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { const float t = val[r] * sc; val[r] = t + sh; } } break;
+      case EP_ACT:
+#pragma unroll
+        for (int r = 0; r < 16; ++r) val[r] = ocr_act(st.act, st.p0, st.p1, val[r]);
+        break;
+      case EP_ADDT:
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const long mr = mb + (r & 3) + 8 * (r >> 2);
+          if (mr < a.M) val[r] = val[r] + st.v0[mr * a.Cs_out + pc];
+        }
+        break;
+      default: break;
+    }
+  }
+  if (a.out_mode == OUT_DECONV) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const long mr = mb + (r & 3) + 8 * (r >> 2);
+      if (mr < a.M) {
+        int rn, ry, rx;
+        decompose(mr, hw, a.OW, rn, ry, rx);
+        const long o = (((long)rn * (2 * a.OH) + 2 * ry + (q >> 1)) * (2 * a.OW) + 2 * rx + (q & 1)) * a.Cs_out + pc;
+        a.out[o] = is_pad ? 0.0f : val[r];
+      }
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const long mr = mb + (r & 3) + 8 * (r >> 2);
+      if (mr < a.M) a.out[mr * a.Cs_out + pc] = is_pad ? 0.0f : val[r];
+    }
+  }
+}
+
+// =====================================================================================
+// Dense conv / linear / 2x2-s2 deconv as implicit GEMM on the f32 matrix cores.
+//   rows  m = (n, y, x) output pixels (stride-1 conv, zero padding), 32 per wave
+//   cols  j = output channels, NT tiles of 32 per wave
+//   k     = ((ky*KW)+kx)*Cin + ci ascending: one v_mfma_f32_32x32x2_f32 consumes (2s, 2s+1)
+// A comes straight from HBM/L2 as one 16-byte load per lane per 8 input channels (C8I layout),
+// B from the host-built fragment image (one 16-byte load per lane per n-tile per 8 channels).
+// No LDS, no barriers: four independent waves per workgroup.
+// =====================================================================================
+template <int NT>
+__global__ void __launch_bounds__(256) conv_mfma_kernel(const ConvArgs a, const Epilogue ep) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int p = lane & 31, h = lane >> 5;
+  const long m0 = ((long)blockIdx.x * 4 + wave) * 32;
+  if (m0 >= a.M) return;
+  const int nt0 = blockIdx.y * NT;
+  const int hw = a.OH * a.OW;
+  const long m = m0 + p;
+  const bool mvalid = m < a.M;
+  int n, y, x;
+  decompose(mvalid ? m : a.M - 1, hw, a.OW, n, y, x);
+
+  floatx16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+
+  const float4* __restrict__ wf = (const float4*)a.wfrag;
+  for (int ky = 0; ky < a.KH; ++ky) {
+    for (int kx = 0; kx < a.KW; ++kx) {
+      const int iy = y - a.PH + ky, ix = x - a.PW + kx;
+      const bool v = mvalid && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+      const float* src = a.in + (((long)n * a.H + (v ? iy : 0)) * a.W + (v ? ix : 0)) * a.Cs_in + 4 * h;
+      const float4* wrow = wf + ((long)(ky * a.KW + kx) * a.C8 * a.NTtot + nt0) * 64 + lane;
+#pragma unroll 2
+      for (int c8 = 0; c8 < a.C8; ++c8) {
+        float4 av = *(const float4*)(src + c8 * 8);
+        if (!v) av = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4* wp = wrow + (long)c8 * a.NTtot * 64;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          if (nt0 + t < a.NTtot) {
+            const float4 bv = wp[t * 64];
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc[t], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+
+  // ---- epilogue: lane owns output column j (one channel), 16 rows ----
+  conv_epilogue_tile(a, ep, acc[0], nt0 + 0, m0, p, h, hw);
+  if constexpr (NT > 1) conv_epilogue_tile(a, ep, acc[1], nt0 + 1, m0, p, h, hw);
+  if constexpr (NT > 2) conv_epilogue_tile(a, ep, acc[2], nt0 + 2, m0, p, h, hw);
+  if constexpr (NT > 3) conv_epilogue_tile(a, ep, acc[3], nt0 + 3, m0, p, h, hw);
+}
+
+void launch_conv_mfma(const ConvArgs& a, const Epilogue& ep, int nt, hipStream_t s) {
+  dim3 grid((unsigned)((a.M + 127) / 128), (unsigned)((a.NTtot + nt - 1) / nt));
+  switch (nt) {
+    case 1: hipLaunchKernelGGL(conv_mfma_kernel<1>, grid, dim3(256), 0, s, a, ep); break;
+    case 2: hipLaunchKernelGGL(conv_mfma_kernel<2>, grid, dim3(256), 0, s, a, ep); break;
+    case 3: hipLaunchKernelGGL(conv_mfma_kernel<3>, grid, dim3(256), 0, s, a, ep); break;
+    default: hipLaunchKernelGGL(conv_mfma_kernel<4>, grid, dim3(256), 0, s, a, ep); break;
+  }
+}
+
+// =====================================================================================
+// Stem: dense conv with Cin = 3 on the plain NHWC3 f32 image (any stride/pad), VALU.
+// One thread = one output pixel, all CS output channels; weights are wave-uniform (scalar loads).
+// =====================================================================================
+template <int CS>
+__global__ void __launch_bounds__(256) stem_conv_kernel(const StemArgs a, const Epilogue ep) {
+  const long m = (long)blockIdx.x * 256 + threadIdx.x;
+  if (m >= a.M) return;
+  int n, y, x;
+  decompose(m, a.OH * a.OW, a.OW, n, y, x);
+  float acc[CS];
+#pragma unroll
+  for (int c = 0; c < CS; ++c) acc[c] = 0.f;
+  for (int ky = 0; ky < a.KH; ++ky)
+    for (int kx = 0; kx < a.KW; ++kx) {
+      const int iy = y * a.SH - a.PH + ky, ix = x * a.SW - a.PW + kx;
+      const bool v = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+      const float* src = a.in + (((long)n * a.H + (v ? iy : 0)) * a.W + (v ? ix : 0)) * 3;
+      float in3[3];
+      in3[0] = v ? src[0] : 0.f;
+      in3[1] = v ? src[1] : 0.f;
+      in3[2] = v ? src[2] : 0.f;
+      const float* w = a.w + (long)(ky * a.KW + kx) * 3 * CS;
+#pragma unroll
+      for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+        for (int c = 0; c < CS; ++c) acc[c] = fmaf(in3[ci], w[ci * CS + c], acc[c]);
+    }
+  float* dst = a.out + m * CS;
+#pragma unroll
+  for (int c = 0; c < CS; c += 4) {
+    float4 v = make_float4(acc[c], acc[c + 1], acc[c + 2], acc[c + 3]);
+    v = apply_epilogue4(ep, v, c, n, y, x, m * CS + c, CS);
+    *(float4*)(dst + c) = v;
+  }
+}
+
+void launch_stem(const StemArgs& a, const Epilogue& ep, hipStream_t s) {
+  dim3 grid((unsigned)((a.M + 255) / 256));
+  if (a.Cs_out == 16) hipLaunchKernelGGL(stem_conv_kernel<16>, grid, dim3(256), 0, s, a, ep);
+  else hipLaunchKernelGGL(stem_conv_kernel<8>, grid, dim3(256), 0, s, a, ep);
+}
+
+// =====================================================================================
+// Depthwise conv, VALU.  One thread = one output pixel x 4 physical channels.
+// =====================================================================================
+template <int K>
+__global__ void __launch_bounds__(256) dw_conv_kernel(const DwArgs a, const Epilogue ep) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  const int c4n = a.Cs >> 2;
+  if (t >= a.M * c4n) return;
+  const long m = t / c4n;
+  const int pc = (int)(t - m * c4n) * 4;
+  int n, y, x;
+  decompose(m, a.OH * a.OW, a.OW, n, y, x);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < K; ++kx) {
+      const int iy = y * a.SH - a.PH + ky, ix = x * a.SW - a.PW + kx;
+      const bool v = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+      float4 av = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (v) av = *(const float4*)(a.in + (((long)n * a.H + iy) * a.W + ix) * a.Cs + pc);
+      const float4 wv = *(const float4*)(a.w + (long)(ky * K + kx) * a.Cs + pc);
+      acc.x = fmaf(av.x, wv.x, acc.x);
+      acc.y = fmaf(av.y, wv.y, acc.y);
+      acc.z = fmaf(av.z, wv.z, acc.z);
+      acc.w = fmaf(av.w, wv.w, acc.w);
+    }
+  const long oidx = m * a.Cs + pc;
+  acc = apply_epilogue4(ep, acc, pc, n, y, x, oidx, a.Cs);
+  *(float4*)(a.out + oidx) = acc;
+}
+
+void launch_dw(const DwArgs& a, const Epilogue& ep, hipStream_t s) {
+  const long total = a.M * (a.Cs >> 2);
+  dim3 grid((unsigned)((total + 255) / 256));
+  if (a.K == 3) hipLaunchKernelGGL(dw_conv_kernel<3>, grid, dim3(256), 0, s, a, ep);
+  else hipLaunchKernelGGL(dw_conv_kernel<5>, grid, dim3(256), 0, s, a, ep);
+}
+
+// =====================================================================================
+// Elementwise chain (SE gate multiply, residual add, FPN upsample-add).
+// =====================================================================================
+__global__ void __launch_bounds__(256) ew_kernel(const float* __restrict__ in, float* __restrict__ out, long M, int H,
+                                                 int W, int Cs, const Epilogue ep) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  const int c4n = Cs >> 2;
+  if (t >= M * c4n) return;
+  const long m = t / c4n;
+  const int pc = (int)(t - m * c4n) * 4;
+  int n, y, x;
+  decompose(m, H * W, W, n, y, x);
+  const long idx = m * Cs + pc;
+  float4 v = *(const float4*)(in + idx);
+  v = apply_epilogue4(ep, v, pc, n, y, x, idx, Cs);
+  *(float4*)(out + idx) = v;
+}
+
+void launch_ew(const float* in, float* out, long M, int H, int W, int Cs, const Epilogue& ep, hipStream_t s) {
+  const long total = M * (Cs >> 2);
+  hipLaunchKernelGGL(ew_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, out, M, H, W, Cs, ep);
+}
+
+// =====================================================================================
+// Global average pool in the contract's order: row-sequential sums, then column-sequential.
+// =====================================================================================
+__global__ void __launch_bounds__(256) gap_rows_kernel(const float* __restrict__ in, float* __restrict__ part, int N,
+                                                       int H, int W, int Cs) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (long)N * H * Cs) return;
+  const int pc = (int)(t % Cs);
+  const long ny = t / Cs;
+  const float* src = in + ny * W * Cs + pc;
+  float s = 0.f;
+  for (int x = 0; x < W; ++x) s = s + src[(long)x * Cs];
+  part[t] = s;
+}
+__global__ void __launch_bounds__(256) gap_cols_kernel(const float* __restrict__ part, float* __restrict__ out, int N,
+                                                       int H, int Cs, float cnt) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= N * Cs) return;
+  const int pc = t % Cs, n = t / Cs;
+  const float* src = part + (long)n * H * Cs + pc;
+  float s = 0.f;
+  for (int y = 0; y < H; ++y) s = s + src[(long)y * Cs];
+  out[t] = s / cnt;
+}
+void launch_gap(const float* in, float* part, float* out, int N, int H, int W, int Cs, hipStream_t s) {
+  const long t1 = (long)N * H * Cs;
+  hipLaunchKernelGGL(gap_rows_kernel, dim3((unsigned)((t1 + 255) / 256)), dim3(256), 0, s, in, part, N, H, W, Cs);
+  hipLaunchKernelGGL(gap_cols_kernel, dim3((unsigned)((N * Cs + 255) / 256)), dim3(256), 0, s, part, out, N, H, Cs,
+                     (float)(H * W));
+}
+
+// =====================================================================================
+// Squeeze-excite FCs: gate = hsig(W2 * relu(W1 * m + b1) + b2); one workgroup per sample.
+// Weights are in logical order; m / gate are [N][Cs] physical.
+// =====================================================================================
+__global__ void __launch_bounds__(256) sefc_kernel(const SeArgs a) {
+  extern __shared__ float sm[];
+  float* m = sm;            // [C] logical
+  float* hbuf = sm + a.C;   // [R]
+  const int n = blockIdx.x;
+  for (int c = threadIdx.x; c < a.C; c += 256) m[c] = a.in[(long)n * a.Cs + c8i_phys(c)];
+  __syncthreads();
+  for (int j = threadIdx.x; j < a.R; j += 256) {
+    const float* w = a.w1 + (long)j * a.C;
+    float acc = 0.f;
+    for (int c = 0; c < a.C; ++c) acc = fmaf(m[c], w[c], acc);
+    acc = acc + a.b1[j];
+    hbuf[j] = fmaxf(acc, 0.0f);
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < a.Cs; c += 256) {
+    const int lc = c8i_logical(c);
+    float g = 0.f;
+    if (lc < a.C) {
+      const float* w = a.w2 + (long)lc * a.R;
+      float acc = 0.f;
+      for (int j = 0; j < a.R; ++j) acc = fmaf(hbuf[j], w[j], acc);
+      acc = acc + a.b2[lc];
+      float t = acc * a.slope;
+      t = t + a.offset;
+      g = fminf(fmaxf(t, 0.0f), 1.0f);
+    }
+    a.out[(long)n * a.Cs + c] = g;
+  }
+}
+void launch_sefc(const SeArgs& a, int N, hipStream_t s) {
+  hipLaunchKernelGGL(sefc_kernel, dim3(N), dim3(256), (a.C + a.R) * sizeof(float), s, a);
+}
+
+// =====================================================================================
+// Concat with per-source nearest upsampling (FPN fuse; rec neck concat).
+// =====================================================================================
+__global__ void __launch_bounds__(256) concat_kernel(const ConcatArgs a) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  const int c4n = a.Cs >> 2;
+  if (t >= a.M * c4n) return;
+  const long m = t / c4n;
+  const int pc = (int)(t - m * c4n) * 4;
+  int n, y, x;
+  decompose(m, a.H * a.W, a.W, n, y, x);
+  int j = 0;
+#pragma unroll
+  for (int i = 1; i < 4; ++i)
+    if (i < a.nsrc && pc >= a.coff[i]) j = i;
+  const int up = a.up[j];
+  const int sh = a.H / up, sw = a.W / up;
+  const float4 v = *(const float4*)(a.src[j] + (((long)n * sh + y / up) * sw + x / up) * a.scs[j] + (pc - a.coff[j]));
+  *(float4*)(a.out + m * a.Cs + pc) = v;
+}
+void launch_concat(const ConcatArgs& a, hipStream_t s) {
+  const long total = a.M * (a.Cs >> 2);
+  hipLaunchKernelGGL(concat_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+}
+
+// =====================================================================================
+// Pooling without padding (rec avg k(3,2)s(3,2) incl. the H=2 truncation quirk; cls max 2x2).
+// =====================================================================================
+__global__ void __launch_bounds__(256) pool_kernel(const PoolArgs a) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  const int c4n = a.Cs >> 2;
+  if (t >= a.M * c4n) return;
+  const long m = t / c4n;
+  const int pc = (int)(t - m * c4n) * 4;
+  int n, y, x;
+  decompose(m, a.OH * a.OW, a.OW, n, y, x);
+  float4 acc = a.is_max ? make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY) : make_float4(0.f, 0.f, 0.f, 0.f);
+  int cnt = 0;
+  for (int dy = 0; dy < a.KH; ++dy)
+    for (int dx = 0; dx < a.KW; ++dx) {
+      const int iy = y * a.SH + dy, ix = x * a.SW + dx;
+      if (iy >= a.H || ix >= a.W) continue;
+      const float4 v = *(const float4*)(a.in + (((long)n * a.H + iy) * a.W + ix) * a.Cs + pc);
+      if (a.is_max) {
+        acc.x = fmaxf(acc.x, v.x); acc.y = fmaxf(acc.y, v.y); acc.z = fmaxf(acc.z, v.z); acc.w = fmaxf(acc.w, v.w);
+      } else {
+        acc.x = acc.x + v.x; acc.y = acc.y + v.y; acc.z = acc.z + v.z; acc.w = acc.w + v.w;
+      }
+      ++cnt;
+    }
+  if (!a.is_max) {
+    const float d = (float)cnt;
+    acc.x = acc.x / d; acc.y = acc.y / d; acc.z = acc.z / d; acc.w = acc.w / d;
+  }
+  *(float4*)(a.out + m * a.Cs + pc) = acc;
+}
+void launch_pool(const PoolArgs& a, hipStream_t s) {
+  const long total = a.M * (a.Cs >> 2);
+  hipLaunchKernelGGL(pool_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+}
+
+// =====================================================================================
+// LayerNorm over C logical channels, one thread per token (sequential sums: the contract's order).
+// =====================================================================================
+__global__ void __launch_bounds__(64) ln_kernel(const float* __restrict__ in, float* __restrict__ out, long rows, int C,
+                                                int Cs, float eps, const float* __restrict__ g,
+                                                const float* __restrict__ b) {
+  const long r = (long)blockIdx.x * 64 + threadIdx.x;
+  if (r >= rows) return;
+  const float* src = in + r * Cs;
+  float* dst = out + r * Cs;
+  float s = 0.f;
+  for (int c = 0; c < C; ++c) s = s + src[c8i_phys(c)];
+  const float mean = s / (float)C;
+  float v = 0.f;
+  for (int c = 0; c < C; ++c) {
+    const float xm = src[c8i_phys(c)] - mean;
+    v = fmaf(xm, xm, v);
+  }
+  const float var = v / (float)C;
+  const float rstd = 1.0f / sqrtf(var + eps);
+  for (int c = 0; c < C; ++c) {
+    const int pc = c8i_phys(c);
+    const float xm = src[pc] - mean;
+    float t = xm * rstd;
+    t = t * g[c];
+    dst[pc] = t + b[c];
+  }
+  for (int pc = 0; pc < Cs; ++pc)
+    if (c8i_logical(pc) >= C) dst[pc] = 0.f;
+}
+void launch_ln(const float* in, float* out, long rows, int C, int Cs, float eps, const float* g, const float* b,
+               hipStream_t s) {
+  hipLaunchKernelGGL(ln_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, s, in, out, rows, C, Cs, eps, g, b);
+}
+
+// =====================================================================================
+// Multi-head self-attention of the SVTR neck (T <= a few hundred, head dim 15).
+// One thread = one (n, head, query); three passes over the keys recompute q.k so nothing is
+// staged (max, sum of exp, P.V) — identical values each pass, so the contract's order holds.
+// =====================================================================================
+template <int HD>
+__global__ void __launch_bounds__(64) attn_kernel(const float* __restrict__ qkv, float* __restrict__ out, int N, int T,
+                                                  int heads, int Cs_in, int Cs_out, float scale) {
+  const long gid = (long)blockIdx.x * 64 + threadIdx.x;
+  if (gid >= (long)N * heads * T) return;
+  const int t = (int)(gid % T);
+  const int hh = (int)((gid / T) % heads);
+  const int n = (int)(gid / ((long)T * heads));
+  const int D = heads * HD;
+  const float* base = qkv + (long)n * T * Cs_in;
+  float q[HD];
+#pragma unroll
+  for (int d = 0; d < HD; ++d) q[d] = base[(long)t * Cs_in + c8i_phys(hh * HD + d)] * scale;
+  int kp[HD], vp[HD];
+#pragma unroll
+  for (int d = 0; d < HD; ++d) {
+    kp[d] = c8i_phys(D + hh * HD + d);
+    vp[d] = c8i_phys(2 * D + hh * HD + d);
+  }
+  float mx = -INFINITY;
+  for (int u = 0; u < T; ++u) {
+    const float* kr = base + (long)u * Cs_in;
+    float acc = 0.f;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) acc = fmaf(q[d], kr[kp[d]], acc);
+    mx = fmaxf(mx, acc);
+  }
+  float sum = 0.f;
+  for (int u = 0; u < T; ++u) {
+    const float* kr = base + (long)u * Cs_in;
+    float acc = 0.f;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) acc = fmaf(q[d], kr[kp[d]], acc);
+    sum = sum + ocr_expf(acc - mx);
+  }
+  float o[HD];
+#pragma unroll
+  for (int d = 0; d < HD; ++d) o[d] = 0.f;
+  for (int u = 0; u < T; ++u) {
+    const float* kr = base + (long)u * Cs_in;
+    float acc = 0.f;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) acc = fmaf(q[d], kr[kp[d]], acc);
+    const float e = ocr_expf(acc - mx);
+    const float pw = e / sum;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) o[d] = fmaf(pw, kr[vp[d]], o[d]);
+  }
+  float* dst = out + ((long)n * T + t) * Cs_out;
+#pragma unroll
+  for (int d = 0; d < HD; ++d) dst[c8i_phys(hh * HD + d)] = o[d];
+}
+void launch_attn(const float* qkv, float* out, int N, int T, int heads, int hd, int Cs_in, int Cs_out, float scale,
+                 hipStream_t s) {
+  const long total = (long)N * heads * T;
+  // hd is 15 for the only attention block on the path (rec plan); the runtime checks it at load.
+  hipLaunchKernelGGL(attn_kernel<15>, dim3((unsigned)((total + 63) / 64)), dim3(64), 0, s, qkv, out, N, T, heads, Cs_in,
+                     Cs_out, scale);
+}
+
+// =====================================================================================
+// Row softmax over plain [rows][C] + greedy-CTC inputs (arg max / max prob per row).
+// One wave per row; the sum is 64 strided partials + halving tree (contract order).
+// probs may be null (production: only idx/prob leave the chip).
+// =====================================================================================
+__global__ void __launch_bounds__(256) softmax_argmax_kernel(const float* __restrict__ logits, float* __restrict__ probs,
+                                                             int* __restrict__ amax, float* __restrict__ pmax, long rows,
+                                                             int C) {
+  const int lane = threadIdx.x & 63;
+  const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const float* src = logits + r * C;
+  float mx = -INFINITY;
+  for (int c = lane; c < C; c += 64) mx = fmaxf(mx, src[c]);
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+  float part = 0.f;
+  for (int c = lane; c < C; c += 64) part = part + ocr_expf(src[c] - mx);
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) part = part + __shfl_xor(part, off);
+  // NOTE: the xor butterfly gives lane 0 exactly the halving tree p[l] + p[l+off]; other lanes may
+  // differ in the last bit (different association), so broadcast lane 0's value.
+  const float sum = __shfl(part, 0);
+  float best = -1.0f;
+  int bi = 0x7fffffff;
+  for (int c = lane; c < C; c += 64) {
+    const float e = ocr_expf(src[c] - mx);
+    const float pr = e / sum;
+    if (probs) probs[r * C + c] = pr;
+    if (pr > best) { best = pr; bi = c; }
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const float ob = __shfl_xor(best, off);
+    const int oi = __shfl_xor(bi, off);
+    if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+  }
+  if (lane == 0) {
+    if (amax) amax[r] = bi;
+    if (pmax) pmax[r] = best;
+  }
+}
+void launch_softmax_argmax(const float* logits, float* probs, int* amax, float* pmax, long rows, int C, hipStream_t s) {
+  hipLaunchKernelGGL(softmax_argmax_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, logits, probs, amax, pmax,
+                     rows, C);
+}
+
+// =====================================================================================
+// DB head tail: deconv 2x2 s2 (Cin -> 1) + bias + sigmoid, fused with the reference's
+// `cbuf[i] = (uchar)(p*255)` and 8-bit threshold (/root/reference/src/ocr_det.cpp:143-154):
+// writes the f32 probability map and the {0,1} bitmap in one pass.
+// One thread = one input pixel -> 4 output pixels.
+// =====================================================================================
+__global__ void __launch_bounds__(256) det_tail_kernel(const DetTailArgs a) {
+  const long m = (long)blockIdx.x * 256 + threadIdx.x;
+  if (m >= a.M) return;
+  int n, y, x;
+  decompose(m, a.H * a.W, a.W, n, y, x);
+  const float* src = a.in + m * a.Cs;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int c = 0; c < a.C; ++c) {
+    const float v = src[c8i_phys(c)];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = fmaf(v, a.w[c * 4 + q], acc[q]);
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    float v = acc[q] + a.bias;
+    const float e = ocr_expf(-v);
+    const float d = 1.0f + e;
+    v = 1.0f / d;
+    const long o = ((long)n * 2 * a.H + 2 * y + (q >> 1)) * (2 * a.W) + 2 * x + (q & 1);
+    a.prob[o] = v;
+    if (a.bitmap) {
+      const int u8 = (int)(v * 255.0f);  // (unsigned char)(p*255): truncation; p in [0,1]
+      a.bitmap[o] = u8 > a.ithresh ? 1 : 0;
+    }
+  }
+}
+void launch_det_tail(const DetTailArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(det_tail_kernel, dim3((unsigned)((a.M + 255) / 256)), dim3(256), 0, s, a);
+}
+
+// ---- layout conversion taps (debug / parity): C8I [M][Cs] -> logical [M][C] ----
+__global__ void __launch_bounds__(256) c8i_to_plain_kernel(const float* __restrict__ in, float* __restrict__ out, long M,
+                                                           int C, int Cs) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= M * C) return;
+  const long m = t / C;
+  const int c = (int)(t - m * C);
+  out[t] = in[m * Cs + c8i_phys(c)];
+}
+void launch_c8i_to_plain(const float* in, float* out, long M, int C, int Cs, hipStream_t s) {
+  hipLaunchKernelGGL(c8i_to_plain_kernel, dim3((unsigned)((M * C + 255) / 256)), dim3(256), 0, s, in, out, M, C, Cs);
+}
+
+// ---- numerics probe (tests): does the hardware match the arithmetic contract? ----
+__global__ void probe_kernel(const float* a, const float* b, float* out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  out[i] = a[i] / b[i];
+  out[n + i] = sqrtf(fabsf(a[i]));
+  out[2 * n + i] = ocr_expf(a[i]);
+  out[3 * n + i] = fmaf(a[i], b[i], a[i]);
+  float t = a[i] * b[i];
+  out[4 * n + i] = t + a[i];
+  out[5 * n + i] = rintf(a[i] * 1.44269504088896341f);
+}
+void launch_probe(const float* a, const float* b, float* out, int n, hipStream_t s) {
+  hipLaunchKernelGGL(probe_kernel, dim3((n + 255) / 256), dim3(256), 0, s, a, b, out, n);
+}
+
+}  // namespace ocr

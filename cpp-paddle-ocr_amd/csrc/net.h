@@ -1,0 +1,126 @@
+// Plan-driven network executor: owns device weights (in kernel-ready layouts), an activation
+// arena, and the per-shape launch list.  One instance per model per handle (= per host thread /
+// HIP stream), mirroring "one predictor per stage object" of the reference
+// (/root/reference/include/paddle_ocr/ocr_det.h:101).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <functional>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "kernels_net.h"
+#include "pd_format.h"
+
+namespace ocr {
+
+struct PlanStage {
+  int kind = 0, act = 0;
+  float p0 = 0, p1 = 0;
+  std::string n0, n1, n2, n3;
+  int tid = -1, up = 1;
+};
+
+struct PlanOp {
+  enum Kind { CONV, DW, DECONV, LINEAR, SEFC, GAP, POOL, EW, CONCAT, LN, ATTN, SOFTMAX, OUTPUT };
+  Kind kind;
+  int in = -1, out = -1;
+  std::vector<int> ins, ups;  // concat
+  int cin = 0, cout = 0, c = 0, cr = 0;
+  int kh = 1, kw = 1, sh = 1, sw = 1, ph = 0, pw = 0;
+  bool pool_max = false;
+  int heads = 0, hd = 0;
+  float scale = 0, eps = 0, slope = 0, offset = 0;
+  std::string w, w1, b1, w2, b2, g, b;
+  std::vector<PlanStage> ep;
+};
+
+struct Plan {
+  std::string name;
+  int ntensors = 0;
+  std::vector<PlanOp> ops;
+};
+
+bool parse_plan(const char* text, Plan& plan, std::string& err);
+
+struct TensorDesc {
+  int n = 0, h = 0, w = 0, c = 0, cs = 0;
+  bool plain = false;  // logical channel order, cs == c
+  size_t offset = 0;   // floats into the arena
+  size_t numel() const { return (size_t)n * h * w * cs; }
+};
+
+struct KernelTiming {
+  double ms = 0;
+  long count = 0;
+  double flops = 0;  // algorithmic FLOPs per launch (last bind)
+  double bytes = 0;  // algorithmic bytes per launch
+};
+
+class Net {
+ public:
+  ~Net();
+  bool load(const char* plan_text, const WeightMap& weights, std::string& err);
+  // Binds shapes (re-planning arena + launches if they changed) and enqueues the network.
+  // x: device f32 [N,H,W,3] plain NHWC (already normalised).
+  bool run(const float* x, int N, int H, int W, hipStream_t s, std::string& err);
+  const TensorDesc& tensor(int tid) const { return tensors_[tid]; }
+  const float* tensor_ptr(int tid) const { return arena_ + tensors_[tid].offset; }
+  int output_tid() const { return out_tid_; }
+  int ntensors() const { return plan_.ntensors; }
+  // Copies tensor `tid` to host in logical NHWC order (parity taps).
+  bool fetch_logical(int tid, std::vector<float>& host, int dims[4], hipStream_t s, std::string& err);
+
+  // --- det tail options: fused u8 threshold bitmap (null = none) ---
+  void set_det_bitmap(uint8_t* bitmap, int ithresh) { det_bitmap_ = bitmap; det_ithresh_ = ithresh; bound_n_ = -1; }
+  // --- rec/cls head options: where the row softmax leaves its results ---
+  void set_head_outputs(float* probs, int* amax, float* pmax) { head_probs_ = probs; head_amax_ = amax; head_pmax_ = pmax; bound_n_ = -1; }
+
+  // parity debugging: give every tensor its own arena slot so intermediate taps stay valid
+  void set_keep_all(bool on) { keep_all_ = on; bound_n_ = -1; }
+
+  // per-kernel-family timing with HIP events on the launch stream (bench / roofline)
+  void enable_timing(bool on) { timing_ = on; }
+  const std::map<std::string, KernelTiming>& timings() const { return timings_; }
+  void reset_timings() { timings_.clear(); }
+  void collect_timings();  // after a stream sync: folds event pairs into timings_
+
+ private:
+  struct Launch {
+    std::string name;
+    double flops = 0, bytes = 0;
+    std::function<void(hipStream_t)> fn;
+  };
+  bool bind(int N, int H, int W, std::string& err);
+  bool build_epilogue(const PlanOp& op, Epilogue& ep, bool conv_path, std::string& err);
+  const float* dev_vec(const std::string& key) const;
+  float* upload(const std::string& key, const std::vector<float>& v);
+
+  Plan plan_;
+  std::map<std::string, float*> dev_;        // uploaded parameter images by key
+  std::map<std::string, float> scalars_;
+  WeightMap host_w_;                          // kept only for scalar lookups / shapes
+  std::vector<TensorDesc> tensors_;
+  std::vector<Launch> launches_;
+  float* arena_ = nullptr;
+  size_t arena_cap_ = 0;
+  float* gap_part_ = nullptr;
+  size_t gap_part_cap_ = 0;
+  int bound_n_ = -1, bound_h_ = -1, bound_w_ = -1;
+  const float* bound_x_ = nullptr;
+  int out_tid_ = -1;
+  uint8_t* det_bitmap_ = nullptr;
+  int det_ithresh_ = 0;
+  float* head_probs_ = nullptr;
+  int* head_amax_ = nullptr;
+  float* head_pmax_ = nullptr;
+  bool timing_ = false;
+  bool keep_all_ = false;
+  std::map<std::string, KernelTiming> timings_;
+  struct EvPair { hipEvent_t a, b; int launch; };
+  std::vector<EvPair> ev_pending_;
+  std::vector<hipEvent_t> ev_pool_;
+};
+
+}  // namespace ocr

@@ -1,0 +1,701 @@
+#include "net.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <sstream>
+
+namespace ocr {
+
+#define HIP_OK(expr)                                                                       \
+  do {                                                                                     \
+    hipError_t _e = (expr);                                                                \
+    if (_e != hipSuccess) {                                                                \
+      err = std::string(#expr) + ": " + hipGetErrorString(_e);                             \
+      return false;                                                                        \
+    }                                                                                      \
+  } while (0)
+
+// ------------------------------------------------------------------ plan text -> Plan
+static std::vector<std::string> split(const std::string& s, char sep) {
+  std::vector<std::string> r;
+  std::stringstream ss(s);
+  std::string t;
+  while (std::getline(ss, t, sep)) r.push_back(t);
+  return r;
+}
+
+bool parse_plan(const char* text, Plan& plan, std::string& err) {
+  std::stringstream ss(text);
+  std::string line;
+  while (std::getline(ss, line)) {
+    if (line.empty() || line[0] == '#') continue;
+    auto toks = split(line, ' ');
+    if (toks[0] == "plan") {
+      plan.name = toks.size() > 1 ? toks[1] : "";
+      for (auto& t : toks)
+        if (t.rfind("ntensors=", 0) == 0) plan.ntensors = atoi(t.c_str() + 9);
+      continue;
+    }
+    PlanOp op;
+    const std::string& k = toks[0];
+    if (k == "conv") op.kind = PlanOp::CONV;
+    else if (k == "dw") op.kind = PlanOp::DW;
+    else if (k == "deconv") op.kind = PlanOp::DECONV;
+    else if (k == "linear") op.kind = PlanOp::LINEAR;
+    else if (k == "sefc") op.kind = PlanOp::SEFC;
+    else if (k == "gap") op.kind = PlanOp::GAP;
+    else if (k == "pool") op.kind = PlanOp::POOL;
+    else if (k == "ew") op.kind = PlanOp::EW;
+    else if (k == "concat") op.kind = PlanOp::CONCAT;
+    else if (k == "ln") op.kind = PlanOp::LN;
+    else if (k == "attn") op.kind = PlanOp::ATTN;
+    else if (k == "softmax") op.kind = PlanOp::SOFTMAX;
+    else if (k == "output") op.kind = PlanOp::OUTPUT;
+    else { err = "plan: unknown op " + k; return false; }
+    for (size_t i = 1; i < toks.size(); ++i) {
+      auto eq = toks[i].find('=');
+      if (eq == std::string::npos) { err = "plan: bad token " + toks[i]; return false; }
+      const std::string key = toks[i].substr(0, eq), v = toks[i].substr(eq + 1);
+      auto I = [&]() { return atoi(v.c_str()); };
+      auto F = [&]() { return strtof(v.c_str(), nullptr); };
+      if (key == "i") {
+        if (op.kind == PlanOp::CONCAT) for (auto& t : split(v, ',')) op.ins.push_back(atoi(t.c_str()));
+        else op.in = I();
+      } else if (key == "up") { for (auto& t : split(v, ',')) op.ups.push_back(atoi(t.c_str())); }
+      else if (key == "o") op.out = I();
+      else if (key == "cin") op.cin = I();
+      else if (key == "cout") op.cout = I();
+      else if (key == "c") op.c = I();
+      else if (key == "cr") op.cr = I();
+      else if (key == "kh") op.kh = I();
+      else if (key == "kw") op.kw = I();
+      else if (key == "sh") op.sh = I();
+      else if (key == "sw") op.sw = I();
+      else if (key == "ph") op.ph = I();
+      else if (key == "pw") op.pw = I();
+      else if (key == "type") op.pool_max = (v == "max");
+      else if (key == "heads") op.heads = I();
+      else if (key == "hd") op.hd = I();
+      else if (key == "scale") op.scale = F();
+      else if (key == "eps") op.eps = F();
+      else if (key == "slope") op.slope = F();
+      else if (key == "offset") op.offset = F();
+      else if (key == "w") op.w = v;
+      else if (key == "w1") op.w1 = v;
+      else if (key == "b1") op.b1 = v;
+      else if (key == "w2") op.w2 = v;
+      else if (key == "b2") op.b2 = v;
+      else if (key == "g") op.g = v;
+      else if (key == "b") op.b = v;
+      else if (key == "ep") {
+        for (auto& st : split(v, '|')) {
+          auto c = st.find(':');
+          const std::string sk = st.substr(0, c);
+          auto args = split(st.substr(c + 1), ',');
+          PlanStage s;
+          if (sk == "bias") { s.kind = EP_BIAS; s.n0 = args[0]; }
+          else if (sk == "smul") { s.kind = EP_SMUL; s.n0 = args[0]; }
+          else if (sk == "sadd") { s.kind = EP_SADD; s.n0 = args[0]; }
+          else if (sk == "bn") { s.kind = EP_BN; s.n0 = args[0]; s.n1 = args[1]; s.n2 = args[2]; s.n3 = args[3]; s.p0 = strtof(args[4].c_str(), nullptr); }
+          else if (sk == "act") {
+            s.kind = EP_ACT;
+            if (args[0] == "relu") s.act = ACT_RELU;
+            else if (args[0] == "hswish") s.act = ACT_HSWISH;
+            else if (args[0] == "hsig") { s.act = ACT_HSIG; s.p0 = strtof(args[1].c_str(), nullptr); s.p1 = strtof(args[2].c_str(), nullptr); }
+            else if (args[0] == "swish") s.act = ACT_SWISH;
+            else if (args[0] == "sigmoid") s.act = ACT_SIGMOID;
+            else { err = "plan: unknown act " + args[0]; return false; }
+          }
+          else if (sk == "mulc") { s.kind = EP_MULC; s.tid = atoi(args[0].c_str()); }
+          else if (sk == "addt") { s.kind = EP_ADDT; s.tid = atoi(args[0].c_str()); }
+          else if (sk == "addup") { s.kind = EP_ADDUP; s.tid = atoi(args[0].c_str()); s.up = atoi(args[1].c_str()); }
+          else { err = "plan: unknown stage " + sk; return false; }
+          op.ep.push_back(s);
+        }
+      } else { err = "plan: unknown key " + key; return false; }
+    }
+    plan.ops.push_back(op);
+  }
+  if (plan.ntensors <= 0) { err = "plan: missing header"; return false; }
+  return true;
+}
+
+// ------------------------------------------------------------------ weights
+Net::~Net() {
+  for (auto& kv : dev_) (void)hipFree(kv.second);
+  if (arena_) (void)hipFree(arena_);
+  if (gap_part_) (void)hipFree(gap_part_);
+  for (auto e : ev_pool_) (void)hipEventDestroy(e);
+  for (auto& p : ev_pending_) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+}
+
+float* Net::upload(const std::string& key, const std::vector<float>& v) {
+  auto it = dev_.find(key);
+  if (it != dev_.end()) return it->second;
+  float* d = nullptr;
+  size_t bytes = std::max<size_t>(v.size(), 4) * sizeof(float);
+  if (hipMalloc(&d, bytes) != hipSuccess) return nullptr;
+  if (!v.empty() && hipMemcpy(d, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+  dev_[key] = d;
+  return d;
+}
+
+const float* Net::dev_vec(const std::string& key) const {
+  auto it = dev_.find(key);
+  return it == dev_.end() ? nullptr : it->second;
+}
+
+// per-channel vector -> physical order, zero padded
+static std::vector<float> perm_vec(const std::vector<float>& v, int C, bool plain) {
+  if (plain) return v;
+  std::vector<float> o(c8i_stride(C), 0.f);
+  for (int c = 0; c < C; ++c) o[c8i_phys(c)] = v[c];
+  return o;
+}
+
+// B-fragment image for conv_mfma_kernel: [tap][C8][NTtot][lane][4];
+// get(col, k, tap) returns the weight of GEMM column `col`, input channel k, tap.
+template <class Get>
+static std::vector<float> build_frag(int taps, int cin, int cols, Get get) {
+  const int C8 = c8i_stride(cin) / 8, NT = (cols + 31) / 32;
+  std::vector<float> f((size_t)taps * C8 * NT * 64 * 4, 0.f);
+  for (int tap = 0; tap < taps; ++tap)
+    for (int c8 = 0; c8 < C8; ++c8)
+      for (int nt = 0; nt < NT; ++nt)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int s = 0; s < 4; ++s) {
+            const int col = nt * 32 + (lane & 31);
+            const int k = c8 * 8 + 2 * s + (lane >> 5);
+            float v = 0.f;
+            if (col < cols && k < cin) v = get(col, k, tap);
+            f[((((size_t)tap * C8 + c8) * NT + nt) * 64 + lane) * 4 + s] = v;
+          }
+  return f;
+}
+
+bool Net::load(const char* plan_text, const WeightMap& W, std::string& err) {
+  if (!parse_plan(plan_text, plan_, err)) return false;
+  host_w_ = W;
+  auto need = [&](const std::string& n) -> const HostTensor* {
+    auto it = W.find(n);
+    if (it == W.end()) { err = "weights: missing parameter '" + n + "' (graph/params mismatch)"; return nullptr; }
+    return &it->second;
+  };
+  // which tensors are kept in plain (logical) channel order
+  std::vector<char> plain(plan_.ntensors, 0);
+  plain[0] = 1;
+  for (auto& op : plan_.ops) {
+    if (op.kind == PlanOp::SOFTMAX) { plain[op.in] = 1; plain[op.out] = 1; }
+    if (op.kind == PlanOp::DECONV && op.cout == 1) plain[op.out] = 1;
+    if (op.kind == PlanOp::OUTPUT) out_tid_ = op.in;
+  }
+  tensors_.assign(plan_.ntensors, TensorDesc());
+  for (int i = 0; i < plan_.ntensors; ++i) tensors_[i].plain = plain[i];
+
+  for (auto& op : plan_.ops) {
+    // epilogue parameter images
+    const int oc = (op.kind == PlanOp::CONV || op.kind == PlanOp::DECONV || op.kind == PlanOp::LINEAR) ? op.cout : op.c;
+    const bool oplain = op.out >= 0 && plain[op.out];
+    for (auto& st : op.ep) {
+      if (st.kind == EP_BIAS) {
+        auto p = need(st.n0); if (!p) return false;
+        if ((int)p->numel() != oc) { err = "bias size mismatch " + st.n0; return false; }
+        if (!upload((oplain ? "vecp:" : "vec:") + st.n0, perm_vec(p->data, oc, oplain))) { err = "hipMalloc failed"; return false; }
+      } else if (st.kind == EP_SMUL || st.kind == EP_SADD) {
+        auto p = need(st.n0); if (!p) return false;
+        scalars_[st.n0] = p->data[0];
+      } else if (st.kind == EP_BN) {
+        auto g = need(st.n0), b = need(st.n1), m = need(st.n2), v = need(st.n3);
+        if (!g || !b || !m || !v) return false;
+        std::vector<float> sc(oc), sh(oc);
+        for (int c = 0; c < oc; ++c) {
+          const float inv = 1.0f / sqrtf(v->data[c] + st.p0);
+          const float s = g->data[c] * inv;
+          const float mi = m->data[c] * inv;
+          const float ms = mi * g->data[c];
+          sc[c] = s;
+          sh[c] = b->data[c] - ms;
+        }
+        if (!upload("bns:" + st.n0, perm_vec(sc, oc, oplain)) || !upload("bnt:" + st.n0, perm_vec(sh, oc, oplain))) { err = "hipMalloc failed"; return false; }
+      }
+    }
+    switch (op.kind) {
+      case PlanOp::CONV: {
+        auto p = need(op.w); if (!p) return false;
+        const int co = op.cout, ci = op.cin, kh = op.kh, kw = op.kw;
+        if (p->dims.size() != 4 || p->dims[0] != co || p->dims[1] != ci || p->dims[2] != kh || p->dims[3] != kw) { err = "conv filter shape mismatch " + op.w; return false; }
+        const float* w = p->data.data();
+        if (ci == 3) {
+          const int cs = c8i_stride(co);
+          std::vector<float> img((size_t)kh * kw * 3 * cs, 0.f);
+          for (int o = 0; o < co; ++o)
+            for (int c = 0; c < 3; ++c)
+              for (int t = 0; t < kh * kw; ++t) img[((size_t)t * 3 + c) * cs + c8i_phys(o)] = w[((size_t)o * 3 + c) * kh * kw + t];
+          if (!upload("stem:" + op.w, img)) { err = "hipMalloc failed"; return false; }
+        } else {
+          if (op.sh != 1 || op.sw != 1) { err = "strided dense conv with Cin != 3 is not on this path"; return false; }
+          const int cols = plain[op.out] ? co : c8i_stride(co);
+          auto f = build_frag(kh * kw, ci, cols, [&](int col, int k, int tap) {
+            return col < co ? w[((size_t)col * ci + k) * kh * kw + tap] : 0.f;
+          });
+          if (!upload("frag:" + op.w, f)) { err = "hipMalloc failed"; return false; }
+        }
+      } break;
+      case PlanOp::LINEAR: {
+        auto p = need(op.w); if (!p) return false;
+        const int ci = op.cin, co = op.cout;
+        if (p->dims.size() != 2 || p->dims[0] != ci || p->dims[1] != co) { err = "linear weight shape mismatch " + op.w; return false; }
+        const float* w = p->data.data();
+        const int cols = plain[op.out] ? co : c8i_stride(co);
+        auto f = build_frag(1, ci, cols, [&](int col, int k, int) { return col < co ? w[(size_t)k * co + col] : 0.f; });
+        if (!upload("frag:" + op.w, f)) { err = "hipMalloc failed"; return false; }
+      } break;
+      case PlanOp::DECONV: {
+        auto p = need(op.w); if (!p) return false;
+        const int ci = op.cin, co = op.cout;
+        if (p->dims.size() != 4 || p->dims[0] != ci || p->dims[1] != co || p->dims[2] != 2 || p->dims[3] != 2) { err = "deconv filter shape mismatch " + op.w; return false; }
+        const float* w = p->data.data();
+        if (co == 1) {
+          std::vector<float> img((size_t)ci * 4);
+          for (int c = 0; c < ci; ++c)
+            for (int q = 0; q < 4; ++q) img[(size_t)c * 4 + q] = w[(size_t)c * 4 + q];
+          if (!upload("tail:" + op.w, img)) { err = "hipMalloc failed"; return false; }
+        } else {
+          const int cp = c8i_stride(co);
+          auto f = build_frag(1, ci, 4 * cp, [&](int col, int k, int) {
+            const int q = col / cp, ch = col % cp;
+            return ch < co ? w[((size_t)k * co + ch) * 4 + q] : 0.f;
+          });
+          if (!upload("frag:" + op.w, f)) { err = "hipMalloc failed"; return false; }
+        }
+      } break;
+      case PlanOp::DW: {
+        auto p = need(op.w); if (!p) return false;
+        const int C = op.c, K = op.kh;
+        if (op.kh != op.kw || (K != 3 && K != 5)) { err = "depthwise kernel size not on this path"; return false; }
+        if (p->dims.size() != 4 || p->dims[0] != C || p->dims[2] != K) { err = "dw filter shape mismatch " + op.w; return false; }
+        const int cs = c8i_stride(C);
+        std::vector<float> img((size_t)K * K * cs, 0.f);
+        for (int c = 0; c < C; ++c)
+          for (int t = 0; t < K * K; ++t) img[(size_t)t * cs + c8i_phys(c)] = p->data[(size_t)c * K * K + t];
+        if (!upload("dw:" + op.w, img)) { err = "hipMalloc failed"; return false; }
+      } break;
+      case PlanOp::SEFC: {
+        for (const std::string* n : {&op.w1, &op.b1, &op.w2, &op.b2}) {
+          auto p = need(*n); if (!p) return false;
+          if (!upload("raw:" + *n, p->data)) { err = "hipMalloc failed"; return false; }
+        }
+      } break;
+      case PlanOp::LN: {
+        for (const std::string* n : {&op.g, &op.b}) {
+          auto p = need(*n); if (!p) return false;
+          if (!upload("raw:" + *n, p->data)) { err = "hipMalloc failed"; return false; }
+        }
+      } break;
+      case PlanOp::ATTN:
+        if (op.hd != 15) { err = "attention head dim not on this path"; return false; }
+        break;
+      default: break;
+    }
+  }
+  if (out_tid_ < 0) { err = "plan has no output"; return false; }
+  return true;
+}
+
+bool Net::build_epilogue(const PlanOp& op, Epilogue& ep, bool conv_path, std::string& err) {
+  ep.n = 0;
+  if ((int)op.ep.size() > OCR_MAX_EP) { err = "epilogue too long"; return false; }
+  const bool oplain = tensors_[op.out].plain;
+  for (auto& st : op.ep) {
+    EpStage& e = ep.st[ep.n++];
+    memset(&e, 0, sizeof(e));
+    e.kind = st.kind;
+    e.act = st.act;
+    e.p0 = st.p0;
+    e.p1 = st.p1;
+    switch (st.kind) {
+      case EP_BIAS: e.v0 = dev_vec((oplain ? "vecp:" : "vec:") + st.n0); break;
+      case EP_SMUL: case EP_SADD: e.p0 = scalars_[st.n0]; break;
+      case EP_BN: e.v0 = dev_vec("bns:" + st.n0); e.v1 = dev_vec("bnt:" + st.n0); break;
+      case EP_ACT: break;
+      case EP_MULC:
+        if (conv_path) { err = "mulc in a conv epilogue is not on this path"; return false; }
+        e.v0 = tensor_ptr(st.tid);
+        break;
+      case EP_ADDT: e.v0 = tensor_ptr(st.tid); break;
+      case EP_ADDUP:
+        if (conv_path) { err = "addup in a conv epilogue is not on this path"; return false; }
+        e.v0 = tensor_ptr(st.tid);
+        e.a0 = st.up;
+        e.a1 = tensors_[st.tid].w;
+        e.a2 = tensors_[st.tid].h;
+        break;
+    }
+  }
+  return true;
+}
+
+// ------------------------------------------------------------------ shape binding
+bool Net::bind(int N, int H, int W, std::string& err) {
+  // 1. shapes
+  auto& T = tensors_;
+  auto setdims = [&](int t, int n, int h, int w, int c) {
+    T[t].n = n; T[t].h = h; T[t].w = w; T[t].c = c;
+    T[t].cs = T[t].plain ? c : c8i_stride(c);
+  };
+  setdims(0, N, H, W, 3);
+  for (auto& op : plan_.ops) {
+    switch (op.kind) {
+      case PlanOp::CONV: {
+        auto& i = T[op.in];
+        setdims(op.out, i.n, (i.h + 2 * op.ph - op.kh) / op.sh + 1, (i.w + 2 * op.pw - op.kw) / op.sw + 1, op.cout);
+      } break;
+      case PlanOp::DW: {
+        auto& i = T[op.in];
+        setdims(op.out, i.n, (i.h + 2 * op.ph - op.kh) / op.sh + 1, (i.w + 2 * op.pw - op.kw) / op.sw + 1, op.c);
+      } break;
+      case PlanOp::DECONV: { auto& i = T[op.in]; setdims(op.out, i.n, i.h * 2, i.w * 2, op.cout); } break;
+      case PlanOp::LINEAR: { auto& i = T[op.in]; setdims(op.out, i.n, i.h, i.w, op.cout); } break;
+      case PlanOp::SEFC: case PlanOp::GAP: { auto& i = T[op.in]; setdims(op.out, i.n, 1, 1, op.c); } break;
+      case PlanOp::POOL: {
+        auto& i = T[op.in];
+        setdims(op.out, i.n, (i.h - op.kh) / op.sh + 1, (i.w - op.kw) / op.sw + 1, op.c);  // C++ truncation on purpose
+      } break;
+      case PlanOp::EW: case PlanOp::LN: case PlanOp::SOFTMAX: { auto& i = T[op.in]; setdims(op.out, i.n, i.h, i.w, i.c); } break;
+      case PlanOp::CONCAT: {
+        auto& l = T[op.ins.back()];
+        setdims(op.out, l.n, l.h * op.ups.back(), l.w * op.ups.back(), op.c);
+      } break;
+      case PlanOp::ATTN: { auto& i = T[op.in]; setdims(op.out, i.n, i.h, i.w, op.heads * op.hd); } break;
+      case PlanOp::OUTPUT: break;
+    }
+    if (op.out >= 0 && (T[op.out].h <= 0 || T[op.out].w <= 0)) { err = "input too small for the network"; return false; }
+  }
+  // 2. arena with liveness reuse
+  const int nops = (int)plan_.ops.size();
+  std::vector<int> last(plan_.ntensors, -1);
+  for (int oi = 0; oi < nops; ++oi) {
+    auto& op = plan_.ops[oi];
+    if (op.in >= 0) last[op.in] = oi;
+    for (int t : op.ins) last[t] = oi;
+    for (auto& st : op.ep) if (st.tid >= 0) last[st.tid] = oi;
+  }
+  last[out_tid_] = nops + 1;
+  struct Blk { size_t off, sz; };
+  std::vector<Blk> freeb;
+  size_t top = 0;
+  size_t gap_need = 0;
+  auto alloc = [&](size_t n) {
+    n = (n + 63) & ~(size_t)63;
+    int best = -1;
+    for (int i = 0; i < (int)freeb.size(); ++i)
+      if (freeb[i].sz >= n && (best < 0 || freeb[i].sz < freeb[best].sz)) best = i;
+    if (best >= 0) {
+      size_t off = freeb[best].off;
+      if (freeb[best].sz == n) freeb.erase(freeb.begin() + best);
+      else { freeb[best].off += n; freeb[best].sz -= n; }
+      return off;
+    }
+    size_t off = top;
+    top += n;
+    return off;
+  };
+  auto release = [&](size_t off, size_t n) {
+    n = (n + 63) & ~(size_t)63;
+    freeb.push_back({off, n});
+    std::sort(freeb.begin(), freeb.end(), [](const Blk& a, const Blk& b) { return a.off < b.off; });
+    for (size_t i = 0; i + 1 < freeb.size();) {
+      if (freeb[i].off + freeb[i].sz == freeb[i + 1].off) { freeb[i].sz += freeb[i + 1].sz; freeb.erase(freeb.begin() + i + 1); }
+      else ++i;
+    }
+    if (!freeb.empty() && freeb.back().off + freeb.back().sz == top) { top = freeb.back().off; freeb.pop_back(); }
+  };
+  for (int oi = 0; oi < nops; ++oi) {
+    auto& op = plan_.ops[oi];
+    if (op.out >= 0) T[op.out].offset = alloc(T[op.out].numel());
+    if (op.kind == PlanOp::GAP) gap_need = std::max(gap_need, (size_t)T[op.in].n * T[op.in].h * T[op.in].cs);
+    // free tensors whose last reader is this op (never the op's own output)
+    for (int t = 1; t < plan_.ntensors; ++t)
+      if (!keep_all_ && last[t] == oi && t != op.out && T[t].numel()) release(T[t].offset, T[t].numel());
+  }
+  // `top` may have shrunk at the end; capacity must cover the high-water mark
+  size_t high = 0;
+  for (int t = 1; t < plan_.ntensors; ++t) high = std::max(high, T[t].offset + ((T[t].numel() + 63) & ~(size_t)63));
+  if (high > arena_cap_) {
+    if (arena_) (void)hipFree(arena_);
+    arena_ = nullptr;
+    arena_cap_ = 0;
+    HIP_OK(hipMalloc(&arena_, high * sizeof(float)));
+    arena_cap_ = high;
+  }
+  if (gap_need > gap_part_cap_) {
+    if (gap_part_) (void)hipFree(gap_part_);
+    gap_part_ = nullptr;
+    gap_part_cap_ = 0;
+    HIP_OK(hipMalloc(&gap_part_, gap_need * sizeof(float)));
+    gap_part_cap_ = gap_need;
+  }
+  // 3. launches
+  launches_.clear();
+  char nm[160];
+  for (int oi = 0; oi < nops; ++oi) {
+    auto& op = plan_.ops[oi];
+    if (op.kind == PlanOp::OUTPUT) continue;
+    const TensorDesc& o = T[op.out];
+    float* optr = arena_ + o.offset;
+    Launch L;
+    switch (op.kind) {
+      case PlanOp::CONV: case PlanOp::LINEAR: case PlanOp::DECONV: {
+        const TensorDesc& in = T[op.in];
+        Epilogue ep;
+        if (op.kind == PlanOp::CONV && op.cin == 3) {
+          if (!build_epilogue(op, ep, false, err)) return false;
+          StemArgs a{};
+          a.out = optr; a.w = dev_vec("stem:" + op.w);
+          a.N = in.n; a.H = in.h; a.W = in.w; a.OH = o.h; a.OW = o.w; a.Cs_out = o.cs;
+          a.KH = op.kh; a.KW = op.kw; a.SH = op.sh; a.SW = op.sw; a.PH = op.ph; a.PW = op.pw;
+          a.M = (long)o.n * o.h * o.w;
+          if (o.cs != 8 && o.cs != 16) { err = "stem width not on this path"; return false; }
+          snprintf(nm, sizeof nm, "%s.%02d.stem%dx%d_3_%d", plan_.name.c_str(), oi, op.kh, op.kw, op.cout);
+          L.name = nm;
+          L.flops = 2.0 * a.M * op.kh * op.kw * 3 * op.cout;
+          L.bytes = 4.0 * ((double)in.numel() + (double)a.M * op.cout);
+          const bool ext_in = (op.in == 0);
+          const float* in_ptr = ext_in ? nullptr : arena_ + in.offset;
+          L.fn = [this, a, ep, ext_in, in_ptr](hipStream_t s) mutable {
+            StemArgs b = a;
+            b.in = ext_in ? this->bound_x_ : in_ptr;
+            launch_stem(b, ep, s);
+          };
+        } else if (op.kind == PlanOp::DECONV && op.cout == 1) {
+          // tail: deconv -> 1 channel, bias (scalar), sigmoid  (+ fused u8 threshold)
+          float bias = 0.f;
+          bool ok = op.ep.size() == 2 && (op.ep[0].kind == EP_SADD || op.ep[0].kind == EP_BIAS) && op.ep[1].kind == EP_ACT && op.ep[1].act == ACT_SIGMOID;
+          if (!ok) { err = "unexpected DB head tail"; return false; }
+          bias = host_w_[op.ep[0].n0].data[0];
+          DetTailArgs a{};
+          a.in = arena_ + in.offset; a.prob = optr; a.bitmap = det_bitmap_; a.w = dev_vec("tail:" + op.w);
+          a.N = in.n; a.H = in.h; a.W = in.w; a.C = op.cin; a.Cs = in.cs; a.bias = bias; a.ithresh = det_ithresh_;
+          a.M = (long)in.n * in.h * in.w;
+          snprintf(nm, sizeof nm, "%s.%02d.det_tail", plan_.name.c_str(), oi);
+          L.name = nm;
+          L.flops = 2.0 * a.M * op.cin * 4;
+          L.bytes = 4.0 * a.M * op.cin + 4.0 * a.M * 4 + (det_bitmap_ ? 1.0 * a.M * 4 : 0.0);
+          L.fn = [a](hipStream_t s) { launch_det_tail(a, s); };
+        } else {
+          if (!build_epilogue(op, ep, true, err)) return false;
+          ConvArgs a{};
+          a.in = arena_ + in.offset; a.out = optr; a.wfrag = dev_vec("frag:" + op.w);
+          a.N = in.n; a.H = in.h; a.W = in.w; a.Cs_in = in.cs; a.C8 = in.cs / 8;
+          a.KH = op.kh; a.KW = op.kw; a.PH = op.ph; a.PW = op.pw;
+          a.need_nyx = 0;
+          if (in.plain) { err = "conv input must be C8I"; return false; }
+          if (op.kind == PlanOp::DECONV) {
+            a.OH = in.h; a.OW = in.w; a.Cs_out = o.cs; a.Cout = op.cout; a.CoutPadded = o.cs;
+            a.ColsStore = 4 * o.cs; a.out_mode = OUT_DECONV; a.KH = a.KW = 1; a.PH = a.PW = 0;
+          } else {
+            a.OH = o.h; a.OW = o.w; a.Cs_out = o.cs; a.Cout = op.cout; a.CoutPadded = o.cs;
+            a.ColsStore = o.plain ? op.cout : o.cs; a.out_mode = o.plain ? OUT_PLAIN : OUT_C8I;
+          }
+          a.NTtot = (a.ColsStore + 31) / 32;
+          a.M = (long)in.n * a.OH * a.OW;
+          if (op.kind == PlanOp::LINEAR) a.M = (long)in.n * in.h * in.w;
+          int nt = a.NTtot <= 4 ? a.NTtot : (a.NTtot % 4 == 0 ? 4 : (a.NTtot % 3 == 0 ? 3 : 4));
+          const int taps = a.KH * a.KW;
+          const char* kind = op.kind == PlanOp::DECONV ? "deconv" : (op.kind == PlanOp::LINEAR ? "linear" : "conv");
+          snprintf(nm, sizeof nm, "%s.%02d.%s%dx%d_%d_%d", plan_.name.c_str(), oi, kind, a.KH, a.KW, op.cin, op.cout);
+          L.name = nm;
+          const double cols = op.kind == PlanOp::DECONV ? 4.0 * op.cout : op.cout;
+          L.flops = 2.0 * a.M * taps * op.cin * cols;
+          L.bytes = 4.0 * ((double)a.M * op.cin + (double)a.M * cols + (double)taps * op.cin * cols);
+          L.fn = [a, ep, nt](hipStream_t s) { launch_conv_mfma(a, ep, nt, s); };
+        }
+      } break;
+      case PlanOp::DW: {
+        const TensorDesc& in = T[op.in];
+        Epilogue ep;
+        if (!build_epilogue(op, ep, false, err)) return false;
+        DwArgs a{};
+        a.in = arena_ + in.offset; a.out = optr; a.w = dev_vec("dw:" + op.w);
+        a.N = in.n; a.H = in.h; a.W = in.w; a.OH = o.h; a.OW = o.w; a.Cs = o.cs; a.K = op.kh;
+        a.SH = op.sh; a.SW = op.sw; a.PH = op.ph; a.PW = op.pw; a.M = (long)o.n * o.h * o.w;
+        snprintf(nm, sizeof nm, "%s.%02d.dw%dx%d_%d_s%d%d", plan_.name.c_str(), oi, op.kh, op.kw, op.c, op.sh, op.sw);
+        L.name = nm;
+        L.flops = 2.0 * a.M * op.kh * op.kw * op.c;
+        L.bytes = 4.0 * ((double)in.n * in.h * in.w * op.c + (double)a.M * op.c);
+        L.fn = [a, ep](hipStream_t s) { launch_dw(a, ep, s); };
+      } break;
+      case PlanOp::EW: {
+        const TensorDesc& in = T[op.in];
+        Epilogue ep;
+        if (!build_epilogue(op, ep, false, err)) return false;
+        const float* ip = arena_ + in.offset;
+        const long M = (long)o.n * o.h * o.w;
+        const int H2 = o.h, W2 = o.w, Cs = o.cs;
+        snprintf(nm, sizeof nm, "%s.%02d.ew_%d", plan_.name.c_str(), oi, op.c);
+        L.name = nm;
+        L.bytes = 4.0 * M * op.c * (2.0 + (double)op.ep.size() - 1.0);
+        L.fn = [ip, optr, M, H2, W2, Cs, ep](hipStream_t s) { launch_ew(ip, optr, M, H2, W2, Cs, ep, s); };
+      } break;
+      case PlanOp::GAP: {
+        const TensorDesc& in = T[op.in];
+        const float* ip = arena_ + in.offset;
+        float* part = gap_part_;
+        const int n = in.n, h = in.h, w = in.w, cs = in.cs;
+        snprintf(nm, sizeof nm, "%s.%02d.gap_%d", plan_.name.c_str(), oi, op.c);
+        L.name = nm;
+        L.bytes = 4.0 * (double)n * h * w * op.c;
+        L.fn = [ip, part, optr, n, h, w, cs](hipStream_t s) { launch_gap(ip, part, optr, n, h, w, cs, s); };
+      } break;
+      case PlanOp::SEFC: {
+        const TensorDesc& in = T[op.in];
+        SeArgs a{};
+        a.in = arena_ + in.offset; a.out = optr;
+        a.w1 = dev_vec("raw:" + op.w1); a.b1 = dev_vec("raw:" + op.b1);
+        a.w2 = dev_vec("raw:" + op.w2); a.b2 = dev_vec("raw:" + op.b2);
+        a.C = op.c; a.Cs = o.cs; a.R = op.cr; a.slope = op.slope; a.offset = op.offset;
+        const int n = in.n;
+        snprintf(nm, sizeof nm, "%s.%02d.sefc_%d", plan_.name.c_str(), oi, op.c);
+        L.name = nm;
+        L.flops = 4.0 * n * op.c * op.cr;
+        L.fn = [a, n](hipStream_t s) { launch_sefc(a, n, s); };
+      } break;
+      case PlanOp::CONCAT: {
+        ConcatArgs a{};
+        a.out = optr; a.H = o.h; a.W = o.w; a.Cs = o.cs; a.M = (long)o.n * o.h * o.w;
+        a.nsrc = (int)op.ins.size();
+        if (a.nsrc > 4) { err = "concat arity not on this path"; return false; }
+        int off = 0;
+        for (int j = 0; j < a.nsrc; ++j) {
+          const TensorDesc& sj = T[op.ins[j]];
+          if (sj.c % 8) { err = "concat source channels must be a multiple of 8"; return false; }
+          a.src[j] = arena_ + sj.offset; a.coff[j] = off; a.scs[j] = sj.cs; a.up[j] = op.ups[j];
+          off += sj.cs;
+        }
+        snprintf(nm, sizeof nm, "%s.%02d.concat_%d", plan_.name.c_str(), oi, op.c);
+        L.name = nm;
+        L.bytes = 8.0 * a.M * op.c;
+        L.fn = [a](hipStream_t s) { launch_concat(a, s); };
+      } break;
+      case PlanOp::POOL: {
+        const TensorDesc& in = T[op.in];
+        PoolArgs a{};
+        a.in = arena_ + in.offset; a.out = optr; a.N = in.n; a.H = in.h; a.W = in.w; a.OH = o.h; a.OW = o.w;
+        a.Cs = o.cs; a.KH = op.kh; a.KW = op.kw; a.SH = op.sh; a.SW = op.sw; a.is_max = op.pool_max;
+        a.M = (long)o.n * o.h * o.w;
+        snprintf(nm, sizeof nm, "%s.%02d.pool_%d", plan_.name.c_str(), oi, op.c);
+        L.name = nm;
+        L.bytes = 4.0 * ((double)in.n * in.h * in.w * op.c + (double)a.M * op.c);
+        L.fn = [a](hipStream_t s) { launch_pool(a, s); };
+      } break;
+      case PlanOp::LN: {
+        const TensorDesc& in = T[op.in];
+        const float* ip = arena_ + in.offset;
+        const long rows = (long)in.n * in.h * in.w;
+        const int C = op.c, Cs = in.cs;
+        const float eps = op.eps;
+        const float* g = dev_vec("raw:" + op.g);
+        const float* b = dev_vec("raw:" + op.b);
+        snprintf(nm, sizeof nm, "%s.%02d.ln_%d", plan_.name.c_str(), oi, op.c);
+        L.name = nm;
+        L.bytes = 8.0 * rows * C;
+        L.fn = [ip, optr, rows, C, Cs, eps, g, b](hipStream_t s) { launch_ln(ip, optr, rows, C, Cs, eps, g, b, s); };
+      } break;
+      case PlanOp::ATTN: {
+        const TensorDesc& in = T[op.in];
+        if (in.h != 1) { err = "attention expects a sequence (H == 1): rec input height must reduce to 1"; return false; }
+        const float* ip = arena_ + in.offset;
+        const int n = in.n, t = in.w, heads = op.heads, hd = op.hd, csi = in.cs, cso = o.cs;
+        const float sc = op.scale;
+        snprintf(nm, sizeof nm, "%s.%02d.attn_%dx%d", plan_.name.c_str(), oi, op.heads, op.hd);
+        L.name = nm;
+        L.flops = 3.0 * 2.0 * n * heads * (double)t * t * hd + 2.0 * n * heads * (double)t * t * hd;
+        L.bytes = 4.0 * n * t * (3.0 + 1.0) * heads * hd;
+        L.fn = [ip, optr, n, t, heads, hd, csi, cso, sc](hipStream_t s) { launch_attn(ip, optr, n, t, heads, hd, csi, cso, sc, s); };
+      } break;
+      case PlanOp::SOFTMAX: {
+        const TensorDesc& in = T[op.in];
+        const float* ip = arena_ + in.offset;
+        const long rows = (long)in.n * in.h * in.w;
+        const int C = op.c;
+        snprintf(nm, sizeof nm, "%s.%02d.softmax_%d", plan_.name.c_str(), oi, op.c);
+        L.name = nm;
+        L.bytes = 4.0 * rows * C * 3;
+        // `optr` (the plan's softmax tensor) is only filled when no external sink is set or probs are requested
+        L.fn = [this, ip, optr, rows, C](hipStream_t s) {
+          float* probs = (this->head_amax_ || this->head_pmax_) ? this->head_probs_ : optr;
+          launch_softmax_argmax(ip, probs, this->head_amax_, this->head_pmax_, rows, C, s);
+        };
+      } break;
+      default: break;
+    }
+    launches_.push_back(std::move(L));
+  }
+  bound_n_ = N; bound_h_ = H; bound_w_ = W;
+  return true;
+}
+
+bool Net::run(const float* x, int N, int H, int W, hipStream_t s, std::string& err) {
+  if (N != bound_n_ || H != bound_h_ || W != bound_w_) {
+    if (!bind(N, H, W, err)) { bound_n_ = -1; return false; }
+  }
+  bound_x_ = x;
+  for (size_t i = 0; i < launches_.size(); ++i) {
+    if (timing_) {
+      hipEvent_t a, b;
+      if (ev_pool_.size() >= 2) { a = ev_pool_.back(); ev_pool_.pop_back(); b = ev_pool_.back(); ev_pool_.pop_back(); }
+      else { HIP_OK(hipEventCreate(&a)); HIP_OK(hipEventCreate(&b)); }
+      HIP_OK(hipEventRecord(a, s));
+      launches_[i].fn(s);
+      HIP_OK(hipEventRecord(b, s));
+      ev_pending_.push_back({a, b, (int)i});
+    } else {
+      launches_[i].fn(s);
+    }
+  }
+  HIP_OK(hipGetLastError());
+  return true;
+}
+
+void Net::collect_timings() {
+  for (auto& p : ev_pending_) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess && p.launch < (int)launches_.size()) {
+      auto& t = timings_[launches_[p.launch].name];
+      t.ms += ms;
+      t.count += 1;
+      t.flops = launches_[p.launch].flops;
+      t.bytes = launches_[p.launch].bytes;
+    }
+    ev_pool_.push_back(p.a);
+    ev_pool_.push_back(p.b);
+  }
+  ev_pending_.clear();
+}
+
+bool Net::fetch_logical(int tid, std::vector<float>& host, int dims[4], hipStream_t s, std::string& err) {
+  if (tid < 0) tid = out_tid_;
+  if (tid <= 0 || tid >= plan_.ntensors || bound_n_ < 0) { err = "bad tensor id"; return false; }
+  const TensorDesc& t = tensors_[tid];
+  dims[0] = t.n; dims[1] = t.h; dims[2] = t.w; dims[3] = t.c;
+  const long M = (long)t.n * t.h * t.w;
+  host.resize((size_t)M * t.c);
+  if (t.plain) {
+    HIP_OK(hipMemcpyAsync(host.data(), arena_ + t.offset, host.size() * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIP_OK(hipStreamSynchronize(s));
+    return true;
+  }
+  float* tmp = nullptr;
+  HIP_OK(hipMalloc(&tmp, host.size() * sizeof(float)));
+  launch_c8i_to_plain(arena_ + t.offset, tmp, M, t.c, t.cs, s);
+  hipError_t e = hipMemcpyAsync(host.data(), tmp, host.size() * sizeof(float), hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  (void)hipFree(tmp);
+  if (e != hipSuccess) { err = hipGetErrorString(e); return false; }
+  return true;
+}
+
+}  // namespace ocr

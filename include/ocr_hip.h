@@ -1,0 +1,146 @@
+/* libocr_hip — C-ABI of the MI355X-native OCR hot path (det -> cls -> rec).
+ *
+ * Drop-in boundary: these entry points are what a maintainer of sssxyd/cpp-paddle-ocr binds in
+ * place of the Paddle Inference predictor + OpenCV pre/post code inside
+ *   DBDetector::Run        /root/reference/src/ocr_det.cpp:93-176   (include/paddle_ocr/ocr_det.h:95-97)
+ *   Classifier::Run        /root/reference/src/ocr_cls.cpp:23-106   (include/paddle_ocr/ocr_cls.h:81-82)
+ *   CRNNRecognizer::Run    /root/reference/src/ocr_rec.cpp:24-135   (include/paddle_ocr/ocr_rec.h:92-95)
+ *   OCRWorker::processRequest  /root/reference/src/ocr_worker.cpp:213-311
+ * Plain pointers and sizes only; every function returns 0 on success and a negative code on
+ * failure (never exit(): compare ocr_det.cpp:41-45).  ocr_last_error() gives the message of the
+ * calling thread's last failure.  One handle = one HIP stream + its device buffers; use one
+ * handle per host thread (the reference's stage objects are not re-entrant either).
+ * INTEGRATION.md shows the C++ shim classes that keep the reference signatures on top of this.
+ */
+#ifndef OCR_HIP_H_
+#define OCR_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OCR_OK 0
+#define OCR_ERR_ARG (-1)      /* bad argument */
+#define OCR_ERR_MODEL (-2)    /* model files missing / do not match the supported graph */
+#define OCR_ERR_DEVICE (-3)   /* HIP runtime failure (message has the HIP error string) */
+#define OCR_ERR_CAPACITY (-4) /* caller buffer too small */
+
+const char* ocr_last_error(void);
+/* Selects the HIP device for the calling thread; fails when no gfx950 device is visible. */
+int ocr_rt_init(int device_id);
+int ocr_rt_device_count(void);
+
+/* An image view: CV_8UC3 BGR rows, possibly a non-contiguous ROI (row_stride in bytes) —
+ * the `const cv::Mat&` of the reference signatures. */
+typedef struct ocr_img {
+  const uint8_t* data;
+  int rows, cols;
+  size_t row_stride;
+} ocr_img;
+
+/* ---------------------------------------------------------------- detector */
+/* Field-for-field the constructor arguments of DBDetector (ocr_det.h:60-75) that still mean
+ * something without Paddle; defaults of ocr_det_cfg_default() are the literals OCRWorker passes
+ * (ocr_worker.cpp:21-35: "max", 512, 0.2, 0.4, 1.8, "fast", no dilation). */
+typedef struct ocr_det_cfg {
+  const char* model_dir; /* directory holding inference.pdmodel + inference.pdiparams */
+  int device_id;
+  const char* limit_type; /* "max" | "min" */
+  int limit_side_len;
+  double det_db_thresh;
+  double det_db_box_thresh;
+  double det_db_unclip_ratio;
+  const char* det_db_score_mode; /* "fast" | "slow" */
+  int use_dilation;
+  const char* precision; /* "fp32" (the only one implemented; others are rejected) */
+  int max_batch;         /* images per ocr_det_run_batch call the handle is sized for (>=1) */
+} ocr_det_cfg;
+void ocr_det_cfg_default(ocr_det_cfg* cfg);
+
+typedef struct ocr_det ocr_det;
+int ocr_det_create(const ocr_det_cfg* cfg, ocr_det** out);
+void ocr_det_destroy(ocr_det* h);
+/* DBDetector::Run for one image.  boxes: cap x 8 int32 (4 points x,y clockwise from top-left, source
+ * image coordinates), *n = boxes found; times[3] = pre / infer / post in ms (ocr_det.cpp:168-175). */
+int ocr_det_run(ocr_det* h, const ocr_img* img, int32_t* boxes, int cap, int* n, double times[3]);
+/* Same for `count` images of identical size in one device pass (batch on the GEMM row axis).
+ * boxes: count x cap x 8; n: count entries. */
+int ocr_det_run_batch(ocr_det* h, const ocr_img* imgs, int count, int32_t* boxes, int cap, int* n, double times[3]);
+/* Parity taps: sizes of the network input of the last run, its probability map (rows*cols f32)
+ * and bitmap. */
+int ocr_det_last_shape(ocr_det* h, int* count, int* rows, int* cols);
+int ocr_det_prob_map(ocr_det* h, int index, float* out, size_t cap_floats);
+int ocr_det_bitmap(ocr_det* h, int index, uint8_t* out, size_t cap_bytes);
+int ocr_det_resized(ocr_det* h, int index, uint8_t* out, size_t cap_bytes); /* u8 BGR after ResizeImgType0 */
+/* Post-processing alone on a caller-supplied probability map (rows x cols f32, values in [0,1]):
+ * threshold (+dilate) -> contours -> boxes -> FilterTagDetRes against a src_rows x src_cols image. */
+int ocr_det_post(ocr_det* h, const float* prob, int rows, int cols, int src_rows, int src_cols, int32_t* boxes, int cap,
+                 int* n);
+
+/* ---------------------------------------------------------------- classifier */
+typedef struct ocr_cls_cfg {
+  const char* model_dir;
+  int device_id;
+  double cls_thresh; /* stored, never consulted — as in the reference (ocr_cls.cpp never reads it) */
+  int cls_batch_num;
+  const char* precision;
+} ocr_cls_cfg;
+void ocr_cls_cfg_default(ocr_cls_cfg* cfg);
+typedef struct ocr_cls ocr_cls;
+int ocr_cls_create(const ocr_cls_cfg* cfg, ocr_cls** out);
+void ocr_cls_destroy(ocr_cls* h);
+/* Classifier::Run: labels/scores are caller-sized to n (ocr_worker.cpp:271-272). */
+int ocr_cls_run(ocr_cls* h, const ocr_img* imgs, int n, int* labels, float* scores, double times[3]);
+/* tap: softmax [n][2] of the last run */
+int ocr_cls_probs(ocr_cls* h, float* out, size_t cap_floats);
+
+/* ---------------------------------------------------------------- recognizer */
+typedef struct ocr_rec_cfg {
+  const char* model_dir;
+  int device_id;
+  const char* label_path; /* ppocr_keys_v1.txt; "#"/" " are added like ocr_rec.h:82-84 */
+  int rec_batch_num;
+  int rec_img_h, rec_img_w;
+  const char* precision;
+} ocr_rec_cfg;
+void ocr_rec_cfg_default(ocr_rec_cfg* cfg);
+typedef struct ocr_rec ocr_rec;
+int ocr_rec_create(const ocr_rec_cfg* cfg, ocr_rec** out);
+void ocr_rec_destroy(ocr_rec* h);
+/* CRNNRecognizer::Run.  For line i: ids[i*max_len .. +lens[i]) are the kept CTC class ids
+ * (dictionary indices, blank and repeats removed), scores[i] the mean max-probability.  Lines the
+ * reference leaves untouched (NaN score: no kept step) get lens[i] = 0, scores[i] = 0. */
+int ocr_rec_run(ocr_rec* h, const ocr_img* imgs, int n, int32_t* ids, int max_len, int* lens, float* scores,
+                double times[3]);
+/* UTF-8 label of a class id (valid until the handle is destroyed); NULL when out of range. */
+const char* ocr_rec_label(ocr_rec* h, int id);
+int ocr_rec_num_classes(ocr_rec* h);
+/* tap: per-step arg max / max prob of line `index` of the last run (T entries), and T */
+int ocr_rec_steps(ocr_rec* h, int index, int32_t* amax, float* pmax, int cap, int* T);
+
+/* ---------------------------------------------------------------- raw network taps (parity tests) */
+typedef struct ocr_net ocr_net;
+/* kind: "det" | "cls" | "rec".  weights: path of a .pdiparams file (NULL: <model_dir>/inference.pdiparams,
+ * falling back to <model_dir>/synthetic.pdiparams). */
+int ocr_net_create(const char* kind, const char* model_dir, const char* weights, int device_id, ocr_net** out);
+void ocr_net_destroy(ocr_net* h);
+/* x: host f32 [N,H,W,3] (already normalised, BGR order).  keep_all != 0 keeps every intermediate tensor. */
+int ocr_net_forward(ocr_net* h, const float* x, int N, int H, int W, int keep_all);
+int ocr_net_num_tensors(ocr_net* h);
+/* tid < 0: network output.  out receives logical NHWC; dims = {N,H,W,C}. */
+int ocr_net_fetch(ocr_net* h, int tid, float* out, size_t cap_floats, int dims[4]);
+/* HIP-event timing of the launches of subsequent ocr_net_forward calls */
+int ocr_net_timing(ocr_net* h, int enable);
+/* writes "name ms count flops bytes\n" lines */
+int ocr_net_timing_report(ocr_net* h, char* buf, size_t cap);
+
+/* numerics probe (tests): out[6*n] = a/b, sqrt|a|, ocr_expf(a), fma(a,b,a), a*b+a, rint(a*log2e) */
+int ocr_probe(const float* a, const float* b, float* out, int n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OCR_HIP_H_ */

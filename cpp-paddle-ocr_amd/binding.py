@@ -143,3 +143,196 @@ class Net:
             self.close()
         except Exception:
             pass
+
+
+# ---------------------------------------------------------------------------------------------
+# stage handles
+# ---------------------------------------------------------------------------------------------
+def _img(a):
+    a = np.asarray(a)
+    assert a.dtype == np.uint8 and a.ndim == 3 and a.shape[2] == 3 and a.strides[2] == 1 and a.strides[1] == 3
+    return ocr_img(a.ctypes.data, a.shape[0], a.shape[1], a.strides[0])
+
+
+def _imgs(arrs):
+    arr = (ocr_img * len(arrs))()
+    for i, a in enumerate(arrs):
+        arr[i] = _img(a)
+    return arr
+
+
+def _stage_protos(L):
+    if getattr(L, "_stage_protos_done", False):
+        return
+    vp, ip = C.c_void_p, C.POINTER(C.c_int)
+    L.ocr_det_cfg_default.argtypes = [C.POINTER(ocr_det_cfg)]
+    L.ocr_det_create.argtypes = [C.POINTER(ocr_det_cfg), C.POINTER(vp)]
+    L.ocr_det_destroy.argtypes = [vp]
+    L.ocr_det_run.argtypes = [vp, C.POINTER(ocr_img), vp, C.c_int, ip, C.POINTER(C.c_double)]
+    L.ocr_det_run_batch.argtypes = [vp, C.POINTER(ocr_img), C.c_int, vp, C.c_int, vp, C.POINTER(C.c_double)]
+    L.ocr_det_last_shape.argtypes = [vp, ip, ip, ip]
+    L.ocr_det_prob_map.argtypes = [vp, C.c_int, vp, C.c_size_t]
+    L.ocr_det_bitmap.argtypes = [vp, C.c_int, vp, C.c_size_t]
+    L.ocr_det_resized.argtypes = [vp, C.c_int, vp, C.c_size_t]
+    L.ocr_det_post.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, ip]
+    L.ocr_cls_cfg_default.argtypes = [C.POINTER(ocr_cls_cfg)]
+    L.ocr_cls_create.argtypes = [C.POINTER(ocr_cls_cfg), C.POINTER(vp)]
+    L.ocr_cls_destroy.argtypes = [vp]
+    L.ocr_cls_run.argtypes = [vp, C.POINTER(ocr_img), C.c_int, vp, vp, C.POINTER(C.c_double)]
+    L.ocr_cls_probs.argtypes = [vp, vp, C.c_size_t]
+    L.ocr_rec_cfg_default.argtypes = [C.POINTER(ocr_rec_cfg)]
+    L.ocr_rec_create.argtypes = [C.POINTER(ocr_rec_cfg), C.POINTER(vp)]
+    L.ocr_rec_destroy.argtypes = [vp]
+    L.ocr_rec_run.argtypes = [vp, C.POINTER(ocr_img), C.c_int, vp, C.c_int, vp, vp, C.POINTER(C.c_double)]
+    L.ocr_rec_label.argtypes = [vp, C.c_int]
+    L.ocr_rec_label.restype = C.c_char_p
+    L.ocr_rec_num_classes.argtypes = [vp]
+    L.ocr_rec_steps.argtypes = [vp, C.c_int, vp, vp, C.c_int, ip]
+    L._stage_protos_done = True
+
+
+class Det:
+    """DBDetector over the C-ABI (ocr_det_*).  Defaults = the literals OCRWorker passes."""
+
+    def __init__(self, model_dir=None, device=0, limit_type="max", limit_side_len=512, thresh=0.2, box_thresh=0.4,
+                 unclip_ratio=1.8, score_mode="fast", use_dilation=False, precision="fp32", max_batch=1):
+        L = lib()
+        _stage_protos(L)
+        cfg = ocr_det_cfg()
+        L.ocr_det_cfg_default(C.byref(cfg))
+        self._keep = [(model_dir or os.path.join(MODELS, "det")).encode(), limit_type.encode(), score_mode.encode(),
+                      precision.encode()]
+        cfg.model_dir, cfg.limit_type, cfg.det_db_score_mode, cfg.precision = self._keep
+        cfg.device_id, cfg.limit_side_len = device, limit_side_len
+        cfg.det_db_thresh, cfg.det_db_box_thresh, cfg.det_db_unclip_ratio = thresh, box_thresh, unclip_ratio
+        cfg.use_dilation, cfg.max_batch = int(use_dilation), max_batch
+        self.h = C.c_void_p()
+        check(L.ocr_det_create(C.byref(cfg), C.byref(self.h)))
+        self.times = (C.c_double * 3)()
+
+    def run(self, img, cap=2000):
+        return self.run_batch([img], cap)[0]
+
+    def run_batch(self, imgs, cap=2000):
+        n = len(imgs)
+        boxes = np.zeros((n, cap, 8), np.int32)
+        cnt = np.zeros(n, np.int32)
+        arr = _imgs(imgs)
+        check(lib().ocr_det_run_batch(self.h, arr, n, boxes.ctypes.data, cap, cnt.ctypes.data, self.times))
+        return [boxes[i, :cnt[i]].reshape(-1, 4, 2).copy() for i in range(n)]
+
+    def last_shape(self):
+        a, b, c = C.c_int(), C.c_int(), C.c_int()
+        check(lib().ocr_det_last_shape(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def prob_map(self, index=0):
+        _, h, w = self.last_shape()
+        out = np.empty((h, w), np.float32)
+        check(lib().ocr_det_prob_map(self.h, index, out.ctypes.data, out.size))
+        return out
+
+    def bitmap(self, index=0):
+        _, h, w = self.last_shape()
+        out = np.empty((h, w), np.uint8)
+        check(lib().ocr_det_bitmap(self.h, index, out.ctypes.data, out.size))
+        return out
+
+    def resized(self, index=0):
+        _, h, w = self.last_shape()
+        out = np.empty((h, w, 3), np.uint8)
+        check(lib().ocr_det_resized(self.h, index, out.ctypes.data, out.size))
+        return out
+
+    def post(self, prob, src_h, src_w, cap=2000):
+        prob = np.ascontiguousarray(prob, dtype=np.float32)
+        boxes = np.zeros((cap, 8), np.int32)
+        n = C.c_int()
+        check(lib().ocr_det_post(self.h, prob.ctypes.data, prob.shape[0], prob.shape[1], src_h, src_w,
+                                 boxes.ctypes.data, cap, C.byref(n)))
+        return boxes[:n.value].reshape(-1, 4, 2).copy()
+
+    def close(self):
+        if self.h:
+            lib().ocr_det_destroy(self.h)
+            self.h = None
+
+
+class Cls:
+    def __init__(self, model_dir=None, device=0, cls_thresh=0.98, cls_batch_num=8, precision="fp32"):
+        L = lib()
+        _stage_protos(L)
+        cfg = ocr_cls_cfg()
+        L.ocr_cls_cfg_default(C.byref(cfg))
+        self._keep = [(model_dir or os.path.join(MODELS, "cls")).encode(), precision.encode()]
+        cfg.model_dir, cfg.precision = self._keep
+        cfg.device_id, cfg.cls_thresh, cfg.cls_batch_num = device, cls_thresh, cls_batch_num
+        self.h = C.c_void_p()
+        check(L.ocr_cls_create(C.byref(cfg), C.byref(self.h)))
+        self.times = (C.c_double * 3)()
+
+    def run(self, crops):
+        n = len(crops)
+        labels = np.zeros(n, np.int32)
+        scores = np.zeros(n, np.float32)
+        if n:
+            check(lib().ocr_cls_run(self.h, _imgs(crops), n, labels.ctypes.data, scores.ctypes.data, self.times))
+        return labels, scores
+
+    def probs(self, n):
+        out = np.empty((n, 2), np.float32)
+        check(lib().ocr_cls_probs(self.h, out.ctypes.data, out.size))
+        return out
+
+    def close(self):
+        if self.h:
+            lib().ocr_cls_destroy(self.h)
+            self.h = None
+
+
+class Rec:
+    def __init__(self, model_dir=None, device=0, label_path=None, rec_batch_num=16, rec_img_h=28, rec_img_w=192,
+                 precision="fp32"):
+        L = lib()
+        _stage_protos(L)
+        cfg = ocr_rec_cfg()
+        L.ocr_rec_cfg_default(C.byref(cfg))
+        md = model_dir or os.path.join(MODELS, "rec")
+        self._keep = [md.encode(), (label_path or os.path.join(md, "ppocr_keys_v1.txt")).encode(), precision.encode()]
+        cfg.model_dir, cfg.label_path, cfg.precision = self._keep
+        cfg.device_id, cfg.rec_batch_num, cfg.rec_img_h, cfg.rec_img_w = device, rec_batch_num, rec_img_h, rec_img_w
+        self.h = C.c_void_p()
+        check(L.ocr_rec_create(C.byref(cfg), C.byref(self.h)))
+        self.times = (C.c_double * 3)()
+
+    def run(self, crops, max_len=512):
+        n = len(crops)
+        ids = np.zeros((n, max_len), np.int32)
+        lens = np.zeros(n, np.int32)
+        scores = np.zeros(n, np.float32)
+        if n:
+            check(lib().ocr_rec_run(self.h, _imgs(crops), n, ids.ctypes.data, max_len, lens.ctypes.data,
+                                    scores.ctypes.data, self.times))
+        return [ids[i, :lens[i]].copy() for i in range(n)], scores
+
+    def steps(self, index, cap=4096):
+        amax = np.zeros(cap, np.int32)
+        pmax = np.zeros(cap, np.float32)
+        T = C.c_int()
+        check(lib().ocr_rec_steps(self.h, index, amax.ctypes.data, pmax.ctypes.data, cap, C.byref(T)))
+        return amax[:T.value].copy(), pmax[:T.value].copy()
+
+    def label(self, i):
+        s = lib().ocr_rec_label(self.h, int(i))
+        return s.decode("utf-8") if s is not None else None
+
+    def text(self, ids):
+        return "".join(self.label(i) for i in ids)
+
+    def num_classes(self):
+        return lib().ocr_rec_num_classes(self.h)
+
+    def close(self):
+        if self.h:
+            lib().ocr_rec_destroy(self.h)
+            self.h = None

@@ -1,0 +1,36 @@
+// Host-visible launch interface of kernels_post.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ocr {
+
+enum : int { POST_ERR_POOL = 1, POST_ERR_HULL = 2, POST_ERR_UNCLIP = 4 };
+
+struct PostArgs {
+  const uint8_t* bitmap;  // [N][H][W] {0,1}
+  const float* pred;      // [N][H][W]
+  int* labels;            // [N*H*W]
+  uint8_t* touch;         // [N*H*W]
+  int* ncont_all;         // [N] borders discovered
+  int* ncont;             // [N] min(discovered, max_cand)
+  int* starts;            // [N][max_cand] start pixel (image-local), reference order
+  int* npts;              // [N][max_cand] CHAIN_APPROX_SIMPLE vertex count
+  int* poff;              // [N][max_cand] offset into the image's key pool (-1: dropped)
+  unsigned long long* pool;  // [N][pool_cap] keys
+  int* iscratch;          // [N][pool_cap*4] hull stacks
+  int* cand_boxes;        // [N][max_cand][8]
+  int* cand_valid;        // [N][max_cand]
+  int* status;            // device error bits (POST_ERR_*)
+  int pool_cap;
+  int H, W, max_cand;
+  float box_thresh, unclip_ratio, ratio_h, ratio_w;
+  int src_h, src_w;
+};
+
+void launch_bitmap(const float* prob, uint8_t* bm, long total, int ithresh, hipStream_t s);
+void launch_dilate2(const uint8_t* src, uint8_t* dst, int N, int H, int W, hipStream_t s);
+// out_boxes [N][cap][8], out_n [N]
+void launch_post(const PostArgs& a, int N, int* out_boxes, int cap, int* out_n, hipStream_t s);
+
+}  // namespace ocr

@@ -1,0 +1,1017 @@
+// DB post-processing on the GPU (replaces /root/reference/src/ocr_det.cpp:137-165 and
+// /root/reference/src/postprocess_op.cpp:20-362 incl. the ClipperOffset calls into
+// /root/reference/src/clipper.cpp:3628-4021, and the OpenCV calls they make: threshold, dilate,
+// findContours(RETR_LIST, CHAIN_APPROX_SIMPLE), minAreaRect, boxPoints, fillPoly, mean).
+//
+// Structure (all HBM-bound integer/byte work; no GEMM):
+//   1. bitmap            fused into the DB-head tail kernel, or bitmap_kernel for caller maps
+//   2. CCL               union-find with atomicMin over 8-connected foreground AND 4-connected
+//                        background in one label image: a border of the reference's raster scan
+//                        starts exactly at the minimum-index pixel of a foreground component
+//                        (outer border) or of a background component that does not touch the
+//                        frame (hole border) — so border starts are found without the sequential
+//                        scan-and-mark of Suzuki-Abe.
+//   3. ordered compaction of the starts (one workgroup per image, wave ballots) -> the last
+//      `max_candidates` discovered, in the reference's reverse discovery order
+//   4. per border: one lane follows it (read-only bitmap, so borders are independent), emitting the
+//      CHAIN_APPROX_SIMPLE vertices as sortable keys
+//   5. per border, one wave: bitonic sort of the keys (LDS), Sklansky hull, float rotating
+//      calipers, box score as a wave-parallel masked mean with the fillPoly raster rule in closed
+//      form, Clipper round-join offset, second minAreaRect, integer box, FilterTagDetRes
+//   6. ordered compaction of surviving boxes
+#include <hip/hip_runtime.h>
+#include <float.h>
+#include <limits.h>
+
+#include "kernels_post.h"
+
+namespace ocr {
+
+// ------------------------------------------------------------------ 1. bitmap for caller-supplied maps
+__global__ void __launch_bounds__(256) bitmap_kernel(const float* __restrict__ prob, uint8_t* __restrict__ bm, long total,
+                                                     int ithresh) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int u8 = (int)(unsigned char)(prob[i] * 255.0f);
+  bm[i] = u8 > ithresh ? 1 : 0;
+}
+// 2x2 rect dilate, anchor (1,1): dst(y,x) = max src(y-1..y, x-1..x)
+__global__ void __launch_bounds__(256) dilate2_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int N, int H,
+                                                      int W) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)N * H * W) return;
+  const int x = (int)(i % W), y = (int)((i / W) % H);
+  uint8_t m = src[i];
+  if (x > 0) m |= src[i - 1];
+  if (y > 0) m |= src[i - W];
+  if (x > 0 && y > 0) m |= src[i - W - 1];
+  dst[i] = m;
+}
+void launch_bitmap(const float* prob, uint8_t* bm, long total, int ithresh, hipStream_t s) {
+  hipLaunchKernelGGL(bitmap_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, prob, bm, total, ithresh);
+}
+void launch_dilate2(const uint8_t* src, uint8_t* dst, int N, int H, int W, hipStream_t s) {
+  const long total = (long)N * H * W;
+  hipLaunchKernelGGL(dilate2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, dst, N, H, W);
+}
+
+// ------------------------------------------------------------------ 2. connected components
+__device__ __forceinline__ int uf_find(const int* L, int a) {
+  int p = L[a];
+  while (p != a) { a = p; p = L[a]; }
+  return a;
+}
+__device__ __forceinline__ void uf_unite(int* L, int a, int b) {
+  bool done;
+  do {
+    a = uf_find(L, a);
+    b = uf_find(L, b);
+    if (a < b) { const int old = atomicMin(&L[b], a); done = (old == b); b = old; }
+    else if (b < a) { const int old = atomicMin(&L[a], b); done = (old == a); a = old; }
+    else done = true;
+  } while (!done);
+}
+__global__ void __launch_bounds__(256) ccl_init_kernel(int* __restrict__ L, uint8_t* __restrict__ touch, long total) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  L[i] = (int)i;
+  touch[i] = 0;
+}
+__global__ void __launch_bounds__(256) ccl_merge_kernel(const uint8_t* __restrict__ bm, int* __restrict__ L, int N, int H,
+                                                        int W) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)N * H * W) return;
+  const int x = (int)(i % W), y = (int)((i / W) % H);
+  const uint8_t v = bm[i];
+  if (x > 0 && bm[i - 1] == v) uf_unite(L, (int)i, (int)(i - 1));
+  if (y > 0) {
+    if (bm[i - W] == v) uf_unite(L, (int)i, (int)(i - W));
+    if (v) {  // 8-connectivity for the foreground only
+      if (x > 0 && bm[i - W - 1]) uf_unite(L, (int)i, (int)(i - W - 1));
+      if (x < W - 1 && bm[i - W + 1]) uf_unite(L, (int)i, (int)(i - W + 1));
+    }
+  }
+}
+__global__ void __launch_bounds__(256) ccl_flatten_kernel(const uint8_t* __restrict__ bm, int* __restrict__ L,
+                                                          uint8_t* __restrict__ touch, int N, int H, int W) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)N * H * W) return;
+  const int r = uf_find(L, (int)i);
+  L[i] = r;
+  if (!bm[i]) {
+    const int x = (int)(i % W), y = (int)((i / W) % H);
+    if (x == 0 || y == 0 || x == W - 1 || y == H - 1) touch[r] = 1;  // background component reaches the frame
+  }
+}
+void launch_ccl(const uint8_t* bm, int* L, uint8_t* touch, int N, int H, int W, hipStream_t s) {
+  const long total = (long)N * H * W;
+  const dim3 g((unsigned)((total + 255) / 256));
+  hipLaunchKernelGGL(ccl_init_kernel, g, dim3(256), 0, s, L, touch, total);
+  hipLaunchKernelGGL(ccl_merge_kernel, g, dim3(256), 0, s, bm, L, N, H, W);
+  hipLaunchKernelGGL(ccl_flatten_kernel, g, dim3(256), 0, s, bm, L, touch, N, H, W);
+}
+
+// ------------------------------------------------------------------ 3. border starts, reference order
+__device__ __forceinline__ bool is_start(const uint8_t* bm, const int* L, const uint8_t* touch, long base, int i) {
+  const long g = base + i;
+  if (L[g] != (int)g) return false;
+  return bm[g] ? true : !touch[g];
+}
+// one workgroup (1024 threads) per image
+__global__ void __launch_bounds__(1024) starts_kernel(const uint8_t* __restrict__ bm, const int* __restrict__ L,
+                                                      const uint8_t* __restrict__ touch, int H, int W, int max_cand,
+                                                      int* __restrict__ ncont_all, int* __restrict__ ncont,
+                                                      int* __restrict__ starts /*[N][max_cand]*/) {
+  __shared__ int wsum[16];
+  __shared__ int total_s;
+  __shared__ int running;
+  const int n = blockIdx.x;
+  const long base = (long)n * H * W;
+  const int per = H * W;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  // pass 1: count
+  int cnt = 0;
+  for (int i = threadIdx.x; i < per; i += 1024) cnt += is_start(bm, L, touch, base, i) ? 1 : 0;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off);
+  if (lane == 0) wsum[wv] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int t = 0;
+    for (int k = 0; k < 16; ++k) t += wsum[k];
+    total_s = t;
+    running = 0;
+    ncont_all[n] = t;
+    ncont[n] = t < max_cand ? t : max_cand;
+  }
+  __syncthreads();
+  const int total = total_s;
+  // pass 2: ranks in raster order; keep the last max_cand, store at reversed position
+  for (int i0 = 0; i0 < per; i0 += 1024) {
+    const int i = i0 + threadIdx.x;
+    const bool st = i < per && is_start(bm, L, touch, base, i);
+    const unsigned long long bal = __ballot(st);
+    const int before = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wsum[wv] = __popcll(bal);
+    __syncthreads();
+    int woff = 0;
+    for (int k = 0; k < wv; ++k) woff += wsum[k];
+    const int rank = running + woff + before;
+    if (st) {
+      const int pos = total - 1 - rank;  // reverse discovery order
+      if (pos < max_cand) starts[(long)n * max_cand + pos] = i;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int t = 0;
+      for (int k = 0; k < 16; ++k) t += wsum[k];
+      running += t;
+    }
+    __syncthreads();
+  }
+}
+void launch_starts(const uint8_t* bm, const int* L, const uint8_t* touch, int N, int H, int W, int max_cand, int* ncont_all,
+                   int* ncont, int* starts, hipStream_t s) {
+  hipLaunchKernelGGL(starts_kernel, dim3(N), dim3(1024), 0, s, bm, L, touch, H, W, max_cand, ncont_all, ncont, starts);
+}
+
+// ------------------------------------------------------------------ 4. border following (icvFetchContour)
+__constant__ int kDx[8] = {1, 1, 0, -1, -1, -1, 0, 1};
+__constant__ int kDy[8] = {0, -1, -1, -1, 0, 1, 1, 1};
+
+#define KEY_OFF 16384
+__device__ __forceinline__ unsigned long long make_key(int x, int y, unsigned idx) {
+  return ((unsigned long long)(unsigned)(x + KEY_OFF) << 48) | ((unsigned long long)(unsigned)(y + KEY_OFF) << 32) | idx;
+}
+__device__ __forceinline__ int key_x(unsigned long long k) { return (int)(k >> 48) - KEY_OFF; }
+__device__ __forceinline__ int key_y(unsigned long long k) { return (int)((k >> 32) & 0xffff) - KEY_OFF; }
+__device__ __forceinline__ unsigned key_i(unsigned long long k) { return (unsigned)(k & 0xffffffffu); }
+
+// follows one border; emits CHAIN_APPROX_SIMPLE vertices (if keys != null) and returns their number
+__device__ int trace_border(const uint8_t* __restrict__ bm, int H, int W, int ox, int oy, bool is_hole,
+                            unsigned long long* keys) {
+  auto nz = [&](int x, int y) -> bool { return x >= 0 && y >= 0 && x < W && y < H && bm[(long)y * W + x] != 0; };
+  int count = 0;
+  int s_end, s;
+  s_end = s = is_hole ? 0 : 4;
+  int i1x, i1y;
+  do {
+    s = (s - 1) & 7;
+    i1x = ox + kDx[s];
+    i1y = oy + kDy[s];
+  } while (!nz(i1x, i1y) && s != s_end);
+  if (s == s_end) {
+    if (keys) keys[0] = make_key(ox, oy, 0);
+    return 1;
+  }
+  int cx = ox, cy = oy;
+  int prev_s = s ^ 4;
+  // a closed border of a W x H bitmap has at most 4*W*H steps; the bound keeps every lane finite
+  const long max_steps = 4L * W * H + 16;
+  for (long step = 0; step < max_steps; ++step) {
+    s_end = s;
+    int nx = cx, ny = cy;
+    while (s < 15) {
+      ++s;
+      nx = cx + kDx[s & 7];
+      ny = cy + kDy[s & 7];
+      if (nz(nx, ny)) break;
+    }
+    s &= 7;
+    if (s != prev_s) {
+      if (keys) keys[count] = make_key(cx, cy, (unsigned)count);
+      ++count;
+      prev_s = s;
+    }
+    const bool last = (nx == ox && ny == oy && cx == i1x && cy == i1y);
+    cx = nx;
+    cy = ny;
+    if (last) break;
+    s = (s + 4) & 7;
+  }
+  return count;
+}
+
+__device__ __forceinline__ void contour_origin(const uint8_t* bm, long base, int start, int W, int& ox, int& oy, bool& hole) {
+  hole = bm[base + start] == 0;
+  const int sx = start % W, sy = start / W;
+  ox = hole ? sx - 1 : sx;
+  oy = sy;
+}
+
+// pass A: count vertices per border.  one lane per border.
+__global__ void __launch_bounds__(64) trace_count_kernel(const uint8_t* __restrict__ bm, int H, int W, int max_cand,
+                                                         const int* __restrict__ ncont, const int* __restrict__ starts,
+                                                         int* __restrict__ npts) {
+  const int n = blockIdx.y;
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= ncont[n]) return;
+  const long base = (long)n * H * W;
+  int ox, oy;
+  bool hole;
+  contour_origin(bm, base, starts[(long)n * max_cand + c], W, ox, oy, hole);
+  npts[(long)n * max_cand + c] = trace_border(bm + base, H, W, ox, oy, hole, nullptr);
+}
+__device__ __forceinline__ int pow2_ceil(int v) {
+  int p = 1;
+  while (p < v) p <<= 1;
+  return p;
+}
+// per image: exclusive scan of pow2-rounded sizes -> offsets; overflow flag
+__global__ void __launch_bounds__(64) trace_offsets_kernel(int max_cand, const int* __restrict__ ncont,
+                                                           const int* __restrict__ npts, int* __restrict__ poff, int pool_cap,
+                                                           int* __restrict__ status) {
+  const int n = blockIdx.x;
+  if (threadIdx.x != 0) return;
+  int off = 0;
+  const int nc = ncont[n];
+  for (int c = 0; c < nc; ++c) {
+    const int sz = npts[(long)n * max_cand + c];
+    const int p2 = sz > 2 ? pow2_ceil(sz) : 0;  // borders with <= 2 vertices are dropped by the reference
+    if (off + p2 > pool_cap) { atomicOr(status, POST_ERR_POOL); poff[(long)n * max_cand + c] = -1; continue; }
+    poff[(long)n * max_cand + c] = off;
+    off += p2;
+  }
+}
+// pass B: store keys (padded with +inf to a power of two)
+__global__ void __launch_bounds__(64) trace_store_kernel(const uint8_t* __restrict__ bm, int H, int W, int max_cand,
+                                                         const int* __restrict__ ncont, const int* __restrict__ starts,
+                                                         const int* __restrict__ npts, const int* __restrict__ poff,
+                                                         unsigned long long* __restrict__ pool, int pool_cap) {
+  const int n = blockIdx.y;
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= ncont[n]) return;
+  const long ci = (long)n * max_cand + c;
+  const int sz = npts[ci];
+  if (sz <= 2 || poff[ci] < 0) return;
+  const long base = (long)n * H * W;
+  int ox, oy;
+  bool hole;
+  contour_origin(bm, base, starts[ci], W, ox, oy, hole);
+  unsigned long long* keys = pool + (long)n * pool_cap + poff[ci];
+  trace_border(bm + base, H, W, ox, oy, hole, keys);
+  const int p2 = pow2_ceil(sz);
+  for (int i = sz; i < p2; ++i) keys[i] = ~0ull;
+}
+
+// ------------------------------------------------------------------ 5. per-border geometry (one wave each)
+struct P2f { float x, y; };
+struct RRect { float cx, cy, w, h, angle; };
+
+template <typename T> __device__ __forceinline__ int sgn(T v) { return (v > 0) - (v < 0); }
+
+// Sklansky scan over sorted points; X/Y accessors by sorted position
+template <class Acc, class DotT>
+__device__ int sklansky(const Acc& P, int start, int end, int* stack, int nsign, int sign2) {
+  int incr = end > start ? 1 : -1;
+  int pprev = start, pcur = pprev + incr, pnext = pcur + incr;
+  int stacksize = 3;
+  if (start == end || (P.x(start) == P.x(end) && P.y(start) == P.y(end))) {
+    stack[0] = start;
+    return 1;
+  }
+  stack[0] = pprev; stack[1] = pcur; stack[2] = pnext;
+  end += incr;
+  while (pnext != end) {
+    auto cury = P.y(pcur), nexty = P.y(pnext);
+    auto by = nexty - cury;
+    if (sgn(by) != nsign) {
+      auto ax = P.x(pcur) - P.x(pprev);
+      auto bx = P.x(pnext) - P.x(pcur);
+      auto ay = cury - P.y(pprev);
+      DotT convexity = (DotT)ay * bx - (DotT)ax * by;
+      if (sgn(convexity) == sign2 && (ax != 0 || ay != 0)) {
+        pprev = pcur; pcur = pnext; pnext += incr;
+        stack[stacksize] = pnext;
+        stacksize++;
+      } else {
+        if (pprev == start) {
+          pcur = pnext; stack[1] = pcur; pnext += incr; stack[2] = pnext;
+        } else {
+          stack[stacksize - 2] = pnext;
+          pcur = pprev;
+          pprev = stack[stacksize - 4];
+          stacksize--;
+        }
+      }
+    } else {
+      pnext += incr;
+      stack[stacksize - 1] = pnext;
+    }
+  }
+  return --stacksize;
+}
+
+// cv::convexHull(points, hull, clockwise=false, returnPoints) over SORTED keys (x, y, original index).
+// Writes hull vertices (as floats) to hull[]; returns their number (or -1 on capacity overflow).
+struct KeyAcc {
+  const unsigned long long* k;
+  __device__ int x(int i) const { return key_x(k[i]); }
+  __device__ int y(int i) const { return key_y(k[i]); }
+  __device__ int orig(int i) const { return (int)key_i(k[i]); }
+};
+template <class Acc, class DotT>
+__device__ int convex_hull_sorted(const Acc& P, int total, int* stack, int* hullbuf, P2f* hull, int hull_cap) {
+  if (total == 0) return 0;
+  int miny_ind = 0, maxy_ind = 0;
+  for (int i = 1; i < total; ++i) {
+    auto y = P.y(i);
+    if (P.y(miny_ind) > y) miny_ind = i;
+    if (P.y(maxy_ind) < y) maxy_ind = i;
+  }
+  int nout = 0;
+  if (P.x(0) == P.x(total - 1) && P.y(0) == P.y(total - 1)) {
+    hullbuf[nout++] = P.orig(0);  // all points identical: index 0 after sort is the smallest original index
+    hull[0].x = (float)P.x(0);
+    hull[0].y = (float)P.y(0);
+    return 1;
+  }
+  // NB: hullbuf holds ORIGINAL indices (the reference's `pointer[...] - data0`); hsorted (second half
+  // of the buffer) remembers the sorted positions so coordinates can be fetched again afterwards.
+  int* hsorted = hullbuf + total;
+  int* tl_stack = stack;
+  int tl_count = sklansky<Acc, DotT>(P, 0, maxy_ind, tl_stack, -1, 1);
+  int* tr_stack = stack + tl_count;
+  int tr_count = sklansky<Acc, DotT>(P, total - 1, maxy_ind, tr_stack, -1, -1);
+  { int* t = tl_stack; tl_stack = tr_stack; tr_stack = t; int c = tl_count; tl_count = tr_count; tr_count = c; }  // !clockwise
+  for (int i = 0; i < tl_count - 1; ++i) { hsorted[nout] = tl_stack[i]; hullbuf[nout++] = P.orig(tl_stack[i]); }
+  for (int i = tr_count - 1; i > 0; --i) { hsorted[nout] = tr_stack[i]; hullbuf[nout++] = P.orig(tr_stack[i]); }
+  const int stop_idx = tr_count > 2 ? tr_stack[1] : tl_count > 2 ? tl_stack[tl_count - 2] : -1;
+  int* bl_stack = stack;
+  int bl_count = sklansky<Acc, DotT>(P, 0, miny_ind, bl_stack, 1, -1);
+  int* br_stack = stack + bl_count;
+  int br_count = sklansky<Acc, DotT>(P, total - 1, miny_ind, br_stack, 1, 1);
+  if (stop_idx >= 0) {
+    const int check_idx = bl_count > 2 ? bl_stack[1] : bl_count + br_count > 2 ? br_stack[2 - bl_count] : -1;
+    if (check_idx == stop_idx || (check_idx >= 0 && P.x(check_idx) == P.x(stop_idx) && P.y(check_idx) == P.y(stop_idx))) {
+      bl_count = bl_count < 2 ? bl_count : 2;
+      br_count = br_count < 2 ? br_count : 2;
+    }
+  }
+  for (int i = 0; i < bl_count - 1; ++i) { hsorted[nout] = bl_stack[i]; hullbuf[nout++] = P.orig(bl_stack[i]); }
+  for (int i = br_count - 1; i > 0; --i) { hsorted[nout] = br_stack[i]; hullbuf[nout++] = P.orig(br_stack[i]); }
+  // cyclic shift so that original indices ascend/descend (only the start vertex changes)
+  int shift = 0;
+  if (nout >= 3) {
+    int min_idx = 0, max_idx = 0, lt = 0, i;
+    for (i = 1; i < nout; ++i) {
+      const int idx = hullbuf[i];
+      lt += hullbuf[i - 1] < idx;
+      if (lt > 1 && lt <= i - 2) break;
+      if (idx < hullbuf[min_idx]) min_idx = i;
+      if (idx > hullbuf[max_idx]) max_idx = i;
+    }
+    const int mmdist = abs(max_idx - min_idx);
+    if ((mmdist == 1 || mmdist == nout - 1) && (lt <= 1 || lt >= nout - 2)) {
+      const int ascending = (max_idx + 1) % nout == min_idx;
+      const int i0 = ascending ? min_idx : max_idx;
+      int j = i0;
+      if (i0 > 0) {
+        for (i = 0; i < nout; ++i) {
+          const int curr_idx = hullbuf[j];
+          const int next_j = j + 1 < nout ? j + 1 : 0;
+          const int next_idx = hullbuf[next_j];
+          if (i < nout - 1 && (ascending != (curr_idx < next_idx))) break;
+          j = next_j;
+        }
+        if (i == nout) shift = i0;
+      }
+    }
+  }
+  if (nout > hull_cap) return -1;
+  for (int i = 0; i < nout; ++i) {
+    const int sp = hsorted[(i + shift) % nout];
+    hull[i].x = (float)P.x(sp);
+    hull[i].y = (float)P.y(sp);
+  }
+  return nout;
+}
+
+// rotatingCalipers(CALIPERS_MINAREARECT); vect/inv are scratch of n entries
+__device__ void rotating_calipers(const P2f* points, int n, P2f* vect, float* inv_vect_length, float out[6]) {
+  float minarea = FLT_MAX;
+  int left = 0, bottom = 0, right = 0, top = 0;
+  int seq[4] = {-1, -1, -1, -1};
+  float orientation = 0, base_a, base_b = 0;
+  float left_x, right_x, top_y, bottom_y;
+  P2f pt0 = points[0];
+  left_x = right_x = pt0.x;
+  top_y = bottom_y = pt0.y;
+  for (int i = 0; i < n; ++i) {
+    if (pt0.x < left_x) left_x = pt0.x, left = i;
+    if (pt0.x > right_x) right_x = pt0.x, right = i;
+    if (pt0.y > top_y) top_y = pt0.y, top = i;
+    if (pt0.y < bottom_y) bottom_y = pt0.y, bottom = i;
+    const P2f pt = points[(i + 1) < n ? i + 1 : 0];
+    const double dx = pt.x - pt0.x, dy = pt.y - pt0.y;
+    vect[i].x = (float)dx;
+    vect[i].y = (float)dy;
+    inv_vect_length[i] = (float)(1. / sqrt(dx * dx + dy * dy));
+    pt0 = pt;
+  }
+  {
+    double ax = vect[n - 1].x, ay = vect[n - 1].y;
+    for (int i = 0; i < n; ++i) {
+      const double bx = vect[i].x, by = vect[i].y;
+      const double convexity = ax * by - ay * bx;
+      if (convexity != 0) { orientation = (convexity > 0) ? 1.f : (-1.f); break; }
+      ax = bx; ay = by;
+    }
+  }
+  base_a = orientation;
+  seq[0] = bottom; seq[1] = right; seq[2] = top; seq[3] = left;
+  int best_left = 0, best_bottom = 0;
+  float b_a = 0, b_w = 0, b_b = 0, b_h = 0;
+  for (int k = 0; k < n; ++k) {
+    float dp[4];
+    dp[0] = +base_a * vect[seq[0]].x + base_b * vect[seq[0]].y;
+    dp[1] = -base_b * vect[seq[1]].x + base_a * vect[seq[1]].y;
+    dp[2] = -base_a * vect[seq[2]].x - base_b * vect[seq[2]].y;
+    dp[3] = +base_b * vect[seq[3]].x - base_a * vect[seq[3]].y;
+    float maxcos = dp[0] * inv_vect_length[seq[0]];
+    int main_element = 0;
+    for (int i = 1; i < 4; ++i) {
+      const float cosalpha = dp[i] * inv_vect_length[seq[i]];
+      if (cosalpha > maxcos) { main_element = i; maxcos = cosalpha; }
+    }
+    {
+      const int pindex = seq[main_element];
+      const float lead_x = vect[pindex].x * inv_vect_length[pindex];
+      const float lead_y = vect[pindex].y * inv_vect_length[pindex];
+      switch (main_element) {
+        case 0: base_a = lead_x; base_b = lead_y; break;
+        case 1: base_a = lead_y; base_b = -lead_x; break;
+        case 2: base_a = -lead_x; base_b = -lead_y; break;
+        default: base_a = -lead_y; base_b = lead_x; break;
+      }
+    }
+    seq[main_element] += 1;
+    seq[main_element] = (seq[main_element] == n) ? 0 : seq[main_element];
+    {
+      float dx = points[seq[1]].x - points[seq[3]].x;
+      float dy = points[seq[1]].y - points[seq[3]].y;
+      const float width = dx * base_a + dy * base_b;
+      dx = points[seq[2]].x - points[seq[0]].x;
+      dy = points[seq[2]].y - points[seq[0]].y;
+      const float height = -dx * base_b + dy * base_a;
+      const float area = width * height;
+      if (area <= minarea) {
+        minarea = area;
+        best_left = seq[3];
+        b_a = base_a; b_w = width; b_b = base_b; b_h = height;
+        best_bottom = seq[0];
+      }
+    }
+  }
+  const float A1 = b_a, B1 = b_b, A2 = -b_b, B2 = b_a;
+  const float C1 = A1 * points[best_left].x + points[best_left].y * B1;
+  const float C2 = A2 * points[best_bottom].x + points[best_bottom].y * B2;
+  const float idet = 1.f / (A1 * B2 - A2 * B1);
+  const float px = (C1 * B2 - C2 * B1) * idet;
+  const float py = (A1 * C2 - A2 * C1) * idet;
+  out[0] = px; out[1] = py;
+  out[2] = A1 * b_w; out[3] = B1 * b_w;
+  out[4] = A2 * b_h; out[5] = B2 * b_h;
+}
+
+__device__ RRect min_area_rect_hull(const P2f* h, int n, P2f* vect, float* inv) {
+  RRect box{0, 0, 0, 0, 0};
+  if (n > 2) {
+    float out[6];
+    rotating_calipers(h, n, vect, inv, out);
+    box.cx = out[0] + (out[2] + out[4]) * 0.5f;
+    box.cy = out[1] + (out[3] + out[5]) * 0.5f;
+    box.w = (float)sqrt((double)out[2] * out[2] + (double)out[3] * out[3]);
+    box.h = (float)sqrt((double)out[4] * out[4] + (double)out[5] * out[5]);
+    box.angle = (float)atan2((double)out[3], (double)out[2]);
+  } else if (n == 2) {
+    box.cx = (h[0].x + h[1].x) * 0.5f;
+    box.cy = (h[0].y + h[1].y) * 0.5f;
+    const double dx = h[1].x - h[0].x, dy = h[1].y - h[0].y;
+    box.w = (float)sqrt(dx * dx + dy * dy);
+    box.h = 0;
+    box.angle = (float)atan2(dy, dx);
+  } else if (n == 1) {
+    box.cx = h[0].x;
+    box.cy = h[0].y;
+  }
+  box.angle = (float)(box.angle * 180 / 3.14159265358979323846);
+  return box;
+}
+
+__device__ void box_points(const RRect& r, P2f pt[4]) {
+  const double ang = r.angle * 3.14159265358979323846 / 180.;
+  const float b = (float)cos(ang) * 0.5f;
+  const float a = (float)sin(ang) * 0.5f;
+  pt[0].x = r.cx - a * r.h - b * r.w;
+  pt[0].y = r.cy + b * r.h - a * r.w;
+  pt[1].x = r.cx + a * r.h - b * r.w;
+  pt[1].y = r.cy - b * r.h - a * r.w;
+  pt[2].x = 2 * r.cx - pt[0].x;
+  pt[2].y = 2 * r.cy - pt[0].y;
+  pt[3].x = 2 * r.cx - pt[1].x;
+  pt[3].y = 2 * r.cy - pt[1].y;
+}
+
+__device__ void get_mini_boxes(const RRect& box, float& ssid, P2f out[4]) {
+  ssid = fmaxf(box.w, box.h);
+  P2f a[4];
+  box_points(box, a);
+  for (int i = 1; i < 4; ++i) {  // std::sort on 4 elements == libstdc++ insertion sort
+    const P2f v = a[i];
+    if (v.x < a[0].x) {
+      for (int k = i; k > 0; --k) a[k] = a[k - 1];
+      a[0] = v;
+    } else {
+      int j = i - 1;
+      while (v.x < a[j].x) { a[j + 1] = a[j]; --j; }
+      a[j + 1] = v;
+    }
+  }
+  P2f idx1, idx2, idx3, idx4;
+  if (a[3].y <= a[2].y) { idx2 = a[3]; idx3 = a[2]; } else { idx2 = a[2]; idx3 = a[3]; }
+  if (a[1].y <= a[0].y) { idx1 = a[1]; idx4 = a[0]; } else { idx1 = a[0]; idx4 = a[1]; }
+  out[0] = idx1; out[1] = idx2; out[2] = idx3; out[3] = idx4;
+}
+
+// ---- fillPoly raster rule in closed form (XY_SHIFT = 16 edge fill + 8-connected Bresenham outline)
+struct LineRast {  // one outline segment after cv::clipLine, LineIterator(leftToRight)
+  int valid, px, py, dx, dy, delta_major, delta_minor, vert, count;
+};
+struct EdgeRast {  // one non-horizontal polygon edge of the scan fill
+  int valid, y0, y1;
+  long long x, dx;
+};
+__device__ bool clip_line(long long w, long long h, long long& x1, long long& y1, long long& x2, long long& y2) {
+  const long long right = w - 1, bottom = h - 1;
+  if (w <= 0 || h <= 0) return false;
+  int c1 = (x1 < 0) + (x1 > right) * 2 + (y1 < 0) * 4 + (y1 > bottom) * 8;
+  int c2 = (x2 < 0) + (x2 > right) * 2 + (y2 < 0) * 4 + (y2 > bottom) * 8;
+  if ((c1 & c2) == 0 && (c1 | c2) != 0) {
+    long long a;
+    if (c1 & 12) { a = c1 < 8 ? 0 : bottom; x1 += (long long)((double)(a - y1) * (x2 - x1) / (y2 - y1)); y1 = a; c1 = (x1 < 0) + (x1 > right) * 2; }
+    if (c2 & 12) { a = c2 < 8 ? 0 : bottom; x2 += (long long)((double)(a - y2) * (x2 - x1) / (y2 - y1)); y2 = a; c2 = (x2 < 0) + (x2 > right) * 2; }
+    if ((c1 & c2) == 0 && (c1 | c2) != 0) {
+      if (c1) { a = c1 == 1 ? 0 : right; y1 += (long long)((double)(a - x1) * (y2 - y1) / (x2 - x1)); x1 = a; c1 = 0; }
+      if (c2) { a = c2 == 1 ? 0 : right; y2 += (long long)((double)(a - x2) * (y2 - y1) / (x2 - x1)); x2 = a; c2 = 0; }
+    }
+  }
+  return (c1 | c2) == 0;
+}
+__device__ LineRast make_line(int W, int H, int ax, int ay, int bx, int by) {
+  LineRast L{};
+  long long x1 = ax, y1 = ay, x2 = bx, y2 = by;
+  if ((unsigned long long)x1 >= (unsigned long long)W || (unsigned long long)x2 >= (unsigned long long)W ||
+      (unsigned long long)y1 >= (unsigned long long)H || (unsigned long long)y2 >= (unsigned long long)H) {
+    if (!clip_line(W, H, x1, y1, x2, y2)) return L;
+  }
+  int dx = (int)(x2 - x1), dy = (int)(y2 - y1);
+  int delta_x = 1, delta_y = 1;
+  int px = (int)x1, py = (int)y1;
+  if (dx < 0) { dx = -dx; dy = -dy; px = (int)x2; py = (int)y2; }
+  if (dy < 0) { dy = -dy; delta_y = -1; }
+  const bool vert = dy > dx;
+  if (vert) { int t = dx; dx = dy; dy = t; t = delta_x; delta_x = delta_y; delta_y = t; }
+  L.valid = 1; L.px = px; L.py = py; L.dx = dx; L.dy = dy;
+  L.delta_major = delta_x; L.delta_minor = delta_y; L.vert = vert; L.count = dx + 1;
+  return L;
+}
+// is (x,y) one of the pixels LineIterator visits?
+__device__ __forceinline__ bool on_line(const LineRast& L, int x, int y) {
+  if (!L.valid) return false;
+  const int maj = L.vert ? y : x, mnr = L.vert ? x : y;
+  const int maj0 = L.vert ? L.py : L.px, mnr0 = L.vert ? L.px : L.py;
+  const int j = (maj - maj0) * L.delta_major;
+  if (j < 0 || j >= L.count) return false;
+  int m = 0;
+  const long long a = 2LL * L.dy * j - L.dx;
+  if (j > 0 && L.dy > 0 && a > 0) m = (int)((a + 2LL * L.dx - 1) / (2LL * L.dx));
+  return mnr == mnr0 + L.delta_minor * m;
+}
+
+// BoxScoreFast: masked mean over the bbox with the mask of fillPoly(int-truncated corners).
+// All 64 lanes participate; returns the score in every lane.
+__device__ float box_score_fast_wave(const P2f arr[4], const float* __restrict__ pred, int H, int W, int lane) {
+  float fxmin = fminf(fminf(arr[0].x, arr[1].x), fminf(arr[2].x, arr[3].x));
+  float fxmax = fmaxf(fmaxf(arr[0].x, arr[1].x), fmaxf(arr[2].x, arr[3].x));
+  float fymin = fminf(fminf(arr[0].y, arr[1].y), fminf(arr[2].y, arr[3].y));
+  float fymax = fmaxf(fmaxf(arr[0].y, arr[1].y), fmaxf(arr[2].y, arr[3].y));
+  auto clampi = [](int v, int lo, int hi) { return v > hi ? hi : (v < lo ? lo : v); };
+  const int xmin = clampi((int)floorf(fxmin), 0, W - 1), xmax = clampi((int)ceilf(fxmax), 0, W - 1);
+  const int ymin = clampi((int)floorf(fymin), 0, H - 1), ymax = clampi((int)ceilf(fymax), 0, H - 1);
+  const int mw = xmax - xmin + 1, mh = ymax - ymin + 1;
+  int vx[4], vy[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { vx[i] = (int)arr[i].x - xmin; vy[i] = (int)arr[i].y - ymin; }
+  LineRast Ls[4];
+  EdgeRast Es[4];
+  int nedges = 0;
+  int ey_min = INT_MAX, ey_max = INT_MIN;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int p = (i + 3) & 3;  // previous vertex: edges run v[count-1] -> v[0] -> ...
+    Ls[i] = make_line(mw, mh, vx[p], vy[p], vx[i], vy[i]);
+    Es[i].valid = 0;
+    if (vy[p] != vy[i]) {
+      const long long p0x = (long long)vx[p] << 16, p1x = (long long)vx[i] << 16;
+      EdgeRast e;
+      e.valid = 1;
+      if (vy[p] < vy[i]) { e.y0 = vy[p]; e.y1 = vy[i]; e.x = p0x; }
+      else { e.y0 = vy[i]; e.y1 = vy[p]; e.x = p1x; }
+      e.dx = (p1x - p0x) / (long long)(vy[i] - vy[p]);
+      Es[i] = e;
+      ++nedges;
+      ey_min = min(ey_min, e.y0);
+      ey_max = max(ey_max, e.y1);
+    }
+  }
+  const bool do_fill = nedges >= 2;
+  double sum = 0.0;
+  int cnt = 0;
+  const long total = (long)mw * mh;
+  for (long t = lane; t < total; t += 64) {
+    const int y = (int)(t / mw), x = (int)(t - (long)y * mw);
+    bool in = on_line(Ls[0], x, y) || on_line(Ls[1], x, y) || on_line(Ls[2], x, y) || on_line(Ls[3], x, y);
+    if (!in && do_fill && y >= ey_min && y < ey_max) {
+      // active edges on this scanline, their x in 16.16, sorted ascending, filled pairwise
+      long long xs[4];
+      int na = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (Es[i].valid && Es[i].y0 <= y && y < Es[i].y1) xs[na++] = Es[i].x + (long long)(y - Es[i].y0) * Es[i].dx;
+      for (int i = 1; i < na; ++i) {
+        const long long v = xs[i];
+        int j = i - 1;
+        while (j >= 0 && xs[j] > v) { xs[j + 1] = xs[j]; --j; }
+        xs[j + 1] = v;
+      }
+      for (int i = 0; i + 1 < na; i += 2) {
+        const int x1 = (int)((xs[i] + 65535) >> 16), x2 = (int)(xs[i + 1] >> 16);
+        if (x >= x1 && x <= x2) in = true;
+      }
+    }
+    if (in) {
+      sum += (double)pred[(long)(y + ymin) * W + x + xmin];
+      ++cnt;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    sum += __shfl_xor(sum, off);
+    cnt += __shfl_xor(cnt, off);
+  }
+  return cnt ? (float)(sum / (double)cnt) : 0.f;
+}
+
+// ---- ClipperOffset (jtRound, etClosedPolygon) + union clean-up, lane 0 only
+struct IPt { long long X, Y; };
+__device__ __forceinline__ long long clip_round(double v) { return v < 0 ? (long long)(v - 0.5) : (long long)(v + 0.5); }
+#define UNCLIP_CAP 512
+// dest: scratch of UNCLIP_CAP; returns point count (0 when Execute yields no path, -1 on overflow)
+__device__ int clipper_offset_round(const IPt in[4], double delta, IPt* dest) {
+  IPt c[4];
+  int highI = 3;
+  while (highI > 0 && in[0].X == in[highI].X && in[0].Y == in[highI].Y) highI--;
+  int len = 0;
+  c[len++] = in[0];
+  for (int i = 1; i <= highI; ++i)
+    if (c[len - 1].X != in[i].X || c[len - 1].Y != in[i].Y) c[len++] = in[i];
+  if (len < 3) return 0;
+  {
+    double a = 0;
+    for (int i = 0, j = len - 1; i < len; ++i) { a += ((double)c[j].X + c[i].X) * ((double)c[j].Y - c[i].Y); j = i; }
+    if (!(-a * 0.5 >= 0)) {
+      for (int i = 0; i < len / 2; ++i) { IPt t = c[i]; c[i] = c[len - 1 - i]; c[len - 1 - i] = t; }
+    }
+  }
+  int nd = 0;
+  const double pi = 3.141592653589793238, two_pi = pi * 2;
+  if (delta > -1.0e-20 && delta < 1.0e-20) {
+    for (int i = 0; i < len; ++i) dest[nd++] = c[i];
+  } else {
+    double y = 0.25;
+    if (0.25 > fabs(delta) * 0.25) y = fabs(delta) * 0.25;
+    double steps = pi / acos(1 - y / fabs(delta));
+    if (steps > fabs(delta) * pi) steps = fabs(delta) * pi;
+    double m_sin = sin(two_pi / steps);
+    const double m_cos = cos(two_pi / steps);
+    const double steps_per_rad = steps / two_pi;
+    if (delta < 0.0) m_sin = -m_sin;
+    double nX[4], nY[4];
+    for (int j = 0; j < len; ++j) {
+      const IPt& p1 = c[j];
+      const IPt& p2 = c[(j + 1) % len];
+      if (p1.X == p2.X && p1.Y == p2.Y) { nX[j] = 0; nY[j] = 0; continue; }
+      double Dx = (double)(p2.X - p1.X), dy = (double)(p2.Y - p1.Y);
+      const double f = 1 * 1.0 / sqrt(Dx * Dx + dy * dy);
+      Dx *= f; dy *= f;
+      nX[j] = dy; nY[j] = -Dx;
+    }
+    int k = len - 1;
+    for (int j = 0; j < len; ++j) {
+      double sinA = nX[k] * nY[j] - nX[j] * nY[k];
+      if (fabs(sinA * delta) < 1.0) {
+        const double cosA = nX[k] * nX[j] + nY[j] * nY[k];
+        if (cosA > 0) {
+          if (nd >= UNCLIP_CAP) return -1;
+          dest[nd++] = {clip_round(c[j].X + nX[k] * delta), clip_round(c[j].Y + nY[k] * delta)};
+          continue;
+        }
+      } else if (sinA > 1.0) sinA = 1.0;
+      else if (sinA < -1.0) sinA = -1.0;
+      if (sinA * delta < 0) {
+        if (nd + 3 > UNCLIP_CAP) return -1;
+        dest[nd++] = {clip_round(c[j].X + nX[k] * delta), clip_round(c[j].Y + nY[k] * delta)};
+        dest[nd++] = c[j];
+        dest[nd++] = {clip_round(c[j].X + nX[j] * delta), clip_round(c[j].Y + nY[j] * delta)};
+      } else {
+        const double a = atan2(sinA, nX[k] * nX[j] + nY[k] * nY[j]);
+        long long r = clip_round(steps_per_rad * fabs(a));
+        const int st = (int)r > 1 ? (int)r : 1;
+        if (nd + st + 1 > UNCLIP_CAP) return -1;
+        double X = nX[k], Y = nY[k], X2;
+        for (int i = 0; i < st; ++i) {
+          dest[nd++] = {clip_round(c[j].X + X * delta), clip_round(c[j].Y + Y * delta)};
+          X2 = X;
+          X = X * m_cos - m_sin * Y;
+          Y = X2 * m_sin + Y * m_cos;
+        }
+        dest[nd++] = {clip_round(c[j].X + nX[j] * delta), clip_round(c[j].Y + nY[j] * delta)};
+      }
+      k = j;
+    }
+  }
+  // union clean-up: duplicates / collinear vertices go; ring starts after the last top-most vertex
+  bool changed = true;
+  while (changed && nd >= 3) {
+    changed = false;
+    int i = 0;
+    while (i < nd && nd >= 3) {
+      const IPt a = dest[(i + nd - 1) % nd], b = dest[i], cc = dest[(i + 1) % nd];
+      if ((b.X == cc.X && b.Y == cc.Y) || (b.X == a.X && b.Y == a.Y) ||
+          (b.Y - a.Y) * (cc.X - b.X) == (b.X - a.X) * (cc.Y - b.Y)) {
+        for (int q = i; q + 1 < nd; ++q) dest[q] = dest[q + 1];
+        --nd;
+        changed = true;
+        if (i > 0) --i;
+      } else
+        ++i;
+    }
+  }
+  if (nd < 3) return 0;
+  long long miny = dest[0].Y;
+  for (int i = 1; i < nd; ++i) miny = dest[i].Y < miny ? dest[i].Y : miny;
+  int e = 0;
+  for (int i = 0; i < nd; ++i)
+    if (dest[i].Y == miny && dest[(i + 1) % nd].Y != miny) { e = i; break; }
+  // rotate left by e+1 (in place, via reversal)
+  const int rsh = (e + 1) % nd;
+  auto rev = [&](int lo, int hi) { while (lo < hi) { IPt t = dest[lo]; dest[lo] = dest[hi]; dest[hi] = t; ++lo; --hi; } };
+  if (rsh) { rev(0, rsh - 1); rev(rsh, nd - 1); rev(0, nd - 1); }
+  return nd;
+}
+
+struct FKeyAcc {  // float-valued integer points sorted through the same key packing
+  const unsigned long long* k;
+  __device__ float x(int i) const { return (float)key_x(k[i]); }
+  __device__ float y(int i) const { return (float)key_y(k[i]); }
+  __device__ int orig(int i) const { return (int)key_i(k[i]); }
+};
+
+#define HULL_CAP 1024
+#define SORT_LDS_CAP 4096
+
+// bitonic sort of n2 (power of two) keys by the whole wave; `a` may be LDS or global
+__device__ void bitonic_sort_wave(unsigned long long* a, int n2, int lane, bool in_lds) {
+  for (int k = 2; k <= n2; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = lane; i < n2; i += 64) {
+        const int l = i ^ j;
+        if (l > i) {
+          unsigned long long x, y;
+          if (in_lds) { x = a[i]; y = a[l]; }
+          else {
+            x = __hip_atomic_load(&a[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            y = __hip_atomic_load(&a[l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          const bool asc = (i & k) == 0;
+          if (asc ? (x > y) : (x < y)) {
+            if (in_lds) { a[i] = y; a[l] = x; }
+            else {
+              __hip_atomic_store(&a[i], y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              __hip_atomic_store(&a[l], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+          }
+        }
+      }
+      __threadfence_block();
+      __syncthreads();
+    }
+  }
+}
+
+// one wave (workgroup of 64) per border
+__global__ void __launch_bounds__(64) border_box_kernel(const PostArgs a) {
+  __shared__ unsigned long long s_keys[SORT_LDS_CAP];
+  __shared__ P2f s_hull[HULL_CAP];
+  __shared__ P2f s_vect[HULL_CAP];
+  __shared__ float s_inv[HULL_CAP];
+  __shared__ IPt s_unclip[UNCLIP_CAP];
+  __shared__ unsigned long long s_ukeys[UNCLIP_CAP];
+  __shared__ int s_ustack[UNCLIP_CAP + 2];
+  __shared__ int s_uhull[2 * UNCLIP_CAP];
+  __shared__ float s_box[8];
+  __shared__ int s_flag;
+  const int n = blockIdx.y, c = blockIdx.x, lane = threadIdx.x;
+  const long ci = (long)n * a.max_cand + c;
+  int* obox = a.cand_boxes + ci * 8;
+  if (c >= a.ncont[n]) return;
+  if (lane == 0) a.cand_valid[ci] = 0;
+  const int total = a.npts[ci];
+  if (total <= 2 || a.poff[ci] < 0) return;  // contours[i].size() <= 2 -> continue
+  const int n2 = pow2_ceil(total);
+  unsigned long long* gkeys = a.pool + (long)n * a.pool_cap + a.poff[ci];
+  unsigned long long* keys;
+  const bool in_lds = n2 <= SORT_LDS_CAP;
+  if (in_lds) {
+    for (int i = lane; i < n2; i += 64) s_keys[i] = gkeys[i];
+    keys = s_keys;
+  } else {
+    keys = gkeys;
+  }
+  __syncthreads();
+  bitonic_sort_wave(keys, n2, lane, in_lds);
+  // ---- minAreaRect(contour) -> GetMiniBoxes (lane 0)
+  if (lane == 0) {
+    s_flag = 0;
+    int* stack = a.iscratch + ((long)n * a.pool_cap + a.poff[ci]) * 4;  // 4 ints per pooled key: stack[n2+2 <= 2*n2], hullbuf[2*n2]
+    int* hullbuf = stack + 2 * n2;
+    KeyAcc P{keys};
+    const int hn = convex_hull_sorted<KeyAcc, int>(P, total, stack, hullbuf, s_hull, HULL_CAP);
+    if (hn < 0) { atomicOr(a.status, POST_ERR_HULL); s_flag = 0; }
+    else {
+      const RRect box = min_area_rect_hull(s_hull, hn, s_vect, s_inv);
+      float ssid;
+      P2f arr[4];
+      get_mini_boxes(box, ssid, arr);
+      if (ssid >= 3.0f) {  // min_size = 3
+        s_flag = 1;
+        for (int i = 0; i < 4; ++i) { s_box[2 * i] = arr[i].x; s_box[2 * i + 1] = arr[i].y; }
+      }
+    }
+  }
+  __syncthreads();
+  if (!s_flag) return;
+  P2f arr[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { arr[i].x = s_box[2 * i]; arr[i].y = s_box[2 * i + 1]; }
+  // ---- BoxScoreFast (whole wave)
+  const float score = box_score_fast_wave(arr, a.pred + (long)n * a.H * a.W, a.H, a.W, lane);
+  if (score < a.box_thresh) return;
+  if (lane != 0) return;
+  // ---- UnClip
+  float area = 0.0f, dist = 0.0f;
+  for (int i = 0; i < 4; ++i) {
+    const int j = (i + 1) % 4;
+    area += arr[i].x * arr[j].y - arr[i].y * arr[j].x;
+    dist += sqrtf((arr[i].x - arr[j].x) * (arr[i].x - arr[j].x) + (arr[i].y - arr[j].y) * (arr[i].y - arr[j].y));
+  }
+  area = fabsf((float)(area / 2.0));
+  const float distance = area * a.unclip_ratio / dist;
+  IPt q[4];
+  for (int i = 0; i < 4; ++i) q[i] = {(long long)(int)arr[i].x, (long long)(int)arr[i].y};
+  const int un = clipper_offset_round(q, (double)distance, s_unclip);
+  if (un < 0) { atomicOr(a.status, POST_ERR_UNCLIP); return; }
+  RRect pts;
+  if (un == 0) {
+    pts = RRect{0, 0, 1, 1, 0};
+  } else {
+    // minAreaRect(points): sort (x, y, index) by insertion, hull, calipers
+    for (int i = 0; i < un; ++i) {
+      const unsigned long long k = make_key((int)s_unclip[i].X, (int)s_unclip[i].Y, (unsigned)i);
+      int j = i - 1;
+      while (j >= 0 && s_ukeys[j] > k) { s_ukeys[j + 1] = s_ukeys[j]; --j; }
+      s_ukeys[j + 1] = k;
+    }
+    FKeyAcc FP{s_ukeys};
+    const int hn = convex_hull_sorted<FKeyAcc, float>(FP, un, s_ustack, s_uhull, s_hull, HULL_CAP);
+    if (hn < 0) { atomicOr(a.status, POST_ERR_HULL); return; }
+    pts = min_area_rect_hull(s_hull, hn, s_vect, s_inv);
+  }
+  if (pts.h < 1.001 && pts.w < 1.001) return;
+  float ssid;
+  P2f clip[4];
+  get_mini_boxes(pts, ssid, clip);
+  if (ssid < 5.0f) return;  // min_size + 2
+  int b[4][2];
+  const float fw = (float)a.W, fh = (float)a.H;
+  for (int k = 0; k < 4; ++k) {
+    float vx = roundf(clip[k].x / fw * fw), vy = roundf(clip[k].y / fh * fh);
+    vx = vx > fw ? fw : (vx < 0 ? 0 : vx);
+    vy = vy > fh ? fh : (vy < 0 ? 0 : vy);
+    b[k][0] = (int)vx;
+    b[k][1] = (int)vy;
+  }
+  // ---- FilterTagDetRes for this box (OrderPointsClockwise, /ratio, clamp, size gate)
+  for (int i = 1; i < 4; ++i) {
+    const int vx = b[i][0], vy = b[i][1];
+    if (vx < b[0][0]) {
+      for (int k = i; k > 0; --k) { b[k][0] = b[k - 1][0]; b[k][1] = b[k - 1][1]; }
+      b[0][0] = vx; b[0][1] = vy;
+    } else {
+      int j = i - 1;
+      while (vx < b[j][0]) { b[j + 1][0] = b[j][0]; b[j + 1][1] = b[j][1]; --j; }
+      b[j + 1][0] = vx; b[j + 1][1] = vy;
+    }
+  }
+  int l0 = 0, l1 = 1, r0 = 2, r1 = 3;
+  if (b[l0][1] > b[l1][1]) { const int t = l0; l0 = l1; l1 = t; }
+  if (b[r0][1] > b[r1][1]) { const int t = r0; r0 = r1; r1 = t; }
+  const int ord[4] = {l0, r0, r1, l1};
+  int f[4][2];
+  for (int m = 0; m < 4; ++m) {
+    int x = (int)((float)b[ord[m]][0] / a.ratio_w);
+    int y = (int)((float)b[ord[m]][1] / a.ratio_h);
+    x = min(max(x, 0), a.src_w - 1);
+    y = min(max(y, 0), a.src_h - 1);
+    f[m][0] = x; f[m][1] = y;
+  }
+  const double dw0 = (double)(f[0][0] - f[1][0]), dw1 = (double)(f[0][1] - f[1][1]);
+  const double dh0 = (double)(f[0][0] - f[3][0]), dh1 = (double)(f[0][1] - f[3][1]);
+  const int rect_width = (int)sqrt(dw0 * dw0 + dw1 * dw1);
+  const int rect_height = (int)sqrt(dh0 * dh0 + dh1 * dh1);
+  if (rect_width <= 4 || rect_height <= 4) return;
+  for (int m = 0; m < 4; ++m) { obox[2 * m] = f[m][0]; obox[2 * m + 1] = f[m][1]; }
+  a.cand_valid[ci] = 1;
+}
+
+// ------------------------------------------------------------------ 6. ordered compaction of surviving boxes
+__global__ void __launch_bounds__(64) boxes_compact_kernel(const PostArgs a, int* __restrict__ out_boxes, int cap,
+                                                           int* __restrict__ out_n) {
+  const int n = blockIdx.x;
+  if (threadIdx.x != 0) return;
+  int k = 0;
+  const int nc = a.ncont[n];
+  for (int c = 0; c < nc; ++c) {
+    const long ci = (long)n * a.max_cand + c;
+    if (!a.cand_valid[ci]) continue;
+    if (k < cap)
+      for (int q = 0; q < 8; ++q) out_boxes[((long)n * cap + k) * 8 + q] = a.cand_boxes[ci * 8 + q];
+    ++k;
+  }
+  out_n[n] = k;
+}
+
+void launch_post(const PostArgs& a, int N, int* out_boxes, int cap, int* out_n, hipStream_t s) {
+  launch_ccl(a.bitmap, a.labels, a.touch, N, a.H, a.W, s);
+  launch_starts(a.bitmap, a.labels, a.touch, N, a.H, a.W, a.max_cand, a.ncont_all, a.ncont, a.starts, s);
+  const dim3 gl((a.max_cand + 63) / 64, N);
+  hipLaunchKernelGGL(trace_count_kernel, gl, dim3(64), 0, s, a.bitmap, a.H, a.W, a.max_cand, a.ncont, a.starts, a.npts);
+  hipLaunchKernelGGL(trace_offsets_kernel, dim3(N), dim3(64), 0, s, a.max_cand, a.ncont, a.npts, a.poff, a.pool_cap, a.status);
+  hipLaunchKernelGGL(trace_store_kernel, gl, dim3(64), 0, s, a.bitmap, a.H, a.W, a.max_cand, a.ncont, a.starts, a.npts, a.poff,
+                     a.pool, a.pool_cap);
+  hipLaunchKernelGGL(border_box_kernel, dim3(a.max_cand, N), dim3(64), 0, s, a);
+  hipLaunchKernelGGL(boxes_compact_kernel, dim3(N), dim3(64), 0, s, a, out_boxes, cap, out_n);
+}
+
+}  // namespace ocr

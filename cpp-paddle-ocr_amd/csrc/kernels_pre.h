@@ -1,0 +1,33 @@
+// Host-visible launch interface of kernels_pre.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ocr {
+
+struct DetPreArgs {
+  const uint8_t* src;       // N images, each src_image_bytes apart, rows src_stride apart (BGR u8)
+  size_t src_image_bytes, src_stride;
+  int N, sh, sw, dh, dw;
+  const float* lut;         // [3][256] normalised value per channel/byte
+  float* out;               // [N][dh][dw][3] f32
+  uint8_t* resized;         // [N][dh][dw][3] u8 or null
+};
+void launch_det_pre(const DetPreArgs& a, hipStream_t s);
+
+// One text line: an ROI (x,y,w,h) of a device-resident BGR image, resized to (imgH x resize_w),
+// written (right-padded to imgW) into slot `slot` of the batch tensor.
+struct LineDesc {
+  const uint8_t* img;
+  size_t stride;
+  int x, y, w, h;
+  int resize_w;
+  int slot;
+};
+void launch_line_pre(const LineDesc* lines, int nlines, int imgH, int imgW, const float* lut, bool pad_after_norm,
+                     float* out, hipStream_t s);
+void launch_rotate180(uint8_t* img, size_t stride, int x0, int y0, int w, int h, hipStream_t s);
+void launch_ctc(const int* amax, const float* pmax, int nlines, int T, int max_len, int* ids, int* lens, float* scores,
+                hipStream_t s);
+
+}  // namespace ocr

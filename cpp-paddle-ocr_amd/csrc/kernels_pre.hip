@@ -1,0 +1,180 @@
+// Image-side kernels: OpenCV-semantics bilinear resize (8-bit fixed point), normalisation via a
+// 3x256 LUT, ROI crops, in-place 180-degree rotation, greedy CTC collapse.
+// Replaces /root/reference/src/preprocess_op.cpp:40-137 (+ cv::resize / convertTo / copyMakeBorder),
+// the ROI views and cv::rotate of /root/reference/src/ocr_worker.cpp:245-281 and the CTC loop of
+// /root/reference/src/ocr_rec.cpp:97-128.  Pure HBM-bound byte work: one thread per output pixel,
+// coalesced along x, no LDS.
+#include <hip/hip_runtime.h>
+
+#include "kernels_pre.h"
+
+namespace ocr {
+
+// cv::resize INTER_LINEAR coefficient for destination index d: source index, a0, a1.
+__device__ __forceinline__ void lin_coef_x(int d, int ssize, double scale, int& s, int& a0, int& a1, bool& edge) {
+  float f = (float)((d + 0.5) * scale - 0.5);
+  s = (int)floorf(f);
+  f -= s;
+  edge = false;
+  if (s < 0) { f = 0; s = 0; }
+  if (s + 1 >= ssize) {
+    edge = true;  // dx >= xmax: HResize takes S[sx]*ONE
+    if (s >= ssize - 1) { f = 0; s = ssize - 1; }
+  }
+  a0 = __float2int_rn((1.f - f) * 2048.f);
+  a1 = __float2int_rn(f * 2048.f);
+  a0 = min(32767, max(-32768, a0));
+  a1 = min(32767, max(-32768, a1));
+}
+__device__ __forceinline__ void lin_coef_y(int d, double scale, int& s, int& b0, int& b1) {
+  float f = (float)((d + 0.5) * scale - 0.5);
+  s = (int)floorf(f);
+  f -= s;
+  b0 = __float2int_rn((1.f - f) * 2048.f);
+  b1 = __float2int_rn(f * 2048.f);
+  b0 = min(32767, max(-32768, b0));
+  b1 = min(32767, max(-32768, b1));
+}
+__device__ __forceinline__ int clipi(int v, int lo, int hi) { return v >= lo ? (v < hi ? v : hi - 1) : lo; }
+
+// one resized BGR pixel of an (sh x sw) source at (dy, dx) of a (dh x dw) destination
+__device__ __forceinline__ void resize_px(const uint8_t* __restrict__ src, size_t stride, int sh, int sw, int dh, int dw,
+                                          int dy, int dx, uint8_t out[3]) {
+  if (sh == dh && sw == dw) {
+    const uint8_t* p = src + (size_t)dy * stride + dx * 3;
+    out[0] = p[0]; out[1] = p[1]; out[2] = p[2];
+    return;
+  }
+  const double inv_x = (double)dw / sw, inv_y = (double)dh / sh;
+  const double scale_x = 1. / inv_x, scale_y = 1. / inv_y;
+  if (sw == 2 * dw && sh == 2 * dh) {  // exact 2x2 decimation: INTER_LINEAR silently becomes INTER_AREA
+    const uint8_t* s0 = src + (size_t)(2 * dy) * stride + (2 * dx) * 3;
+    const uint8_t* s1 = s0 + stride;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) out[c] = (uint8_t)((s0[c] + s0[3 + c] + s1[c] + s1[3 + c] + 2) >> 2);
+    return;
+  }
+  int sx, a0, a1, sy, b0, b1;
+  bool edge;
+  lin_coef_x(dx, sw, scale_x, sx, a0, a1, edge);
+  lin_coef_y(dy, scale_y, sy, b0, b1);
+  const int y0 = clipi(sy, 0, sh), y1 = clipi(sy + 1, 0, sh);
+  const uint8_t* r0 = src + (size_t)y0 * stride + sx * 3;
+  const uint8_t* r1 = src + (size_t)y1 * stride + sx * 3;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    int S0, S1;
+    if (!edge) {
+      S0 = r0[c] * a0 + r0[3 + c] * a1;
+      S1 = r1[c] * a0 + r1[3 + c] * a1;
+    } else {
+      S0 = r0[c] * 2048;
+      S1 = r1[c] * 2048;
+    }
+    const int v = (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2;
+    out[c] = (uint8_t)min(255, max(0, v));
+  }
+}
+
+// det: N same-size images -> resized u8 (tap) + normalised f32 NHWC
+__global__ void __launch_bounds__(256) det_pre_kernel(const DetPreArgs a) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  const long per = (long)a.dh * a.dw;
+  if (t >= per * a.N) return;
+  const int n = (int)(t / per);
+  const int r = (int)(t - (long)n * per);
+  const int dy = r / a.dw, dx = r - dy * a.dw;
+  uint8_t px[3];
+  resize_px(a.src + (size_t)n * a.src_image_bytes, a.src_stride, a.sh, a.sw, a.dh, a.dw, dy, dx, px);
+  float* o = a.out + t * 3;
+  o[0] = a.lut[px[0]];
+  o[1] = a.lut[256 + px[1]];
+  o[2] = a.lut[512 + px[2]];
+  if (a.resized) {
+    uint8_t* u = a.resized + t * 3;
+    u[0] = px[0]; u[1] = px[1]; u[2] = px[2];
+  }
+}
+void launch_det_pre(const DetPreArgs& a, hipStream_t s) {
+  const long total = (long)a.N * a.dh * a.dw;
+  hipLaunchKernelGGL(det_pre_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+}
+
+// rec / cls: one text line = ROI of a device image -> [imgH][imgW][3] f32 slot of the batch tensor
+__global__ void __launch_bounds__(256) line_pre_kernel(const LineDesc* __restrict__ lines, int nlines, int imgH, int imgW,
+                                                       const float* __restrict__ lut, float pad_value,
+                                                       float* __restrict__ out) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  const long per = (long)imgH * imgW;
+  if (t >= per * nlines) return;
+  const int li = (int)(t / per);
+  const int r = (int)(t - (long)li * per);
+  const int dy = r / imgW, dx = r - dy * imgW;
+  const LineDesc L = lines[li];
+  float* o = out + ((size_t)L.slot * per + r) * 3;
+  if (dx >= L.resize_w) {
+    // rec: u8 zero pad BEFORE normalise (lut[0]); cls: 0.0f AFTER normalise -> pad_value selects
+    if (pad_value == 0.0f) { o[0] = 0.f; o[1] = 0.f; o[2] = 0.f; }
+    else { o[0] = lut[0]; o[1] = lut[256]; o[2] = lut[512]; }
+    return;
+  }
+  uint8_t px[3];
+  resize_px(L.img + (size_t)L.y * L.stride + (size_t)L.x * 3, L.stride, L.h, L.w, imgH, L.resize_w, dy, dx, px);
+  o[0] = lut[px[0]];
+  o[1] = lut[256 + px[1]];
+  o[2] = lut[512 + px[2]];
+}
+void launch_line_pre(const LineDesc* lines, int nlines, int imgH, int imgW, const float* lut, bool pad_after_norm,
+                     float* out, hipStream_t s) {
+  const long total = (long)nlines * imgH * imgW;
+  if (total == 0) return;
+  hipLaunchKernelGGL(line_pre_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, lines, nlines, imgH, imgW, lut,
+                     pad_after_norm ? 0.0f : 1.0f, out);
+}
+
+// cv::rotate(roi, roi, ROTATE_180) in place: pixel i <-> total-1-i
+__global__ void __launch_bounds__(256) rotate180_kernel(uint8_t* img, size_t stride, int x0, int y0, int w, int h) {
+  const long total = (long)w * h;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total / 2) return;
+  const long j = total - 1 - i;
+  uint8_t* a = img + (size_t)(y0 + i / w) * stride + (size_t)(x0 + i % w) * 3;
+  uint8_t* b = img + (size_t)(y0 + j / w) * stride + (size_t)(x0 + j % w) * 3;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) { const uint8_t t = a[c]; a[c] = b[c]; b[c] = t; }
+}
+void launch_rotate180(uint8_t* img, size_t stride, int x0, int y0, int w, int h, hipStream_t s) {
+  const long half = ((long)w * h) / 2;
+  if (half <= 0) return;
+  hipLaunchKernelGGL(rotate180_kernel, dim3((unsigned)((half + 255) / 256)), dim3(256), 0, s, img, stride, x0, y0, w, h);
+}
+
+// greedy CTC collapse, one thread per line (sequential over T: the score sum order of the reference)
+__global__ void __launch_bounds__(64) ctc_kernel(const int* __restrict__ amax, const float* __restrict__ pmax, int nlines,
+                                                 int T, int max_len, int* __restrict__ ids, int* __restrict__ lens,
+                                                 float* __restrict__ scores) {
+  const int li = blockIdx.x * 64 + threadIdx.x;
+  if (li >= nlines) return;
+  const int* am = amax + (long)li * T;
+  const float* pm = pmax + (long)li * T;
+  int last = 0, count = 0;
+  float s = 0.f;
+  for (int n = 0; n < T; ++n) {
+    const int idx = am[n];
+    if (idx > 0 && !(n > 0 && idx == last)) {
+      s += pm[n];
+      if (count < max_len) ids[(long)li * max_len + count] = idx;
+      count += 1;
+    }
+    last = idx;
+  }
+  lens[li] = count;
+  scores[li] = count > 0 ? s / (float)count : 0.f;
+}
+void launch_ctc(const int* amax, const float* pmax, int nlines, int T, int max_len, int* ids, int* lens, float* scores,
+                hipStream_t s) {
+  if (nlines <= 0) return;
+  hipLaunchKernelGGL(ctc_kernel, dim3((nlines + 63) / 64), dim3(64), 0, s, amax, pmax, nlines, T, max_len, ids, lens, scores);
+}
+
+}  // namespace ocr

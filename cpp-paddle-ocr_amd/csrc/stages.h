@@ -1,0 +1,163 @@
+// Stage objects behind the C-ABI: detector, classifier, recognizer.  Each owns one HIP stream, its
+// network and its device buffers ("one handle per host thread").
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/ocr_hip.h"
+#include "kernels_post.h"
+#include "kernels_pre.h"
+#include "net.h"
+
+namespace ocr {
+
+// growable device buffer
+template <class T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t cap = 0;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  bool ensure(size_t n, std::string& err) {
+    if (n <= cap) return true;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    hipError_t e = hipMalloc(&p, n * sizeof(T));
+    if (e != hipSuccess) { err = std::string("hipMalloc: ") + hipGetErrorString(e); return false; }
+    cap = n;
+    return true;
+  }
+};
+
+struct StageTimer {  // pre / infer / post in ms from HIP events on the stage's stream
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  bool init(std::string& err);
+  ~StageTimer();
+  void mark(int i, hipStream_t s) { (void)hipEventRecord(ev[i], s); }
+  void read(double times[3]);
+};
+
+struct DetConfig {
+  std::string model_dir, limit_type = "max", score_mode = "fast", precision = "fp32";
+  int device = 0, limit_side_len = 512, use_dilation = 0, max_batch = 1;
+  double thresh = 0.2, box_thresh = 0.4, unclip_ratio = 1.8;
+};
+
+class DetStage {
+ public:
+  ~DetStage();
+  bool create(const DetConfig& cfg, std::string& err, int& code);
+  // imgs: `count` same-size host images.  boxes [count][cap][8], n [count].
+  int run(const ocr_img* imgs, int count, int32_t* boxes, int cap, int* n, double times[3], std::string& err);
+  // the same on images that already sit in device memory (packed BGR rows, one image every img_bytes)
+  int run_device(const uint8_t* dev_imgs, size_t img_bytes, size_t stride, int rows, int cols, int count, int32_t* boxes,
+                 int cap, int* n, double times[3], std::string& err);
+  int post_only(const float* prob, int rows, int cols, int src_rows, int src_cols, int32_t* boxes, int cap, int* n,
+                std::string& err);
+  // device-resident copy of the last uploaded images (for the fused pipeline)
+  const uint8_t* dev_images() const { return src_.p; }
+  size_t dev_image_bytes() const { return (size_t)src_rows_ * src_cols_ * 3; }
+  hipStream_t stream() const { return stream_; }
+  Net& net() { return net_; }
+  int last_count = 0, last_h = 0, last_w = 0;
+  const float* prob_dev() const { return net_.tensor_ptr(net_.output_tid()); }
+  const uint8_t* bitmap_dev() const { return cfg_.use_dilation ? bitmap2_.p : bitmap_.p; }
+  const uint8_t* resized_dev() const { return resized_.p; }
+  const DetConfig& cfg() const { return cfg_; }
+  static void resize_shape(int h, int w, const std::string& limit_type, int limit_side_len, int& rh, int& rw,
+                           float& ratio_h, float& ratio_w);
+
+ private:
+  bool ensure_post(int count, int H, int W, std::string& err);
+  int run_post(int count, int H, int W, const float* prob, float ratio_h, float ratio_w, int src_h, int src_w,
+               int32_t* boxes, int cap, int* n, std::string& err);
+  DetConfig cfg_;
+  Net net_;
+  hipStream_t stream_ = nullptr;
+  StageTimer timer_;
+  DevBuf<float> lut_, x_, prob_in_;
+  DevBuf<uint8_t> src_, resized_, bitmap_, bitmap2_, touch_;
+  DevBuf<int> labels_, ncont_all_, ncont_, starts_, npts_, poff_, iscratch_, cand_boxes_, cand_valid_, status_, out_boxes_,
+      out_n_;
+  DevBuf<unsigned long long> pool_;
+  int src_rows_ = 0, src_cols_ = 0;
+  int ithresh_ = 0;
+  int pool_cap_ = 0;
+  int bm_n_ = 0, bm_h_ = 0, bm_w_ = 0;
+};
+
+struct LineSrc {  // a text-line image living in device memory
+  const uint8_t* img;
+  size_t stride;
+  int x, y, w, h;
+};
+
+struct RecConfig {
+  std::string model_dir, label_path, precision = "fp32";
+  int device = 0, batch_num = 16, img_h = 28, img_w = 192;
+};
+
+class RecStage {
+ public:
+  ~RecStage();
+  bool create(const RecConfig& cfg, std::string& err, int& code);
+  int run(const ocr_img* imgs, int n, int32_t* ids, int max_len, int* lens, float* scores, double times[3],
+          std::string& err);
+  // lines already on the device (the stream must be ordered after whatever produced them)
+  int run_lines(const std::vector<LineSrc>& lines, int32_t* ids, int max_len, int* lens, float* scores, std::string& err);
+  const std::vector<std::string>& labels() const { return labels_; }
+  hipStream_t stream() const { return stream_; }
+  Net& net() { return net_; }
+  // per-step taps of the last run, in input order: T per line, amax/pmax concatenated
+  std::vector<int> tap_T, tap_off;
+  std::vector<int> tap_amax;
+  std::vector<float> tap_pmax;
+
+ private:
+  RecConfig cfg_;
+  Net net_;
+  hipStream_t stream_ = nullptr;
+  StageTimer timer_;
+  std::vector<std::string> labels_;
+  DevBuf<float> lut_, x_, pmax_, scores_;
+  DevBuf<int> amax_, ids_, lens_;
+  DevBuf<uint8_t> staging_;
+  DevBuf<LineDesc> descs_;
+};
+
+struct ClsConfig {
+  std::string model_dir, precision = "fp32";
+  int device = 0, batch_num = 8;
+  double thresh = 0.98;
+};
+
+class ClsStage {
+ public:
+  ~ClsStage();
+  bool create(const ClsConfig& cfg, std::string& err, int& code);
+  int run(const ocr_img* imgs, int n, int* labels, float* scores, double times[3], std::string& err);
+  int run_lines(const std::vector<LineSrc>& lines, int* labels, float* scores, std::string& err);
+  hipStream_t stream() const { return stream_; }
+  std::vector<float> tap_probs;  // [n][2] of the last run
+
+ private:
+  ClsConfig cfg_;
+  Net net_;
+  hipStream_t stream_ = nullptr;
+  StageTimer timer_;
+  DevBuf<float> lut_, x_, pmax_, probs_;
+  DevBuf<int> amax_;
+  DevBuf<uint8_t> staging_;
+  DevBuf<LineDesc> descs_;
+};
+
+// Uploads ROI views into one packed staging buffer and describes them as device lines.
+bool upload_lines(const ocr_img* imgs, int n, DevBuf<uint8_t>& staging, std::vector<LineSrc>& out, hipStream_t s,
+                  std::string& err);
+
+// 3x256 normalisation LUT: Normalize::Run per byte value (convertTo 1/255, then scale/shift)
+std::vector<float> make_norm_lut(const float mean[3], const float scale[3]);
+
+}  // namespace ocr

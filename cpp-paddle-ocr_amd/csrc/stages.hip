@@ -1,0 +1,443 @@
+#include "stages.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <fstream>
+#include <map>
+
+#include "capi_common.h"
+
+namespace ocr {
+
+#define ST_HIP(expr)                                                              \
+  do {                                                                            \
+    hipError_t _e = (expr);                                                       \
+    if (_e != hipSuccess) {                                                       \
+      err = std::string(#expr) + ": " + hipGetErrorString(_e);                    \
+      return OCR_ERR_DEVICE;                                                      \
+    }                                                                             \
+  } while (0)
+
+bool StageTimer::init(std::string& err) {
+  for (int i = 0; i < 4; ++i)
+    if (hipEventCreate(&ev[i]) != hipSuccess) { err = "hipEventCreate failed"; return false; }
+  return true;
+}
+StageTimer::~StageTimer() {
+  for (int i = 0; i < 4; ++i)
+    if (ev[i]) (void)hipEventDestroy(ev[i]);
+}
+void StageTimer::read(double times[3]) {
+  if (!times) return;
+  for (int i = 0; i < 3; ++i) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, ev[i], ev[i + 1]) != hipSuccess) ms = 0.f;
+    times[i] = ms;
+  }
+}
+
+std::vector<float> make_norm_lut(const float mean[3], const float scale[3]) {
+  // Normalize::Run (/root/reference/src/preprocess_op.cpp:40-55): convertTo(CV_32FC3, 1/255), then per
+  // channel convertTo(alpha = scale, beta = -mean*scale); both are x*a+b in float.
+  std::vector<float> lut(3 * 256);
+  const float e = (float)(1.0 / 255.0);
+  for (int c = 0; c < 3; ++c) {
+    const float a = (float)(1.0 * (double)scale[c]);
+    const float b = (float)((0.0 - (double)mean[c]) * (double)scale[c]);
+    for (int v = 0; v < 256; ++v) lut[c * 256 + v] = fmaf((float)v * e, a, b);
+  }
+  return lut;
+}
+
+bool upload_lines(const ocr_img* imgs, int n, DevBuf<uint8_t>& staging, std::vector<LineSrc>& out, hipStream_t s,
+                  std::string& err) {
+  size_t total = 0;
+  for (int i = 0; i < n; ++i) {
+    if (!imgs[i].data || imgs[i].rows <= 0 || imgs[i].cols <= 0) { err = "empty text-line image"; return false; }
+    total += ((size_t)imgs[i].rows * imgs[i].cols * 3 + 15) & ~(size_t)15;
+  }
+  if (!staging.ensure(total, err)) return false;
+  size_t off = 0;
+  out.resize(n);
+  for (int i = 0; i < n; ++i) {
+    const size_t row = (size_t)imgs[i].cols * 3;
+    const size_t stride = imgs[i].row_stride ? imgs[i].row_stride : row;
+    if (hipMemcpy2DAsync(staging.p + off, row, imgs[i].data, stride, row, imgs[i].rows, hipMemcpyHostToDevice, s) !=
+        hipSuccess) { err = "hipMemcpy2DAsync failed"; return false; }
+    out[i] = LineSrc{staging.p + off, row, 0, 0, imgs[i].cols, imgs[i].rows};
+    off += ((size_t)imgs[i].rows * row + 15) & ~(size_t)15;
+  }
+  return true;
+}
+
+// ================================================================= detector
+DetStage::~DetStage() {
+  if (stream_) (void)hipStreamDestroy(stream_);
+}
+
+void DetStage::resize_shape(int h, int w, const std::string& limit_type, int limit_side_len, int& rh, int& rw,
+                            float& ratio_h, float& ratio_w) {
+  // ResizeImgType0::Run, /root/reference/src/preprocess_op.cpp:57-93
+  float ratio = 1.f;
+  if (limit_type == "min") {
+    const int min_wh = std::min(h, w);
+    if (min_wh < limit_side_len) ratio = h < w ? float(limit_side_len) / float(h) : float(limit_side_len) / float(w);
+  } else {
+    const int max_wh = std::max(h, w);
+    if (max_wh > limit_side_len) ratio = h > w ? float(limit_side_len) / float(h) : float(limit_side_len) / float(w);
+  }
+  int resize_h = int(float(h) * ratio);
+  int resize_w = int(float(w) * ratio);
+  resize_h = std::max(int(round(float(resize_h) / 32) * 32), 32);
+  resize_w = std::max(int(round(float(resize_w) / 32) * 32), 32);
+  rh = resize_h;
+  rw = resize_w;
+  ratio_h = float(resize_h) / float(h);
+  ratio_w = float(resize_w) / float(w);
+}
+
+bool DetStage::create(const DetConfig& cfg, std::string& err, int& code) {
+  cfg_ = cfg;
+  code = OCR_ERR_ARG;
+  if (cfg.precision != "fp32") { err = "precision '" + cfg.precision + "' is not implemented (fp32 only)"; return false; }
+  if (cfg.score_mode != "fast") { err = "det_db_score_mode '" + cfg.score_mode + "' is not implemented on the device path (fast only)"; return false; }
+  if (cfg.limit_type != "max" && cfg.limit_type != "min") { err = "limit_type must be max or min"; return false; }
+  if (cfg.max_batch < 1) { err = "max_batch must be >= 1"; return false; }
+  code = ocr_rt_init(cfg.device);
+  if (code) { err = ocr_last_error(); return false; }
+  WeightMap w;
+  code = OCR_ERR_MODEL;
+  if (!load_model_dir(cfg.model_dir, nullptr, w, err)) return false;
+  if (!net_.load(embedded_plan("det"), w, err)) return false;
+  code = OCR_ERR_DEVICE;
+  if (hipStreamCreate(&stream_) != hipSuccess) { err = "hipStreamCreate failed"; return false; }
+  if (!timer_.init(err)) return false;
+  const float mean[3] = {0.485f, 0.456f, 0.406f};                      // ocr_det.h:121
+  const float scale[3] = {1 / 0.229f, 1 / 0.224f, 1 / 0.225f};        // ocr_det.h:122
+  const auto lut = make_norm_lut(mean, scale);
+  if (!lut_.ensure(lut.size(), err)) return false;
+  if (hipMemcpy(lut_.p, lut.data(), lut.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { err = "lut upload failed"; return false; }
+  ithresh_ = (int)std::floor(cfg.thresh * 255);  // cv::threshold on 8U floors the threshold (ocr_det.cpp:151-154)
+  code = OCR_OK;
+  return true;
+}
+
+bool DetStage::ensure_post(int count, int H, int W, std::string& err) {
+  const size_t px = (size_t)count * H * W;
+  const int max_cand = 1000;
+  pool_cap_ = std::max(1 << 16, (H * W) / 2);
+  return labels_.ensure(px, err) && touch_.ensure(px, err) && ncont_all_.ensure(count, err) && ncont_.ensure(count, err) &&
+         starts_.ensure((size_t)count * max_cand, err) && npts_.ensure((size_t)count * max_cand, err) &&
+         poff_.ensure((size_t)count * max_cand, err) && pool_.ensure((size_t)count * pool_cap_, err) &&
+         iscratch_.ensure((size_t)count * pool_cap_ * 4, err) && cand_boxes_.ensure((size_t)count * max_cand * 8, err) &&
+         cand_valid_.ensure((size_t)count * max_cand, err) && status_.ensure(1, err) &&
+         (cfg_.use_dilation ? bitmap2_.ensure(px, err) : true);
+}
+
+int DetStage::run_post(int count, int H, int W, const float* prob, float ratio_h, float ratio_w, int src_h, int src_w,
+                       int32_t* boxes, int cap, int* n, std::string& err) {
+  if (!ensure_post(count, H, W, err)) return OCR_ERR_DEVICE;
+  if (!out_boxes_.ensure((size_t)count * cap * 8, err) || !out_n_.ensure(count, err)) return OCR_ERR_DEVICE;
+  ST_HIP(hipMemsetAsync(status_.p, 0, sizeof(int), stream_));
+  const uint8_t* bm = bitmap_.p;
+  if (cfg_.use_dilation) {
+    launch_dilate2(bitmap_.p, bitmap2_.p, count, H, W, stream_);
+    bm = bitmap2_.p;
+  }
+  PostArgs a{};
+  a.bitmap = bm; a.pred = prob; a.labels = labels_.p; a.touch = touch_.p; a.ncont_all = ncont_all_.p; a.ncont = ncont_.p;
+  a.starts = starts_.p; a.npts = npts_.p; a.poff = poff_.p; a.pool = pool_.p; a.iscratch = iscratch_.p;
+  a.cand_boxes = cand_boxes_.p; a.cand_valid = cand_valid_.p; a.status = status_.p; a.pool_cap = pool_cap_;
+  a.H = H; a.W = W; a.max_cand = 1000;
+  a.box_thresh = (float)cfg_.box_thresh; a.unclip_ratio = (float)cfg_.unclip_ratio;
+  a.ratio_h = ratio_h; a.ratio_w = ratio_w; a.src_h = src_h; a.src_w = src_w;
+  launch_post(a, count, out_boxes_.p, cap, out_n_.p, stream_);
+  int status = 0;
+  ST_HIP(hipMemcpyAsync(n, out_n_.p, count * sizeof(int), hipMemcpyDeviceToHost, stream_));
+  ST_HIP(hipMemcpyAsync(boxes, out_boxes_.p, (size_t)count * cap * 8 * sizeof(int), hipMemcpyDeviceToHost, stream_));
+  ST_HIP(hipMemcpyAsync(&status, status_.p, sizeof(int), hipMemcpyDeviceToHost, stream_));
+  timer_.mark(3, stream_);
+  ST_HIP(hipStreamSynchronize(stream_));
+  if (status) {
+    err = "det post-processing scratch exhausted (status " + std::to_string(status) + ")";
+    return OCR_ERR_CAPACITY;
+  }
+  for (int i = 0; i < count; ++i)
+    if (n[i] > cap) { err = "more boxes than the caller's capacity"; return OCR_ERR_CAPACITY; }
+  return OCR_OK;
+}
+
+int DetStage::run(const ocr_img* imgs, int count, int32_t* boxes, int cap, int* n, double times[3], std::string& err) {
+  if (!imgs || count < 1 || !boxes || !n || cap < 1) { err = "bad argument"; return OCR_ERR_ARG; }
+  const int rows = imgs[0].rows, cols = imgs[0].cols;
+  for (int i = 0; i < count; ++i) {
+    if (!imgs[i].data || imgs[i].rows <= 0 || imgs[i].cols <= 0) { err = "Empty image data provided"; return OCR_ERR_ARG; }
+    if (imgs[i].rows != rows || imgs[i].cols != cols) { err = "ocr_det_run_batch needs images of one size"; return OCR_ERR_ARG; }
+  }
+  ST_HIP(hipSetDevice(cfg_.device));
+  const size_t row = (size_t)cols * 3, img_bytes = row * rows;
+  if (!src_.ensure(img_bytes * count, err)) return OCR_ERR_DEVICE;
+  timer_.mark(0, stream_);
+  for (int i = 0; i < count; ++i) {
+    const size_t stride = imgs[i].row_stride ? imgs[i].row_stride : row;
+    ST_HIP(hipMemcpy2DAsync(src_.p + img_bytes * i, row, imgs[i].data, stride, row, rows, hipMemcpyHostToDevice, stream_));
+  }
+  src_rows_ = rows;
+  src_cols_ = cols;
+  return run_device(src_.p, img_bytes, row, rows, cols, count, boxes, cap, n, times, err);
+}
+
+int DetStage::run_device(const uint8_t* dev_imgs, size_t img_bytes, size_t stride, int rows, int cols, int count,
+                         int32_t* boxes, int cap, int* n, double times[3], std::string& err) {
+  ST_HIP(hipSetDevice(cfg_.device));
+  int rh, rw;
+  float ratio_h, ratio_w;
+  resize_shape(rows, cols, cfg_.limit_type, cfg_.limit_side_len, rh, rw, ratio_h, ratio_w);
+  const size_t px = (size_t)count * rh * rw;
+  const uint8_t* old_bm = bitmap_.p;
+  if (!x_.ensure(px * 3, err) || !resized_.ensure(px * 3, err) || !bitmap_.ensure(px, err)) return OCR_ERR_DEVICE;
+  if (dev_imgs != src_.p) timer_.mark(0, stream_);
+  DetPreArgs pa{};
+  pa.src = dev_imgs; pa.src_image_bytes = img_bytes; pa.src_stride = stride;
+  pa.N = count; pa.sh = rows; pa.sw = cols; pa.dh = rh; pa.dw = rw; pa.lut = lut_.p; pa.out = x_.p; pa.resized = resized_.p;
+  launch_det_pre(pa, stream_);
+  timer_.mark(1, stream_);
+  if (bitmap_.p != old_bm || bm_n_ == 0) { net_.set_det_bitmap(bitmap_.p, ithresh_); bm_n_ = 1; }
+  if (!net_.run(x_.p, count, rh, rw, stream_, err)) return OCR_ERR_DEVICE;
+  timer_.mark(2, stream_);
+  last_count = count; last_h = rh; last_w = rw;
+  const int rc = run_post(count, rh, rw, prob_dev(), ratio_h, ratio_w, rows, cols, boxes, cap, n, err);
+  net_.collect_timings();
+  timer_.read(times);
+  return rc;
+}
+
+int DetStage::post_only(const float* prob, int rows, int cols, int src_rows, int src_cols, int32_t* boxes, int cap, int* n,
+                        std::string& err) {
+  if (!prob || rows <= 0 || cols <= 0 || !boxes || !n || cap < 1) { err = "bad argument"; return OCR_ERR_ARG; }
+  ST_HIP(hipSetDevice(cfg_.device));
+  const size_t px = (size_t)rows * cols;
+  if (!prob_in_.ensure(px, err) || !bitmap_.ensure(px, err)) return OCR_ERR_DEVICE;
+  bm_n_ = 0;  // the fused-bitmap pointer may have moved: re-arm on the next network run
+  ST_HIP(hipMemcpyAsync(prob_in_.p, prob, px * sizeof(float), hipMemcpyHostToDevice, stream_));
+  launch_bitmap(prob_in_.p, bitmap_.p, (long)px, ithresh_, stream_);
+  last_count = 1; last_h = rows; last_w = cols;
+  const float ratio_h = float(rows) / float(src_rows), ratio_w = float(cols) / float(src_cols);
+  return run_post(1, rows, cols, prob_in_.p, ratio_h, ratio_w, src_rows, src_cols, boxes, cap, n, err);
+}
+
+// ================================================================= recognizer
+RecStage::~RecStage() {
+  if (stream_) (void)hipStreamDestroy(stream_);
+}
+
+bool RecStage::create(const RecConfig& cfg, std::string& err, int& code) {
+  cfg_ = cfg;
+  code = OCR_ERR_ARG;
+  if (cfg.precision != "fp32") { err = "precision '" + cfg.precision + "' is not implemented (fp32 only)"; return false; }
+  if (cfg.batch_num < 1 || cfg.img_h < 1 || cfg.img_w < 1) { err = "bad rec shape"; return false; }
+  code = ocr_rt_init(cfg.device);
+  if (code) { err = ocr_last_error(); return false; }
+  code = OCR_ERR_MODEL;
+  // Utility::ReadDict + "#" / " " (ocr_rec.h:82-84)
+  std::ifstream in(cfg.label_path);
+  if (!in) { err = "no such label file: " + cfg.label_path; return false; }
+  labels_.clear();
+  labels_.push_back("#");
+  for (std::string line; std::getline(in, line);) labels_.push_back(line);
+  labels_.push_back(" ");
+  WeightMap w;
+  if (!load_model_dir(cfg.model_dir, nullptr, w, err)) return false;
+  if (!net_.load(embedded_plan("rec"), w, err)) return false;
+  code = OCR_ERR_DEVICE;
+  if (hipStreamCreate(&stream_) != hipSuccess) { err = "hipStreamCreate failed"; return false; }
+  if (!timer_.init(err)) return false;
+  const float mean[3] = {0.5f, 0.5f, 0.5f}, scale[3] = {1 / 0.5f, 1 / 0.5f, 1 / 0.5f};  // ocr_rec.h:108-109
+  const auto lut = make_norm_lut(mean, scale);
+  if (!lut_.ensure(lut.size(), err)) return false;
+  if (hipMemcpy(lut_.p, lut.data(), lut.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { err = "lut upload failed"; return false; }
+  code = OCR_OK;
+  return true;
+}
+
+int RecStage::run(const ocr_img* imgs, int n, int32_t* ids, int max_len, int* lens, float* scores, double times[3],
+                  std::string& err) {
+  if (n < 0 || (n > 0 && (!imgs || !ids || !lens || !scores)) || max_len < 1) { err = "bad argument"; return OCR_ERR_ARG; }
+  if (times) times[0] = times[1] = times[2] = 0;
+  if (n == 0) return OCR_OK;
+  ST_HIP(hipSetDevice(cfg_.device));
+  timer_.mark(0, stream_);
+  std::vector<LineSrc> lines;
+  if (!upload_lines(imgs, n, staging_, lines, stream_, err)) return OCR_ERR_DEVICE;
+  timer_.mark(1, stream_);
+  const int rc = run_lines(lines, ids, max_len, lens, scores, err);
+  timer_.mark(2, stream_);
+  timer_.mark(3, stream_);
+  (void)hipStreamSynchronize(stream_);
+  timer_.read(times);
+  return rc;
+}
+
+int RecStage::run_lines(const std::vector<LineSrc>& lines, int32_t* ids, int max_len, int* lens, float* scores,
+                        std::string& err) {
+  const int n = (int)lines.size();
+  const int imgH = cfg_.img_h, imgW = cfg_.img_w;
+  // CRNNRecognizer::Run batching, /root/reference/src/ocr_rec.cpp:34-57
+  std::vector<float> width_list(n);
+  for (int i = 0; i < n; ++i) width_list[i] = float(lines[i].w) / lines[i].h;
+  std::vector<size_t> indices(n);
+  for (int i = 0; i < n; ++i) indices[i] = i;
+  std::sort(indices.begin(), indices.end(), [&](size_t a, size_t b) { return width_list[a] < width_list[b]; });
+  struct Item { int line; int resize_w; };
+  std::map<int, std::vector<Item>> groups;  // tensor width -> lines (order inside a width is irrelevant)
+  for (int beg = 0; beg < n; beg += cfg_.batch_num) {
+    const int end = std::min(n, beg + cfg_.batch_num);
+    float max_wh_ratio = imgW * 1.0 / imgH;
+    for (int ino = beg; ino < end; ++ino) {
+      const int h = lines[indices[ino]].h, w = lines[indices[ino]].w;
+      const float wh_ratio = w * 1.0 / h;
+      max_wh_ratio = std::max(max_wh_ratio, wh_ratio);
+    }
+    const int bw = int(imgH * max_wh_ratio);  // CrnnResizeImg: imgW = int(imgH * wh_ratio)
+    const int tensor_w = std::max(bw, imgW);
+    for (int ino = beg; ino < end; ++ino) {
+      const LineSrc& L = lines[indices[ino]];
+      const float ratio = float(L.w) / float(L.h);
+      const int resize_w = ceilf(imgH * ratio) > bw ? bw : int(ceilf(imgH * ratio));
+      groups[tensor_w].push_back({(int)indices[ino], resize_w});
+    }
+  }
+  tap_T.assign(n, 0);
+  tap_off.assign(n, 0);
+  tap_amax.clear();
+  tap_pmax.clear();
+  for (int i = 0; i < n; ++i) { lens[i] = 0; scores[i] = 0.f; }
+  std::vector<int> h_ids, h_lens, h_amax;
+  std::vector<float> h_scores, h_pmax;
+  for (auto& kv : groups) {
+    const int Wt = kv.first;
+    const int ng = (int)kv.second.size();
+    std::vector<LineDesc> d(ng);
+    for (int j = 0; j < ng; ++j) {
+      const LineSrc& L = lines[kv.second[j].line];
+      d[j] = LineDesc{L.img, L.stride, L.x, L.y, L.w, L.h, kv.second[j].resize_w, j};
+    }
+    if (!descs_.ensure(ng, err) || !x_.ensure((size_t)ng * imgH * Wt * 3, err)) return OCR_ERR_DEVICE;
+    ST_HIP(hipMemcpyAsync(descs_.p, d.data(), ng * sizeof(LineDesc), hipMemcpyHostToDevice, stream_));
+    launch_line_pre(descs_.p, ng, imgH, Wt, lut_.p, false, x_.p, stream_);
+    // head sinks must exist before the network binds its launches; T is known only after shape
+    // inference, so size them by the widest possible T = Wt (>= Wt/8)
+    const int* old_a = amax_.p;
+    const float* old_p = pmax_.p;
+    if (!amax_.ensure((size_t)ng * Wt, err) || !pmax_.ensure((size_t)ng * Wt, err)) return OCR_ERR_DEVICE;
+    if (amax_.p != old_a || pmax_.p != old_p || !old_a) net_.set_head_outputs(nullptr, amax_.p, pmax_.p);
+    if (!net_.run(x_.p, ng, imgH, Wt, stream_, err)) return OCR_ERR_DEVICE;
+    const TensorDesc& ot = net_.tensor(net_.output_tid());
+    if (ot.h != 1) { err = "rec_img_h does not reduce to a single row"; return OCR_ERR_ARG; }
+    if (ot.c != (int)labels_.size()) { err = "dictionary size does not match the CTC head"; return OCR_ERR_MODEL; }
+    const int T = ot.w;
+    if (!ids_.ensure((size_t)ng * max_len, err) || !lens_.ensure(ng, err) || !scores_.ensure(ng, err)) return OCR_ERR_DEVICE;
+    launch_ctc(amax_.p, pmax_.p, ng, T, max_len, ids_.p, lens_.p, scores_.p, stream_);
+    h_ids.resize((size_t)ng * max_len);
+    h_lens.resize(ng);
+    h_scores.resize(ng);
+    h_amax.resize((size_t)ng * T);
+    h_pmax.resize((size_t)ng * T);
+    ST_HIP(hipMemcpyAsync(h_ids.data(), ids_.p, h_ids.size() * sizeof(int), hipMemcpyDeviceToHost, stream_));
+    ST_HIP(hipMemcpyAsync(h_lens.data(), lens_.p, ng * sizeof(int), hipMemcpyDeviceToHost, stream_));
+    ST_HIP(hipMemcpyAsync(h_scores.data(), scores_.p, ng * sizeof(float), hipMemcpyDeviceToHost, stream_));
+    ST_HIP(hipMemcpyAsync(h_amax.data(), amax_.p, h_amax.size() * sizeof(int), hipMemcpyDeviceToHost, stream_));
+    ST_HIP(hipMemcpyAsync(h_pmax.data(), pmax_.p, h_pmax.size() * sizeof(float), hipMemcpyDeviceToHost, stream_));
+    ST_HIP(hipStreamSynchronize(stream_));
+    net_.collect_timings();
+    for (int j = 0; j < ng; ++j) {
+      const int li = kv.second[j].line;
+      if (h_lens[j] > max_len) { err = "text longer than max_len"; return OCR_ERR_CAPACITY; }
+      lens[li] = h_lens[j];
+      scores[li] = h_scores[j];
+      memcpy(ids + (size_t)li * max_len, h_ids.data() + (size_t)j * max_len, (size_t)h_lens[j] * sizeof(int));
+      tap_T[li] = T;
+      tap_off[li] = (int)tap_amax.size();
+      tap_amax.insert(tap_amax.end(), h_amax.begin() + (size_t)j * T, h_amax.begin() + (size_t)(j + 1) * T);
+      tap_pmax.insert(tap_pmax.end(), h_pmax.begin() + (size_t)j * T, h_pmax.begin() + (size_t)(j + 1) * T);
+    }
+  }
+  return OCR_OK;
+}
+
+// ================================================================= classifier
+ClsStage::~ClsStage() {
+  if (stream_) (void)hipStreamDestroy(stream_);
+}
+
+bool ClsStage::create(const ClsConfig& cfg, std::string& err, int& code) {
+  cfg_ = cfg;
+  code = OCR_ERR_ARG;
+  if (cfg.precision != "fp32") { err = "precision '" + cfg.precision + "' is not implemented (fp32 only)"; return false; }
+  if (cfg.batch_num < 1) { err = "cls_batch_num must be >= 1"; return false; }
+  code = ocr_rt_init(cfg.device);
+  if (code) { err = ocr_last_error(); return false; }
+  code = OCR_ERR_MODEL;
+  WeightMap w;
+  if (!load_model_dir(cfg.model_dir, nullptr, w, err)) return false;
+  if (!net_.load(embedded_plan("cls"), w, err)) return false;
+  code = OCR_ERR_DEVICE;
+  if (hipStreamCreate(&stream_) != hipSuccess) { err = "hipStreamCreate failed"; return false; }
+  if (!timer_.init(err)) return false;
+  const float mean[3] = {0.5f, 0.5f, 0.5f}, scale[3] = {1 / 0.5f, 1 / 0.5f, 1 / 0.5f};  // ocr_cls.h:93-94
+  const auto lut = make_norm_lut(mean, scale);
+  if (!lut_.ensure(lut.size(), err)) return false;
+  if (hipMemcpy(lut_.p, lut.data(), lut.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { err = "lut upload failed"; return false; }
+  code = OCR_OK;
+  return true;
+}
+
+int ClsStage::run(const ocr_img* imgs, int n, int* labels, float* scores, double times[3], std::string& err) {
+  if (n < 0 || (n > 0 && (!imgs || !labels || !scores))) { err = "bad argument"; return OCR_ERR_ARG; }
+  if (times) times[0] = times[1] = times[2] = 0;
+  if (n == 0) return OCR_OK;
+  ST_HIP(hipSetDevice(cfg_.device));
+  timer_.mark(0, stream_);
+  std::vector<LineSrc> lines;
+  if (!upload_lines(imgs, n, staging_, lines, stream_, err)) return OCR_ERR_DEVICE;
+  timer_.mark(1, stream_);
+  const int rc = run_lines(lines, labels, scores, err);
+  timer_.mark(2, stream_);
+  timer_.mark(3, stream_);
+  (void)hipStreamSynchronize(stream_);
+  timer_.read(times);
+  return rc;
+}
+
+int ClsStage::run_lines(const std::vector<LineSrc>& lines, int* labels, float* scores, std::string& err) {
+  // Classifier::Run, /root/reference/src/ocr_cls.cpp:23-106: fixed 3x48x192 input, so the reference's
+  // batches of cls_batch_num are independent rows of one launch here.
+  const int n = (int)lines.size();
+  const int imgH = 48, imgW = 192;
+  std::vector<LineDesc> d(n);
+  for (int i = 0; i < n; ++i) {
+    const LineSrc& L = lines[i];
+    const float ratio = float(L.w) / float(L.h);
+    const int resize_w = ceilf(imgH * ratio) > imgW ? imgW : int(ceilf(imgH * ratio));
+    d[i] = LineDesc{L.img, L.stride, L.x, L.y, L.w, L.h, resize_w, i};
+  }
+  if (!descs_.ensure(n, err) || !x_.ensure((size_t)n * imgH * imgW * 3, err)) return OCR_ERR_DEVICE;
+  ST_HIP(hipMemcpyAsync(descs_.p, d.data(), n * sizeof(LineDesc), hipMemcpyHostToDevice, stream_));
+  launch_line_pre(descs_.p, n, imgH, imgW, lut_.p, true, x_.p, stream_);
+  const int* old_a = amax_.p;
+  const float* old_p = pmax_.p;
+  const float* old_q = probs_.p;
+  if (!amax_.ensure(n, err) || !pmax_.ensure(n, err) || !probs_.ensure((size_t)n * 2, err)) return OCR_ERR_DEVICE;
+  if (amax_.p != old_a || pmax_.p != old_p || probs_.p != old_q || !old_a) net_.set_head_outputs(probs_.p, amax_.p, pmax_.p);
+  if (!net_.run(x_.p, n, imgH, imgW, stream_, err)) return OCR_ERR_DEVICE;
+  tap_probs.resize((size_t)n * 2);
+  ST_HIP(hipMemcpyAsync(labels, amax_.p, n * sizeof(int), hipMemcpyDeviceToHost, stream_));
+  ST_HIP(hipMemcpyAsync(scores, pmax_.p, n * sizeof(float), hipMemcpyDeviceToHost, stream_));
+  ST_HIP(hipMemcpyAsync(tap_probs.data(), probs_.p, tap_probs.size() * sizeof(float), hipMemcpyDeviceToHost, stream_));
+  ST_HIP(hipStreamSynchronize(stream_));
+  net_.collect_timings();
+  return OCR_OK;
+}
+
+}  // namespace ocr

@@ -86,3 +86,101 @@ class OracleNet:
             lib().oracle_net_destroy(self.h)
         except Exception:
             pass
+
+
+# ---------------------------------------------------------------------------------------------
+# image / post-processing oracle functions (oracle_img.cpp, oracle_post.cpp)
+# ---------------------------------------------------------------------------------------------
+def _p(a):
+    return a.ctypes.data
+
+
+def resize_u8c3(img, dh, dw):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    out = np.empty((dh, dw, 3), np.uint8)
+    lib().oracle_resize_u8c3(C.c_void_p(_p(img)), img.shape[0], img.shape[1], C.c_size_t(img.strides[0]),
+                             C.c_void_p(_p(out)), dh, dw)
+    return out
+
+
+def det_resize_shape(h, w, limit_type="max", limit_side_len=512):
+    rh, rw = C.c_int(), C.c_int()
+    fh, fw = C.c_float(), C.c_float()
+    lib().oracle_det_resize_shape(h, w, limit_type.encode(), limit_side_len, C.byref(rh), C.byref(rw), C.byref(fh),
+                                  C.byref(fw))
+    return rh.value, rw.value, fh.value, fw.value
+
+
+def det_preprocess(img, rh, rw):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    out = np.empty((rh, rw, 3), np.float32)
+    res = np.empty((rh, rw, 3), np.uint8)
+    lib().oracle_det_preprocess(C.c_void_p(_p(img)), img.shape[0], img.shape[1], C.c_size_t(img.strides[0]), rh, rw,
+                                C.c_void_p(_p(out)), C.c_void_p(_p(res)))
+    return out, res
+
+
+def bitmap(pred, thresh, use_dilation=False):
+    pred = np.ascontiguousarray(pred, dtype=np.float32)
+    bm = np.empty(pred.shape, np.uint8)
+    lib().oracle_bitmap(C.c_void_p(_p(pred)), pred.shape[0], pred.shape[1], C.c_double(thresh), int(use_dilation),
+                        C.c_void_p(_p(bm)))
+    return bm
+
+
+def det_post(pred, thresh, box_thresh, unclip_ratio, src_h, src_w, use_dilation=False, slow=False, cap=2000):
+    pred = np.ascontiguousarray(pred, dtype=np.float32)
+    boxes = np.zeros((cap, 8), np.int32)
+    n = lib().oracle_det_post(C.c_void_p(_p(pred)), pred.shape[0], pred.shape[1], C.c_double(thresh),
+                              C.c_double(box_thresh), C.c_double(unclip_ratio), int(use_dilation), int(slow), src_h,
+                              src_w, C.c_void_p(_p(boxes)), cap)
+    assert n <= cap
+    return boxes[:n].reshape(n, 4, 2).copy()
+
+
+def crop_rect(box, rows, cols):
+    b = np.ascontiguousarray(np.asarray(box, dtype=np.int32).reshape(8))
+    x, y, w, h = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    ok = lib().oracle_crop_rect(C.c_void_p(_p(b)), rows, cols, C.byref(x), C.byref(y), C.byref(w), C.byref(h))
+    return (x.value, y.value, w.value, h.value) if ok else None
+
+
+def rec_preprocess(crop, imgH, imgW):
+    crop = np.asarray(crop, dtype=np.uint8)
+    out = np.empty((imgH, imgW, 3), np.float32)
+    lib().oracle_rec_preprocess(C.c_void_p(crop.ctypes.data), crop.shape[0], crop.shape[1],
+                                C.c_size_t(crop.strides[0]), imgH, imgW, C.c_void_p(_p(out)))
+    return out
+
+
+def cls_preprocess(crop):
+    crop = np.asarray(crop, dtype=np.uint8)
+    out = np.empty((48, 192, 3), np.float32)
+    lib().oracle_cls_preprocess(C.c_void_p(crop.ctypes.data), crop.shape[0], crop.shape[1],
+                                C.c_size_t(crop.strides[0]), C.c_void_p(_p(out)))
+    return out
+
+
+def rotate180_inplace(view):
+    assert view.dtype == np.uint8 and view.strides[1] == 3 and view.strides[2] == 1
+    lib().oracle_rotate180_inplace(C.c_void_p(view.ctypes.data), view.shape[0], view.shape[1],
+                                   C.c_size_t(view.strides[0]))
+
+
+def argsort(v):
+    v = np.ascontiguousarray(v, dtype=np.float32)
+    idx = np.empty(v.size, np.int32)
+    lib().oracle_argsort(C.c_void_p(_p(v)), v.size, C.c_void_p(_p(idx)))
+    return idx
+
+
+def ctc_decode(amax, pmax):
+    amax = np.ascontiguousarray(amax, dtype=np.int32)
+    pmax = np.ascontiguousarray(pmax, dtype=np.float32)
+    ids = np.empty(amax.size, np.int32)
+    score = C.c_float()
+    n = lib().oracle_ctc_decode(C.c_void_p(_p(amax)), C.c_void_p(_p(pmax)), amax.size, C.c_void_p(_p(ids)),
+                                C.byref(score))
+    if n < 0:
+        return None, None
+    return ids[:n].copy(), score.value

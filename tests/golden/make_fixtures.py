@@ -1,0 +1,63 @@
+"""Generates the committed fixtures of tests/golden/ (run in the dev container, where
+/root/reference exists).
+
+  card_jd_bgr.npy     the reference's only test image (/root/reference/images/card-jd.jpg, used by
+                      /root/reference/tests/test_ocr_worker.cpp:182-233), decoded with PIL/libjpeg to
+                      BGR u8 [178,391,3].  (OpenCV's own JPEG decode may differ by +-1 LSB: SURVEY §8c G3.)
+  unclip_ref.json     golden vectors of ClipperOffset(jtRound, etClosedPolygon).Execute produced by the
+                      REFERENCE's compiled src/clipper.cpp (oracle/_ref/libclipper_ref.so): the exact
+                      call DBPostProcessor::UnClip makes (postprocess_op.cpp:46-55).
+"""
+import ctypes as C
+import json
+import math
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+
+
+def card():
+    from PIL import Image
+    im = np.array(Image.open("/root/reference/images/card-jd.jpg").convert("RGB"))[:, :, ::-1].copy()
+    np.save(os.path.join(HERE, "card_jd_bgr.npy"), im)
+
+
+def unclip(n=600):
+    R = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libclipper_ref.so"))
+    R.clipper_ref_offset.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+    rs = np.random.RandomState(20251003)
+    out = np.zeros(4000, np.int64)
+    ps = np.zeros(8, np.int32)
+    npth = C.c_int()
+    cases = []
+    for t in range(n):
+        cx, cy = rs.rand(2) * 900 + 30
+        w = rs.rand() * 300 + 1
+        h = rs.rand() * 60 + 0.5
+        ang = (rs.rand() - 0.5) * (math.pi if t % 3 == 0 else 0.2)
+        ca, sa = math.cos(ang), math.sin(ang)
+        pts = [(int(cx + sx * w / 2 * ca - sy * h / 2 * sa), int(cy + sx * w / 2 * sa + sy * h / 2 * ca))
+               for sx, sy in ((-1, -1), (1, -1), (1, 1), (-1, 1))]
+        if t % 7 == 0:
+            pts = pts[::-1]
+        if t % 41 == 0:
+            pts[1] = pts[0]  # duplicate vertex
+        if t % 53 == 0:
+            pts = [pts[0]] * 4  # fully degenerate
+        d = float(np.float32(w * h * (1.8 if t % 2 else 2.0) / (2 * (w + h))))
+        if t % 29 == 0:
+            d = 0.0
+        xy = np.array(pts, np.int64).ravel()
+        k = R.clipper_ref_offset(xy.ctypes.data, 4, d, out.ctypes.data, 2000, ps.ctypes.data, 8, C.byref(npth))
+        assert k >= 0 and npth.value <= 1
+        cases.append(dict(quad=[list(p) for p in pts], delta=d, paths=npth.value,
+                          out=out[:2 * k].reshape(-1, 2).tolist()))
+    json.dump(cases, open(os.path.join(HERE, "unclip_ref.json"), "w"), separators=(",", ":"))
+
+
+if __name__ == "__main__":
+    card()
+    unclip()

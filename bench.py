@@ -1,0 +1,206 @@
+"""Benchmark of the hot path: images/sec end-to-end (det + cls + rec) at 960x960 on N MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One step = one pass of the whole pipeline (OCRWorker::processRequest, batched) over one batch of 64
+synthetic 960x960 card images per GPU (BASELINE.json configs[1]); inputs are resident in HBM when
+the timed region starts.  det/rec weights are seeded synthetic (the reference ships none), so the
+SURVEY.md section-8d protocol applies: the det network runs in full and is timed, while
+thresholding/box extraction/recognition consume a synthetic probability map rendered from the same
+text-line layout so that box counts and rec batch shapes are controlled.  cls uses the real weights.
+Whole images are sharded over ranks; there is no data-path collective (weak scaling).
+"""
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from __graft_entry__ import load_package  # noqa: E402
+
+BATCH = 64
+H = W = 960
+K_LINES = 32
+FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+HBM_PEAK_GBS = 8000.0
+
+
+def shard_seeds(rank, world, batch=BATCH):
+    """Image i of the stream goes to rank i mod world (gpu_worker_pool sharding): rank r gets seeds
+    r, r+world, ...  Returned as cfg2 sample indices."""
+    return [rank + world * j for j in range(batch)]
+
+
+def make_inputs(seeds):
+    from synth_data import cfg2_sample
+    cache = os.path.join("/tmp", "ocr_bench_cache")
+    os.makedirs(cache, exist_ok=True)
+    imgs, probs = [], []
+    for s in seeds:
+        fn = os.path.join(cache, "cfg2_%d.npz" % s)
+        if os.path.exists(fn):
+            z = np.load(fn)
+            img, prob = z["img"], z["prob"]
+        else:
+            img, prob, _ = cfg2_sample(s, H, W, K_LINES)
+            try:
+                np.savez(fn, img=img, prob=prob)
+            except OSError:
+                pass
+        imgs.append(img)
+        probs.append(prob)
+    return np.stack(imgs), np.stack(probs)
+
+
+def cpu_baseline(imgs, probs, budget_s=25.0):
+    """The CPU oracle (this build's restatement of the reference CPU path: the reference itself needs
+    Paddle Inference + OpenCV, absent here) on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from pipeline import Pipeline, DetCfg
+    import oracle as O
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or O.usable_cores()
+    pipe = Pipeline(det_cfg=DetCfg(limit_side_len=960), rec_batch_num=16, rec_img_h=48, rec_img_w=320, enable_cls=True)
+    t0 = time.time()
+    done = 0
+    for i in range(len(imgs)):
+        img = imgs[i].copy()
+        x, _ = O.det_preprocess(img, H, W)
+        pipe.det.run(x[None])  # full det network (timed, result replaced by the synthetic map as on the GPU)
+        boxes = O.det_post(probs[i], 0.2, 0.4, 1.8, H, W)
+        views = []
+        for b in boxes:
+            r = O.crop_rect(b, H, W)
+            if r:
+                xx, yy, ww, hh = r
+                views.append(img[yy:yy + hh, xx:xx + ww])
+        if views:
+            labels, _ = pipe.cls_run(views)
+            for k, v in enumerate(views):
+                if labels[k] == 1:
+                    O.rotate180_inplace(v)
+            pipe.rec_run(views)
+        done += 1
+        if time.time() - t0 > budget_s:
+            break
+    dt = time.time() - t0
+    return {"value": done / dt, "unit": "images/sec", "cores": threads, "kind": "port",
+            "sample": "%d of the %d images of rank 0's batch, same pipeline and parameters, %.1f s" % (done, len(imgs), dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+    pkg = load_package()
+
+    imgs, probs = make_inputs(shard_seeds(rank, world))
+    pipe = pkg.Pipe(device=local, enable_cls=True, limit_side_len=960, rec_batch_num=16, rec_img_h=48, rec_img_w=320)
+    d_imgs = pkg.DevArray(imgs)
+    d_probs = pkg.DevArray(probs)
+
+    def barrier():
+        pkg.check(pkg.lib().ocr_dev_sync())
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        pipe.run_device(d_imgs, H, W, BATCH, d_probs, collect=False)
+    if not args.no_kernel_timing:
+        pipe.timing(True)  # HIP events around every network launch, on the launch stream
+    step_ms = []
+    nwords = 0
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        s0 = time.perf_counter()
+        nwords = pipe.run_device(d_imgs, H, W, BATCH, d_probs, collect=False)
+        step_ms.append((time.perf_counter() - s0) * 1e3)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    stage_ms = list(pipe.times)
+
+    if rank == 0:
+        out = {
+            "metric": "images/sec end-to-end (det+cls+rec) at 960x960",
+            "value": world * BATCH * args.steps / elapsed,
+            "unit": "images/sec",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed * 1e3 / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[1]: batch=64 synthetic 960x960 card images per GPU, "
+                                   "PP-OCRv4 mobile det (limit_side_len=960) + cls + rec (48x320, rec_batch_num=16), "
+                                   "%d text lines/image, seeded synthetic det/rec weights with the SURVEY 8d "
+                                   "probability-map protocol, real cls weights" % K_LINES,
+                       "images_per_step_per_gpu": BATCH, "sharding": "image i -> rank i mod n_gpus, no collective"},
+            "p50_step_ms": statistics.median(step_ms),
+            "p50_ms_per_image": statistics.median(step_ms) / BATCH,
+            "stage_ms_last_step": {"det": stage_ms[0], "cls": stage_ms[1], "rec": stage_ms[2]},
+            "words_per_step": nwords,
+        }
+        if not args.no_kernel_timing:
+            rep = pipe.timing_report()
+            if rep:
+                top = max(rep.items(), key=lambda kv: kv[1]["ms"])
+                name, r = top
+                avg_ms = r["ms"] / max(1, r["count"])
+                tflops = r["flops"] / (r["ms"] * 1e-3) / 1e12 if r["ms"] > 0 else 0.0
+                out["roofline"] = {"kernel": name, "bound": "mfma", "achieved": tflops, "peak": FP32_MFMA_PEAK_TFLOPS,
+                                   "unit": "TFLOP/s", "frac": tflops / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                                   "avg_launch_ms": avg_ms, "launches": r["count"],
+                                   "algorithmic_flops_per_launch": r["flops"] / max(1, r["count"]),
+                                   "algorithmic_bytes_per_launch": r["bytes"] / max(1, r["count"]),
+                                   "hbm_GBps_algorithmic": r["bytes"] / (r["ms"] * 1e-3) / 1e9 if r["ms"] > 0 else 0.0}
+                tot = sum(v["ms"] for v in rep.values())
+                out["kernel_time_share_top5"] = {k: round(v["ms"] / tot, 4) for k, v in
+                                                 sorted(rep.items(), key=lambda kv: -kv[1]["ms"])[:5]}
+                out["network_kernel_ms_per_step"] = tot / args.steps
+                if os.environ.get("OCR_BENCH_KERNEL_TABLE"):
+                    with open(os.environ["OCR_BENCH_KERNEL_TABLE"], "w") as f:
+                        for k, v in sorted(rep.items(), key=lambda kv: -kv[1]["ms"]):
+                            f.write("%-40s ms/step %8.3f launches/step %5.1f  TFLOP/s %7.2f  GB/s(alg) %8.1f\n" % (
+                                k, v["ms"] / args.steps, v["count"] / args.steps,
+                                v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] else 0,
+                                v["bytes"] / (v["ms"] * 1e-3) / 1e9 if v["ms"] else 0))
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(imgs, probs)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    pipe.close()
+
+
+if __name__ == "__main__":
+    main()

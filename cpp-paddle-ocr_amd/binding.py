@@ -336,3 +336,157 @@ class Rec:
         if self.h:
             lib().ocr_rec_destroy(self.h)
             self.h = None
+
+
+# ---------------------------------------------------------------------------------------------
+# fused pipeline + device helpers
+# ---------------------------------------------------------------------------------------------
+class ocr_pipe_cfg(C.Structure):
+    _fields_ = [("det", ocr_det_cfg), ("cls", ocr_cls_cfg), ("rec", ocr_rec_cfg), ("enable_cls", C.c_int)]
+
+
+class ocr_word(C.Structure):
+    _fields_ = [("box", C.c_int32 * 8), ("ids_off", C.c_int32), ("ids_len", C.c_int32), ("confidence", C.c_float)]
+
+
+EXPORTS += ["ocr_pipe_cfg_default", "ocr_pipe_create", "ocr_pipe_destroy", "ocr_pipe_run", "ocr_pipe_run_device",
+            "ocr_pipe_label", "ocr_pipe_det_shape", "ocr_pipe_timing", "ocr_pipe_timing_report", "ocr_dev_alloc",
+            "ocr_dev_free", "ocr_dev_upload", "ocr_dev_download", "ocr_dev_sync"]
+
+
+def _pipe_protos(L):
+    if getattr(L, "_pipe_protos_done", False):
+        return
+    _stage_protos(L)
+    vp, ip = C.c_void_p, C.POINTER(C.c_int)
+    L.ocr_pipe_cfg_default.argtypes = [C.POINTER(ocr_pipe_cfg)]
+    L.ocr_pipe_create.argtypes = [C.POINTER(ocr_pipe_cfg), C.POINTER(vp)]
+    L.ocr_pipe_destroy.argtypes = [vp]
+    L.ocr_pipe_run.argtypes = [vp, C.POINTER(ocr_img), C.c_int, vp, C.c_int, vp, vp, vp, C.c_int, C.POINTER(C.c_double)]
+    L.ocr_pipe_run_device.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, vp, vp, vp, C.c_int,
+                                      C.POINTER(C.c_double)]
+    L.ocr_pipe_label.argtypes = [vp, C.c_int]
+    L.ocr_pipe_label.restype = C.c_char_p
+    L.ocr_pipe_det_shape.argtypes = [vp, C.c_int, C.c_int, ip, ip]
+    L.ocr_pipe_timing.argtypes = [vp, C.c_int]
+    L.ocr_pipe_timing_report.argtypes = [vp, C.c_char_p, C.c_size_t]
+    L.ocr_dev_alloc.argtypes = [C.POINTER(vp), C.c_size_t]
+    L.ocr_dev_free.argtypes = [vp]
+    L.ocr_dev_upload.argtypes = [vp, vp, C.c_size_t]
+    L.ocr_dev_download.argtypes = [vp, vp, C.c_size_t]
+    L._pipe_protos_done = True
+
+
+class DevArray:
+    """A device allocation filled from a numpy array (inputs 'already resident in HBM')."""
+
+    def __init__(self, host):
+        L = lib()
+        _pipe_protos(L)
+        host = np.ascontiguousarray(host)
+        self.nbytes = host.nbytes
+        self.shape, self.dtype = host.shape, host.dtype
+        self.ptr = C.c_void_p()
+        check(L.ocr_dev_alloc(C.byref(self.ptr), self.nbytes))
+        check(L.ocr_dev_upload(self.ptr, host.ctypes.data, self.nbytes))
+
+    def download(self):
+        out = np.empty(self.shape, self.dtype)
+        check(lib().ocr_dev_download(out.ctypes.data, self.ptr, self.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr:
+            lib().ocr_dev_free(self.ptr)
+            self.ptr = None
+
+
+class Pipe:
+    """OCRWorker::processRequest over the C-ABI (ocr_pipe_*) for batches of images."""
+
+    def __init__(self, model_root=None, device=0, enable_cls=False, limit_type="max", limit_side_len=512, thresh=0.2,
+                 box_thresh=0.4, unclip_ratio=1.8, use_dilation=False, rec_batch_num=16, rec_img_h=28, rec_img_w=192,
+                 cls_batch_num=8):
+        L = lib()
+        _pipe_protos(L)
+        root = model_root or MODELS
+        cfg = ocr_pipe_cfg()
+        L.ocr_pipe_cfg_default(C.byref(cfg))
+        self._keep = [os.path.join(root, "det").encode(), os.path.join(root, "cls").encode(),
+                      os.path.join(root, "rec").encode(), os.path.join(root, "rec", "ppocr_keys_v1.txt").encode(),
+                      limit_type.encode()]
+        cfg.det.model_dir, cfg.cls.model_dir, cfg.rec.model_dir, cfg.rec.label_path, cfg.det.limit_type = self._keep
+        cfg.det.device_id = device
+        cfg.det.limit_side_len = limit_side_len
+        cfg.det.det_db_thresh, cfg.det.det_db_box_thresh, cfg.det.det_db_unclip_ratio = thresh, box_thresh, unclip_ratio
+        cfg.det.use_dilation = int(use_dilation)
+        cfg.rec.rec_batch_num, cfg.rec.rec_img_h, cfg.rec.rec_img_w = rec_batch_num, rec_img_h, rec_img_w
+        cfg.cls.cls_batch_num = cls_batch_num
+        cfg.enable_cls = int(enable_cls)
+        self.h = C.c_void_p()
+        check(L.ocr_pipe_create(C.byref(cfg), C.byref(self.h)))
+        self.times = (C.c_double * 3)()
+        self._cap_words, self._cap_ids = 0, 0
+
+    def _bufs(self, count):
+        cw, ci = count * 1000, count * 1000 * 64
+        if cw > self._cap_words:
+            self._words = (ocr_word * cw)()
+            self._ids = np.zeros(ci, np.int32)
+            self._cap_words, self._cap_ids = cw, ci
+        return self._words, self._ids
+
+    def _collect(self, count, words, ids, off, nw):
+        out = []
+        for i in range(count):
+            ws = []
+            for k in range(off[i], off[i] + nw[i]):
+                w = words[k]
+                ws.append(dict(box=np.array(w.box[:], np.int32).reshape(4, 2),
+                               ids=ids[w.ids_off:w.ids_off + w.ids_len].copy(), confidence=float(w.confidence)))
+            out.append(ws)
+        return out
+
+    def run(self, imgs):
+        n = len(imgs)
+        words, ids = self._bufs(n)
+        off = np.zeros(n, np.int32)
+        nw = np.zeros(n, np.int32)
+        check(lib().ocr_pipe_run(self.h, _imgs(imgs), n, words, self._cap_words, off.ctypes.data, nw.ctypes.data,
+                                 ids.ctypes.data, self._cap_ids, self.times))
+        return self._collect(n, words, ids, off, nw)
+
+    def run_device(self, dev_imgs, rows, cols, count, dev_prob=None, collect=True):
+        words, ids = self._bufs(count)
+        off = np.zeros(count, np.int32)
+        nw = np.zeros(count, np.int32)
+        check(lib().ocr_pipe_run_device(self.h, dev_imgs.ptr, rows, cols, count, dev_prob.ptr if dev_prob else None,
+                                        words, self._cap_words, off.ctypes.data, nw.ctypes.data, ids.ctypes.data,
+                                        self._cap_ids, self.times))
+        return self._collect(count, words, ids, off, nw) if collect else int(nw.sum())
+
+    def det_shape(self, rows, cols):
+        a, b = C.c_int(), C.c_int()
+        check(lib().ocr_pipe_det_shape(self.h, rows, cols, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def label(self, i):
+        s = lib().ocr_pipe_label(self.h, int(i))
+        return s.decode("utf-8") if s is not None else None
+
+    def timing(self, on=True):
+        check(lib().ocr_pipe_timing(self.h, int(on)))
+
+    def timing_report(self):
+        buf = C.create_string_buffer(1 << 18)
+        check(lib().ocr_pipe_timing_report(self.h, buf, len(buf)))
+        out = {}
+        for line in buf.value.decode().splitlines():
+            name, ms, cnt, fl, by = line.split()
+            out[name] = dict(ms=float(ms), count=int(cnt), flops=float(fl), bytes=float(by))
+        return out
+
+    def close(self):
+        if self.h:
+            lib().ocr_pipe_destroy(self.h)
+            self.h = None

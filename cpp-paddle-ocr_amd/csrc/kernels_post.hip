@@ -799,6 +799,11 @@ __device__ int clipper_offset_round(const IPt in[4], double delta, IPt* dest) {
     }
   }
   if (nd < 3) return 0;
+  {  // non-positive winding (ring folded over itself at tiny delta) is not part of a pftPositive union
+    double a = 0;
+    for (int i = 0, j = nd - 1; i < nd; ++i) { a += ((double)dest[j].X + dest[i].X) * ((double)dest[j].Y - dest[i].Y); j = i; }
+    if (!(-a * 0.5 > 0)) return 0;
+  }
   long long miny = dest[0].Y;
   for (int i = 1; i < nd; ++i) miny = dest[i].Y < miny ? dest[i].Y : miny;
   int e = 0;

@@ -54,8 +54,8 @@ struct TensorDesc {
 struct KernelTiming {
   double ms = 0;
   long count = 0;
-  double flops = 0;  // algorithmic FLOPs per launch (last bind)
-  double bytes = 0;  // algorithmic bytes per launch
+  double flops = 0;  // algorithmic FLOPs summed over the timed launches
+  double bytes = 0;  // algorithmic bytes summed over the timed launches
 };
 
 class Net {
@@ -118,7 +118,7 @@ class Net {
   bool timing_ = false;
   bool keep_all_ = false;
   std::map<std::string, KernelTiming> timings_;
-  struct EvPair { hipEvent_t a, b; int launch; };
+  struct EvPair { hipEvent_t a, b; std::string name; double flops, bytes; };
   std::vector<EvPair> ev_pending_;
   std::vector<hipEvent_t> ev_pool_;
 };

@@ -651,7 +651,7 @@ bool Net::run(const float* x, int N, int H, int W, hipStream_t s, std::string& e
       HIP_OK(hipEventRecord(a, s));
       launches_[i].fn(s);
       HIP_OK(hipEventRecord(b, s));
-      ev_pending_.push_back({a, b, (int)i});
+      ev_pending_.push_back({a, b, launches_[i].name, launches_[i].flops, launches_[i].bytes});
     } else {
       launches_[i].fn(s);
     }
@@ -663,12 +663,12 @@ bool Net::run(const float* x, int N, int H, int W, hipStream_t s, std::string& e
 void Net::collect_timings() {
   for (auto& p : ev_pending_) {
     float ms = 0.f;
-    if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess && p.launch < (int)launches_.size()) {
-      auto& t = timings_[launches_[p.launch].name];
+    if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+      auto& t = timings_[p.name];
       t.ms += ms;
       t.count += 1;
-      t.flops = launches_[p.launch].flops;
-      t.bytes = launches_[p.launch].bytes;
+      t.flops += p.flops;
+      t.bytes += p.bytes;
     }
     ev_pool_.push_back(p.a);
     ev_pool_.push_back(p.b);

@@ -52,8 +52,12 @@ class DetStage {
   // imgs: `count` same-size host images.  boxes [count][cap][8], n [count].
   int run(const ocr_img* imgs, int count, int32_t* boxes, int cap, int* n, double times[3], std::string& err);
   // the same on images that already sit in device memory (packed BGR rows, one image every img_bytes)
+  // prob_override (device, [count][rh][rw] f32, may be null): the benchmark protocol of SURVEY.md §8d —
+  // the network still runs, but thresholding / scoring read this map instead of the network's.
   int run_device(const uint8_t* dev_imgs, size_t img_bytes, size_t stride, int rows, int cols, int count, int32_t* boxes,
-                 int cap, int* n, double times[3], std::string& err);
+                 int cap, int* n, double times[3], std::string& err, const float* prob_override = nullptr);
+  // mutable view of the uploaded copies (the request's clone: cls rotation happens in place on it)
+  uint8_t* dev_images_mut() { return src_.p; }
   int post_only(const float* prob, int rows, int cols, int src_rows, int src_cols, int32_t* boxes, int cap, int* n,
                 std::string& err);
   // device-resident copy of the last uploaded images (for the fused pipeline)
@@ -105,8 +109,13 @@ class RecStage {
   bool create(const RecConfig& cfg, std::string& err, int& code);
   int run(const ocr_img* imgs, int n, int32_t* ids, int max_len, int* lens, float* scores, double times[3],
           std::string& err);
-  // lines already on the device (the stream must be ordered after whatever produced them)
-  int run_lines(const std::vector<LineSrc>& lines, int32_t* ids, int max_len, int* lens, float* scores, std::string& err);
+  // lines already on the device (the stream must be ordered after whatever produced them).
+  // seg: offsets of per-image segments (size nimages+1); the reference's aspect-sort / batch-of-16
+  // rule is applied inside each segment, launches are shared across segments of equal tensor width.
+  int run_lines(const std::vector<LineSrc>& lines, const std::vector<int>& seg, int32_t* ids, int max_len, int* lens,
+                float* scores, std::string& err);
+  bool want_taps = true;
+  int max_lines_per_launch = 1024;
   const std::vector<std::string>& labels() const { return labels_; }
   hipStream_t stream() const { return stream_; }
   Net& net() { return net_; }

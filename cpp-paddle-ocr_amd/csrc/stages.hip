@@ -189,7 +189,7 @@ int DetStage::run(const ocr_img* imgs, int count, int32_t* boxes, int cap, int* 
 }
 
 int DetStage::run_device(const uint8_t* dev_imgs, size_t img_bytes, size_t stride, int rows, int cols, int count,
-                         int32_t* boxes, int cap, int* n, double times[3], std::string& err) {
+                         int32_t* boxes, int cap, int* n, double times[3], std::string& err, const float* prob_override) {
   ST_HIP(hipSetDevice(cfg_.device));
   int rh, rw;
   float ratio_h, ratio_w;
@@ -207,7 +207,14 @@ int DetStage::run_device(const uint8_t* dev_imgs, size_t img_bytes, size_t strid
   if (!net_.run(x_.p, count, rh, rw, stream_, err)) return OCR_ERR_DEVICE;
   timer_.mark(2, stream_);
   last_count = count; last_h = rh; last_w = rw;
-  const int rc = run_post(count, rh, rw, prob_dev(), ratio_h, ratio_w, rows, cols, boxes, cap, n, err);
+  const float* pred = prob_dev();
+  if (prob_override) {
+    launch_bitmap(prob_override, bitmap_.p, (long)px, ithresh_, stream_);
+    pred = prob_override;
+  }
+  src_rows_ = rows;
+  src_cols_ = cols;
+  const int rc = run_post(count, rh, rw, pred, ratio_h, ratio_w, rows, cols, boxes, cap, n, err);
   net_.collect_timings();
   timer_.read(times);
   return rc;
@@ -271,7 +278,8 @@ int RecStage::run(const ocr_img* imgs, int n, int32_t* ids, int max_len, int* le
   std::vector<LineSrc> lines;
   if (!upload_lines(imgs, n, staging_, lines, stream_, err)) return OCR_ERR_DEVICE;
   timer_.mark(1, stream_);
-  const int rc = run_lines(lines, ids, max_len, lens, scores, err);
+  const std::vector<int> seg = {0, n};
+  const int rc = run_lines(lines, seg, ids, max_len, lens, scores, err);
   timer_.mark(2, stream_);
   timer_.mark(3, stream_);
   (void)hipStreamSynchronize(stream_);
@@ -279,35 +287,45 @@ int RecStage::run(const ocr_img* imgs, int n, int32_t* ids, int max_len, int* le
   return rc;
 }
 
-int RecStage::run_lines(const std::vector<LineSrc>& lines, int32_t* ids, int max_len, int* lens, float* scores,
-                        std::string& err) {
+int RecStage::run_lines(const std::vector<LineSrc>& lines, const std::vector<int>& seg, int32_t* ids, int max_len,
+                        int* lens, float* scores, std::string& err) {
   const int n = (int)lines.size();
   const int imgH = cfg_.img_h, imgW = cfg_.img_w;
-  // CRNNRecognizer::Run batching, /root/reference/src/ocr_rec.cpp:34-57
-  std::vector<float> width_list(n);
-  for (int i = 0; i < n; ++i) width_list[i] = float(lines[i].w) / lines[i].h;
-  std::vector<size_t> indices(n);
-  for (int i = 0; i < n; ++i) indices[i] = i;
-  std::sort(indices.begin(), indices.end(), [&](size_t a, size_t b) { return width_list[a] < width_list[b]; });
   struct Item { int line; int resize_w; };
-  std::map<int, std::vector<Item>> groups;  // tensor width -> lines (order inside a width is irrelevant)
-  for (int beg = 0; beg < n; beg += cfg_.batch_num) {
-    const int end = std::min(n, beg + cfg_.batch_num);
-    float max_wh_ratio = imgW * 1.0 / imgH;
-    for (int ino = beg; ino < end; ++ino) {
-      const int h = lines[indices[ino]].h, w = lines[indices[ino]].w;
-      const float wh_ratio = w * 1.0 / h;
-      max_wh_ratio = std::max(max_wh_ratio, wh_ratio);
-    }
-    const int bw = int(imgH * max_wh_ratio);  // CrnnResizeImg: imgW = int(imgH * wh_ratio)
-    const int tensor_w = std::max(bw, imgW);
-    for (int ino = beg; ino < end; ++ino) {
-      const LineSrc& L = lines[indices[ino]];
-      const float ratio = float(L.w) / float(L.h);
-      const int resize_w = ceilf(imgH * ratio) > bw ? bw : int(ceilf(imgH * ratio));
-      groups[tensor_w].push_back({(int)indices[ino], resize_w});
+  std::map<int, std::vector<Item>> groups;  // tensor width -> lines (samples of one launch are independent)
+  for (size_t sg = 0; sg + 1 < seg.size(); ++sg) {
+    // CRNNRecognizer::Run batching, /root/reference/src/ocr_rec.cpp:34-57, on one image's lines
+    const int s0 = seg[sg], sn = seg[sg + 1] - seg[sg];
+    std::vector<float> width_list(sn);
+    for (int i = 0; i < sn; ++i) width_list[i] = float(lines[s0 + i].w) / lines[s0 + i].h;
+    std::vector<size_t> indices(sn);
+    for (int i = 0; i < sn; ++i) indices[i] = i;
+    std::sort(indices.begin(), indices.end(), [&](size_t a, size_t b) { return width_list[a] < width_list[b]; });
+    for (int beg = 0; beg < sn; beg += cfg_.batch_num) {
+      const int end = std::min(sn, beg + cfg_.batch_num);
+      float max_wh_ratio = imgW * 1.0 / imgH;
+      for (int ino = beg; ino < end; ++ino) {
+        const int h = lines[s0 + indices[ino]].h, w = lines[s0 + indices[ino]].w;
+        const float wh_ratio = w * 1.0 / h;
+        max_wh_ratio = std::max(max_wh_ratio, wh_ratio);
+      }
+      const int bw = int(imgH * max_wh_ratio);  // CrnnResizeImg: imgW = int(imgH * wh_ratio)
+      const int tensor_w = std::max(bw, imgW);
+      for (int ino = beg; ino < end; ++ino) {
+        const LineSrc& L = lines[s0 + indices[ino]];
+        const float ratio = float(L.w) / float(L.h);
+        const int resize_w = ceilf(imgH * ratio) > bw ? bw : int(ceilf(imgH * ratio));
+        auto& g = groups[tensor_w];
+        g.push_back({s0 + (int)indices[ino], resize_w});
+      }
     }
   }
+  // bound the rows of one launch (activation arena) by splitting wide groups
+  std::vector<std::pair<int, std::vector<Item>>> launches;
+  for (auto& kv : groups)
+    for (size_t b = 0; b < kv.second.size(); b += max_lines_per_launch)
+      launches.emplace_back(kv.first, std::vector<Item>(kv.second.begin() + b,
+                                                        kv.second.begin() + std::min(kv.second.size(), b + (size_t)max_lines_per_launch)));
   tap_T.assign(n, 0);
   tap_off.assign(n, 0);
   tap_amax.clear();
@@ -315,7 +333,7 @@ int RecStage::run_lines(const std::vector<LineSrc>& lines, int32_t* ids, int max
   for (int i = 0; i < n; ++i) { lens[i] = 0; scores[i] = 0.f; }
   std::vector<int> h_ids, h_lens, h_amax;
   std::vector<float> h_scores, h_pmax;
-  for (auto& kv : groups) {
+  for (auto& kv : launches) {
     const int Wt = kv.first;
     const int ng = (int)kv.second.size();
     std::vector<LineDesc> d(ng);
@@ -342,13 +360,15 @@ int RecStage::run_lines(const std::vector<LineSrc>& lines, int32_t* ids, int max
     h_ids.resize((size_t)ng * max_len);
     h_lens.resize(ng);
     h_scores.resize(ng);
-    h_amax.resize((size_t)ng * T);
-    h_pmax.resize((size_t)ng * T);
     ST_HIP(hipMemcpyAsync(h_ids.data(), ids_.p, h_ids.size() * sizeof(int), hipMemcpyDeviceToHost, stream_));
     ST_HIP(hipMemcpyAsync(h_lens.data(), lens_.p, ng * sizeof(int), hipMemcpyDeviceToHost, stream_));
     ST_HIP(hipMemcpyAsync(h_scores.data(), scores_.p, ng * sizeof(float), hipMemcpyDeviceToHost, stream_));
-    ST_HIP(hipMemcpyAsync(h_amax.data(), amax_.p, h_amax.size() * sizeof(int), hipMemcpyDeviceToHost, stream_));
-    ST_HIP(hipMemcpyAsync(h_pmax.data(), pmax_.p, h_pmax.size() * sizeof(float), hipMemcpyDeviceToHost, stream_));
+    if (want_taps) {
+      h_amax.resize((size_t)ng * T);
+      h_pmax.resize((size_t)ng * T);
+      ST_HIP(hipMemcpyAsync(h_amax.data(), amax_.p, h_amax.size() * sizeof(int), hipMemcpyDeviceToHost, stream_));
+      ST_HIP(hipMemcpyAsync(h_pmax.data(), pmax_.p, h_pmax.size() * sizeof(float), hipMemcpyDeviceToHost, stream_));
+    }
     ST_HIP(hipStreamSynchronize(stream_));
     net_.collect_timings();
     for (int j = 0; j < ng; ++j) {
@@ -358,9 +378,11 @@ int RecStage::run_lines(const std::vector<LineSrc>& lines, int32_t* ids, int max
       scores[li] = h_scores[j];
       memcpy(ids + (size_t)li * max_len, h_ids.data() + (size_t)j * max_len, (size_t)h_lens[j] * sizeof(int));
       tap_T[li] = T;
-      tap_off[li] = (int)tap_amax.size();
-      tap_amax.insert(tap_amax.end(), h_amax.begin() + (size_t)j * T, h_amax.begin() + (size_t)(j + 1) * T);
-      tap_pmax.insert(tap_pmax.end(), h_pmax.begin() + (size_t)j * T, h_pmax.begin() + (size_t)(j + 1) * T);
+      if (want_taps) {
+        tap_off[li] = (int)tap_amax.size();
+        tap_amax.insert(tap_amax.end(), h_amax.begin() + (size_t)j * T, h_amax.begin() + (size_t)(j + 1) * T);
+        tap_pmax.insert(tap_pmax.end(), h_pmax.begin() + (size_t)j * T, h_pmax.begin() + (size_t)(j + 1) * T);
+      }
     }
   }
   return OCR_OK;

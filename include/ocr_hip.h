@@ -121,6 +121,53 @@ int ocr_rec_num_classes(ocr_rec* h);
 /* tap: per-step arg max / max prob of line `index` of the last run (T entries), and T */
 int ocr_rec_steps(ocr_rec* h, int index, int32_t* amax, float* pmax, int cap, int* T);
 
+
+/* ---------------------------------------------------------------- pipeline */
+/* OCRWorker::processRequest (/root/reference/src/ocr_worker.cpp:213-311) for a batch of images in one
+ * device pass: det -> axis-aligned crops -> [cls -> in-place 180 degree rotation] -> rec -> CTC.
+ * The three stage handles live on one device; images are uploaded once and the crops are taken
+ * from the device copy (the reference's ROI views of the request's cv::Mat clone). */
+typedef struct ocr_pipe_cfg {
+  ocr_det_cfg det;
+  ocr_cls_cfg cls;
+  ocr_rec_cfg rec;
+  int enable_cls; /* OCRWorker(..., enable_cls = false) */
+} ocr_pipe_cfg;
+void ocr_pipe_cfg_default(ocr_pipe_cfg* cfg);
+/* WordResult (ocr_worker.h:34-38): text as class ids ids[ids_off .. ids_off+ids_len) */
+typedef struct ocr_word {
+  int32_t box[8];
+  int32_t ids_off, ids_len;
+  float confidence;
+} ocr_word;
+typedef struct ocr_pipe ocr_pipe;
+int ocr_pipe_create(const ocr_pipe_cfg* cfg, ocr_pipe** out);
+void ocr_pipe_destroy(ocr_pipe* h);
+/* imgs: `count` images (any mix of sizes; equal sizes share one det pass).  words: cap_words entries,
+ * image i owns words[word_off[i] .. word_off[i]+nwords[i]); ids: cap_ids class ids.
+ * times[3] = det / cls / rec wall ms. */
+int ocr_pipe_run(ocr_pipe* h, const ocr_img* imgs, int count, ocr_word* words, int cap_words, int* word_off, int* nwords,
+                 int32_t* ids, int cap_ids, double times[3]);
+/* The same with inputs already resident in HBM: `count` packed BGR images of rows x cols (one every
+ * rows*cols*3 bytes, device pointer), and optionally `dev_prob` = count probability maps of the
+ * detector's input resolution that replace the network's map for thresholding/scoring (benchmark
+ * protocol for synthetic weights; the network still runs and is timed). */
+int ocr_pipe_run_device(ocr_pipe* h, const void* dev_bgr, int rows, int cols, int count, const float* dev_prob, ocr_word* words,
+                        int cap_words, int* word_off, int* nwords, int32_t* ids, int cap_ids, double times[3]);
+const char* ocr_pipe_label(ocr_pipe* h, int id);
+/* network input size the detector uses for a rows x cols image (ResizeImgType0) */
+int ocr_pipe_det_shape(ocr_pipe* h, int rows, int cols, int* net_rows, int* net_cols);
+/* HIP-event timing of every kernel launch of the three networks during subsequent runs */
+int ocr_pipe_timing(ocr_pipe* h, int enable);
+int ocr_pipe_timing_report(ocr_pipe* h, char* buf, size_t cap);
+
+/* device memory helpers for callers without a HIP binding of their own (bench, tests) */
+int ocr_dev_alloc(void** p, size_t bytes);
+int ocr_dev_free(void* p);
+int ocr_dev_upload(void* dst, const void* src, size_t bytes);
+int ocr_dev_download(void* dst, const void* src, size_t bytes);
+int ocr_dev_sync(void);
+
 /* ---------------------------------------------------------------- raw network taps (parity tests) */
 typedef struct ocr_net ocr_net;
 /* kind: "det" | "cls" | "rec".  weights: path of a .pdiparams file (NULL: <model_dir>/inference.pdiparams,

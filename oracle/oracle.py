@@ -15,9 +15,23 @@ from pdmodel import Program, read_params  # noqa: E402
 _lib = None
 
 
+def usable_cores():
+    """CPU threads this process may actually use (affinity mask and cgroup quota), capped at 32:
+    the oracle's loops are small and oversubscribed OpenMP teams make it slower, not faster."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 32))
+
+
 def lib():
     global _lib
     if _lib is None:
+        os.environ.setdefault("OMP_NUM_THREADS", str(usable_cores()))
         path = os.path.join(HERE, "liboracle.so")
         if not os.path.exists(path):
             raise RuntimeError("oracle/liboracle.so missing: run `make -C oracle` (or __graft_entry__.build())")

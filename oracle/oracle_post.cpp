@@ -695,6 +695,9 @@ std::vector<IPt> clipper_offset_round(const std::vector<IPt>& path, double delta
     }
   }
   if (p.size() < 3) return {};
+  // a tiny delta on a ~1 px thin quad can fold the ring over itself: a ring with non-positive winding
+  // is not part of a pftPositive union
+  if (!(path_area(p) > 0)) return {};
   long long miny = p[0].Y;
   for (auto& q : p) miny = std::min(miny, q.Y);
   size_t e = 0;

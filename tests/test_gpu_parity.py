@@ -1,0 +1,217 @@
+"""Parity tests proper: the HIP path through the C-ABI against the CPU oracle on the same seeded
+inputs.  Bars: bit-exact for bytes / integers / indices (resized image, bitmap, boxes, CTC ids) AND for
+the f32 maps, logits and scores — the kernels implement the oracle's arithmetic contract exactly
+(DESIGN.md section 4), so `==` is the comparison, tighter than the 1e-3 the north star allows."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_native_library_is_loaded(pkg, built):
+    import ctypes
+    pkg.check(pkg.lib().ocr_rt_init(0))
+    maps = open("/proc/self/maps").read()
+    assert "libocr_hip.so" in maps  # the in-tree HIP library, not a fallback
+
+
+def test_numerics_probe_matches_ieee_and_contract(pkg, built):
+    import oracle as O
+    rs = np.random.RandomState(0)
+    a = np.concatenate([rs.randn(4096) * 10, rs.rand(4096) * 100 - 50, [0.0, -0.0, 1.0, 88.5, -90.0, 1e-30]]).astype(np.float32)
+    b = (rs.randn(a.size) * 3 + 0.01).astype(np.float32)
+    out = pkg.probe(a, b)
+    assert np.array_equal(out[0], a / b)                      # correctly rounded division
+    assert np.array_equal(out[1], np.sqrt(np.abs(a)))         # correctly rounded sqrt
+    ref_exp = np.array([O.lib().oracle_expf(float(v)) for v in a], np.float32)
+    assert np.array_equal(out[2], ref_exp)                    # the contract's exp, bit for bit
+    assert np.array_equal(out[3], (a.astype(np.float64) * b + a).astype(np.float32))  # fma: one rounding
+    assert np.array_equal(out[4], (a * b) + a)                # a*b+a is NOT contracted (-ffp-contract=off)
+
+
+@pytest.mark.parametrize("kind,shape", [("cls", (3, 48, 192)), ("det", (2, 64, 96)), ("det", (1, 192, 384)),
+                                        ("rec", (3, 48, 160)), ("rec", (2, 28, 192)), ("rec", (1, 48, 1000))])
+def test_network_outputs_bit_identical(pkg, built, kind, shape):
+    from oracle import OracleNet
+    x = np.random.RandomState(7).randn(shape[0], shape[1], shape[2], 3).astype(np.float32)
+    o = OracleNet(kind)
+    g = pkg.Net(kind)
+    yo, yg = o.run(x), g.forward(x, keep_all=True)
+    assert yo.shape == yg.shape and np.array_equal(yo, yg)
+    # layer by layer (every plan tensor, converted back from the device's interleaved channel layout)
+    for tid in range(1, g.num_tensors()):
+        to = o.tensor(tid)
+        if to.size:
+            assert np.array_equal(to, g.fetch(tid)), "tensor %d" % tid
+    g.close()
+
+
+def test_det_on_reference_image_worker_defaults(pkg, built, card):
+    """cfg1: card-jd.jpg, limit 512 / 0.2 / 0.4 / 1.8 / fast (ocr_worker.cpp:21-35)."""
+    from pipeline import Pipeline
+    pipe, det = Pipeline(), pkg.Det()
+    bo, bg = pipe.det_run(card), det.run(card)
+    assert det.last_shape() == (1, 192, 384)                  # 178x391 -> 192x384 (SURVEY 8 "cfg1")
+    assert np.array_equal(det.resized(), pipe.taps["det_resized"])
+    assert np.array_equal(det.prob_map(), pipe.taps["det_prob"])
+    assert np.array_equal(det.bitmap(), pipe.taps["det_bitmap"])
+    assert len(bo) == len(bg) > 0 and all(np.array_equal(a, b) for a, b in zip(bo, bg))
+    # strided ROI view input (a cv::Mat ROI): same result as its contiguous copy
+    big = np.zeros((200, 420, 3), np.uint8)
+    big[10:188, 20:411] = card
+    bv = det.run(big[10:188, 20:411])
+    assert len(bv) == len(bg) and all(np.array_equal(a, b) for a, b in zip(bv, bg))
+    det.close()
+
+
+@pytest.mark.parametrize("dilate", [False, True])
+def test_det_post_on_probability_maps(pkg, built, dilate):
+    import oracle as O
+    from scipy import ndimage
+    from synth_data import cfg2_sample
+    det = pkg.Det(limit_side_len=960, thresh=0.3, box_thresh=0.5, unclip_ratio=2.0, use_dilation=dilate)
+    for i in range(3):
+        _, prob, _ = cfg2_sample(i)
+        bo, bg = O.det_post(prob, 0.3, 0.5, 2.0, 960, 960, dilate), det.post(prob, 960, 960)
+        assert len(bo) == len(bg) == 32 and all(np.array_equal(a, b) for a, b in zip(bo, bg))
+    rs = np.random.RandomState(3)
+    for i in range(6):   # blobs, specks, holes, borders touching the frame; different source scale
+        H, W = 224 + 32 * i, 320
+        f = ndimage.gaussian_filter(rs.rand(H, W), 1.0 + i)
+        f = ((f - f.min()) / (f.max() - f.min())) ** (1.5 + 0.5 * i)
+        f = f.astype(np.float32)
+        bo, bg = O.det_post(f, 0.3, 0.5, 2.0, 2 * H, 3 * W, dilate), det.post(f, 2 * H, 3 * W)
+        assert len(bo) == len(bg) and all(np.array_equal(a, b) for a, b in zip(bo, bg))
+    # edge cases: empty map, full map, single pixel, 1-px lines
+    for f in (np.zeros((64, 96), np.float32), np.ones((64, 96), np.float32)):
+        assert len(det.post(f, 64, 96)) == len(O.det_post(f, 0.3, 0.5, 2.0, 64, 96, dilate))
+    f = np.zeros((64, 96), np.float32)
+    f[10, 10] = 1
+    f[20, 5:60] = 1
+    f[30:50, 70] = 1
+    f[40:60, 10:50] = 0.95
+    bo, bg = O.det_post(f, 0.3, 0.5, 2.0, 64, 96, dilate), det.post(f, 64, 96)
+    assert len(bo) == len(bg) and all(np.array_equal(a, b) for a, b in zip(bo, bg))
+    det.close()
+
+
+def test_det_batch_full_size_and_determinism(pkg, built):
+    """cfg2 size (960x960) with the full network on synthetic weights: batch == singles == oracle."""
+    from pipeline import Pipeline, DetCfg
+    from synth_data import cfg2_sample
+    imgs = [cfg2_sample(i)[0] for i in range(3)]
+    det = pkg.Det(limit_side_len=960, thresh=0.3, box_thresh=0.5, unclip_ratio=2.0, max_batch=3)
+    batch = det.run_batch(imgs)
+    prob1 = det.prob_map(1)
+    again = det.run_batch(imgs)
+    assert all(np.array_equal(a, b) for x, y in zip(batch, again) for a, b in zip(x, y))  # idempotent
+    single = det.run(imgs[1])
+    assert np.array_equal(det.prob_map(0), prob1)                                         # batch-invariant
+    assert len(single) == len(batch[1]) and all(np.array_equal(a, b) for a, b in zip(single, batch[1]))
+    po = Pipeline(det_cfg=DetCfg(limit_side_len=960, thresh=0.3, box_thresh=0.5, unclip_ratio=2.0))
+    bo = po.det_run(imgs[1])
+    assert np.array_equal(po.taps["det_prob"], prob1)
+    assert len(bo) == len(single) and all(np.array_equal(a, b) for a, b in zip(bo, single))
+    for b in batch:  # size-independent properties of FilterTagDetRes
+        for q in b:
+            assert (q >= 0).all() and (q[:, 0] <= 959).all() and (q[:, 1] <= 959).all()
+            assert int(np.hypot(*(q[0] - q[1]))) > 4 and int(np.hypot(*(q[0] - q[3]))) > 4
+    det.close()
+
+
+def _crops():
+    import oracle as O
+    from synth_data import cfg2_sample
+    img, prob, _ = cfg2_sample(0)
+    boxes = O.det_post(prob, 0.3, 0.5, 2.0, 960, 960)
+    crops = []
+    for b in boxes:
+        r = O.crop_rect(b, 960, 960)
+        if r:
+            x, y, w, h = r
+            crops.append(img[y:y + h, x:x + w])   # ROI views with the parent's row stride
+    return crops
+
+
+@pytest.mark.parametrize("h,w,bn", [(48, 320, 6), (28, 192, 16)])
+def test_rec_ids_scores_and_steps(pkg, built, h, w, bn):
+    from pipeline import Pipeline
+    crops = _crops()
+    assert len(crops) == 32
+    po = Pipeline(rec_batch_num=bn, rec_img_h=h, rec_img_w=w)
+    rec = pkg.Rec(rec_batch_num=bn, rec_img_h=h, rec_img_w=w)
+    to, so, steps = po.rec_run(crops)
+    tg, sg = rec.run(crops)
+    assert rec.num_classes() == 6625 and rec.label(0) == "#" and rec.label(6624) == " "
+    assert all(np.array_equal(a, b) for a, b in zip(to, tg))     # CTC class ids: bit-exact
+    assert np.array_equal(so, sg)                                # mean max-probability: bit-exact
+    for i in range(len(crops)):
+        am, pm = rec.steps(i)
+        assert np.array_equal(am, steps[i][0]) and np.array_equal(pm, steps[i][1])
+    # ragged / empty inputs
+    assert rec.run([])[0] == []
+    one = rec.run([crops[3]])
+    assert len(one[0]) == 1
+    rec.close()
+
+
+def test_cls_on_real_weights(pkg, built):
+    from pipeline import Pipeline
+    crops = _crops()
+    po, cls = Pipeline(enable_cls=True), pkg.Cls()
+    lo, so = po.cls_run(crops)
+    lg, sg = cls.run(crops)
+    assert np.array_equal(lo, lg) and np.array_equal(so, sg)
+    assert np.array_equal(cls.probs(len(crops)), po.taps["cls_probs"])
+    assert 0 < lg.sum() < len(crops)      # both orientations occur, so the rotate path is exercised below
+    cls.close()
+
+
+@pytest.mark.parametrize("cls_on", [False, True])
+def test_pipeline_process_request(pkg, built, card, cls_on):
+    """OCRWorker::processRequest: ids kept per request, mixed sizes in one call, cls rotation in place."""
+    from pipeline import Pipeline
+    pg, po = pkg.Pipe(enable_cls=cls_on), Pipeline(enable_cls=cls_on)
+    imgs = [card, card[:, ::-1].copy(), card[:120].copy(), card]
+    got = pg.run(imgs)
+    for img, g in zip(imgs, got):
+        w = po.process(img)["words"]
+        assert len(g) == len(w)
+        for a, b in zip(g, w):
+            assert np.array_equal(a["box"], b["box"]) and np.array_equal(a["ids"], b["ids"])
+            assert a["confidence"] == np.float32(b["confidence"])
+    # an image without text: success with zero words (ocr_worker.cpp:235-241)
+    blank = np.full((64, 64, 3), 255, np.uint8)
+    assert len(pg.run([blank])[0]) == len(po.process(blank)["words"])
+    with pytest.raises(pkg.OcrError, match="Empty image"):
+        pg.run([np.zeros((0, 0, 3), np.uint8)])
+    pg.close()
+
+
+def test_pipeline_device_resident_bench_protocol(pkg, built):
+    import oracle as O
+    from pipeline import Pipeline, DetCfg
+    from synth_data import cfg2_sample
+    s = [cfg2_sample(i) for i in range(2)]
+    imgs, probs = np.stack([a[0] for a in s]), np.stack([a[1] for a in s])
+    pg = pkg.Pipe(enable_cls=True, limit_side_len=960, rec_batch_num=16, rec_img_h=48, rec_img_w=320)
+    d_i, d_p = pkg.DevArray(imgs), pkg.DevArray(probs)
+    got = pg.run_device(d_i, 960, 960, 2, d_p)
+    assert np.array_equal(d_i.download(), imgs)   # the caller's images are cloned, not rotated in place
+    po = Pipeline(det_cfg=DetCfg(limit_side_len=960), rec_batch_num=16, rec_img_h=48, rec_img_w=320, enable_cls=True)
+    for i in range(2):
+        img = imgs[i].copy()
+        boxes = O.det_post(probs[i], 0.2, 0.4, 1.8, 960, 960)
+        views = [img[y:y + h, x:x + w] for x, y, w, h in (O.crop_rect(b, 960, 960) for b in boxes)]
+        labels, _ = po.cls_run(views)
+        for k, v in enumerate(views):
+            if labels[k] == 1:
+                O.rotate180_inplace(v)
+        texts, scores, _ = po.rec_run(views)
+        assert len(got[i]) == len(texts) == 32
+        for k, g in enumerate(got[i]):
+            assert np.array_equal(g["box"], boxes[k]) and np.array_equal(g["ids"], texts[k]) and g["confidence"] == scores[k]
+    pg.close()

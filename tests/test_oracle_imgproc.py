@@ -1,0 +1,139 @@
+"""Properties and cross-checks of the oracle's OpenCV-semantics restatements (no OpenCV exists in
+the container: these pin internal consistency, not OpenCV itself — see oracle/oracle_post.cpp header)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+from hypothesis import given, settings, strategies as st
+
+
+def _contours(O, bm):
+    H, W = bm.shape
+    pts = np.zeros(2 * 400000, np.int32)
+    sizes = np.zeros(20000, np.int32)
+    L = O.lib()
+    L.oracle_find_contours.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+    n = L.oracle_find_contours(np.ascontiguousarray(bm).ctypes.data, H, W, pts.ctypes.data, 400000, sizes.ctypes.data, 20000)
+    out, k = [], 0
+    for i in range(n):
+        out.append(pts[2 * k:2 * (k + sizes[i])].reshape(-1, 2).copy())
+        k += sizes[i]
+    return out
+
+
+def test_contours_known_shapes(built):
+    import oracle as O
+    bm = np.zeros((8, 10), np.uint8)
+    bm[2:5, 3:8] = 1
+    assert [c.tolist() for c in _contours(O, bm)] == [[[3, 2], [3, 4], [7, 4], [7, 2]]]
+    bm = np.zeros((8, 10), np.uint8)
+    bm[1:7, 1:9] = 1
+    bm[3:5, 3:6] = 0   # RETR_LIST returns the hole border too, and first (reverse discovery order)
+    cs = [c.tolist() for c in _contours(O, bm)]
+    assert cs[1] == [[1, 1], [1, 6], [8, 6], [8, 1]] and len(cs) == 2 and len(cs[0]) == 8
+    bm = np.zeros((5, 7), np.uint8)
+    bm[2, 1:6] = 1     # a 1-px run collapses to two points (dropped by the `size() <= 2` gate)
+    assert [c.tolist() for c in _contours(O, bm)] == [[[1, 2], [5, 2]]]
+    bm = np.ones((4, 5), np.uint8)  # touches every image border: handled through the 1-px zero frame
+    assert [c.tolist() for c in _contours(O, bm)] == [[[0, 0], [0, 3], [4, 3], [4, 0]]]
+
+
+def test_contour_count_is_components_plus_holes(built):
+    from scipy import ndimage
+    import oracle as O
+    rs = np.random.RandomState(0)
+    for _ in range(12):
+        H, W = rs.randint(20, 160), rs.randint(20, 160)
+        f = ndimage.gaussian_filter(rs.rand(H, W), rs.rand() * 3 + 0.5)
+        bm = (f > np.percentile(f, rs.randint(30, 80))).astype(np.uint8)
+        cs = _contours(O, bm)
+        _, nfg = ndimage.label(bm, structure=np.ones((3, 3)))
+        _, nbg = ndimage.label(np.pad(1 - bm, 1, constant_values=1))
+        assert len(cs) == nfg + nbg - 1
+        assert all(bm[p[:, 1], p[:, 0]].all() for p in cs)
+
+
+def test_min_area_rect_is_minimal(built):
+    from scipy.spatial import ConvexHull
+    import oracle as O
+    L = O.lib()
+    L.oracle_min_area_rect_i.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    rs = np.random.RandomState(0)
+    for _ in range(100):
+        pts = rs.randint(0, 300, (rs.randint(5, 60), 2)).astype(np.int32)
+        out = np.zeros(5, np.float32)
+        L.oracle_min_area_rect_i(np.ascontiguousarray(pts).ctypes.data, len(pts), out.ctypes.data)
+        h = pts[ConvexHull(pts).vertices].astype(np.float64)
+        best = min(np.ptp(h @ e) * np.ptp(h @ np.array([-e[1], e[0]]))
+                   for e in ((h[(i + 1) % len(h)] - h[i]) / np.linalg.norm(h[(i + 1) % len(h)] - h[i]) for i in range(len(h))))
+        assert abs(out[2] * out[3] - best) / best < 1e-5
+
+
+def test_resize_identity_area_and_range(built):
+    import oracle as O
+    rs = np.random.RandomState(0)
+    img = rs.randint(0, 256, (40, 60, 3)).astype(np.uint8)
+    assert np.array_equal(O.resize_u8c3(img, 40, 60), img)                       # dsize == ssize: copy
+    area = ((img[0::2, 0::2].astype(int) + img[0::2, 1::2] + img[1::2, 0::2] + img[1::2, 1::2] + 2) >> 2).astype(np.uint8)
+    assert np.array_equal(O.resize_u8c3(img, 20, 30), area)                      # exact 2x: INTER_AREA
+    flat = np.full((17, 23, 3), 131, np.uint8)
+    assert (O.resize_u8c3(flat, 48, 91) == 131).all()                            # constants stay constant
+    up = O.resize_u8c3(img, 77, 101)
+    assert up.min() >= img.min() and up.max() <= img.max()
+    view = img[5:25, 7:37]                                                        # ROI view with a row stride
+    assert np.array_equal(O.resize_u8c3(view, 48, 100), O.resize_u8c3(view.copy(), 48, 100))
+
+
+@settings(max_examples=200, deadline=None)
+@given(st.integers(1, 3000), st.integers(1, 3000), st.sampled_from(["max", "min"]), st.sampled_from([512, 736, 960]))
+def test_det_resize_shape_properties(h, w, limit_type, side):
+    import oracle as O
+    rh, rw, fh, fw = O.det_resize_shape(h, w, limit_type, side)
+    assert rh % 32 == 0 and rw % 32 == 0 and rh >= 32 and rw >= 32
+    assert fh == np.float32(rh) / np.float32(h) and fw == np.float32(rw) / np.float32(w)
+    if limit_type == "max":
+        assert max(rh, rw) <= side + 16 or max(h, w) <= side
+
+
+@settings(max_examples=200, deadline=None)
+@given(st.floats(0, 1, width=32), st.sampled_from([0.2, 0.3, 0.5]))
+def test_threshold_is_floor_on_truncated_byte(p, thr):
+    """cbuf = (uchar)(p*255); cv::threshold floors thr*255: bit = trunc(p*255) > floor(thr*255)."""
+    import oracle as O
+    bm = O.bitmap(np.array([[p]], np.float32), thr)
+    assert int(bm[0, 0]) == int(int(np.float32(p) * np.float32(255)) > int(np.floor(thr * 255)))
+
+
+@settings(max_examples=200, deadline=None)
+@given(st.lists(st.integers(0, 5), min_size=1, max_size=40))
+def test_ctc_collapse_rule(amax):
+    import oracle as O
+    pmax = np.linspace(0.5, 0.9, len(amax)).astype(np.float32)
+    ids, score = O.ctc_decode(np.array(amax, np.int32), pmax)
+    want = [a for i, a in enumerate(amax) if a > 0 and not (i > 0 and a == amax[i - 1])]
+    if not want:
+        assert ids is None        # NaN score: the reference `continue`s and leaves ""/0.0
+    else:
+        assert ids.tolist() == want
+        keep = [pmax[i] for i, a in enumerate(amax) if a > 0 and not (i > 0 and a == amax[i - 1])]
+        s = np.float32(0)
+        for v in keep:
+            s = np.float32(s + v)
+        assert score == np.float32(s / np.float32(len(keep)))
+
+
+def test_crop_rect(built):
+    import oracle as O
+    assert O.crop_rect([[10, 5], [50, 5], [50, 20], [10, 20]], 100, 100) == (10, 5, 41, 16)
+    assert O.crop_rect([[90, 90], [120, 90], [120, 130], [90, 130]], 100, 100) == (90, 90, 10, 10)
+    assert O.crop_rect([[100, 0], [120, 0], [120, 5], [100, 5]], 100, 100) is None
+
+
+def test_rec_preprocess_pad_and_cls_pad(built):
+    import oracle as O
+    crop = np.random.RandomState(0).randint(0, 256, (20, 30, 3)).astype(np.uint8)
+    x = O.rec_preprocess(crop, 48, 320)
+    assert x.shape == (48, 320, 3) and (x[:, 72:] == -1.0).all()      # u8 zero pad BEFORE normalise -> -1
+    c = O.cls_preprocess(crop)
+    assert c.shape == (48, 192, 3) and (c[:, 72:] == 0.0).all()       # cls pads with 0.0 AFTER normalise
+    assert np.array_equal(x[:, :72], c[:, :72])

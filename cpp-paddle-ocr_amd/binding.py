@@ -150,6 +150,8 @@ class Net:
 # ---------------------------------------------------------------------------------------------
 def _img(a):
     a = np.asarray(a)
+    if a.size == 0:
+        return ocr_img(None, 0, 0, 0)  # the library reports "Empty image data provided"
     assert a.dtype == np.uint8 and a.ndim == 3 and a.shape[2] == 3 and a.strides[2] == 1 and a.strides[1] == 3
     return ocr_img(a.ctypes.data, a.shape[0], a.shape[1], a.strides[0])
 

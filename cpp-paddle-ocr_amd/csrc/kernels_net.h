@@ -11,7 +11,8 @@ enum : int { OUT_C8I = 0, OUT_PLAIN = 1, OUT_DECONV = 2 };
 struct ConvArgs {
   const float* in;   // [N,H,W,Cs_in] C8I
   float* out;
-  const float* wfrag;  // [tap][C8][NTtot][64 lanes][4]
+  const float* wfrag;  // [tap][C8][NTtot][64 lanes][4], NTtot padded to a multiple of the launch's NT
+  const float* zeros;  // >= Cs_in zero floats (source of padded taps / rows beyond M)
   long M;              // N*OH*OW GEMM rows
   int N, H, W, Cs_in, C8;
   int OH, OW, Cs_out;
@@ -24,6 +25,8 @@ struct ConvArgs {
   int need_nyx;
 };
 void launch_conv_mfma(const ConvArgs& a, const Epilogue& ep, int nt, hipStream_t s);
+// column tiles per wave for a GEMM with `tiles` 32-wide column tiles
+inline int conv_nt_for(int tiles) { return tiles <= 4 ? tiles : (tiles % 4 == 0 ? 4 : (tiles % 3 == 0 ? 3 : 4)); }
 
 struct StemArgs {
   const float* in;  // [N,H,W,3] plain

@@ -169,30 +169,52 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(const ConvArgs a, const 
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
 
+  // K loop flattened over (tap, 8-channel group) with a one-deep register prefetch: the loads of
+  // step kk+1 are in flight while the 4*NT MFMAs of step kk issue (HBM/L2 latency is otherwise
+  // exposed once per 8 channels at the 2-3 waves/SIMD this kernel's accumulators allow).
   const float4* __restrict__ wf = (const float4*)a.wfrag;
-  for (int ky = 0; ky < a.KH; ++ky) {
-    for (int kx = 0; kx < a.KW; ++kx) {
-      const int iy = y - a.PH + ky, ix = x - a.PW + kx;
-      const bool v = mvalid && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-      const float* src = a.in + (((long)n * a.H + (v ? iy : 0)) * a.W + (v ? ix : 0)) * a.Cs_in + 4 * h;
-      const float4* wrow = wf + ((long)(ky * a.KW + kx) * a.C8 * a.NTtot + nt0) * 64 + lane;
-#pragma unroll 2
-      for (int c8 = 0; c8 < a.C8; ++c8) {
-        float4 av = *(const float4*)(src + c8 * 8);
-        if (!v) av = make_float4(0.f, 0.f, 0.f, 0.f);
-        const float4* wp = wrow + (long)c8 * a.NTtot * 64;
+  const int KK = a.KH * a.KW * a.C8;
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  // incremental (tap, c8) walk of the prefetch pointer: no division in the loop
+  int p_c8 = 0, p_ky = 0, p_kx = 0;
+  bool p_valid;
+  const float* p_src;
+  const float4* p_w = wf + (long)nt0 * 64 + lane;
+  auto set_tap = [&]() {
+    const int iy = y - a.PH + p_ky, ix = x - a.PW + p_kx;
+    p_valid = mvalid && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+    // padding / out-of-range rows read a zero page: the prefetched value is never touched by a select,
+    // so nothing has to wait for the load before the MFMAs of the current step issue
+    p_src = p_valid ? a.in + (((long)n * a.H + iy) * a.W + ix) * a.Cs_in + 4 * h : a.zeros + 4 * h;
+  };
+  set_tap();
+  auto load_step = [&](float4& av, float4 (&bv)[NT]) {
+    av = *(const float4*)(p_src + p_c8 * 8);
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-          if (nt0 + t < a.NTtot) {
-            const float4 bv = wp[t * 64];
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc[t], 0, 0, 0);
-          }
-        }
-      }
+    for (int t = 0; t < NT; ++t) bv[t] = p_w[t * 64];  // the fragment image is padded to whole NT groups
+    p_w += (long)a.NTtot * 64;
+    if (++p_c8 == a.C8) {
+      p_c8 = 0;
+      if (++p_kx == a.KW) { p_kx = 0; ++p_ky; }
+      if (p_ky < a.KH) set_tap();
     }
+  };
+  float4 av_cur, bv_cur[NT], av_nxt = zero4, bv_nxt[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) bv_nxt[t] = zero4;
+  load_step(av_cur, bv_cur);
+  for (int kk = 0; kk < KK; ++kk) {
+    if (kk + 1 < KK) load_step(av_nxt, bv_nxt);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av_cur.x, bv_cur[t].x, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av_cur.y, bv_cur[t].y, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av_cur.z, bv_cur[t].z, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av_cur.w, bv_cur[t].w, acc[t], 0, 0, 0);
+    }
+    av_cur = av_nxt;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) bv_cur[t] = bv_nxt[t];
   }
 
   // ---- epilogue: lane owns output column j (one channel), 16 rows ----
@@ -256,42 +278,95 @@ void launch_stem(const StemArgs& a, const Epilogue& ep, hipStream_t s) {
 }
 
 // =====================================================================================
-// Depthwise conv, VALU.  One thread = one output pixel x 4 physical channels.
+// Depthwise conv, VALU.  One thread = TO consecutive output pixels of a row x 4 physical channels:
+// each input row segment is loaded once into registers and reused by the K taps of all TO outputs
+// (K*((TO-1)*SW+K)/TO loads per output instead of K*K).  Every output still accumulates its taps in
+// (ky, kx) order: the arithmetic contract is untouched.
 // =====================================================================================
-template <int K>
+template <int K, int SW, int TO>
 __global__ void __launch_bounds__(256) dw_conv_kernel(const DwArgs a, const Epilogue ep) {
+  constexpr int NIN = (TO - 1) * SW + K;
   const long t = (long)blockIdx.x * 256 + threadIdx.x;
   const int c4n = a.Cs >> 2;
-  if (t >= a.M * c4n) return;
-  const long m = t / c4n;
-  const int pc = (int)(t - m * c4n) * 4;
-  int n, y, x;
-  decompose(m, a.OH * a.OW, a.OW, n, y, x);
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int strips = (a.OW + TO - 1) / TO;
+  const long nstrip = (long)a.N * a.OH * strips;
+  if (t >= nstrip * c4n) return;
+  const long sidx = t / c4n;
+  const int pc = (int)(t - sidx * c4n) * 4;
+  const int sx = (int)(sidx % strips);
+  const long ny = sidx / strips;
+  const int y = (int)(ny % a.OH), n = (int)(ny / a.OH);
+  const int x0 = sx * TO;
+  float4 acc[TO];
 #pragma unroll
-  for (int ky = 0; ky < K; ++ky)
+  for (int o = 0; o < TO; ++o) acc[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int ixb = x0 * SW - a.PW;
+#pragma unroll 1
+  for (int ky = 0; ky < K; ++ky) {  // one input row at a time keeps ~60 VGPRs live (occupancy), K rows would not
+    const int iy = y * a.SH - a.PH + ky;
+    const bool rv = iy >= 0 && iy < a.H;
+    const float* row = a.in + (((long)n * a.H + (rv ? iy : 0)) * a.W) * a.Cs + pc;
+    float4 in[NIN];
+#pragma unroll
+    for (int j = 0; j < NIN; ++j) {
+      const int ix = ixb + j;
+      in[j] = (rv && ix >= 0 && ix < a.W) ? *(const float4*)(row + (long)ix * a.Cs) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
 #pragma unroll
     for (int kx = 0; kx < K; ++kx) {
-      const int iy = y * a.SH - a.PH + ky, ix = x * a.SW - a.PW + kx;
-      const bool v = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-      float4 av = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (v) av = *(const float4*)(a.in + (((long)n * a.H + iy) * a.W + ix) * a.Cs + pc);
       const float4 wv = *(const float4*)(a.w + (long)(ky * K + kx) * a.Cs + pc);
-      acc.x = fmaf(av.x, wv.x, acc.x);
-      acc.y = fmaf(av.y, wv.y, acc.y);
-      acc.z = fmaf(av.z, wv.z, acc.z);
-      acc.w = fmaf(av.w, wv.w, acc.w);
+#pragma unroll
+      for (int o = 0; o < TO; ++o) {
+        const float4 v = in[o * SW + kx];
+        acc[o].x = fmaf(v.x, wv.x, acc[o].x);
+        acc[o].y = fmaf(v.y, wv.y, acc[o].y);
+        acc[o].z = fmaf(v.z, wv.z, acc[o].z);
+        acc[o].w = fmaf(v.w, wv.w, acc[o].w);
+      }
     }
-  const long oidx = m * a.Cs + pc;
-  acc = apply_epilogue4(ep, acc, pc, n, y, x, oidx, a.Cs);
-  *(float4*)(a.out + oidx) = acc;
+  }
+  // epilogue: stage loop outside, the TO outputs inside (one copy of each stage's code)
+  const long obase = (((long)n * a.OH + y) * a.OW + x0) * a.Cs + pc;
+  for (int s = 0; s < ep.n; ++s) {
+    const EpStage& st = ep.st[s];
+#pragma unroll
+    for (int o = 0; o < TO; ++o) {
+      float4& v = acc[o];
+      switch (st.kind) {
+        case EP_BIAS: { const float4 b = *(const float4*)(st.v0 + pc); v.x = v.x + b.x; v.y = v.y + b.y; v.z = v.z + b.z; v.w = v.w + b.w; } break;
+        case EP_SMUL: v.x = st.p0 * v.x; v.y = st.p0 * v.y; v.z = st.p0 * v.z; v.w = st.p0 * v.w; break;
+        case EP_SADD: v.x = v.x + st.p0; v.y = v.y + st.p0; v.z = v.z + st.p0; v.w = v.w + st.p0; break;
+        case EP_BN: {
+          const float4 sc = *(const float4*)(st.v0 + pc), sh = *(const float4*)(st.v1 + pc);
+          float t;
+          t = v.x * sc.x; v.x = t + sh.x;
+          t = v.y * sc.y; v.y = t + sh.y;
+          t = v.z * sc.z; v.z = t + sh.z;
+          t = v.w * sc.w; v.w = t + sh.w;
+        } break;
+        case EP_ACT:
+          v.x = ocr_act(st.act, st.p0, st.p1, v.x); v.y = ocr_act(st.act, st.p0, st.p1, v.y);
+          v.z = ocr_act(st.act, st.p0, st.p1, v.z); v.w = ocr_act(st.act, st.p0, st.p1, v.w);
+          break;
+        case EP_MULC: { const float4 g = *(const float4*)(st.v0 + (long)n * a.Cs + pc); v.x = v.x * g.x; v.y = v.y * g.y; v.z = v.z * g.z; v.w = v.w * g.w; } break;
+        case EP_ADDT: if (x0 + o < a.OW) { const float4 g = *(const float4*)(st.v0 + obase + (long)o * a.Cs); v.x = v.x + g.x; v.y = v.y + g.y; v.z = v.z + g.z; v.w = v.w + g.w; } break;
+        default: break;  // ADDUP never follows a depthwise conv on this path (host checks)
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 0; o < TO; ++o)
+    if (x0 + o < a.OW) *(float4*)(a.out + obase + (long)o * a.Cs) = acc[o];
 }
 
 void launch_dw(const DwArgs& a, const Epilogue& ep, hipStream_t s) {
-  const long total = a.M * (a.Cs >> 2);
+  constexpr int TO = 4;
+  const long total = (long)a.N * a.OH * ((a.OW + TO - 1) / TO) * (a.Cs >> 2);
   dim3 grid((unsigned)((total + 255) / 256));
-  if (a.K == 3) hipLaunchKernelGGL(dw_conv_kernel<3>, grid, dim3(256), 0, s, a, ep);
-  else hipLaunchKernelGGL(dw_conv_kernel<5>, grid, dim3(256), 0, s, a, ep);
+  if (a.K == 3 && a.SW == 1) hipLaunchKernelGGL((dw_conv_kernel<3, 1, TO>), grid, dim3(256), 0, s, a, ep);
+  else if (a.K == 3) hipLaunchKernelGGL((dw_conv_kernel<3, 2, TO>), grid, dim3(256), 0, s, a, ep);
+  else if (a.SW == 1) hipLaunchKernelGGL((dw_conv_kernel<5, 1, TO>), grid, dim3(256), 0, s, a, ep);
+  else hipLaunchKernelGGL((dw_conv_kernel<5, 2, TO>), grid, dim3(256), 0, s, a, ep);
 }
 
 // =====================================================================================

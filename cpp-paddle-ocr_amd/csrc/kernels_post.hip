@@ -71,25 +71,47 @@ __device__ __forceinline__ void uf_unite(int* L, int a, int b) {
     else done = true;
   } while (!done);
 }
-__global__ void __launch_bounds__(256) ccl_init_kernel(int* __restrict__ L, uint8_t* __restrict__ touch, long total) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= total) return;
-  L[i] = (int)i;
-  touch[i] = 0;
+// Initial labels = start pixel of the horizontal run (same value as the left neighbours) a pixel lies in:
+// one wave walks one image row in 64-pixel segments (ballot + carry), so the union-find below only
+// has to join RUNS, not pixels.
+__global__ void __launch_bounds__(256) ccl_rows_kernel(const uint8_t* __restrict__ bm, int* __restrict__ L,
+                                                       uint8_t* __restrict__ touch, int N, int H, int W) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= (long)N * H) return;
+  const long base = row * W;
+  int carry = 0;
+  for (int x0 = 0; x0 < W; x0 += 64) {
+    const int x = x0 + lane;
+    const bool in = x < W;
+    const uint8_t v = in ? bm[base + x] : 2;
+    const uint8_t pv = (in && x > 0) ? bm[base + x - 1] : 3;
+    const bool st = in && (v != pv);
+    const unsigned long long bal = __ballot(st);
+    const unsigned long long below = bal & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
+    const int rs = below ? x0 + (63 - __clzll(below)) : carry;
+    if (in) {
+      L[base + x] = (int)(base + rs);
+      touch[base + x] = 0;
+    }
+    carry = __shfl(rs, 63);
+  }
 }
+__device__ __forceinline__ bool run_start(const uint8_t* bm, long i, int x) { return x == 0 || bm[i - 1] != bm[i]; }
 __global__ void __launch_bounds__(256) ccl_merge_kernel(const uint8_t* __restrict__ bm, int* __restrict__ L, int N, int H,
                                                         int W) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= (long)N * H * W) return;
   const int x = (int)(i % W), y = (int)((i / W) % H);
-  const uint8_t v = bm[i];
-  if (x > 0 && bm[i - 1] == v) uf_unite(L, (int)i, (int)(i - 1));
-  if (y > 0) {
-    if (bm[i - W] == v) uf_unite(L, (int)i, (int)(i - W));
-    if (v) {  // 8-connectivity for the foreground only
-      if (x > 0 && bm[i - W - 1]) uf_unite(L, (int)i, (int)(i - W - 1));
-      if (x < W - 1 && bm[i - W + 1]) uf_unite(L, (int)i, (int)(i - W + 1));
-    }
+  if (y == 0) return;
+  const uint8_t v = bm[i], up = bm[i - W];
+  if (up == v) {
+    // two vertically overlapping runs are joined once, at the leftmost column of the overlap
+    if (run_start(bm, i, x) || run_start(bm, i - W, x)) uf_unite(L, (int)i, (int)(i - W));
+  } else if (v) {
+    // 8-connectivity of the foreground: diagonal-only contacts
+    if (x > 0 && bm[i - W - 1]) uf_unite(L, (int)i, (int)(i - W - 1));
+    if (x < W - 1 && bm[i - W + 1]) uf_unite(L, (int)i, (int)(i - W + 1));
   }
 }
 __global__ void __launch_bounds__(256) ccl_flatten_kernel(const uint8_t* __restrict__ bm, int* __restrict__ L,
@@ -106,7 +128,7 @@ __global__ void __launch_bounds__(256) ccl_flatten_kernel(const uint8_t* __restr
 void launch_ccl(const uint8_t* bm, int* L, uint8_t* touch, int N, int H, int W, hipStream_t s) {
   const long total = (long)N * H * W;
   const dim3 g((unsigned)((total + 255) / 256));
-  hipLaunchKernelGGL(ccl_init_kernel, g, dim3(256), 0, s, L, touch, total);
+  hipLaunchKernelGGL(ccl_rows_kernel, dim3((unsigned)(((long)N * H + 3) / 4)), dim3(256), 0, s, bm, L, touch, N, H, W);
   hipLaunchKernelGGL(ccl_merge_kernel, g, dim3(256), 0, s, bm, L, N, H, W);
   hipLaunchKernelGGL(ccl_flatten_kernel, g, dim3(256), 0, s, bm, L, touch, N, H, W);
 }

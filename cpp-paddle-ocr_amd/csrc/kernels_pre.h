@@ -27,6 +27,13 @@ struct LineDesc {
 void launch_line_pre(const LineDesc* lines, int nlines, int imgH, int imgW, const float* lut, bool pad_after_norm,
                      float* out, hipStream_t s);
 void launch_rotate180(uint8_t* img, size_t stride, int x0, int y0, int w, int h, hipStream_t s);
+struct RotDesc {
+  uint8_t* img;
+  size_t stride;
+  int x, y, w, h;
+};
+// seg: nimages+1 offsets into d; rotations of one image are applied in order by one workgroup
+void launch_rotate180_list(const RotDesc* d, const int* seg, int nimages, hipStream_t s);
 void launch_ctc(const int* amax, const float* pmax, int nlines, int T, int max_len, int* ids, int* lens, float* scores,
                 hipStream_t s);
 

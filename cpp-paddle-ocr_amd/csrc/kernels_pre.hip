@@ -149,6 +149,29 @@ void launch_rotate180(uint8_t* img, size_t stride, int x0, int y0, int w, int h,
   hipLaunchKernelGGL(rotate180_kernel, dim3((unsigned)((half + 255) / 256)), dim3(256), 0, s, img, stride, x0, y0, w, h);
 }
 
+// The same for a whole batch: one workgroup per image applies that image's rotations in request order
+// (ROIs of one image may overlap, so their order matters; different images are independent).
+__global__ void __launch_bounds__(1024) rotate180_list_kernel(const RotDesc* __restrict__ d, const int* __restrict__ seg) {
+  const int b = blockIdx.x;
+  for (int r = seg[b]; r < seg[b + 1]; ++r) {
+    const RotDesc q = d[r];
+    const long total = (long)q.w * q.h;
+    for (long i = threadIdx.x; i < total / 2; i += 1024) {
+      const long j = total - 1 - i;
+      uint8_t* pa = q.img + (size_t)(q.y + i / q.w) * q.stride + (size_t)(q.x + i % q.w) * 3;
+      uint8_t* pb = q.img + (size_t)(q.y + j / q.w) * q.stride + (size_t)(q.x + j % q.w) * 3;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { const uint8_t t = pa[c]; pa[c] = pb[c]; pb[c] = t; }
+    }
+    __threadfence_block();
+    __syncthreads();
+  }
+}
+void launch_rotate180_list(const RotDesc* d, const int* seg, int nimages, hipStream_t s) {
+  if (nimages <= 0) return;
+  hipLaunchKernelGGL(rotate180_list_kernel, dim3(nimages), dim3(1024), 0, s, d, seg);
+}
+
 // greedy CTC collapse, one thread per line (sequential over T: the score sum order of the reference)
 __global__ void __launch_bounds__(64) ctc_kernel(const int* __restrict__ amax, const float* __restrict__ pmax, int nlines,
                                                  int T, int max_len, int* __restrict__ ids, int* __restrict__ lens,

@@ -160,7 +160,8 @@ static std::vector<float> perm_vec(const std::vector<float>& v, int C, bool plai
 // get(col, k, tap) returns the weight of GEMM column `col`, input channel k, tap.
 template <class Get>
 static std::vector<float> build_frag(int taps, int cin, int cols, Get get) {
-  const int C8 = c8i_stride(cin) / 8, NT = (cols + 31) / 32;
+  const int C8 = c8i_stride(cin) / 8, tiles = (cols + 31) / 32, g = conv_nt_for(tiles);
+  const int NT = (tiles + g - 1) / g * g;  // whole groups of the launch's tiles-per-wave (zero tiles pad)
   std::vector<float> f((size_t)taps * C8 * NT * 64 * 4, 0.f);
   for (int tap = 0; tap < taps; ++tap)
     for (int c8 = 0; c8 < C8; ++c8)
@@ -302,6 +303,7 @@ bool Net::load(const char* plan_text, const WeightMap& W, std::string& err) {
     }
   }
   if (out_tid_ < 0) { err = "plan has no output"; return false; }
+  if (!upload("zeros", std::vector<float>(4096, 0.f))) { err = "hipMalloc failed"; return false; }
   return true;
 }
 
@@ -500,10 +502,12 @@ bool Net::bind(int N, int H, int W, std::string& err) {
             a.OH = o.h; a.OW = o.w; a.Cs_out = o.cs; a.Cout = op.cout; a.CoutPadded = o.cs;
             a.ColsStore = o.plain ? op.cout : o.cs; a.out_mode = o.plain ? OUT_PLAIN : OUT_C8I;
           }
-          a.NTtot = (a.ColsStore + 31) / 32;
+          const int tiles = (a.ColsStore + 31) / 32;
+          const int nt = conv_nt_for(tiles);
+          a.NTtot = (tiles + nt - 1) / nt * nt;
+          a.zeros = dev_vec("zeros");
           a.M = (long)in.n * a.OH * a.OW;
           if (op.kind == PlanOp::LINEAR) a.M = (long)in.n * in.h * in.w;
-          int nt = a.NTtot <= 4 ? a.NTtot : (a.NTtot % 4 == 0 ? 4 : (a.NTtot % 3 == 0 ? 3 : 4));
           const int taps = a.KH * a.KW;
           const char* kind = op.kind == PlanOp::DECONV ? "deconv" : (op.kind == PlanOp::LINEAR ? "linear" : "conv");
           snprintf(nm, sizeof nm, "%s.%02d.%s%dx%d_%d_%d", plan_.name.c_str(), oi, kind, a.KH, a.KW, op.cin, op.cout);
@@ -518,6 +522,7 @@ bool Net::bind(int N, int H, int W, std::string& err) {
         const TensorDesc& in = T[op.in];
         Epilogue ep;
         if (!build_epilogue(op, ep, false, err)) return false;
+        for (auto& st : op.ep) if (st.kind == EP_ADDUP) { err = "addup after a depthwise conv is not on this path"; return false; }
         DwArgs a{};
         a.in = arena_ + in.offset; a.out = optr; a.w = dev_vec("dw:" + op.w);
         a.N = in.n; a.H = in.h; a.W = in.w; a.OH = o.h; a.OW = o.w; a.Cs = o.cs; a.K = op.kh;

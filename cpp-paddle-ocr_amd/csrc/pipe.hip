@@ -23,6 +23,8 @@ struct ocr_pipe {
   std::unique_ptr<ClsStage> cls;
   int device = 0;
   DevBuf<uint8_t> upload;
+  DevBuf<RotDesc> rot_desc;
+  DevBuf<int> rot_seg;
   std::vector<int32_t> boxes;
   std::vector<int> nbox;
 
@@ -64,11 +66,25 @@ struct ocr_pipe {
       std::vector<float> scores(lines.size());
       rc = cls->run_lines(lines, labels.data(), scores.data(), err);
       if (rc) return rc;
-      // rotate in request order, in place on the device copy (cv::rotate on ROI views aliasing the image)
-      for (size_t i = 0; i < lines.size(); ++i)
-        if (labels[i] == 1)
-          launch_rotate180(const_cast<uint8_t*>(lines[i].img), lines[i].stride, lines[i].x, lines[i].y, lines[i].w, lines[i].h,
-                           cls->stream());
+      // rotate in request order, in place on the device copy (cv::rotate on ROI views aliasing the image):
+      // one workgroup per image walks that image's rotations sequentially
+      std::vector<RotDesc> rd;
+      std::vector<int> rseg(1, 0);
+      for (int i = 0; i < count; ++i) {
+        for (int k = seg[i]; k < seg[i + 1]; ++k)
+          if (labels[k] == 1)
+            rd.push_back(RotDesc{const_cast<uint8_t*>(lines[k].img), lines[k].stride, lines[k].x, lines[k].y, lines[k].w, lines[k].h});
+        rseg.push_back((int)rd.size());
+      }
+      if (!rd.empty()) {
+        if (!rot_desc.ensure(rd.size(), err) || !rot_seg.ensure(rseg.size(), err)) return OCR_ERR_DEVICE;
+        if (hipMemcpyAsync(rot_desc.p, rd.data(), rd.size() * sizeof(RotDesc), hipMemcpyHostToDevice, cls->stream()) != hipSuccess ||
+            hipMemcpyAsync(rot_seg.p, rseg.data(), rseg.size() * sizeof(int), hipMemcpyHostToDevice, cls->stream()) != hipSuccess) {
+          err = "rotation list upload failed";
+          return OCR_ERR_DEVICE;
+        }
+        launch_rotate180_list(rot_desc.p, rot_seg.p, count, cls->stream());
+      }
       if (hipStreamSynchronize(cls->stream()) != hipSuccess) { err = "cls stream sync failed"; return OCR_ERR_DEVICE; }
     }
     double t2 = now_ms();

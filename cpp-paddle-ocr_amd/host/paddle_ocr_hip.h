@@ -1,0 +1,377 @@
+// Host layer above the C-ABI (include/ocr_hip.h): the reference's operator interface for this path
+// with the same names, argument meaning and error behaviour, over an ImageView instead of cv::Mat.
+//
+//   PaddleOCR::DBDetector      /root/reference/include/paddle_ocr/ocr_det.h:28-131
+//   PaddleOCR::Classifier      /root/reference/include/paddle_ocr/ocr_cls.h:28-104
+//   PaddleOCR::CRNNRecognizer  /root/reference/include/paddle_ocr/ocr_rec.h:28-122
+//   PaddleOCR::OCRRequest / WordResult / OCRResult / OCRWorker   include/paddle_ocr/ocr_worker.h:22-94
+//   PaddleOCR::GPUWorkerPool   include/paddle_ocr/gpu_worker_pool.h:14-31
+//
+// Differences, all forced by the missing third-party types: images are `ImageView` (the fields of a
+// CV_8UC3 cv::Mat that the path reads); the worker's result is an OCRResult plus a JSON string with
+// the reference's keys (src/ocr_worker.cpp:155-190) written by a 40-line emitter instead of jsoncpp.
+// Header-only; link with -locr_hip.
+#pragma once
+#include <atomic>
+#include <condition_variable>
+#include <cstdint>
+#include <cstring>
+#include <future>
+#include <memory>
+#include <mutex>
+#include <queue>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/ocr_hip.h"
+
+namespace PaddleOCR {
+
+// The part of cv::Mat this path uses: CV_8UC3 BGR rows, possibly an ROI of a larger image.
+struct ImageView {
+  const uint8_t* data = nullptr;
+  int rows = 0, cols = 0;
+  size_t step = 0;  // bytes per row
+  bool empty() const { return !data || rows <= 0 || cols <= 0; }
+  ImageView roi(int x, int y, int w, int h) const { return ImageView{data + (size_t)y * step + (size_t)x * 3, h, w, step}; }
+  ocr_img c() const { return ocr_img{data, rows, cols, step}; }
+};
+
+// An owning image (cv::Mat::clone()).
+struct Image {
+  std::vector<uint8_t> pixels;
+  int rows = 0, cols = 0;
+  Image() = default;
+  explicit Image(const ImageView& v) : rows(v.rows), cols(v.cols) {
+    if (!v.empty()) {
+      pixels.resize((size_t)rows * cols * 3);
+      for (int y = 0; y < rows; ++y) memcpy(&pixels[(size_t)y * cols * 3], v.data + (size_t)y * v.step, (size_t)cols * 3);
+    }
+  }
+  ImageView view() const { return ImageView{pixels.data(), rows, cols, (size_t)cols * 3}; }
+  bool empty() const { return pixels.empty(); }
+};
+
+inline void check_ocr(int rc, const char* what) {
+  if (rc != OCR_OK) throw std::runtime_error(std::string(what) + ": " + ocr_last_error());
+}
+
+class DBDetector {
+ public:
+  // Same parameter list as the reference constructor (ocr_det.h:60-75).  use_gpu must be true: this
+  // build is the GPU path; gpu_mem / cpu threads / mkldnn / tensorrt are accepted and ignored.
+  explicit DBDetector(const std::string& model_dir, const bool& use_gpu, const int& gpu_id, const int& /*gpu_mem*/,
+                      const int& /*cpu_math_library_num_threads*/, const bool& /*use_mkldnn*/, const std::string& limit_type,
+                      const int& limit_side_len, const double& det_db_thresh, const double& det_db_box_thresh,
+                      const double& det_db_unclip_ratio, const std::string& det_db_score_mode, const bool& use_dilation,
+                      const bool& /*use_tensorrt*/, const std::string& precision) {
+    if (!use_gpu) throw std::runtime_error("DBDetector: this build has no CPU path (use_gpu must be true)");
+    ocr_det_cfg c;
+    ocr_det_cfg_default(&c);
+    c.model_dir = model_dir.c_str(); c.device_id = gpu_id; c.limit_type = limit_type.c_str();
+    c.limit_side_len = limit_side_len; c.det_db_thresh = det_db_thresh; c.det_db_box_thresh = det_db_box_thresh;
+    c.det_db_unclip_ratio = det_db_unclip_ratio; c.det_db_score_mode = det_db_score_mode.c_str();
+    c.use_dilation = use_dilation; c.precision = precision.c_str();
+    check_ocr(ocr_det_create(&c, &h_), "DBDetector");  // the reference exit(1)s here (ocr_det.cpp:41-45); we throw
+  }
+  ~DBDetector() { ocr_det_destroy(h_); }
+  DBDetector(const DBDetector&) = delete;
+  DBDetector& operator=(const DBDetector&) = delete;
+
+  // void Run(const cv::Mat&, vector<vector<vector<int>>>& boxes, vector<double>& times)  (ocr_det.h:95-97)
+  void Run(const ImageView& img, std::vector<std::vector<std::vector<int>>>& boxes, std::vector<double>& times) {
+    std::vector<int32_t> flat(1000 * 8);
+    int n = 0;
+    double t[3] = {0, 0, 0};
+    ocr_img im = img.c();
+    check_ocr(ocr_det_run(h_, &im, flat.data(), 1000, &n, t), "DBDetector::Run");
+    boxes.clear();
+    for (int i = 0; i < n; ++i) {
+      std::vector<std::vector<int>> b(4, std::vector<int>(2));
+      for (int k = 0; k < 4; ++k) { b[k][0] = flat[i * 8 + 2 * k]; b[k][1] = flat[i * 8 + 2 * k + 1]; }
+      boxes.emplace_back(std::move(b));
+    }
+    times.insert(times.end(), t, t + 3);
+  }
+
+ private:
+  ocr_det* h_ = nullptr;
+};
+
+class Classifier {
+ public:
+  explicit Classifier(const std::string& model_dir, const bool& use_gpu, const int& gpu_id, const int& /*gpu_mem*/,
+                      const int& /*cpu_math_library_num_threads*/, const bool& /*use_mkldnn*/, const double& cls_thresh,
+                      const bool& /*use_tensorrt*/, const std::string& precision, const int& cls_batch_num) {
+    if (!use_gpu) throw std::runtime_error("Classifier: this build has no CPU path (use_gpu must be true)");
+    ocr_cls_cfg c;
+    ocr_cls_cfg_default(&c);
+    c.model_dir = model_dir.c_str(); c.device_id = gpu_id; c.cls_thresh = cls_thresh; c.cls_batch_num = cls_batch_num;
+    c.precision = precision.c_str();
+    check_ocr(ocr_cls_create(&c, &h_), "Classifier");
+  }
+  ~Classifier() { ocr_cls_destroy(h_); }
+  Classifier(const Classifier&) = delete;
+  Classifier& operator=(const Classifier&) = delete;
+  // outputs are pre-sized by the caller (ocr_worker.cpp:271-272)
+  void Run(const std::vector<ImageView>& img_list, std::vector<int>& cls_labels, std::vector<float>& cls_scores,
+           std::vector<double>& times) {
+    std::vector<ocr_img> v;
+    for (auto& i : img_list) v.push_back(i.c());
+    double t[3] = {0, 0, 0};
+    check_ocr(ocr_cls_run(h_, v.data(), (int)v.size(), cls_labels.data(), cls_scores.data(), t), "Classifier::Run");
+    times.insert(times.end(), t, t + 3);
+  }
+
+ private:
+  ocr_cls* h_ = nullptr;
+};
+
+class CRNNRecognizer {
+ public:
+  explicit CRNNRecognizer(const std::string& model_dir, const bool& use_gpu, const int& gpu_id, const int& /*gpu_mem*/,
+                          const int& /*cpu_math_library_num_threads*/, const bool& /*use_mkldnn*/,
+                          const std::string& label_path, const bool& /*use_tensorrt*/, const std::string& precision,
+                          const int& rec_batch_num, const int& rec_img_h, const int& rec_img_w) {
+    if (!use_gpu) throw std::runtime_error("CRNNRecognizer: this build has no CPU path (use_gpu must be true)");
+    ocr_rec_cfg c;
+    ocr_rec_cfg_default(&c);
+    c.model_dir = model_dir.c_str(); c.device_id = gpu_id; c.label_path = label_path.c_str();
+    c.rec_batch_num = rec_batch_num; c.rec_img_h = rec_img_h; c.rec_img_w = rec_img_w; c.precision = precision.c_str();
+    check_ocr(ocr_rec_create(&c, &h_), "CRNNRecognizer");
+  }
+  ~CRNNRecognizer() { ocr_rec_destroy(h_); }
+  CRNNRecognizer(const CRNNRecognizer&) = delete;
+  CRNNRecognizer& operator=(const CRNNRecognizer&) = delete;
+  // rec_texts / rec_text_scores are pre-sized by the caller (ocr_worker.cpp:286-287); lines whose
+  // score would be NaN keep their previous content, like the reference's `continue` (ocr_rec.cpp:123-125)
+  void Run(const std::vector<ImageView>& img_list, std::vector<std::string>& rec_texts, std::vector<float>& rec_text_scores,
+           std::vector<double>& times) {
+    const int n = (int)img_list.size(), max_len = 512;
+    std::vector<ocr_img> v;
+    for (auto& i : img_list) v.push_back(i.c());
+    std::vector<int32_t> ids((size_t)n * max_len);
+    std::vector<int> lens(n);
+    std::vector<float> scores(n);
+    double t[3] = {0, 0, 0};
+    check_ocr(ocr_rec_run(h_, v.data(), n, ids.data(), max_len, lens.data(), scores.data(), t), "CRNNRecognizer::Run");
+    for (int i = 0; i < n; ++i) {
+      if (lens[i] == 0) continue;
+      std::string s;
+      for (int k = 0; k < lens[i]; ++k) s += ocr_rec_label(h_, ids[(size_t)i * max_len + k]);
+      rec_texts[i] = std::move(s);
+      rec_text_scores[i] = scores[i];
+    }
+    times.insert(times.end(), t, t + 3);
+  }
+
+ private:
+  ocr_rec* h_ = nullptr;
+};
+
+// ---------------------------------------------------------------- worker (ocr_worker.h:22-94)
+struct OCRRequest {
+  int request_id;
+  Image image_data;  // deep copy, like `image_data(img.clone())`
+  std::promise<std::string> result_promise;
+  OCRRequest(int id, const ImageView& img) : request_id(id), image_data(img) {}
+};
+struct WordResult {
+  std::string text;
+  std::vector<std::vector<int>> box;
+  float confidence;
+};
+struct OCRResult {
+  int request_id = 0;
+  bool success = false;
+  int width = 0, height = 0;
+  std::string error_message;
+  std::vector<WordResult> words;
+  double processing_time_ms = 0;
+};
+
+namespace detail {
+inline void json_escape(std::string& o, const std::string& s) {
+  o += '"';
+  for (unsigned char ch : s) {
+    switch (ch) {
+      case '"': o += "\\\""; break;
+      case '\\': o += "\\\\"; break;
+      case '\n': o += "\\n"; break;
+      case '\r': o += "\\r"; break;
+      case '\t': o += "\\t"; break;
+      default:
+        if (ch < 0x20) { char b[8]; snprintf(b, sizeof b, "\\u%04x", ch); o += b; }
+        else o += (char)ch;  // emitUTF8 = true (ocr_worker.cpp:188)
+    }
+  }
+  o += '"';
+}
+// keys and order as jsoncpp emits them (alphabetical), no indentation (ocr_worker.cpp:155-190)
+inline std::string result_json(const OCRResult& r, int worker_id) {
+  std::string o = "{";
+  char buf[64];
+  if (!r.success) { o += "\"error\":"; json_escape(o, r.error_message); o += ","; }
+  snprintf(buf, sizeof buf, "\"height\":%d,", r.height); o += buf;
+  snprintf(buf, sizeof buf, "\"processing_time_ms\":%.17g,", r.processing_time_ms); o += buf;
+  snprintf(buf, sizeof buf, "\"request_id\":%d,", r.request_id); o += buf;
+  o += std::string("\"success\":") + (r.success ? "true" : "false") + ",";
+  snprintf(buf, sizeof buf, "\"width\":%d,", r.width); o += buf;
+  if (r.success) {
+    o += "\"words\":[";
+    for (size_t i = 0; i < r.words.size(); ++i) {
+      const WordResult& w = r.words[i];
+      if (i) o += ",";
+      o += "{\"box\":[";
+      for (size_t k = 0; k < w.box.size(); ++k) {
+        snprintf(buf, sizeof buf, "%s[%d,%d]", k ? "," : "", w.box[k][0], w.box[k][1]);
+        o += buf;
+      }
+      snprintf(buf, sizeof buf, "],\"confidence\":%.17g,\"text\":", (double)w.confidence);
+      o += buf;
+      json_escape(o, w.text);
+      o += "}";
+    }
+    o += "],";
+  }
+  snprintf(buf, sizeof buf, "\"worker_id\":%d}", worker_id); o += buf;
+  return o;
+}
+}  // namespace detail
+
+class OCRWorker {
+ public:
+  // OCRWorker(worker_id, model_dir, use_gpu, gpu_id = 0, enable_cls = false); hyper-parameters are the
+  // literals of the reference constructor (ocr_worker.cpp:21-63) — they are ocr_pipe_cfg_default().
+  OCRWorker(int worker_id, const std::string& model_dir, bool use_gpu, int gpu_id = 0, bool enable_cls = false)
+      : worker_id_(worker_id), running_(false), is_idle_(true) {
+    if (!use_gpu) throw std::runtime_error("OCRWorker: this build has no CPU path (use_gpu must be true)");
+    det_dir_ = model_dir + "/det"; cls_dir_ = model_dir + "/cls"; rec_dir_ = model_dir + "/rec";
+    dict_ = model_dir + "/rec/ppocr_keys_v1.txt";
+    ocr_pipe_cfg c;
+    ocr_pipe_cfg_default(&c);
+    c.det.model_dir = det_dir_.c_str(); c.det.device_id = gpu_id;
+    c.cls.model_dir = cls_dir_.c_str();
+    c.rec.model_dir = rec_dir_.c_str(); c.rec.label_path = dict_.c_str();
+    c.enable_cls = enable_cls;
+    check_ocr(ocr_pipe_create(&c, &pipe_), "OCRWorker");
+  }
+  virtual ~OCRWorker() { stop(); ocr_pipe_destroy(pipe_); }
+
+  void start() {
+    if (running_) return;
+    running_ = true;
+    worker_thread_ = std::thread(&OCRWorker::workerLoop, this);
+  }
+  void stop() {
+    if (!running_) return;
+    running_ = false;
+    cv_.notify_all();
+    if (worker_thread_.joinable()) worker_thread_.join();
+  }
+  void addRequest(std::shared_ptr<OCRRequest> request) {
+    { std::lock_guard<std::mutex> lock(queue_mutex_); request_queue_.push(request); }
+    cv_.notify_one();
+  }
+  bool isIdle() const { return is_idle_; }
+  int getWorkerId() const { return worker_id_; }
+
+  // processRequest (ocr_worker.cpp:213-311) — public here so tests can call it without the thread
+  OCRResult processRequest(const OCRRequest& request) {
+    const auto t0 = std::chrono::high_resolution_clock::now();
+    OCRResult result;
+    result.request_id = request.request_id;
+    result.success = false;
+    if (request.image_data.empty()) { result.error_message = "Empty image data provided"; return result; }
+    result.width = request.image_data.cols;
+    result.height = request.image_data.rows;
+    std::vector<ocr_word> words(1000);
+    std::vector<int32_t> ids(1000 * 256);
+    int off = 0, n = 0;
+    ocr_img im = request.image_data.view().c();
+    const int rc = ocr_pipe_run(pipe_, &im, 1, words.data(), (int)words.size(), &off, &n, ids.data(), (int)ids.size(), nullptr);
+    if (rc != OCR_OK) { result.error_message = ocr_last_error(); return result; }  // the reference's catch (...) path
+    result.success = true;
+    for (int i = 0; i < n; ++i) {
+      WordResult w;
+      for (int k = 0; k < words[i].ids_len; ++k) w.text += ocr_pipe_label(pipe_, ids[words[i].ids_off + k]);
+      w.confidence = words[i].confidence;
+      w.box.assign(4, std::vector<int>(2));
+      for (int k = 0; k < 4; ++k) { w.box[k][0] = words[i].box[2 * k]; w.box[k][1] = words[i].box[2 * k + 1]; }
+      result.words.push_back(std::move(w));
+    }
+    result.processing_time_ms =
+        std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count();
+    return result;
+  }
+
+ private:
+  void workerLoop() {
+    while (running_) {
+      std::shared_ptr<OCRRequest> request;
+      {
+        std::unique_lock<std::mutex> lock(queue_mutex_);
+        cv_.wait(lock, [this] { return !request_queue_.empty() || !running_; });
+        if (!running_) break;
+        if (!request_queue_.empty()) { request = request_queue_.front(); request_queue_.pop(); is_idle_ = false; }
+      }
+      if (request) {
+        OCRResult r;
+        try {
+          r = processRequest(*request);
+        } catch (const std::exception& e) {
+          r.request_id = request->request_id;
+          r.success = false;
+          r.error_message = e.what();
+        }
+        request->result_promise.set_value(detail::result_json(r, worker_id_));
+        is_idle_ = true;
+      }
+    }
+  }
+
+  int worker_id_;
+  std::atomic<bool> running_, is_idle_;
+  std::thread worker_thread_;
+  std::queue<std::shared_ptr<OCRRequest>> request_queue_;
+  std::mutex queue_mutex_;
+  std::condition_variable cv_;
+  ocr_pipe* pipe_ = nullptr;
+  std::string det_dir_, cls_dir_, rec_dir_, dict_;
+};
+
+// ---------------------------------------------------------------- pool (gpu_worker_pool.h:14-31)
+// The reference pins every worker to GPU 0 (gpu_worker_pool.cpp:12-16); here worker i runs on GPU
+// i mod ocr_rt_device_count(): whole images are sharded over the node's GPUs, nothing else changes.
+class GPUWorkerPool {
+ public:
+  GPUWorkerPool(const std::string& model_dir, int num_workers = 2) : next_worker_index_(0) {
+    const int ngpu = ocr_rt_device_count();
+    if (ngpu <= 0) throw std::runtime_error("GPUWorkerPool: no HIP device visible");
+    for (int i = 0; i < num_workers; ++i) workers_.emplace_back(std::make_unique<OCRWorker>(i, model_dir, true, i % ngpu));
+  }
+  ~GPUWorkerPool() { stop(); }
+  void start() { for (auto& w : workers_) w->start(); }
+  void stop() { for (auto& w : workers_) w->stop(); }
+  std::future<std::string> submitRequest(std::shared_ptr<OCRRequest> request) {
+    auto future = request->result_promise.get_future();
+    getAvailableWorker()->addRequest(request);
+    return future;
+  }
+  int getOptimalWorkerCount() { return ocr_rt_device_count(); }  // declared, never defined in the reference
+
+ private:
+  OCRWorker* getAvailableWorker() {  // first idle, else round robin (gpu_worker_pool.cpp:46-59)
+    std::lock_guard<std::mutex> lock(workers_mutex_);
+    for (auto& w : workers_) if (w->isIdle()) return w.get();
+    const int index = next_worker_index_.fetch_add(1) % (int)workers_.size();
+    return workers_[index].get();
+  }
+  std::vector<std::unique_ptr<OCRWorker>> workers_;
+  std::mutex workers_mutex_;
+  std::atomic<int> next_worker_index_;
+};
+
+}  // namespace PaddleOCR

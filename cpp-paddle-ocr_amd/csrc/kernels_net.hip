@@ -82,61 +82,63 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvArgs& a, const Epil
                                                    long m0, int p, int h, int hw) {
   const int co = nt * 32 + p;  // logical column of the GEMM
   if (nt >= a.NTtot || co >= a.ColsStore) return;
-  int ch = co, q = 0;  // channel for per-channel params; deconv quadrant
-  if (a.out_mode == OUT_DECONV) { q = co / a.CoutPadded; ch = co - q * a.CoutPadded; }
+  int ch = co, dq = 0;  // channel for per-channel params; deconv quadrant
+  if (a.out_mode == OUT_DECONV) { dq = co / a.CoutPadded; ch = co - dq * a.CoutPadded; }
   const int pc = (a.out_mode == OUT_PLAIN) ? ch : c8i_phys(ch);
   const bool is_pad = ch >= a.Cout;
   const long mb = m0 + 4 * h;  // row(r) = mb + (r&3) + 8*(r>>2)
-  float val[16];
+  // four registers (= four consecutive rows) at a time: keeps the epilogue's live set small so the
+  // kernel's VGPR budget is set by the main loop (occupancy), not by 16 interleaved divisions
 #pragma unroll
-  for (int r = 0; r < 16; ++r) val[r] = accv[r];
-  for (int s = 0; s < ep.n; ++s) {
-    const EpStage& st = ep.st[s];
-    switch (st.kind) {
-      case EP_BIAS: { const float b = st.v0[pc];
+  for (int g = 0; g < 4; ++g) {
+    float val[4];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) val[r] = val[r] + b; } break;
-      case EP_SMUL:
+    for (int q = 0; q < 4; ++q) val[q] = accv[4 * g + q];
+    const long mg = mb + 8 * g;
+    for (int s = 0; s < ep.n; ++s) {
+      const EpStage& st = ep.st[s];
+      switch (st.kind) {
+        case EP_BIAS: { const float b = st.v0[pc];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) val[r] = st.p0 * val[r];
-        break;
-      case EP_SADD:
+          for (int q = 0; q < 4; ++q) val[q] = val[q] + b; } break;
+        case EP_SMUL:
 #pragma unroll
-        for (int r = 0; r < 16; ++r) val[r] = val[r] + st.p0;
-        break;
-      case EP_BN: { const float sc = st.v0[pc], sh = st.v1[pc];
+          for (int q = 0; q < 4; ++q) val[q] = st.p0 * val[q];
+          break;
+        case EP_SADD:
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { const float t = val[r] * sc; val[r] = t + sh; } } break;
-      case EP_ACT:
+          for (int q = 0; q < 4; ++q) val[q] = val[q] + st.p0;
+          break;
+        case EP_BN: { const float sc = st.v0[pc], sh = st.v1[pc];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) val[r] = ocr_act(st.act, st.p0, st.p1, val[r]);
-        break;
-      case EP_ADDT:
+          for (int q = 0; q < 4; ++q) { const float t = val[q] * sc; val[q] = t + sh; } } break;
+        case EP_ACT:
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const long mr = mb + (r & 3) + 8 * (r >> 2);
-          if (mr < a.M) val[r] = val[r] + st.v0[mr * a.Cs_out + pc];
-        }
-        break;
-      default: break;
-    }
-  }
-  if (a.out_mode == OUT_DECONV) {
+          for (int q = 0; q < 4; ++q) val[q] = ocr_act(st.act, st.p0, st.p1, val[q]);
+          break;
+        case EP_ADDT:
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const long mr = mb + (r & 3) + 8 * (r >> 2);
-      if (mr < a.M) {
-        int rn, ry, rx;
-        decompose(mr, hw, a.OW, rn, ry, rx);
-        const long o = (((long)rn * (2 * a.OH) + 2 * ry + (q >> 1)) * (2 * a.OW) + 2 * rx + (q & 1)) * a.Cs_out + pc;
-        a.out[o] = is_pad ? 0.0f : val[r];
+          for (int q = 0; q < 4; ++q)
+            if (mg + q < a.M) val[q] = val[q] + st.v0[(mg + q) * a.Cs_out + pc];
+          break;
+        default: break;
       }
     }
-  } else {
+    if (a.out_mode == OUT_DECONV) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const long mr = mb + (r & 3) + 8 * (r >> 2);
-      if (mr < a.M) a.out[mr * a.Cs_out + pc] = is_pad ? 0.0f : val[r];
+      for (int q = 0; q < 4; ++q) {
+        const long mr = mg + q;
+        if (mr < a.M) {
+          int rn, ry, rx;
+          decompose(mr, hw, a.OW, rn, ry, rx);
+          const long o = (((long)rn * (2 * a.OH) + 2 * ry + (dq >> 1)) * (2 * a.OW) + 2 * rx + (dq & 1)) * a.Cs_out + pc;
+          a.out[o] = is_pad ? 0.0f : val[q];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (mg + q < a.M) a.out[(mg + q) * a.Cs_out + pc] = is_pad ? 0.0f : val[q];
     }
   }
 }
@@ -151,7 +153,7 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvArgs& a, const Epil
 // No LDS, no barriers: four independent waves per workgroup.
 // =====================================================================================
 template <int NT>
-__global__ void __launch_bounds__(256) conv_mfma_kernel(const ConvArgs a, const Epilogue ep) {
+__global__ void __launch_bounds__(256, (NT <= 2 ? 4 : 3)) conv_mfma_kernel(const ConvArgs a, const Epilogue ep) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int p = lane & 31, h = lane >> 5;
   const long m0 = ((long)blockIdx.x * 4 + wave) * 32;

@@ -1,0 +1,43 @@
+"""The C++ host layer (shim classes + OCRWorker + GPUWorkerPool over the C-ABI) through its test binary,
+which mirrors the reference's tests/test_ocr_worker.cpp; the JSON of the first request is compared with
+the oracle pipeline."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "cpp-paddle-ocr_amd", "host")
+
+
+def test_host_layer_compiles(built):
+    subprocess.check_call(["make", "-s", "-C", HOST])
+    assert os.path.exists(os.path.join(HOST, "test_worker"))
+
+
+@pytest.mark.gpu
+def test_worker_and_pool_binary(built, card, tmp_path):
+    from pipeline import Pipeline
+    subprocess.check_call(["make", "-s", "-C", HOST])
+    raw = tmp_path / "card.bgr"
+    card.tofile(raw)
+    out = subprocess.run([os.path.join(HOST, "test_worker"), os.path.join(ROOT, "models"), str(raw),
+                          "%dx%d" % card.shape[:2]], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "ALL OK" in out.stdout and "FAIL" not in out.stdout
+    js = json.loads([l for l in out.stdout.splitlines() if l.startswith("JSON ")][0][5:])
+    assert js["request_id"] == 100 and js["worker_id"] == 7 and js["success"] is True
+    assert js["width"] == card.shape[1] and js["height"] == card.shape[0] and js["processing_time_ms"] > 0
+    import oracle as O
+    want = Pipeline().process(card)["words"]
+    labels = ["#"] + open(os.path.join(ROOT, "models", "rec", "ppocr_keys_v1.txt"), encoding="utf-8").read().split("\n")
+    if labels[-1] == "":
+        labels.pop()
+    labels.append(" ")
+    assert len(js["words"]) == len(want)
+    for g, w in zip(js["words"], want):
+        assert g["box"] == np.asarray(w["box"]).tolist()
+        assert g["text"] == "".join(labels[i] for i in w["ids"])
+        assert np.float32(g["confidence"]) == np.float32(w["confidence"])

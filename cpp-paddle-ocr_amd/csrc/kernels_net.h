@@ -25,6 +25,8 @@ struct ConvArgs {
   int need_nyx;
 };
 void launch_conv_mfma(const ConvArgs& a, const Epilogue& ep, int nt, hipStream_t s);
+// LDS-staged variant of the same GEMM (default when K = taps*Cs_in >= 64)
+void launch_conv_lds(const ConvArgs& a, const Epilogue& ep, int nt, hipStream_t s);
 // column tiles per wave for a GEMM with `tiles` 32-wide column tiles
 inline int conv_nt_for(int tiles) { return tiles <= 4 ? tiles : (tiles % 4 == 0 ? 4 : (tiles % 3 == 0 ? 3 : 4)); }
 

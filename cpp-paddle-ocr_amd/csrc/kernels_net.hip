@@ -249,6 +249,164 @@ void launch_conv_mfma(const ConvArgs& a, const Epilogue& ep, int nt, hipStream_t
 }
 
 // =====================================================================================
+// The same implicit GEMM with operands staged through LDS (the default for K >= 64).
+//   workgroup tile : 128 output pixels (4 waves x 32) x NT*32 output channels
+//   K chunk        : BK input channels of one tap; A tile 128 x BK (rows padded by 16 B: the
+//                    16-lane groups of ds_read_b128 then hit 16 distinct 4-bank slots),
+//                    B tile = the BK/8 x NT fragment KBs of the chunk, shared by the 4 waves
+//   global -> LDS  : every thread moves 16-byte pieces; a pixel's BK channels are one contiguous
+//                    BK*4-byte run (a full 128-B line for BK = 32), B pieces are linear
+//   pipeline       : chunk c+1 travels global -> registers while chunk c is multiplied out of LDS,
+//                    then registers -> the other LDS buffer; one barrier per chunk
+// vs conv_mfma_kernel (fragment-shaped loads straight from L1/L2): B leaves L2 once per workgroup
+// instead of once per wave, A arrives in whole lines, and the matrix pipe is fed from LDS
+// (rocprof r1e: the direct kernel kept the MFMA pipe 44-54 % busy, TA-bound for NT = 1).
+// The MFMA sequence per output is unchanged: same ascending-k chain, bit-identical results.
+// =====================================================================================
+template <int NT, int BK>
+__global__ void __launch_bounds__(256, 2) conv_lds_kernel(const ConvArgs a, const Epilogue ep) {
+  constexpr int A_STRIDE = BK + 4;            // floats per staged row
+  constexpr int A_TILE = 128 * A_STRIDE;      // floats
+  constexpr int B_TILE = (BK / 8) * NT * 256; // floats
+  constexpr int A_PER_THR = BK / 8;           // float4 pieces of A per thread per chunk
+  constexpr int SEG = BK / 4;                 // 16-B pieces per row
+  constexpr int B_PIECES = (BK / 8) * NT * 64;  // float4 pieces of B per chunk
+  constexpr int B_PER_THR = (B_PIECES + 255) / 256;
+  __shared__ float4 smem4[2 * (A_TILE + B_TILE) / 4];
+  float* smem = (float*)smem4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int p = lane & 31, h = lane >> 5;
+  const unsigned lb = xcd_swizzle(blockIdx.x, gridDim.x);
+  const unsigned groups = (unsigned)a.NTtot / NT;
+  const long m_base = (long)(lb / groups) * 128;
+  const int nt0 = (int)(lb % groups) * NT;
+  const int hw = a.OH * a.OW;
+  const long m0 = m_base + wave * 32;
+
+  // per-row addressing state of the 128 staged rows, computed once into LDS (a per-thread array of
+  // it ends up in scratch): {image offset in floats (lo, hi) or -1, y, x}
+  __shared__ int4 rowinfo[128];
+  if (tid < 128) {
+    const long m = m_base + tid;
+    int4 ri = make_int4(-1, -1, 0, 0);
+    if (m < a.M) {
+      int n, y, x;
+      decompose(m, hw, a.OW, n, y, x);
+      const long off = (long)n * a.H * a.W * a.Cs_in;
+      ri = make_int4((int)(off & 0xffffffffL), (int)(off >> 32), y, x);
+    }
+    rowinfo[tid] = ri;
+  }
+  __syncthreads();
+  const int cpt = a.Cs_in / BK;  // chunks per tap
+  const int nchunks = a.KH * a.KW * cpt;
+  const float4* __restrict__ wf = (const float4*)a.wfrag;
+
+  floatx16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+
+  // One loop body, one copy of each phase (c = -1 is the pipeline fill): keeps the staging
+  // registers ra/rb in VGPRs (two call sites of a lambda pushed them to scratch).
+  for (int c = -1; c < nchunks; ++c) {
+    // staging registers as named scalars (arrays of them were demoted to scratch by the compiler)
+    float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+    ra0 = ra1 = ra2 = ra3 = rb0 = rb1 = rb2 = rb3 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool more = c + 1 < nchunks;
+    if (more) {  // ---- global -> registers for chunk c+1
+      const int cn = c + 1;
+      const int tap = cn / cpt, cc = cn - tap * cpt;
+      const int ky = tap / a.KW, kx = tap - ky * a.KW;
+      auto load_a = [&](int i) __attribute__((always_inline)) -> float4 {
+        const int idx = tid + i * 256, row = idx / SEG, seg = idx - row * SEG;
+        const int4 ri = rowinfo[row];
+        const long img = ((long)ri.y << 32) | (unsigned)ri.x;
+        const int iy = ri.z - a.PH + ky, ix = ri.w - a.PW + kx;
+        // branch-free validity and address (no short-circuit control flow around the load)
+        const bool v = (ri.y >= 0) & (iy >= 0) & (iy < a.H) & (ix >= 0) & (ix < a.W);
+        const long off = img + ((long)(v ? iy : 0) * a.W + (v ? ix : 0)) * a.Cs_in + cc * BK + seg * 4;
+        const float* src = v ? a.in + off : a.zeros;
+        return *(const float4*)src;
+      };
+      ra0 = load_a(0);
+      if constexpr (A_PER_THR > 1) ra1 = load_a(1);
+      if constexpr (A_PER_THR > 2) { ra2 = load_a(2); ra3 = load_a(3); }
+      const float4* wsrc = wf + ((long)cn * (BK / 8) * a.NTtot + nt0) * 64;
+      auto load_b = [&](int i) __attribute__((always_inline)) -> float4 {
+        const int j = tid + i * 256;
+        const int jj = j < B_PIECES ? j : 0;
+        const int sstep = jj / (NT * 64), rem = jj - sstep * (NT * 64);
+        return wsrc[(long)sstep * a.NTtot * 64 + rem];
+      };
+      rb0 = load_b(0);
+      if constexpr (B_PER_THR > 1) rb1 = load_b(1);
+      if constexpr (B_PER_THR > 2) rb2 = load_b(2);
+      if constexpr (B_PER_THR > 3) rb3 = load_b(3);
+    }
+    if (c >= 0) {  // ---- multiply chunk c out of LDS
+      const int buf = c & 1;
+      const float* sA = smem + buf * (A_TILE + B_TILE) + (wave * 32 + p) * A_STRIDE + 4 * h;
+      const float4* sB = (const float4*)(smem + buf * (A_TILE + B_TILE) + A_TILE) + lane;
+#pragma unroll
+      for (int sstep = 0; sstep < BK / 8; ++sstep) {
+        const float4 av = *(const float4*)(sA + sstep * 8);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const float4 bv = sB[(sstep * NT + t) * 64];
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc[t], 0, 0, 0);
+        }
+      }
+    }
+    if (more) {  // ---- registers -> the other LDS buffer
+      float* sAw = smem + ((c + 1) & 1) * (A_TILE + B_TILE);
+      float4* sBw = (float4*)(sAw + A_TILE);
+      auto store_a = [&](int i, const float4& v) __attribute__((always_inline)) {
+        const int idx = tid + i * 256, row = idx / SEG, seg = idx - row * SEG;
+        *(float4*)(sAw + row * A_STRIDE + seg * 4) = v;
+      };
+      store_a(0, ra0);
+      if constexpr (A_PER_THR > 1) store_a(1, ra1);
+      if constexpr (A_PER_THR > 2) { store_a(2, ra2); store_a(3, ra3); }
+      auto store_b = [&](int i, const float4& v) __attribute__((always_inline)) {
+        const int j = tid + i * 256;
+        if (j < B_PIECES) sBw[j] = v;
+      };
+      store_b(0, rb0);
+      if constexpr (B_PER_THR > 1) store_b(1, rb1);
+      if constexpr (B_PER_THR > 2) store_b(2, rb2);
+      if constexpr (B_PER_THR > 3) store_b(3, rb3);
+    }
+    __syncthreads();
+  }
+  if (m0 >= a.M) return;
+  conv_epilogue_tile(a, ep, acc[0], nt0 + 0, m0, p, h, hw);
+  if constexpr (NT > 1) conv_epilogue_tile(a, ep, acc[1], nt0 + 1, m0, p, h, hw);
+  if constexpr (NT > 2) conv_epilogue_tile(a, ep, acc[2], nt0 + 2, m0, p, h, hw);
+  if constexpr (NT > 3) conv_epilogue_tile(a, ep, acc[3], nt0 + 3, m0, p, h, hw);
+}
+
+template <int NT>
+static void launch_conv_lds_nt(const ConvArgs& a, const Epilogue& ep, dim3 grid, hipStream_t s) {
+  if (a.Cs_in % 32 == 0) hipLaunchKernelGGL((conv_lds_kernel<NT, 32>), grid, dim3(256), 0, s, a, ep);
+  else if (a.Cs_in % 16 == 0) hipLaunchKernelGGL((conv_lds_kernel<NT, 16>), grid, dim3(256), 0, s, a, ep);
+  else hipLaunchKernelGGL((conv_lds_kernel<NT, 8>), grid, dim3(256), 0, s, a, ep);
+}
+void launch_conv_lds(const ConvArgs& a, const Epilogue& ep, int nt, hipStream_t s) {
+  dim3 grid((unsigned)(((a.M + 127) / 128) * (a.NTtot / nt)));
+  switch (nt) {
+    case 1: launch_conv_lds_nt<1>(a, ep, grid, s); break;
+    case 2: launch_conv_lds_nt<2>(a, ep, grid, s); break;
+    case 3: launch_conv_lds_nt<3>(a, ep, grid, s); break;
+    default: launch_conv_lds_nt<4>(a, ep, grid, s); break;
+  }
+}
+
+// =====================================================================================
 // Stem: dense conv with Cin = 3 on the plain NHWC3 f32 image (any stride/pad), VALU.
 // One thread = one output pixel, all CS output channels; weights are wave-uniform (scalar loads).
 // =====================================================================================

@@ -515,7 +515,13 @@ bool Net::bind(int N, int H, int W, std::string& err) {
           const double cols = op.kind == PlanOp::DECONV ? 4.0 * op.cout : op.cout;
           L.flops = 2.0 * a.M * taps * op.cin * cols;
           L.bytes = 4.0 * ((double)a.M * op.cin + (double)a.M * cols + (double)taps * op.cin * cols);
-          L.fn = [a, ep, nt](hipStream_t s) { launch_conv_mfma(a, ep, nt, s); };
+          // OCR_CONV_IMPL=direct|lds overrides the choice (A/B measurements); results are identical
+          static const char* impl = getenv("OCR_CONV_IMPL");
+          // measured (gpurun_out r1g): LDS staging wins for multi-tap convs (3x3 96->24: 58 vs 51 TFLOP/s),
+          // the direct kernel for 1x1 (480->480: 88 vs 71; thin K: 54 vs 39)
+          const bool use_lds = impl ? !strcmp(impl, "lds") : (taps > 1 && in.cs >= 64);
+          if (use_lds) L.fn = [a, ep, nt](hipStream_t s) { launch_conv_lds(a, ep, nt, s); };
+          else L.fn = [a, ep, nt](hipStream_t s) { launch_conv_mfma(a, ep, nt, s); };
         }
       } break;
       case PlanOp::DW: {

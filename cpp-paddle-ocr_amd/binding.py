@@ -485,7 +485,11 @@ class Pipe:
         out = {}
         for line in buf.value.decode().splitlines():
             name, ms, cnt, fl, by = line.split()
-            out[name] = dict(ms=float(ms), count=int(cnt), flops=float(fl), bytes=float(by))
+            r = out.setdefault(name, dict(ms=0.0, count=0, flops=0.0, bytes=0.0))  # both rec lanes share names
+            r["ms"] += float(ms)
+            r["count"] += int(cnt)
+            r["flops"] += float(fl)
+            r["bytes"] += float(by)
         return out
 
     def close(self):

@@ -253,12 +253,14 @@ int ocr_pipe_timing(ocr_pipe* h, int enable) {
   h->det.net().reset_timings();
   h->rec.net().enable_timing(enable != 0);
   h->rec.net().reset_timings();
+  h->rec.net2().enable_timing(enable != 0);
+  h->rec.net2().reset_timings();
   return OCR_OK;
 }
 int ocr_pipe_timing_report(ocr_pipe* h, char* buf, size_t cap) {
   if (!h || !buf) return fail(OCR_ERR_ARG, "null argument");
   size_t off = 0;
-  for (Net* net : {&h->det.net(), &h->rec.net()})
+  for (Net* net : {&h->det.net(), &h->rec.net(), &h->rec.net2()})
     for (auto& kv : net->timings()) {
       int n = snprintf(buf + off, cap > off ? cap - off : 0, "%s %.6f %ld %.0f %.0f\n", kv.first.c_str(), kv.second.ms,
                        kv.second.count, kv.second.flops, kv.second.bytes);

@@ -119,6 +119,7 @@ class RecStage {
   const std::vector<std::string>& labels() const { return labels_; }
   hipStream_t stream() const { return stream_; }
   Net& net() { return net_; }
+  Net& net2() { return net2_; }
   // per-step taps of the last run, in input order: T per line, amax/pmax concatenated
   std::vector<int> tap_T, tap_off;
   std::vector<int> tap_amax;
@@ -126,11 +127,12 @@ class RecStage {
 
  private:
   RecConfig cfg_;
-  Net net_;
-  hipStream_t stream_ = nullptr;
+  Net net_, net2_;          // two execution lanes (see run_lines)
+  hipStream_t stream_ = nullptr, stream2_ = nullptr;
+  hipEvent_t ev_descs_ = nullptr;
   StageTimer timer_;
   std::vector<std::string> labels_;
-  DevBuf<float> lut_, x_, pmax_, scores_;
+  DevBuf<float> lut_, x_, x2_, pmax_, scores_;
   DevBuf<int> amax_, ids_, lens_;
   DevBuf<uint8_t> staging_;
   DevBuf<LineDesc> descs_;

@@ -237,6 +237,8 @@ int DetStage::post_only(const float* prob, int rows, int cols, int src_rows, int
 // ================================================================= recognizer
 RecStage::~RecStage() {
   if (stream_) (void)hipStreamDestroy(stream_);
+  if (stream2_) (void)hipStreamDestroy(stream2_);
+  if (ev_descs_) (void)hipEventDestroy(ev_descs_);
 }
 
 bool RecStage::create(const RecConfig& cfg, std::string& err, int& code) {
@@ -256,9 +258,10 @@ bool RecStage::create(const RecConfig& cfg, std::string& err, int& code) {
   labels_.push_back(" ");
   WeightMap w;
   if (!load_model_dir(cfg.model_dir, nullptr, w, err)) return false;
-  if (!net_.load(embedded_plan("rec"), w, err)) return false;
+  if (!net_.load(embedded_plan("rec"), w, err) || !net2_.load(embedded_plan("rec"), w, err)) return false;
   code = OCR_ERR_DEVICE;
-  if (hipStreamCreate(&stream_) != hipSuccess) { err = "hipStreamCreate failed"; return false; }
+  if (hipStreamCreate(&stream_) != hipSuccess || hipStreamCreate(&stream2_) != hipSuccess ||
+      hipEventCreateWithFlags(&ev_descs_, hipEventDisableTiming) != hipSuccess) { err = "hipStreamCreate failed"; return false; }
   if (!timer_.init(err)) return false;
   const float mean[3] = {0.5f, 0.5f, 0.5f}, scale[3] = {1 / 0.5f, 1 / 0.5f, 1 / 0.5f};  // ocr_rec.h:108-109
   const auto lut = make_norm_lut(mean, scale);
@@ -331,57 +334,86 @@ int RecStage::run_lines(const std::vector<LineSrc>& lines, const std::vector<int
   tap_amax.clear();
   tap_pmax.clear();
   for (int i = 0; i < n; ++i) { lens[i] = 0; scores[i] = 0.f; }
-  std::vector<int> h_ids, h_lens, h_amax;
-  std::vector<float> h_scores, h_pmax;
-  for (auto& kv : launches) {
-    const int Wt = kv.first;
-    const int ng = (int)kv.second.size();
-    std::vector<LineDesc> d(ng);
-    for (int j = 0; j < ng; ++j) {
-      const LineSrc& L = lines[kv.second[j].line];
-      d[j] = LineDesc{L.img, L.stride, L.x, L.y, L.w, L.h, kv.second[j].resize_w, j};
+  if (launches.empty()) return OCR_OK;
+  // Two execution lanes (network instance + stream each): the largest launch runs on lane 0 while the
+  // small odd-width launches (latency-bound: 16 lines each) run back to back on lane 1 and fill the
+  // gaps.  Everything is enqueued first; one synchronisation and one round of D2H copies at the end.
+  const int nl = (int)launches.size();
+  int big = 0;
+  for (int i = 1; i < nl; ++i)
+    if ((long)launches[i].second.size() * launches[i].first > (long)launches[big].second.size() * launches[big].first) big = i;
+  struct Slot { int lane, ng, Wt, T; size_t step_off, line_off; };
+  std::vector<Slot> slots(nl);
+  size_t step_total = 0, line_total = 0;
+  for (int i = 0; i < nl; ++i) {
+    slots[i] = Slot{(i == big || nl == 1) ? 0 : 1, (int)launches[i].second.size(), launches[i].first, 0, step_total, line_total};
+    step_total += (size_t)slots[i].ng * (launches[i].first / 4 + 8);  // >= ng * T
+    line_total += slots[i].ng;
+  }
+  if (!amax_.ensure(step_total, err) || !pmax_.ensure(step_total, err) || !ids_.ensure(line_total * max_len, err) ||
+      !lens_.ensure(line_total, err) || !scores_.ensure(line_total, err) || !descs_.ensure(line_total, err))
+    return OCR_ERR_DEVICE;
+  size_t xneed[2] = {0, 0};
+  for (int i = 0; i < nl; ++i) xneed[slots[i].lane] = std::max(xneed[slots[i].lane], (size_t)slots[i].ng * imgH * slots[i].Wt * 3);
+  if (!x_.ensure(xneed[0], err) || !x2_.ensure(xneed[1], err)) return OCR_ERR_DEVICE;
+  std::vector<LineDesc> d(line_total);
+  for (int i = 0; i < nl; ++i)
+    for (int j = 0; j < slots[i].ng; ++j) {
+      const LineSrc& L = lines[launches[i].second[j].line];
+      d[slots[i].line_off + j] = LineDesc{L.img, L.stride, L.x, L.y, L.w, L.h, launches[i].second[j].resize_w, j};
     }
-    if (!descs_.ensure(ng, err) || !x_.ensure((size_t)ng * imgH * Wt * 3, err)) return OCR_ERR_DEVICE;
-    ST_HIP(hipMemcpyAsync(descs_.p, d.data(), ng * sizeof(LineDesc), hipMemcpyHostToDevice, stream_));
-    launch_line_pre(descs_.p, ng, imgH, Wt, lut_.p, false, x_.p, stream_);
-    // head sinks must exist before the network binds its launches; T is known only after shape
-    // inference, so size them by the widest possible T = Wt (>= Wt/8)
-    const int* old_a = amax_.p;
-    const float* old_p = pmax_.p;
-    if (!amax_.ensure((size_t)ng * Wt, err) || !pmax_.ensure((size_t)ng * Wt, err)) return OCR_ERR_DEVICE;
-    if (amax_.p != old_a || pmax_.p != old_p || !old_a) net_.set_head_outputs(nullptr, amax_.p, pmax_.p);
-    if (!net_.run(x_.p, ng, imgH, Wt, stream_, err)) return OCR_ERR_DEVICE;
-    const TensorDesc& ot = net_.tensor(net_.output_tid());
-    if (ot.h != 1) { err = "rec_img_h does not reduce to a single row"; return OCR_ERR_ARG; }
-    if (ot.c != (int)labels_.size()) { err = "dictionary size does not match the CTC head"; return OCR_ERR_MODEL; }
-    const int T = ot.w;
-    if (!ids_.ensure((size_t)ng * max_len, err) || !lens_.ensure(ng, err) || !scores_.ensure(ng, err)) return OCR_ERR_DEVICE;
-    launch_ctc(amax_.p, pmax_.p, ng, T, max_len, ids_.p, lens_.p, scores_.p, stream_);
-    h_ids.resize((size_t)ng * max_len);
-    h_lens.resize(ng);
-    h_scores.resize(ng);
-    ST_HIP(hipMemcpyAsync(h_ids.data(), ids_.p, h_ids.size() * sizeof(int), hipMemcpyDeviceToHost, stream_));
-    ST_HIP(hipMemcpyAsync(h_lens.data(), lens_.p, ng * sizeof(int), hipMemcpyDeviceToHost, stream_));
-    ST_HIP(hipMemcpyAsync(h_scores.data(), scores_.p, ng * sizeof(float), hipMemcpyDeviceToHost, stream_));
-    if (want_taps) {
-      h_amax.resize((size_t)ng * T);
-      h_pmax.resize((size_t)ng * T);
-      ST_HIP(hipMemcpyAsync(h_amax.data(), amax_.p, h_amax.size() * sizeof(int), hipMemcpyDeviceToHost, stream_));
-      ST_HIP(hipMemcpyAsync(h_pmax.data(), pmax_.p, h_pmax.size() * sizeof(float), hipMemcpyDeviceToHost, stream_));
+  ST_HIP(hipMemcpyAsync(descs_.p, d.data(), line_total * sizeof(LineDesc), hipMemcpyHostToDevice, stream_));
+  ST_HIP(hipEventRecord(ev_descs_, stream_));
+  ST_HIP(hipStreamWaitEvent(stream2_, ev_descs_, 0));
+  for (int pass = 0; pass < 2; ++pass) {      // lane 0's launch first so the big kernels are queued early
+    for (int i = 0; i < nl; ++i) {
+      Slot& sl = slots[i];
+      if (sl.lane != pass) continue;
+      Net& net = sl.lane ? net2_ : net_;
+      hipStream_t st = sl.lane ? stream2_ : stream_;
+      float* x = sl.lane ? x2_.p : x_.p;
+      launch_line_pre(descs_.p + sl.line_off, sl.ng, imgH, sl.Wt, lut_.p, false, x, st);
+      net.set_head_outputs(nullptr, amax_.p + sl.step_off, pmax_.p + sl.step_off);
+      if (!net.run(x, sl.ng, imgH, sl.Wt, st, err)) return OCR_ERR_DEVICE;
+      const TensorDesc& ot = net.tensor(net.output_tid());
+      if (ot.h != 1) { err = "rec_img_h does not reduce to a single row"; return OCR_ERR_ARG; }
+      if (ot.c != (int)labels_.size()) { err = "dictionary size does not match the CTC head"; return OCR_ERR_MODEL; }
+      sl.T = ot.w;
+      if ((size_t)sl.ng * sl.T > (size_t)sl.ng * (sl.Wt / 4 + 8)) { err = "rec step buffer too small"; return OCR_ERR_CAPACITY; }
+      launch_ctc(amax_.p + sl.step_off, pmax_.p + sl.step_off, sl.ng, sl.T, max_len, ids_.p + sl.line_off * max_len,
+                 lens_.p + sl.line_off, scores_.p + sl.line_off, st);
     }
-    ST_HIP(hipStreamSynchronize(stream_));
-    net_.collect_timings();
-    for (int j = 0; j < ng; ++j) {
-      const int li = kv.second[j].line;
-      if (h_lens[j] > max_len) { err = "text longer than max_len"; return OCR_ERR_CAPACITY; }
-      lens[li] = h_lens[j];
-      scores[li] = h_scores[j];
-      memcpy(ids + (size_t)li * max_len, h_ids.data() + (size_t)j * max_len, (size_t)h_lens[j] * sizeof(int));
-      tap_T[li] = T;
+  }
+  ST_HIP(hipStreamSynchronize(stream2_));
+  std::vector<int> h_ids(line_total * max_len), h_lens(line_total), h_amax;
+  std::vector<float> h_scores(line_total), h_pmax;
+  ST_HIP(hipMemcpyAsync(h_ids.data(), ids_.p, h_ids.size() * sizeof(int), hipMemcpyDeviceToHost, stream_));
+  ST_HIP(hipMemcpyAsync(h_lens.data(), lens_.p, line_total * sizeof(int), hipMemcpyDeviceToHost, stream_));
+  ST_HIP(hipMemcpyAsync(h_scores.data(), scores_.p, line_total * sizeof(float), hipMemcpyDeviceToHost, stream_));
+  if (want_taps) {
+    h_amax.resize(step_total);
+    h_pmax.resize(step_total);
+    ST_HIP(hipMemcpyAsync(h_amax.data(), amax_.p, step_total * sizeof(int), hipMemcpyDeviceToHost, stream_));
+    ST_HIP(hipMemcpyAsync(h_pmax.data(), pmax_.p, step_total * sizeof(float), hipMemcpyDeviceToHost, stream_));
+  }
+  ST_HIP(hipStreamSynchronize(stream_));
+  net_.collect_timings();
+  net2_.collect_timings();
+  for (int i = 0; i < nl; ++i) {
+    const Slot& sl = slots[i];
+    for (int j = 0; j < sl.ng; ++j) {
+      const int li = launches[i].second[j].line;
+      const size_t q = sl.line_off + j;
+      if (h_lens[q] > max_len) { err = "text longer than max_len"; return OCR_ERR_CAPACITY; }
+      lens[li] = h_lens[q];
+      scores[li] = h_scores[q];
+      memcpy(ids + (size_t)li * max_len, h_ids.data() + q * max_len, (size_t)h_lens[q] * sizeof(int));
+      tap_T[li] = sl.T;
       if (want_taps) {
         tap_off[li] = (int)tap_amax.size();
-        tap_amax.insert(tap_amax.end(), h_amax.begin() + (size_t)j * T, h_amax.begin() + (size_t)(j + 1) * T);
-        tap_pmax.insert(tap_pmax.end(), h_pmax.begin() + (size_t)j * T, h_pmax.begin() + (size_t)(j + 1) * T);
+        const size_t o = sl.step_off + (size_t)j * sl.T;
+        tap_amax.insert(tap_amax.end(), h_amax.begin() + o, h_amax.begin() + o + sl.T);
+        tap_pmax.insert(tap_pmax.end(), h_pmax.begin() + o, h_pmax.begin() + o + sl.T);
       }
     }
   }

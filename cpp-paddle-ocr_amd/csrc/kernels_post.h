@@ -12,6 +12,7 @@ struct PostArgs {
   const float* pred;      // [N][H][W]
   int* labels;            // [N*H*W]
   uint8_t* touch;         // [N*H*W]
+  int* chunk_cnt;         // [N][128] scratch of the ordered compaction
   int* ncont_all;         // [N] borders discovered
   int* ncont;             // [N] min(discovered, max_cand)
   int* starts;            // [N][max_cand] start pixel (image-local), reference order

@@ -139,62 +139,77 @@ __device__ __forceinline__ bool is_start(const uint8_t* bm, const int* L, const 
   if (L[g] != (int)g) return false;
   return bm[g] ? true : !touch[g];
 }
-// one workgroup (1024 threads) per image
-__global__ void __launch_bounds__(1024) starts_kernel(const uint8_t* __restrict__ bm, const int* __restrict__ L,
-                                                      const uint8_t* __restrict__ touch, int H, int W, int max_cand,
-                                                      int* __restrict__ ncont_all, int* __restrict__ ncont,
-                                                      int* __restrict__ starts /*[N][max_cand]*/) {
-  __shared__ int wsum[16];
-  __shared__ int total_s;
-  __shared__ int running;
-  const int n = blockIdx.x;
-  const long base = (long)n * H * W;
-  const int per = H * W;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  // pass 1: count
+// Ordered compaction in three small kernels so that every CU takes part (a single workgroup per image
+// left 3/4 of the chip idle): per-chunk counts, a per-image scan of the chunk counts, ranked writes.
+#define START_CHUNKS 128
+__global__ void __launch_bounds__(256) starts_count_kernel(const uint8_t* __restrict__ bm, const int* __restrict__ L,
+                                                           const uint8_t* __restrict__ touch, int H, int W,
+                                                           int* __restrict__ chunk_cnt) {
+  __shared__ int wsum[4];
+  const int n = blockIdx.y, c = blockIdx.x;
+  const int per = H * W, chunk = (per + START_CHUNKS - 1) / START_CHUNKS;
+  const long base = (long)n * per;
+  const int lo = c * chunk, hi = min(per, lo + chunk);
   int cnt = 0;
-  for (int i = threadIdx.x; i < per; i += 1024) cnt += is_start(bm, L, touch, base, i) ? 1 : 0;
+  for (int i = lo + threadIdx.x; i < hi; i += 256) cnt += is_start(bm, L, touch, base, i) ? 1 : 0;
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off);
-  if (lane == 0) wsum[wv] = cnt;
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = cnt;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    int t = 0;
-    for (int k = 0; k < 16; ++k) t += wsum[k];
-    total_s = t;
-    running = 0;
-    ncont_all[n] = t;
-    ncont[n] = t < max_cand ? t : max_cand;
+  if (threadIdx.x == 0) chunk_cnt[n * START_CHUNKS + c] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+__global__ void __launch_bounds__(64) starts_scan_kernel(int* __restrict__ chunk_cnt, int max_cand, int* __restrict__ ncont_all,
+                                                         int* __restrict__ ncont) {
+  const int n = blockIdx.x;
+  if (threadIdx.x != 0) return;
+  int run = 0;
+  for (int c = 0; c < START_CHUNKS; ++c) {
+    const int v = chunk_cnt[n * START_CHUNKS + c];
+    chunk_cnt[n * START_CHUNKS + c] = run;  // exclusive offset
+    run += v;
   }
+  ncont_all[n] = run;
+  ncont[n] = run < max_cand ? run : max_cand;
+}
+__global__ void __launch_bounds__(256) starts_write_kernel(const uint8_t* __restrict__ bm, const int* __restrict__ L,
+                                                           const uint8_t* __restrict__ touch, int H, int W, int max_cand,
+                                                           const int* __restrict__ chunk_off, const int* __restrict__ ncont_all,
+                                                           int* __restrict__ starts /*[N][max_cand]*/) {
+  __shared__ int wsum[4];
+  __shared__ int running;
+  const int n = blockIdx.y, c = blockIdx.x;
+  const int per = H * W, chunk = (per + START_CHUNKS - 1) / START_CHUNKS;
+  const long base = (long)n * per;
+  const int lo = c * chunk, hi = min(per, lo + chunk);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int total = ncont_all[n];
+  if (threadIdx.x == 0) running = chunk_off[n * START_CHUNKS + c];
   __syncthreads();
-  const int total = total_s;
-  // pass 2: ranks in raster order; keep the last max_cand, store at reversed position
-  for (int i0 = 0; i0 < per; i0 += 1024) {
+  for (int i0 = lo; i0 < hi; i0 += 256) {
     const int i = i0 + threadIdx.x;
-    const bool st = i < per && is_start(bm, L, touch, base, i);
+    const bool st = i < hi && is_start(bm, L, touch, base, i);
     const unsigned long long bal = __ballot(st);
     const int before = __popcll(bal & ((1ull << lane) - 1ull));
     if (lane == 0) wsum[wv] = __popcll(bal);
     __syncthreads();
     int woff = 0;
     for (int k = 0; k < wv; ++k) woff += wsum[k];
-    const int rank = running + woff + before;
+    const int rank = running + woff + before;  // raster-order rank = discovery order of the reference scan
     if (st) {
-      const int pos = total - 1 - rank;  // reverse discovery order
+      const int pos = total - 1 - rank;        // findContours returns borders in reverse discovery order
       if (pos < max_cand) starts[(long)n * max_cand + pos] = i;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-      int t = 0;
-      for (int k = 0; k < 16; ++k) t += wsum[k];
-      running += t;
-    }
+    if (threadIdx.x == 0) running += wsum[0] + wsum[1] + wsum[2] + wsum[3];
     __syncthreads();
   }
 }
 void launch_starts(const uint8_t* bm, const int* L, const uint8_t* touch, int N, int H, int W, int max_cand, int* ncont_all,
-                   int* ncont, int* starts, hipStream_t s) {
-  hipLaunchKernelGGL(starts_kernel, dim3(N), dim3(1024), 0, s, bm, L, touch, H, W, max_cand, ncont_all, ncont, starts);
+                   int* ncont, int* starts, int* chunk_cnt, hipStream_t s) {
+  hipLaunchKernelGGL(starts_count_kernel, dim3(START_CHUNKS, N), dim3(256), 0, s, bm, L, touch, H, W, chunk_cnt);
+  hipLaunchKernelGGL(starts_scan_kernel, dim3(N), dim3(64), 0, s, chunk_cnt, max_cand, ncont_all, ncont);
+  hipLaunchKernelGGL(starts_write_kernel, dim3(START_CHUNKS, N), dim3(256), 0, s, bm, L, touch, H, W, max_cand, chunk_cnt,
+                     ncont_all, starts);
 }
 
 // ------------------------------------------------------------------ 4. border following (icvFetchContour)
@@ -209,37 +224,58 @@ __device__ __forceinline__ int key_x(unsigned long long k) { return (int)(k >> 4
 __device__ __forceinline__ int key_y(unsigned long long k) { return (int)((k >> 32) & 0xffff) - KEY_OFF; }
 __device__ __forceinline__ unsigned key_i(unsigned long long k) { return (unsigned)(k & 0xffffffffu); }
 
+// 8-neighbour occupancy of (cx, cy) as a bit mask (bit d = direction d of kDx/kDy): the eight byte
+// loads are independent, so one step of the border walk costs one memory round trip instead of up to
+// eight dependent ones.
+__device__ __forceinline__ unsigned nbr_mask(const uint8_t* __restrict__ bm, int H, int W, int cx, int cy) {
+  unsigned m = 0;
+#pragma unroll
+  for (int d = 0; d < 8; ++d) {
+    const int x = cx + kDx[d], y = cy + kDy[d];
+    const bool in = x >= 0 && y >= 0 && x < W && y < H;
+    const uint8_t v = bm[in ? (long)y * W + x : 0];
+    m |= (in && v) ? (1u << d) : 0u;
+  }
+  return m;
+}
+
 // follows one border; emits CHAIN_APPROX_SIMPLE vertices (if keys != null) and returns their number
 __device__ int trace_border(const uint8_t* __restrict__ bm, int H, int W, int ox, int oy, bool is_hole,
                             unsigned long long* keys) {
-  auto nz = [&](int x, int y) -> bool { return x >= 0 && y >= 0 && x < W && y < H && bm[(long)y * W + x] != 0; };
   int count = 0;
   int s_end, s;
   s_end = s = is_hole ? 0 : 4;
-  int i1x, i1y;
-  do {
-    s = (s - 1) & 7;
-    i1x = ox + kDx[s];
-    i1y = oy + kDy[s];
-  } while (!nz(i1x, i1y) && s != s_end);
-  if (s == s_end) {
+  // first neighbour clockwise from s_end: s = s_end-1, s_end-2, ... (mod 8), at most 8 probes
+  const unsigned m0 = nbr_mask(bm, H, W, ox, oy);
+  int found = -1;
+#pragma unroll
+  for (int k = 1; k <= 8; ++k) {
+    const int d = (s_end - k) & 7;
+    if (found < 0 && (k == 8 || ((m0 >> d) & 1u))) found = d;  // k == 8 lands on s_end itself (loop exit s == s_end)
+  }
+  s = found;
+  if (s == s_end && !((m0 >> s) & 1u)) {  // isolated pixel
     if (keys) keys[0] = make_key(ox, oy, 0);
     return 1;
   }
+  if (s == s_end) {
+    // the do-while stopped because s wrapped to s_end, but that neighbour is set: the reference treats
+    // `s == s_end` as the single-pixel case regardless (icvFetchContour) — keep that behaviour
+    if (keys) keys[0] = make_key(ox, oy, 0);
+    return 1;
+  }
+  const int i1x = ox + kDx[s], i1y = oy + kDy[s];
   int cx = ox, cy = oy;
   int prev_s = s ^ 4;
   // a closed border of a W x H bitmap has at most 4*W*H steps; the bound keeps every lane finite
   const long max_steps = 4L * W * H + 16;
   for (long step = 0; step < max_steps; ++step) {
-    s_end = s;
-    int nx = cx, ny = cy;
-    while (s < 15) {
-      ++s;
-      nx = cx + kDx[s & 7];
-      ny = cy + kDy[s & 7];
-      if (nz(nx, ny)) break;
-    }
-    s &= 7;
+    const unsigned m = nbr_mask(bm, H, W, cx, cy);
+    // first set direction counter-clockwise after s: s+1, s+2, ... (the previous pixel guarantees a hit)
+    const unsigned rot = ((m | (m << 8)) >> ((s + 1) & 7)) & 0xffu;
+    const int j = rot ? __ffs(rot) - 1 : 7;
+    s = (s + 1 + j) & 7;
+    const int nx = cx + kDx[s], ny = cy + kDy[s];
     if (s != prev_s) {
       if (keys) keys[count] = make_key(cx, cy, (unsigned)count);
       ++count;
@@ -638,17 +674,21 @@ __device__ LineRast make_line(int W, int H, int ax, int ay, int bx, int by) {
   L.delta_major = delta_x; L.delta_minor = delta_y; L.vert = vert; L.count = dx + 1;
   return L;
 }
-// is (x,y) one of the pixels LineIterator visits?
+// is (x,y) one of the pixels LineIterator visits?  (closed form of the Bresenham error recurrence;
+// all quantities fit 32 bits: |dx|,|dy|,j < 2^15)
 __device__ __forceinline__ bool on_line(const LineRast& L, int x, int y) {
   if (!L.valid) return false;
   const int maj = L.vert ? y : x, mnr = L.vert ? x : y;
   const int maj0 = L.vert ? L.py : L.px, mnr0 = L.vert ? L.px : L.py;
   const int j = (maj - maj0) * L.delta_major;
   if (j < 0 || j >= L.count) return false;
-  int m = 0;
-  const long long a = 2LL * L.dy * j - L.dx;
-  if (j > 0 && L.dy > 0 && a > 0) m = (int)((a + 2LL * L.dx - 1) / (2LL * L.dx));
-  return mnr == mnr0 + L.delta_minor * m;
+  const int d = (mnr - mnr0) * L.delta_minor;  // minor offset this pixel would need
+  if (d < 0 || d > L.dy) return false;
+  // m_j = 0 if 2*dy*j - dx <= 0 else ceil((2*dy*j - dx) / (2*dx));  test m_j == d without dividing:
+  const int a = 2 * L.dy * j - L.dx;
+  if (a <= 0) return d == 0;
+  // ceil(a / (2dx)) == d  <=>  (d-1)*2dx < a <= d*2dx
+  return (long long)(d - 1) * 2 * L.dx < a && a <= (long long)d * 2 * L.dx;
 }
 
 // BoxScoreFast: masked mean over the bbox with the mask of fillPoly(int-truncated corners).
@@ -693,8 +733,8 @@ __device__ float box_score_fast_wave(const P2f arr[4], const float* __restrict__
   const long total = (long)mw * mh;
   for (long t = lane; t < total; t += 64) {
     const int y = (int)(t / mw), x = (int)(t - (long)y * mw);
-    bool in = on_line(Ls[0], x, y) || on_line(Ls[1], x, y) || on_line(Ls[2], x, y) || on_line(Ls[3], x, y);
-    if (!in && do_fill && y >= ey_min && y < ey_max) {
+    bool in = false;
+    if (do_fill && y >= ey_min && y < ey_max) {  // interior first: it covers most of the bbox and needs no outline test
       // active edges on this scanline, their x in 16.16, sorted ascending, filled pairwise
       long long xs[4];
       int na = 0;
@@ -712,6 +752,7 @@ __device__ float box_score_fast_wave(const P2f arr[4], const float* __restrict__
         if (x >= x1 && x <= x2) in = true;
       }
     }
+    if (!in) in = on_line(Ls[0], x, y) || on_line(Ls[1], x, y) || on_line(Ls[2], x, y) || on_line(Ls[3], x, y);
     if (in) {
       sum += (double)pred[(long)(y + ymin) * W + x + xmin];
       ++cnt;
@@ -1031,7 +1072,7 @@ __global__ void __launch_bounds__(64) boxes_compact_kernel(const PostArgs a, int
 
 void launch_post(const PostArgs& a, int N, int* out_boxes, int cap, int* out_n, hipStream_t s) {
   launch_ccl(a.bitmap, a.labels, a.touch, N, a.H, a.W, s);
-  launch_starts(a.bitmap, a.labels, a.touch, N, a.H, a.W, a.max_cand, a.ncont_all, a.ncont, a.starts, s);
+  launch_starts(a.bitmap, a.labels, a.touch, N, a.H, a.W, a.max_cand, a.ncont_all, a.ncont, a.starts, a.chunk_cnt, s);
   const dim3 gl((a.max_cand + 63) / 64, N);
   hipLaunchKernelGGL(trace_count_kernel, gl, dim3(64), 0, s, a.bitmap, a.H, a.W, a.max_cand, a.ncont, a.starts, a.npts);
   hipLaunchKernelGGL(trace_offsets_kernel, dim3(N), dim3(64), 0, s, a.max_cand, a.ncont, a.npts, a.poff, a.pool_cap, a.status);

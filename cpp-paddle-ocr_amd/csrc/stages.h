@@ -83,7 +83,7 @@ class DetStage {
   StageTimer timer_;
   DevBuf<float> lut_, x_, prob_in_;
   DevBuf<uint8_t> src_, resized_, bitmap_, bitmap2_, touch_;
-  DevBuf<int> labels_, ncont_all_, ncont_, starts_, npts_, poff_, iscratch_, cand_boxes_, cand_valid_, status_, out_boxes_,
+  DevBuf<int> labels_, chunk_cnt_, ncont_all_, ncont_, starts_, npts_, poff_, iscratch_, cand_boxes_, cand_valid_, status_, out_boxes_,
       out_n_;
   DevBuf<unsigned long long> pool_;
   int src_rows_ = 0, src_cols_ = 0;

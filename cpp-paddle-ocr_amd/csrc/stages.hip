@@ -127,7 +127,7 @@ bool DetStage::ensure_post(int count, int H, int W, std::string& err) {
   const size_t px = (size_t)count * H * W;
   const int max_cand = 1000;
   pool_cap_ = std::max(1 << 16, (H * W) / 2);
-  return labels_.ensure(px, err) && touch_.ensure(px, err) && ncont_all_.ensure(count, err) && ncont_.ensure(count, err) &&
+  return labels_.ensure(px, err) && touch_.ensure(px, err) && chunk_cnt_.ensure((size_t)count * 128, err) && ncont_all_.ensure(count, err) && ncont_.ensure(count, err) &&
          starts_.ensure((size_t)count * max_cand, err) && npts_.ensure((size_t)count * max_cand, err) &&
          poff_.ensure((size_t)count * max_cand, err) && pool_.ensure((size_t)count * pool_cap_, err) &&
          iscratch_.ensure((size_t)count * pool_cap_ * 4, err) && cand_boxes_.ensure((size_t)count * max_cand * 8, err) &&
@@ -146,7 +146,7 @@ int DetStage::run_post(int count, int H, int W, const float* prob, float ratio_h
     bm = bitmap2_.p;
   }
   PostArgs a{};
-  a.bitmap = bm; a.pred = prob; a.labels = labels_.p; a.touch = touch_.p; a.ncont_all = ncont_all_.p; a.ncont = ncont_.p;
+  a.bitmap = bm; a.pred = prob; a.labels = labels_.p; a.touch = touch_.p; a.chunk_cnt = chunk_cnt_.p; a.ncont_all = ncont_all_.p; a.ncont = ncont_.p;
   a.starts = starts_.p; a.npts = npts_.p; a.poff = poff_.p; a.pool = pool_.p; a.iscratch = iscratch_.p;
   a.cand_boxes = cand_boxes_.p; a.cand_valid = cand_valid_.p; a.status = status_.p; a.pool_cap = pool_cap_;
   a.H = H; a.W = W; a.max_cand = 1000;

@@ -176,8 +176,14 @@ def main():
                 name, r = top
                 avg_ms = r["ms"] / max(1, r["count"])
                 tflops = r["flops"] / (r["ms"] * 1e-3) / 1e12 if r["ms"] > 0 else 0.0
+                traffic = None
+                tf = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
+                if os.path.exists(tf):  # HBM bytes per launch from the rocprofv3 --pmc passes (tools/pmc_traffic.py)
+                    pm = json.load(open(tf))
+                    if pm.get("kernel") == name:
+                        traffic = pm["traffic_bytes_per_launch"]
                 out["roofline"] = {"kernel": name, "bound": "mfma", "achieved": tflops, "peak": FP32_MFMA_PEAK_TFLOPS,
-                                   "unit": "TFLOP/s", "frac": tflops / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                                   "unit": "TFLOP/s", "frac": tflops / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
                                    "avg_launch_ms": avg_ms, "launches": r["count"],
                                    "algorithmic_flops_per_launch": r["flops"] / max(1, r["count"]),
                                    "algorithmic_bytes_per_launch": r["bytes"] / max(1, r["count"]),

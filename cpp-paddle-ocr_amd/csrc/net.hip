@@ -643,6 +643,9 @@ bool Net::bind(int N, int H, int W, std::string& err) {
       } break;
       default: break;
     }
+    // instance tag: the same op at another bound shape is another roofline row
+    snprintf(nm, sizeof nm, "@%dx%dx%d", N, H, W);
+    L.name += nm;
     launches_.push_back(std::move(L));
   }
   bound_n_ = N; bound_h_ = H; bound_w_ = W;

@@ -84,72 +84,87 @@ __device__ __forceinline__ float4 apply_epilogue4(const Epilogue& ep, float4 v, 
   return v;
 }
 
-// Epilogue of one 32x32 accumulator tile.  Stage loop outside, the 16 rows unrolled inside each
-// stage, so the accumulator is only ever indexed statically (stays in registers).  Conv epilogues
-// on this path carry per-channel / scalar stages and same-shape residual adds only (the plan
-// generator never fuses MULC/ADDUP into a conv; the host checks).
+// Epilogue of one 32x32 accumulator tile.  The GEMM is issued as D = W * X^T (weights are the MFMA
+// A operand, pixels the B operand), so a lane owns ONE pixel (column = lane & 31) and 16 output
+// channels: registers 4g..4g+3 are the four consecutive PHYSICAL channels tile*32 + 8g + 4*(lane>>5).
+// => per-channel parameters arrive as float4, results leave as 16-byte stores, and per-pixel stages
+// (SE gate, residual, upsample-add) need the pixel's (n, y, x) only once per lane.
 __device__ __forceinline__ void conv_epilogue_tile(const ConvArgs& a, const Epilogue& ep, const floatx16& accv, int nt,
-                                                   long m0, int p, int h, int hw) {
-  const int co = nt * 32 + p;  // logical column of the GEMM
-  if (nt >= a.NTtot || co >= a.ColsStore) return;
-  int ch = co, dq = 0;  // channel for per-channel params; deconv quadrant
-  if (a.out_mode == OUT_DECONV) { dq = co / a.CoutPadded; ch = co - dq * a.CoutPadded; }
-  const int pc = (a.out_mode == OUT_PLAIN) ? ch : c8i_phys(ch);
-  const bool is_pad = ch >= a.Cout;
-  const long mb = m0 + 4 * h;  // row(r) = mb + (r&3) + 8*(r>>2)
-  // four registers (= four consecutive rows) at a time: keeps the epilogue's live set small so the
-  // kernel's VGPR budget is set by the main loop (occupancy), not by 16 interleaved divisions
+                                                   long m, int hb, int n, int y, int x) {
+  if (nt * 32 >= a.ColsStore || m >= a.M) return;
+  float4 v[4];
+  int pc[4], oy[4], ox[4];
+  long oidx[4];
+  bool live[4];
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
-    float val[4];
+    const int R = nt * 32 + 8 * g + 4 * hb;  // first of four consecutive GEMM rows (physical channels)
+    live[g] = R < a.ColsStore;
+    v[g] = make_float4(accv[4 * g], accv[4 * g + 1], accv[4 * g + 2], accv[4 * g + 3]);
+    pc[g] = R; oy[g] = y; ox[g] = x;
+    if (a.out_mode == OUT_DECONV) {
+      const int dq = R / a.CoutPadded;
+      pc[g] = R - dq * a.CoutPadded;
+      oy[g] = 2 * y + (dq >> 1);
+      ox[g] = 2 * x + (dq & 1);
+      oidx[g] = (((long)n * (2 * a.OH) + oy[g]) * (2 * a.OW) + ox[g]) * a.Cs_out + pc[g];
+    } else {
+      oidx[g] = m * a.Cs_out + R;
+    }
+    if (!live[g]) { pc[g] = 0; oidx[g] = 0; }
+  }
+  // stage loop outside, the four channel quads inside: one copy of each stage's code, `ep` is only
+  // ever indexed by the (uniform) stage counter
+  for (int s = 0; s < ep.n; ++s) {
+    const EpStage& st = ep.st[s];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) val[q] = accv[4 * g + q];
-    const long mg = mb + 8 * g;
-    for (int s = 0; s < ep.n; ++s) {
-      const EpStage& st = ep.st[s];
+    for (int g = 0; g < 4; ++g) {
+      float4& w = v[g];
       switch (st.kind) {
-        case EP_BIAS: { const float b = st.v0[pc];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) val[q] = val[q] + b; } break;
-        case EP_SMUL:
-#pragma unroll
-          for (int q = 0; q < 4; ++q) val[q] = st.p0 * val[q];
-          break;
-        case EP_SADD:
-#pragma unroll
-          for (int q = 0; q < 4; ++q) val[q] = val[q] + st.p0;
-          break;
-        case EP_BN: { const float sc = st.v0[pc], sh = st.v1[pc];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) { const float t = val[q] * sc; val[q] = t + sh; } } break;
+        case EP_BIAS: { const float4 b = *(const float4*)(st.v0 + pc[g]); w.x = w.x + b.x; w.y = w.y + b.y; w.z = w.z + b.z; w.w = w.w + b.w; } break;
+        case EP_SMUL: w.x = st.p0 * w.x; w.y = st.p0 * w.y; w.z = st.p0 * w.z; w.w = st.p0 * w.w; break;
+        case EP_SADD: w.x = w.x + st.p0; w.y = w.y + st.p0; w.z = w.z + st.p0; w.w = w.w + st.p0; break;
+        case EP_BN: {
+          const float4 sc = *(const float4*)(st.v0 + pc[g]), sh = *(const float4*)(st.v1 + pc[g]);
+          float t;
+          t = w.x * sc.x; w.x = t + sh.x;
+          t = w.y * sc.y; w.y = t + sh.y;
+          t = w.z * sc.z; w.z = t + sh.z;
+          t = w.w * sc.w; w.w = t + sh.w;
+        } break;
         case EP_ACT:
-#pragma unroll
-          for (int q = 0; q < 4; ++q) val[q] = ocr_act(st.act, st.p0, st.p1, val[q]);
+          w.x = ocr_act(st.act, st.p0, st.p1, w.x); w.y = ocr_act(st.act, st.p0, st.p1, w.y);
+          w.z = ocr_act(st.act, st.p0, st.p1, w.z); w.w = ocr_act(st.act, st.p0, st.p1, w.w);
           break;
-        case EP_ADDT:
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            if (mg + q < a.M) val[q] = val[q] + st.v0[(mg + q) * a.Cs_out + pc];
-          break;
-        default: break;
+        case EP_MULC: { const float4 q = *(const float4*)(st.v0 + (long)n * a.Cs_out + pc[g]); w.x = w.x * q.x; w.y = w.y * q.y; w.z = w.z * q.z; w.w = w.w * q.w; } break;
+        case EP_ADDT: { const float4 q = *(const float4*)(st.v0 + oidx[g]); w.x = w.x + q.x; w.y = w.y + q.y; w.z = w.z + q.z; w.w = w.w + q.w; } break;
+        case EP_ADDUP: {
+          const float4 q = *(const float4*)(st.v0 + (((long)n * st.a2 + oy[g] / st.a0) * st.a1 + ox[g] / st.a0) * a.Cs_out + pc[g]);
+          w.x = w.x + q.x; w.y = w.y + q.y; w.z = w.z + q.z; w.w = w.w + q.w;
+        } break;
       }
     }
-    if (a.out_mode == OUT_DECONV) {
+  }
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const long mr = mg + q;
-        if (mr < a.M) {
-          int rn, ry, rx;
-          decompose(mr, hw, a.OW, rn, ry, rx);
-          const long o = (((long)rn * (2 * a.OH) + 2 * ry + (dq >> 1)) * (2 * a.OW) + 2 * rx + (dq & 1)) * a.Cs_out + pc;
-          a.out[o] = is_pad ? 0.0f : val[q];
-        }
-      }
-    } else {
+  for (int g = 0; g < 4; ++g) {
+    if (!live[g]) continue;
+    float4 w = v[g];
+    if (a.out_mode == OUT_PLAIN) {
+      // logits / cls head: logical channel order, row stride = Cout (rows are not 16-byte aligned):
+      // scalar stores; per-channel parameter vectors of plain outputs are padded to whole tiles
+      const float e[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
       for (int q = 0; q < 4; ++q)
-        if (mg + q < a.M) a.out[(mg + q) * a.Cs_out + pc] = is_pad ? 0.0f : val[q];
+        if (pc[g] + q < a.Cout) a.out[oidx[g] + q] = e[q];
+      continue;
     }
+    if (a.Cout != a.Cs_out) {  // keep the pad channels of the octet layout at zero
+      if (c8i_logical(pc[g]) >= a.Cout) w.x = 0.f;
+      if (c8i_logical(pc[g] + 1) >= a.Cout) w.y = 0.f;
+      if (c8i_logical(pc[g] + 2) >= a.Cout) w.z = 0.f;
+      if (c8i_logical(pc[g] + 3) >= a.Cout) w.w = 0.f;
+    }
+    *(float4*)(a.out + oidx[g]) = w;
   }
 }
 
@@ -221,10 +236,10 @@ __global__ void __launch_bounds__(256, (NT <= 2 ? 4 : 3)) conv_mfma_kernel(const
     if (kk + 1 < KK) load_step(av_nxt, bv_nxt);
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av_cur.x, bv_cur[t].x, acc[t], 0, 0, 0);
-      acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av_cur.y, bv_cur[t].y, acc[t], 0, 0, 0);
-      acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av_cur.z, bv_cur[t].z, acc[t], 0, 0, 0);
-      acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av_cur.w, bv_cur[t].w, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv_cur[t].x, av_cur.x, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv_cur[t].y, av_cur.y, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv_cur[t].z, av_cur.z, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv_cur[t].w, av_cur.w, acc[t], 0, 0, 0);
     }
     av_cur = av_nxt;
 #pragma unroll
@@ -232,10 +247,10 @@ __global__ void __launch_bounds__(256, (NT <= 2 ? 4 : 3)) conv_mfma_kernel(const
   }
 
   // ---- epilogue: lane owns output column j (one channel), 16 rows ----
-  conv_epilogue_tile(a, ep, acc[0], nt0 + 0, m0, p, h, hw);
-  if constexpr (NT > 1) conv_epilogue_tile(a, ep, acc[1], nt0 + 1, m0, p, h, hw);
-  if constexpr (NT > 2) conv_epilogue_tile(a, ep, acc[2], nt0 + 2, m0, p, h, hw);
-  if constexpr (NT > 3) conv_epilogue_tile(a, ep, acc[3], nt0 + 3, m0, p, h, hw);
+  conv_epilogue_tile(a, ep, acc[0], nt0 + 0, m, h, n, y, x);
+  if constexpr (NT > 1) conv_epilogue_tile(a, ep, acc[1], nt0 + 1, m, h, n, y, x);
+  if constexpr (NT > 2) conv_epilogue_tile(a, ep, acc[2], nt0 + 2, m, h, n, y, x);
+  if constexpr (NT > 3) conv_epilogue_tile(a, ep, acc[3], nt0 + 3, m, h, n, y, x);
 }
 
 void launch_conv_mfma(const ConvArgs& a, const Epilogue& ep, int nt, hipStream_t s) {
@@ -355,10 +370,10 @@ __global__ void __launch_bounds__(256, 2) conv_lds_kernel(const ConvArgs a, cons
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
           const float4 bv = sB[(sstep * NT + t) * 64];
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv.x, av.x, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv.y, av.y, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv.z, av.z, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv.w, av.w, acc[t], 0, 0, 0);
         }
       }
     }
@@ -383,11 +398,14 @@ __global__ void __launch_bounds__(256, 2) conv_lds_kernel(const ConvArgs a, cons
     }
     __syncthreads();
   }
-  if (m0 >= a.M) return;
-  conv_epilogue_tile(a, ep, acc[0], nt0 + 0, m0, p, h, hw);
-  if constexpr (NT > 1) conv_epilogue_tile(a, ep, acc[1], nt0 + 1, m0, p, h, hw);
-  if constexpr (NT > 2) conv_epilogue_tile(a, ep, acc[2], nt0 + 2, m0, p, h, hw);
-  if constexpr (NT > 3) conv_epilogue_tile(a, ep, acc[3], nt0 + 3, m0, p, h, hw);
+  const long m = m0 + p;
+  if (m >= a.M) return;
+  int n, y, x;
+  decompose(m, hw, a.OW, n, y, x);
+  conv_epilogue_tile(a, ep, acc[0], nt0 + 0, m, h, n, y, x);
+  if constexpr (NT > 1) conv_epilogue_tile(a, ep, acc[1], nt0 + 1, m, h, n, y, x);
+  if constexpr (NT > 2) conv_epilogue_tile(a, ep, acc[2], nt0 + 2, m, h, n, y, x);
+  if constexpr (NT > 3) conv_epilogue_tile(a, ep, acc[3], nt0 + 3, m, h, n, y, x);
 }
 
 template <int NT>

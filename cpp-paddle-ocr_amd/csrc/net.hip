@@ -150,7 +150,11 @@ const float* Net::dev_vec(const std::string& key) const {
 
 // per-channel vector -> physical order, zero padded
 static std::vector<float> perm_vec(const std::vector<float>& v, int C, bool plain) {
-  if (plain) return v;
+  if (plain) {  // logical order, zero padded to whole 32-channel tiles (+ one float4) for vector loads
+    std::vector<float> o(((size_t)C + 31) / 32 * 32 + 4, 0.f);
+    for (int c = 0; c < C; ++c) o[c] = v[c];
+    return o;
+  }
   std::vector<float> o(c8i_stride(C), 0.f);
   for (int c = 0; c < C; ++c) o[c8i_phys(c)] = v[c];
   return o;
@@ -238,9 +242,12 @@ bool Net::load(const char* plan_text, const WeightMap& W, std::string& err) {
           if (!upload("stem:" + op.w, img)) { err = "hipMalloc failed"; return false; }
         } else {
           if (op.sh != 1 || op.sw != 1) { err = "strided dense conv with Cin != 3 is not on this path"; return false; }
-          const int cols = plain[op.out] ? co : c8i_stride(co);
+          // GEMM row R of the fragment image is PHYSICAL output channel R (logical for plain outputs)
+          const bool pl = plain[op.out];
+          const int cols = pl ? co : c8i_stride(co);
           auto f = build_frag(kh * kw, ci, cols, [&](int col, int k, int tap) {
-            return col < co ? w[((size_t)col * ci + k) * kh * kw + tap] : 0.f;
+            const int ch = pl ? col : c8i_logical(col);
+            return ch < co ? w[((size_t)ch * ci + k) * kh * kw + tap] : 0.f;
           });
           if (!upload("frag:" + op.w, f)) { err = "hipMalloc failed"; return false; }
         }
@@ -250,8 +257,12 @@ bool Net::load(const char* plan_text, const WeightMap& W, std::string& err) {
         const int ci = op.cin, co = op.cout;
         if (p->dims.size() != 2 || p->dims[0] != ci || p->dims[1] != co) { err = "linear weight shape mismatch " + op.w; return false; }
         const float* w = p->data.data();
-        const int cols = plain[op.out] ? co : c8i_stride(co);
-        auto f = build_frag(1, ci, cols, [&](int col, int k, int) { return col < co ? w[(size_t)k * co + col] : 0.f; });
+        const bool pl = plain[op.out];
+        const int cols = pl ? co : c8i_stride(co);
+        auto f = build_frag(1, ci, cols, [&](int col, int k, int) {
+          const int ch = pl ? col : c8i_logical(col);
+          return ch < co ? w[(size_t)k * co + ch] : 0.f;
+        });
         if (!upload("frag:" + op.w, f)) { err = "hipMalloc failed"; return false; }
       } break;
       case PlanOp::DECONV: {
@@ -267,7 +278,7 @@ bool Net::load(const char* plan_text, const WeightMap& W, std::string& err) {
         } else {
           const int cp = c8i_stride(co);
           auto f = build_frag(1, ci, 4 * cp, [&](int col, int k, int) {
-            const int q = col / cp, ch = col % cp;
+            const int q = col / cp, ch = c8i_logical(col % cp);
             return ch < co ? w[((size_t)k * co + ch) * 4 + q] : 0.f;
           });
           if (!upload("frag:" + op.w, f)) { err = "hipMalloc failed"; return false; }
@@ -324,12 +335,10 @@ bool Net::build_epilogue(const PlanOp& op, Epilogue& ep, bool conv_path, std::st
       case EP_BN: e.v0 = dev_vec("bns:" + st.n0); e.v1 = dev_vec("bnt:" + st.n0); break;
       case EP_ACT: break;
       case EP_MULC:
-        if (conv_path) { err = "mulc in a conv epilogue is not on this path"; return false; }
         e.v0 = tensor_ptr(st.tid);
         break;
       case EP_ADDT: e.v0 = tensor_ptr(st.tid); break;
       case EP_ADDUP:
-        if (conv_path) { err = "addup in a conv epilogue is not on this path"; return false; }
         e.v0 = tensor_ptr(st.tid);
         e.a0 = st.up;
         e.a1 = tensors_[st.tid].w;

@@ -23,6 +23,10 @@ struct PostArgs {
   int* cand_boxes;        // [N][max_cand][8]
   int* cand_valid;        // [N][max_cand]
   int* status;            // device error bits (POST_ERR_*)
+  unsigned* mask_pool;    // [N][mask_pool_words] scratch of the slow (polygon) score; null in fast mode
+  unsigned* mask_pool_top;  // [N] bump cursors (zeroed per call)
+  unsigned mask_pool_words;
+  int slow;               // det_db_score_mode == "slow"
   int pool_cap;
   int H, W, max_cand;
   float box_thresh, unclip_ratio, ratio_h, ratio_w;

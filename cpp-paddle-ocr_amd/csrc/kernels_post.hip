@@ -766,6 +766,155 @@ __device__ float box_score_fast_wave(const P2f arr[4], const float* __restrict__
   return cnt ? (float)(sum / (double)cnt) : 0.f;
 }
 
+// PolygonScoreAcc (score_mode "slow", /root/reference/src/postprocess_op.cpp:170-214): masked mean over the
+// border's bounding box with mask = cv::fillPoly(border polygon).  The polygon has hundreds of
+// vertices, so the mask is rasterised into a bit image in scratch instead of evaluated per pixel:
+//   outline : lanes stride over the edges, each walks its (clipped) Bresenham line, atomicOr of bits
+//   interior: counting sort of the scanline crossings by row (count / scan / scatter), then one lane
+//             per row sorts its few crossings and sets the spans [ceil(x_even), floor(x_odd)]
+//   mean    : lanes stride over the mask words.
+// pts: the border's vertices in contour order as (x, y) keys.  scratch: this border's slice of the
+// per-image word pool.  Returns the score in every lane, or -1 when the pool is exhausted.
+// cross-lane traffic through global scratch goes past the (non-coherent) vector L1
+#define GLD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define GST(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+__device__ float polygon_score_wave(const unsigned long long* __restrict__ pts, int npts, 
+                                    const float* __restrict__ pred, int H, int W, unsigned* pool, unsigned pool_words,
+                                    unsigned* pool_top, int lane, int* s_tmp /* >= 4 ints of LDS */) {
+  // bounding box of the vertices (ints already; PolygonScoreAcc floors/ceils floats of ints)
+  int bx0 = INT_MAX, bx1 = INT_MIN, by0 = INT_MAX, by1 = INT_MIN;
+  for (int i = lane; i < npts; i += 64) {
+    const int x = key_x(GLD(&pts[i])), y = key_y(GLD(&pts[i]));
+    bx0 = min(bx0, x); bx1 = max(bx1, x); by0 = min(by0, y); by1 = max(by1, y);
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    bx0 = min(bx0, __shfl_xor(bx0, off)); bx1 = max(bx1, __shfl_xor(bx1, off));
+    by0 = min(by0, __shfl_xor(by0, off)); by1 = max(by1, __shfl_xor(by1, off));
+  }
+  auto clampi = [](int v, int lo, int hi) { return v > hi ? hi : (v < lo ? lo : v); };
+  const int xmin = clampi(bx0, 0, W - 1), xmax = clampi(bx1, 0, W - 1);
+  const int ymin = clampi(by0, 0, H - 1), ymax = clampi(by1, 0, H - 1);
+  const int mw = xmax - xmin + 1, mh = ymax - ymin + 1;
+  const int wpr = (mw + 31) >> 5;  // mask words per row
+  // scratch carve-up: mask[mh*wpr] | cnt[mh+1] | crossings[2 words each]
+  // crossings total = sum over edges of their clipped height (<= npts * mh, usually ~2*mh)
+  // pass 0: count crossings
+  long long total_cross = 0;
+  for (int i = lane; i < npts; i += 64) {
+    const int j = i == 0 ? npts - 1 : i - 1;
+    const int y0 = key_y(GLD(&pts[j])) - ymin, y1 = key_y(GLD(&pts[i])) - ymin;
+    if (y0 != y1) {
+      const int lo = max(min(y0, y1), 0), hi = min(max(y0, y1), mh);
+      if (hi > lo) total_cross += hi - lo;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) total_cross += __shfl_xor(total_cross, off);
+  // whole 128-byte lines per border: no line of this scratch is shared with another wave
+  const unsigned need = ((unsigned)mh * wpr + (unsigned)(mh + 1) + (unsigned)mh + 2u + (unsigned)(2 * total_cross) + 31u) & ~31u;
+  if (lane == 0) {
+    const unsigned base = atomicAdd(pool_top, need);
+    s_tmp[0] = (base + need <= pool_words) ? (int)base : -1;
+  }
+  __syncthreads();
+  const int base = s_tmp[0];
+  __syncthreads();
+  if (base < 0) return -1.0f;
+  unsigned* mask = pool + base;
+  int* cnt = (int*)(mask + (size_t)mh * wpr);     // [mh+1] counts -> offsets
+  int* fillp = cnt + mh + 1;                      // [mh] scatter cursors
+  long long* cross = (long long*)(((size_t)(fillp + mh) + 7) & ~(size_t)7);  // 8-byte aligned (2 spare words reserved)
+  for (int i = lane; i < mh * wpr; i += 64) GST(&mask[i], 0u);
+  for (int i = lane; i <= mh; i += 64) GST(&cnt[i], 0);
+  __threadfence_block();
+  __syncthreads();
+  // ---- outline + crossing counts
+  for (int i = lane; i < npts; i += 64) {
+    const int j = i == 0 ? npts - 1 : i - 1;
+    const int ax = key_x(GLD(&pts[j])) - xmin, ay = key_y(GLD(&pts[j])) - ymin, bx = key_x(GLD(&pts[i])) - xmin, by = key_y(GLD(&pts[i])) - ymin;
+    const LineRast L = make_line(mw, mh, ax, ay, bx, by);
+    if (L.valid) {
+      int px = L.px, py = L.py, err = L.dx - 2 * L.dy;
+      for (int k = 0; k < L.count; ++k) {
+        atomicOr(&mask[(size_t)py * wpr + (px >> 5)], 1u << (px & 31));
+        const bool stepm = err < 0;
+        err += -2 * L.dy + (stepm ? 2 * L.dx : 0);
+        if (L.vert) { py += L.delta_major; if (stepm) px += L.delta_minor; }
+        else { px += L.delta_major; if (stepm) py += L.delta_minor; }
+      }
+    }
+    if (ay != by) {
+      const int lo = max(min(ay, by), 0), hi = min(max(ay, by), mh);
+      for (int y = lo; y < hi; ++y) atomicAdd(&cnt[y], 1);
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+  if (lane == 0) {  // exclusive scan of the per-row counts (mh <= image height)
+    int run = 0;
+    for (int y = 0; y < mh; ++y) { const int c = GLD(&cnt[y]); GST(&cnt[y], run); GST(&fillp[y], run); run += c; }
+    GST(&cnt[mh], run);
+  }
+  __threadfence_block();
+  __syncthreads();
+  // ---- scatter crossings (x in 16.16 at each scanline the edge covers)
+  for (int i = lane; i < npts; i += 64) {
+    const int j = i == 0 ? npts - 1 : i - 1;
+    const int ax = key_x(GLD(&pts[j])) - xmin, ay = key_y(GLD(&pts[j])) - ymin, bx = key_x(GLD(&pts[i])) - xmin, by = key_y(GLD(&pts[i])) - ymin;
+    if (ay == by) continue;
+    const long long p0x = (long long)ax << 16, p1x = (long long)bx << 16;
+    const long long dx = (p1x - p0x) / (long long)(by - ay);
+    const int y0 = min(ay, by), y1 = max(ay, by);
+    const long long x0 = ay < by ? p0x : p1x;
+    const int lo = max(y0, 0), hi = min(y1, mh);
+    for (int y = lo; y < hi; ++y) GST(&cross[atomicAdd(&fillp[y], 1)], x0 + (long long)(y - y0) * dx);
+  }
+  __threadfence_block();
+  __syncthreads();
+  // ---- spans: one lane per row
+  for (int y = lane; y < mh; y += 64) {
+    const int b = GLD(&cnt[y]), e = GLD(&cnt[y + 1]);
+    for (int i = b + 1; i < e; ++i) {  // insertion sort (a handful of crossings per row; this lane owns [b, e))
+      const long long v = GLD(&cross[i]);
+      int k = i - 1;
+      while (k >= b) {
+        const long long u = GLD(&cross[k]);
+        if (u <= v) break;
+        GST(&cross[k + 1], u);
+        --k;
+      }
+      GST(&cross[k + 1], v);
+    }
+    for (int i = b; i + 1 < e; i += 2) {
+      int x1 = (int)((GLD(&cross[i]) + 65535) >> 16), x2 = (int)(GLD(&cross[i + 1]) >> 16);
+      if (x1 < mw && x2 >= 0) {
+        x1 = max(x1, 0);
+        x2 = min(x2, mw - 1);
+        for (int x = x1; x <= x2; ++x) atomicOr(&mask[(size_t)y * wpr + (x >> 5)], 1u << (x & 31));
+      }
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+  // ---- masked mean
+  double sum = 0.0;
+  int n = 0;
+  for (int i = lane; i < mh * wpr; i += 64) {
+    unsigned m = GLD(&mask[i]);
+    const int y = i / wpr, xb = (i - y * wpr) << 5;
+    while (m) {
+      const int b = __ffs(m) - 1;
+      m &= m - 1;
+      sum += (double)pred[(long)(y + ymin) * W + xb + b + xmin];
+      ++n;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) { sum += __shfl_xor(sum, off); n += __shfl_xor(n, off); }
+  return n ? (float)(sum / (double)n) : 0.f;
+}
+
 // ---- ClipperOffset (jtRound, etClosedPolygon) + union clean-up, lane 0 only
 struct IPt { long long X, Y; };
 __device__ __forceinline__ long long clip_round(double v) { return v < 0 ? (long long)(v - 0.5) : (long long)(v + 0.5); }
@@ -973,8 +1122,26 @@ __global__ void __launch_bounds__(64) border_box_kernel(const PostArgs a) {
   P2f arr[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) { arr[i].x = s_box[2 * i]; arr[i].y = s_box[2 * i + 1]; }
-  // ---- BoxScoreFast (whole wave)
-  const float score = box_score_fast_wave(arr, a.pred + (long)n * a.H * a.W, a.H, a.W, lane);
+  // ---- box score (whole wave)
+  float score;
+  if (a.slow) {
+    // PolygonScoreAcc needs the vertices in contour order: the unsorted keys are still in the pool when
+    // the sort ran in LDS; after an in-place (global) sort restore the order by sorting on the index
+    if (!in_lds) {
+      for (int i = lane; i < n2; i += 64) { const unsigned long long k = GLD(&gkeys[i]); GST(&gkeys[i], (k << 32) | (k >> 32)); }
+      __threadfence_block();
+      __syncthreads();
+      bitonic_sort_wave(gkeys, n2, lane, false);
+      for (int i = lane; i < n2; i += 64) { const unsigned long long k = GLD(&gkeys[i]); GST(&gkeys[i], (k << 32) | (k >> 32)); }
+      __threadfence_block();
+      __syncthreads();
+    }
+    score = polygon_score_wave(gkeys, total, a.pred + (long)n * a.H * a.W, a.H, a.W, a.mask_pool + (size_t)n * a.mask_pool_words,
+                               a.mask_pool_words, a.mask_pool_top + n, lane, &s_flag);
+    if (score < 0.f) { if (lane == 0) atomicOr(a.status, POST_ERR_POOL); return; }
+  } else {
+    score = box_score_fast_wave(arr, a.pred + (long)n * a.H * a.W, a.H, a.W, lane);
+  }
   if (score < a.box_thresh) return;
   if (lane != 0) return;
   // ---- UnClip

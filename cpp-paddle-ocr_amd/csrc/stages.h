@@ -86,6 +86,9 @@ class DetStage {
   DevBuf<int> labels_, chunk_cnt_, ncont_all_, ncont_, starts_, npts_, poff_, iscratch_, cand_boxes_, cand_valid_, status_, out_boxes_,
       out_n_;
   DevBuf<unsigned long long> pool_;
+  DevBuf<unsigned> mask_pool_, mask_top_;
+  // words of polygon-score scratch per image: masks + crossing lists of all its borders (8 map areas of bits + slack)
+  static size_t mask_words(int H, int W) { return (((size_t)H * W / 4 + (1u << 16)) + 31) & ~(size_t)31; }
   int src_rows_ = 0, src_cols_ = 0;
   int ithresh_ = 0;
   int pool_cap_ = 0;

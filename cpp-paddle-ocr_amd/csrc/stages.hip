@@ -101,7 +101,7 @@ bool DetStage::create(const DetConfig& cfg, std::string& err, int& code) {
   cfg_ = cfg;
   code = OCR_ERR_ARG;
   if (cfg.precision != "fp32") { err = "precision '" + cfg.precision + "' is not implemented (fp32 only)"; return false; }
-  if (cfg.score_mode != "fast") { err = "det_db_score_mode '" + cfg.score_mode + "' is not implemented on the device path (fast only)"; return false; }
+  if (cfg.score_mode != "fast" && cfg.score_mode != "slow") { err = "det_db_score_mode must be fast or slow"; return false; }
   if (cfg.limit_type != "max" && cfg.limit_type != "min") { err = "limit_type must be max or min"; return false; }
   if (cfg.max_batch < 1) { err = "max_batch must be >= 1"; return false; }
   code = ocr_rt_init(cfg.device);
@@ -132,7 +132,8 @@ bool DetStage::ensure_post(int count, int H, int W, std::string& err) {
          poff_.ensure((size_t)count * max_cand, err) && pool_.ensure((size_t)count * pool_cap_, err) &&
          iscratch_.ensure((size_t)count * pool_cap_ * 4, err) && cand_boxes_.ensure((size_t)count * max_cand * 8, err) &&
          cand_valid_.ensure((size_t)count * max_cand, err) && status_.ensure(1, err) &&
-         (cfg_.use_dilation ? bitmap2_.ensure(px, err) : true);
+         (cfg_.use_dilation ? bitmap2_.ensure(px, err) : true) &&
+         (cfg_.score_mode == "slow" ? (mask_pool_.ensure((size_t)count * mask_words(H, W), err) && mask_top_.ensure(count, err)) : true);
 }
 
 int DetStage::run_post(int count, int H, int W, const float* prob, float ratio_h, float ratio_w, int src_h, int src_w,
@@ -152,6 +153,11 @@ int DetStage::run_post(int count, int H, int W, const float* prob, float ratio_h
   a.H = H; a.W = W; a.max_cand = 1000;
   a.box_thresh = (float)cfg_.box_thresh; a.unclip_ratio = (float)cfg_.unclip_ratio;
   a.ratio_h = ratio_h; a.ratio_w = ratio_w; a.src_h = src_h; a.src_w = src_w;
+  a.slow = cfg_.score_mode == "slow";
+  if (a.slow) {
+    a.mask_pool = mask_pool_.p; a.mask_pool_top = mask_top_.p; a.mask_pool_words = (unsigned)mask_words(H, W);
+    ST_HIP(hipMemsetAsync(mask_top_.p, 0, count * sizeof(unsigned), stream_));
+  }
   launch_post(a, count, out_boxes_.p, cap, out_n_.p, stream_);
   int status = 0;
   ST_HIP(hipMemcpyAsync(n, out_n_.p, count * sizeof(int), hipMemcpyDeviceToHost, stream_));

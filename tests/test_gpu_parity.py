@@ -98,6 +98,41 @@ def test_det_post_on_probability_maps(pkg, built, dilate):
     det.close()
 
 
+@pytest.mark.parametrize("dilate", [False, True])
+def test_det_post_slow_score_mode(pkg, built, dilate):
+    """det_db_score_mode="slow": PolygonScoreAcc over the contour itself (postprocess_op.cpp:170-214)."""
+    import oracle as O
+    from scipy import ndimage
+    from synth_data import cfg2_sample
+    det = pkg.Det(limit_side_len=960, thresh=0.3, box_thresh=0.6, unclip_ratio=2.0, use_dilation=dilate, score_mode="slow")
+    for i in range(2):
+        _, prob, _ = cfg2_sample(i)
+        bo, bg = O.det_post(prob, 0.3, 0.6, 2.0, 960, 960, dilate, slow=True), det.post(prob, 960, 960)
+        assert len(bo) == len(bg) > 0 and all(np.array_equal(a, b) for a, b in zip(bo, bg))
+    rs = np.random.RandomState(11)
+    for i in range(8):   # ragged blobs with holes and frame contact: polygon mask != box mask
+        H, W = 192 + 64 * i, 352 + 32 * (i % 3)
+        f = ndimage.gaussian_filter(rs.rand(H, W), 1.0 + 0.7 * i)
+        f = (((f - f.min()) / (f.max() - f.min())) ** (1.2 + 0.3 * i)).astype(np.float32)
+        bo, bg = O.det_post(f, 0.3, 0.6, 2.0, 2 * H, 3 * W, dilate, slow=True), det.post(f, 2 * H, 3 * W)
+        assert len(bo) == len(bg) and all(np.array_equal(a, b) for a, b in zip(bo, bg))
+    # ~900 ragged borders, the largest with 8-16 thousand vertices (> 4096: the global-memory sort path restores contour order)
+    H = W = 960
+    f = (ndimage.gaussian_filter(np.random.RandomState(5).rand(H, W), 3.0) > 0.5).astype(np.float32)
+    f[0, :] = f[-1, :] = f[:, 0] = f[:, -1] = 1
+    det2 = pkg.Det(limit_side_len=960, thresh=0.3, box_thresh=0.1, unclip_ratio=2.0, use_dilation=dilate, score_mode="slow")
+    fast = pkg.Det(limit_side_len=960, thresh=0.3, box_thresh=0.1, unclip_ratio=2.0, use_dilation=dilate)
+    bo, bg = O.det_post(f, 0.3, 0.1, 2.0, H, W, dilate, slow=True), det2.post(f, H, W)
+    assert len(bo) == len(bg) > 500 and all(np.array_equal(a, b) for a, b in zip(bo, bg))
+    if dilate:    # the mode is really a different score, not an alias of "fast"
+        assert len(bg) != len(fast.post(f, H, W))
+    det2.close()
+    for z in (np.zeros((64, 96), np.float32), np.ones((64, 96), np.float32)):
+        assert len(det.post(z, 64, 96)) == len(O.det_post(z, 0.3, 0.6, 2.0, 64, 96, dilate, slow=True))
+    det.close()
+    fast.close()
+
+
 def test_det_batch_full_size_and_determinism(pkg, built):
     """cfg2 size (960x960) with the full network on synthetic weights: batch == singles == oracle."""
     from pipeline import Pipeline, DetCfg

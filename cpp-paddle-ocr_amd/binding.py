@@ -344,7 +344,8 @@ class Rec:
 # fused pipeline + device helpers
 # ---------------------------------------------------------------------------------------------
 class ocr_pipe_cfg(C.Structure):
-    _fields_ = [("det", ocr_det_cfg), ("cls", ocr_cls_cfg), ("rec", ocr_rec_cfg), ("enable_cls", C.c_int)]
+    _fields_ = [("det", ocr_det_cfg), ("cls", ocr_cls_cfg), ("rec", ocr_rec_cfg), ("enable_cls", C.c_int),
+                ("crop_mode", C.c_int)]
 
 
 class ocr_word(C.Structure):
@@ -353,7 +354,7 @@ class ocr_word(C.Structure):
 
 EXPORTS += ["ocr_pipe_cfg_default", "ocr_pipe_create", "ocr_pipe_destroy", "ocr_pipe_run", "ocr_pipe_run_device",
             "ocr_pipe_label", "ocr_pipe_det_shape", "ocr_pipe_timing", "ocr_pipe_timing_report", "ocr_dev_alloc",
-            "ocr_dev_free", "ocr_dev_upload", "ocr_dev_download", "ocr_dev_sync"]
+            "ocr_dev_free", "ocr_dev_upload", "ocr_dev_download", "ocr_dev_sync", "ocr_rotate_crop", "ocr_rotate_crop_shape"]
 
 
 def _pipe_protos(L):
@@ -376,7 +377,40 @@ def _pipe_protos(L):
     L.ocr_dev_free.argtypes = [vp]
     L.ocr_dev_upload.argtypes = [vp, vp, C.c_size_t]
     L.ocr_dev_download.argtypes = [vp, vp, C.c_size_t]
+    L.ocr_rotate_crop.argtypes = [vp, C.c_int, C.c_int, C.c_size_t, vp, C.c_int, vp, C.c_size_t, vp, ip, ip]
+    L.ocr_rotate_crop_shape.argtypes = [C.c_int, C.c_int, vp, ip, ip]
     L._pipe_protos_done = True
+
+
+CROP_BOUNDING_RECT, CROP_ROTATE = 0, 1
+
+
+def rotate_crop_shape(rows, cols, box):
+    """ocr_rotate_crop_shape: (rows, cols) of GetRotateCropImage's result (host arithmetic only)."""
+    L = lib()
+    _pipe_protos(L)
+    b = np.ascontiguousarray(np.asarray(box, np.int32).reshape(8))
+    r, c = C.c_int(), C.c_int()
+    check(L.ocr_rotate_crop_shape(rows, cols, b.ctypes.data, C.byref(r), C.byref(c)))
+    return r.value, c.value
+
+
+def rotate_crops(img, boxes):
+    """Utility::GetRotateCropImage for each box of one image on the device (ocr_rotate_crop)."""
+    L = lib()
+    _pipe_protos(L)
+    img = np.asarray(img, np.uint8)
+    assert img.ndim == 3 and img.shape[2] == 3 and img.strides[1] == 3 and img.strides[2] == 1
+    b = np.ascontiguousarray(np.asarray(boxes, np.int32).reshape(-1, 8))
+    n = b.shape[0]
+    shapes = [rotate_crop_shape(img.shape[0], img.shape[1], b[k]) for k in range(n)]
+    cap = sum(r * c * 3 for r, c in shapes)
+    out = np.empty(max(cap, 1), np.uint8)
+    off = np.zeros(n + 1, np.uint64)
+    rr, cc = (C.c_int * n)(), (C.c_int * n)()
+    check(L.ocr_rotate_crop(img.ctypes.data, img.shape[0], img.shape[1], img.strides[0], b.ctypes.data, n, out.ctypes.data,
+                            cap, off.ctypes.data, rr, cc))
+    return [out[int(off[k]):int(off[k + 1])].reshape(rr[k], cc[k], 3).copy() for k in range(n)]
 
 
 class DevArray:
@@ -408,7 +442,7 @@ class Pipe:
 
     def __init__(self, model_root=None, device=0, enable_cls=False, limit_type="max", limit_side_len=512, thresh=0.2,
                  box_thresh=0.4, unclip_ratio=1.8, use_dilation=False, rec_batch_num=16, rec_img_h=28, rec_img_w=192,
-                 cls_batch_num=8):
+                 cls_batch_num=8, crop_mode=CROP_BOUNDING_RECT, score_mode="fast"):
         L = lib()
         _pipe_protos(L)
         root = model_root or MODELS
@@ -416,8 +450,9 @@ class Pipe:
         L.ocr_pipe_cfg_default(C.byref(cfg))
         self._keep = [os.path.join(root, "det").encode(), os.path.join(root, "cls").encode(),
                       os.path.join(root, "rec").encode(), os.path.join(root, "rec", "ppocr_keys_v1.txt").encode(),
-                      limit_type.encode()]
-        cfg.det.model_dir, cfg.cls.model_dir, cfg.rec.model_dir, cfg.rec.label_path, cfg.det.limit_type = self._keep
+                      limit_type.encode(), score_mode.encode()]
+        (cfg.det.model_dir, cfg.cls.model_dir, cfg.rec.model_dir, cfg.rec.label_path, cfg.det.limit_type,
+         cfg.det.det_db_score_mode) = self._keep
         cfg.det.device_id = device
         cfg.det.limit_side_len = limit_side_len
         cfg.det.det_db_thresh, cfg.det.det_db_box_thresh, cfg.det.det_db_unclip_ratio = thresh, box_thresh, unclip_ratio
@@ -425,6 +460,7 @@ class Pipe:
         cfg.rec.rec_batch_num, cfg.rec.rec_img_h, cfg.rec.rec_img_w = rec_batch_num, rec_img_h, rec_img_w
         cfg.cls.cls_batch_num = cls_batch_num
         cfg.enable_cls = int(enable_cls)
+        cfg.crop_mode = int(crop_mode)
         self.h = C.c_void_p()
         check(L.ocr_pipe_create(C.byref(cfg), C.byref(self.h)))
         self.times = (C.c_double * 3)()

@@ -34,6 +34,17 @@ struct RotDesc {
 };
 // seg: nimages+1 offsets into d; rotations of one image are applied in order by one workgroup
 void launch_rotate180_list(const RotDesc* d, const int* seg, int nimages, hipStream_t s);
+// One perspective crop (Utility::GetRotateCropImage): destination pixel -> source position through
+// the inverse homography, bilinear taps in 15-bit fixed point, constant-0 border, optional 90-degree turn.
+struct WarpDesc {
+  const uint8_t* src;   // first pixel of the bounding-box crop inside the source image
+  size_t sstride;
+  int sw, sh;           // crop size (taps outside read 0)
+  uint8_t* dst;         // packed result, (rot ? dw x dh : dh x dw) x 3
+  int dw, dh, rot, bw0;
+  double m[9];
+};
+void launch_warp_crops(const WarpDesc* d, int ncrops, int max_pixels, hipStream_t s);
 void launch_ctc(const int* amax, const float* pmax, int nlines, int T, int max_len, int* ids, int* lens, float* scores,
                 hipStream_t s);
 

@@ -6,6 +6,8 @@
 // coalesced along x, no LDS.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "kernels_pre.h"
 
 namespace ocr {
@@ -170,6 +172,55 @@ __global__ void __launch_bounds__(1024) rotate180_list_kernel(const RotDesc* __r
 void launch_rotate180_list(const RotDesc* d, const int* seg, int nimages, hipStream_t s) {
   if (nimages <= 0) return;
   hipLaunchKernelGGL(rotate180_list_kernel, dim3(nimages), dim3(1024), 0, s, d, seg);
+}
+
+// cv::warpPerspective(crop, M, INTER_LINEAR, BORDER_CONSTANT 0) restated per pixel
+// (/root/reference/src/utility.cpp:175-180; the reference's BORDER_REPLICATE lands in the flags slot
+// and therefore selects INTER_LINEAR).  The source coordinate is evaluated in double exactly as
+// WarpPerspectiveInvoker does: base terms at the start of the pixel's bw0-column block, the in-block
+// offset added afterwards, scaled by 32/W, rounded to nearest-even, split into integer and 1/32 parts.
+__global__ void __launch_bounds__(256) warp_crop_kernel(const WarpDesc* __restrict__ descs) {
+  const WarpDesc& q = descs[blockIdx.y];
+  const int dw = q.dw, dh = q.dh;
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (long)dw * dh) return;
+  const int y = (int)(t / dw), x = (int)(t - (long)y * dw);
+  const int xb = (x / q.bw0) * q.bw0, x1 = x - xb;
+  const double X0 = q.m[0] * xb + q.m[1] * y + q.m[2];
+  const double Y0 = q.m[3] * xb + q.m[4] * y + q.m[5];
+  const double W0 = q.m[6] * xb + q.m[7] * y + q.m[8];
+  double W = W0 + q.m[6] * x1;
+  W = W != 0. ? 32. / W : 0.;
+  double fX = (X0 + q.m[0] * x1) * W, fY = (Y0 + q.m[3] * x1) * W;
+  fX = fX < 2147483647.0 ? fX : 2147483647.0;   // std::min(INT_MAX, v) then std::max(INT_MIN, .)
+  fX = -2147483648.0 < fX ? fX : -2147483648.0;
+  fY = fY < 2147483647.0 ? fY : 2147483647.0;
+  fY = -2147483648.0 < fY ? fY : -2147483648.0;
+  const int X = __double2int_rn(fX), Y = __double2int_rn(fY);
+  const int sx = min(32767, max(-32768, X >> 5)), sy = min(32767, max(-32768, Y >> 5));
+  const int fx = X & 31, fy = Y & 31;
+  const int w00 = (32 - fy) * (32 - fx) * 32, w01 = (32 - fy) * fx * 32, w10 = fy * (32 - fx) * 32, w11 = fy * fx * 32;
+  uint8_t* D = q.dst + (q.rot ? ((size_t)(dw - 1 - x) * dh + y) * 3 : ((size_t)y * dw + x) * 3);
+  if (sx >= q.sw || sx + 1 < 0 || sy >= q.sh || sy + 1 < 0) {
+    D[0] = 0; D[1] = 0; D[2] = 0;
+    return;
+  }
+  const bool xin0 = sx >= 0, xin1 = sx + 1 < q.sw, yin0 = sy >= 0, yin1 = sy + 1 < q.sh;
+  const uint8_t* r0 = q.src + (long)sy * (long)q.sstride + (long)sx * 3;
+  const uint8_t* r1 = r0 + q.sstride;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const int v00 = (yin0 && xin0) ? r0[c] : 0, v01 = (yin0 && xin1) ? r0[3 + c] : 0;
+    const int v10 = (yin1 && xin0) ? r1[c] : 0, v11 = (yin1 && xin1) ? r1[3 + c] : 0;
+    const int v = (v00 * w00 + v01 * w01 + v10 * w10 + v11 * w11 + (1 << 14)) >> 15;
+    D[c] = (uint8_t)min(255, max(0, v));
+  }
+}
+void launch_warp_crops(const WarpDesc* d, int ncrops, int max_pixels, hipStream_t s) {
+  if (max_pixels <= 0) return;
+  for (int at = 0; at < ncrops; at += 65535)  // grid.y limit
+    hipLaunchKernelGGL(warp_crop_kernel, dim3((unsigned)((max_pixels + 255) / 256), (unsigned)std::min(65535, ncrops - at)), dim3(256),
+                       0, s, d + at);
 }
 
 // greedy CTC collapse, one thread per line (sequential over T: the score sum order of the reference)

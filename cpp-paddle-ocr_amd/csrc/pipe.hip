@@ -7,6 +7,7 @@
 #include <memory>
 
 #include "capi_common.h"
+#include "crop.h"
 #include "stages.h"
 
 using namespace ocr;
@@ -25,6 +26,9 @@ struct ocr_pipe {
   DevBuf<uint8_t> upload;
   DevBuf<RotDesc> rot_desc;
   DevBuf<int> rot_seg;
+  int crop_mode = 0;  // OCR_CROP_BOUNDING_RECT | OCR_CROP_ROTATE
+  DevBuf<uint8_t> crop_arena;
+  DevBuf<WarpDesc> warp_desc;
   std::vector<int32_t> boxes;
   std::vector<int> nbox;
 
@@ -43,6 +47,11 @@ struct ocr_pipe {
     // crop rectangles: cv::boundingRect(points) & image rect (ocr_worker.cpp:245-258)
     std::vector<LineSrc> lines;
     std::vector<int> seg(1, 0);
+    std::vector<int> line_box;  // box index (within its image) of every line
+    if (crop_mode == OCR_CROP_ROTATE) {
+      rc = rotate_crops(dev, rows, cols, count, cap, lines, seg, line_box, err);
+      if (rc) return rc;
+    } else
     for (int i = 0; i < count; ++i) {
       for (int j = 0; j < nbox[i]; ++j) {
         const int32_t* b = &boxes[((size_t)i * cap + j) * 8];
@@ -53,8 +62,12 @@ struct ocr_pipe {
         }
         const int ix0 = std::max(x0, 0), iy0 = std::max(y0, 0);
         const int ix1 = std::min(x1 + 1, cols), iy1 = std::min(y1 + 1, rows);
-        if (ix1 - ix0 > 0 && iy1 - iy0 > 0)
+        if (ix1 - ix0 > 0 && iy1 - iy0 > 0) {
+          // `word.box = det_boxes[i]` pairs text k with box k of the image, even when an empty crop was
+          // skipped before it (reference quirk, ocr_worker.cpp:293-299) — kept.
+          line_box.push_back((int)lines.size() - seg.back());
           lines.push_back(LineSrc{dev + img_bytes * i, row, ix0, iy0, ix1 - ix0, iy1 - iy0});
+        }
       }
       seg.push_back((int)lines.size());
     }
@@ -99,9 +112,7 @@ struct ocr_pipe {
     for (int i = 0; i < count; ++i) {
       for (int k = seg[i]; k < seg[i + 1]; ++k) {
         ocr_word w;
-        // `word.box = det_boxes[i]` pairs text k with box k of the image, even when an empty crop was
-        // skipped before it (reference quirk, ocr_worker.cpp:293-299) — kept.
-        memcpy(w.box, &boxes[((size_t)i * cap + (k - seg[i])) * 8], sizeof(w.box));
+        memcpy(w.box, &boxes[((size_t)i * cap + line_box[k]) * 8], sizeof(w.box));
         w.ids_off = (int32_t)out_ids[i].size();
         w.ids_len = lens[k];
         w.confidence = scores[k];
@@ -109,6 +120,47 @@ struct ocr_pipe {
         out_words[i].push_back(w);
       }
     }
+    return OCR_OK;
+  }
+
+  // crop_mode OCR_CROP_ROTATE: every box becomes its own perspective-rectified image
+  // (Utility::GetRotateCropImage, utility.cpp:137-190) in the crop arena
+  int rotate_crops(const uint8_t* dev, int rows, int cols, int count, int cap, std::vector<LineSrc>& lines, std::vector<int>& seg,
+                   std::vector<int>& line_box, std::string& err) {
+    const size_t row = (size_t)cols * 3, img_bytes = row * rows;
+    std::vector<WarpDesc> wd;
+    std::vector<size_t> off;
+    size_t total = 0;
+    int max_px = 0;
+    for (int i = 0; i < count; ++i) {
+      for (int j = 0; j < nbox[i]; ++j) {
+        CropPlan p;
+        if (!plan_rotate_crop(rows, cols, &boxes[((size_t)i * cap + j) * 8], p)) continue;
+        WarpDesc d;
+        d.src = dev + img_bytes * i + (size_t)p.top * row + (size_t)p.left * 3;
+        d.sstride = row; d.sw = p.sw; d.sh = p.sh; d.dst = nullptr; d.dw = p.dw; d.dh = p.dh; d.rot = p.rot; d.bw0 = p.bw0;
+        memcpy(d.m, p.minv, sizeof(d.m));
+        wd.push_back(d);
+        off.push_back(total);
+        total += ((size_t)p.dw * p.dh * 3 + 15) & ~(size_t)15;
+        max_px = std::max(max_px, p.dw * p.dh);
+        line_box.push_back(j);
+        lines.push_back(LineSrc{nullptr, (size_t)p.ocols * 3, 0, 0, p.ocols, p.orows});
+      }
+      seg.push_back((int)lines.size());
+    }
+    if (wd.empty()) return OCR_OK;
+    if (!crop_arena.ensure(total, err) || !warp_desc.ensure(wd.size(), err)) return OCR_ERR_DEVICE;
+    for (size_t k = 0; k < wd.size(); ++k) {
+      wd[k].dst = crop_arena.p + off[k];
+      lines[k].img = wd[k].dst;
+    }
+    if (hipMemcpyAsync(warp_desc.p, wd.data(), wd.size() * sizeof(WarpDesc), hipMemcpyHostToDevice, det.stream()) != hipSuccess) {
+      err = "crop list upload failed";
+      return OCR_ERR_DEVICE;
+    }
+    launch_warp_crops(warp_desc.p, (int)wd.size(), max_px, det.stream());
+    if (hipStreamSynchronize(det.stream()) != hipSuccess) { err = "crop kernel failed"; return OCR_ERR_DEVICE; }
     return OCR_OK;
   }
 };
@@ -142,6 +194,7 @@ void ocr_pipe_cfg_default(ocr_pipe_cfg* c) {
   ocr_cls_cfg_default(&c->cls);
   ocr_rec_cfg_default(&c->rec);
   c->enable_cls = 0;
+  c->crop_mode = OCR_CROP_BOUNDING_RECT;
 }
 
 int ocr_pipe_create(const ocr_pipe_cfg* c, ocr_pipe** out) {
@@ -149,6 +202,8 @@ int ocr_pipe_create(const ocr_pipe_cfg* c, ocr_pipe** out) {
   if (c->enable_cls && !c->cls.model_dir) return fail(OCR_ERR_ARG, "cls model_dir missing");
   std::unique_ptr<ocr_pipe> h(new ocr_pipe());
   h->device = c->det.device_id;
+  if (c->crop_mode != OCR_CROP_BOUNDING_RECT && c->crop_mode != OCR_CROP_ROTATE) return fail(OCR_ERR_ARG, "unknown crop_mode");
+  h->crop_mode = c->crop_mode;
   std::string err;
   int code = 0;
   DetConfig d;
@@ -268,6 +323,55 @@ int ocr_pipe_timing_report(ocr_pipe* h, char* buf, size_t cap) {
       off += n;
     }
   if (off < cap) buf[off] = 0;
+  return OCR_OK;
+}
+
+int ocr_rotate_crop_shape(int rows, int cols, const int32_t* box, int* out_rows, int* out_cols) {
+  if (!box || !out_rows || !out_cols) return fail(OCR_ERR_ARG, "null argument");
+  CropPlan p;
+  if (!plan_rotate_crop(rows, cols, box, p)) return fail(OCR_ERR_ARG, "box has no crop inside the image");
+  *out_rows = p.orows;
+  *out_cols = p.ocols;
+  return OCR_OK;
+}
+
+int ocr_rotate_crop(const uint8_t* bgr, int rows, int cols, size_t row_stride, const int32_t* boxes, int n, uint8_t* out,
+                    size_t out_cap, size_t* out_off, int* out_rows, int* out_cols) {
+  if (!bgr || rows <= 0 || cols <= 0 || !boxes || n < 1 || !out || !out_off || !out_rows || !out_cols)
+    return fail(OCR_ERR_ARG, "bad argument");
+  const size_t row = (size_t)cols * 3, stride = row_stride ? row_stride : row;
+  std::vector<WarpDesc> wd(n);
+  std::vector<size_t> src_off(n);
+  size_t total = 0;
+  int max_px = 0;
+  for (int k = 0; k < n; ++k) {
+    CropPlan p;
+    if (!plan_rotate_crop(rows, cols, boxes + 8 * k, p)) return fail(OCR_ERR_ARG, "box has no crop inside the image");
+    WarpDesc& d = wd[k];
+    d.sstride = row; d.sw = p.sw; d.sh = p.sh; d.dw = p.dw; d.dh = p.dh; d.rot = p.rot; d.bw0 = p.bw0;
+    src_off[k] = (size_t)p.top * row + (size_t)p.left * 3;
+    memcpy(d.m, p.minv, sizeof(d.m));
+    out_off[k] = total;
+    out_rows[k] = p.orows;
+    out_cols[k] = p.ocols;
+    total += (size_t)p.dw * p.dh * 3;
+    max_px = std::max(max_px, p.dw * p.dh);
+  }
+  out_off[n] = total;
+  if (total > out_cap) return fail(OCR_ERR_CAPACITY, "crop buffer too small");
+  std::string err;
+  DevBuf<uint8_t> dimg, dout;
+  DevBuf<WarpDesc> ddesc;
+  if (!dimg.ensure(row * rows, err) || !dout.ensure(total, err) || !ddesc.ensure(n, err)) return fail(OCR_ERR_DEVICE, err);
+  for (int k = 0; k < n; ++k) {
+    wd[k].src = dimg.p + src_off[k];
+    wd[k].dst = dout.p + out_off[k];
+  }
+  CAPI_HIP(hipMemcpy2D(dimg.p, row, bgr, stride, row, rows, hipMemcpyHostToDevice));
+  CAPI_HIP(hipMemcpy(ddesc.p, wd.data(), n * sizeof(WarpDesc), hipMemcpyHostToDevice));
+  launch_warp_crops(ddesc.p, n, max_px, 0);
+  CAPI_HIP(hipGetLastError());
+  CAPI_HIP(hipMemcpy(out, dout.p, total, hipMemcpyDeviceToHost));
   return OCR_OK;
 }
 

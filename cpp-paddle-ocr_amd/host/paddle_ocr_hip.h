@@ -58,6 +58,26 @@ inline void check_ocr(int rc, const char* what) {
   if (rc != OCR_OK) throw std::runtime_error(std::string(what) + ": " + ocr_last_error());
 }
 
+// Utility (the hot subset of /root/reference/include/paddle_ocr/utility.h)
+class Utility {
+ public:
+  // Utility::GetRotateCropImage (utility.cpp:137-190): perspective-rectified crop of one det box.
+  // Throws where the reference would die inside cv::Mat::operator() (box outside the image / empty).
+  static Image GetRotateCropImage(const ImageView& srcimage, const std::vector<std::vector<int>>& box) {
+    if (srcimage.empty() || box.size() != 4) throw std::runtime_error("GetRotateCropImage: bad input");
+    int32_t b[8];
+    for (int i = 0; i < 4; ++i) { b[2 * i] = box[i].at(0); b[2 * i + 1] = box[i].at(1); }
+    Image out;
+    check_ocr(ocr_rotate_crop_shape(srcimage.rows, srcimage.cols, b, &out.rows, &out.cols), "GetRotateCropImage");
+    out.pixels.resize((size_t)out.rows * out.cols * 3);
+    size_t off[2];
+    int r, c;
+    check_ocr(ocr_rotate_crop(srcimage.data, srcimage.rows, srcimage.cols, srcimage.step, b, 1, out.pixels.data(), out.pixels.size(),
+                              off, &r, &c), "GetRotateCropImage");
+    return out;
+  }
+};
+
 class DBDetector {
  public:
   // Same parameter list as the reference constructor (ocr_det.h:60-75).  use_gpu must be true: this
@@ -245,7 +265,9 @@ class OCRWorker {
  public:
   // OCRWorker(worker_id, model_dir, use_gpu, gpu_id = 0, enable_cls = false); hyper-parameters are the
   // literals of the reference constructor (ocr_worker.cpp:21-63) — they are ocr_pipe_cfg_default().
-  OCRWorker(int worker_id, const std::string& model_dir, bool use_gpu, int gpu_id = 0, bool enable_cls = false)
+  // rotate_crops (extension, default off): crops through Utility::GetRotateCropImage instead of ROI views.
+  OCRWorker(int worker_id, const std::string& model_dir, bool use_gpu, int gpu_id = 0, bool enable_cls = false,
+            bool rotate_crops = false)
       : worker_id_(worker_id), running_(false), is_idle_(true) {
     if (!use_gpu) throw std::runtime_error("OCRWorker: this build has no CPU path (use_gpu must be true)");
     det_dir_ = model_dir + "/det"; cls_dir_ = model_dir + "/cls"; rec_dir_ = model_dir + "/rec";
@@ -256,6 +278,7 @@ class OCRWorker {
     c.cls.model_dir = cls_dir_.c_str();
     c.rec.model_dir = rec_dir_.c_str(); c.rec.label_path = dict_.c_str();
     c.enable_cls = enable_cls;
+    c.crop_mode = rotate_crops ? OCR_CROP_ROTATE : OCR_CROP_BOUNDING_RECT;
     check_ocr(ocr_pipe_create(&c, &pipe_), "OCRWorker");
   }
   virtual ~OCRWorker() { stop(); ocr_pipe_destroy(pipe_); }

@@ -69,6 +69,24 @@ int main(int argc, char** argv) {
     OCRResult res = wc.processRequest(r);
     CHECK(res.success && res.width == cols && res.height == rows && res.processing_time_ms > 0);
     printf("CLSWORDS %zu\n", res.words.size());
+    OCRWorker wr(2, model_root, true, 0, true, true);  // cls on, perspective crops
+    OCRResult rr = wr.processRequest(r);
+    CHECK(rr.success && rr.words.size() == res.words.size());
+  }
+  {
+    // Utility::GetRotateCropImage: an axis-aligned box is the plain crop; a tall one comes back turned
+    Image im(img);
+    Image c = Utility::GetRotateCropImage(img, {{5, 7}, {90, 7}, {90, 40}, {5, 40}});
+    CHECK(c.rows == 33 && c.cols == 85);
+    bool same = true;
+    for (int y = 0; y < c.rows && same; ++y)
+      same = memcmp(&c.pixels[(size_t)y * c.cols * 3], &im.pixels[((size_t)(y + 7) * cols + 5) * 3], (size_t)c.cols * 3) == 0;
+    CHECK(same);
+    Image t = Utility::GetRotateCropImage(img, {{5, 7}, {30, 7}, {30, 140}, {5, 140}});
+    CHECK(t.rows == 25 && t.cols == 133);
+    bool threw = false;
+    try { Utility::GetRotateCropImage(img, {{5, 5}, {5, 5}, {5, 5}, {5, 5}}); } catch (const std::exception&) { threw = true; }
+    CHECK(threw);
   }
   {
     bool threw = false;

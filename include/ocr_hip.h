@@ -124,7 +124,7 @@ int ocr_rec_steps(ocr_rec* h, int index, int32_t* amax, float* pmax, int cap, in
 
 /* ---------------------------------------------------------------- pipeline */
 /* OCRWorker::processRequest (/root/reference/src/ocr_worker.cpp:213-311) for a batch of images in one
- * device pass: det -> axis-aligned crops -> [cls -> in-place 180 degree rotation] -> rec -> CTC.
+ * device pass: det -> crops (crop_mode) -> [cls -> in-place 180 degree rotation] -> rec -> CTC.
  * The three stage handles live on one device; images are uploaded once and the crops are taken
  * from the device copy (the reference's ROI views of the request's cv::Mat clone). */
 typedef struct ocr_pipe_cfg {
@@ -132,7 +132,10 @@ typedef struct ocr_pipe_cfg {
   ocr_cls_cfg cls;
   ocr_rec_cfg rec;
   int enable_cls; /* OCRWorker(..., enable_cls = false) */
+  int crop_mode;  /* OCR_CROP_BOUNDING_RECT: ROI views, what the worker does (ocr_worker.cpp:244-259);
+                   * OCR_CROP_ROTATE: Utility::GetRotateCropImage per box (utility.cpp:137-190) */
 } ocr_pipe_cfg;
+enum { OCR_CROP_BOUNDING_RECT = 0, OCR_CROP_ROTATE = 1 };
 void ocr_pipe_cfg_default(ocr_pipe_cfg* cfg);
 /* WordResult (ocr_worker.h:34-38): text as class ids ids[ids_off .. ids_off+ids_len) */
 typedef struct ocr_word {
@@ -160,6 +163,18 @@ int ocr_pipe_det_shape(ocr_pipe* h, int rows, int cols, int* net_rows, int* net_
 /* HIP-event timing of every kernel launch of the three networks during subsequent runs */
 int ocr_pipe_timing(ocr_pipe* h, int enable);
 int ocr_pipe_timing_report(ocr_pipe* h, char* buf, size_t cap);
+
+/* Utility::GetRotateCropImage (/root/reference/src/utility.cpp:137-190) for n boxes (n x 8 ints,
+ * x0,y0..x3,y3) of one host image: bounding-box crop, cv::getPerspectiveTransform onto
+ * int(|p0p1|) x int(|p0p3|), cv::warpPerspective (bilinear, constant-0 border: the reference passes
+ * BORDER_REPLICATE in the flags slot), and a 90-degree turn when rows >= 1.5 cols.
+ * Crop k is out[out_off[k] .. out_off[k+1]) as packed BGR of out_rows[k] x out_cols[k];
+ * out_off has n+1 entries.  A box whose bounding box is empty or leaves the image is an OCR_ERR_ARG
+ * (the reference would throw from cv::Mat::operator() inside a noexcept function). */
+int ocr_rotate_crop(const uint8_t* bgr, int rows, int cols, size_t row_stride, const int32_t* boxes, int n, uint8_t* out,
+                    size_t out_cap, size_t* out_off, int* out_rows, int* out_cols);
+/* size of that crop without computing it (host arithmetic only) */
+int ocr_rotate_crop_shape(int rows, int cols, const int32_t* box, int* out_rows, int* out_cols);
 
 /* device memory helpers for callers without a HIP binding of their own (bench, tests) */
 int ocr_dev_alloc(void** p, size_t bytes);

@@ -159,6 +159,20 @@ def crop_rect(box, rows, cols):
     return (x.value, y.value, w.value, h.value) if ok else None
 
 
+def rotate_crop(img, box):
+    """Utility::GetRotateCropImage (utility.cpp:137-190); None when the bounding-box crop is empty."""
+    img = np.asarray(img, dtype=np.uint8)
+    assert img.strides[1] == 3 and img.strides[2] == 1
+    b = np.ascontiguousarray(np.asarray(box, dtype=np.int32).reshape(8))
+    r, c = C.c_int(), C.c_int()
+    if not lib().oracle_rotate_crop_shape(img.shape[0], img.shape[1], C.c_void_p(_p(b)), C.byref(r), C.byref(c)):
+        return None
+    out = np.empty((r.value, c.value, 3), np.uint8)
+    lib().oracle_rotate_crop(C.c_void_p(img.ctypes.data), img.shape[0], img.shape[1], C.c_size_t(img.strides[0]),
+                             C.c_void_p(_p(b)), C.c_void_p(_p(out)), C.byref(r), C.byref(c))
+    return out
+
+
 def rec_preprocess(crop, imgH, imgW):
     crop = np.asarray(crop, dtype=np.uint8)
     out = np.empty((imgH, imgW, 3), np.float32)

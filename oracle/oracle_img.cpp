@@ -12,6 +12,7 @@
 // (SURVEY.md Appendix B.1, B.2, B.9).  PARITY UNPINNED: the reference holds no golden image
 // vectors and OpenCV cannot run in this container.
 #include <algorithm>
+#include <climits>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -188,3 +189,175 @@ void oracle_rotate180_inplace(uint8_t* bgr, int rows, int cols, size_t stride) {
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------ Utility::GetRotateCropImage
+// /root/reference/src/utility.cpp:137-190.  OpenCV pieces restated (OpenCV 4.x, classic code path):
+//   getPerspectiveTransform : 8x8 system in double, cv::solve(DECOMP_LU) = LU with partial pivoting
+//   warpPerspective         : the reference passes cv::BORDER_REPLICATE (=1) in the FLAGS slot
+//                             (utility.cpp:178-180), so flags = INTER_LINEAR and the border mode stays
+//                             BORDER_CONSTANT with value 0; M is inverted with the 3x3 closed form;
+//                             coordinates in double per (bw0 x bh0) block, rounded to 1/32 px,
+//                             bilinear taps with 15-bit fixed-point weights
+//   transpose + flip(0)     : when rows >= 1.5 * cols
+namespace {
+// hal::LU64f (modules/core/src/matrix_decomp.cpp LUImpl), one right-hand side
+int lu_solve(double* A, int m, double* b) {
+  const double eps = 2.220446049250313e-16 * 100;
+  for (int i = 0; i < m; ++i) {
+    int k = i;
+    for (int j = i + 1; j < m; ++j)
+      if (std::fabs(A[j * m + i]) > std::fabs(A[k * m + i])) k = j;
+    if (std::fabs(A[k * m + i]) < eps) return 0;
+    if (k != i) {
+      for (int j = i; j < m; ++j) std::swap(A[i * m + j], A[k * m + j]);
+      std::swap(b[i], b[k]);
+    }
+    const double d = -1 / A[i * m + i];
+    for (int j = i + 1; j < m; ++j) {
+      const double alpha = A[j * m + i] * d;
+      for (int c = i + 1; c < m; ++c) A[j * m + c] += alpha * A[i * m + c];
+      b[j] += alpha * b[i];
+    }
+  }
+  for (int i = m - 1; i >= 0; --i) {
+    double s = b[i];
+    for (int c = i + 1; c < m; ++c) s -= A[i * m + c] * b[c];
+    b[i] = s / A[i * m + i];
+  }
+  return 1;
+}
+// cv::getPerspectiveTransform(src[4], dst[4]) -> M[9]
+void perspective_transform(const float sx[4], const float sy[4], const float dx[4], const float dy[4], double M[9]) {
+  double a[64], b[8];
+  for (int i = 0; i < 4; ++i) {
+    double* r0 = a + i * 8;
+    double* r1 = a + (i + 4) * 8;
+    r0[0] = r1[3] = sx[i];
+    r0[1] = r1[4] = sy[i];
+    r0[2] = r1[5] = 1;
+    r0[3] = r0[4] = r0[5] = r1[0] = r1[1] = r1[2] = 0;
+    r0[6] = -(double)sx[i] * dx[i];
+    r0[7] = -(double)sy[i] * dx[i];
+    r1[6] = -(double)sx[i] * dy[i];
+    r1[7] = -(double)sy[i] * dy[i];
+    b[i] = dx[i];
+    b[i + 4] = dy[i];
+  }
+  if (!lu_solve(a, 8, b))
+    for (int i = 0; i < 8; ++i) b[i] = 0;  // cv::solve on a singular system leaves X = 0
+  for (int i = 0; i < 8; ++i) M[i] = b[i];
+  M[8] = 1.;
+}
+// cv::invert of a 3x3 CV_64F (closed form, matrix_decomp / lapack.cpp); singular -> all zeros
+void invert3(const double S[9], double T[9]) {
+  const double d0 = S[0] * (S[4] * S[8] - S[5] * S[7]) - S[1] * (S[3] * S[8] - S[5] * S[6]) + S[2] * (S[3] * S[7] - S[4] * S[6]);
+  if (d0 == 0.) {
+    for (int i = 0; i < 9; ++i) T[i] = 0;
+    return;
+  }
+  const double d = 1. / d0;
+  T[0] = (S[4] * S[8] - S[5] * S[7]) * d;
+  T[1] = (S[2] * S[7] - S[1] * S[8]) * d;
+  T[2] = (S[1] * S[5] - S[2] * S[4]) * d;
+  T[3] = (S[5] * S[6] - S[3] * S[8]) * d;
+  T[4] = (S[0] * S[8] - S[2] * S[6]) * d;
+  T[5] = (S[2] * S[3] - S[0] * S[5]) * d;
+  T[6] = (S[3] * S[7] - S[4] * S[6]) * d;
+  T[7] = (S[1] * S[6] - S[0] * S[7]) * d;
+  T[8] = (S[0] * S[4] - S[1] * S[3]) * d;
+}
+inline int round_sat_int(double v) {  // saturate_cast<int>(double) = cvRound: nearest-even
+  return (int)std::nearbyint(v);
+}
+inline short sat_short(int v) { return (short)(v < -32768 ? -32768 : (v > 32767 ? 32767 : v)); }
+// cv::warpPerspective(src, dst(dh x dw), M, INTER_LINEAR, BORDER_CONSTANT, 0) for 8UC3
+void warp_perspective_u8c3(const uint8_t* src, int sh, int sw, size_t sstride, const double M0[9], uint8_t* dst, int dh, int dw) {
+  double M[9];
+  invert3(M0, M);
+  const int BLOCK_SZ = 32;
+  int bh0 = std::min(BLOCK_SZ / 2, dh);
+  const int bw0 = std::min(BLOCK_SZ * BLOCK_SZ / bh0, dw);
+  bh0 = std::min(BLOCK_SZ * BLOCK_SZ / bw0, dh);
+  (void)bh0;  // rows of a block share nothing: only the column split enters the arithmetic
+  for (int y = 0; y < dh; ++y)
+    for (int xb = 0; xb < dw; xb += bw0) {
+      const int bw = std::min(bw0, dw - xb);
+      const double X0 = M[0] * xb + M[1] * y + M[2];
+      const double Y0 = M[3] * xb + M[4] * y + M[5];
+      const double W0 = M[6] * xb + M[7] * y + M[8];
+      for (int x1 = 0; x1 < bw; ++x1) {
+        double W = W0 + M[6] * x1;
+        W = W ? 32. / W : 0;
+        const double fX = std::max((double)INT_MIN, std::min((double)INT_MAX, (X0 + M[0] * x1) * W));
+        const double fY = std::max((double)INT_MIN, std::min((double)INT_MAX, (Y0 + M[3] * x1) * W));
+        const int X = round_sat_int(fX), Y = round_sat_int(fY);
+        const int sx = sat_short(X >> 5), sy = sat_short(Y >> 5);
+        const int fx = X & 31, fy = Y & 31;
+        // 15-bit weights of the (fy, fx) table entry; entry (0,0) is {32767,0,0,1} in OpenCV after its
+        // sum fix-up, which rounds to the same byte as {32768,0,0,0} for every input
+        const int w[4] = {(32 - fy) * (32 - fx) * 32, (32 - fy) * fx * 32, fy * (32 - fx) * 32, fy * fx * 32};
+        uint8_t* D = dst + ((size_t)y * dw + xb + x1) * 3;
+        if (sx >= sw || sx + 1 < 0 || sy >= sh || sy + 1 < 0) {
+          D[0] = D[1] = D[2] = 0;
+          continue;
+        }
+        for (int k = 0; k < 3; ++k) {
+          auto at = [&](int yy, int xx) -> int {
+            return (xx >= 0 && xx < sw && yy >= 0 && yy < sh) ? src[(size_t)yy * sstride + (size_t)xx * 3 + k] : 0;
+          };
+          const int v = at(sy, sx) * w[0] + at(sy, sx + 1) * w[1] + at(sy + 1, sx) * w[2] + at(sy + 1, sx + 1) * w[3];
+          const int r = (v + (1 << 14)) >> 15;
+          D[k] = (uint8_t)(r < 0 ? 0 : (r > 255 ? 255 : r));
+        }
+      }
+    }
+}
+}  // namespace
+
+extern "C" {
+// out dims of GetRotateCropImage for a box (utility.cpp:143-164, 182-189); returns 0 when the
+// bounding-box crop is empty or leaves the image (cv::Mat::operator() would throw inside noexcept)
+int oracle_rotate_crop_shape(int rows, int cols, const int* box8, int* orows, int* ocols) {
+  int left = box8[0], right = box8[0], top = box8[1], bottom = box8[1];
+  for (int i = 1; i < 4; ++i) {
+    left = std::min(left, box8[2 * i]); right = std::max(right, box8[2 * i]);
+    top = std::min(top, box8[2 * i + 1]); bottom = std::max(bottom, box8[2 * i + 1]);
+  }
+  if (left < 0 || top < 0 || right > cols || bottom > rows || right - left <= 0 || bottom - top <= 0) return 0;
+  const int cw = int(std::sqrt(std::pow(box8[0] - box8[2], 2) + std::pow(box8[1] - box8[3], 2)));
+  const int ch = int(std::sqrt(std::pow(box8[0] - box8[6], 2) + std::pow(box8[1] - box8[7], 2)));
+  int dw = cw, dh = ch;
+  if (cw <= 0 || ch <= 0) { dw = right - left; dh = bottom - top; }  // dsize.empty() -> src.size()
+  if (float(dh) >= float(dw) * 1.5) { *orows = dw; *ocols = dh; }
+  else { *orows = dh; *ocols = dw; }
+  return 1;
+}
+int oracle_rotate_crop(const uint8_t* bgr, int rows, int cols, size_t stride, const int* box8, uint8_t* out, int* orows,
+                       int* ocols) {
+  if (!oracle_rotate_crop_shape(rows, cols, box8, orows, ocols)) return 0;
+  int left = box8[0], right = box8[0], top = box8[1], bottom = box8[1];
+  for (int i = 1; i < 4; ++i) {
+    left = std::min(left, box8[2 * i]); right = std::max(right, box8[2 * i]);
+    top = std::min(top, box8[2 * i + 1]); bottom = std::max(bottom, box8[2 * i + 1]);
+  }
+  const int cw = int(std::sqrt(std::pow(box8[0] - box8[2], 2) + std::pow(box8[1] - box8[3], 2)));
+  const int ch = int(std::sqrt(std::pow(box8[0] - box8[6], 2) + std::pow(box8[1] - box8[7], 2)));
+  const float px[4] = {(float)(box8[0] - left), (float)(box8[2] - left), (float)(box8[4] - left), (float)(box8[6] - left)};
+  const float py[4] = {(float)(box8[1] - top), (float)(box8[3] - top), (float)(box8[5] - top), (float)(box8[7] - top)};
+  const float qx[4] = {0.f, (float)cw, (float)cw, 0.f}, qy[4] = {0.f, 0.f, (float)ch, (float)ch};
+  double M[9];
+  perspective_transform(px, py, qx, qy, M);
+  int dw = cw, dh = ch;
+  if (cw <= 0 || ch <= 0) { dw = right - left; dh = bottom - top; }
+  std::vector<uint8_t> warped((size_t)dh * dw * 3);
+  warp_perspective_u8c3(bgr + (size_t)top * stride + (size_t)left * 3, bottom - top, right - left, stride, M, warped.data(), dh, dw);
+  if (float(dh) >= float(dw) * 1.5) {
+    // transpose, then flip around the x axis: out(r, c) = warped(c, dw-1-r), out is dw rows x dh cols
+    for (int r = 0; r < dw; ++r)
+      for (int c = 0; c < dh; ++c) memcpy(out + ((size_t)r * dh + c) * 3, &warped[((size_t)c * dw + (dw - 1 - r)) * 3], 3);
+  } else {
+    memcpy(out, warped.data(), warped.size());
+  }
+  return 1;
+}
+}

@@ -24,7 +24,9 @@ class DetCfg:
 
 
 class Pipeline:
-    def __init__(self, det_cfg=None, rec_batch_num=16, rec_img_h=28, rec_img_w=192, cls_batch_num=8, enable_cls=False):
+    def __init__(self, det_cfg=None, rec_batch_num=16, rec_img_h=28, rec_img_w=192, cls_batch_num=8, enable_cls=False,
+                 crop_mode="rect"):
+        self.crop_mode = crop_mode  # "rect": worker's ROI views; "rotate": Utility::GetRotateCropImage per box
         self.det_cfg = det_cfg or DetCfg()
         self.det = O.OracleNet("det")
         self.rec = O.OracleNet("rec")
@@ -118,11 +120,18 @@ class Pipeline:
         words = []
         if len(boxes) == 0:
             return dict(success=True, width=cols, height=rows, words=words)
-        views = []
-        for b in boxes:
+        views, owner = [], []
+        for bi, b in enumerate(boxes):
+            if self.crop_mode == "rotate":
+                c = O.rotate_crop(image, b)          # utility.cpp:137-190: an independent image per box
+                if c is not None:
+                    views.append(c)
+                    owner.append(bi)
+                continue
             r = O.crop_rect(b, rows, cols)
             if r is not None:
                 x, y, w, h = r
+                owner.append(len(views))             # boxes[i] for text i: reference quirk kept
                 views.append(image[y:y + h, x:x + w])
         if not views:
             return dict(success=True, width=cols, height=rows, words=words)
@@ -133,5 +142,5 @@ class Pipeline:
                     O.rotate180_inplace(v)  # in place on the shared image, like cv::rotate on an ROI view
         texts, scores, _ = self.rec_run(views)
         for i in range(len(texts)):
-            words.append(dict(ids=texts[i], confidence=float(scores[i]), box=boxes[i]))  # boxes[i]: reference quirk kept
+            words.append(dict(ids=texts[i], confidence=float(scores[i]), box=boxes[owner[i]]))
         return dict(success=True, width=cols, height=rows, words=words)

@@ -226,6 +226,70 @@ def test_pipeline_process_request(pkg, built, card, cls_on):
     pg.close()
 
 
+def _random_quads(rs, rows, cols, n):
+    """Rotated / sheared / tall text boxes inside a rows x cols image (x0,y0..x3,y3, clockwise from TL)."""
+    out = []
+    while len(out) < n:
+        cx, cy = rs.uniform(0, cols), rs.uniform(0, rows)
+        w, h = rs.uniform(3, cols / 2), rs.uniform(3, rows / 3)
+        if rs.rand() < 0.25:
+            w, h = h, w * 1.6                                      # tall: the 90-degree branch
+        a = np.deg2rad(rs.uniform(-40, 40))
+        ca, sa = np.cos(a), np.sin(a)
+        q = np.array([[-w / 2, -h / 2], [w / 2, -h / 2], [w / 2, h / 2], [-w / 2, h / 2]])
+        q = q @ np.array([[ca, sa], [-sa, ca]]) + [cx, cy] + rs.uniform(-3, 3, (4, 2))   # perspective jitter
+        q = np.clip(np.round(q), [0, 0], [cols - 1, rows - 1]).astype(np.int32)
+        if np.ptp(q[:, 0]) > 0 and np.ptp(q[:, 1]) > 0:
+            out.append(q)
+    return out
+
+
+def test_rotate_crop_matches_oracle(pkg, built, card):
+    """Utility::GetRotateCropImage (utility.cpp:137-190): homography in double on the host, warp on the device."""
+    import oracle as O
+    rs = np.random.RandomState(21)
+    noise = rs.randint(0, 256, (300, 420, 3)).astype(np.uint8)
+    for img in (card, noise, noise[20:280, 10:400]):              # the last one is a strided view
+        rows, cols = img.shape[:2]
+        quads = _random_quads(rs, rows, cols, 150)
+        quads.append(np.array([[5, 7], [90, 7], [90, 40], [5, 40]], np.int32))          # axis-aligned: identity warp
+        quads.append(np.array([[5, 7], [30, 7], [30, 140], [5, 140]], np.int32))        # tall: rot90 of the crop
+        quads.append(np.array([[0, 0], [cols - 1, 0], [cols - 1, rows - 1], [0, rows - 1]], np.int32))
+        quads.append(np.array([[50, 50], [50, 50], [80, 90], [50, 90]], np.int32))      # zero width -> dsize falls back
+        got = pkg.rotate_crops(img, quads)
+        for q, g in zip(quads, got):
+            o = O.rotate_crop(img, q)
+            assert g.shape == o.shape == pkg.rotate_crop_shape(rows, cols, q) + (3,)
+            assert np.array_equal(g, o)
+        assert np.array_equal(got[150], img[7:40, 5:90])
+        assert np.array_equal(got[151], np.rot90(img[7:140, 5:30]))
+    with pytest.raises(pkg.OcrError, match="no crop inside"):
+        pkg.rotate_crops(card, [np.array([[5, 5], [5, 5], [5, 5], [5, 5]], np.int32)])
+    with pytest.raises(pkg.OcrError, match="no crop inside"):
+        pkg.rotate_crops(card, [np.array([[-3, 5], [50, 5], [50, 30], [-3, 30]], np.int32)])
+
+
+@pytest.mark.parametrize("cls_on", [False, True])
+def test_pipeline_rotate_crop_mode(pkg, built, card, cls_on):
+    """Opt-in crop mode: every det box goes through GetRotateCropImage instead of the ROI view."""
+    from pipeline import Pipeline
+    pg = pkg.Pipe(enable_cls=cls_on, crop_mode=pkg.CROP_ROTATE)
+    po, pr = Pipeline(enable_cls=cls_on, crop_mode="rotate"), Pipeline(enable_cls=cls_on)
+    imgs = [card, np.ascontiguousarray(np.rot90(card)), card[:120].copy()]
+    got = pg.run(imgs)
+    differs = 0
+    for img, g in zip(imgs, got):
+        w = po.process(img)["words"]
+        assert len(g) == len(w) > 0
+        for a, b in zip(g, w):
+            assert np.array_equal(a["box"], b["box"]) and np.array_equal(a["ids"], b["ids"])
+            assert a["confidence"] == np.float32(b["confidence"])
+        wr = pr.process(img)["words"]
+        differs += sum(a["confidence"] != b["confidence"] for a, b in zip(w, wr))
+    assert differs > 0      # the mode changes what rec sees
+    pg.close()
+
+
 def test_pipeline_device_resident_bench_protocol(pkg, built):
     import oracle as O
     from pipeline import Pipeline, DetCfg

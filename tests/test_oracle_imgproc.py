@@ -137,3 +137,35 @@ def test_rec_preprocess_pad_and_cls_pad(built):
     c = O.cls_preprocess(crop)
     assert c.shape == (48, 192, 3) and (c[:, 72:] == 0.0).all()       # cls pads with 0.0 AFTER normalise
     assert np.array_equal(x[:, :72], c[:, :72])
+
+
+def test_rotate_crop_restatement_properties(built):
+    """GetRotateCropImage (utility.cpp:137-190): what must hold whatever the homography arithmetic is."""
+    import oracle as O
+    rs = np.random.RandomState(4)
+    img = rs.randint(0, 256, (150, 220, 3)).astype(np.uint8)
+    # axis-aligned box: the homography is the identity, so the warp is the [top,bottom) x [left,right) crop
+    assert np.array_equal(O.rotate_crop(img, [[20, 30], [100, 30], [100, 60], [20, 60]]), img[30:60, 20:100])
+    # rows >= 1.5 cols: transpose + flip(0) = 90 degrees counter-clockwise
+    assert np.array_equal(O.rotate_crop(img, [[20, 30], [40, 30], [40, 100], [20, 100]]), np.rot90(img[30:100, 20:40]))
+    assert O.rotate_crop(img, [[20, 30], [40, 30], [40, 59], [20, 59]]).shape == (29, 20, 3)      # 29 < 30: not turned
+    assert O.rotate_crop(img, [[20, 30], [40, 30], [40, 60], [20, 60]]).shape == (20, 30, 3)      # 30 >= 30: turned
+    # corners listed from another start: the crop turns with them (box given as TR,BR,BL,TL -> 90 degrees cw,
+    # then the tall result is turned back by the 1.5 rule)
+    q = O.rotate_crop(img, [[100, 30], [100, 60], [20, 60], [20, 30]])
+    assert q.shape == (30, 80, 3)
+    # a smooth ramp stays a ramp under a rotated quad: bilinear taps, no border leak inside the quad
+    yy, xx = np.mgrid[0:150, 0:220]
+    ramp = np.stack([xx, yy, (xx + yy) // 2], -1).astype(np.uint8)
+    c = O.rotate_crop(ramp, [[20, 40], [100, 30], [104, 60], [24, 70]])
+    assert c.shape == (30, 80, 3)
+    assert tuple(c[0, 0]) == (20, 40, 30) and abs(int(c[0, -1, 0]) - 99) <= 1 and abs(int(c[-1, 0, 1]) - 69) <= 1
+    assert (np.diff(c[:, :, 0].astype(int), axis=1) >= 0).all() and (np.diff(c[:, :, 1].astype(int), axis=0) >= 0).all()
+    # the warp reads the CROP, not the image: outside the bounding box taps are 0 (BORDER_CONSTANT; the
+    # reference's cv::BORDER_REPLICATE sits in the flags slot, utility.cpp:178-180)
+    white = np.full((100, 100, 3), 255, np.uint8)
+    c = O.rotate_crop(white, [[10, 10], [60, 10], [70, 40], [10, 40]])     # p2 sticks out: dst corner maps inside
+    assert c.min() == 255 or (c == 255).mean() > 0.95
+    # empty / outside boxes have no crop
+    assert O.rotate_crop(img, [[5, 5], [5, 5], [5, 5], [5, 5]]) is None
+    assert O.rotate_crop(img, [[-1, 5], [30, 5], [30, 20], [-1, 20]]) is None

@@ -17,6 +17,16 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 // give each XCD a CONTIGUOUS range of logical tiles: re-reads then hit that XCD's L2 instead of
 // HBM (rocprof r1e: 7x over-fetch on the det 3x3 conv, 5x on dw5x5 before this).  Bijective for any
 // block count; affects speed only.
+// development probe (tools/micro/conv_probe.hip defines OCR_CONV_PROBE): per-wave phase timestamps
+#ifdef OCR_CONV_PROBE
+__device__ long long* g_conv_probe;
+#define CONV_PROBE(slot)                                                                               \
+  if (g_conv_probe && (threadIdx.x & 63) == 0)                                                         \
+    g_conv_probe[((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (slot)] = (long long)clock64()
+#else
+#define CONV_PROBE(slot)
+#endif
+
 __device__ __forceinline__ unsigned xcd_swizzle(unsigned bid, unsigned nblk) {
   const unsigned q = nblk >> 3, r = nblk & 7, x = bid & 7, i = bid >> 3;
   return x * q + (x < r ? x : r) + i;
@@ -84,88 +94,162 @@ __device__ __forceinline__ float4 apply_epilogue4(const Epilogue& ep, float4 v, 
   return v;
 }
 
-// Epilogue of one 32x32 accumulator tile.  The GEMM is issued as D = W * X^T (weights are the MFMA
-// A operand, pixels the B operand), so a lane owns ONE pixel (column = lane & 31) and 16 output
-// channels: registers 4g..4g+3 are the four consecutive PHYSICAL channels tile*32 + 8g + 4*(lane>>5).
-// => per-channel parameters arrive as float4, results leave as 16-byte stores, and per-pixel stages
-// (SE gate, residual, upsample-add) need the pixel's (n, y, x) only once per lane.
-__device__ __forceinline__ void conv_epilogue_tile(const ConvArgs& a, const Epilogue& ep, const floatx16& accv, int nt,
-                                                   long m, int hb, int n, int y, int x) {
-  if (nt * 32 >= a.ColsStore || m >= a.M) return;
-  float4 v[4];
-  int pc[4], oy[4], ox[4];
-  long oidx[4];
-  bool live[4];
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    const int R = nt * 32 + 8 * g + 4 * hb;  // first of four consecutive GEMM rows (physical channels)
-    live[g] = R < a.ColsStore;
-    v[g] = make_float4(accv[4 * g], accv[4 * g + 1], accv[4 * g + 2], accv[4 * g + 3]);
-    pc[g] = R; oy[g] = y; ox[g] = x;
-    if (a.out_mode == OUT_DECONV) {
-      const int dq = R / a.CoutPadded;
-      pc[g] = R - dq * a.CoutPadded;
-      oy[g] = 2 * y + (dq >> 1);
-      ox[g] = 2 * x + (dq & 1);
-      oidx[g] = (((long)n * (2 * a.OH) + oy[g]) * (2 * a.OW) + ox[g]) * a.Cs_out + pc[g];
-    } else {
-      oidx[g] = m * a.Cs_out + R;
+// Epilogue of the NT 32x32 accumulator tiles of a wave.  The GEMM is issued as D = W * X^T (weights
+// are the MFMA A operand, pixels the B operand), so a lane owns ONE pixel (column = lane & 31) and, per
+// tile, 16 output channels: registers 4g..4g+3 are the four consecutive PHYSICAL channels
+// tile*32 + 8g + 4*(lane>>5).  => per-channel parameters arrive as float4, results leave as 16-byte
+// stores, per-pixel stages (SE gate, residual, upsample-add) need the pixel's (n, y, x) once per lane.
+//
+// Shape of the code (probe, tools/micro/conv_probe.hip: at K = 240 the old tile-by-tile epilogue lasted
+// as long as the K loop, almost all of it waiting): the STAGE loop is outermost and every stage sweeps
+// all tiles, so a stage's parameter loads for the whole wave are issued back to back and waited for
+// once, the stage descriptor is decoded once, and no load is ever issued behind a store (loads and
+// stores retire through one in-order counter).  PLAIN (logical channel order, unaligned rows: the two
+// heads) is a template parameter so the packed path keeps its 16-byte stores.
+template <int NT, int MODE>
+__device__ __forceinline__ void conv_finish(const ConvArgs& a, const Epilogue& ep, floatx16 (&acc)[NT], int nt0, long m, int hb,
+                                            int n, int y, int x, const float* spar) {
+  if (m >= a.M) return;
+  // Row of quad (t, g): R = r0 + rel, rel = 32t + 8g a compile-time constant, r0 = nt0*32 + 4hb.
+  // Everything addressed per quad is "one per-lane base + a uniform offset": nothing per-quad is kept
+  // in registers across the stage loop (16 channel indices + 16 64-bit offsets hoisted out of it cost
+  // 50 VGPRs and spilled).  Packed modes: ColsStore and CoutPadded are multiples of 8, so whether a
+  // quad exists and which deconv quadrant it falls in is uniform; PLAIN (ColsStore = Cout) tests rows.
+  const int c0 = nt0 * 32, r0 = c0 + 4 * hb;
+  auto exists = [&](int rel) { return c0 + rel < a.ColsStore; };  // uniform
+  // offset of the quad's first float relative to the lane's pixel in an output-shaped tensor
+  auto ooff = [&](int rel) -> long {
+    if constexpr (MODE == OUT_DECONV) {
+      const int dq = (c0 + rel) / a.CoutPadded;  // uniform
+      return ((long)(dq >> 1) * (2 * a.OW) + (dq & 1)) * a.Cs_out + (rel - dq * a.CoutPadded);
     }
-    if (!live[g]) { pc[g] = 0; oidx[g] = 0; }
+    return rel;
+  };
+  // channel offset of the quad relative to r0 in a per-channel vector
+  auto coff = [&](int rel) {
+    if constexpr (MODE == OUT_DECONV) return rel - ((c0 + rel) / a.CoutPadded) * a.CoutPadded;
+    return rel;
+  };
+  const long opix = MODE == OUT_DECONV ? (((long)n * (2 * a.OH) + 2 * y) * (2 * a.OW) + 2 * x) * a.Cs_out + r0
+                                       : m * a.Cs_out + r0;
+#define OCR_EP_SWEEP(BODY)                                   \
+  _Pragma("unroll") for (int t = 0; t < NT; ++t) {           \
+    _Pragma("unroll") for (int g = 0; g < 4; ++g) {          \
+      constexpr_rel(t, g);                                   \
+      if (!exists(rel)) continue;                            \
+      float wx = acc[t][4 * g], wy = acc[t][4 * g + 1];      \
+      float wz = acc[t][4 * g + 2], ww = acc[t][4 * g + 3];  \
+      BODY                                                   \
+      acc[t][4 * g] = wx; acc[t][4 * g + 1] = wy;            \
+      acc[t][4 * g + 2] = wz; acc[t][4 * g + 3] = ww;        \
+    }                                                        \
   }
-  // stage loop outside, the four channel quads inside: one copy of each stage's code, `ep` is only
-  // ever indexed by the (uniform) stage counter
+#define constexpr_rel(t, g) const int rel = 32 * (t) + 8 * (g)
   for (int s = 0; s < ep.n; ++s) {
     const EpStage& st = ep.st[s];
+    switch (st.kind) {
+      case EP_BIAS: {
+        const float* q0 = spar + (2 * s) * NT * 32 + 4 * hb;
+        OCR_EP_SWEEP({ const float4 b = *(const float4*)(q0 + rel); wx = wx + b.x; wy = wy + b.y; wz = wz + b.z; ww = ww + b.w; })
+      } break;
+      case EP_SMUL: {
+        const float k = st.p0;
+        OCR_EP_SWEEP({ wx = k * wx; wy = k * wy; wz = k * wz; ww = k * ww; })
+      } break;
+      case EP_SADD: {
+        const float k = st.p0;
+        OCR_EP_SWEEP({ wx = wx + k; wy = wy + k; wz = wz + k; ww = ww + k; })
+      } break;
+      case EP_BN: {
+        const float* q0 = spar + (2 * s) * NT * 32 + 4 * hb;
+        OCR_EP_SWEEP({
+          const float4 sc = *(const float4*)(q0 + rel);
+          const float4 sh = *(const float4*)(q0 + NT * 32 + rel);
+          float u;
+          u = wx * sc.x; wx = u + sh.x;
+          u = wy * sc.y; wy = u + sh.y;
+          u = wz * sc.z; wz = u + sh.z;
+          u = ww * sc.w; ww = u + sh.w;
+        })
+      } break;
+      case EP_ACT: {
+        // the activation kind is decoded once per stage, not once per value
+        const float p0 = st.p0, p1 = st.p1;
+#define OCR_ACT_SWEEP(KIND) OCR_EP_SWEEP({ wx = ocr_act(KIND, p0, p1, wx); wy = ocr_act(KIND, p0, p1, wy); wz = ocr_act(KIND, p0, p1, wz); ww = ocr_act(KIND, p0, p1, ww); })
+        switch (st.act) {
+          case ACT_RELU: OCR_ACT_SWEEP(ACT_RELU) break;
+          case ACT_HSWISH: OCR_ACT_SWEEP(ACT_HSWISH) break;
+          case ACT_HSIG: OCR_ACT_SWEEP(ACT_HSIG) break;
+          case ACT_SWISH: OCR_ACT_SWEEP(ACT_SWISH) break;
+          default: OCR_ACT_SWEEP(ACT_SIGMOID) break;
+        }
+#undef OCR_ACT_SWEEP
+      } break;
+      case EP_MULC: {  // per-image channel gate [N][Cs_out]
+        const float* gate = st.v0 + (long)n * a.Cs_out + r0;
+        OCR_EP_SWEEP({ const float4 r = *(const float4*)(gate + coff(rel)); wx = wx * r.x; wy = wy * r.y; wz = wz * r.z; ww = ww * r.w; })
+      } break;
+      case EP_ADDT: {  // tensor of the output's shape
+        const float* res = st.v0 + opix;
+        OCR_EP_SWEEP({ const float4 r = *(const float4*)(res + ooff(rel)); wx = wx + r.x; wy = wy + r.y; wz = wz + r.z; ww = ww + r.w; })
+      } break;
+      case EP_ADDUP: {  // nearest-upsampled coarser map (never after a deconv)
+        const float* up = st.v0 + (((long)n * st.a2 + y / st.a0) * st.a1 + x / st.a0) * a.Cs_out + r0;
+        OCR_EP_SWEEP({ const float4 r = *(const float4*)(up + coff(rel)); wx = wx + r.x; wy = wy + r.y; wz = wz + r.z; ww = ww + r.w; })
+      } break;
+    }
+  }
+#undef OCR_EP_SWEEP
+  // ---- stores, after the last load
+  float* obase = a.out + opix;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      float4& w = v[g];
-      switch (st.kind) {
-        case EP_BIAS: { const float4 b = *(const float4*)(st.v0 + pc[g]); w.x = w.x + b.x; w.y = w.y + b.y; w.z = w.z + b.z; w.w = w.w + b.w; } break;
-        case EP_SMUL: w.x = st.p0 * w.x; w.y = st.p0 * w.y; w.z = st.p0 * w.z; w.w = st.p0 * w.w; break;
-        case EP_SADD: w.x = w.x + st.p0; w.y = w.y + st.p0; w.z = w.z + st.p0; w.w = w.w + st.p0; break;
-        case EP_BN: {
-          const float4 sc = *(const float4*)(st.v0 + pc[g]), sh = *(const float4*)(st.v1 + pc[g]);
-          float t;
-          t = w.x * sc.x; w.x = t + sh.x;
-          t = w.y * sc.y; w.y = t + sh.y;
-          t = w.z * sc.z; w.z = t + sh.z;
-          t = w.w * sc.w; w.w = t + sh.w;
-        } break;
-        case EP_ACT:
-          w.x = ocr_act(st.act, st.p0, st.p1, w.x); w.y = ocr_act(st.act, st.p0, st.p1, w.y);
-          w.z = ocr_act(st.act, st.p0, st.p1, w.z); w.w = ocr_act(st.act, st.p0, st.p1, w.w);
-          break;
-        case EP_MULC: { const float4 q = *(const float4*)(st.v0 + (long)n * a.Cs_out + pc[g]); w.x = w.x * q.x; w.y = w.y * q.y; w.z = w.z * q.z; w.w = w.w * q.w; } break;
-        case EP_ADDT: { const float4 q = *(const float4*)(st.v0 + oidx[g]); w.x = w.x + q.x; w.y = w.y + q.y; w.z = w.z + q.z; w.w = w.w + q.w; } break;
-        case EP_ADDUP: {
-          const float4 q = *(const float4*)(st.v0 + (((long)n * st.a2 + oy[g] / st.a0) * st.a1 + ox[g] / st.a0) * a.Cs_out + pc[g]);
-          w.x = w.x + q.x; w.y = w.y + q.y; w.z = w.z + q.z; w.w = w.w + q.w;
-        } break;
+      constexpr_rel(t, g);
+      if (!exists(rel)) continue;
+      float4 w = make_float4(acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]);
+      float* dst = obase + ooff(rel);
+      if constexpr (MODE == OUT_PLAIN) {
+        // logical channel order, row stride = Cout (rows are not 16-byte aligned): scalar stores;
+        // per-channel parameter vectors of plain outputs are padded to whole tiles
+        const int R = r0 + rel;
+        if (R < a.Cout) dst[0] = w.x;
+        if (R + 1 < a.Cout) dst[1] = w.y;
+        if (R + 2 < a.Cout) dst[2] = w.z;
+        if (R + 3 < a.Cout) dst[3] = w.w;
+      } else {
+        if (a.Cout != a.Cs_out) {  // keep the pad channels of the octet layout at zero
+          const int pc = r0 + coff(rel);
+          if (c8i_logical(pc) >= a.Cout) w.x = 0.f;
+          if (c8i_logical(pc + 1) >= a.Cout) w.y = 0.f;
+          if (c8i_logical(pc + 2) >= a.Cout) w.z = 0.f;
+          if (c8i_logical(pc + 3) >= a.Cout) w.w = 0.f;
+        }
+        *(float4*)dst = w;
       }
     }
   }
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    if (!live[g]) continue;
-    float4 w = v[g];
-    if (a.out_mode == OUT_PLAIN) {
-      // logits / cls head: logical channel order, row stride = Cout (rows are not 16-byte aligned):
-      // scalar stores; per-channel parameter vectors of plain outputs are padded to whole tiles
-      const float e[4] = {w.x, w.y, w.z, w.w};
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        if (pc[g] + q < a.Cout) a.out[oidx[g] + q] = e[q];
-      continue;
+#undef constexpr_rel
+}
+
+// Per-channel epilogue vectors (bias, BN scale/shift) of this workgroup's NT*32 GEMM rows, copied to
+// LDS at kernel start: spar[(2*stage + k)*NT*32 + row - nt0*32].  An epilogue load from global memory
+// queues behind every streaming load of the CU's 12-16 waves (probe: ~10k clocks each time);
+// the LDS copy is fetched while the K loop runs and read back in ~100 clocks.
+template <int NT>
+__device__ __forceinline__ void conv_stage_params(const ConvArgs& a, const Epilogue& ep, int nt0, float* spar) {
+  const int i = threadIdx.x;
+  if (i < NT * 32) {
+    const int R = nt0 * 32 + i;
+    const int pc = R >= a.ColsStore ? 0 : (a.out_mode == OUT_DECONV ? R % a.CoutPadded : R);
+    for (int s = 0; s < ep.n; ++s) {
+      const EpStage& st = ep.st[s];
+      if (st.kind == EP_BIAS || st.kind == EP_BN) spar[(2 * s) * NT * 32 + i] = st.v0[pc];
+      if (st.kind == EP_BN) spar[(2 * s + 1) * NT * 32 + i] = st.v1[pc];
     }
-    if (a.Cout != a.Cs_out) {  // keep the pad channels of the octet layout at zero
-      if (c8i_logical(pc[g]) >= a.Cout) w.x = 0.f;
-      if (c8i_logical(pc[g] + 1) >= a.Cout) w.y = 0.f;
-      if (c8i_logical(pc[g] + 2) >= a.Cout) w.z = 0.f;
-      if (c8i_logical(pc[g] + 3) >= a.Cout) w.w = 0.f;
-    }
-    *(float4*)(a.out + oidx[g]) = w;
   }
+  __syncthreads();
 }
 
 // =====================================================================================
@@ -177,15 +261,18 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvArgs& a, const Epil
 // B from the host-built fragment image (one 16-byte load per lane per n-tile per 8 channels).
 // No LDS, no barriers: four independent waves per workgroup.
 // =====================================================================================
-template <int NT>
-__global__ void __launch_bounds__(256, (NT <= 2 ? 4 : 3)) conv_mfma_kernel(const ConvArgs a, const Epilogue ep) {
+template <int NT, int MODE>
+__global__ void __launch_bounds__(256, (NT <= 3 ? 4 : 3)) conv_mfma_kernel(const ConvArgs a, const Epilogue ep) {
+  CONV_PROBE(0);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int p = lane & 31, h = lane >> 5;
   const unsigned lb = xcd_swizzle(blockIdx.x, gridDim.x);  // logical block: N-group fastest, then M-tile
   const unsigned groups = (unsigned)a.NTtot / NT;
   const long m0 = ((long)(lb / groups) * 4 + wave) * 32;
-  if (m0 >= a.M) return;
   const int nt0 = (int)(lb % groups) * NT;
+  __shared__ float s_par[OCR_MAX_EP * 2 * NT * 32];
+  conv_stage_params<NT>(a, ep, nt0, s_par);
+  if (m0 >= a.M) return;
   const int hw = a.OH * a.OW;
   const long m = m0 + p;
   const bool mvalid = m < a.M;
@@ -198,69 +285,97 @@ __global__ void __launch_bounds__(256, (NT <= 2 ? 4 : 3)) conv_mfma_kernel(const
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
 
-  // K loop flattened over (tap, 8-channel group) with a one-deep register prefetch: the loads of
-  // step kk+1 are in flight while the 4*NT MFMAs of step kk issue (HBM/L2 latency is otherwise
-  // exposed once per 8 channels at the 2-3 waves/SIMD this kernel's accumulators allow).
+  // K loop flattened over (tap, 8-channel group), software-pipelined over two register sets: the loads
+  // of step kk+1 are in flight while the 4*NT MFMAs of step kk issue.  The loop body is straight-line
+  // (no branch between a load and the MFMAs that overlap it, the walk of (tap, c8) is done with selects,
+  // the step past the end re-reads the last one), so the waitcnt the compiler places before each MFMA
+  // group counts the loads issued after the ones it needs instead of draining everything.
   const float4* __restrict__ wf = (const float4*)a.wfrag;
   const int KK = a.KH * a.KW * a.C8;
-  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  // incremental (tap, c8) walk of the prefetch pointer: no division in the loop
-  int p_c8 = 0, p_ky = 0, p_kx = 0;
-  bool p_valid;
-  const float* p_src;
+  int p_c8 = 0, p_ky = 0, p_kx = 0, p_step = 0;
   const float4* p_w = wf + (long)nt0 * 64 + lane;
-  auto set_tap = [&]() {
-    const int iy = y - a.PH + p_ky, ix = x - a.PW + p_kx;
-    p_valid = mvalid && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-    // padding / out-of-range rows read a zero page: the prefetched value is never touched by a select,
-    // so nothing has to wait for the load before the MFMAs of the current step issue
-    p_src = p_valid ? a.in + (((long)n * a.H + iy) * a.W + ix) * a.Cs_in + 4 * h : a.zeros + 4 * h;
-  };
-  set_tap();
+  const long wstride = (long)a.NTtot * 64;
+  const float* zpage = a.zeros + 4 * h;
+  // this lane's pixel at tap (0,0), channel 4h; a tap adds the uniform offset (ky*W + kx)*Cs_in
+  const float* lane_base = a.in + 4 * h + (((long)n * a.H + (y - a.PH)) * a.W + (x - a.PW)) * a.Cs_in;
+  long tap_off = 0;  // + c8*8, elements
   auto load_step = [&](float4& av, float4 (&bv)[NT]) {
-    av = *(const float4*)(p_src + p_c8 * 8);
+    const int iy = y - a.PH + p_ky, ix = x - a.PW + p_kx;
+    const bool valid = mvalid && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+    // padding / out-of-range rows read a zero page: no select ever touches a loaded value
+    const float* src = valid ? lane_base + tap_off : zpage;
+#ifdef OCR_PROBE_NOX
+    av = make_float4((float)(size_t)src, 1.f, 2.f, 3.f);
+#else
+    av = *(const float4*)src;
+#endif
 #pragma unroll
-    for (int t = 0; t < NT; ++t) bv[t] = p_w[t * 64];  // the fragment image is padded to whole NT groups
-    p_w += (long)a.NTtot * 64;
-    if (++p_c8 == a.C8) {
-      p_c8 = 0;
-      if (++p_kx == a.KW) { p_kx = 0; ++p_ky; }
-      if (p_ky < a.KH) set_tap();
-    }
+    for (int t = 0; t < NT; ++t)
+#ifdef OCR_PROBE_NOW
+      bv[t] = make_float4((float)(size_t)p_w, (float)t, 2.f, 3.f);
+#else
+      bv[t] = p_w[t * 64];  // the fragment image is padded to whole NT groups
+#endif
+    const bool more = p_step + 1 < KK;                 // past the end: stay on the last step (loaded, unused)
+    p_step += more;
+    p_w += more ? wstride : 0;
+    p_c8 += more;
+    const bool wc = p_c8 == a.C8;
+    p_c8 = wc ? 0 : p_c8;
+    p_kx += wc;
+    const bool wx = p_kx == a.KW;
+    p_kx = wx ? 0 : p_kx;
+    p_ky += wx;
+    tap_off = ((long)p_ky * a.W + p_kx) * a.Cs_in + p_c8 * 8;
   };
-  float4 av_cur, bv_cur[NT], av_nxt = zero4, bv_nxt[NT];
-#pragma unroll
-  for (int t = 0; t < NT; ++t) bv_nxt[t] = zero4;
-  load_step(av_cur, bv_cur);
-  for (int kk = 0; kk < KK; ++kk) {
-    if (kk + 1 < KK) load_step(av_nxt, bv_nxt);
+  auto mfma_step = [&](const float4& av, const float4 (&bv)[NT]) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv_cur[t].x, av_cur.x, acc[t], 0, 0, 0);
-      acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv_cur[t].y, av_cur.y, acc[t], 0, 0, 0);
-      acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv_cur[t].z, av_cur.z, acc[t], 0, 0, 0);
-      acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv_cur[t].w, av_cur.w, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[t].x, av.x, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[t].y, av.y, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[t].z, av.z, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[t].w, av.w, acc[t], 0, 0, 0);
     }
-    av_cur = av_nxt;
-#pragma unroll
-    for (int t = 0; t < NT; ++t) bv_cur[t] = bv_nxt[t];
+  };
+  float4 a0, b0[NT], a1, b1[NT];
+  load_step(a0, b0);
+  CONV_PROBE(1);
+  int kk = 0;
+  for (; kk + 2 <= KK; kk += 2) {
+    load_step(a1, b1);
+    __builtin_amdgcn_sched_barrier(0);  // keep the loads ahead of the MFMAs they overlap
+    mfma_step(a0, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    load_step(a0, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_step(a1, b1);
+    __builtin_amdgcn_sched_barrier(0);
   }
+  if (kk < KK) mfma_step(a0, b0);
+  CONV_PROBE(2);
+  // the epilogue's VALU work competes for the issue port with the MFMAs of the other waves on this
+  // SIMD; at equal priority it gets roughly one slot per MFMA and lasts as long as the K loop did
+  // (probe: 80k of 160k clocks per wave at K = 240).  A wave that has left the loop goes first.
+  __builtin_amdgcn_s_setprio(3);
 
   // ---- epilogue: lane owns output column j (one channel), 16 rows ----
-  conv_epilogue_tile(a, ep, acc[0], nt0 + 0, m, h, n, y, x);
-  if constexpr (NT > 1) conv_epilogue_tile(a, ep, acc[1], nt0 + 1, m, h, n, y, x);
-  if constexpr (NT > 2) conv_epilogue_tile(a, ep, acc[2], nt0 + 2, m, h, n, y, x);
-  if constexpr (NT > 3) conv_epilogue_tile(a, ep, acc[3], nt0 + 3, m, h, n, y, x);
+  conv_finish<NT, MODE>(a, ep, acc, nt0, m, h, n, y, x, s_par);
+  CONV_PROBE(3);
 }
 
 void launch_conv_mfma(const ConvArgs& a, const Epilogue& ep, int nt, hipStream_t s) {
   dim3 grid((unsigned)(((a.M + 127) / 128) * (a.NTtot / nt)));
-  switch (nt) {
-    case 1: hipLaunchKernelGGL(conv_mfma_kernel<1>, grid, dim3(256), 0, s, a, ep); break;
-    case 2: hipLaunchKernelGGL(conv_mfma_kernel<2>, grid, dim3(256), 0, s, a, ep); break;
-    case 3: hipLaunchKernelGGL(conv_mfma_kernel<3>, grid, dim3(256), 0, s, a, ep); break;
-    default: hipLaunchKernelGGL(conv_mfma_kernel<4>, grid, dim3(256), 0, s, a, ep); break;
+#define OCR_LAUNCH_MODE(MODE)                                                                                   \
+  switch (nt) {                                                                                                 \
+    case 1: hipLaunchKernelGGL((conv_mfma_kernel<1, MODE>), grid, dim3(256), 0, s, a, ep); break;               \
+    case 2: hipLaunchKernelGGL((conv_mfma_kernel<2, MODE>), grid, dim3(256), 0, s, a, ep); break;               \
+    case 3: hipLaunchKernelGGL((conv_mfma_kernel<3, MODE>), grid, dim3(256), 0, s, a, ep); break;               \
+    default: hipLaunchKernelGGL((conv_mfma_kernel<4, MODE>), grid, dim3(256), 0, s, a, ep); break;              \
   }
+  if (a.out_mode == OUT_PLAIN) { OCR_LAUNCH_MODE(OUT_PLAIN) }
+  else if (a.out_mode == OUT_DECONV) { OCR_LAUNCH_MODE(OUT_DECONV) }
+  else { OCR_LAUNCH_MODE(OUT_C8I) }
+#undef OCR_LAUNCH_MODE
 }
 
 // =====================================================================================
@@ -312,7 +427,8 @@ __global__ void __launch_bounds__(256, 2) conv_lds_kernel(const ConvArgs a, cons
     }
     rowinfo[tid] = ri;
   }
-  __syncthreads();
+  __shared__ float s_par[OCR_MAX_EP * 2 * NT * 32];
+  conv_stage_params<NT>(a, ep, nt0, s_par);  // ends with the barrier that also publishes rowinfo
   const int cpt = a.Cs_in / BK;  // chunks per tap
   const int nchunks = a.KH * a.KW * cpt;
   const float4* __restrict__ wf = (const float4*)a.wfrag;
@@ -402,10 +518,7 @@ __global__ void __launch_bounds__(256, 2) conv_lds_kernel(const ConvArgs a, cons
   if (m >= a.M) return;
   int n, y, x;
   decompose(m, hw, a.OW, n, y, x);
-  conv_epilogue_tile(a, ep, acc[0], nt0 + 0, m, h, n, y, x);
-  if constexpr (NT > 1) conv_epilogue_tile(a, ep, acc[1], nt0 + 1, m, h, n, y, x);
-  if constexpr (NT > 2) conv_epilogue_tile(a, ep, acc[2], nt0 + 2, m, h, n, y, x);
-  if constexpr (NT > 3) conv_epilogue_tile(a, ep, acc[3], nt0 + 3, m, h, n, y, x);
+  conv_finish<NT, OUT_C8I>(a, ep, acc, nt0, m, h, n, y, x, s_par);
 }
 
 template <int NT>

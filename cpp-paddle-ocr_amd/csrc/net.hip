@@ -439,7 +439,7 @@ bool Net::bind(int N, int H, int W, std::string& err) {
     if (arena_) (void)hipFree(arena_);
     arena_ = nullptr;
     arena_cap_ = 0;
-    HIP_OK(hipMalloc(&arena_, high * sizeof(float)));
+    HIP_OK(hipMalloc(&arena_, (high + 64) * sizeof(float)));  // + 256 B: conv1x1 block loads may run past the last row
     arena_cap_ = high;
   }
   if (gap_need > gap_part_cap_) {
@@ -528,7 +528,7 @@ bool Net::bind(int N, int H, int W, std::string& err) {
           static const char* impl = getenv("OCR_CONV_IMPL");
           // measured (gpurun_out r1g): LDS staging wins for multi-tap convs (3x3 96->24: 58 vs 51 TFLOP/s),
           // the direct kernel for 1x1 (480->480: 88 vs 71; thin K: 54 vs 39)
-          const bool use_lds = impl ? !strcmp(impl, "lds") : (taps > 1 && in.cs >= 64);
+          const bool use_lds = a.out_mode == OUT_C8I && (impl ? !strcmp(impl, "lds") : (taps > 1 && in.cs >= 64));
           if (use_lds) L.fn = [a, ep, nt](hipStream_t s) { launch_conv_lds(a, ep, nt, s); };
           else L.fn = [a, ep, nt](hipStream_t s) { launch_conv_mfma(a, ep, nt, s); };
         }

@@ -1,0 +1,87 @@
+// Development probe: runs the product's conv_mfma_kernel (included from csrc) on a synthetic 1x1 conv
+// and reports TFLOP/s plus the per-wave phase breakdown from clock64() stamps.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -DOCR_CONV_PROBE -I../../cpp-paddle-ocr_amd/csrc -o conv_probe conv_probe.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <algorithm>
+#include "kernels_net.hip"
+using namespace ocr;
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+
+static void run(long M, int cin, int cout, int variant, int epi) {
+  const int cs_in = (cin + 7) / 8 * 8, cs_out = (cout + 7) / 8 * 8;
+  const int tiles = (cs_out + 31) / 32, nt = conv_nt_for(tiles), NTtot = (tiles + nt - 1) / nt * nt, C8 = cs_in / 8;
+  float *x, *y, *w, *z, *bn;
+  CK(hipMalloc(&x, (M * cs_in + 64) * 4)); CK(hipMalloc(&y, M * cs_out * 4)); CK(hipMalloc(&w, (size_t)C8 * NTtot * 64 * 4 * 4));
+  CK(hipMalloc(&z, 4096 * 4)); CK(hipMalloc(&bn, 8192 * 4));
+  CK(hipMemset(x, 0, (M * cs_in + 64) * 4)); CK(hipMemset(w, 0, (size_t)C8 * NTtot * 64 * 16)); CK(hipMemset(z, 0, 4096 * 4)); CK(hipMemset(bn, 0, 8192 * 4));
+  ConvArgs a{};
+  a.in = x; a.out = y; a.wfrag = w; a.zeros = z; a.M = M; a.N = 1; a.H = 1; a.W = (int)M; a.Cs_in = cs_in; a.C8 = C8;
+  a.OH = 1; a.OW = (int)M; a.Cs_out = cs_out; a.Cout = cout; a.CoutPadded = cs_out; a.ColsStore = cs_out; a.NTtot = NTtot;
+  a.KH = a.KW = 1; a.PH = a.PW = 0; a.out_mode = OUT_C8I;
+  Epilogue ep{};
+  if (epi) {
+    ep.n = epi >= 2 ? 2 : 1;
+    ep.st[0].kind = EP_BN; ep.st[0].v0 = bn; ep.st[0].v1 = bn + 4096;
+    ep.st[1].kind = EP_ACT; ep.st[1].act = epi == 2 ? ACT_RELU : ACT_HSWISH; ep.st[1].p0 = 1.f; ep.st[1].p1 = 0.f;
+  }
+  const long nwaves = ((M + 127) / 128) * (NTtot / nt) * 4;
+  long long* probe;
+  CK(hipMalloc(&probe, nwaves * 4 * 8));
+  CK(hipMemset(probe, 0, nwaves * 4 * 8));
+  long long* nullp = nullptr;
+  auto launch = [&]() { launch_conv_mfma(a, ep, nt, 0); };
+  CK(hipMemcpyToSymbol(HIP_SYMBOL(g_conv_probe), &nullp, sizeof(nullp)));
+  launch();
+  CK(hipDeviceSynchronize());
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  CK(hipEventRecord(e0));
+  for (int i = 0; i < 5; ++i) launch();
+  CK(hipEventRecord(e1));
+  CK(hipEventSynchronize(e1));
+  float ms;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  ms /= 5;
+  const double fl = 2.0 * M * cin * cout;
+  printf("M=%ld %d->%d nt=%d variant=%d epi=%d: %.3f ms %.1f TFLOP/s\n", M, cin, cout, nt, variant, (int)epi, ms, fl / ms / 1e9);
+  CK(hipMemcpyToSymbol(HIP_SYMBOL(g_conv_probe), &probe, sizeof(probe)));
+  launch();
+  CK(hipDeviceSynchronize());
+  std::vector<long long> h(nwaves * 4);
+  CK(hipMemcpy(h.data(), probe, nwaves * 32, hipMemcpyDeviceToHost));
+  long long* chk = nullptr;
+  CK(hipMemcpyFromSymbol(&chk, HIP_SYMBOL(g_conv_probe), sizeof(chk)));
+  printf("   probe ptr %p (symbol %p) first %lld %lld %lld %lld\n", (void*)probe, (void*)chk, h[0], h[1], h[2], h[3]);
+  double s01 = 0, s12 = 0, s23 = 0;
+  long cnt = 0;
+  long long tmin = -1, tmax = 0;
+  for (long i = 0; i < nwaves; ++i) {
+    if (!h[i * 4 + 3]) continue;
+    s01 += h[i * 4 + 1] - h[i * 4]; s12 += h[i * 4 + 2] - h[i * 4 + 1]; s23 += h[i * 4 + 3] - h[i * 4 + 2];
+    if (tmin < 0 || h[i * 4] < tmin) tmin = h[i * 4];
+    tmax = std::max(tmax, h[i * 4 + 3]);
+    ++cnt;
+  }
+  // distribution of the loop phase and concurrency: waves alive at the median time
+  if (variant == 0 && cnt) {
+    std::vector<long long> lp;
+    for (long i = 0; i < nwaves; ++i) if (h[i * 4 + 3]) lp.push_back(h[i * 4 + 2] - h[i * 4 + 1]);
+    std::sort(lp.begin(), lp.end());
+    const long long tmid = (tmin + tmax) / 2;
+    long alive = 0;
+    for (long i = 0; i < nwaves; ++i) if (h[i * 4 + 3] && h[i * 4] <= tmid && h[i * 4 + 3] >= tmid) ++alive;
+    printf("   loop clk p10 %lld p50 %lld p90 %lld; waves alive at mid-kernel %ld\n", lp[lp.size() / 10], lp[lp.size() / 2], lp[lp.size() * 9 / 10], alive);
+  }
+  if (variant == 0)
+    printf("   waves %ld  prologue %.0f  loop %.0f  epilogue %.0f clk(avg/wave)  kernel span %lld clk  (clock64 units)\n", cnt, s01 / cnt, s12 / cnt,
+           s23 / cnt, tmax - tmin);
+  hipFree(x); hipFree(y); hipFree(w); hipFree(z); hipFree(bn); hipFree(probe);
+}
+
+int main(int argc, char** argv) {
+  for (int e = 0; e < 4; ++e) run(1966080, 240, 240, 0, e);
+  return 0;
+}

@@ -118,7 +118,7 @@ class RecStage {
   int run_lines(const std::vector<LineSrc>& lines, const std::vector<int>& seg, int32_t* ids, int max_len, int* lens,
                 float* scores, std::string& err);
   bool want_taps = true;
-  int max_lines_per_launch = 1024;
+  int max_lines_per_launch = 4096;  // rows of one launch (bounds the activation arena: ~1.2 MB per 48x320 line)
   const std::vector<std::string>& labels() const { return labels_; }
   hipStream_t stream() const { return stream_; }
   Net& net() { return net_; }

@@ -6,6 +6,9 @@
 // (/root/reference/src/ocr_det.cpp:122, ocr_cls.cpp:74, ocr_rec.cpp:81).
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
+#include <cstdlib>
+
 #include "kernels_net.h"
 
 namespace ocr {
@@ -581,95 +584,154 @@ void launch_stem(const StemArgs& a, const Epilogue& ep, hipStream_t s) {
 }
 
 // =====================================================================================
-// Depthwise conv, VALU.  One thread = TO consecutive output pixels of a row x 4 physical channels:
-// each input row segment is loaded once into registers and reused by the K taps of all TO outputs
-// (K*((TO-1)*SW+K)/TO loads per output instead of K*K).  Every output still accumulates its taps in
-// (ky, kx) order: the arithmetic contract is untouched.
+// Depthwise conv, VALU.  One thread = a TO x R patch of output pixels (TO along x, R rows) x 4 physical
+// channels.  The thread walks the (R-1)*SH + K input rows the patch needs from top to bottom; each row
+// segment is loaded once into registers and feeds every output row it is a tap of, so an output costs
+// ((R-1)*SH+K) * ((TO-1)*SW+K) / (TO*R) input loads instead of K*K (5x5, stride 1, 8x2: 4.5 vs 25; the
+// 4x1 patch this replaces: 10), plus K*K / TO weight loads.  The kernel is bound by the L1/TA rate of
+// those loads, not by HBM.  For every output the taps still arrive in (ky, kx) ascending order (rows
+// top to bottom, kx inner): the arithmetic contract is untouched.
 // =====================================================================================
-template <int K, int SW, int TO>
+template <int K, int SW, int TO, int R>
 __global__ void __launch_bounds__(256) dw_conv_kernel(const DwArgs a, const Epilogue ep) {
   constexpr int NIN = (TO - 1) * SW + K;
   const long t = (long)xcd_swizzle(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
   const int c4n = a.Cs >> 2;
-  const int strips = (a.OW + TO - 1) / TO;
-  const long nstrip = (long)a.N * a.OH * strips;
-  if (t >= nstrip * c4n) return;
+  const int strips = (a.OW + TO - 1) / TO, bands = (a.OH + R - 1) / R;
+  const long npatch = (long)a.N * bands * strips;
+  if (t >= npatch * c4n) return;
   const long sidx = t / c4n;
   const int pc = (int)(t - sidx * c4n) * 4;
   const int sx = (int)(sidx % strips);
-  const long ny = sidx / strips;
-  const int y = (int)(ny % a.OH), n = (int)(ny / a.OH);
+  const long nb = sidx / strips;
+  const int y0 = (int)(nb % bands) * R, n = (int)(nb / bands);
   const int x0 = sx * TO;
-  float4 acc[TO];
+  float4 acc[R][TO];
 #pragma unroll
-  for (int o = 0; o < TO; ++o) acc[o] = make_float4(0.f, 0.f, 0.f, 0.f);
-  const int ixb = x0 * SW - a.PW;
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int o = 0; o < TO; ++o) acc[r][o] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int ixb = x0 * SW - a.PW, iyb = y0 * a.SH - a.PH;
+  const int nrows = (R - 1) * a.SH + K;
 #pragma unroll 1
-  for (int ky = 0; ky < K; ++ky) {  // one input row at a time keeps ~60 VGPRs live (occupancy), K rows would not
-    const int iy = y * a.SH - a.PH + ky;
+  for (int j = 0; j < nrows; ++j) {  // one input row at a time (registers); rows beyond the image are zero rows
+    const int iy = iyb + j;
     const bool rv = iy >= 0 && iy < a.H;
     const float* row = a.in + (((long)n * a.H + (rv ? iy : 0)) * a.W) * a.Cs + pc;
     float4 in[NIN];
 #pragma unroll
-    for (int j = 0; j < NIN; ++j) {
-      const int ix = ixb + j;
-      in[j] = (rv && ix >= 0 && ix < a.W) ? *(const float4*)(row + (long)ix * a.Cs) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int q = 0; q < NIN; ++q) {
+      const int ix = ixb + q;
+      in[q] = (rv && ix >= 0 && ix < a.W) ? *(const float4*)(row + (long)ix * a.Cs) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
-    for (int kx = 0; kx < K; ++kx) {
-      const float4 wv = *(const float4*)(a.w + (long)(ky * K + kx) * a.Cs + pc);
+    for (int r = 0; r < R; ++r) {
+      const int ky = j - r * a.SH;  // uniform
+      if (ky < 0 || ky >= K) continue;
+      const float* wrow = a.w + (long)(ky * K) * a.Cs + pc;
 #pragma unroll
-      for (int o = 0; o < TO; ++o) {
-        const float4 v = in[o * SW + kx];
-        acc[o].x = fmaf(v.x, wv.x, acc[o].x);
-        acc[o].y = fmaf(v.y, wv.y, acc[o].y);
-        acc[o].z = fmaf(v.z, wv.z, acc[o].z);
-        acc[o].w = fmaf(v.w, wv.w, acc[o].w);
+      for (int kx = 0; kx < K; ++kx) {
+        const float4 wv = *(const float4*)(wrow + (long)kx * a.Cs);
+#pragma unroll
+        for (int o = 0; o < TO; ++o) {
+          const float4 v = in[o * SW + kx];
+          acc[r][o].x = fmaf(v.x, wv.x, acc[r][o].x);
+          acc[r][o].y = fmaf(v.y, wv.y, acc[r][o].y);
+          acc[r][o].z = fmaf(v.z, wv.z, acc[r][o].z);
+          acc[r][o].w = fmaf(v.w, wv.w, acc[r][o].w);
+        }
       }
     }
   }
-  // epilogue: stage loop outside, the TO outputs inside (one copy of each stage's code)
-  const long obase = (((long)n * a.OH + y) * a.OW + x0) * a.Cs + pc;
+  // epilogue: stage loop outside, the patch inside (one copy of each stage's code)
+  const long obase = (((long)n * a.OH + y0) * a.OW + x0) * a.Cs + pc;
+  const long orow = (long)a.OW * a.Cs;
   for (int s = 0; s < ep.n; ++s) {
     const EpStage& st = ep.st[s];
-#pragma unroll
-    for (int o = 0; o < TO; ++o) {
-      float4& v = acc[o];
-      switch (st.kind) {
-        case EP_BIAS: { const float4 b = *(const float4*)(st.v0 + pc); v.x = v.x + b.x; v.y = v.y + b.y; v.z = v.z + b.z; v.w = v.w + b.w; } break;
-        case EP_SMUL: v.x = st.p0 * v.x; v.y = st.p0 * v.y; v.z = st.p0 * v.z; v.w = st.p0 * v.w; break;
-        case EP_SADD: v.x = v.x + st.p0; v.y = v.y + st.p0; v.z = v.z + st.p0; v.w = v.w + st.p0; break;
-        case EP_BN: {
-          const float4 sc = *(const float4*)(st.v0 + pc), sh = *(const float4*)(st.v1 + pc);
-          float t;
-          t = v.x * sc.x; v.x = t + sh.x;
-          t = v.y * sc.y; v.y = t + sh.y;
-          t = v.z * sc.z; v.z = t + sh.z;
-          t = v.w * sc.w; v.w = t + sh.w;
-        } break;
-        case EP_ACT:
-          v.x = ocr_act(st.act, st.p0, st.p1, v.x); v.y = ocr_act(st.act, st.p0, st.p1, v.y);
-          v.z = ocr_act(st.act, st.p0, st.p1, v.z); v.w = ocr_act(st.act, st.p0, st.p1, v.w);
-          break;
-        case EP_MULC: { const float4 g = *(const float4*)(st.v0 + (long)n * a.Cs + pc); v.x = v.x * g.x; v.y = v.y * g.y; v.z = v.z * g.z; v.w = v.w * g.w; } break;
-        case EP_ADDT: if (x0 + o < a.OW) { const float4 g = *(const float4*)(st.v0 + obase + (long)o * a.Cs); v.x = v.x + g.x; v.y = v.y + g.y; v.z = v.z + g.z; v.w = v.w + g.w; } break;
-        default: break;  // ADDUP never follows a depthwise conv on this path (host checks)
-      }
+#define OCR_DW_SWEEP(BODY)                                       \
+  _Pragma("unroll") for (int r = 0; r < R; ++r)                   \
+    _Pragma("unroll") for (int o = 0; o < TO; ++o) {              \
+      float4& v = acc[r][o];                                      \
+      BODY                                                        \
     }
+    switch (st.kind) {
+      case EP_BIAS: {
+        const float4 b = *(const float4*)(st.v0 + pc);
+        OCR_DW_SWEEP({ v.x = v.x + b.x; v.y = v.y + b.y; v.z = v.z + b.z; v.w = v.w + b.w; })
+      } break;
+      case EP_SMUL: {
+        const float k = st.p0;
+        OCR_DW_SWEEP({ v.x = k * v.x; v.y = k * v.y; v.z = k * v.z; v.w = k * v.w; })
+      } break;
+      case EP_SADD: {
+        const float k = st.p0;
+        OCR_DW_SWEEP({ v.x = v.x + k; v.y = v.y + k; v.z = v.z + k; v.w = v.w + k; })
+      } break;
+      case EP_BN: {
+        const float4 sc = *(const float4*)(st.v0 + pc), sh = *(const float4*)(st.v1 + pc);
+        OCR_DW_SWEEP({
+          float u;
+          u = v.x * sc.x; v.x = u + sh.x;
+          u = v.y * sc.y; v.y = u + sh.y;
+          u = v.z * sc.z; v.z = u + sh.z;
+          u = v.w * sc.w; v.w = u + sh.w;
+        })
+      } break;
+      case EP_ACT: {
+        const float p0 = st.p0, p1 = st.p1;
+#define OCR_DW_ACT(KIND) OCR_DW_SWEEP({ v.x = ocr_act(KIND, p0, p1, v.x); v.y = ocr_act(KIND, p0, p1, v.y); v.z = ocr_act(KIND, p0, p1, v.z); v.w = ocr_act(KIND, p0, p1, v.w); })
+        switch (st.act) {
+          case ACT_RELU: OCR_DW_ACT(ACT_RELU) break;
+          case ACT_HSWISH: OCR_DW_ACT(ACT_HSWISH) break;
+          case ACT_HSIG: OCR_DW_ACT(ACT_HSIG) break;
+          case ACT_SWISH: OCR_DW_ACT(ACT_SWISH) break;
+          default: OCR_DW_ACT(ACT_SIGMOID) break;
+        }
+#undef OCR_DW_ACT
+      } break;
+      case EP_MULC: {
+        const float4 g = *(const float4*)(st.v0 + (long)n * a.Cs + pc);
+        OCR_DW_SWEEP({ v.x = v.x * g.x; v.y = v.y * g.y; v.z = v.z * g.z; v.w = v.w * g.w; })
+      } break;
+      case EP_ADDT:
+        OCR_DW_SWEEP({
+          if (y0 + r < a.OH && x0 + o < a.OW) {
+            const float4 g = *(const float4*)(st.v0 + obase + r * orow + (long)o * a.Cs);
+            v.x = v.x + g.x; v.y = v.y + g.y; v.z = v.z + g.z; v.w = v.w + g.w;
+          }
+        })
+        break;
+      default: break;  // ADDUP never follows a depthwise conv on this path (host checks)
+    }
+#undef OCR_DW_SWEEP
   }
 #pragma unroll
-  for (int o = 0; o < TO; ++o)
-    if (x0 + o < a.OW) *(float4*)(a.out + obase + (long)o * a.Cs) = acc[o];
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int o = 0; o < TO; ++o)
+      if (y0 + r < a.OH && x0 + o < a.OW) *(float4*)(a.out + obase + r * orow + (long)o * a.Cs) = acc[r][o];
 }
 
-void launch_dw(const DwArgs& a, const Epilogue& ep, hipStream_t s) {
-  constexpr int TO = 4;
-  const long total = (long)a.N * a.OH * ((a.OW + TO - 1) / TO) * (a.Cs >> 2);
+template <int TO, int R>
+static void launch_dw_patch(const DwArgs& a, const Epilogue& ep, hipStream_t s) {
+  const long total = (long)a.N * ((a.OH + R - 1) / R) * ((a.OW + TO - 1) / TO) * (a.Cs >> 2);
   dim3 grid((unsigned)((total + 255) / 256));
-  if (a.K == 3 && a.SW == 1) hipLaunchKernelGGL((dw_conv_kernel<3, 1, TO>), grid, dim3(256), 0, s, a, ep);
-  else if (a.K == 3) hipLaunchKernelGGL((dw_conv_kernel<3, 2, TO>), grid, dim3(256), 0, s, a, ep);
-  else if (a.SW == 1) hipLaunchKernelGGL((dw_conv_kernel<5, 1, TO>), grid, dim3(256), 0, s, a, ep);
-  else hipLaunchKernelGGL((dw_conv_kernel<5, 2, TO>), grid, dim3(256), 0, s, a, ep);
+  if (a.K == 3 && a.SW == 1) hipLaunchKernelGGL((dw_conv_kernel<3, 1, TO, R>), grid, dim3(256), 0, s, a, ep);
+  else if (a.K == 3) hipLaunchKernelGGL((dw_conv_kernel<3, 2, TO, R>), grid, dim3(256), 0, s, a, ep);
+  else if (a.SW == 1) hipLaunchKernelGGL((dw_conv_kernel<5, 1, TO, R>), grid, dim3(256), 0, s, a, ep);
+  else hipLaunchKernelGGL((dw_conv_kernel<5, 2, TO, R>), grid, dim3(256), 0, s, a, ep);
+}
+void launch_dw(const DwArgs& a, const Epilogue& ep, hipStream_t s) {
+  // OCR_DW_PATCH=TOxR overrides (A/B measurements; results are identical)
+  static const char* env = getenv("OCR_DW_PATCH");
+  int to = 8, r = 2;
+  if (env) sscanf(env, "%dx%d", &to, &r);
+  if (a.OW < 8) to = 4;
+  if (a.OH < 2) r = 1;
+  if (to == 8 && r == 2) launch_dw_patch<8, 2>(a, ep, s);
+  else if (to == 8) launch_dw_patch<8, 1>(a, ep, s);
+  else if (r == 2) launch_dw_patch<4, 2>(a, ep, s);
+  else launch_dw_patch<4, 1>(a, ep, s);
 }
 
 // =====================================================================================

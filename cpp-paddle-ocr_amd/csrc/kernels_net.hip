@@ -111,8 +111,12 @@ __device__ __forceinline__ float4 apply_epilogue4(const Epilogue& ep, float4 v, 
 // heads) is a template parameter so the packed path keeps its 16-byte stores.
 template <int NT, int MODE>
 __device__ __forceinline__ void conv_finish(const ConvArgs& a, const Epilogue& ep, floatx16 (&acc)[NT], int nt0, long m, int hb,
-                                            int n, int y, int x, const float* spar) {
+                                            const float* spar) {
   if (m >= a.M) return;
+  // the pixel's (n, y, x) is only needed by the deconv scatter and by the per-image / upsampled
+  // stages: decoded there (two integer divisions), not in front of every K loop
+  int n = 0, y = 0, x = 0;
+  if constexpr (MODE == OUT_DECONV) decompose(m, a.OH * a.OW, a.OW, n, y, x);
   // Row of quad (t, g): R = r0 + rel, rel = 32t + 8g a compile-time constant, r0 = nt0*32 + 4hb.
   // Everything addressed per quad is "one per-lane base + a uniform offset": nothing per-quad is kept
   // in registers across the stage loop (16 channel indices + 16 64-bit offsets hoisted out of it cost
@@ -189,6 +193,7 @@ __device__ __forceinline__ void conv_finish(const ConvArgs& a, const Epilogue& e
 #undef OCR_ACT_SWEEP
       } break;
       case EP_MULC: {  // per-image channel gate [N][Cs_out]
+        if constexpr (MODE != OUT_DECONV) decompose(m, a.OH * a.OW, a.OW, n, y, x);
         const float* gate = st.v0 + (long)n * a.Cs_out + r0;
         OCR_EP_SWEEP({ const float4 r = *(const float4*)(gate + coff(rel)); wx = wx * r.x; wy = wy * r.y; wz = wz * r.z; ww = ww * r.w; })
       } break;
@@ -197,6 +202,7 @@ __device__ __forceinline__ void conv_finish(const ConvArgs& a, const Epilogue& e
         OCR_EP_SWEEP({ const float4 r = *(const float4*)(res + ooff(rel)); wx = wx + r.x; wy = wy + r.y; wz = wz + r.z; ww = ww + r.w; })
       } break;
       case EP_ADDUP: {  // nearest-upsampled coarser map (never after a deconv)
+        if constexpr (MODE != OUT_DECONV) decompose(m, a.OH * a.OW, a.OW, n, y, x);
         const float* up = st.v0 + (((long)n * st.a2 + y / st.a0) * st.a1 + x / st.a0) * a.Cs_out + r0;
         OCR_EP_SWEEP({ const float4 r = *(const float4*)(up + coff(rel)); wx = wx + r.x; wy = wy + r.y; wz = wz + r.z; ww = ww + r.w; })
       } break;
@@ -229,7 +235,11 @@ __device__ __forceinline__ void conv_finish(const ConvArgs& a, const Epilogue& e
           if (c8i_logical(pc + 2) >= a.Cout) w.z = 0.f;
           if (c8i_logical(pc + 3) >= a.Cout) w.w = 0.f;
         }
+#ifdef OCR_PROBE_NOSTORE
+        if (w.x == 12345.678f) *(float4*)dst = w;  // development probe: keep the value live, skip the traffic
+#else
         *(float4*)dst = w;
+#endif
       }
     }
   }
@@ -246,10 +256,18 @@ __device__ __forceinline__ void conv_stage_params(const ConvArgs& a, const Epilo
   if (i < NT * 32) {
     const int R = nt0 * 32 + i;
     const int pc = R >= a.ColsStore ? 0 : (a.out_mode == OUT_DECONV ? R % a.CoutPadded : R);
-    for (int s = 0; s < ep.n; ++s) {
-      const EpStage& st = ep.st[s];
-      if (st.kind == EP_BIAS || st.kind == EP_BN) spar[(2 * s) * NT * 32 + i] = st.v0[pc];
-      if (st.kind == EP_BN) spar[(2 * s + 1) * NT * 32 + i] = st.v1[pc];
+    float v[2 * OCR_MAX_EP];  // every stage's loads are issued before the first is waited for
+#pragma unroll
+    for (int s = 0; s < OCR_MAX_EP; ++s) {
+      const int kind = s < ep.n ? ep.st[s].kind : -1;
+      v[2 * s] = (kind == EP_BIAS || kind == EP_BN) ? ep.st[s].v0[pc] : 0.f;
+      v[2 * s + 1] = kind == EP_BN ? ep.st[s].v1[pc] : 0.f;
+    }
+#pragma unroll
+    for (int s = 0; s < OCR_MAX_EP; ++s) {
+      const int kind = s < ep.n ? ep.st[s].kind : -1;
+      if (kind == EP_BIAS || kind == EP_BN) spar[(2 * s) * NT * 32 + i] = v[2 * s];
+      if (kind == EP_BN) spar[(2 * s + 1) * NT * 32 + i] = v[2 * s + 1];
     }
   }
   __syncthreads();
@@ -264,7 +282,7 @@ __device__ __forceinline__ void conv_stage_params(const ConvArgs& a, const Epilo
 // B from the host-built fragment image (one 16-byte load per lane per n-tile per 8 channels).
 // No LDS, no barriers: four independent waves per workgroup.
 // =====================================================================================
-template <int NT, int MODE>
+template <int NT, int MODE, bool TAP1>
 __global__ void __launch_bounds__(256, (NT <= 3 ? 4 : 3)) conv_mfma_kernel(const ConvArgs a, const Epilogue ep) {
   CONV_PROBE(0);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -276,11 +294,8 @@ __global__ void __launch_bounds__(256, (NT <= 3 ? 4 : 3)) conv_mfma_kernel(const
   __shared__ float s_par[OCR_MAX_EP * 2 * NT * 32];
   conv_stage_params<NT>(a, ep, nt0, s_par);
   if (m0 >= a.M) return;
-  const int hw = a.OH * a.OW;
   const long m = m0 + p;
   const bool mvalid = m < a.M;
-  int n, y, x;
-  decompose(mvalid ? m : a.M - 1, hw, a.OW, n, y, x);
 
   floatx16 acc[NT];
 #pragma unroll
@@ -290,28 +305,44 @@ __global__ void __launch_bounds__(256, (NT <= 3 ? 4 : 3)) conv_mfma_kernel(const
 
   // K loop flattened over (tap, 8-channel group), software-pipelined over two register sets: the loads
   // of step kk+1 are in flight while the 4*NT MFMAs of step kk issue.  The loop body is straight-line
-  // (no branch between a load and the MFMAs that overlap it, the walk of (tap, c8) is done with selects,
-  // the step past the end re-reads the last one), so the waitcnt the compiler places before each MFMA
-  // group counts the loads issued after the ones it needs instead of draining everything.
+  // (no branch between a load and the MFMAs that overlap it, the step past the end re-reads the last
+  // one), so the waitcnt the compiler places before each MFMA group counts the loads issued after the
+  // ones it needs instead of draining everything.
+  // What a step costs besides its MFMAs is not hidden by the other waves of the SIMD (probe with all
+  // memory traffic removed: the generic walk below holds the kernel at 75% of the MFMA rate), so the
+  // single-tap case - 1x1 conv, linear, deconv: most of the FLOPs - gets a walk of a few instructions.
   const float4* __restrict__ wf = (const float4*)a.wfrag;
   const int KK = a.KH * a.KW * a.C8;
-  int p_c8 = 0, p_ky = 0, p_kx = 0, p_step = 0;
   const float4* p_w = wf + (long)nt0 * 64 + lane;
   const long wstride = (long)a.NTtot * 64;
   const float* zpage = a.zeros + 4 * h;
-  // this lane's pixel at tap (0,0), channel 4h; a tap adds the uniform offset (ky*W + kx)*Cs_in
-  const float* lane_base = a.in + 4 * h + (((long)n * a.H + (y - a.PH)) * a.W + (x - a.PW)) * a.Cs_in;
+  // ---- single tap: step j reads the lane's row at channel 8j and fragment block j
+  const float* xrow = mvalid ? a.in + m * a.Cs_in + 4 * h : zpage;
+  int p_step = 0;
+  // ---- general: incremental (tap, c8) walk with selects
+  int p_c8 = 0, p_ky = 0, p_kx = 0;
+  int n = 0, y = 0, x = 0;
+  const float* lane_base = nullptr;
   long tap_off = 0;  // + c8*8, elements
+  if constexpr (!TAP1) {
+    decompose(mvalid ? m : a.M - 1, a.OH * a.OW, a.OW, n, y, x);
+    // this lane's pixel at tap (0,0), channel 4h; a tap adds the uniform offset (ky*W + kx)*Cs_in
+    lane_base = a.in + 4 * h + (((long)n * a.H + (y - a.PH)) * a.W + (x - a.PW)) * a.Cs_in;
+  }
   auto load_step = [&](float4& av, float4 (&bv)[NT]) {
-    const int iy = y - a.PH + p_ky, ix = x - a.PW + p_kx;
-    const bool valid = mvalid && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-    // padding / out-of-range rows read a zero page: no select ever touches a loaded value
-    const float* src = valid ? lane_base + tap_off : zpage;
+    if constexpr (TAP1) {
 #ifdef OCR_PROBE_NOX
-    av = make_float4((float)(size_t)src, 1.f, 2.f, 3.f);
+      av = make_float4((float)(size_t)xrow, 1.f, 2.f, 3.f);
 #else
-    av = *(const float4*)src;
+      av = *(const float4*)(xrow + p_step * 8);
 #endif
+    } else {
+      const int iy = y - a.PH + p_ky, ix = x - a.PW + p_kx;
+      const bool valid = mvalid && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+      // padding / out-of-range rows read a zero page: no select ever touches a loaded value
+      const float* src = valid ? lane_base + tap_off : zpage;
+      av = *(const float4*)src;
+    }
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #ifdef OCR_PROBE_NOW
@@ -322,14 +353,16 @@ __global__ void __launch_bounds__(256, (NT <= 3 ? 4 : 3)) conv_mfma_kernel(const
     const bool more = p_step + 1 < KK;                 // past the end: stay on the last step (loaded, unused)
     p_step += more;
     p_w += more ? wstride : 0;
-    p_c8 += more;
-    const bool wc = p_c8 == a.C8;
-    p_c8 = wc ? 0 : p_c8;
-    p_kx += wc;
-    const bool wx = p_kx == a.KW;
-    p_kx = wx ? 0 : p_kx;
-    p_ky += wx;
-    tap_off = ((long)p_ky * a.W + p_kx) * a.Cs_in + p_c8 * 8;
+    if constexpr (!TAP1) {
+      p_c8 += more;
+      const bool wc = p_c8 == a.C8;
+      p_c8 = wc ? 0 : p_c8;
+      p_kx += wc;
+      const bool wx = p_kx == a.KW;
+      p_kx = wx ? 0 : p_kx;
+      p_ky += wx;
+      tap_off = ((long)p_ky * a.W + p_kx) * a.Cs_in + p_c8 * 8;
+    }
   };
   auto mfma_step = [&](const float4& av, const float4 (&bv)[NT]) {
 #pragma unroll
@@ -362,22 +395,25 @@ __global__ void __launch_bounds__(256, (NT <= 3 ? 4 : 3)) conv_mfma_kernel(const
   __builtin_amdgcn_s_setprio(3);
 
   // ---- epilogue: lane owns output column j (one channel), 16 rows ----
-  conv_finish<NT, MODE>(a, ep, acc, nt0, m, h, n, y, x, s_par);
+  conv_finish<NT, MODE>(a, ep, acc, nt0, m, h, s_par);
   CONV_PROBE(3);
 }
 
 void launch_conv_mfma(const ConvArgs& a, const Epilogue& ep, int nt, hipStream_t s) {
   dim3 grid((unsigned)(((a.M + 127) / 128) * (a.NTtot / nt)));
-#define OCR_LAUNCH_MODE(MODE)                                                                                   \
+#define OCR_LAUNCH_MODE(MODE, TAP1)                                                                             \
   switch (nt) {                                                                                                 \
-    case 1: hipLaunchKernelGGL((conv_mfma_kernel<1, MODE>), grid, dim3(256), 0, s, a, ep); break;               \
-    case 2: hipLaunchKernelGGL((conv_mfma_kernel<2, MODE>), grid, dim3(256), 0, s, a, ep); break;               \
-    case 3: hipLaunchKernelGGL((conv_mfma_kernel<3, MODE>), grid, dim3(256), 0, s, a, ep); break;               \
-    default: hipLaunchKernelGGL((conv_mfma_kernel<4, MODE>), grid, dim3(256), 0, s, a, ep); break;              \
+    case 1: hipLaunchKernelGGL((conv_mfma_kernel<1, MODE, TAP1>), grid, dim3(256), 0, s, a, ep); break;         \
+    case 2: hipLaunchKernelGGL((conv_mfma_kernel<2, MODE, TAP1>), grid, dim3(256), 0, s, a, ep); break;         \
+    case 3: hipLaunchKernelGGL((conv_mfma_kernel<3, MODE, TAP1>), grid, dim3(256), 0, s, a, ep); break;         \
+    default: hipLaunchKernelGGL((conv_mfma_kernel<4, MODE, TAP1>), grid, dim3(256), 0, s, a, ep); break;        \
   }
-  if (a.out_mode == OUT_PLAIN) { OCR_LAUNCH_MODE(OUT_PLAIN) }
-  else if (a.out_mode == OUT_DECONV) { OCR_LAUNCH_MODE(OUT_DECONV) }
-  else { OCR_LAUNCH_MODE(OUT_C8I) }
+  const bool tap1 = a.KH == 1 && a.KW == 1 && a.PH == 0 && a.PW == 0 && a.OH == a.H && a.OW == a.W;
+  if (a.out_mode == OUT_PLAIN && tap1) { OCR_LAUNCH_MODE(OUT_PLAIN, true) }
+  else if (a.out_mode == OUT_DECONV && tap1) { OCR_LAUNCH_MODE(OUT_DECONV, true) }
+  else if (a.out_mode == OUT_C8I && tap1) { OCR_LAUNCH_MODE(OUT_C8I, true) }
+  else if (a.out_mode == OUT_C8I) { OCR_LAUNCH_MODE(OUT_C8I, false) }
+  else { fprintf(stderr, "launch_conv_mfma: multi-tap conv with a plain/deconv output is not instantiated\n"); abort(); }
 #undef OCR_LAUNCH_MODE
 }
 
@@ -521,7 +557,7 @@ __global__ void __launch_bounds__(256, 2) conv_lds_kernel(const ConvArgs a, cons
   if (m >= a.M) return;
   int n, y, x;
   decompose(m, hw, a.OW, n, y, x);
-  conv_finish<NT, OUT_C8I>(a, ep, acc, nt0, m, h, n, y, x, s_par);
+  conv_finish<NT, OUT_C8I>(a, ep, acc, nt0, m, h, s_par);
 }
 
 template <int NT>

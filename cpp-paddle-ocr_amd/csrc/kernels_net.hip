@@ -389,10 +389,6 @@ __global__ void __launch_bounds__(256, (NT <= 3 ? 4 : 3)) conv_mfma_kernel(const
   }
   if (kk < KK) mfma_step(a0, b0);
   CONV_PROBE(2);
-  // the epilogue's VALU work competes for the issue port with the MFMAs of the other waves on this
-  // SIMD; at equal priority it gets roughly one slot per MFMA and lasts as long as the K loop did
-  // (probe: 80k of 160k clocks per wave at K = 240).  A wave that has left the loop goes first.
-  __builtin_amdgcn_s_setprio(3);
 
   // ---- epilogue: lane owns output column j (one channel), 16 rows ----
   conv_finish<NT, MODE>(a, ep, acc, nt0, m, h, s_par);

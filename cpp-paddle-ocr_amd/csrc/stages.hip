@@ -266,7 +266,11 @@ bool RecStage::create(const RecConfig& cfg, std::string& err, int& code) {
   if (!load_model_dir(cfg.model_dir, nullptr, w, err)) return false;
   if (!net_.load(embedded_plan("rec"), w, err) || !net2_.load(embedded_plan("rec"), w, err)) return false;
   code = OCR_ERR_DEVICE;
-  if (hipStreamCreate(&stream_) != hipSuccess || hipStreamCreate(&stream2_) != hipSuccess ||
+  // lane 1 carries the small odd-width launches: a high-priority queue, so their workgroups are placed
+  // as soon as slots free up instead of waiting behind the thousands queued by lane 0's big kernels
+  int prio_lo = 0, prio_hi = 0;
+  (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+  if (hipStreamCreate(&stream_) != hipSuccess || hipStreamCreateWithPriority(&stream2_, hipStreamDefault, prio_hi) != hipSuccess ||
       hipEventCreateWithFlags(&ev_descs_, hipEventDisableTiming) != hipSuccess) { err = "hipStreamCreate failed"; return false; }
   if (!timer_.init(err)) return false;
   const float mean[3] = {0.5f, 0.5f, 0.5f}, scale[3] = {1 / 0.5f, 1 / 0.5f, 1 / 0.5f};  // ocr_rec.h:108-109

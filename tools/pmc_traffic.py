@@ -2,10 +2,11 @@
 with the gfx950 corrections of MI355X_MICROARCH.md §HBM: bytes_read = FETCH_SIZE * 1024 * 2 (FETCH_SIZE
 tallies the 128-B requests of a wide coalesced stream at 64 B), bytes_written = WRITE_SIZE * 1024.
 
-The dominant kernel of bench.py is rec op 30 (conv1x1 480->480 at H/8 = 6 rows): conv_mfma_kernel<3>
-on the 1024-line launch has grid 19200 workgroups x 256 threads (M = 1024*6*80 rows / 128 x 5 column
-groups).  rec op 25 (conv1x1 240->480, same output shape) shares that kernel and grid; in dispatch
-order the two alternate (op 25 first), so every second dispatch of the pair is op 30.
+The dominant kernel of bench.py is rec op 30 (conv1x1 480->480 at H/8 = 6 rows): conv_mfma_kernel<3, ...>
+on the 1872-line launch (all width-320 lines of the 64 images) has grid 35100 workgroups x 256 threads
+(M = 1872*6*80 rows / 128 x 5 column groups).  rec ops 25, 32 and 34 share that kernel and grid; within
+one forward pass they are dispatched in plan order 25, 30, 32, 34, so op 30 is every fourth dispatch
+starting at the second.
 
     python tools/pmc_traffic.py gpurun_out/prof_<tag> profiles/<name>.json
 """
@@ -28,19 +29,20 @@ def rows(d, counter):
 
 def main():
     root, dst = sys.argv[1], sys.argv[2]
-    grid = 19200 * 256
-    sel = lambda rs: [r for r in rs if "conv_mfma_kernel<3>" in r[1] and r[2] == grid][1::2]
+    LINES = 1872
+    grid = (LINES * 6 * 80 // 128) * 5 * 256
+    sel = lambda rs: [r for r in rs if "conv_mfma_kernel<3" in r[1] and r[2] == grid][1::4]
     fe = sel(rows(os.path.join(root, "pmc_fetch"), "FETCH_SIZE"))
     wr = sel(rows(os.path.join(root, "pmc_write"), "WRITE_SIZE"))
     mf = sel(rows(os.path.join(root, "pmc_sq"), "SQ_VALU_MFMA_BUSY_CYCLES"))
     gui = sel(rows(os.path.join(root, "pmc_sq"), "GRBM_GUI_ACTIVE"))
     rd = sum(r[3] for r in fe) / len(fe) * 1024 * 2
     wb = sum(r[3] for r in wr) / len(wr) * 1024
-    M, K, N = 1024 * 6 * 80, 480, 480
+    M, K, N = LINES * 6 * 80, 480, 480
     alg = 4.0 * (M * K + M * N + K * N)
     out = {
-        "kernel": "rec.30.conv1x1_480_480@1024x48x320",
-        "launch": "conv_mfma_kernel<3>, grid 19200x256 (the 1024-line, width-320 launch)",
+        "kernel": "rec.30.conv1x1_480_480@%dx48x320" % LINES,
+        "launch": "conv_mfma_kernel<3, OUT_C8I, single-tap>, grid %dx256 (the %d-line, width-320 launch)" % (grid // 256, LINES),
         "dispatches_averaged": len(fe),
         "hbm_read_bytes_per_launch": rd,
         "hbm_write_bytes_per_launch": wb,

@@ -126,8 +126,16 @@ def main():
 
     for _ in range(args.warmup):
         pipe.run_device(d_imgs, H, W, BATCH, d_probs, collect=False)
+    survey = None
     if not args.no_kernel_timing:
-        pipe.timing(True)  # HIP events around every network launch, on the launch stream
+        # One untimed survey pass with HIP events around EVERY network launch (on the launch stream) finds the
+        # dominant kernel and gives the per-kernel table; in the timed region only that kernel carries events
+        # (a thousand event pairs per step cost ~4% of the step).
+        pipe.timing(True)
+        pipe.run_device(d_imgs, H, W, BATCH, d_probs, collect=False)
+        survey = pipe.timing_report()
+        dominant = max(survey.items(), key=lambda kv: kv[1]["ms"])[0]
+        pipe.timing(True, only=dominant)   # also resets the accumulated timings
     step_ms = []
     nwords = 0
     barrier()
@@ -170,7 +178,7 @@ def main():
             "words_per_step": nwords,
         }
         if not args.no_kernel_timing:
-            rep = pipe.timing_report()
+            rep = pipe.timing_report()   # the dominant kernel's launches inside the timed region
             if rep:
                 top = max(rep.items(), key=lambda kv: kv[1]["ms"])
                 name, r = top
@@ -188,15 +196,16 @@ def main():
                                    "algorithmic_flops_per_launch": r["flops"] / max(1, r["count"]),
                                    "algorithmic_bytes_per_launch": r["bytes"] / max(1, r["count"]),
                                    "hbm_GBps_algorithmic": r["bytes"] / (r["ms"] * 1e-3) / 1e9 if r["ms"] > 0 else 0.0}
-                tot = sum(v["ms"] for v in rep.values())
+            if survey:   # per-kernel shares from the untimed survey pass (one step, every launch timed)
+                tot = sum(v["ms"] for v in survey.values())
                 out["kernel_time_share_top5"] = {k: round(v["ms"] / tot, 4) for k, v in
-                                                 sorted(rep.items(), key=lambda kv: -kv[1]["ms"])[:5]}
-                out["network_kernel_ms_per_step"] = tot / args.steps
+                                                 sorted(survey.items(), key=lambda kv: -kv[1]["ms"])[:5]}
+                out["network_kernel_ms_per_step"] = tot
                 if os.environ.get("OCR_BENCH_KERNEL_TABLE"):
                     with open(os.environ["OCR_BENCH_KERNEL_TABLE"], "w") as f:
-                        for k, v in sorted(rep.items(), key=lambda kv: -kv[1]["ms"]):
+                        for k, v in sorted(survey.items(), key=lambda kv: -kv[1]["ms"]):
                             f.write("%-40s ms/step %8.3f launches/step %5.1f  TFLOP/s %7.2f  GB/s(alg) %8.1f\n" % (
-                                k, v["ms"] / args.steps, v["count"] / args.steps,
+                                k, v["ms"], v["count"],
                                 v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] else 0,
                                 v["bytes"] / (v["ms"] * 1e-3) / 1e9 if v["ms"] else 0))
         if world == 1 and not args.no_cpu_baseline:

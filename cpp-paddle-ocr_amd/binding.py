@@ -353,7 +353,7 @@ class ocr_word(C.Structure):
 
 
 EXPORTS += ["ocr_pipe_cfg_default", "ocr_pipe_create", "ocr_pipe_destroy", "ocr_pipe_run", "ocr_pipe_run_device",
-            "ocr_pipe_label", "ocr_pipe_det_shape", "ocr_pipe_timing", "ocr_pipe_timing_report", "ocr_dev_alloc",
+            "ocr_pipe_label", "ocr_pipe_det_shape", "ocr_pipe_timing", "ocr_pipe_timing_filter", "ocr_pipe_timing_report", "ocr_dev_alloc",
             "ocr_dev_free", "ocr_dev_upload", "ocr_dev_download", "ocr_dev_sync", "ocr_rotate_crop", "ocr_rotate_crop_shape"]
 
 
@@ -373,6 +373,7 @@ def _pipe_protos(L):
     L.ocr_pipe_det_shape.argtypes = [vp, C.c_int, C.c_int, ip, ip]
     L.ocr_pipe_timing.argtypes = [vp, C.c_int]
     L.ocr_pipe_timing_report.argtypes = [vp, C.c_char_p, C.c_size_t]
+    L.ocr_pipe_timing_filter.argtypes = [vp, C.c_char_p]
     L.ocr_dev_alloc.argtypes = [C.POINTER(vp), C.c_size_t]
     L.ocr_dev_free.argtypes = [vp]
     L.ocr_dev_upload.argtypes = [vp, vp, C.c_size_t]
@@ -512,7 +513,9 @@ class Pipe:
         s = lib().ocr_pipe_label(self.h, int(i))
         return s.decode("utf-8") if s is not None else None
 
-    def timing(self, on=True):
+    def timing(self, on=True, only=None):
+        """HIP events around network launches; `only`: restrict them to launches whose name contains it."""
+        check(lib().ocr_pipe_timing_filter(self.h, only.encode() if only else None))
         check(lib().ocr_pipe_timing(self.h, int(on)))
 
     def timing_report(self):

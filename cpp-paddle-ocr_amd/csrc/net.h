@@ -82,6 +82,8 @@ class Net {
 
   // per-kernel-family timing with HIP events on the launch stream (bench / roofline)
   void enable_timing(bool on) { timing_ = on; }
+  // events only around launches whose name contains `substr` (empty: every launch)
+  void set_timing_filter(const std::string& substr) { timing_filter_ = substr; }
   const std::map<std::string, KernelTiming>& timings() const { return timings_; }
   void reset_timings() { timings_.clear(); }
   void collect_timings();  // after a stream sync: folds event pairs into timings_
@@ -116,6 +118,7 @@ class Net {
   int* head_amax_ = nullptr;
   float* head_pmax_ = nullptr;
   bool timing_ = false;
+  std::string timing_filter_;
   bool keep_all_ = false;
   std::map<std::string, KernelTiming> timings_;
   struct EvPair { hipEvent_t a, b; std::string name; double flops, bytes; };

@@ -667,7 +667,7 @@ bool Net::run(const float* x, int N, int H, int W, hipStream_t s, std::string& e
   }
   bound_x_ = x;
   for (size_t i = 0; i < launches_.size(); ++i) {
-    if (timing_) {
+    if (timing_ && (timing_filter_.empty() || launches_[i].name.find(timing_filter_) != std::string::npos)) {
       hipEvent_t a, b;
       if (ev_pool_.size() >= 2) { a = ev_pool_.back(); ev_pool_.pop_back(); b = ev_pool_.back(); ev_pool_.pop_back(); }
       else { HIP_OK(hipEventCreate(&a)); HIP_OK(hipEventCreate(&b)); }

@@ -312,6 +312,14 @@ int ocr_pipe_timing(ocr_pipe* h, int enable) {
   h->rec.net2().reset_timings();
   return OCR_OK;
 }
+int ocr_pipe_timing_filter(ocr_pipe* h, const char* substr) {
+  if (!h) return fail(OCR_ERR_ARG, "null handle");
+  const std::string f = substr ? substr : "";
+  h->det.net().set_timing_filter(f);
+  h->rec.net().set_timing_filter(f);
+  h->rec.net2().set_timing_filter(f);
+  return OCR_OK;
+}
 int ocr_pipe_timing_report(ocr_pipe* h, char* buf, size_t cap) {
   if (!h || !buf) return fail(OCR_ERR_ARG, "null argument");
   size_t off = 0;

@@ -162,6 +162,8 @@ const char* ocr_pipe_label(ocr_pipe* h, int id);
 int ocr_pipe_det_shape(ocr_pipe* h, int rows, int cols, int* net_rows, int* net_cols);
 /* HIP-event timing of every kernel launch of the three networks during subsequent runs */
 int ocr_pipe_timing(ocr_pipe* h, int enable);
+/* restrict the events to launches whose name contains substr (NULL or "": all launches) */
+int ocr_pipe_timing_filter(ocr_pipe* h, const char* substr);
 int ocr_pipe_timing_report(ocr_pipe* h, char* buf, size_t cap);
 
 /* Utility::GetRotateCropImage (/root/reference/src/utility.cpp:137-190) for n boxes (n x 8 ints,

@@ -314,3 +314,27 @@ def test_pipeline_device_resident_bench_protocol(pkg, built):
         for k, g in enumerate(got[i]):
             assert np.array_equal(g["box"], boxes[k]) and np.array_equal(g["ids"], texts[k]) and g["confidence"] == scores[k]
     pg.close()
+
+
+def test_pipeline_cfg3_mixed_sizes(pkg, built):
+    """cfg3: images of different sizes in one call (each size its own det pass, 'max' limit 960 rounds to
+    multiples of 32), cls on, whole path through the real networks (synthetic det/rec weights)."""
+    from pipeline import Pipeline, DetCfg
+    from synth_data import cfg3_sample
+    imgs = [cfg3_sample(i)[0] for i in range(3)]
+    assert len({im.shape for im in imgs}) == 3
+    kw = dict(rec_batch_num=16, rec_img_h=48, rec_img_w=320, enable_cls=True)
+    pg = pkg.Pipe(limit_side_len=960, **kw)
+    po = Pipeline(det_cfg=DetCfg(limit_side_len=960), **kw)
+    got = pg.run(imgs + [imgs[0]])                       # a repeated size shares its det pass
+    for img, g in zip(imgs + [imgs[0]], got):
+        nr, nc = pg.det_shape(*img.shape[:2])
+        assert nr % 32 == 0 and nc % 32 == 0 and max(nr, nc) <= 960
+        w = po.process(img)["words"]
+        assert len(g) == len(w)
+        for a, b in zip(g, w):
+            assert np.array_equal(a["box"], b["box"]) and np.array_equal(a["ids"], b["ids"])
+            assert a["confidence"] == np.float32(b["confidence"])
+    assert sum(len(g) for g in got) > 0
+    assert all(np.array_equal(a["box"], b["box"]) and np.array_equal(a["ids"], b["ids"]) for a, b in zip(got[0], got[3]))
+    pg.close()

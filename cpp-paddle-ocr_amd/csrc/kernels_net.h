@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "ocr_common.h"
 
 namespace ocr {
@@ -28,7 +30,12 @@ void launch_conv_mfma(const ConvArgs& a, const Epilogue& ep, int nt, hipStream_t
 // LDS-staged variant of the same GEMM (default when K = taps*Cs_in >= 64)
 void launch_conv_lds(const ConvArgs& a, const Epilogue& ep, int nt, hipStream_t s);
 // column tiles per wave for a GEMM with `tiles` 32-wide column tiles
-inline int conv_nt_for(int tiles) { return tiles <= 4 ? tiles : (tiles % 4 == 0 ? 4 : (tiles % 3 == 0 ? 3 : 4)); }
+inline int conv_nt_for(int tiles) {
+  static const char* e = getenv("OCR_CONV_NT_MAX");  // A/B measurements (results are identical)
+  static const int cap = e ? atoi(e) : 4;
+  if (cap < 4 && tiles > cap) return tiles % cap == 0 ? cap : (cap > 2 && tiles % (cap - 1) == 0 ? cap - 1 : cap);
+  return tiles <= 4 ? tiles : (tiles % 4 == 0 ? 4 : (tiles % 3 == 0 ? 3 : 4));
+}
 
 struct StemArgs {
   const float* in;  // [N,H,W,3] plain

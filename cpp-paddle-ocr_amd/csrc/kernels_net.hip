@@ -624,9 +624,18 @@ void launch_stem(const StemArgs& a, const Epilogue& ep, hipStream_t s) {
 // those loads, not by HBM.  For every output the taps still arrive in (ky, kx) ascending order (rows
 // top to bottom, kx inner): the arithmetic contract is untouched.
 // =====================================================================================
+// The K*K x Cs weights are copied to LDS once per workgroup (a workgroup's 256 threads span every channel
+// quad): a thread's 50 weight fetches per patch become LDS reads and leave the L1/TA path to the pixels.
 template <int K, int SW, int TO, int R>
 __global__ void __launch_bounds__(256) dw_conv_kernel(const DwArgs a, const Epilogue ep) {
   constexpr int NIN = (TO - 1) * SW + K;
+  extern __shared__ float4 s_dw_w[];  // [K*K][Cs/4]
+  {
+    const int nw4 = K * K * (a.Cs >> 2);
+    const float4* gw = (const float4*)a.w;
+    for (int i = threadIdx.x; i < nw4; i += 256) s_dw_w[i] = gw[i];
+    __syncthreads();
+  }
   const long t = (long)xcd_swizzle(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
   const int c4n = a.Cs >> 2;
   const int strips = (a.OW + TO - 1) / TO, bands = (a.OH + R - 1) / R;
@@ -645,25 +654,28 @@ __global__ void __launch_bounds__(256) dw_conv_kernel(const DwArgs a, const Epil
     for (int o = 0; o < TO; ++o) acc[r][o] = make_float4(0.f, 0.f, 0.f, 0.f);
   const int ixb = x0 * SW - a.PW, iyb = y0 * a.SH - a.PH;
   const int nrows = (R - 1) * a.SH + K;
-#pragma unroll 1
-  for (int j = 0; j < nrows; ++j) {  // one input row at a time (registers); rows beyond the image are zero rows
+  // Two row buffers in ping-pong: row j+1 is in flight while row j is consumed (the kernel runs at 2-3
+  // waves/SIMD, so the bytes in flight per wave are what hides the memory latency).  Rows beyond the
+  // image are zero rows; the row after the last one is loaded (clamped) and never used.
+  auto load_row = [&](float4 (&in)[NIN], int j) {
     const int iy = iyb + j;
-    const bool rv = iy >= 0 && iy < a.H;
+    const bool rv = j < nrows && iy >= 0 && iy < a.H;
     const float* row = a.in + (((long)n * a.H + (rv ? iy : 0)) * a.W) * a.Cs + pc;
-    float4 in[NIN];
 #pragma unroll
     for (int q = 0; q < NIN; ++q) {
       const int ix = ixb + q;
       in[q] = (rv && ix >= 0 && ix < a.W) ? *(const float4*)(row + (long)ix * a.Cs) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+  };
+  auto use_row = [&](const float4 (&in)[NIN], int j) {
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int ky = j - r * a.SH;  // uniform
       if (ky < 0 || ky >= K) continue;
-      const float* wrow = a.w + (long)(ky * K) * a.Cs + pc;
+      const float4* wrow = s_dw_w + (ky * K) * (a.Cs >> 2) + (pc >> 2);
 #pragma unroll
       for (int kx = 0; kx < K; ++kx) {
-        const float4 wv = *(const float4*)(wrow + (long)kx * a.Cs);
+        const float4 wv = wrow[kx * (a.Cs >> 2)];
 #pragma unroll
         for (int o = 0; o < TO; ++o) {
           const float4 v = in[o * SW + kx];
@@ -674,6 +686,19 @@ __global__ void __launch_bounds__(256) dw_conv_kernel(const DwArgs a, const Epil
         }
       }
     }
+  };
+  float4 rowA[NIN], rowB[NIN];
+  load_row(rowA, 0);
+#pragma unroll 1
+  for (int j = 0; j < nrows; j += 2) {
+    load_row(rowB, j + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    use_row(rowA, j);
+    __builtin_amdgcn_sched_barrier(0);
+    load_row(rowA, j + 2);
+    __builtin_amdgcn_sched_barrier(0);
+    if (j + 1 < nrows) use_row(rowB, j + 1);
+    __builtin_amdgcn_sched_barrier(0);
   }
   // epilogue: stage loop outside, the patch inside (one copy of each stage's code)
   const long obase = (((long)n * a.OH + y0) * a.OW + x0) * a.Cs + pc;
@@ -748,17 +773,18 @@ template <int TO, int R>
 static void launch_dw_patch(const DwArgs& a, const Epilogue& ep, hipStream_t s) {
   const long total = (long)a.N * ((a.OH + R - 1) / R) * ((a.OW + TO - 1) / TO) * (a.Cs >> 2);
   dim3 grid((unsigned)((total + 255) / 256));
-  if (a.K == 3 && a.SW == 1) hipLaunchKernelGGL((dw_conv_kernel<3, 1, TO, R>), grid, dim3(256), 0, s, a, ep);
-  else if (a.K == 3) hipLaunchKernelGGL((dw_conv_kernel<3, 2, TO, R>), grid, dim3(256), 0, s, a, ep);
-  else if (a.SW == 1) hipLaunchKernelGGL((dw_conv_kernel<5, 1, TO, R>), grid, dim3(256), 0, s, a, ep);
-  else hipLaunchKernelGGL((dw_conv_kernel<5, 2, TO, R>), grid, dim3(256), 0, s, a, ep);
+  const unsigned lds = (unsigned)(a.K * a.K * a.Cs * sizeof(float));  // <= 48 KB for 5x5 x 480 channels
+  if (a.K == 3 && a.SW == 1) hipLaunchKernelGGL((dw_conv_kernel<3, 1, TO, R>), grid, dim3(256), lds, s, a, ep);
+  else if (a.K == 3) hipLaunchKernelGGL((dw_conv_kernel<3, 2, TO, R>), grid, dim3(256), lds, s, a, ep);
+  else if (a.SW == 1) hipLaunchKernelGGL((dw_conv_kernel<5, 1, TO, R>), grid, dim3(256), lds, s, a, ep);
+  else hipLaunchKernelGGL((dw_conv_kernel<5, 2, TO, R>), grid, dim3(256), lds, s, a, ep);
 }
 void launch_dw(const DwArgs& a, const Epilogue& ep, hipStream_t s) {
   // OCR_DW_PATCH=TOxR overrides (A/B measurements; results are identical)
   static const char* env = getenv("OCR_DW_PATCH");
   int to = 8, r = 2;
   if (env) sscanf(env, "%dx%d", &to, &r);
-  if (a.OW < 8) to = 4;
+  if (a.OW < 8 || (a.SW == 2 && !env)) to = 4;  // stride 2 needs 2*TO+K-2 pixels per row buffer: 8 wide does not fit the registers
   if (a.OH < 2) r = 1;
   if (to == 8 && r == 2) launch_dw_patch<8, 2>(a, ep, s);
   else if (to == 8) launch_dw_patch<8, 1>(a, ep, s);

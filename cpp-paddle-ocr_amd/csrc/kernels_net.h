@@ -8,7 +8,7 @@
 
 namespace ocr {
 
-enum : int { OUT_C8I = 0, OUT_PLAIN = 1, OUT_DECONV = 2 };
+enum : int { OUT_C8I = 0, OUT_PLAIN = 1, OUT_DECONV = 2, OUT_HEAD = 3 };
 
 struct ConvArgs {
   const float* in;   // [N,H,W,Cs_in] C8I
@@ -25,6 +25,11 @@ struct ConvArgs {
   int KH, KW, PH, PW;
   int out_mode;
   int need_nyx;
+  // OUT_HEAD (linear + softmax fused, nothing of the logits is stored): per (row, 128-column group)
+  // the group's max logit, sum of exp(logit - max) and arg max; [M][NTtot/NT] each
+  float* head_max;
+  float* head_sum;
+  int* head_idx;
 };
 void launch_conv_mfma(const ConvArgs& a, const Epilogue& ep, int nt, hipStream_t s);
 // LDS-staged variant of the same GEMM (default when K = taps*Cs_in >= 64)
@@ -88,6 +93,9 @@ void launch_ln(const float* in, float* out, long rows, int C, int Cs, float eps,
                hipStream_t s);
 void launch_attn(const float* qkv, float* out, int N, int T, int heads, int hd, int Cs_in, int Cs_out, float scale,
                  hipStream_t s);
+// second half of the fused head: rows x groups partials -> arg max / max probability per row
+void launch_head_combine(const float* hmax, const float* hsum, const int* hidx, long rows, int groups, int* amax, float* pmax,
+                         hipStream_t s);
 void launch_softmax_argmax(const float* logits, float* probs, int* amax, float* pmax, long rows, int C, hipStream_t s);
 
 struct DetTailArgs {

@@ -209,6 +209,45 @@ __device__ __forceinline__ void conv_finish(const ConvArgs& a, const Epilogue& e
     }
   }
 #undef OCR_EP_SWEEP
+  if constexpr (MODE == OUT_HEAD) {
+    // Fused softmax head, first half (canonical order of the row softmax, shared with the oracle and with
+    // softmax_argmax_kernel): columns in groups of 128; inside a group two interleaved chains - the
+    // columns with ((c >> 2) & 1) == 0 and == 1, i.e. the two half-waves of this layout - each summed in
+    // ascending column order, then chain 0 + chain 1.  The logits never leave the registers.
+    float mx = -INFINITY;
+    int mi = 0x7fffffff;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int c = r0 + 32 * t + 8 * g + k;
+          const float v = acc[t][4 * g + k];
+          if (c < a.Cout && v > mx) { mx = v; mi = c; }  // ascending c: the first maximum wins
+        }
+    const float omx = __shfl_xor(mx, 32);
+    const int omi = __shfl_xor(mi, 32);
+    if (omx > mx || (omx == mx && omi < mi)) { mx = omx; mi = omi; }
+    float part = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int c = r0 + 32 * t + 8 * g + k;
+          if (c < a.Cout) part = part + ocr_expf(acc[t][4 * g + k] - mx);
+        }
+    const float other = __shfl_xor(part, 32);
+    if (hb == 0) {
+      const long q = m * (a.NTtot / NT) + nt0 / NT;
+      a.head_max[q] = mx;
+      a.head_sum[q] = part + other;
+      a.head_idx[q] = mi;
+    }
+    return;
+  }
   // ---- stores, after the last load
   float* obase = a.out + opix;
 #pragma unroll
@@ -405,7 +444,8 @@ void launch_conv_mfma(const ConvArgs& a, const Epilogue& ep, int nt, hipStream_t
     default: hipLaunchKernelGGL((conv_mfma_kernel<4, MODE, TAP1>), grid, dim3(256), 0, s, a, ep); break;        \
   }
   const bool tap1 = a.KH == 1 && a.KW == 1 && a.PH == 0 && a.PW == 0 && a.OH == a.H && a.OW == a.W;
-  if (a.out_mode == OUT_PLAIN && tap1) { OCR_LAUNCH_MODE(OUT_PLAIN, true) }
+  if (a.out_mode == OUT_HEAD && tap1) { OCR_LAUNCH_MODE(OUT_HEAD, true) }
+  else if (a.out_mode == OUT_PLAIN && tap1) { OCR_LAUNCH_MODE(OUT_PLAIN, true) }
   else if (a.out_mode == OUT_DECONV && tap1) { OCR_LAUNCH_MODE(OUT_DECONV, true) }
   else if (a.out_mode == OUT_C8I && tap1) { OCR_LAUNCH_MODE(OUT_C8I, true) }
   else if (a.out_mode == OUT_C8I) { OCR_LAUNCH_MODE(OUT_C8I, false) }
@@ -1047,34 +1087,49 @@ void launch_attn(const float* qkv, float* out, int N, int T, int heads, int hd, 
 
 // =====================================================================================
 // Row softmax over plain [rows][C] + greedy-CTC inputs (arg max / max prob per row).
-// One wave per row; the sum is 64 strided partials + halving tree (contract order).
-// probs may be null (production: only idx/prob leave the chip).
+// Canonical order (the same in conv_finish<OUT_HEAD> + head_combine_kernel and in
+// the oracle): columns in groups of 128; per group its max m_g and s_g = chain0 + chain1, chain h = the
+// columns with ((c >> 2) & 1) == h summed in ascending order of exp(x_c - m_g); per row M = max_g m_g,
+// S = sum over ascending g of s_g * exp(m_g - M); p_c = exp(x_c - M) / S; arg max = first maximum of the
+// LOGITS, its probability exp(0) / S.
+// This kernel is the unfused form (probabilities requested: parity taps, the 2-class cls head):
+// one wave per row, lane l walks chains l and l + 64 of the 2 * ceil(C/128) chains.
 // =====================================================================================
 __global__ void __launch_bounds__(256) softmax_argmax_kernel(const float* __restrict__ logits, float* __restrict__ probs,
                                                              int* __restrict__ amax, float* __restrict__ pmax, long rows,
                                                              int C) {
-  const int lane = threadIdx.x & 63;
-  const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  __shared__ float s_m[4][128], s_s[4][128];  // per wave: group max, chain sums (up to 64 groups = 8192 columns)
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const long r = (long)blockIdx.x * 4 + wv;
   if (r >= rows) return;
   const float* src = logits + r * C;
-  float mx = -INFINITY;
-  for (int c = lane; c < C; c += 64) mx = fmaxf(mx, src[c]);
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
-  float part = 0.f;
-  for (int c = lane; c < C; c += 64) part = part + ocr_expf(src[c] - mx);
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) part = part + __shfl_xor(part, off);
-  // NOTE: the xor butterfly gives lane 0 exactly the halving tree p[l] + p[l+off]; other lanes may
-  // differ in the last bit (different association), so broadcast lane 0's value.
-  const float sum = __shfl(part, 0);
-  float best = -1.0f;
+  const int G = (C + 127) >> 7;
+  for (int ch = lane; ch < 2 * G; ch += 64) {
+    const int g = ch >> 1, h = ch & 1, c0 = g << 7;
+    float mx = -INFINITY;
+    for (int c = c0; c < min(c0 + 128, C); ++c) mx = fmaxf(mx, src[c]);
+    float part = 0.f;
+    for (int c = c0; c < min(c0 + 128, C); ++c)
+      if (((c >> 2) & 1) == h) part = part + ocr_expf(src[c] - mx);
+    s_m[wv][g] = mx;  // both chains of a group write the same value
+    s_s[wv][ch] = part;
+  }
+  __threadfence_block();
+  __builtin_amdgcn_wave_barrier();
+  float M = -INFINITY;
+  for (int g = 0; g < G; ++g) M = fmaxf(M, s_m[wv][g]);
+  float S = 0.f;
+  for (int g = 0; g < G; ++g) {
+    const float sg = s_s[wv][2 * g] + s_s[wv][2 * g + 1];
+    const float t = sg * ocr_expf(s_m[wv][g] - M);
+    S = S + t;
+  }
+  float best = -INFINITY;
   int bi = 0x7fffffff;
   for (int c = lane; c < C; c += 64) {
-    const float e = ocr_expf(src[c] - mx);
-    const float pr = e / sum;
-    if (probs) probs[r * C + c] = pr;
-    if (pr > best) { best = pr; bi = c; }
+    const float x = src[c];
+    if (probs) probs[r * C + c] = ocr_expf(x - M) / S;
+    if (x > best) { best = x; bi = c; }
   }
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) {
@@ -1084,12 +1139,39 @@ __global__ void __launch_bounds__(256) softmax_argmax_kernel(const float* __rest
   }
   if (lane == 0) {
     if (amax) amax[r] = bi;
-    if (pmax) pmax[r] = best;
+    if (pmax) pmax[r] = ocr_expf(best - M) / S;
   }
 }
 void launch_softmax_argmax(const float* logits, float* probs, int* amax, float* pmax, long rows, int C, hipStream_t s) {
   hipLaunchKernelGGL(softmax_argmax_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, logits, probs, amax, pmax,
                      rows, C);
+}
+
+// Fused head, second half: one thread per row folds the per-group partials in ascending group order.
+__global__ void __launch_bounds__(256) head_combine_kernel(const float* __restrict__ hmax, const float* __restrict__ hsum,
+                                                           const int* __restrict__ hidx, long rows, int G,
+                                                           int* __restrict__ amax, float* __restrict__ pmax) {
+  const long r = (long)blockIdx.x * 256 + threadIdx.x;
+  if (r >= rows) return;
+  const float* m = hmax + r * G;
+  const float* sg = hsum + r * G;
+  const int* ix = hidx + r * G;
+  float M = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int g = 0; g < G; ++g)
+    if (m[g] > M) { M = m[g]; bi = ix[g]; }  // ascending groups: the first maximum wins
+  float S = 0.f;
+  for (int g = 0; g < G; ++g) {
+    const float t = sg[g] * ocr_expf(m[g] - M);
+    S = S + t;
+  }
+  if (amax) amax[r] = bi;
+  if (pmax) pmax[r] = ocr_expf(M - M) / S;
+}
+void launch_head_combine(const float* hmax, const float* hsum, const int* hidx, long rows, int groups, int* amax, float* pmax,
+                         hipStream_t s) {
+  hipLaunchKernelGGL(head_combine_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, hmax, hsum, hidx, rows, groups,
+                     amax, pmax);
 }
 
 // =====================================================================================

@@ -109,6 +109,10 @@ class Net {
   size_t arena_cap_ = 0;
   float* gap_part_ = nullptr;
   size_t gap_part_cap_ = 0;
+  float* head_part_ = nullptr;  // fused softmax head: [rows][groups] max | sum | idx
+  size_t head_part_cap_ = 0;
+  long fused_head_rows_ = -1;  // rows of the linear that was bound in OUT_HEAD mode (-1: none)
+  int fused_head_groups_ = 0;
   int bound_n_ = -1, bound_h_ = -1, bound_w_ = -1;
   const float* bound_x_ = nullptr;
   int out_tid_ = -1;

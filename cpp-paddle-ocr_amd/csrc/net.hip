@@ -128,6 +128,7 @@ Net::~Net() {
   for (auto& kv : dev_) (void)hipFree(kv.second);
   if (arena_) (void)hipFree(arena_);
   if (gap_part_) (void)hipFree(gap_part_);
+  if (head_part_) (void)hipFree(head_part_);
   for (auto e : ev_pool_) (void)hipEventDestroy(e);
   for (auto& p : ev_pending_) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
 }
@@ -351,6 +352,7 @@ bool Net::build_epilogue(const PlanOp& op, Epilogue& ep, bool conv_path, std::st
 
 // ------------------------------------------------------------------ shape binding
 bool Net::bind(int N, int H, int W, std::string& err) {
+  fused_head_rows_ = -1;
   // 1. shapes
   auto& T = tensors_;
   auto setdims = [&](int t, int n, int h, int w, int c) {
@@ -514,6 +516,29 @@ bool Net::bind(int N, int H, int W, std::string& err) {
           const int tiles = (a.ColsStore + 31) / 32;
           const int nt = conv_nt_for(tiles);
           a.NTtot = (tiles + nt - 1) / nt * nt;
+          // linear -> softmax with only (arg max, max prob) wanted: the softmax is folded into the linear's
+          // epilogue (no logits tensor) and a per-row combine; canonical groups are 128 columns wide
+          const bool fuse_head = op.kind == PlanOp::LINEAR && o.plain && oi + 1 < nops && plan_.ops[oi + 1].kind == PlanOp::SOFTMAX &&
+                                 plan_.ops[oi + 1].in == op.out && (head_amax_ || head_pmax_) && !head_probs_ && !keep_all_ &&
+                                 (tiles <= 4 || nt == 4);
+          if (fuse_head) {
+            a.out_mode = OUT_HEAD;
+            const long hrows = (long)in.n * in.h * in.w;
+            const int groups = a.NTtot / nt;
+            const size_t need = (size_t)hrows * groups * 3;
+            if (need > head_part_cap_) {
+              if (head_part_) (void)hipFree(head_part_);
+              head_part_ = nullptr;
+              head_part_cap_ = 0;
+              HIP_OK(hipMalloc(&head_part_, need * sizeof(float)));
+              head_part_cap_ = need;
+            }
+            a.head_max = head_part_;
+            a.head_sum = head_part_ + (size_t)hrows * groups;
+            a.head_idx = (int*)(head_part_ + (size_t)hrows * groups * 2);
+            fused_head_rows_ = hrows;
+            fused_head_groups_ = groups;
+          }
           a.zeros = dev_vec("zeros");
           a.M = (long)in.n * a.OH * a.OW;
           if (op.kind == PlanOp::LINEAR) a.M = (long)in.n * in.h * in.w;
@@ -523,7 +548,8 @@ bool Net::bind(int N, int H, int W, std::string& err) {
           L.name = nm;
           const double cols = op.kind == PlanOp::DECONV ? 4.0 * op.cout : op.cout;
           L.flops = 2.0 * a.M * taps * op.cin * cols;
-          L.bytes = 4.0 * ((double)a.M * op.cin + (double)a.M * cols + (double)taps * op.cin * cols);
+          L.bytes = 4.0 * ((double)a.M * op.cin + (a.out_mode == OUT_HEAD ? 3.0 * a.M * (a.NTtot / nt) : (double)a.M * cols) +
+                           (double)taps * op.cin * cols);
           // OCR_CONV_IMPL=direct|lds overrides the choice (A/B measurements); results are identical
           static const char* impl = getenv("OCR_CONV_IMPL");
           // measured (gpurun_out r1g): LDS staging wins for multi-tap convs (3x3 96->24: 58 vs 51 TFLOP/s),
@@ -645,10 +671,20 @@ bool Net::bind(int N, int H, int W, std::string& err) {
         L.name = nm;
         L.bytes = 4.0 * rows * C * 3;
         // `optr` (the plan's softmax tensor) is only filled when no external sink is set or probs are requested
-        L.fn = [this, ip, optr, rows, C](hipStream_t s) {
-          float* probs = (this->head_amax_ || this->head_pmax_) ? this->head_probs_ : optr;
-          launch_softmax_argmax(ip, probs, this->head_amax_, this->head_pmax_, rows, C, s);
-        };
+        if (fused_head_rows_ == rows && oi > 0 && plan_.ops[oi - 1].kind == PlanOp::LINEAR && plan_.ops[oi - 1].out == op.in) {
+          // second half of the fused head (the linear before this op ran in OUT_HEAD mode)
+          const float* hm = head_part_;
+          const float* hs = head_part_ + (size_t)rows * fused_head_groups_;
+          const int* hi = (const int*)(head_part_ + (size_t)rows * fused_head_groups_ * 2);
+          const int G = fused_head_groups_;
+          L.bytes = 12.0 * rows * G;
+          L.fn = [this, hm, hs, hi, rows, G](hipStream_t s) { launch_head_combine(hm, hs, hi, rows, G, this->head_amax_, this->head_pmax_, s); };
+        } else {
+          L.fn = [this, ip, optr, rows, C](hipStream_t s) {
+            float* probs = (this->head_amax_ || this->head_pmax_) ? this->head_probs_ : optr;
+            launch_softmax_argmax(ip, probs, this->head_amax_, this->head_pmax_, rows, C, s);
+          };
+        }
       } break;
       default: break;
     }

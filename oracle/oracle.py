@@ -70,6 +70,7 @@ def load_weights(net, model_root=None):
 
 class OracleNet:
     def __init__(self, net, weights=None):
+        self.net = net
         L = lib()
         self.h = L.oracle_net_create(plan_text(net).encode())
         assert self.h, "plan parse failed"
@@ -87,6 +88,16 @@ class OracleNet:
         if rc:
             raise RuntimeError(lib().oracle_net_error(self.h).decode())
         return self.tensor(-1)
+
+    def logits(self):
+        """Input of the final softmax op (arg max is taken over the logits: DESIGN.md section 4)."""
+        if not hasattr(self, "_logits_tid"):
+            tid = None
+            for line in plan_text(self.net).splitlines():
+                if line.startswith("softmax "):
+                    tid = int([f for f in line.split() if f.startswith("i=")][0][2:])
+            self._logits_tid = tid
+        return self.tensor(self._logits_tid)
 
     def tensor(self, tid):
         dims = (C.c_int * 4)()

@@ -16,7 +16,8 @@
 //   * a*x+b stages are mul then add (two roundings); division and sqrt are IEEE;
 //   * exp is ocr_expf below (Cephes-style, fmaf Horner), never libm;
 //   * reductions: GAP = row-sequential then column-sequential; LN/attention sequential;
-//     final softmax sum = 64 strided partials + halving tree (wave64 order).
+//     row softmax: groups of 128 columns, two interleaved chains per group, groups folded in order
+//     with exp(m_g - M) rescaling (see the softmax op below).
 // Layout here is plain NHWC; the device uses an octet-interleaved channel order, which does not
 // change any of the above.
 #include <cmath>
@@ -525,15 +526,28 @@ bool run(Net& net, const float* x_nhwc, int N, int H, int W) {
       for (long r = 0; r < (long)rows; ++r) {
         const float* src = in.d.data() + (size_t)r * C;
         float* dst = out.d.data() + (size_t)r * C;
-        float m = -INFINITY;
-        for (int c = 0; c < C; ++c) m = fmaxf(m, src[c]);
-        float part[64];
-        for (int l = 0; l < 64; ++l) part[l] = 0.f;
-        for (int c = 0; c < C; ++c) { dst[c] = ocr_expf(src[c] - m); part[c & 63] = part[c & 63] + dst[c]; }
-        for (int off = 32; off >= 1; off >>= 1)
-          for (int l = 0; l < off; ++l) part[l] = part[l] + part[l + off];
-        float sum = part[0];
-        for (int c = 0; c < C; ++c) dst[c] = dst[c] / sum;
+        // canonical order: groups of 128 columns; per group its max m_g and
+        // s_g = chain0 + chain1, chain h = columns with ((c >> 2) & 1) == h in ascending order of
+        // exp(x_c - m_g); row: M = max m_g, S = sum over ascending g of s_g * exp(m_g - M); p = exp(x - M) / S
+        const int G = (C + 127) / 128;
+        std::vector<float> gm(G), gs(G);
+        for (int g = 0; g < G; ++g) {
+          const int c0 = g * 128, c1 = std::min(c0 + 128, C);
+          float m = -INFINITY;
+          for (int c = c0; c < c1; ++c) m = fmaxf(m, src[c]);
+          float ch[2] = {0.f, 0.f};
+          for (int c = c0; c < c1; ++c) ch[(c >> 2) & 1] = ch[(c >> 2) & 1] + ocr_expf(src[c] - m);
+          gm[g] = m;
+          gs[g] = ch[0] + ch[1];
+        }
+        float M = -INFINITY;
+        for (int g = 0; g < G; ++g) M = fmaxf(M, gm[g]);
+        float S = 0.f;
+        for (int g = 0; g < G; ++g) {
+          const float t = gs[g] * ocr_expf(gm[g] - M);
+          S = S + t;
+        }
+        for (int c = 0; c < C; ++c) dst[c] = ocr_expf(src[c] - M) / S;
       }
     } else {
       net.err = "unknown plan op " + k;

@@ -61,9 +61,10 @@ class Pipeline:
             end = min(n, beg + self.cls_batch_num)
             x = np.stack([O.cls_preprocess(crops[i]) for i in range(beg, end)])
             p = self.cls.run(x).reshape(end - beg, 2)
+            lg = self.cls.logits().reshape(end - beg, 2)
             for j in range(end - beg):
-                labels[beg + j] = int(np.argmax(p[j]))  # first maximum, like std::max_element
-                scores[beg + j] = p[j].max()
+                labels[beg + j] = int(np.argmax(lg[j]))  # first maximum (of the logits), like std::max_element
+                scores[beg + j] = p[j][labels[beg + j]]
                 probs[beg + j] = p[j]
         self.taps["cls_probs"] = probs
         return labels, scores
@@ -97,10 +98,13 @@ class Pipeline:
                     xi = pad
                 batch.append(xi)
             p = self.rec.run(np.stack(batch))  # [N,1,T,6625]
+            lg = self.rec.logits()
             for m in range(end - beg):
                 pm = p[m, 0]
-                amax = pm.argmax(axis=1).astype(np.int32)
-                pmax = pm.max(axis=1).astype(np.float32)
+                # arg max = first maximum of the logits (exp is not strictly monotonic after rounding);
+                # its probability is the softmax value at that index
+                amax = lg[m, 0].argmax(axis=1).astype(np.int32)
+                pmax = pm[np.arange(pm.shape[0]), amax].astype(np.float32)
                 ids, sc = O.ctc_decode(amax, pmax)
                 li = indices[beg + m]
                 steps[li] = (amax, pmax)

@@ -126,7 +126,7 @@ def main():
 
     for _ in range(args.warmup):
         pipe.run_device(d_imgs, H, W, BATCH, d_probs, collect=False)
-    survey = None
+    survey = primary = None
     if not args.no_kernel_timing:
         # One untimed survey pass with HIP events around EVERY network launch (on the launch stream) finds the
         # dominant kernel and gives the per-kernel table; in the timed region only that kernel carries events
@@ -134,7 +134,14 @@ def main():
         pipe.timing(True)
         pipe.run_device(d_imgs, H, W, BATCH, d_probs, collect=False)
         survey = pipe.timing_report()
-        dominant = max(survey.items(), key=lambda kv: kv[1]["ms"])[0]
+        # The odd-width rec launches (16-32 lines) share the GPU with the big one on a second stream: their
+        # event spans are mostly time spent waiting for free CUs, not kernel time.  The dominant kernel is
+        # looked for among the det launches and the rec launch with the most lines.
+        def lines_of(name):
+            return int(name.split("@")[1].split("x")[0])
+        rec_max = max(lines_of(k) for k in survey if k.startswith("rec."))
+        primary = {k: v for k, v in survey.items() if not k.startswith("rec.") or lines_of(k) == rec_max}
+        dominant = max(primary.items(), key=lambda kv: kv[1]["ms"])[0]
         pipe.timing(True, only=dominant)   # also resets the accumulated timings
     step_ms = []
     nwords = 0
@@ -197,10 +204,10 @@ def main():
                                    "algorithmic_bytes_per_launch": r["bytes"] / max(1, r["count"]),
                                    "hbm_GBps_algorithmic": r["bytes"] / (r["ms"] * 1e-3) / 1e9 if r["ms"] > 0 else 0.0}
             if survey:   # per-kernel shares from the untimed survey pass (one step, every launch timed)
-                tot = sum(v["ms"] for v in survey.values())
+                tot = sum(v["ms"] for v in primary.values())
                 out["kernel_time_share_top5"] = {k: round(v["ms"] / tot, 4) for k, v in
-                                                 sorted(survey.items(), key=lambda kv: -kv[1]["ms"])[:5]}
-                out["network_kernel_ms_per_step"] = tot
+                                                 sorted(primary.items(), key=lambda kv: -kv[1]["ms"])[:5]}
+                out["network_kernel_ms_per_step"] = tot   # det + the big rec launch (see `primary` above)
                 if os.environ.get("OCR_BENCH_KERNEL_TABLE"):
                     with open(os.environ["OCR_BENCH_KERNEL_TABLE"], "w") as f:
                         for k, v in sorted(survey.items(), key=lambda kv: -kv[1]["ms"]):

@@ -1187,22 +1187,37 @@ __global__ void __launch_bounds__(256) det_tail_kernel(const DetTailArgs a) {
   decompose(m, a.H * a.W, a.W, n, y, x);
   const float* src = a.in + m * a.Cs;
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int c = 0; c < a.C; ++c) {
-    const float v = src[c8i_phys(c)];
+  // The pixel's channels arrive as two 16-byte loads per octet (C8I: evens, then odds) and are consumed in
+  // ascending logical order c = 8o, 8o+1, ... - the same fma chain as a channel-by-channel walk.
+  for (int o8 = 0; o8 < a.Cs; o8 += 8) {
+    const float4 ev = *(const float4*)(src + o8), od = *(const float4*)(src + o8 + 4);
+    const float v[8] = {ev.x, od.x, ev.y, od.y, ev.z, od.z, ev.w, od.w};
 #pragma unroll
-    for (int q = 0; q < 4; ++q) acc[q] = fmaf(v, a.w[c * 4 + q], acc[q]);
+    for (int j = 0; j < 8; ++j) {
+      const int c = o8 + j;
+      if (c < a.C) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = fmaf(v[j], a.w[c * 4 + q], acc[q]);
+      }
+    }
   }
+  float pr[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    float v = acc[q] + a.bias;
+    const float v = acc[q] + a.bias;
     const float e = ocr_expf(-v);
     const float d = 1.0f + e;
-    v = 1.0f / d;
-    const long o = ((long)n * 2 * a.H + 2 * y + (q >> 1)) * (2 * a.W) + 2 * x + (q & 1);
-    a.prob[o] = v;
+    pr[q] = 1.0f / d;
+  }
+  // rows 2y and 2y+1, columns 2x and 2x+1: one 8-byte store per row (2-byte for the bitmap)
+#pragma unroll
+  for (int dy = 0; dy < 2; ++dy) {
+    const long o = ((long)n * 2 * a.H + 2 * y + dy) * (2 * a.W) + 2 * x;
+    *(float2*)(a.prob + o) = make_float2(pr[2 * dy], pr[2 * dy + 1]);
     if (a.bitmap) {
-      const int u8 = (int)(v * 255.0f);  // (unsigned char)(p*255): truncation; p in [0,1]
-      a.bitmap[o] = u8 > a.ithresh ? 1 : 0;
+      // (unsigned char)(p*255): truncation; p in [0,1]
+      const int b0 = (int)(pr[2 * dy] * 255.0f) > a.ithresh ? 1 : 0, b1 = (int)(pr[2 * dy + 1] * 255.0f) > a.ithresh ? 1 : 0;
+      *(unsigned short*)(a.bitmap + o) = (unsigned short)(b0 | (b1 << 8));
     }
   }
 }

@@ -918,7 +918,7 @@ __device__ float polygon_score_wave(const unsigned long long* __restrict__ pts, 
 // ---- ClipperOffset (jtRound, etClosedPolygon) + union clean-up, lane 0 only
 struct IPt { long long X, Y; };
 __device__ __forceinline__ long long clip_round(double v) { return v < 0 ? (long long)(v - 0.5) : (long long)(v + 0.5); }
-#define UNCLIP_CAP 512
+#define UNCLIP_CAP 256
 // dest: scratch of UNCLIP_CAP; returns point count (0 when Execute yields no path, -1 on overflow)
 __device__ int clipper_offset_round(const IPt in[4], double delta, IPt* dest) {
   IPt c[4];
@@ -1035,8 +1035,8 @@ struct FKeyAcc {  // float-valued integer points sorted through the same key pac
   __device__ int orig(int i) const { return (int)key_i(k[i]); }
 };
 
-#define HULL_CAP 1024
-#define SORT_LDS_CAP 4096
+#define HULL_CAP 512
+#define SORT_LDS_CAP 512
 
 // bitonic sort of n2 (power of two) keys by the whole wave; `a` may be LDS or global
 __device__ void bitonic_sort_wave(unsigned long long* a, int n2, int lane, bool in_lds) {

@@ -37,5 +37,6 @@ void launch_bitmap(const float* prob, uint8_t* bm, long total, int ithresh, hipS
 void launch_dilate2(const uint8_t* src, uint8_t* dst, int N, int H, int W, hipStream_t s);
 // out_boxes [N][cap][8], out_n [N]
 void launch_post(const PostArgs& a, int N, int* out_boxes, int cap, int* out_n, hipStream_t s);
+void launch_post_large(const PostArgs& a, int N, int* out_boxes, int cap, int* out_n, hipStream_t s);
 
 }  // namespace ocr

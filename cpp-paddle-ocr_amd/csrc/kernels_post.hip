@@ -918,9 +918,8 @@ __device__ float polygon_score_wave(const unsigned long long* __restrict__ pts, 
 // ---- ClipperOffset (jtRound, etClosedPolygon) + union clean-up, lane 0 only
 struct IPt { long long X, Y; };
 __device__ __forceinline__ long long clip_round(double v) { return v < 0 ? (long long)(v - 0.5) : (long long)(v + 0.5); }
-#define UNCLIP_CAP 256
-// dest: scratch of UNCLIP_CAP; returns point count (0 when Execute yields no path, -1 on overflow)
-__device__ int clipper_offset_round(const IPt in[4], double delta, IPt* dest) {
+// dest: scratch of `cap` points; returns point count (0 when Execute yields no path, -1 on overflow)
+__device__ int clipper_offset_round(const IPt in[4], double delta, IPt* dest, int cap) {
   IPt c[4];
   int highI = 3;
   while (highI > 0 && in[0].X == in[highI].X && in[0].Y == in[highI].Y) highI--;
@@ -965,14 +964,14 @@ __device__ int clipper_offset_round(const IPt in[4], double delta, IPt* dest) {
       if (fabs(sinA * delta) < 1.0) {
         const double cosA = nX[k] * nX[j] + nY[j] * nY[k];
         if (cosA > 0) {
-          if (nd >= UNCLIP_CAP) return -1;
+          if (nd >= cap) return -1;
           dest[nd++] = {clip_round(c[j].X + nX[k] * delta), clip_round(c[j].Y + nY[k] * delta)};
           continue;
         }
       } else if (sinA > 1.0) sinA = 1.0;
       else if (sinA < -1.0) sinA = -1.0;
       if (sinA * delta < 0) {
-        if (nd + 3 > UNCLIP_CAP) return -1;
+        if (nd + 3 > cap) return -1;
         dest[nd++] = {clip_round(c[j].X + nX[k] * delta), clip_round(c[j].Y + nY[k] * delta)};
         dest[nd++] = c[j];
         dest[nd++] = {clip_round(c[j].X + nX[j] * delta), clip_round(c[j].Y + nY[j] * delta)};
@@ -980,7 +979,7 @@ __device__ int clipper_offset_round(const IPt in[4], double delta, IPt* dest) {
         const double a = atan2(sinA, nX[k] * nX[j] + nY[k] * nY[j]);
         long long r = clip_round(steps_per_rad * fabs(a));
         const int st = (int)r > 1 ? (int)r : 1;
-        if (nd + st + 1 > UNCLIP_CAP) return -1;
+        if (nd + st + 1 > cap) return -1;
         double X = nX[k], Y = nY[k], X2;
         for (int i = 0; i < st; ++i) {
           dest[nd++] = {clip_round(c[j].X + X * delta), clip_round(c[j].Y + Y * delta)};
@@ -1035,8 +1034,6 @@ struct FKeyAcc {  // float-valued integer points sorted through the same key pac
   __device__ int orig(int i) const { return (int)key_i(k[i]); }
 };
 
-#define HULL_CAP 512
-#define SORT_LDS_CAP 512
 
 // bitonic sort of n2 (power of two) keys by the whole wave; `a` may be LDS or global
 __device__ void bitonic_sort_wave(unsigned long long* a, int n2, int lane, bool in_lds) {
@@ -1067,7 +1064,12 @@ __device__ void bitonic_sort_wave(unsigned long long* a, int n2, int lane, bool 
   }
 }
 
-// one wave (workgroup of 64) per border
+// one wave (workgroup of 64) per border.  The LDS working set decides how many borders a CU holds at once
+// (the work per border is a chain of dependent single-lane steps, so that is the throughput):
+// <512, 512, 256> is 23 KB - six borders per CU - and covers every border of a 960x960 map short of a
+// convex lattice polygon with more than 512 corners; launch_post_large re-runs the stage with
+// <4096, 1024, 512> (70 KB) when a border overflowed one of them (POST_ERR_HULL / POST_ERR_UNCLIP).
+template <int SORT_LDS_CAP, int HULL_CAP, int UNCLIP_CAP, bool RETRY>
 __global__ void __launch_bounds__(64) border_box_kernel(const PostArgs a) {
   __shared__ unsigned long long s_keys[SORT_LDS_CAP];
   __shared__ P2f s_hull[HULL_CAP];
@@ -1127,7 +1129,7 @@ __global__ void __launch_bounds__(64) border_box_kernel(const PostArgs a) {
   if (a.slow) {
     // PolygonScoreAcc needs the vertices in contour order: the unsorted keys are still in the pool when
     // the sort ran in LDS; after an in-place (global) sort restore the order by sorting on the index
-    if (!in_lds) {
+    if (!in_lds || RETRY) {  // (a first pass that sorted in place may have stopped before restoring the order)
       for (int i = lane; i < n2; i += 64) { const unsigned long long k = GLD(&gkeys[i]); GST(&gkeys[i], (k << 32) | (k >> 32)); }
       __threadfence_block();
       __syncthreads();
@@ -1155,7 +1157,7 @@ __global__ void __launch_bounds__(64) border_box_kernel(const PostArgs a) {
   const float distance = area * a.unclip_ratio / dist;
   IPt q[4];
   for (int i = 0; i < 4; ++i) q[i] = {(long long)(int)arr[i].x, (long long)(int)arr[i].y};
-  const int un = clipper_offset_round(q, (double)distance, s_unclip);
+  const int un = clipper_offset_round(q, (double)distance, s_unclip, UNCLIP_CAP);
   if (un < 0) { atomicOr(a.status, POST_ERR_UNCLIP); return; }
   RRect pts;
   if (un == 0) {
@@ -1245,7 +1247,12 @@ void launch_post(const PostArgs& a, int N, int* out_boxes, int cap, int* out_n, 
   hipLaunchKernelGGL(trace_offsets_kernel, dim3(N), dim3(64), 0, s, a.max_cand, a.ncont, a.npts, a.poff, a.pool_cap, a.status);
   hipLaunchKernelGGL(trace_store_kernel, gl, dim3(64), 0, s, a.bitmap, a.H, a.W, a.max_cand, a.ncont, a.starts, a.npts, a.poff,
                      a.pool, a.pool_cap);
-  hipLaunchKernelGGL(border_box_kernel, dim3(a.max_cand, N), dim3(64), 0, s, a);
+  hipLaunchKernelGGL((border_box_kernel<512, 512, 256, false>), dim3(a.max_cand, N), dim3(64), 0, s, a);
+  hipLaunchKernelGGL(boxes_compact_kernel, dim3(N), dim3(64), 0, s, a, out_boxes, cap, out_n);
+}
+// second try of the per-border stage with the large LDS working set (the traced borders are still in the pool)
+void launch_post_large(const PostArgs& a, int N, int* out_boxes, int cap, int* out_n, hipStream_t s) {
+  hipLaunchKernelGGL((border_box_kernel<4096, 1024, 512, true>), dim3(a.max_cand, N), dim3(64), 0, s, a);
   hipLaunchKernelGGL(boxes_compact_kernel, dim3(N), dim3(64), 0, s, a, out_boxes, cap, out_n);
 }
 

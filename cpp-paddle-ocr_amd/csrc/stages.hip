@@ -165,6 +165,16 @@ int DetStage::run_post(int count, int H, int W, const float* prob, float ratio_h
   ST_HIP(hipMemcpyAsync(&status, status_.p, sizeof(int), hipMemcpyDeviceToHost, stream_));
   timer_.mark(3, stream_);
   ST_HIP(hipStreamSynchronize(stream_));
+  if (status && !(status & ~(POST_ERR_HULL | POST_ERR_UNCLIP))) {
+    // a border outgrew the small LDS working set of the per-border stage: run that stage again with the large one
+    ST_HIP(hipMemsetAsync(status_.p, 0, sizeof(int), stream_));
+    if (a.slow) ST_HIP(hipMemsetAsync(mask_top_.p, 0, count * sizeof(unsigned), stream_));
+    launch_post_large(a, count, out_boxes_.p, cap, out_n_.p, stream_);
+    ST_HIP(hipMemcpyAsync(n, out_n_.p, count * sizeof(int), hipMemcpyDeviceToHost, stream_));
+    ST_HIP(hipMemcpyAsync(boxes, out_boxes_.p, (size_t)count * cap * 8 * sizeof(int), hipMemcpyDeviceToHost, stream_));
+    ST_HIP(hipMemcpyAsync(&status, status_.p, sizeof(int), hipMemcpyDeviceToHost, stream_));
+    ST_HIP(hipStreamSynchronize(stream_));
+  }
   if (status) {
     err = "det post-processing scratch exhausted (status " + std::to_string(status) + ")";
     return OCR_ERR_CAPACITY;

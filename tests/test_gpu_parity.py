@@ -133,6 +133,19 @@ def test_det_post_slow_score_mode(pkg, built, dilate):
     fast.close()
 
 
+def test_det_post_large_working_set_fallback(pkg, built):
+    """A border whose unclip polygon outgrows the small per-border LDS working set (256 points) is redone
+    with the large one: same boxes as the oracle, no error."""
+    import oracle as O
+    f = np.zeros((960, 960), np.float32)
+    f[60:900, 80:880] = 0.9                      # one huge box: delta = area * ratio / perimeter ~ 4100 px
+    f[20:40, 20:300] = 0.9                       # and an ordinary one
+    det = pkg.Det(limit_side_len=960, thresh=0.3, box_thresh=0.5, unclip_ratio=20.0)
+    bo, bg = O.det_post(f, 0.3, 0.5, 20.0, 960, 960), det.post(f, 960, 960)
+    assert len(bo) == len(bg) == 2 and all(np.array_equal(a, b) for a, b in zip(bo, bg))
+    det.close()
+
+
 def test_det_batch_full_size_and_determinism(pkg, built):
     """cfg2 size (960x960) with the full network on synthetic weights: batch == singles == oracle."""
     from pipeline import Pipeline, DetCfg

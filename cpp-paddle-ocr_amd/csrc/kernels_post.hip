@@ -240,13 +240,13 @@ __device__ __forceinline__ unsigned nbr_mask(const uint8_t* __restrict__ bm, int
 }
 
 // follows one border; emits CHAIN_APPROX_SIMPLE vertices (if keys != null) and returns their number
-__device__ int trace_border(const uint8_t* __restrict__ bm, int H, int W, int ox, int oy, bool is_hole,
-                            unsigned long long* keys) {
+template <class NB>
+__device__ int trace_border_t(NB nb, int H, int W, int ox, int oy, bool is_hole, unsigned long long* keys) {
   int count = 0;
   int s_end, s;
   s_end = s = is_hole ? 0 : 4;
   // first neighbour clockwise from s_end: s = s_end-1, s_end-2, ... (mod 8), at most 8 probes
-  const unsigned m0 = nbr_mask(bm, H, W, ox, oy);
+  const unsigned m0 = nb(ox, oy);
   int found = -1;
 #pragma unroll
   for (int k = 1; k <= 8; ++k) {
@@ -270,7 +270,7 @@ __device__ int trace_border(const uint8_t* __restrict__ bm, int H, int W, int ox
   // a closed border of a W x H bitmap has at most 4*W*H steps; the bound keeps every lane finite
   const long max_steps = 4L * W * H + 16;
   for (long step = 0; step < max_steps; ++step) {
-    const unsigned m = nbr_mask(bm, H, W, cx, cy);
+    const unsigned m = nb(cx, cy);
     // first set direction counter-clockwise after s: s+1, s+2, ... (the previous pixel guarantees a hit)
     const unsigned rot = ((m | (m << 8)) >> ((s + 1) & 7)) & 0xffu;
     const int j = rot ? __ffs(rot) - 1 : 7;
@@ -289,6 +289,29 @@ __device__ int trace_border(const uint8_t* __restrict__ bm, int H, int W, int ox
   }
   return count;
 }
+
+__device__ int trace_border(const uint8_t* __restrict__ bm, int H, int W, int ox, int oy, bool is_hole,
+                            unsigned long long* keys) {
+  return trace_border_t([&](int cx, int cy) { return nbr_mask(bm, H, W, cx, cy); }, H, W, ox, oy, is_hole, keys);
+}
+
+// The bitmap of one image as bits in LDS, with a one-pixel zero frame: bit (x+1) of row (y+1).  A step of the
+// border walk then costs a few LDS reads (~100 clocks) instead of a global round trip (~1 us).
+struct LdsBits {
+  const unsigned* bits;
+  int stride;  // words per row
+  __device__ __forceinline__ unsigned row3(int Y, int b) const {  // bits b, b+1, b+2 of row Y
+    const unsigned* r = bits + Y * stride + (b >> 5);
+    const unsigned long long v = ((unsigned long long)r[1] << 32) | r[0];
+    return (unsigned)(v >> (b & 31)) & 7u;
+  }
+  __device__ __forceinline__ unsigned operator()(int cx, int cy) const {
+    const unsigned up = row3(cy, cx), mid = row3(cy + 1, cx), dn = row3(cy + 2, cx);  // x-1..x+1 -> shifted bits cx..cx+2
+    return ((mid >> 2) & 1u) | (((up >> 2) & 1u) << 1) | (((up >> 1) & 1u) << 2) | ((up & 1u) << 3) | ((mid & 1u) << 4) |
+           ((dn & 1u) << 5) | (((dn >> 1) & 1u) << 6) | (((dn >> 2) & 1u) << 7);
+  }
+};
+__host__ __device__ inline int lds_bits_stride(int W) { return (W + 2 + 31) / 32 + 1; }
 
 __device__ __forceinline__ void contour_origin(const uint8_t* bm, long base, int start, int W, int& ox, int& oy, bool& hole) {
   hole = bm[base + start] == 0;
@@ -350,6 +373,67 @@ __global__ void __launch_bounds__(64) trace_store_kernel(const uint8_t* __restri
   trace_border(bm + base, H, W, ox, oy, hole, keys);
   const int p2 = pow2_ceil(sz);
   for (int i = sz; i < p2; ++i) keys[i] = ~0ull;
+}
+
+// Both passes with the image's bitmap packed into LDS (one workgroup per image; maps up to ~1.2 Mpixel fit
+// the 160 KB): STORE = false counts the vertices per border, STORE = true writes the keys.
+template <bool STORE>
+__global__ void __launch_bounds__(256) trace_lds_kernel(const uint8_t* __restrict__ bm, int H, int W, int max_cand,
+                                                        const int* __restrict__ ncont, const int* __restrict__ starts,
+                                                        int* __restrict__ npts, const int* __restrict__ poff,
+                                                        unsigned long long* __restrict__ pool, int pool_cap) {
+  extern __shared__ unsigned s_bits[];
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const long base = (long)n * H * W;
+  const int stride = lds_bits_stride(W);
+  const int nc = ncont[n];
+  if (nc == 0) return;
+  for (int i = tid; i < (H + 2) * stride; i += 256) {
+    const int Y = i / stride, w = i - Y * stride;
+    unsigned word = 0;
+    if (Y >= 1 && Y <= H) {
+      const uint8_t* row = bm + base + (long)(Y - 1) * W;
+      // shifted bit position b = x + 1  ->  word w holds x = 32w - 1 .. 32w + 30:
+      // bit 0 from the byte before the 32-byte group, bits 1..31 from the group's first 31 bytes
+      const int x0 = 32 * w;
+      if (x0 - 1 >= 0 && x0 - 1 < W && row[x0 - 1]) word |= 1u;
+      if ((W & 15) == 0 && x0 + 32 <= W) {  // two 16-byte loads (rows are 16-byte aligned when W % 16 == 0)
+        const uint4 q0 = *(const uint4*)(row + x0), q1 = *(const uint4*)(row + x0 + 16);
+        const unsigned v[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int b = 4 * k + j + 1;
+            if (b < 32 && ((v[k] >> (8 * j)) & 0xffu)) word |= 1u << b;
+          }
+      } else {
+        for (int b = 1; b < 32; ++b) {
+          const int x = x0 + b - 1;
+          if (x < W && row[x]) word |= 1u << b;
+        }
+      }
+    }
+    s_bits[i] = word;
+  }
+  __syncthreads();
+  const LdsBits nb{s_bits, stride};
+  for (int c = tid; c < nc; c += 256) {
+    const long ci = (long)n * max_cand + c;
+    int ox, oy;
+    bool hole;
+    contour_origin(bm, base, starts[ci], W, ox, oy, hole);
+    if (!STORE) {
+      npts[ci] = trace_border_t(nb, H, W, ox, oy, hole, nullptr);
+    } else {
+      const int sz = npts[ci];
+      if (sz <= 2 || poff[ci] < 0) continue;
+      unsigned long long* keys = pool + (long)n * pool_cap + poff[ci];
+      trace_border_t(nb, H, W, ox, oy, hole, keys);
+      const int p2 = pow2_ceil(sz);
+      for (int i = sz; i < p2; ++i) keys[i] = ~0ull;
+    }
+  }
 }
 
 // ------------------------------------------------------------------ 5. per-border geometry (one wave each)
@@ -1243,9 +1327,19 @@ void launch_post(const PostArgs& a, int N, int* out_boxes, int cap, int* out_n, 
   launch_ccl(a.bitmap, a.labels, a.touch, N, a.H, a.W, s);
   launch_starts(a.bitmap, a.labels, a.touch, N, a.H, a.W, a.max_cand, a.ncont_all, a.ncont, a.starts, a.chunk_cnt, s);
   const dim3 gl((a.max_cand + 63) / 64, N);
-  hipLaunchKernelGGL(trace_count_kernel, gl, dim3(64), 0, s, a.bitmap, a.H, a.W, a.max_cand, a.ncont, a.starts, a.npts);
+  const size_t lds = (size_t)(a.H + 2) * lds_bits_stride(a.W) * sizeof(unsigned);
+  bool in_lds = lds <= 150 * 1024;  // 960x960: 119 KB
+  if (in_lds && lds > 64 * 1024) {  // more than the default dynamic LDS limit: raise it once per process
+    static const bool raised =
+        hipFuncSetAttribute((const void*)trace_lds_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess &&
+        hipFuncSetAttribute((const void*)trace_lds_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess;
+    in_lds = raised;
+  }
+  if (in_lds) hipLaunchKernelGGL((trace_lds_kernel<false>), dim3(N), dim3(256), lds, s, a.bitmap, a.H, a.W, a.max_cand, a.ncont, a.starts, a.npts, a.poff, a.pool, a.pool_cap);
+  else hipLaunchKernelGGL(trace_count_kernel, gl, dim3(64), 0, s, a.bitmap, a.H, a.W, a.max_cand, a.ncont, a.starts, a.npts);
   hipLaunchKernelGGL(trace_offsets_kernel, dim3(N), dim3(64), 0, s, a.max_cand, a.ncont, a.npts, a.poff, a.pool_cap, a.status);
-  hipLaunchKernelGGL(trace_store_kernel, gl, dim3(64), 0, s, a.bitmap, a.H, a.W, a.max_cand, a.ncont, a.starts, a.npts, a.poff,
+  if (in_lds) hipLaunchKernelGGL((trace_lds_kernel<true>), dim3(N), dim3(256), lds, s, a.bitmap, a.H, a.W, a.max_cand, a.ncont, a.starts, a.npts, a.poff, a.pool, a.pool_cap);
+  else hipLaunchKernelGGL(trace_store_kernel, gl, dim3(64), 0, s, a.bitmap, a.H, a.W, a.max_cand, a.ncont, a.starts, a.npts, a.poff,
                      a.pool, a.pool_cap);
   hipLaunchKernelGGL((border_box_kernel<512, 512, 256, false>), dim3(a.max_cand, N), dim3(64), 0, s, a);
   hipLaunchKernelGGL(boxes_compact_kernel, dim3(N), dim3(64), 0, s, a, out_boxes, cap, out_n);

@@ -375,13 +375,14 @@ __global__ void __launch_bounds__(64) trace_store_kernel(const uint8_t* __restri
   for (int i = sz; i < p2; ++i) keys[i] = ~0ull;
 }
 
-// Both passes with the image's bitmap packed into LDS (one workgroup per image; maps up to ~1.2 Mpixel fit
-// the 160 KB): STORE = false counts the vertices per border, STORE = true writes the keys.
-template <bool STORE>
+// Border following with the image's bitmap packed into LDS (one workgroup per image; maps up to ~1.2 Mpixel
+// fit the 160 KB).  One launch does what trace_count / trace_offsets / trace_store do with the global bitmap:
+// count the vertices of every border, lay the borders out in the image's key pool, walk them again to store.
 __global__ void __launch_bounds__(256) trace_lds_kernel(const uint8_t* __restrict__ bm, int H, int W, int max_cand,
                                                         const int* __restrict__ ncont, const int* __restrict__ starts,
-                                                        int* __restrict__ npts, const int* __restrict__ poff,
-                                                        unsigned long long* __restrict__ pool, int pool_cap) {
+                                                        int* __restrict__ npts, int* __restrict__ poff,
+                                                        unsigned long long* __restrict__ pool, int pool_cap,
+                                                        int* __restrict__ status) {
   extern __shared__ unsigned s_bits[];
   const int n = blockIdx.x, tid = threadIdx.x;
   const long base = (long)n * H * W;
@@ -423,16 +424,33 @@ __global__ void __launch_bounds__(256) trace_lds_kernel(const uint8_t* __restric
     int ox, oy;
     bool hole;
     contour_origin(bm, base, starts[ci], W, ox, oy, hole);
-    if (!STORE) {
-      npts[ci] = trace_border_t(nb, H, W, ox, oy, hole, nullptr);
-    } else {
-      const int sz = npts[ci];
-      if (sz <= 2 || poff[ci] < 0) continue;
-      unsigned long long* keys = pool + (long)n * pool_cap + poff[ci];
-      trace_border_t(nb, H, W, ox, oy, hole, keys);
-      const int p2 = pow2_ceil(sz);
-      for (int i = sz; i < p2; ++i) keys[i] = ~0ull;
+    npts[ci] = trace_border_t(nb, H, W, ox, oy, hole, nullptr);
+  }
+  __threadfence_block();
+  __syncthreads();
+  if (tid == 0) {  // exclusive scan of the pow2-rounded sizes (trace_offsets_kernel)
+    int off = 0;
+    for (int c = 0; c < nc; ++c) {
+      const int sz = npts[(long)n * max_cand + c];
+      const int p2 = sz > 2 ? pow2_ceil(sz) : 0;  // borders with <= 2 vertices are dropped by the reference
+      if (off + p2 > pool_cap) { atomicOr(status, POST_ERR_POOL); poff[(long)n * max_cand + c] = -1; continue; }
+      poff[(long)n * max_cand + c] = off;
+      off += p2;
     }
+  }
+  __threadfence_block();
+  __syncthreads();
+  for (int c = tid; c < nc; c += 256) {
+    const long ci = (long)n * max_cand + c;
+    const int sz = npts[ci];
+    if (sz <= 2 || poff[ci] < 0) continue;
+    int ox, oy;
+    bool hole;
+    contour_origin(bm, base, starts[ci], W, ox, oy, hole);
+    unsigned long long* keys = pool + (long)n * pool_cap + poff[ci];
+    trace_border_t(nb, H, W, ox, oy, hole, keys);
+    const int p2 = pow2_ceil(sz);
+    for (int i = sz; i < p2; ++i) keys[i] = ~0ull;
   }
 }
 
@@ -1157,10 +1175,14 @@ template <int SORT_LDS_CAP, int HULL_CAP, int UNCLIP_CAP, bool RETRY>
 __global__ void __launch_bounds__(64) border_box_kernel(const PostArgs a) {
   __shared__ unsigned long long s_keys[SORT_LDS_CAP];
   __shared__ P2f s_hull[HULL_CAP];
-  __shared__ P2f s_vect[HULL_CAP];
-  __shared__ float s_inv[HULL_CAP];
-  __shared__ IPt s_unclip[UNCLIP_CAP];
-  __shared__ unsigned long long s_ukeys[UNCLIP_CAP];
+  // one region, two lives: the calipers' scratch (edge vectors, inverse lengths) while a hull is measured,
+  // the unclip polygon and its sort keys in between (each is dead when the other is written)
+  constexpr int kCal = HULL_CAP * (int)(sizeof(P2f) + sizeof(float)), kUn = UNCLIP_CAP * (int)(sizeof(IPt) + sizeof(unsigned long long));
+  __shared__ __attribute__((aligned(16))) unsigned char s_region[kCal > kUn ? kCal : kUn];
+  P2f* s_vect = (P2f*)s_region;
+  float* s_inv = (float*)(s_region + HULL_CAP * sizeof(P2f));
+  IPt* s_unclip = (IPt*)s_region;
+  unsigned long long* s_ukeys = (unsigned long long*)(s_region + UNCLIP_CAP * sizeof(IPt));
   __shared__ int s_ustack[UNCLIP_CAP + 2];
   __shared__ int s_uhull[2 * UNCLIP_CAP];
   __shared__ float s_box[8];
@@ -1331,16 +1353,18 @@ void launch_post(const PostArgs& a, int N, int* out_boxes, int cap, int* out_n, 
   bool in_lds = lds <= 150 * 1024;  // 960x960: 119 KB
   if (in_lds && lds > 64 * 1024) {  // more than the default dynamic LDS limit: raise it once per process
     static const bool raised =
-        hipFuncSetAttribute((const void*)trace_lds_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess &&
-        hipFuncSetAttribute((const void*)trace_lds_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess;
+        hipFuncSetAttribute((const void*)trace_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess;
     in_lds = raised;
   }
-  if (in_lds) hipLaunchKernelGGL((trace_lds_kernel<false>), dim3(N), dim3(256), lds, s, a.bitmap, a.H, a.W, a.max_cand, a.ncont, a.starts, a.npts, a.poff, a.pool, a.pool_cap);
-  else hipLaunchKernelGGL(trace_count_kernel, gl, dim3(64), 0, s, a.bitmap, a.H, a.W, a.max_cand, a.ncont, a.starts, a.npts);
-  hipLaunchKernelGGL(trace_offsets_kernel, dim3(N), dim3(64), 0, s, a.max_cand, a.ncont, a.npts, a.poff, a.pool_cap, a.status);
-  if (in_lds) hipLaunchKernelGGL((trace_lds_kernel<true>), dim3(N), dim3(256), lds, s, a.bitmap, a.H, a.W, a.max_cand, a.ncont, a.starts, a.npts, a.poff, a.pool, a.pool_cap);
-  else hipLaunchKernelGGL(trace_store_kernel, gl, dim3(64), 0, s, a.bitmap, a.H, a.W, a.max_cand, a.ncont, a.starts, a.npts, a.poff,
-                     a.pool, a.pool_cap);
+  if (in_lds) {
+    hipLaunchKernelGGL(trace_lds_kernel, dim3(N), dim3(256), lds, s, a.bitmap, a.H, a.W, a.max_cand, a.ncont, a.starts, a.npts, a.poff,
+                       a.pool, a.pool_cap, a.status);
+  } else {
+    hipLaunchKernelGGL(trace_count_kernel, gl, dim3(64), 0, s, a.bitmap, a.H, a.W, a.max_cand, a.ncont, a.starts, a.npts);
+    hipLaunchKernelGGL(trace_offsets_kernel, dim3(N), dim3(64), 0, s, a.max_cand, a.ncont, a.npts, a.poff, a.pool_cap, a.status);
+    hipLaunchKernelGGL(trace_store_kernel, gl, dim3(64), 0, s, a.bitmap, a.H, a.W, a.max_cand, a.ncont, a.starts, a.npts, a.poff,
+                       a.pool, a.pool_cap);
+  }
   hipLaunchKernelGGL((border_box_kernel<512, 512, 256, false>), dim3(a.max_cand, N), dim3(64), 0, s, a);
   hipLaunchKernelGGL(boxes_compact_kernel, dim3(N), dim3(64), 0, s, a, out_boxes, cap, out_n);
 }

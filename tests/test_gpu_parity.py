@@ -206,6 +206,28 @@ def test_rec_ids_scores_and_steps(pkg, built, h, w, bn):
     rec.close()
 
 
+def test_rec_cls_extreme_crops(pkg, built):
+    """Single pixels, one-pixel-high strips, needle-thin columns, a crop exactly 2x the target size (the
+    INTER_AREA switch of cv::resize) and very wide lines (tensor width above rec_img_w)."""
+    from pipeline import Pipeline
+    rs = np.random.RandomState(8)
+    shapes = [(1, 1), (1, 300), (300, 1), (2, 2), (96, 640), (96, 384), (48, 320), (7, 1000), (13, 37), (200, 9)]
+    crops = [rs.randint(0, 256, (h, w, 3)).astype(np.uint8) for h, w in shapes]
+    po = Pipeline(rec_batch_num=4, rec_img_h=48, rec_img_w=320, enable_cls=True)
+    rec, cls = pkg.Rec(rec_batch_num=4, rec_img_h=48, rec_img_w=320), pkg.Cls()
+    to, so, steps = po.rec_run(crops)
+    tg, sg = rec.run(crops)
+    assert all(np.array_equal(a, b) for a, b in zip(to, tg)) and np.array_equal(so, sg)
+    for i in range(len(crops)):
+        am, pm = rec.steps(i)
+        assert np.array_equal(am, steps[i][0]) and np.array_equal(pm, steps[i][1])
+    lo, sco = po.cls_run(crops)
+    lg, scg = cls.run(crops)
+    assert np.array_equal(lo, lg) and np.array_equal(sco, scg)
+    rec.close()
+    cls.close()
+
+
 def test_cls_on_real_weights(pkg, built):
     from pipeline import Pipeline
     crops = _crops()

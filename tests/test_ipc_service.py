@@ -1,0 +1,132 @@
+"""The Linux IPC service (host/ocr_ipc_service.h, ocr_service): the reference's JSON protocol
+(/root/reference/src/ocr_ipc_service.cpp:310-448) over a Unix-domain socket with 4-byte length framing.
+CPU part: everything that does not need a worker (status, errors, limits, shutdown).  GPU part: recognize
+with a file path and with base64 PNG, compared with the pipeline."""
+import base64
+import io
+import json
+import os
+import socket
+import struct
+import subprocess
+import time
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "cpp-paddle-ocr_amd", "host")
+
+
+class Client:
+    def __init__(self, path):
+        self.s = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+        for _ in range(200):
+            try:
+                self.s.connect(path)
+                return
+            except OSError:
+                time.sleep(0.05)
+        raise RuntimeError("service did not come up")
+
+    def call_raw(self, payload: bytes):
+        self.s.sendall(struct.pack("<I", len(payload)) + payload)
+        n = struct.unpack("<I", self._read(4))[0]
+        return json.loads(self._read(n).decode("utf-8"))
+
+    def call(self, obj):
+        return self.call_raw(json.dumps(obj).encode("utf-8"))
+
+    def _read(self, n):
+        b = b""
+        while len(b) < n:
+            c = self.s.recv(n - len(b))
+            assert c, "service closed the connection"
+            b += c
+        return b
+
+
+def _start(tmp_path, gpu_workers):
+    subprocess.check_call(["make", "-s", "-C", HOST])
+    sock = str(tmp_path / "ocr.sock")
+    proc = subprocess.Popen([os.path.join(HOST, "ocr_service"), "--model-dir", os.path.join(ROOT, "models"), "--pipe-name", sock,
+                             "--gpu-workers", str(gpu_workers)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    return proc, sock
+
+
+def _png_bytes(bgr):
+    from PIL import Image
+    buf = io.BytesIO()
+    Image.fromarray(bgr[:, :, ::-1]).save(buf, format="PNG")
+    return buf.getvalue()
+
+
+def test_ipc_protocol_without_workers(built, card, tmp_path):
+    proc, sock = _start(tmp_path, 0)
+    try:
+        c = Client(sock)
+        st = c.call({"command": "status"})
+        assert st["success"] is True
+        info = json.loads(st["status"])                      # a JSON document inside a string, like the reference
+        assert info == {"running": True, "total_requests": 0, "successful_requests": 0, "average_processing_time_ms": 0.0}
+        assert c.call({"command": "bogus"}) == {"success": False, "error": "Unknown command: bogus"}
+        assert c.call({"nothing": 1}) == {"success": False, "error": "Unknown command: "}
+        bad = c.call_raw(b'{"command": "status"')
+        assert bad["success"] is False and bad["error"].startswith("Invalid JSON: ")
+        assert c.call({"command": "recognize"}) == {"success": False, "error": "Missing image_path or image_data"}
+        assert c.call({"command": "recognize", "image_path": "/nonexistent.png"}) == \
+            {"success": False, "error": "Failed to load image from path: /nonexistent.png"}
+        assert c.call({"command": "recognize", "image_data": "@@@@"}) == \
+            {"success": False, "error": "Base64 decode error: invalid character"}
+        assert c.call({"command": "recognize", "image_data": base64.b64encode(b"not an image").decode()}) == \
+            {"success": False, "error": "Failed to decode base64 image data"}
+        # a decodable image (PNG through libpng, PPM, BMP) reaches the worker stage: none configured here
+        ppm = b"P6\n# c\n%d %d\n255\n" % (card.shape[1], card.shape[0]) + card[:, :, ::-1].tobytes()
+        from PIL import Image
+        bmp = io.BytesIO()
+        Image.fromarray(card[:, :, ::-1]).save(bmp, format="BMP")
+        for blob in (_png_bytes(card), ppm, bmp.getvalue()):
+            r = c.call({"command": "recognize", "image_data": base64.b64encode(blob).decode()})
+            assert r == {"success": False, "error": "No GPU workers configured (this build has no CPU path)"}
+        # a message that fills the 1 MiB read buffer is refused, the connection stays usable
+        r = c.call_raw(b" " * (1048576 - 1))
+        assert r == {"success": False, "error": "Data too large for buffer (max 1MB). Consider using file path transmission."}
+        assert c.call({"command": "status"})["success"] is True
+        # two clients at once
+        c2 = Client(sock)
+        assert c2.call({"command": "status"})["success"] is True
+        sd = c.call({"command": "shutdown"})
+        assert sd == {"success": True, "message": "Shutdown command received, stopping service..."}
+        assert proc.wait(timeout=20) == 0
+    finally:
+        if proc.poll() is None:
+            proc.kill()
+
+
+@pytest.mark.gpu
+def test_ipc_recognize_matches_pipeline(pkg, built, card, tmp_path):
+    proc, sock = _start(tmp_path, 1)
+    try:
+        c = Client(sock)
+        path = tmp_path / "card.png"
+        path.write_bytes(_png_bytes(card))
+        pipe = pkg.Pipe()
+        want = pipe.run([card])[0]
+        labels = [pipe.label(i) for i in range(6625)]
+        for req in ({"command": "recognize", "image_path": str(path)},
+                    {"command": "recognize", "image_data": base64.b64encode(_png_bytes(card)).decode()}):
+            r = c.call(req)
+            assert r["success"] is True and r["width"] == card.shape[1] and r["height"] == card.shape[0]
+            assert len(r["words"]) == len(want) > 0
+            for g, w in zip(r["words"], want):
+                assert np.array_equal(np.array(g["box"]), w["box"])
+                assert g["text"] == "".join(labels[i] for i in w["ids"])
+                assert np.float32(g["confidence"]) == np.float32(w["confidence"])
+        info = json.loads(c.call({"command": "status"})["status"])
+        assert info["total_requests"] == 2 and info["successful_requests"] == 2 and info["average_processing_time_ms"] > 0
+        c.call({"command": "shutdown"})
+        assert proc.wait(timeout=30) == 0
+        pipe.close()
+    finally:
+        if proc.poll() is None:
+            proc.kill()

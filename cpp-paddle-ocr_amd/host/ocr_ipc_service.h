@@ -3,7 +3,7 @@
 // over a Unix-domain stream socket; a message (the pipe's PIPE_TYPE_MESSAGE unit) is framed as a 4-byte
 // little-endian length followed by that many bytes of JSON, in both directions.
 //
-//   {"command":"recognize","image_path":"..."}            image file: PNG, binary PPM (P6), 24-bit BMP
+//   {"command":"recognize","image_path":"..."}            image file: PNG, baseline JPEG, binary PPM (P6), BMP
 //   {"command":"recognize","image_data":"<base64>"}       the same file contents, base64
 //   {"command":"status"}    -> {"success":true,"status":"{\"running\":..,\"total_requests\":..,...}"}
 //   {"command":"shutdown"}  -> {"success":true,"message":"Shutdown command received, stopping service..."}
@@ -14,8 +14,9 @@
 // Differences, by necessity: the transport (socket path instead of \\.\pipe\ocr_service); replies are compact
 // JSON (jsoncpp's default writer indents); cv::imread/imdecode are replaced by the decoders below - PNG through
 // the system's libpng16 (its simplified API, loaded with dlopen: the image ships the .so but no headers), PPM
-// and BMP natively.  JPEG is NOT decoded in this build (no libjpeg headers, no decoder of our own yet): such
-// requests fail with "Failed to load image ...", like an unreadable file does in the reference.
+// and BMP natively, JPEG with the baseline decoder of jpeg_decode.h (a restatement of libjpeg's default
+// pipeline, checked bit for bit against libjpeg-turbo through PIL; progressive JPEGs are refused and fail
+// with "Failed to load image ...", like an unreadable file does in the reference).
 // There is no CPU worker pool: cpu_workers is accepted and ignored, gpu_workers = 0 leaves `recognize`
 // answering with an error (status / shutdown still work - that is what the CPU-only tests drive).
 #pragma once
@@ -37,6 +38,7 @@
 #include <thread>
 #include <vector>
 
+#include "jpeg_decode.h"
 #include "paddle_ocr_hip.h"
 
 namespace PaddleOCR {
@@ -251,8 +253,14 @@ inline bool decode_png(const std::vector<uint8_t>& d, Image& im) {
   if (!finish(&pi, nullptr, im.pixels.data(), 0, nullptr)) { pfree(&pi); im = Image(); return false; }
   return true;
 }
+inline bool decode_jpeg(const std::vector<uint8_t>& d, Image& im) {
+  if (d.size() < 4 || d[0] != 0xFF || d[1] != 0xD8) return false;
+  jpeg::Decoder dec;
+  if (!dec.decode(d.data(), d.size(), im.pixels, im.rows, im.cols)) { im = Image(); return false; }
+  return true;
+}
 inline bool decode_image(const std::vector<uint8_t>& bytes, Image& im) {
-  return decode_png(bytes, im) || decode_ppm(bytes, im) || decode_bmp(bytes, im);
+  return decode_png(bytes, im) || decode_jpeg(bytes, im) || decode_ppm(bytes, im) || decode_bmp(bytes, im);
 }
 inline bool read_file(const std::string& path, std::vector<uint8_t>& out) {
   std::ifstream f(path, std::ios::binary);

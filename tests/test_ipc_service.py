@@ -61,6 +61,50 @@ def _png_bytes(bgr):
     return buf.getvalue()
 
 
+def _jpeg_bytes(rgb, **kw):
+    from PIL import Image
+    buf = io.BytesIO()
+    Image.fromarray(rgb).save(buf, format="JPEG", **kw)
+    return buf.getvalue()
+
+
+def test_jpeg_decoder_matches_libjpeg(built, card, tmp_path):
+    """host/jpeg_decode.h restates libjpeg's default pipeline (islow IDCT, fancy upsampling, fixed-point
+    YCC->RGB): bit-exact with libjpeg-turbo (through PIL) for every baseline variant; progressive is refused."""
+    from PIL import Image
+    subprocess.check_call(["make", "-s", "-C", HOST])
+    tool = os.path.join(HOST, "decode_tool")
+    rs = np.random.RandomState(0)
+    yy, xx = np.mgrid[0:200, 0:300]
+    images = {"card": card[:, :, ::-1].copy(), "noise": rs.randint(0, 256, (53, 37, 3)).astype(np.uint8),
+              "ramp": np.stack([xx * 255 // 300, yy * 255 // 200, (xx + yy) * 255 // 500], -1).astype(np.uint8),
+              "one": rs.randint(0, 256, (1, 1, 3)).astype(np.uint8), "thin": rs.randint(0, 256, (3, 130, 3)).astype(np.uint8)}
+    cases = []
+    for name, arr in images.items():
+        for ss in (0, 1, 2):
+            cases.append((name, arr, dict(quality=90, subsampling=ss)))
+        cases.append((name, arr, dict(quality=25)))
+    cases.append(("gray", np.array(Image.fromarray(images["card"]).convert("L")), dict(quality=85)))
+    cases.append(("restart", images["card"], dict(quality=85, restart_marker_blocks=3)))
+    cases.append(("optimize", images["card"], dict(quality=85, optimize=True)))
+    for name, arr, kw in cases:
+        src, dst = tmp_path / "t.jpg", tmp_path / "t.ppm"
+        src.write_bytes(_jpeg_bytes(arr, **kw))
+        want = np.array(Image.open(src).convert("RGB"))
+        assert subprocess.run([tool, str(src), str(dst)]).returncode == 0, (name, kw)
+        got = np.array(Image.open(dst))
+        assert np.array_equal(got, want), (name, kw)
+    src = tmp_path / "p.jpg"
+    src.write_bytes(_jpeg_bytes(images["card"], quality=85, progressive=True))
+    assert subprocess.run([tool, str(src), str(tmp_path / "p.ppm")], capture_output=True).returncode != 0
+    # the other containers of the service decode to the same pixels
+    for fmt in ("PNG", "BMP", "PPM"):
+        src = tmp_path / ("c." + fmt.lower())
+        Image.fromarray(images["card"]).save(src, format=fmt)
+        assert subprocess.run([tool, str(src), str(tmp_path / "c.out.ppm")]).returncode == 0
+        assert np.array_equal(np.array(Image.open(tmp_path / "c.out.ppm")), images["card"])
+
+
 def test_ipc_protocol_without_workers(built, card, tmp_path):
     proc, sock = _start(tmp_path, 0)
     try:
@@ -80,12 +124,12 @@ def test_ipc_protocol_without_workers(built, card, tmp_path):
             {"success": False, "error": "Base64 decode error: invalid character"}
         assert c.call({"command": "recognize", "image_data": base64.b64encode(b"not an image").decode()}) == \
             {"success": False, "error": "Failed to decode base64 image data"}
-        # a decodable image (PNG through libpng, PPM, BMP) reaches the worker stage: none configured here
+        # a decodable image (PNG through libpng, baseline JPEG, PPM, BMP) reaches the worker stage: none configured here
         ppm = b"P6\n# c\n%d %d\n255\n" % (card.shape[1], card.shape[0]) + card[:, :, ::-1].tobytes()
         from PIL import Image
         bmp = io.BytesIO()
         Image.fromarray(card[:, :, ::-1]).save(bmp, format="BMP")
-        for blob in (_png_bytes(card), ppm, bmp.getvalue()):
+        for blob in (_png_bytes(card), _jpeg_bytes(card[:, :, ::-1].copy(), quality=90), ppm, bmp.getvalue()):
             r = c.call({"command": "recognize", "image_data": base64.b64encode(blob).decode()})
             assert r == {"success": False, "error": "No GPU workers configured (this build has no CPU path)"}
         # a message that fills the 1 MiB read buffer is refused, the connection stays usable
@@ -122,8 +166,17 @@ def test_ipc_recognize_matches_pipeline(pkg, built, card, tmp_path):
                 assert np.array_equal(np.array(g["box"]), w["box"])
                 assert g["text"] == "".join(labels[i] for i in w["ids"])
                 assert np.float32(g["confidence"]) == np.float32(w["confidence"])
+        # a JPEG request: the service's decoder, then the same pipeline as on the decoded pixels
+        from PIL import Image
+        jb = _jpeg_bytes(card[:, :, ::-1].copy(), quality=92)
+        dec = np.array(Image.open(io.BytesIO(jb)).convert("RGB"))[:, :, ::-1].copy()
+        wj = pipe.run([dec])[0]
+        r = c.call({"command": "recognize", "image_data": base64.b64encode(jb).decode()})
+        assert r["success"] is True and len(r["words"]) == len(wj) > 0
+        for g, w in zip(r["words"], wj):
+            assert np.array_equal(np.array(g["box"]), w["box"]) and g["text"] == "".join(labels[i] for i in w["ids"])
         info = json.loads(c.call({"command": "status"})["status"])
-        assert info["total_requests"] == 2 and info["successful_requests"] == 2 and info["average_processing_time_ms"] > 0
+        assert info["total_requests"] == 3 and info["successful_requests"] == 3 and info["average_processing_time_ms"] > 0
         c.call({"command": "shutdown"})
         assert proc.wait(timeout=30) == 0
         pipe.close()

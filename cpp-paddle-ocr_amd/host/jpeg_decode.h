@@ -1,13 +1,14 @@
-// Baseline JPEG decoder for the IPC service (the reference decodes with cv::imread / cv::imdecode, i.e. libjpeg
+// JPEG decoder (sequential and progressive Huffman) for the IPC service (the reference decodes with cv::imread / cv::imdecode, i.e. libjpeg
 // with its defaults - /root/reference/src/ocr_ipc_service.cpp:42,336).  The image ships libjpeg.so without
 // headers, so this is a restatement of what libjpeg(-turbo) computes with default settings, stage by stage:
-//   * Huffman-coded sequential DCT (SOF0 / SOF1, 8-bit), restart intervals, 1 or 3 components,
-//     sampling 4:4:4, 4:2:2 (h2v1) and 4:2:0 (h2v2);
+//   * Huffman-coded sequential (SOF0 / SOF1) and progressive (SOF2: spectral selection and successive
+//     approximation, jdphuff.c) DCT, 8-bit, restart intervals, interleaved and per-component scans,
+//     1 or 3 components, sampling 4:4:4, 4:2:2 (h2v1) and 4:2:0 (h2v2);
 //   * dequantisation + the "islow" integer IDCT (jidctint.c: 13-bit constants, two passes, PASS1_BITS = 2);
 //   * "fancy" (triangle) chroma upsampling, h2v1 and h2v2 (jdsample.c), image edges replicated;
 //   * YCbCr -> RGB with the 16-bit fixed-point tables of jdcolor.c.
 // tests/test_ipc_service.py checks the output bit for bit against PIL (libjpeg-turbo) on encoded test images.
-// Progressive (SOF2), arithmetic coding, 12-bit, CMYK and other samplings are refused (decode fails).
+// Arithmetic coding, lossless, 12-bit, CMYK and other samplings are refused (decode fails).
 #pragma once
 #include <cstdint>
 #include <cstring>
@@ -42,6 +43,7 @@ struct Component {
   int bw = 0, bh = 0;        // blocks per row / column (padded to whole MCUs)
   int dw = 0, dh = 0;        // downsampled size in samples (unpadded)
   int pred = 0;
+  std::vector<int16_t> coef;   // bw*bh blocks x 64, natural order, not yet dequantised
   std::vector<uint8_t> plane;  // bw*8 x bh*8 samples
 };
 
@@ -52,22 +54,25 @@ class Decoder {
     d_ = data; n_ = size; pos_ = 0;
     if (n_ < 4 || d_[0] != 0xFF || d_[1] != 0xD8) return false;
     pos_ = 2;
-    bool have_frame = false;
+    bool have_frame = false, have_scan = false;
     for (;;) {
       int m = next_marker();
-      if (m < 0) return false;
-      if (m == 0xD9) return false;  // EOI before a scan
-      if (m == 0xC0 || m == 0xC1) { if (!read_sof()) return false; have_frame = true; continue; }
-      if ((m >= 0xC2 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC)) return false;  // progressive, lossless, arithmetic
+      if (m < 0) { if (have_scan) break; return false; }  // truncated after some data: libjpeg fills in the rest
+      if (m == 0xD9) { if (have_scan) break; return false; }
+      if (m == 0xC0 || m == 0xC1 || m == 0xC2) { if (have_frame || !read_sof(m == 0xC2)) return false; have_frame = true; continue; }
+      if ((m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC)) return false;  // lossless, differential, arithmetic
       if (m == 0xC4) { if (!read_dht()) return false; continue; }
       if (m == 0xDB) { if (!read_dqt()) return false; continue; }
       if (m == 0xDD) { if (!read_dri()) return false; continue; }
       if (m == 0xDA) {
         if (!have_frame || !read_sos() || !decode_scan()) return false;
-        break;  // baseline: one interleaved scan carries everything we accept
+        have_scan = true;
+        continue;
       }
+      if (m >= 0xD0 && m <= 0xD7) continue;  // stray RSTn
       if (!skip_segment()) return false;
     }
+    reconstruct();
     return output(bgr, rows, cols);
   }
 
@@ -127,7 +132,8 @@ class Decoder {
     pos_ += len;
     return true;
   }
-  bool read_sof() {
+  bool read_sof(bool progressive) {
+    progressive_ = progressive;
     size_t len;
     if (!seg(len) || len < 8) return false;
     const uint8_t* q = d_ + pos_ + 2;
@@ -161,6 +167,7 @@ class Decoder {
       c.dw = (W_ * c.h + hmax_ - 1) / hmax_;
       c.dh = (H_ * c.v + vmax_ - 1) / vmax_;
       c.plane.assign((size_t)c.bw * 8 * c.bh * 8, 0);
+      c.coef.assign((size_t)c.bw * c.bh * 64, 0);
     }
     pos_ += len;
     return true;
@@ -169,15 +176,27 @@ class Decoder {
     size_t len;
     if (!seg(len)) return false;
     const uint8_t* q = d_ + pos_ + 2;
-    const int ns = q[0];
-    if (ns != nc_ || len != (size_t)(6 + 2 * ns)) return false;  // one interleaved scan with every component
-    for (int i = 0; i < ns; ++i) {
-      if (q[1 + 2 * i] != comp_[i].id) return false;
-      comp_[i].td = q[2 + 2 * i] >> 4;
-      comp_[i].ta = q[2 + 2 * i] & 15;
-      if (comp_[i].td > 3 || comp_[i].ta > 3 || !dc_[comp_[i].td].set || !ac_[comp_[i].ta].set) return false;
+    ns_ = q[0];
+    if (ns_ < 1 || ns_ > nc_ || len != (size_t)(6 + 2 * ns_)) return false;
+    for (int i = 0; i < ns_; ++i) {
+      int ci = -1;
+      for (int j = 0; j < nc_; ++j) if (comp_[j].id == q[1 + 2 * i]) ci = j;
+      if (ci < 0) return false;
+      scan_[i] = ci;
+      comp_[ci].td = q[2 + 2 * i] >> 4;
+      comp_[ci].ta = q[2 + 2 * i] & 15;
+      if (comp_[ci].td > 3 || comp_[ci].ta > 3) return false;
     }
-    if (q[1 + 2 * ns] != 0 || q[2 + 2 * ns] != 63) return false;  // Ss, Se of a sequential scan
+    ss_ = q[1 + 2 * ns_]; se_ = q[2 + 2 * ns_]; ah_ = q[3 + 2 * ns_] >> 4; al_ = q[3 + 2 * ns_] & 15;
+    if (!progressive_) {
+      if (ss_ != 0 || se_ != 63 || ah_ != 0 || al_ != 0) return false;
+    } else {
+      if (ss_ > se_ || se_ > 63 || (ss_ == 0 && se_ != 0) || (ss_ > 0 && ns_ != 1) || al_ > 13) return false;
+    }
+    for (int i = 0; i < ns_; ++i) {
+      const Component& c = comp_[scan_[i]];
+      if ((ss_ == 0 && ah_ == 0 && !dc_[c.td].set) || (se_ > 0 && !ac_[c.ta].set)) return false;
+    }
     pos_ += len;
     return true;
   }
@@ -215,31 +234,112 @@ class Decoder {
     return -1;
   }
   static int extend(int v, int t) { return v < (1 << (t - 1)) ? v - (1 << t) + 1 : v; }
-  bool decode_block(Component& c, int coef[64]) {
+  static const uint8_t* zigzag() {
     static const uint8_t zz[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
                                    41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
                                    30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
-    memset(coef, 0, 64 * sizeof(int));
+    return zz;
+  }
+  // sequential block: DC difference + run/size AC codes
+  bool block_sequential(Component& c, int16_t* b) {
+    const uint8_t* zz = zigzag();
     const int t = decode_symbol(dc_[c.td]);
     if (t < 0 || t > 15) return false;
-    const int diff = t ? extend(getbits(t), t) : 0;
-    c.pred += diff;
-    coef[0] = c.pred * qt_[c.tq][0];
+    c.pred += t ? extend(getbits(t), t) : 0;
+    b[0] = (int16_t)c.pred;
     for (int k = 1; k < 64;) {
       const int rs = decode_symbol(ac_[c.ta]);
       if (rs < 0) return false;
-      const int r = rs >> 4, s = rs & 15;
-      if (s == 0) {
+      const int r = rs >> 4, sz = rs & 15;
+      if (sz == 0) {
         if (r != 15) break;  // EOB
         k += 16;
         continue;
       }
       k += r;
       if (k > 63) return false;
-      coef[zz[k]] = extend(getbits(s), s) * qt_[c.tq][k];
+      b[zz[k]] = (int16_t)extend(getbits(sz), sz);
       ++k;
     }
     return true;
+  }
+  // progressive, jdphuff.c: DC first / refine, AC first / refine
+  bool block_dc_first(Component& c, int16_t* b) {
+    const int t = decode_symbol(dc_[c.td]);
+    if (t < 0 || t > 15) return false;
+    c.pred += t ? extend(getbits(t), t) : 0;
+    b[0] = (int16_t)(c.pred * (1 << al_));
+    return true;
+  }
+  bool block_dc_refine(int16_t* b) {
+    if (getbits(1)) b[0] = (int16_t)(b[0] | (1 << al_));
+    return true;
+  }
+  bool block_ac_first(Component& c, int16_t* b) {
+    const uint8_t* zz = zigzag();
+    if (eobrun_ > 0) { --eobrun_; return true; }
+    for (int k = ss_; k <= se_; ++k) {
+      const int rs = decode_symbol(ac_[c.ta]);
+      if (rs < 0) return false;
+      const int r = rs >> 4, sz = rs & 15;
+      if (sz) {
+        k += r;
+        if (k > 63) return false;
+        b[zz[k]] = (int16_t)(extend(getbits(sz), sz) * (1 << al_));
+      } else if (r == 15) {
+        k += 15;
+      } else {
+        eobrun_ = 1 << r;
+        if (r) eobrun_ += getbits(r);
+        --eobrun_;
+        break;
+      }
+    }
+    return true;
+  }
+  bool block_ac_refine(Component& c, int16_t* b) {
+    const uint8_t* zz = zigzag();
+    const int p1 = 1 << al_, m1 = -(1 << al_);
+    int k = ss_;
+    if (eobrun_ == 0) {
+      for (; k <= se_; ++k) {
+        const int rs = decode_symbol(ac_[c.ta]);
+        if (rs < 0) return false;
+        int r = rs >> 4, sz = rs & 15, val = 0;
+        if (sz) {
+          if (sz != 1) return false;
+          val = getbits(1) ? p1 : m1;
+        } else if (r != 15) {
+          eobrun_ = 1 << r;
+          if (r) eobrun_ += getbits(r);
+          break;  // the rest of this block is handled by the end-of-band logic below
+        }
+        // skip over already-nonzero coefficients (applying correction bits) and r zero ones
+        do {
+          int16_t& cf = b[zz[k]];
+          if (cf != 0) {
+            if (getbits(1) && (cf & p1) == 0) cf = (int16_t)(cf + (cf >= 0 ? p1 : m1));
+          } else if (--r < 0) {
+            break;
+          }
+          ++k;
+        } while (k <= se_);
+        if (val && k <= 63) b[zz[k]] = (int16_t)val;
+      }
+    }
+    if (eobrun_ > 0) {
+      for (; k <= se_; ++k) {
+        int16_t& cf = b[zz[k]];
+        if (cf != 0 && getbits(1) && (cf & p1) == 0) cf = (int16_t)(cf + (cf >= 0 ? p1 : m1));
+      }
+      --eobrun_;
+    }
+    return true;
+  }
+  bool decode_one_block(Component& c, int16_t* b) {
+    if (!progressive_) return block_sequential(c, b);
+    if (ss_ == 0) return ah_ == 0 ? block_dc_first(c, b) : block_dc_refine(b);
+    return ah_ == 0 ? block_ac_first(c, b) : block_ac_refine(c, b);
   }
 
   // ---------------------------------------------------------------- jidctint.c, jpeg_idct_islow
@@ -279,36 +379,61 @@ class Decoder {
     }
   }
 
-  bool decode_scan() {
-    acc_ = 0; bits_ = 0; hit_marker_ = false;
+  bool restart_if_due(int& until_restart, int& next_rst) {
+    if (!restart_ || until_restart != 0) return true;
+    bits_ = 0; acc_ = 0; hit_marker_ = false;  // byte-align, expect RSTn
+    while (pos_ + 1 < n_ && !(d_[pos_] == 0xFF && d_[pos_ + 1] >= 0xD0 && d_[pos_ + 1] <= 0xD7)) ++pos_;
+    if (pos_ + 1 >= n_ || d_[pos_ + 1] != 0xD0 + next_rst) return false;
+    pos_ += 2;
+    next_rst = (next_rst + 1) & 7;
     for (int i = 0; i < nc_; ++i) comp_[i].pred = 0;
-    int coef[64];
-    int until_restart = restart_;
-    int next_rst = 0;
+    eobrun_ = 0;
+    until_restart = restart_;
+    return true;
+  }
+  bool decode_scan() {
+    acc_ = 0; bits_ = 0; hit_marker_ = false; eobrun_ = 0;
+    for (int i = 0; i < nc_; ++i) comp_[i].pred = 0;
+    int until_restart = restart_, next_rst = 0;
+    if (ns_ == 1) {
+      // one component: its own block grid, not padded to whole MCUs
+      Component& c = comp_[scan_[0]];
+      const int nbx = (c.dw + 7) / 8, nby = (c.dh + 7) / 8;
+      for (int by = 0; by < nby; ++by)
+        for (int bx = 0; bx < nbx; ++bx) {
+          if (!restart_if_due(until_restart, next_rst)) return false;
+          if (!decode_one_block(c, &c.coef[((size_t)by * c.bw + bx) * 64])) return false;
+          if (restart_) --until_restart;
+        }
+      return true;
+    }
     for (int my = 0; my < mcuy_; ++my)
       for (int mx = 0; mx < mcux_; ++mx) {
-        if (restart_ && until_restart == 0) {
-          // byte-align, expect RSTn
-          bits_ = 0; acc_ = 0; hit_marker_ = false;
-          while (pos_ + 1 < n_ && !(d_[pos_] == 0xFF && d_[pos_ + 1] >= 0xD0 && d_[pos_ + 1] <= 0xD7)) ++pos_;
-          if (pos_ + 1 >= n_ || d_[pos_ + 1] != 0xD0 + next_rst) return false;
-          pos_ += 2;
-          next_rst = (next_rst + 1) & 7;
-          for (int i = 0; i < nc_; ++i) comp_[i].pred = 0;
-          until_restart = restart_;
-        }
-        for (int i = 0; i < nc_; ++i) {
-          Component& c = comp_[i];
+        if (!restart_if_due(until_restart, next_rst)) return false;
+        for (int i = 0; i < ns_; ++i) {
+          Component& c = comp_[scan_[i]];
           for (int by = 0; by < c.v; ++by)
-            for (int bx = 0; bx < c.h; ++bx) {
-              if (!decode_block(c, coef)) return false;
-              const int X = (mx * c.h + bx) * 8, Y = (my * c.v + by) * 8;
-              idct(coef, c.plane.data() + (size_t)Y * c.bw * 8 + X, c.bw * 8);
-            }
+            for (int bx = 0; bx < c.h; ++bx)
+              if (!decode_one_block(c, &c.coef[((size_t)(my * c.v + by) * c.bw + mx * c.h + bx) * 64])) return false;
         }
         if (restart_) --until_restart;
       }
     return true;
+  }
+  // dequantise + IDCT every block
+  void reconstruct() {
+    const uint8_t* zz = zigzag();
+    int q[64], in[64];
+    for (int i = 0; i < nc_; ++i) {
+      Component& c = comp_[i];
+      for (int k = 0; k < 64; ++k) q[zz[k]] = qt_[c.tq][k];
+      for (int by = 0; by < c.bh; ++by)
+        for (int bx = 0; bx < c.bw; ++bx) {
+          const int16_t* b = &c.coef[((size_t)by * c.bw + bx) * 64];
+          for (int k = 0; k < 64; ++k) in[k] = b[k] * q[k];
+          idct(in, c.plane.data() + (size_t)by * 8 * c.bw * 8 + bx * 8, c.bw * 8);
+        }
+    }
   }
 
   // ---------------------------------------------------------------- jdsample.c fancy upsampling
@@ -408,6 +533,8 @@ class Decoder {
   Huff dc_[4], ac_[4];
   Component comp_[3];
   int W_ = 0, H_ = 0, nc_ = 0, hmax_ = 1, vmax_ = 1, mcux_ = 0, mcuy_ = 0, restart_ = 0;
+  bool progressive_ = false;
+  int ns_ = 0, scan_[3] = {0, 0, 0}, ss_ = 0, se_ = 63, ah_ = 0, al_ = 0, eobrun_ = 0;
   uint32_t acc_ = 0;
   int bits_ = 0;
   bool hit_marker_ = false;

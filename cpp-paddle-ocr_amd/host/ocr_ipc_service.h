@@ -3,7 +3,7 @@
 // over a Unix-domain stream socket; a message (the pipe's PIPE_TYPE_MESSAGE unit) is framed as a 4-byte
 // little-endian length followed by that many bytes of JSON, in both directions.
 //
-//   {"command":"recognize","image_path":"..."}            image file: PNG, baseline JPEG, binary PPM (P6), BMP
+//   {"command":"recognize","image_path":"..."}            image file: PNG, JPEG, binary PPM (P6), BMP
 //   {"command":"recognize","image_data":"<base64>"}       the same file contents, base64
 //   {"command":"status"}    -> {"success":true,"status":"{\"running\":..,\"total_requests\":..,...}"}
 //   {"command":"shutdown"}  -> {"success":true,"message":"Shutdown command received, stopping service..."}
@@ -14,9 +14,8 @@
 // Differences, by necessity: the transport (socket path instead of \\.\pipe\ocr_service); replies are compact
 // JSON (jsoncpp's default writer indents); cv::imread/imdecode are replaced by the decoders below - PNG through
 // the system's libpng16 (its simplified API, loaded with dlopen: the image ships the .so but no headers), PPM
-// and BMP natively, JPEG with the baseline decoder of jpeg_decode.h (a restatement of libjpeg's default
-// pipeline, checked bit for bit against libjpeg-turbo through PIL; progressive JPEGs are refused and fail
-// with "Failed to load image ...", like an unreadable file does in the reference).
+// and BMP natively, JPEG with the decoder of jpeg_decode.h (a restatement of libjpeg's default pipeline,
+// sequential and progressive, checked bit for bit against libjpeg-turbo through PIL).
 // There is no CPU worker pool: cpu_workers is accepted and ignored, gpu_workers = 0 leaves `recognize`
 // answering with an error (status / shutdown still work - that is what the CPU-only tests drive).
 #pragma once

@@ -69,8 +69,8 @@ def _jpeg_bytes(rgb, **kw):
 
 
 def test_jpeg_decoder_matches_libjpeg(built, card, tmp_path):
-    """host/jpeg_decode.h restates libjpeg's default pipeline (islow IDCT, fancy upsampling, fixed-point
-    YCC->RGB): bit-exact with libjpeg-turbo (through PIL) for every baseline variant; progressive is refused."""
+    """host/jpeg_decode.h restates libjpeg's default pipeline (Huffman sequential + progressive, islow IDCT,
+    fancy upsampling, fixed-point YCC->RGB): bit-exact with libjpeg-turbo (through PIL) on every variant."""
     from PIL import Image
     subprocess.check_call(["make", "-s", "-C", HOST])
     tool = os.path.join(HOST, "decode_tool")
@@ -83,10 +83,14 @@ def test_jpeg_decoder_matches_libjpeg(built, card, tmp_path):
     for name, arr in images.items():
         for ss in (0, 1, 2):
             cases.append((name, arr, dict(quality=90, subsampling=ss)))
+            cases.append((name, arr, dict(quality=80, subsampling=ss, progressive=True)))
         cases.append((name, arr, dict(quality=25)))
     cases.append(("gray", np.array(Image.fromarray(images["card"]).convert("L")), dict(quality=85)))
     cases.append(("restart", images["card"], dict(quality=85, restart_marker_blocks=3)))
     cases.append(("optimize", images["card"], dict(quality=85, optimize=True)))
+    cases.append(("gray progressive", np.array(Image.fromarray(images["card"]).convert("L")), dict(quality=85, progressive=True)))
+    cases.append(("restart progressive", images["card"], dict(quality=85, restart_marker_blocks=3, progressive=True)))
+    cases.append(("progressive q98", images["card"], dict(quality=98, progressive=True)))
     for name, arr, kw in cases:
         src, dst = tmp_path / "t.jpg", tmp_path / "t.ppm"
         src.write_bytes(_jpeg_bytes(arr, **kw))
@@ -94,9 +98,11 @@ def test_jpeg_decoder_matches_libjpeg(built, card, tmp_path):
         assert subprocess.run([tool, str(src), str(dst)]).returncode == 0, (name, kw)
         got = np.array(Image.open(dst))
         assert np.array_equal(got, want), (name, kw)
-    src = tmp_path / "p.jpg"
-    src.write_bytes(_jpeg_bytes(images["card"], quality=85, progressive=True))
-    assert subprocess.run([tool, str(src), str(tmp_path / "p.ppm")], capture_output=True).returncode != 0
+    # garbage and truncated headers are refused, not crashed on
+    for blob in (b"\xff\xd8\xff\xd9", b"\xff\xd8" + bytes(100), _jpeg_bytes(images["card"], quality=85)[:150]):
+        src = tmp_path / "bad.jpg"
+        src.write_bytes(blob)
+        assert subprocess.run([tool, str(src), str(tmp_path / "bad.ppm")], capture_output=True).returncode == 1
     # the other containers of the service decode to the same pixels
     for fmt in ("PNG", "BMP", "PPM"):
         src = tmp_path / ("c." + fmt.lower())

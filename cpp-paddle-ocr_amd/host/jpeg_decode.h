@@ -142,6 +142,7 @@ class Decoder {
     W_ = (q[3] << 8) | q[4];
     nc_ = q[5];
     if (H_ <= 0 || W_ <= 0 || (nc_ != 1 && nc_ != 3) || len < (size_t)(8 + 3 * nc_)) return false;
+    if ((long)H_ * W_ > (64L << 20)) return false;  // 64 Mpixel cap: a service must not be made to allocate gigabytes by a header
     hmax_ = vmax_ = 1;
     for (int i = 0; i < nc_; ++i) {
       comp_[i].id = q[6 + 3 * i];

@@ -1020,8 +1020,73 @@ __global__ void __launch_bounds__(64) ln_kernel(const float* __restrict__ in, fl
   for (int pc = 0; pc < Cs; ++pc)
     if (c8i_logical(pc) >= C) dst[pc] = 0.f;
 }
+// Same arithmetic, memory access restructured for the channel counts without pad channels (C == Cs,
+// C % 8 == 0; 120 on the rec path): a workgroup moves 64 whole rows - one contiguous span of global
+// memory - through LDS with full-line loads and stores, and each lane walks its own row out of
+// registers.  The per-row chains (ascending logical channel) are exactly those of ln_kernel; only who
+// fetches which byte changed.  ln_kernel's one-row-per-lane global reads were a dependent chain of
+// strided loads: ~120 us for ANY row count (rocprof r1: 105-250 us per call).
+template <int C>
+__global__ void __launch_bounds__(64) ln_tile_kernel(const float* __restrict__ in, float* __restrict__ out, long rows,
+                                                     float eps, const float* __restrict__ g,
+                                                     const float* __restrict__ b) {
+  constexpr int LS = C + 1;  // odd row stride: a column walk across lanes touches every bank once
+  __shared__ float s_x[64 * LS];
+  const int lane = threadIdx.x;
+  const long r0 = (long)blockIdx.x * 64;
+  const int nrows = (int)(rows - r0 < 64 ? rows - r0 : 64);
+  const int nvec = nrows * (C / 4);
+  const float4* __restrict__ src = (const float4*)(in + r0 * C);
+  float4* __restrict__ dstv = (float4*)(out + r0 * C);
+#pragma unroll 6
+  for (int i = lane; i < nvec; i += 64) {
+    const float4 v = src[i];
+    const int row = i / (C / 4), col = (i - row * (C / 4)) * 4;
+    float* d = s_x + row * LS + col;
+    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+  }
+  __syncthreads();
+  if (lane < nrows) {
+    float x[C];  // physical (octet-interleaved) order
+    float* row = s_x + lane * LS;
+#pragma unroll
+    for (int pc = 0; pc < C; ++pc) x[pc] = row[pc];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) s = s + x[c8i_phys(c)];
+    const float mean = s / (float)C;
+    float v = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const float xm = x[c8i_phys(c)] - mean;
+      v = fmaf(xm, xm, v);
+    }
+    const float var = v / (float)C;
+    const float rstd = 1.0f / sqrtf(var + eps);
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const int pc = c8i_phys(c);
+      const float xm = x[pc] - mean;
+      float t = xm * rstd;
+      t = t * g[c];
+      row[pc] = t + b[c];
+    }
+  }
+  __syncthreads();
+#pragma unroll 6
+  for (int i = lane; i < nvec; i += 64) {
+    const int row = i / (C / 4), col = (i - row * (C / 4)) * 4;
+    const float* d = s_x + row * LS + col;
+    dstv[i] = make_float4(d[0], d[1], d[2], d[3]);
+  }
+}
+
 void launch_ln(const float* in, float* out, long rows, int C, int Cs, float eps, const float* g, const float* b,
                hipStream_t s) {
+  if (C == 120 && Cs == 120) {
+    hipLaunchKernelGGL(ln_tile_kernel<120>, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, s, in, out, rows, eps, g, b);
+    return;
+  }
   hipLaunchKernelGGL(ln_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, s, in, out, rows, C, Cs, eps, g, b);
 }
 
@@ -1082,8 +1147,91 @@ __global__ void __launch_bounds__(64) attn_kernel(const float* __restrict__ qkv,
 #pragma unroll
   for (int d = 0; d < HD; ++d) dst[c8i_phys(hh * HD + d)] = o[d];
 }
+// Same chains with the operands staged: one wave per (line n, head).  K and V rows of the head sit in
+// LDS (16-float rows, every lane reads the same row: broadcast), the scaled q row in registers, and the
+// score of (query, key) is computed once and parked in LDS ([key][lane]: conflict-free) instead of being
+// recomputed in each of the three passes.  Values and their order are those of attn_kernel.
+// attn_kernel's per-thread global walks cost 0.3-1.1 ms per call regardless of size (rocprof r1).
+template <int HD>
+__global__ void __launch_bounds__(64) attn_lds_kernel(const float* __restrict__ qkv, float* __restrict__ out, int N, int T,
+                                                      int heads, int Cs_in, int Cs_out, float scale) {
+  static_assert(HD <= 16, "head rows are padded to 16 floats");
+  extern __shared__ float s_att[];
+  float* s_k = s_att;                 // [T][16]
+  float* s_v = s_k + (long)T * 16;    // [T][16]
+  float* s_q = s_v + (long)T * 16;    // [64][17]
+  float* s_e = s_q + 64 * 17;         // [T][64]
+  const int lane = threadIdx.x;
+  const int hh = blockIdx.x % heads, n = blockIdx.x / heads;
+  const int D = heads * HD;
+  const float* base = qkv + (long)n * T * Cs_in;
+  for (int i = lane; i < T * 32; i += 64) {
+    const int u = i >> 5, which = (i >> 4) & 1, d = i & 15;
+    float val = 0.f;
+    if (d < HD) val = base[(long)u * Cs_in + c8i_phys((1 + which) * D + hh * HD + d)];
+    (which ? s_v : s_k)[u * 16 + d] = val;
+  }
+  for (int t0 = 0; t0 < T; t0 += 64) {
+    __syncthreads();  // K/V staged (first chunk); previous chunk's q rows consumed (later chunks)
+    for (int i = lane; i < 64 * 16; i += 64) {
+      const int tq = i >> 4, d = i & 15;
+      if (d < HD && t0 + tq < T) s_q[tq * 17 + d] = base[(long)(t0 + tq) * Cs_in + c8i_phys(hh * HD + d)];
+    }
+    __syncthreads();
+    const int t = t0 + lane;
+    if (t < T) {
+      float q[HD];
+#pragma unroll
+      for (int d = 0; d < HD; ++d) q[d] = s_q[lane * 17 + d] * scale;
+      float mx = -INFINITY;
+      for (int u = 0; u < T; ++u) {
+        float kr[16];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *(float4*)(kr + 4 * j) = *(const float4*)(s_k + u * 16 + 4 * j);
+        float acc = 0.f;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) acc = fmaf(q[d], kr[d], acc);
+        s_e[u * 64 + lane] = acc;
+        mx = fmaxf(mx, acc);
+      }
+      float sum = 0.f;
+      for (int u = 0; u < T; ++u) {
+        const float e = ocr_expf(s_e[u * 64 + lane] - mx);
+        sum = sum + e;
+        s_e[u * 64 + lane] = e;
+      }
+      float o[HD];
+#pragma unroll
+      for (int d = 0; d < HD; ++d) o[d] = 0.f;
+      for (int u = 0; u < T; ++u) {
+        float vr[16];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *(float4*)(vr + 4 * j) = *(const float4*)(s_v + u * 16 + 4 * j);
+        const float pw = s_e[u * 64 + lane] / sum;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) o[d] = fmaf(pw, vr[d], o[d]);
+      }
+      float* dst = out + ((long)n * T + t) * Cs_out;
+#pragma unroll
+      for (int d = 0; d < HD; ++d) dst[c8i_phys(hh * HD + d)] = o[d];
+    }
+  }
+}
+
 void launch_attn(const float* qkv, float* out, int N, int T, int heads, int hd, int Cs_in, int Cs_out, float scale,
                  hipStream_t s) {
+  const size_t lds = ((size_t)T * 96 + 64 * 17) * sizeof(float);
+  if (lds <= 150 * 1024) {
+    static bool once = [] {
+      return hipFuncSetAttribute((const void*)attn_lds_kernel<15>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) ==
+             hipSuccess;
+    }();
+    if (once) {
+      hipLaunchKernelGGL(attn_lds_kernel<15>, dim3((unsigned)(N * heads)), dim3(64), lds, s, qkv, out, N, T, heads, Cs_in,
+                         Cs_out, scale);
+      return;
+    }
+  }
   const long total = (long)N * heads * T;
   // hd is 15 for the only attention block on the path (rec plan); the runtime checks it at load.
   hipLaunchKernelGGL(attn_kernel<15>, dim3((unsigned)((total + 63) / 64)), dim3(64), 0, s, qkv, out, N, T, heads, Cs_in,

@@ -29,8 +29,8 @@ static void run(long M, int cin, int cout, int variant, int epi) {
   }
   const long nwaves = ((M + 127) / 128) * (NTtot / nt) * 4;
   long long* probe;
-  CK(hipMalloc(&probe, nwaves * 4 * 8));
-  CK(hipMemset(probe, 0, nwaves * 4 * 8));
+  CK(hipMalloc(&probe, nwaves * 8 * 8));
+  CK(hipMemset(probe, 0, nwaves * 8 * 8));
   long long* nullp = nullptr;
   auto launch = [&]() { launch_conv_mfma(a, ep, nt, 0); };
   CK(hipMemcpyToSymbol(HIP_SYMBOL(g_conv_probe), &nullp, sizeof(nullp)));
@@ -50,8 +50,12 @@ static void run(long M, int cin, int cout, int variant, int epi) {
   CK(hipMemcpyToSymbol(HIP_SYMBOL(g_conv_probe), &probe, sizeof(probe)));
   launch();
   CK(hipDeviceSynchronize());
+  std::vector<long long> h8(nwaves * 8);
+  CK(hipMemcpy(h8.data(), probe, nwaves * 64, hipMemcpyDeviceToHost));
   std::vector<long long> h(nwaves * 4);
-  CK(hipMemcpy(h.data(), probe, nwaves * 32, hipMemcpyDeviceToHost));
+  double p04 = 0, p45 = 0, p51 = 0; long pc = 0;
+  for (long i = 0; i < nwaves; ++i) { for (int k = 0; k < 4; ++k) h[i * 4 + k] = h8[i * 8 + k]; if (h8[i * 8 + 3]) { p04 += h8[i * 8 + 4] - h8[i * 8]; p45 += h8[i * 8 + 5] - h8[i * 8 + 4]; p51 += h8[i * 8 + 1] - h8[i * 8 + 5]; ++pc; } }
+  if (pc) printf("   prologue split: entry->staging %.0f  staging+barrier %.0f  setup+first loads %.0f\n", p04 / pc, p45 / pc, p51 / pc);
   long long* chk = nullptr;
   CK(hipMemcpyFromSymbol(&chk, HIP_SYMBOL(g_conv_probe), sizeof(chk)));
   printf("   probe ptr %p (symbol %p) first %lld %lld %lld %lld\n", (void*)probe, (void*)chk, h[0], h[1], h[2], h[3]);

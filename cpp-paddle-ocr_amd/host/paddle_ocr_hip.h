@@ -15,6 +15,7 @@
 #include <atomic>
 #include <condition_variable>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <future>
 #include <memory>
@@ -266,9 +267,19 @@ class OCRWorker {
   // OCRWorker(worker_id, model_dir, use_gpu, gpu_id = 0, enable_cls = false); hyper-parameters are the
   // literals of the reference constructor (ocr_worker.cpp:21-63) — they are ocr_pipe_cfg_default().
   // rotate_crops (extension, default off): crops through Utility::GetRotateCropImage instead of ROI views.
+  // max_batch (extension): the worker thread takes up to this many QUEUED requests at once and runs them
+  // as one ocr_pipe_run - the GPU is fed whole batches under concurrent load, a lone request is still
+  // served immediately (nothing ever waits for a batch to fill).  Per-image results do not depend on what
+  // else is in the batch (tests/test_gpu_parity.py, tests/test_ipc_service.py).  0 = OCR_WORKER_MAX_BATCH
+  // from the environment, else 32; 1 = the reference's one-request-at-a-time loop.
   OCRWorker(int worker_id, const std::string& model_dir, bool use_gpu, int gpu_id = 0, bool enable_cls = false,
-            bool rotate_crops = false)
+            bool rotate_crops = false, int max_batch = 0)
       : worker_id_(worker_id), running_(false), is_idle_(true) {
+    if (max_batch <= 0) {
+      const char* e = getenv("OCR_WORKER_MAX_BATCH");
+      max_batch = e ? atoi(e) : 32;
+    }
+    max_batch_ = max_batch < 1 ? 1 : max_batch;
     if (!use_gpu) throw std::runtime_error("OCRWorker: this build has no CPU path (use_gpu must be true)");
     det_dir_ = model_dir + "/det"; cls_dir_ = model_dir + "/cls"; rec_dir_ = model_dir + "/rec";
     dict_ = model_dir + "/rec/ppocr_keys_v1.txt";
@@ -330,32 +341,92 @@ class OCRWorker {
     return result;
   }
 
+  // The same for several requests in one pipeline run; results[i] belongs to requests[i].  A failure of
+  // the batched run (one oversized image, say) falls back to request-by-request processing, so a request
+  // fails or succeeds exactly as it would alone.  processing_time_ms is the wall time of the run a request
+  // was part of.
+  std::vector<OCRResult> processBatch(const std::vector<const OCRRequest*>& requests) {
+    const auto t0 = std::chrono::high_resolution_clock::now();
+    std::vector<OCRResult> results(requests.size());
+    std::vector<ocr_img> imgs;
+    std::vector<size_t> owner;
+    for (size_t i = 0; i < requests.size(); ++i) {
+      results[i].request_id = requests[i]->request_id;
+      if (requests[i]->image_data.empty()) { results[i].error_message = "Empty image data provided"; continue; }
+      results[i].width = requests[i]->image_data.cols;
+      results[i].height = requests[i]->image_data.rows;
+      imgs.push_back(requests[i]->image_data.view().c());
+      owner.push_back(i);
+    }
+    if (imgs.empty()) return results;
+    if (imgs.size() == 1) { results[owner[0]] = processRequest(*requests[owner[0]]); return results; }
+    const int k = (int)imgs.size();
+    // result buffers live with the worker (grown once): 1000 words of up to 256 ids per image, as processRequest
+    if (batch_words_.size() < (size_t)k * 1000) { batch_words_.resize((size_t)k * 1000); batch_ids_.resize((size_t)k * 1000 * 256); }
+    std::vector<ocr_word>& words = batch_words_;
+    std::vector<int32_t>& ids = batch_ids_;
+    std::vector<int> off(k), cnt(k);
+    const int rc = ocr_pipe_run(pipe_, imgs.data(), k, words.data(), k * 1000, off.data(), cnt.data(), ids.data(),
+                                k * 1000 * 256, nullptr);
+    if (rc != OCR_OK) {
+      for (size_t j = 0; j < owner.size(); ++j) results[owner[j]] = processRequest(*requests[owner[j]]);
+      return results;
+    }
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count();
+    for (int j = 0; j < k; ++j) {
+      OCRResult& r = results[owner[j]];
+      r.success = true;
+      for (int i = off[j]; i < off[j] + cnt[j]; ++i) {
+        WordResult w;
+        for (int q = 0; q < words[i].ids_len; ++q) w.text += ocr_pipe_label(pipe_, ids[words[i].ids_off + q]);
+        w.confidence = words[i].confidence;
+        w.box.assign(4, std::vector<int>(2));
+        for (int q = 0; q < 4; ++q) { w.box[q][0] = words[i].box[2 * q]; w.box[q][1] = words[i].box[2 * q + 1]; }
+        r.words.push_back(std::move(w));
+      }
+      r.processing_time_ms = ms;
+    }
+    return results;
+  }
+  int maxBatch() const { return max_batch_; }
+
  private:
   void workerLoop() {
     while (running_) {
-      std::shared_ptr<OCRRequest> request;
+      std::vector<std::shared_ptr<OCRRequest>> batch;
       {
         std::unique_lock<std::mutex> lock(queue_mutex_);
         cv_.wait(lock, [this] { return !request_queue_.empty() || !running_; });
         if (!running_) break;
-        if (!request_queue_.empty()) { request = request_queue_.front(); request_queue_.pop(); is_idle_ = false; }
-      }
-      if (request) {
-        OCRResult r;
-        try {
-          r = processRequest(*request);
-        } catch (const std::exception& e) {
-          r.request_id = request->request_id;
-          r.success = false;
-          r.error_message = e.what();
+        while (!request_queue_.empty() && (int)batch.size() < max_batch_) {
+          batch.push_back(request_queue_.front());
+          request_queue_.pop();
         }
-        request->result_promise.set_value(detail::result_json(r, worker_id_));
-        is_idle_ = true;
+        if (!batch.empty()) is_idle_ = false;
       }
+      if (batch.empty()) continue;
+      std::vector<const OCRRequest*> ptrs;
+      for (auto& b : batch) ptrs.push_back(b.get());
+      std::vector<OCRResult> rs;
+      try {
+        rs = processBatch(ptrs);
+      } catch (const std::exception& e) {
+        rs.assign(batch.size(), OCRResult());
+        for (size_t i = 0; i < batch.size(); ++i) {
+          rs[i].request_id = batch[i]->request_id;
+          rs[i].success = false;
+          rs[i].error_message = e.what();
+        }
+      }
+      for (size_t i = 0; i < batch.size(); ++i) batch[i]->result_promise.set_value(detail::result_json(rs[i], worker_id_));
+      is_idle_ = true;
     }
   }
 
   int worker_id_;
+  int max_batch_ = 1;
+  std::vector<ocr_word> batch_words_;
+  std::vector<int32_t> batch_ids_;
   std::atomic<bool> running_, is_idle_;
   std::thread worker_thread_;
   std::queue<std::shared_ptr<OCRRequest>> request_queue_;

@@ -189,3 +189,49 @@ def test_ipc_recognize_matches_pipeline(pkg, built, card, tmp_path):
     finally:
         if proc.poll() is None:
             proc.kill()
+
+
+@pytest.mark.gpu
+def test_ipc_concurrent_requests_are_batched_with_identical_results(pkg, built, card, tmp_path):
+    """Concurrent clients: the worker takes the queued requests as one pipeline run (OCRWorker::processBatch).
+    Every reply must be what the request gets alone - same boxes, text and confidence bits."""
+    import threading
+    proc, sock = _start(tmp_path, 1)
+    try:
+        imgs = [card, np.ascontiguousarray(card[:, ::-1]), np.ascontiguousarray(card[::2, ::2]),
+                np.ascontiguousarray(card[100:700, 50:900])]
+        paths = []
+        for i, im in enumerate(imgs):
+            p = tmp_path / f"img{i}.png"
+            p.write_bytes(_png_bytes(im))
+            paths.append(str(p))
+        c0 = Client(sock)
+        alone = [c0.call({"command": "recognize", "image_path": p}) for p in paths]
+        assert all(a["success"] for a in alone) and len(alone[0]["words"]) > 0
+        nthreads, rounds = 8, 3
+        out = [[None] * rounds for _ in range(nthreads)]
+
+        def work(t):
+            c = Client(sock)
+            for r in range(rounds):
+                k = (t + r) % len(paths)
+                out[t][r] = (k, c.call({"command": "recognize", "image_path": paths[k]}))
+
+        th = [threading.Thread(target=work, args=(t,)) for t in range(nthreads)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        for t in range(nthreads):
+            for r in range(rounds):
+                k, got = out[t][r]
+                want = alone[k]
+                assert got["success"] is True and got["width"] == want["width"] and got["height"] == want["height"]
+                assert len(got["words"]) == len(want["words"])
+                for g, w in zip(got["words"], want["words"]):
+                    assert g["box"] == w["box"] and g["text"] == w["text"] and g["confidence"] == w["confidence"]
+        info = json.loads(c0.call({"command": "status"})["status"])
+        assert info["total_requests"] == len(paths) + nthreads * rounds == info["successful_requests"]
+        c0.call({"command": "shutdown"})
+        assert proc.wait(timeout=30) == 0
+    finally:
+        if proc.poll() is None:
+            proc.kill()

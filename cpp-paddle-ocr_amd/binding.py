@@ -82,7 +82,7 @@ def check(rc):
 def probe(a, b):
     a = np.ascontiguousarray(a, dtype=np.float32)
     b = np.ascontiguousarray(b, dtype=np.float32)
-    out = np.empty((6, a.size), dtype=np.float32)
+    out = np.empty((8, a.size), dtype=np.float32)
     check(lib().ocr_probe(a.ctypes.data, b.ctypes.data, out.ctypes.data, a.size))
     return out
 

@@ -156,11 +156,11 @@ int ocr_probe(const float* a, const float* b, float* out, int n) {
   float *da = nullptr, *db = nullptr, *dout = nullptr;
   CAPI_HIP(hipMalloc(&da, n * sizeof(float)));
   CAPI_HIP(hipMalloc(&db, n * sizeof(float)));
-  CAPI_HIP(hipMalloc(&dout, 6 * (size_t)n * sizeof(float)));
+  CAPI_HIP(hipMalloc(&dout, 8 * (size_t)n * sizeof(float)));
   CAPI_HIP(hipMemcpy(da, a, n * sizeof(float), hipMemcpyHostToDevice));
   CAPI_HIP(hipMemcpy(db, b, n * sizeof(float), hipMemcpyHostToDevice));
   launch_probe(da, db, dout, n, nullptr);
-  CAPI_HIP(hipMemcpy(out, dout, 6 * (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+  CAPI_HIP(hipMemcpy(out, dout, 8 * (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
   (void)hipFree(da); (void)hipFree(db); (void)hipFree(dout);
   return OCR_OK;
 }

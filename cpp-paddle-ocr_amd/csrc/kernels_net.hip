@@ -82,6 +82,7 @@ __device__ __forceinline__ float4 apply_epilogue4(const Epilogue& ep, float4 v, 
         t = v.w * sc.w; v.w = t + sh.w;
       } break;
       case EP_ACT:
+        if (st.act == ACT_HSWISH) { ocr_hswish4(v.x, v.y, v.z, v.w); break; }
         v.x = ocr_act(st.act, st.p0, st.p1, v.x); v.y = ocr_act(st.act, st.p0, st.p1, v.y);
         v.z = ocr_act(st.act, st.p0, st.p1, v.z); v.w = ocr_act(st.act, st.p0, st.p1, v.w);
         break;
@@ -185,7 +186,13 @@ __device__ __forceinline__ void conv_finish(const ConvArgs& a, const Epilogue& e
 #define OCR_ACT_SWEEP(KIND) OCR_EP_SWEEP({ wx = ocr_act(KIND, p0, p1, wx); wy = ocr_act(KIND, p0, p1, wy); wz = ocr_act(KIND, p0, p1, wz); ww = ocr_act(KIND, p0, p1, ww); })
         switch (st.act) {
           case ACT_RELU: OCR_ACT_SWEEP(ACT_RELU) break;
-          case ACT_HSWISH: OCR_ACT_SWEEP(ACT_HSWISH) break;
+          case ACT_HSWISH: {
+            // range pass, then the division-free sweep (ocr_common.h); anything out of range takes the division
+            float mn = INFINITY, mx = 0.0f;
+            OCR_EP_SWEEP({ ocr_absrange(mn, mx, wx, wy); ocr_absrange(mn, mx, wz, ww); })
+            if (ocr_hsw_fast_ok(mn, mx)) { OCR_EP_SWEEP({ ocr_hswish4_fast(wx, wy, wz, ww); }) }
+            else { OCR_ACT_SWEEP(ACT_HSWISH) }
+          } break;
           case ACT_HSIG: OCR_ACT_SWEEP(ACT_HSIG) break;
           case ACT_SWISH: OCR_ACT_SWEEP(ACT_SWISH) break;
           default: OCR_ACT_SWEEP(ACT_SIGMOID) break;
@@ -667,7 +674,7 @@ void launch_stem(const StemArgs& a, const Epilogue& ep, hipStream_t s) {
 // The K*K x Cs weights are copied to LDS once per workgroup (a workgroup's 256 threads span every channel
 // quad): a thread's 50 weight fetches per patch become LDS reads and leave the L1/TA path to the pixels.
 template <int K, int SW, int TO, int R>
-__global__ void __launch_bounds__(256) dw_conv_kernel(const DwArgs a, const Epilogue ep) {
+__global__ void __launch_bounds__(256, 2) dw_conv_kernel(const DwArgs a, const Epilogue ep) {
   constexpr int NIN = (TO - 1) * SW + K;
   extern __shared__ float4 s_dw_w[];  // [K*K][Cs/4]
   {
@@ -687,14 +694,18 @@ __global__ void __launch_bounds__(256) dw_conv_kernel(const DwArgs a, const Epil
   const long nb = sidx / strips;
   const int y0 = (int)(nb % bands) * R, n = (int)(nb / bands);
   const int x0 = sx * TO;
-  float4 acc[R][TO];
+  // Accumulators and arithmetic are written as explicit 2-vectors (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32:
+  // two f32 lanes per VALU slot, each lane the same IEEE operation as the scalar instruction), not left to the
+  // SLP vectoriser, whose pairing changes with unrelated edits of the epilogue.
+  struct F4 { ocr_f2 lo, hi; };
+  F4 acc[R][TO];
 #pragma unroll
   for (int r = 0; r < R; ++r)
 #pragma unroll
-    for (int o = 0; o < TO; ++o) acc[r][o] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int o = 0; o < TO; ++o) { acc[r][o].lo = ocr_f2{0.f, 0.f}; acc[r][o].hi = ocr_f2{0.f, 0.f}; }
   const int ixb = x0 * SW - a.PW, iyb = y0 * a.SH - a.PH;
   const int nrows = (R - 1) * a.SH + K;
-  // Two row buffers in ping-pong: row j+1 is in flight while row j is consumed (the kernel runs at 2-3
+  // Two row buffers in ping-pong: row j+1 is in flight while row j is consumed (the kernel runs at 2
   // waves/SIMD, so the bytes in flight per wave are what hides the memory latency).  Rows beyond the
   // image are zero rows; the row after the last one is loaded (clamped) and never used.
   auto load_row = [&](float4 (&in)[NIN], int j) {
@@ -716,13 +727,12 @@ __global__ void __launch_bounds__(256) dw_conv_kernel(const DwArgs a, const Epil
 #pragma unroll
       for (int kx = 0; kx < K; ++kx) {
         const float4 wv = wrow[kx * (a.Cs >> 2)];
+        const ocr_f2 wlo = {wv.x, wv.y}, whi = {wv.z, wv.w};
 #pragma unroll
         for (int o = 0; o < TO; ++o) {
           const float4 v = in[o * SW + kx];
-          acc[r][o].x = fmaf(v.x, wv.x, acc[r][o].x);
-          acc[r][o].y = fmaf(v.y, wv.y, acc[r][o].y);
-          acc[r][o].z = fmaf(v.z, wv.z, acc[r][o].z);
-          acc[r][o].w = fmaf(v.w, wv.w, acc[r][o].w);
+          acc[r][o].lo = __builtin_elementwise_fma(ocr_f2{v.x, v.y}, wlo, acc[r][o].lo);
+          acc[r][o].hi = __builtin_elementwise_fma(ocr_f2{v.z, v.w}, whi, acc[r][o].hi);
         }
       }
     }
@@ -748,38 +758,44 @@ __global__ void __launch_bounds__(256) dw_conv_kernel(const DwArgs a, const Epil
 #define OCR_DW_SWEEP(BODY)                                       \
   _Pragma("unroll") for (int r = 0; r < R; ++r)                   \
     _Pragma("unroll") for (int o = 0; o < TO; ++o) {              \
-      float4& v = acc[r][o];                                      \
+      F4& v = acc[r][o];                                          \
       BODY                                                        \
     }
     switch (st.kind) {
       case EP_BIAS: {
         const float4 b = *(const float4*)(st.v0 + pc);
-        OCR_DW_SWEEP({ v.x = v.x + b.x; v.y = v.y + b.y; v.z = v.z + b.z; v.w = v.w + b.w; })
+        const ocr_f2 blo = {b.x, b.y}, bhi = {b.z, b.w};
+        OCR_DW_SWEEP({ v.lo = v.lo + blo; v.hi = v.hi + bhi; })
       } break;
       case EP_SMUL: {
-        const float k = st.p0;
-        OCR_DW_SWEEP({ v.x = k * v.x; v.y = k * v.y; v.z = k * v.z; v.w = k * v.w; })
+        const ocr_f2 k = {st.p0, st.p0};
+        OCR_DW_SWEEP({ v.lo = k * v.lo; v.hi = k * v.hi; })
       } break;
       case EP_SADD: {
-        const float k = st.p0;
-        OCR_DW_SWEEP({ v.x = v.x + k; v.y = v.y + k; v.z = v.z + k; v.w = v.w + k; })
+        const ocr_f2 k = {st.p0, st.p0};
+        OCR_DW_SWEEP({ v.lo = v.lo + k; v.hi = v.hi + k; })
       } break;
       case EP_BN: {
         const float4 sc = *(const float4*)(st.v0 + pc), sh = *(const float4*)(st.v1 + pc);
+        const ocr_f2 clo = {sc.x, sc.y}, chi = {sc.z, sc.w}, hlo = {sh.x, sh.y}, hhi = {sh.z, sh.w};
         OCR_DW_SWEEP({
-          float u;
-          u = v.x * sc.x; v.x = u + sh.x;
-          u = v.y * sc.y; v.y = u + sh.y;
-          u = v.z * sc.z; v.z = u + sh.z;
-          u = v.w * sc.w; v.w = u + sh.w;
+          ocr_f2 u;
+          u = v.lo * clo; v.lo = u + hlo;
+          u = v.hi * chi; v.hi = u + hhi;
         })
       } break;
       case EP_ACT: {
         const float p0 = st.p0, p1 = st.p1;
-#define OCR_DW_ACT(KIND) OCR_DW_SWEEP({ v.x = ocr_act(KIND, p0, p1, v.x); v.y = ocr_act(KIND, p0, p1, v.y); v.z = ocr_act(KIND, p0, p1, v.z); v.w = ocr_act(KIND, p0, p1, v.w); })
+#define OCR_DW_ACT(KIND) OCR_DW_SWEEP({ v.lo.x = ocr_act(KIND, p0, p1, v.lo.x); v.lo.y = ocr_act(KIND, p0, p1, v.lo.y); v.hi.x = ocr_act(KIND, p0, p1, v.hi.x); v.hi.y = ocr_act(KIND, p0, p1, v.hi.y); })
         switch (st.act) {
           case ACT_RELU: OCR_DW_ACT(ACT_RELU) break;
-          case ACT_HSWISH: OCR_DW_ACT(ACT_HSWISH) break;
+          case ACT_HSWISH: {
+            // range pass, then the division-free sweep (ocr_common.h); anything out of range takes the division
+            float mn = INFINITY, mx = 0.0f;
+            OCR_DW_SWEEP({ ocr_absrange(mn, mx, v.lo.x, v.lo.y); ocr_absrange(mn, mx, v.hi.x, v.hi.y); })
+            if (ocr_hsw_fast_ok(mn, mx)) { OCR_DW_SWEEP({ v.lo = ocr_hswish2_fast(v.lo); v.hi = ocr_hswish2_fast(v.hi); }) }
+            else { OCR_DW_ACT(ACT_HSWISH) }
+          } break;
           case ACT_HSIG: OCR_DW_ACT(ACT_HSIG) break;
           case ACT_SWISH: OCR_DW_ACT(ACT_SWISH) break;
           default: OCR_DW_ACT(ACT_SIGMOID) break;
@@ -788,13 +804,17 @@ __global__ void __launch_bounds__(256) dw_conv_kernel(const DwArgs a, const Epil
       } break;
       case EP_MULC: {
         const float4 g = *(const float4*)(st.v0 + (long)n * a.Cs + pc);
-        OCR_DW_SWEEP({ v.x = v.x * g.x; v.y = v.y * g.y; v.z = v.z * g.z; v.w = v.w * g.w; })
+        const ocr_f2 glo = {g.x, g.y}, ghi = {g.z, g.w};
+        OCR_DW_SWEEP({ v.lo = v.lo * glo; v.hi = v.hi * ghi; })
       } break;
       case EP_ADDT:
         OCR_DW_SWEEP({
           if (y0 + r < a.OH && x0 + o < a.OW) {
             const float4 g = *(const float4*)(st.v0 + obase + r * orow + (long)o * a.Cs);
-            v.x = v.x + g.x; v.y = v.y + g.y; v.z = v.z + g.z; v.w = v.w + g.w;
+            ocr_f2 glo;
+            ocr_f2 ghi;
+            glo.x = g.x; glo.y = g.y; ghi.x = g.z; ghi.y = g.w;
+            v.lo = v.lo + glo; v.hi = v.hi + ghi;
           }
         })
         break;
@@ -806,7 +826,8 @@ __global__ void __launch_bounds__(256) dw_conv_kernel(const DwArgs a, const Epil
   for (int r = 0; r < R; ++r)
 #pragma unroll
     for (int o = 0; o < TO; ++o)
-      if (y0 + r < a.OH && x0 + o < a.OW) *(float4*)(a.out + obase + r * orow + (long)o * a.Cs) = acc[r][o];
+      if (y0 + r < a.OH && x0 + o < a.OW)
+        *(float4*)(a.out + obase + r * orow + (long)o * a.Cs) = make_float4(acc[r][o].lo.x, acc[r][o].lo.y, acc[r][o].hi.x, acc[r][o].hi.y);
 }
 
 template <int TO, int R>
@@ -1402,6 +1423,12 @@ __global__ void probe_kernel(const float* a, const float* b, float* out, int n) 
   float t = a[i] * b[i];
   out[4 * n + i] = t + a[i];
   out[5 * n + i] = rintf(a[i] * 1.44269504088896341f);
+  // hard-swish as the epilogues compute it: the quad form (range guard + division-free path) with this
+  // element and three neighbours, and the scalar contract form
+  float q0 = a[i], q1 = a[(i + 1) % n], q2 = b[i], q3 = a[(i + 7) % n];
+  ocr_hswish4(q0, q1, q2, q3);
+  out[6 * n + i] = q0;
+  out[7 * n + i] = q2;
 }
 void launch_probe(const float* a, const float* b, float* out, int n, hipStream_t s) {
   hipLaunchKernelGGL(probe_kernel, dim3((n + 255) / 256), dim3(256), 0, s, a, b, out, n);

@@ -65,6 +65,62 @@ struct Epilogue {
   EpStage st[OCR_MAX_EP];
 };
 
+#if defined(__HIPCC__)
+// ---- hard-swish without the IEEE division sequence ---------------------------------------------------
+// u / 6.0f costs 13 VALU slots per value (two v_div_scale, a quarter-rate v_rcp, five fma, v_div_fmas,
+// v_div_fixup), and VALU work is not hidden behind another wave's MFMAs on this chip
+// (tools/micro/mfma_valu.hip: the two add up), so epilogue instructions cost matrix time one for one.
+// With r = RN(1/6): q0 = RN(u*r), e = fma(-6, q0, u) is the exact residual and RN(q0 + e*r) is the
+// correctly rounded quotient whenever q0 is a normal number (Markstein); copysign restores -0.  Checked
+// against u / 6.0f over all 2^32 bit patterns (tools/check_div6.c, run by tests/test_identities.py): the only inputs that differ are those
+// whose q0 is denormal or not finite (exact ties exist only among denormal quotients).  For
+// u = y * clamp(y + 3, 0, 6) that cannot happen while 2^-119 <= |y| < 2^125 (then u = +-0 or
+// 2^-118 <= |u| < 2^128): a sweep first takes min/max of |y| over its values (one v_min3/v_max3 pair per
+// two values) and falls back to the division for anything outside, zero included.  NaN needs no guard: it
+// comes out as NaN either way.
+typedef float ocr_f2 __attribute__((ext_vector_type(2)));
+#define OCR_HSW_LO 0x1p-119f
+#define OCR_HSW_HI 0x1p+125f
+__device__ __forceinline__ void ocr_absrange(float& mn, float& mx, float a, float b) {
+  asm("v_min3_f32 %0, %0, |%1|, |%2|" : "+v"(mn) : "v"(a), "v"(b));
+  asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(mx) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ bool ocr_hsw_fast_ok(float mn, float mx) { return mn >= OCR_HSW_LO && mx < OCR_HSW_HI; }
+__device__ __forceinline__ ocr_f2 ocr_hswish2_fast(ocr_f2 y) {
+  const ocr_f2 three = {3.0f, 3.0f};
+  const ocr_f2 r = {0x1.555556p-3f, 0x1.555556p-3f};  // RN(1/6) = 0x3e2aaaab
+  const ocr_f2 m6 = {-6.0f, -6.0f};
+  ocr_f2 t = y + three;
+  t.x = fminf(fmaxf(t.x, 0.0f), 6.0f);
+  t.y = fminf(fmaxf(t.y, 0.0f), 6.0f);
+  const ocr_f2 u = y * t;
+  const ocr_f2 q0 = u * r;
+  const ocr_f2 e = __builtin_elementwise_fma(m6, q0, u);
+  ocr_f2 q = __builtin_elementwise_fma(e, r, q0);
+  q.x = __builtin_copysignf(q.x, u.x);
+  q.y = __builtin_copysignf(q.y, u.y);
+  return q;
+}
+// four values whose |y| range has been checked with ocr_hsw_fast_ok
+__device__ __forceinline__ void ocr_hswish4_fast(float& a, float& b, float& c, float& d) {
+  const ocr_f2 q0 = ocr_hswish2_fast(ocr_f2{a, b}), q1 = ocr_hswish2_fast(ocr_f2{c, d});
+  a = q0.x; b = q0.y; c = q1.x; d = q1.y;
+}
+__device__ __forceinline__ float ocr_hswish_div(float y) {
+  float t = fminf(fmaxf(y + 3.0f, 0.0f), 6.0f);
+  float u = y * t;
+  return u / 6.0f;
+}
+// self-contained form for code that handles one quad at a time
+__device__ __forceinline__ void ocr_hswish4(float& a, float& b, float& c, float& d) {
+  float mn = INFINITY, mx = 0.0f;
+  ocr_absrange(mn, mx, a, b);
+  ocr_absrange(mn, mx, c, d);
+  if (ocr_hsw_fast_ok(mn, mx)) ocr_hswish4_fast(a, b, c, d);
+  else { a = ocr_hswish_div(a); b = ocr_hswish_div(b); c = ocr_hswish_div(c); d = ocr_hswish_div(d); }
+}
+#endif
+
 OCR_HD float ocr_act(int act, float p0, float p1, float y) {
   switch (act) {
     case ACT_RELU: return fmaxf(y, 0.0f);

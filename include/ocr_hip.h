@@ -201,7 +201,7 @@ int ocr_net_timing(ocr_net* h, int enable);
 /* writes "name ms count flops bytes\n" lines */
 int ocr_net_timing_report(ocr_net* h, char* buf, size_t cap);
 
-/* numerics probe (tests): out[6*n] = a/b, sqrt|a|, ocr_expf(a), fma(a,b,a), a*b+a, rint(a*log2e) */
+/* numerics probe (tests): out[8*n] = a/b, sqrt|a|, ocr_expf(a), fma(a,b,a), a*b+a, rint(a*log2e), hswish(a), hswish(b) */
 int ocr_probe(const float* a, const float* b, float* out, int n);
 
 #ifdef __cplusplus

@@ -32,6 +32,37 @@ def test_numerics_probe_matches_ieee_and_contract(pkg, built):
     assert np.array_equal(out[4], (a * b) + a)                # a*b+a is NOT contracted (-ffp-contract=off)
 
 
+def _hswish_contract(y):
+    """ocr_act(ACT_HSWISH): t = clamp(y + 3, 0, 6); u = y * t; u / 6, every step rounded to f32."""
+    y = y.astype(np.float32)
+    with np.errstate(all="ignore"):
+        t = np.minimum(np.maximum(y + np.float32(3), np.float32(0)), np.float32(6))
+        return (y * t) / np.float32(6)
+
+
+def test_hswish_division_free_path_is_the_division(pkg, built):
+    """The epilogues replace u/6 by q0 = u*r, e = fma(-6, q0, u), q = fma(e, r, q0) behind a range guard
+    (ocr_common.h; tools/check_div6.c is the exhaustive CPU proof of the identity).  Here: the device code
+    itself on ordinary values and on every kind of edge - zeros of both signs, denormals, the binades where
+    the quotient goes denormal, exact ties among denormal quotients, huge values whose u overflows,
+    infinities - bit for bit against the contract's division."""
+    rs = np.random.RandomState(1)
+    bits = lambda v: np.asarray(v, np.float32).view(np.uint32)
+    edge = np.array([0.0, -0.0, 3e-45, -3e-45, 1e-39, -1e-39, 1.1754944e-38, -1.1754944e-38, 2e-38, 1e-37, -1e-36,
+                     1e-30, 5e37, 5.7e37, -5.7e37, 1e38, -1e38, 3.4e38, np.inf, -np.inf, -3.0, -3.0000002, -2.9999998,
+                     3.0, 2.9999998, 3.0000002, 6.0, -6.0], np.float32)
+    ties = (np.arange(1, 4000, dtype=np.uint32) * 2 + 1).view(np.float32)          # odd multiples of 2^-149
+    tiny = (rs.randint(1, 0x02000000, 20000).astype(np.uint32) | (rs.randint(0, 2, 20000).astype(np.uint32) << 31)).view(np.float32)
+    a = np.concatenate([edge, ties, -ties, tiny, rs.randn(60000).astype(np.float32) * 4,
+                        (rs.rand(20000).astype(np.float32) - 0.5) * 1e-3]).astype(np.float32)
+    b = np.concatenate([rs.randn(a.size - 3000).astype(np.float32) * 3, tiny[:3000]]).astype(np.float32)
+    out = pkg.probe(a, b)
+    want_a, want_b = _hswish_contract(a), _hswish_contract(b)
+    same = lambda g, w: (bits(g) == bits(w)) | (np.isnan(g) & np.isnan(w))
+    assert same(out[6], want_a).all(), a[~same(out[6], want_a)][:8]
+    assert same(out[7], want_b).all(), b[~same(out[7], want_b)][:8]
+
+
 @pytest.mark.parametrize("kind,shape", [("cls", (3, 48, 192)), ("det", (2, 64, 96)), ("det", (1, 192, 384)),
                                         ("rec", (3, 48, 160)), ("rec", (2, 28, 192)), ("rec", (1, 48, 1000))])
 def test_network_outputs_bit_identical(pkg, built, kind, shape):

@@ -34,6 +34,8 @@ struct ConvArgs {
 void launch_conv_mfma(const ConvArgs& a, const Epilogue& ep, int nt, hipStream_t s);
 // LDS-staged variant of the same GEMM (default when K = taps*Cs_in >= 64)
 void launch_conv_lds(const ConvArgs& a, const Epilogue& ep, int nt, hipStream_t s);
+// 3x3 s1 p1 conv with the input tile resident in LDS; returns false when the shape is not on that path
+bool launch_conv3x3_tile(const ConvArgs& a, const Epilogue& ep, int nt, hipStream_t s);
 // column tiles per wave for a GEMM with `tiles` 32-wide column tiles
 inline int conv_nt_for(int tiles) {
   static const char* e = getenv("OCR_CONV_NT_MAX");  // A/B measurements (results are identical)

@@ -603,6 +603,130 @@ __global__ void __launch_bounds__(256, 2) conv_lds_kernel(const ConvArgs a, cons
   conv_finish<NT, OUT_C8I>(a, ep, acc, nt0, m, h, s_par);
 }
 
+// =====================================================================================
+// 3x3 stride-1 pad-1 conv with the whole input tile resident in LDS (the DB neck/head 96 -> 24 convs:
+// 5.56 of det's 10.36 GFLOP).  conv_lds_kernel above re-stages the 128-pixel A tile for every tap and
+// channel chunk (27 chunks, a barrier each, the input fetched 9 times through L1/L2: rocprof 2.8x the
+// algorithmic HBM bytes, MFMA pipe 54 % busy).  Here a workgroup owns an 8 x 16 pixel tile of one image:
+//   fill   : the 10 x 18 halo region x all Cin channels goes global -> LDS once (coalesced 16-byte pieces,
+//            zero outside the image), rows padded by 16 B so the 16-lane groups of ds_read_b128 are
+//            conflict-free; ONE barrier
+//   K loop : 9 taps x C8 octets straight out of LDS, no further barrier; a wave = 2 tile rows x 16 columns
+//            (32 pixels) x NT column tiles; weight fragments come from L1/L2 a whole tap ahead (two
+//            register sets - occupancy is LDS-bound at 2 workgroups per CU, registers are free)
+// Same ascending (tap, channel) MFMA chain per output: bit-identical to the other conv kernels.
+// =====================================================================================
+template <int C8, int NT>
+__global__ void __launch_bounds__(256, 2) conv3x3_tile_kernel(const ConvArgs a, const Epilogue ep, const int tiles_x,
+                                                              const int tiles_y) {
+  constexpr int TH = 8, TW = 16, RH = TH + 2, RW = TW + 2;
+  constexpr int CS = C8 * 8, STRIDE = CS + 4;  // floats per staged pixel
+  constexpr int Q = CS / 4;                    // 16-byte pieces per pixel
+  extern __shared__ float4 s_tile4[];
+  float* s_tile = (float*)s_tile4;             // [RH*RW][STRIDE]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int p = lane & 31, h = lane >> 5;
+  const unsigned lb = xcd_swizzle(blockIdx.x, gridDim.x);
+  const unsigned groups = (unsigned)a.NTtot / NT;
+  const int nt0 = (int)(lb % groups) * NT;
+  unsigned tile = lb / groups;
+  const int tx = (int)(tile % tiles_x);
+  tile /= tiles_x;
+  const int ty = (int)(tile % tiles_y), n = (int)(tile / tiles_y);
+  const int y0 = ty * TH, x0 = tx * TW;
+  // ---- fill: (RH*RW) pixels x Q pieces, consecutive threads take consecutive pieces of a pixel
+  {
+    const float* img = a.in + (long)n * a.H * a.W * CS;
+    constexpr int PIECES = RH * RW * Q, PER_THR = (PIECES + 255) / 256;
+    float4 r[PER_THR];
+#pragma unroll
+    for (int i = 0; i < PER_THR; ++i) {
+      const int idx = tid + i * 256;
+      const int px = idx / Q, q = idx - px * Q;
+      const int py = px / RW, pxx = px - py * RW;
+      const int iy = y0 - 1 + py, ix = x0 - 1 + pxx;
+      const bool v = idx < PIECES && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+      r[i] = v ? *(const float4*)(img + ((long)iy * a.W + ix) * CS + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < PER_THR; ++i) {
+      const int idx = tid + i * 256;
+      const int px = idx / Q, q = idx - px * Q;
+      if (idx < PIECES) *(float4*)(s_tile + px * STRIDE + q * 4) = r[i];
+    }
+  }
+  __shared__ float s_par[OCR_MAX_EP * 2 * NT * 32];
+  conv_stage_params<NT>(a, ep, nt0, s_par);  // ends with the barrier that also publishes the tile
+
+  floatx16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+  const int ly = wave * 2 + (p >> 4), lx = p & 15;  // this lane's pixel inside the tile
+  const float* sA = s_tile + (ly * RW + lx) * STRIDE + 4 * h;
+  const float4* __restrict__ wf = (const float4*)a.wfrag + (long)nt0 * 64 + lane;
+  const long wstride = (long)a.NTtot * 64;
+  auto load_tap = [&](float4 (&bv)[C8][NT], int tap) {
+    const float4* q = wf + (long)(tap < 9 ? tap : 8) * C8 * wstride;
+#pragma unroll
+    for (int c = 0; c < C8; ++c)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) bv[c][t] = q[c * wstride + t * 64];
+  };
+  auto mul_tap = [&](const float4 (&bv)[C8][NT], int tap) {
+    const int ky = tap / 3, kx = tap - ky * 3;
+    const float* src = sA + (ky * RW + kx) * STRIDE;
+#pragma unroll
+    for (int c = 0; c < C8; ++c) {
+      const float4 av = *(const float4*)(src + c * 8);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[c][t].x, av.x, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[c][t].y, av.y, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[c][t].z, av.z, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[c][t].w, av.w, acc[t], 0, 0, 0);
+      }
+    }
+  };
+  float4 bA[C8][NT], bB[C8][NT];
+  load_tap(bA, 0);
+#pragma unroll 1
+  for (int tap = 0; tap < 9; tap += 2) {
+    load_tap(bB, tap + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mul_tap(bA, tap);
+    __builtin_amdgcn_sched_barrier(0);
+    if (tap + 1 < 9) {
+      load_tap(bA, tap + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      mul_tap(bB, tap + 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  const int oy = y0 + ly, ox = x0 + lx;
+  const long m = (oy < a.OH && ox < a.OW) ? ((long)n * a.OH + oy) * a.OW + ox : a.M;
+  conv_finish<NT, OUT_C8I>(a, ep, acc, nt0, m, h, s_par);
+}
+
+// true if the launch was taken (3x3, stride 1, pad 1, 96 input channels, C8I output); OCR_CONV_TILE=0 disables
+bool launch_conv3x3_tile(const ConvArgs& a, const Epilogue& ep, int nt, hipStream_t s) {
+  static const char* env = getenv("OCR_CONV_TILE");
+  if (env && env[0] == '0') return false;
+  if (!(a.KH == 3 && a.KW == 3 && a.PH == 1 && a.PW == 1 && a.OH == a.H && a.OW == a.W && a.out_mode == OUT_C8I)) return false;
+  if (a.Cs_in != 96 || nt != 1) return false;
+  const int tiles_x = (a.OW + 15) / 16, tiles_y = (a.OH + 7) / 8;
+  const dim3 grid((unsigned)((long)a.N * tiles_y * tiles_x * (a.NTtot / nt)));
+  const unsigned lds = 10 * 18 * (96 + 4) * sizeof(float);  // 72 000 B: two workgroups per CU
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)conv3x3_tile_kernel<12, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv3x3_tile_kernel<12, 1>), grid, dim3(256), lds, s, a, ep, tiles_x, tiles_y);
+  return true;
+}
+
 template <int NT>
 static void launch_conv_lds_nt(const ConvArgs& a, const Epilogue& ep, dim3 grid, hipStream_t s) {
   if (a.Cs_in % 32 == 0) hipLaunchKernelGGL((conv_lds_kernel<NT, 32>), grid, dim3(256), 0, s, a, ep);

@@ -555,7 +555,7 @@ bool Net::bind(int N, int H, int W, std::string& err) {
           // measured (gpurun_out r1g): LDS staging wins for multi-tap convs (3x3 96->24: 58 vs 51 TFLOP/s),
           // the direct kernel for 1x1 (480->480: 88 vs 71; thin K: 54 vs 39)
           const bool use_lds = a.out_mode == OUT_C8I && (impl ? !strcmp(impl, "lds") : (taps > 1 && in.cs >= 64));
-          if (use_lds) L.fn = [a, ep, nt](hipStream_t s) { launch_conv_lds(a, ep, nt, s); };
+          if (use_lds) L.fn = [a, ep, nt](hipStream_t s) { if (!launch_conv3x3_tile(a, ep, nt, s)) launch_conv_lds(a, ep, nt, s); };
           else L.fn = [a, ep, nt](hipStream_t s) { launch_conv_mfma(a, ep, nt, s); };
         }
       } break;

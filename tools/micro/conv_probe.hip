@@ -86,6 +86,10 @@ static void run(long M, int cin, int cout, int variant, int epi) {
 }
 
 int main(int argc, char** argv) {
+  if (argc >= 4) {  // conv_probe M cin cout [epi]
+    run(atol(argv[1]), atoi(argv[2]), atoi(argv[3]), 0, argc > 4 ? atoi(argv[4]) : 3);
+    return 0;
+  }
   run(1966080, 240, 240, 0, 0);
   run(1966080, 240, 240, 0, 3);
   run(491520, 480, 480, 0, 3);

@@ -30,6 +30,10 @@ struct ConvArgs {
   float* head_max;
   float* head_sum;
   int* head_idx;
+  // SE gate folded into the A operand of a 1x1 conv (the `ew mulc` pass it replaces computed x * gate[n][c],
+  // one rounding, and this conv then read the product): [N][Cs_in] physical channel order, null = none
+  const float* gate;
+  int gate_hw;  // pixels per image (row m belongs to image m / gate_hw)
 };
 void launch_conv_mfma(const ConvArgs& a, const Epilogue& ep, int nt, hipStream_t s);
 // LDS-staged variant of the same GEMM (default when K = taps*Cs_in >= 64)

@@ -328,7 +328,7 @@ __device__ __forceinline__ void conv_stage_params(const ConvArgs& a, const Epilo
 // B from the host-built fragment image (one 16-byte load per lane per n-tile per 8 channels).
 // No LDS, no barriers: four independent waves per workgroup.
 // =====================================================================================
-template <int NT, int MODE, bool TAP1>
+template <int NT, int MODE, bool TAP1, bool GATE = false>
 __global__ void __launch_bounds__(256, (NT <= 3 ? 4 : 3)) conv_mfma_kernel(const ConvArgs a, const Epilogue ep) {
   CONV_PROBE(0);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -364,6 +364,11 @@ __global__ void __launch_bounds__(256, (NT <= 3 ? 4 : 3)) conv_mfma_kernel(const
   const float* zpage = a.zeros + 4 * h;
   // ---- single tap: step j reads the lane's row at channel 8j and fragment block j
   const float* xrow = mvalid ? a.in + m * a.Cs_in + 4 * h : zpage;
+  // GATE: the SE gate of the lane's image, same four channels as the pixel load (single-tap only)
+  const float* grow = zpage;
+  if constexpr (GATE) {
+    if (mvalid) grow = a.gate + (long)((unsigned)m / (unsigned)a.gate_hw) * a.Cs_in + 4 * h;
+  }
   int p_step = 0;
   // ---- general: incremental (tap, c8) walk with selects
   int p_c8 = 0, p_ky = 0, p_kx = 0;
@@ -375,7 +380,8 @@ __global__ void __launch_bounds__(256, (NT <= 3 ? 4 : 3)) conv_mfma_kernel(const
     // this lane's pixel at tap (0,0), channel 4h; a tap adds the uniform offset (ky*W + kx)*Cs_in
     lane_base = a.in + 4 * h + (((long)n * a.H + (y - a.PH)) * a.W + (x - a.PW)) * a.Cs_in;
   }
-  auto load_step = [&](float4& av, float4 (&bv)[NT]) {
+  auto load_step = [&](float4& av, float4 (&bv)[NT], float4& gv) {
+    if constexpr (GATE) gv = *(const float4*)(grow + p_step * 8);
     if constexpr (TAP1) {
 #ifdef OCR_PROBE_NOX
       av = make_float4((float)(size_t)xrow, 1.f, 2.f, 3.f);
@@ -410,7 +416,9 @@ __global__ void __launch_bounds__(256, (NT <= 3 ? 4 : 3)) conv_mfma_kernel(const
       tap_off = ((long)p_ky * a.W + p_kx) * a.Cs_in + p_c8 * 8;
     }
   };
-  auto mfma_step = [&](const float4& av, const float4 (&bv)[NT]) {
+  auto mfma_step = [&](const float4& av0, const float4 (&bv)[NT], const float4& gv) {
+    float4 av = av0;
+    if constexpr (GATE) { av.x = av0.x * gv.x; av.y = av0.y * gv.y; av.z = av0.z * gv.z; av.w = av0.w * gv.w; }  // x * gate: one rounding, as ew_kernel did
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[t].x, av.x, acc[t], 0, 0, 0);
@@ -420,20 +428,21 @@ __global__ void __launch_bounds__(256, (NT <= 3 ? 4 : 3)) conv_mfma_kernel(const
     }
   };
   float4 a0, b0[NT], a1, b1[NT];
-  load_step(a0, b0);
+  float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0;
+  load_step(a0, b0, g0);
   CONV_PROBE(1);
   int kk = 0;
   for (; kk + 2 <= KK; kk += 2) {
-    load_step(a1, b1);
+    load_step(a1, b1, g1);
     __builtin_amdgcn_sched_barrier(0);  // keep the loads ahead of the MFMAs they overlap
-    mfma_step(a0, b0);
+    mfma_step(a0, b0, g0);
     __builtin_amdgcn_sched_barrier(0);
-    load_step(a0, b0);
+    load_step(a0, b0, g0);
     __builtin_amdgcn_sched_barrier(0);
-    mfma_step(a1, b1);
+    mfma_step(a1, b1, g1);
     __builtin_amdgcn_sched_barrier(0);
   }
-  if (kk < KK) mfma_step(a0, b0);
+  if (kk < KK) mfma_step(a0, b0, g0);
   CONV_PROBE(2);
 
   // ---- epilogue: lane owns output column j (one channel), 16 rows ----
@@ -451,6 +460,16 @@ void launch_conv_mfma(const ConvArgs& a, const Epilogue& ep, int nt, hipStream_t
     default: hipLaunchKernelGGL((conv_mfma_kernel<4, MODE, TAP1>), grid, dim3(256), 0, s, a, ep); break;        \
   }
   const bool tap1 = a.KH == 1 && a.KW == 1 && a.PH == 0 && a.PW == 0 && a.OH == a.H && a.OW == a.W;
+  if (a.gate) {
+    if (!(tap1 && a.out_mode == OUT_C8I)) { fprintf(stderr, "launch_conv_mfma: gated input needs a 1x1 conv with a C8I output\n"); abort(); }
+    switch (nt) {
+      case 1: hipLaunchKernelGGL((conv_mfma_kernel<1, OUT_C8I, true, true>), grid, dim3(256), 0, s, a, ep); break;
+      case 2: hipLaunchKernelGGL((conv_mfma_kernel<2, OUT_C8I, true, true>), grid, dim3(256), 0, s, a, ep); break;
+      case 3: hipLaunchKernelGGL((conv_mfma_kernel<3, OUT_C8I, true, true>), grid, dim3(256), 0, s, a, ep); break;
+      default: hipLaunchKernelGGL((conv_mfma_kernel<4, OUT_C8I, true, true>), grid, dim3(256), 0, s, a, ep); break;
+    }
+    return;
+  }
   if (a.out_mode == OUT_HEAD && tap1) { OCR_LAUNCH_MODE(OUT_HEAD, true) }
   else if (a.out_mode == OUT_PLAIN && tap1) { OCR_LAUNCH_MODE(OUT_PLAIN, true) }
   else if (a.out_mode == OUT_DECONV && tap1) { OCR_LAUNCH_MODE(OUT_DECONV, true) }

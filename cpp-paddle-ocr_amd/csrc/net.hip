@@ -389,10 +389,42 @@ bool Net::bind(int N, int H, int W, std::string& err) {
   }
   // 2. arena with liveness reuse
   const int nops = (int)plan_.ops.size();
+  // SE gate folding: `ew x -> x * gate[n][c]` whose only reader is a 1x1 conv disappears - the conv reads x and
+  // the gate and forms the same product (one rounding) on its way into the matrix pipe.  Saves a full read +
+  // write pass per SE block (cls: 9, rec: 2, det backbone: 2).  Not in keep-all mode (every plan tensor must
+  // exist for the parity taps); OCR_FUSE_GATE=0 disables (A/B measurements, results are identical).
+  std::vector<int> gate_src(nops, -1), gate_tid(nops, -1);
+  std::vector<char> folded(nops, 0);
+  static const char* fuse_env = getenv("OCR_FUSE_GATE");
+  if (!keep_all_ && !(fuse_env && fuse_env[0] == '0')) {
+    std::vector<int> uses(plan_.ntensors, 0);
+    for (auto& op : plan_.ops) {
+      if (op.in >= 0) uses[op.in]++;
+      for (int t : op.ins) uses[t]++;
+      for (auto& st : op.ep) if (st.tid >= 0) uses[st.tid]++;
+    }
+    for (int oi = 0; oi < nops; ++oi) {
+      auto& op = plan_.ops[oi];
+      if (op.kind != PlanOp::EW || op.ep.size() != 1 || op.ep[0].kind != EP_MULC || op.out == out_tid_ || uses[op.out] != 1) continue;
+      for (int oj = oi + 1; oj < nops; ++oj) {
+        auto& c = plan_.ops[oj];
+        if (c.in != op.out) continue;
+        const bool one = c.kind == PlanOp::CONV && c.kh == 1 && c.kw == 1 && c.sh == 1 && c.sw == 1 && c.ph == 0 && c.pw == 0 && c.cin != 3;
+        if (one && !T[c.out].plain && (long)T[op.in].n * T[op.in].h * T[op.in].w < 0x7fffffffL) {
+          folded[oi] = 1;
+          gate_src[oj] = op.in;
+          gate_tid[oj] = op.ep[0].tid;
+        }
+        break;
+      }
+    }
+  }
   std::vector<int> last(plan_.ntensors, -1);
   for (int oi = 0; oi < nops; ++oi) {
     auto& op = plan_.ops[oi];
-    if (op.in >= 0) last[op.in] = oi;
+    if (folded[oi]) continue;  // its reads happen in the conv it was folded into
+    if (gate_src[oi] >= 0) { last[gate_src[oi]] = oi; last[gate_tid[oi]] = oi; }
+    else if (op.in >= 0) last[op.in] = oi;
     for (int t : op.ins) last[t] = oi;
     for (auto& st : op.ep) if (st.tid >= 0) last[st.tid] = oi;
   }
@@ -428,6 +460,7 @@ bool Net::bind(int N, int H, int W, std::string& err) {
   };
   for (int oi = 0; oi < nops; ++oi) {
     auto& op = plan_.ops[oi];
+    if (folded[oi]) { T[op.out].offset = 0; continue; }  // never materialised
     if (op.out >= 0) T[op.out].offset = alloc(T[op.out].numel());
     if (op.kind == PlanOp::GAP) gap_need = std::max(gap_need, (size_t)T[op.in].n * T[op.in].h * T[op.in].cs);
     // free tensors whose last reader is this op (never the op's own output)
@@ -436,7 +469,9 @@ bool Net::bind(int N, int H, int W, std::string& err) {
   }
   // `top` may have shrunk at the end; capacity must cover the high-water mark
   size_t high = 0;
-  for (int t = 1; t < plan_.ntensors; ++t) high = std::max(high, T[t].offset + ((T[t].numel() + 63) & ~(size_t)63));
+  std::vector<char> dead(plan_.ntensors, 0);
+  for (int oi = 0; oi < nops; ++oi) if (folded[oi]) dead[plan_.ops[oi].out] = 1;
+  for (int t = 1; t < plan_.ntensors; ++t) if (!dead[t]) high = std::max(high, T[t].offset + ((T[t].numel() + 63) & ~(size_t)63));
   if (high > arena_cap_) {
     if (arena_) (void)hipFree(arena_);
     arena_ = nullptr;
@@ -456,13 +491,13 @@ bool Net::bind(int N, int H, int W, std::string& err) {
   char nm[160];
   for (int oi = 0; oi < nops; ++oi) {
     auto& op = plan_.ops[oi];
-    if (op.kind == PlanOp::OUTPUT) continue;
+    if (op.kind == PlanOp::OUTPUT || folded[oi]) continue;
     const TensorDesc& o = T[op.out];
     float* optr = arena_ + o.offset;
     Launch L;
     switch (op.kind) {
       case PlanOp::CONV: case PlanOp::LINEAR: case PlanOp::DECONV: {
-        const TensorDesc& in = T[op.in];
+        const TensorDesc& in = T[gate_src[oi] >= 0 ? gate_src[oi] : op.in];
         Epilogue ep;
         if (op.kind == PlanOp::CONV && op.cin == 3) {
           if (!build_epilogue(op, ep, false, err)) return false;
@@ -540,6 +575,7 @@ bool Net::bind(int N, int H, int W, std::string& err) {
             fused_head_groups_ = groups;
           }
           a.zeros = dev_vec("zeros");
+          if (gate_src[oi] >= 0) { a.gate = arena_ + T[gate_tid[oi]].offset; a.gate_hw = in.h * in.w; }
           a.M = (long)in.n * a.OH * a.OW;
           if (op.kind == PlanOp::LINEAR) a.M = (long)in.n * in.h * in.w;
           const int taps = a.KH * a.KW;
@@ -548,13 +584,14 @@ bool Net::bind(int N, int H, int W, std::string& err) {
           L.name = nm;
           const double cols = op.kind == PlanOp::DECONV ? 4.0 * op.cout : op.cout;
           L.flops = 2.0 * a.M * taps * op.cin * cols;
+          if (a.gate) L.name += "_gated";
           L.bytes = 4.0 * ((double)a.M * op.cin + (a.out_mode == OUT_HEAD ? 3.0 * a.M * (a.NTtot / nt) : (double)a.M * cols) +
                            (double)taps * op.cin * cols);
           // OCR_CONV_IMPL=direct|lds overrides the choice (A/B measurements); results are identical
           static const char* impl = getenv("OCR_CONV_IMPL");
           // measured (gpurun_out r1g): LDS staging wins for multi-tap convs (3x3 96->24: 58 vs 51 TFLOP/s),
           // the direct kernel for 1x1 (480->480: 88 vs 71; thin K: 54 vs 39)
-          const bool use_lds = a.out_mode == OUT_C8I && (impl ? !strcmp(impl, "lds") : (taps > 1 && in.cs >= 64));
+          const bool use_lds = !a.gate && a.out_mode == OUT_C8I && (impl ? !strcmp(impl, "lds") : (taps > 1 && in.cs >= 64));
           if (use_lds) L.fn = [a, ep, nt](hipStream_t s) { if (!launch_conv3x3_tile(a, ep, nt, s)) launch_conv_lds(a, ep, nt, s); };
           else L.fn = [a, ep, nt](hipStream_t s) { launch_conv_mfma(a, ep, nt, s); };
         }

@@ -310,6 +310,8 @@ int ocr_pipe_timing(ocr_pipe* h, int enable) {
   h->rec.net().reset_timings();
   h->rec.net2().enable_timing(enable != 0);
   h->rec.net2().reset_timings();
+  h->rec.net3().enable_timing(enable != 0);
+  h->rec.net3().reset_timings();
   return OCR_OK;
 }
 int ocr_pipe_timing_filter(ocr_pipe* h, const char* substr) {
@@ -318,18 +320,27 @@ int ocr_pipe_timing_filter(ocr_pipe* h, const char* substr) {
   h->det.net().set_timing_filter(f);
   h->rec.net().set_timing_filter(f);
   h->rec.net2().set_timing_filter(f);
+  h->rec.net3().set_timing_filter(f);
   return OCR_OK;
 }
 int ocr_pipe_timing_report(ocr_pipe* h, char* buf, size_t cap) {
   if (!h || !buf) return fail(OCR_ERR_ARG, "null argument");
   size_t off = 0;
-  for (Net* net : {&h->det.net(), &h->rec.net(), &h->rec.net2()})
+  // the two halves of a split rec launch have the same instance names: one row per name
+  std::map<std::string, KernelTiming> all;
+  for (Net* net : {&h->det.net(), &h->rec.net(), &h->rec.net2(), &h->rec.net3()})
     for (auto& kv : net->timings()) {
+      KernelTiming& t = all[kv.first];
+      t.ms += kv.second.ms; t.count += kv.second.count; t.flops += kv.second.flops; t.bytes += kv.second.bytes;
+    }
+  {
+    for (auto& kv : all) {
       int n = snprintf(buf + off, cap > off ? cap - off : 0, "%s %.6f %ld %.0f %.0f\n", kv.first.c_str(), kv.second.ms,
                        kv.second.count, kv.second.flops, kv.second.bytes);
       if (n < 0 || off + n >= cap) return fail(OCR_ERR_CAPACITY, "report buffer too small");
       off += n;
     }
+  }
   if (off < cap) buf[off] = 0;
   return OCR_OK;
 }

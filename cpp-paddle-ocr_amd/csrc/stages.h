@@ -123,6 +123,7 @@ class RecStage {
   hipStream_t stream() const { return stream_; }
   Net& net() { return net_; }
   Net& net2() { return net2_; }
+  Net& net3() { return net3_; }
   // per-step taps of the last run, in input order: T per line, amax/pmax concatenated
   std::vector<int> tap_T, tap_off;
   std::vector<int> tap_amax;
@@ -130,12 +131,14 @@ class RecStage {
 
  private:
   RecConfig cfg_;
-  Net net_, net2_;          // two execution lanes (see run_lines)
-  hipStream_t stream_ = nullptr, stream2_ = nullptr;
+  Net net_, net2_, net3_;   // execution lanes (see run_lines): 0 and 2 share the big launch, 1 takes the small ones
+  hipStream_t stream_ = nullptr, stream2_ = nullptr, stream3_ = nullptr;
+  int split_tail_ = -1;     // index of the second half in the current launch list
+  int split_ = 1;           // parts the largest launch is cut into (OCR_REC_SPLIT, 1 or 2)
   hipEvent_t ev_descs_ = nullptr;
   StageTimer timer_;
   std::vector<std::string> labels_;
-  DevBuf<float> lut_, x_, x2_, pmax_, scores_;
+  DevBuf<float> lut_, x_, x2_, x3_, pmax_, scores_;
   DevBuf<int> amax_, ids_, lens_;
   DevBuf<uint8_t> staging_;
   DevBuf<LineDesc> descs_;

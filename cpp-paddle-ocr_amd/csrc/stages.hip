@@ -254,6 +254,7 @@ int DetStage::post_only(const float* prob, int rows, int cols, int src_rows, int
 RecStage::~RecStage() {
   if (stream_) (void)hipStreamDestroy(stream_);
   if (stream2_) (void)hipStreamDestroy(stream2_);
+  if (stream3_) (void)hipStreamDestroy(stream3_);
   if (ev_descs_) (void)hipEventDestroy(ev_descs_);
 }
 
@@ -274,13 +275,15 @@ bool RecStage::create(const RecConfig& cfg, std::string& err, int& code) {
   labels_.push_back(" ");
   WeightMap w;
   if (!load_model_dir(cfg.model_dir, nullptr, w, err)) return false;
-  if (!net_.load(embedded_plan("rec"), w, err) || !net2_.load(embedded_plan("rec"), w, err)) return false;
+  if (!net_.load(embedded_plan("rec"), w, err) || !net2_.load(embedded_plan("rec"), w, err) || !net3_.load(embedded_plan("rec"), w, err)) return false;
+  if (const char* e = getenv("OCR_REC_SPLIT")) split_ = atoi(e) >= 2 ? 2 : 1;
   code = OCR_ERR_DEVICE;
   // lane 1 carries the small odd-width launches: a high-priority queue, so their workgroups are placed
   // as soon as slots free up instead of waiting behind the thousands queued by lane 0's big kernels
   int prio_lo = 0, prio_hi = 0;
   (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
   if (hipStreamCreate(&stream_) != hipSuccess || hipStreamCreateWithPriority(&stream2_, hipStreamDefault, prio_hi) != hipSuccess ||
+      hipStreamCreate(&stream3_) != hipSuccess ||
       hipEventCreateWithFlags(&ev_descs_, hipEventDisableTiming) != hipSuccess) { err = "hipStreamCreate failed"; return false; }
   if (!timer_.init(err)) return false;
   const float mean[3] = {0.5f, 0.5f, 0.5f}, scale[3] = {1 / 0.5f, 1 / 0.5f, 1 / 0.5f};  // ocr_rec.h:108-109
@@ -349,6 +352,22 @@ int RecStage::run_lines(const std::vector<LineSrc>& lines, const std::vector<int
     for (size_t b = 0; b < kv.second.size(); b += max_lines_per_launch)
       launches.emplace_back(kv.first, std::vector<Item>(kv.second.begin() + b,
                                                         kv.second.begin() + std::min(kv.second.size(), b + (size_t)max_lines_per_launch)));
+  // The largest launch can be cut in two halves that run on two streams (lanes 0 and 2): the memory-bound
+  // kernels of one half (depthwise, SE, pooling) then share the chip with the matrix-bound 1x1 convs of the
+  // other instead of each running alone.  Samples of a launch are independent: results do not change.
+  if (split_ == 2 && !launches.empty()) {
+    size_t bi = 0;
+    for (size_t i = 1; i < launches.size(); ++i)
+      if ((long)launches[i].second.size() * launches[i].first > (long)launches[bi].second.size() * launches[bi].first) bi = i;
+    const size_t cnt = launches[bi].second.size();
+    if (cnt >= 256) {
+      const size_t half = (cnt / 2 + 15) / 16 * 16;
+      std::vector<Item> tail(launches[bi].second.begin() + half, launches[bi].second.end());
+      launches[bi].second.resize(half);
+      launches.emplace_back(launches[bi].first, std::move(tail));
+      split_tail_ = (int)launches.size() - 1;
+    } else split_tail_ = -1;
+  } else split_tail_ = -1;
   tap_T.assign(n, 0);
   tap_off.assign(n, 0);
   tap_amax.clear();
@@ -366,16 +385,16 @@ int RecStage::run_lines(const std::vector<LineSrc>& lines, const std::vector<int
   std::vector<Slot> slots(nl);
   size_t step_total = 0, line_total = 0;
   for (int i = 0; i < nl; ++i) {
-    slots[i] = Slot{(i == big || nl == 1) ? 0 : 1, (int)launches[i].second.size(), launches[i].first, 0, step_total, line_total};
+    slots[i] = Slot{(i == big || nl == 1) ? 0 : (i == split_tail_ ? 2 : 1), (int)launches[i].second.size(), launches[i].first, 0, step_total, line_total};
     step_total += (size_t)slots[i].ng * (launches[i].first / 4 + 8);  // >= ng * T
     line_total += slots[i].ng;
   }
   if (!amax_.ensure(step_total, err) || !pmax_.ensure(step_total, err) || !ids_.ensure(line_total * max_len, err) ||
       !lens_.ensure(line_total, err) || !scores_.ensure(line_total, err) || !descs_.ensure(line_total, err))
     return OCR_ERR_DEVICE;
-  size_t xneed[2] = {0, 0};
+  size_t xneed[3] = {0, 0, 0};
   for (int i = 0; i < nl; ++i) xneed[slots[i].lane] = std::max(xneed[slots[i].lane], (size_t)slots[i].ng * imgH * slots[i].Wt * 3);
-  if (!x_.ensure(xneed[0], err) || !x2_.ensure(xneed[1], err)) return OCR_ERR_DEVICE;
+  if (!x_.ensure(xneed[0], err) || !x2_.ensure(xneed[1], err) || !x3_.ensure(xneed[2], err)) return OCR_ERR_DEVICE;
   std::vector<LineDesc> d(line_total);
   for (int i = 0; i < nl; ++i)
     for (int j = 0; j < slots[i].ng; ++j) {
@@ -385,13 +404,14 @@ int RecStage::run_lines(const std::vector<LineSrc>& lines, const std::vector<int
   ST_HIP(hipMemcpyAsync(descs_.p, d.data(), line_total * sizeof(LineDesc), hipMemcpyHostToDevice, stream_));
   ST_HIP(hipEventRecord(ev_descs_, stream_));
   ST_HIP(hipStreamWaitEvent(stream2_, ev_descs_, 0));
-  for (int pass = 0; pass < 2; ++pass) {      // lane 0's launch first so the big kernels are queued early
+  ST_HIP(hipStreamWaitEvent(stream3_, ev_descs_, 0));
+  for (int pass : {0, 2, 1}) {      // the big launches first so their kernels are queued early
     for (int i = 0; i < nl; ++i) {
       Slot& sl = slots[i];
       if (sl.lane != pass) continue;
-      Net& net = sl.lane ? net2_ : net_;
-      hipStream_t st = sl.lane ? stream2_ : stream_;
-      float* x = sl.lane ? x2_.p : x_.p;
+      Net& net = sl.lane == 0 ? net_ : (sl.lane == 1 ? net2_ : net3_);
+      hipStream_t st = sl.lane == 0 ? stream_ : (sl.lane == 1 ? stream2_ : stream3_);
+      float* x = sl.lane == 0 ? x_.p : (sl.lane == 1 ? x2_.p : x3_.p);
       launch_line_pre(descs_.p + sl.line_off, sl.ng, imgH, sl.Wt, lut_.p, false, x, st);
       net.set_head_outputs(nullptr, amax_.p + sl.step_off, pmax_.p + sl.step_off);
       if (!net.run(x, sl.ng, imgH, sl.Wt, st, err)) return OCR_ERR_DEVICE;
@@ -405,6 +425,7 @@ int RecStage::run_lines(const std::vector<LineSrc>& lines, const std::vector<int
     }
   }
   ST_HIP(hipStreamSynchronize(stream2_));
+  ST_HIP(hipStreamSynchronize(stream3_));
   std::vector<int> h_ids(line_total * max_len), h_lens(line_total), h_amax;
   std::vector<float> h_scores(line_total), h_pmax;
   ST_HIP(hipMemcpyAsync(h_ids.data(), ids_.p, h_ids.size() * sizeof(int), hipMemcpyDeviceToHost, stream_));
@@ -419,6 +440,7 @@ int RecStage::run_lines(const std::vector<LineSrc>& lines, const std::vector<int
   ST_HIP(hipStreamSynchronize(stream_));
   net_.collect_timings();
   net2_.collect_timings();
+  net3_.collect_timings();
   for (int i = 0; i < nl; ++i) {
     const Slot& sl = slots[i];
     for (int j = 0; j < sl.ng; ++j) {

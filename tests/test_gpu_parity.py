@@ -63,6 +63,20 @@ def test_hswish_division_free_path_is_the_division(pkg, built):
     assert same(out[7], want_b).all(), b[~same(out[7], want_b)][:8]
 
 
+@pytest.mark.parametrize("kind,shape", [("cls", (5, 48, 192)), ("det", (3, 96, 128)), ("rec", (5, 48, 320)), ("rec", (2, 28, 192))])
+def test_production_mode_output_bit_identical(pkg, built, kind, shape):
+    """keep_all=False is what the stages run: liveness-reused arena, and the SE gate multiplies folded into
+    the 1x1 convs that read them (net.hip, `folded`).  Several images per launch so that the per-image gate
+    rows matter; the final output must still equal the oracle's bit for bit."""
+    from oracle import OracleNet
+    x = np.random.RandomState(11).randn(shape[0], shape[1], shape[2], 3).astype(np.float32)
+    o = OracleNet(kind)
+    g = pkg.Net(kind)
+    yo, yg = o.run(x), g.forward(x, keep_all=False)
+    assert yo.shape == yg.shape and np.array_equal(yo, yg)
+    g.close()
+
+
 @pytest.mark.parametrize("kind,shape", [("cls", (3, 48, 192)), ("det", (2, 64, 96)), ("det", (1, 192, 384)),
                                         ("rec", (3, 48, 160)), ("rec", (2, 28, 192)), ("rec", (1, 48, 1000))])
 def test_network_outputs_bit_identical(pkg, built, kind, shape):

@@ -2,11 +2,10 @@
 with the gfx950 corrections of MI355X_MICROARCH.md §HBM: bytes_read = FETCH_SIZE * 1024 * 2 (FETCH_SIZE
 tallies the 128-B requests of a wide coalesced stream at 64 B), bytes_written = WRITE_SIZE * 1024.
 
-The dominant kernel of bench.py is rec op 30 (conv1x1 480->480 at H/8 = 6 rows): conv_mfma_kernel<3, ...>
-on the 1872-line launch (all width-320 lines of the 64 images) has grid 35100 workgroups x 256 threads
-(M = 1872*6*80 rows / 128 x 5 column groups).  rec ops 25, 32 and 34 share that kernel and grid; within
-one forward pass they are dispatched in plan order 25, 30, 32, 34, so op 30 is every fourth dispatch
-starting at the second.
+The dominant kernel of bench.py is rec op 30 (conv1x1 480->480 at H/8 = 6 rows, reading the SE-gated
+depthwise output): conv_mfma_kernel<3, ...> on the 1872-line launch (all width-320 lines of the 64 images)
+has grid 35100 workgroups x 256 threads (M = 1872*6*80 rows / 128 x 5 column groups).  rec ops 25, 32 and
+34 have the same grid; see sel() for which dispatches are op 30.
 
     python tools/pmc_traffic.py gpurun_out/prof_<tag> profiles/<name>.json
 """
@@ -31,7 +30,14 @@ def main():
     root, dst = sys.argv[1], sys.argv[2]
     LINES = 1872
     grid = (LINES * 6 * 80 // 128) * 5 * 256
-    sel = lambda rs: [r for r in rs if "conv_mfma_kernel<3" in r[1] and r[2] == grid][1::4]
+    # with the SE gate folded into its consumers (net.hip) ops 25 and 30 run the GATE instantiation
+    # conv_mfma_kernel<3, 0, true, true> on this grid, in that order: op 30 is every second dispatch of it;
+    # with OCR_FUSE_GATE=0 ops 25, 30, 32, 34 share one kernel and op 30 is every fourth starting at the second
+    def sel(rs):
+        gated = [r for r in rs if "conv_mfma_kernel<3, 0, true, true>" in r[1] and r[2] == grid]
+        if gated:
+            return gated[1::2]
+        return [r for r in rs if "conv_mfma_kernel<3" in r[1] and r[2] == grid][1::4]
     fe = sel(rows(os.path.join(root, "pmc_fetch"), "FETCH_SIZE"))
     wr = sel(rows(os.path.join(root, "pmc_write"), "WRITE_SIZE"))
     mf = sel(rows(os.path.join(root, "pmc_sq"), "SQ_VALU_MFMA_BUSY_CYCLES"))
@@ -41,8 +47,9 @@ def main():
     M, K, N = LINES * 6 * 80, 480, 480
     alg = 4.0 * (M * K + M * N + K * N)
     out = {
-        "kernel": "rec.30.conv1x1_480_480@%dx48x320" % LINES,
-        "launch": "conv_mfma_kernel<3, OUT_C8I, single-tap>, grid %dx256 (the %d-line, width-320 launch)" % (grid // 256, LINES),
+        "kernel": "rec.30.conv1x1_480_480%s@%dx48x320" % ("_gated" if any("true, true>" in r[1] for r in fe) else "", LINES),
+        "launch": "conv_mfma_kernel<3, OUT_C8I, single-tap%s>, grid %dx256 (the %d-line, width-320 launch)" % (
+            ", SE gate folded into the A operand" if any("true, true>" in r[1] for r in fe) else "", grid // 256, LINES),
         "dispatches_averaged": len(fe),
         "hbm_read_bytes_per_launch": rd,
         "hbm_write_bytes_per_launch": wb,

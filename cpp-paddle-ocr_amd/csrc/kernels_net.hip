@@ -737,10 +737,14 @@ bool launch_conv3x3_tile(const ConvArgs& a, const Epilogue& ep, int nt, hipStrea
   const int tiles_x = (a.OW + 15) / 16, tiles_y = (a.OH + 7) / 8;
   const dim3 grid((unsigned)((long)a.N * tiles_y * tiles_x * (a.NTtot / nt)));
   const unsigned lds = 10 * 18 * (96 + 4) * sizeof(float);  // 72 000 B: two workgroups per CU
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)conv3x3_tile_kernel<12, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
+  // more than 64 KB of dynamic LDS has to be allowed per device (a worker pool drives several from one process)
+  static bool attr_set[64] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+    if (hipFuncSetAttribute((const void*)conv3x3_tile_kernel<12, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return false;  // the general kernel takes the launch
+    if (dev >= 0 && dev < 64) attr_set[dev] = true;
   }
   hipLaunchKernelGGL((conv3x3_tile_kernel<12, 1>), grid, dim3(256), lds, s, a, ep, tiles_x, tiles_y);
   return true;

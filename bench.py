@@ -107,7 +107,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("OCR_BENCH_FORCE_DIST"):  # the env switch rehearses the RCCL path with one rank
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local)

@@ -75,7 +75,10 @@ class Net {
   // --- det tail options: fused u8 threshold bitmap (null = none) ---
   void set_det_bitmap(uint8_t* bitmap, int ithresh) { det_bitmap_ = bitmap; det_ithresh_ = ithresh; bound_n_ = -1; }
   // --- rec/cls head options: where the row softmax leaves its results ---
-  void set_head_outputs(float* probs, int* amax, float* pmax) { head_probs_ = probs; head_amax_ = amax; head_pmax_ = pmax; bound_n_ = -1; }
+  void set_head_outputs(float* probs, int* amax, float* pmax) {
+    if (probs == head_probs_ && amax == head_amax_ && pmax == head_pmax_) return;  // unchanged: keep the binding (and its graph)
+    head_probs_ = probs; head_amax_ = amax; head_pmax_ = pmax; bound_n_ = -1;
+  }
 
   // parity debugging: give every tensor its own arena slot so intermediate taps stay valid
   void set_keep_all(bool on) { keep_all_ = on; bound_n_ = -1; }
@@ -125,6 +128,14 @@ class Net {
   std::string timing_filter_;
   bool keep_all_ = false;
   std::map<std::string, KernelTiming> timings_;
+  // hipGraph of the bound launch list: captured on the second run of a binding with the same input pointer and
+  // stream, replayed afterwards (one graph launch instead of 60-75 kernel launches: what a single request's
+  // latency is made of).  Dropped by every re-bind; not used while per-launch timing events are on.
+  void drop_graph();
+  hipGraphExec_t graph_exec_ = nullptr;
+  const float* graph_x_ = nullptr;
+  hipStream_t graph_stream_ = nullptr;
+  int runs_since_bind_ = 0;
   struct EvPair { hipEvent_t a, b; std::string name; double flops, bytes; };
   std::vector<EvPair> ev_pending_;
   std::vector<hipEvent_t> ev_pool_;

@@ -129,6 +129,7 @@ Net::~Net() {
   if (arena_) (void)hipFree(arena_);
   if (gap_part_) (void)hipFree(gap_part_);
   if (head_part_) (void)hipFree(head_part_);
+  drop_graph();
   for (auto e : ev_pool_) (void)hipEventDestroy(e);
   for (auto& p : ev_pending_) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
 }
@@ -352,6 +353,7 @@ bool Net::build_epilogue(const PlanOp& op, Epilogue& ep, bool conv_path, std::st
 
 // ------------------------------------------------------------------ shape binding
 bool Net::bind(int N, int H, int W, std::string& err) {
+  drop_graph();
   fused_head_rows_ = -1;
   // 1. shapes
   auto& T = tensors_;
@@ -734,11 +736,45 @@ bool Net::bind(int N, int H, int W, std::string& err) {
   return true;
 }
 
+void Net::drop_graph() {
+  if (graph_exec_) (void)hipGraphExecDestroy(graph_exec_);
+  graph_exec_ = nullptr;
+  runs_since_bind_ = 0;
+}
+
 bool Net::run(const float* x, int N, int H, int W, hipStream_t s, std::string& err) {
   if (N != bound_n_ || H != bound_h_ || W != bound_w_) {
+    drop_graph();
     if (!bind(N, H, W, err)) { bound_n_ = -1; return false; }
   }
   bound_x_ = x;
+  static const char* graph_env = getenv("OCR_GRAPH");  // OCR_GRAPH=0: plain launches only
+  const bool graphs = !(graph_env && graph_env[0] == '0') && !timing_ && !keep_all_;
+  if (graphs && graph_exec_ && graph_x_ == x && graph_stream_ == s) {
+    HIP_OK(hipGraphLaunch(graph_exec_, s));
+    return true;
+  }
+  if (graphs && runs_since_bind_ >= 1 && !launches_.empty()) {
+    // second run of this binding: record the launch list (the first run went out plainly, so one-time
+    // per-device setup such as function attributes is behind us), then replay it
+    if (graph_exec_) { (void)hipGraphExecDestroy(graph_exec_); graph_exec_ = nullptr; }
+    hipGraph_t g = nullptr;
+    if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+      for (auto& L : launches_) L.fn(s);
+      const hipError_t ce = hipStreamEndCapture(s, &g);
+      if (ce == hipSuccess && g && hipGraphInstantiate(&graph_exec_, g, nullptr, nullptr, 0) == hipSuccess) {
+        (void)hipGraphDestroy(g);
+        graph_x_ = x;
+        graph_stream_ = s;
+        HIP_OK(hipGraphLaunch(graph_exec_, s));
+        return true;
+      }
+      if (g) (void)hipGraphDestroy(g);
+      graph_exec_ = nullptr;
+      (void)hipGetLastError();  // capture not available: fall through to plain launches
+    }
+  }
+  ++runs_since_bind_;
   for (size_t i = 0; i < launches_.size(); ++i) {
     if (timing_ && (timing_filter_.empty() || launches_[i].name.find(timing_filter_) != std::string::npos)) {
       hipEvent_t a, b;

@@ -92,7 +92,7 @@ class DetStage {
   int src_rows_ = 0, src_cols_ = 0;
   int ithresh_ = 0;
   int pool_cap_ = 0;
-  int bm_n_ = 0, bm_h_ = 0, bm_w_ = 0;
+  int bm_n_ = 0;  // 1 once the fused-bitmap pointer has been handed to the network
 };
 
 struct LineSrc {  // a text-line image living in device memory

@@ -4,6 +4,7 @@
 
 #include <cstdlib>
 
+#include "lds_attr.h"
 #include "ocr_common.h"
 
 namespace ocr {

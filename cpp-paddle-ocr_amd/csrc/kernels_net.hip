@@ -738,14 +738,8 @@ bool launch_conv3x3_tile(const ConvArgs& a, const Epilogue& ep, int nt, hipStrea
   const dim3 grid((unsigned)((long)a.N * tiles_y * tiles_x * (a.NTtot / nt)));
   const unsigned lds = 10 * 18 * (96 + 4) * sizeof(float);  // 72 000 B: two workgroups per CU
   // more than 64 KB of dynamic LDS has to be allowed per device (a worker pool drives several from one process)
-  static bool attr_set[64] = {};
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-    if (hipFuncSetAttribute((const void*)conv3x3_tile_kernel<12, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return false;  // the general kernel takes the launch
-    if (dev >= 0 && dev < 64) attr_set[dev] = true;
-  }
+  static unsigned char attr_state[64] = {};
+  if (!raise_dynamic_lds((const void*)conv3x3_tile_kernel<12, 1>, (int)lds, attr_state)) return false;  // the general kernel takes the launch
   hipLaunchKernelGGL((conv3x3_tile_kernel<12, 1>), grid, dim3(256), lds, s, a, ep, tiles_x, tiles_y);
   return true;
 }
@@ -1390,11 +1384,8 @@ void launch_attn(const float* qkv, float* out, int N, int T, int heads, int hd, 
                  hipStream_t s) {
   const size_t lds = ((size_t)T * 96 + 64 * 17) * sizeof(float);
   if (lds <= 150 * 1024) {
-    static bool once = [] {
-      return hipFuncSetAttribute((const void*)attn_lds_kernel<15>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) ==
-             hipSuccess;
-    }();
-    if (once) {
+    static unsigned char attr_state[64] = {};  // per device: the pool drives several from one process
+    if (lds <= 64 * 1024 || raise_dynamic_lds((const void*)attn_lds_kernel<15>, 150 * 1024, attr_state)) {
       hipLaunchKernelGGL(attn_lds_kernel<15>, dim3((unsigned)(N * heads)), dim3(64), lds, s, qkv, out, N, T, heads, Cs_in,
                          Cs_out, scale);
       return;

@@ -24,6 +24,7 @@
 #include <limits.h>
 
 #include "kernels_post.h"
+#include "lds_attr.h"
 
 namespace ocr {
 
@@ -1351,10 +1352,9 @@ void launch_post(const PostArgs& a, int N, int* out_boxes, int cap, int* out_n, 
   const dim3 gl((a.max_cand + 63) / 64, N);
   const size_t lds = (size_t)(a.H + 2) * lds_bits_stride(a.W) * sizeof(unsigned);
   bool in_lds = lds <= 150 * 1024;  // 960x960: 119 KB
-  if (in_lds && lds > 64 * 1024) {  // more than the default dynamic LDS limit: raise it once per process
-    static const bool raised =
-        hipFuncSetAttribute((const void*)trace_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess;
-    in_lds = raised;
+  if (in_lds && lds > 64 * 1024) {  // more than the default dynamic LDS limit: raise it, per device
+    static unsigned char attr_state[64] = {};
+    in_lds = raise_dynamic_lds((const void*)trace_lds_kernel, 150 * 1024, attr_state);  // refused: the global-bitmap kernels below
   }
   if (in_lds) {
     hipLaunchKernelGGL(trace_lds_kernel, dim3(N), dim3(256), lds, s, a.bitmap, a.H, a.W, a.max_cand, a.ncont, a.starts, a.npts, a.poff,

@@ -5,8 +5,10 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <array>
 #include <functional>
 #include <map>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -73,15 +75,20 @@ class Net {
   bool fetch_logical(int tid, std::vector<float>& host, int dims[4], hipStream_t s, std::string& err);
 
   // --- det tail options: fused u8 threshold bitmap (null = none) ---
-  void set_det_bitmap(uint8_t* bitmap, int ithresh) { det_bitmap_ = bitmap; det_ithresh_ = ithresh; bound_n_ = -1; }
+  void set_det_bitmap(uint8_t* bitmap, int ithresh) { det_bitmap_ = bitmap; det_ithresh_ = ithresh; invalidate(); }
   // --- rec/cls head options: where the row softmax leaves its results ---
+  // The launches read these pointers when they are issued, so new sinks of the same kind keep every binding (a
+  // recorded graph holds the pointers it was captured with and is re-recorded when they differ: Net::run); only
+  // a change of WHICH outputs are wanted changes the launch list (fused head or not).
   void set_head_outputs(float* probs, int* amax, float* pmax) {
-    if (probs == head_probs_ && amax == head_amax_ && pmax == head_pmax_) return;  // unchanged: keep the binding (and its graph)
-    head_probs_ = probs; head_amax_ = amax; head_pmax_ = pmax; bound_n_ = -1;
+    const bool same_kind = (probs != nullptr) == (head_probs_ != nullptr) && (amax != nullptr) == (head_amax_ != nullptr) &&
+                           (pmax != nullptr) == (head_pmax_ != nullptr);
+    head_probs_ = probs; head_amax_ = amax; head_pmax_ = pmax;
+    if (!same_kind) invalidate();
   }
 
   // parity debugging: give every tensor its own arena slot so intermediate taps stay valid
-  void set_keep_all(bool on) { keep_all_ = on; bound_n_ = -1; }
+  void set_keep_all(bool on) { if (on != keep_all_) { keep_all_ = on; invalidate(); } }
 
   // per-kernel-family timing with HIP events on the launch stream (bench / roofline)
   void enable_timing(bool on) { timing_ = on; }
@@ -97,6 +104,25 @@ class Net {
     double flops = 0, bytes = 0;
     std::function<void(hipStream_t)> fn;
   };
+  // One bound input shape: tensor shapes + arena offsets, the launch list, and (once the same input buffer has
+  // been seen twice in a row) the hipGraph of that list.  Bindings are cached per (N, H, W): a mixed-size request
+  // stream (BASELINE configs[2]) and the rec lanes' odd widths come back to shapes they have seen without
+  // re-planning or re-recording.  Launches hold arena pointers: whatever moves the arena drops the cache.
+  struct Binding {
+    int n = 0, h = 0, w = 0;
+    std::vector<TensorDesc> tensors;
+    std::vector<Launch> launches;
+    hipGraphExec_t graph_exec = nullptr;
+    const float* graph_x = nullptr;
+    hipStream_t graph_stream = nullptr;
+    const void* graph_head[3] = {nullptr, nullptr, nullptr};
+    const float* last_x = nullptr;   // input of the previous run of this binding
+    bool graph_failed = false;       // capture was refused once: plain launches from then on
+    unsigned long stamp = 0;         // LRU
+    ~Binding() { if (graph_exec) (void)hipGraphExecDestroy(graph_exec); }
+  };
+  static constexpr size_t kMaxBindings = 48;
+  void invalidate() { cache_.clear(); cur_ = nullptr; }
   bool bind(int N, int H, int W, std::string& err);
   bool build_epilogue(const PlanOp& op, Epilogue& ep, bool conv_path, std::string& err);
   const float* dev_vec(const std::string& key) const;
@@ -106,8 +132,10 @@ class Net {
   std::map<std::string, float*> dev_;        // uploaded parameter images by key
   std::map<std::string, float> scalars_;
   WeightMap host_w_;                          // kept only for scalar lookups / shapes
-  std::vector<TensorDesc> tensors_;
-  std::vector<Launch> launches_;
+  std::vector<TensorDesc> tensors_;           // shapes/offsets of the current binding (plain flags fixed at load)
+  std::map<std::array<int, 3>, std::unique_ptr<Binding>> cache_;
+  Binding* cur_ = nullptr;
+  unsigned long clock_ = 0;
   float* arena_ = nullptr;
   size_t arena_cap_ = 0;
   float* gap_part_ = nullptr;
@@ -116,7 +144,6 @@ class Net {
   size_t head_part_cap_ = 0;
   long fused_head_rows_ = -1;  // rows of the linear that was bound in OUT_HEAD mode (-1: none)
   int fused_head_groups_ = 0;
-  int bound_n_ = -1, bound_h_ = -1, bound_w_ = -1;
   const float* bound_x_ = nullptr;
   int out_tid_ = -1;
   uint8_t* det_bitmap_ = nullptr;
@@ -128,14 +155,10 @@ class Net {
   std::string timing_filter_;
   bool keep_all_ = false;
   std::map<std::string, KernelTiming> timings_;
-  // hipGraph of the bound launch list: captured on the second run of a binding with the same input pointer and
-  // stream, replayed afterwards (one graph launch instead of 60-75 kernel launches: what a single request's
-  // latency is made of).  Dropped by every re-bind; not used while per-launch timing events are on.
-  void drop_graph();
-  hipGraphExec_t graph_exec_ = nullptr;
-  const float* graph_x_ = nullptr;
-  hipStream_t graph_stream_ = nullptr;
-  int runs_since_bind_ = 0;
+  // hipGraph of a binding's launch list: recorded when a run finds the input pointer of the binding's previous
+  // run (the first run went out plainly, so one-time per-device setup such as function attributes is behind us),
+  // replayed while input, stream and head sinks stay the same (one graph launch instead of 60-75 kernel launches:
+  // what a single request's latency is made of).  Not used while per-launch timing events are on.
   struct EvPair { hipEvent_t a, b; std::string name; double flops, bytes; };
   std::vector<EvPair> ev_pending_;
   std::vector<hipEvent_t> ev_pool_;

@@ -159,6 +159,7 @@ int DetStage::run_post(int count, int H, int W, const float* prob, float ratio_h
     ST_HIP(hipMemsetAsync(mask_top_.p, 0, count * sizeof(unsigned), stream_));
   }
   launch_post(a, count, out_boxes_.p, cap, out_n_.p, stream_);
+  ST_HIP(hipGetLastError());  // a refused launch (e.g. LDS limit on this device) must not leave stale borders behind
   int status = 0;
   ST_HIP(hipMemcpyAsync(n, out_n_.p, count * sizeof(int), hipMemcpyDeviceToHost, stream_));
   ST_HIP(hipMemcpyAsync(boxes, out_boxes_.p, (size_t)count * cap * 8 * sizeof(int), hipMemcpyDeviceToHost, stream_));
@@ -170,6 +171,7 @@ int DetStage::run_post(int count, int H, int W, const float* prob, float ratio_h
     ST_HIP(hipMemsetAsync(status_.p, 0, sizeof(int), stream_));
     if (a.slow) ST_HIP(hipMemsetAsync(mask_top_.p, 0, count * sizeof(unsigned), stream_));
     launch_post_large(a, count, out_boxes_.p, cap, out_n_.p, stream_);
+    ST_HIP(hipGetLastError());
     ST_HIP(hipMemcpyAsync(n, out_n_.p, count * sizeof(int), hipMemcpyDeviceToHost, stream_));
     ST_HIP(hipMemcpyAsync(boxes, out_boxes_.p, (size_t)count * cap * 8 * sizeof(int), hipMemcpyDeviceToHost, stream_));
     ST_HIP(hipMemcpyAsync(&status, status_.p, sizeof(int), hipMemcpyDeviceToHost, stream_));

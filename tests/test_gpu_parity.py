@@ -77,6 +77,28 @@ def test_production_mode_output_bit_identical(pkg, built, kind, shape):
     g.close()
 
 
+@pytest.mark.parametrize("graph", ["1", "0"])
+@pytest.mark.parametrize("kind,shape,other", [("rec", (3, 48, 160), (2, 48, 96)), ("det", (2, 64, 96), (1, 96, 64)),
+                                              ("cls", (4, 48, 192), (1, 48, 192))])
+def test_repeated_runs_of_a_binding_track_their_input(pkg, built, monkeypatch, graph, kind, shape, other):
+    """A binding is run plainly once, recorded into a hipGraph when the same input buffer comes back, and replayed
+    afterwards (Net::run).  Six runs of one shape with NEW contents each time, a different shape in between (the
+    cached binding and its graph must survive the switch), every run compared with the oracle; the same with
+    graphs off."""
+    from oracle import OracleNet
+    monkeypatch.setenv("OCR_GRAPH", graph)
+    o = OracleNet(kind)
+    g = pkg.Net(kind)
+    rs = np.random.RandomState(23)
+    for it in range(6):
+        x = rs.randn(shape[0], shape[1], shape[2], 3).astype(np.float32)
+        assert np.array_equal(o.run(x), g.forward(x, keep_all=False)), "run %d" % it
+        if it in (2, 4):
+            y = rs.randn(other[0], other[1], other[2], 3).astype(np.float32)
+            assert np.array_equal(o.run(y), g.forward(y, keep_all=False)), "other shape after run %d" % it
+    g.close()
+
+
 @pytest.mark.parametrize("kind,shape", [("cls", (3, 48, 192)), ("det", (2, 64, 96)), ("det", (1, 192, 384)),
                                         ("rec", (3, 48, 160)), ("rec", (2, 28, 192)), ("rec", (1, 48, 1000))])
 def test_network_outputs_bit_identical(pkg, built, kind, shape):

@@ -48,3 +48,58 @@ def test_single_rank_is_the_whole_stream():
     sys.path.insert(0, ROOT)
     import bench
     assert bench.shard_seeds(0, 1, batch=64) == list(range(64))
+
+
+def _run_bench(args, env_extra=None, timeout=300):
+    import json
+    import subprocess
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    return p.returncode, (json.loads(lines[-1]) if lines else None), p.stderr
+
+
+def test_bench_gpus_flag_starts_that_many_ranks_and_gathers_their_results():
+    """`bench.py --gpus 2` with no launcher: the same spawn, sharding, max-over-ranks timing and record gather the GPU
+    run uses, on two gloo ranks with the stub pipeline.  The line must report the ranks the
+    process group saw, and every rank's neighbour check of the gathered records must pass."""
+    rc, out, err = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--stub-pipeline"])
+    assert rc == 0, err[-2000:]
+    assert out["n_gpus"] == 2 and out["gather"]["ranks"] == 2 and out["gather"]["backend"] == "gloo"
+    assert out["gather"]["matches_single_rank"] is True and out["gather"]["verified_images_per_rank"] == 4
+    assert len(out["gather"]["records_per_rank"]) == 2 and all(8 <= c <= 24 for c in out["gather"]["records_per_rank"])
+    assert out["value"] > 0 and out["scaling"] == "weak" and out["data"].startswith("stub")
+
+
+def test_bench_gather_check_catches_a_rank_that_reports_a_wrong_box():
+    rc, out, err = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0", "--stub-pipeline"], {"OCR_BENCH_STUB_CORRUPT": "1"})
+    assert rc != 0 and out is not None and "error" in out and out["gather"]["matches_single_rank"] is False
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    rc, out, err = _run_bench(["--gpus", "4", "--stub-pipeline"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert rc != 0 and out is None and "WORLD_SIZE=1" in err
+
+
+def test_result_records_roundtrip():
+    import importlib.util
+    import numpy as np
+    spec = importlib.util.spec_from_file_location("rg", os.path.join(ROOT, "cpp-paddle-ocr_amd", "result_gather.py"))
+    G = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(G)
+    words = [[dict(box=np.arange(8).reshape(4, 2), ids=np.array([5, 9, 9, 2]), confidence=0.75)], [],
+             [dict(box=-np.arange(8).reshape(4, 2), ids=np.array([], np.int32), confidence=0.0),
+              dict(box=np.full((4, 2), 959), ids=np.array([6624]), confidence=1.0)]]
+    recs, n = G.pack_records(words, [10, 12, 14], cap=8)
+    assert n == 3 and recs.shape == (8, 16) and (recs[3:, 0] == -1).all()
+    by = G.records_by_image(recs)
+    assert sorted(by) == [10, 14] and len(by[14]) == 2 and by[14][1][1] == 1
+    assert by[10][0][11] == 4 and by[10][0][10] == np.float32(0.75).view(np.int32)
+    assert G.fnv1a32([5, 9, 9, 2]) != G.fnv1a32([5, 9, 2, 9])          # order-sensitive
+    assert by[10][0][12] == G.fnv1a32(np.array([5, 9, 9, 2]))
+    import pytest
+    with pytest.raises(ValueError):
+        G.pack_records(words, [0, 1, 2], cap=2)

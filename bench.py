@@ -395,4 +395,6 @@ def main(argv=None):
 
 
 if __name__ == "__main__":
+    import faulthandler
+    faulthandler.enable()   # a crash inside the HIP library or RCCL leaves a stack on stderr, not an empty line
     main()

@@ -50,7 +50,7 @@ EXPORTS = [
     "ocr_cls_cfg_default", "ocr_cls_create", "ocr_cls_destroy", "ocr_cls_run", "ocr_cls_probs",
     "ocr_rec_cfg_default", "ocr_rec_create", "ocr_rec_destroy", "ocr_rec_run", "ocr_rec_label",
     "ocr_rec_num_classes", "ocr_rec_steps",
-    "ocr_net_create", "ocr_net_destroy", "ocr_net_forward", "ocr_net_num_tensors", "ocr_net_fetch",
+    "ocr_net_create", "ocr_net_destroy", "ocr_net_forward", "ocr_net_num_tensors", "ocr_net_tensor_exists", "ocr_net_fetch",
     "ocr_net_timing", "ocr_net_timing_report", "ocr_probe",
 ]
 
@@ -66,6 +66,7 @@ def lib():
         L.ocr_net_destroy.argtypes = [C.c_void_p]
         L.ocr_net_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
         L.ocr_net_num_tensors.argtypes = [C.c_void_p]
+        L.ocr_net_tensor_exists.argtypes = [C.c_void_p, C.c_int]
         L.ocr_net_fetch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_int)]
         L.ocr_net_timing.argtypes = [C.c_void_p, C.c_int]
         L.ocr_net_timing_report.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
@@ -120,6 +121,10 @@ class Net:
 
     def num_tensors(self):
         return lib().ocr_net_num_tensors(self.h)
+
+    def exists(self, tid):
+        """did the last forward write plan tensor `tid`? (a fused-away tensor never reaches device memory)"""
+        return bool(lib().ocr_net_tensor_exists(self.h, int(tid)))
 
     def timing(self, on=True):
         check(lib().ocr_net_timing(self.h, int(on)))

@@ -110,7 +110,7 @@ int ocr_net_forward(ocr_net* h, const float* x, int N, int H, int W, int keep_al
     h->x_cap = n;
   }
   CAPI_HIP(hipMemcpyAsync(h->x_dev, x, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
-  h->net.set_keep_all(keep_all != 0);
+  h->net.set_keep_all(keep_all < 0 || keep_all > 2 ? 1 : keep_all);
   std::string err;
   if (!h->net.run(h->x_dev, N, H, W, h->stream, err)) return fail(OCR_ERR_DEVICE, err);
   CAPI_HIP(hipStreamSynchronize(h->stream));
@@ -119,6 +119,7 @@ int ocr_net_forward(ocr_net* h, const float* x, int N, int H, int W, int keep_al
 }
 
 int ocr_net_num_tensors(ocr_net* h) { return h ? h->net.ntensors() : 0; }
+int ocr_net_tensor_exists(ocr_net* h, int tid) { return h && h->net.materialised(tid) ? 1 : 0; }
 
 int ocr_net_fetch(ocr_net* h, int tid, float* out, size_t cap_floats, int dims[4]) {
   if (!h || !out || !dims) return fail(OCR_ERR_ARG, "null argument");

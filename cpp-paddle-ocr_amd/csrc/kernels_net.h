@@ -67,6 +67,20 @@ struct DwArgs {
 };
 void launch_dw(const DwArgs& a, const Epilogue& ep, hipStream_t s);
 
+// Fused depthwise conv (+ its epilogue) -> 1x1 conv (+ its epilogue), kernels_dwpw.hip.  `c` describes the 1x1 conv
+// exactly as launch_conv_mfma would get it (c.in unused: its input never exists in HBM); the depthwise part:
+struct DwPwArgs {
+  ConvArgs c;
+  const float* dw_in;  // [N,H,W,Cs] C8I, Cs = c.Cs_in
+  const float* dw_w;   // [K*K][Cs] physical order
+  const float* dw_v0;  // per-channel vector of the depthwise epilogue's bias / BN-scale stage (null: none)
+  const float* dw_v1;  // BN shift (null: none)
+  int H, W, K, SH, SW, PH, PW;
+  int tiles_x, tiles_y;  // filled by the launcher
+};
+// false: the shape is not instantiated (the caller launches the unfused pair).  query = true only asks.
+bool launch_dwpw(const DwPwArgs& a, const Epilogue& ep_dw, const Epilogue& ep_pw, hipStream_t s, bool query = false);
+
 void launch_ew(const float* in, float* out, long M, int H, int W, int Cs, const Epilogue& ep, hipStream_t s);
 void launch_gap(const float* in, float* part, float* out, int N, int H, int W, int Cs, hipStream_t s);
 

@@ -9,315 +9,10 @@
 #include <cstdio>
 #include <cstdlib>
 
+#include "conv_device.h"
 #include "kernels_net.h"
 
 namespace ocr {
-
-typedef float floatx16 __attribute__((ext_vector_type(16)));
-
-// Workgroups are dealt round-robin over the 8 XCDs (each with a private 4 MiB L2).  Neighbouring
-// tiles of these kernels re-read each other's input rows (3x3/5x5 taps, N-groups of one M-tile), so
-// give each XCD a CONTIGUOUS range of logical tiles: re-reads then hit that XCD's L2 instead of
-// HBM (rocprof r1e: 7x over-fetch on the det 3x3 conv, 5x on dw5x5 before this).  Bijective for any
-// block count; affects speed only.
-// development probe (tools/micro/conv_probe.hip defines OCR_CONV_PROBE): per-wave phase timestamps
-#ifdef OCR_CONV_PROBE
-__device__ long long* g_conv_probe;
-#define CONV_PROBE(slot)                                                                               \
-  if (g_conv_probe && (threadIdx.x & 63) == 0)                                                         \
-    g_conv_probe[((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (slot)] = (long long)clock64()
-#else
-#define CONV_PROBE(slot)
-#endif
-
-__device__ __forceinline__ unsigned xcd_swizzle(unsigned bid, unsigned nblk) {
-  const unsigned q = nblk >> 3, r = nblk & 7, x = bid & 7, i = bid >> 3;
-  return x * q + (x < r ? x : r) + i;
-}
-
-__device__ __forceinline__ void decompose(long m, int hw, int w, int& n, int& y, int& x) {
-  n = (int)(m / hw);
-  int r = (int)(m - (long)n * hw);
-  y = r / w;
-  x = r - y * w;
-}
-
-// ---- scalar epilogue for one value at (n, y, x, physical channel pc); oidx = its NHWC offset ----
-__device__ __forceinline__ float apply_epilogue(const Epilogue& ep, float v, int pc, int n, int y, int x, long oidx,
-                                                int cs) {
-  for (int s = 0; s < ep.n; ++s) {
-    const EpStage& st = ep.st[s];
-    switch (st.kind) {
-      case EP_BIAS: v = v + st.v0[pc]; break;
-      case EP_SMUL: v = st.p0 * v; break;
-      case EP_SADD: v = v + st.p0; break;
-      case EP_BN: { float t = v * st.v0[pc]; v = t + st.v1[pc]; } break;
-      case EP_ACT: v = ocr_act(st.act, st.p0, st.p1, v); break;
-      case EP_MULC: v = v * st.v0[(long)n * cs + pc]; break;
-      case EP_ADDT: v = v + st.v0[oidx]; break;
-      case EP_ADDUP: {
-        int sy = y / st.a0, sx = x / st.a0;
-        v = v + st.v0[(((long)n * st.a2 + sy) * st.a1 + sx) * cs + pc];
-      } break;
-    }
-  }
-  return v;
-}
-
-// 4 consecutive physical channels
-__device__ __forceinline__ float4 apply_epilogue4(const Epilogue& ep, float4 v, int pc, int n, int y, int x, long oidx,
-                                                  int cs) {
-  for (int s = 0; s < ep.n; ++s) {
-    const EpStage& st = ep.st[s];
-    switch (st.kind) {
-      case EP_BIAS: { float4 b = *(const float4*)(st.v0 + pc); v.x = v.x + b.x; v.y = v.y + b.y; v.z = v.z + b.z; v.w = v.w + b.w; } break;
-      case EP_SMUL: v.x = st.p0 * v.x; v.y = st.p0 * v.y; v.z = st.p0 * v.z; v.w = st.p0 * v.w; break;
-      case EP_SADD: v.x = v.x + st.p0; v.y = v.y + st.p0; v.z = v.z + st.p0; v.w = v.w + st.p0; break;
-      case EP_BN: {
-        float4 sc = *(const float4*)(st.v0 + pc), sh = *(const float4*)(st.v1 + pc);
-        float t;
-        t = v.x * sc.x; v.x = t + sh.x;
-        t = v.y * sc.y; v.y = t + sh.y;
-        t = v.z * sc.z; v.z = t + sh.z;
-        t = v.w * sc.w; v.w = t + sh.w;
-      } break;
-      case EP_ACT:
-        if (st.act == ACT_HSWISH) { ocr_hswish4(v.x, v.y, v.z, v.w); break; }
-        v.x = ocr_act(st.act, st.p0, st.p1, v.x); v.y = ocr_act(st.act, st.p0, st.p1, v.y);
-        v.z = ocr_act(st.act, st.p0, st.p1, v.z); v.w = ocr_act(st.act, st.p0, st.p1, v.w);
-        break;
-      case EP_MULC: { float4 g = *(const float4*)(st.v0 + (long)n * cs + pc); v.x = v.x * g.x; v.y = v.y * g.y; v.z = v.z * g.z; v.w = v.w * g.w; } break;
-      case EP_ADDT: { float4 g = *(const float4*)(st.v0 + oidx); v.x = v.x + g.x; v.y = v.y + g.y; v.z = v.z + g.z; v.w = v.w + g.w; } break;
-      case EP_ADDUP: {
-        int sy = y / st.a0, sx = x / st.a0;
-        float4 g = *(const float4*)(st.v0 + (((long)n * st.a2 + sy) * st.a1 + sx) * cs + pc);
-        v.x = v.x + g.x; v.y = v.y + g.y; v.z = v.z + g.z; v.w = v.w + g.w;
-      } break;
-    }
-  }
-  return v;
-}
-
-// Epilogue of the NT 32x32 accumulator tiles of a wave.  The GEMM is issued as D = W * X^T (weights
-// are the MFMA A operand, pixels the B operand), so a lane owns ONE pixel (column = lane & 31) and, per
-// tile, 16 output channels: registers 4g..4g+3 are the four consecutive PHYSICAL channels
-// tile*32 + 8g + 4*(lane>>5).  => per-channel parameters arrive as float4, results leave as 16-byte
-// stores, per-pixel stages (SE gate, residual, upsample-add) need the pixel's (n, y, x) once per lane.
-//
-// Shape of the code (probe, tools/micro/conv_probe.hip: at K = 240 the old tile-by-tile epilogue lasted
-// as long as the K loop, almost all of it waiting): the STAGE loop is outermost and every stage sweeps
-// all tiles, so a stage's parameter loads for the whole wave are issued back to back and waited for
-// once, the stage descriptor is decoded once, and no load is ever issued behind a store (loads and
-// stores retire through one in-order counter).  PLAIN (logical channel order, unaligned rows: the two
-// heads) is a template parameter so the packed path keeps its 16-byte stores.
-template <int NT, int MODE>
-__device__ __forceinline__ void conv_finish(const ConvArgs& a, const Epilogue& ep, floatx16 (&acc)[NT], int nt0, long m, int hb,
-                                            const float* spar) {
-  if (m >= a.M) return;
-  // the pixel's (n, y, x) is only needed by the deconv scatter and by the per-image / upsampled
-  // stages: decoded there (two integer divisions), not in front of every K loop
-  int n = 0, y = 0, x = 0;
-  if constexpr (MODE == OUT_DECONV) decompose(m, a.OH * a.OW, a.OW, n, y, x);
-  // Row of quad (t, g): R = r0 + rel, rel = 32t + 8g a compile-time constant, r0 = nt0*32 + 4hb.
-  // Everything addressed per quad is "one per-lane base + a uniform offset": nothing per-quad is kept
-  // in registers across the stage loop (16 channel indices + 16 64-bit offsets hoisted out of it cost
-  // 50 VGPRs and spilled).  Packed modes: ColsStore and CoutPadded are multiples of 8, so whether a
-  // quad exists and which deconv quadrant it falls in is uniform; PLAIN (ColsStore = Cout) tests rows.
-  const int c0 = nt0 * 32, r0 = c0 + 4 * hb;
-  auto exists = [&](int rel) { return c0 + rel < a.ColsStore; };  // uniform
-  // offset of the quad's first float relative to the lane's pixel in an output-shaped tensor
-  auto ooff = [&](int rel) -> long {
-    if constexpr (MODE == OUT_DECONV) {
-      const int dq = (c0 + rel) / a.CoutPadded;  // uniform
-      return ((long)(dq >> 1) * (2 * a.OW) + (dq & 1)) * a.Cs_out + (rel - dq * a.CoutPadded);
-    }
-    return rel;
-  };
-  // channel offset of the quad relative to r0 in a per-channel vector
-  auto coff = [&](int rel) {
-    if constexpr (MODE == OUT_DECONV) return rel - ((c0 + rel) / a.CoutPadded) * a.CoutPadded;
-    return rel;
-  };
-  const long opix = MODE == OUT_DECONV ? (((long)n * (2 * a.OH) + 2 * y) * (2 * a.OW) + 2 * x) * a.Cs_out + r0
-                                       : m * a.Cs_out + r0;
-#define OCR_EP_SWEEP(BODY)                                   \
-  _Pragma("unroll") for (int t = 0; t < NT; ++t) {           \
-    _Pragma("unroll") for (int g = 0; g < 4; ++g) {          \
-      constexpr_rel(t, g);                                   \
-      if (!exists(rel)) continue;                            \
-      float wx = acc[t][4 * g], wy = acc[t][4 * g + 1];      \
-      float wz = acc[t][4 * g + 2], ww = acc[t][4 * g + 3];  \
-      BODY                                                   \
-      acc[t][4 * g] = wx; acc[t][4 * g + 1] = wy;            \
-      acc[t][4 * g + 2] = wz; acc[t][4 * g + 3] = ww;        \
-    }                                                        \
-  }
-#define constexpr_rel(t, g) const int rel = 32 * (t) + 8 * (g)
-  for (int s = 0; s < ep.n; ++s) {
-    const EpStage& st = ep.st[s];
-    switch (st.kind) {
-      case EP_BIAS: {
-        const float* q0 = spar + (2 * s) * NT * 32 + 4 * hb;
-        OCR_EP_SWEEP({ const float4 b = *(const float4*)(q0 + rel); wx = wx + b.x; wy = wy + b.y; wz = wz + b.z; ww = ww + b.w; })
-      } break;
-      case EP_SMUL: {
-        const float k = st.p0;
-        OCR_EP_SWEEP({ wx = k * wx; wy = k * wy; wz = k * wz; ww = k * ww; })
-      } break;
-      case EP_SADD: {
-        const float k = st.p0;
-        OCR_EP_SWEEP({ wx = wx + k; wy = wy + k; wz = wz + k; ww = ww + k; })
-      } break;
-      case EP_BN: {
-        const float* q0 = spar + (2 * s) * NT * 32 + 4 * hb;
-        OCR_EP_SWEEP({
-          const float4 sc = *(const float4*)(q0 + rel);
-          const float4 sh = *(const float4*)(q0 + NT * 32 + rel);
-          float u;
-          u = wx * sc.x; wx = u + sh.x;
-          u = wy * sc.y; wy = u + sh.y;
-          u = wz * sc.z; wz = u + sh.z;
-          u = ww * sc.w; ww = u + sh.w;
-        })
-      } break;
-      case EP_ACT: {
-        // the activation kind is decoded once per stage, not once per value
-        const float p0 = st.p0, p1 = st.p1;
-#define OCR_ACT_SWEEP(KIND) OCR_EP_SWEEP({ wx = ocr_act(KIND, p0, p1, wx); wy = ocr_act(KIND, p0, p1, wy); wz = ocr_act(KIND, p0, p1, wz); ww = ocr_act(KIND, p0, p1, ww); })
-        switch (st.act) {
-          case ACT_RELU: OCR_ACT_SWEEP(ACT_RELU) break;
-          case ACT_HSWISH: {
-            // range pass, then the division-free sweep (ocr_common.h); anything out of range takes the division
-            float mn = INFINITY, mx = 0.0f;
-            OCR_EP_SWEEP({ ocr_absrange(mn, mx, wx, wy); ocr_absrange(mn, mx, wz, ww); })
-            if (ocr_hsw_fast_ok(mn, mx)) { OCR_EP_SWEEP({ ocr_hswish4_fast(wx, wy, wz, ww); }) }
-            else { OCR_ACT_SWEEP(ACT_HSWISH) }
-          } break;
-          case ACT_HSIG: OCR_ACT_SWEEP(ACT_HSIG) break;
-          case ACT_SWISH: OCR_ACT_SWEEP(ACT_SWISH) break;
-          default: OCR_ACT_SWEEP(ACT_SIGMOID) break;
-        }
-#undef OCR_ACT_SWEEP
-      } break;
-      case EP_MULC: {  // per-image channel gate [N][Cs_out]
-        if constexpr (MODE != OUT_DECONV) decompose(m, a.OH * a.OW, a.OW, n, y, x);
-        const float* gate = st.v0 + (long)n * a.Cs_out + r0;
-        OCR_EP_SWEEP({ const float4 r = *(const float4*)(gate + coff(rel)); wx = wx * r.x; wy = wy * r.y; wz = wz * r.z; ww = ww * r.w; })
-      } break;
-      case EP_ADDT: {  // tensor of the output's shape
-        const float* res = st.v0 + opix;
-        OCR_EP_SWEEP({ const float4 r = *(const float4*)(res + ooff(rel)); wx = wx + r.x; wy = wy + r.y; wz = wz + r.z; ww = ww + r.w; })
-      } break;
-      case EP_ADDUP: {  // nearest-upsampled coarser map (never after a deconv)
-        if constexpr (MODE != OUT_DECONV) decompose(m, a.OH * a.OW, a.OW, n, y, x);
-        const float* up = st.v0 + (((long)n * st.a2 + y / st.a0) * st.a1 + x / st.a0) * a.Cs_out + r0;
-        OCR_EP_SWEEP({ const float4 r = *(const float4*)(up + coff(rel)); wx = wx + r.x; wy = wy + r.y; wz = wz + r.z; ww = ww + r.w; })
-      } break;
-    }
-  }
-#undef OCR_EP_SWEEP
-  if constexpr (MODE == OUT_HEAD) {
-    // Fused softmax head, first half (canonical order of the row softmax, shared with the oracle and with
-    // softmax_argmax_kernel): columns in groups of 128; inside a group two interleaved chains - the
-    // columns with ((c >> 2) & 1) == 0 and == 1, i.e. the two half-waves of this layout - each summed in
-    // ascending column order, then chain 0 + chain 1.  The logits never leave the registers.
-    float mx = -INFINITY;
-    int mi = 0x7fffffff;
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int g = 0; g < 4; ++g)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int c = r0 + 32 * t + 8 * g + k;
-          const float v = acc[t][4 * g + k];
-          if (c < a.Cout && v > mx) { mx = v; mi = c; }  // ascending c: the first maximum wins
-        }
-    const float omx = __shfl_xor(mx, 32);
-    const int omi = __shfl_xor(mi, 32);
-    if (omx > mx || (omx == mx && omi < mi)) { mx = omx; mi = omi; }
-    float part = 0.f;
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int g = 0; g < 4; ++g)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int c = r0 + 32 * t + 8 * g + k;
-          if (c < a.Cout) part = part + ocr_expf(acc[t][4 * g + k] - mx);
-        }
-    const float other = __shfl_xor(part, 32);
-    if (hb == 0) {
-      const long q = m * (a.NTtot / NT) + nt0 / NT;
-      a.head_max[q] = mx;
-      a.head_sum[q] = part + other;
-      a.head_idx[q] = mi;
-    }
-    return;
-  }
-  // ---- stores, after the last load
-  float* obase = a.out + opix;
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      constexpr_rel(t, g);
-      if (!exists(rel)) continue;
-      float4 w = make_float4(acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]);
-      float* dst = obase + ooff(rel);
-      if constexpr (MODE == OUT_PLAIN) {
-        // logical channel order, row stride = Cout (rows are not 16-byte aligned): scalar stores;
-        // per-channel parameter vectors of plain outputs are padded to whole tiles
-        const int R = r0 + rel;
-        if (R < a.Cout) dst[0] = w.x;
-        if (R + 1 < a.Cout) dst[1] = w.y;
-        if (R + 2 < a.Cout) dst[2] = w.z;
-        if (R + 3 < a.Cout) dst[3] = w.w;
-      } else {
-        if (a.Cout != a.Cs_out) {  // keep the pad channels of the octet layout at zero
-          const int pc = r0 + coff(rel);
-          if (c8i_logical(pc) >= a.Cout) w.x = 0.f;
-          if (c8i_logical(pc + 1) >= a.Cout) w.y = 0.f;
-          if (c8i_logical(pc + 2) >= a.Cout) w.z = 0.f;
-          if (c8i_logical(pc + 3) >= a.Cout) w.w = 0.f;
-        }
-#ifdef OCR_PROBE_NOSTORE
-        if (w.x == 12345.678f) *(float4*)dst = w;  // development probe: keep the value live, skip the traffic
-#else
-        *(float4*)dst = w;
-#endif
-      }
-    }
-  }
-#undef constexpr_rel
-}
-
-// Per-channel epilogue vectors (bias, BN scale/shift) of this workgroup's NT*32 GEMM rows, copied to
-// LDS at kernel start: spar[(2*stage + k)*NT*32 + row - nt0*32].  An epilogue load from global memory
-// queues behind every streaming load of the CU's 12-16 waves (probe: ~10k clocks each time);
-// the LDS copy is fetched while the K loop runs and read back in ~100 clocks.
-template <int NT>
-__device__ __forceinline__ void conv_stage_params(const ConvArgs& a, const Epilogue& ep, int nt0, float* spar) {
-  const int i = threadIdx.x;
-  if (i < NT * 32) {
-    const int R = nt0 * 32 + i;
-    const int pc = R >= a.ColsStore ? 0 : (a.out_mode == OUT_DECONV ? R % a.CoutPadded : R);
-    float v[2 * OCR_MAX_EP];  // every stage's loads are issued before the first is waited for
-#pragma unroll
-    for (int s = 0; s < OCR_MAX_EP; ++s) {
-      const int kind = s < ep.n ? ep.st[s].kind : -1;
-      v[2 * s] = (kind == EP_BIAS || kind == EP_BN) ? ep.st[s].v0[pc] : 0.f;
-      v[2 * s + 1] = kind == EP_BN ? ep.st[s].v1[pc] : 0.f;
-    }
-#pragma unroll
-    for (int s = 0; s < OCR_MAX_EP; ++s) {
-      const int kind = s < ep.n ? ep.st[s].kind : -1;
-      if (kind == EP_BIAS || kind == EP_BN) spar[(2 * s) * NT * 32 + i] = v[2 * s];
-      if (kind == EP_BN) spar[(2 * s + 1) * NT * 32 + i] = v[2 * s + 1];
-    }
-  }
-  __syncthreads();
-}
 
 // =====================================================================================
 // Dense conv / linear / 2x2-s2 deconv as implicit GEMM on the f32 matrix cores.

@@ -87,8 +87,13 @@ class Net {
     if (!same_kind) invalidate();
   }
 
-  // parity debugging: give every tensor its own arena slot so intermediate taps stay valid
-  void set_keep_all(bool on) { if (on != keep_all_) { keep_all_ = on; invalidate(); } }
+  // parity debugging: give every tensor its own arena slot so intermediate taps stay valid.
+  // 0 = production (liveness-reused arena, fusions on), 1 = every plan tensor materialised (no fusion),
+  // 2 = production launch list (gate folding, depthwise->pointwise fusion) but no arena reuse: every tensor that
+  //     exists in production can be fetched and compared
+  void set_keep_all(int mode) { if (mode != keep_all_) { keep_all_ = mode; invalidate(); } }
+  // does tensor `tid` exist in HBM under the current binding? (fused-away tensors do not)
+  bool materialised(int tid) const { return cur_ && tid > 0 && tid < (int)cur_->exists.size() && cur_->exists[tid]; }
 
   // per-kernel-family timing with HIP events on the launch stream (bench / roofline)
   void enable_timing(bool on) { timing_ = on; }
@@ -111,6 +116,7 @@ class Net {
   struct Binding {
     int n = 0, h = 0, w = 0;
     std::vector<TensorDesc> tensors;
+    std::vector<char> exists;        // per plan tensor: written to HBM by this binding's launches
     std::vector<Launch> launches;
     hipGraphExec_t graph_exec = nullptr;
     const float* graph_x = nullptr;
@@ -153,7 +159,7 @@ class Net {
   float* head_pmax_ = nullptr;
   bool timing_ = false;
   std::string timing_filter_;
-  bool keep_all_ = false;
+  int keep_all_ = 0;
   std::map<std::string, KernelTiming> timings_;
   // hipGraph of a binding's launch list: recorded when a run finds the input pointer of the binding's previous
   // run (the first run went out plainly, so one-time per-device setup such as function attributes is behind us),

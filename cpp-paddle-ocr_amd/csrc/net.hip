@@ -401,13 +401,13 @@ bool Net::bind(int N, int H, int W, std::string& err) {
   std::vector<int> gate_src(nops, -1), gate_tid(nops, -1);
   std::vector<char> folded(nops, 0);
   static const char* fuse_env = getenv("OCR_FUSE_GATE");
-  if (!keep_all_ && !(fuse_env && fuse_env[0] == '0')) {
-    std::vector<int> uses(plan_.ntensors, 0);
-    for (auto& op : plan_.ops) {
-      if (op.in >= 0) uses[op.in]++;
-      for (int t : op.ins) uses[t]++;
-      for (auto& st : op.ep) if (st.tid >= 0) uses[st.tid]++;
-    }
+  std::vector<int> uses(plan_.ntensors, 0);
+  for (auto& op : plan_.ops) {
+    if (op.in >= 0) uses[op.in]++;
+    for (int t : op.ins) uses[t]++;
+    for (auto& st : op.ep) if (st.tid >= 0) uses[st.tid]++;
+  }
+  if (keep_all_ != 1 && !(fuse_env && fuse_env[0] == '0')) {
     for (int oi = 0; oi < nops; ++oi) {
       auto& op = plan_.ops[oi];
       if (op.kind != PlanOp::EW || op.ep.size() != 1 || op.ep[0].kind != EP_MULC || op.out == out_tid_ || uses[op.out] != 1) continue;
@@ -424,11 +424,49 @@ bool Net::bind(int N, int H, int W, std::string& err) {
       }
     }
   }
+  // Depthwise -> pointwise fusion (kernels_dwpw.hip): a depthwise conv whose only reader is an ungated 1x1 conv runs
+  // inside that conv's launch; its output tensor never exists.  OCR_FUSE_DWPW=0 disables (A/B, results identical).
+  std::vector<int> dwpw_of(nops, -1);  // conv op -> the depthwise op it absorbs
+  static const char* dwpw_env = getenv("OCR_FUSE_DWPW");
+  if (keep_all_ != 1 && !(dwpw_env && dwpw_env[0] == '0')) {
+    for (int oi = 0; oi + 1 < nops; ++oi) {
+      auto& d = plan_.ops[oi];
+      if (d.kind != PlanOp::DW || d.out == out_tid_ || uses[d.out] != 1) continue;
+      int nvec = 0;
+      bool ok = true;
+      for (auto& st : d.ep) {
+        if (st.kind == EP_BIAS || st.kind == EP_BN) ++nvec;
+        else if (st.kind != EP_SMUL && st.kind != EP_SADD && st.kind != EP_ACT) ok = false;
+      }
+      if (!ok || nvec > 1) continue;
+      for (int oj = oi + 1; oj < nops; ++oj) {
+        auto& c = plan_.ops[oj];
+        if (c.in != d.out) continue;
+        const bool one = c.kind == PlanOp::CONV && c.kh == 1 && c.kw == 1 && c.sh == 1 && c.sw == 1 && c.ph == 0 && c.pw == 0 && c.cin != 3;
+        int slots = 0;
+        for (auto& st : c.ep) slots += st.kind == EP_BIAS ? 1 : (st.kind == EP_BN ? 2 : 0);
+        if (one && gate_src[oj] < 0 && !T[c.out].plain && slots <= 2 && T[d.in].cs % 8 == 0 && !T[d.in].plain) {
+          // shape on the fused path?  (asks the launcher, which also raises the kernel's LDS limit on this device)
+          DwPwArgs q{};
+          q.K = d.kh; q.SH = d.sh; q.SW = d.sw;
+          q.c.Cs_in = T[d.out].cs;
+          const int tiles = (T[c.out].cs + 31) / 32, nt = conv_nt_for(tiles);
+          q.c.NTtot = (tiles + nt - 1) / nt * nt;
+          Epilogue none{};
+          if (d.kh == d.kw && launch_dwpw(q, none, none, nullptr, true)) dwpw_of[oj] = oi;
+        }
+        break;
+      }
+    }
+  }
+  std::vector<char> fused_dw(nops, 0);
+  for (int oj = 0; oj < nops; ++oj) if (dwpw_of[oj] >= 0) fused_dw[dwpw_of[oj]] = 1;
   std::vector<int> last(plan_.ntensors, -1);
   for (int oi = 0; oi < nops; ++oi) {
     auto& op = plan_.ops[oi];
-    if (folded[oi]) continue;  // its reads happen in the conv it was folded into
+    if (folded[oi] || fused_dw[oi]) continue;  // its reads happen in the conv it was folded / fused into
     if (gate_src[oi] >= 0) { last[gate_src[oi]] = oi; last[gate_tid[oi]] = oi; }
+    else if (dwpw_of[oi] >= 0) last[plan_.ops[dwpw_of[oi]].in] = oi;
     else if (op.in >= 0) last[op.in] = oi;
     for (int t : op.ins) last[t] = oi;
     for (auto& st : op.ep) if (st.tid >= 0) last[st.tid] = oi;
@@ -465,17 +503,19 @@ bool Net::bind(int N, int H, int W, std::string& err) {
   };
   for (int oi = 0; oi < nops; ++oi) {
     auto& op = plan_.ops[oi];
-    if (folded[oi]) { T[op.out].offset = 0; continue; }  // never materialised
+    if (folded[oi] || fused_dw[oi]) { T[op.out].offset = 0; continue; }  // never materialised
     if (op.out >= 0) T[op.out].offset = alloc(T[op.out].numel());
     if (op.kind == PlanOp::GAP) gap_need = std::max(gap_need, (size_t)T[op.in].n * T[op.in].h * T[op.in].cs);
     // free tensors whose last reader is this op (never the op's own output)
     for (int t = 1; t < plan_.ntensors; ++t)
-      if (!keep_all_ && last[t] == oi && t != op.out && T[t].numel()) release(T[t].offset, T[t].numel());
+      if (keep_all_ == 0 && last[t] == oi && t != op.out && T[t].numel()) release(T[t].offset, T[t].numel());
   }
   // `top` may have shrunk at the end; capacity must cover the high-water mark
   size_t high = 0;
   std::vector<char> dead(plan_.ntensors, 0);
-  for (int oi = 0; oi < nops; ++oi) if (folded[oi]) dead[plan_.ops[oi].out] = 1;
+  for (int oi = 0; oi < nops; ++oi) if (folded[oi] || fused_dw[oi]) dead[plan_.ops[oi].out] = 1;
+  B->exists.assign(plan_.ntensors, 0);
+  for (int t = 1; t < plan_.ntensors; ++t) B->exists[t] = !dead[t];
   for (int t = 1; t < plan_.ntensors; ++t) if (!dead[t]) high = std::max(high, T[t].offset + ((T[t].numel() + 63) & ~(size_t)63));
   if (high > arena_cap_) {
     if (arena_) (void)hipFree(arena_);
@@ -497,7 +537,7 @@ bool Net::bind(int N, int H, int W, std::string& err) {
   char nm[160];
   for (int oi = 0; oi < nops; ++oi) {
     auto& op = plan_.ops[oi];
-    if (op.kind == PlanOp::OUTPUT || folded[oi]) continue;
+    if (op.kind == PlanOp::OUTPUT || folded[oi] || fused_dw[oi]) continue;
     const TensorDesc& o = T[op.out];
     float* optr = arena_ + o.offset;
     Launch L;
@@ -560,7 +600,7 @@ bool Net::bind(int N, int H, int W, std::string& err) {
           // linear -> softmax with only (arg max, max prob) wanted: the softmax is folded into the linear's
           // epilogue (no logits tensor) and a per-row combine; canonical groups are 128 columns wide
           const bool fuse_head = op.kind == PlanOp::LINEAR && o.plain && oi + 1 < nops && plan_.ops[oi + 1].kind == PlanOp::SOFTMAX &&
-                                 plan_.ops[oi + 1].in == op.out && (head_amax_ || head_pmax_) && !head_probs_ && !keep_all_ &&
+                                 plan_.ops[oi + 1].in == op.out && (head_amax_ || head_pmax_) && !head_probs_ && keep_all_ == 0 &&
                                  (tiles <= 4 || nt == 4);
           if (fuse_head) {
             a.out_mode = OUT_HEAD;
@@ -599,7 +639,26 @@ bool Net::bind(int N, int H, int W, std::string& err) {
           // measured (gpurun_out r1g): LDS staging wins for multi-tap convs (3x3 96->24: 58 vs 51 TFLOP/s),
           // the direct kernel for 1x1 (480->480: 88 vs 71; thin K: 54 vs 39)
           const bool use_lds = !a.gate && a.out_mode == OUT_C8I && (impl ? !strcmp(impl, "lds") : (taps > 1 && in.cs >= 64));
-          if (use_lds) L.fn = [a, ep, nt](hipStream_t s) { if (!launch_conv3x3_tile(a, ep, nt, s)) launch_conv_lds(a, ep, nt, s); };
+          if (dwpw_of[oi] >= 0) {
+            const PlanOp& d = plan_.ops[dwpw_of[oi]];
+            const TensorDesc& din = T[d.in];
+            Epilogue epd;
+            if (!build_epilogue(d, epd, false, err)) return false;
+            DwPwArgs f{};
+            f.c = a;
+            f.c.in = nullptr;
+            f.dw_in = arena_ + din.offset; f.dw_w = dev_vec("dw:" + d.w);
+            for (int k = 0; k < epd.n; ++k)
+              if (epd.st[k].kind == EP_BIAS || epd.st[k].kind == EP_BN) { f.dw_v0 = epd.st[k].v0; f.dw_v1 = epd.st[k].kind == EP_BN ? epd.st[k].v1 : nullptr; }
+            f.H = din.h; f.W = din.w; f.K = d.kh; f.SH = d.sh; f.SW = d.sw; f.PH = d.ph; f.PW = d.pw;
+            snprintf(nm, sizeof nm, "%s.%02d.dwpw%dx%d_%d_%d_s%d%d", plan_.name.c_str(), dwpw_of[oi], d.kh, d.kw, op.cin, op.cout, d.sh, d.sw);
+            L.name = nm;
+            L.flops += 2.0 * a.M * d.kh * d.kw * d.c;
+            L.bytes = 4.0 * ((double)din.n * din.h * din.w * d.c + (double)a.M * cols + (double)op.cin * cols + (double)d.kh * d.kw * d.c);
+            L.fn = [f, epd, ep](hipStream_t s) {
+              if (!launch_dwpw(f, epd, ep, s)) { fprintf(stderr, "launch_dwpw: shape accepted at bind time was refused at launch\n"); abort(); }
+            };
+          } else if (use_lds) L.fn = [a, ep, nt](hipStream_t s) { if (!launch_conv3x3_tile(a, ep, nt, s)) launch_conv_lds(a, ep, nt, s); };
           else L.fn = [a, ep, nt](hipStream_t s) { launch_conv_mfma(a, ep, nt, s); };
         }
       } break;
@@ -832,6 +891,7 @@ void Net::collect_timings() {
 bool Net::fetch_logical(int tid, std::vector<float>& host, int dims[4], hipStream_t s, std::string& err) {
   if (tid < 0) tid = out_tid_;
   if (tid <= 0 || tid >= plan_.ntensors || !cur_) { err = "bad tensor id"; return false; }
+  if (!cur_->exists[tid]) { err = "tensor is fused away under this binding (never written to device memory)"; return false; }
   const TensorDesc& t = tensors_[tid];
   dims[0] = t.n; dims[1] = t.h; dims[2] = t.w; dims[3] = t.c;
   const long M = (long)t.n * t.h * t.w;

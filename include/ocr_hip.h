@@ -191,9 +191,13 @@ typedef struct ocr_net ocr_net;
  * falling back to <model_dir>/synthetic.pdiparams). */
 int ocr_net_create(const char* kind, const char* model_dir, const char* weights, int device_id, ocr_net** out);
 void ocr_net_destroy(ocr_net* h);
-/* x: host f32 [N,H,W,3] (already normalised, BGR order).  keep_all != 0 keeps every intermediate tensor. */
+/* x: host f32 [N,H,W,3] (already normalised, BGR order).  keep_all: 0 = production launch list and arena reuse;
+ * 1 = every plan tensor materialised in its own slot (no fusion); 2 = the production launch list (SE gates folded,
+ * depthwise->pointwise pairs fused) with every tensor it writes kept in its own slot. */
 int ocr_net_forward(ocr_net* h, const float* x, int N, int H, int W, int keep_all);
 int ocr_net_num_tensors(ocr_net* h);
+/* 1 if the last forward wrote tensor `tid` to device memory (fused-away tensors never exist), else 0 */
+int ocr_net_tensor_exists(ocr_net* h, int tid);
 /* tid < 0: network output.  out receives logical NHWC; dims = {N,H,W,C}. */
 int ocr_net_fetch(ocr_net* h, int tid, float* out, size_t cap_floats, int dims[4]);
 /* HIP-event timing of the launches of subsequent ocr_net_forward calls */

@@ -77,6 +77,33 @@ def test_production_mode_output_bit_identical(pkg, built, kind, shape):
     g.close()
 
 
+@pytest.mark.parametrize("kind,shape", [("det", (2, 96, 160)), ("det", (1, 192, 384)), ("det", (3, 64, 64)), ("rec", (3, 48, 320)),
+                                        ("rec", (2, 28, 192)), ("rec", (1, 48, 1000)), ("rec", (5, 48, 136)), ("cls", (3, 48, 192))])
+def test_fused_launch_list_every_materialised_tensor_bit_identical(pkg, built, kind, shape):
+    """keep_all=2 runs the PRODUCTION launch list (SE gates folded into 1x1 convs, depthwise -> pointwise pairs fused
+    into one launch: kernels_dwpw.hip) but gives every tensor its own slot: each tensor the fused list still writes
+    must equal the oracle's, and the fused-away ones must be exactly the depthwise outputs / gated products.
+    Shapes include maps that are not multiples of the 8x16 / 4x16 tiles and single-row-pair maps."""
+    from oracle import OracleNet
+    x = np.random.RandomState(5).randn(shape[0], shape[1], shape[2], 3).astype(np.float32)
+    o = OracleNet(kind)
+    g = pkg.Net(kind)
+    yo, yg = o.run(x), g.forward(x, keep_all=2)
+    assert yo.shape == yg.shape and np.array_equal(yo, yg)
+    missing = 0
+    for tid in range(1, g.num_tensors()):
+        to = o.tensor(tid)
+        if not to.size:
+            continue
+        if g.exists(tid):
+            assert np.array_equal(to, g.fetch(tid)), "tensor %d" % tid
+        else:
+            missing += 1
+    if kind in ("det", "rec"):
+        assert missing >= 8          # the fused pairs really ran fused
+    g.close()
+
+
 @pytest.mark.parametrize("graph", ["1", "0"])
 @pytest.mark.parametrize("kind,shape,other", [("rec", (3, 48, 160), (2, 48, 96)), ("det", (2, 64, 96), (1, 96, 64)),
                                               ("cls", (4, 48, 192), (1, 48, 192))])

@@ -188,6 +188,9 @@ def main(argv=None):
         vimgs, vprobs = stub_inputs(vseeds) if vcount else (None, None)
     else:
         workers = max(1, min(16, (os.cpu_count() or 2) // max(1, world)))
+        if any("rocprof" in os.environ.get(k, "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_FORCE_LOAD")) \
+                or any(k.startswith("ROCPROF") for k in os.environ):
+            workers = 1   # a profiler's preloaded library has initialised the GPU already: do not fork this process
         imgs, probs = make_inputs(seeds, workers)
         vimgs, vprobs = make_inputs(vseeds, workers) if vcount else (None, None)
 

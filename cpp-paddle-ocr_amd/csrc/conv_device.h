@@ -106,7 +106,7 @@ __device__ __forceinline__ float4 apply_epilogue4(const Epilogue& ep, float4 v, 
 // heads) is a template parameter so the packed path keeps its 16-byte stores.
 template <int NT, int MODE>
 __device__ __forceinline__ void conv_finish(const ConvArgs& a, const Epilogue& ep, floatx16 (&acc)[NT], int nt0, long m, int hb,
-                                            const float* spar) {
+                                            const float* spar, const int sstride = NT * 32) {
   if (m >= a.M) return;
   // the pixel's (n, y, x) is only needed by the deconv scatter and by the per-image / upsampled
   // stages: decoded there (two integer divisions), not in front of every K loop
@@ -152,7 +152,7 @@ __device__ __forceinline__ void conv_finish(const ConvArgs& a, const Epilogue& e
     const EpStage& st = ep.st[s];
     switch (st.kind) {
       case EP_BIAS: {
-        const float* q0 = spar + vs * NT * 32 + 4 * hb;
+        const float* q0 = spar + vs * sstride + 4 * hb;
         vs += 1;
         OCR_EP_SWEEP({ const float4 b = *(const float4*)(q0 + rel); wx = wx + b.x; wy = wy + b.y; wz = wz + b.z; ww = ww + b.w; })
       } break;
@@ -165,11 +165,11 @@ __device__ __forceinline__ void conv_finish(const ConvArgs& a, const Epilogue& e
         OCR_EP_SWEEP({ wx = wx + k; wy = wy + k; wz = wz + k; ww = ww + k; })
       } break;
       case EP_BN: {
-        const float* q0 = spar + vs * NT * 32 + 4 * hb;
+        const float* q0 = spar + vs * sstride + 4 * hb;
         vs += 2;
         OCR_EP_SWEEP({
           const float4 sc = *(const float4*)(q0 + rel);
-          const float4 sh = *(const float4*)(q0 + NT * 32 + rel);
+          const float4 sh = *(const float4*)(q0 + sstride + rel);
           float u;
           u = wx * sc.x; wx = u + sh.x;
           u = wy * sc.y; wy = u + sh.y;

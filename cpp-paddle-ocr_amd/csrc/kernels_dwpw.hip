@@ -46,131 +46,174 @@ struct DwPwGeom {
   static constexpr int IN_TILE = IH * IW * S, OP_TILE = P * S, WT = K * K * CK;
   static constexpr int G_PIECES = IH * IW * Q, G_PER = (G_PIECES + 255) / 256;
   static constexpr int NIT = (TH / PR) * TW * Q, IT_PER = (NIT + 255) / 256;
-  static constexpr int VEC_SLOTS = 2;  // per-channel vectors of the 1x1 conv's epilogue (host checks)
-  static constexpr size_t lds_floats(int nt) {
-    return 2 * (size_t)IN_TILE + 2 * (size_t)OP_TILE + 2 * (size_t)WT + 4 * (size_t)CK + (size_t)WC * VEC_SLOTS * nt * 32;
+  static constexpr size_t lds_floats(int nttot) {
+    return 2 * (size_t)IN_TILE + 2 * (size_t)OP_TILE + 2 * (size_t)WT + 2 * (size_t)CK + (size_t)nttot * 32;
   }
 };
 
-// per-channel epilogue vectors of the 1x1 conv for the WC column groups of this workgroup (conv_stage_params for
-// more than one group): region wc holds slot*NT*32 + row, as conv_finish<NT> reads it
-template <int NT, int WC, int SLOTS>
-__device__ __forceinline__ void dwpw_stage_params(const ConvArgs& a, const Epilogue& ep, int nt0_wg, float* spar) {
-  const int i = threadIdx.x;
-  if (i < WC * NT * 32) {
-    const int g = i / (NT * 32), ii = i - g * (NT * 32);
-    const int R = (nt0_wg + g * NT) * 32 + ii;
-    const int pc = R >= a.ColsStore ? 0 : R;
-    float v[2 * OCR_MAX_EP];
-#pragma unroll
-    for (int s = 0; s < OCR_MAX_EP; ++s) {
-      const int kind = s < ep.n ? ep.st[s].kind : -1;
-      v[2 * s] = (kind == EP_BIAS || kind == EP_BN) ? ep.st[s].v0[pc] : 0.f;
-      v[2 * s + 1] = kind == EP_BN ? ep.st[s].v1[pc] : 0.f;
+// position of a work unit (column block fastest, then tile x, tile y, image), advanced without divisions
+struct UnitPos {
+  int cb, tx, ty, n;
+  __device__ __forceinline__ void init(unsigned u, int cblocks, int tiles_x, int tiles_y) {
+    cb = (int)(u % (unsigned)cblocks);
+    unsigned t = u / (unsigned)cblocks;
+    tx = (int)(t % (unsigned)tiles_x);
+    t /= (unsigned)tiles_x;
+    ty = (int)(t % (unsigned)tiles_y);
+    n = (int)(t / (unsigned)tiles_y);
+  }
+  __device__ __forceinline__ void next(int cblocks, int tiles_x, int tiles_y) {
+    if (++cb == cblocks) {
+      cb = 0;
+      if (++tx == tiles_x) {
+        tx = 0;
+        if (++ty == tiles_y) { ty = 0; ++n; }
+      }
     }
-    float* dst = spar + g * (SLOTS * NT * 32) + ii;
-    int vs = 0;
-#pragma unroll
-    for (int s = 0; s < OCR_MAX_EP; ++s) {
-      const int kind = s < ep.n ? ep.st[s].kind : -1;
-      if ((kind == EP_BIAS || kind == EP_BN) && vs < SLOTS) { dst[vs * NT * 32] = v[2 * s]; ++vs; }
-      if (kind == EP_BN && vs < SLOTS) { dst[vs * NT * 32] = v[2 * s + 1]; ++vs; }
-    }
+  }
+};
+
+// the LAB chain on two packed pairs; bias already added by the caller where it comes from elsewhere
+template <bool ACT>
+__device__ __forceinline__ void lab_apply(F4& v, const ocr_f2 blo, const ocr_f2 bhi, const float s0, const float a0, const float s1,
+                                          const float a1, const bool fast) {
+  const ocr_f2 S0 = {s0, s0}, A0 = {a0, a0};
+  v.lo = v.lo + blo; v.hi = v.hi + bhi;
+  v.lo = S0 * v.lo; v.hi = S0 * v.hi;
+  v.lo = v.lo + A0; v.hi = v.hi + A0;
+  if constexpr (ACT) {
+    if (fast) { v.lo = ocr_hswish2_fast(v.lo); v.hi = ocr_hswish2_fast(v.hi); }
+    else { v.lo.x = ocr_hswish_div(v.lo.x); v.lo.y = ocr_hswish_div(v.lo.y); v.hi.x = ocr_hswish_div(v.hi.x); v.hi.y = ocr_hswish_div(v.hi.y); }
+    const ocr_f2 S1 = {s1, s1}, A1 = {a1, a1};
+    v.lo = S1 * v.lo; v.hi = S1 * v.hi;
+    v.lo = v.lo + A1; v.hi = v.hi + A1;
   }
 }
 
 }  // namespace
 
-template <int K, int SH, int SW, int CK, bool WIDE, int NT>
-__global__ void __launch_bounds__(256, 2) dwpw_kernel(const DwPwArgs a, const Epilogue epd, const Epilogue epp) {
+// A workgroup owns a contiguous range of `upw` work units (unit = one pixel tile x one column block, in
+// raster order, XCD-contiguous) and runs ONE software pipeline over all (unit, channel chunk) items of the range, so
+// the loads of the next tile are in flight while the current one is multiplied and stored:
+//   iteration k:  DW(k)   MMA(k-1) [+ the 1x1 conv's epilogue and stores when it closes a unit]   S(k+1)   G(k+3)   barrier
+// G runs two items ahead of S through two register sets, S one item ahead of DW through two LDS buffers.
+// Everything per-thread that does not depend on the tile (LDS offsets of its pieces and items) is computed once.
+template <int K, int SH, int SW, int CK, bool WIDE, int NT, bool DWACT, int GD>
+__global__ void __launch_bounds__(256, 2) dwpw_kernel(const DwPwArgs a) {
   using G_ = DwPwGeom<K, SH, SW, CK, WIDE>;
   constexpr int WC = G_::WC, TW = G_::TW, TH = G_::TH, PR = G_::PR, IW = G_::IW;
   constexpr int S = G_::S, Q = G_::Q, C8S = G_::C8S, IN_TILE = G_::IN_TILE, OP_TILE = G_::OP_TILE, WT = G_::WT;
-  constexpr int G_PIECES = G_::G_PIECES, G_PER = G_::G_PER, NIT = G_::NIT, IT_PER = G_::IT_PER, SLOTS = G_::VEC_SLOTS;
+  constexpr int G_PIECES = G_::G_PIECES, G_PER = G_::G_PER, NIT = G_::NIT, IT_PER = G_::IT_PER;
   constexpr int WQ = K * K * Q;  // 16-byte pieces of the chunk's depthwise weights
-  static_assert(WQ + 2 * Q <= 256, "one weight / vector piece per thread");
+  static_assert(WQ + Q <= 256, "one weight / bias piece per thread");
   static_assert(C8S % 2 == 0, "the fragment stream is walked two octets at a time");
+  static_assert(NIT % 256 == 0, "every thread owns the same number of depthwise items");
   extern __shared__ float4 s_dwpw4[];
   float* s_in = (float*)s_dwpw4;      // [2][IH*IW][S]   haloed input region of a chunk
   float* s_op = s_in + 2 * IN_TILE;   // [2][P][S]       depthwise result = MFMA pixel operand
   float* s_w = s_op + 2 * OP_TILE;    // [2][K*K][CK]    depthwise weights of a chunk
-  float* s_b = s_w + 2 * WT;          // [2][2][CK]      its per-channel vectors (bias | BN scale, BN shift)
-  float* s_par = s_b + 4 * CK;        // [WC][SLOTS][NT*32]  the 1x1 conv's per-channel vectors
+  float* s_b = s_w + 2 * WT;          // [2][CK]         depthwise bias of a chunk
+  float* s_par = s_b + 2 * CK;        // [NTtot*32]      the 1x1 conv's bias, every column
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int p = lane & 31, h = lane >> 5;
   const ConvArgs& c = a.c;
   const int Cs = c.Cs_in;
-  const unsigned lb = xcd_swizzle(blockIdx.x, gridDim.x);  // column block fastest, then tiles in raster order
-  const unsigned cblocks = (unsigned)c.NTtot / (NT * WC);
-  const int cb = (int)(lb % cblocks);
-  unsigned tile = lb / cblocks;
-  const int tx = (int)(tile % (unsigned)a.tiles_x);
-  tile /= (unsigned)a.tiles_x;
-  const int ty = (int)(tile % (unsigned)a.tiles_y), n = (int)(tile / (unsigned)a.tiles_y);
-  const int y0 = ty * TH, x0 = tx * TW;
-  const int wp = WIDE ? (wave & 1) : wave, wc = WIDE ? (wave >> 1) : 0;
-  const int nt0 = (cb * WC + wc) * NT;
   const int nch = Cs / CK;
+  const int cblocks = c.NTtot / (NT * WC);
+  const int wp = WIDE ? (wave & 1) : wave, wc = WIDE ? (wave >> 1) : 0;
+  // ---- this workgroup's units
+  const unsigned lb = xcd_swizzle(blockIdx.x, gridDim.x);
+  const unsigned u0 = lb * a.upw;
+  const unsigned u1 = u0 + a.upw < a.nunits ? u0 + a.upw : a.nunits;
+  if (u0 >= u1) return;
+  const int nunits = (int)(u1 - u0);
+  const int total = nunits * nch;
 
-  // ---- fill plan: this thread's pieces of the input region (float offset inside the image, -1 = zero)
-  const float* img = a.dw_in + (long)n * a.H * a.W * Cs;
-  const int iy0 = y0 * SH - a.PH, ix0 = x0 * SW - a.PW;
-  int goff[G_PER];
+  // ---- per-thread plans (tile-independent)
+  int g_lds[G_PER], g_pos[G_PER];  // LDS float offset of piece i; (row << 16 | column << 8 | first channel) in the region, -1: none
 #pragma unroll
   for (int i = 0; i < G_PER; ++i) {
     const int idx = tid + i * 256;
     const int px = idx / Q, q = idx - px * Q;
     const int py = px / IW, pxx = px - py * IW;
-    const int iy = iy0 + py, ix = ix0 + pxx;
-    const bool ok = idx < G_PIECES && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-    goff[i] = ok ? (iy * a.W + ix) * Cs + 4 * q : -1;
+    g_lds[i] = px * S + 4 * q;
+    g_pos[i] = idx < G_PIECES ? ((py << 16) | (pxx << 8) | (4 * q)) : -1;
   }
-  float4 greg[G_PER];
-  float4 wreg = make_float4(0.f, 0.f, 0.f, 0.f);
-  auto G = [&](int ch) {
-    const float* base = img + ch * CK;
+  int d_in[IT_PER], d_op[IT_PER], d_q[IT_PER];
 #pragma unroll
-    for (int i = 0; i < G_PER; ++i)
-      greg[i] = goff[i] >= 0 ? *(const float4*)(base + goff[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
-    if (tid < WQ) {
-      const int t = tid / Q, q = tid - t * Q;
-      wreg = *(const float4*)(a.dw_w + (long)t * Cs + ch * CK + 4 * q);
-    } else if (tid < WQ + 2 * Q) {
-      const int j = tid - WQ;
-      const float* src = j < Q ? a.dw_v0 : a.dw_v1;
-      wreg = src ? *(const float4*)(src + ch * CK + 4 * (j < Q ? j : j - Q)) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  };
-  auto Sfill = [&](int buf) {
-    float* si = s_in + buf * IN_TILE;
+  for (int u = 0; u < IT_PER; ++u) {
+    const int it = tid + u * 256;
+    const int txx = it & (TW - 1), r_ = it / TW;
+    const int rp = r_ % (TH / PR), q = r_ / (TH / PR);
+    d_in[u] = ((rp * PR * SH) * IW + txx * SW) * S + 4 * q;
+    d_op[u] = (rp * PR * TW + txx) * S + 4 * q;
+    d_q[u] = 4 * q;
+  }
+
+  // ---- G: global -> registers, item by item (its own unit / chunk counters run ahead of everything else)
+  UnitPos g_pos_u;
+  g_pos_u.init(u0, cblocks, a.tiles_x, a.tiles_y);
+  int g_units = nunits, g_ch = 0;
+  const float* g_img = a.dw_in;
+  int goff[G_PER];
+  auto g_setup = [&]() __attribute__((always_inline)) {  // image offsets of this thread's pieces for unit g_pos_u (-1: zero)
+    g_img = a.dw_in + (long)g_pos_u.n * a.H * a.W * Cs;
+    const int iy0 = g_pos_u.ty * TH * SH - a.PH, ix0 = g_pos_u.tx * TW * SW - a.PW;
 #pragma unroll
     for (int i = 0; i < G_PER; ++i) {
-      const int idx = tid + i * 256;
-      const int px = idx / Q, q = idx - px * Q;
-      if (G_PIECES % 256 == 0 || idx < G_PIECES) *(float4*)(si + px * S + 4 * q) = greg[i];
+      const int iy = iy0 + (g_pos[i] >> 16), ix = ix0 + ((g_pos[i] >> 8) & 0xff);
+      const bool ok = g_pos[i] >= 0 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+      goff[i] = ok ? (iy * a.W + ix) * Cs + (g_pos[i] & 0xff) : -1;
     }
+  };
+  auto G = [&](float4 (&greg)[G_PER], float4& wreg) __attribute__((always_inline)) {
+    if (g_units > 0) {
+      const float* base = g_img + g_ch * CK;
+#pragma unroll
+      for (int i = 0; i < G_PER; ++i)
+#ifdef OCR_DWPW_NO_G  // development probe (tools/micro/dwpw_probe.hip): no input traffic
+        greg[i] = make_float4((float)goff[i], (float)(size_t)base, 0.f, 0.f);
+#else
+        greg[i] = goff[i] >= 0 ? *(const float4*)(base + goff[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
+#endif
+      if (tid < WQ) wreg = *(const float4*)(a.dw_w + (long)(tid / Q) * Cs + g_ch * CK + 4 * (tid % Q));
+      else if (tid < WQ + Q) wreg = *(const float4*)(a.dw_ep.bias + g_ch * CK + 4 * (tid - WQ));
+      if (++g_ch == nch) {
+        g_ch = 0;
+        if (--g_units > 0) {
+          g_pos_u.next(cblocks, a.tiles_x, a.tiles_y);
+          g_setup();
+        }
+      }
+    }
+  };
+  auto Sfill = [&](int buf, const float4 (&greg)[G_PER], const float4& wreg) __attribute__((always_inline)) {
+    float* si = s_in + buf * IN_TILE;
+#pragma unroll
+    for (int i = 0; i < G_PER; ++i)
+      if (G_PIECES % 256 == 0 || g_pos[i] >= 0) *(float4*)(si + g_lds[i]) = greg[i];
     if (tid < WQ) *(float4*)(s_w + buf * WT + 4 * tid) = wreg;            // [tap][CK]: tap*CK + 4q = 4*tid
-    else if (tid < WQ + 2 * Q) *(float4*)(s_b + buf * 2 * CK + 4 * (tid - WQ)) = wreg;
+    else if (tid < WQ + Q) *(float4*)(s_b + buf * CK + 4 * (tid - WQ)) = wreg;
   };
 
-  // ---- depthwise conv + epilogue of one chunk: s_in[buf] -> s_op[buf]
-  auto DW = [&](int buf) {
+  // ---- depthwise conv + its LAB epilogue of one chunk: s_in[buf] -> s_op[buf]
+  const float ds0 = a.dw_ep.s0, da0 = a.dw_ep.a0, ds1 = a.dw_ep.s1, da1 = a.dw_ep.a1;
+  auto DW = [&](int buf) __attribute__((always_inline)) {
     const float* si = s_in + buf * IN_TILE;
     float* so = s_op + buf * OP_TILE;
     const float* sw = s_w + buf * WT;
-    const float* sb = s_b + buf * 2 * CK;
+    const float* sb = s_b + buf * CK;
 #pragma unroll
     for (int u = 0; u < IT_PER; ++u) {
-      const int it = tid + u * 256;
-      if (NIT % 256 != 0 && it >= NIT) break;
-      const int txx = it & (TW - 1), r_ = it / TW;
-      const int rp = r_ % (TH / PR), q = r_ / (TH / PR);
       F4 acc[PR];
 #pragma unroll
       for (int o = 0; o < PR; ++o) { acc[o].lo = ocr_f2{0.f, 0.f}; acc[o].hi = ocr_f2{0.f, 0.f}; }
-      const float* col = si + ((rp * PR * SH) * IW + txx * SW) * S + 4 * q;
-      const float* wq = sw + 4 * q;
+      const float* col = si + d_in[u];
+      const float* wq = sw + d_q[u];
+#ifdef OCR_DWPW_NO_TAPS  // development probe: epilogue and operand write only
+      acc[0].lo.x = col[0] + wq[0];
+#else
 #pragma unroll
       for (int r = 0; r < (PR - 1) * SH + K; ++r) {
 #pragma unroll
@@ -186,78 +229,68 @@ __global__ void __launch_bounds__(256, 2) dwpw_kernel(const DwPwArgs a, const Ep
           }
         }
       }
-      // the depthwise conv's epilogue (bias / BN, LAB scalars, activation), stage loop outside
-      for (int s = 0; s < epd.n; ++s) {
-        const EpStage& st = epd.st[s];
-#define OCR_DP_SWEEP(BODY) _Pragma("unroll") for (int o = 0; o < PR; ++o) { F4& v = acc[o]; BODY }
-        switch (st.kind) {
-          case EP_BIAS: {
-            const float4 b = *(const float4*)(sb + 4 * q);
-            const ocr_f2 blo = {b.x, b.y}, bhi = {b.z, b.w};
-            OCR_DP_SWEEP({ v.lo = v.lo + blo; v.hi = v.hi + bhi; })
-          } break;
-          case EP_SMUL: {
-            const ocr_f2 k = {st.p0, st.p0};
-            OCR_DP_SWEEP({ v.lo = k * v.lo; v.hi = k * v.hi; })
-          } break;
-          case EP_SADD: {
-            const ocr_f2 k = {st.p0, st.p0};
-            OCR_DP_SWEEP({ v.lo = v.lo + k; v.hi = v.hi + k; })
-          } break;
-          case EP_BN: {
-            const float4 sc = *(const float4*)(sb + 4 * q), sh = *(const float4*)(sb + CK + 4 * q);
-            const ocr_f2 clo = {sc.x, sc.y}, chi = {sc.z, sc.w}, hlo = {sh.x, sh.y}, hhi = {sh.z, sh.w};
-            OCR_DP_SWEEP({
-              ocr_f2 t;
-              t = v.lo * clo; v.lo = t + hlo;
-              t = v.hi * chi; v.hi = t + hhi;
-            })
-          } break;
-          case EP_ACT: {
-            const float p0 = st.p0, p1 = st.p1;
-#define OCR_DP_ACT(KIND) OCR_DP_SWEEP({ v.lo.x = ocr_act(KIND, p0, p1, v.lo.x); v.lo.y = ocr_act(KIND, p0, p1, v.lo.y); v.hi.x = ocr_act(KIND, p0, p1, v.hi.x); v.hi.y = ocr_act(KIND, p0, p1, v.hi.y); })
-            switch (st.act) {
-              case ACT_RELU: OCR_DP_ACT(ACT_RELU) break;
-              case ACT_HSWISH: {
-                float mn = INFINITY, mx = 0.0f;
-                OCR_DP_SWEEP({ ocr_absrange(mn, mx, v.lo.x, v.lo.y); ocr_absrange(mn, mx, v.hi.x, v.hi.y); })
-                if (ocr_hsw_fast_ok(mn, mx)) { OCR_DP_SWEEP({ v.lo = ocr_hswish2_fast(v.lo); v.hi = ocr_hswish2_fast(v.hi); }) }
-                else { OCR_DP_ACT(ACT_HSWISH) }
-              } break;
-              case ACT_HSIG: OCR_DP_ACT(ACT_HSIG) break;
-              case ACT_SWISH: OCR_DP_ACT(ACT_SWISH) break;
-              default: OCR_DP_ACT(ACT_SIGMOID) break;
-            }
-#undef OCR_DP_ACT
-          } break;
-          default: break;  // per-pixel stages never follow a fused depthwise conv (host checks)
+#endif
+      const float4 b = *(const float4*)(sb + d_q[u]);
+      const ocr_f2 blo = {b.x, b.y}, bhi = {b.z, b.w};
+      bool fast = true;
+      if constexpr (DWACT) {  // the division-free hard-swish needs every pre-activation value in its proven range
+        const ocr_f2 S0 = {ds0, ds0}, A0 = {da0, da0};
+        float mn = INFINITY, mx = 0.0f;
+#pragma unroll
+        for (int o = 0; o < PR; ++o) {
+          ocr_f2 tl = acc[o].lo + blo, th = acc[o].hi + bhi;
+          tl = S0 * tl; th = S0 * th;
+          tl = tl + A0; th = th + A0;
+          ocr_absrange(mn, mx, tl.x, tl.y);
+          ocr_absrange(mn, mx, th.x, th.y);
         }
-#undef OCR_DP_SWEEP
+        fast = ocr_hsw_fast_ok(mn, mx);
       }
 #pragma unroll
-      for (int o = 0; o < PR; ++o)
-        *(float4*)(so + ((rp * PR + o) * TW + txx) * S + 4 * q) = make_float4(acc[o].lo.x, acc[o].lo.y, acc[o].hi.x, acc[o].hi.y);
+      for (int o = 0; o < PR; ++o) {
+        lab_apply<DWACT>(acc[o], blo, bhi, ds0, da0, ds1, da1, fast);
+        *(float4*)(so + d_op[u] + o * TW * S) = make_float4(acc[o].lo.x, acc[o].lo.y, acc[o].hi.x, acc[o].hi.y);
+      }
     }
   };
 
-  // ---- 1x1 conv of one chunk on the matrix cores: s_op[buf] x fragment image
+  // ---- 1x1 conv on the matrix cores: s_op[buf] x fragment image; its own unit / step counters (B runs a step ahead)
   floatx16 acc[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
-  const float4* p_w = (const float4*)c.wfrag + (long)nt0 * 64 + lane;
   const long wstride = (long)c.NTtot * 64;
-  int w_left = nch * C8S - 1;  // fragment steps after the current one
-  float4 b0[NT], b1[NT];
-  auto loadB = [&](float4 (&bv)[NT]) {
+  const int KK = nch * C8S;
+  UnitPos b_pos, m_pos;
+  b_pos.init(u0, cblocks, a.tiles_x, a.tiles_y);
+  m_pos = b_pos;
+  int b_units = nunits, b_step = 0;
+  const float4* const w_lane = (const float4*)c.wfrag + (long)wc * NT * 64 + lane;
+  const float4* p_w = w_lane + (long)b_pos.cb * WC * NT * 64;
+  // The fragments of a WHOLE chunk are fetched at the top of the iteration that multiplies it, before the depthwise
+  // phase: the L2 round trip (the streamed input evicts them from L1) hides behind the depthwise arithmetic.
+  float4 bq[C8S][NT];
+  auto loadB = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t) bv[t] = p_w[t * 64];
-    const bool more = w_left > 0;  // past the end: stay on the last step (loaded, unused)
-    p_w += more ? wstride : 0;
-    w_left -= more;
+    for (int j = 0; j < C8S; ++j) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) bq[j][t] = p_w[j * wstride + t * 64];
+    }
+    b_step += C8S;
+    if (b_step == KK) {  // next unit: back to the first step of ITS column block (past the end: the last one again)
+      b_step = 0;
+      if (b_units > 1) { --b_units; b_pos.next(cblocks, a.tiles_x, a.tiles_y); }
+      p_w = w_lane + (long)b_pos.cb * WC * NT * 64;
+    } else {
+      p_w += C8S * wstride;
+    }
   };
-  auto mfma4 = [&](const float4 (&bv)[NT], const float4& av) {
+  auto mfma4 = [&](const float4 (&bv)[NT], const float4& av) __attribute__((always_inline)) {
+#ifdef OCR_DWPW_NO_MMA  // development probe: operands fetched, matrix pipe idle
+    acc[0][0] += bv[0].x * av.x + bv[NT - 1].w * av.w;
+    return;
+#endif
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[t].x, av.x, acc[t], 0, 0, 0);
@@ -266,79 +299,194 @@ __global__ void __launch_bounds__(256, 2) dwpw_kernel(const DwPwArgs a, const Ep
       acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[t].w, av.w, acc[t], 0, 0, 0);
     }
   };
-  auto MMA = [&](int buf) {
-    const float* so = s_op + buf * OP_TILE + (wp * 32 + p) * S + 4 * h;
+  const float ps0 = a.pw_ep.s0, pa0 = a.pw_ep.a0, ps1 = a.pw_ep.s1, pa1 = a.pw_ep.a1;
+  const int pix = wp * 32 + p, pix_y = pix / TW, pix_x = pix & (TW - 1);
+  const int op_off = pix * S + 4 * h;
+  // the 1x1 conv's LAB epilogue + 16-byte stores for this lane's pixel: acc[t][4g..4g+3] = physical channels
+  // nt0*32 + 32t + 8g + 4h .. +3 (conv_device.h, conv_finish)
+  auto finish = [&]() __attribute__((always_inline)) {
+    const int nt0 = (m_pos.cb * WC + wc) * NT;
+    const int oy = m_pos.ty * TH + pix_y, ox = m_pos.tx * TW + pix_x;
+    const bool inside = oy < c.OH && ox < c.OW;
+    const int r0 = nt0 * 32 + 4 * h;
+    const float* sp = s_par + r0;
+    float* obase = c.out + (((long)m_pos.n * c.OH + oy) * c.OW + ox) * c.Cs_out + r0;
+    const ocr_f2 S0 = {ps0, ps0}, A0 = {pa0, pa0};
+    float mn = INFINITY, mx = 0.0f;
 #pragma unroll
-    for (int j = 0; j < C8S; j += 2) {
-      loadB(b1);
-      mfma4(b0, *(const float4*)(so + 8 * j));
-      loadB(b0);
-      mfma4(b1, *(const float4*)(so + 8 * (j + 1)));
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 b = *(const float4*)(sp + 32 * t + 8 * g);
+        ocr_f2 tl = ocr_f2{acc[t][4 * g], acc[t][4 * g + 1]} + ocr_f2{b.x, b.y};
+        ocr_f2 th = ocr_f2{acc[t][4 * g + 2], acc[t][4 * g + 3]} + ocr_f2{b.z, b.w};
+        tl = S0 * tl; th = S0 * th;
+        tl = tl + A0; th = th + A0;
+        acc[t][4 * g] = tl.x; acc[t][4 * g + 1] = tl.y; acc[t][4 * g + 2] = th.x; acc[t][4 * g + 3] = th.y;
+        if (nt0 * 32 + 32 * t + 8 * g < c.ColsStore) { ocr_absrange(mn, mx, tl.x, tl.y); ocr_absrange(mn, mx, th.x, th.y); }
+      }
+    const bool fast = ocr_hsw_fast_ok(mn, mx);
+    const ocr_f2 S1 = {ps1, ps1}, A1 = {pa1, pa1};
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        ocr_f2 tl = {acc[t][4 * g], acc[t][4 * g + 1]}, th = {acc[t][4 * g + 2], acc[t][4 * g + 3]};
+        if (fast) { tl = ocr_hswish2_fast(tl); th = ocr_hswish2_fast(th); }
+        else { tl.x = ocr_hswish_div(tl.x); tl.y = ocr_hswish_div(tl.y); th.x = ocr_hswish_div(th.x); th.y = ocr_hswish_div(th.y); }
+        tl = S1 * tl; th = S1 * th;
+        tl = tl + A1; th = th + A1;
+#ifdef OCR_PROBE_NOSTORE
+        if (tl.x == 12345.678f)
+#endif
+        if (inside && nt0 * 32 + 32 * t + 8 * g < c.ColsStore) *(float4*)(obase + 32 * t + 8 * g) = make_float4(tl.x, tl.y, th.x, th.y);
+        acc[t][4 * g] = 0.f; acc[t][4 * g + 1] = 0.f; acc[t][4 * g + 2] = 0.f; acc[t][4 * g + 3] = 0.f;
+      }
+  };
+  int m_ch = 0;
+  auto MMA = [&](int buf) __attribute__((always_inline)) {
+    const float* so = s_op + buf * OP_TILE + op_off;
+    float4 av[C8S];
+#pragma unroll
+    for (int j = 0; j < C8S; ++j) av[j] = *(const float4*)(so + 8 * j);
+#pragma unroll
+    for (int j = 0; j < C8S; ++j) mfma4(bq[j], av[j]);
+    if (++m_ch == nch) {  // the unit is complete
+      finish();
+      m_ch = 0;
+      m_pos.next(cblocks, a.tiles_x, a.tiles_y);
     }
   };
 
   // ---- pipeline
-  G(0);
-  dwpw_stage_params<NT, WC, SLOTS>(c, epp, cb * WC * NT, s_par);
-  Sfill(0);
-  __syncthreads();
-  if (nch > 1) G(1);
-  loadB(b0);
-  for (int i = 0; i < nch; ++i) {
-    DW(i & 1);
-    if (i >= 1) MMA((i - 1) & 1);
-    if (i + 1 < nch) Sfill((i + 1) & 1);
-    if (i + 2 < nch) G(i + 2);
+  for (int i = tid; i < c.NTtot * 32; i += 256) s_par[i] = i < c.ColsStore ? a.pw_ep.bias[i] : 0.f;
+  g_setup();
+  if constexpr (GD == 2) {
+    float4 gA[G_PER], gB[G_PER], wA = make_float4(0.f, 0.f, 0.f, 0.f), wB = wA;
+#pragma unroll
+    for (int i = 0; i < G_PER; ++i) gA[i] = gB[i] = wA;
+    G(gA, wA);  // item 0
+    G(gB, wB);  // item 1
+    Sfill(0, gA, wA);
+    G(gA, wA);  // item 2
     __syncthreads();
+    // one body for every iteration (k = total only drains the last MMA); unrolled by two for the register sets
+    auto iter = [&](int k, float4 (&gs)[G_PER], float4& ws) __attribute__((always_inline)) {  // gs holds item k+1
+      if (k >= 1) loadB();
+      if (k < total) DW(k & 1);
+      if (k >= 1) MMA((k - 1) & 1);
+      if (k + 1 < total) {
+        Sfill((k + 1) & 1, gs, ws);
+        G(gs, ws);  // item k+3
+      }
+      if (k < total) __syncthreads();
+    };
+    for (int k = 0; k <= total; k += 2) {
+      iter(k, gB, wB);
+      if (k + 1 <= total) iter(k + 1, gA, wA);
+    }
+  } else {  // one register set: G runs one item ahead of S (long iterations: the matrix work covers the round trip)
+    float4 g[G_PER], w = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < G_PER; ++i) g[i] = w;
+    G(g, w);  // item 0
+    Sfill(0, g, w);
+    G(g, w);  // item 1
+    __syncthreads();
+    for (int k = 0; k <= total; ++k) {
+      if (k >= 1) loadB();
+      if (k < total) DW(k & 1);
+      if (k >= 1) MMA((k - 1) & 1);
+      if (k + 1 < total) {
+        Sfill((k + 1) & 1, g, w);
+        G(g, w);  // item k+2
+      }
+      if (k < total) __syncthreads();
+    }
   }
-  MMA((nch - 1) & 1);
-
-  const int pix = wp * 32 + p;
-  const int oy = y0 + pix / TW, ox = x0 + (pix & (TW - 1));
-  const long m = (oy < c.OH && ox < c.OW) ? ((long)n * c.OH + oy) * c.OW + ox : c.M;
-  conv_finish<NT, OUT_C8I>(c, epp, acc, nt0, m, h, s_par + wc * (SLOTS * NT * 32));
 }
 
 namespace {
 
-template <int K, int SH, int SW, int CK, bool WIDE, int NT>
-bool launch_one(const DwPwArgs& a0, const Epilogue& epd, const Epilogue& epp, hipStream_t s, bool query) {
+template <int K, int SH, int SW, int CK, bool WIDE, int NT, bool DWACT, int GD>
+bool launch_one(const DwPwArgs& a0, hipStream_t s, bool query) {
   using G_ = DwPwGeom<K, SH, SW, CK, WIDE>;
+  const size_t lds = G_::lds_floats(a0.c.NTtot) * sizeof(float);
+  // per device: the dynamic-LDS limit, and how many of these workgroups a CU holds (the grid is persistent)
+  static unsigned char attr_state[64] = {};
+  static int per_cu[64] = {}, cus[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+  if (lds > 64 * 1024 && !raise_dynamic_lds((const void*)dwpw_kernel<K, SH, SW, CK, WIDE, NT, DWACT, GD>, (int)lds, attr_state)) return false;
+  if (!per_cu[dev]) {
+    int nb = 0;
+    hipDeviceProp_t prop;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, dwpw_kernel<K, SH, SW, CK, WIDE, NT, DWACT, GD>, 256, lds) != hipSuccess || nb < 1 ||
+        hipGetDeviceProperties(&prop, dev) != hipSuccess) { (void)hipGetLastError(); return false; }
+    per_cu[dev] = nb;
+    cus[dev] = prop.multiProcessorCount;
+  }
+  if (query) return true;  // asked at bind time, on the device that will run it: a refusal falls back to the pair
   DwPwArgs a = a0;
   a.tiles_x = (a.c.OW + G_::TW - 1) / G_::TW;
   a.tiles_y = (a.c.OH + G_::TH - 1) / G_::TH;
   const unsigned cblocks = (unsigned)a.c.NTtot / (NT * G_::WC);
-  const dim3 grid((unsigned)((long)a.c.N * a.tiles_y * a.tiles_x * cblocks));
-  const size_t lds = G_::lds_floats(NT) * sizeof(float);
-  if (lds > 64 * 1024) {
-    static unsigned char attr_state[64] = {};
-    if (!raise_dynamic_lds((const void*)dwpw_kernel<K, SH, SW, CK, WIDE, NT>, (int)lds, attr_state)) return false;
-  }
-  if (query) return true;  // asked at bind time, on the device that will run it: a refusal falls back to the pair
-  hipLaunchKernelGGL((dwpw_kernel<K, SH, SW, CK, WIDE, NT>), grid, dim3(256), lds, s, a, epd, epp);
+  const long nunits = (long)a.c.N * a.tiles_y * a.tiles_x * cblocks;
+  if (nunits <= 0 || nunits > 0x7fffffffL) return false;
+  a.nunits = (unsigned)nunits;
+  // Units per workgroup: enough (unit, chunk) items for the pipeline to run in steady state, few enough that the grid
+  // stays many times larger than the chip - other streams' kernels take CU slots at any moment, and a grid sized to
+  // "exactly resident" then runs its leftover workgroups as a second full-length wave (measured: 2x on rec.07 with
+  // the odd-width lane active).  OCR_DWPW_ITEMS overrides the target item count (A/B; results are identical).
+  static const char* env = getenv("OCR_DWPW_ITEMS");
+  const int target = env ? atoi(env) : 32;
+  const int nch = a.c.Cs_in / CK;
+  long upw = (target + nch - 1) / nch;
+  const long resident = (long)cus[dev] * per_cu[dev];
+  while (upw > 1 && (nunits + upw - 1) / upw < 8 * resident) --upw;  // small problems: keep every CU busy
+  a.upw = (unsigned)upw;
+  const dim3 grid((unsigned)((nunits + upw - 1) / upw));
+  hipLaunchKernelGGL((dwpw_kernel<K, SH, SW, CK, WIDE, NT, DWACT, GD>), grid, dim3(256), lds, s, a);
   return true;
 }
 
 }  // namespace
 
+bool lab_from_epilogue(const Epilogue& ep, LabEp& out) {
+  out = LabEp{};
+  if (ep.n != 3 && ep.n != 6) return false;
+  if (ep.st[0].kind != EP_BIAS || ep.st[1].kind != EP_SMUL || ep.st[2].kind != EP_SADD) return false;
+  out.bias = ep.st[0].v0;
+  out.s0 = ep.st[1].p0;
+  out.a0 = ep.st[2].p0;
+  if (ep.n == 6) {
+    if (ep.st[3].kind != EP_ACT || ep.st[3].act != ACT_HSWISH || ep.st[4].kind != EP_SMUL || ep.st[5].kind != EP_SADD) return false;
+    out.act = 1;
+    out.s1 = ep.st[4].p0;
+    out.a1 = ep.st[5].p0;
+  }
+  return true;
+}
+
 // The instantiated shapes (everything else stays an unfused pair): K, strides, chunk width, workgroup shape
 // (thin: 4 waves = 4 pixel groups of an 8x16 tile, all <= 4 column tiles per wave; wide: 2 pixel groups of a 4x16
 // tile x 2 column groups), column tiles per wave.  `query` only answers whether the pair is on this path.
-bool launch_dwpw(const DwPwArgs& a, const Epilogue& epd, const Epilogue& epp, hipStream_t s, bool query) {
+bool launch_dwpw(const DwPwArgs& a, hipStream_t s, bool query) {
   const int K = a.K, SH = a.SH, SW = a.SW, Cs = a.c.Cs_in, tiles = a.c.NTtot;
-#define OCR_DWPW_CASE(K_, SH_, SW_, CK_, WIDE_, NT_, COND)                                                \
+  if (!a.pw_ep.act || !a.dw_ep.act) return false;  // the pairs on the hot path: full chain on both sides
+#define OCR_DWPW_CASE(K_, SH_, SW_, CK_, WIDE_, NT_, GD_, COND)                                           \
   if (K == K_ && SH == SH_ && SW == SW_ && Cs % CK_ == 0 && tiles % (NT_ * (WIDE_ ? 2 : 1)) == 0 && (COND)) \
-    return launch_one<K_, SH_, SW_, CK_, WIDE_, NT_>(a, epd, epp, s, query);
+    return launch_one<K_, SH_, SW_, CK_, WIDE_, NT_, true, GD_>(a, s, query);
   // thin layers: tiles <= 4, one wave owns every output column of its 32 pixels
-  OCR_DWPW_CASE(3, 1, 1, 16, false, 1, tiles == 1)
-  OCR_DWPW_CASE(3, 1, 1, 16, false, 2, tiles == 2)
-  OCR_DWPW_CASE(3, 1, 1, 16, false, 3, tiles == 3)
-  OCR_DWPW_CASE(3, 1, 1, 16, false, 4, tiles == 4)
-  OCR_DWPW_CASE(3, 2, 1, 16, false, 4, tiles == 4)
+  OCR_DWPW_CASE(3, 1, 1, 16, false, 1, 2, tiles == 1)
+  OCR_DWPW_CASE(3, 1, 1, 16, false, 2, 2, tiles == 2)
+  OCR_DWPW_CASE(3, 1, 1, 16, false, 3, 2, tiles == 3)
+  OCR_DWPW_CASE(3, 1, 1, 16, false, 4, 1, tiles == 4)
+  OCR_DWPW_CASE(3, 2, 1, 16, false, 4, 1, tiles == 4)
   // wide layers: two column groups per workgroup (and further column blocks in the grid)
-  OCR_DWPW_CASE(3, 1, 2, 16, true, 4, tiles == 8)
-  OCR_DWPW_CASE(5, 1, 1, 16, true, 4, tiles == 8)
-  OCR_DWPW_CASE(5, 1, 1, 32, true, 3, tiles == 6 || tiles == 12)
+  OCR_DWPW_CASE(3, 1, 2, 16, true, 4, 1, tiles == 8)
+  OCR_DWPW_CASE(5, 1, 1, 16, true, 4, 1, tiles == 8)
+  OCR_DWPW_CASE(5, 1, 1, 32, true, 3, 1, tiles == 6 || tiles == 12)
 #undef OCR_DWPW_CASE
   return false;
 }

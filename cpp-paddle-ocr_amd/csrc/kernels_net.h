@@ -67,19 +67,29 @@ struct DwArgs {
 };
 void launch_dw(const DwArgs& a, const Epilogue& ep, hipStream_t s);
 
-// Fused depthwise conv (+ its epilogue) -> 1x1 conv (+ its epilogue), kernels_dwpw.hip.  `c` describes the 1x1 conv
-// exactly as launch_conv_mfma would get it (c.in unused: its input never exists in HBM); the depthwise part:
+// Fused depthwise conv (+ its epilogue) -> 1x1 conv (+ its epilogue), kernels_dwpw.hip.  Both epilogues are the
+// PPLCNetV3 "learnable affine block" chain of the plans, fixed at compile time (a generic stage interpreter made the
+// kernel VALU-bound on its own bookkeeping):  y = x + bias[c];  y = s0 * y;  y = y + a0;  [y = hswish(y);
+// y = s1 * y;  y = y + a1]  - every step its own rounding, as ocr_common.h's stages.
+struct LabEp {
+  const float* bias;  // [Cs] physical channel order
+  float s0, a0, s1, a1;
+  int act;            // 1: the hswish + second affine follow; 0: the chain ends after a0
+};
 struct DwPwArgs {
-  ConvArgs c;
+  ConvArgs c;          // the 1x1 conv as launch_conv_mfma would get it (c.in unused: that tensor never exists; c.zeros used)
   const float* dw_in;  // [N,H,W,Cs] C8I, Cs = c.Cs_in
   const float* dw_w;   // [K*K][Cs] physical order
-  const float* dw_v0;  // per-channel vector of the depthwise epilogue's bias / BN-scale stage (null: none)
-  const float* dw_v1;  // BN shift (null: none)
+  LabEp dw_ep, pw_ep;
   int H, W, K, SH, SW, PH, PW;
   int tiles_x, tiles_y;  // filled by the launcher
+  unsigned nunits;       // work units = pixel tiles x column blocks (filled by the launcher)
+  unsigned upw;          // units per workgroup (filled by the launcher)
 };
+// host: is this stage list the chain above?  fills `out` (bias pointer left null: the caller resolves it)
+bool lab_from_epilogue(const Epilogue& ep, LabEp& out);
 // false: the shape is not instantiated (the caller launches the unfused pair).  query = true only asks.
-bool launch_dwpw(const DwPwArgs& a, const Epilogue& ep_dw, const Epilogue& ep_pw, hipStream_t s, bool query = false);
+bool launch_dwpw(const DwPwArgs& a, hipStream_t s, bool query = false);
 
 void launch_ew(const float* in, float* out, long M, int H, int W, int Cs, const Epilogue& ep, hipStream_t s);
 void launch_gap(const float* in, float* part, float* out, int N, int H, int W, int Cs, hipStream_t s);

@@ -432,28 +432,25 @@ bool Net::bind(int N, int H, int W, std::string& err) {
     for (int oi = 0; oi + 1 < nops; ++oi) {
       auto& d = plan_.ops[oi];
       if (d.kind != PlanOp::DW || d.out == out_tid_ || uses[d.out] != 1) continue;
-      int nvec = 0;
-      bool ok = true;
-      for (auto& st : d.ep) {
-        if (st.kind == EP_BIAS || st.kind == EP_BN) ++nvec;
-        else if (st.kind != EP_SMUL && st.kind != EP_SADD && st.kind != EP_ACT) ok = false;
-      }
-      if (!ok || nvec > 1) continue;
+      // both epilogues must be the LAB chain the kernel compiles in: bias | smul | sadd | hswish | smul | sadd
+      auto is_lab = [](const std::vector<PlanStage>& ep) {
+        return ep.size() == 6 && ep[0].kind == EP_BIAS && ep[1].kind == EP_SMUL && ep[2].kind == EP_SADD && ep[3].kind == EP_ACT &&
+               ep[3].act == ACT_HSWISH && ep[4].kind == EP_SMUL && ep[5].kind == EP_SADD;
+      };
+      if (!is_lab(d.ep)) continue;
       for (int oj = oi + 1; oj < nops; ++oj) {
         auto& c = plan_.ops[oj];
         if (c.in != d.out) continue;
         const bool one = c.kind == PlanOp::CONV && c.kh == 1 && c.kw == 1 && c.sh == 1 && c.sw == 1 && c.ph == 0 && c.pw == 0 && c.cin != 3;
-        int slots = 0;
-        for (auto& st : c.ep) slots += st.kind == EP_BIAS ? 1 : (st.kind == EP_BN ? 2 : 0);
-        if (one && gate_src[oj] < 0 && !T[c.out].plain && slots <= 2 && T[d.in].cs % 8 == 0 && !T[d.in].plain) {
+        if (one && gate_src[oj] < 0 && !T[c.out].plain && is_lab(c.ep) && T[d.in].cs % 8 == 0 && !T[d.in].plain && c.cout % 8 == 0) {
           // shape on the fused path?  (asks the launcher, which also raises the kernel's LDS limit on this device)
           DwPwArgs q{};
           q.K = d.kh; q.SH = d.sh; q.SW = d.sw;
           q.c.Cs_in = T[d.out].cs;
           const int tiles = (T[c.out].cs + 31) / 32, nt = conv_nt_for(tiles);
           q.c.NTtot = (tiles + nt - 1) / nt * nt;
-          Epilogue none{};
-          if (d.kh == d.kw && launch_dwpw(q, none, none, nullptr, true)) dwpw_of[oj] = oi;
+          q.dw_ep.act = q.pw_ep.act = 1;
+          if (d.kh == d.kw && launch_dwpw(q, nullptr, true)) dwpw_of[oj] = oi;
         }
         break;
       }
@@ -648,15 +645,14 @@ bool Net::bind(int N, int H, int W, std::string& err) {
             f.c = a;
             f.c.in = nullptr;
             f.dw_in = arena_ + din.offset; f.dw_w = dev_vec("dw:" + d.w);
-            for (int k = 0; k < epd.n; ++k)
-              if (epd.st[k].kind == EP_BIAS || epd.st[k].kind == EP_BN) { f.dw_v0 = epd.st[k].v0; f.dw_v1 = epd.st[k].kind == EP_BN ? epd.st[k].v1 : nullptr; }
+            if (!lab_from_epilogue(epd, f.dw_ep) || !lab_from_epilogue(ep, f.pw_ep)) { err = "dwpw: epilogue is not the LAB chain"; return false; }
             f.H = din.h; f.W = din.w; f.K = d.kh; f.SH = d.sh; f.SW = d.sw; f.PH = d.ph; f.PW = d.pw;
             snprintf(nm, sizeof nm, "%s.%02d.dwpw%dx%d_%d_%d_s%d%d", plan_.name.c_str(), dwpw_of[oi], d.kh, d.kw, op.cin, op.cout, d.sh, d.sw);
             L.name = nm;
             L.flops += 2.0 * a.M * d.kh * d.kw * d.c;
             L.bytes = 4.0 * ((double)din.n * din.h * din.w * d.c + (double)a.M * cols + (double)op.cin * cols + (double)d.kh * d.kw * d.c);
-            L.fn = [f, epd, ep](hipStream_t s) {
-              if (!launch_dwpw(f, epd, ep, s)) { fprintf(stderr, "launch_dwpw: shape accepted at bind time was refused at launch\n"); abort(); }
+            L.fn = [f](hipStream_t s) {
+              if (!launch_dwpw(f, s)) { fprintf(stderr, "launch_dwpw: shape accepted at bind time was refused at launch\n"); abort(); }
             };
           } else if (use_lds) L.fn = [a, ep, nt](hipStream_t s) { if (!launch_conv3x3_tile(a, ep, nt, s)) launch_conv_lds(a, ep, nt, s); };
           else L.fn = [a, ep, nt](hipStream_t s) { launch_conv_mfma(a, ep, nt, s); };

@@ -302,44 +302,40 @@ int ocr_pipe_det_shape(ocr_pipe* h, int rows, int cols, int* net_rows, int* net_
   return OCR_OK;
 }
 
+static std::vector<Net*> pipe_nets(ocr_pipe* h) {
+  std::vector<Net*> v{&h->det.net()};
+  for (int i = 0; i < h->rec.num_lanes(); ++i) v.push_back(&h->rec.lane_net(i));
+  return v;
+}
 int ocr_pipe_timing(ocr_pipe* h, int enable) {
   if (!h) return fail(OCR_ERR_ARG, "null handle");
-  h->det.net().enable_timing(enable != 0);
-  h->det.net().reset_timings();
-  h->rec.net().enable_timing(enable != 0);
-  h->rec.net().reset_timings();
-  h->rec.net2().enable_timing(enable != 0);
-  h->rec.net2().reset_timings();
-  h->rec.net3().enable_timing(enable != 0);
-  h->rec.net3().reset_timings();
+  for (Net* net : pipe_nets(h)) {
+    net->enable_timing(enable != 0);
+    net->reset_timings();
+  }
   return OCR_OK;
 }
 int ocr_pipe_timing_filter(ocr_pipe* h, const char* substr) {
   if (!h) return fail(OCR_ERR_ARG, "null handle");
   const std::string f = substr ? substr : "";
-  h->det.net().set_timing_filter(f);
-  h->rec.net().set_timing_filter(f);
-  h->rec.net2().set_timing_filter(f);
-  h->rec.net3().set_timing_filter(f);
+  for (Net* net : pipe_nets(h)) net->set_timing_filter(f);
   return OCR_OK;
 }
 int ocr_pipe_timing_report(ocr_pipe* h, char* buf, size_t cap) {
   if (!h || !buf) return fail(OCR_ERR_ARG, "null argument");
   size_t off = 0;
-  // the two halves of a split rec launch have the same instance names: one row per name
+  // the halves of a split rec launch (and equal shapes on different lanes) have the same instance names: one row per name
   std::map<std::string, KernelTiming> all;
-  for (Net* net : {&h->det.net(), &h->rec.net(), &h->rec.net2(), &h->rec.net3()})
+  for (Net* net : pipe_nets(h))
     for (auto& kv : net->timings()) {
       KernelTiming& t = all[kv.first];
       t.ms += kv.second.ms; t.count += kv.second.count; t.flops += kv.second.flops; t.bytes += kv.second.bytes;
     }
-  {
-    for (auto& kv : all) {
-      int n = snprintf(buf + off, cap > off ? cap - off : 0, "%s %.6f %ld %.0f %.0f\n", kv.first.c_str(), kv.second.ms,
-                       kv.second.count, kv.second.flops, kv.second.bytes);
-      if (n < 0 || off + n >= cap) return fail(OCR_ERR_CAPACITY, "report buffer too small");
-      off += n;
-    }
+  for (auto& kv : all) {
+    int n = snprintf(buf + off, cap > off ? cap - off : 0, "%s %.6f %ld %.0f %.0f\n", kv.first.c_str(), kv.second.ms,
+                     kv.second.count, kv.second.flops, kv.second.bytes);
+    if (n < 0 || off + n >= cap) return fail(OCR_ERR_CAPACITY, "report buffer too small");
+    off += n;
   }
   if (off < cap) buf[off] = 0;
   return OCR_OK;

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -120,10 +121,9 @@ class RecStage {
   bool want_taps = true;
   int max_lines_per_launch = 4096;  // rows of one launch (bounds the activation arena: ~1.2 MB per 48x320 line)
   const std::vector<std::string>& labels() const { return labels_; }
-  hipStream_t stream() const { return stream_; }
-  Net& net() { return net_; }
-  Net& net2() { return net2_; }
-  Net& net3() { return net3_; }
+  hipStream_t stream() const { return lanes_[0]->stream; }
+  int num_lanes() const { return (int)lanes_.size(); }
+  Net& lane_net(int i) { return lanes_[i]->net; }
   // per-step taps of the last run, in input order: T per line, amax/pmax concatenated
   std::vector<int> tap_T, tap_off;
   std::vector<int> tap_amax;
@@ -131,14 +131,24 @@ class RecStage {
 
  private:
   RecConfig cfg_;
-  Net net_, net2_, net3_;   // execution lanes (see run_lines): 0 and 2 share the big launch, 1 takes the small ones
-  hipStream_t stream_ = nullptr, stream2_ = nullptr, stream3_ = nullptr;
+  // Execution lanes (network instance + stream + input buffer each, see run_lines): 0 takes the largest launch, 1 the
+  // second half when that launch is split (OCR_REC_SPLIT=2), 2.. the small odd-width launches round-robin
+  // (OCR_REC_SMALL_LANES of them, high-priority streams): independent dependent-kernel chains side by side.
+  struct Lane {
+    Net net;
+    hipStream_t stream = nullptr;
+    DevBuf<float> x;
+    ~Lane() { if (stream) (void)hipStreamDestroy(stream); }
+  };
+  std::vector<std::unique_ptr<Lane>> lanes_;
+  int small_lanes_ = 4;
   int split_tail_ = -1;     // index of the second half in the current launch list
   int split_ = 1;           // parts the largest launch is cut into (OCR_REC_SPLIT, 1 or 2)
+  bool serial_ = false;     // OCR_REC_LANES=1: every launch on lane 0, one after the other
   hipEvent_t ev_descs_ = nullptr;
   StageTimer timer_;
   std::vector<std::string> labels_;
-  DevBuf<float> lut_, x_, x2_, x3_, pmax_, scores_;
+  DevBuf<float> lut_, pmax_, scores_;
   DevBuf<int> amax_, ids_, lens_;
   DevBuf<uint8_t> staging_;
   DevBuf<LineDesc> descs_;

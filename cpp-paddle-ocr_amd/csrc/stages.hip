@@ -254,9 +254,7 @@ int DetStage::post_only(const float* prob, int rows, int cols, int src_rows, int
 
 // ================================================================= recognizer
 RecStage::~RecStage() {
-  if (stream_) (void)hipStreamDestroy(stream_);
-  if (stream2_) (void)hipStreamDestroy(stream2_);
-  if (stream3_) (void)hipStreamDestroy(stream3_);
+  lanes_.clear();
   if (ev_descs_) (void)hipEventDestroy(ev_descs_);
 }
 
@@ -277,16 +275,25 @@ bool RecStage::create(const RecConfig& cfg, std::string& err, int& code) {
   labels_.push_back(" ");
   WeightMap w;
   if (!load_model_dir(cfg.model_dir, nullptr, w, err)) return false;
-  if (!net_.load(embedded_plan("rec"), w, err) || !net2_.load(embedded_plan("rec"), w, err) || !net3_.load(embedded_plan("rec"), w, err)) return false;
   if (const char* e = getenv("OCR_REC_SPLIT")) split_ = atoi(e) >= 2 ? 2 : 1;
-  code = OCR_ERR_DEVICE;
-  // lane 1 carries the small odd-width launches: a high-priority queue, so their workgroups are placed
-  // as soon as slots free up instead of waiting behind the thousands queued by lane 0's big kernels
+  if (const char* e = getenv("OCR_REC_LANES")) serial_ = atoi(e) == 1;
+  if (const char* e = getenv("OCR_REC_SMALL_LANES")) small_lanes_ = std::min(16, std::max(1, atoi(e)));
+  // the small lanes carry the odd-width launches: high-priority queues, so their workgroups are placed as soon as
+  // slots free up instead of waiting behind the thousands queued by lane 0's big kernels
   int prio_lo = 0, prio_hi = 0;
   (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-  if (hipStreamCreate(&stream_) != hipSuccess || hipStreamCreateWithPriority(&stream2_, hipStreamDefault, prio_hi) != hipSuccess ||
-      hipStreamCreate(&stream3_) != hipSuccess ||
-      hipEventCreateWithFlags(&ev_descs_, hipEventDisableTiming) != hipSuccess) { err = "hipStreamCreate failed"; return false; }
+  const int nlanes = serial_ ? 1 : 2 + small_lanes_;
+  for (int i = 0; i < nlanes; ++i) {
+    std::unique_ptr<Lane> L(new Lane());
+    code = OCR_ERR_MODEL;
+    if (!L->net.load(embedded_plan("rec"), w, err)) return false;
+    code = OCR_ERR_DEVICE;
+    const hipError_t e = i >= 2 ? hipStreamCreateWithPriority(&L->stream, hipStreamDefault, prio_hi) : hipStreamCreate(&L->stream);
+    if (e != hipSuccess) { err = "hipStreamCreate failed"; return false; }
+    lanes_.push_back(std::move(L));
+  }
+  code = OCR_ERR_DEVICE;
+  if (hipEventCreateWithFlags(&ev_descs_, hipEventDisableTiming) != hipSuccess) { err = "hipEventCreate failed"; return false; }
   if (!timer_.init(err)) return false;
   const float mean[3] = {0.5f, 0.5f, 0.5f}, scale[3] = {1 / 0.5f, 1 / 0.5f, 1 / 0.5f};  // ocr_rec.h:108-109
   const auto lut = make_norm_lut(mean, scale);
@@ -302,15 +309,16 @@ int RecStage::run(const ocr_img* imgs, int n, int32_t* ids, int max_len, int* le
   if (times) times[0] = times[1] = times[2] = 0;
   if (n == 0) return OCR_OK;
   ST_HIP(hipSetDevice(cfg_.device));
-  timer_.mark(0, stream_);
+  const hipStream_t stream0 = lanes_[0]->stream;
+  timer_.mark(0, stream0);
   std::vector<LineSrc> lines;
-  if (!upload_lines(imgs, n, staging_, lines, stream_, err)) return OCR_ERR_DEVICE;
-  timer_.mark(1, stream_);
+  if (!upload_lines(imgs, n, staging_, lines, stream0, err)) return OCR_ERR_DEVICE;
+  timer_.mark(1, stream0);
   const std::vector<int> seg = {0, n};
   const int rc = run_lines(lines, seg, ids, max_len, lens, scores, err);
-  timer_.mark(2, stream_);
-  timer_.mark(3, stream_);
-  (void)hipStreamSynchronize(stream_);
+  timer_.mark(2, stream0);
+  timer_.mark(3, stream0);
+  (void)hipStreamSynchronize(stream0);
   timer_.read(times);
   return rc;
 }
@@ -319,6 +327,7 @@ int RecStage::run_lines(const std::vector<LineSrc>& lines, const std::vector<int
                         int* lens, float* scores, std::string& err) {
   const int n = (int)lines.size();
   const int imgH = cfg_.img_h, imgW = cfg_.img_w;
+  const hipStream_t stream0 = lanes_[0]->stream;
   struct Item { int line; int resize_w; };
   std::map<int, std::vector<Item>> groups;  // tensor width -> lines (samples of one launch are independent)
   for (size_t sg = 0; sg + 1 < seg.size(); ++sg) {
@@ -386,34 +395,37 @@ int RecStage::run_lines(const std::vector<LineSrc>& lines, const std::vector<int
   struct Slot { int lane, ng, Wt, T; size_t step_off, line_off; };
   std::vector<Slot> slots(nl);
   size_t step_total = 0, line_total = 0;
+  int small_rr = 0;
   for (int i = 0; i < nl; ++i) {
-    slots[i] = Slot{(i == big || nl == 1) ? 0 : (i == split_tail_ ? 2 : 1), (int)launches[i].second.size(), launches[i].first, 0, step_total, line_total};
+    int lane = 0;
+    if (!(i == big || nl == 1 || serial_)) lane = i == split_tail_ ? 1 : 2 + (small_rr++ % small_lanes_);
+    slots[i] = Slot{lane, (int)launches[i].second.size(), launches[i].first, 0, step_total, line_total};
     step_total += (size_t)slots[i].ng * (launches[i].first / 4 + 8);  // >= ng * T
     line_total += slots[i].ng;
   }
   if (!amax_.ensure(step_total, err) || !pmax_.ensure(step_total, err) || !ids_.ensure(line_total * max_len, err) ||
       !lens_.ensure(line_total, err) || !scores_.ensure(line_total, err) || !descs_.ensure(line_total, err))
     return OCR_ERR_DEVICE;
-  size_t xneed[3] = {0, 0, 0};
+  std::vector<size_t> xneed(lanes_.size(), 0);
   for (int i = 0; i < nl; ++i) xneed[slots[i].lane] = std::max(xneed[slots[i].lane], (size_t)slots[i].ng * imgH * slots[i].Wt * 3);
-  if (!x_.ensure(xneed[0], err) || !x2_.ensure(xneed[1], err) || !x3_.ensure(xneed[2], err)) return OCR_ERR_DEVICE;
+  for (size_t l = 0; l < lanes_.size(); ++l)
+    if (xneed[l] && !lanes_[l]->x.ensure(xneed[l], err)) return OCR_ERR_DEVICE;
   std::vector<LineDesc> d(line_total);
   for (int i = 0; i < nl; ++i)
     for (int j = 0; j < slots[i].ng; ++j) {
       const LineSrc& L = lines[launches[i].second[j].line];
       d[slots[i].line_off + j] = LineDesc{L.img, L.stride, L.x, L.y, L.w, L.h, launches[i].second[j].resize_w, j};
     }
-  ST_HIP(hipMemcpyAsync(descs_.p, d.data(), line_total * sizeof(LineDesc), hipMemcpyHostToDevice, stream_));
-  ST_HIP(hipEventRecord(ev_descs_, stream_));
-  ST_HIP(hipStreamWaitEvent(stream2_, ev_descs_, 0));
-  ST_HIP(hipStreamWaitEvent(stream3_, ev_descs_, 0));
-  for (int pass : {0, 2, 1}) {      // the big launches first so their kernels are queued early
+  ST_HIP(hipMemcpyAsync(descs_.p, d.data(), line_total * sizeof(LineDesc), hipMemcpyHostToDevice, stream0));
+  ST_HIP(hipEventRecord(ev_descs_, stream0));
+  for (size_t l = 1; l < lanes_.size(); ++l) ST_HIP(hipStreamWaitEvent(lanes_[l]->stream, ev_descs_, 0));
+  for (int pass = 0; pass < (int)lanes_.size(); ++pass) {      // the big launches first so their kernels are queued early
     for (int i = 0; i < nl; ++i) {
       Slot& sl = slots[i];
       if (sl.lane != pass) continue;
-      Net& net = sl.lane == 0 ? net_ : (sl.lane == 1 ? net2_ : net3_);
-      hipStream_t st = sl.lane == 0 ? stream_ : (sl.lane == 1 ? stream2_ : stream3_);
-      float* x = sl.lane == 0 ? x_.p : (sl.lane == 1 ? x2_.p : x3_.p);
+      Net& net = lanes_[sl.lane]->net;
+      hipStream_t st = lanes_[sl.lane]->stream;
+      float* x = lanes_[sl.lane]->x.p;
       launch_line_pre(descs_.p + sl.line_off, sl.ng, imgH, sl.Wt, lut_.p, false, x, st);
       net.set_head_outputs(nullptr, amax_.p + sl.step_off, pmax_.p + sl.step_off);
       if (!net.run(x, sl.ng, imgH, sl.Wt, st, err)) return OCR_ERR_DEVICE;
@@ -426,23 +438,20 @@ int RecStage::run_lines(const std::vector<LineSrc>& lines, const std::vector<int
                  lens_.p + sl.line_off, scores_.p + sl.line_off, st);
     }
   }
-  ST_HIP(hipStreamSynchronize(stream2_));
-  ST_HIP(hipStreamSynchronize(stream3_));
+  for (size_t l = 1; l < lanes_.size(); ++l) ST_HIP(hipStreamSynchronize(lanes_[l]->stream));
   std::vector<int> h_ids(line_total * max_len), h_lens(line_total), h_amax;
   std::vector<float> h_scores(line_total), h_pmax;
-  ST_HIP(hipMemcpyAsync(h_ids.data(), ids_.p, h_ids.size() * sizeof(int), hipMemcpyDeviceToHost, stream_));
-  ST_HIP(hipMemcpyAsync(h_lens.data(), lens_.p, line_total * sizeof(int), hipMemcpyDeviceToHost, stream_));
-  ST_HIP(hipMemcpyAsync(h_scores.data(), scores_.p, line_total * sizeof(float), hipMemcpyDeviceToHost, stream_));
+  ST_HIP(hipMemcpyAsync(h_ids.data(), ids_.p, h_ids.size() * sizeof(int), hipMemcpyDeviceToHost, stream0));
+  ST_HIP(hipMemcpyAsync(h_lens.data(), lens_.p, line_total * sizeof(int), hipMemcpyDeviceToHost, stream0));
+  ST_HIP(hipMemcpyAsync(h_scores.data(), scores_.p, line_total * sizeof(float), hipMemcpyDeviceToHost, stream0));
   if (want_taps) {
     h_amax.resize(step_total);
     h_pmax.resize(step_total);
-    ST_HIP(hipMemcpyAsync(h_amax.data(), amax_.p, step_total * sizeof(int), hipMemcpyDeviceToHost, stream_));
-    ST_HIP(hipMemcpyAsync(h_pmax.data(), pmax_.p, step_total * sizeof(float), hipMemcpyDeviceToHost, stream_));
+    ST_HIP(hipMemcpyAsync(h_amax.data(), amax_.p, step_total * sizeof(int), hipMemcpyDeviceToHost, stream0));
+    ST_HIP(hipMemcpyAsync(h_pmax.data(), pmax_.p, step_total * sizeof(float), hipMemcpyDeviceToHost, stream0));
   }
-  ST_HIP(hipStreamSynchronize(stream_));
-  net_.collect_timings();
-  net2_.collect_timings();
-  net3_.collect_timings();
+  ST_HIP(hipStreamSynchronize(stream0));
+  for (auto& L : lanes_) L->net.collect_timings();
   for (int i = 0; i < nl; ++i) {
     const Slot& sl = slots[i];
     for (int j = 0; j < sl.ng; ++j) {

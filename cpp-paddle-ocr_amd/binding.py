@@ -39,7 +39,7 @@ class ocr_cls_cfg(C.Structure):
 class ocr_rec_cfg(C.Structure):
     _fields_ = [("model_dir", C.c_char_p), ("device_id", C.c_int), ("label_path", C.c_char_p),
                 ("rec_batch_num", C.c_int), ("rec_img_h", C.c_int), ("rec_img_w", C.c_int),
-                ("precision", C.c_char_p)]
+                ("precision", C.c_char_p), ("sort_mode", C.c_int)]
 
 
 # every symbol include/ocr_hip.h declares (tests check the .so exports all of them)
@@ -299,7 +299,7 @@ class Cls:
 
 class Rec:
     def __init__(self, model_dir=None, device=0, label_path=None, rec_batch_num=16, rec_img_h=28, rec_img_w=192,
-                 precision="fp32"):
+                 precision="fp32", sort_mode=0):
         L = lib()
         _stage_protos(L)
         cfg = ocr_rec_cfg()
@@ -308,6 +308,7 @@ class Rec:
         self._keep = [md.encode(), (label_path or os.path.join(md, "ppocr_keys_v1.txt")).encode(), precision.encode()]
         cfg.model_dir, cfg.label_path, cfg.precision = self._keep
         cfg.device_id, cfg.rec_batch_num, cfg.rec_img_h, cfg.rec_img_w = device, rec_batch_num, rec_img_h, rec_img_w
+        cfg.sort_mode = int(sort_mode)
         self.h = C.c_void_p()
         check(L.ocr_rec_create(C.byref(cfg), C.byref(self.h)))
         self.times = (C.c_double * 3)()
@@ -448,7 +449,7 @@ class Pipe:
 
     def __init__(self, model_root=None, device=0, enable_cls=False, limit_type="max", limit_side_len=512, thresh=0.2,
                  box_thresh=0.4, unclip_ratio=1.8, use_dilation=False, rec_batch_num=16, rec_img_h=28, rec_img_w=192,
-                 cls_batch_num=8, crop_mode=CROP_BOUNDING_RECT, score_mode="fast"):
+                 cls_batch_num=8, crop_mode=CROP_BOUNDING_RECT, score_mode="fast", rec_sort_mode=0):
         L = lib()
         _pipe_protos(L)
         root = model_root or MODELS
@@ -464,6 +465,7 @@ class Pipe:
         cfg.det.det_db_thresh, cfg.det.det_db_box_thresh, cfg.det.det_db_unclip_ratio = thresh, box_thresh, unclip_ratio
         cfg.det.use_dilation = int(use_dilation)
         cfg.rec.rec_batch_num, cfg.rec.rec_img_h, cfg.rec.rec_img_w = rec_batch_num, rec_img_h, rec_img_w
+        cfg.rec.sort_mode = int(rec_sort_mode)
         cfg.cls.cls_batch_num = cls_batch_num
         cfg.enable_cls = int(enable_cls)
         cfg.crop_mode = int(crop_mode)

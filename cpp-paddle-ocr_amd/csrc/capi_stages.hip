@@ -145,6 +145,7 @@ int ocr_rec_create(const ocr_rec_cfg* c, ocr_rec** out) {
   cfg.label_path = c->label_path;
   cfg.device = c->device_id;
   cfg.batch_num = c->rec_batch_num;
+  cfg.sort_mode = c->sort_mode;
   cfg.img_h = c->rec_img_h;
   cfg.img_w = c->rec_img_w;
   if (c->precision) cfg.precision = c->precision;

@@ -275,7 +275,11 @@ __global__ void __launch_bounds__(256, 2) dwpw_kernel(const DwPwArgs a) {
 #pragma unroll
     for (int j = 0; j < C8S; ++j) {
 #pragma unroll
+#ifdef OCR_DWPW_NO_B  // development probe: no fragment traffic
+      for (int t = 0; t < NT; ++t) bq[j][t] = make_float4((float)(size_t)p_w, (float)j, (float)t, 1.f);
+#else
       for (int t = 0; t < NT; ++t) bq[j][t] = p_w[j * wstride + t * 64];
+#endif
     }
     b_step += C8S;
     if (b_step == KK) {  // next unit: back to the first step of ITS column block (past the end: the last one again)

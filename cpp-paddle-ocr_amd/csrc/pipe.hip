@@ -218,7 +218,7 @@ int ocr_pipe_create(const ocr_pipe_cfg* c, ocr_pipe** out) {
   if (!h->det.create(d, err, code)) return fail(code, err);
   RecConfig r;
   r.model_dir = c->rec.model_dir; r.label_path = c->rec.label_path; r.device = c->det.device_id;
-  r.batch_num = c->rec.rec_batch_num; r.img_h = c->rec.rec_img_h; r.img_w = c->rec.rec_img_w;
+  r.batch_num = c->rec.rec_batch_num; r.img_h = c->rec.rec_img_h; r.img_w = c->rec.rec_img_w; r.sort_mode = c->rec.sort_mode;
   if (c->rec.precision) r.precision = c->rec.precision;
   if (!h->rec.create(r, err, code)) return fail(code, err);
   h->rec.want_taps = false;

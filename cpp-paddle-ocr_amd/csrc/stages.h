@@ -105,6 +105,7 @@ struct LineSrc {  // a text-line image living in device memory
 struct RecConfig {
   std::string model_dir, label_path, precision = "fp32";
   int device = 0, batch_num = 16, img_h = 28, img_w = 192;
+  int sort_mode = 0;  // OCR_SORT_STD | OCR_SORT_STABLE
 };
 
 class RecStage {

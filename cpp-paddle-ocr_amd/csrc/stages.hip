@@ -263,6 +263,7 @@ bool RecStage::create(const RecConfig& cfg, std::string& err, int& code) {
   code = OCR_ERR_ARG;
   if (cfg.precision != "fp32") { err = "precision '" + cfg.precision + "' is not implemented (fp32 only)"; return false; }
   if (cfg.batch_num < 1 || cfg.img_h < 1 || cfg.img_w < 1) { err = "bad rec shape"; return false; }
+  if (cfg.sort_mode != OCR_SORT_STD && cfg.sort_mode != OCR_SORT_STABLE) { err = "unknown sort_mode"; return false; }
   code = ocr_rt_init(cfg.device);
   if (code) { err = ocr_last_error(); return false; }
   code = OCR_ERR_MODEL;
@@ -337,7 +338,9 @@ int RecStage::run_lines(const std::vector<LineSrc>& lines, const std::vector<int
     for (int i = 0; i < sn; ++i) width_list[i] = float(lines[s0 + i].w) / lines[s0 + i].h;
     std::vector<size_t> indices(sn);
     for (int i = 0; i < sn; ++i) indices[i] = i;
-    std::sort(indices.begin(), indices.end(), [&](size_t a, size_t b) { return width_list[a] < width_list[b]; });
+    // Utility::argsort is std::sort: the order of equal ratios is the host library's
+    if (cfg_.sort_mode == OCR_SORT_STABLE) std::stable_sort(indices.begin(), indices.end(), [&](size_t a, size_t b) { return width_list[a] < width_list[b]; });
+    else std::sort(indices.begin(), indices.end(), [&](size_t a, size_t b) { return width_list[a] < width_list[b]; });
     for (int beg = 0; beg < sn; beg += cfg_.batch_num) {
       const int end = std::min(sn, beg + cfg_.batch_num);
       float max_wh_ratio = imgW * 1.0 / imgH;

@@ -105,7 +105,13 @@ typedef struct ocr_rec_cfg {
   int rec_batch_num;
   int rec_img_h, rec_img_w;
   const char* precision;
+  /* how lines with EQUAL w/h ratio are ordered before the batches of rec_batch_num are cut (Utility::argsort is
+   * std::sort, utility.cpp:192-203, whose order of ties is the host library's): OCR_SORT_STD = this build's
+   * std::sort (libstdc++ introsort, what the oracle runs); OCR_SORT_STABLE = ties keep their input order, which is
+   * what MSVC's std::sort (the reference's toolchain) does for up to 32 crops (insertion sort below _ISORT_MAX). */
+  int sort_mode;
 } ocr_rec_cfg;
+enum { OCR_SORT_STD = 0, OCR_SORT_STABLE = 1 };
 void ocr_rec_cfg_default(ocr_rec_cfg* cfg);
 typedef struct ocr_rec ocr_rec;
 int ocr_rec_create(const ocr_rec_cfg* cfg, ocr_rec** out);

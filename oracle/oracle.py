@@ -206,10 +206,10 @@ def rotate180_inplace(view):
                                    C.c_size_t(view.strides[0]))
 
 
-def argsort(v):
+def argsort(v, stable=False):
     v = np.ascontiguousarray(v, dtype=np.float32)
     idx = np.empty(v.size, np.int32)
-    lib().oracle_argsort(C.c_void_p(_p(v)), v.size, C.c_void_p(_p(idx)))
+    (lib().oracle_argsort_stable if stable else lib().oracle_argsort)(C.c_void_p(_p(v)), v.size, C.c_void_p(_p(idx)))
     return idx
 
 

@@ -930,5 +930,14 @@ void oracle_argsort(const float* v, int n, int* idx) {
   std::sort(a.begin(), a.end(), [v](size_t p1, size_t p2) { return v[p1] < v[p2]; });
   for (int i = 0; i < n; ++i) idx[i] = (int)a[i];
 }
+// The same with ties kept in input order: what std::sort does in the reference's own toolchain (MSVC STL: insertion
+// sort for ranges of at most _ISORT_MAX = 32 elements) for up to 32 crops.  PARITY UNPINNED beyond 32 elements:
+// MSVC's median-guess quicksort is not restated.
+void oracle_argsort_stable(const float* v, int n, int* idx) {
+  std::vector<size_t> a(n);
+  for (int i = 0; i < n; ++i) a[i] = i;
+  std::stable_sort(a.begin(), a.end(), [v](size_t p1, size_t p2) { return v[p1] < v[p2]; });
+  for (int i = 0; i < n; ++i) idx[i] = (int)a[i];
+}
 
 }  // extern "C"

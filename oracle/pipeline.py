@@ -25,7 +25,8 @@ class DetCfg:
 
 class Pipeline:
     def __init__(self, det_cfg=None, rec_batch_num=16, rec_img_h=28, rec_img_w=192, cls_batch_num=8, enable_cls=False,
-                 crop_mode="rect"):
+                 crop_mode="rect", rec_sort="std"):
+        self.rec_sort = rec_sort    # "std": this host's std::sort; "stable": ties in input order (MSVC's std::sort up to 32 crops)
         self.crop_mode = crop_mode  # "rect": worker's ROI views; "rotate": Utility::GetRotateCropImage per box
         self.det_cfg = det_cfg or DetCfg()
         self.det = O.OracleNet("det")
@@ -78,7 +79,7 @@ class Pipeline:
         if n == 0:
             return texts, scores, steps
         width_list = np.array([np.float32(c.shape[1]) / np.float32(c.shape[0]) for c in crops], np.float32)
-        indices = O.argsort(width_list)
+        indices = O.argsort(width_list, stable=self.rec_sort == "stable")
         imgH, imgW = self.rec_img_h, self.rec_img_w
         for beg in range(0, n, self.rec_batch_num):
             end = min(n, beg + self.rec_batch_num)

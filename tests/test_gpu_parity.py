@@ -467,3 +467,26 @@ def test_pipeline_cfg3_mixed_sizes(pkg, built):
     assert sum(len(g) for g in got) > 0
     assert all(np.array_equal(a["box"], b["box"]) and np.array_equal(a["ids"], b["ids"]) for a, b in zip(got[0], got[3]))
     pg.close()
+
+
+@pytest.mark.parametrize("mode", ["std", "stable"])
+def test_rec_batches_with_tied_ratios_follow_the_sort_mode(pkg, built, mode):
+    """More than rec_batch_num crops with EQUAL w/h ratios: which of them share a batch (and so its tensor width)
+    depends on how std::sort orders ties (Utility::argsort, utility.cpp:192-203).  Both orders are available
+    (ocr_rec_cfg.sort_mode); each must equal the oracle run in the same mode, ids, scores and per-step taps."""
+    from pipeline import Pipeline
+    rs = np.random.RandomState(31)
+    crops = []
+    for i in range(40):   # three ratio classes, 40 crops: ties straddle the batch boundaries at 16 and 32
+        h, w = [(24, 96), (12, 48), (30, 200)][i % 3] if i % 5 else (20, 300 + i)
+        crops.append(rs.randint(0, 255, (h, w, 3)).astype(np.uint8))
+    pipe = Pipeline(rec_batch_num=16, rec_img_h=48, rec_img_w=320, rec_sort=mode)
+    rec = pkg.Rec(rec_batch_num=16, rec_img_h=48, rec_img_w=320, sort_mode=1 if mode == "stable" else 0)
+    to, so, steps = pipe.rec_run(crops)
+    tg, sg = rec.run(crops)
+    for i in range(len(crops)):
+        assert np.array_equal(to[i], tg[i]), i
+        assert so[i] == sg[i], i
+        am, pm = rec.steps(i)
+        assert np.array_equal(am, steps[i][0]) and np.array_equal(pm, steps[i][1]), i
+    rec.close()

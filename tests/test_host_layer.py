@@ -41,3 +41,22 @@ def test_worker_and_pool_binary(built, card, tmp_path):
         assert g["box"] == np.asarray(w["box"]).tolist()
         assert g["text"] == "".join(labels[i] for i in w["ids"])
         assert np.float32(g["confidence"]) == np.float32(w["confidence"])
+
+
+def test_argsort_tie_order_modes(built):
+    """Utility::argsort is std::sort (utility.cpp:192-203): the order of EQUAL ratios is the host library's.  "std" is
+    this toolchain's std::sort; "stable" keeps ties in input order, which is what MSVC's std::sort (the reference's
+    toolchain) does for up to 32 elements (insertion sort).  Both sort correctly; they may differ only on ties."""
+    import numpy as np
+    import oracle as O
+    rs = np.random.RandomState(4)
+    for n in (1, 5, 16, 17, 33, 40, 200):
+        v = rs.randint(0, 6, n).astype(np.float32) * 0.5       # many ties
+        a, b = O.argsort(v), O.argsort(v, stable=True)
+        assert sorted(a.tolist()) == sorted(b.tolist()) == list(range(n))
+        assert (np.diff(v[a]) >= 0).all() and (np.diff(v[b]) >= 0).all()
+        for x in np.unique(v):                                  # stable: ties in input order
+            idx = b[v[b] == x]
+            assert (np.diff(idx) > 0).all()
+    v = rs.rand(64).astype(np.float32)                          # no ties: one answer
+    assert np.array_equal(O.argsort(v), O.argsort(v, stable=True))

@@ -359,6 +359,7 @@ class ocr_word(C.Structure):
 
 
 EXPORTS += ["ocr_pipe_cfg_default", "ocr_pipe_create", "ocr_pipe_destroy", "ocr_pipe_run", "ocr_pipe_run_device",
+            "ocr_pipe_stage", "ocr_pipe_slot_probs", "ocr_pipe_run_staged",
             "ocr_pipe_label", "ocr_pipe_det_shape", "ocr_pipe_timing", "ocr_pipe_timing_filter", "ocr_pipe_timing_report", "ocr_dev_alloc",
             "ocr_dev_free", "ocr_dev_upload", "ocr_dev_download", "ocr_dev_sync", "ocr_rotate_crop", "ocr_rotate_crop_shape"]
 
@@ -374,6 +375,9 @@ def _pipe_protos(L):
     L.ocr_pipe_run.argtypes = [vp, C.POINTER(ocr_img), C.c_int, vp, C.c_int, vp, vp, vp, C.c_int, C.POINTER(C.c_double)]
     L.ocr_pipe_run_device.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, vp, vp, vp, C.c_int,
                                       C.POINTER(C.c_double)]
+    L.ocr_pipe_stage.argtypes = [vp, C.c_int, C.POINTER(ocr_img), C.c_int]
+    L.ocr_pipe_slot_probs.argtypes = [vp, C.c_int, vp, C.c_int]
+    L.ocr_pipe_run_staged.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp, vp, C.c_int, C.POINTER(C.c_double)]
     L.ocr_pipe_label.argtypes = [vp, C.c_int]
     L.ocr_pipe_label.restype = C.c_char_p
     L.ocr_pipe_det_shape.argtypes = [vp, C.c_int, C.c_int, ip, ip]
@@ -502,6 +506,30 @@ class Pipe:
                                  ids.ctypes.data, self._cap_ids, self.times))
         return self._collect(n, words, ids, off, nw)
 
+    def stage(self, slot, imgs, probs=None):
+        """ocr_pipe_stage: host images (any sizes) -> pinned memory -> device, asynchronously.  probs: per image a
+        float32 map of the detector's input resolution (det_shape), attached with ocr_pipe_slot_probs; None keeps
+        whatever maps the slot has (they survive re-staging the same sizes in the same order)."""
+        n = len(imgs)
+        self._staged_n = getattr(self, "_staged_n", {})
+        check(lib().ocr_pipe_stage(self.h, slot, _imgs(imgs), n))
+        self._staged_n[slot] = n
+        if probs is not None:
+            arr = (C.c_void_p * n)()
+            maps = [np.ascontiguousarray(p, dtype=np.float32) for p in probs]
+            for i, m in enumerate(maps):
+                arr[i] = m.ctypes.data
+            check(lib().ocr_pipe_slot_probs(self.h, slot, arr, n))
+
+    def run_staged(self, slot, collect=True):
+        count = self._staged_n[slot]
+        words, ids = self._bufs(count)
+        off = np.zeros(count, np.int32)
+        nw = np.zeros(count, np.int32)
+        check(lib().ocr_pipe_run_staged(self.h, slot, words, self._cap_words, off.ctypes.data, nw.ctypes.data, ids.ctypes.data,
+                                        self._cap_ids, self.times))
+        return self._collect(count, words, ids, off, nw) if collect else int(nw.sum())
+
     def run_device(self, dev_imgs, rows, cols, count, dev_prob=None, collect=True):
         words, ids = self._bufs(count)
         off = np.zeros(count, np.int32)
@@ -526,7 +554,7 @@ class Pipe:
         check(lib().ocr_pipe_timing(self.h, int(on)))
 
     def timing_report(self):
-        buf = C.create_string_buffer(1 << 18)
+        buf = C.create_string_buffer(1 << 24)   # one row per (launch, bound shape): a mixed-size batch has tens of thousands
         check(lib().ocr_pipe_timing_report(self.h, buf, len(buf)))
         out = {}
         for line in buf.value.decode().splitlines():

@@ -127,7 +127,7 @@ class Net {
     unsigned long stamp = 0;         // LRU
     ~Binding() { if (graph_exec) (void)hipGraphExecDestroy(graph_exec); }
   };
-  static constexpr size_t kMaxBindings = 48;
+  static constexpr size_t kMaxBindings = 512;  // a mixed-size stream revisits sizes: BASELINE configs[2] has ~400 distinct det shapes
   void invalidate() { cache_.clear(); cur_ = nullptr; }
   bool bind(int N, int H, int W, std::string& err);
   bool build_epilogue(const PlanOp& op, Epilogue& ep, bool conv_path, std::string& err);

@@ -217,6 +217,8 @@ bool Net::load(const char* plan_text, const WeightMap& W, std::string& err) {
       } else if (st.kind == EP_BN) {
         auto g = need(st.n0), b = need(st.n1), m = need(st.n2), v = need(st.n3);
         if (!g || !b || !m || !v) return false;
+        for (const HostTensor* t : {g, b, m, v})
+          if ((int)t->numel() != oc) { err = "batch-norm vector size mismatch near " + st.n0 + " (different architecture?)"; return false; }
         std::vector<float> sc(oc), sh(oc);
         for (int c = 0; c < oc; ++c) {
           const float inv = 1.0f / sqrtf(v->data[c] + st.p0);
@@ -298,6 +300,12 @@ bool Net::load(const char* plan_text, const WeightMap& W, std::string& err) {
         if (!upload("dw:" + op.w, img)) { err = "hipMalloc failed"; return false; }
       } break;
       case PlanOp::SEFC: {
+        {
+          auto w1 = need(op.w1), b1 = need(op.b1), w2 = need(op.w2), b2 = need(op.b2);
+          if (!w1 || !b1 || !w2 || !b2) return false;
+          if ((long)w1->numel() != (long)op.cr * op.c || (int)b1->numel() != op.cr || (long)w2->numel() != (long)op.c * op.cr ||
+              (int)b2->numel() != op.c) { err = "squeeze-excite weight size mismatch " + op.w1; return false; }
+        }
         for (const std::string* n : {&op.w1, &op.b1, &op.w2, &op.b2}) {
           auto p = need(*n); if (!p) return false;
           if (!upload("raw:" + *n, p->data)) { err = "hipMalloc failed"; return false; }
@@ -306,6 +314,7 @@ bool Net::load(const char* plan_text, const WeightMap& W, std::string& err) {
       case PlanOp::LN: {
         for (const std::string* n : {&op.g, &op.b}) {
           auto p = need(*n); if (!p) return false;
+          if ((int)p->numel() != op.c) { err = "layer-norm vector size mismatch " + *n; return false; }
           if (!upload("raw:" + *n, p->data)) { err = "hipMalloc failed"; return false; }
         }
       } break;

@@ -5,6 +5,7 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <thread>
 
 #include "capi_common.h"
 #include "crop.h"
@@ -18,30 +19,184 @@ double now_ms() {
 }
 }  // namespace
 
+static int emit(const std::vector<std::vector<ocr_word>>& W, const std::vector<std::vector<int32_t>>& I, const std::vector<int>& order,
+                ocr_word* words, int cap_words, int* word_off, int* nwords, int32_t* ids, int cap_ids);
+
+// One staged batch: host images copied into pinned memory and sent to the device on the copy stream, laid out size
+// group by size group (images of one size are contiguous: one det pass each).  Two slots = double buffering: batch
+// k+1 is staged (by another host thread) while batch k runs - SURVEY.md section 8e's "double-buffered pinned staging".
+struct StageSlot {
+  struct Img { int rows, cols, orig; size_t off, prob_off; };
+  struct Group { int rows, cols, first, count; size_t off, prob_off; };
+  uint8_t* pinned = nullptr;
+  size_t pinned_cap = 0;
+  DevBuf<uint8_t> dev;
+  DevBuf<float> probs;
+  std::vector<Img> imgs;      // layout order
+  std::vector<Group> groups;
+  size_t bytes = 0, prob_floats = 0;
+  bool has_probs = false, staged = false;
+  hipEvent_t ready = nullptr;
+  ~StageSlot() {
+    if (pinned) (void)hipHostFree(pinned);
+    if (ready) (void)hipEventDestroy(ready);
+  }
+};
+
 struct ocr_pipe {
   DetStage det;
+  // Further detector instances (own stream, network, buffers) for batches of MIXED sizes: every distinct size is its own
+  // det pass (a few images at most), a latency-bound chain of ~90 small launches that leaves the chip idle - several
+  // chains side by side, each driven by its own host thread, fill it.  OCR_DET_LANES (default 8) instances in all.
+  std::vector<std::unique_ptr<DetStage>> det_extra;
+  DetConfig det_cfg;
+  int det_lanes = 8;
   RecStage rec;
   std::unique_ptr<ClsStage> cls;
   int device = 0;
-  DevBuf<uint8_t> upload;
+  StageSlot slots[2];
+  hipStream_t copy_stream = nullptr;
+  DevBuf<uint8_t> work;  // the requests' clones (OCRRequest copies the Mat, ocr_worker.h:28-29): cls rotates in place on them
   DevBuf<RotDesc> rot_desc;
   DevBuf<int> rot_seg;
   int crop_mode = 0;  // OCR_CROP_BOUNDING_RECT | OCR_CROP_ROTATE
   DevBuf<uint8_t> crop_arena;
   DevBuf<WarpDesc> warp_desc;
-  std::vector<int32_t> boxes;
+  std::vector<int32_t> boxes;  // [image in layout order][cap][8]
   std::vector<int> nbox;
+  static constexpr int kCap = 1000;  // max_candidates bounds the boxes of one image (postprocess_op.cpp:260)
 
-  // one det pass over `count` same-size images living at dev (+ optional prob maps), then crops/cls/rec
-  int run_group(uint8_t* dev, int rows, int cols, int count, const float* dev_prob, std::vector<std::vector<ocr_word>>& out_words,
-                std::vector<std::vector<int32_t>>& out_ids, double times[3], std::string& err) {
-    const int cap = 1000;  // max_candidates bounds the boxes of one image (postprocess_op.cpp:260)
-    boxes.resize((size_t)count * cap * 8);
-    nbox.resize(count);
-    const size_t row = (size_t)cols * 3, img_bytes = row * rows;
+  ~ocr_pipe() { if (copy_stream) (void)hipStreamDestroy(copy_stream); }
+
+  // ---- stage: host images -> pinned -> device (asynchronous after the host copies)
+  int stage(int si, const ocr_img* imgs, int count, std::string& err) {
+    StageSlot& S = slots[si];
+    if (!copy_stream && hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking) != hipSuccess) { err = "hipStreamCreate failed"; return OCR_ERR_DEVICE; }
+    if (!S.ready && hipEventCreateWithFlags(&S.ready, hipEventDisableTiming) != hipSuccess) { err = "hipEventCreate failed"; return OCR_ERR_DEVICE; }
+    if (S.staged && hipEventSynchronize(S.ready) != hipSuccess) { err = "staging event failed"; return OCR_ERR_DEVICE; }  // pinned buffer free again
+    // layout: stable order by (rows, cols)
+    std::vector<int> order(count);
+    for (int i = 0; i < count; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+      return imgs[a].rows != imgs[b].rows ? imgs[a].rows < imgs[b].rows : imgs[a].cols < imgs[b].cols;
+    });
+    const std::vector<StageSlot::Img> before = S.imgs;
+    S.imgs.clear();
+    S.groups.clear();
+    size_t off = 0, poff = 0;
+    for (int k = 0; k < count; ++k) {
+      const ocr_img& im = imgs[order[k]];
+      if (S.groups.empty() || S.groups.back().rows != im.rows || S.groups.back().cols != im.cols) {
+        off = (off + 255) & ~(size_t)255;
+        S.groups.push_back({im.rows, im.cols, k, 0, off, poff});
+      }
+      S.groups.back().count++;
+      int rh = 0, rw = 0;
+      { float a, b; DetStage::resize_shape(im.rows, im.cols, det.cfg().limit_type, det.cfg().limit_side_len, rh, rw, a, b); }
+      S.imgs.push_back({im.rows, im.cols, order[k], off, poff});
+      off += (size_t)im.rows * im.cols * 3;
+      poff += (size_t)rh * rw;
+    }
+    S.bytes = off;
+    S.prob_floats = poff;
+    // probability maps attached to the slot (benchmark protocol) stay valid only while the layout is the same
+    bool same = before.size() == S.imgs.size();
+    for (size_t k = 0; same && k < before.size(); ++k)
+      same = before[k].rows == S.imgs[k].rows && before[k].cols == S.imgs[k].cols && before[k].orig == S.imgs[k].orig;
+    if (!same) S.has_probs = false;
+    if (off > S.pinned_cap) {
+      if (S.pinned) (void)hipHostFree(S.pinned);
+      S.pinned = nullptr;
+      S.pinned_cap = 0;
+      if (hipHostMalloc((void**)&S.pinned, off, hipHostMallocDefault) != hipSuccess) { err = "hipHostMalloc failed"; return OCR_ERR_DEVICE; }
+      S.pinned_cap = off;
+    }
+    if (!S.dev.ensure(off + 256, err)) return OCR_ERR_DEVICE;
+    // host copies on a few threads (one thread moves ~10 GB/s: 64 images of 960x960 would take 18 ms)
+    {
+      const int nthreads = (int)std::min<size_t>(8, std::max<size_t>(1, off >> 22));
+      auto copy_range = [&](int t) {
+        for (int k = t; k < count; k += nthreads) {
+          const ocr_img& im = imgs[S.imgs[k].orig];
+          const size_t row = (size_t)im.cols * 3, stride = im.row_stride ? im.row_stride : row;
+          uint8_t* dst = S.pinned + S.imgs[k].off;
+          if (stride == row) memcpy(dst, im.data, row * im.rows);
+          else for (int y = 0; y < im.rows; ++y) memcpy(dst + row * y, im.data + stride * y, row);
+        }
+      };
+      std::vector<std::thread> th;
+      for (int t = 1; t < nthreads; ++t) th.emplace_back(copy_range, t);
+      copy_range(0);
+      for (auto& t : th) t.join();
+    }
+    if (hipMemcpyAsync(S.dev.p, S.pinned, off, hipMemcpyHostToDevice, copy_stream) != hipSuccess) { err = "H2D copy failed"; return OCR_ERR_DEVICE; }
+    if (hipEventRecord(S.ready, copy_stream) != hipSuccess) { err = "hipEventRecord failed"; return OCR_ERR_DEVICE; }
+    S.staged = true;
+    return OCR_OK;
+  }
+
+  // benchmark protocol for synthetic weights: per staged image a probability map of the
+  // detector's input resolution that replaces the network's map for thresholding / scoring
+  int slot_probs(int si, const float* const* probs, int count, std::string& err) {
+    StageSlot& S = slots[si];
+    if (!S.staged || count != (int)S.imgs.size()) { err = "stage the slot's images first (same count)"; return OCR_ERR_ARG; }
+    if (!S.probs.ensure(S.prob_floats + 64, err)) return OCR_ERR_DEVICE;
+    for (int k = 0; k < count; ++k) {
+      const size_t n = (k + 1 < count ? S.imgs[k + 1].prob_off : S.prob_floats) - S.imgs[k].prob_off;
+      if (hipMemcpyAsync(S.probs.p + S.imgs[k].prob_off, probs[S.imgs[k].orig], n * sizeof(float), hipMemcpyHostToDevice, copy_stream) != hipSuccess) {
+        err = "probability map upload failed";
+        return OCR_ERR_DEVICE;
+      }
+    }
+    if (hipEventRecord(S.ready, copy_stream) != hipSuccess) { err = "hipEventRecord failed"; return OCR_ERR_DEVICE; }
+    S.has_probs = true;
+    return OCR_OK;
+  }
+
+  // ---- run: det per size group, then ONE cls pass and ONE rec pass over the crops of every image of the batch
+  // (results are batch-invariant, so pooling lines across sizes changes nothing but the launch count)
+  int run_images(uint8_t* base, const std::vector<StageSlot::Img>& imgs, const std::vector<StageSlot::Group>& groups, const float* probs,
+                 std::vector<std::vector<ocr_word>>& out_words, std::vector<std::vector<int32_t>>& out_ids, double times[3], std::string& err) {
+    const int count = (int)imgs.size();
+    boxes.resize((size_t)count * kCap * 8);
+    nbox.assign(count, 0);
     double t0 = now_ms();
-    int rc = det.run_device(dev, img_bytes, row, rows, cols, count, boxes.data(), cap, nbox.data(), nullptr, err, dev_prob);
-    if (rc) return rc;
+    auto run_group = [&](DetStage& d, const StageSlot::Group& g, std::string& e) {
+      const size_t row = (size_t)g.cols * 3, img_bytes = row * g.rows;
+      return d.run_device(base + g.off, img_bytes, row, g.rows, g.cols, g.count, boxes.data() + (size_t)g.first * kCap * 8, kCap,
+                          nbox.data() + g.first, nullptr, e, probs ? probs + g.prob_off : nullptr);
+    };
+    const int lanes = (int)std::min<size_t>((size_t)det_lanes, groups.size());
+    if (lanes <= 1) {
+      for (const auto& g : groups) {
+        int rc = run_group(det, g, err);
+        if (rc) return rc;
+      }
+    } else {
+      while ((int)det_extra.size() < lanes - 1) {   // created on first use: single-size callers never pay for them
+        std::unique_ptr<DetStage> d(new DetStage());
+        int code = 0;
+        if (!d->create(det_cfg, err, code)) return code ? code : OCR_ERR_DEVICE;
+        det_extra.push_back(std::move(d));
+      }
+      // the clone above was enqueued on lane 0's stream: the other lanes' streams must not read it earlier
+      if (hipStreamSynchronize(det.stream()) != hipSuccess) { err = "det stream sync failed"; return OCR_ERR_DEVICE; }
+      std::vector<int> rcs(lanes, OCR_OK);
+      std::vector<std::string> errs(lanes);
+      auto lane_fn = [&](int l) {
+        DetStage& d = l == 0 ? det : *det_extra[l - 1];
+        for (size_t gi = l; gi < groups.size(); gi += lanes) {
+          rcs[l] = run_group(d, groups[gi], errs[l]);
+          if (rcs[l]) return;
+        }
+      };
+      std::vector<std::thread> th;
+      for (int l = 1; l < lanes; ++l) th.emplace_back(lane_fn, l);
+      lane_fn(0);
+      for (auto& t : th) t.join();
+      for (int l = 0; l < lanes; ++l)
+        if (rcs[l]) { err = errs[l]; return rcs[l]; }
+    }
     double t1 = now_ms();
     times[0] += t1 - t0;
     // crop rectangles: cv::boundingRect(points) & image rect (ocr_worker.cpp:245-258)
@@ -49,12 +204,14 @@ struct ocr_pipe {
     std::vector<int> seg(1, 0);
     std::vector<int> line_box;  // box index (within its image) of every line
     if (crop_mode == OCR_CROP_ROTATE) {
-      rc = rotate_crops(dev, rows, cols, count, cap, lines, seg, line_box, err);
+      int rc = rotate_crops(base, imgs, lines, seg, line_box, err);
       if (rc) return rc;
     } else
     for (int i = 0; i < count; ++i) {
+      const int rows = imgs[i].rows, cols = imgs[i].cols;
+      const size_t row = (size_t)cols * 3;
       for (int j = 0; j < nbox[i]; ++j) {
-        const int32_t* b = &boxes[((size_t)i * cap + j) * 8];
+        const int32_t* b = &boxes[((size_t)i * kCap + j) * 8];
         int x0 = b[0], x1 = b[0], y0 = b[1], y1 = b[1];
         for (int k = 1; k < 4; ++k) {
           x0 = std::min(x0, b[2 * k]); x1 = std::max(x1, b[2 * k]);
@@ -66,7 +223,7 @@ struct ocr_pipe {
           // `word.box = det_boxes[i]` pairs text k with box k of the image, even when an empty crop was
           // skipped before it (reference quirk, ocr_worker.cpp:293-299) — kept.
           line_box.push_back((int)lines.size() - seg.back());
-          lines.push_back(LineSrc{dev + img_bytes * i, row, ix0, iy0, ix1 - ix0, iy1 - iy0});
+          lines.push_back(LineSrc{base + imgs[i].off, row, ix0, iy0, ix1 - ix0, iy1 - iy0});
         }
       }
       seg.push_back((int)lines.size());
@@ -77,7 +234,7 @@ struct ocr_pipe {
     if (cls) {
       std::vector<int> labels(lines.size());
       std::vector<float> scores(lines.size());
-      rc = cls->run_lines(lines, labels.data(), scores.data(), err);
+      int rc = cls->run_lines(lines, labels.data(), scores.data(), err);
       if (rc) return rc;
       // rotate in request order, in place on the device copy (cv::rotate on ROI views aliasing the image):
       // one workgroup per image walks that image's rotations sequentially
@@ -106,13 +263,13 @@ struct ocr_pipe {
     std::vector<int32_t> ids(lines.size() * max_len);
     std::vector<int> lens(lines.size());
     std::vector<float> scores(lines.size());
-    rc = rec.run_lines(lines, seg, ids.data(), max_len, lens.data(), scores.data(), err);
+    int rc = rec.run_lines(lines, seg, ids.data(), max_len, lens.data(), scores.data(), err);
     if (rc) return rc;
     times[2] += now_ms() - t2;
     for (int i = 0; i < count; ++i) {
       for (int k = seg[i]; k < seg[i + 1]; ++k) {
         ocr_word w;
-        memcpy(w.box, &boxes[((size_t)i * cap + line_box[k]) * 8], sizeof(w.box));
+        memcpy(w.box, &boxes[((size_t)i * kCap + line_box[k]) * 8], sizeof(w.box));
         w.ids_off = (int32_t)out_ids[i].size();
         w.ids_len = lens[k];
         w.confidence = scores[k];
@@ -123,21 +280,42 @@ struct ocr_pipe {
     return OCR_OK;
   }
 
+  // run a staged slot: wait for its upload, clone, run, hand the results back in the caller's order
+  int run_slot(int si, ocr_word* words, int cap_words, int* word_off, int* nwords, int32_t* ids, int cap_ids, double times[3]) {
+    StageSlot& S = slots[si];
+    if (!S.staged || S.imgs.empty()) return fail(OCR_ERR_ARG, "nothing staged in this slot");
+    std::string err;
+    if (hipStreamWaitEvent(det.stream(), S.ready, 0) != hipSuccess) return fail(OCR_ERR_DEVICE, "hipStreamWaitEvent failed");
+    if (!work.ensure(S.bytes + 256, err)) return fail(OCR_ERR_DEVICE, err);
+    if (hipMemcpyAsync(work.p, S.dev.p, S.bytes, hipMemcpyDeviceToDevice, det.stream()) != hipSuccess) return fail(OCR_ERR_DEVICE, "clone failed");
+    double t[3] = {0, 0, 0};
+    std::vector<std::vector<ocr_word>> W;
+    std::vector<std::vector<int32_t>> I;
+    const int rc = run_images(work.p, S.imgs, S.groups, S.has_probs ? S.probs.p : nullptr, W, I, t, err);
+    if (rc) return fail(rc, err);
+    if (times) { times[0] = t[0]; times[1] = t[1]; times[2] = t[2]; }
+    const int count = (int)S.imgs.size();
+    std::vector<int> order(count);  // order[original index] = layout index
+    for (int k = 0; k < count; ++k) order[S.imgs[k].orig] = k;
+    return emit(W, I, order, words, cap_words, word_off, nwords, ids, cap_ids);
+  }
+
   // crop_mode OCR_CROP_ROTATE: every box becomes its own perspective-rectified image
   // (Utility::GetRotateCropImage, utility.cpp:137-190) in the crop arena
-  int rotate_crops(const uint8_t* dev, int rows, int cols, int count, int cap, std::vector<LineSrc>& lines, std::vector<int>& seg,
+  int rotate_crops(const uint8_t* base, const std::vector<StageSlot::Img>& imgs, std::vector<LineSrc>& lines, std::vector<int>& seg,
                    std::vector<int>& line_box, std::string& err) {
-    const size_t row = (size_t)cols * 3, img_bytes = row * rows;
     std::vector<WarpDesc> wd;
     std::vector<size_t> off;
     size_t total = 0;
     int max_px = 0;
-    for (int i = 0; i < count; ++i) {
+    for (int i = 0; i < (int)imgs.size(); ++i) {
+      const int rows = imgs[i].rows, cols = imgs[i].cols;
+      const size_t row = (size_t)cols * 3;
       for (int j = 0; j < nbox[i]; ++j) {
         CropPlan p;
-        if (!plan_rotate_crop(rows, cols, &boxes[((size_t)i * cap + j) * 8], p)) continue;
+        if (!plan_rotate_crop(rows, cols, &boxes[((size_t)i * kCap + j) * 8], p)) continue;
         WarpDesc d;
-        d.src = dev + img_bytes * i + (size_t)p.top * row + (size_t)p.left * 3;
+        d.src = base + imgs[i].off + (size_t)p.top * row + (size_t)p.left * 3;
         d.sstride = row; d.sw = p.sw; d.sh = p.sh; d.dst = nullptr; d.dw = p.dw; d.dh = p.dh; d.rot = p.rot; d.bw0 = p.bw0;
         memcpy(d.m, p.minv, sizeof(d.m));
         wd.push_back(d);
@@ -216,6 +394,8 @@ int ocr_pipe_create(const ocr_pipe_cfg* c, ocr_pipe** out) {
   if (c->det.precision) d.precision = c->det.precision;
   d.max_batch = c->det.max_batch > 0 ? c->det.max_batch : 1;
   if (!h->det.create(d, err, code)) return fail(code, err);
+  h->det_cfg = d;
+  if (const char* e = getenv("OCR_DET_LANES")) h->det_lanes = std::min(16, std::max(1, atoi(e)));
   RecConfig r;
   r.model_dir = c->rec.model_dir; r.label_path = c->rec.label_path; r.device = c->det.device_id;
   r.batch_num = c->rec.rec_batch_num; r.img_h = c->rec.rec_img_h; r.img_w = c->rec.rec_img_w; r.sort_mode = c->rec.sort_mode;
@@ -245,10 +425,13 @@ int ocr_pipe_run_device(ocr_pipe* h, const void* dev_bgr, int rows, int cols, in
   std::vector<std::vector<int32_t>> I;
   std::string err;
   // the request's clone (OCRRequest copies the Mat, ocr_worker.h:28-29): cls rotation is in place on it
-  const size_t bytes = (size_t)rows * cols * 3 * count;
-  if (!h->upload.ensure(bytes, err)) return fail(OCR_ERR_DEVICE, err);
-  CAPI_HIP(hipMemcpyAsync(h->upload.p, dev_bgr, bytes, hipMemcpyDeviceToDevice, h->det.stream()));
-  const int rc = h->run_group(h->upload.p, rows, cols, count, dev_prob, W, I, t, err);
+  const size_t img_bytes = (size_t)rows * cols * 3, bytes = img_bytes * count;
+  if (!h->work.ensure(bytes + 256, err)) return fail(OCR_ERR_DEVICE, err);
+  CAPI_HIP(hipMemcpyAsync(h->work.p, dev_bgr, bytes, hipMemcpyDeviceToDevice, h->det.stream()));
+  std::vector<StageSlot::Img> imgs(count);
+  for (int i = 0; i < count; ++i) imgs[i] = {rows, cols, i, img_bytes * i, 0};
+  const std::vector<StageSlot::Group> groups = {{rows, cols, 0, count, 0, 0}};
+  const int rc = h->run_images(h->work.p, imgs, groups, dev_prob, W, I, t, err);
   if (rc) return fail(rc, err);
   if (times) { times[0] = t[0]; times[1] = t[1]; times[2] = t[2]; }
   std::vector<int> order(count);
@@ -256,38 +439,38 @@ int ocr_pipe_run_device(ocr_pipe* h, const void* dev_bgr, int rows, int cols, in
   return emit(W, I, order, words, cap_words, word_off, nwords, ids, cap_ids);
 }
 
-int ocr_pipe_run(ocr_pipe* h, const ocr_img* imgs, int count, ocr_word* words, int cap_words, int* word_off, int* nwords,
-                 int32_t* ids, int cap_ids, double times[3]) {
-  if (!h || !imgs || count < 1 || !words || !word_off || !nwords || !ids) return fail(OCR_ERR_ARG, "bad argument");
+int ocr_pipe_stage(ocr_pipe* h, int slot, const ocr_img* imgs, int count) {
+  if (!h || !imgs || count < 1 || slot < 0 || slot > 1) return fail(OCR_ERR_ARG, "bad argument");
   for (int i = 0; i < count; ++i)
     if (!imgs[i].data || imgs[i].rows <= 0 || imgs[i].cols <= 0) return fail(OCR_ERR_ARG, "Empty image data provided");
   CAPI_HIP(hipSetDevice(h->device));
-  // images of one size share a det pass
-  std::map<std::pair<int, int>, std::vector<int>> by_size;
-  for (int i = 0; i < count; ++i) by_size[{imgs[i].rows, imgs[i].cols}].push_back(i);
-  std::vector<std::vector<ocr_word>> W(count);
-  std::vector<std::vector<int32_t>> I(count);
-  double t[3] = {0, 0, 0};
   std::string err;
-  for (auto& kv : by_size) {
-    const int rows = kv.first.first, cols = kv.first.second, n = (int)kv.second.size();
-    const size_t row = (size_t)cols * 3, img_bytes = row * rows;
-    if (!h->upload.ensure(img_bytes * n, err)) return fail(OCR_ERR_DEVICE, err);
-    for (int k = 0; k < n; ++k) {
-      const ocr_img& im = imgs[kv.second[k]];
-      const size_t stride = im.row_stride ? im.row_stride : row;
-      CAPI_HIP(hipMemcpy2DAsync(h->upload.p + img_bytes * k, row, im.data, stride, row, rows, hipMemcpyHostToDevice, h->det.stream()));
-    }
-    std::vector<std::vector<ocr_word>> w;
-    std::vector<std::vector<int32_t>> d;
-    const int rc = h->run_group(h->upload.p, rows, cols, n, nullptr, w, d, t, err);
-    if (rc) return fail(rc, err);
-    for (int k = 0; k < n; ++k) { W[kv.second[k]] = std::move(w[k]); I[kv.second[k]] = std::move(d[k]); }
-  }
-  if (times) { times[0] = t[0]; times[1] = t[1]; times[2] = t[2]; }
-  std::vector<int> order(count);
-  for (int i = 0; i < count; ++i) order[i] = i;
-  return emit(W, I, order, words, cap_words, word_off, nwords, ids, cap_ids);
+  const int rc = h->stage(slot, imgs, count, err);
+  return rc ? fail(rc, err) : OCR_OK;
+}
+
+int ocr_pipe_slot_probs(ocr_pipe* h, int slot, const float* const* probs, int count) {
+  if (!h || !probs || count < 1 || slot < 0 || slot > 1) return fail(OCR_ERR_ARG, "bad argument");
+  for (int i = 0; i < count; ++i) if (!probs[i]) return fail(OCR_ERR_ARG, "null probability map");
+  CAPI_HIP(hipSetDevice(h->device));
+  std::string err;
+  const int rc = h->slot_probs(slot, probs, count, err);
+  return rc ? fail(rc, err) : OCR_OK;
+}
+
+int ocr_pipe_run_staged(ocr_pipe* h, int slot, ocr_word* words, int cap_words, int* word_off, int* nwords, int32_t* ids,
+                        int cap_ids, double times[3]) {
+  if (!h || slot < 0 || slot > 1 || !words || !word_off || !nwords || !ids) return fail(OCR_ERR_ARG, "bad argument");
+  CAPI_HIP(hipSetDevice(h->device));
+  return h->run_slot(slot, words, cap_words, word_off, nwords, ids, cap_ids, times);
+}
+
+int ocr_pipe_run(ocr_pipe* h, const ocr_img* imgs, int count, ocr_word* words, int cap_words, int* word_off, int* nwords,
+                 int32_t* ids, int cap_ids, double times[3]) {
+  if (!h || !imgs || count < 1 || !words || !word_off || !nwords || !ids) return fail(OCR_ERR_ARG, "bad argument");
+  const int rc = ocr_pipe_stage(h, 0, imgs, count);
+  if (rc) return rc;
+  return h->run_slot(0, words, cap_words, word_off, nwords, ids, cap_ids, times);
 }
 
 const char* ocr_pipe_label(ocr_pipe* h, int id) {

@@ -175,7 +175,7 @@ class Decoder {
   }
   bool read_sos() {
     size_t len;
-    if (!seg(len)) return false;
+    if (!seg(len) || len < 3) return false;  // q[0] below is byte 3 of the segment: a truncated SOS must not be read past
     const uint8_t* q = d_ + pos_ + 2;
     ns_ = q[0];
     if (ns_ < 1 || ns_ > nc_ || len != (size_t)(6 + 2 * ns_)) return false;

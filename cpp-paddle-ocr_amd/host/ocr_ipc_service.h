@@ -178,6 +178,9 @@ inline bool base64_decode(const std::string& in, std::vector<uint8_t>& out) {
 }
 
 // ---- image decoders: file contents -> packed BGR (what cv::imread / cv::imdecode return) ----
+// Every decoder refuses headers that would make the service allocate gigabytes from a sub-megabyte request
+// (the same 64 Mpixel cap as jpeg_decode.h).
+constexpr long kMaxDecodedPixels = 64L << 20;
 inline bool decode_ppm(const std::vector<uint8_t>& d, Image& im) {
   if (d.size() < 11 || d[0] != 'P' || d[1] != '6') return false;
   size_t i = 2;
@@ -195,7 +198,7 @@ inline bool decode_ppm(const std::vector<uint8_t>& d, Image& im) {
   }
   ++i;  // the single whitespace after maxval
   const long w = v[0], h = v[1];
-  if (w <= 0 || h <= 0 || v[2] != 255 || d.size() < i + (size_t)w * h * 3) return false;
+  if (w <= 0 || h <= 0 || w * h > kMaxDecodedPixels || v[2] != 255 || d.size() < i + (size_t)w * h * 3) return false;
   im.rows = (int)h; im.cols = (int)w;
   im.pixels.resize((size_t)w * h * 3);
   for (size_t p = 0; p < (size_t)w * h; ++p) {  // RGB -> BGR
@@ -211,6 +214,7 @@ inline bool decode_bmp(const std::vector<uint8_t>& d, Image& im) {
   const unsigned bpp = d[28] | (d[29] << 8), comp = u32(30);
   if (hdr < 40 || w <= 0 || hs == 0 || (bpp != 24 && bpp != 32) || (comp != 0 && !(bpp == 32 && comp == 3))) return false;
   const int h = hs < 0 ? -hs : hs;
+  if (hs == INT32_MIN || (long)w * h > kMaxDecodedPixels) return false;
   const size_t stride = ((size_t)w * (bpp / 8) + 3) & ~(size_t)3;
   if (d.size() < off + stride * h) return false;
   im.rows = h; im.cols = w;
@@ -246,7 +250,8 @@ inline bool decode_png(const std::vector<uint8_t>& d, Image& im) {
   pi.format = 0x12;  // PNG_FORMAT_BGR: 8-bit, colour, blue first, alpha removed (composited on black like a
                      // missing background; cv::imread(IMREAD_COLOR) drops alpha without compositing - differs
                      // only for translucent pixels)
-  if (pi.width == 0 || pi.height == 0 || pi.width > 100000 || pi.height > 100000) { pfree(&pi); return false; }
+  if (pi.width == 0 || pi.height == 0 || pi.width > 100000 || pi.height > 100000 ||
+      (long)pi.width * (long)pi.height > kMaxDecodedPixels) { pfree(&pi); return false; }
   im.rows = (int)pi.height; im.cols = (int)pi.width;
   im.pixels.resize((size_t)pi.width * pi.height * 3);
   if (!finish(&pi, nullptr, im.pixels.data(), 0, nullptr)) { pfree(&pi); im = Image(); return false; }
@@ -394,10 +399,17 @@ class OCRIPCService {
   }
 
  private:
+  static constexpr size_t kMaxClients = 256;
   void acceptLoop() {
     while (running_) {
       const int fd = accept(listen_fd_, nullptr, nullptr);
       if (fd < 0) { if (!running_) break; continue; }
+      {
+        // a bound on concurrent clients (each holds a thread and a 1 MiB request buffer): beyond it the connection is
+        // closed at once, which a client sees as "service busy" and retries
+        std::lock_guard<std::mutex> lock(client_threads_mutex_);
+        if (client_fds_.size() >= kMaxClients) { close(fd); continue; }
+      }
       const int big = 2 * READ_BUFFER_SIZE;
       setsockopt(fd, SOL_SOCKET, SO_RCVBUF, &big, sizeof big);
       setsockopt(fd, SOL_SOCKET, SO_SNDBUF, &big, sizeof big);

@@ -279,7 +279,8 @@ class OCRWorker {
       const char* e = getenv("OCR_WORKER_MAX_BATCH");
       max_batch = e ? atoi(e) : 32;
     }
-    max_batch_ = max_batch < 1 ? 1 : max_batch;
+    max_batch_ = max_batch < 1 ? 1 : (max_batch > 256 ? 256 : max_batch);  // result buffers: 1 MB of ids per image
+    gpu_id_ = gpu_id;
     if (!use_gpu) throw std::runtime_error("OCRWorker: this build has no CPU path (use_gpu must be true)");
     det_dir_ = model_dir + "/det"; cls_dir_ = model_dir + "/cls"; rec_dir_ = model_dir + "/rec";
     dict_ = model_dir + "/rec/ppocr_keys_v1.txt";
@@ -300,10 +301,24 @@ class OCRWorker {
     worker_thread_ = std::thread(&OCRWorker::workerLoop, this);
   }
   void stop() {
-    if (!running_) return;
-    running_ = false;
+    {
+      // under the queue mutex: a worker between its predicate check and its wait would otherwise miss the wake-up
+      std::lock_guard<std::mutex> lock(queue_mutex_);
+      if (!running_) return;
+      running_ = false;
+    }
     cv_.notify_all();
     if (worker_thread_.joinable()) worker_thread_.join();
+    // requests still queued get an answer, not a broken promise
+    std::queue<std::shared_ptr<OCRRequest>> rest;
+    { std::lock_guard<std::mutex> lock(queue_mutex_); rest.swap(request_queue_); }
+    for (; !rest.empty(); rest.pop()) {
+      OCRResult r;
+      r.request_id = rest.front()->request_id;
+      r.success = false;
+      r.error_message = "worker stopped before the request was processed";
+      rest.front()->result_promise.set_value(detail::result_json(r, worker_id_));
+    }
   }
   void addRequest(std::shared_ptr<OCRRequest> request) {
     { std::lock_guard<std::mutex> lock(queue_mutex_); request_queue_.push(request); }
@@ -311,6 +326,7 @@ class OCRWorker {
   }
   bool isIdle() const { return is_idle_; }
   int getWorkerId() const { return worker_id_; }
+  int getGpuId() const { return gpu_id_; }
 
   // processRequest (ocr_worker.cpp:213-311) — public here so tests can call it without the thread
   OCRResult processRequest(const OCRRequest& request) {
@@ -424,6 +440,7 @@ class OCRWorker {
   }
 
   int worker_id_;
+  int gpu_id_ = 0;
   int max_batch_ = 1;
   std::vector<ocr_word> batch_words_;
   std::vector<int32_t> batch_ids_;
@@ -455,6 +472,7 @@ class GPUWorkerPool {
     return future;
   }
   int getOptimalWorkerCount() { return ocr_rt_device_count(); }  // declared, never defined in the reference
+  int workerDevice(int i) const { return workers_[i]->getGpuId(); }
 
  private:
   OCRWorker* getAvailableWorker() {  // first idle, else round robin (gpu_worker_pool.cpp:46-59)

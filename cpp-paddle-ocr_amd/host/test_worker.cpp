@@ -28,6 +28,23 @@ int main(int argc, char** argv) {
   f.read((char*)px.data(), px.size());
   ImageView img{px.data(), rows, cols, (size_t)cols * 3};
 
+  if (argc > 4 && std::string(argv[4]) == "multi") {
+    // two workers of one pool on two DIFFERENT devices from one process (gpu_worker_pool.cpp:12-16 maps every worker to
+    // GPU 0; here worker i -> GPU i mod n): every per-device resource (kernel attributes, streams, arenas) must exist on
+    // both.  Prints each reply's JSON; tests/test_host_layer.py compares all of them with the oracle.
+    const int ngpu = ocr_rt_device_count();
+    if (ngpu < 2) { printf("SKIP one device\n"); return 0; }
+    GPUWorkerPool pool(model_root, 2);
+    CHECK(pool.workerDevice(0) == 0 && pool.workerDevice(1) == 1);
+    pool.start();
+    std::vector<std::future<std::string>> fut;
+    for (int id = 0; id < 8; ++id) fut.push_back(pool.submitRequest(std::make_shared<OCRRequest>(id, img)));
+    for (int id = 0; id < 8; ++id) printf("POOLJSON %s\n", fut[id].get().c_str());
+    pool.stop();
+    printf("%s\n", failures ? "FAILED" : "ALL OK");
+    return failures ? 1 : 0;
+  }
+
   {
     OCRWorker w(7, model_root, true, 0);
     CHECK(w.isIdle());

@@ -152,9 +152,11 @@ typedef struct ocr_word {
 typedef struct ocr_pipe ocr_pipe;
 int ocr_pipe_create(const ocr_pipe_cfg* cfg, ocr_pipe** out);
 void ocr_pipe_destroy(ocr_pipe* h);
-/* imgs: `count` images (any mix of sizes; equal sizes share one det pass).  words: cap_words entries,
- * image i owns words[word_off[i] .. word_off[i]+nwords[i]); ids: cap_ids class ids.
- * times[3] = det / cls / rec wall ms. */
+/* imgs: `count` images (any mix of sizes).  Images of equal size share one det pass; the text lines of ALL images
+ * then go through one cls pass and one rec pass (each image's lines are still sorted and cut into batches of
+ * rec_batch_num on their own, ocr_rec.cpp:34-57: results do not depend on what else is in the call).
+ * words: cap_words entries, image i owns words[word_off[i] .. word_off[i]+nwords[i]); ids: cap_ids class ids.
+ * times[3] = det / cls / rec wall ms.  = ocr_pipe_stage(slot 0) + ocr_pipe_run_staged(slot 0). */
 int ocr_pipe_run(ocr_pipe* h, const ocr_img* imgs, int count, ocr_word* words, int cap_words, int* word_off, int* nwords,
                  int32_t* ids, int cap_ids, double times[3]);
 /* The same with inputs already resident in HBM: `count` packed BGR images of rows x cols (one every
@@ -163,6 +165,18 @@ int ocr_pipe_run(ocr_pipe* h, const ocr_img* imgs, int count, ocr_word* words, i
  * protocol for synthetic weights; the network still runs and is timed). */
 int ocr_pipe_run_device(ocr_pipe* h, const void* dev_bgr, int rows, int cols, int count, const float* dev_prob, ocr_word* words,
                         int cap_words, int* word_off, int* nwords, int32_t* ids, int cap_ids, double times[3]);
+/* Double-buffered input: ocr_pipe_stage copies the host images into pinned memory (a few
+ * host threads) and starts their upload on a copy stream, then returns; ocr_pipe_run_staged waits for that upload on
+ * the device and runs the batch.  Two slots (0, 1): one host thread stages batch k+1 into the other slot while
+ * another is inside ocr_pipe_run_staged for batch k; a slot may be run any number of times (its images then are
+ * "already resident in HBM").
+ * ocr_pipe_slot_probs (benchmark protocol): per staged image a HOST pointer to a probability map
+ * of the detector's input resolution (ocr_pipe_det_shape) that replaces the network's map, as dev_prob of
+ * ocr_pipe_run_device; the maps stay attached while the slot is re-staged with the same sizes in the same order. */
+int ocr_pipe_stage(ocr_pipe* h, int slot, const ocr_img* imgs, int count);
+int ocr_pipe_slot_probs(ocr_pipe* h, int slot, const float* const* probs, int count);
+int ocr_pipe_run_staged(ocr_pipe* h, int slot, ocr_word* words, int cap_words, int* word_off, int* nwords, int32_t* ids,
+                        int cap_ids, double times[3]);
 const char* ocr_pipe_label(ocr_pipe* h, int id);
 /* network input size the detector uses for a rows x cols image (ResizeImgType0) */
 int ocr_pipe_det_shape(ocr_pipe* h, int rows, int cols, int* net_rows, int* net_cols);

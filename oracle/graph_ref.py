@@ -5,7 +5,8 @@ NCHW), used as a *second opinion* on the fused plan and on the C oracle
 (SURVEY.md §8c G5).  It follows the op semantics Paddle documents for each operator
 (SURVEY.md Appendix A); it does not share code with the plan executor.
 
-Only tests/ may import this module.
+Only tests/ and bench.py's cpu_baseline leg (tools/cpu_baseline_worker.py: torch-CPU/oneDNN as the closest available
+stand-in for Paddle+MKLDNN kernel quality, SURVEY.md 8d "B2") may import this module.
 """
 import os
 import sys
@@ -30,18 +31,33 @@ def _bcast(y, x, axis):
     return y.reshape(shape)
 
 
-def run_graph(pdmodel_path, params, x, taps=None):
-    """params: name -> ndarray.  x: ndarray [N,3,H,W].  Returns output ndarray.
+_CACHE = {}
+
+
+def _prepared(pdmodel_path, params, dtype):
+    """Parsed program + parameter tensors, kept per (graph, parameter dict, dtype): repeated runs (the CPU baseline,
+    the float64 arbiter) do not re-parse the protobuf or re-wrap 200 arrays."""
+    key = (pdmodel_path, id(params), dtype)
+    if key not in _CACHE:
+        if len(_CACHE) > 8:
+            _CACHE.clear()
+        _CACHE[key] = (Program(pdmodel_path), {k: torch.from_numpy(np.ascontiguousarray(v)).to(dtype) for k, v in params.items()})
+    return _CACHE[key]
+
+
+def run_graph(pdmodel_path, params, x, taps=None, dtype=torch.float32):
+    """params: name -> ndarray.  x: ndarray [N,3,H,W].  Returns output ndarray (of `dtype`: torch.float64 makes this
+    interpreter the arbiter between the f32 oracle and f32 torch).
     taps: optional dict var_name -> None, filled with ndarrays for requested vars."""
-    prog = Program(pdmodel_path)
-    env = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in params.items()}
+    prog, env0 = _prepared(pdmodel_path, params, dtype)
+    env = dict(env0)
     shapes = {}
     with torch.no_grad():
         for op in prog.ops:
             t = op.type
             a = op.attrs
             if t == "feed":
-                env[op.out("Out")] = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))
+                env[op.out("Out")] = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(dtype)
             elif t == "fetch":
                 out = env[op.inp("X")]
             elif t in ("conv2d", "depthwise_conv2d"):

@@ -116,12 +116,12 @@ class Pipeline:
         return texts, scores, steps
 
     # ---- OCRWorker::processRequest
-    def process(self, image):
+    def process(self, image, prob_override=None):
         if image is None or image.size == 0:
             return dict(success=False, error="Empty image data provided")
         image = image.copy()  # OCRRequest clones the Mat (ocr_worker.h:28-29)
         rows, cols = image.shape[:2]
-        boxes = self.det_run(image)
+        boxes = self.det_run(image, prob_override)
         words = []
         if len(boxes) == 0:
             return dict(success=True, width=cols, height=rows, words=words)

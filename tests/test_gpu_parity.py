@@ -490,3 +490,35 @@ def test_rec_batches_with_tied_ratios_follow_the_sort_mode(pkg, built, mode):
         am, pm = rec.steps(i)
         assert np.array_equal(am, steps[i][0]) and np.array_equal(pm, steps[i][1]), i
     rec.close()
+
+
+def test_pipeline_cfg3_pooled_lines_and_staged_slots(pkg, built):
+    """BASELINE configs[2] shape of work: 16 images of 16 distinct sizes in ONE call.  det runs per size; the text
+    lines of all images share one cls pass and one rec pass (pipe.hip run_images) - every word must still equal
+    what the oracle produces for that image alone.  Synthetic probability maps (SURVEY 8d protocol) so that every
+    image has lines.  Also: the double-buffered staging API - slot 1 staged while slot 0's results are read, a slot
+    run twice gives the same words (the staged images are not rotated in place), run() == stage + run_staged."""
+    from pipeline import Pipeline, DetCfg
+    from synth_data import cfg3_sample, cfg3_prob_at
+    kw = dict(rec_batch_num=16, rec_img_h=48, rec_img_w=320, enable_cls=True)
+    pg = pkg.Pipe(limit_side_len=960, **kw)
+    po = Pipeline(det_cfg=DetCfg(limit_side_len=960), **kw)
+    imgs = [cfg3_sample(i)[0] for i in range(16)]
+    assert len({im.shape for im in imgs}) >= 8
+    probs = [cfg3_prob_at(i, *pg.det_shape(*imgs[i].shape[:2])) for i in range(16)]
+    pg.stage(0, imgs[:10], probs[:10])
+    pg.stage(1, imgs[10:], probs[10:])
+    got = pg.run_staged(0) + pg.run_staged(1)
+    again = pg.run_staged(0)
+    total = 0
+    for i, g in enumerate(got):
+        w = po.process(imgs[i], probs[i])["words"]
+        assert len(g) == len(w) > 0, i
+        total += len(g)
+        for a, b in zip(g, w):
+            assert np.array_equal(a["box"], b["box"]) and np.array_equal(a["ids"], b["ids"])
+            assert a["confidence"] == np.float32(b["confidence"])
+    assert total > 200
+    for a, b in zip(again, got[:10]):
+        assert len(a) == len(b) and all(np.array_equal(x["ids"], y["ids"]) and x["confidence"] == y["confidence"] for x, y in zip(a, b))
+    pg.close()

@@ -43,6 +43,28 @@ def test_worker_and_pool_binary(built, card, tmp_path):
         assert np.float32(g["confidence"]) == np.float32(w["confidence"])
 
 
+@pytest.mark.gpu
+def test_pool_on_two_devices(built, card, tmp_path, pkg):
+    """GPUWorkerPool with worker i on GPU i mod n, from ONE process (gpu_worker_pool.cpp:12-16 shape).
+    Needs two visible devices (the driver's multi-GPU node); on a one-GPU lease it is skipped."""
+    if pkg.lib().ocr_rt_device_count() < 2:
+        pytest.skip("one device visible")
+    from pipeline import Pipeline
+    subprocess.check_call(["make", "-s", "-C", HOST])
+    raw = tmp_path / "card.bgr"
+    card.tofile(raw)
+    out = subprocess.run([os.path.join(HOST, "test_worker"), os.path.join(ROOT, "models"), str(raw),
+                          "%dx%d" % card.shape[:2], "multi"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "ALL OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+    want = Pipeline().process(card)["words"]
+    replies = [json.loads(l[9:]) for l in out.stdout.splitlines() if l.startswith("POOLJSON ")]
+    assert len(replies) == 8 and {r["worker_id"] for r in replies} == {0, 1}
+    for r in replies:
+        assert r["success"] is True and len(r["words"]) == len(want)
+        for g, w in zip(r["words"], want):
+            assert g["box"] == np.asarray(w["box"]).tolist() and np.float32(g["confidence"]) == np.float32(w["confidence"])
+
+
 def test_argsort_tie_order_modes(built):
     """Utility::argsort is std::sort (utility.cpp:192-203): the order of EQUAL ratios is the host library's.  "std" is
     this toolchain's std::sort; "stable" keeps ties in input order, which is what MSVC's std::sort (the reference's

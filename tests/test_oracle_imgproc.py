@@ -169,3 +169,107 @@ def test_rotate_crop_restatement_properties(built):
     # empty / outside boxes have no crop
     assert O.rotate_crop(img, [[5, 5], [5, 5], [5, 5], [5, 5]]) is None
     assert O.rotate_crop(img, [[-1, 5], [30, 5], [30, 20], [-1, 20]]) is None
+
+
+def _expand_simple(poly):
+    """CHAIN_APPROX_SIMPLE keeps only the end points of straight runs (8 directions): the full pixel chain back."""
+    pts = set()
+    n = len(poly)
+    for i in range(n):
+        (x0, y0), (x1, y1) = poly[i], poly[(i + 1) % n]
+        dx, dy = int(np.sign(x1 - x0)), int(np.sign(y1 - y0))
+        steps = max(abs(x1 - x0), abs(y1 - y0))
+        assert abs(x1 - x0) in (0, steps) and abs(y1 - y0) in (0, steps)   # straight in one of the 8 directions
+        for k in range(steps + 1):
+            pts.add((x0 + k * dx, y0 + k * dy))
+    return pts
+
+
+def test_contour_point_sets_equal_the_border_definition(built):
+    """Second, independently written check of findContours(RETR_LIST, CHAIN_APPROX_SIMPLE) - point SETS, not counts.
+    Suzuki-Abe's border between an 8-connected 1-component S1 and a 4-connected 0-component S2 is, by definition, the
+    set of pixels of S1 with a 4-neighbour in S2.  Computed here with scipy labelling (no border following at all) and
+    compared with the pixel chains the oracle's contours expand to: every (S1, S2) adjacency is one contour, every
+    contour is exactly one such set."""
+    from scipy import ndimage
+    import oracle as O
+    rs = np.random.RandomState(7)
+    for trial in range(14):
+        H, W = rs.randint(16, 120), rs.randint(16, 120)
+        f = ndimage.gaussian_filter(rs.rand(H, W), rs.rand() * 2.5 + 0.4)
+        bm = (f > np.percentile(f, rs.randint(25, 80))).astype(np.uint8)
+        if trial % 4 == 0:
+            bm[rs.randint(0, H), :] = 1          # 1-px lines, frame contact
+            bm[:, rs.randint(0, W)] = 1
+        fg, nfg = ndimage.label(bm, structure=np.ones((3, 3)))
+        bgp, nbg = ndimage.label(np.pad(1 - bm, 1, constant_values=1))      # 4-connected zeros, with the outside frame
+        want = {}
+        ys, xs = np.nonzero(bm)
+        for y, x in zip(ys, xs):
+            for dy, dx in ((-1, 0), (1, 0), (0, -1), (0, 1)):
+                b = bgp[y + 1 + dy, x + 1 + dx]
+                if b:
+                    want.setdefault((fg[y, x], b), set()).add((x, y))
+        got = [_expand_simple([tuple(p) for p in c.tolist()]) for c in _contours(O, bm)]
+        assert len(got) == len(want) == nfg + nbg - 1
+        left = dict(want)
+        for pts in got:
+            keys = [k for k, v in left.items() if v == pts]
+            assert len(keys) >= 1, "a contour that is no (component, background) border set"
+            del left[keys[0]]
+        assert not left
+
+
+def test_fixed_point_resize_against_exact_rational_bilinear(built):
+    """cv::resize INTER_LINEAR on 8-bit data works in fixed point (11-bit coefficients, 22-bit products).  An
+    independent evaluation: the same sample positions (float32 arithmetic on the coordinates, as OpenCV) but the
+    interpolation itself in exact rational arithmetic.  The fixed-point result must be within 1 of the exactly
+    rounded value everywhere and equal to it at more than 4 of 5 positions; plus a plain-Python big-int restatement of the
+    fixed-point formula (written from the formula, not from the oracle's C) that must match bit for bit."""
+    from fractions import Fraction
+    import oracle as O
+    rs = np.random.RandomState(3)
+    for (sh, sw, dh, dw) in [(9, 13, 17, 31), (20, 24, 11, 7), (6, 40, 48, 57), (31, 5, 12, 23), (8, 8, 9, 8)]:
+        img = rs.randint(0, 256, (sh, sw, 3)).astype(np.uint8)
+        got = O.resize_u8c3(img, dh, dw)
+        if dh * 2 == sh and dw * 2 == sw:
+            continue
+        sx_, sy_ = 1.0 / (np.float64(dw) / sw), 1.0 / (np.float64(dh) / sh)   # resize.cpp: scale = 1 / inv_scale
+
+        def coords(n_dst, n_src, scale, clamp):
+            # x: positions left of the first / right of the last pixel centre take that pixel alone (weight 0 on the
+            # neighbour); y: the fraction is kept and the two ROWS are clipped instead (resize.cpp, resizeGeneric_)
+            out = []
+            for d in range(n_dst):
+                f = np.float32((d + 0.5) * scale - 0.5)
+                s = int(np.floor(f))
+                f = np.float32(f - np.float32(s))
+                if clamp and s < 0:
+                    s, f = 0, np.float32(0)
+                if clamp and s >= n_src - 1:
+                    s, f = n_src - 1, np.float32(0)
+                out.append((s, f))
+            return out
+        cx, cy = coords(dw, sw, sx_, True), coords(dh, sh, sy_, False)
+        sat = lambda v: int(max(-32768, min(32767, int(np.rint(np.float32(v))))))
+        worst, exact_hits, total = 0, 0, 0
+        for y, (sy, fy) in enumerate(cy):
+            for x, (sx, fx) in enumerate(cx):
+                x1 = min(sx + 1, sw - 1)
+                y0, y1 = min(max(sy, 0), sh - 1), min(max(sy + 1, 0), sh - 1)
+                a0, a1 = sat((np.float32(1) - fx) * np.float32(2048)), sat(fx * np.float32(2048))
+                b0, b1 = sat((np.float32(1) - fy) * np.float32(2048)), sat(fy * np.float32(2048))
+                for c in range(3):
+                    p00, p01, p10, p11 = (int(img[y0, sx, c]), int(img[y0, x1, c]), int(img[y1, sx, c]), int(img[y1, x1, c]))
+                    # plain big-int restatement of the fixed-point formula
+                    r0, r1 = p00 * a0 + p01 * a1, p10 * a0 + p11 * a1
+                    v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2
+                    assert got[y, x, c] == max(0, min(255, v))
+                    # exact rational bilinear at the same float32 sample offsets
+                    FX, FY = Fraction(float(fx)), Fraction(float(fy))
+                    e = (p00 * (1 - FX) + p01 * FX) * (1 - FY) + (p10 * (1 - FX) + p11 * FX) * FY
+                    r = int(e + Fraction(1, 2))
+                    worst = max(worst, abs(int(got[y, x, c]) - r))
+                    exact_hits += int(got[y, x, c]) == r
+                    total += 1
+        assert worst <= 1 and exact_hits / total > 0.8, (worst, exact_hits / total)

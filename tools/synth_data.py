@@ -101,6 +101,19 @@ def cfg2_sample(i, H=960, W=960, K=32):
     return make_image(seed, H, W, K, layout), make_prob_map(seed, H, W, K, layout), layout
 
 
+def cfg3_prob_at(i, rh, rw):
+    """The synthetic probability map of cfg3 sample i at the detector's input resolution rh x rw (the layout's
+    rectangles scaled per axis; angles are within 5 degrees, so a scaled rectangle stays a rectangle to a pixel)."""
+    seed = 2000 + i
+    u = Rng(seed ^ 0xC3).uniform(3)
+    H = 640 + int(u[0] * 641)
+    W = 640 + int(u[1] * 641)
+    K = 4 + int(u[2] * 61)
+    sx, sy = rw / W, rh / H
+    layout = [(cx * sx, cy * sy, w * sx, h * sy, ang) for (cx, cy, w, h, ang) in make_layout(seed, H, W, K)]
+    return make_prob_map(seed, rh, rw, K, layout)
+
+
 def cfg3_sample(i):
     """mixed-aspect 640-1280 px images, K in 4..64 (cls on)."""
     seed = 2000 + i

@@ -6,6 +6,13 @@
 #include "capi_common.h"
 #include "plans_embedded.inc"
 
+// The pipeline keeps a dozen independent launch chains in flight (rec lanes for odd tensor widths, det lanes for mixed
+// image sizes, copy stream).  The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues, 4 by default:
+// more chains than queues serialise behind each other (measured: BASELINE configs[2] det 531 -> 357 ms per 512 images
+// with 16).  The runtime reads the variable when it initialises, i.e. at the first HIP call of the process; this runs
+// when the library is loaded.  A value the user has set is left alone.
+__attribute__((constructor)) static void ocr_runtime_env_defaults() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+
 namespace ocr {
 
 static thread_local std::string g_last_error;

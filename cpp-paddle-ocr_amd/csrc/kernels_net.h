@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <vector>
 
 #include "lds_attr.h"
 #include "ocr_common.h"
@@ -41,6 +42,9 @@ void launch_conv_mfma(const ConvArgs& a, const Epilogue& ep, int nt, hipStream_t
 void launch_conv_lds(const ConvArgs& a, const Epilogue& ep, int nt, hipStream_t s);
 // 3x3 s1 p1 conv with the input tile resident in LDS; returns false when the shape is not on that path
 bool launch_conv3x3_tile(const ConvArgs& a, const Epilogue& ep, int nt, hipStream_t s);
+// 3x3 s1 p1 conv 96 -> 24 channels on 4x4x1 matrix blocks (no zero columns); wimg from conv3x3_c24_image
+bool launch_conv3x3_c24(const ConvArgs& a, const Epilogue& ep, const float* wimg, hipStream_t s);
+std::vector<float> conv3x3_c24_image(const float* w, int co, int ci);
 // column tiles per wave for a GEMM with `tiles` 32-wide column tiles
 inline int conv_nt_for(int tiles) {
   static const char* e = getenv("OCR_CONV_NT_MAX");  // A/B measurements (results are identical)

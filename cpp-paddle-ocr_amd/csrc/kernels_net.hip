@@ -8,6 +8,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <vector>
 
 #include "conv_device.h"
 #include "kernels_net.h"
@@ -421,6 +422,169 @@ __global__ void __launch_bounds__(256, 2) conv3x3_tile_kernel(const ConvArgs a, 
   const int oy = y0 + ly, ox = x0 + lx;
   const long m = (oy < a.OH && ox < a.OW) ? ((long)n * a.OH + oy) * a.OW + ox : a.M;
   conv_finish<NT, OUT_C8I>(a, ep, acc, nt0, m, h, s_par);
+}
+
+// =====================================================================================
+// The same conv for 24 output channels on 4x4x1 matrix blocks (the five DB neck / head 96 -> 24 convs).
+// conv3x3_tile_kernel<12, 1> multiplies 32-column tiles: with 24 channels a quarter of every v_mfma_f32_32x32x2_f32 is
+// spent on zero columns (83 TFLOP/s useful = 0.71 of a pipe that can give 0.75).  v_mfma_f32_4x4x1_16B_f32 is sixteen
+// independent 4x4 outer products per instruction (measured 128 TFLOP/s back to back, tools/micro/mfma_4x4.hip, against
+// 150 for 32x32x2): a block = 4 pixels x 4 output channels, so 24 channels are six blocks wide and nothing is wasted.
+//   lane l of a wave  : B operand = pixel l of the wave's 64 pixels (one input channel per instruction, K = 1);
+//                       result    = its pixel's channels 4g .. 4g+3 in four registers -> one 16-byte store
+//   A operand         : ONE register per k for all 24 channels - lane 4g + m holds the weight of channel 4g + m, and
+//                       instruction g broadcasts block g's four lanes to all sixteen blocks (CBSZ = 4, ABID = g)
+//   workgroup         : the 8 x 16 pixel tile of conv3x3_tile_kernel (10 x 18 x 96 halo region in LDS, one barrier),
+//                       4 waves = 2 pixel halves x 2 channel halves (3 blocks of 4 channels each)
+//   k order           : tap-major, then LOGICAL input channel ascending - an octet of the C8I layout is read as
+//                       two float4 (physical 0..3 = logical 0,2,4,6; physical 4..7 = logical 1,3,5,7) and issued
+//                       lo.x, hi.x, lo.y, hi.y, ...: the contract's chain, one fma per instruction
+//   weights           : image [tap][octet][32 lanes][8 logical steps] (lanes 24..31 zero), two 16-byte loads per lane
+//                       and octet, a whole octet ahead
+// =====================================================================================
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+template <int C8, int TH>
+__global__ void __launch_bounds__(TH * 32, 2) conv3x3_c24_kernel(const ConvArgs a, const Epilogue ep, const float* __restrict__ wimg,
+                                                             const int tiles_x, const int tiles_y) {
+  constexpr int TW = 16, RH = TH + 2, RW = TW + 2, NTHR = TH * 32;  // 64 pixels x 2 channel halves per 4 tile rows
+  constexpr int CS = C8 * 8, STRIDE = CS + 4;  // floats per staged pixel
+  constexpr int Q = CS / 4;                    // 16-byte pieces per pixel
+  extern __shared__ float4 s_tile4[];
+  float* s_tile = (float*)s_tile4;             // [RH*RW][STRIDE]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const unsigned lb = xcd_swizzle(blockIdx.x, gridDim.x);
+  unsigned tile = lb;
+  const int tx = (int)(tile % tiles_x);
+  tile /= tiles_x;
+  const int ty = (int)(tile % tiles_y), n = (int)(tile / tiles_y);
+  const int y0 = ty * TH, x0 = tx * TW;
+  {  // fill: (RH*RW) pixels x Q pieces, consecutive threads take consecutive pieces of a pixel
+    const float* img = a.in + (long)n * a.H * a.W * CS;
+    constexpr int PIECES = RH * RW * Q, PER_THR = (PIECES + NTHR - 1) / NTHR;
+    float4 r[PER_THR];
+#pragma unroll
+    for (int i = 0; i < PER_THR; ++i) {
+      const int idx = tid + i * NTHR;
+      const int px = idx / Q, q = idx - px * Q;
+      const int py = px / RW, pxx = px - py * RW;
+      const int iy = y0 - 1 + py, ix = x0 - 1 + pxx;
+      const bool v = idx < PIECES && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+      r[i] = v ? *(const float4*)(img + ((long)iy * a.W + ix) * CS + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < PER_THR; ++i) {
+      const int idx = tid + i * NTHR;
+      const int px = idx / Q, q = idx - px * Q;
+      if (idx < PIECES) *(float4*)(s_tile + px * STRIDE + q * 4) = r[i];
+    }
+  }
+  __syncthreads();
+  const int ph = wave & 1, chh = __builtin_amdgcn_readfirstlane(wave >> 1);  // the channel half as a scalar
+  const int ly = ph * 4 + (lane >> 4), lx = lane & 15;  // this lane's pixel inside the tile
+  const float* sA = s_tile + (ly * RW + lx) * STRIDE;
+  const float4* wl = (const float4*)wimg + (lane & 31) * 2;  // [tap][octet][32][8]
+  floatx4 acc[3];
+#pragma unroll
+  for (int g = 0; g < 3; ++g) acc[g] = floatx4{0.f, 0.f, 0.f, 0.f};
+  // operands of a whole octet (weights from L1, pixels from LDS) are fetched one octet ahead of their 24 instructions
+  struct Oct { float4 w0, w1, lo, hi; };
+  auto load_oct = [&](Oct& o, const float* src_tap, const float4* w_tap, int c) __attribute__((always_inline)) {
+    o.w0 = w_tap[c * 64];
+    o.w1 = w_tap[c * 64 + 1];
+    o.lo = *(const float4*)(src_tap + c * 8);
+    o.hi = *(const float4*)(src_tap + c * 8 + 4);
+  };
+  auto mul_oct = [&](const Oct& o) __attribute__((always_inline)) {
+    const float xs[8] = {o.lo.x, o.hi.x, o.lo.y, o.hi.y, o.lo.z, o.hi.z, o.lo.w, o.hi.w};  // logical channels 8c .. 8c+7
+    const float ws[8] = {o.w0.x, o.w0.y, o.w0.z, o.w0.w, o.w1.x, o.w1.y, o.w1.z, o.w1.w};
+    if (chh == 0) {  // wave-uniform (a scalar branch): blocks 0..2 or 3..5 of the weight register
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(ws[s], xs[s], acc[0], 4, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(ws[s], xs[s], acc[1], 4, 1, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(ws[s], xs[s], acc[2], 4, 2, 0);
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(ws[s], xs[s], acc[0], 4, 3, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(ws[s], xs[s], acc[1], 4, 4, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(ws[s], xs[s], acc[2], 4, 5, 0);
+      }
+    }
+  };
+  static_assert(C8 % 2 == 0, "octets are walked in pairs");
+  Oct oA, oB;
+  load_oct(oA, sA, wl, 0);
+#pragma unroll 1
+  for (int tap = 0; tap < 9; ++tap) {   // the 12 octets of a tap unrolled: every operand address is base + constant
+    const int ky = tap / 3, kx = tap - ky * 3;
+    const float* src = sA + (ky * RW + kx) * STRIDE;
+    const float4* wt = wl + (long)tap * C8 * 64;
+    const int nt = tap < 8 ? tap + 1 : 8, nky = nt / 3, nkx = nt - nky * 3;  // past the end: the last tap again (unused)
+    const float* nsrc = sA + (nky * RW + nkx) * STRIDE;
+    const float4* nwt = wl + (long)nt * C8 * 64;
+#pragma unroll
+    for (int c = 0; c < C8; c += 2) {
+      load_oct(oB, src, wt, c + 1);
+#ifndef OCR_C24_NOSCHED
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+      mul_oct(oA);
+#ifndef OCR_C24_NOSCHED
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+      if (c + 2 < C8) load_oct(oA, src, wt, c + 2);
+      else load_oct(oA, nsrc, nwt, 0);
+#ifndef OCR_C24_NOSCHED
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+      mul_oct(oB);
+#ifndef OCR_C24_NOSCHED
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+    }
+  }
+  const int oy = y0 + ly, ox = x0 + lx;
+  if (oy >= a.OH || ox >= a.OW) return;
+  const long m = ((long)n * a.OH + oy) * a.OW + ox;
+#pragma unroll
+  for (int g = 0; g < 3; ++g) {
+    const int pc = chh * 12 + g * 4;
+    float4 v = make_float4(acc[g][0], acc[g][1], acc[g][2], acc[g][3]);
+    v = apply_epilogue4(ep, v, pc, n, oy, ox, m * a.Cs_out + pc, a.Cs_out);
+    *(float4*)(a.out + m * a.Cs_out + pc) = v;
+  }
+}
+
+// weights image of conv3x3_c24_kernel from the logical filter w[co][ci][3][3] (co = 24, ci = 96); host side
+std::vector<float> conv3x3_c24_image(const float* w, int co, int ci) {
+  const int C8 = ci / 8;
+  std::vector<float> img((size_t)9 * C8 * 32 * 8, 0.f);
+  for (int tap = 0; tap < 9; ++tap)
+    for (int c = 0; c < C8; ++c)
+      for (int pco = 0; pco < 24; ++pco)
+        for (int s = 0; s < 8; ++s) {
+          const int lco = c8i_logical(pco), lci = c * 8 + s;  // logical
+          if (lco < co) img[((((size_t)tap * C8 + c) * 32) + pco) * 8 + s] = w[((size_t)lco * ci + lci) * 9 + tap];
+        }
+  return img;
+}
+
+bool launch_conv3x3_c24(const ConvArgs& a, const Epilogue& ep, const float* wimg, hipStream_t s) {
+  static const char* env = getenv("OCR_CONV_C24");  // OCR_CONV_C24=0: the 32-column tile kernel (A/B; results are identical)
+  if (env && env[0] == '0') return false;
+  if (!wimg || !(a.KH == 3 && a.KW == 3 && a.PH == 1 && a.PW == 1 && a.OH == a.H && a.OW == a.W && a.out_mode == OUT_C8I)) return false;
+  if (a.Cs_in != 96 || a.Cs_out != 24 || a.Cout != 24) return false;
+  for (int i = 0; i < ep.n; ++i) if (ep.st[i].kind == EP_ADDUP) return false;
+  const int tiles_x = (a.OW + 15) / 16;   // (4-row tiles, 3 workgroups per CU: 64 instead of 90 TFLOP/s - measured, removed)
+  const int tiles_y = (a.OH + 7) / 8;
+  const dim3 grid((unsigned)((long)a.N * tiles_y * tiles_x));
+  const unsigned lds = 10 * 18 * (96 + 4) * sizeof(float);  // 72 000 B: two workgroups per CU
+  static unsigned char attr_state[64] = {};
+  if (!raise_dynamic_lds((const void*)conv3x3_c24_kernel<12, 8>, (int)lds, attr_state)) return false;
+  hipLaunchKernelGGL((conv3x3_c24_kernel<12, 8>), grid, dim3(256), lds, s, a, ep, wimg, tiles_x, tiles_y);
+  return true;
 }
 
 // true if the launch was taken (3x3, stride 1, pad 1, 96 input channels, C8I output); OCR_CONV_TILE=0 disables

@@ -254,6 +254,7 @@ bool Net::load(const char* plan_text, const WeightMap& W, std::string& err) {
             return ch < co ? w[((size_t)ch * ci + k) * kh * kw + tap] : 0.f;
           });
           if (!upload("frag:" + op.w, f)) { err = "hipMalloc failed"; return false; }
+          if (kh == 3 && kw == 3 && ci == 96 && co == 24 && !pl && !upload("c24:" + op.w, conv3x3_c24_image(w, co, ci))) { err = "hipMalloc failed"; return false; }
         }
       } break;
       case PlanOp::LINEAR: {
@@ -663,7 +664,12 @@ bool Net::bind(int N, int H, int W, std::string& err) {
             L.fn = [f](hipStream_t s) {
               if (!launch_dwpw(f, s)) { fprintf(stderr, "launch_dwpw: shape accepted at bind time was refused at launch\n"); abort(); }
             };
-          } else if (use_lds) L.fn = [a, ep, nt](hipStream_t s) { if (!launch_conv3x3_tile(a, ep, nt, s)) launch_conv_lds(a, ep, nt, s); };
+          } else if (use_lds) {
+            const float* c24 = dev_vec("c24:" + op.w);
+            L.fn = [a, ep, nt, c24](hipStream_t s) {
+              if (!launch_conv3x3_c24(a, ep, c24, s) && !launch_conv3x3_tile(a, ep, nt, s)) launch_conv_lds(a, ep, nt, s);
+            };
+          }
           else L.fn = [a, ep, nt](hipStream_t s) { launch_conv_mfma(a, ep, nt, s); };
         }
       } break;

@@ -359,7 +359,7 @@ class ocr_word(C.Structure):
 
 
 EXPORTS += ["ocr_pipe_cfg_default", "ocr_pipe_create", "ocr_pipe_destroy", "ocr_pipe_run", "ocr_pipe_run_device",
-            "ocr_pipe_stage", "ocr_pipe_slot_probs", "ocr_pipe_run_staged",
+            "ocr_pipe_stage", "ocr_pipe_slot_probs", "ocr_pipe_run_staged", "ocr_pipe_stage_jpeg", "ocr_jpeg_decode",
             "ocr_pipe_label", "ocr_pipe_det_shape", "ocr_pipe_timing", "ocr_pipe_timing_filter", "ocr_pipe_timing_report", "ocr_dev_alloc",
             "ocr_dev_free", "ocr_dev_upload", "ocr_dev_download", "ocr_dev_sync", "ocr_rotate_crop", "ocr_rotate_crop_shape"]
 

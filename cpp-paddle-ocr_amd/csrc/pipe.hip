@@ -3,12 +3,14 @@
 #include <algorithm>
 #include <chrono>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <memory>
 #include <thread>
 
 #include "capi_common.h"
 #include "crop.h"
+#include "jpeg_stage.h"
 #include "stages.h"
 
 using namespace ocr;
@@ -56,6 +58,7 @@ struct ocr_pipe {
   int device = 0;
   StageSlot slots[2];
   hipStream_t copy_stream = nullptr;
+  JpegScratch jpeg;
   DevBuf<uint8_t> work;  // the requests' clones (OCRRequest copies the Mat, ocr_worker.h:28-29): cls rotates in place on them
   DevBuf<RotDesc> rot_desc;
   DevBuf<int> rot_seg;
@@ -69,32 +72,29 @@ struct ocr_pipe {
   ~ocr_pipe() { if (copy_stream) (void)hipStreamDestroy(copy_stream); }
 
   // ---- stage: host images -> pinned -> device (asynchronous after the host copies)
-  int stage(int si, const ocr_img* imgs, int count, std::string& err) {
-    StageSlot& S = slots[si];
+  // layout of a batch in a slot: stable order by (rows, cols), images of one size contiguous
+  int layout(StageSlot& S, int count, const std::function<void(int, int&, int&)>& size_of, std::string& err) {
     if (!copy_stream && hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking) != hipSuccess) { err = "hipStreamCreate failed"; return OCR_ERR_DEVICE; }
     if (!S.ready && hipEventCreateWithFlags(&S.ready, hipEventDisableTiming) != hipSuccess) { err = "hipEventCreate failed"; return OCR_ERR_DEVICE; }
     if (S.staged && hipEventSynchronize(S.ready) != hipSuccess) { err = "staging event failed"; return OCR_ERR_DEVICE; }  // pinned buffer free again
-    // layout: stable order by (rows, cols)
-    std::vector<int> order(count);
-    for (int i = 0; i < count; ++i) order[i] = i;
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
-      return imgs[a].rows != imgs[b].rows ? imgs[a].rows < imgs[b].rows : imgs[a].cols < imgs[b].cols;
-    });
+    std::vector<int> order(count), rows(count), cols(count);
+    for (int i = 0; i < count; ++i) { order[i] = i; size_of(i, rows[i], cols[i]); }
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return rows[a] != rows[b] ? rows[a] < rows[b] : cols[a] < cols[b]; });
     const std::vector<StageSlot::Img> before = S.imgs;
     S.imgs.clear();
     S.groups.clear();
     size_t off = 0, poff = 0;
     for (int k = 0; k < count; ++k) {
-      const ocr_img& im = imgs[order[k]];
-      if (S.groups.empty() || S.groups.back().rows != im.rows || S.groups.back().cols != im.cols) {
+      const int r = rows[order[k]], c = cols[order[k]];
+      if (S.groups.empty() || S.groups.back().rows != r || S.groups.back().cols != c) {
         off = (off + 255) & ~(size_t)255;
-        S.groups.push_back({im.rows, im.cols, k, 0, off, poff});
+        S.groups.push_back({r, c, k, 0, off, poff});
       }
       S.groups.back().count++;
       int rh = 0, rw = 0;
-      { float a, b; DetStage::resize_shape(im.rows, im.cols, det.cfg().limit_type, det.cfg().limit_side_len, rh, rw, a, b); }
-      S.imgs.push_back({im.rows, im.cols, order[k], off, poff});
-      off += (size_t)im.rows * im.cols * 3;
+      { float a, b; DetStage::resize_shape(r, c, det.cfg().limit_type, det.cfg().limit_side_len, rh, rw, a, b); }
+      S.imgs.push_back({r, c, order[k], off, poff});
+      off += (size_t)r * c * 3;
       poff += (size_t)rh * rw;
     }
     S.bytes = off;
@@ -104,6 +104,16 @@ struct ocr_pipe {
     for (size_t k = 0; same && k < before.size(); ++k)
       same = before[k].rows == S.imgs[k].rows && before[k].cols == S.imgs[k].cols && before[k].orig == S.imgs[k].orig;
     if (!same) S.has_probs = false;
+    if (!S.dev.ensure(off + 256, err)) return OCR_ERR_DEVICE;
+    return OCR_OK;
+  }
+
+  // ---- stage: host images -> pinned -> device (asynchronous after the host copies)
+  int stage(int si, const ocr_img* imgs, int count, std::string& err) {
+    StageSlot& S = slots[si];
+    int rc = layout(S, count, [&](int i, int& r, int& c) { r = imgs[i].rows; c = imgs[i].cols; }, err);
+    if (rc) return rc;
+    const size_t off = S.bytes;
     if (off > S.pinned_cap) {
       if (S.pinned) (void)hipHostFree(S.pinned);
       S.pinned = nullptr;
@@ -111,7 +121,6 @@ struct ocr_pipe {
       if (hipHostMalloc((void**)&S.pinned, off, hipHostMallocDefault) != hipSuccess) { err = "hipHostMalloc failed"; return OCR_ERR_DEVICE; }
       S.pinned_cap = off;
     }
-    if (!S.dev.ensure(off + 256, err)) return OCR_ERR_DEVICE;
     // host copies on a few threads (one thread moves ~10 GB/s: 64 images of 960x960 would take 18 ms)
     {
       const int nthreads = (int)std::min<size_t>(8, std::max<size_t>(1, off >> 22));
@@ -130,6 +139,21 @@ struct ocr_pipe {
       for (auto& t : th) t.join();
     }
     if (hipMemcpyAsync(S.dev.p, S.pinned, off, hipMemcpyHostToDevice, copy_stream) != hipSuccess) { err = "H2D copy failed"; return OCR_ERR_DEVICE; }
+    if (hipEventRecord(S.ready, copy_stream) != hipSuccess) { err = "hipEventRecord failed"; return OCR_ERR_DEVICE; }
+    S.staged = true;
+    return OCR_OK;
+  }
+
+  // ---- stage JPEG coefficients: the pixel half of the decoder runs on the copy stream, into the slot
+  int stage_jpeg(int si, const ocr_jpeg_img* imgs, int count, std::string& err) {
+    StageSlot& S = slots[si];
+    int rc = layout(S, count, [&](int i, int& r, int& c) { r = imgs[i].rows; c = imgs[i].cols; }, err);
+    if (rc) return rc;
+    std::vector<ocr_jpeg_img> ordered(count);
+    std::vector<uint8_t*> dst(count);
+    for (int k = 0; k < count; ++k) { ordered[k] = imgs[S.imgs[k].orig]; dst[k] = S.dev.p + S.imgs[k].off; }
+    rc = jpeg_decode_async(ordered.data(), count, dst.data(), jpeg, copy_stream, err);
+    if (rc) return rc;
     if (hipEventRecord(S.ready, copy_stream) != hipSuccess) { err = "hipEventRecord failed"; return OCR_ERR_DEVICE; }
     S.staged = true;
     return OCR_OK;
@@ -446,6 +470,16 @@ int ocr_pipe_stage(ocr_pipe* h, int slot, const ocr_img* imgs, int count) {
   CAPI_HIP(hipSetDevice(h->device));
   std::string err;
   const int rc = h->stage(slot, imgs, count, err);
+  return rc ? fail(rc, err) : OCR_OK;
+}
+
+int ocr_pipe_stage_jpeg(ocr_pipe* h, int slot, const ocr_jpeg_img* imgs, int count) {
+  if (!h || !imgs || count < 1 || slot < 0 || slot > 1) return fail(OCR_ERR_ARG, "bad argument");
+  for (int i = 0; i < count; ++i)
+    if (!jpeg_img_valid(imgs[i])) return fail(OCR_ERR_ARG, "bad JPEG coefficient descriptor");
+  CAPI_HIP(hipSetDevice(h->device));
+  std::string err;
+  const int rc = h->stage_jpeg(slot, imgs, count, err);
   return rc ? fail(rc, err) : OCR_OK;
 }
 

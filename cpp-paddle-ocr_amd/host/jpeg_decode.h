@@ -47,10 +47,60 @@ struct Component {
   std::vector<uint8_t> plane;  // bw*8 x bh*8 samples
 };
 
+// Entropy-decoded image: quantised DCT coefficients per component, what the scans of the file say and nothing more.
+// The pixel half of decoding (dequantisation, IDCT, upsampling, colour) can then run on the host (Decoder::pixels)
+// or on the device (ocr_pipe_stage_jpeg / ocr_jpeg_decode of include/ocr_hip.h) with identical results.
+struct Coefs {
+  int rows = 0, cols = 0, ncomp = 0, hmax = 1, vmax = 1;
+  struct Comp {
+    std::vector<int16_t> coef;  // bw*bh blocks x 64, blocks row-major, natural order inside
+    uint16_t quant[64] = {};    // natural order
+    int bw = 0, bh = 0, dw = 0, dh = 0;
+  } comp[3];
+};
+
 class Decoder {
  public:
   // decodes to packed BGR; false on anything unsupported or malformed
   bool decode(const uint8_t* data, size_t size, std::vector<uint8_t>& bgr, int& rows, int& cols) {
+    if (!parse(data, size)) return false;
+    reconstruct();
+    return output(bgr, rows, cols);
+  }
+  // the bit-serial half only
+  bool decode_coefficients(const uint8_t* data, size_t size, Coefs& out) {
+    if (!parse(data, size)) return false;
+    const uint8_t* zz = zigzag();
+    out.rows = H_; out.cols = W_; out.ncomp = nc_; out.hmax = hmax_; out.vmax = vmax_;
+    for (int i = 0; i < nc_; ++i) {
+      Component& c = comp_[i];
+      Coefs::Comp& o = out.comp[i];
+      o.coef.swap(c.coef);
+      for (int k = 0; k < 64; ++k) o.quant[zz[k]] = (uint16_t)qt_[c.tq][k];
+      o.bw = c.bw; o.bh = c.bh; o.dw = c.dw; o.dh = c.dh;
+    }
+    return true;
+  }
+  // the pixel half on the host, from coefficients (what the device back-end computes)
+  static bool pixels(const Coefs& in, std::vector<uint8_t>& bgr, int& rows, int& cols) {
+    Decoder d;
+    const uint8_t* zz = zigzag();
+    d.H_ = in.rows; d.W_ = in.cols; d.nc_ = in.ncomp; d.hmax_ = in.hmax; d.vmax_ = in.vmax;
+    for (int i = 0; i < in.ncomp; ++i) {
+      Component& c = d.comp_[i];
+      const Coefs::Comp& s = in.comp[i];
+      c.h = i == 0 ? in.hmax : 1; c.v = i == 0 ? in.vmax : 1; c.tq = i;
+      c.bw = s.bw; c.bh = s.bh; c.dw = s.dw; c.dh = s.dh;
+      c.coef = s.coef;
+      c.plane.assign((size_t)c.bw * 8 * c.bh * 8, 0);
+      for (int k = 0; k < 64; ++k) d.qt_[i][k] = s.quant[zz[k]];
+    }
+    d.reconstruct();
+    return d.output(bgr, rows, cols);
+  }
+
+ private:
+  bool parse(const uint8_t* data, size_t size) {
     d_ = data; n_ = size; pos_ = 0;
     if (n_ < 4 || d_[0] != 0xFF || d_[1] != 0xD8) return false;
     pos_ = 2;
@@ -72,11 +122,9 @@ class Decoder {
       if (m >= 0xD0 && m <= 0xD7) continue;  // stray RSTn
       if (!skip_segment()) return false;
     }
-    reconstruct();
-    return output(bgr, rows, cols);
+    return true;
   }
 
- private:
   // ---------------------------------------------------------------- markers / headers
   int next_marker() {
     while (pos_ + 1 < n_) {

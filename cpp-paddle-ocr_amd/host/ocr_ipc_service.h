@@ -257,14 +257,25 @@ inline bool decode_png(const std::vector<uint8_t>& d, Image& im) {
   if (!finish(&pi, nullptr, im.pixels.data(), 0, nullptr)) { pfree(&pi); im = Image(); return false; }
   return true;
 }
-inline bool decode_jpeg(const std::vector<uint8_t>& d, Image& im) {
+// device_pixels: stop after the entropy decoding and leave the pixel half to the GPU worker (OCR_DEVICE_JPEG=0 or
+// device_pixels = false: everything on this host thread)
+inline bool decode_jpeg(const std::vector<uint8_t>& d, Image& im, bool device_pixels = false) {
   if (d.size() < 4 || d[0] != 0xFF || d[1] != 0xD8) return false;
   jpeg::Decoder dec;
+  static const char* env = getenv("OCR_DEVICE_JPEG");
+  if (device_pixels && !(env && env[0] == '0')) {
+    auto c = std::make_shared<jpeg::Coefs>();
+    if (!dec.decode_coefficients(d.data(), d.size(), *c)) { im = Image(); return false; }
+    im.pixels.clear();
+    im.rows = c->rows; im.cols = c->cols;
+    im.jpeg = std::move(c);
+    return true;
+  }
   if (!dec.decode(d.data(), d.size(), im.pixels, im.rows, im.cols)) { im = Image(); return false; }
   return true;
 }
-inline bool decode_image(const std::vector<uint8_t>& bytes, Image& im) {
-  return decode_png(bytes, im) || decode_jpeg(bytes, im) || decode_ppm(bytes, im) || decode_bmp(bytes, im);
+inline bool decode_image(const std::vector<uint8_t>& bytes, Image& im, bool device_pixels = false) {
+  return decode_png(bytes, im) || decode_jpeg(bytes, im, device_pixels) || decode_ppm(bytes, im) || decode_bmp(bytes, im);
 }
 inline bool read_file(const std::string& path, std::vector<uint8_t>& out) {
   std::ifstream f(path, std::ios::binary);
@@ -345,19 +356,19 @@ class OCRIPCService {
         std::string error_msg;
         if (!image_path.empty()) {
           std::vector<uint8_t> bytes;
-          if (!ipc::read_file(image_path, bytes) || !ipc::decode_image(bytes, image) || image.empty())
+          if (!ipc::read_file(image_path, bytes) || !ipc::decode_image(bytes, image, gpu_worker_pool_ != nullptr) || image.empty())
             error_msg = "Failed to load image from path: " + image_path;
         } else if (!image_base64.empty()) {
           std::vector<uint8_t> bytes;
           if (!ipc::base64_decode(image_base64, bytes)) error_msg = "Base64 decode error: invalid character";
-          else if (!ipc::decode_image(bytes, image) || image.empty()) error_msg = "Failed to decode base64 image data";
+          else if (!ipc::decode_image(bytes, image, gpu_worker_pool_ != nullptr) || image.empty()) error_msg = "Failed to decode base64 image data";
         } else {
           error_msg = "Missing image_path or image_data";
         }
         if (!error_msg.empty()) return ipc::error_reply(error_msg);
         if (!gpu_worker_pool_) return ipc::error_reply("No GPU workers configured (this build has no CPU path)");
         const int request_id = request_counter_.fetch_add(1);
-        auto request = std::make_shared<OCRRequest>(request_id, image.view());
+        auto request = std::make_shared<OCRRequest>(request_id, std::move(image));
         total_requests_.fetch_add(1);
         std::string result = gpu_worker_pool_->submitRequest(request).get();
         if (result.find("\"success\":true") != std::string::npos) successful_requests_.fetch_add(1);

@@ -27,6 +27,7 @@
 #include <vector>
 
 #include "../../include/ocr_hip.h"
+#include "jpeg_decode.h"
 
 namespace PaddleOCR {
 
@@ -44,6 +45,9 @@ struct ImageView {
 struct Image {
   std::vector<uint8_t> pixels;
   int rows = 0, cols = 0;
+  // a JPEG that has only been entropy-decoded: the worker finishes it on the device (ocr_pipe_stage_jpeg); `pixels`
+  // stays empty unless someone asks for them (materialise())
+  std::shared_ptr<jpeg::Coefs> jpeg;
   Image() = default;
   explicit Image(const ImageView& v) : rows(v.rows), cols(v.cols) {
     if (!v.empty()) {
@@ -52,7 +56,25 @@ struct Image {
     }
   }
   ImageView view() const { return ImageView{pixels.data(), rows, cols, (size_t)cols * 3}; }
-  bool empty() const { return pixels.empty(); }
+  bool empty() const { return pixels.empty() && !jpeg; }
+  bool device_decodable() const { return pixels.empty() && jpeg; }
+  void materialise() {  // the pixel half of the JPEG on the host
+    if (!device_decodable()) return;
+    if (!jpeg::Decoder::pixels(*jpeg, pixels, rows, cols)) throw std::runtime_error("JPEG reconstruction failed");
+    jpeg.reset();
+  }
+  ocr_jpeg_img jpeg_desc() const {
+    ocr_jpeg_img d;
+    memset(&d, 0, sizeof d);
+    d.rows = jpeg->rows; d.cols = jpeg->cols; d.ncomp = jpeg->ncomp; d.hmax = jpeg->hmax; d.vmax = jpeg->vmax;
+    for (int i = 0; i < jpeg->ncomp; ++i) {
+      const auto& c = jpeg->comp[i];
+      d.comp[i].coef = c.coef.data();
+      memcpy(d.comp[i].quant, c.quant, sizeof c.quant);
+      d.comp[i].bw = c.bw; d.comp[i].bh = c.bh; d.comp[i].dw = c.dw; d.comp[i].dh = c.dh;
+    }
+    return d;
+  }
 };
 
 inline void check_ocr(int rc, const char* what) {
@@ -198,6 +220,7 @@ struct OCRRequest {
   Image image_data;  // deep copy, like `image_data(img.clone())`
   std::promise<std::string> result_promise;
   OCRRequest(int id, const ImageView& img) : request_id(id), image_data(img) {}
+  OCRRequest(int id, Image&& img) : request_id(id), image_data(std::move(img)) {}  // keeps a JPEG coefficient payload
 };
 struct WordResult {
   std::string text;
@@ -340,8 +363,15 @@ class OCRWorker {
     std::vector<ocr_word> words(1000);
     std::vector<int32_t> ids(1000 * 256);
     int off = 0, n = 0;
-    ocr_img im = request.image_data.view().c();
-    const int rc = ocr_pipe_run(pipe_, &im, 1, words.data(), (int)words.size(), &off, &n, ids.data(), (int)ids.size(), nullptr);
+    int rc;
+    if (request.image_data.device_decodable()) {  // JPEG: pixels are produced on the device, straight into the staging slot
+      const ocr_jpeg_img jd = request.image_data.jpeg_desc();
+      rc = ocr_pipe_stage_jpeg(pipe_, 0, &jd, 1);
+      if (rc == OCR_OK) rc = ocr_pipe_run_staged(pipe_, 0, words.data(), (int)words.size(), &off, &n, ids.data(), (int)ids.size(), nullptr);
+    } else {
+      ocr_img im = request.image_data.view().c();
+      rc = ocr_pipe_run(pipe_, &im, 1, words.data(), (int)words.size(), &off, &n, ids.data(), (int)ids.size(), nullptr);
+    }
     if (rc != OCR_OK) { result.error_message = ocr_last_error(); return result; }  // the reference's catch (...) path
     result.success = true;
     for (int i = 0; i < n; ++i) {
@@ -365,25 +395,39 @@ class OCRWorker {
     const auto t0 = std::chrono::high_resolution_clock::now();
     std::vector<OCRResult> results(requests.size());
     std::vector<ocr_img> imgs;
+    std::vector<ocr_jpeg_img> jimgs;
     std::vector<size_t> owner;
+    // a batch of JPEGs only is decoded on the device; a mixed batch takes the host path for its JPEGs
+    bool all_jpeg = true;
+    for (size_t i = 0; i < requests.size(); ++i)
+      if (!requests[i]->image_data.empty() && !requests[i]->image_data.device_decodable()) all_jpeg = false;
     for (size_t i = 0; i < requests.size(); ++i) {
       results[i].request_id = requests[i]->request_id;
       if (requests[i]->image_data.empty()) { results[i].error_message = "Empty image data provided"; continue; }
       results[i].width = requests[i]->image_data.cols;
       results[i].height = requests[i]->image_data.rows;
-      imgs.push_back(requests[i]->image_data.view().c());
+      if (all_jpeg) jimgs.push_back(requests[i]->image_data.jpeg_desc());
+      else {
+        const_cast<OCRRequest*>(requests[i])->image_data.materialise();
+        imgs.push_back(requests[i]->image_data.view().c());
+      }
       owner.push_back(i);
     }
-    if (imgs.empty()) return results;
-    if (imgs.size() == 1) { results[owner[0]] = processRequest(*requests[owner[0]]); return results; }
-    const int k = (int)imgs.size();
+    if (owner.empty()) return results;
+    if (owner.size() == 1) { results[owner[0]] = processRequest(*requests[owner[0]]); return results; }
+    const int k = (int)owner.size();
     // result buffers live with the worker (grown once): 1000 words of up to 256 ids per image, as processRequest
     if (batch_words_.size() < (size_t)k * 1000) { batch_words_.resize((size_t)k * 1000); batch_ids_.resize((size_t)k * 1000 * 256); }
     std::vector<ocr_word>& words = batch_words_;
     std::vector<int32_t>& ids = batch_ids_;
     std::vector<int> off(k), cnt(k);
-    const int rc = ocr_pipe_run(pipe_, imgs.data(), k, words.data(), k * 1000, off.data(), cnt.data(), ids.data(),
-                                k * 1000 * 256, nullptr);
+    int rc;
+    if (all_jpeg) {
+      rc = ocr_pipe_stage_jpeg(pipe_, 0, jimgs.data(), k);
+      if (rc == OCR_OK) rc = ocr_pipe_run_staged(pipe_, 0, words.data(), k * 1000, off.data(), cnt.data(), ids.data(), k * 1000 * 256, nullptr);
+    } else {
+      rc = ocr_pipe_run(pipe_, imgs.data(), k, words.data(), k * 1000, off.data(), cnt.data(), ids.data(), k * 1000 * 256, nullptr);
+    }
     if (rc != OCR_OK) {
       for (size_t j = 0; j < owner.size(); ++j) results[owner[j]] = processRequest(*requests[owner[j]]);
       return results;

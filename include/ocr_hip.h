@@ -177,6 +177,24 @@ int ocr_pipe_stage(ocr_pipe* h, int slot, const ocr_img* imgs, int count);
 int ocr_pipe_slot_probs(ocr_pipe* h, int slot, const float* const* probs, int count);
 int ocr_pipe_run_staged(ocr_pipe* h, int slot, ocr_word* words, int cap_words, int* word_off, int* nwords, int32_t* ids,
                         int cap_ids, double times[3]);
+/* JPEG inputs with the pixel half of the decoder on the device: the caller runs the
+ * bit-serial entropy decoding (host/jpeg_decode.h, Decoder::decode_coefficients) and hands over quantised DCT
+ * coefficients; dequantisation, IDCT, chroma upsampling and colour conversion run on the copy stream straight into
+ * the slot - otherwise exactly ocr_pipe_stage.  Results equal decoding on the host first, bit for bit. */
+typedef struct ocr_jpeg_comp {
+  const int16_t* coef; /* host: bw*bh blocks x 64 quantised coefficients, blocks row-major, natural order inside */
+  uint16_t quant[64];  /* quantisation table, natural order */
+  int bw, bh;          /* blocks per row / column (padded to whole MCUs) */
+  int dw, dh;          /* component size in samples: ceil(cols*h/hmax), ceil(rows*v/vmax) */
+} ocr_jpeg_comp;
+typedef struct ocr_jpeg_img {
+  int rows, cols, ncomp; /* ncomp 1 (grey) or 3 (YCbCr) */
+  int hmax, vmax;        /* luma sampling factors, chroma 1x1: 1x1 (4:4:4), 2x1 (4:2:2), 2x2 (4:2:0) */
+  ocr_jpeg_comp comp[3];
+} ocr_jpeg_img;
+int ocr_pipe_stage_jpeg(ocr_pipe* h, int slot, const ocr_jpeg_img* imgs, int count);
+/* the same device decode of one image with the pixels copied back to the host (tests, tools) */
+int ocr_jpeg_decode(const ocr_jpeg_img* img, int device_id, uint8_t* bgr, size_t cap_bytes);
 const char* ocr_pipe_label(ocr_pipe* h, int id);
 /* network input size the detector uses for a rows x cols image (ResizeImgType0) */
 int ocr_pipe_det_shape(ocr_pipe* h, int rows, int cols, int* net_rows, int* net_cols);

@@ -68,12 +68,8 @@ def _jpeg_bytes(rgb, **kw):
     return buf.getvalue()
 
 
-def test_jpeg_decoder_matches_libjpeg(built, card, tmp_path):
-    """host/jpeg_decode.h restates libjpeg's default pipeline (Huffman sequential + progressive, islow IDCT,
-    fancy upsampling, fixed-point YCC->RGB): bit-exact with libjpeg-turbo (through PIL) on every variant."""
+def _jpeg_cases(card):
     from PIL import Image
-    subprocess.check_call(["make", "-s", "-C", HOST])
-    tool = os.path.join(HOST, "decode_tool")
     rs = np.random.RandomState(0)
     yy, xx = np.mgrid[0:200, 0:300]
     images = {"card": card[:, :, ::-1].copy(), "noise": rs.randint(0, 256, (53, 37, 3)).astype(np.uint8),
@@ -91,6 +87,16 @@ def test_jpeg_decoder_matches_libjpeg(built, card, tmp_path):
     cases.append(("gray progressive", np.array(Image.fromarray(images["card"]).convert("L")), dict(quality=85, progressive=True)))
     cases.append(("restart progressive", images["card"], dict(quality=85, restart_marker_blocks=3, progressive=True)))
     cases.append(("progressive q98", images["card"], dict(quality=98, progressive=True)))
+    return images, cases
+
+
+def test_jpeg_decoder_matches_libjpeg(built, card, tmp_path):
+    """host/jpeg_decode.h restates libjpeg's default pipeline (Huffman sequential + progressive, islow IDCT,
+    fancy upsampling, fixed-point YCC->RGB): bit-exact with libjpeg-turbo (through PIL) on every variant."""
+    from PIL import Image
+    subprocess.check_call(["make", "-s", "-C", HOST])
+    tool = os.path.join(HOST, "decode_tool")
+    images, cases = _jpeg_cases(card)
     for name, arr, kw in cases:
         src, dst = tmp_path / "t.jpg", tmp_path / "t.ppm"
         src.write_bytes(_jpeg_bytes(arr, **kw))
@@ -109,6 +115,27 @@ def test_jpeg_decoder_matches_libjpeg(built, card, tmp_path):
         Image.fromarray(images["card"]).save(src, format=fmt)
         assert subprocess.run([tool, str(src), str(tmp_path / "c.out.ppm")]).returncode == 0
         assert np.array_equal(np.array(Image.open(tmp_path / "c.out.ppm")), images["card"])
+
+
+@pytest.mark.gpu
+def test_device_jpeg_decode_equals_host(built, card, tmp_path):
+    """the pixel half of JPEG decoding on the device (csrc/kernels_jpeg.hip through ocr_jpeg_decode: the
+    host only entropy-decodes).  Same variants as the host test - sequential / progressive, 4:4:4 / 4:2:2 / 4:2:0, grey,
+    restart intervals, 1x1 and 3-row images, quality 25..98 - each bit for bit equal to libjpeg-turbo (PIL), hence
+    to host/jpeg_decode.h."""
+    from PIL import Image
+    subprocess.check_call(["make", "-s", "-C", HOST])
+    tool = os.path.join(HOST, "decode_tool")
+    images, cases = _jpeg_cases(card)
+    big = np.random.RandomState(5).randint(0, 256, (333, 517, 3)).astype(np.uint8)
+    cases += [("big", big, dict(quality=75, subsampling=ss)) for ss in (0, 1, 2)]
+    for name, arr, kw in cases:
+        src, dst = tmp_path / "t.jpg", tmp_path / "t.ppm"
+        src.write_bytes(_jpeg_bytes(arr, **kw))
+        want = np.array(Image.open(src).convert("RGB"))
+        r = subprocess.run([tool, "--device", str(src), str(dst)], capture_output=True, text=True)
+        assert r.returncode == 0, (name, kw, r.stderr)
+        assert np.array_equal(np.array(Image.open(dst)), want), (name, kw)
 
 
 def test_ipc_protocol_without_workers(built, card, tmp_path):
@@ -205,6 +232,12 @@ def test_ipc_concurrent_requests_are_batched_with_identical_results(pkg, built, 
             p = tmp_path / f"img{i}.png"
             p.write_bytes(_png_bytes(im))
             paths.append(str(p))
+        # JPEG requests too: a batch of JPEGs only is decoded on the device (OCRWorker::processBatch -> ocr_pipe_stage_jpeg),
+        # a batch that mixes them with PNGs finishes its JPEGs on the host - the replies must not depend on which
+        for i, (im, ss) in enumerate(zip(imgs, (0, 1, 2, 2))):
+            p = tmp_path / f"img{i}.jpg"
+            p.write_bytes(_jpeg_bytes(np.ascontiguousarray(im[:, :, ::-1]), quality=90, subsampling=ss))
+            paths.append(str(p))
         c0 = Client(sock)
         alone = [c0.call({"command": "recognize", "image_path": p}) for p in paths]
         assert all(a["success"] for a in alone) and len(alone[0]["words"]) > 0
@@ -220,6 +253,20 @@ def test_ipc_concurrent_requests_are_batched_with_identical_results(pkg, built, 
         th = [threading.Thread(target=work, args=(t,)) for t in range(nthreads)]
         [t.start() for t in th]
         [t.join() for t in th]
+        # one more round with JPEGs only (the all-JPEG batch path)
+        jp = [k for k, p in enumerate(paths) if p.endswith(".jpg")]
+        extra = [[None] for _ in range(nthreads)]
+
+        def work_jpeg(t):
+            c = Client(sock)
+            k = jp[t % len(jp)]
+            extra[t][0] = (k, c.call({"command": "recognize", "image_path": paths[k]}))
+
+        th = [threading.Thread(target=work_jpeg, args=(t,)) for t in range(nthreads)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        out = [out[t] + extra[t] for t in range(nthreads)]
+        rounds += 1
         for t in range(nthreads):
             for r in range(rounds):
                 k, got = out[t][r]

@@ -481,6 +481,13 @@ bool launch_dwpw(const DwPwArgs& a, hipStream_t s, bool query) {
 #define OCR_DWPW_CASE(K_, SH_, SW_, CK_, WIDE_, NT_, GD_, COND)                                           \
   if (K == K_ && SH == SH_ && SW == SW_ && Cs % CK_ == 0 && tiles % (NT_ * (WIDE_ ? 2 : 1)) == 0 && (COND)) \
     return launch_one<K_, SH_, SW_, CK_, WIDE_, NT_, true, GD_>(a, s, query);
+  // 4-tile layers: a 4x16 tile with 32-channel chunks and 2 x 2 column tiles per wave beats the thin shape by 15-25 %
+  // (half the B-fragment traffic per MFMA); OCR_DWPW_T4=thin keeps the thin shape for A/B runs
+  static const char* t4 = getenv("OCR_DWPW_T4");
+  if (!(t4 && t4[0] == 't')) {
+    OCR_DWPW_CASE(3, 1, 1, 32, true, 2, 1, tiles == 4)
+    OCR_DWPW_CASE(3, 2, 1, 32, true, 2, 1, tiles == 4)
+  }
   // thin layers: tiles <= 4, one wave owns every output column of its 32 pixels
   OCR_DWPW_CASE(3, 1, 1, 16, false, 1, 2, tiles == 1)
   OCR_DWPW_CASE(3, 1, 1, 16, false, 2, 2, tiles == 2)

@@ -168,6 +168,7 @@ class ClsStage {
   int run(const ocr_img* imgs, int n, int* labels, float* scores, double times[3], std::string& err);
   int run_lines(const std::vector<LineSrc>& lines, int* labels, float* scores, std::string& err);
   hipStream_t stream() const { return stream_; }
+  Net& net() { return net_; }
   std::vector<float> tap_probs;  // [n][2] of the last run
 
  private:

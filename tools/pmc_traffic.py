@@ -60,6 +60,15 @@ def main():
         "avg_duration_us_under_pmc": sum(r[4] for r in fe) / len(fe) / 1e3,
         "corrections": "FETCH_SIZE*1024*2, WRITE_SIZE*1024 (MI355X_MICROARCH.md HBM section); separate --pmc passes",
     }
+    # the same dispatches in the plain --kernel-trace --stats run (no counters): the duration bench.py's events must agree with
+    tr = []
+    for fn in glob.glob(os.path.join(root, "trace", "*", "*_kernel_trace.csv")):
+        for r in csv.DictReader(open(fn)):
+            tr.append((int(r["Start_Timestamp"]), r["Kernel_Name"], int(r.get("Grid_Size") or r["Grid_Size_X"]), 0.0, int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+    tr = sel(sorted(tr))
+    if tr:
+        out["avg_duration_us_kernel_trace"] = sum(r[4] for r in tr) / len(tr) / 1e3
+        out["dispatches_in_kernel_trace"] = len(tr)
     json.dump(out, open(dst, "w"), indent=1)
     print(json.dumps(out, indent=1))
 

@@ -26,13 +26,29 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
+#include <utility>
 
 #include "conv_device.h"
 #include "kernels_net.h"
 
 namespace ocr {
 
+#ifdef OCR_DWPW_CLOCKS  // development probe: clocks per phase of the steady-state step, summed over every wave
+__device__ unsigned long long ocr_dwpw_clk[8];
+#define OCR_CLK(i) { const long long t_ = clock64(); clk[i] += t_ - tlast; tlast = t_; }
+#else
+#define OCR_CLK(i)
+#endif
+
 namespace {
+
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>): an unrolled loop whose index is a constant expression
+// (#pragma unroll gives up on the 30-step bodies below, and the arrays they index would land in scratch)
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 struct F4 { ocr_f2 lo, hi; };
 
@@ -98,8 +114,8 @@ __device__ __forceinline__ void lab_apply(F4& v, const ocr_f2 blo, const ocr_f2 
 //   iteration k:  DW(k)   MMA(k-1) [+ the 1x1 conv's epilogue and stores when it closes a unit]   S(k+1)   G(k+3)   barrier
 // G runs two items ahead of S through two register sets, S one item ahead of DW through two LDS buffers.
 // Everything per-thread that does not depend on the tile (LDS offsets of its pieces and items) is computed once.
-template <int K, int SH, int SW, int CK, bool WIDE, int NT, bool DWACT, int GD>
-__global__ void __launch_bounds__(256, 2) dwpw_kernel(const DwPwArgs a) {
+template <int K, int SH, int SW, int CK, bool WIDE, int NT, bool DWACT, int GD, int TD, int LB>
+__global__ void __launch_bounds__(256, LB) dwpw_kernel(const DwPwArgs a) {
   using G_ = DwPwGeom<K, SH, SW, CK, WIDE>;
   constexpr int WC = G_::WC, TW = G_::TW, TH = G_::TH, PR = G_::PR, IW = G_::IW;
   constexpr int S = G_::S, Q = G_::Q, C8S = G_::C8S, IN_TILE = G_::IN_TILE, OP_TILE = G_::OP_TILE, WT = G_::WT;
@@ -167,32 +183,54 @@ __global__ void __launch_bounds__(256, 2) dwpw_kernel(const DwPwArgs a) {
       goff[i] = ok ? (iy * a.W + ix) * Cs + (g_pos[i] & 0xff) : -1;
     }
   };
-  auto G = [&](float4 (&greg)[G_PER], float4& wreg) __attribute__((always_inline)) {
-    if (g_units > 0) {
-      const float* base = g_img + g_ch * CK;
+  // Every call issues the same G_PER + 1 loads, unconditionally (pieces outside the image read a valid address and are
+  // zeroed afterwards; calls past the last item re-read the last one): vmcnt retires in order, and only with a fixed
+  // number of loads per call can the waits for the fragments (issued BEFORE this item's region) be exact counts.  With
+  // loads under lane- or item-dependent branches the compiler falls back to vmcnt(0) in the middle of the matrix phase.
+  const float* const w_piece = tid < WQ ? a.dw_w + (long)(tid / Q) * Cs + 4 * (tid % Q)
+                                        : a.dw_ep.bias + (tid < WQ + Q ? 4 * (tid - WQ) : 0);
+  struct GSet { float4 r[G_PER]; float4 w; unsigned keep; };  // one item's region pieces in flight, + which are real
+  auto G = [&](GSet& gs) __attribute__((always_inline)) {
+    float4 (&greg)[G_PER] = gs.r;
+    float4& wreg = gs.w;
+    const float* base = g_img + g_ch * CK;
 #pragma unroll
-      for (int i = 0; i < G_PER; ++i)
+    for (int i = 0; i < G_PER; ++i)
 #ifdef OCR_DWPW_NO_G  // development probe (tools/micro/dwpw_probe.hip): no input traffic
-        greg[i] = make_float4((float)goff[i], (float)(size_t)base, 0.f, 0.f);
+      greg[i] = make_float4((float)goff[i], (float)(size_t)base, 0.f, 0.f);
 #else
-        greg[i] = goff[i] >= 0 ? *(const float4*)(base + goff[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
+      greg[i] = *(const float4*)(base + (goff[i] >= 0 ? goff[i] : 0));
 #endif
-      if (tid < WQ) wreg = *(const float4*)(a.dw_w + (long)(tid / Q) * Cs + g_ch * CK + 4 * (tid % Q));
-      else if (tid < WQ + Q) wreg = *(const float4*)(a.dw_ep.bias + g_ch * CK + 4 * (tid - WQ));
-      if (++g_ch == nch) {
-        g_ch = 0;
-        if (--g_units > 0) {
-          g_pos_u.next(cblocks, a.tiles_x, a.tiles_y);
-          g_setup();
-        }
+    wreg = *(const float4*)(w_piece + g_ch * CK);
+    // which pieces are real: remembered with the data (goff may belong to the next unit by the time S runs)
+    unsigned keep = 0;
+#pragma unroll
+    for (int i = 0; i < G_PER; ++i) keep |= goff[i] >= 0 ? 1u << i : 0u;
+    gs.keep = keep;
+    if (g_units > 0 && ++g_ch == nch) {
+      g_ch = 0;
+      if (--g_units > 0) {
+        g_pos_u.next(cblocks, a.tiles_x, a.tiles_y);
+        g_setup();
+      } else {
+        g_ch = nch - 1;  // past the end: stay on the last chunk of the last unit
+        g_units = 0;
       }
     }
   };
-  auto Sfill = [&](int buf, const float4 (&greg)[G_PER], const float4& wreg) __attribute__((always_inline)) {
+  auto Sfill = [&](int buf, const GSet& gs) __attribute__((always_inline)) {
+    const float4 (&greg)[G_PER] = gs.r;
+    const float4& wreg = gs.w;
     float* si = s_in + buf * IN_TILE;
+    const unsigned keep = gs.keep;
 #pragma unroll
     for (int i = 0; i < G_PER; ++i)
-      if (G_PIECES % 256 == 0 || g_pos[i] >= 0) *(float4*)(si + g_lds[i]) = greg[i];
+      if (G_PIECES % 256 == 0 || g_pos[i] >= 0) {
+        // (AND with a lane mask, not a select on the loaded value: a select's load is sunk under a branch)
+        const unsigned m = (keep >> i) & 1u ? 0xffffffffu : 0u;
+        *(float4*)(si + g_lds[i]) = make_float4(__uint_as_float(__float_as_uint(greg[i].x) & m), __uint_as_float(__float_as_uint(greg[i].y) & m),
+                                                __uint_as_float(__float_as_uint(greg[i].z) & m), __uint_as_float(__float_as_uint(greg[i].w) & m));
+      }
     if (tid < WQ) *(float4*)(s_w + buf * WT + 4 * tid) = wreg;            // [tap][CK]: tap*CK + 4q = 4*tid
     else if (tid < WQ + Q) *(float4*)(s_b + buf * CK + 4 * (tid - WQ)) = wreg;
   };
@@ -271,6 +309,16 @@ __global__ void __launch_bounds__(256, 2) dwpw_kernel(const DwPwArgs a) {
   // The fragments of a WHOLE chunk are fetched at the top of the iteration that multiplies it, before the depthwise
   // phase: the L2 round trip (the streamed input evicts them from L1) hides behind the depthwise arithmetic.
   float4 bq[C8S][NT];
+  auto advanceB = [&]() __attribute__((always_inline)) {  // p_w -> the fragments of the item after the one just fetched
+    b_step += C8S;
+    if (b_step == KK) {  // next unit: back to the first step of ITS column block (past the end: the last one again)
+      b_step = 0;
+      if (b_units > 1) { --b_units; b_pos.next(cblocks, a.tiles_x, a.tiles_y); }
+      p_w = w_lane + (long)b_pos.cb * WC * NT * 64;
+    } else {
+      p_w += C8S * wstride;
+    }
+  };
   auto loadB = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < C8S; ++j) {
@@ -281,14 +329,7 @@ __global__ void __launch_bounds__(256, 2) dwpw_kernel(const DwPwArgs a) {
       for (int t = 0; t < NT; ++t) bq[j][t] = p_w[j * wstride + t * 64];
 #endif
     }
-    b_step += C8S;
-    if (b_step == KK) {  // next unit: back to the first step of ITS column block (past the end: the last one again)
-      b_step = 0;
-      if (b_units > 1) { --b_units; b_pos.next(cblocks, a.tiles_x, a.tiles_y); }
-      p_w = w_lane + (long)b_pos.cb * WC * NT * 64;
-    } else {
-      p_w += C8S * wstride;
-    }
+    advanceB();
   };
   auto mfma4 = [&](const float4 (&bv)[NT], const float4& av) __attribute__((always_inline)) {
 #ifdef OCR_DWPW_NO_MMA  // development probe: operands fetched, matrix pipe idle
@@ -348,6 +389,13 @@ __global__ void __launch_bounds__(256, 2) dwpw_kernel(const DwPwArgs a) {
       }
   };
   int m_ch = 0;
+  auto mma_end = [&]() __attribute__((always_inline)) {
+    if (++m_ch == nch) {  // the unit is complete
+      finish();
+      m_ch = 0;
+      m_pos.next(cblocks, a.tiles_x, a.tiles_y);
+    }
+  };
   auto MMA = [&](int buf) __attribute__((always_inline)) {
     const float* so = s_op + buf * OP_TILE + op_off;
     float4 av[C8S];
@@ -355,64 +403,176 @@ __global__ void __launch_bounds__(256, 2) dwpw_kernel(const DwPwArgs a) {
     for (int j = 0; j < C8S; ++j) av[j] = *(const float4*)(so + 8 * j);
 #pragma unroll
     for (int j = 0; j < C8S; ++j) mfma4(bq[j], av[j]);
-    if (++m_ch == nch) {  // the unit is complete
-      finish();
-      m_ch = 0;
-      m_pos.next(cblocks, a.tiles_x, a.tiles_y);
-    }
+    mma_end();
+  };
+
+  // ---- steady state: everything else of an iteration INSIDE the matrix instructions of chunk k-1.
+  // Run one after the other, a wave spends the depthwise phase waiting for LDS (one round trip per tap, 25 for a 5x5:
+  // 4960 of the 12300 clocks of an item, measured with clock64 around the phases), the matrix phase waiting for the
+  // matrix pipe, then the fragment loads, the LDS fill and the next global loads, and 2-3 waves per SIMD cannot cover
+  // all of that.  Here the iteration is a sequence of steps, each followed by its share of the chunk's MFMAs and kept
+  // apart by sched_barrier, so that the step issues in the shadow of the 64-cycle matrix instructions:
+  //   tap steps      the LDS reads of tap s+D, the packed FMAs of tap s (chunk k)
+  //   fill / load    registers -> LDS of item k+1, global loads of item k+2
+  //   epilogue       the depthwise epilogue of chunk k and its operand write
+  // and the fragment registers of chunk k-1 are refilled with chunk k's as soon as their last MFMA has issued.
+  // Arithmetic and its order are those of DW and MMA.
+  static_assert(IT_PER == 1, "one depthwise item per thread and chunk");
+#ifdef OCR_DWPW_CLOCKS
+  long long clk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = clock64();
+#endif
+  auto FUSED = [&](int dbuf, int mbuf, int fbuf, GSet& gs) __attribute__((always_inline)) {
+    const float* col = s_in + dbuf * IN_TILE + d_in[0];
+    const float* wq = s_w + dbuf * WT + d_q[0];
+    const float* sb = s_b + dbuf * CK;
+    float* so = s_op + dbuf * OP_TILE;
+    const float* som = s_op + mbuf * OP_TILE + op_off;
+    constexpr int ROWS = (PR - 1) * SH + K, NS = ROWS * K, D = TD, RS = D + 1, NM = C8S * NT * 4, NST = NS + 1;
+    const float4* const pb = p_w;  // the next item's fragments
+    float4 av[C8S];
+#pragma unroll
+    for (int j = 0; j < C8S; ++j) av[j] = *(const float4*)(som + 8 * j);
+    F4 dacc[PR];
+#pragma unroll
+    for (int o = 0; o < PR; ++o) { dacc[o].lo = ocr_f2{0.f, 0.f}; dacc[o].hi = ocr_f2{0.f, 0.f}; }
+    float4 tv[RS], tw[RS][PR];
+    auto fetch = [&](int st, int slot) __attribute__((always_inline)) {
+      const int r = st / K, kx = st - r * K;
+      tv[slot] = *(const float4*)(col + (r * IW + kx) * S);
+#pragma unroll
+      for (int o = 0; o < PR; ++o) {
+        const int ky = r - o * SH;
+        if (ky >= 0 && ky < K) tw[slot][o] = *(const float4*)(wq + (ky * K + kx) * CK);
+      }
+    };
+    auto comp = [](const float4& v, int c) __attribute__((always_inline)) { return c == 0 ? v.x : c == 1 ? v.y : c == 2 ? v.z : v.w; };
+#pragma unroll
+    for (int st = 0; st < D; ++st) fetch(st, st % RS);
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<NST>([&](auto st_) __attribute__((always_inline)) {
+      constexpr int st = decltype(st_)::value;
+      if constexpr (st < NS) {
+        if (st + D < NS) fetch(st + D, (st + D) % RS);
+        const int r = st / K, slot = st % RS;
+        const float4 v = tv[slot];
+#pragma unroll
+        for (int o = 0; o < PR; ++o) {
+          const int ky = r - o * SH;
+          if (ky < 0 || ky >= K) continue;
+          const float4 w = tw[slot][o];
+          dacc[o].lo = __builtin_elementwise_fma(ocr_f2{v.x, v.y}, ocr_f2{w.x, w.y}, dacc[o].lo);
+          dacc[o].hi = __builtin_elementwise_fma(ocr_f2{v.z, v.w}, ocr_f2{w.z, w.w}, dacc[o].hi);
+        }
+      } else {  // the depthwise epilogue and the operand write, as in DW
+        const float4 b = *(const float4*)(sb + d_q[0]);
+        const ocr_f2 blo = {b.x, b.y}, bhi = {b.z, b.w};
+        bool fast = true;
+        if constexpr (DWACT) {
+          const ocr_f2 S0 = {ds0, ds0}, A0 = {da0, da0};
+          float mn = INFINITY, mx = 0.0f;
+#pragma unroll
+          for (int o = 0; o < PR; ++o) {
+            ocr_f2 tl = dacc[o].lo + blo, th = dacc[o].hi + bhi;
+            tl = S0 * tl; th = S0 * th;
+            tl = tl + A0; th = th + A0;
+            ocr_absrange(mn, mx, tl.x, tl.y);
+            ocr_absrange(mn, mx, th.x, th.y);
+          }
+          fast = ocr_hsw_fast_ok(mn, mx);
+        }
+#pragma unroll
+        for (int o = 0; o < PR; ++o) {
+          lab_apply<DWACT>(dacc[o], blo, bhi, ds0, da0, ds1, da1, fast);
+          *(float4*)(so + d_op[0] + o * TW * S) = make_float4(dacc[o].lo.x, dacc[o].lo.y, dacc[o].hi.x, dacc[o].hi.y);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      static_for<(st + 1) * NM / NST - st * NM / NST>([&](auto m_) __attribute__((always_inline)) {  // k-ascending per accumulator: octet, column tile, component
+        constexpr int m = st * NM / NST + decltype(m_)::value;
+        constexpr int j = m / (4 * NT), t = (m / 4) % NT, c4 = m % 4;
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(bq[j][t], c4), comp(av[j], c4), acc[t], 0, 0, 0);
+        if (c4 == 3)  // the last use of this fragment register: refill it
+#ifdef OCR_DWPW_NO_B
+          bq[j][t] = make_float4((float)(size_t)pb, (float)j, (float)t, 1.f);
+#else
+          bq[j][t] = pb[j * wstride + t * 64];
+#endif
+      });
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    OCR_CLK(0)
+    advanceB();
+    OCR_CLK(1)
+    // (inside the step sequence these two cost 40-60 registers - measured - and with them the second or third wave)
+    Sfill(fbuf, gs);
+    OCR_CLK(2)
+    G(gs);
+    OCR_CLK(3)
+    mma_end();
   };
 
   // ---- pipeline
   for (int i = tid; i < c.NTtot * 32; i += 256) s_par[i] = i < c.ColsStore ? a.pw_ep.bias[i] : 0.f;
   g_setup();
+  // Iteration k: depthwise of item k inside the matrix work of item k-1, then the fragments of item k (used by the
+  // next iteration), the LDS fill of item k+1 and the global loads of item k+2 (k+3 with two register sets).  The
+  // steady-state step has NO branch around a vector-memory instruction - G, Sfill and loadB run unconditionally (past
+  // the last item they re-read it / fill a buffer nobody reads) and the first and last iterations are peeled - so that
+  // every s_waitcnt vmcnt the compiler places is an exact in-order count instead of vmcnt(0).
+  auto step = [&](int k, GSet& gs) __attribute__((always_inline)) {
+    OCR_CLK(7)
+    FUSED(k & 1, (k - 1) & 1, (k + 1) & 1, gs);
+    OCR_CLK(5)
+    __syncthreads();
+    OCR_CLK(4)
+  };
+  GSet gA;
+#pragma unroll
+  for (int i = 0; i < G_PER; ++i) gA.r[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  gA.w = make_float4(0.f, 0.f, 0.f, 0.f);
+  gA.keep = 0;
   if constexpr (GD == 2) {
-    float4 gA[G_PER], gB[G_PER], wA = make_float4(0.f, 0.f, 0.f, 0.f), wB = wA;
-#pragma unroll
-    for (int i = 0; i < G_PER; ++i) gA[i] = gB[i] = wA;
-    G(gA, wA);  // item 0
-    G(gB, wB);  // item 1
-    Sfill(0, gA, wA);
-    G(gA, wA);  // item 2
+    GSet gB = gA;
+    G(gA);  // item 0
+    G(gB);  // item 1
+    Sfill(0, gA);
+    G(gA);  // item 2
     __syncthreads();
-    // one body for every iteration (k = total only drains the last MMA); unrolled by two for the register sets
-    auto iter = [&](int k, float4 (&gs)[G_PER], float4& ws) __attribute__((always_inline)) {  // gs holds item k+1
-      if (k >= 1) loadB();
-      if (k < total) DW(k & 1);
-      if (k >= 1) MMA((k - 1) & 1);
-      if (k + 1 < total) {
-        Sfill((k + 1) & 1, gs, ws);
-        G(gs, ws);  // item k+3
-      }
-      if (k < total) __syncthreads();
-    };
-    for (int k = 0; k <= total; k += 2) {
-      iter(k, gB, wB);
-      if (k + 1 <= total) iter(k + 1, gA, wA);
+    DW(0);
+    loadB();
+    Sfill(1, gB);
+    G(gB);  // item 3
+    __syncthreads();
+    int k = 1;
+    for (; k + 1 < total; k += 2) {  // odd k: set A holds item k+1, even k: set B
+      step(k, gA);
+      step(k + 1, gB);
     }
+    if (k < total) step(k, gA);
   } else {  // one register set: G runs one item ahead of S (long iterations: the matrix work covers the round trip)
-    float4 g[G_PER], w = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int i = 0; i < G_PER; ++i) g[i] = w;
-    G(g, w);  // item 0
-    Sfill(0, g, w);
-    G(g, w);  // item 1
+    G(gA);  // item 0
+    Sfill(0, gA);
+    G(gA);  // item 1
     __syncthreads();
-    for (int k = 0; k <= total; ++k) {
-      if (k >= 1) loadB();
-      if (k < total) DW(k & 1);
-      if (k >= 1) MMA((k - 1) & 1);
-      if (k + 1 < total) {
-        Sfill((k + 1) & 1, g, w);
-        G(g, w);  // item k+2
-      }
-      if (k < total) __syncthreads();
-    }
+    DW(0);
+    loadB();
+    Sfill(1, gA);
+    G(gA);  // item 2
+    __syncthreads();
+    for (int k = 1; k < total; ++k) step(k, gA);
   }
+  MMA((total - 1) & 1);
+#ifdef OCR_DWPW_CLOCKS
+  if (lane == 0) {
+    for (int i = 0; i < 6; ++i) atomicAdd(&ocr_dwpw_clk[i], (unsigned long long)clk[i]);
+    atomicAdd(&ocr_dwpw_clk[6], (unsigned long long)(total - 1));
+  }
+#endif
 }
 
 namespace {
 
-template <int K, int SH, int SW, int CK, bool WIDE, int NT, bool DWACT, int GD>
+template <int K, int SH, int SW, int CK, bool WIDE, int NT, bool DWACT, int GD, int TD, int LB>
 bool launch_one(const DwPwArgs& a0, hipStream_t s, bool query) {
   using G_ = DwPwGeom<K, SH, SW, CK, WIDE>;
   const size_t lds = G_::lds_floats(a0.c.NTtot) * sizeof(float);
@@ -421,11 +581,11 @@ bool launch_one(const DwPwArgs& a0, hipStream_t s, bool query) {
   static int per_cu[64] = {}, cus[64] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
-  if (lds > 64 * 1024 && !raise_dynamic_lds((const void*)dwpw_kernel<K, SH, SW, CK, WIDE, NT, DWACT, GD>, (int)lds, attr_state)) return false;
+  if (lds > 64 * 1024 && !raise_dynamic_lds((const void*)dwpw_kernel<K, SH, SW, CK, WIDE, NT, DWACT, GD, TD, LB>, (int)lds, attr_state)) return false;
   if (!per_cu[dev]) {
     int nb = 0;
     hipDeviceProp_t prop;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, dwpw_kernel<K, SH, SW, CK, WIDE, NT, DWACT, GD>, 256, lds) != hipSuccess || nb < 1 ||
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, dwpw_kernel<K, SH, SW, CK, WIDE, NT, DWACT, GD, TD, LB>, 256, lds) != hipSuccess || nb < 1 ||
         hipGetDeviceProperties(&prop, dev) != hipSuccess) { (void)hipGetLastError(); return false; }
     per_cu[dev] = nb;
     cus[dev] = prop.multiProcessorCount;
@@ -450,7 +610,7 @@ bool launch_one(const DwPwArgs& a0, hipStream_t s, bool query) {
   while (upw > 1 && (nunits + upw - 1) / upw < 8 * resident) --upw;  // small problems: keep every CU busy
   a.upw = (unsigned)upw;
   const dim3 grid((unsigned)((nunits + upw - 1) / upw));
-  hipLaunchKernelGGL((dwpw_kernel<K, SH, SW, CK, WIDE, NT, DWACT, GD>), grid, dim3(256), lds, s, a);
+  hipLaunchKernelGGL((dwpw_kernel<K, SH, SW, CK, WIDE, NT, DWACT, GD, TD, LB>), grid, dim3(256), lds, s, a);
   return true;
 }
 
@@ -478,26 +638,29 @@ bool lab_from_epilogue(const Epilogue& ep, LabEp& out) {
 bool launch_dwpw(const DwPwArgs& a, hipStream_t s, bool query) {
   const int K = a.K, SH = a.SH, SW = a.SW, Cs = a.c.Cs_in, tiles = a.c.NTtot;
   if (!a.pw_ep.act || !a.dw_ep.act) return false;  // the pairs on the hot path: full chain on both sides
-#define OCR_DWPW_CASE(K_, SH_, SW_, CK_, WIDE_, NT_, GD_, COND)                                           \
+#define OCR_DWPW_CASE(K_, SH_, SW_, CK_, WIDE_, NT_, GD_, TD_, LB_, COND)                                  \
   if (K == K_ && SH == SH_ && SW == SW_ && Cs % CK_ == 0 && tiles % (NT_ * (WIDE_ ? 2 : 1)) == 0 && (COND)) \
-    return launch_one<K_, SH_, SW_, CK_, WIDE_, NT_, true, GD_>(a, s, query);
+    return launch_one<K_, SH_, SW_, CK_, WIDE_, NT_, true, GD_, TD_, LB_>(a, s, query);
+  // TD = how many tap steps ahead the LDS reads run, LB = workgroups per CU the register budget is cut for (3: 168
+  // registers, 2: 256): per shape, whichever measured faster (tools/micro/dwpw_probe) - a third wave per SIMD where the
+  // kernel fits without spilling, deeper read-ahead where it does not.
   // 4-tile layers: a 4x16 tile with 32-channel chunks and 2 x 2 column tiles per wave beats the thin shape by 15-25 %
   // (half the B-fragment traffic per MFMA); OCR_DWPW_T4=thin keeps the thin shape for A/B runs
   static const char* t4 = getenv("OCR_DWPW_T4");
   if (!(t4 && t4[0] == 't')) {
-    OCR_DWPW_CASE(3, 1, 1, 32, true, 2, 1, tiles == 4)
-    OCR_DWPW_CASE(3, 2, 1, 32, true, 2, 1, tiles == 4)
+    OCR_DWPW_CASE(3, 1, 1, 32, true, 2, 1, 1, 3, tiles == 4)
+    OCR_DWPW_CASE(3, 2, 1, 32, true, 2, 1, 2, 2, tiles == 4)
   }
   // thin layers: tiles <= 4, one wave owns every output column of its 32 pixels
-  OCR_DWPW_CASE(3, 1, 1, 16, false, 1, 2, tiles == 1)
-  OCR_DWPW_CASE(3, 1, 1, 16, false, 2, 2, tiles == 2)
-  OCR_DWPW_CASE(3, 1, 1, 16, false, 3, 2, tiles == 3)
-  OCR_DWPW_CASE(3, 1, 1, 16, false, 4, 1, tiles == 4)
-  OCR_DWPW_CASE(3, 2, 1, 16, false, 4, 1, tiles == 4)
+  OCR_DWPW_CASE(3, 1, 1, 16, false, 1, 2, 2, 2, tiles == 1)
+  OCR_DWPW_CASE(3, 1, 1, 16, false, 2, 2, 1, 3, tiles == 2)
+  OCR_DWPW_CASE(3, 1, 1, 16, false, 3, 2, 2, 2, tiles == 3)
+  OCR_DWPW_CASE(3, 1, 1, 16, false, 4, 1, 2, 2, tiles == 4)
+  OCR_DWPW_CASE(3, 2, 1, 16, false, 4, 1, 2, 2, tiles == 4)
   // wide layers: two column groups per workgroup (and further column blocks in the grid)
-  OCR_DWPW_CASE(3, 1, 2, 16, true, 4, 1, tiles == 8)
-  OCR_DWPW_CASE(5, 1, 1, 16, true, 4, 1, tiles == 8)
-  OCR_DWPW_CASE(5, 1, 1, 32, true, 3, 1, tiles == 6 || tiles == 12)
+  OCR_DWPW_CASE(3, 1, 2, 16, true, 4, 1, 2, 2, tiles == 8)
+  OCR_DWPW_CASE(5, 1, 1, 16, true, 4, 1, 1, 3, tiles == 8)
+  OCR_DWPW_CASE(5, 1, 1, 32, true, 3, 1, 2, 2, tiles == 6 || tiles == 12)
 #undef OCR_DWPW_CASE
   return false;
 }

@@ -29,6 +29,9 @@ static void run(int N, int H, int W, int K, int SH, int SW, int cin, int cout) {
   CK(hipDeviceSynchronize());
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+#ifdef OCR_DWPW_CLOCKS
+  { unsigned long long z[8] = {}; CK(hipMemcpyToSymbol(HIP_SYMBOL(ocr_dwpw_clk), z, sizeof z)); }
+#endif
   CK(hipEventRecord(e0));
   for (int i = 0; i < 5; ++i) launch_dwpw(a, 0);
   CK(hipEventRecord(e1));
@@ -38,6 +41,11 @@ static void run(int N, int H, int W, int K, int SH, int SW, int cin, int cout) {
   ms /= 5;
   const double fl = 2.0 * M * cin * cout + 2.0 * M * K * K * cin, by = 4.0 * (Min * cin + M * cout);
   printf("N=%d %dx%d dw%dx%d s%d%d %d->%d: %.3f ms  %.1f TFLOP/s  %.0f GB/s\n", N, H, W, K, K, SH, SW, cin, cout, ms, fl / ms / 1e9, by / ms / 1e6);
+#ifdef OCR_DWPW_CLOCKS
+  { unsigned long long z[8]; CK(hipMemcpyFromSymbol(z, HIP_SYMBOL(ocr_dwpw_clk), sizeof z));
+    if (z[6]) printf("   clocks per wave-item: steps %.0f  advB %.0f  S %.0f  G %.0f  barrier %.0f  finish %.0f  (wave-items %llu)\n",
+                     (double)z[0] / z[6], (double)z[1] / z[6], (double)z[2] / z[6], (double)z[3] / z[6], (double)z[4] / z[6], (double)z[5] / z[6], z[6]); }
+#endif
   (void)hipFree(x); (void)hipFree(y); (void)hipFree(w); (void)hipFree(dw); (void)hipFree(vec);
 }
 

@@ -361,7 +361,7 @@ class ocr_word(C.Structure):
 EXPORTS += ["ocr_pipe_cfg_default", "ocr_pipe_create", "ocr_pipe_destroy", "ocr_pipe_run", "ocr_pipe_run_device",
             "ocr_pipe_stage", "ocr_pipe_slot_probs", "ocr_pipe_run_staged", "ocr_pipe_stage_jpeg", "ocr_jpeg_decode",
             "ocr_pipe_label", "ocr_pipe_det_shape", "ocr_pipe_timing", "ocr_pipe_timing_filter", "ocr_pipe_timing_report", "ocr_dev_alloc",
-            "ocr_dev_free", "ocr_dev_upload", "ocr_dev_download", "ocr_dev_sync", "ocr_rotate_crop", "ocr_rotate_crop_shape"]
+            "ocr_dev_free", "ocr_dev_upload", "ocr_dev_download", "ocr_dev_sync", "ocr_rotate_crop", "ocr_rotate_crop_shape", "ocr_rotate180_rois"]
 
 
 def _pipe_protos(L):
@@ -390,6 +390,7 @@ def _pipe_protos(L):
     L.ocr_dev_download.argtypes = [vp, vp, C.c_size_t]
     L.ocr_rotate_crop.argtypes = [vp, C.c_int, C.c_int, C.c_size_t, vp, C.c_int, vp, C.c_size_t, vp, ip, ip]
     L.ocr_rotate_crop_shape.argtypes = [C.c_int, C.c_int, vp, ip, ip]
+    L.ocr_rotate180_rois.argtypes = [vp, C.c_int, C.c_int, C.c_size_t, vp, C.c_int]
     L._pipe_protos_done = True
 
 
@@ -404,6 +405,16 @@ def rotate_crop_shape(rows, cols, box):
     r, c = C.c_int(), C.c_int()
     check(L.ocr_rotate_crop_shape(rows, cols, b.ctypes.data, C.byref(r), C.byref(c)))
     return r.value, c.value
+
+
+def rotate180_rois(img, rects):
+    """ocr_rotate180_rois: in-place 180-degree rotation of the (x, y, w, h) rectangles of a BGR u8 image, in list order."""
+    L = lib()
+    _pipe_protos(L)
+    img = np.ascontiguousarray(img, dtype=np.uint8).copy()
+    r = np.ascontiguousarray(rects, dtype=np.int32).reshape(-1, 4)
+    check(L.ocr_rotate180_rois(img.ctypes.data, img.shape[0], img.shape[1], img.strides[0], r.ctypes.data, len(r)))
+    return img
 
 
 def rotate_crops(img, boxes):

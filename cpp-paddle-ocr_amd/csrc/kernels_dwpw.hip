@@ -358,11 +358,17 @@ __global__ void __launch_bounds__(256, LB) dwpw_kernel(const DwPwArgs a) {
     float* obase = c.out + (((long)m_pos.n * c.OH + oy) * c.OW + ox) * c.Cs_out + r0;
     const ocr_f2 S0 = {ps0, ps0}, A0 = {pa0, pa0};
     float mn = INFINITY, mx = 0.0f;
+    // a column tile's four bias vectors as one group of LDS reads (left alone, each read is sunk next to its use:
+    // 4*NT dependent round trips per tile)
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int t = 0; t < NT; ++t) {
+      float4 bias4[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) bias4[g] = *(const float4*)(sp + 32 * t + 8 * g);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const float4 b = *(const float4*)(sp + 32 * t + 8 * g);
+        const float4 b = bias4[g];
         ocr_f2 tl = ocr_f2{acc[t][4 * g], acc[t][4 * g + 1]} + ocr_f2{b.x, b.y};
         ocr_f2 th = ocr_f2{acc[t][4 * g + 2], acc[t][4 * g + 3]} + ocr_f2{b.z, b.w};
         tl = S0 * tl; th = S0 * th;
@@ -370,6 +376,7 @@ __global__ void __launch_bounds__(256, LB) dwpw_kernel(const DwPwArgs a) {
         acc[t][4 * g] = tl.x; acc[t][4 * g + 1] = tl.y; acc[t][4 * g + 2] = th.x; acc[t][4 * g + 3] = th.y;
         if (nt0 * 32 + 32 * t + 8 * g < c.ColsStore) { ocr_absrange(mn, mx, tl.x, tl.y); ocr_absrange(mn, mx, th.x, th.y); }
       }
+    }
     const bool fast = ocr_hsw_fast_ok(mn, mx);
     const ocr_f2 S1 = {ps1, ps1}, A1 = {pa1, pa1};
 #pragma unroll

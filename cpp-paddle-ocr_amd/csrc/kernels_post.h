@@ -31,6 +31,7 @@ struct PostArgs {
   int H, W, max_cand;
   float box_thresh, unclip_ratio, ratio_h, ratio_w;
   int src_h, src_w;
+  int probe_stop;         // development probe (OCR_POST_STOP): border_box_kernel returns after stage n (timing only)
 };
 
 void launch_bitmap(const float* prob, uint8_t* bm, long total, int ithresh, hipStream_t s);

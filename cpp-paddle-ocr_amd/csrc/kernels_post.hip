@@ -242,7 +242,7 @@ __device__ __forceinline__ unsigned nbr_mask(const uint8_t* __restrict__ bm, int
 
 // follows one border; emits CHAIN_APPROX_SIMPLE vertices (if keys != null) and returns their number
 template <class NB>
-__device__ int trace_border_t(NB nb, int H, int W, int ox, int oy, bool is_hole, unsigned long long* keys) {
+__device__ int trace_border_t(NB nb, int H, int W, int ox, int oy, bool is_hole, unsigned long long* keys, int cap = INT_MAX) {
   int count = 0;
   int s_end, s;
   s_end = s = is_hole ? 0 : 4;
@@ -278,7 +278,7 @@ __device__ int trace_border_t(NB nb, int H, int W, int ox, int oy, bool is_hole,
     s = (s + 1 + j) & 7;
     const int nx = cx + kDx[s], ny = cy + kDy[s];
     if (s != prev_s) {
-      if (keys) keys[count] = make_key(cx, cy, (unsigned)count);
+      if (keys && count < cap) keys[count] = make_key(cx, cy, (unsigned)count);
       ++count;
       prev_s = s;
     }
@@ -295,6 +295,10 @@ __device__ int trace_border(const uint8_t* __restrict__ bm, int H, int W, int ox
                             unsigned long long* keys) {
   return trace_border_t([&](int cx, int cy) { return nbr_mask(bm, H, W, cx, cy); }, H, W, ox, oy, is_hole, keys);
 }
+
+// cross-lane traffic through global scratch goes past the (non-coherent) vector L1
+#define GLD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define GST(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 
 // The bitmap of one image as bits in LDS, with a one-pixel zero frame: bit (x+1) of row (y+1).  A step of the
 // border walk then costs a few LDS reads (~100 clocks) instead of a global round trip (~1 us).
@@ -379,18 +383,19 @@ __global__ void __launch_bounds__(64) trace_store_kernel(const uint8_t* __restri
 // Border following with the image's bitmap packed into LDS (one workgroup per image; maps up to ~1.2 Mpixel
 // fit the 160 KB).  One launch does what trace_count / trace_offsets / trace_store do with the global bitmap:
 // count the vertices of every border, lay the borders out in the image's key pool, walk them again to store.
-__global__ void __launch_bounds__(256) trace_lds_kernel(const uint8_t* __restrict__ bm, int H, int W, int max_cand,
+constexpr int kTraceThreads = 1024;  // the bitmap -> LDS fill is latency-bound: 16 waves keep 4x the loads in flight
+__global__ void __launch_bounds__(kTraceThreads) trace_lds_kernel(const uint8_t* __restrict__ bm, int H, int W, int max_cand,
                                                         const int* __restrict__ ncont, const int* __restrict__ starts,
                                                         int* __restrict__ npts, int* __restrict__ poff,
                                                         unsigned long long* __restrict__ pool, int pool_cap,
-                                                        int* __restrict__ status) {
+                                                        int* __restrict__ iscratch, int slice_limit, int* __restrict__ status) {
   extern __shared__ unsigned s_bits[];
   const int n = blockIdx.x, tid = threadIdx.x;
   const long base = (long)n * H * W;
   const int stride = lds_bits_stride(W);
   const int nc = ncont[n];
   if (nc == 0) return;
-  for (int i = tid; i < (H + 2) * stride; i += 256) {
+  for (int i = tid; i < (H + 2) * stride; i += kTraceThreads) {
     const int Y = i / stride, w = i - Y * stride;
     unsigned word = 0;
     if (Y >= 1 && Y <= H) {
@@ -420,35 +425,55 @@ __global__ void __launch_bounds__(256) trace_lds_kernel(const uint8_t* __restric
   }
   __syncthreads();
   const LdsBits nb{s_bits, stride};
-  for (int c = tid; c < nc; c += 256) {
+  // sizes and pool offsets of the image's borders stay in LDS between the passes (behind the bitmap): the serial scan
+  // and the second pass then read LDS instead of global values other lanes have just written
+  int* s_npts = (int*)(s_bits + (H + 2) * stride);
+  int* s_poff = s_npts + max_cand;
+  // ONE walk per border: its vertices go to a provisional slice of the image's hull scratch (idle until the per-border
+  // stage; 2 * pool_cap key slots shared evenly by the image's borders) while they are counted, and are copied into the
+  // pool once the offsets are known.  A border that outgrows its slice is walked a second time, as before.
+  unsigned long long* prov = (unsigned long long*)(iscratch + (long)n * pool_cap * 4);
+  const long slice = 2L * pool_cap / nc;
+  const int cap_each = slice > slice_limit ? slice_limit : (int)slice;
+  for (int c = tid; c < nc; c += kTraceThreads) {
     const long ci = (long)n * max_cand + c;
     int ox, oy;
     bool hole;
     contour_origin(bm, base, starts[ci], W, ox, oy, hole);
-    npts[ci] = trace_border_t(nb, H, W, ox, oy, hole, nullptr);
+    const int sz = trace_border_t(nb, H, W, ox, oy, hole, prov + (long)c * cap_each, cap_each);
+    npts[ci] = sz;
+    s_npts[c] = sz;
   }
   __threadfence_block();
   __syncthreads();
   if (tid == 0) {  // exclusive scan of the pow2-rounded sizes (trace_offsets_kernel)
     int off = 0;
     for (int c = 0; c < nc; ++c) {
-      const int sz = npts[(long)n * max_cand + c];
+      const int sz = s_npts[c];
       const int p2 = sz > 2 ? pow2_ceil(sz) : 0;  // borders with <= 2 vertices are dropped by the reference
-      if (off + p2 > pool_cap) { atomicOr(status, POST_ERR_POOL); poff[(long)n * max_cand + c] = -1; continue; }
-      poff[(long)n * max_cand + c] = off;
+      if (off + p2 > pool_cap) { atomicOr(status, POST_ERR_POOL); s_poff[c] = -1; continue; }
+      s_poff[c] = off;
       off += p2;
     }
   }
-  __threadfence_block();
   __syncthreads();
-  for (int c = tid; c < nc; c += 256) {
+  for (int c = 0; c < nc; ++c) {  // every border: the workgroup copies its keys (padded with +inf to a power of two)
+    const int sz = s_npts[c], po = s_poff[c];
+    if (tid == 0) poff[(long)n * max_cand + c] = po;
+    if (sz <= 2 || po < 0 || sz > cap_each) continue;
+    unsigned long long* keys = pool + (long)n * pool_cap + po;
+    const unsigned long long* src = prov + (long)c * cap_each;
+    const int p2 = pow2_ceil(sz);
+    for (int i = tid; i < p2; i += kTraceThreads) keys[i] = i < sz ? GLD(&src[i]) : ~0ull;
+  }
+  for (int c = tid; c < nc; c += kTraceThreads) {  // the borders that outgrew their slice
+    const int sz = s_npts[c], po = s_poff[c];
+    if (sz <= 2 || po < 0 || sz <= cap_each) continue;
     const long ci = (long)n * max_cand + c;
-    const int sz = npts[ci];
-    if (sz <= 2 || poff[ci] < 0) continue;
     int ox, oy;
     bool hole;
     contour_origin(bm, base, starts[ci], W, ox, oy, hole);
-    unsigned long long* keys = pool + (long)n * pool_cap + poff[ci];
+    unsigned long long* keys = pool + (long)n * pool_cap + po;
     trace_border_t(nb, H, W, ox, oy, hole, keys);
     const int p2 = pow2_ceil(sz);
     for (int i = sz; i < p2; ++i) keys[i] = ~0ull;
@@ -833,11 +858,33 @@ __device__ float box_score_fast_wave(const P2f arr[4], const float* __restrict__
   const bool do_fill = nedges >= 2;
   double sum = 0.0;
   int cnt = 0;
-  const long total = (long)mw * mh;
-  for (long t = lane; t < total; t += 64) {
-    const int y = (int)(t / mw), x = (int)(t - (long)y * mw);
-    bool in = false;
-    if (do_fill && y >= ey_min && y < ey_max) {  // interior first: it covers most of the bbox and needs no outline test
+  // Row by row: the scan-fill spans of a row are worked out once per row, not once per pixel (the per-pixel form spent
+  // 640 of the border stage's 950 us here: a 64-bit division for the pixel position, four 64-bit edge evaluations and a
+  // sort for every pixel).  A lane group of W2 lanes owns a row; narrow boxes put 64 / W2 rows side by side.
+  const int W2 = mw >= 64 ? 64 : pow2_ceil(mw), rows_per_iter = 64 / W2;
+  const int lrow = lane / W2, lx = lane - lrow * W2;
+  // An item = U pixels of one row per lane (x = xb + u * W2).  The U probability loads of item i+1 are issued before
+  // item i's mask tests and are consumed through a select: a load under the `in` branch is one exposed memory round
+  // trip per pixel (330 us of latency for a few thousand pixels per lane).
+  constexpr int U = 8;
+  const int nxb = (mw + U * W2 - 1) / (U * W2), nyb = (mh + rows_per_iter - 1) / rows_per_iter, nitems = nxb * nyb;
+  auto fetch = [&](int item, float (&v)[U]) {
+    const int yb = item / nxb, xb = (item - yb * nxb) * U * W2 + lx;
+    int y = yb * rows_per_iter + lrow;
+    y = y < mh ? y : mh - 1;  // lanes past the last row read a valid one and mask it off below
+    const float* prow = pred + (long)(y + ymin) * W + xmin;
+#pragma unroll
+    for (int u = 0; u < U; ++u) { const int x = xb + u * W2; v[u] = prow[x < mw ? x : mw - 1]; }
+  };
+  float va[U], vb[U];
+  if (nitems > 0) fetch(0, va);
+  for (int item = 0; item < nitems; ++item) {
+    if (item + 1 < nitems) fetch(item + 1, vb);
+    const int yb = item / nxb, xb = (item - yb * nxb) * U * W2 + lx;
+    const int y = yb * rows_per_iter + lrow;
+    const bool yok = y < mh;
+    int s1[2] = {1, 1}, s2[2] = {0, 0};  // filled spans [s1, s2] of this row (empty by default)
+    if (do_fill && yok && y >= ey_min && y < ey_max) {
       // active edges on this scanline, their x in 16.16, sorted ascending, filled pairwise
       long long xs[4];
       int na = 0;
@@ -851,15 +898,22 @@ __device__ float box_score_fast_wave(const P2f arr[4], const float* __restrict__
         xs[j + 1] = v;
       }
       for (int i = 0; i + 1 < na; i += 2) {
-        const int x1 = (int)((xs[i] + 65535) >> 16), x2 = (int)(xs[i + 1] >> 16);
-        if (x >= x1 && x <= x2) in = true;
+        s1[i >> 1] = (int)((xs[i] + 65535) >> 16);
+        s2[i >> 1] = (int)(xs[i + 1] >> 16);
       }
     }
-    if (!in) in = on_line(Ls[0], x, y) || on_line(Ls[1], x, y) || on_line(Ls[2], x, y) || on_line(Ls[3], x, y);
-    if (in) {
-      sum += (double)pred[(long)(y + ymin) * W + x + xmin];
-      ++cnt;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int x = xb + u * W2;
+      const bool ok = yok && x < mw;
+      bool in = (x >= s1[0] && x <= s2[0]) || (x >= s1[1] && x <= s2[1]);  // interior first: most of the bbox, no outline test
+      if (!in && ok) in = on_line(Ls[0], x, y) || on_line(Ls[1], x, y) || on_line(Ls[2], x, y) || on_line(Ls[3], x, y);
+      in = in && ok;
+      sum += in ? (double)va[u] : 0.0;  // + 0.0 leaves the sum as it is
+      cnt += in;
     }
+#pragma unroll
+    for (int u = 0; u < U; ++u) va[u] = vb[u];
   }
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) {
@@ -878,9 +932,6 @@ __device__ float box_score_fast_wave(const P2f arr[4], const float* __restrict__
 //   mean    : lanes stride over the mask words.
 // pts: the border's vertices in contour order as (x, y) keys.  scratch: this border's slice of the
 // per-image word pool.  Returns the score in every lane, or -1 when the pool is exhausted.
-// cross-lane traffic through global scratch goes past the (non-coherent) vector L1
-#define GLD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-#define GST(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 __device__ float polygon_score_wave(const unsigned long long* __restrict__ pts, int npts, 
                                     const float* __restrict__ pred, int H, int W, unsigned* pool, unsigned pool_words,
                                     unsigned* pool_top, int lane, int* s_tmp /* >= 4 ints of LDS */) {
@@ -1178,8 +1229,11 @@ __global__ void __launch_bounds__(64) border_box_kernel(const PostArgs a) {
   __shared__ P2f s_hull[HULL_CAP];
   // one region, two lives: the calipers' scratch (edge vectors, inverse lengths) while a hull is measured,
   // the unclip polygon and its sort keys in between (each is dead when the other is written)
+  // (third life: the contour hull's Sklansky stack and index buffer, 4 ints per sorted key, when the sort ran in LDS -
+  // in global memory every stack pop of the single-lane scan is a dependent L2 round trip)
   constexpr int kCal = HULL_CAP * (int)(sizeof(P2f) + sizeof(float)), kUn = UNCLIP_CAP * (int)(sizeof(IPt) + sizeof(unsigned long long));
-  __shared__ __attribute__((aligned(16))) unsigned char s_region[kCal > kUn ? kCal : kUn];
+  constexpr int kStk = RETRY ? 0 : SORT_LDS_CAP * 4 * (int)sizeof(int), kCU = kCal > kUn ? kCal : kUn;  // (the retry pass: rare, large contours)
+  __shared__ __attribute__((aligned(16))) unsigned char s_region[kCU > kStk ? kCU : kStk];
   P2f* s_vect = (P2f*)s_region;
   float* s_inv = (float*)(s_region + HULL_CAP * sizeof(P2f));
   IPt* s_unclip = (IPt*)s_region;
@@ -1207,14 +1261,17 @@ __global__ void __launch_bounds__(64) border_box_kernel(const PostArgs a) {
   }
   __syncthreads();
   bitonic_sort_wave(keys, n2, lane, in_lds);
+  if (a.probe_stop == 1) return;
   // ---- minAreaRect(contour) -> GetMiniBoxes (lane 0)
   if (lane == 0) {
     s_flag = 0;
-    int* stack = a.iscratch + ((long)n * a.pool_cap + a.poff[ci]) * 4;  // 4 ints per pooled key: stack[n2+2 <= 2*n2], hullbuf[2*n2]
+    // 4 ints per key: stack[n2+2 <= 2*n2], hullbuf[2*n2]
+    int* stack = in_lds && !RETRY ? (int*)s_region : a.iscratch + ((long)n * a.pool_cap + a.poff[ci]) * 4;
     int* hullbuf = stack + 2 * n2;
     KeyAcc P{keys};
     const int hn = convex_hull_sorted<KeyAcc, int>(P, total, stack, hullbuf, s_hull, HULL_CAP);
     if (hn < 0) { atomicOr(a.status, POST_ERR_HULL); s_flag = 0; }
+    else if (a.probe_stop == 2) { s_flag = 0; }
     else {
       const RRect box = min_area_rect_hull(s_hull, hn, s_vect, s_inv);
       float ssid;
@@ -1227,7 +1284,7 @@ __global__ void __launch_bounds__(64) border_box_kernel(const PostArgs a) {
     }
   }
   __syncthreads();
-  if (!s_flag) return;
+  if (!s_flag || a.probe_stop == 3) return;
   P2f arr[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) { arr[i].x = s_box[2 * i]; arr[i].y = s_box[2 * i + 1]; }
@@ -1253,6 +1310,7 @@ __global__ void __launch_bounds__(64) border_box_kernel(const PostArgs a) {
   }
   if (score < a.box_thresh) return;
   if (lane != 0) return;
+  if (a.probe_stop == 4) return;
   // ---- UnClip
   float area = 0.0f, dist = 0.0f;
   for (int i = 0; i < 4; ++i) {
@@ -1266,6 +1324,7 @@ __global__ void __launch_bounds__(64) border_box_kernel(const PostArgs a) {
   for (int i = 0; i < 4; ++i) q[i] = {(long long)(int)arr[i].x, (long long)(int)arr[i].y};
   const int un = clipper_offset_round(q, (double)distance, s_unclip, UNCLIP_CAP);
   if (un < 0) { atomicOr(a.status, POST_ERR_UNCLIP); return; }
+  if (a.probe_stop == 5) return;
   RRect pts;
   if (un == 0) {
     pts = RRect{0, 0, 1, 1, 0};
@@ -1350,15 +1409,18 @@ void launch_post(const PostArgs& a, int N, int* out_boxes, int cap, int* out_n, 
   launch_ccl(a.bitmap, a.labels, a.touch, N, a.H, a.W, s);
   launch_starts(a.bitmap, a.labels, a.touch, N, a.H, a.W, a.max_cand, a.ncont_all, a.ncont, a.starts, a.chunk_cnt, s);
   const dim3 gl((a.max_cand + 63) / 64, N);
-  const size_t lds = (size_t)(a.H + 2) * lds_bits_stride(a.W) * sizeof(unsigned);
+  const size_t lds = ((size_t)(a.H + 2) * lds_bits_stride(a.W) + 2 * (size_t)a.max_cand) * sizeof(unsigned);  // bitmap bits + sizes + offsets
   bool in_lds = lds <= 150 * 1024;  // 960x960: 119 KB
   if (in_lds && lds > 64 * 1024) {  // more than the default dynamic LDS limit: raise it, per device
     static unsigned char attr_state[64] = {};
     in_lds = raise_dynamic_lds((const void*)trace_lds_kernel, 150 * 1024, attr_state);  // refused: the global-bitmap kernels below
   }
   if (in_lds) {
-    hipLaunchKernelGGL(trace_lds_kernel, dim3(N), dim3(256), lds, s, a.bitmap, a.H, a.W, a.max_cand, a.ncont, a.starts, a.npts, a.poff,
-                       a.pool, a.pool_cap, a.status);
+    // OCR_TRACE_SLICE (tests): cap on a border's provisional slice, to drive the second-walk path with small inputs
+    const char* sl = getenv("OCR_TRACE_SLICE");
+    const int slice_limit = sl && atoi(sl) > 0 ? atoi(sl) : INT_MAX;
+    hipLaunchKernelGGL(trace_lds_kernel, dim3(N), dim3(kTraceThreads), lds, s, a.bitmap, a.H, a.W, a.max_cand, a.ncont, a.starts, a.npts, a.poff,
+                       a.pool, a.pool_cap, a.iscratch, slice_limit, a.status);
   } else {
     hipLaunchKernelGGL(trace_count_kernel, gl, dim3(64), 0, s, a.bitmap, a.H, a.W, a.max_cand, a.ncont, a.starts, a.npts);
     hipLaunchKernelGGL(trace_offsets_kernel, dim3(N), dim3(64), 0, s, a.max_cand, a.ncont, a.npts, a.poff, a.pool_cap, a.status);

@@ -32,8 +32,8 @@ struct RotDesc {
   size_t stride;
   int x, y, w, h;
 };
-// seg: nimages+1 offsets into d; rotations of one image are applied in order by one workgroup
-void launch_rotate180_list(const RotDesc* d, const int* seg, int nimages, hipStream_t s);
+// d: the ROIs of ONE level (pairwise disjoint, see kernels_pre.hip), rotated concurrently
+void launch_rotate180_level(const RotDesc* d, int nrois, hipStream_t s);
 // One perspective crop (Utility::GetRotateCropImage): destination pixel -> source position through
 // the inverse homography, bilinear taps in 15-bit fixed point, constant-0 border, optional 90-degree turn.
 struct WarpDesc {

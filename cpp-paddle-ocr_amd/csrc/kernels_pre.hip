@@ -151,27 +151,29 @@ void launch_rotate180(uint8_t* img, size_t stride, int x0, int y0, int w, int h,
   hipLaunchKernelGGL(rotate180_kernel, dim3((unsigned)((half + 255) / 256)), dim3(256), 0, s, img, stride, x0, y0, w, h);
 }
 
-// The same for a whole batch: one workgroup per image applies that image's rotations in request order
-// (ROIs of one image may overlap, so their order matters; different images are independent).
-__global__ void __launch_bounds__(1024) rotate180_list_kernel(const RotDesc* __restrict__ d, const int* __restrict__ seg) {
-  const int b = blockIdx.x;
-  for (int r = seg[b]; r < seg[b + 1]; ++r) {
-    const RotDesc q = d[r];
-    const long total = (long)q.w * q.h;
-    for (long i = threadIdx.x; i < total / 2; i += 1024) {
-      const long j = total - 1 - i;
-      uint8_t* pa = q.img + (size_t)(q.y + i / q.w) * q.stride + (size_t)(q.x + i % q.w) * 3;
-      uint8_t* pb = q.img + (size_t)(q.y + j / q.w) * q.stride + (size_t)(q.x + j % q.w) * 3;
+// The same for a whole batch.  ROIs of one image may overlap, so their order matters - but only between ROIs that do
+// overlap: the host sorts the batch into levels (level of a ROI = 1 + the highest level among the EARLIER ROIs of its
+// image that intersect it; pipe.hip), ROIs of one level are pairwise disjoint, and a launch per level, in ascending
+// order, keeps every overlapping pair in request order.  Block (r, c): ROI r of the level, row chunk c; pixel (y, x)
+// swaps with (h-1-y, w-1-x) for the first total/2 pixels in raster order (cv::rotate's flip, no divisions).
+__global__ void __launch_bounds__(256) rotate180_level_kernel(const RotDesc* __restrict__ d) {
+  const RotDesc q = d[blockIdx.x];
+  const int half_rows = q.h >> 1;
+  for (int y = blockIdx.y; y < half_rows + (q.h & 1); y += gridDim.y) {
+    const int xe = y < half_rows ? q.w : q.w >> 1;  // the middle row of an odd height: its first half
+    uint8_t* ra = q.img + (size_t)(q.y + y) * q.stride + (size_t)q.x * 3;
+    uint8_t* rb = q.img + (size_t)(q.y + q.h - 1 - y) * q.stride + (size_t)q.x * 3;
+    for (int x = threadIdx.x; x < xe; x += 256) {
+      uint8_t* pa = ra + (size_t)x * 3;
+      uint8_t* pb = rb + (size_t)(q.w - 1 - x) * 3;
 #pragma unroll
       for (int c = 0; c < 3; ++c) { const uint8_t t = pa[c]; pa[c] = pb[c]; pb[c] = t; }
     }
-    __threadfence_block();
-    __syncthreads();
   }
 }
-void launch_rotate180_list(const RotDesc* d, const int* seg, int nimages, hipStream_t s) {
-  if (nimages <= 0) return;
-  hipLaunchKernelGGL(rotate180_list_kernel, dim3(nimages), dim3(1024), 0, s, d, seg);
+void launch_rotate180_level(const RotDesc* d, int nrois, hipStream_t s) {
+  if (nrois <= 0) return;
+  hipLaunchKernelGGL(rotate180_level_kernel, dim3(nrois, 8), dim3(256), 0, s, d);
 }
 
 // cv::warpPerspective(crop, M, INTER_LINEAR, BORDER_CONSTANT 0) restated per pixel

@@ -45,6 +45,47 @@ struct StageSlot {
   }
 };
 
+// In-place 180-degree rotations of ROIs in request order (the cls stage: cv::rotate on views that alias their image,
+// /root/reference/src/ocr_worker.cpp:255-262).  Only ROIs that intersect constrain each other: level = 1 + the highest
+// level among the EARLIER intersecting ROIs in the same buffer (img pointer + stride identify the image), one launch per
+// level over its pairwise disjoint ROIs, levels in ascending order.
+static int rotate180_in_order(const std::vector<RotDesc>& rd, DevBuf<RotDesc>& scratch, hipStream_t stream, std::string& err) {
+  if (rd.empty()) return OCR_OK;
+  std::vector<int> level(rd.size(), 0);
+  int nlevels = 1;
+  for (size_t k = 0; k < rd.size(); ++k) {
+    const RotDesc& q = rd[k];
+    const uint8_t* q0 = q.img + (size_t)q.y * q.stride;  // rows [q0, q1) of the underlying allocation
+    const uint8_t* q1 = q.img + (size_t)(q.y + q.h) * q.stride;
+    for (size_t j = 0; j < k; ++j) {
+      const RotDesc& e = rd[j];
+      bool hit;
+      if (e.img == q.img && e.stride == q.stride)
+        hit = e.x < q.x + q.w && q.x < e.x + e.w && e.y < q.y + q.h && q.y < e.y + e.h;
+      else  // different views: conservative byte-range test (crop buffers of the rotate-crop path never overlap)
+        hit = e.img + (size_t)e.y * e.stride < q1 && q0 < e.img + (size_t)(e.y + e.h) * e.stride;
+      if (hit) level[k] = std::max(level[k], level[j] + 1);
+    }
+    nlevels = std::max(nlevels, level[k] + 1);
+  }
+  std::vector<RotDesc> sorted;
+  std::vector<int> lstart(1, 0);
+  sorted.reserve(rd.size());
+  for (int lv = 0; lv < nlevels; ++lv) {
+    for (size_t j = 0; j < rd.size(); ++j)
+      if (level[j] == lv) sorted.push_back(rd[j]);
+    lstart.push_back((int)sorted.size());
+  }
+  if (!scratch.ensure(sorted.size(), err)) return OCR_ERR_DEVICE;
+  if (hipMemcpyAsync(scratch.p, sorted.data(), sorted.size() * sizeof(RotDesc), hipMemcpyHostToDevice, stream) != hipSuccess) {
+    err = "rotation list upload failed";
+    return OCR_ERR_DEVICE;
+  }
+  for (int lv = 0; lv < nlevels; ++lv) launch_rotate180_level(scratch.p + lstart[lv], lstart[lv + 1] - lstart[lv], stream);
+  if (hipGetLastError() != hipSuccess) { err = "rotation launch failed"; return OCR_ERR_DEVICE; }
+  return OCR_OK;
+}
+
 struct ocr_pipe {
   DetStage det;
   // Further detector instances (own stream, network, buffers) for batches of MIXED sizes: every distinct size is its own
@@ -61,7 +102,6 @@ struct ocr_pipe {
   JpegScratch jpeg;
   DevBuf<uint8_t> work;  // the requests' clones (OCRRequest copies the Mat, ocr_worker.h:28-29): cls rotates in place on them
   DevBuf<RotDesc> rot_desc;
-  DevBuf<int> rot_seg;
   int crop_mode = 0;  // OCR_CROP_BOUNDING_RECT | OCR_CROP_ROTATE
   DevBuf<uint8_t> crop_arena;
   DevBuf<WarpDesc> warp_desc;
@@ -260,25 +300,12 @@ struct ocr_pipe {
       std::vector<float> scores(lines.size());
       int rc = cls->run_lines(lines, labels.data(), scores.data(), err);
       if (rc) return rc;
-      // rotate in request order, in place on the device copy (cv::rotate on ROI views aliasing the image):
-      // one workgroup per image walks that image's rotations sequentially
+      // rotate in request order, in place on the device copy (cv::rotate on ROI views aliasing the image)
       std::vector<RotDesc> rd;
-      std::vector<int> rseg(1, 0);
-      for (int i = 0; i < count; ++i) {
-        for (int k = seg[i]; k < seg[i + 1]; ++k)
-          if (labels[k] == 1)
-            rd.push_back(RotDesc{const_cast<uint8_t*>(lines[k].img), lines[k].stride, lines[k].x, lines[k].y, lines[k].w, lines[k].h});
-        rseg.push_back((int)rd.size());
-      }
-      if (!rd.empty()) {
-        if (!rot_desc.ensure(rd.size(), err) || !rot_seg.ensure(rseg.size(), err)) return OCR_ERR_DEVICE;
-        if (hipMemcpyAsync(rot_desc.p, rd.data(), rd.size() * sizeof(RotDesc), hipMemcpyHostToDevice, cls->stream()) != hipSuccess ||
-            hipMemcpyAsync(rot_seg.p, rseg.data(), rseg.size() * sizeof(int), hipMemcpyHostToDevice, cls->stream()) != hipSuccess) {
-          err = "rotation list upload failed";
-          return OCR_ERR_DEVICE;
-        }
-        launch_rotate180_list(rot_desc.p, rot_seg.p, count, cls->stream());
-      }
+      for (size_t k = 0; k < lines.size(); ++k)
+        if (labels[k] == 1) rd.push_back(RotDesc{const_cast<uint8_t*>(lines[k].img), lines[k].stride, lines[k].x, lines[k].y, lines[k].w, lines[k].h});
+      int rrc = rotate180_in_order(rd, rot_desc, cls->stream(), err);
+      if (rrc) return rrc;
       if (hipStreamSynchronize(cls->stream()) != hipSuccess) { err = "cls stream sync failed"; return OCR_ERR_DEVICE; }
     }
     double t2 = now_ms();
@@ -605,6 +632,26 @@ int ocr_rotate_crop(const uint8_t* bgr, int rows, int cols, size_t row_stride, c
   launch_warp_crops(ddesc.p, n, max_px, 0);
   CAPI_HIP(hipGetLastError());
   CAPI_HIP(hipMemcpy(out, dout.p, total, hipMemcpyDeviceToHost));
+  return OCR_OK;
+}
+
+int ocr_rotate180_rois(uint8_t* bgr, int rows, int cols, size_t row_stride, const int32_t* rects, int n) {
+  if (!bgr || rows <= 0 || cols <= 0 || !rects || n < 1) return fail(OCR_ERR_ARG, "bad argument");
+  const size_t row = (size_t)cols * 3, stride = row_stride ? row_stride : row;
+  std::string err;
+  DevBuf<uint8_t> dimg;
+  DevBuf<RotDesc> ddesc;
+  if (!dimg.ensure(row * rows, err)) return fail(OCR_ERR_DEVICE, err);
+  std::vector<RotDesc> rd(n);
+  for (int k = 0; k < n; ++k) {
+    const int32_t* r = rects + 4 * k;
+    if (r[0] < 0 || r[1] < 0 || r[2] < 1 || r[3] < 1 || r[0] + r[2] > cols || r[1] + r[3] > rows) return fail(OCR_ERR_ARG, "rectangle outside the image");
+    rd[k] = RotDesc{dimg.p, row, r[0], r[1], r[2], r[3]};
+  }
+  CAPI_HIP(hipMemcpy2D(dimg.p, row, bgr, stride, row, rows, hipMemcpyHostToDevice));
+  const int rc = rotate180_in_order(rd, ddesc, 0, err);
+  if (rc) return fail(rc, err);
+  CAPI_HIP(hipMemcpy2D(bgr, stride, dimg.p, row, row, rows, hipMemcpyDeviceToHost));
   return OCR_OK;
 }
 

@@ -227,6 +227,21 @@ def test_det_post_slow_score_mode(pkg, built, dilate):
     fast.close()
 
 
+def test_det_post_border_walk_with_tiny_provisional_slices(pkg, built, monkeypatch):
+    """The border walk stores vertices into a provisional slice while it counts them and walks a border again when
+    the slice was too small (trace_lds_kernel): with 4-vertex slices every real border takes that path."""
+    import oracle as O
+    from synth_data import cfg2_sample
+    _, prob, _ = cfg2_sample(4)
+    det = pkg.Det(limit_side_len=960, thresh=0.3, box_thresh=0.5, unclip_ratio=2.0)
+    want = O.det_post(prob, 0.3, 0.5, 2.0, 960, 960)
+    for limit in ("4", "64", ""):
+        monkeypatch.setenv("OCR_TRACE_SLICE", limit)
+        got = det.post(prob, 960, 960)
+        assert len(want) == len(got) == 32 and all(np.array_equal(a, b) for a, b in zip(want, got))
+    det.close()
+
+
 def test_det_post_large_working_set_fallback(pkg, built):
     """A border whose unclip polygon outgrows the small per-border LDS working set (256 points) is redone
     with the large one: same boxes as the oracle, no error."""
@@ -396,6 +411,40 @@ def test_rotate_crop_matches_oracle(pkg, built, card):
         pkg.rotate_crops(card, [np.array([[5, 5], [5, 5], [5, 5], [5, 5]], np.int32)])
     with pytest.raises(pkg.OcrError, match="no crop inside"):
         pkg.rotate_crops(card, [np.array([[-3, 5], [50, 5], [50, 30], [-3, 30]], np.int32)])
+
+
+def test_rotations_of_overlapping_rois_keep_request_order(pkg, built):
+    """The classifier's in-place cv::rotate on ROI views of one image (ocr_worker.cpp:255-262): overlapping crops see
+    each other's result, so the device's level schedule (disjoint ROIs concurrently, intersecting ones in list order)
+    must equal rotating one after the other."""
+    import oracle as O
+    rs = np.random.RandomState(77)
+    img = rs.randint(0, 256, (240, 330, 3)).astype(np.uint8)
+    cases = []
+    # chains of overlapping rectangles, nested ones, odd/even sizes, single rows/columns, repeats of the same rectangle
+    cases.append([(10, 10, 100, 40), (60, 30, 120, 41), (150, 50, 51, 33), (10, 10, 100, 40), (0, 0, 330, 240)])
+    cases.append([(5, 5, 1, 1), (5, 5, 2, 1), (5, 5, 1, 2), (7, 3, 9, 1), (3, 7, 1, 9), (0, 0, 3, 3)])
+    cases.append([(x, y, 37, 21) for y in range(0, 200, 13) for x in range(0, 280, 29)])          # dense overlaps: many levels
+    cases.append([(x, y, 20, 10) for y in range(0, 230, 10) for x in range(0, 320, 20)])          # a disjoint tiling: one level
+    rnd = []
+    for _ in range(200):
+        w, h = rs.randint(1, 120), rs.randint(1, 60)
+        rnd.append((rs.randint(0, 330 - w + 1), rs.randint(0, 240 - h + 1), w, h))
+    cases.append(rnd)
+    for rects in cases:
+        want = img.copy()
+        for (x, y, w, h) in rects:
+            O.rotate180_inplace(want[y:y + h, x:x + w])
+        got = pkg.rotate180_rois(img, rects)
+        assert np.array_equal(got, want)
+    # strided host image
+    view = img[:, 10:300]
+    want = np.ascontiguousarray(view).copy()
+    for (x, y, w, h) in cases[0][:3]:
+        O.rotate180_inplace(want[y:y + h, x:x + w])
+    assert np.array_equal(pkg.rotate180_rois(view, cases[0][:3]), want)
+    with pytest.raises(pkg.OcrError, match="outside the image"):
+        pkg.rotate180_rois(img, [(300, 10, 40, 10)])
 
 
 @pytest.mark.parametrize("cls_on", [False, True])

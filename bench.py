@@ -212,6 +212,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-request latency calls (profiling runs)")
     ap.add_argument("--no-host-input", action="store_true", help="skip the host-input (PCIe-inclusive) leg")
+    ap.add_argument("--no-two-workers", action="store_true", help="skip the two-workers-per-GPU leg")
     ap.add_argument("--verify-images", type=int, default=4,
                     help="images of the neighbour rank's shard each rank re-computes to check the gathered records")
     ap.add_argument("--stub-pipeline", action="store_true",
@@ -411,6 +412,37 @@ def main(argv=None):
         if cfg == "cfg3":
             pipe.stage(0, img_list, prob_list)   # slot 0 as the resident batch again (the gather step below re-runs it)
 
+    # ---- two pipeline workers sharing the GPU (the reference's pool maps worker i -> GPU i mod n, gpu_worker_pool.cpp:
+    # 46-59, so a device may serve several workers): each worker has its own ocr_pipe, streams and arenas and runs the
+    # same resident batch `steps` times; while one worker is in its latency-bound phases (det post-processing, cls,
+    # the tail of rec) the other one's dense kernels fill the GPU.  An extra key, never `value`: the per-kernel
+    # roofline figures above are measured with one worker owning the device.
+    two_workers = None
+    if not stub and cfg == "cfg2" and world == 1 and not args.no_two_workers:
+        import threading
+        pipe2 = pkg.Pipe(device=local, enable_cls=True, limit_side_len=960, rec_batch_num=16, rec_img_h=48, rec_img_w=320)
+        pipe.stage(0, img_list, prob_list)
+        pipe2.stage(0, img_list, prob_list)
+        for p_ in (pipe, pipe2):
+            p_.run_staged(0, collect=False)
+        wsteps = max(2, args.steps)
+        def work(p_):
+            for _ in range(wsteps):
+                p_.run_staged(0, collect=False)
+        ths = [threading.Thread(target=work, args=(p_,)) for p_ in (pipe, pipe2)]
+        sync()
+        t0w = time.perf_counter()
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+        sync()
+        elw = time.perf_counter() - t0w
+        pipe2.close()
+        two_workers = {"value": batch * 2 * wsteps / elw, "unit": "images/sec", "ms_per_step": elw * 1e3 / (2 * wsteps), "steps": 2 * wsteps,
+                       "what": "two pipeline workers (two ocr_pipe handles, own streams and arenas) on this one GPU, each running the "
+                               "resident batch %d times concurrently" % wsteps}
+
     # ---- result gather (after the timed region): every rank's words of one step as fixed-size records
     gather = None
     gcap = max(GATHER_CAP, batch * 80)
@@ -506,6 +538,8 @@ def main(argv=None):
         }
         if host_in:
             out["host_input"] = host_in
+        if two_workers:
+            out["two_workers_per_gpu"] = two_workers
         if gather:
             out["gather"] = gather
         if single_ms:

@@ -16,7 +16,8 @@ const char* embedded_plan(const char* kind);  // "det" | "cls" | "rec" -> plan t
 // Resolves the weights file of a model directory the way the reference resolves its model file
 // (ocr_det.cpp:28-40 probes four names): inference.pdiparams, model.pdiparams, then the build's
 // synthetic.pdiparams.  Loads names from the .pdmodel next to it.
-bool load_model_dir(const std::string& model_dir, const char* weights_override, WeightMap& w, std::string& err);
+// kind ("det" | "cls" | "rec"): the graph in model_dir must carry the signature stored in that plan
+bool load_model_dir(const std::string& model_dir, const char* weights_override, const char* kind, WeightMap& w, std::string& err);
 
 int fail(int code, const std::string& msg);
 

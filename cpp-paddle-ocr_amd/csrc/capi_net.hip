@@ -29,11 +29,30 @@ const char* embedded_plan(const char* kind) {
   return nullptr;
 }
 
-bool load_model_dir(const std::string& model_dir, const char* weights_override, WeightMap& w, std::string& err) {
+bool load_model_dir(const std::string& model_dir, const char* weights_override, const char* kind, WeightMap& w, std::string& err) {
   std::string model;
   for (const char* n : {"/inference.pdmodel", "/model.pdmodel"})
     if (file_exists(model_dir + n)) { model = model_dir + n; break; }
   if (model.empty()) { err = "No valid model file found in " + model_dir; return false; }
+  // the graph must be the one the compiled-in plan was generated from (`plan <kind> ... graph_ops= graph_fnv=`)
+  if (const char* plan = embedded_plan(kind)) {
+    const char* po = strstr(plan, "graph_ops=");
+    const char* pf = strstr(plan, "graph_fnv=");
+    if (po && pf) {
+      int nops = 0;
+      unsigned long long fnv = 0;
+      if (!pdmodel_graph_signature(model, nops, fnv, err)) return false;
+      const int want_ops = atoi(po + 10);
+      const unsigned long long want_fnv = strtoull(pf + 10, nullptr, 16);
+      if (nops != want_ops || fnv != want_fnv) {
+        char msg[320];
+        snprintf(msg, sizeof msg, "%s is not the %s graph this library was built for (%d ops, signature %016llx; the plan expects %d, %016llx): "
+                 "regenerate the plans with tools/make_plan.py and rebuild", model.c_str(), kind, nops, fnv, want_ops, want_fnv);
+        err = msg;
+        return false;
+      }
+    }
+  }
   std::string params;
   if (weights_override) params = weights_override;
   else
@@ -88,7 +107,7 @@ int ocr_net_create(const char* kind, const char* model_dir, const char* weights,
   if (rc) return rc;
   WeightMap w;
   std::string err;
-  if (!load_model_dir(model_dir, weights, w, err)) return fail(OCR_ERR_MODEL, err);
+  if (!load_model_dir(model_dir, weights, kind, w, err)) return fail(OCR_ERR_MODEL, err);
   std::unique_ptr<ocr_net> h(new ocr_net());
   h->device = device_id;
   if (!h->net.load(plan, w, err)) return fail(OCR_ERR_MODEL, err);

@@ -109,6 +109,46 @@ bool pdmodel_persistable_names(const std::string& path, std::vector<std::string>
   return true;
 }
 
+bool pdmodel_graph_signature(const std::string& path, int& nops, unsigned long long& fnv, std::string& err) {
+  std::vector<uint8_t> buf;
+  if (!read_file(path, buf)) {
+    err = "cannot read " + path;
+    return false;
+  }
+  nops = 0;
+  fnv = 1469598103934665603ull;
+  auto mix = [&](const uint8_t* p, size_t n) {
+    for (size_t i = 0; i < n; ++i) { fnv ^= p[i]; fnv *= 1099511628211ull; }
+  };
+  Span prog{buf.data(), buf.size()};
+  int f, w;
+  uint64_t v;
+  Span sub{};
+  bool first_block = true;
+  while (prog.n) {
+    if (!next_field(prog, f, w, v, sub)) { err = "malformed ProgramDesc"; return false; }
+    if (f != 1 || w != 2 || !first_block) continue;  // blocks = 1
+    first_block = false;
+    Span blk = sub;
+    while (blk.n) {
+      Span op{};
+      if (!next_field(blk, f, w, v, op)) { err = "malformed BlockDesc"; return false; }
+      if (f != 4 || w != 2) continue;  // ops = 4
+      while (op.n) {
+        Span x{};
+        if (!next_field(op, f, w, v, x)) { err = "malformed OpDesc"; return false; }
+        if (f == 3 && w == 2) {  // type = 3
+          if (nops) { const uint8_t sep = ';'; mix(&sep, 1); }
+          mix(x.p, x.n);
+          ++nops;
+        }
+      }
+    }
+  }
+  if (!nops) { err = "no ops in " + path; return false; }
+  return true;
+}
+
 bool pdiparams_read(const std::string& path, const std::vector<std::string>& names, WeightMap& out, std::string& err) {
   std::vector<uint8_t> buf;
   if (!read_file(path, buf)) {

@@ -21,6 +21,11 @@ using WeightMap = std::map<std::string, HostTensor>;
 // which save_inference_model concatenates them.  Returns false + err on malformed input.
 bool pdmodel_persistable_names(const std::string& path, std::vector<std::string>& names, std::string& err);
 
+// Signature of the graph: number of ops of block 0 and FNV-1a 64 over their type names joined by ';' (feed / fetch
+// included).  tools/make_plan.py stores the same two numbers in the plan it generates; a model directory whose graph
+// differs from the compiled-in plan is refused at load (its weights would be bound to the wrong layers).
+bool pdmodel_graph_signature(const std::string& path, int& nops, unsigned long long& fnv, std::string& err);
+
 // Reads every record of a .pdiparams file, pairing them with `names` in order.
 bool pdiparams_read(const std::string& path, const std::vector<std::string>& names, WeightMap& out, std::string& err);
 

@@ -108,7 +108,7 @@ bool DetStage::create(const DetConfig& cfg, std::string& err, int& code) {
   if (code) { err = ocr_last_error(); return false; }
   WeightMap w;
   code = OCR_ERR_MODEL;
-  if (!load_model_dir(cfg.model_dir, nullptr, w, err)) return false;
+  if (!load_model_dir(cfg.model_dir, nullptr, "det", w, err)) return false;
   if (!net_.load(embedded_plan("det"), w, err)) return false;
   code = OCR_ERR_DEVICE;
   if (hipStreamCreate(&stream_) != hipSuccess) { err = "hipStreamCreate failed"; return false; }
@@ -276,7 +276,7 @@ bool RecStage::create(const RecConfig& cfg, std::string& err, int& code) {
   for (std::string line; std::getline(in, line);) labels_.push_back(line);
   labels_.push_back(" ");
   WeightMap w;
-  if (!load_model_dir(cfg.model_dir, nullptr, w, err)) return false;
+  if (!load_model_dir(cfg.model_dir, nullptr, "rec", w, err)) return false;
   if (const char* e = getenv("OCR_REC_SPLIT")) split_ = atoi(e) >= 2 ? 2 : 1;
   if (const char* e = getenv("OCR_REC_LANES")) serial_ = atoi(e) == 1;
   if (const char* e = getenv("OCR_REC_SMALL_LANES")) small_lanes_ = std::min(16, std::max(1, atoi(e)));
@@ -491,7 +491,7 @@ bool ClsStage::create(const ClsConfig& cfg, std::string& err, int& code) {
   if (code) { err = ocr_last_error(); return false; }
   code = OCR_ERR_MODEL;
   WeightMap w;
-  if (!load_model_dir(cfg.model_dir, nullptr, w, err)) return false;
+  if (!load_model_dir(cfg.model_dir, nullptr, "cls", w, err)) return false;
   if (!net_.load(embedded_plan("cls"), w, err)) return false;
   code = OCR_ERR_DEVICE;
   if (hipStreamCreate(&stream_) != hipSuccess) { err = "hipStreamCreate failed"; return false; }

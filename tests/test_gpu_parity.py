@@ -126,6 +126,17 @@ def test_repeated_runs_of_a_binding_track_their_input(pkg, built, monkeypatch, g
     g.close()
 
 
+def test_model_directory_with_another_graph_is_refused(pkg, built):
+    """The compiled-in plan binds weights to layers by name: a model directory whose graph is not the one the plan was
+    generated from (op count / op-type signature, pd_format.cpp) must fail at load, not run with misbound weights."""
+    import os
+    for kind, other in (("det", "cls"), ("cls", "rec"), ("rec", "det")):
+        with pytest.raises(pkg.OcrError, match="is not the %s graph" % kind):
+            pkg.Net(kind, model_dir=os.path.join(pkg.MODELS, other))
+    with pytest.raises(pkg.OcrError, match="is not the det graph"):
+        pkg.Det(model_dir=os.path.join(pkg.MODELS, "rec"))
+
+
 @pytest.mark.parametrize("kind,shape", [("cls", (3, 48, 192)), ("det", (2, 64, 96)), ("det", (1, 192, 384)),
                                         ("rec", (3, 48, 160)), ("rec", (2, 28, 192)), ("rec", (1, 48, 1000))])
 def test_network_outputs_bit_identical(pkg, built, kind, shape):

@@ -343,7 +343,11 @@ def main():
         path = os.path.join(outdir, name + ".plan")
         with open(path, "w") as f:
             f.write("# generated by tools/make_plan.py from models/%s/inference.pdmodel - do not edit\n" % name)
-            f.write("plan %s ntensors=%d\n" % (name, len(chans)))
+            # graph signature (pd_format.cpp pdmodel_graph_signature): op count and FNV-1a 64 of the type names joined by ';'
+            sig = 1469598103934665603
+            for b in ";".join(o.type for o in prog.ops).encode():
+                sig = ((sig ^ b) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+            f.write("plan %s ntensors=%d graph_ops=%d graph_fnv=%016x\n" % (name, len(chans), len(prog.ops), sig))
             for p in plan:
                 f.write(p.line() + "\n")
         kinds = {}

@@ -4,7 +4,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 O=$R/gpurun_out/post_trace
 rm -rf $O
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-latency --no-host-input > $O.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-latency --no-host-input --no-two-workers > $O.log 2>&1
 python3 - <<PY
 import csv, glob
 f = glob.glob("$O/**/*_kernel_stats.csv", recursive=True)[0]

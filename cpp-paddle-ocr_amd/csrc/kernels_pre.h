@@ -32,8 +32,9 @@ struct RotDesc {
   size_t stride;
   int x, y, w, h;
 };
-// d: the ROIs of ONE level (pairwise disjoint, see kernels_pre.hip), rotated concurrently
-void launch_rotate180_level(const RotDesc* d, int nrois, hipStream_t s);
+// d: ROIs grouped into components of mutually reachable intersecting ROIs, each group in request order; seg: ngroups+1
+// offsets into d.  One workgroup per group applies its rotations one after the other, groups run concurrently.
+void launch_rotate180_groups(const RotDesc* d, const int* seg, int ngroups, hipStream_t s);
 // One perspective crop (Utility::GetRotateCropImage): destination pixel -> source position through
 // the inverse homography, bilinear taps in 15-bit fixed point, constant-0 border, optional 90-degree turn.
 struct WarpDesc {

@@ -152,28 +152,44 @@ void launch_rotate180(uint8_t* img, size_t stride, int x0, int y0, int w, int h,
 }
 
 // The same for a whole batch.  ROIs of one image may overlap, so their order matters - but only between ROIs that do
-// overlap: the host sorts the batch into levels (level of a ROI = 1 + the highest level among the EARLIER ROIs of its
-// image that intersect it; pipe.hip), ROIs of one level are pairwise disjoint, and a launch per level, in ascending
-// order, keeps every overlapping pair in request order.  Block (r, c): ROI r of the level, row chunk c; pixel (y, x)
-// swaps with (h-1-y, w-1-x) for the first total/2 pixels in raster order (cv::rotate's flip, no divisions).
-__global__ void __launch_bounds__(256) rotate180_level_kernel(const RotDesc* __restrict__ d) {
-  const RotDesc q = d[blockIdx.x];
-  const int half_rows = q.h >> 1;
-  for (int y = blockIdx.y; y < half_rows + (q.h & 1); y += gridDim.y) {
-    const int xe = y < half_rows ? q.w : q.w >> 1;  // the middle row of an odd height: its first half
-    uint8_t* ra = q.img + (size_t)(q.y + y) * q.stride + (size_t)q.x * 3;
-    uint8_t* rb = q.img + (size_t)(q.y + q.h - 1 - y) * q.stride + (size_t)q.x * 3;
-    for (int x = threadIdx.x; x < xe; x += 256) {
-      uint8_t* pa = ra + (size_t)x * 3;
-      uint8_t* pb = rb + (size_t)(q.w - 1 - x) * 3;
+// overlap: the host groups the batch into the connected components of the "intersects" relation (pipe.hip), one
+// workgroup applies the rotations of ONE component in request order, components run concurrently.  Pixel i of the
+// first total/2 in raster order swaps with pixel total-1-i (cv::rotate's flip).
+__global__ void __launch_bounds__(1024) rotate180_groups_kernel(const RotDesc* __restrict__ d, const int* __restrict__ seg) {
+  constexpr int P = 8;  // pixel pairs per thread and round: all their loads are in flight before the first store
+  for (int r = seg[blockIdx.x]; r < seg[blockIdx.x + 1]; ++r) {
+    const RotDesc q = d[r];
+    const unsigned w = (unsigned)q.w, npairs = (w * (unsigned)q.h) >> 1;  // (w, h < 2^15: 32-bit arithmetic)
+    uint8_t* base = q.img + (size_t)q.y * q.stride + (size_t)q.x * 3;
+    for (unsigned i0 = 0; i0 < npairs; i0 += 1024 * P) {
+      uint8_t* pa[P];
+      uint8_t* pb[P];
+      uint8_t va[P][3], vb[P][3];
 #pragma unroll
-      for (int c = 0; c < 3; ++c) { const uint8_t t = pa[c]; pa[c] = pb[c]; pb[c] = t; }
+      for (int u = 0; u < P; ++u) {
+        const unsigned i = i0 + (unsigned)u * 1024 + threadIdx.x;
+        const unsigned ic = i < npairs ? i : 0;  // past the end: pair 0 is read, nothing is written
+        const unsigned y = ic / w, x = ic - y * w;
+        pa[u] = base + (size_t)y * q.stride + (size_t)x * 3;
+        pb[u] = base + (size_t)((unsigned)q.h - 1 - y) * q.stride + (size_t)(w - 1 - x) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { va[u][c] = pa[u][c]; vb[u][c] = pb[u][c]; }
+      }
+#pragma unroll
+      for (int u = 0; u < P; ++u) {
+        if (i0 + (unsigned)u * 1024 + threadIdx.x < npairs) {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) { pa[u][c] = vb[u][c]; pb[u][c] = va[u][c]; }
+        }
+      }
     }
+    __threadfence_block();
+    __syncthreads();
   }
 }
-void launch_rotate180_level(const RotDesc* d, int nrois, hipStream_t s) {
-  if (nrois <= 0) return;
-  hipLaunchKernelGGL(rotate180_level_kernel, dim3(nrois, 8), dim3(256), 0, s, d);
+void launch_rotate180_groups(const RotDesc* d, const int* seg, int ngroups, hipStream_t s) {
+  if (ngroups <= 0) return;
+  hipLaunchKernelGGL(rotate180_groups_kernel, dim3(ngroups), dim3(1024), 0, s, d, seg);
 }
 
 // cv::warpPerspective(crop, M, INTER_LINEAR, BORDER_CONSTANT 0) restated per pixel

@@ -46,42 +46,48 @@ struct StageSlot {
 };
 
 // In-place 180-degree rotations of ROIs in request order (the cls stage: cv::rotate on views that alias their image,
-// /root/reference/src/ocr_worker.cpp:255-262).  Only ROIs that intersect constrain each other: level = 1 + the highest
-// level among the EARLIER intersecting ROIs in the same buffer (img pointer + stride identify the image), one launch per
-// level over its pairwise disjoint ROIs, levels in ascending order.
-static int rotate180_in_order(const std::vector<RotDesc>& rd, DevBuf<RotDesc>& scratch, hipStream_t stream, std::string& err) {
+// /root/reference/src/ocr_worker.cpp:255-262).  Only ROIs that intersect constrain each other: the ROIs of a view
+// (img pointer + stride identify the image; different views are different images or separate crop buffers and do not
+// alias) are grouped into the connected components of "intersects"; a component keeps request order inside one
+// workgroup, components run concurrently, ONE launch for the batch.
+static int rotate180_in_order(const std::vector<RotDesc>& rd, DevBuf<RotDesc>& scratch, DevBuf<int>& seg_scratch, hipStream_t stream,
+                              std::string& err) {
   if (rd.empty()) return OCR_OK;
-  std::vector<int> level(rd.size(), 0);
-  int nlevels = 1;
-  for (size_t k = 0; k < rd.size(); ++k) {
+  const int n = (int)rd.size();
+  std::vector<int> parent(n);
+  for (int i = 0; i < n; ++i) parent[i] = i;
+  auto find = [&](int a) { while (parent[a] != a) { parent[a] = parent[parent[a]]; a = parent[a]; } return a; };
+  std::map<std::pair<const uint8_t*, size_t>, std::vector<int>> views;  // per view the list is short (the lines of one image)
+  for (int k = 0; k < n; ++k) {
     const RotDesc& q = rd[k];
-    const uint8_t* q0 = q.img + (size_t)q.y * q.stride;  // rows [q0, q1) of the underlying allocation
-    const uint8_t* q1 = q.img + (size_t)(q.y + q.h) * q.stride;
-    for (size_t j = 0; j < k; ++j) {
+    std::vector<int>& mine = views[{q.img, q.stride}];
+    for (int j : mine) {
       const RotDesc& e = rd[j];
-      bool hit;
-      if (e.img == q.img && e.stride == q.stride)
-        hit = e.x < q.x + q.w && q.x < e.x + e.w && e.y < q.y + q.h && q.y < e.y + e.h;
-      else  // different views: conservative byte-range test (crop buffers of the rotate-crop path never overlap)
-        hit = e.img + (size_t)e.y * e.stride < q1 && q0 < e.img + (size_t)(e.y + e.h) * e.stride;
-      if (hit) level[k] = std::max(level[k], level[j] + 1);
+      if (e.x < q.x + q.w && q.x < e.x + e.w && e.y < q.y + q.h && q.y < e.y + e.h) {
+        const int a = find(j), b = find(k);
+        if (a != b) parent[std::max(a, b)] = std::min(a, b);  // the root is the component's first ROI
+      }
     }
-    nlevels = std::max(nlevels, level[k] + 1);
+    mine.push_back(k);
   }
+  // components in order of their first ROI, members in request order
+  std::vector<std::vector<int>> members(n);
+  for (int k = 0; k < n; ++k) members[find(k)].push_back(k);
   std::vector<RotDesc> sorted;
-  std::vector<int> lstart(1, 0);
-  sorted.reserve(rd.size());
-  for (int lv = 0; lv < nlevels; ++lv) {
-    for (size_t j = 0; j < rd.size(); ++j)
-      if (level[j] == lv) sorted.push_back(rd[j]);
-    lstart.push_back((int)sorted.size());
+  std::vector<int> seg(1, 0);
+  sorted.reserve(n);
+  for (int r = 0; r < n; ++r) {
+    if (members[r].empty()) continue;
+    for (int k : members[r]) sorted.push_back(rd[k]);
+    seg.push_back((int)sorted.size());
   }
-  if (!scratch.ensure(sorted.size(), err)) return OCR_ERR_DEVICE;
-  if (hipMemcpyAsync(scratch.p, sorted.data(), sorted.size() * sizeof(RotDesc), hipMemcpyHostToDevice, stream) != hipSuccess) {
+  if (!scratch.ensure(sorted.size(), err) || !seg_scratch.ensure(seg.size(), err)) return OCR_ERR_DEVICE;
+  if (hipMemcpyAsync(scratch.p, sorted.data(), sorted.size() * sizeof(RotDesc), hipMemcpyHostToDevice, stream) != hipSuccess ||
+      hipMemcpyAsync(seg_scratch.p, seg.data(), seg.size() * sizeof(int), hipMemcpyHostToDevice, stream) != hipSuccess) {
     err = "rotation list upload failed";
     return OCR_ERR_DEVICE;
   }
-  for (int lv = 0; lv < nlevels; ++lv) launch_rotate180_level(scratch.p + lstart[lv], lstart[lv + 1] - lstart[lv], stream);
+  launch_rotate180_groups(scratch.p, seg_scratch.p, (int)seg.size() - 1, stream);
   if (hipGetLastError() != hipSuccess) { err = "rotation launch failed"; return OCR_ERR_DEVICE; }
   return OCR_OK;
 }
@@ -102,6 +108,7 @@ struct ocr_pipe {
   JpegScratch jpeg;
   DevBuf<uint8_t> work;  // the requests' clones (OCRRequest copies the Mat, ocr_worker.h:28-29): cls rotates in place on them
   DevBuf<RotDesc> rot_desc;
+  DevBuf<int> rot_seg;
   int crop_mode = 0;  // OCR_CROP_BOUNDING_RECT | OCR_CROP_ROTATE
   DevBuf<uint8_t> crop_arena;
   DevBuf<WarpDesc> warp_desc;
@@ -304,7 +311,7 @@ struct ocr_pipe {
       std::vector<RotDesc> rd;
       for (size_t k = 0; k < lines.size(); ++k)
         if (labels[k] == 1) rd.push_back(RotDesc{const_cast<uint8_t*>(lines[k].img), lines[k].stride, lines[k].x, lines[k].y, lines[k].w, lines[k].h});
-      int rrc = rotate180_in_order(rd, rot_desc, cls->stream(), err);
+      int rrc = rotate180_in_order(rd, rot_desc, rot_seg, cls->stream(), err);
       if (rrc) return rrc;
       if (hipStreamSynchronize(cls->stream()) != hipSuccess) { err = "cls stream sync failed"; return OCR_ERR_DEVICE; }
     }
@@ -641,6 +648,7 @@ int ocr_rotate180_rois(uint8_t* bgr, int rows, int cols, size_t row_stride, cons
   std::string err;
   DevBuf<uint8_t> dimg;
   DevBuf<RotDesc> ddesc;
+  DevBuf<int> dseg;
   if (!dimg.ensure(row * rows, err)) return fail(OCR_ERR_DEVICE, err);
   std::vector<RotDesc> rd(n);
   for (int k = 0; k < n; ++k) {
@@ -649,7 +657,7 @@ int ocr_rotate180_rois(uint8_t* bgr, int rows, int cols, size_t row_stride, cons
     rd[k] = RotDesc{dimg.p, row, r[0], r[1], r[2], r[3]};
   }
   CAPI_HIP(hipMemcpy2D(dimg.p, row, bgr, stride, row, rows, hipMemcpyHostToDevice));
-  const int rc = rotate180_in_order(rd, ddesc, 0, err);
+  const int rc = rotate180_in_order(rd, ddesc, dseg, 0, err);
   if (rc) return fail(rc, err);
   CAPI_HIP(hipMemcpy2D(bgr, stride, dimg.p, row, row, rows, hipMemcpyDeviceToHost));
   return OCR_OK;

@@ -218,8 +218,8 @@ int ocr_rotate_crop_shape(int rows, int cols, const int32_t* box, int* out_rows,
 
 /* The classifier's in-place rotations (/root/reference/src/ocr_worker.cpp:255-262: `cv::rotate(img_list[i], img_list[i], 1)`
  * on crops that are ROI views of ONE image, so overlapping crops see each other's result): rotates the n rectangles
- * (n x 4 ints: x, y, w, h, inside the image) of a host image by 180 degrees in list order, on the device.  Disjoint
- * rectangles run concurrently, intersecting ones in list order. */
+ * (n x 4 ints: x, y, w, h, inside the image) of a host image by 180 degrees in list order, on the device.  Rectangles
+ * that are connected through intersections form a group that keeps list order; groups run concurrently. */
 int ocr_rotate180_rois(uint8_t* bgr, int rows, int cols, size_t row_stride, const int32_t* rects, int n);
 
 /* device memory helpers for callers without a HIP binding of their own (bench, tests) */

@@ -835,7 +835,15 @@ bool Net::run(const float* x, int N, int H, int W, hipStream_t s, std::string& e
   B.stamp = ++clock_;
   bound_x_ = x;
   const char* graph_env = getenv("OCR_GRAPH");  // OCR_GRAPH=0: plain launches only
-  const bool graphs = !(graph_env && graph_env[0] == '0') && !timing_ && !keep_all_ && !B.graph_failed && !B.launches.empty();
+  // event timing needs plain launches - but only where an event would be placed: with a name filter (bench.py times the
+  // dominant kernel alone inside its timed region) every binding without a matching launch keeps replaying its graph
+  bool timed_here = timing_;
+  if (timing_ && !timing_filter_.empty()) {
+    timed_here = false;
+    for (const auto& L : B.launches)
+      if (L.name.find(timing_filter_) != std::string::npos) { timed_here = true; break; }
+  }
+  const bool graphs = !(graph_env && graph_env[0] == '0') && !timed_here && !keep_all_ && !B.graph_failed && !B.launches.empty();
   const void* head[3] = {head_probs_, head_amax_, head_pmax_};
   const bool repeat = B.last_x == x;  // the caller feeds this shape from one buffer: worth recording
   B.last_x = x;

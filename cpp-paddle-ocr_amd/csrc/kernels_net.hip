@@ -889,7 +889,17 @@ __global__ void __launch_bounds__(256) gap_rows_kernel(const float* __restrict__
   const long ny = t / c4n;
   const float* src = in + ny * W * Cs + pc;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int x = 0; x < W; ++x) {
+  // eight loads in flight, then their eight sequential adds (the sum's order is the contract's: left to right)
+  constexpr int U = 8;
+  int x = 0;
+  for (; x + U <= W; x += U) {
+    float4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = *(const float4*)(src + (long)(x + u) * Cs);
+#pragma unroll
+    for (int u = 0; u < U; ++u) { s.x = s.x + v[u].x; s.y = s.y + v[u].y; s.z = s.z + v[u].z; s.w = s.w + v[u].w; }
+  }
+  for (; x < W; ++x) {
     const float4 v = *(const float4*)(src + (long)x * Cs);
     s.x = s.x + v.x; s.y = s.y + v.y; s.z = s.z + v.z; s.w = s.w + v.w;
   }

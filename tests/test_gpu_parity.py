@@ -77,6 +77,34 @@ def test_production_mode_output_bit_identical(pkg, built, kind, shape):
     g.close()
 
 
+_AB_CHILD = r"""
+import sys, numpy as np
+sys.path[:0] = [sys.argv[1], sys.argv[1] + "/oracle", sys.argv[1] + "/tools"]
+import __graft_entry__ as ge
+pkg = ge.load_package()
+from oracle import OracleNet
+for kind, shape in (("det", (2, 96, 160)), ("rec", (3, 48, 320)), ("rec", (5, 48, 136)), ("cls", (2, 48, 192))):
+    x = np.random.RandomState(3).randn(shape[0], shape[1], shape[2], 3).astype(np.float32)
+    o, g = OracleNet(kind), pkg.Net(kind)
+    assert np.array_equal(o.run(x), g.forward(x, keep_all=False)), (kind, shape)
+    g.close()
+print("AB OK")
+"""
+
+
+@pytest.mark.parametrize("env", [{"OCR_DWPW_T4": "thin"}, {"OCR_DWPW_ITEMS": "7"}, {"OCR_DWPW_ITEMS": "1"}, {"OCR_FUSE_DWPW": "0"},
+                                 {"OCR_CONV_C24": "0", "OCR_FUSE_GATE": "0"}])
+def test_ab_switches_do_not_change_results(built, env):
+    """INTEGRATION.md's runtime switches select other kernel shapes / launch lists (read once per process, so each
+    setting runs in a child process): the production-mode outputs stay bit-identical to the oracle.  OCR_DWPW_ITEMS = 7
+    and 1 give workgroups odd and single-item pipelines (the peeled first / last iterations of kernels_dwpw.hip)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", _AB_CHILD, root], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "AB OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
 @pytest.mark.parametrize("kind,shape", [("det", (2, 96, 160)), ("det", (1, 192, 384)), ("det", (3, 64, 64)), ("rec", (3, 48, 320)),
                                         ("rec", (2, 28, 192)), ("rec", (1, 48, 1000)), ("rec", (5, 48, 136)), ("cls", (3, 48, 192))])
 def test_fused_launch_list_every_materialised_tensor_bit_identical(pkg, built, kind, shape):

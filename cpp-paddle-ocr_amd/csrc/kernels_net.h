@@ -68,8 +68,14 @@ struct DwArgs {
   const float* w;  // [K*K][Cs] physical order
   long M;
   int N, H, W, OH, OW, Cs, K, SH, SW, PH, PW;
+  // non-null: the conv also leaves the global average pool's first pass here - for every output row its sum over x,
+  // left to right, [N*OH][Cs] (what gap_rows_kernel computes from the tensor in a second full read); a thread then
+  // owns whole rows (all strips of its band, in x order) instead of one patch
+  float* rowsum = nullptr;
 };
 void launch_dw(const DwArgs& a, const Epilogue& ep, hipStream_t s);
+// the pool's second pass alone (column-sequential sums of the row sums, / count): after a depthwise conv with `rowsum`
+void launch_gap_cols(const float* part, float* out, int N, int H, int W, int Cs, hipStream_t s);
 
 // Fused depthwise conv (+ its epilogue) -> 1x1 conv (+ its epilogue), kernels_dwpw.hip.  Both epilogues are the
 // PPLCNetV3 "learnable affine block" chain of the plans, fixed at compile time (a generic stage interpreter made the

@@ -673,7 +673,7 @@ void launch_stem(const StemArgs& a, const Epilogue& ep, hipStream_t s) {
 // =====================================================================================
 // The K*K x Cs weights are copied to LDS once per workgroup (a workgroup's 256 threads span every channel
 // quad): a thread's 50 weight fetches per patch become LDS reads and leave the L1/TA path to the pixels.
-template <int K, int SW, int TO, int R>
+template <int K, int SW, int TO, int R, bool ROWSUM = false>
 __global__ void __launch_bounds__(256, 2) dw_conv_kernel(const DwArgs a, const Epilogue ep) {
   constexpr int NIN = (TO - 1) * SW + K;
   extern __shared__ float4 s_dw_w[];  // [K*K][Cs/4]
@@ -686,18 +686,25 @@ __global__ void __launch_bounds__(256, 2) dw_conv_kernel(const DwArgs a, const E
   const long t = (long)xcd_swizzle(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
   const int c4n = a.Cs >> 2;
   const int strips = (a.OW + TO - 1) / TO, bands = (a.OH + R - 1) / R;
-  const long npatch = (long)a.N * bands * strips;
+  // ROWSUM: a thread owns a band (R output rows) of one image x 4 channels and walks its strips left to right, so the
+  // pool's row sums (x ascending from 0, the contract's order) accumulate in registers beside the conv
+  const long npatch = (long)a.N * bands * (ROWSUM ? 1 : strips);
   if (t >= npatch * c4n) return;
   const long sidx = t / c4n;
   const int pc = (int)(t - sidx * c4n) * 4;
-  const int sx = (int)(sidx % strips);
-  const long nb = sidx / strips;
+  const int sx_first = ROWSUM ? 0 : (int)(sidx % strips), sx_end = ROWSUM ? strips : sx_first + 1;
+  const long nb = ROWSUM ? sidx : sidx / strips;
   const int y0 = (int)(nb % bands) * R, n = (int)(nb / bands);
+  struct F4 { ocr_f2 lo, hi; };
+  F4 rsum[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) { rsum[r].lo = ocr_f2{0.f, 0.f}; rsum[r].hi = ocr_f2{0.f, 0.f}; }
+#pragma unroll 1
+  for (int sx = sx_first; sx < sx_end; ++sx) {
   const int x0 = sx * TO;
   // Accumulators and arithmetic are written as explicit 2-vectors (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32:
   // two f32 lanes per VALU slot, each lane the same IEEE operation as the scalar instruction), not left to the
   // SLP vectoriser, whose pairing changes with unrelated edits of the epilogue.
-  struct F4 { ocr_f2 lo, hi; };
   F4 acc[R][TO];
 #pragma unroll
   for (int r = 0; r < R; ++r)
@@ -826,15 +833,33 @@ __global__ void __launch_bounds__(256, 2) dw_conv_kernel(const DwArgs a, const E
   for (int r = 0; r < R; ++r)
 #pragma unroll
     for (int o = 0; o < TO; ++o)
-      if (y0 + r < a.OH && x0 + o < a.OW)
+      if (y0 + r < a.OH && x0 + o < a.OW) {
         *(float4*)(a.out + obase + r * orow + (long)o * a.Cs) = make_float4(acc[r][o].lo.x, acc[r][o].lo.y, acc[r][o].hi.x, acc[r][o].hi.y);
+        if constexpr (ROWSUM) { rsum[r].lo = rsum[r].lo + acc[r][o].lo; rsum[r].hi = rsum[r].hi + acc[r][o].hi; }  // s = s + v, x ascending
+      }
+  }  // strips
+  if constexpr (ROWSUM) {
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+      if (y0 + r < a.OH)
+        *(float4*)(a.rowsum + ((long)n * a.OH + y0 + r) * a.Cs + pc) = make_float4(rsum[r].lo.x, rsum[r].lo.y, rsum[r].hi.x, rsum[r].hi.y);
+  }
 }
 
 template <int TO, int R>
 static void launch_dw_patch(const DwArgs& a, const Epilogue& ep, hipStream_t s) {
+  const unsigned lds = (unsigned)(a.K * a.K * a.Cs * sizeof(float));  // <= 48 KB for 5x5 x 480 channels
+  if (a.rowsum) {  // a thread per band: all strips of its rows
+    const long bands = (long)a.N * ((a.OH + R - 1) / R) * (a.Cs >> 2);
+    dim3 g((unsigned)((bands + 255) / 256));
+    if (a.K == 3 && a.SW == 1) hipLaunchKernelGGL((dw_conv_kernel<3, 1, TO, R, true>), g, dim3(256), lds, s, a, ep);
+    else if (a.K == 3) hipLaunchKernelGGL((dw_conv_kernel<3, 2, TO, R, true>), g, dim3(256), lds, s, a, ep);
+    else if (a.SW == 1) hipLaunchKernelGGL((dw_conv_kernel<5, 1, TO, R, true>), g, dim3(256), lds, s, a, ep);
+    else hipLaunchKernelGGL((dw_conv_kernel<5, 2, TO, R, true>), g, dim3(256), lds, s, a, ep);
+    return;
+  }
   const long total = (long)a.N * ((a.OH + R - 1) / R) * ((a.OW + TO - 1) / TO) * (a.Cs >> 2);
   dim3 grid((unsigned)((total + 255) / 256));
-  const unsigned lds = (unsigned)(a.K * a.K * a.Cs * sizeof(float));  // <= 48 KB for 5x5 x 480 channels
   if (a.K == 3 && a.SW == 1) hipLaunchKernelGGL((dw_conv_kernel<3, 1, TO, R>), grid, dim3(256), lds, s, a, ep);
   else if (a.K == 3) hipLaunchKernelGGL((dw_conv_kernel<3, 2, TO, R>), grid, dim3(256), lds, s, a, ep);
   else if (a.SW == 1) hipLaunchKernelGGL((dw_conv_kernel<5, 1, TO, R>), grid, dim3(256), lds, s, a, ep);
@@ -914,6 +939,9 @@ __global__ void __launch_bounds__(256) gap_cols_kernel(const float* __restrict__
   float s = 0.f;
   for (int y = 0; y < H; ++y) s = s + src[(long)y * Cs];
   out[t] = s / cnt;
+}
+void launch_gap_cols(const float* part, float* out, int N, int H, int W, int Cs, hipStream_t s) {
+  hipLaunchKernelGGL(gap_cols_kernel, dim3((unsigned)((N * Cs + 255) / 256)), dim3(256), 0, s, part, out, N, H, Cs, (float)(H * W));
 }
 void launch_gap(const float* in, float* part, float* out, int N, int H, int W, int Cs, hipStream_t s) {
   const long t1 = (long)N * H * (Cs >> 2);

@@ -468,6 +468,23 @@ bool Net::bind(int N, int H, int W, std::string& err) {
   }
   std::vector<char> fused_dw(nops, 0);
   for (int oj = 0; oj < nops; ++oj) if (dwpw_of[oj] >= 0) fused_dw[dwpw_of[oj]] = 1;
+  // ---- depthwise conv -> global average pool (the SE blocks): the conv leaves the pool's row sums (its first pass, a
+  // second full read of the tensor otherwise) while it writes the tensor; only the column pass stays a launch.  Needs
+  // enough bands (a thread owns whole rows then) to fill the chip.  OCR_FUSE_GAP=0 disables (A/B, results identical).
+  std::vector<char> dw_rowsum(nops, 0);
+  static const char* gap_env = getenv("OCR_FUSE_GAP");
+  if (keep_all_ != 1 && !(gap_env && gap_env[0] == '0')) {
+    for (int oi = 1; oi < nops; ++oi) {
+      const PlanOp& g = plan_.ops[oi];
+      const PlanOp& d = plan_.ops[oi - 1];
+      if (g.kind != PlanOp::GAP || d.kind != PlanOp::DW || d.out != g.in || fused_dw[oi - 1] || d.out == out_tid_) continue;
+      const TensorDesc& o = T[d.out];
+      const int rows_per_band = o.h >= 2 ? 2 : 1;
+      const long threads = (long)o.n * ((o.h + rows_per_band - 1) / rows_per_band) * (o.cs >> 2);
+      // (stride-2 rows measured slower this way: rec op 21 0.55 -> 0.72 ms for a 0.18 ms pool pass)
+      if (threads >= 64 * 1024 && d.sh == 1 && d.sw == 1) dw_rowsum[oi - 1] = 1;
+    }
+  }
   std::vector<int> last(plan_.ntensors, -1);
   for (int oi = 0; oi < nops; ++oi) {
     auto& op = plan_.ops[oi];
@@ -682,7 +699,8 @@ bool Net::bind(int N, int H, int W, std::string& err) {
         a.in = arena_ + in.offset; a.out = optr; a.w = dev_vec("dw:" + op.w);
         a.N = in.n; a.H = in.h; a.W = in.w; a.OH = o.h; a.OW = o.w; a.Cs = o.cs; a.K = op.kh;
         a.SH = op.sh; a.SW = op.sw; a.PH = op.ph; a.PW = op.pw; a.M = (long)o.n * o.h * o.w;
-        snprintf(nm, sizeof nm, "%s.%02d.dw%dx%d_%d_s%d%d", plan_.name.c_str(), oi, op.kh, op.kw, op.c, op.sh, op.sw);
+        if (dw_rowsum[oi]) a.rowsum = gap_part_;
+        snprintf(nm, sizeof nm, "%s.%02d.dw%dx%d_%d_s%d%d%s", plan_.name.c_str(), oi, op.kh, op.kw, op.c, op.sh, op.sw, dw_rowsum[oi] ? "_rowsum" : "");
         L.name = nm;
         L.flops = 2.0 * a.M * op.kh * op.kw * op.c;
         L.bytes = 4.0 * ((double)in.n * in.h * in.w * op.c + (double)a.M * op.c);
@@ -708,6 +726,10 @@ bool Net::bind(int N, int H, int W, std::string& err) {
         snprintf(nm, sizeof nm, "%s.%02d.gap_%d", plan_.name.c_str(), oi, op.c);
         L.name = nm;
         L.bytes = 4.0 * (double)n * h * w * op.c;
+        if (oi > 0 && dw_rowsum[oi - 1]) {  // the row sums are already in `part` (written by the depthwise conv before this op)
+          L.bytes = 4.0 * (double)n * h * op.c;
+          L.fn = [part, optr, n, h, w, cs](hipStream_t s) { launch_gap_cols(part, optr, n, h, w, cs, s); };
+        } else
         L.fn = [ip, part, optr, n, h, w, cs](hipStream_t s) { launch_gap(ip, part, optr, n, h, w, cs, s); };
       } break;
       case PlanOp::SEFC: {

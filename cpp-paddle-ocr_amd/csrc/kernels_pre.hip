@@ -153,33 +153,52 @@ void launch_rotate180(uint8_t* img, size_t stride, int x0, int y0, int w, int h,
 
 // The same for a whole batch.  ROIs of one image may overlap, so their order matters - but only between ROIs that do
 // overlap: the host groups the batch into the connected components of the "intersects" relation (pipe.hip), one
-// workgroup applies the rotations of ONE component in request order, components run concurrently.  Pixel i of the
-// first total/2 in raster order swaps with pixel total-1-i (cv::rotate's flip).
+// workgroup applies the rotations of ONE component in request order, components run concurrently.  Pixel (y, x)
+// swaps with (h-1-y, w-1-x) for the first total/2 pixels in raster order (cv::rotate's flip).
+// one BGR pixel as the low 24 bits of a word.  A pixel that is not the last of its ROI row is fetched with ONE unaligned
+// 4-byte load (the fourth byte is the next pixel's first, inside the ROI); the TA processes a wave's byte loads no
+// faster than its dword loads, and the kernel is bound by their number.
+__device__ __forceinline__ unsigned load_px(const uint8_t* p, bool wide) {
+  if (wide) {
+    unsigned v;
+    __builtin_memcpy(&v, p, 4);
+    return v & 0xffffffu;
+  }
+  return (unsigned)p[0] | ((unsigned)p[1] << 8) | ((unsigned)p[2] << 16);
+}
+__device__ __forceinline__ void store_px(uint8_t* p, unsigned v) {
+  const unsigned short lo = (unsigned short)(v & 0xffffu);
+  __builtin_memcpy(p, &lo, 2);
+  p[2] = (uint8_t)(v >> 16);
+}
 __global__ void __launch_bounds__(1024) rotate180_groups_kernel(const RotDesc* __restrict__ d, const int* __restrict__ seg) {
-  constexpr int P = 8;  // pixel pairs per thread and round: all their loads are in flight before the first store
+  // 16 rows x 64 columns of threads; a thread's P pixels of a row (x = tx + 64 u) are all loaded, with their mirror
+  // pixels, before the first store: no divisions, one memory round trip per 16 x 512 pixel block
+  constexpr int P = 8;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   for (int r = seg[blockIdx.x]; r < seg[blockIdx.x + 1]; ++r) {
     const RotDesc q = d[r];
-    const unsigned w = (unsigned)q.w, npairs = (w * (unsigned)q.h) >> 1;  // (w, h < 2^15: 32-bit arithmetic)
+    const int half_rows = q.h >> 1, rows = half_rows + (q.h & 1);
     uint8_t* base = q.img + (size_t)q.y * q.stride + (size_t)q.x * 3;
-    for (unsigned i0 = 0; i0 < npairs; i0 += 1024 * P) {
-      uint8_t* pa[P];
-      uint8_t* pb[P];
-      uint8_t va[P][3], vb[P][3];
+    for (int y = ty; y < rows; y += 16) {
+      const int xe = y < half_rows ? q.w : q.w >> 1;  // the middle row of an odd height: its first half
+      uint8_t* ra = base + (size_t)y * q.stride;
+      uint8_t* rb = base + (size_t)(q.h - 1 - y) * q.stride;
+      for (int x0 = tx; x0 < xe; x0 += 64 * P) {
+        unsigned va[P], vb[P];
 #pragma unroll
-      for (int u = 0; u < P; ++u) {
-        const unsigned i = i0 + (unsigned)u * 1024 + threadIdx.x;
-        const unsigned ic = i < npairs ? i : 0;  // past the end: pair 0 is read, nothing is written
-        const unsigned y = ic / w, x = ic - y * w;
-        pa[u] = base + (size_t)y * q.stride + (size_t)x * 3;
-        pb[u] = base + (size_t)((unsigned)q.h - 1 - y) * q.stride + (size_t)(w - 1 - x) * 3;
+        for (int u = 0; u < P; ++u) {
+          const int x = x0 + 64 * u, xc = x < xe ? x : 0;  // past the end: pixel 0 is read, nothing is written
+          va[u] = load_px(ra + (size_t)xc * 3, xc + 1 < q.w);
+          vb[u] = load_px(rb + (size_t)(q.w - 1 - xc) * 3, xc > 0);
+        }
 #pragma unroll
-        for (int c = 0; c < 3; ++c) { va[u][c] = pa[u][c]; vb[u][c] = pb[u][c]; }
-      }
-#pragma unroll
-      for (int u = 0; u < P; ++u) {
-        if (i0 + (unsigned)u * 1024 + threadIdx.x < npairs) {
-#pragma unroll
-          for (int c = 0; c < 3; ++c) { pa[u][c] = vb[u][c]; pb[u][c] = va[u][c]; }
+        for (int u = 0; u < P; ++u) {
+          const int x = x0 + 64 * u;
+          if (x < xe) {
+            store_px(ra + (size_t)x * 3, vb[u]);
+            store_px(rb + (size_t)(q.w - 1 - x) * 3, va[u]);
+          }
         }
       }
     }

@@ -632,21 +632,42 @@ __global__ void __launch_bounds__(256) stem_conv_kernel(const StemArgs a, const 
   float acc[CS];
 #pragma unroll
   for (int c = 0; c < CS; ++c) acc[c] = 0.f;
-  for (int ky = 0; ky < a.KH; ++ky)
-    for (int kx = 0; kx < a.KW; ++kx) {
-      const int iy = y * a.SH - a.PH + ky, ix = x * a.SW - a.PW + kx;
-      const bool v = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-      const float* src = a.in + (((long)n * a.H + (v ? iy : 0)) * a.W + (v ? ix : 0)) * 3;
-      float in3[3];
-      in3[0] = v ? src[0] : 0.f;
-      in3[1] = v ? src[1] : 0.f;
-      in3[2] = v ? src[2] : 0.f;
-      const float* w = a.w + (long)(ky * a.KW + kx) * 3 * CS;
+  // one 12-byte load per tap (the pixel's three floats; 4-byte alignment is all dwordx3 needs), masked afterwards
+  // with a lane mask: three dword loads under a select each made the kernel bound by the number of load instructions
+  struct P3 { float c[3]; };
+  auto tap_load = [&](int ky, int kx, P3& px, unsigned& keep) {
+    const int iy = y * a.SH - a.PH + ky, ix = x * a.SW - a.PW + kx;
+    const bool v = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+    const float* src = a.in + (((long)n * a.H + (v ? iy : 0)) * a.W + (v ? ix : 0)) * 3;
+    __builtin_memcpy(&px, __builtin_assume_aligned(src, 4), 12);
+    keep = v ? 0xffffffffu : 0u;
+  };
+  auto tap_fma = [&](int ky, int kx, const P3& px, unsigned keep) {
+    float in3[3];
 #pragma unroll
-      for (int ci = 0; ci < 3; ++ci)
+    for (int ci = 0; ci < 3; ++ci) in3[ci] = __uint_as_float(__float_as_uint(px.c[ci]) & keep);
+    const float* w = a.w + (long)(ky * a.KW + kx) * 3 * CS;
 #pragma unroll
-        for (int c = 0; c < CS; ++c) acc[c] = fmaf(in3[ci], w[ci * CS + c], acc[c]);
-    }
+    for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+      for (int c = 0; c < CS; ++c) acc[c] = fmaf(in3[ci], w[ci * CS + c], acc[c]);
+  };
+  if (a.KH == 3 && a.KW == 3) {  // every stem on this path: the nine taps' loads in flight before the first FMA
+    P3 px[9];
+    unsigned keep[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) tap_load(t / 3, t % 3, px[t], keep[t]);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) tap_fma(t / 3, t % 3, px[t], keep[t]);
+  } else {
+    for (int ky = 0; ky < a.KH; ++ky)
+      for (int kx = 0; kx < a.KW; ++kx) {
+        P3 px;
+        unsigned keep;
+        tap_load(ky, kx, px, keep);
+        tap_fma(ky, kx, px, keep);
+      }
+  }
   float* dst = a.out + m * CS;
 #pragma unroll
   for (int c = 0; c < CS; c += 4) {

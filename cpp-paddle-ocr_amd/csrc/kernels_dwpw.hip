@@ -6,16 +6,19 @@
 // in depthwise kernels at 0.4 of the HBM peak).  Here the depthwise result never leaves the CU:
 //
 //   workgroup   : a TH x 16 tile of OUTPUT pixels of one image (32*WP pixels) x WC*NT*32 output channels
-//   channel loop: chunks of CK input channels, software-pipelined, ONE barrier per chunk:
-//       G  global -> registers   the haloed input region of chunk i+2 (16-byte pieces, zero outside the image),
-//                                the chunk's K*K depthwise weights and its per-channel epilogue vectors
-//       DW LDS -> VALU -> LDS    depthwise conv of chunk i+1 + its whole epilogue, written as the MFMA pixel operand:
-//                                a thread owns PR vertically adjacent output pixels x 4 physical channels, taps in
-//                                (ky, kx) ascending order from 0 - the contract's chain
-//       MMA LDS -> MFMA          chunk i: v_mfma_f32_32x32x2_f32 against the 1x1 weights' fragment image (the same
-//                                image conv_mfma_kernel reads; a wave = 32 pixels x NT column tiles), ascending k
-//       S  registers -> LDS      chunk i+2's region into the buffer chunk i+1 has just left
-//   epilogue    : conv_finish (the 1x1 conv's own epilogue and 16-byte stores), unchanged
+//   channel loop: chunks of CK input channels, software-pipelined, ONE barrier per chunk; in iteration k:
+//       steps            the depthwise taps of chunk k issued INSIDE the MFMA stream of chunk k-1 (FUSED below):
+//         DW  LDS -> VALU      a thread owns PR vertically adjacent output pixels x 4 physical channels, taps in
+//                              (ky, kx) ascending order from 0 - the contract's chain - read
+//                              TD steps ahead of their FMAs; the whole depthwise epilogue, written to LDS as the MFMA
+//                              pixel operand
+//         MMA LDS -> MFMA      v_mfma_f32_32x32x2_f32 against the 1x1 weights' fragment image (the same image
+//                              conv_mfma_kernel reads; a wave = 32 pixels x NT column tiles), ascending k; a fragment
+//                              register is refilled with chunk k's fragment right after its last MFMA
+//       S  registers -> LDS    chunk k+1's haloed input region (16-byte pieces, zero outside the image), its K*K
+//                              depthwise weights and its per-channel epilogue vector
+//       G  global -> registers the same for chunk k+2 (k+3 with two register sets)
+//   epilogue    : the 1x1 conv's own LAB chain and 16-byte stores when a tile's last chunk has been multiplied
 //
 // The pixel operand lives in LDS exactly as the C8I tensor would in HBM (pixel-major, 4 consecutive physical channels
 // per lane), so the matrix pipe sees the same k-ordered chain as the unfused pair: results are bit-identical
@@ -111,8 +114,10 @@ __device__ __forceinline__ void lab_apply(F4& v, const ocr_f2 blo, const ocr_f2 
 // A workgroup owns a contiguous range of `upw` work units (unit = one pixel tile x one column block, in
 // raster order, XCD-contiguous) and runs ONE software pipeline over all (unit, channel chunk) items of the range, so
 // the loads of the next tile are in flight while the current one is multiplied and stored:
-//   iteration k:  DW(k)   MMA(k-1) [+ the 1x1 conv's epilogue and stores when it closes a unit]   S(k+1)   G(k+3)   barrier
-// G runs two items ahead of S through two register sets, S one item ahead of DW through two LDS buffers.
+//   iteration k:  [taps(k) inside MMA(k-1), fragment refills for MMA(k)]  S(k+1)  G(k+2 | k+3)
+//                 [the 1x1 conv's epilogue and stores when MMA(k-1) closes a unit]  barrier
+// G runs one or two items (GD) ahead of S through as many register sets, S one item ahead of the taps through two LDS
+// buffers.  TD = tap steps the LDS reads run ahead, LB = workgroups per CU the register budget is cut for.
 // Everything per-thread that does not depend on the tile (LDS offsets of its pieces and items) is computed once.
 template <int K, int SH, int SW, int CK, bool WIDE, int NT, bool DWACT, int GD, int TD, int LB>
 __global__ void __launch_bounds__(256, LB) dwpw_kernel(const DwPwArgs a) {

@@ -79,59 +79,104 @@ __device__ __forceinline__ void resize_px(const uint8_t* __restrict__ src, size_
 }
 
 // det: N same-size images -> resized u8 (tap) + normalised f32 NHWC
+// PX adjacent output pixels per thread (PX = 4 when the row length allows): the kernel is bound by a thread's chain
+// source bytes -> table -> store times the number of thread waves it takes, so all PX pixels' source bytes are fetched
+// before the first store (no store between them: byte pointers alias everything), the normalisation table sits in LDS
+// instead of behind a second L2 round trip, and a thread's PX * 12 output bytes leave as 16-byte stores.
+template <int PX>
 __global__ void __launch_bounds__(256) det_pre_kernel(const DetPreArgs a) {
-  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  __shared__ float s_lut[768];
+  for (int i = threadIdx.x; i < 768; i += 256) s_lut[i] = a.lut[i];
+  __syncthreads();
+  const long t = ((long)blockIdx.x * 256 + threadIdx.x) * PX;
   const long per = (long)a.dh * a.dw;
   if (t >= per * a.N) return;
   const int n = (int)(t / per);
   const int r = (int)(t - (long)n * per);
-  const int dy = r / a.dw, dx = r - dy * a.dw;
-  uint8_t px[3];
-  resize_px(a.src + (size_t)n * a.src_image_bytes, a.src_stride, a.sh, a.sw, a.dh, a.dw, dy, dx, px);
+  const int dy = r / a.dw, dx = r - dy * a.dw;  // (dw % PX == 0: the PX pixels are in one row)
+  uint8_t px[PX][3];
+#pragma unroll
+  for (int u = 0; u < PX; ++u)
+    resize_px(a.src + (size_t)n * a.src_image_bytes, a.src_stride, a.sh, a.sw, a.dh, a.dw, dy, dx + u, px[u]);
+  float v[PX * 3];
+#pragma unroll
+  for (int u = 0; u < PX; ++u) {
+    v[3 * u] = s_lut[px[u][0]];
+    v[3 * u + 1] = s_lut[256 + px[u][1]];
+    v[3 * u + 2] = s_lut[512 + px[u][2]];
+  }
   float* o = a.out + t * 3;
-  o[0] = a.lut[px[0]];
-  o[1] = a.lut[256 + px[1]];
-  o[2] = a.lut[512 + px[2]];
+  if constexpr (PX == 4) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q) *(float4*)(o + 4 * q) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+  } else {
+#pragma unroll
+    for (int q = 0; q < PX * 3; ++q) o[q] = v[q];
+  }
   if (a.resized) {
-    uint8_t* u = a.resized + t * 3;
-    u[0] = px[0]; u[1] = px[1]; u[2] = px[2];
+    uint8_t* u8 = a.resized + t * 3;
+#pragma unroll
+    for (int u = 0; u < PX; ++u) { u8[3 * u] = px[u][0]; u8[3 * u + 1] = px[u][1]; u8[3 * u + 2] = px[u][2]; }
   }
 }
 void launch_det_pre(const DetPreArgs& a, hipStream_t s) {
   const long total = (long)a.N * a.dh * a.dw;
-  hipLaunchKernelGGL(det_pre_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+  if (a.dw % 4 == 0) hipLaunchKernelGGL(det_pre_kernel<4>, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(det_pre_kernel<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
 }
 
 // rec / cls: one text line = ROI of a device image -> [imgH][imgW][3] f32 slot of the batch tensor
+template <int PX>
 __global__ void __launch_bounds__(256) line_pre_kernel(const LineDesc* __restrict__ lines, int nlines, int imgH, int imgW,
                                                        const float* __restrict__ lut, float pad_value,
                                                        float* __restrict__ out) {
-  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  // (as det_pre_kernel: PX adjacent pixels per thread, their source bytes fetched before the first store, table in LDS)
+  __shared__ float s_lut[768];
+  for (int i = threadIdx.x; i < 768; i += 256) s_lut[i] = lut[i];
+  __syncthreads();
+  const long t = ((long)blockIdx.x * 256 + threadIdx.x) * PX;
   const long per = (long)imgH * imgW;
   if (t >= per * nlines) return;
   const int li = (int)(t / per);
   const int r = (int)(t - (long)li * per);
-  const int dy = r / imgW, dx = r - dy * imgW;
+  const int dy = r / imgW, dx = r - dy * imgW;  // (imgW % PX == 0: the PX pixels are in one row)
   const LineDesc L = lines[li];
   float* o = out + ((size_t)L.slot * per + r) * 3;
-  if (dx >= L.resize_w) {
-    // rec: u8 zero pad BEFORE normalise (lut[0]); cls: 0.0f AFTER normalise -> pad_value selects
-    if (pad_value == 0.0f) { o[0] = 0.f; o[1] = 0.f; o[2] = 0.f; }
-    else { o[0] = lut[0]; o[1] = lut[256]; o[2] = lut[512]; }
-    return;
+  uint8_t px[PX][3];
+#pragma unroll
+  for (int u = 0; u < PX; ++u) {
+    const int x = dx + u < L.resize_w ? dx + u : L.resize_w - 1;  // pad columns: a valid pixel is read and dropped
+    resize_px(L.img + (size_t)L.y * L.stride + (size_t)L.x * 3, L.stride, L.h, L.w, imgH, L.resize_w, dy, x, px[u]);
   }
-  uint8_t px[3];
-  resize_px(L.img + (size_t)L.y * L.stride + (size_t)L.x * 3, L.stride, L.h, L.w, imgH, L.resize_w, dy, dx, px);
-  o[0] = lut[px[0]];
-  o[1] = lut[256 + px[1]];
-  o[2] = lut[512 + px[2]];
+  float v[PX * 3];
+#pragma unroll
+  for (int u = 0; u < PX; ++u) {
+    const bool pad = dx + u >= L.resize_w;
+    // rec: u8 zero pad BEFORE normalise (lut[0]); cls: 0.0f AFTER normalise -> pad_value selects
+    const bool zero = pad && pad_value == 0.0f;
+    const float v0 = s_lut[pad ? 0 : px[u][0]], v1 = s_lut[256 + (pad ? 0 : px[u][1])], v2 = s_lut[512 + (pad ? 0 : px[u][2])];
+    v[3 * u] = zero ? 0.f : v0;
+    v[3 * u + 1] = zero ? 0.f : v1;
+    v[3 * u + 2] = zero ? 0.f : v2;
+  }
+  if constexpr (PX == 4) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q) *(float4*)(o + 4 * q) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+  } else {
+#pragma unroll
+    for (int q = 0; q < PX * 3; ++q) o[q] = v[q];
+  }
 }
 void launch_line_pre(const LineDesc* lines, int nlines, int imgH, int imgW, const float* lut, bool pad_after_norm,
                      float* out, hipStream_t s) {
   const long total = (long)nlines * imgH * imgW;
   if (total == 0) return;
-  hipLaunchKernelGGL(line_pre_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, lines, nlines, imgH, imgW, lut,
-                     pad_after_norm ? 0.0f : 1.0f, out);
+  if (imgW % 4 == 0)
+    hipLaunchKernelGGL(line_pre_kernel<4>, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, s, lines, nlines, imgH, imgW, lut,
+                       pad_after_norm ? 0.0f : 1.0f, out);
+  else
+    hipLaunchKernelGGL(line_pre_kernel<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, lines, nlines, imgH, imgW, lut,
+                       pad_after_norm ? 0.0f : 1.0f, out);
 }
 
 // cv::rotate(roi, roi, ROTATE_180) in place: pixel i <-> total-1-i

@@ -620,6 +620,10 @@ bool launch_one(const DwPwArgs& a0, hipStream_t s, bool query) {
   long upw = (target + nch - 1) / nch;
   const long resident = (long)cus[dev] * per_cu[dev];
   while (upw > 1 && (nunits + upw - 1) / upw < 8 * resident) --upw;  // small problems: keep every CU busy
+  // OCR_DWPW_FORCE_UPW (tests): units per workgroup regardless of the problem size, so that small inputs run the
+  // multi-unit pipelines (unit boundaries inside a workgroup, a shorter last workgroup) that production batches run
+  static const char* force = getenv("OCR_DWPW_FORCE_UPW");
+  if (force && atoi(force) > 0) upw = atoi(force);
   a.upw = (unsigned)upw;
   const dim3 grid((unsigned)((nunits + upw - 1) / upw));
   hipLaunchKernelGGL((dwpw_kernel<K, SH, SW, CK, WIDE, NT, DWACT, GD, TD, LB>), grid, dim3(256), lds, s, a);

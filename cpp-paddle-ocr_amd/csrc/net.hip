@@ -482,7 +482,9 @@ bool Net::bind(int N, int H, int W, std::string& err) {
       const int rows_per_band = o.h >= 2 ? 2 : 1;
       const long threads = (long)o.n * ((o.h + rows_per_band - 1) / rows_per_band) * (o.cs >> 2);
       // (stride-2 rows measured slower this way: rec op 21 0.55 -> 0.72 ms for a 0.18 ms pool pass)
-      if (threads >= 64 * 1024 && d.sh == 1 && d.sw == 1) dw_rowsum[oi - 1] = 1;
+      static const char* min_env = getenv("OCR_FUSE_GAP_MIN");  // tests: 1 sends small shapes down this path too
+      const long min_threads = min_env ? atol(min_env) : 64 * 1024;
+      if (threads >= min_threads && d.sh == 1 && d.sw == 1) dw_rowsum[oi - 1] = 1;
     }
   }
   std::vector<int> last(plan_.ntensors, -1);

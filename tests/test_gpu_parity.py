@@ -83,7 +83,8 @@ sys.path[:0] = [sys.argv[1], sys.argv[1] + "/oracle", sys.argv[1] + "/tools"]
 import __graft_entry__ as ge
 pkg = ge.load_package()
 from oracle import OracleNet
-for kind, shape in (("det", (2, 96, 160)), ("rec", (3, 48, 320)), ("rec", (5, 48, 136)), ("cls", (2, 48, 192))):
+for kind, shape in (("det", (2, 96, 160)), ("det", (1, 192, 384)), ("rec", (3, 48, 320)), ("rec", (5, 48, 136)), ("rec", (2, 28, 192)),
+                    ("cls", (2, 48, 192))):
     x = np.random.RandomState(3).randn(shape[0], shape[1], shape[2], 3).astype(np.float32)
     o, g = OracleNet(kind), pkg.Net(kind)
     assert np.array_equal(o.run(x), g.forward(x, keep_all=False)), (kind, shape)
@@ -93,11 +94,14 @@ print("AB OK")
 
 
 @pytest.mark.parametrize("env", [{"OCR_DWPW_T4": "thin"}, {"OCR_DWPW_ITEMS": "7"}, {"OCR_DWPW_ITEMS": "1"}, {"OCR_FUSE_DWPW": "0"},
-                                 {"OCR_CONV_C24": "0", "OCR_FUSE_GATE": "0", "OCR_FUSE_GAP": "0"}])
+                                 {"OCR_CONV_C24": "0", "OCR_FUSE_GATE": "0", "OCR_FUSE_GAP": "0"}, {"OCR_FUSE_GAP_MIN": "1"}, {"OCR_DWPW_FORCE_UPW": "3"}, {"OCR_DWPW_FORCE_UPW": "16", "OCR_DWPW_T4": "thin"}])
 def test_ab_switches_do_not_change_results(built, env):
     """INTEGRATION.md's runtime switches select other kernel shapes / launch lists (read once per process, so each
     setting runs in a child process): the production-mode outputs stay bit-identical to the oracle.  OCR_DWPW_ITEMS = 7
-    and 1 give workgroups odd and single-item pipelines (the peeled first / last iterations of kernels_dwpw.hip)."""
+    and 1 give workgroups odd and single-item pipelines (the peeled first / last iterations of kernels_dwpw.hip);
+    OCR_DWPW_FORCE_UPW gives the workgroups of these small inputs several units each (production batches have 2-32:
+    unit boundaries inside a pipeline, a shorter last workgroup); OCR_FUSE_GAP_MIN = 1 sends these small batches down the depthwise-conv-with-row-sums path that otherwise starts at
+    64 k bands (production batches)."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -584,6 +584,40 @@ def test_rec_batches_with_tied_ratios_follow_the_sort_mode(pkg, built, mode):
     rec.close()
 
 
+def test_pipeline_production_batch_equals_oracle_on_sampled_images(pkg, built):
+    """BASELINE configs[1] at its full size: 64 synthetic 960x960 images (2048 text lines) in one call - the batch at
+    which the production-only paths switch on (workgroups with several units in the fused depthwise->pointwise kernels,
+    depthwise convs that leave the pool's row sums, the 1872-line rec launch beside the small-width lanes, 64-image det
+    tensors of 0.9 GB).  Results are batch-invariant, so any image's words must equal what the oracle produces for that
+    image alone: checked on five images spread over the batch (the oracle needs ~2 s per image)."""
+    from pipeline import Pipeline, DetCfg
+    from synth_data import cfg2_sample
+    kw = dict(rec_batch_num=16, rec_img_h=48, rec_img_w=320, enable_cls=True)
+    pg = pkg.Pipe(limit_side_len=960, **kw)
+    po = Pipeline(det_cfg=DetCfg(limit_side_len=960), **kw)
+    samples = [cfg2_sample(i) for i in range(64)]
+    imgs = [s_[0] for s_ in samples]
+    probs = [s_[1] for s_ in samples]
+    pg.stage(0, imgs, probs)
+    got = pg.run_staged(0)
+    assert len(got) == 64 and sum(len(g) for g in got) == 64 * 32
+    for i in (0, 13, 31, 46, 63):
+        w = po.process(imgs[i], probs[i])["words"]
+        assert len(got[i]) == len(w) == 32, i
+        for a, b in zip(got[i], w):
+            assert np.array_equal(a["box"], b["box"]) and np.array_equal(a["ids"], b["ids"]), i
+            assert a["confidence"] == np.float32(b["confidence"]), i
+    pg.close()
+    # the detection network itself at 64 images per launch (the pipeline above thresholds the protocol's synthetic maps):
+    # probability maps of two images far into the batch against the oracle's
+    det = pkg.Det(limit_side_len=960, thresh=0.3, box_thresh=0.5, unclip_ratio=2.0, max_batch=64)
+    det.run_batch(imgs)
+    for i in (41, 63):
+        po.det_run(imgs[i])
+        assert np.array_equal(det.prob_map(i), po.taps["det_prob"]), i
+    det.close()
+
+
 def test_pipeline_cfg3_pooled_lines_and_staged_slots(pkg, built):
     """BASELINE configs[2] shape of work: 16 images of 16 distinct sizes in ONE call.  det runs per size; the text
     lines of all images share one cls pass and one rec pass (pipe.hip run_images) - every word must still equal

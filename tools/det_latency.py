@@ -1,3 +1,5 @@
+"""Development measurement: wall time and stage times of repeated single-image detector runs on one mixed-size
+(configs[2]) image - the latency-bound per-size pass that the detector lanes of ocr_pipe overlap.  Run from the repo root."""
 import sys, time, os
 sys.path.insert(0, '.'); sys.path.insert(0, 'tools')
 import numpy as np

@@ -115,23 +115,30 @@ __global__ void __launch_bounds__(256) ccl_merge_kernel(const uint8_t* __restric
     if (x < W - 1 && bm[i - W + 1]) uf_unite(L, (int)i, (int)(i - W + 1));
   }
 }
-__global__ void __launch_bounds__(256) ccl_flatten_kernel(const uint8_t* __restrict__ bm, int* __restrict__ L,
-                                                          uint8_t* __restrict__ touch, int N, int H, int W) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= (long)N * H * W) return;
-  const int r = uf_find(L, (int)i);
-  L[i] = r;
-  if (!bm[i]) {
-    const int x = (int)(i % W), y = (int)((i / W) % H);
-    if (x == 0 || y == 0 || x == W - 1 || y == H - 1) touch[r] = 1;  // background component reaches the frame
-  }
+// After the merge a pixel is a component's representative iff L[i] == i, and that is all the border-start search asks
+// of the labels (is_start): no pass that rewrites every pixel's label to its root is needed.  What remains of it is the
+// frame test of the BACKGROUND components (a hole border exists only for a background component that does not reach the
+// frame): one thread per frame pixel marks the root of its component.
+__global__ void __launch_bounds__(256) ccl_frame_kernel(const uint8_t* __restrict__ bm, const int* __restrict__ L,
+                                                        uint8_t* __restrict__ touch, int N, int H, int W) {
+  const int per = 2 * W + 2 * H;  // top row, bottom row, left column, right column (corners twice: harmless)
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (long)N * per) return;
+  const int n = (int)(t / per), k = (int)(t - (long)n * per);
+  int x, y;
+  if (k < W) { x = k; y = 0; }
+  else if (k < 2 * W) { x = k - W; y = H - 1; }
+  else if (k < 2 * W + H) { x = 0; y = k - 2 * W; }
+  else { x = W - 1; y = k - 2 * W - H; }
+  const long i = ((long)n * H + y) * W + x;
+  if (!bm[i]) touch[uf_find(L, (int)i)] = 1;  // background component reaches the frame
 }
 void launch_ccl(const uint8_t* bm, int* L, uint8_t* touch, int N, int H, int W, hipStream_t s) {
-  const long total = (long)N * H * W;
-  const dim3 g((unsigned)((total + 255) / 256));
   hipLaunchKernelGGL(ccl_rows_kernel, dim3((unsigned)(((long)N * H + 3) / 4)), dim3(256), 0, s, bm, L, touch, N, H, W);
-  hipLaunchKernelGGL(ccl_merge_kernel, g, dim3(256), 0, s, bm, L, N, H, W);
-  hipLaunchKernelGGL(ccl_flatten_kernel, g, dim3(256), 0, s, bm, L, touch, N, H, W);
+  const long total = (long)N * H * W;
+  hipLaunchKernelGGL(ccl_merge_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, bm, L, N, H, W);
+  const long frame = (long)N * (2 * W + 2 * H);
+  hipLaunchKernelGGL(ccl_frame_kernel, dim3((unsigned)((frame + 255) / 256)), dim3(256), 0, s, bm, L, touch, N, H, W);
 }
 
 // ------------------------------------------------------------------ 3. border starts, reference order

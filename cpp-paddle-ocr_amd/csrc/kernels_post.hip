@@ -99,20 +99,27 @@ __global__ void __launch_bounds__(256) ccl_rows_kernel(const uint8_t* __restrict
   }
 }
 __device__ __forceinline__ bool run_start(const uint8_t* bm, long i, int x) { return x == 0 || bm[i - 1] != bm[i]; }
+// (one wave per image row, walking it in 64-pixel segments as ccl_rows_kernel does: a flat pixel index costs two
+// 64-bit divisions per thread, most of this kernel's instructions)
 __global__ void __launch_bounds__(256) ccl_merge_kernel(const uint8_t* __restrict__ bm, int* __restrict__ L, int N, int H,
                                                         int W) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= (long)N * H * W) return;
-  const int x = (int)(i % W), y = (int)((i / W) % H);
-  if (y == 0) return;
-  const uint8_t v = bm[i], up = bm[i - W];
-  if (up == v) {
-    // two vertically overlapping runs are joined once, at the leftmost column of the overlap
-    if (run_start(bm, i, x) || run_start(bm, i - W, x)) uf_unite(L, (int)i, (int)(i - W));
-  } else if (v) {
-    // 8-connectivity of the foreground: diagonal-only contacts
-    if (x > 0 && bm[i - W - 1]) uf_unite(L, (int)i, (int)(i - W - 1));
-    if (x < W - 1 && bm[i - W + 1]) uf_unite(L, (int)i, (int)(i - W + 1));
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= (long)N * H || row % H == 0) return;  // the first row of an image has nothing above it
+  const long base = row * W;
+  for (int x0 = 0; x0 < W; x0 += 64) {
+    const int x = x0 + lane;
+    if (x >= W) break;
+    const long i = base + x;
+    const uint8_t v = bm[i], up = bm[i - W];
+    if (up == v) {
+      // two vertically overlapping runs are joined once, at the leftmost column of the overlap
+      if (run_start(bm, i, x) || run_start(bm, i - W, x)) uf_unite(L, (int)i, (int)(i - W));
+    } else if (v) {
+      // 8-connectivity of the foreground: diagonal-only contacts
+      if (x > 0 && bm[i - W - 1]) uf_unite(L, (int)i, (int)(i - W - 1));
+      if (x < W - 1 && bm[i - W + 1]) uf_unite(L, (int)i, (int)(i - W + 1));
+    }
   }
 }
 // After the merge a pixel is a component's representative iff L[i] == i, and that is all the border-start search asks
@@ -135,8 +142,7 @@ __global__ void __launch_bounds__(256) ccl_frame_kernel(const uint8_t* __restric
 }
 void launch_ccl(const uint8_t* bm, int* L, uint8_t* touch, int N, int H, int W, hipStream_t s) {
   hipLaunchKernelGGL(ccl_rows_kernel, dim3((unsigned)(((long)N * H + 3) / 4)), dim3(256), 0, s, bm, L, touch, N, H, W);
-  const long total = (long)N * H * W;
-  hipLaunchKernelGGL(ccl_merge_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, bm, L, N, H, W);
+  hipLaunchKernelGGL(ccl_merge_kernel, dim3((unsigned)(((long)N * H + 3) / 4)), dim3(256), 0, s, bm, L, N, H, W);
   const long frame = (long)N * (2 * W + 2 * H);
   hipLaunchKernelGGL(ccl_frame_kernel, dim3((unsigned)((frame + 255) / 256)), dim3(256), 0, s, bm, L, touch, N, H, W);
 }

@@ -1419,8 +1419,7 @@ __global__ void __launch_bounds__(256) det_tail_kernel(const DetTailArgs a) {
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
   // The pixel's channels arrive as two 16-byte loads per octet (C8I: evens, then odds) and are consumed in
   // ascending logical order c = 8o, 8o+1, ... - the same fma chain as a channel-by-channel walk.
-  for (int o8 = 0; o8 < a.Cs; o8 += 8) {
-    const float4 ev = *(const float4*)(src + o8), od = *(const float4*)(src + o8 + 4);
+  auto octet = [&](int o8, const float4& ev, const float4& od) {
     const float v[8] = {ev.x, od.x, ev.y, od.y, ev.z, od.z, ev.w, od.w};
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -1430,6 +1429,15 @@ __global__ void __launch_bounds__(256) det_tail_kernel(const DetTailArgs a) {
         for (int q = 0; q < 4; ++q) acc[q] = fmaf(v[j], a.w[c * 4 + q], acc[q]);
       }
     }
+  };
+  if (a.Cs == 24) {  // the DB head: the pixel's six 16-byte loads in flight before the first FMA (same chain order)
+    float4 r[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) r[k] = *(const float4*)(src + 4 * k);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) octet(8 * k, r[2 * k], r[2 * k + 1]);
+  } else {
+    for (int o8 = 0; o8 < a.Cs; o8 += 8) octet(o8, *(const float4*)(src + o8), *(const float4*)(src + o8 + 4));
   }
   float pr[4];
 #pragma unroll

@@ -39,16 +39,14 @@ __device__ __forceinline__ void lin_coef_y(int d, double scale, int& s, int& b0,
 }
 __device__ __forceinline__ int clipi(int v, int lo, int hi) { return v >= lo ? (v < hi ? v : hi - 1) : lo; }
 
-// one resized BGR pixel of an (sh x sw) source at (dy, dx) of a (dh x dw) destination
-__device__ __forceinline__ void resize_px(const uint8_t* __restrict__ src, size_t stride, int sh, int sw, int dh, int dw,
-                                          int dy, int dx, uint8_t out[3]) {
+// one resized BGR pixel of an (sh x sw) source at (dy, dx) of a (dh x dw) destination; scale_x/y = 1 / ((double)d / s)
+__device__ __forceinline__ void resize_px_scaled(const uint8_t* __restrict__ src, size_t stride, int sh, int sw, int dh, int dw,
+                                                 double scale_x, double scale_y, int dy, int dx, uint8_t out[3]) {
   if (sh == dh && sw == dw) {
     const uint8_t* p = src + (size_t)dy * stride + dx * 3;
     out[0] = p[0]; out[1] = p[1]; out[2] = p[2];
     return;
   }
-  const double inv_x = (double)dw / sw, inv_y = (double)dh / sh;
-  const double scale_x = 1. / inv_x, scale_y = 1. / inv_y;
   if (sw == 2 * dw && sh == 2 * dh) {  // exact 2x2 decimation: INTER_LINEAR silently becomes INTER_AREA
     const uint8_t* s0 = src + (size_t)(2 * dy) * stride + (2 * dx) * 3;
     const uint8_t* s1 = s0 + stride;
@@ -63,19 +61,42 @@ __device__ __forceinline__ void resize_px(const uint8_t* __restrict__ src, size_
   const int y0 = clipi(sy, 0, sh), y1 = clipi(sy + 1, 0, sh);
   const uint8_t* r0 = src + (size_t)y0 * stride + sx * 3;
   const uint8_t* r1 = src + (size_t)y1 * stride + sx * 3;
+  // the two source pixels of a row = six consecutive bytes: ONE unaligned 8-byte load when those eight bytes lie inside
+  // the source row (sx <= sw - 3), byte loads at the row's end.  The texture-address unit takes as long for a wave's
+  // byte load as for its 8-byte load, and twelve byte loads per pixel were what bounded the kernel.
+  unsigned long long q0, q1;
+  if (sx + 3 <= sw) {
+    __builtin_memcpy(&q0, r0, 8);
+    __builtin_memcpy(&q1, r1, 8);
+  } else {
+    q0 = (unsigned long long)r0[0] | ((unsigned long long)r0[1] << 8) | ((unsigned long long)r0[2] << 16);
+    q1 = (unsigned long long)r1[0] | ((unsigned long long)r1[1] << 8) | ((unsigned long long)r1[2] << 16);
+    if (!edge) {
+      q0 |= ((unsigned long long)r0[3] << 24) | ((unsigned long long)r0[4] << 32) | ((unsigned long long)r0[5] << 40);
+      q1 |= ((unsigned long long)r1[3] << 24) | ((unsigned long long)r1[4] << 32) | ((unsigned long long)r1[5] << 40);
+    }
+  }
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
+    const int p00 = (int)((q0 >> (8 * c)) & 0xffu), p01 = (int)((q0 >> (8 * (3 + c))) & 0xffu);
+    const int p10 = (int)((q1 >> (8 * c)) & 0xffu), p11 = (int)((q1 >> (8 * (3 + c))) & 0xffu);
     int S0, S1;
     if (!edge) {
-      S0 = r0[c] * a0 + r0[3 + c] * a1;
-      S1 = r1[c] * a0 + r1[3 + c] * a1;
+      S0 = p00 * a0 + p01 * a1;
+      S1 = p10 * a0 + p11 * a1;
     } else {
-      S0 = r0[c] * 2048;
-      S1 = r1[c] * 2048;
+      S0 = p00 * 2048;
+      S1 = p10 * 2048;
     }
     const int v = (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2;
     out[c] = (uint8_t)min(255, max(0, v));
   }
+}
+
+__device__ __forceinline__ void resize_px(const uint8_t* __restrict__ src, size_t stride, int sh, int sw, int dh, int dw,
+                                          int dy, int dx, uint8_t out[3]) {
+  const double inv_x = (double)dw / sw, inv_y = (double)dh / sh;
+  resize_px_scaled(src, stride, sh, sw, dh, dw, 1. / inv_x, 1. / inv_y, dy, dx, out);
 }
 
 // det: N same-size images -> resized u8 (tap) + normalised f32 NHWC
@@ -146,7 +167,8 @@ __global__ void __launch_bounds__(256) line_pre_kernel(const LineDesc* __restric
 #pragma unroll
   for (int u = 0; u < PX; ++u) {
     const int x = dx + u < L.resize_w ? dx + u : L.resize_w - 1;  // pad columns: a valid pixel is read and dropped
-    resize_px(L.img + (size_t)L.y * L.stride + (size_t)L.x * 3, L.stride, L.h, L.w, imgH, L.resize_w, dy, x, px[u]);
+    resize_px_scaled(L.img + (size_t)L.y * L.stride + (size_t)L.x * 3, L.stride, L.h, L.w, imgH, L.resize_w, L.scale_x, L.scale_y, dy, x,
+                     px[u]);
   }
   float v[PX * 3];
 #pragma unroll

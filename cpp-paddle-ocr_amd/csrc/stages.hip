@@ -418,7 +418,7 @@ int RecStage::run_lines(const std::vector<LineSrc>& lines, const std::vector<int
   for (int i = 0; i < nl; ++i)
     for (int j = 0; j < slots[i].ng; ++j) {
       const LineSrc& L = lines[launches[i].second[j].line];
-      d[slots[i].line_off + j] = LineDesc{L.img, L.stride, L.x, L.y, L.w, L.h, launches[i].second[j].resize_w, j};
+      d[slots[i].line_off + j] = LineDesc::make(L.img, L.stride, L.x, L.y, L.w, L.h, launches[i].second[j].resize_w, j, imgH);
     }
   ST_HIP(hipMemcpyAsync(descs_.p, d.data(), line_total * sizeof(LineDesc), hipMemcpyHostToDevice, stream0));
   ST_HIP(hipEventRecord(ev_descs_, stream0));
@@ -531,7 +531,7 @@ int ClsStage::run_lines(const std::vector<LineSrc>& lines, int* labels, float* s
     const LineSrc& L = lines[i];
     const float ratio = float(L.w) / float(L.h);
     const int resize_w = ceilf(imgH * ratio) > imgW ? imgW : int(ceilf(imgH * ratio));
-    d[i] = LineDesc{L.img, L.stride, L.x, L.y, L.w, L.h, resize_w, i};
+    d[i] = LineDesc::make(L.img, L.stride, L.x, L.y, L.w, L.h, resize_w, i, imgH);
   }
   if (!descs_.ensure(n, err) || !x_.ensure((size_t)n * imgH * imgW * 3, err)) return OCR_ERR_DEVICE;
   ST_HIP(hipMemcpyAsync(descs_.p, d.data(), n * sizeof(LineDesc), hipMemcpyHostToDevice, stream_));

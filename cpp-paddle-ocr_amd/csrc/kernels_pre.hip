@@ -116,9 +116,24 @@ __global__ void __launch_bounds__(256) det_pre_kernel(const DetPreArgs a) {
   const int r = (int)(t - (long)n * per);
   const int dy = r / a.dw, dx = r - dy * a.dw;  // (dw % PX == 0: the PX pixels are in one row)
   uint8_t px[PX][3];
+  const uint8_t* img = a.src + (size_t)n * a.src_image_bytes;
+  bool done = false;
+  if constexpr (PX == 4) {
+    // same-size images (a 960x960 card at limit_side_len 960): the four pixels are twelve consecutive source bytes -
+    // three dword loads when the address is 4-byte aligned (it is for packed rows whose length is a multiple of 4)
+    const uint8_t* p = img + (size_t)dy * a.src_stride + (size_t)dx * 3;
+    if (a.sh == a.dh && a.sw == a.dw && (((size_t)p) & 3) == 0) {
+      unsigned w3[3];
+      __builtin_memcpy(w3, __builtin_assume_aligned(p, 4), 12);
 #pragma unroll
-  for (int u = 0; u < PX; ++u)
-    resize_px(a.src + (size_t)n * a.src_image_bytes, a.src_stride, a.sh, a.sw, a.dh, a.dw, dy, dx + u, px[u]);
+      for (int b = 0; b < 12; ++b) px[b / 3][b % 3] = (uint8_t)(w3[b >> 2] >> (8 * (b & 3)));
+      done = true;
+    }
+  }
+  if (!done) {
+#pragma unroll
+    for (int u = 0; u < PX; ++u) resize_px(img, a.src_stride, a.sh, a.sw, a.dh, a.dw, dy, dx + u, px[u]);
+  }
   float v[PX * 3];
 #pragma unroll
   for (int u = 0; u < PX; ++u) {
@@ -136,6 +151,15 @@ __global__ void __launch_bounds__(256) det_pre_kernel(const DetPreArgs a) {
   }
   if (a.resized) {
     uint8_t* u8 = a.resized + t * 3;
+    if constexpr (PX == 4) {  // (t % 4 == 0: the twelve bytes start 4-byte aligned when the tap buffer is)
+      if ((((size_t)u8) & 3) == 0) {
+        unsigned w3[3] = {0u, 0u, 0u};
+#pragma unroll
+        for (int b = 0; b < 12; ++b) w3[b >> 2] |= (unsigned)px[b / 3][b % 3] << (8 * (b & 3));
+        __builtin_memcpy(__builtin_assume_aligned(u8, 4), w3, 12);
+        return;
+      }
+    }
 #pragma unroll
     for (int u = 0; u < PX; ++u) { u8[3 * u] = px[u][0]; u8[3 * u + 1] = px[u][1]; u8[3 * u + 2] = px[u][2]; }
   }

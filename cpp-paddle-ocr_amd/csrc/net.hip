@@ -689,7 +689,23 @@ bool Net::bind(int N, int H, int W, std::string& err) {
               if (!launch_conv3x3_c24(a, ep, c24, s) && !launch_conv3x3_tile(a, ep, nt, s)) launch_conv_lds(a, ep, nt, s);
             };
           }
-          else L.fn = [a, ep, nt](hipStream_t s) { launch_conv_mfma(a, ep, nt, s); };
+          else {
+            // Small GEMMs (a request's few text lines, the small-width rec launches): fewer column tiles per wave, as long
+            // as that keeps dividing the fragment image's tile count, until the launch has ~2 workgroups per CU - a wave's
+            // K walk is a chain of NT * K / 2 dependent-in-order MFMAs and with one wave per SIMD its length IS the
+            // kernel's time (rec op 30 on 32 lines: 720 -> 240 MFMAs per wave).  Results do not depend on NT.
+            int ntl = nt;
+            static const char* small_env = getenv("OCR_CONV_SMALL_NT");  // =0: keep the table's NT (A/B)
+            if (a.out_mode != OUT_HEAD && !(small_env && small_env[0] == '0')) {
+              auto wgs = [&](int t) { return ((a.M + 127) / 128) * (long)(a.NTtot / t); };
+              while (ntl > 1 && wgs(ntl) < 512) {
+                int t = ntl - 1;
+                while (t > 1 && a.NTtot % t) --t;
+                ntl = t;
+              }
+            }
+            L.fn = [a, ep, ntl](hipStream_t s) { launch_conv_mfma(a, ep, ntl, s); };
+          }
         }
       } break;
       case PlanOp::DW: {

@@ -151,6 +151,26 @@ struct DetTailArgs {
 };
 void launch_det_tail(const DetTailArgs& a, hipStream_t s);
 
+// The DB head's two transposed convs as ONE kernel: deconv 2x2 s2 (C -> C) + bias + BN + relu, then the tail above
+// (deconv 2x2 s2 C -> 1 + bias + sigmoid + 8-bit threshold).  A thread owns one input pixel = a 4x4 block of the
+// probability map; the C-channel map between the two (64 x 480 x 480 x 24 floats at configs[1]: 1.4 GB written and
+// read back) never exists.  Same fma chains as the matrix-core deconv followed by det_tail_kernel: k ascending from 0.
+struct DbHeadArgs {
+  const float* in;    // [N,H,W,Cs] C8I
+  float* prob;        // [N,4H,4W]
+  uint8_t* bitmap;    // [N,4H,4W] {0,1} or null
+  const float* w1;    // [C k][4 q][C c] logical channels, q = dy*2+dx
+  const float* bias1; // [Cs] physical order
+  const float* bn_s;  // [Cs] physical order: scale
+  const float* bn_t;  // [Cs] physical order: shift
+  const float* w2;    // [C][4]
+  long M;             // N*H*W input pixels
+  int N, H, W, Cs;
+  float bias2;
+  int ithresh;
+};
+bool launch_db_head(const DbHeadArgs& a, int C, hipStream_t s);  // false: C is not on this path (24 only)
+
 void launch_c8i_to_plain(const float* in, float* out, long M, int C, int Cs, hipStream_t s);
 void launch_probe(const float* a, const float* b, float* out, int n, hipStream_t s);
 

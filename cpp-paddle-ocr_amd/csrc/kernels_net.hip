@@ -1463,6 +1463,91 @@ void launch_det_tail(const DetTailArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(det_tail_kernel, dim3((unsigned)((a.M + 255) / 256)), dim3(256), 0, s, a);
 }
 
+// =====================================================================================
+// DB head, both transposed convs in one kernel (DbHeadArgs, kernels_net.h).  VALU: 24 x 96 + 96 x 4 fmas per input
+// pixel with wave-uniform weights (scalar loads), against 2 x 1.4 GB of traffic for the tensor it removes.
+// =====================================================================================
+template <int C>
+__global__ void __launch_bounds__(256) db_head_kernel(const DbHeadArgs a) {
+  static_assert(C % 8 == 0, "whole octets");
+  // Weights are wave-uniform scalar operands (two adjacent output channels per v_pk_fma_f32).  Measured alternatives:
+  // weights in LDS read as 16-byte broadcasts 4.3 ms (every read sunk next to its FMA: one LDS round trip per two
+  // FMAs), scalar loads fenced per channel pair 0.9 ms (a wait in front of every pair); left to the scheduler the
+  // scalar loads are hoisted and partly parked in VGPR lanes, and that is still the fastest form (0.67 ms).
+  const long m = (long)blockIdx.x * 256 + threadIdx.x;
+  if (m >= a.M) return;
+  int n, y, x;
+  decompose(m, a.H * a.W, a.W, n, y, x);
+  // the pixel's channels in LOGICAL order (C8I: an octet's evens, then its odds), all loads in flight at once
+  const float* src = a.in + m * a.Cs;
+  float4 r[C / 4];
+#pragma unroll
+  for (int k = 0; k < C / 4; ++k) r[k] = *(const float4*)(src + 4 * k);
+  float xl[C];
+#pragma unroll
+  for (int o = 0; o < C / 8; ++o) {
+    const float4 ev = r[2 * o], od = r[2 * o + 1];
+    xl[8 * o] = ev.x; xl[8 * o + 1] = od.x; xl[8 * o + 2] = ev.y; xl[8 * o + 3] = od.y;
+    xl[8 * o + 4] = ev.z; xl[8 * o + 5] = od.z; xl[8 * o + 6] = ev.w; xl[8 * o + 7] = od.w;
+  }
+  const long OW = 4L * a.W;
+  const long obase = ((long)n * 4 * a.H + 4 * y) * OW + 4 * x;
+  float pr[4][4];  // [row of the 4x4 block][column]
+  // (two adjacent output channels per instruction: each lane of a v_pk_fma_f32 is the same IEEE fma as the scalar one)
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {  // quadrant of the first deconv: rows 2*(q>>1).., columns 2*(q&1)..
+    float hq[C];
+#pragma unroll
+    for (int c = 0; c < C; c += 2) {
+      ocr_f2 acc = {0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < C; ++k) {
+        const float* w = a.w1 + (k * 4 + q) * C + c;
+        acc = __builtin_elementwise_fma(ocr_f2{xl[k], xl[k]}, ocr_f2{w[0], w[1]}, acc);
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int pc = c8i_phys(c + j);
+        float v = (j ? acc.y : acc.x) + a.bias1[pc];
+        const float u = v * a.bn_s[pc];
+        v = u + a.bn_t[pc];
+        hq[c + j] = fmaxf(v, 0.0f);
+      }
+    }
+    ocr_f2 o01 = {0.f, 0.f}, o23 = {0.f, 0.f};  // the second deconv's four outputs of this quadrant
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const float* w = a.w2 + c * 4;
+      o01 = __builtin_elementwise_fma(ocr_f2{hq[c], hq[c]}, ocr_f2{w[0], w[1]}, o01);
+      o23 = __builtin_elementwise_fma(ocr_f2{hq[c], hq[c]}, ocr_f2{w[2], w[3]}, o23);
+    }
+    const float o4[4] = {o01.x, o01.y, o23.x, o23.y};
+#pragma unroll
+    for (int q2 = 0; q2 < 4; ++q2) {
+      const float v = o4[q2] + a.bias2;
+      const float e = ocr_expf(-v);
+      const float d = 1.0f + e;
+      pr[2 * (q >> 1) + (q2 >> 1)][2 * (q & 1) + (q2 & 1)] = 1.0f / d;
+    }
+  }
+#pragma unroll
+  for (int row = 0; row < 4; ++row) {
+    const long o = obase + row * OW;
+    *(float4*)(a.prob + o) = make_float4(pr[row][0], pr[row][1], pr[row][2], pr[row][3]);
+    if (a.bitmap) {
+      unsigned bits = 0;  // (unsigned char)(p*255): truncation; p in [0,1]
+#pragma unroll
+      for (int col = 0; col < 4; ++col) bits |= ((int)(pr[row][col] * 255.0f) > a.ithresh ? 1u : 0u) << (8 * col);
+      *(unsigned*)(a.bitmap + o) = bits;
+    }
+  }
+}
+bool launch_db_head(const DbHeadArgs& a, int C, hipStream_t s) {
+  if (C != 24 || a.Cs != 24) return false;
+  hipLaunchKernelGGL(db_head_kernel<24>, dim3((unsigned)((a.M + 255) / 256)), dim3(256), 0, s, a);
+  return true;
+}
+
 // ---- layout conversion taps (debug / parity): C8I [M][Cs] -> logical [M][C] ----
 __global__ void __launch_bounds__(256) c8i_to_plain_kernel(const float* __restrict__ in, float* __restrict__ out, long M,
                                                            int C, int Cs) {

@@ -287,6 +287,12 @@ bool Net::load(const char* plan_text, const WeightMap& W, std::string& err) {
             return ch < co ? w[((size_t)k * co + ch) * 4 + q] : 0.f;
           });
           if (!upload("frag:" + op.w, f)) { err = "hipMalloc failed"; return false; }
+          // [k][q][c] logical channels for the fused DB head (db_head_kernel)
+          std::vector<float> img((size_t)ci * 4 * co);
+          for (int k = 0; k < ci; ++k)
+            for (int q = 0; q < 4; ++q)
+              for (int c = 0; c < co; ++c) img[((size_t)k * 4 + q) * co + c] = w[((size_t)k * co + c) * 4 + q];
+          if (!upload("dbh1:" + op.w, img)) { err = "hipMalloc failed"; return false; }
         }
       } break;
       case PlanOp::DW: {
@@ -487,12 +493,28 @@ bool Net::bind(int N, int H, int W, std::string& err) {
       if (threads >= min_threads && d.sh == 1 && d.sw == 1) dw_rowsum[oi - 1] = 1;
     }
   }
+  // ---- DB head: deconv (C -> C, bias + BN + relu) -> deconv (C -> 1, bias + sigmoid) as one kernel; the C-channel map
+  // between them (1.4 GB at configs[1]) is never written.  OCR_FUSE_DBHEAD=0 disables (A/B, results identical).
+  std::vector<int> dbhead_of(nops, -1);  // tail op -> the deconv it absorbs
+  static const char* dbh_env = getenv("OCR_FUSE_DBHEAD");
+  if (keep_all_ != 1 && !(dbh_env && dbh_env[0] == '0')) {
+    for (int oi = 0; oi + 1 < nops; ++oi) {
+      const PlanOp& d = plan_.ops[oi];
+      const PlanOp& t = plan_.ops[oi + 1];
+      if (d.kind != PlanOp::DECONV || d.cout == 1 || t.kind != PlanOp::DECONV || t.cout != 1 || t.in != d.out) continue;
+      if (uses[d.out] != 1 || d.out == out_tid_ || d.cin != 24 || d.cout != 24 || T[d.in].cs != 24) continue;
+      if (d.ep.size() != 3 || d.ep[0].kind != EP_BIAS || d.ep[1].kind != EP_BN || d.ep[2].kind != EP_ACT || d.ep[2].act != ACT_RELU) continue;
+      dbhead_of[oi + 1] = oi;
+      fused_dw[oi] = 1;  // (same bookkeeping as a fused depthwise conv: no launch, no tensor)
+    }
+  }
   std::vector<int> last(plan_.ntensors, -1);
   for (int oi = 0; oi < nops; ++oi) {
     auto& op = plan_.ops[oi];
     if (folded[oi] || fused_dw[oi]) continue;  // its reads happen in the conv it was folded / fused into
     if (gate_src[oi] >= 0) { last[gate_src[oi]] = oi; last[gate_tid[oi]] = oi; }
     else if (dwpw_of[oi] >= 0) last[plan_.ops[dwpw_of[oi]].in] = oi;
+    else if (dbhead_of[oi] >= 0) last[plan_.ops[dbhead_of[oi]].in] = oi;
     else if (op.in >= 0) last[op.in] = oi;
     for (int t : op.ins) last[t] = oi;
     for (auto& st : op.ep) if (st.tid >= 0) last[st.tid] = oi;
@@ -605,6 +627,25 @@ bool Net::bind(int N, int H, int W, std::string& err) {
           L.flops = 2.0 * a.M * op.cin * 4;
           L.bytes = 4.0 * a.M * op.cin + 4.0 * a.M * 4 + (det_bitmap_ ? 1.0 * a.M * 4 : 0.0);
           L.fn = [a](hipStream_t s) { launch_det_tail(a, s); };
+          if (dbhead_of[oi] >= 0) {
+            const PlanOp& d = plan_.ops[dbhead_of[oi]];
+            const TensorDesc& din = T[d.in];
+            Epilogue epd;
+            if (!build_epilogue(d, epd, true, err)) return false;
+            DbHeadArgs h{};
+            h.in = arena_ + din.offset; h.prob = optr; h.bitmap = det_bitmap_;
+            h.w1 = dev_vec("dbh1:" + d.w); h.bias1 = epd.st[0].v0; h.bn_s = epd.st[1].v0; h.bn_t = epd.st[1].v1;
+            h.w2 = a.w; h.M = (long)din.n * din.h * din.w; h.N = din.n; h.H = din.h; h.W = din.w; h.Cs = din.cs;
+            h.bias2 = a.bias; h.ithresh = a.ithresh;
+            snprintf(nm, sizeof nm, "%s.%02d.db_head_%d", plan_.name.c_str(), dbhead_of[oi], d.cin);
+            L.name = nm;
+            L.flops = 2.0 * h.M * (4.0 * d.cin * d.cout + 16.0 * d.cout);
+            L.bytes = 4.0 * h.M * d.cin + 4.0 * h.M * 16 + (det_bitmap_ ? 1.0 * h.M * 16 : 0.0);
+            const int C = d.cin;
+            L.fn = [h, C](hipStream_t s) {
+              if (!launch_db_head(h, C, s)) { fprintf(stderr, "launch_db_head: shape accepted at bind time was refused at launch\n"); abort(); }
+            };
+          }
         } else {
           if (!build_epilogue(op, ep, true, err)) return false;
           ConvArgs a{};

@@ -10,7 +10,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-LIB_PATH = os.path.join(HERE, "lib", "libocr_hip.so")
+LIB_PATH = os.environ.get("OCR_LIB_PATH") or os.path.join(HERE, "lib", "libocr_hip.so")   # (override: A/B runs against another build)
 MODELS = os.path.join(ROOT, "models")
 
 _lib = None
@@ -50,7 +50,7 @@ EXPORTS = [
     "ocr_cls_cfg_default", "ocr_cls_create", "ocr_cls_destroy", "ocr_cls_run", "ocr_cls_probs",
     "ocr_rec_cfg_default", "ocr_rec_create", "ocr_rec_destroy", "ocr_rec_run", "ocr_rec_label",
     "ocr_rec_num_classes", "ocr_rec_steps",
-    "ocr_net_create", "ocr_net_destroy", "ocr_net_forward", "ocr_net_num_tensors", "ocr_net_tensor_exists", "ocr_net_fetch",
+    "ocr_net_create", "ocr_net_destroy", "ocr_net_forward", "ocr_net_forward_ragged", "ocr_net_num_tensors", "ocr_net_tensor_exists", "ocr_net_fetch",
     "ocr_net_timing", "ocr_net_timing_report", "ocr_probe",
 ]
 
@@ -65,6 +65,8 @@ def lib():
         L.ocr_net_create.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
         L.ocr_net_destroy.argtypes = [C.c_void_p]
         L.ocr_net_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+        if hasattr(L, "ocr_net_forward_ragged"):
+            L.ocr_net_forward_ragged.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
         L.ocr_net_num_tensors.argtypes = [C.c_void_p]
         L.ocr_net_tensor_exists.argtypes = [C.c_void_p, C.c_int]
         L.ocr_net_fetch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_int)]
@@ -103,6 +105,15 @@ class Net:
         n, h, w, c = x.shape
         assert c == 3
         check(lib().ocr_net_forward(self.h, x.ctypes.data, n, h, w, int(keep_all)))
+        return self.fetch(-1)
+
+    def forward_ragged(self, lines, keep_all=False):
+        """lines: list of f32 [H, W_i, 3] arrays of one height -> the output's lines one after the other [1, 1, sum T_i, C]"""
+        h = lines[0].shape[0]
+        assert all(l.shape[0] == h and l.shape[2] == 3 for l in lines)
+        x = np.concatenate([np.ascontiguousarray(l, dtype=np.float32).reshape(-1) for l in lines])
+        widths = np.array([l.shape[1] for l in lines], dtype=np.int32)
+        check(lib().ocr_net_forward_ragged(self.h, x.ctypes.data, len(lines), h, widths.ctypes.data, int(keep_all)))
         return self.fetch(-1)
 
     def fetch(self, tid, cap=None):

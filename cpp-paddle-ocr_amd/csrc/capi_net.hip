@@ -1,6 +1,7 @@
 // C-ABI: runtime init, raw network taps, numerics probe.
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "capi_common.h"
@@ -96,6 +97,27 @@ int ocr_rt_init(int device_id) {
   CAPI_HIP(hipGetDeviceProperties(&prop, device_id));
   if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
     return fail(OCR_ERR_DEVICE, std::string("device is ") + prop.gcnArchName + ", this build targets gfx950 (MI355X) only");
+  // One idle high-priority stream per device, created before the pipeline's own streams and kept for the life of the
+  // process.  Measured (round 3, tools/ab_cfg3.sh; ROCm 7.2 runtime): BASELINE configs[2]'s detector - eight host
+  // threads driving eight normal-priority streams with one small launch chain per image size - takes 145 ms per 256
+  // images when the process owns a stream of another priority class and 193 ms when it does not (rounds 1-2 had such
+  // streams by accident: the recognizer's odd-width lanes); five more normal streams, GPU_MAX_HW_QUEUES = 8 / 32 and
+  // DEBUG_HIP_DYNAMIC_QUEUES = 0 / 1 change nothing.  The runtime's mapping of streams to hardware queues is not
+  // documented; this is the measured configuration.  OCR_PRIO_ANCHOR=0 leaves it out (A/B).
+  {
+    static std::mutex mu;
+    static hipStream_t anchor[64] = {};
+    std::lock_guard<std::mutex> lk(mu);
+    const char* e = getenv("OCR_PRIO_ANCHOR");
+    if (device_id < 64 && !anchor[device_id] && !(e && e[0] == '0')) {
+      int lo = 0, hi = 0;
+      if (hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo &&
+          hipStreamCreateWithPriority(&anchor[device_id], hipStreamDefault, hi) != hipSuccess) {
+        anchor[device_id] = nullptr;
+        (void)hipGetLastError();
+      }
+    }
+  }
   return OCR_OK;
 }
 
@@ -139,6 +161,30 @@ int ocr_net_forward(ocr_net* h, const float* x, int N, int H, int W, int keep_al
   h->net.set_keep_all(keep_all < 0 || keep_all > 2 ? 1 : keep_all);
   std::string err;
   if (!h->net.run(h->x_dev, N, H, W, h->stream, err)) return fail(OCR_ERR_DEVICE, err);
+  CAPI_HIP(hipStreamSynchronize(h->stream));
+  h->net.collect_timings();
+  return OCR_OK;
+}
+
+int ocr_net_forward_ragged(ocr_net* h, const float* x, int N, int H, const int* widths, int keep_all) {
+  if (!h || !x || !widths || N <= 0 || H <= 0) return fail(OCR_ERR_ARG, "bad argument");
+  CAPI_HIP(hipSetDevice(h->device));
+  size_t n = 0;
+  for (int i = 0; i < N; ++i) {
+    if (widths[i] <= 0) return fail(OCR_ERR_ARG, "bad line width");
+    n += (size_t)H * widths[i] * 3;
+  }
+  if (n > h->x_cap) {
+    if (h->x_dev) (void)hipFree(h->x_dev);
+    h->x_dev = nullptr;
+    h->x_cap = 0;
+    CAPI_HIP(hipMalloc(&h->x_dev, n * sizeof(float)));
+    h->x_cap = n;
+  }
+  CAPI_HIP(hipMemcpyAsync(h->x_dev, x, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  h->net.set_keep_all(keep_all < 0 || keep_all > 2 ? 1 : keep_all);
+  std::string err;
+  if (!h->net.run_ragged(h->x_dev, H, widths, N, h->stream, err)) return fail(OCR_ERR_DEVICE, err);
   CAPI_HIP(hipStreamSynchronize(h->stream));
   h->net.collect_timings();
   return OCR_OK;

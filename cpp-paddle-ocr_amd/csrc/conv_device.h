@@ -36,6 +36,33 @@ __device__ __forceinline__ void decompose(long m, int hw, int w, int& n, int& y,
   x = r - y * w;
 }
 
+// ---- ragged batches (kernels_net.h, RagLevel) ----
+// Line of flat index t when line n starts at mul * cw[n]: the largest n in [0, N) with mul * cw[n] <= t.
+__device__ __forceinline__ int rag_line(const int* __restrict__ cw, int N, long t, long mul) {
+  int lo = 0, hi = N;  // mul * cw[lo] <= t < mul * cw[hi]
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if ((long)cw[mid] * mul <= t) lo = mid;
+    else hi = mid;
+  }
+  return lo;
+}
+// The same for a thread of a workgroup whose FIRST flat index is t0 (wave-uniform: the search runs on scalar values),
+// walking forward from that line: a workgroup's indices span a line or two.
+__device__ __forceinline__ int rag_line_near(const int* __restrict__ cw, int N, long t, long mul, long t0) {
+  int n = rag_line(cw, N, t0, mul);
+  while (n + 1 < N && (long)cw[n + 1] * mul <= t) ++n;
+  return n;
+}
+// pixel m of a ragged tensor with H rows per line -> (line, y, x); m0 = the workgroup's first pixel (uniform)
+__device__ __forceinline__ void rag_decompose(const RagLevel& r, int N, int H, long m, long m0, int& n, int& y, int& x, int& w) {
+  n = rag_line_near(r.cw, N, m, H, m0);
+  w = r.w[n];
+  const int rem = (int)(m - (long)r.cw[n] * H);
+  y = rem / w;
+  x = rem - y * w;
+}
+
 // ---- scalar epilogue for one value at (n, y, x, physical channel pc); oidx = its NHWC offset ----
 __device__ __forceinline__ float apply_epilogue(const Epilogue& ep, float v, int pc, int n, int y, int x, long oidx,
                                                 int cs) {

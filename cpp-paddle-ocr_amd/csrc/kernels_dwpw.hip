@@ -29,6 +29,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <mutex>
 #include <type_traits>
 #include <utility>
 
@@ -70,26 +71,50 @@ struct DwPwGeom {
   }
 };
 
-// position of a work unit (column block fastest, then tile x, tile y, image), advanced without divisions
+// position of a work unit (column block fastest, then tile x, tile y, image), advanced without divisions.
+// RAG (ragged batch; kernels_net.h, RagLevel): an image is a text line with its own width - its tile-column count is
+// re-read from the table when the walk enters a line; widths and first pixels are read where they are used (g_setup,
+// finish: once per unit).  All of this is wave-uniform (scalar registers, which these kernels have none to spare of:
+// the uniform instantiations carry no ragged state at all).
+template <bool RAG>
 struct UnitPos {
   int cb, tx, ty, n;
-  __device__ __forceinline__ void init(unsigned u, int cblocks, int tiles_x, int tiles_y) {
+  int txn;  // RAG: tile columns of line n
+  __device__ __forceinline__ int cols(const DwPwArgs& a) const { return RAG ? txn : a.tiles_x; }
+  __device__ __forceinline__ void init(unsigned u, int cblocks, const DwPwArgs& a) {
     cb = (int)(u % (unsigned)cblocks);
     unsigned t = u / (unsigned)cblocks;
-    tx = (int)(t % (unsigned)tiles_x);
-    t /= (unsigned)tiles_x;
-    ty = (int)(t % (unsigned)tiles_y);
-    n = (int)(t / (unsigned)tiles_y);
+    if constexpr (RAG) {
+      n = rag_line(a.rtiles, a.c.N, t, a.tiles_y);
+      txn = a.rtiles[n + 1] - a.rtiles[n];
+      t -= (unsigned)a.rtiles[n] * (unsigned)a.tiles_y;
+      ty = (int)(t / (unsigned)txn);
+      tx = (int)(t - (unsigned)ty * (unsigned)txn);
+    } else {
+      txn = 0;
+      tx = (int)(t % (unsigned)a.tiles_x);
+      t /= (unsigned)a.tiles_x;
+      ty = (int)(t % (unsigned)a.tiles_y);
+      n = (int)(t / (unsigned)a.tiles_y);
+    }
   }
-  __device__ __forceinline__ void next(int cblocks, int tiles_x, int tiles_y) {
+  __device__ __forceinline__ void next(int cblocks, const DwPwArgs& a) {
     if (++cb == cblocks) {
       cb = 0;
-      if (++tx == tiles_x) {
+      if (++tx == cols(a)) {
         tx = 0;
-        if (++ty == tiles_y) { ty = 0; ++n; }
+        if (++ty == a.tiles_y) {
+          ty = 0; ++n;
+          if constexpr (RAG) txn = a.rtiles[n + 1] - a.rtiles[n];  // (the table has one entry past N: the walk steps onto "line N" after the last unit)
+        }
       }
     }
   }
+  // width and first pixel of image n on the input / output side
+  __device__ __forceinline__ int in_w(const DwPwArgs& a) const { return RAG ? a.rin.w[n] : a.W; }
+  __device__ __forceinline__ int out_w(const DwPwArgs& a) const { return RAG ? a.rout.w[n] : a.c.OW; }
+  __device__ __forceinline__ long in_pix(const DwPwArgs& a) const { return RAG ? (long)a.rin.cw[n] * a.H : (long)n * a.H * a.W; }
+  __device__ __forceinline__ long out_pix(const DwPwArgs& a) const { return RAG ? (long)a.rout.cw[n] * a.c.OH : (long)n * a.c.OH * a.c.OW; }
 };
 
 // the LAB chain on two packed pairs; bias already added by the caller where it comes from elsewhere
@@ -119,7 +144,7 @@ __device__ __forceinline__ void lab_apply(F4& v, const ocr_f2 blo, const ocr_f2 
 // G runs one or two items (GD) ahead of S through as many register sets, S one item ahead of the taps through two LDS
 // buffers.  TD = tap steps the LDS reads run ahead, LB = workgroups per CU the register budget is cut for.
 // Everything per-thread that does not depend on the tile (LDS offsets of its pieces and items) is computed once.
-template <int K, int SH, int SW, int CK, bool WIDE, int NT, bool DWACT, int GD, int TD, int LB>
+template <int K, int SH, int SW, int CK, bool WIDE, int NT, bool DWACT, int GD, int TD, int LB, bool RAG>
 __global__ void __launch_bounds__(256, LB) dwpw_kernel(const DwPwArgs a) {
   using G_ = DwPwGeom<K, SH, SW, CK, WIDE>;
   constexpr int WC = G_::WC, TW = G_::TW, TH = G_::TH, PR = G_::PR, IW = G_::IW;
@@ -173,19 +198,20 @@ __global__ void __launch_bounds__(256, LB) dwpw_kernel(const DwPwArgs a) {
   }
 
   // ---- G: global -> registers, item by item (its own unit / chunk counters run ahead of everything else)
-  UnitPos g_pos_u;
-  g_pos_u.init(u0, cblocks, a.tiles_x, a.tiles_y);
+  UnitPos<RAG> g_pos_u;
+  g_pos_u.init(u0, cblocks, a);
   int g_units = nunits, g_ch = 0;
   const float* g_img = a.dw_in;
   int goff[G_PER];
   auto g_setup = [&]() __attribute__((always_inline)) {  // image offsets of this thread's pieces for unit g_pos_u (-1: zero)
-    g_img = a.dw_in + (long)g_pos_u.n * a.H * a.W * Cs;
+    g_img = a.dw_in + g_pos_u.in_pix(a) * Cs;
     const int iy0 = g_pos_u.ty * TH * SH - a.PH, ix0 = g_pos_u.tx * TW * SW - a.PW;
+    const int iwn = g_pos_u.in_w(a);
 #pragma unroll
     for (int i = 0; i < G_PER; ++i) {
       const int iy = iy0 + (g_pos[i] >> 16), ix = ix0 + ((g_pos[i] >> 8) & 0xff);
-      const bool ok = g_pos[i] >= 0 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-      goff[i] = ok ? (iy * a.W + ix) * Cs + (g_pos[i] & 0xff) : -1;
+      const bool ok = g_pos[i] >= 0 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)iwn;
+      goff[i] = ok ? (iy * iwn + ix) * Cs + (g_pos[i] & 0xff) : -1;
     }
   };
   // Every call issues the same G_PER + 1 loads, unconditionally (pieces outside the image read a valid address and are
@@ -215,7 +241,7 @@ __global__ void __launch_bounds__(256, LB) dwpw_kernel(const DwPwArgs a) {
     if (g_units > 0 && ++g_ch == nch) {
       g_ch = 0;
       if (--g_units > 0) {
-        g_pos_u.next(cblocks, a.tiles_x, a.tiles_y);
+        g_pos_u.next(cblocks, a);
         g_setup();
       } else {
         g_ch = nch - 1;  // past the end: stay on the last chunk of the last unit
@@ -305,8 +331,8 @@ __global__ void __launch_bounds__(256, LB) dwpw_kernel(const DwPwArgs a) {
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
   const long wstride = (long)c.NTtot * 64;
   const int KK = nch * C8S;
-  UnitPos b_pos, m_pos;
-  b_pos.init(u0, cblocks, a.tiles_x, a.tiles_y);
+  UnitPos<RAG> b_pos, m_pos;
+  b_pos.init(u0, cblocks, a);
   m_pos = b_pos;
   int b_units = nunits, b_step = 0;
   const float4* const w_lane = (const float4*)c.wfrag + (long)wc * NT * 64 + lane;
@@ -318,7 +344,7 @@ __global__ void __launch_bounds__(256, LB) dwpw_kernel(const DwPwArgs a) {
     b_step += C8S;
     if (b_step == KK) {  // next unit: back to the first step of ITS column block (past the end: the last one again)
       b_step = 0;
-      if (b_units > 1) { --b_units; b_pos.next(cblocks, a.tiles_x, a.tiles_y); }
+      if (b_units > 1) { --b_units; b_pos.next(cblocks, a); }
       p_w = w_lane + (long)b_pos.cb * WC * NT * 64;
     } else {
       p_w += C8S * wstride;
@@ -357,10 +383,11 @@ __global__ void __launch_bounds__(256, LB) dwpw_kernel(const DwPwArgs a) {
   auto finish = [&]() __attribute__((always_inline)) {
     const int nt0 = (m_pos.cb * WC + wc) * NT;
     const int oy = m_pos.ty * TH + pix_y, ox = m_pos.tx * TW + pix_x;
-    const bool inside = oy < c.OH && ox < c.OW;
+    const int own = m_pos.out_w(a);
+    const bool inside = oy < c.OH && ox < own;
     const int r0 = nt0 * 32 + 4 * h;
     const float* sp = s_par + r0;
-    float* obase = c.out + (((long)m_pos.n * c.OH + oy) * c.OW + ox) * c.Cs_out + r0;
+    float* obase = c.out + (m_pos.out_pix(a) + (long)oy * own + ox) * c.Cs_out + r0;
     const ocr_f2 S0 = {ps0, ps0}, A0 = {pa0, pa0};
     float mn = INFINITY, mx = 0.0f;
     // a column tile's four bias vectors as one group of LDS reads (left alone, each read is sunk next to its use:
@@ -405,7 +432,7 @@ __global__ void __launch_bounds__(256, LB) dwpw_kernel(const DwPwArgs a) {
     if (++m_ch == nch) {  // the unit is complete
       finish();
       m_ch = 0;
-      m_pos.next(cblocks, a.tiles_x, a.tiles_y);
+      m_pos.next(cblocks, a);
     }
   };
   auto MMA = [&](int buf) __attribute__((always_inline)) {
@@ -584,30 +611,45 @@ __global__ void __launch_bounds__(256, LB) dwpw_kernel(const DwPwArgs a) {
 
 namespace {
 
-template <int K, int SH, int SW, int CK, bool WIDE, int NT, bool DWACT, int GD, int TD, int LB>
+template <int K, int SH, int SW, int CK, bool WIDE, int NT, bool DWACT, int GD, int TD, int LB, bool RAG>
 bool launch_one(const DwPwArgs& a0, hipStream_t s, bool query) {
   using G_ = DwPwGeom<K, SH, SW, CK, WIDE>;
   const size_t lds = G_::lds_floats(a0.c.NTtot) * sizeof(float);
-  // per device: the dynamic-LDS limit, and how many of these workgroups a CU holds (the grid is persistent)
-  static unsigned char attr_state[64] = {};
-  static int per_cu[64] = {}, cus[64] = {};
+  // per device: the dynamic-LDS limit, and how many of these workgroups a CU holds.  One instantiation serves several
+  // column-tile counts (its parameter block, and with it the LDS size, grows with NTtot): the attribute memo re-raises
+  // for a larger request (lds_attr.h) and the occupancy memo is per LDS size.  Detector lanes and pool workers launch
+  // from several host threads: the memo is guarded.
+  static LdsAttrMemo attr_state;
+  struct Occ { size_t lds; int per_cu, cus; };
+  static Occ occ[64][2] = {};
+  static std::mutex occ_mu;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
-  if (lds > 64 * 1024 && !raise_dynamic_lds((const void*)dwpw_kernel<K, SH, SW, CK, WIDE, NT, DWACT, GD, TD, LB>, (int)lds, attr_state)) return false;
-  if (!per_cu[dev]) {
-    int nb = 0;
-    hipDeviceProp_t prop;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, dwpw_kernel<K, SH, SW, CK, WIDE, NT, DWACT, GD, TD, LB>, 256, lds) != hipSuccess || nb < 1 ||
-        hipGetDeviceProperties(&prop, dev) != hipSuccess) { (void)hipGetLastError(); return false; }
-    per_cu[dev] = nb;
-    cus[dev] = prop.multiProcessorCount;
+  if (lds > 64 * 1024 && !raise_dynamic_lds((const void*)dwpw_kernel<K, SH, SW, CK, WIDE, NT, DWACT, GD, TD, LB, RAG>, (int)lds, attr_state)) return false;
+  int per_cu_dev = 0, cus_dev = 0;
+  {
+    std::lock_guard<std::mutex> lk(occ_mu);
+    Occ* e = nullptr;
+    for (Occ& o : occ[dev])
+      if (o.per_cu && o.lds == lds) e = &o;
+    if (!e) {
+      int nb = 0;
+      hipDeviceProp_t prop;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, dwpw_kernel<K, SH, SW, CK, WIDE, NT, DWACT, GD, TD, LB, RAG>, 256, lds) != hipSuccess || nb < 1 ||
+          hipGetDeviceProperties(&prop, dev) != hipSuccess) { (void)hipGetLastError(); return false; }
+      e = occ[dev][0].per_cu ? &occ[dev][1] : &occ[dev][0];  // (two sizes per instantiation on the plans' shapes; a third replaces the second)
+      *e = Occ{lds, nb, prop.multiProcessorCount};
+    }
+    per_cu_dev = e->per_cu;
+    cus_dev = e->cus;
   }
   if (query) return true;  // asked at bind time, on the device that will run it: a refusal falls back to the pair
   DwPwArgs a = a0;
   a.tiles_x = (a.c.OW + G_::TW - 1) / G_::TW;
   a.tiles_y = (a.c.OH + G_::TH - 1) / G_::TH;
   const unsigned cblocks = (unsigned)a.c.NTtot / (NT * G_::WC);
-  const long nunits = (long)a.c.N * a.tiles_y * a.tiles_x * cblocks;
+  static_assert(G_::TW == 16, "DwPwArgs::rtiles counts 16-pixel tile columns");
+  const long nunits = (a.rtiles ? (long)a.rtiles_total : (long)a.c.N * a.tiles_x) * a.tiles_y * cblocks;
   if (nunits <= 0 || nunits > 0x7fffffffL) return false;
   a.nunits = (unsigned)nunits;
   // Units per workgroup: enough (unit, chunk) items for the pipeline to run in steady state, few enough that the grid
@@ -618,7 +660,7 @@ bool launch_one(const DwPwArgs& a0, hipStream_t s, bool query) {
   const int target = env ? atoi(env) : 32;
   const int nch = a.c.Cs_in / CK;
   long upw = (target + nch - 1) / nch;
-  const long resident = (long)cus[dev] * per_cu[dev];
+  const long resident = (long)cus_dev * per_cu_dev;
   while (upw > 1 && (nunits + upw - 1) / upw < 8 * resident) --upw;  // small problems: keep every CU busy
   // OCR_DWPW_FORCE_UPW (tests): units per workgroup regardless of the problem size, so that small inputs run the
   // multi-unit pipelines (unit boundaries inside a workgroup, a shorter last workgroup) that production batches run
@@ -626,7 +668,7 @@ bool launch_one(const DwPwArgs& a0, hipStream_t s, bool query) {
   if (force && atoi(force) > 0) upw = atoi(force);
   a.upw = (unsigned)upw;
   const dim3 grid((unsigned)((nunits + upw - 1) / upw));
-  hipLaunchKernelGGL((dwpw_kernel<K, SH, SW, CK, WIDE, NT, DWACT, GD, TD, LB>), grid, dim3(256), lds, s, a);
+  hipLaunchKernelGGL((dwpw_kernel<K, SH, SW, CK, WIDE, NT, DWACT, GD, TD, LB, RAG>), grid, dim3(256), lds, s, a);
   return true;
 }
 
@@ -656,7 +698,8 @@ bool launch_dwpw(const DwPwArgs& a, hipStream_t s, bool query) {
   if (!a.pw_ep.act || !a.dw_ep.act) return false;  // the pairs on the hot path: full chain on both sides
 #define OCR_DWPW_CASE(K_, SH_, SW_, CK_, WIDE_, NT_, GD_, TD_, LB_, COND)                                  \
   if (K == K_ && SH == SH_ && SW == SW_ && Cs % CK_ == 0 && tiles % (NT_ * (WIDE_ ? 2 : 1)) == 0 && (COND)) \
-    return launch_one<K_, SH_, SW_, CK_, WIDE_, NT_, true, GD_, TD_, LB_>(a, s, query);
+    return a.rtiles ? launch_one<K_, SH_, SW_, CK_, WIDE_, NT_, true, GD_, TD_, LB_, true>(a, s, query)                 \
+                    : launch_one<K_, SH_, SW_, CK_, WIDE_, NT_, true, GD_, TD_, LB_, false>(a, s, query);
   // TD = how many tap steps ahead the LDS reads run, LB = workgroups per CU the register budget is cut for (3: 168
   // registers, 2: 256): per shape, whichever measured faster (tools/micro/dwpw_probe) - a third wave per SIMD where the
   // kernel fits without spilling, deeper read-ahead where it does not.

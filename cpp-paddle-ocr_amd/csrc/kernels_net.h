@@ -12,6 +12,18 @@ namespace ocr {
 
 enum : int { OUT_C8I = 0, OUT_PLAIN = 1, OUT_DECONV = 2, OUT_HEAD = 3 };
 
+// Ragged batch (the recognizer, /root/reference/src/ocr_rec.cpp:47-72: every batch of 16 lines has its own tensor
+// width): the N samples of ONE launch are text lines of one height H and their own widths.  A tensor at a "width
+// level" (input, /2 after the stem, /4, /8 = CTC steps) stores line n as a dense [H][w[n]][Cs] block that starts at
+// pixel H * cw[n]; cw = exclusive prefix sums of w, N + 1 entries.  Pointwise ops (1x1 conv, linear, layer norm, the
+// CTC head) see one row axis of H * cw[N] pixels and need nothing else; spatial ops take the line's own width for
+// their zero padding, SE pools and attention their own counts.  Every line's arithmetic is what a launch of that
+// line alone would compute: results do not depend on what else is in the batch.
+struct RagLevel {
+  const int* w = nullptr;   // [N]   line widths at this level (device memory); null = uniform batch
+  const int* cw = nullptr;  // [N+1] prefix sums of w
+};
+
 struct ConvArgs {
   const float* in;   // [N,H,W,Cs_in] C8I
   float* out;
@@ -36,6 +48,8 @@ struct ConvArgs {
   // one rounding, and this conv then read the product): [N][Cs_in] physical channel order, null = none
   const float* gate;
   int gate_hw;  // pixels per image (row m belongs to image m / gate_hw)
+  // ragged batch (rin.w != null): N lines, in.H rows each, widths rin.w[n] -> rout.w[n] (H / OH are uniform)
+  RagLevel rin, rout;
 };
 void launch_conv_mfma(const ConvArgs& a, const Epilogue& ep, int nt, hipStream_t s);
 // LDS-staged variant of the same GEMM (default when K = taps*Cs_in >= 64)
@@ -59,6 +73,7 @@ struct StemArgs {
   const float* w;   // [KH*KW*3][Cs_out] physical order
   long M;
   int N, H, W, OH, OW, Cs_out, KH, KW, SH, SW, PH, PW;
+  RagLevel rin, rout;  // ragged batch: W / OW per line
 };
 void launch_stem(const StemArgs& a, const Epilogue& ep, hipStream_t s);
 
@@ -72,10 +87,14 @@ struct DwArgs {
   // left to right, [N*OH][Cs] (what gap_rows_kernel computes from the tensor in a second full read); a thread then
   // owns whole rows (all strips of its band, in x order) instead of one patch
   float* rowsum = nullptr;
+  RagLevel rin, rout;          // ragged batch: W / OW per line
+  const int* rwork = nullptr;  // ragged, no rowsum: [N+1] prefix sums of the lines' strip counts ceil(OW_n / TO) for the launcher's TO
+  int rwork_total = 0;         // rwork[N] (host copy: the launcher sizes the grid with it)
 };
 void launch_dw(const DwArgs& a, const Epilogue& ep, hipStream_t s);
+int dw_patch_to(int OW, int SW);  // output pixels per thread along x the launcher will pick
 // the pool's second pass alone (column-sequential sums of the row sums, / count): after a depthwise conv with `rowsum`
-void launch_gap_cols(const float* part, float* out, int N, int H, int W, int Cs, hipStream_t s);
+void launch_gap_cols(const float* part, float* out, int N, int H, int W, int Cs, hipStream_t s, RagLevel rag = RagLevel());
 
 // Fused depthwise conv (+ its epilogue) -> 1x1 conv (+ its epilogue), kernels_dwpw.hip.  Both epilogues are the
 // PPLCNetV3 "learnable affine block" chain of the plans, fixed at compile time (a generic stage interpreter made the
@@ -95,14 +114,20 @@ struct DwPwArgs {
   int tiles_x, tiles_y;  // filled by the launcher
   unsigned nunits;       // work units = pixel tiles x column blocks (filled by the launcher)
   unsigned upw;          // units per workgroup (filled by the launcher)
+  // ragged batch: line widths in / out and [N+1] prefix sums of the lines' tile-column counts ceil(OW_n / 16)
+  RagLevel rin, rout;
+  const int* rtiles = nullptr;
+  int rtiles_total = 0;  // rtiles[N] (host copy: the launcher sizes the grid with it)
 };
 // host: is this stage list the chain above?  fills `out` (bias pointer left null: the caller resolves it)
 bool lab_from_epilogue(const Epilogue& ep, LabEp& out);
 // false: the shape is not instantiated (the caller launches the unfused pair).  query = true only asks.
 bool launch_dwpw(const DwPwArgs& a, hipStream_t s, bool query = false);
 
-void launch_ew(const float* in, float* out, long M, int H, int W, int Cs, const Epilogue& ep, hipStream_t s);
-void launch_gap(const float* in, float* part, float* out, int N, int H, int W, int Cs, hipStream_t s);
+// rag (ragged batch of N lines): the per-image stages (channel gate) find their line from the row index
+void launch_ew(const float* in, float* out, long M, int H, int W, int Cs, const Epilogue& ep, hipStream_t s, int N = 0,
+               RagLevel rag = RagLevel());
+void launch_gap(const float* in, float* part, float* out, int N, int H, int W, int Cs, hipStream_t s, RagLevel rag = RagLevel());
 
 struct SeArgs {
   const float* in;  // [N][Cs]
@@ -127,13 +152,17 @@ struct PoolArgs {
   float* out;
   long M;
   int N, H, W, OH, OW, Cs, KH, KW, SH, SW, is_max;
+  RagLevel rin, rout;  // ragged batch: W / OW per line
 };
 void launch_pool(const PoolArgs& a, hipStream_t s);
 
 void launch_ln(const float* in, float* out, long rows, int C, int Cs, float eps, const float* g, const float* b,
                hipStream_t s);
+// rag (ragged batch): line n is a sequence of rag.w[n] tokens starting at row rag.cw[n]; T = the longest line
 void launch_attn(const float* qkv, float* out, int N, int T, int heads, int hd, int Cs_in, int Cs_out, float scale,
-                 hipStream_t s);
+                 hipStream_t s, RagLevel rag = RagLevel());
+// does the ragged form of the attention kernel take sequences of this length? (its working set must fit LDS)
+bool attn_ragged_fits(int T);
 // second half of the fused head: rows x groups partials -> arg max / max probability per row
 void launch_head_combine(const float* hmax, const float* hsum, const int* hidx, long rows, int groups, int* amax, float* pmax,
                          hipStream_t s);

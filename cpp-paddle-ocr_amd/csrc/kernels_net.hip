@@ -63,18 +63,27 @@ __global__ void __launch_bounds__(256, (NT <= 3 ? 4 : 3)) conv_mfma_kernel(const
   // GATE: the SE gate of the lane's image, same four channels as the pixel load (single-tap only)
   const float* grow = zpage;
   if constexpr (GATE) {
-    if (mvalid) grow = a.gate + (long)((unsigned)m / (unsigned)a.gate_hw) * a.Cs_in + 4 * h;
+    if (mvalid) {
+      const int gn = a.rin.w ? rag_line_near(a.rin.cw, a.N, m, a.H, (long)(lb / groups) * 128) : (int)((unsigned)m / (unsigned)a.gate_hw);
+      grow = a.gate + (long)gn * a.Cs_in + 4 * h;
+    }
   }
   int p_step = 0;
   // ---- general: incremental (tap, c8) walk with selects
   int p_c8 = 0, p_ky = 0, p_kx = 0;
   int n = 0, y = 0, x = 0;
+  int lw = a.W;  // the lane's line width (ragged batch: its own)
   const float* lane_base = nullptr;
   long tap_off = 0;  // + c8*8, elements
   if constexpr (!TAP1) {
-    decompose(mvalid ? m : a.M - 1, a.OH * a.OW, a.OW, n, y, x);
-    // this lane's pixel at tap (0,0), channel 4h; a tap adds the uniform offset (ky*W + kx)*Cs_in
-    lane_base = a.in + 4 * h + (((long)n * a.H + (y - a.PH)) * a.W + (x - a.PW)) * a.Cs_in;
+    if (a.rin.w) {  // stride-1 "same" convs only (host): the output level is the input level
+      rag_decompose(a.rin, a.N, a.H, mvalid ? m : a.M - 1, (long)(lb / groups) * 128, n, y, x, lw);
+      lane_base = a.in + 4 * h + ((long)a.rin.cw[n] * a.H + (long)(y - a.PH) * lw + (x - a.PW)) * a.Cs_in;
+    } else {
+      decompose(mvalid ? m : a.M - 1, a.OH * a.OW, a.OW, n, y, x);
+      // this lane's pixel at tap (0,0), channel 4h; a tap adds the uniform offset (ky*W + kx)*Cs_in
+      lane_base = a.in + 4 * h + (((long)n * a.H + (y - a.PH)) * a.W + (x - a.PW)) * a.Cs_in;
+    }
   }
   auto load_step = [&](float4& av, float4 (&bv)[NT], float4& gv) {
     if constexpr (GATE) gv = *(const float4*)(grow + p_step * 8);
@@ -86,7 +95,7 @@ __global__ void __launch_bounds__(256, (NT <= 3 ? 4 : 3)) conv_mfma_kernel(const
 #endif
     } else {
       const int iy = y - a.PH + p_ky, ix = x - a.PW + p_kx;
-      const bool valid = mvalid && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+      const bool valid = mvalid && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)lw;
       // padding / out-of-range rows read a zero page: no select ever touches a loaded value
       const float* src = valid ? lane_base + tap_off : zpage;
       av = *(const float4*)src;
@@ -109,7 +118,7 @@ __global__ void __launch_bounds__(256, (NT <= 3 ? 4 : 3)) conv_mfma_kernel(const
       const bool wx = p_kx == a.KW;
       p_kx = wx ? 0 : p_kx;
       p_ky += wx;
-      tap_off = ((long)p_ky * a.W + p_kx) * a.Cs_in + p_c8 * 8;
+      tap_off = ((long)p_ky * lw + p_kx) * a.Cs_in + p_c8 * 8;
     }
   };
   auto mfma_step = [&](const float4& av0, const float4 (&bv)[NT], const float4& gv) {
@@ -211,16 +220,22 @@ __global__ void __launch_bounds__(256, 2) conv_lds_kernel(const ConvArgs a, cons
   const long m0 = m_base + wave * 32;
 
   // per-row addressing state of the 128 staged rows, computed once into LDS (a per-thread array of
-  // it ends up in scratch): {image offset in floats (lo, hi) or -1, y, x}
+  // it ends up in scratch): {first pixel of the row's image or -1, the image's width, y, x}
   __shared__ int4 rowinfo[128];
   if (tid < 128) {
     const long m = m_base + tid;
-    int4 ri = make_int4(-1, -1, 0, 0);
+    int4 ri = make_int4(-1, 1, 0, 0);
     if (m < a.M) {
-      int n, y, x;
-      decompose(m, hw, a.OW, n, y, x);
-      const long off = (long)n * a.H * a.W * a.Cs_in;
-      ri = make_int4((int)(off & 0xffffffffL), (int)(off >> 32), y, x);
+      int n, y, x, w = a.W;
+      long pix0;
+      if (a.rin.w) {  // ragged batch (stride-1 "same" convs only: output level = input level)
+        rag_decompose(a.rin, a.N, a.H, m, m_base, n, y, x, w);
+        pix0 = (long)a.rin.cw[n] * a.H;
+      } else {
+        decompose(m, hw, a.OW, n, y, x);
+        pix0 = (long)n * a.H * a.W;
+      }
+      ri = make_int4((int)pix0, w, y, x);  // (pixel counts of a launch stay below 2^31: host check)
     }
     rowinfo[tid] = ri;
   }
@@ -250,11 +265,10 @@ __global__ void __launch_bounds__(256, 2) conv_lds_kernel(const ConvArgs a, cons
       auto load_a = [&](int i) __attribute__((always_inline)) -> float4 {
         const int idx = tid + i * 256, row = idx / SEG, seg = idx - row * SEG;
         const int4 ri = rowinfo[row];
-        const long img = ((long)ri.y << 32) | (unsigned)ri.x;
         const int iy = ri.z - a.PH + ky, ix = ri.w - a.PW + kx;
         // branch-free validity and address (no short-circuit control flow around the load)
-        const bool v = (ri.y >= 0) & (iy >= 0) & (iy < a.H) & (ix >= 0) & (ix < a.W);
-        const long off = img + ((long)(v ? iy : 0) * a.W + (v ? ix : 0)) * a.Cs_in + cc * BK + seg * 4;
+        const bool v = (ri.x >= 0) & (iy >= 0) & (iy < a.H) & (ix >= 0) & (ix < ri.y);
+        const long off = ((long)ri.x + (long)(v ? iy : 0) * ri.y + (v ? ix : 0)) * a.Cs_in + cc * BK + seg * 4;
         const float* src = v ? a.in + off : a.zeros;
         return *(const float4*)src;
       };
@@ -313,8 +327,6 @@ __global__ void __launch_bounds__(256, 2) conv_lds_kernel(const ConvArgs a, cons
   }
   const long m = m0 + p;
   if (m >= a.M) return;
-  int n, y, x;
-  decompose(m, hw, a.OW, n, y, x);
   conv_finish<NT, OUT_C8I>(a, ep, acc, nt0, m, h, s_par);
 }
 
@@ -581,7 +593,7 @@ bool launch_conv3x3_c24(const ConvArgs& a, const Epilogue& ep, const float* wimg
   const int tiles_y = (a.OH + 7) / 8;
   const dim3 grid((unsigned)((long)a.N * tiles_y * tiles_x));
   const unsigned lds = 10 * 18 * (96 + 4) * sizeof(float);  // 72 000 B: two workgroups per CU
-  static unsigned char attr_state[64] = {};
+  static LdsAttrMemo attr_state;
   if (!raise_dynamic_lds((const void*)conv3x3_c24_kernel<12, 8>, (int)lds, attr_state)) return false;
   hipLaunchKernelGGL((conv3x3_c24_kernel<12, 8>), grid, dim3(256), lds, s, a, ep, wimg, tiles_x, tiles_y);
   return true;
@@ -597,7 +609,7 @@ bool launch_conv3x3_tile(const ConvArgs& a, const Epilogue& ep, int nt, hipStrea
   const dim3 grid((unsigned)((long)a.N * tiles_y * tiles_x * (a.NTtot / nt)));
   const unsigned lds = 10 * 18 * (96 + 4) * sizeof(float);  // 72 000 B: two workgroups per CU
   // more than 64 KB of dynamic LDS has to be allowed per device (a worker pool drives several from one process)
-  static unsigned char attr_state[64] = {};
+  static LdsAttrMemo attr_state;
   if (!raise_dynamic_lds((const void*)conv3x3_tile_kernel<12, 1>, (int)lds, attr_state)) return false;  // the general kernel takes the launch
   hipLaunchKernelGGL((conv3x3_tile_kernel<12, 1>), grid, dim3(256), lds, s, a, ep, tiles_x, tiles_y);
   return true;
@@ -625,10 +637,21 @@ void launch_conv_lds(const ConvArgs& a, const Epilogue& ep, int nt, hipStream_t 
 // =====================================================================================
 template <int CS>
 __global__ void __launch_bounds__(256) stem_conv_kernel(const StemArgs a, const Epilogue ep) {
-  const long m = (long)xcd_swizzle(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
+  const long m_wg = (long)xcd_swizzle(blockIdx.x, gridDim.x) * 256;
+  const long m = m_wg + threadIdx.x;
   if (m >= a.M) return;
   int n, y, x;
-  decompose(m, a.OH * a.OW, a.OW, n, y, x);
+  int iw = a.W;              // input width of the pixel's image (ragged batch: the line's own)
+  long ipix0;                // first input pixel of that image
+  if (a.rout.w) {
+    int ow;
+    rag_decompose(a.rout, a.N, a.OH, m, m_wg, n, y, x, ow);
+    iw = a.rin.w[n];
+    ipix0 = (long)a.rin.cw[n] * a.H;
+  } else {
+    decompose(m, a.OH * a.OW, a.OW, n, y, x);
+    ipix0 = (long)n * a.H * a.W;
+  }
   float acc[CS];
 #pragma unroll
   for (int c = 0; c < CS; ++c) acc[c] = 0.f;
@@ -637,8 +660,8 @@ __global__ void __launch_bounds__(256) stem_conv_kernel(const StemArgs a, const 
   struct P3 { float c[3]; };
   auto tap_load = [&](int ky, int kx, P3& px, unsigned& keep) {
     const int iy = y * a.SH - a.PH + ky, ix = x * a.SW - a.PW + kx;
-    const bool v = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-    const float* src = a.in + (((long)n * a.H + (v ? iy : 0)) * a.W + (v ? ix : 0)) * 3;
+    const bool v = iy >= 0 && iy < a.H && ix >= 0 && ix < iw;
+    const float* src = a.in + (ipix0 + (long)(v ? iy : 0) * iw + (v ? ix : 0)) * 3;
     __builtin_memcpy(&px, __builtin_assume_aligned(src, 4), 12);
     keep = v ? 0xffffffffu : 0u;
   };
@@ -694,7 +717,7 @@ void launch_stem(const StemArgs& a, const Epilogue& ep, hipStream_t s) {
 // =====================================================================================
 // The K*K x Cs weights are copied to LDS once per workgroup (a workgroup's 256 threads span every channel
 // quad): a thread's 50 weight fetches per patch become LDS reads and leave the L1/TA path to the pixels.
-template <int K, int SW, int TO, int R, bool ROWSUM = false>
+template <int K, int SW, int TO, int R, bool ROWSUM = false, bool RAG = false>
 __global__ void __launch_bounds__(256, 2) dw_conv_kernel(const DwArgs a, const Epilogue ep) {
   constexpr int NIN = (TO - 1) * SW + K;
   extern __shared__ float4 s_dw_w[];  // [K*K][Cs/4]
@@ -704,18 +727,41 @@ __global__ void __launch_bounds__(256, 2) dw_conv_kernel(const DwArgs a, const E
     for (int i = threadIdx.x; i < nw4; i += 256) s_dw_w[i] = gw[i];
     __syncthreads();
   }
-  const long t = (long)xcd_swizzle(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
+  const long t_wg = (long)xcd_swizzle(blockIdx.x, gridDim.x) * 256;
+  const long t = t_wg + threadIdx.x;
   const int c4n = a.Cs >> 2;
-  const int strips = (a.OW + TO - 1) / TO, bands = (a.OH + R - 1) / R;
+  const int bands = (a.OH + R - 1) / R;
+  constexpr bool rag = RAG;  // ragged batch (own instantiation: the uniform one keeps its widths in scalar registers)
   // ROWSUM: a thread owns a band (R output rows) of one image x 4 channels and walks its strips left to right, so the
   // pool's row sums (x ascending from 0, the contract's order) accumulate in registers beside the conv
-  const long npatch = (long)a.N * bands * (ROWSUM ? 1 : strips);
+  // ragged batch: patches are counted line by line (a.rwork: prefix sums of the lines' strip counts)
+  const long npatch = ROWSUM ? (long)a.N * bands : (rag ? (long)a.rwork_total * bands : (long)a.N * bands * ((a.OW + TO - 1) / TO));
   if (t >= npatch * c4n) return;
   const long sidx = t / c4n;
   const int pc = (int)(t - sidx * c4n) * 4;
-  const int sx_first = ROWSUM ? 0 : (int)(sidx % strips), sx_end = ROWSUM ? strips : sx_first + 1;
-  const long nb = ROWSUM ? sidx : sidx / strips;
-  const int y0 = (int)(nb % bands) * R, n = (int)(nb / bands);
+  int n, y0, sx_first, sx_end;
+  int IW = a.W, OW = a.OW;  // widths of the patch's image (ragged batch: the line's own)
+  long ipix0, opix0;        // its first input / output pixel
+  if constexpr (ROWSUM || !rag) {
+    const int strips = rag ? 1 : (a.OW + TO - 1) / TO;
+    sx_first = ROWSUM ? 0 : (int)(sidx % strips);
+    const long nb = ROWSUM ? sidx : sidx / strips;
+    y0 = (int)(nb % bands) * R;
+    n = (int)(nb / bands);
+    if constexpr (rag) { IW = a.rin.w[n]; OW = a.rout.w[n]; }
+    sx_end = ROWSUM ? (OW + TO - 1) / TO : sx_first + 1;
+  } else {
+    n = rag_line_near(a.rwork, a.N, sidx, bands, t_wg / c4n);
+    IW = a.rin.w[n]; OW = a.rout.w[n];
+    const int strips = (OW + TO - 1) / TO;
+    const int rem = (int)(sidx - (long)a.rwork[n] * bands);
+    const int band = rem / strips;
+    y0 = band * R;
+    sx_first = rem - band * strips;
+    sx_end = sx_first + 1;
+  }
+  if constexpr (rag) { ipix0 = (long)a.rin.cw[n] * a.H; opix0 = (long)a.rout.cw[n] * a.OH; }
+  else { ipix0 = (long)n * a.H * a.W; opix0 = (long)n * a.OH * a.OW; }
   struct F4 { ocr_f2 lo, hi; };
   F4 rsum[R];
 #pragma unroll
@@ -739,11 +785,11 @@ __global__ void __launch_bounds__(256, 2) dw_conv_kernel(const DwArgs a, const E
   auto load_row = [&](float4 (&in)[NIN], int j) {
     const int iy = iyb + j;
     const bool rv = j < nrows && iy >= 0 && iy < a.H;
-    const float* row = a.in + (((long)n * a.H + (rv ? iy : 0)) * a.W) * a.Cs + pc;
+    const float* row = a.in + (ipix0 + (long)(rv ? iy : 0) * IW) * a.Cs + pc;
 #pragma unroll
     for (int q = 0; q < NIN; ++q) {
       const int ix = ixb + q;
-      in[q] = (rv && ix >= 0 && ix < a.W) ? *(const float4*)(row + (long)ix * a.Cs) : make_float4(0.f, 0.f, 0.f, 0.f);
+      in[q] = (rv && ix >= 0 && ix < IW) ? *(const float4*)(row + (long)ix * a.Cs) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
   auto use_row = [&](const float4 (&in)[NIN], int j) {
@@ -779,8 +825,8 @@ __global__ void __launch_bounds__(256, 2) dw_conv_kernel(const DwArgs a, const E
     __builtin_amdgcn_sched_barrier(0);
   }
   // epilogue: stage loop outside, the patch inside (one copy of each stage's code)
-  const long obase = (((long)n * a.OH + y0) * a.OW + x0) * a.Cs + pc;
-  const long orow = (long)a.OW * a.Cs;
+  const long obase = (opix0 + (long)y0 * OW + x0) * a.Cs + pc;
+  const long orow = (long)OW * a.Cs;
   for (int s = 0; s < ep.n; ++s) {
     const EpStage& st = ep.st[s];
 #define OCR_DW_SWEEP(BODY)                                       \
@@ -837,7 +883,7 @@ __global__ void __launch_bounds__(256, 2) dw_conv_kernel(const DwArgs a, const E
       } break;
       case EP_ADDT:
         OCR_DW_SWEEP({
-          if (y0 + r < a.OH && x0 + o < a.OW) {
+          if (y0 + r < a.OH && x0 + o < OW) {
             const float4 g = *(const float4*)(st.v0 + obase + r * orow + (long)o * a.Cs);
             ocr_f2 glo;
             ocr_f2 ghi;
@@ -854,7 +900,7 @@ __global__ void __launch_bounds__(256, 2) dw_conv_kernel(const DwArgs a, const E
   for (int r = 0; r < R; ++r)
 #pragma unroll
     for (int o = 0; o < TO; ++o)
-      if (y0 + r < a.OH && x0 + o < a.OW) {
+      if (y0 + r < a.OH && x0 + o < OW) {
         *(float4*)(a.out + obase + r * orow + (long)o * a.Cs) = make_float4(acc[r][o].lo.x, acc[r][o].lo.y, acc[r][o].hi.x, acc[r][o].hi.y);
         if constexpr (ROWSUM) { rsum[r].lo = rsum[r].lo + acc[r][o].lo; rsum[r].hi = rsum[r].hi + acc[r][o].hi; }  // s = s + v, x ascending
       }
@@ -867,49 +913,68 @@ __global__ void __launch_bounds__(256, 2) dw_conv_kernel(const DwArgs a, const E
   }
 }
 
-template <int TO, int R>
+template <int TO, int R, bool RAG>
 static void launch_dw_patch(const DwArgs& a, const Epilogue& ep, hipStream_t s) {
   const unsigned lds = (unsigned)(a.K * a.K * a.Cs * sizeof(float));  // <= 48 KB for 5x5 x 480 channels
   if (a.rowsum) {  // a thread per band: all strips of its rows
     const long bands = (long)a.N * ((a.OH + R - 1) / R) * (a.Cs >> 2);
     dim3 g((unsigned)((bands + 255) / 256));
-    if (a.K == 3 && a.SW == 1) hipLaunchKernelGGL((dw_conv_kernel<3, 1, TO, R, true>), g, dim3(256), lds, s, a, ep);
-    else if (a.K == 3) hipLaunchKernelGGL((dw_conv_kernel<3, 2, TO, R, true>), g, dim3(256), lds, s, a, ep);
-    else if (a.SW == 1) hipLaunchKernelGGL((dw_conv_kernel<5, 1, TO, R, true>), g, dim3(256), lds, s, a, ep);
-    else hipLaunchKernelGGL((dw_conv_kernel<5, 2, TO, R, true>), g, dim3(256), lds, s, a, ep);
+    if (a.K == 3 && a.SW == 1) hipLaunchKernelGGL((dw_conv_kernel<3, 1, TO, R, true, RAG>), g, dim3(256), lds, s, a, ep);
+    else if (a.K == 3) hipLaunchKernelGGL((dw_conv_kernel<3, 2, TO, R, true, RAG>), g, dim3(256), lds, s, a, ep);
+    else if (a.SW == 1) hipLaunchKernelGGL((dw_conv_kernel<5, 1, TO, R, true, RAG>), g, dim3(256), lds, s, a, ep);
+    else hipLaunchKernelGGL((dw_conv_kernel<5, 2, TO, R, true, RAG>), g, dim3(256), lds, s, a, ep);
     return;
   }
-  const long total = (long)a.N * ((a.OH + R - 1) / R) * ((a.OW + TO - 1) / TO) * (a.Cs >> 2);
+  const long total = (RAG ? (long)a.rwork_total : (long)a.N * ((a.OW + TO - 1) / TO)) * ((a.OH + R - 1) / R) * (a.Cs >> 2);
   dim3 grid((unsigned)((total + 255) / 256));
-  if (a.K == 3 && a.SW == 1) hipLaunchKernelGGL((dw_conv_kernel<3, 1, TO, R>), grid, dim3(256), lds, s, a, ep);
-  else if (a.K == 3) hipLaunchKernelGGL((dw_conv_kernel<3, 2, TO, R>), grid, dim3(256), lds, s, a, ep);
-  else if (a.SW == 1) hipLaunchKernelGGL((dw_conv_kernel<5, 1, TO, R>), grid, dim3(256), lds, s, a, ep);
-  else hipLaunchKernelGGL((dw_conv_kernel<5, 2, TO, R>), grid, dim3(256), lds, s, a, ep);
+  if (a.K == 3 && a.SW == 1) hipLaunchKernelGGL((dw_conv_kernel<3, 1, TO, R, false, RAG>), grid, dim3(256), lds, s, a, ep);
+  else if (a.K == 3) hipLaunchKernelGGL((dw_conv_kernel<3, 2, TO, R, false, RAG>), grid, dim3(256), lds, s, a, ep);
+  else if (a.SW == 1) hipLaunchKernelGGL((dw_conv_kernel<5, 1, TO, R, false, RAG>), grid, dim3(256), lds, s, a, ep);
+  else hipLaunchKernelGGL((dw_conv_kernel<5, 2, TO, R, false, RAG>), grid, dim3(256), lds, s, a, ep);
 }
-void launch_dw(const DwArgs& a, const Epilogue& ep, hipStream_t s) {
+// output pixels per thread along x (ragged batch: OW = the narrowest line; the host builds DwArgs::rwork for this value)
+int dw_patch_to(int OW, int SW) {
   // OCR_DW_PATCH=TOxR overrides (A/B measurements; results are identical)
   static const char* env = getenv("OCR_DW_PATCH");
   int to = 8, r = 2;
   if (env) sscanf(env, "%dx%d", &to, &r);
-  if (a.OW < 8 || (a.SW == 2 && !env)) to = 4;  // stride 2 needs 2*TO+K-2 pixels per row buffer: 8 wide does not fit the registers
+  if (OW < 8 || (SW == 2 && !env)) to = 4;  // stride 2 needs 2*TO+K-2 pixels per row buffer: 8 wide does not fit the registers
+  return to == 8 ? 8 : 4;
+}
+void launch_dw(const DwArgs& a, const Epilogue& ep, hipStream_t s) {
+  static const char* env = getenv("OCR_DW_PATCH");
+  int to = 8, r = 2;
+  if (env) sscanf(env, "%dx%d", &to, &r);
+  to = dw_patch_to(a.OW, a.SW);
   if (a.OH < 2) r = 1;
-  if (to == 8 && r == 2) launch_dw_patch<8, 2>(a, ep, s);
-  else if (to == 8) launch_dw_patch<8, 1>(a, ep, s);
-  else if (r == 2) launch_dw_patch<4, 2>(a, ep, s);
-  else launch_dw_patch<4, 1>(a, ep, s);
+  if (a.rout.w) {  // ragged batch (the recognizer)
+    if (to == 8 && r == 2) launch_dw_patch<8, 2, true>(a, ep, s);
+    else if (to == 8) launch_dw_patch<8, 1, true>(a, ep, s);
+    else if (r == 2) launch_dw_patch<4, 2, true>(a, ep, s);
+    else launch_dw_patch<4, 1, true>(a, ep, s);
+    return;
+  }
+  if (to == 8 && r == 2) launch_dw_patch<8, 2, false>(a, ep, s);
+  else if (to == 8) launch_dw_patch<8, 1, false>(a, ep, s);
+  else if (r == 2) launch_dw_patch<4, 2, false>(a, ep, s);
+  else launch_dw_patch<4, 1, false>(a, ep, s);
 }
 
 // =====================================================================================
 // Elementwise chain (SE gate multiply, residual add, FPN upsample-add).
 // =====================================================================================
 __global__ void __launch_bounds__(256) ew_kernel(const float* __restrict__ in, float* __restrict__ out, long M, int H,
-                                                 int W, int Cs, const Epilogue ep) {
+                                                 int W, int Cs, const Epilogue ep, int N, const RagLevel rag) {
   const long t = (long)blockIdx.x * 256 + threadIdx.x;
   const int c4n = Cs >> 2;
   if (t >= M * c4n) return;
   const long m = t / c4n;
   const int pc = (int)(t - m * c4n) * 4;
   int n, y, x;
+  if (rag.w) {  // ragged batch: the line of this pixel (per-line stages: the SE gate); no upsampled operands (host)
+    int w;
+    rag_decompose(rag, N, H, m, (long)blockIdx.x * 256 / c4n, n, y, x, w);
+  } else
   decompose(m, H * W, W, n, y, x);
   const long idx = m * Cs + pc;
   float4 v = *(const float4*)(in + idx);
@@ -917,16 +982,16 @@ __global__ void __launch_bounds__(256) ew_kernel(const float* __restrict__ in, f
   *(float4*)(out + idx) = v;
 }
 
-void launch_ew(const float* in, float* out, long M, int H, int W, int Cs, const Epilogue& ep, hipStream_t s) {
+void launch_ew(const float* in, float* out, long M, int H, int W, int Cs, const Epilogue& ep, hipStream_t s, int N, RagLevel rag) {
   const long total = M * (Cs >> 2);
-  hipLaunchKernelGGL(ew_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, out, M, H, W, Cs, ep);
+  hipLaunchKernelGGL(ew_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, out, M, H, W, Cs, ep, N, rag);
 }
 
 // =====================================================================================
 // Global average pool in the contract's order: row-sequential sums, then column-sequential.
 // =====================================================================================
 __global__ void __launch_bounds__(256) gap_rows_kernel(const float* __restrict__ in, float* __restrict__ part, int N,
-                                                       int H, int W, int Cs) {
+                                                       int H, int W, int Cs, const RagLevel rag) {
   // one thread = 4 physical channels of one image row: four independent sequential sums, 16-byte loads
   const int c4n = Cs >> 2;
   const long t = (long)blockIdx.x * 256 + threadIdx.x;
@@ -934,6 +999,11 @@ __global__ void __launch_bounds__(256) gap_rows_kernel(const float* __restrict__
   const int pc = (int)(t % c4n) * 4;
   const long ny = t / c4n;
   const float* src = in + ny * W * Cs + pc;
+  if (rag.w) {  // ragged batch: row y of line n, the line's own width
+    const int n = (int)(ny / H), y = (int)(ny - (long)n * H);
+    W = rag.w[n];
+    src = in + ((long)rag.cw[n] * H + (long)y * W) * Cs + pc;
+  }
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   // eight loads in flight, then their eight sequential adds (the sum's order is the contract's: left to right)
   constexpr int U = 8;
@@ -952,23 +1022,24 @@ __global__ void __launch_bounds__(256) gap_rows_kernel(const float* __restrict__
   *(float4*)(part + ny * Cs + pc) = s;
 }
 __global__ void __launch_bounds__(256) gap_cols_kernel(const float* __restrict__ part, float* __restrict__ out, int N,
-                                                       int H, int Cs, float cnt) {
+                                                       int H, int Cs, float cnt, const RagLevel rag) {
   const int t = blockIdx.x * 256 + threadIdx.x;
   if (t >= N * Cs) return;
   const int pc = t % Cs, n = t / Cs;
+  if (rag.w) cnt = (float)(H * rag.w[n]);  // ragged batch: the line's own pixel count
   const float* src = part + (long)n * H * Cs + pc;
   float s = 0.f;
   for (int y = 0; y < H; ++y) s = s + src[(long)y * Cs];
   out[t] = s / cnt;
 }
-void launch_gap_cols(const float* part, float* out, int N, int H, int W, int Cs, hipStream_t s) {
-  hipLaunchKernelGGL(gap_cols_kernel, dim3((unsigned)((N * Cs + 255) / 256)), dim3(256), 0, s, part, out, N, H, Cs, (float)(H * W));
+void launch_gap_cols(const float* part, float* out, int N, int H, int W, int Cs, hipStream_t s, RagLevel rag) {
+  hipLaunchKernelGGL(gap_cols_kernel, dim3((unsigned)((N * Cs + 255) / 256)), dim3(256), 0, s, part, out, N, H, Cs, (float)(H * W), rag);
 }
-void launch_gap(const float* in, float* part, float* out, int N, int H, int W, int Cs, hipStream_t s) {
+void launch_gap(const float* in, float* part, float* out, int N, int H, int W, int Cs, hipStream_t s, RagLevel rag) {
   const long t1 = (long)N * H * (Cs >> 2);
-  hipLaunchKernelGGL(gap_rows_kernel, dim3((unsigned)((t1 + 255) / 256)), dim3(256), 0, s, in, part, N, H, W, Cs);
+  hipLaunchKernelGGL(gap_rows_kernel, dim3((unsigned)((t1 + 255) / 256)), dim3(256), 0, s, in, part, N, H, W, Cs, rag);
   hipLaunchKernelGGL(gap_cols_kernel, dim3((unsigned)((N * Cs + 255) / 256)), dim3(256), 0, s, part, out, N, H, Cs,
-                     (float)(H * W));
+                     (float)(H * W), rag);
 }
 
 // =====================================================================================
@@ -1038,20 +1109,31 @@ void launch_concat(const ConcatArgs& a, hipStream_t s) {
 // Pooling without padding (rec avg k(3,2)s(3,2) incl. the H=2 truncation quirk; cls max 2x2).
 // =====================================================================================
 __global__ void __launch_bounds__(256) pool_kernel(const PoolArgs a) {
-  const long t = (long)xcd_swizzle(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
+  const long t_wg = (long)xcd_swizzle(blockIdx.x, gridDim.x) * 256;
+  const long t = t_wg + threadIdx.x;
   const int c4n = a.Cs >> 2;
   if (t >= a.M * c4n) return;
   const long m = t / c4n;
   const int pc = (int)(t - m * c4n) * 4;
   int n, y, x;
-  decompose(m, a.OH * a.OW, a.OW, n, y, x);
+  int IW = a.W;
+  long ipix0;
+  if (a.rout.w) {  // ragged batch: the line's own widths
+    int ow;
+    rag_decompose(a.rout, a.N, a.OH, m, t_wg / c4n, n, y, x, ow);
+    IW = a.rin.w[n];
+    ipix0 = (long)a.rin.cw[n] * a.H;
+  } else {
+    decompose(m, a.OH * a.OW, a.OW, n, y, x);
+    ipix0 = (long)n * a.H * a.W;
+  }
   float4 acc = a.is_max ? make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY) : make_float4(0.f, 0.f, 0.f, 0.f);
   int cnt = 0;
   for (int dy = 0; dy < a.KH; ++dy)
     for (int dx = 0; dx < a.KW; ++dx) {
       const int iy = y * a.SH + dy, ix = x * a.SW + dx;
-      if (iy >= a.H || ix >= a.W) continue;
-      const float4 v = *(const float4*)(a.in + (((long)n * a.H + iy) * a.W + ix) * a.Cs + pc);
+      if (iy >= a.H || ix >= IW) continue;
+      const float4 v = *(const float4*)(a.in + (ipix0 + (long)iy * IW + ix) * a.Cs + pc);
       if (a.is_max) {
         acc.x = fmaxf(acc.x, v.x); acc.y = fmaxf(acc.y, v.y); acc.z = fmaxf(acc.z, v.z); acc.w = fmaxf(acc.w, v.w);
       } else {
@@ -1234,17 +1316,19 @@ __global__ void __launch_bounds__(64) attn_kernel(const float* __restrict__ qkv,
 // attn_kernel's per-thread global walks cost 0.3-1.1 ms per call regardless of size (rocprof r1).
 template <int HD>
 __global__ void __launch_bounds__(64) attn_lds_kernel(const float* __restrict__ qkv, float* __restrict__ out, int N, int T,
-                                                      int heads, int Cs_in, int Cs_out, float scale) {
+                                                      int heads, int Cs_in, int Cs_out, float scale, const RagLevel rag) {
   static_assert(HD <= 16, "head rows are padded to 16 floats");
   extern __shared__ float s_att[];
+  const int lane = threadIdx.x;
+  const int hh = blockIdx.x % heads, n = blockIdx.x / heads;
+  long row0 = (long)n * T;            // the line's first token
+  if (rag.w) { T = rag.w[n]; row0 = rag.cw[n]; }  // ragged batch: the line's own length (LDS is sized for the longest)
   float* s_k = s_att;                 // [T][16]
   float* s_v = s_k + (long)T * 16;    // [T][16]
   float* s_q = s_v + (long)T * 16;    // [64][17]
   float* s_e = s_q + 64 * 17;         // [T][64]
-  const int lane = threadIdx.x;
-  const int hh = blockIdx.x % heads, n = blockIdx.x / heads;
   const int D = heads * HD;
-  const float* base = qkv + (long)n * T * Cs_in;
+  const float* base = qkv + row0 * Cs_in;
   for (int i = lane; i < T * 32; i += 64) {
     const int u = i >> 5, which = (i >> 4) & 1, d = i & 15;
     float val = 0.f;
@@ -1291,24 +1375,26 @@ __global__ void __launch_bounds__(64) attn_lds_kernel(const float* __restrict__ 
 #pragma unroll
         for (int d = 0; d < HD; ++d) o[d] = fmaf(pw, vr[d], o[d]);
       }
-      float* dst = out + ((long)n * T + t) * Cs_out;
+      float* dst = out + (row0 + t) * Cs_out;
 #pragma unroll
       for (int d = 0; d < HD; ++d) dst[c8i_phys(hh * HD + d)] = o[d];
     }
   }
 }
 
+bool attn_ragged_fits(int T) { return ((size_t)T * 96 + 64 * 17) * sizeof(float) <= 150 * 1024; }
 void launch_attn(const float* qkv, float* out, int N, int T, int heads, int hd, int Cs_in, int Cs_out, float scale,
-                 hipStream_t s) {
+                 hipStream_t s, RagLevel rag) {
   const size_t lds = ((size_t)T * 96 + 64 * 17) * sizeof(float);
   if (lds <= 150 * 1024) {
-    static unsigned char attr_state[64] = {};  // per device: the pool drives several from one process
+    static LdsAttrMemo attr_state;  // per device: the pool drives several from one process
     if (lds <= 64 * 1024 || raise_dynamic_lds((const void*)attn_lds_kernel<15>, 150 * 1024, attr_state)) {
       hipLaunchKernelGGL(attn_lds_kernel<15>, dim3((unsigned)(N * heads)), dim3(64), lds, s, qkv, out, N, T, heads, Cs_in,
-                         Cs_out, scale);
+                         Cs_out, scale, rag);
       return;
     }
   }
+  if (rag.w) { fprintf(stderr, "launch_attn: a ragged batch needs the LDS form (attn_ragged_fits)\n"); return; }
   const long total = (long)N * heads * T;
   // hd is 15 for the only attention block on the path (rec plan); the runtime checks it at load.
   hipLaunchKernelGGL(attn_kernel<15>, dim3((unsigned)((total + 63) / 64)), dim3(64), 0, s, qkv, out, N, T, heads, Cs_in,

@@ -1425,7 +1425,7 @@ void launch_post(const PostArgs& a, int N, int* out_boxes, int cap, int* out_n, 
   const size_t lds = ((size_t)(a.H + 2) * lds_bits_stride(a.W) + 2 * (size_t)a.max_cand) * sizeof(unsigned);  // bitmap bits + sizes + offsets
   bool in_lds = lds <= 150 * 1024;  // 960x960: 119 KB
   if (in_lds && lds > 64 * 1024) {  // more than the default dynamic LDS limit: raise it, per device
-    static unsigned char attr_state[64] = {};
+    static LdsAttrMemo attr_state;
     in_lds = raise_dynamic_lds((const void*)trace_lds_kernel, 150 * 1024, attr_state);  // refused: the global-bitmap kernels below
   }
   if (in_lds) {

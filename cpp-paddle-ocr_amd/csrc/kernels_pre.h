@@ -26,8 +26,11 @@ struct LineDesc {
   // cv::resize's scale factors of this line, 1 / ((double)dst / src) per axis, computed once on the host (the same two
   // IEEE double operations the kernel used to repeat in every thread: four f64 divisions were 40 % of its instructions)
   double scale_x, scale_y;
+  // ragged batch (launch_line_pre_ragged / launch_ctc_ragged): the line's own tensor width, its first pixel in the
+  // batch tensor (= imgH * the widths of the lines before it), and where its CTC steps sit in the step arrays
+  int tensor_w = 0, pix0 = 0, step0 = 0, steps = 0;
   static LineDesc make(const uint8_t* img, size_t stride, int x, int y, int w, int h, int resize_w, int slot, int imgH) {
-    LineDesc d{img, stride, x, y, w, h, resize_w, slot, 0.0, 0.0};
+    LineDesc d{img, stride, x, y, w, h, resize_w, slot, 0.0, 0.0, 0, 0, 0, 0};
     const double inv_x = (double)resize_w / w, inv_y = (double)imgH / h;
     d.scale_x = 1. / inv_x;
     d.scale_y = 1. / inv_y;
@@ -56,7 +59,13 @@ struct WarpDesc {
   double m[9];
 };
 void launch_warp_crops(const WarpDesc* d, int ncrops, int max_pixels, hipStream_t s);
+// ragged batch: line i = [imgH][lines[i].tensor_w][3] at pixel lines[i].pix0 of `out` (lines ordered by pix0)
+void launch_line_pre_ragged(const LineDesc* lines, int nlines, long total_pixels, int imgH, const float* lut, float* out,
+                            hipStream_t s);
 void launch_ctc(const int* amax, const float* pmax, int nlines, int T, int max_len, int* ids, int* lens, float* scores,
                 hipStream_t s);
+// ragged batch: line i has lines[i].steps steps starting at lines[i].step0 of amax / pmax
+void launch_ctc_ragged(const int* amax, const float* pmax, const LineDesc* lines, int nlines, int max_len, int* ids, int* lens,
+                       float* scores, hipStream_t s);
 
 }  // namespace ocr

@@ -225,6 +225,42 @@ void launch_line_pre(const LineDesc* lines, int nlines, int imgH, int imgW, cons
                        pad_after_norm ? 0.0f : 1.0f, out);
 }
 
+// Ragged batch (rec): every line has its own tensor width (kernels_net.h, RagLevel); one thread per output pixel, the
+// line found from the pixel index (lines[i].pix0 ascending).  Same per-pixel arithmetic as line_pre_kernel; the pad is
+// the recognizer's (u8 zero BEFORE normalisation, /root/reference/src/preprocess_op.cpp:115-117).
+__global__ void __launch_bounds__(256) line_pre_ragged_kernel(const LineDesc* __restrict__ lines, int nlines, long total, int imgH,
+                                                              const float* __restrict__ lut, float* __restrict__ out) {
+  __shared__ float s_lut[768];
+  for (int i = threadIdx.x; i < 768; i += 256) s_lut[i] = lut[i];
+  __syncthreads();
+  const long t0 = (long)blockIdx.x * 256, t = t0 + threadIdx.x;
+  if (t >= total) return;
+  int lo = 0, hi = nlines;  // the workgroup's first pixel (uniform), then forward: a workgroup spans a line or two
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if ((long)lines[mid].pix0 <= t0) lo = mid;
+    else hi = mid;
+  }
+  while (lo + 1 < nlines && (long)lines[lo + 1].pix0 <= t) ++lo;
+  const LineDesc L = lines[lo];
+  const int r = (int)(t - L.pix0);
+  const int dy = r / L.tensor_w, dx = r - dy * L.tensor_w;
+  const bool pad = dx >= L.resize_w;
+  uint8_t px[3];
+  resize_px_scaled(L.img + (size_t)L.y * L.stride + (size_t)L.x * 3, L.stride, L.h, L.w, imgH, L.resize_w, L.scale_x, L.scale_y, dy,
+                   pad ? L.resize_w - 1 : dx, px);  // pad columns: a valid pixel is read and dropped
+  float* o = out + t * 3;
+  o[0] = s_lut[pad ? 0 : px[0]];
+  o[1] = s_lut[256 + (pad ? 0 : px[1])];
+  o[2] = s_lut[512 + (pad ? 0 : px[2])];
+}
+void launch_line_pre_ragged(const LineDesc* lines, int nlines, long total_pixels, int imgH, const float* lut, float* out,
+                            hipStream_t s) {
+  if (total_pixels <= 0) return;
+  hipLaunchKernelGGL(line_pre_ragged_kernel, dim3((unsigned)((total_pixels + 255) / 256)), dim3(256), 0, s, lines, nlines, total_pixels,
+                     imgH, lut, out);
+}
+
 // cv::rotate(roi, roi, ROTATE_180) in place: pixel i <-> total-1-i
 __global__ void __launch_bounds__(256) rotate180_kernel(uint8_t* img, size_t stride, int x0, int y0, int w, int h) {
   const long total = (long)w * h;
@@ -354,11 +390,13 @@ void launch_warp_crops(const WarpDesc* d, int ncrops, int max_pixels, hipStream_
 // greedy CTC collapse, one thread per line (sequential over T: the score sum order of the reference)
 __global__ void __launch_bounds__(64) ctc_kernel(const int* __restrict__ amax, const float* __restrict__ pmax, int nlines,
                                                  int T, int max_len, int* __restrict__ ids, int* __restrict__ lens,
-                                                 float* __restrict__ scores) {
+                                                 float* __restrict__ scores, const LineDesc* __restrict__ lines) {
   const int li = blockIdx.x * 64 + threadIdx.x;
   if (li >= nlines) return;
-  const int* am = amax + (long)li * T;
-  const float* pm = pmax + (long)li * T;
+  long first = (long)li * T;
+  if (lines) { first = lines[li].step0; T = lines[li].steps; }  // ragged batch: the line's own step count
+  const int* am = amax + first;
+  const float* pm = pmax + first;
   int last = 0, count = 0;
   float s = 0.f;
   for (int n = 0; n < T; ++n) {
@@ -376,7 +414,13 @@ __global__ void __launch_bounds__(64) ctc_kernel(const int* __restrict__ amax, c
 void launch_ctc(const int* amax, const float* pmax, int nlines, int T, int max_len, int* ids, int* lens, float* scores,
                 hipStream_t s) {
   if (nlines <= 0) return;
-  hipLaunchKernelGGL(ctc_kernel, dim3((nlines + 63) / 64), dim3(64), 0, s, amax, pmax, nlines, T, max_len, ids, lens, scores);
+  hipLaunchKernelGGL(ctc_kernel, dim3((nlines + 63) / 64), dim3(64), 0, s, amax, pmax, nlines, T, max_len, ids, lens, scores,
+                     (const LineDesc*)nullptr);
+}
+void launch_ctc_ragged(const int* amax, const float* pmax, const LineDesc* lines, int nlines, int max_len, int* ids, int* lens,
+                       float* scores, hipStream_t s) {
+  if (nlines <= 0) return;
+  hipLaunchKernelGGL(ctc_kernel, dim3((nlines + 63) / 64), dim3(64), 0, s, amax, pmax, nlines, 0, max_len, ids, lens, scores, lines);
 }
 
 }  // namespace ocr

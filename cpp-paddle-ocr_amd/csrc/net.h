@@ -50,7 +50,12 @@ struct TensorDesc {
   int n = 0, h = 0, w = 0, c = 0, cs = 0;
   bool plain = false;  // logical channel order, cs == c
   size_t offset = 0;   // floats into the arena
-  size_t numel() const { return (size_t)n * h * w * cs; }
+  // ragged batch (Net::run_ragged): the tensor's width level (-1: a uniform tensor, e.g. the per-line SE vectors) and
+  // its pixel count h * sum of the lines' widths at that level; `w` is then the widest line
+  int lvl = -1;
+  long pix = 0;
+  long pixels() const { return lvl >= 0 ? pix : (long)n * h * w; }
+  size_t numel() const { return (size_t)pixels() * cs; }
 };
 
 struct KernelTiming {
@@ -67,6 +72,16 @@ class Net {
   // Binds shapes (re-planning arena + launches if they changed) and enqueues the network.
   // x: device f32 [N,H,W,3] plain NHWC (already normalised).
   bool run(const float* x, int N, int H, int W, hipStream_t s, std::string& err);
+  // Ragged batch (the recognizer): N text lines of height H, line n of width widths[n]; x = the lines' [H][w][3]
+  // blocks one after the other.  One launch list for all widths (kernels_net.h, RagLevel); every line's results are
+  // those of a run of that line alone.  bind_ragged alone prepares the binding (so that the caller can ask for the
+  // output widths before it fills x); run_ragged binds if needed.
+  bool bind_ragged(int H, const int* widths, int N, std::string& err);
+  bool run_ragged(const float* x, int H, const int* widths, int N, hipStream_t s, std::string& err);
+  // line widths of tensor `tid` under the current ragged binding (host copy), e.g. the CTC step counts of the output
+  const std::vector<int>& ragged_widths(int tid) const;
+  // can this many lines / pixels go into one ragged launch? (32-bit pixel indices, attention working set)
+  static bool ragged_ok(int H, const int* widths, int N, std::string& why);
   const TensorDesc& tensor(int tid) const { return tensors_[tid]; }
   const float* tensor_ptr(int tid) const { return arena_ + tensors_[tid].offset; }
   int output_tid() const { return out_tid_; }
@@ -113,8 +128,22 @@ class Net {
   // been seen twice in a row) the hipGraph of that list.  Bindings are cached per (N, H, W): a mixed-size request
   // stream (BASELINE configs[2]) and the rec lanes' odd widths come back to shapes they have seen without
   // re-planning or re-recording.  Launches hold arena pointers: whatever moves the arena drops the cache.
+  // device memory of the ragged bindings' line tables: handed back when a binding dies, freed with the network
+  struct TablePool {
+    std::vector<std::pair<int*, size_t>> free_list;
+    ~TablePool() { for (auto& e : free_list) (void)hipFree(e.first); }
+  };
   struct Binding {
     int n = 0, h = 0, w = 0;
+    // ragged batch: the lines' widths per level, the packed tables (per level: w[N], cw[N+1], and the prefix sums of
+    // ceil(w / 16), ceil(w / 8), ceil(w / 4), N + 2 entries each) on the host and on the device
+    std::vector<int> widths;
+    std::vector<std::vector<int>> level_w;
+    std::vector<int> rag_host;
+    int* rag_dev = nullptr;
+    size_t rag_cap = 0;
+    bool rag_uploaded = false;
+    std::shared_ptr<TablePool> pool;
     std::vector<TensorDesc> tensors;
     std::vector<char> exists;        // per plan tensor: written to HBM by this binding's launches
     std::vector<Launch> launches;
@@ -125,11 +154,19 @@ class Net {
     const float* last_x = nullptr;   // input of the previous run of this binding
     bool graph_failed = false;       // capture was refused once: plain launches from then on
     unsigned long stamp = 0;         // LRU
-    ~Binding() { if (graph_exec) (void)hipGraphExecDestroy(graph_exec); }
+    ~Binding() {
+      if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
+      if (rag_dev && pool) pool->free_list.emplace_back(rag_dev, rag_cap);
+      else if (rag_dev) (void)hipFree(rag_dev);
+    }
   };
+  std::shared_ptr<TablePool> pool_ = std::make_shared<TablePool>();
+  static constexpr size_t kMaxRaggedBindings = 32;
   static constexpr size_t kMaxBindings = 512;  // a mixed-size stream revisits sizes: BASELINE configs[2] has ~400 distinct det shapes
   void invalidate() { cache_.clear(); cur_ = nullptr; }
-  bool bind(int N, int H, int W, std::string& err);
+  bool bind(int N, int H, int W, std::string& err, const int* widths = nullptr);
+  bool run_bound(const float* x, hipStream_t s, std::string& err);
+  static std::vector<int> shape_key(int N, int H, int W, const int* widths);
   bool build_epilogue(const PlanOp& op, Epilogue& ep, bool conv_path, std::string& err);
   const float* dev_vec(const std::string& key) const;
   float* upload(const std::string& key, const std::vector<float>& v);
@@ -139,7 +176,7 @@ class Net {
   std::map<std::string, float> scalars_;
   WeightMap host_w_;                          // kept only for scalar lookups / shapes
   std::vector<TensorDesc> tensors_;           // shapes/offsets of the current binding (plain flags fixed at load)
-  std::map<std::array<int, 3>, std::unique_ptr<Binding>> cache_;
+  std::map<std::vector<int>, std::unique_ptr<Binding>> cache_;  // key: shape_key
   Binding* cur_ = nullptr;
   unsigned long clock_ = 0;
   float* arena_ = nullptr;

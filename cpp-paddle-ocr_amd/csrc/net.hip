@@ -368,9 +368,43 @@ bool Net::build_epilogue(const PlanOp& op, Epilogue& ep, bool conv_path, std::st
 }
 
 // ------------------------------------------------------------------ shape binding
-bool Net::bind(int N, int H, int W, std::string& err) {
+std::vector<int> Net::shape_key(int N, int H, int W, const int* widths) {
+  if (!widths) return {N, H, W};
+  std::vector<int> k = {-1, H};  // ragged: run lengths of the lines' widths, in line order
+  for (int i = 0; i < N;) {
+    int j = i;
+    while (j < N && widths[j] == widths[i]) ++j;
+    k.push_back(widths[i]);
+    k.push_back(j - i);
+    i = j;
+  }
+  return k;
+}
+
+bool Net::ragged_ok(int H, const int* widths, int N, std::string& why) {
+  long pix = 0;
+  int wmax = 0;
+  for (int i = 0; i < N; ++i) {
+    if (widths[i] < 1) { why = "line width < 1"; return false; }
+    pix += (long)H * widths[i];
+    wmax = std::max(wmax, widths[i]);
+  }
+  if (N < 1 || pix >= (1L << 30)) { why = "too many pixels for one ragged launch"; return false; }
+  if (!attn_ragged_fits(wmax / 8 + 2)) { why = "line too wide for the ragged attention kernel"; return false; }
+  return true;
+}
+
+const std::vector<int>& Net::ragged_widths(int tid) const {
+  static const std::vector<int> none;
+  if (!cur_ || tid < 0 || tid >= (int)tensors_.size() || tensors_[tid].lvl < 0) return none;
+  return cur_->level_w[tensors_[tid].lvl];
+}
+
+bool Net::bind(int N, int H, int W, std::string& err, const int* widths) {
   std::unique_ptr<Binding> B(new Binding());
+  const bool rag = widths != nullptr;
   B->n = N; B->h = H; B->w = W;
+  B->pool = pool_;
   std::vector<Launch>& launches_ = B->launches;
   bool moved = false;  // a shared device buffer was reallocated: the other bindings' launches point into the old one
   fused_head_rows_ = -1;
@@ -379,9 +413,76 @@ bool Net::bind(int N, int H, int W, std::string& err) {
   auto setdims = [&](int t, int n, int h, int w, int c) {
     T[t].n = n; T[t].h = h; T[t].w = w; T[t].c = c;
     T[t].cs = T[t].plain ? c : c8i_stride(c);
+    T[t].lvl = -1; T[t].pix = 0;
   };
-  setdims(0, N, H, W, 3);
+  // ragged batch: width levels.  A level = the lines' widths after some chain of (kernel, stride, pad) along x;
+  // ops that keep the width stay on their input's level.
+  std::vector<std::vector<int>>& LW = B->level_w;
+  std::vector<long> ltot;
+  std::vector<int> lmax, lmin;
+  auto add_level = [&](std::vector<int> w) -> int {
+    for (size_t l = 0; l < LW.size(); ++l) if (LW[l] == w) return (int)l;
+    long tot = 0;
+    int mx = 0, mn = 0x7fffffff;
+    for (int v : w) { tot += v; mx = std::max(mx, v); mn = std::min(mn, v); }
+    LW.push_back(std::move(w));
+    ltot.push_back(tot); lmax.push_back(mx); lmin.push_back(mn);
+    return (int)LW.size() - 1;
+  };
+  auto derive = [&](int lvl, int k, int s, int p) -> int {  // < 0: a line got too narrow
+    if (k == 1 && s == 1 && p == 0) return lvl;
+    std::vector<int> w(LW[lvl].size());
+    for (size_t i = 0; i < w.size(); ++i) {
+      w[i] = (LW[lvl][i] + 2 * p - k) / s + 1;  // C++ truncation, as the uniform shapes below
+      if (LW[lvl][i] + 2 * p - k < 0 || w[i] <= 0) return -1;
+    }
+    return add_level(std::move(w));
+  };
+  auto setrag = [&](int t, int h, int lvl, int c) {
+    setdims(t, N, h, lmax[lvl], c);
+    T[t].lvl = lvl;
+    T[t].pix = (long)h * ltot[lvl];
+  };
+  if (rag) {
+    B->widths.assign(widths, widths + N);
+    setrag(0, H, add_level(B->widths), 3);
+  } else setdims(0, N, H, W, 3);
   for (auto& op : plan_.ops) {
+    if (rag && op.kind != PlanOp::OUTPUT) {
+      const TensorDesc& i = T[op.kind == PlanOp::CONCAT ? op.ins.back() : op.in];
+      int lvl = i.lvl, oh = i.h, oc = i.c;
+      bool per_line = false;  // the op's output is one vector per line
+      switch (op.kind) {
+        case PlanOp::CONV: case PlanOp::DW:
+          if (lvl < 0) { err = "ragged batch: spatial op on a per-line vector"; return false; }
+          oh = (i.h + 2 * op.ph - op.kh) / op.sh + 1;
+          lvl = derive(lvl, op.kw, op.sw, op.pw);
+          oc = op.kind == PlanOp::CONV ? op.cout : op.c;
+          break;
+        case PlanOp::POOL:
+          if (lvl < 0) { err = "ragged batch: spatial op on a per-line vector"; return false; }
+          oh = (i.h - op.kh) / op.sh + 1;
+          lvl = derive(lvl, op.kw, op.sw, 0);
+          oc = op.c;
+          break;
+        case PlanOp::LINEAR: oc = op.cout; break;
+        case PlanOp::SEFC: case PlanOp::GAP: per_line = true; oc = op.c; break;
+        case PlanOp::EW: case PlanOp::LN: case PlanOp::SOFTMAX: break;
+        case PlanOp::CONCAT:
+          for (size_t j = 0; j < op.ins.size(); ++j)
+            if (op.ups[j] != 1 || T[op.ins[j]].lvl != lvl || T[op.ins[j]].h != oh) { err = "ragged batch: concat of different resolutions is not on this path"; return false; }
+          oc = op.c;
+          break;
+        case PlanOp::ATTN: oc = op.heads * op.hd; break;
+        default: err = "ragged batch: op kind not on this path (transposed conv)"; return false;
+      }
+      if (per_line) { setdims(op.out, N, 1, 1, oc); continue; }
+      if (lvl < 0 && T[op.in].lvl >= 0) { err = "input too small for the network"; return false; }
+      if (lvl < 0) { setdims(op.out, i.n, i.h, i.w, oc); continue; }  // per-line vector -> per-line vector (sefc chain)
+      if (oh <= 0) { err = "input too small for the network"; return false; }
+      setrag(op.out, oh, lvl, oc);
+      continue;
+    }
     switch (op.kind) {
       case PlanOp::CONV: {
         auto& i = T[op.in];
@@ -408,6 +509,51 @@ bool Net::bind(int N, int H, int W, std::string& err) {
     }
     if (op.out >= 0 && (T[op.out].h <= 0 || T[op.out].w <= 0)) { err = "input too small for the network"; return false; }
   }
+  // ragged batch: the line tables, packed: per level  w[N] | cw[N+1] | prefix sums of ceil(w/16), ceil(w/8), ceil(w/4)
+  // (N+2 entries each: the fused depthwise kernel's tile walk reads one entry past N)
+  const size_t lstride = rag ? (size_t)N + (N + 1) + 3 * ((size_t)N + 2) : 0;
+  if (rag) {
+    B->rag_host.assign(lstride * LW.size(), 0);
+    for (size_t l = 0; l < LW.size(); ++l) {
+      int* w = B->rag_host.data() + l * lstride;
+      int* cw = w + N;
+      int* ct[3] = {cw + N + 1, cw + N + 1 + (N + 2), cw + N + 1 + 2 * (N + 2)};
+      const int div[3] = {16, 8, 4};
+      for (int i = 0; i < N; ++i) {
+        w[i] = LW[l][i];
+        cw[i + 1] = cw[i] + w[i];
+        for (int d = 0; d < 3; ++d) ct[d][i + 1] = ct[d][i] + (w[i] + div[d] - 1) / div[d];
+      }
+      for (int d = 0; d < 3; ++d) ct[d][N + 1] = ct[d][N];
+    }
+    const size_t need = B->rag_host.size();
+    for (size_t i = 0; i < pool_->free_list.size(); ++i)
+      if (pool_->free_list[i].second >= need) {
+        B->rag_dev = pool_->free_list[i].first;
+        B->rag_cap = pool_->free_list[i].second;
+        pool_->free_list.erase(pool_->free_list.begin() + i);
+        break;
+      }
+    if (!B->rag_dev) {
+      const size_t cap = need + need / 2;
+      HIP_OK(hipMalloc(&B->rag_dev, cap * sizeof(int)));
+      B->rag_cap = cap;
+    }
+  }
+  const int* rag_dev = B->rag_dev;
+  auto rlevel = [&](const TensorDesc& t) {
+    RagLevel r;
+    if (rag && t.lvl >= 0) { r.w = rag_dev + (size_t)t.lvl * lstride; r.cw = r.w + N; }
+    return r;
+  };
+  auto rwork = [&](const TensorDesc& t, int div) -> const int* {  // prefix sums of ceil(w / div), div in {16, 8, 4}
+    return rag_dev + (size_t)t.lvl * lstride + N + (N + 1) + (div == 16 ? 0 : div == 8 ? 1 : 2) * ((size_t)N + 2);
+  };
+  auto rwork_total = [&](const TensorDesc& t, int div) {
+    long tot = 0;
+    for (int v : LW[t.lvl]) tot += (v + div - 1) / div;
+    return (int)tot;
+  };
   // 2. arena with liveness reuse
   const int nops = (int)plan_.ops.size();
   // SE gate folding: `ew x -> x * gate[n][c]` whose only reader is a 1x1 conv disappears - the conv reads x and
@@ -431,7 +577,7 @@ bool Net::bind(int N, int H, int W, std::string& err) {
         auto& c = plan_.ops[oj];
         if (c.in != op.out) continue;
         const bool one = c.kind == PlanOp::CONV && c.kh == 1 && c.kw == 1 && c.sh == 1 && c.sw == 1 && c.ph == 0 && c.pw == 0 && c.cin != 3;
-        if (one && !T[c.out].plain && (long)T[op.in].n * T[op.in].h * T[op.in].w < 0x7fffffffL) {
+        if (one && !T[c.out].plain && T[op.in].pixels() < 0x7fffffffL) {
           folded[oi] = 1;
           gate_src[oj] = op.in;
           gate_tid[oj] = op.ep[0].tid;
@@ -466,6 +612,7 @@ bool Net::bind(int N, int H, int W, std::string& err) {
           const int tiles = (T[c.out].cs + 31) / 32, nt = conv_nt_for(tiles);
           q.c.NTtot = (tiles + nt - 1) / nt * nt;
           q.dw_ep.act = q.pw_ep.act = 1;
+          if (rag) q.rtiles = rag_dev;  // (the ragged instantiation is its own kernel: own LDS attribute)
           if (d.kh == d.kw && launch_dwpw(q, nullptr, true)) dwpw_of[oj] = oi;
         }
         break;
@@ -599,7 +746,8 @@ bool Net::bind(int N, int H, int W, std::string& err) {
           a.out = optr; a.w = dev_vec("stem:" + op.w);
           a.N = in.n; a.H = in.h; a.W = in.w; a.OH = o.h; a.OW = o.w; a.Cs_out = o.cs;
           a.KH = op.kh; a.KW = op.kw; a.SH = op.sh; a.SW = op.sw; a.PH = op.ph; a.PW = op.pw;
-          a.M = (long)o.n * o.h * o.w;
+          a.M = o.pixels();
+          a.rin = rlevel(in); a.rout = rlevel(o);
           if (o.cs != 8 && o.cs != 16) { err = "stem width not on this path"; return false; }
           snprintf(nm, sizeof nm, "%s.%02d.stem%dx%d_3_%d", plan_.name.c_str(), oi, op.kh, op.kw, op.cout);
           L.name = nm;
@@ -654,6 +802,12 @@ bool Net::bind(int N, int H, int W, std::string& err) {
           a.KH = op.kh; a.KW = op.kw; a.PH = op.ph; a.PW = op.pw;
           a.need_nyx = 0;
           if (in.plain) { err = "conv input must be C8I"; return false; }
+          if (rag) {
+            // pointwise, or a stride-1 "same" conv along x (the 1x3 neck convs): rows in = rows out, one level
+            if (in.lvl < 0 || o.lvl != in.lvl || o.h != in.h) { err = "ragged batch: dense conv must keep its input's shape"; return false; }
+            for (auto& st : op.ep) if (st.kind == EP_MULC || st.kind == EP_ADDUP) { err = "ragged batch: per-image epilogue stage after a dense conv is not on this path"; return false; }
+            a.rin = rlevel(in); a.rout = rlevel(o);
+          }
           if (op.kind == PlanOp::DECONV) {
             a.OH = in.h; a.OW = in.w; a.Cs_out = o.cs; a.Cout = op.cout; a.CoutPadded = o.cs;
             a.ColsStore = 4 * o.cs; a.out_mode = OUT_DECONV; a.KH = a.KW = 1; a.PH = a.PW = 0;
@@ -671,7 +825,7 @@ bool Net::bind(int N, int H, int W, std::string& err) {
                                  (tiles <= 4 || nt == 4);
           if (fuse_head) {
             a.out_mode = OUT_HEAD;
-            const long hrows = (long)in.n * in.h * in.w;
+            const long hrows = in.pixels();
             const int groups = a.NTtot / nt;
             const size_t need = (size_t)hrows * groups * 3;
             if (need > head_part_cap_) {
@@ -692,6 +846,7 @@ bool Net::bind(int N, int H, int W, std::string& err) {
           if (gate_src[oi] >= 0) { a.gate = arena_ + T[gate_tid[oi]].offset; a.gate_hw = in.h * in.w; }
           a.M = (long)in.n * a.OH * a.OW;
           if (op.kind == PlanOp::LINEAR) a.M = (long)in.n * in.h * in.w;
+          if (rag) a.M = in.pixels();
           const int taps = a.KH * a.KW;
           const char* kind = op.kind == PlanOp::DECONV ? "deconv" : (op.kind == PlanOp::LINEAR ? "linear" : "conv");
           snprintf(nm, sizeof nm, "%s.%02d.%s%dx%d_%d_%d", plan_.name.c_str(), oi, kind, a.KH, a.KW, op.cin, op.cout);
@@ -717,10 +872,16 @@ bool Net::bind(int N, int H, int W, std::string& err) {
             f.dw_in = arena_ + din.offset; f.dw_w = dev_vec("dw:" + d.w);
             if (!lab_from_epilogue(epd, f.dw_ep) || !lab_from_epilogue(ep, f.pw_ep)) { err = "dwpw: epilogue is not the LAB chain"; return false; }
             f.H = din.h; f.W = din.w; f.K = d.kh; f.SH = d.sh; f.SW = d.sw; f.PH = d.ph; f.PW = d.pw;
+            if (rag) {
+              f.rin = rlevel(din); f.rout = rlevel(o);
+              f.c.rin = f.c.rout = RagLevel();
+              f.rtiles = rwork(o, 16);
+              f.rtiles_total = rwork_total(o, 16);
+            }
             snprintf(nm, sizeof nm, "%s.%02d.dwpw%dx%d_%d_%d_s%d%d", plan_.name.c_str(), dwpw_of[oi], d.kh, d.kw, op.cin, op.cout, d.sh, d.sw);
             L.name = nm;
             L.flops += 2.0 * a.M * d.kh * d.kw * d.c;
-            L.bytes = 4.0 * ((double)din.n * din.h * din.w * d.c + (double)a.M * cols + (double)op.cin * cols + (double)d.kh * d.kw * d.c);
+            L.bytes = 4.0 * ((double)din.pixels() * d.c + (double)a.M * cols + (double)op.cin * cols + (double)d.kh * d.kw * d.c);
             L.fn = [f](hipStream_t s) {
               if (!launch_dwpw(f, s)) { fprintf(stderr, "launch_dwpw: shape accepted at bind time was refused at launch\n"); abort(); }
             };
@@ -757,12 +918,19 @@ bool Net::bind(int N, int H, int W, std::string& err) {
         DwArgs a{};
         a.in = arena_ + in.offset; a.out = optr; a.w = dev_vec("dw:" + op.w);
         a.N = in.n; a.H = in.h; a.W = in.w; a.OH = o.h; a.OW = o.w; a.Cs = o.cs; a.K = op.kh;
-        a.SH = op.sh; a.SW = op.sw; a.PH = op.ph; a.PW = op.pw; a.M = (long)o.n * o.h * o.w;
+        a.SH = op.sh; a.SW = op.sw; a.PH = op.ph; a.PW = op.pw; a.M = o.pixels();
         if (dw_rowsum[oi]) a.rowsum = gap_part_;
+        if (rag) {
+          a.rin = rlevel(in); a.rout = rlevel(o);
+          a.OW = lmin[o.lvl];  // the launcher picks its strip width from the narrowest line
+          const int to = dw_patch_to(a.OW, a.SW);
+          a.rwork = rwork(o, to);
+          a.rwork_total = rwork_total(o, to);
+        }
         snprintf(nm, sizeof nm, "%s.%02d.dw%dx%d_%d_s%d%d%s", plan_.name.c_str(), oi, op.kh, op.kw, op.c, op.sh, op.sw, dw_rowsum[oi] ? "_rowsum" : "");
         L.name = nm;
         L.flops = 2.0 * a.M * op.kh * op.kw * op.c;
-        L.bytes = 4.0 * ((double)in.n * in.h * in.w * op.c + (double)a.M * op.c);
+        L.bytes = 4.0 * ((double)in.pixels() * op.c + (double)a.M * op.c);
         L.fn = [a, ep](hipStream_t s) { launch_dw(a, ep, s); };
       } break;
       case PlanOp::EW: {
@@ -770,26 +938,30 @@ bool Net::bind(int N, int H, int W, std::string& err) {
         Epilogue ep;
         if (!build_epilogue(op, ep, false, err)) return false;
         const float* ip = arena_ + in.offset;
-        const long M = (long)o.n * o.h * o.w;
+        const long M = o.pixels();
         const int H2 = o.h, W2 = o.w, Cs = o.cs;
+        if (rag) for (auto& st : op.ep) if (st.kind == EP_ADDUP) { err = "ragged batch: upsampled operand is not on this path"; return false; }
+        const RagLevel rl = rlevel(o);
+        const int nl = o.n;
         snprintf(nm, sizeof nm, "%s.%02d.ew_%d", plan_.name.c_str(), oi, op.c);
         L.name = nm;
         L.bytes = 4.0 * M * op.c * (2.0 + (double)op.ep.size() - 1.0);
-        L.fn = [ip, optr, M, H2, W2, Cs, ep](hipStream_t s) { launch_ew(ip, optr, M, H2, W2, Cs, ep, s); };
+        L.fn = [ip, optr, M, H2, W2, Cs, ep, nl, rl](hipStream_t s) { launch_ew(ip, optr, M, H2, W2, Cs, ep, s, nl, rl); };
       } break;
       case PlanOp::GAP: {
         const TensorDesc& in = T[op.in];
         const float* ip = arena_ + in.offset;
         float* part = gap_part_;
         const int n = in.n, h = in.h, w = in.w, cs = in.cs;
+        const RagLevel rl = rlevel(in);
         snprintf(nm, sizeof nm, "%s.%02d.gap_%d", plan_.name.c_str(), oi, op.c);
         L.name = nm;
-        L.bytes = 4.0 * (double)n * h * w * op.c;
+        L.bytes = 4.0 * (double)in.pixels() * op.c;
         if (oi > 0 && dw_rowsum[oi - 1]) {  // the row sums are already in `part` (written by the depthwise conv before this op)
           L.bytes = 4.0 * (double)n * h * op.c;
-          L.fn = [part, optr, n, h, w, cs](hipStream_t s) { launch_gap_cols(part, optr, n, h, w, cs, s); };
+          L.fn = [part, optr, n, h, w, cs, rl](hipStream_t s) { launch_gap_cols(part, optr, n, h, w, cs, s, rl); };
         } else
-        L.fn = [ip, part, optr, n, h, w, cs](hipStream_t s) { launch_gap(ip, part, optr, n, h, w, cs, s); };
+        L.fn = [ip, part, optr, n, h, w, cs, rl](hipStream_t s) { launch_gap(ip, part, optr, n, h, w, cs, s, rl); };
       } break;
       case PlanOp::SEFC: {
         const TensorDesc& in = T[op.in];
@@ -806,7 +978,8 @@ bool Net::bind(int N, int H, int W, std::string& err) {
       } break;
       case PlanOp::CONCAT: {
         ConcatArgs a{};
-        a.out = optr; a.H = o.h; a.W = o.w; a.Cs = o.cs; a.M = (long)o.n * o.h * o.w;
+        a.out = optr; a.H = o.h; a.W = o.w; a.Cs = o.cs; a.M = o.pixels();
+        if (rag) { a.H = 1; a.W = (int)a.M; }  // same-resolution sources (checked above): one row axis
         a.nsrc = (int)op.ins.size();
         if (a.nsrc > 4) { err = "concat arity not on this path"; return false; }
         int off = 0;
@@ -826,16 +999,17 @@ bool Net::bind(int N, int H, int W, std::string& err) {
         PoolArgs a{};
         a.in = arena_ + in.offset; a.out = optr; a.N = in.n; a.H = in.h; a.W = in.w; a.OH = o.h; a.OW = o.w;
         a.Cs = o.cs; a.KH = op.kh; a.KW = op.kw; a.SH = op.sh; a.SW = op.sw; a.is_max = op.pool_max;
-        a.M = (long)o.n * o.h * o.w;
+        a.M = o.pixels();
+        a.rin = rlevel(in); a.rout = rlevel(o);
         snprintf(nm, sizeof nm, "%s.%02d.pool_%d", plan_.name.c_str(), oi, op.c);
         L.name = nm;
-        L.bytes = 4.0 * ((double)in.n * in.h * in.w * op.c + (double)a.M * op.c);
+        L.bytes = 4.0 * ((double)in.pixels() * op.c + (double)a.M * op.c);
         L.fn = [a](hipStream_t s) { launch_pool(a, s); };
       } break;
       case PlanOp::LN: {
         const TensorDesc& in = T[op.in];
         const float* ip = arena_ + in.offset;
-        const long rows = (long)in.n * in.h * in.w;
+        const long rows = in.pixels();
         const int C = op.c, Cs = in.cs;
         const float eps = op.eps;
         const float* g = dev_vec("raw:" + op.g);
@@ -851,16 +1025,20 @@ bool Net::bind(int N, int H, int W, std::string& err) {
         const float* ip = arena_ + in.offset;
         const int n = in.n, t = in.w, heads = op.heads, hd = op.hd, csi = in.cs, cso = o.cs;
         const float sc = op.scale;
+        const RagLevel rl = rlevel(in);
+        if (rag && !attn_ragged_fits(t)) { err = "ragged batch: line too wide for the attention kernel"; return false; }
+        double tt = (double)n * t * t;  // sum over lines of T^2
+        if (rag) { tt = 0; for (int v : LW[in.lvl]) tt += (double)v * v; }
         snprintf(nm, sizeof nm, "%s.%02d.attn_%dx%d", plan_.name.c_str(), oi, op.heads, op.hd);
         L.name = nm;
-        L.flops = 3.0 * 2.0 * n * heads * (double)t * t * hd + 2.0 * n * heads * (double)t * t * hd;
-        L.bytes = 4.0 * n * t * (3.0 + 1.0) * heads * hd;
-        L.fn = [ip, optr, n, t, heads, hd, csi, cso, sc](hipStream_t s) { launch_attn(ip, optr, n, t, heads, hd, csi, cso, sc, s); };
+        L.flops = 3.0 * 2.0 * heads * tt * hd + 2.0 * heads * tt * hd;
+        L.bytes = 4.0 * in.pixels() * (3.0 + 1.0) * heads * hd;
+        L.fn = [ip, optr, n, t, heads, hd, csi, cso, sc, rl](hipStream_t s) { launch_attn(ip, optr, n, t, heads, hd, csi, cso, sc, s, rl); };
       } break;
       case PlanOp::SOFTMAX: {
         const TensorDesc& in = T[op.in];
         const float* ip = arena_ + in.offset;
-        const long rows = (long)in.n * in.h * in.w;
+        const long rows = in.pixels();
         const int C = op.c;
         snprintf(nm, sizeof nm, "%s.%02d.softmax_%d", plan_.name.c_str(), oi, op.c);
         L.name = nm;
@@ -884,7 +1062,8 @@ bool Net::bind(int N, int H, int W, std::string& err) {
       default: break;
     }
     // instance tag: the same op at another bound shape is another roofline row
-    snprintf(nm, sizeof nm, "@%dx%dx%d", N, H, W);
+    if (rag) snprintf(nm, sizeof nm, "@%dx%dx~%ld", N, H, ltot[0] / N);  // ragged: the lines' mean width
+    else snprintf(nm, sizeof nm, "@%dx%dx%d", N, H, W);
     L.name += nm;
     launches_.push_back(std::move(L));
   }
@@ -897,13 +1076,13 @@ bool Net::bind(int N, int H, int W, std::string& err) {
   }
   B->tensors = tensors_;
   cur_ = B.get();
-  cache_[{N, H, W}] = std::move(B);
+  cache_[shape_key(N, H, W, widths)] = std::move(B);
   return true;
 }
 
 bool Net::run(const float* x, int N, int H, int W, hipStream_t s, std::string& err) {
-  if (!cur_ || cur_->n != N || cur_->h != H || cur_->w != W) {
-    auto it = cache_.find({N, H, W});
+  if (!cur_ || !cur_->widths.empty() || cur_->n != N || cur_->h != H || cur_->w != W) {
+    auto it = cache_.find(shape_key(N, H, W, nullptr));
     if (it != cache_.end()) {
       cur_ = it->second.get();
       tensors_ = cur_->tensors;
@@ -912,8 +1091,47 @@ bool Net::run(const float* x, int N, int H, int W, hipStream_t s, std::string& e
       if (!bind(N, H, W, err)) { invalidate(); return false; }
     }
   }
+  return run_bound(x, s, err);
+}
+
+bool Net::bind_ragged(int H, const int* widths, int N, std::string& err) {
+  if (N < 1 || !widths) { err = "ragged batch: no lines"; return false; }
+  if (!ragged_ok(H, widths, N, err)) return false;
+  if (cur_ && cur_->h == H && (int)cur_->widths.size() == N && std::equal(widths, widths + N, cur_->widths.begin())) return true;
+  auto it = cache_.find(shape_key(N, H, 0, widths));
+  // (the key is the run-length form: a cached binding with the same runs has the same widths line by line)
+  if (it != cache_.end()) {
+    cur_ = it->second.get();
+    tensors_ = cur_->tensors;
+    return true;
+  }
+  cur_ = nullptr;
+  // ragged bindings carry per-line tables: keep fewer of them than of the uniform ones
+  size_t nrag = 0;
+  for (auto& kv : cache_) nrag += !kv.second->widths.empty();
+  while (nrag >= kMaxRaggedBindings) {
+    auto old = cache_.end();
+    for (auto i2 = cache_.begin(); i2 != cache_.end(); ++i2)
+      if (!i2->second->widths.empty() && (old == cache_.end() || i2->second->stamp < old->second->stamp)) old = i2;
+    cache_.erase(old);
+    --nrag;
+  }
+  if (!bind(N, H, 0, err, widths)) { invalidate(); return false; }
+  return true;
+}
+
+bool Net::run_ragged(const float* x, int H, const int* widths, int N, hipStream_t s, std::string& err) {
+  if (!bind_ragged(H, widths, N, err)) return false;
+  return run_bound(x, s, err);
+}
+
+bool Net::run_bound(const float* x, hipStream_t s, std::string& err) {
   Binding& B = *cur_;
   B.stamp = ++clock_;
+  if (B.rag_dev && !B.rag_uploaded) {  // the line tables travel once, on the stream that runs the launches
+    HIP_OK(hipMemcpyAsync(B.rag_dev, B.rag_host.data(), B.rag_host.size() * sizeof(int), hipMemcpyHostToDevice, s));
+    B.rag_uploaded = true;
+  }
   bound_x_ = x;
   const char* graph_env = getenv("OCR_GRAPH");  // OCR_GRAPH=0: plain launches only
   // event timing needs plain launches - but only where an event would be placed: with a name filter (bench.py times the
@@ -994,7 +1212,8 @@ bool Net::fetch_logical(int tid, std::vector<float>& host, int dims[4], hipStrea
   if (!cur_->exists[tid]) { err = "tensor is fused away under this binding (never written to device memory)"; return false; }
   const TensorDesc& t = tensors_[tid];
   dims[0] = t.n; dims[1] = t.h; dims[2] = t.w; dims[3] = t.c;
-  const long M = (long)t.n * t.h * t.w;
+  const long M = t.pixels();
+  if (t.lvl >= 0) { dims[0] = 1; dims[1] = 1; dims[2] = (int)M; }  // ragged: the lines' [h][w] blocks one after the other
   host.resize((size_t)M * t.c);
   if (t.plain) {
     HIP_OK(hipMemcpyAsync(host.data(), arena_ + t.offset, host.size() * sizeof(float), hipMemcpyDeviceToHost, s));

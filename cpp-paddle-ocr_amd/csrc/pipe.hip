@@ -556,7 +556,7 @@ int ocr_pipe_det_shape(ocr_pipe* h, int rows, int cols, int* net_rows, int* net_
 static std::vector<Net*> pipe_nets(ocr_pipe* h) {
   std::vector<Net*> v{&h->det.net()};
   if (h->cls) v.push_back(&h->cls->net());
-  for (int i = 0; i < h->rec.num_lanes(); ++i) v.push_back(&h->rec.lane_net(i));
+  v.push_back(&h->rec.net());
   return v;
 }
 int ocr_pipe_timing(ocr_pipe* h, int enable) {

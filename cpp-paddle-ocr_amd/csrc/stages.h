@@ -120,11 +120,10 @@ class RecStage {
   int run_lines(const std::vector<LineSrc>& lines, const std::vector<int>& seg, int32_t* ids, int max_len, int* lens,
                 float* scores, std::string& err);
   bool want_taps = true;
-  int max_lines_per_launch = 4096;  // rows of one launch (bounds the activation arena: ~1.2 MB per 48x320 line)
+  int max_lines_per_launch = 4096;  // bounds the activation arena of one launch: this many 48x320 lines' pixels (~1.2 MB each)
   const std::vector<std::string>& labels() const { return labels_; }
-  hipStream_t stream() const { return lanes_[0]->stream; }
-  int num_lanes() const { return (int)lanes_.size(); }
-  Net& lane_net(int i) { return lanes_[i]->net; }
+  hipStream_t stream() const { return stream_; }
+  Net& net() { return net_; }
   // per-step taps of the last run, in input order: T per line, amax/pmax concatenated
   std::vector<int> tap_T, tap_off;
   std::vector<int> tap_amax;
@@ -132,24 +131,13 @@ class RecStage {
 
  private:
   RecConfig cfg_;
-  // Execution lanes (network instance + stream + input buffer each, see run_lines): 0 takes the largest launch, 1 the
-  // second half when that launch is split (OCR_REC_SPLIT=2), 2.. the small odd-width launches round-robin
-  // (OCR_REC_SMALL_LANES of them, high-priority streams): independent dependent-kernel chains side by side.
-  struct Lane {
-    Net net;
-    hipStream_t stream = nullptr;
-    DevBuf<float> x;
-    ~Lane() { if (stream) (void)hipStreamDestroy(stream); }
-  };
-  std::vector<std::unique_ptr<Lane>> lanes_;
-  int small_lanes_ = 4;
-  int split_tail_ = -1;     // index of the second half in the current launch list
-  int split_ = 1;           // parts the largest launch is cut into (OCR_REC_SPLIT, 1 or 2)
-  bool serial_ = false;     // OCR_REC_LANES=1: every launch on lane 0, one after the other
-  hipEvent_t ev_descs_ = nullptr;
+  // One network instance, one stream: the lines of a call run as ONE ragged launch list whatever their tensor widths
+  // (run_lines); rounds 1-2 launched once per distinct width on up to six streams ("lanes").
+  Net net_;
+  hipStream_t stream_ = nullptr;
   StageTimer timer_;
   std::vector<std::string> labels_;
-  DevBuf<float> lut_, pmax_, scores_;
+  DevBuf<float> lut_, pmax_, scores_, x_;
   DevBuf<int> amax_, ids_, lens_;
   DevBuf<uint8_t> staging_;
   DevBuf<LineDesc> descs_;

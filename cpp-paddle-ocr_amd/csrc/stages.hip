@@ -255,8 +255,7 @@ int DetStage::post_only(const float* prob, int rows, int cols, int src_rows, int
 
 // ================================================================= recognizer
 RecStage::~RecStage() {
-  lanes_.clear();
-  if (ev_descs_) (void)hipEventDestroy(ev_descs_);
+  if (stream_) (void)hipStreamDestroy(stream_);
 }
 
 bool RecStage::create(const RecConfig& cfg, std::string& err, int& code) {
@@ -277,25 +276,9 @@ bool RecStage::create(const RecConfig& cfg, std::string& err, int& code) {
   labels_.push_back(" ");
   WeightMap w;
   if (!load_model_dir(cfg.model_dir, nullptr, "rec", w, err)) return false;
-  if (const char* e = getenv("OCR_REC_SPLIT")) split_ = atoi(e) >= 2 ? 2 : 1;
-  if (const char* e = getenv("OCR_REC_LANES")) serial_ = atoi(e) == 1;
-  if (const char* e = getenv("OCR_REC_SMALL_LANES")) small_lanes_ = std::min(16, std::max(1, atoi(e)));
-  // the small lanes carry the odd-width launches: high-priority queues, so their workgroups are placed as soon as
-  // slots free up instead of waiting behind the thousands queued by lane 0's big kernels
-  int prio_lo = 0, prio_hi = 0;
-  (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-  const int nlanes = serial_ ? 1 : 2 + small_lanes_;
-  for (int i = 0; i < nlanes; ++i) {
-    std::unique_ptr<Lane> L(new Lane());
-    code = OCR_ERR_MODEL;
-    if (!L->net.load(embedded_plan("rec"), w, err)) return false;
-    code = OCR_ERR_DEVICE;
-    const hipError_t e = i >= 2 ? hipStreamCreateWithPriority(&L->stream, hipStreamDefault, prio_hi) : hipStreamCreate(&L->stream);
-    if (e != hipSuccess) { err = "hipStreamCreate failed"; return false; }
-    lanes_.push_back(std::move(L));
-  }
+  if (!net_.load(embedded_plan("rec"), w, err)) return false;
   code = OCR_ERR_DEVICE;
-  if (hipEventCreateWithFlags(&ev_descs_, hipEventDisableTiming) != hipSuccess) { err = "hipEventCreate failed"; return false; }
+  if (hipStreamCreate(&stream_) != hipSuccess) { err = "hipStreamCreate failed"; return false; }
   if (!timer_.init(err)) return false;
   const float mean[3] = {0.5f, 0.5f, 0.5f}, scale[3] = {1 / 0.5f, 1 / 0.5f, 1 / 0.5f};  // ocr_rec.h:108-109
   const auto lut = make_norm_lut(mean, scale);
@@ -311,16 +294,15 @@ int RecStage::run(const ocr_img* imgs, int n, int32_t* ids, int max_len, int* le
   if (times) times[0] = times[1] = times[2] = 0;
   if (n == 0) return OCR_OK;
   ST_HIP(hipSetDevice(cfg_.device));
-  const hipStream_t stream0 = lanes_[0]->stream;
-  timer_.mark(0, stream0);
+  timer_.mark(0, stream_);
   std::vector<LineSrc> lines;
-  if (!upload_lines(imgs, n, staging_, lines, stream0, err)) return OCR_ERR_DEVICE;
-  timer_.mark(1, stream0);
+  if (!upload_lines(imgs, n, staging_, lines, stream_, err)) return OCR_ERR_DEVICE;
+  timer_.mark(1, stream_);
   const std::vector<int> seg = {0, n};
   const int rc = run_lines(lines, seg, ids, max_len, lens, scores, err);
-  timer_.mark(2, stream0);
-  timer_.mark(3, stream0);
-  (void)hipStreamSynchronize(stream0);
+  timer_.mark(2, stream_);
+  timer_.mark(3, stream_);
+  (void)hipStreamSynchronize(stream_);
   timer_.read(times);
   return rc;
 }
@@ -329,9 +311,9 @@ int RecStage::run_lines(const std::vector<LineSrc>& lines, const std::vector<int
                         int* lens, float* scores, std::string& err) {
   const int n = (int)lines.size();
   const int imgH = cfg_.img_h, imgW = cfg_.img_w;
-  const hipStream_t stream0 = lanes_[0]->stream;
-  struct Item { int line; int resize_w; };
-  std::map<int, std::vector<Item>> groups;  // tensor width -> lines (samples of one launch are independent)
+  struct Item { int line, resize_w, tensor_w; };
+  std::vector<Item> items;
+  items.reserve(n);
   for (size_t sg = 0; sg + 1 < seg.size(); ++sg) {
     // CRNNRecognizer::Run batching, /root/reference/src/ocr_rec.cpp:34-57, on one image's lines
     const int s0 = seg[sg], sn = seg[sg + 1] - seg[sg];
@@ -356,124 +338,143 @@ int RecStage::run_lines(const std::vector<LineSrc>& lines, const std::vector<int
         const LineSrc& L = lines[s0 + indices[ino]];
         const float ratio = float(L.w) / float(L.h);
         const int resize_w = ceilf(imgH * ratio) > bw ? bw : int(ceilf(imgH * ratio));
-        auto& g = groups[tensor_w];
-        g.push_back({s0 + (int)indices[ino], resize_w});
+        items.push_back({s0 + (int)indices[ino], resize_w, tensor_w});
       }
     }
   }
-  // bound the rows of one launch (activation arena) by splitting wide groups
-  std::vector<std::pair<int, std::vector<Item>>> launches;
-  for (auto& kv : groups)
-    for (size_t b = 0; b < kv.second.size(); b += max_lines_per_launch)
-      launches.emplace_back(kv.first, std::vector<Item>(kv.second.begin() + b,
-                                                        kv.second.begin() + std::min(kv.second.size(), b + (size_t)max_lines_per_launch)));
-  // The largest launch can be cut in two halves that run on two streams (lanes 0 and 2): the memory-bound
-  // kernels of one half (depthwise, SE, pooling) then share the chip with the matrix-bound 1x1 convs of the
-  // other instead of each running alone.  Samples of a launch are independent: results do not change.
-  if (split_ == 2 && !launches.empty()) {
-    size_t bi = 0;
-    for (size_t i = 1; i < launches.size(); ++i)
-      if ((long)launches[i].second.size() * launches[i].first > (long)launches[bi].second.size() * launches[bi].first) bi = i;
-    const size_t cnt = launches[bi].second.size();
-    if (cnt >= 256) {
-      const size_t half = (cnt / 2 + 15) / 16 * 16;
-      std::vector<Item> tail(launches[bi].second.begin() + half, launches[bi].second.end());
-      launches[bi].second.resize(half);
-      launches.emplace_back(launches[bi].first, std::move(tail));
-      split_tail_ = (int)launches.size() - 1;
-    } else split_tail_ = -1;
-  } else split_tail_ = -1;
   tap_T.assign(n, 0);
   tap_off.assign(n, 0);
   tap_amax.clear();
   tap_pmax.clear();
   for (int i = 0; i < n; ++i) { lens[i] = 0; scores[i] = 0.f; }
-  if (launches.empty()) return OCR_OK;
-  // Two execution lanes (network instance + stream each): the largest launch runs on lane 0 while the
-  // small odd-width launches (latency-bound: 16 lines each) run back to back on lane 1 and fill the
-  // gaps.  Everything is enqueued first; one synchronisation and one round of D2H copies at the end.
-  const int nl = (int)launches.size();
-  int big = 0;
-  for (int i = 1; i < nl; ++i)
-    if ((long)launches[i].second.size() * launches[i].first > (long)launches[big].second.size() * launches[big].first) big = i;
-  struct Slot { int lane, ng, Wt, T; size_t step_off, line_off; };
-  std::vector<Slot> slots(nl);
-  size_t step_total = 0, line_total = 0;
-  int small_rr = 0;
-  for (int i = 0; i < nl; ++i) {
-    int lane = 0;
-    if (!(i == big || nl == 1 || serial_)) lane = i == split_tail_ ? 1 : 2 + (small_rr++ % small_lanes_);
-    slots[i] = Slot{lane, (int)launches[i].second.size(), launches[i].first, 0, step_total, line_total};
-    step_total += (size_t)slots[i].ng * (launches[i].first / 4 + 8);  // >= ng * T
-    line_total += slots[i].ng;
-  }
-  if (!amax_.ensure(step_total, err) || !pmax_.ensure(step_total, err) || !ids_.ensure(line_total * max_len, err) ||
-      !lens_.ensure(line_total, err) || !scores_.ensure(line_total, err) || !descs_.ensure(line_total, err))
-    return OCR_ERR_DEVICE;
-  std::vector<size_t> xneed(lanes_.size(), 0);
-  for (int i = 0; i < nl; ++i) xneed[slots[i].lane] = std::max(xneed[slots[i].lane], (size_t)slots[i].ng * imgH * slots[i].Wt * 3);
-  for (size_t l = 0; l < lanes_.size(); ++l)
-    if (xneed[l] && !lanes_[l]->x.ensure(xneed[l], err)) return OCR_ERR_DEVICE;
-  std::vector<LineDesc> d(line_total);
-  for (int i = 0; i < nl; ++i)
-    for (int j = 0; j < slots[i].ng; ++j) {
-      const LineSrc& L = lines[launches[i].second[j].line];
-      d[slots[i].line_off + j] = LineDesc::make(L.img, L.stride, L.x, L.y, L.w, L.h, launches[i].second[j].resize_w, j, imgH);
+  if (items.empty()) return OCR_OK;
+  // One launch list for every tensor width of the call (a ragged batch: kernels_net.h, RagLevel).  In the reference each
+  // batch of rec_batch_num lines is a predictor run of its own width (ocr_rec.cpp:47-81); a line's results depend on
+  // its own tensor width only (padding, attention length), never on the other lines of a launch, so the lines of all
+  // batches - and of all images of a request batch - share the launches.  Lines in ascending tensor width (equal
+  // widths stay neighbours: a workgroup's tiles then belong to lines of one shape); a launch is cut where its
+  // activation arena would pass the pixel budget; a line too wide for the ragged attention kernel's LDS working set
+  // (> ~3000 px) runs as a uniform launch of its own width.
+  std::stable_sort(items.begin(), items.end(), [](const Item& a, const Item& b) { return a.tensor_w < b.tensor_w; });
+  struct Slot { int first, count; bool ragged; int T; size_t step_off; };
+  std::vector<Slot> slots;
+  const long budget = (long)max_lines_per_launch * imgH * std::max(imgW, 320);
+  {
+    int i = 0;
+    const int ni = (int)items.size();
+    while (i < ni) {
+      if (!attn_ragged_fits(items[i].tensor_w / 8 + 2)) {  // uniform launch: the lines of exactly this width
+        int j = i;
+        while (j < ni && items[j].tensor_w == items[i].tensor_w && j - i < max_lines_per_launch) ++j;
+        slots.push_back({i, j - i, false, 0, 0});
+        i = j;
+        continue;
+      }
+      long pix = 0;
+      int j = i;
+      while (j < ni && attn_ragged_fits(items[j].tensor_w / 8 + 2) && (j == i || pix + (long)imgH * items[j].tensor_w <= budget)) {
+        pix += (long)imgH * items[j].tensor_w;
+        ++j;
+      }
+      slots.push_back({i, j - i, true, 0, 0});
+      i = j;
     }
-  ST_HIP(hipMemcpyAsync(descs_.p, d.data(), line_total * sizeof(LineDesc), hipMemcpyHostToDevice, stream0));
-  ST_HIP(hipEventRecord(ev_descs_, stream0));
-  for (size_t l = 1; l < lanes_.size(); ++l) ST_HIP(hipStreamWaitEvent(lanes_[l]->stream, ev_descs_, 0));
-  for (int pass = 0; pass < (int)lanes_.size(); ++pass) {      // the big launches first so their kernels are queued early
-    for (int i = 0; i < nl; ++i) {
-      Slot& sl = slots[i];
-      if (sl.lane != pass) continue;
-      Net& net = lanes_[sl.lane]->net;
-      hipStream_t st = lanes_[sl.lane]->stream;
-      float* x = lanes_[sl.lane]->x.p;
-      launch_line_pre(descs_.p + sl.line_off, sl.ng, imgH, sl.Wt, lut_.p, false, x, st);
-      net.set_head_outputs(nullptr, amax_.p + sl.step_off, pmax_.p + sl.step_off);
-      if (!net.run(x, sl.ng, imgH, sl.Wt, st, err)) return OCR_ERR_DEVICE;
-      const TensorDesc& ot = net.tensor(net.output_tid());
+  }
+  // per launch: bind (host only), so that the step counts are known before the line descriptors travel
+  const int ni = (int)items.size();
+  std::vector<LineDesc> d(ni);
+  std::vector<int> widths;
+  size_t step_total = 0, xneed = 0;
+  for (Slot& sl : slots) {
+    sl.step_off = step_total;
+    if (sl.ragged) {
+      widths.resize(sl.count);
+      for (int j = 0; j < sl.count; ++j) widths[j] = items[sl.first + j].tensor_w;
+      if (!net_.bind_ragged(imgH, widths.data(), sl.count, err)) return OCR_ERR_DEVICE;
+      const TensorDesc& ot = net_.tensor(net_.output_tid());
+      if (ot.h != 1) { err = "rec_img_h does not reduce to a single row"; return OCR_ERR_ARG; }
+      if (ot.c != (int)labels_.size()) { err = "dictionary size does not match the CTC head"; return OCR_ERR_MODEL; }
+      const std::vector<int>& T = net_.ragged_widths(net_.output_tid());
+      long pix = 0;
+      for (int j = 0; j < sl.count; ++j) {
+        const Item& it = items[sl.first + j];
+        const LineSrc& L = lines[it.line];
+        LineDesc& q = d[sl.first + j];
+        q = LineDesc::make(L.img, L.stride, L.x, L.y, L.w, L.h, it.resize_w, j, imgH);
+        q.tensor_w = it.tensor_w;
+        q.pix0 = (int)pix;
+        q.step0 = (int)(step_total - sl.step_off);
+        q.steps = T[j];
+        pix += (long)imgH * it.tensor_w;
+        step_total += T[j];
+      }
+      xneed = std::max(xneed, (size_t)pix * 3);
+    } else {
+      for (int j = 0; j < sl.count; ++j) {
+        const Item& it = items[sl.first + j];
+        const LineSrc& L = lines[it.line];
+        d[sl.first + j] = LineDesc::make(L.img, L.stride, L.x, L.y, L.w, L.h, it.resize_w, j, imgH);
+      }
+      step_total += (size_t)sl.count * (items[sl.first].tensor_w / 4 + 8);  // >= count * T
+      xneed = std::max(xneed, (size_t)sl.count * imgH * items[sl.first].tensor_w * 3);
+    }
+  }
+  if (!amax_.ensure(step_total, err) || !pmax_.ensure(step_total, err) || !ids_.ensure((size_t)ni * max_len, err) ||
+      !lens_.ensure(ni, err) || !scores_.ensure(ni, err) || !descs_.ensure(ni, err) || !x_.ensure(xneed, err))
+    return OCR_ERR_DEVICE;
+  ST_HIP(hipMemcpyAsync(descs_.p, d.data(), (size_t)ni * sizeof(LineDesc), hipMemcpyHostToDevice, stream_));
+  for (Slot& sl : slots) {
+    net_.set_head_outputs(nullptr, amax_.p + sl.step_off, pmax_.p + sl.step_off);
+    if (sl.ragged) {
+      widths.resize(sl.count);
+      long pix = 0;
+      for (int j = 0; j < sl.count; ++j) { widths[j] = items[sl.first + j].tensor_w; pix += (long)imgH * widths[j]; }
+      launch_line_pre_ragged(descs_.p + sl.first, sl.count, pix, imgH, lut_.p, x_.p, stream_);
+      if (!net_.run_ragged(x_.p, imgH, widths.data(), sl.count, stream_, err)) return OCR_ERR_DEVICE;
+      launch_ctc_ragged(amax_.p + sl.step_off, pmax_.p + sl.step_off, descs_.p + sl.first, sl.count, max_len,
+                        ids_.p + (size_t)sl.first * max_len, lens_.p + sl.first, scores_.p + sl.first, stream_);
+    } else {
+      const int Wt = items[sl.first].tensor_w;
+      launch_line_pre(descs_.p + sl.first, sl.count, imgH, Wt, lut_.p, false, x_.p, stream_);
+      if (!net_.run(x_.p, sl.count, imgH, Wt, stream_, err)) return OCR_ERR_DEVICE;
+      const TensorDesc& ot = net_.tensor(net_.output_tid());
       if (ot.h != 1) { err = "rec_img_h does not reduce to a single row"; return OCR_ERR_ARG; }
       if (ot.c != (int)labels_.size()) { err = "dictionary size does not match the CTC head"; return OCR_ERR_MODEL; }
       sl.T = ot.w;
-      if ((size_t)sl.ng * sl.T > (size_t)sl.ng * (sl.Wt / 4 + 8)) { err = "rec step buffer too small"; return OCR_ERR_CAPACITY; }
-      launch_ctc(amax_.p + sl.step_off, pmax_.p + sl.step_off, sl.ng, sl.T, max_len, ids_.p + sl.line_off * max_len,
-                 lens_.p + sl.line_off, scores_.p + sl.line_off, st);
+      if (sl.T > Wt / 4 + 8) { err = "rec step buffer too small"; return OCR_ERR_CAPACITY; }
+      launch_ctc(amax_.p + sl.step_off, pmax_.p + sl.step_off, sl.count, sl.T, max_len, ids_.p + (size_t)sl.first * max_len,
+                 lens_.p + sl.first, scores_.p + sl.first, stream_);
     }
   }
-  for (size_t l = 1; l < lanes_.size(); ++l) ST_HIP(hipStreamSynchronize(lanes_[l]->stream));
-  std::vector<int> h_ids(line_total * max_len), h_lens(line_total), h_amax;
-  std::vector<float> h_scores(line_total), h_pmax;
-  ST_HIP(hipMemcpyAsync(h_ids.data(), ids_.p, h_ids.size() * sizeof(int), hipMemcpyDeviceToHost, stream0));
-  ST_HIP(hipMemcpyAsync(h_lens.data(), lens_.p, line_total * sizeof(int), hipMemcpyDeviceToHost, stream0));
-  ST_HIP(hipMemcpyAsync(h_scores.data(), scores_.p, line_total * sizeof(float), hipMemcpyDeviceToHost, stream0));
+  std::vector<int> h_ids((size_t)ni * max_len), h_lens(ni), h_amax;
+  std::vector<float> h_scores(ni), h_pmax;
+  ST_HIP(hipMemcpyAsync(h_ids.data(), ids_.p, h_ids.size() * sizeof(int), hipMemcpyDeviceToHost, stream_));
+  ST_HIP(hipMemcpyAsync(h_lens.data(), lens_.p, (size_t)ni * sizeof(int), hipMemcpyDeviceToHost, stream_));
+  ST_HIP(hipMemcpyAsync(h_scores.data(), scores_.p, (size_t)ni * sizeof(float), hipMemcpyDeviceToHost, stream_));
   if (want_taps) {
     h_amax.resize(step_total);
     h_pmax.resize(step_total);
-    ST_HIP(hipMemcpyAsync(h_amax.data(), amax_.p, step_total * sizeof(int), hipMemcpyDeviceToHost, stream0));
-    ST_HIP(hipMemcpyAsync(h_pmax.data(), pmax_.p, step_total * sizeof(float), hipMemcpyDeviceToHost, stream0));
+    ST_HIP(hipMemcpyAsync(h_amax.data(), amax_.p, step_total * sizeof(int), hipMemcpyDeviceToHost, stream_));
+    ST_HIP(hipMemcpyAsync(h_pmax.data(), pmax_.p, step_total * sizeof(float), hipMemcpyDeviceToHost, stream_));
   }
-  ST_HIP(hipStreamSynchronize(stream0));
-  for (auto& L : lanes_) L->net.collect_timings();
-  for (int i = 0; i < nl; ++i) {
-    const Slot& sl = slots[i];
-    for (int j = 0; j < sl.ng; ++j) {
-      const int li = launches[i].second[j].line;
-      const size_t q = sl.line_off + j;
+  ST_HIP(hipStreamSynchronize(stream_));
+  net_.collect_timings();
+  for (const Slot& sl : slots)
+    for (int j = 0; j < sl.count; ++j) {
+      const int q = sl.first + j, li = items[q].line;
       if (h_lens[q] > max_len) { err = "text longer than max_len"; return OCR_ERR_CAPACITY; }
       lens[li] = h_lens[q];
       scores[li] = h_scores[q];
-      memcpy(ids + (size_t)li * max_len, h_ids.data() + q * max_len, (size_t)h_lens[q] * sizeof(int));
-      tap_T[li] = sl.T;
+      memcpy(ids + (size_t)li * max_len, h_ids.data() + (size_t)q * max_len, (size_t)h_lens[q] * sizeof(int));
+      const int T = sl.ragged ? d[q].steps : sl.T;
+      tap_T[li] = T;
       if (want_taps) {
         tap_off[li] = (int)tap_amax.size();
-        const size_t o = sl.step_off + (size_t)j * sl.T;
-        tap_amax.insert(tap_amax.end(), h_amax.begin() + o, h_amax.begin() + o + sl.T);
-        tap_pmax.insert(tap_pmax.end(), h_pmax.begin() + o, h_pmax.begin() + o + sl.T);
+        const size_t o = sl.step_off + (sl.ragged ? (size_t)d[q].step0 : (size_t)j * sl.T);
+        tap_amax.insert(tap_amax.end(), h_amax.begin() + o, h_amax.begin() + o + T);
+        tap_pmax.insert(tap_pmax.end(), h_pmax.begin() + o, h_pmax.begin() + o + T);
       }
     }
-  }
   return OCR_OK;
 }
 

@@ -239,6 +239,12 @@ void ocr_net_destroy(ocr_net* h);
  * 1 = every plan tensor materialised in its own slot (no fusion); 2 = the production launch list (SE gates folded,
  * depthwise->pointwise pairs fused) with every tensor it writes kept in its own slot. */
 int ocr_net_forward(ocr_net* h, const float* x, int N, int H, int W, int keep_all);
+/* Ragged batch (rec only): N text lines of height H, line n of width widths[n]; x = the lines' [H][widths[n]][3]
+ * blocks one after the other.  One launch list for all widths (the recognizer's production path: every batch of
+ * rec_batch_num lines has its own tensor width, src/ocr_rec.cpp:47-72); each line's results are those of
+ * ocr_net_forward on that line alone.  ocr_net_fetch then returns a tensor's lines one after the other with
+ * dims = {1, 1, total pixels, C} (per-line vectors such as the SE gates: {N, 1, 1, C}). */
+int ocr_net_forward_ragged(ocr_net* h, const float* x, int N, int H, const int* widths, int keep_all);
 int ocr_net_num_tensors(ocr_net* h);
 /* 1 if the last forward wrote tensor `tid` to device memory (fused-away tensors never exist), else 0 */
 int ocr_net_tensor_exists(ocr_net* h, int tid);

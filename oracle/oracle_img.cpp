@@ -332,6 +332,17 @@ int oracle_rotate_crop_shape(int rows, int cols, const int* box8, int* orows, in
   else { *orows = dh; *ocols = dw; }
   return 1;
 }
+// --- pieces, exposed for unit tests (tests/test_oracle_independent.py) ---
+// cv::getPerspectiveTransform: src / dst = 4 (x, y) pairs each
+void oracle_perspective_transform(const float* src_xy, const float* dst_xy, double* M9) {
+  float sx[4], sy[4], dx[4], dy[4];
+  for (int i = 0; i < 4; ++i) { sx[i] = src_xy[2 * i]; sy[i] = src_xy[2 * i + 1]; dx[i] = dst_xy[2 * i]; dy[i] = dst_xy[2 * i + 1]; }
+  perspective_transform(sx, sy, dx, dy, M9);
+}
+// cv::warpPerspective(src, dst(dh x dw), M, INTER_LINEAR, BORDER_CONSTANT 0) for 8UC3 with a given forward matrix
+void oracle_warp_perspective(const uint8_t* src, int sh, int sw, size_t sstride, const double* M9, uint8_t* dst, int dh, int dw) {
+  warp_perspective_u8c3(src, sh, sw, sstride, M9, dst, dh, dw);
+}
 int oracle_rotate_crop(const uint8_t* bgr, int rows, int cols, size_t stride, const int* box8, uint8_t* out, int* orows,
                        int* ocols) {
   if (!oracle_rotate_crop_shape(rows, cols, box8, orows, ocols)) return 0;

@@ -89,6 +89,13 @@ for kind, shape in (("det", (2, 96, 160)), ("det", (1, 192, 384)), ("rec", (3, 4
     o, g = OracleNet(kind), pkg.Net(kind)
     assert np.array_equal(o.run(x), g.forward(x, keep_all=False)), (kind, shape)
     g.close()
+# the recognizer's production path: a ragged batch (own width per line) against each line alone
+rs = np.random.RandomState(4)
+lines = [rs.randn(48, w, 3).astype(np.float32) for w in (320, 320, 333, 136, 320, 350)]
+o, g = OracleNet("rec"), pkg.Net("rec")
+want = np.concatenate([o.run(l[None]).reshape(-1, 6625) for l in lines])
+assert np.array_equal(want, g.forward_ragged(lines, keep_all=False).reshape(-1, 6625)), "ragged rec"
+g.close()
 print("AB OK")
 """
 
@@ -133,6 +140,45 @@ def test_fused_launch_list_every_materialised_tensor_bit_identical(pkg, built, k
             missing += 1
     if kind in ("det", "rec"):
         assert missing >= 8          # the fused pairs really ran fused
+    g.close()
+
+
+@pytest.mark.parametrize("keep_all", [0, 1, 2])
+@pytest.mark.parametrize("h,widths", [(48, [320, 320, 327, 345, 40, 320, 1000, 64, 321]), (28, [192, 201, 192, 77])])
+def test_ragged_rec_batch_equals_each_line_alone(pkg, built, keep_all, h, widths):
+    """The recognizer runs ONE launch list per call: every line keeps its own tensor width (the width of its batch of
+    rec_batch_num, src/ocr_rec.cpp:47-72) inside a ragged batch (kernels_net.h, RagLevel).  Every tensor of every
+    line must equal what the oracle computes for that line alone - in all three launch-list modes (production,
+    every plan tensor materialised, production list with every written tensor kept).  Widths include odd ones
+    (odd widths at every level), a very wide line, lines narrower than a 16-pixel tile row and equal neighbours."""
+    from oracle import OracleNet
+    rs = np.random.RandomState(31)
+    lines = [rs.randn(h, w, 3).astype(np.float32) for w in widths]
+    o = OracleNet("rec")
+    g = pkg.Net("rec")
+    y = g.forward_ragged(lines, keep_all=keep_all)
+    nt = g.num_tensors()
+    outs, taps = [], {t: [] for t in range(1, nt)}
+    for l in lines:
+        outs.append(o.run(l[None]))
+        if keep_all:
+            for t in range(1, nt):
+                taps[t].append(o.tensor(t).copy())
+    C = outs[0].shape[-1]
+    assert np.array_equal(np.concatenate([v.reshape(-1, C) for v in outs]), y.reshape(-1, C))
+    checked = 0
+    for t in range(1, nt if keep_all else 1):
+        if not taps[t][0].size or not g.exists(t):
+            continue
+        c = taps[t][0].shape[-1]
+        assert np.array_equal(np.concatenate([v.reshape(-1, c) for v in taps[t]]), g.fetch(t).reshape(-1, c)), "tensor %d" % t
+        checked += 1
+    assert checked >= (40 if keep_all else 0)
+    # the same binding again with new contents, then another composition, then the first one (cached binding + tables)
+    lines2 = [rs.randn(h, w, 3).astype(np.float32) for w in widths]
+    want2 = np.concatenate([o.run(l[None]).reshape(-1, C) for l in lines2[:3]])
+    assert np.array_equal(want2, g.forward_ragged(lines2[:3], keep_all=keep_all).reshape(-1, C))
+    assert np.array_equal(np.concatenate([v.reshape(-1, C) for v in outs]), g.forward_ragged(lines, keep_all=keep_all).reshape(-1, C))
     g.close()
 
 

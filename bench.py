@@ -8,7 +8,10 @@
 
 One step = one pass of the whole pipeline (OCRWorker::processRequest, batched) over one batch of 64
 synthetic 960x960 card images per GPU (BASELINE.json configs[1]); inputs are resident in HBM when
-the timed region starts.  det/rec weights are seeded synthetic (the reference ships none), so the
+the timed region starts (`value`; the same batch handed over as HOST buffers every step is `host_input`).
+The pipeline runs a batch as two chains on two parts of it (ocr_pipe_cfg.phases = 2, the default); the per-kernel
+`roofline` comes from a second timed region on a single-chain pipeline (phases = 1: one kernel at a time owns the
+device, so a launch's HIP-event duration is that kernel's), reported with its own images/sec as `single_chain`.  det/rec weights are seeded synthetic (the reference ships none), so the
 SURVEY.md section-8d protocol applies: the det network runs in full and is timed, while
 thresholding/box extraction/recognition consume a synthetic probability map rendered from the same
 text-line layout so that box counts and rec batch shapes are controlled.  cls uses the real weights.
@@ -93,8 +96,9 @@ def _cfg3_item(args):
     img = cfg3_sample(i)[0]
     h, w = img.shape[:2]
     ratio = 1.0 if max(h, w) <= limit else (np.float32(limit) / np.float32(h) if h > w else np.float32(limit) / np.float32(w))
-    rh = max(int(round(float(int(np.float32(h) * np.float32(ratio))) / 32) * 32), 32)   # ResizeImgType0, preprocess_op.cpp:74-88
-    rw = max(int(round(float(int(np.float32(w) * np.float32(ratio))) / 32) * 32), 32)
+    r32 = lambda v: int(np.floor(np.float32(v) / np.float32(32) + np.float32(0.5)))   # C round(): halves away from zero (Python's round is half-even)
+    rh = max(r32(int(np.float32(h) * np.float32(ratio))) * 32, 32)   # ResizeImgType0, preprocess_op.cpp:74-88
+    rw = max(r32(int(np.float32(w) * np.float32(ratio))) * 32, 32)
     return img, cfg3_prob_at(i, rh, rw)
 
 
@@ -191,7 +195,7 @@ def cpu_baseline(budget_s=8.0):
     except Exception:
         pass
     return {"value": best[1]["images_per_sec"] if best[1] else None, "unit": "images/sec",
-            "cores": best[1]["workers"] * 2 if best[1] else 0, "kind": "port",
+            "cores": best[1]["workers"] * 2 if best[1] else 0, "host_cores_allowed": cores, "kind": "port",
             "sample": "best of the reference-shaped legs (%s): every leg is ~%.0f s of the same cfg2 pipeline and parameters on "
                       "fresh images per worker; host has %d usable cores (%s)" % (best[0], budget_s, cores, cpu),
             "legs": out}
@@ -319,7 +323,9 @@ def main(argv=None):
     else:
         from __graft_entry__ import load_package
         pkg = load_package()
-        pipe = pkg.Pipe(device=local, enable_cls=True, limit_side_len=960, rec_batch_num=16, rec_img_h=48, rec_img_w=320)
+        mk_pipe = lambda phases=0: pkg.Pipe(device=local, enable_cls=True, limit_side_len=960, rec_batch_num=16, rec_img_h=48,
+                                            rec_img_w=320, phases=phases)
+        pipe = mk_pipe()
         sync = lambda: pkg.check(pkg.lib().ocr_dev_sync())
         if cfg == "cfg2":
             d_imgs = pkg.DevArray(imgs)
@@ -329,15 +335,19 @@ def main(argv=None):
             pipe.stage(0, img_list, prob_list)     # resident in HBM from here on: a step re-runs the staged slot
             run_step = lambda collect=False: pipe.run_staged(0, collect=collect)
         else:
-            # cfg4: this rank's share of the stream in batches of 64 through the two staging slots
+            # cfg4: this rank's share of the stream in batches of 64 through the two staging slots.  Batch b is images
+            # b*64 .. b*64+63 of the rank's cyclic pool of `pool_n` distinct images: pool_n / 64 distinct compositions, every
+            # one staged from HOST memory when its turn comes; the protocol's probability maps are uploaded once per pool
+            # image and attached device-to-device (they stand in for the detector's own output, not for request data).
             total_stream = args.images or 10000
             mine = len(range(rank, total_stream, world))
             stream_batches = (mine + batch - 1) // batch
-            cyc = [(img_list[(b * batch + j) % pool_n], prob_list[(b * batch + j) % pool_n]) for b in range(2) for j in range(batch)]
-            # two fixed batch compositions (even / odd batches of the cycle) so that the protocol's maps stay attached
-            comp = [([c[0] for c in cyc[:batch]], [c[1] for c in cyc[:batch]]), ([c[0] for c in cyc[batch:]], [c[1] for c in cyc[batch:]])]
-            pipe.stage(0, comp[0][0], comp[0][1])
-            pipe.stage(1, comp[1][0], comp[1][1])
+            d_pool_probs = [pkg.DevArray(p_) for p_ in prob_list]
+            comp_of = lambda b: [(b * batch + j) % pool_n for j in range(batch)]
+            def stage_batch(slot, b):
+                ids_ = comp_of(b)
+                pipe.stage_dev_probs(slot, [img_list[i] for i in ids_], [d_pool_probs[i] for i in ids_])
+            stage_batch(0, 0)
             run_step = lambda collect=False: pipe.run_staged(0, collect=collect)
 
     def barrier():
@@ -347,24 +357,12 @@ def main(argv=None):
 
     for _ in range(args.warmup):
         run_step()
-    survey = primary = None
-    kernel_timing = not args.no_kernel_timing and not stub
-    if kernel_timing:
-        # One untimed survey pass with HIP events around EVERY network launch (on the launch stream) finds the
-        # dominant kernel and gives the per-kernel table; in the timed region only that kernel carries events
-        # (a thousand event pairs per step cost ~4% of the step).
-        pipe.timing(True)
-        run_step()
-        survey = pipe.timing_report()
-        # The odd-width rec launches (16-32 lines) share the GPU with the big one on other streams: their
-        # event spans are mostly time spent waiting for free CUs, not kernel time.  The dominant kernel is
-        # looked for among the det launches and the rec launch with the most lines.
-        def lines_of(name):
-            return int(name.split("@")[1].split("x")[0])
-        rec_max = max([lines_of(k) for k in survey if k.startswith("rec.")] or [0])
-        primary = {k: v for k, v in survey.items() if not k.startswith("rec.") or lines_of(k) == rec_max}
-        dominant = max(primary.items(), key=lambda kv: kv[1]["ms"])[0]
-        pipe.timing(True, only=dominant)   # also resets the accumulated timings
+    kernel_timing = not args.no_kernel_timing and not stub and cfg in ("cfg2", "cfg3")
+    if cfg == "cfg4" and not stub:
+        for b in range(pool_n // batch):   # every composition once, untimed: the stream's steady state has seen all its shapes
+            stage_batch(0, b)
+            pipe.run_staged(0, collect=False)
+        stats0 = pipe.stats()
     step_ms = []
     nwords = 0
     barrier()
@@ -372,11 +370,11 @@ def main(argv=None):
     if cfg == "cfg4" and not stub:
         import threading
         steps_done = stream_batches
-        pipe.stage(0, comp[0][0])
+        stage_batch(0, 0)
         for b in range(stream_batches):
             s0 = time.perf_counter()
             sl = b & 1
-            th = threading.Thread(target=pipe.stage, args=(1 - sl, comp[1 - sl][0]))
+            th = threading.Thread(target=stage_batch, args=(1 - sl, b + 1))
             th.start()
             nwords = pipe.run_staged(sl, collect=False)
             th.join()
@@ -395,11 +393,49 @@ def main(argv=None):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     stage_ms = list(pipe.times)
-    rep_timed = None
-    if kernel_timing and rank == 0:
-        rep_timed = pipe.timing_report()   # the dominant kernel's launches inside the timed region
-    if kernel_timing:
-        pipe.timing(False)                 # (resets the accumulated timings: read them first)
+    stream_stats = None
+    if cfg == "cfg4" and not stub:
+        st1 = pipe.stats()
+        runs = st1["runs"] - stats0["runs"]
+        stream_stats = {"network_runs": runs, "new_bindings": st1["binds"] - stats0["binds"],
+                        "binding_cache_hit_rate": 1.0 - (st1["binds"] - stats0["binds"]) / max(1, runs),
+                        "graph_replay_rate": (st1["graph_replays"] - stats0["graph_replays"]) / max(1, runs),
+                        "distinct_batch_compositions": pool_n // batch}
+
+    # ---- roofline leg, rank 0 of a single-GPU run: a second timed region of the same steps on a SINGLE-CHAIN pipeline
+    # (phases = 1).  One untimed survey pass with HIP events around every network launch (on the launch stream) finds the
+    # dominant kernel and gives the per-kernel table; in the timed steps only that kernel carries events (a thousand
+    # event pairs per step cost ~4 % of the step).  With two chains a kernel shares the chip with the other chain's
+    # kernels and an event span stops being a property of the kernel.
+    survey = rep_timed = single_chain = None
+    if kernel_timing and rank == 0 and world == 1:
+        pipe1 = mk_pipe(1)
+        if cfg == "cfg2":
+            run1 = lambda: pipe1.run_device(d_imgs, H, W, BATCH, d_probs, collect=False)
+        else:
+            pipe1.stage(0, img_list, prob_list)
+            run1 = lambda: pipe1.run_staged(0, collect=False)
+        run1()
+        run1()
+        pipe1.timing(True)
+        run1()
+        survey = pipe1.timing_report()
+        dominant = max(survey.items(), key=lambda kv: kv[1]["ms"])[0]
+        pipe1.timing(True, only=dominant)   # also resets the accumulated timings
+        rsteps = max(2, min(args.steps, 10))
+        sync()
+        t0r = time.perf_counter()
+        for _ in range(rsteps):
+            run1()
+        sync()
+        elr = time.perf_counter() - t0r
+        rep_timed = pipe1.timing_report()
+        pipe1.timing(False)
+        single_chain = {"value": batch * rsteps / elr, "unit": "images/sec", "ms_per_step": elr * 1e3 / rsteps, "steps": rsteps,
+                        "stage_ms_last_step": dict(zip(("det", "cls", "rec"), list(pipe1.times))),
+                        "what": "the same resident steps on a pipeline with ONE chain (ocr_pipe_cfg.phases = 1): the timed region the "
+                                "roofline figures are measured in"}
+        pipe1.close()
 
     # ---- host-input leg (PCIe-inclusive), rank 0 of a single-GPU run only: same batch from host memory every step
     host_in = None
@@ -420,7 +456,7 @@ def main(argv=None):
     two_workers = None
     if not stub and cfg == "cfg2" and world == 1 and not args.no_two_workers:
         import threading
-        pipe2 = pkg.Pipe(device=local, enable_cls=True, limit_side_len=960, rec_batch_num=16, rec_img_h=48, rec_img_w=320)
+        pipe2 = mk_pipe()
         pipe.stage(0, img_list, prob_list)
         pipe2.stage(0, img_list, prob_list)
         for p_ in (pipe, pipe2):
@@ -440,8 +476,8 @@ def main(argv=None):
         elw = time.perf_counter() - t0w
         pipe2.close()
         two_workers = {"value": batch * 2 * wsteps / elw, "unit": "images/sec", "ms_per_step": elw * 1e3 / (2 * wsteps), "steps": 2 * wsteps,
-                       "what": "two pipeline workers (two ocr_pipe handles, own streams and arenas) on this one GPU, each running the "
-                               "resident batch %d times concurrently" % wsteps}
+                       "what": "two pipeline workers (two ocr_pipe handles, own streams and arenas, two chains each) on this one GPU, "
+                               "each running the resident batch %d times concurrently" % wsteps}
 
     # ---- result gather (after the timed region): every rank's words of one step as fixed-size records
     gather = None
@@ -509,9 +545,10 @@ def main(argv=None):
             "cfg3": "BASELINE.json configs[2]: batch=%d mixed-aspect 640-1280 px images per GPU (seeds 2000+i), 4-64 text lines each, "
                     "det (limit 960 'max', one pass per distinct size) + cls + rec with the lines of all images pooled, resident in HBM; "
                     "same weights and probability-map protocol as cfg2" % batch,
-            "cfg4": "BASELINE.json configs[3]: %d-image stream of cfg3 images (cyclic over 256 distinct ones per rank), image i -> rank "
-                    "i mod n_gpus, batches of 64 from HOST memory through the double-buffered pinned staging (PCIe-inclusive by "
-                    "construction: a stream does not fit the resident protocol); same weights and protocol as cfg2" % (args.images or 10000),
+            "cfg4": "BASELINE.json configs[3]: %d-image stream of cfg3 images, image i -> rank i mod n_gpus; every rank cycles through its "
+                    "pool of 256 distinct images in batches of 64 (4 distinct batch compositions, each staged from HOST memory when its "
+                    "turn comes, through the double-buffered pinned staging: PCIe-inclusive by construction); same weights and "
+                    "protocol as cfg2" % (args.images or 10000),
         }[cfg]
         images_total = (sum(len(range(r, args.images or 10000, world)) for r in range(world)) if cfg == "cfg4" and not stub
                         else n_ranks * batch * steps_done)
@@ -536,6 +573,12 @@ def main(argv=None):
             "stage_ms_last_step": {"det": stage_ms[0], "cls": stage_ms[1], "rec": stage_ms[2]},
             "words_per_step": nwords,
         }
+        out["resident"] = {"value": out["value"], "unit": "images/sec",
+                           "what": "`value`: inputs already in HBM when the timed region starts (the contract of this line)"} if cfg != "cfg4" else None
+        if stream_stats:
+            out["stream"] = stream_stats
+        if single_chain:
+            out["single_chain"] = single_chain
         if host_in:
             out["host_input"] = host_in
         if two_workers:
@@ -562,7 +605,7 @@ def main(argv=None):
                 gbps = r["bytes"] / (r["ms"] * 1e-3) / 1e9 if r["ms"] > 0 else 0.0
                 # which roof binds this kernel: its algorithmic intensity against the f32 ridge (157.3 TFLOP/s / 8 TB/s)
                 hbm_bound = r["bytes"] > 0 and r["flops"] / r["bytes"] < FP32_MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
-                out["roofline"] = {"kernel": name, "bound": "hbm" if hbm_bound else "mfma",
+                out["roofline"] = {"kernel": name, "measured_in": "single_chain", "bound": "hbm" if hbm_bound else "mfma",
                                    "achieved": gbps if hbm_bound else tflops, "peak": HBM_PEAK_GBS if hbm_bound else FP32_MFMA_PEAK_TFLOPS,
                                    "unit": "GB/s" if hbm_bound else "TFLOP/s",
                                    "frac": gbps / HBM_PEAK_GBS if hbm_bound else tflops / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
@@ -571,10 +614,10 @@ def main(argv=None):
                                    "algorithmic_bytes_per_launch": r["bytes"] / max(1, r["count"]),
                                    "tflops": tflops, "hbm_GBps_algorithmic": gbps}
             if survey:   # per-kernel shares from the untimed survey pass (one step, every launch timed)
-                tot = sum(v["ms"] for v in primary.values())
+                tot = sum(v["ms"] for v in survey.values())
                 out["kernel_time_share_top5"] = {k: round(v["ms"] / tot, 4) for k, v in
-                                                 sorted(primary.items(), key=lambda kv: -kv[1]["ms"])[:5]}
-                out["network_kernel_ms_per_step"] = tot   # det + the big rec launch (see `primary` above)
+                                                 sorted(survey.items(), key=lambda kv: -kv[1]["ms"])[:5]}
+                out["network_kernel_ms_per_step"] = tot
                 if os.environ.get("OCR_BENCH_KERNEL_TABLE"):
                     with open(os.environ["OCR_BENCH_KERNEL_TABLE"], "w") as f:
                         for k, v in sorted(survey.items(), key=lambda kv: -kv[1]["ms"]):

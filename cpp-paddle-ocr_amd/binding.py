@@ -362,7 +362,7 @@ class Rec:
 # ---------------------------------------------------------------------------------------------
 class ocr_pipe_cfg(C.Structure):
     _fields_ = [("det", ocr_det_cfg), ("cls", ocr_cls_cfg), ("rec", ocr_rec_cfg), ("enable_cls", C.c_int),
-                ("crop_mode", C.c_int)]
+                ("crop_mode", C.c_int), ("phases", C.c_int)]
 
 
 class ocr_word(C.Structure):
@@ -371,7 +371,7 @@ class ocr_word(C.Structure):
 
 EXPORTS += ["ocr_pipe_cfg_default", "ocr_pipe_create", "ocr_pipe_destroy", "ocr_pipe_run", "ocr_pipe_run_device",
             "ocr_pipe_stage", "ocr_pipe_slot_probs", "ocr_pipe_run_staged", "ocr_pipe_stage_jpeg", "ocr_jpeg_decode",
-            "ocr_pipe_label", "ocr_pipe_det_shape", "ocr_pipe_timing", "ocr_pipe_timing_filter", "ocr_pipe_timing_report", "ocr_dev_alloc",
+            "ocr_pipe_label", "ocr_pipe_det_shape", "ocr_pipe_stats", "ocr_pipe_timing", "ocr_pipe_timing_filter", "ocr_pipe_timing_report", "ocr_dev_alloc",
             "ocr_dev_free", "ocr_dev_upload", "ocr_dev_download", "ocr_dev_sync", "ocr_rotate_crop", "ocr_rotate_crop_shape", "ocr_rotate180_rois"]
 
 
@@ -393,6 +393,7 @@ def _pipe_protos(L):
     L.ocr_pipe_label.restype = C.c_char_p
     L.ocr_pipe_det_shape.argtypes = [vp, C.c_int, C.c_int, ip, ip]
     L.ocr_pipe_timing.argtypes = [vp, C.c_int]
+    L.ocr_pipe_stats.argtypes = [vp, C.POINTER(C.c_longlong)]
     L.ocr_pipe_timing_report.argtypes = [vp, C.c_char_p, C.c_size_t]
     L.ocr_pipe_timing_filter.argtypes = [vp, C.c_char_p]
     L.ocr_dev_alloc.argtypes = [C.POINTER(vp), C.c_size_t]
@@ -475,7 +476,7 @@ class Pipe:
 
     def __init__(self, model_root=None, device=0, enable_cls=False, limit_type="max", limit_side_len=512, thresh=0.2,
                  box_thresh=0.4, unclip_ratio=1.8, use_dilation=False, rec_batch_num=16, rec_img_h=28, rec_img_w=192,
-                 cls_batch_num=8, crop_mode=CROP_BOUNDING_RECT, score_mode="fast", rec_sort_mode=0):
+                 cls_batch_num=8, crop_mode=CROP_BOUNDING_RECT, score_mode="fast", rec_sort_mode=0, phases=0):
         L = lib()
         _pipe_protos(L)
         root = model_root or MODELS
@@ -495,6 +496,7 @@ class Pipe:
         cfg.cls.cls_batch_num = cls_batch_num
         cfg.enable_cls = int(enable_cls)
         cfg.crop_mode = int(crop_mode)
+        cfg.phases = int(phases)
         self.h = C.c_void_p()
         check(L.ocr_pipe_create(C.byref(cfg), C.byref(self.h)))
         self.times = (C.c_double * 3)()
@@ -542,6 +544,24 @@ class Pipe:
             for i, m in enumerate(maps):
                 arr[i] = m.ctypes.data
             check(lib().ocr_pipe_slot_probs(self.h, slot, arr, n))
+
+    def stage_dev_probs(self, slot, imgs, dev_probs):
+        """ocr_pipe_stage with probability maps that already sit in device memory (DevArray per image): they are copied
+        device to device into the slot (a request stream's maps are uploaded once per distinct image, not per batch)."""
+        n = len(imgs)
+        self._staged_n = getattr(self, "_staged_n", {})
+        check(lib().ocr_pipe_stage(self.h, slot, _imgs(imgs), n))
+        self._staged_n[slot] = n
+        arr = (C.c_void_p * n)()
+        for i, d in enumerate(dev_probs):
+            arr[i] = d.ptr.value
+        check(lib().ocr_pipe_slot_probs(self.h, slot, arr, n))
+
+    def stats(self):
+        """{'runs', 'binds', 'graph_replays'} summed over the pipeline's networks (Net::stats)"""
+        out = (C.c_longlong * 3)()
+        check(lib().ocr_pipe_stats(self.h, out))
+        return dict(runs=int(out[0]), binds=int(out[1]), graph_replays=int(out[2]))
 
     def run_staged(self, slot, collect=True):
         count = self._staged_n[slot]

@@ -11,6 +11,7 @@
 namespace ocr {
 
 void set_last_error(const std::string& msg);
+void priority_anchor(int device_id, bool again = false);             // one idle high-priority stream per device (capi_net.hip)
 const char* embedded_plan(const char* kind);  // "det" | "cls" | "rec" -> plan text or nullptr
 
 // Resolves the weights file of a model directory the way the reference resolves its model file

@@ -65,6 +65,34 @@ bool load_model_dir(const std::string& model_dir, const char* weights_override, 
   return pdiparams_read(params, names, w, err);
 }
 
+// Idle high-priority streams, kept for the life of the process.  Measured (round 3, tools/ab_cfg3.sh, ROCm 7.2 runtime,
+// 256 mixed-size images): BASELINE configs[2]'s detector - host threads driving normal-priority streams ("lanes") with
+// one small launch chain per image size - is bimodal: 145-150 ms or 190-270 ms per step, and which one depends on how
+// many streams of which priority class the process created BEFORE the lanes' streams.  Rounds 1-2 were in the fast mode
+// by accident (the recognizer's odd-width lanes were high-priority streams).  With one chain per pipeline: no such
+// stream 193 ms, one created after the recognizer's stream 151 ms, one created before every other stream 196 ms, five
+// more NORMAL streams 197 ms.  With two chains (the default): none 195 ms, one after all stage streams 266 ms, two
+// 148 ms.  GPU_MAX_HW_QUEUES = 8 / 32 and DEBUG_HIP_DYNAMIC_QUEUES = 0 / 1 do not move the slow mode.  The runtime's
+// mapping of streams to hardware queues is not documented; ocr_pipe_create uses the configuration that measured fast
+// (two such streams after its stage objects).  OCR_PRIO_ANCHOR=0 leaves them out (A/B).  The structural fix is a
+// ragged detector batch (one launch list for all sizes, as the recognizer's), which needs no lanes at all.
+void priority_anchor(int device_id, bool again) {
+  static std::mutex mu;
+  static hipStream_t anchor[64] = {};
+  std::lock_guard<std::mutex> lk(mu);
+  const char* e = getenv("OCR_PRIO_ANCHOR");
+  if (device_id < 0 || device_id >= 64 || (anchor[device_id] && !again) || (e && e[0] == '0')) return;
+  int least = 0, greatest = 0;
+  if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess || least == greatest ||
+      hipStreamCreateWithPriority(&anchor[device_id], hipStreamDefault, greatest) != hipSuccess) {
+    anchor[device_id] = nullptr;
+    (void)hipGetLastError();
+    return;
+  }
+  (void)hipMemsetAsync(nullptr, 0, 0, anchor[device_id]);  // (touch the stream: the runtime creates its queue on first use)
+  (void)hipGetLastError();
+}
+
 }  // namespace ocr
 
 using namespace ocr;
@@ -97,27 +125,6 @@ int ocr_rt_init(int device_id) {
   CAPI_HIP(hipGetDeviceProperties(&prop, device_id));
   if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
     return fail(OCR_ERR_DEVICE, std::string("device is ") + prop.gcnArchName + ", this build targets gfx950 (MI355X) only");
-  // One idle high-priority stream per device, created before the pipeline's own streams and kept for the life of the
-  // process.  Measured (round 3, tools/ab_cfg3.sh; ROCm 7.2 runtime): BASELINE configs[2]'s detector - eight host
-  // threads driving eight normal-priority streams with one small launch chain per image size - takes 145 ms per 256
-  // images when the process owns a stream of another priority class and 193 ms when it does not (rounds 1-2 had such
-  // streams by accident: the recognizer's odd-width lanes); five more normal streams, GPU_MAX_HW_QUEUES = 8 / 32 and
-  // DEBUG_HIP_DYNAMIC_QUEUES = 0 / 1 change nothing.  The runtime's mapping of streams to hardware queues is not
-  // documented; this is the measured configuration.  OCR_PRIO_ANCHOR=0 leaves it out (A/B).
-  {
-    static std::mutex mu;
-    static hipStream_t anchor[64] = {};
-    std::lock_guard<std::mutex> lk(mu);
-    const char* e = getenv("OCR_PRIO_ANCHOR");
-    if (device_id < 64 && !anchor[device_id] && !(e && e[0] == '0')) {
-      int lo = 0, hi = 0;
-      if (hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo &&
-          hipStreamCreateWithPriority(&anchor[device_id], hipStreamDefault, hi) != hipSuccess) {
-        anchor[device_id] = nullptr;
-        (void)hipGetLastError();
-      }
-    }
-  }
   return OCR_OK;
 }
 

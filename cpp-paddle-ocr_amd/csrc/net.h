@@ -117,6 +117,9 @@ class Net {
   const std::map<std::string, KernelTiming>& timings() const { return timings_; }
   void reset_timings() { timings_.clear(); }
   void collect_timings();  // after a stream sync: folds event pairs into timings_
+  // binding-cache statistics: runs, runs that had to bind a new shape, runs replayed from a recorded hipGraph
+  struct Stats { long runs = 0, binds = 0, graph_replays = 0; };
+  const Stats& stats() const { return stats_; }
 
  private:
   struct Launch {
@@ -195,6 +198,7 @@ class Net {
   int* head_amax_ = nullptr;
   float* head_pmax_ = nullptr;
   bool timing_ = false;
+  Stats stats_;
   std::string timing_filter_;
   int keep_all_ = 0;
   std::map<std::string, KernelTiming> timings_;

@@ -401,6 +401,7 @@ const std::vector<int>& Net::ragged_widths(int tid) const {
 }
 
 bool Net::bind(int N, int H, int W, std::string& err, const int* widths) {
+  stats_.binds++;
   std::unique_ptr<Binding> B(new Binding());
   const bool rag = widths != nullptr;
   B->n = N; B->h = H; B->w = W;
@@ -1128,6 +1129,7 @@ bool Net::run_ragged(const float* x, int H, const int* widths, int N, hipStream_
 bool Net::run_bound(const float* x, hipStream_t s, std::string& err) {
   Binding& B = *cur_;
   B.stamp = ++clock_;
+  stats_.runs++;
   if (B.rag_dev && !B.rag_uploaded) {  // the line tables travel once, on the stream that runs the launches
     HIP_OK(hipMemcpyAsync(B.rag_dev, B.rag_host.data(), B.rag_host.size() * sizeof(int), hipMemcpyHostToDevice, s));
     B.rag_uploaded = true;
@@ -1149,6 +1151,7 @@ bool Net::run_bound(const float* x, hipStream_t s, std::string& err) {
   if (graphs && B.graph_exec && B.graph_x == x && B.graph_stream == s && !memcmp(B.graph_head, head, sizeof head)) {
     HIP_OK(hipGraphLaunch(B.graph_exec, s));
     HIP_OK(hipGetLastError());
+    stats_.graph_replays++;
     return true;
   }
   if (graphs && repeat) {

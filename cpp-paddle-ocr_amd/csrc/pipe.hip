@@ -92,7 +92,11 @@ static int rotate180_in_order(const std::vector<RotDesc>& rd, DevBuf<RotDesc>& s
   return OCR_OK;
 }
 
-struct ocr_pipe {
+// One chain det -> crops -> [cls -> rotate] -> rec (OCRWorker::processRequest) with its own stage objects, streams and
+// buffers.  A pipeline owns two of them (ocr_pipe below): the chain of a batch is a sequence of dependent phases, some
+// of them latency-bound (det post-processing, cls, the tails of the networks), and two chains side by side on two
+// halves of the batch fill each other's gaps.
+struct PipeWorker {
   DetStage det;
   // Further detector instances (own stream, network, buffers) for batches of MIXED sizes: every distinct size is its own
   // det pass (a few images at most), a latency-bound chain of ~90 small launches that leaves the chip idle - several
@@ -102,11 +106,6 @@ struct ocr_pipe {
   int det_lanes = 8;
   RecStage rec;
   std::unique_ptr<ClsStage> cls;
-  int device = 0;
-  StageSlot slots[2];
-  hipStream_t copy_stream = nullptr;
-  JpegScratch jpeg;
-  DevBuf<uint8_t> work;  // the requests' clones (OCRRequest copies the Mat, ocr_worker.h:28-29): cls rotates in place on them
   DevBuf<RotDesc> rot_desc;
   DevBuf<int> rot_seg;
   int crop_mode = 0;  // OCR_CROP_BOUNDING_RECT | OCR_CROP_ROTATE
@@ -116,111 +115,17 @@ struct ocr_pipe {
   std::vector<int> nbox;
   static constexpr int kCap = 1000;  // max_candidates bounds the boxes of one image (postprocess_op.cpp:260)
 
-  ~ocr_pipe() { if (copy_stream) (void)hipStreamDestroy(copy_stream); }
-
-  // ---- stage: host images -> pinned -> device (asynchronous after the host copies)
-  // layout of a batch in a slot: stable order by (rows, cols), images of one size contiguous
-  int layout(StageSlot& S, int count, const std::function<void(int, int&, int&)>& size_of, std::string& err) {
-    if (!copy_stream && hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking) != hipSuccess) { err = "hipStreamCreate failed"; return OCR_ERR_DEVICE; }
-    if (!S.ready && hipEventCreateWithFlags(&S.ready, hipEventDisableTiming) != hipSuccess) { err = "hipEventCreate failed"; return OCR_ERR_DEVICE; }
-    if (S.staged && hipEventSynchronize(S.ready) != hipSuccess) { err = "staging event failed"; return OCR_ERR_DEVICE; }  // pinned buffer free again
-    std::vector<int> order(count), rows(count), cols(count);
-    for (int i = 0; i < count; ++i) { order[i] = i; size_of(i, rows[i], cols[i]); }
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return rows[a] != rows[b] ? rows[a] < rows[b] : cols[a] < cols[b]; });
-    const std::vector<StageSlot::Img> before = S.imgs;
-    S.imgs.clear();
-    S.groups.clear();
-    size_t off = 0, poff = 0;
-    for (int k = 0; k < count; ++k) {
-      const int r = rows[order[k]], c = cols[order[k]];
-      if (S.groups.empty() || S.groups.back().rows != r || S.groups.back().cols != c) {
-        off = (off + 255) & ~(size_t)255;
-        S.groups.push_back({r, c, k, 0, off, poff});
-      }
-      S.groups.back().count++;
-      int rh = 0, rw = 0;
-      { float a, b; DetStage::resize_shape(r, c, det.cfg().limit_type, det.cfg().limit_side_len, rh, rw, a, b); }
-      S.imgs.push_back({r, c, order[k], off, poff});
-      off += (size_t)r * c * 3;
-      poff += (size_t)rh * rw;
+  int create(const DetConfig& d, const RecConfig& r, const ClsConfig* k, int crop, std::string& err) {
+    int code = 0;
+    if (!det.create(d, err, code)) return code ? code : OCR_ERR_DEVICE;
+    det_cfg = d;
+    if (!rec.create(r, err, code)) return code ? code : OCR_ERR_DEVICE;
+    rec.want_taps = false;
+    if (k) {
+      cls.reset(new ClsStage());
+      if (!cls->create(*k, err, code)) return code ? code : OCR_ERR_DEVICE;
     }
-    S.bytes = off;
-    S.prob_floats = poff;
-    // probability maps attached to the slot (benchmark protocol) stay valid only while the layout is the same
-    bool same = before.size() == S.imgs.size();
-    for (size_t k = 0; same && k < before.size(); ++k)
-      same = before[k].rows == S.imgs[k].rows && before[k].cols == S.imgs[k].cols && before[k].orig == S.imgs[k].orig;
-    if (!same) S.has_probs = false;
-    if (!S.dev.ensure(off + 256, err)) return OCR_ERR_DEVICE;
-    return OCR_OK;
-  }
-
-  // ---- stage: host images -> pinned -> device (asynchronous after the host copies)
-  int stage(int si, const ocr_img* imgs, int count, std::string& err) {
-    StageSlot& S = slots[si];
-    int rc = layout(S, count, [&](int i, int& r, int& c) { r = imgs[i].rows; c = imgs[i].cols; }, err);
-    if (rc) return rc;
-    const size_t off = S.bytes;
-    if (off > S.pinned_cap) {
-      if (S.pinned) (void)hipHostFree(S.pinned);
-      S.pinned = nullptr;
-      S.pinned_cap = 0;
-      if (hipHostMalloc((void**)&S.pinned, off, hipHostMallocDefault) != hipSuccess) { err = "hipHostMalloc failed"; return OCR_ERR_DEVICE; }
-      S.pinned_cap = off;
-    }
-    // host copies on a few threads (one thread moves ~10 GB/s: 64 images of 960x960 would take 18 ms)
-    {
-      const int nthreads = (int)std::min<size_t>(8, std::max<size_t>(1, off >> 22));
-      auto copy_range = [&](int t) {
-        for (int k = t; k < count; k += nthreads) {
-          const ocr_img& im = imgs[S.imgs[k].orig];
-          const size_t row = (size_t)im.cols * 3, stride = im.row_stride ? im.row_stride : row;
-          uint8_t* dst = S.pinned + S.imgs[k].off;
-          if (stride == row) memcpy(dst, im.data, row * im.rows);
-          else for (int y = 0; y < im.rows; ++y) memcpy(dst + row * y, im.data + stride * y, row);
-        }
-      };
-      std::vector<std::thread> th;
-      for (int t = 1; t < nthreads; ++t) th.emplace_back(copy_range, t);
-      copy_range(0);
-      for (auto& t : th) t.join();
-    }
-    if (hipMemcpyAsync(S.dev.p, S.pinned, off, hipMemcpyHostToDevice, copy_stream) != hipSuccess) { err = "H2D copy failed"; return OCR_ERR_DEVICE; }
-    if (hipEventRecord(S.ready, copy_stream) != hipSuccess) { err = "hipEventRecord failed"; return OCR_ERR_DEVICE; }
-    S.staged = true;
-    return OCR_OK;
-  }
-
-  // ---- stage JPEG coefficients: the pixel half of the decoder runs on the copy stream, into the slot
-  int stage_jpeg(int si, const ocr_jpeg_img* imgs, int count, std::string& err) {
-    StageSlot& S = slots[si];
-    int rc = layout(S, count, [&](int i, int& r, int& c) { r = imgs[i].rows; c = imgs[i].cols; }, err);
-    if (rc) return rc;
-    std::vector<ocr_jpeg_img> ordered(count);
-    std::vector<uint8_t*> dst(count);
-    for (int k = 0; k < count; ++k) { ordered[k] = imgs[S.imgs[k].orig]; dst[k] = S.dev.p + S.imgs[k].off; }
-    rc = jpeg_decode_async(ordered.data(), count, dst.data(), jpeg, copy_stream, err);
-    if (rc) return rc;
-    if (hipEventRecord(S.ready, copy_stream) != hipSuccess) { err = "hipEventRecord failed"; return OCR_ERR_DEVICE; }
-    S.staged = true;
-    return OCR_OK;
-  }
-
-  // benchmark protocol for synthetic weights (SURVEY.md section 8d): per staged image a probability map of the
-  // detector's input resolution that replaces the network's map for thresholding / scoring
-  int slot_probs(int si, const float* const* probs, int count, std::string& err) {
-    StageSlot& S = slots[si];
-    if (!S.staged || count != (int)S.imgs.size()) { err = "stage the slot's images first (same count)"; return OCR_ERR_ARG; }
-    if (!S.probs.ensure(S.prob_floats + 64, err)) return OCR_ERR_DEVICE;
-    for (int k = 0; k < count; ++k) {
-      const size_t n = (k + 1 < count ? S.imgs[k + 1].prob_off : S.prob_floats) - S.imgs[k].prob_off;
-      if (hipMemcpyAsync(S.probs.p + S.imgs[k].prob_off, probs[S.imgs[k].orig], n * sizeof(float), hipMemcpyHostToDevice, copy_stream) != hipSuccess) {
-        err = "probability map upload failed";
-        return OCR_ERR_DEVICE;
-      }
-    }
-    if (hipEventRecord(S.ready, copy_stream) != hipSuccess) { err = "hipEventRecord failed"; return OCR_ERR_DEVICE; }
-    S.has_probs = true;
+    crop_mode = crop;
     return OCR_OK;
   }
 
@@ -338,26 +243,6 @@ struct ocr_pipe {
     return OCR_OK;
   }
 
-  // run a staged slot: wait for its upload, clone, run, hand the results back in the caller's order
-  int run_slot(int si, ocr_word* words, int cap_words, int* word_off, int* nwords, int32_t* ids, int cap_ids, double times[3]) {
-    StageSlot& S = slots[si];
-    if (!S.staged || S.imgs.empty()) return fail(OCR_ERR_ARG, "nothing staged in this slot");
-    std::string err;
-    if (hipStreamWaitEvent(det.stream(), S.ready, 0) != hipSuccess) return fail(OCR_ERR_DEVICE, "hipStreamWaitEvent failed");
-    if (!work.ensure(S.bytes + 256, err)) return fail(OCR_ERR_DEVICE, err);
-    if (hipMemcpyAsync(work.p, S.dev.p, S.bytes, hipMemcpyDeviceToDevice, det.stream()) != hipSuccess) return fail(OCR_ERR_DEVICE, "clone failed");
-    double t[3] = {0, 0, 0};
-    std::vector<std::vector<ocr_word>> W;
-    std::vector<std::vector<int32_t>> I;
-    const int rc = run_images(work.p, S.imgs, S.groups, S.has_probs ? S.probs.p : nullptr, W, I, t, err);
-    if (rc) return fail(rc, err);
-    if (times) { times[0] = t[0]; times[1] = t[1]; times[2] = t[2]; }
-    const int count = (int)S.imgs.size();
-    std::vector<int> order(count);  // order[original index] = layout index
-    for (int k = 0; k < count; ++k) order[S.imgs[k].orig] = k;
-    return emit(W, I, order, words, cap_words, word_off, nwords, ids, cap_ids);
-  }
-
   // crop_mode OCR_CROP_ROTATE: every box becomes its own perspective-rectified image
   // (Utility::GetRotateCropImage, utility.cpp:137-190) in the crop arena
   int rotate_crops(const uint8_t* base, const std::vector<StageSlot::Img>& imgs, std::vector<LineSrc>& lines, std::vector<int>& seg,
@@ -401,6 +286,212 @@ struct ocr_pipe {
   }
 };
 
+struct ocr_pipe {
+  PipeWorker w0;
+  // The second chain (OCR_PIPE_PHASES / ocr_pipe_cfg.phases = 2, the default): a batch of two or more images is cut in
+  // two parts that run concurrently, each on its own worker and host thread.  Results are per image and do not depend
+  // on what else is in a batch, so nothing changes but the overlap.  phases = 1 keeps one chain (one kernel at a time
+  // owns the chip: what the per-kernel roofline figures of bench.py are measured with).
+  std::unique_ptr<PipeWorker> w1;
+  int phases = 2;
+  int device = 0;
+  StageSlot slots[2];
+  hipStream_t copy_stream = nullptr;
+  JpegScratch jpeg;
+  DevBuf<uint8_t> work;  // the requests' clones (OCRRequest copies the Mat, ocr_worker.h:28-29): cls rotates in place on them
+
+  ~ocr_pipe() { if (copy_stream) (void)hipStreamDestroy(copy_stream); }
+
+  // ---- stage: host images -> pinned -> device (asynchronous after the host copies)
+  // layout of a batch in a slot: stable order by (rows, cols), images of one size contiguous
+  int layout(StageSlot& S, int count, const std::function<void(int, int&, int&)>& size_of, std::string& err) {
+    if (!copy_stream && hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking) != hipSuccess) { err = "hipStreamCreate failed"; return OCR_ERR_DEVICE; }
+    if (!S.ready && hipEventCreateWithFlags(&S.ready, hipEventDisableTiming) != hipSuccess) { err = "hipEventCreate failed"; return OCR_ERR_DEVICE; }
+    if (S.staged && hipEventSynchronize(S.ready) != hipSuccess) { err = "staging event failed"; return OCR_ERR_DEVICE; }  // pinned buffer free again
+    std::vector<int> order(count), rows(count), cols(count);
+    for (int i = 0; i < count; ++i) { order[i] = i; size_of(i, rows[i], cols[i]); }
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return rows[a] != rows[b] ? rows[a] < rows[b] : cols[a] < cols[b]; });
+    const std::vector<StageSlot::Img> before = S.imgs;
+    S.imgs.clear();
+    S.groups.clear();
+    size_t off = 0, poff = 0;
+    for (int k = 0; k < count; ++k) {
+      const int r = rows[order[k]], c = cols[order[k]];
+      if (S.groups.empty() || S.groups.back().rows != r || S.groups.back().cols != c) {
+        off = (off + 255) & ~(size_t)255;
+        S.groups.push_back({r, c, k, 0, off, poff});
+      }
+      S.groups.back().count++;
+      int rh = 0, rw = 0;
+      { float a, b; DetStage::resize_shape(r, c, w0.det.cfg().limit_type, w0.det.cfg().limit_side_len, rh, rw, a, b); }
+      S.imgs.push_back({r, c, order[k], off, poff});
+      off += (size_t)r * c * 3;
+      poff += (size_t)rh * rw;
+    }
+    S.bytes = off;
+    S.prob_floats = poff;
+    // probability maps attached to the slot (benchmark protocol) stay valid only while the layout is the same
+    bool same = before.size() == S.imgs.size();
+    for (size_t k = 0; same && k < before.size(); ++k)
+      same = before[k].rows == S.imgs[k].rows && before[k].cols == S.imgs[k].cols && before[k].orig == S.imgs[k].orig;
+    if (!same) S.has_probs = false;
+    if (!S.dev.ensure(off + 256, err)) return OCR_ERR_DEVICE;
+    return OCR_OK;
+  }
+
+  // ---- stage: host images -> pinned -> device (asynchronous after the host copies)
+  int stage(int si, const ocr_img* imgs, int count, std::string& err) {
+    StageSlot& S = slots[si];
+    int rc = layout(S, count, [&](int i, int& r, int& c) { r = imgs[i].rows; c = imgs[i].cols; }, err);
+    if (rc) return rc;
+    const size_t off = S.bytes;
+    if (off > S.pinned_cap) {
+      if (S.pinned) (void)hipHostFree(S.pinned);
+      S.pinned = nullptr;
+      S.pinned_cap = 0;
+      if (hipHostMalloc((void**)&S.pinned, off, hipHostMallocDefault) != hipSuccess) { err = "hipHostMalloc failed"; return OCR_ERR_DEVICE; }
+      S.pinned_cap = off;
+    }
+    // host copies on a few threads (one thread moves ~10 GB/s: 64 images of 960x960 would take 18 ms)
+    {
+      const int nthreads = (int)std::min<size_t>(8, std::max<size_t>(1, off >> 22));
+      auto copy_range = [&](int t) {
+        for (int k = t; k < count; k += nthreads) {
+          const ocr_img& im = imgs[S.imgs[k].orig];
+          const size_t row = (size_t)im.cols * 3, stride = im.row_stride ? im.row_stride : row;
+          uint8_t* dst = S.pinned + S.imgs[k].off;
+          if (stride == row) memcpy(dst, im.data, row * im.rows);
+          else for (int y = 0; y < im.rows; ++y) memcpy(dst + row * y, im.data + stride * y, row);
+        }
+      };
+      std::vector<std::thread> th;
+      for (int t = 1; t < nthreads; ++t) th.emplace_back(copy_range, t);
+      copy_range(0);
+      for (auto& t : th) t.join();
+    }
+    if (hipMemcpyAsync(S.dev.p, S.pinned, off, hipMemcpyHostToDevice, copy_stream) != hipSuccess) { err = "H2D copy failed"; return OCR_ERR_DEVICE; }
+    if (hipEventRecord(S.ready, copy_stream) != hipSuccess) { err = "hipEventRecord failed"; return OCR_ERR_DEVICE; }
+    S.staged = true;
+    return OCR_OK;
+  }
+
+  // ---- stage JPEG coefficients: the pixel half of the decoder runs on the copy stream, into the slot
+  int stage_jpeg(int si, const ocr_jpeg_img* imgs, int count, std::string& err) {
+    StageSlot& S = slots[si];
+    int rc = layout(S, count, [&](int i, int& r, int& c) { r = imgs[i].rows; c = imgs[i].cols; }, err);
+    if (rc) return rc;
+    std::vector<ocr_jpeg_img> ordered(count);
+    std::vector<uint8_t*> dst(count);
+    for (int k = 0; k < count; ++k) { ordered[k] = imgs[S.imgs[k].orig]; dst[k] = S.dev.p + S.imgs[k].off; }
+    rc = jpeg_decode_async(ordered.data(), count, dst.data(), jpeg, copy_stream, err);
+    if (rc) return rc;
+    if (hipEventRecord(S.ready, copy_stream) != hipSuccess) { err = "hipEventRecord failed"; return OCR_ERR_DEVICE; }
+    S.staged = true;
+    return OCR_OK;
+  }
+
+  // benchmark protocol for synthetic weights (SURVEY.md section 8d): per staged image a probability map of the
+  // detector's input resolution that replaces the network's map for thresholding / scoring
+  int slot_probs(int si, const float* const* probs, int count, std::string& err) {
+    StageSlot& S = slots[si];
+    if (!S.staged || count != (int)S.imgs.size()) { err = "stage the slot's images first (same count)"; return OCR_ERR_ARG; }
+    if (!S.probs.ensure(S.prob_floats + 64, err)) return OCR_ERR_DEVICE;
+    for (int k = 0; k < count; ++k) {
+      const size_t n = (k + 1 < count ? S.imgs[k + 1].prob_off : S.prob_floats) - S.imgs[k].prob_off;
+      const hipError_t e = hipMemcpyAsync(S.probs.p + S.imgs[k].prob_off, probs[S.imgs[k].orig], n * sizeof(float), hipMemcpyDefault, copy_stream);
+      if (e != hipSuccess) {
+        err = std::string("probability map upload failed: ") + hipGetErrorString(e);
+        return OCR_ERR_DEVICE;
+      }
+    }
+    if (hipEventRecord(S.ready, copy_stream) != hipSuccess) { err = "hipEventRecord failed"; return OCR_ERR_DEVICE; }
+    S.has_probs = true;
+    return OCR_OK;
+  }
+
+  // ---- run: one chain, or two chains on two parts of the batch
+  int run_images(uint8_t* base, const std::vector<StageSlot::Img>& imgs, const std::vector<StageSlot::Group>& groups, const float* probs,
+                 std::vector<std::vector<ocr_word>>& out_words, std::vector<std::vector<int32_t>>& out_ids, double times[3], std::string& err) {
+    const int count = (int)imgs.size();
+    if (!w1 || count < 2) return w0.run_images(base, imgs, groups, probs, out_words, out_ids, times, err);
+    // parts: whole size groups dealt to the lighter part (pixels), the heaviest group cut in two when that balances better
+    std::vector<StageSlot::Img> pi[2];
+    std::vector<StageSlot::Group> pg[2];
+    std::vector<int> gidx[2];  // layout index of a part's images
+    size_t load[2] = {0, 0};
+    auto give = [&](int p, const StageSlot::Group& g, int first, int n) {  // images first .. first+n-1 of group g
+      int rh = 0, rw = 0;
+      { float a, b; DetStage::resize_shape(g.rows, g.cols, w0.det.cfg().limit_type, w0.det.cfg().limit_side_len, rh, rw, a, b); }
+      StageSlot::Group ng = g;
+      ng.first = (int)pi[p].size();
+      ng.count = n;
+      ng.off = g.off + (size_t)first * g.rows * g.cols * 3;
+      ng.prob_off = g.prob_off + (size_t)first * rh * rw;
+      pg[p].push_back(ng);
+      for (int k = 0; k < n; ++k) { pi[p].push_back(imgs[g.first + first + k]); gidx[p].push_back(g.first + first + k); }
+      load[p] += (size_t)n * g.rows * g.cols;
+    };
+    size_t total = 0;
+    for (const auto& g : groups) total += (size_t)g.count * g.rows * g.cols;
+    for (const auto& g : groups) {
+      const size_t px = (size_t)g.rows * g.cols, gl = px * g.count;
+      const int p = load[0] <= load[1] ? 0 : 1;
+      // cut the group where the lighter part reaches half of the batch (groups of one image are never cut)
+      const size_t room = total / 2 > load[p] ? total / 2 - load[p] : 0;
+      if (g.count >= 2 && gl > room + px && room >= px) {
+        const int na = (int)std::min<size_t>(g.count - 1, std::max<size_t>(1, (room + px / 2) / px));
+        give(p, g, 0, na);
+        give(1 - p, g, na, g.count - na);
+      } else give(p, g, 0, g.count);
+    }
+    if (pi[0].empty() || pi[1].empty()) return w0.run_images(base, imgs, groups, probs, out_words, out_ids, times, err);
+    // the clone was enqueued on worker 0's detector stream: the other worker's streams must not read it earlier
+    if (hipStreamSynchronize(w0.det.stream()) != hipSuccess) { err = "det stream sync failed"; return OCR_ERR_DEVICE; }
+    std::vector<std::vector<ocr_word>> W[2];
+    std::vector<std::vector<int32_t>> I[2];
+    double t[2][3] = {{0, 0, 0}, {0, 0, 0}};
+    int rc[2] = {OCR_OK, OCR_OK};
+    std::string errs[2];
+    std::thread other([&]() {
+      (void)hipSetDevice(device);
+      rc[1] = w1->run_images(base, pi[1], pg[1], probs, W[1], I[1], t[1], errs[1]);
+    });
+    rc[0] = w0.run_images(base, pi[0], pg[0], probs, W[0], I[0], t[0], errs[0]);
+    other.join();
+    for (int p = 0; p < 2; ++p)
+      if (rc[p]) { err = errs[p]; return rc[p]; }
+    out_words.assign(count, {});
+    out_ids.assign(count, {});
+    for (int p = 0; p < 2; ++p)
+      for (size_t k = 0; k < gidx[p].size(); ++k) {
+        out_words[gidx[p][k]] = std::move(W[p][k]);
+        out_ids[gidx[p][k]] = std::move(I[p][k]);
+      }
+    for (int k = 0; k < 3; ++k) times[k] += std::max(t[0][k], t[1][k]);  // the two chains ran side by side
+    return OCR_OK;
+  }
+
+  // run a staged slot: wait for its upload, clone, run, hand the results back in the caller's order
+  int run_slot(int si, ocr_word* words, int cap_words, int* word_off, int* nwords, int32_t* ids, int cap_ids, double times[3]) {
+    StageSlot& S = slots[si];
+    if (!S.staged || S.imgs.empty()) return fail(OCR_ERR_ARG, "nothing staged in this slot");
+    std::string err;
+    if (hipStreamWaitEvent(w0.det.stream(), S.ready, 0) != hipSuccess) return fail(OCR_ERR_DEVICE, "hipStreamWaitEvent failed");
+    if (!work.ensure(S.bytes + 256, err)) return fail(OCR_ERR_DEVICE, err);
+    if (hipMemcpyAsync(work.p, S.dev.p, S.bytes, hipMemcpyDeviceToDevice, w0.det.stream()) != hipSuccess) return fail(OCR_ERR_DEVICE, "clone failed");
+    double t[3] = {0, 0, 0};
+    std::vector<std::vector<ocr_word>> W;
+    std::vector<std::vector<int32_t>> I;
+    const int rc = run_images(work.p, S.imgs, S.groups, S.has_probs ? S.probs.p : nullptr, W, I, t, err);
+    if (rc) return fail(rc, err);
+    if (times) { times[0] = t[0]; times[1] = t[1]; times[2] = t[2]; }
+    const int count = (int)S.imgs.size();
+    std::vector<int> order(count);  // order[original index] = layout index
+    for (int k = 0; k < count; ++k) order[S.imgs[k].orig] = k;
+    return emit(W, I, order, words, cap_words, word_off, nwords, ids, cap_ids);
+  }
+};
+
 static int emit(const std::vector<std::vector<ocr_word>>& W, const std::vector<std::vector<int32_t>>& I, const std::vector<int>& order,
                 ocr_word* words, int cap_words, int* word_off, int* nwords, int32_t* ids, int cap_ids) {
   int wo = 0, io = 0;
@@ -439,9 +530,10 @@ int ocr_pipe_create(const ocr_pipe_cfg* c, ocr_pipe** out) {
   std::unique_ptr<ocr_pipe> h(new ocr_pipe());
   h->device = c->det.device_id;
   if (c->crop_mode != OCR_CROP_BOUNDING_RECT && c->crop_mode != OCR_CROP_ROTATE) return fail(OCR_ERR_ARG, "unknown crop_mode");
-  h->crop_mode = c->crop_mode;
+  if (c->phases < 0 || c->phases > 2) return fail(OCR_ERR_ARG, "phases must be 0 (default), 1 or 2");
+  h->phases = c->phases ? c->phases : 2;
+  if (const char* e = getenv("OCR_PIPE_PHASES")) h->phases = atoi(e) == 1 ? 1 : 2;
   std::string err;
-  int code = 0;
   DetConfig d;
   d.model_dir = c->det.model_dir; d.device = c->det.device_id;
   if (c->det.limit_type) d.limit_type = c->det.limit_type;
@@ -451,23 +543,32 @@ int ocr_pipe_create(const ocr_pipe_cfg* c, ocr_pipe** out) {
   d.use_dilation = c->det.use_dilation;
   if (c->det.precision) d.precision = c->det.precision;
   d.max_batch = c->det.max_batch > 0 ? c->det.max_batch : 1;
-  if (!h->det.create(d, err, code)) return fail(code, err);
-  h->det_cfg = d;
-  if (const char* e = getenv("OCR_DET_LANES")) h->det_lanes = std::min(16, std::max(1, atoi(e)));
   RecConfig r;
   r.model_dir = c->rec.model_dir; r.label_path = c->rec.label_path; r.device = c->det.device_id;
   r.batch_num = c->rec.rec_batch_num; r.img_h = c->rec.rec_img_h; r.img_w = c->rec.rec_img_w; r.sort_mode = c->rec.sort_mode;
   if (c->rec.precision) r.precision = c->rec.precision;
-  if (!h->rec.create(r, err, code)) return fail(code, err);
-  h->rec.want_taps = false;
+  ClsConfig k;
   if (c->enable_cls) {
-    ClsConfig k;
     k.model_dir = c->cls.model_dir; k.device = c->det.device_id; k.thresh = c->cls.cls_thresh;
     k.batch_num = c->cls.cls_batch_num > 0 ? c->cls.cls_batch_num : 1;
     if (c->cls.precision) k.precision = c->cls.precision;
-    h->cls.reset(new ClsStage());
-    if (!h->cls->create(k, err, code)) return fail(code, err);
   }
+  int lanes = 8;
+  if (const char* e = getenv("OCR_DET_LANES")) lanes = std::min(32, std::max(1, atoi(e)));
+  int rc = h->w0.create(d, r, c->enable_cls ? &k : nullptr, c->crop_mode, err);
+  if (rc) return fail(rc, err);
+  h->w0.det_lanes = lanes;
+  if (h->phases == 2) {
+    h->w1.reset(new PipeWorker());
+    rc = h->w1->create(d, r, c->enable_cls ? &k : nullptr, c->crop_mode, err);
+    if (rc) return fail(rc, err);
+    // the detector lanes (mixed-size batches) are dealt over the two chains
+    h->w0.det_lanes = h->w1->det_lanes = std::max(1, (lanes + 1) / 2);
+  }
+  // two idle high-priority streams, created after the stage objects' streams and before the detector lanes' (which
+  // come into being at the first mixed-size batch): the configuration in which the lanes measured fastest (capi_net.hip)
+  priority_anchor(h->device, true);
+  priority_anchor(h->device, true);
   *out = h.release();
   return OCR_OK;
 }
@@ -485,7 +586,7 @@ int ocr_pipe_run_device(ocr_pipe* h, const void* dev_bgr, int rows, int cols, in
   // the request's clone (OCRRequest copies the Mat, ocr_worker.h:28-29): cls rotation is in place on it
   const size_t img_bytes = (size_t)rows * cols * 3, bytes = img_bytes * count;
   if (!h->work.ensure(bytes + 256, err)) return fail(OCR_ERR_DEVICE, err);
-  CAPI_HIP(hipMemcpyAsync(h->work.p, dev_bgr, bytes, hipMemcpyDeviceToDevice, h->det.stream()));
+  CAPI_HIP(hipMemcpyAsync(h->work.p, dev_bgr, bytes, hipMemcpyDeviceToDevice, h->w0.det.stream()));
   std::vector<StageSlot::Img> imgs(count);
   for (int i = 0; i < count; ++i) imgs[i] = {rows, cols, i, img_bytes * i, 0};
   const std::vector<StageSlot::Group> groups = {{rows, cols, 0, count, 0, 0}};
@@ -542,21 +643,25 @@ int ocr_pipe_run(ocr_pipe* h, const ocr_img* imgs, int count, ocr_word* words, i
 }
 
 const char* ocr_pipe_label(ocr_pipe* h, int id) {
-  if (!h || id < 0 || id >= (int)h->rec.labels().size()) return nullptr;
-  return h->rec.labels()[id].c_str();
+  if (!h || id < 0 || id >= (int)h->w0.rec.labels().size()) return nullptr;
+  return h->w0.rec.labels()[id].c_str();
 }
 
 int ocr_pipe_det_shape(ocr_pipe* h, int rows, int cols, int* net_rows, int* net_cols) {
   if (!h || !net_rows || !net_cols) return fail(OCR_ERR_ARG, "null argument");
   float a, b;
-  DetStage::resize_shape(rows, cols, h->det.cfg().limit_type, h->det.cfg().limit_side_len, *net_rows, *net_cols, a, b);
+  DetStage::resize_shape(rows, cols, h->w0.det.cfg().limit_type, h->w0.det.cfg().limit_side_len, *net_rows, *net_cols, a, b);
   return OCR_OK;
 }
 
 static std::vector<Net*> pipe_nets(ocr_pipe* h) {
-  std::vector<Net*> v{&h->det.net()};
-  if (h->cls) v.push_back(&h->cls->net());
-  v.push_back(&h->rec.net());
+  std::vector<Net*> v;
+  for (PipeWorker* w : {&h->w0, h->w1.get()}) {
+    if (!w) continue;
+    v.push_back(&w->det.net());
+    if (w->cls) v.push_back(&w->cls->net());
+    v.push_back(&w->rec.net());
+  }
   return v;
 }
 int ocr_pipe_timing(ocr_pipe* h, int enable) {
@@ -564,6 +669,19 @@ int ocr_pipe_timing(ocr_pipe* h, int enable) {
   for (Net* net : pipe_nets(h)) {
     net->enable_timing(enable != 0);
     net->reset_timings();
+  }
+  return OCR_OK;
+}
+int ocr_pipe_stats(ocr_pipe* h, long long out[3]) {
+  if (!h || !out) return fail(OCR_ERR_ARG, "null argument");
+  out[0] = out[1] = out[2] = 0;
+  auto add = [&](Net& n) { out[0] += n.stats().runs; out[1] += n.stats().binds; out[2] += n.stats().graph_replays; };
+  for (PipeWorker* w : {&h->w0, h->w1.get()}) {
+    if (!w) continue;
+    add(w->det.net());
+    for (auto& d : w->det_extra) add(d->net());
+    if (w->cls) add(w->cls->net());
+    add(w->rec.net());
   }
   return OCR_OK;
 }

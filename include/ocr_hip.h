@@ -140,6 +140,10 @@ typedef struct ocr_pipe_cfg {
   int enable_cls; /* OCRWorker(..., enable_cls = false) */
   int crop_mode;  /* OCR_CROP_BOUNDING_RECT: ROI views, what the worker does (ocr_worker.cpp:244-259);
                    * OCR_CROP_ROTATE: Utility::GetRotateCropImage per box (utility.cpp:137-190) */
+  int phases;     /* chains a batch is run on: 2 (and 0, the default) = two parts of the batch side by side, each with its own
+                   * stage objects, streams and host thread (the latency-bound phases of one run under the dense kernels
+                   * of the other; results are per image and do not change); 1 = one chain, one kernel at a time owns the
+                   * device.  OCR_PIPE_PHASES in the environment overrides. */
 } ocr_pipe_cfg;
 enum { OCR_CROP_BOUNDING_RECT = 0, OCR_CROP_ROTATE = 1 };
 void ocr_pipe_cfg_default(ocr_pipe_cfg* cfg);
@@ -170,7 +174,7 @@ int ocr_pipe_run_device(ocr_pipe* h, const void* dev_bgr, int rows, int cols, in
  * the device and runs the batch.  Two slots (0, 1): one host thread stages batch k+1 into the other slot while
  * another is inside ocr_pipe_run_staged for batch k; a slot may be run any number of times (its images then are
  * "already resident in HBM").
- * ocr_pipe_slot_probs (benchmark protocol): per staged image a HOST pointer to a probability map
+ * ocr_pipe_slot_probs (benchmark protocol): per staged image a pointer (host or device memory) to a probability map
  * of the detector's input resolution (ocr_pipe_det_shape) that replaces the network's map, as dev_prob of
  * ocr_pipe_run_device; the maps stay attached while the slot is re-staged with the same sizes in the same order. */
 int ocr_pipe_stage(ocr_pipe* h, int slot, const ocr_img* imgs, int count);
@@ -198,6 +202,9 @@ int ocr_jpeg_decode(const ocr_jpeg_img* img, int device_id, uint8_t* bgr, size_t
 const char* ocr_pipe_label(ocr_pipe* h, int id);
 /* network input size the detector uses for a rows x cols image (ResizeImgType0) */
 int ocr_pipe_det_shape(ocr_pipe* h, int rows, int cols, int* net_rows, int* net_cols);
+/* binding-cache statistics summed over the pipeline's networks: out = {network runs, runs that had to bind a new
+ * shape (plan the arena, build the launch list), runs replayed from a recorded hipGraph} */
+int ocr_pipe_stats(ocr_pipe* h, long long out[3]);
 /* HIP-event timing of every kernel launch of the three networks during subsequent runs */
 int ocr_pipe_timing(ocr_pipe* h, int enable);
 /* restrict the events to launches whose name contains substr (NULL or "": all launches) */

@@ -438,11 +438,14 @@ def test_cls_on_real_weights(pkg, built):
     cls.close()
 
 
+@pytest.mark.parametrize("phases", [1, 2])
 @pytest.mark.parametrize("cls_on", [False, True])
-def test_pipeline_process_request(pkg, built, card, cls_on):
-    """OCRWorker::processRequest: ids kept per request, mixed sizes in one call, cls rotation in place."""
+def test_pipeline_process_request(pkg, built, card, cls_on, phases):
+    """OCRWorker::processRequest: ids kept per request, mixed sizes in one call, cls rotation in place.  phases = 2 (the
+    default) runs the batch as two chains on two parts of it, each with its own stage objects and host thread
+    (pipe.hip, ocr_pipe::run_images); phases = 1 as one chain: the results are the same."""
     from pipeline import Pipeline
-    pg, po = pkg.Pipe(enable_cls=cls_on), Pipeline(enable_cls=cls_on)
+    pg, po = pkg.Pipe(enable_cls=cls_on, phases=phases), Pipeline(enable_cls=cls_on)
     imgs = [card, card[:, ::-1].copy(), card[:120].copy(), card]
     got = pg.run(imgs)
     for img, g in zip(imgs, got):
@@ -594,6 +597,12 @@ def test_pipeline_cfg3_mixed_sizes(pkg, built):
     pg = pkg.Pipe(limit_side_len=960, **kw)
     po = Pipeline(det_cfg=DetCfg(limit_side_len=960), **kw)
     got = pg.run(imgs + [imgs[0]])                       # a repeated size shares its det pass
+    pg1 = pkg.Pipe(limit_side_len=960, phases=1, **kw)   # one chain: word for word what the two chains gave
+    got1 = pg1.run(imgs + [imgs[0]])
+    assert [len(g) for g in got1] == [len(g) for g in got]
+    assert all(np.array_equal(a["box"], b["box"]) and np.array_equal(a["ids"], b["ids"]) and a["confidence"] == b["confidence"]
+               for ga, gb in zip(got, got1) for a, b in zip(ga, gb))
+    pg1.close()
     for img, g in zip(imgs + [imgs[0]], got):
         nr, nc = pg.det_shape(*img.shape[:2])
         assert nr % 32 == 0 and nc % 32 == 0 and max(nr, nc) <= 960

@@ -13,10 +13,10 @@ try:
 except Exception as e: print("$name ERR", e)
 PY
 }
-run new_x01 new OCR_DEBUG_EXTRA_STREAMS=0,1
-run new_dq0 new DEBUG_HIP_DYNAMIC_QUEUES=0
-run new_dq1 new DEBUG_HIP_DYNAMIC_QUEUES=1
-run new_dp new OCR_DEBUG_DET_PRIO=1
-run new_dp_l16 new OCR_DEBUG_DET_PRIO=1 OCR_DET_LANES=16
-run new_x01_l16 new OCR_DEBUG_EXTRA_STREAMS=0,1 OCR_DET_LANES=16
-run new_x01_l4 new OCR_DEBUG_EXTRA_STREAMS=0,1 OCR_DET_LANES=4
+run a3 new OCR_PRIO_ANCHOR=3
+run a4 new OCR_PRIO_ANCHOR=4
+run a5 new OCR_PRIO_ANCHOR=5
+run a3l16 new OCR_PRIO_ANCHOR=3 OCR_DET_LANES=16
+run a4l16 new OCR_PRIO_ANCHOR=4 OCR_DET_LANES=16
+run a0l16 new OCR_PRIO_ANCHOR=0 OCR_DET_LANES=16
+run a0l32 new OCR_PRIO_ANCHOR=0 OCR_DET_LANES=32

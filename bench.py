@@ -30,6 +30,11 @@ import time
 
 import numpy as np
 
+# hardware queues the HIP runtime multiplexes streams onto (its default of 4 serialises the pipeline's chains).  The
+# library sets the same default when it is loaded; under a launcher torch / RCCL initialise HIP before that, so every
+# rank of every run gets it here.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))

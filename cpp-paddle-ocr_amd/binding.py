@@ -51,7 +51,7 @@ EXPORTS = [
     "ocr_rec_cfg_default", "ocr_rec_create", "ocr_rec_destroy", "ocr_rec_run", "ocr_rec_label",
     "ocr_rec_num_classes", "ocr_rec_steps",
     "ocr_net_create", "ocr_net_destroy", "ocr_net_forward", "ocr_net_forward_ragged", "ocr_net_num_tensors", "ocr_net_tensor_exists", "ocr_net_fetch",
-    "ocr_net_timing", "ocr_net_timing_report", "ocr_probe",
+    "ocr_net_timing", "ocr_net_timing_report", "ocr_probe", "ocr_selftest_refuse_launch", "ocr_selftest_lds_memo",
 ]
 
 
@@ -73,6 +73,8 @@ def lib():
         L.ocr_net_timing.argtypes = [C.c_void_p, C.c_int]
         L.ocr_net_timing_report.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
         L.ocr_probe.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        if hasattr(L, "ocr_selftest_refuse_launch"):
+            L.ocr_selftest_refuse_launch.argtypes = [C.c_char_p]
         _lib = L
     return _lib
 

@@ -1,5 +1,6 @@
 // Shared helpers of the C-ABI translation units.
 #pragma once
+#include "rt_options.h"
 #include <hip/hip_runtime.h>
 
 #include <memory>

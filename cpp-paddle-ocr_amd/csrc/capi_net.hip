@@ -1,5 +1,6 @@
 // C-ABI: runtime init, raw network taps, numerics probe.
 #include <cstdio>
+#include <atomic>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -15,6 +16,42 @@
 __attribute__((constructor)) static void ocr_runtime_env_defaults() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
 
 namespace ocr {
+
+const RtOptions& rt_options() {
+  static RtOptions o;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    auto off = [](const char* n) { const char* e = getenv(n); return e && e[0] == '0'; };
+    auto num = [](const char* n, long def) { const char* e = getenv(n); return e && *e ? atol(e) : def; };
+    o.fuse_gate = !off("OCR_FUSE_GATE");
+    o.fuse_dwpw = !off("OCR_FUSE_DWPW");
+    o.fuse_gap = !off("OCR_FUSE_GAP");
+    o.fuse_gap_min = num("OCR_FUSE_GAP_MIN", 64 * 1024);
+    o.fuse_dbhead = !off("OCR_FUSE_DBHEAD");
+    if (const char* e = getenv("OCR_CONV_IMPL")) o.conv_impl = !strcmp(e, "direct") ? 1 : (!strcmp(e, "lds") ? 2 : 0);
+    o.conv_small_nt = !off("OCR_CONV_SMALL_NT");
+    o.conv_nt_max = (int)num("OCR_CONV_NT_MAX", 4);
+    o.conv_c24 = !off("OCR_CONV_C24");
+    o.conv_tile = !off("OCR_CONV_TILE");
+    if (const char* e = getenv("OCR_DW_PATCH")) sscanf(e, "%dx%d", &o.dw_patch_to, &o.dw_patch_r);
+    o.dwpw_items = (int)num("OCR_DWPW_ITEMS", 32);
+    o.dwpw_force_upw = (int)num("OCR_DWPW_FORCE_UPW", 0);
+    if (const char* e = getenv("OCR_DWPW_T4")) o.dwpw_t4_thin = e[0] == 't';
+    o.trace_slice = (int)num("OCR_TRACE_SLICE", 0);
+    o.prio_anchor = !off("OCR_PRIO_ANCHOR");
+  });
+  return o;
+}
+static std::mutex g_refuse_mu;
+static std::string g_refuse;
+static std::atomic<bool> g_refuse_on{false};
+const char* rt_refuse_launch() { return g_refuse_on.load(std::memory_order_acquire) ? g_refuse.c_str() : ""; }
+void rt_set_refuse_launch(const char* substr) {
+  std::lock_guard<std::mutex> lk(g_refuse_mu);
+  g_refuse_on.store(false, std::memory_order_release);
+  g_refuse = substr ? substr : "";
+  g_refuse_on.store(!g_refuse.empty(), std::memory_order_release);
+}
 
 static thread_local std::string g_last_error;
 void set_last_error(const std::string& msg) { g_last_error = msg; }
@@ -80,8 +117,7 @@ void priority_anchor(int device_id, bool again) {
   static std::mutex mu;
   static hipStream_t anchor[64] = {};
   std::lock_guard<std::mutex> lk(mu);
-  const char* e = getenv("OCR_PRIO_ANCHOR");
-  if (device_id < 0 || device_id >= 64 || (anchor[device_id] && !again) || (e && e[0] == '0')) return;
+  if (device_id < 0 || device_id >= 64 || (anchor[device_id] && !again) || !rt_options().prio_anchor) return;
   int least = 0, greatest = 0;
   if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess || least == greatest ||
       hipStreamCreateWithPriority(&anchor[device_id], hipStreamDefault, greatest) != hipSuccess) {
@@ -116,6 +152,7 @@ int ocr_rt_device_count(void) {
 }
 
 int ocr_rt_init(int device_id) {
+  (void)rt_options();  // the environment is read here, once
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
   if (e != hipSuccess || n <= 0) return fail(OCR_ERR_DEVICE, "no HIP device visible: this library has no CPU fallback");
@@ -229,6 +266,48 @@ int ocr_net_timing_report(ocr_net* h, char* buf, size_t cap) {
   }
   if (off < cap) buf[off] = 0;
   return OCR_OK;
+}
+
+int ocr_selftest_refuse_launch(const char* substr) {
+  rt_set_refuse_launch(substr);
+  return OCR_OK;
+}
+
+// The per-device dynamic-LDS memo of the kernel launchers (lds_attr.h) on faked devices: no HIP call is made, so this
+// runs without a GPU - the one-process-several-devices path of the worker pool otherwise needs a multi-GPU lease.
+namespace {
+int g_fake_dev = 0;
+int g_fake_calls = 0, g_fake_last_bytes = 0;
+bool g_fake_refuse = false;
+}  // namespace
+int ocr_selftest_lds_memo(void) {
+  LdsAttrHooks& hk = lds_attr_hooks();
+  const LdsAttrHooks saved = hk;
+  hk.get_device = [] { return g_fake_dev; };
+  hk.set_attribute = [](const void*, int bytes) { ++g_fake_calls; g_fake_last_bytes = bytes; return !g_fake_refuse; };
+  static LdsAttrMemo memo;  // (a fresh one per process: the test runs once)
+  const void* k = (const void*)&g_fake_dev;
+  std::string why;
+  auto expect = [&](bool cond, const char* what) { if (!cond && why.empty()) why = what; };
+  g_fake_calls = 0;
+  g_fake_dev = 0;
+  expect(raise_dynamic_lds(k, 70000, memo) && g_fake_calls == 1, "first request on device 0 must raise the attribute");
+  expect(raise_dynamic_lds(k, 70000, memo) && g_fake_calls == 1, "the same request again is answered from the memo");
+  expect(raise_dynamic_lds(k, 65000, memo) && g_fake_calls == 1, "a smaller request is covered by the raised limit");
+  expect(raise_dynamic_lds(k, 72704, memo) && g_fake_calls == 2 && g_fake_last_bytes == 72704, "a larger request must raise again");
+  g_fake_dev = 1;
+  expect(raise_dynamic_lds(k, 70000, memo) && g_fake_calls == 3, "another device has its own memo entry");
+  g_fake_dev = 2;
+  g_fake_refuse = true;
+  expect(!raise_dynamic_lds(k, 70000, memo) && g_fake_calls == 4, "a refusal is reported");
+  g_fake_refuse = false;
+  expect(!raise_dynamic_lds(k, 70000, memo) && g_fake_calls == 4, "and remembered: the caller keeps its small-LDS path on that device");
+  g_fake_dev = 0;
+  expect(raise_dynamic_lds(k, 72704, memo) && g_fake_calls == 4, "device 0 is unaffected by the other devices' entries");
+  g_fake_dev = -1;
+  expect(!raise_dynamic_lds(k, 1, memo), "no current device");
+  hk = saved;
+  return why.empty() ? OCR_OK : fail(OCR_ERR_DEVICE, why);
 }
 
 int ocr_probe(const float* a, const float* b, float* out, int n) {

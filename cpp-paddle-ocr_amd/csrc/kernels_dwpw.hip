@@ -656,16 +656,14 @@ bool launch_one(const DwPwArgs& a0, hipStream_t s, bool query) {
   // stays many times larger than the chip - other streams' kernels take CU slots at any moment, and a grid sized to
   // "exactly resident" then runs its leftover workgroups as a second full-length wave (measured: 2x on rec.07 with
   // the odd-width lane active).  OCR_DWPW_ITEMS overrides the target item count (A/B; results are identical).
-  static const char* env = getenv("OCR_DWPW_ITEMS");
-  const int target = env ? atoi(env) : 32;
+  const int target = rt_options().dwpw_items;
   const int nch = a.c.Cs_in / CK;
   long upw = (target + nch - 1) / nch;
   const long resident = (long)cus_dev * per_cu_dev;
   while (upw > 1 && (nunits + upw - 1) / upw < 8 * resident) --upw;  // small problems: keep every CU busy
   // OCR_DWPW_FORCE_UPW (tests): units per workgroup regardless of the problem size, so that small inputs run the
   // multi-unit pipelines (unit boundaries inside a workgroup, a shorter last workgroup) that production batches run
-  static const char* force = getenv("OCR_DWPW_FORCE_UPW");
-  if (force && atoi(force) > 0) upw = atoi(force);
+  if (rt_options().dwpw_force_upw > 0) upw = rt_options().dwpw_force_upw;
   a.upw = (unsigned)upw;
   const dim3 grid((unsigned)((nunits + upw - 1) / upw));
   hipLaunchKernelGGL((dwpw_kernel<K, SH, SW, CK, WIDE, NT, DWACT, GD, TD, LB, RAG>), grid, dim3(256), lds, s, a);
@@ -705,8 +703,7 @@ bool launch_dwpw(const DwPwArgs& a, hipStream_t s, bool query) {
   // kernel fits without spilling, deeper read-ahead where it does not.
   // 4-tile layers: a 4x16 tile with 32-channel chunks and 2 x 2 column tiles per wave beats the thin shape by 15-25 %
   // (half the B-fragment traffic per MFMA); OCR_DWPW_T4=thin keeps the thin shape for A/B runs
-  static const char* t4 = getenv("OCR_DWPW_T4");
-  if (!(t4 && t4[0] == 't')) {
+  if (!rt_options().dwpw_t4_thin) {
     OCR_DWPW_CASE(3, 1, 1, 32, true, 2, 1, 1, 3, tiles == 4)
     OCR_DWPW_CASE(3, 2, 1, 32, true, 2, 1, 2, 2, tiles == 4)
   }

@@ -7,6 +7,7 @@
 
 #include "lds_attr.h"
 #include "ocr_common.h"
+#include "rt_options.h"
 
 namespace ocr {
 
@@ -51,7 +52,8 @@ struct ConvArgs {
   // ragged batch (rin.w != null): N lines, in.H rows each, widths rin.w[n] -> rout.w[n] (H / OH are uniform)
   RagLevel rin, rout;
 };
-void launch_conv_mfma(const ConvArgs& a, const Epilogue& ep, int nt, hipStream_t s);
+// false: the combination (gated input / multi-tap conv with a plain or deconv output) is not instantiated
+bool launch_conv_mfma(const ConvArgs& a, const Epilogue& ep, int nt, hipStream_t s);
 // LDS-staged variant of the same GEMM (default when K = taps*Cs_in >= 64)
 void launch_conv_lds(const ConvArgs& a, const Epilogue& ep, int nt, hipStream_t s);
 // 3x3 s1 p1 conv with the input tile resident in LDS; returns false when the shape is not on that path
@@ -61,8 +63,7 @@ bool launch_conv3x3_c24(const ConvArgs& a, const Epilogue& ep, const float* wimg
 std::vector<float> conv3x3_c24_image(const float* w, int co, int ci);
 // column tiles per wave for a GEMM with `tiles` 32-wide column tiles
 inline int conv_nt_for(int tiles) {
-  static const char* e = getenv("OCR_CONV_NT_MAX");  // A/B measurements (results are identical)
-  static const int cap = e ? atoi(e) : 4;
+  const int cap = rt_options().conv_nt_max;  // OCR_CONV_NT_MAX: A/B measurements (results are identical)
   if (cap < 4 && tiles > cap) return tiles % cap == 0 ? cap : (cap > 2 && tiles % (cap - 1) == 0 ? cap - 1 : cap);
   return tiles <= 4 ? tiles : (tiles % 4 == 0 ? 4 : (tiles % 3 == 0 ? 3 : 4));
 }

@@ -155,7 +155,7 @@ __global__ void __launch_bounds__(256, (NT <= 3 ? 4 : 3)) conv_mfma_kernel(const
   CONV_PROBE(3);
 }
 
-void launch_conv_mfma(const ConvArgs& a, const Epilogue& ep, int nt, hipStream_t s) {
+bool launch_conv_mfma(const ConvArgs& a, const Epilogue& ep, int nt, hipStream_t s) {
   dim3 grid((unsigned)(((a.M + 127) / 128) * (a.NTtot / nt)));
 #define OCR_LAUNCH_MODE(MODE, TAP1)                                                                             \
   switch (nt) {                                                                                                 \
@@ -166,22 +166,23 @@ void launch_conv_mfma(const ConvArgs& a, const Epilogue& ep, int nt, hipStream_t
   }
   const bool tap1 = a.KH == 1 && a.KW == 1 && a.PH == 0 && a.PW == 0 && a.OH == a.H && a.OW == a.W;
   if (a.gate) {
-    if (!(tap1 && a.out_mode == OUT_C8I)) { fprintf(stderr, "launch_conv_mfma: gated input needs a 1x1 conv with a C8I output\n"); abort(); }
+    if (!(tap1 && a.out_mode == OUT_C8I)) return false;  // a gated input needs a 1x1 conv with a C8I output
     switch (nt) {
       case 1: hipLaunchKernelGGL((conv_mfma_kernel<1, OUT_C8I, true, true>), grid, dim3(256), 0, s, a, ep); break;
       case 2: hipLaunchKernelGGL((conv_mfma_kernel<2, OUT_C8I, true, true>), grid, dim3(256), 0, s, a, ep); break;
       case 3: hipLaunchKernelGGL((conv_mfma_kernel<3, OUT_C8I, true, true>), grid, dim3(256), 0, s, a, ep); break;
       default: hipLaunchKernelGGL((conv_mfma_kernel<4, OUT_C8I, true, true>), grid, dim3(256), 0, s, a, ep); break;
     }
-    return;
+    return true;
   }
   if (a.out_mode == OUT_HEAD && tap1) { OCR_LAUNCH_MODE(OUT_HEAD, true) }
   else if (a.out_mode == OUT_PLAIN && tap1) { OCR_LAUNCH_MODE(OUT_PLAIN, true) }
   else if (a.out_mode == OUT_DECONV && tap1) { OCR_LAUNCH_MODE(OUT_DECONV, true) }
   else if (a.out_mode == OUT_C8I && tap1) { OCR_LAUNCH_MODE(OUT_C8I, true) }
   else if (a.out_mode == OUT_C8I) { OCR_LAUNCH_MODE(OUT_C8I, false) }
-  else { fprintf(stderr, "launch_conv_mfma: multi-tap conv with a plain/deconv output is not instantiated\n"); abort(); }
+  else return false;  // a multi-tap conv with a plain / deconv output is not instantiated
 #undef OCR_LAUNCH_MODE
+  return true;
 }
 
 // =====================================================================================
@@ -584,8 +585,7 @@ std::vector<float> conv3x3_c24_image(const float* w, int co, int ci) {
 }
 
 bool launch_conv3x3_c24(const ConvArgs& a, const Epilogue& ep, const float* wimg, hipStream_t s) {
-  static const char* env = getenv("OCR_CONV_C24");  // OCR_CONV_C24=0: the 32-column tile kernel (A/B; results are identical)
-  if (env && env[0] == '0') return false;
+  if (!rt_options().conv_c24) return false;  // OCR_CONV_C24=0: the 32-column tile kernel (A/B; results are identical)
   if (!wimg || !(a.KH == 3 && a.KW == 3 && a.PH == 1 && a.PW == 1 && a.OH == a.H && a.OW == a.W && a.out_mode == OUT_C8I)) return false;
   if (a.Cs_in != 96 || a.Cs_out != 24 || a.Cout != 24) return false;
   for (int i = 0; i < ep.n; ++i) if (ep.st[i].kind == EP_ADDUP) return false;
@@ -601,8 +601,7 @@ bool launch_conv3x3_c24(const ConvArgs& a, const Epilogue& ep, const float* wimg
 
 // true if the launch was taken (3x3, stride 1, pad 1, 96 input channels, C8I output); OCR_CONV_TILE=0 disables
 bool launch_conv3x3_tile(const ConvArgs& a, const Epilogue& ep, int nt, hipStream_t s) {
-  static const char* env = getenv("OCR_CONV_TILE");
-  if (env && env[0] == '0') return false;
+  if (!rt_options().conv_tile) return false;
   if (!(a.KH == 3 && a.KW == 3 && a.PH == 1 && a.PW == 1 && a.OH == a.H && a.OW == a.W && a.out_mode == OUT_C8I)) return false;
   if (a.Cs_in != 96 || nt != 1) return false;
   const int tiles_x = (a.OW + 15) / 16, tiles_y = (a.OH + 7) / 8;
@@ -935,17 +934,14 @@ static void launch_dw_patch(const DwArgs& a, const Epilogue& ep, hipStream_t s) 
 // output pixels per thread along x (ragged batch: OW = the narrowest line; the host builds DwArgs::rwork for this value)
 int dw_patch_to(int OW, int SW) {
   // OCR_DW_PATCH=TOxR overrides (A/B measurements; results are identical)
-  static const char* env = getenv("OCR_DW_PATCH");
-  int to = 8, r = 2;
-  if (env) sscanf(env, "%dx%d", &to, &r);
+  const bool env = rt_options().dw_patch_to > 0;
+  int to = env ? rt_options().dw_patch_to : 8;
   if (OW < 8 || (SW == 2 && !env)) to = 4;  // stride 2 needs 2*TO+K-2 pixels per row buffer: 8 wide does not fit the registers
   return to == 8 ? 8 : 4;
 }
 void launch_dw(const DwArgs& a, const Epilogue& ep, hipStream_t s) {
-  static const char* env = getenv("OCR_DW_PATCH");
-  int to = 8, r = 2;
-  if (env) sscanf(env, "%dx%d", &to, &r);
-  to = dw_patch_to(a.OW, a.SW);
+  int r = rt_options().dw_patch_r > 0 ? rt_options().dw_patch_r : 2;
+  const int to = dw_patch_to(a.OW, a.SW);
   if (a.OH < 2) r = 1;
   if (a.rout.w) {  // ragged batch (the recognizer)
     if (to == 8 && r == 2) launch_dw_patch<8, 2, true>(a, ep, s);

@@ -25,6 +25,14 @@
 
 #include "kernels_post.h"
 #include "lds_attr.h"
+#include "rt_options.h"
+
+// development probe (OCR_POST_STOP, only in -DOCR_DEV_PROBES builds): the per-border stage returns after phase n
+#ifdef OCR_DEV_PROBES
+#define OCR_PROBE_STOP(a, n) ((a).probe_stop == (n))
+#else
+#define OCR_PROBE_STOP(a, n) false
+#endif
 
 namespace ocr {
 
@@ -1274,7 +1282,7 @@ __global__ void __launch_bounds__(64) border_box_kernel(const PostArgs a) {
   }
   __syncthreads();
   bitonic_sort_wave(keys, n2, lane, in_lds);
-  if (a.probe_stop == 1) return;
+  if (OCR_PROBE_STOP(a, 1)) return;
   // ---- minAreaRect(contour) -> GetMiniBoxes (lane 0)
   if (lane == 0) {
     s_flag = 0;
@@ -1284,7 +1292,7 @@ __global__ void __launch_bounds__(64) border_box_kernel(const PostArgs a) {
     KeyAcc P{keys};
     const int hn = convex_hull_sorted<KeyAcc, int>(P, total, stack, hullbuf, s_hull, HULL_CAP);
     if (hn < 0) { atomicOr(a.status, POST_ERR_HULL); s_flag = 0; }
-    else if (a.probe_stop == 2) { s_flag = 0; }
+    else if (OCR_PROBE_STOP(a, 2)) { s_flag = 0; }
     else {
       const RRect box = min_area_rect_hull(s_hull, hn, s_vect, s_inv);
       float ssid;
@@ -1297,7 +1305,7 @@ __global__ void __launch_bounds__(64) border_box_kernel(const PostArgs a) {
     }
   }
   __syncthreads();
-  if (!s_flag || a.probe_stop == 3) return;
+  if (!s_flag || OCR_PROBE_STOP(a, 3)) return;
   P2f arr[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) { arr[i].x = s_box[2 * i]; arr[i].y = s_box[2 * i + 1]; }
@@ -1323,7 +1331,7 @@ __global__ void __launch_bounds__(64) border_box_kernel(const PostArgs a) {
   }
   if (score < a.box_thresh) return;
   if (lane != 0) return;
-  if (a.probe_stop == 4) return;
+  if (OCR_PROBE_STOP(a, 4)) return;
   // ---- UnClip
   float area = 0.0f, dist = 0.0f;
   for (int i = 0; i < 4; ++i) {
@@ -1337,7 +1345,7 @@ __global__ void __launch_bounds__(64) border_box_kernel(const PostArgs a) {
   for (int i = 0; i < 4; ++i) q[i] = {(long long)(int)arr[i].x, (long long)(int)arr[i].y};
   const int un = clipper_offset_round(q, (double)distance, s_unclip, UNCLIP_CAP);
   if (un < 0) { atomicOr(a.status, POST_ERR_UNCLIP); return; }
-  if (a.probe_stop == 5) return;
+  if (OCR_PROBE_STOP(a, 5)) return;
   RRect pts;
   if (un == 0) {
     pts = RRect{0, 0, 1, 1, 0};
@@ -1430,8 +1438,7 @@ void launch_post(const PostArgs& a, int N, int* out_boxes, int cap, int* out_n, 
   }
   if (in_lds) {
     // OCR_TRACE_SLICE (tests): cap on a border's provisional slice, to drive the second-walk path with small inputs
-    const char* sl = getenv("OCR_TRACE_SLICE");
-    const int slice_limit = sl && atoi(sl) > 0 ? atoi(sl) : INT_MAX;
+    const int slice_limit = rt_options().trace_slice > 0 ? rt_options().trace_slice : INT_MAX;
     hipLaunchKernelGGL(trace_lds_kernel, dim3(N), dim3(kTraceThreads), lds, s, a.bitmap, a.H, a.W, a.max_cand, a.ncont, a.starts, a.npts, a.poff,
                        a.pool, a.pool_cap, a.iscratch, slice_limit, a.status);
   } else {

@@ -198,6 +198,10 @@ class Net {
   int* head_amax_ = nullptr;
   float* head_pmax_ = nullptr;
   bool timing_ = false;
+  bool graphs_ = true;          // OCR_GRAPH=0 (read when the network is loaded): plain launches only
+  // set by a launch closure whose launcher refused a shape that bind() had accepted (cannot happen by construction;
+  // a service process must get an error reply out of it, not an abort): run_bound fails the run with it
+  std::string launch_error_;
   Stats stats_;
   std::string timing_filter_;
   int keep_all_ = 0;

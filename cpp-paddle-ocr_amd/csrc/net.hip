@@ -185,6 +185,7 @@ static std::vector<float> build_frag(int taps, int cin, int cols, Get get) {
 
 bool Net::load(const char* plan_text, const WeightMap& W, std::string& err) {
   if (!parse_plan(plan_text, plan_, err)) return false;
+  { const char* e = getenv("OCR_GRAPH"); graphs_ = !(e && e[0] == '0'); }
   host_w_ = W;
   auto need = [&](const std::string& n) -> const HostTensor* {
     auto it = W.find(n);
@@ -563,14 +564,13 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths) {
   // exist for the parity taps); OCR_FUSE_GATE=0 disables (A/B measurements, results are identical).
   std::vector<int> gate_src(nops, -1), gate_tid(nops, -1);
   std::vector<char> folded(nops, 0);
-  static const char* fuse_env = getenv("OCR_FUSE_GATE");
   std::vector<int> uses(plan_.ntensors, 0);
   for (auto& op : plan_.ops) {
     if (op.in >= 0) uses[op.in]++;
     for (int t : op.ins) uses[t]++;
     for (auto& st : op.ep) if (st.tid >= 0) uses[st.tid]++;
   }
-  if (keep_all_ != 1 && !(fuse_env && fuse_env[0] == '0')) {
+  if (keep_all_ != 1 && rt_options().fuse_gate) {
     for (int oi = 0; oi < nops; ++oi) {
       auto& op = plan_.ops[oi];
       if (op.kind != PlanOp::EW || op.ep.size() != 1 || op.ep[0].kind != EP_MULC || op.out == out_tid_ || uses[op.out] != 1) continue;
@@ -590,8 +590,7 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths) {
   // Depthwise -> pointwise fusion (kernels_dwpw.hip): a depthwise conv whose only reader is an ungated 1x1 conv runs
   // inside that conv's launch; its output tensor never exists.  OCR_FUSE_DWPW=0 disables (A/B, results identical).
   std::vector<int> dwpw_of(nops, -1);  // conv op -> the depthwise op it absorbs
-  static const char* dwpw_env = getenv("OCR_FUSE_DWPW");
-  if (keep_all_ != 1 && !(dwpw_env && dwpw_env[0] == '0')) {
+  if (keep_all_ != 1 && rt_options().fuse_dwpw) {
     for (int oi = 0; oi + 1 < nops; ++oi) {
       auto& d = plan_.ops[oi];
       if (d.kind != PlanOp::DW || d.out == out_tid_ || uses[d.out] != 1) continue;
@@ -626,8 +625,7 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths) {
   // second full read of the tensor otherwise) while it writes the tensor; only the column pass stays a launch.  Needs
   // enough bands (a thread owns whole rows then) to fill the chip.  OCR_FUSE_GAP=0 disables (A/B, results identical).
   std::vector<char> dw_rowsum(nops, 0);
-  static const char* gap_env = getenv("OCR_FUSE_GAP");
-  if (keep_all_ != 1 && !(gap_env && gap_env[0] == '0')) {
+  if (keep_all_ != 1 && rt_options().fuse_gap) {
     for (int oi = 1; oi < nops; ++oi) {
       const PlanOp& g = plan_.ops[oi];
       const PlanOp& d = plan_.ops[oi - 1];
@@ -636,16 +634,14 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths) {
       const int rows_per_band = o.h >= 2 ? 2 : 1;
       const long threads = (long)o.n * ((o.h + rows_per_band - 1) / rows_per_band) * (o.cs >> 2);
       // (stride-2 rows measured slower this way: rec op 21 0.55 -> 0.72 ms for a 0.18 ms pool pass)
-      static const char* min_env = getenv("OCR_FUSE_GAP_MIN");  // tests: 1 sends small shapes down this path too
-      const long min_threads = min_env ? atol(min_env) : 64 * 1024;
+      const long min_threads = rt_options().fuse_gap_min;  // OCR_FUSE_GAP_MIN (tests: 1 sends small shapes down this path too)
       if (threads >= min_threads && d.sh == 1 && d.sw == 1) dw_rowsum[oi - 1] = 1;
     }
   }
   // ---- DB head: deconv (C -> C, bias + BN + relu) -> deconv (C -> 1, bias + sigmoid) as one kernel; the C-channel map
   // between them (1.4 GB at configs[1]) is never written.  OCR_FUSE_DBHEAD=0 disables (A/B, results identical).
   std::vector<int> dbhead_of(nops, -1);  // tail op -> the deconv it absorbs
-  static const char* dbh_env = getenv("OCR_FUSE_DBHEAD");
-  if (keep_all_ != 1 && !(dbh_env && dbh_env[0] == '0')) {
+  if (keep_all_ != 1 && rt_options().fuse_dbhead) {
     for (int oi = 0; oi + 1 < nops; ++oi) {
       const PlanOp& d = plan_.ops[oi];
       const PlanOp& t = plan_.ops[oi + 1];
@@ -791,8 +787,8 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths) {
             L.flops = 2.0 * h.M * (4.0 * d.cin * d.cout + 16.0 * d.cout);
             L.bytes = 4.0 * h.M * d.cin + 4.0 * h.M * 16 + (det_bitmap_ ? 1.0 * h.M * 16 : 0.0);
             const int C = d.cin;
-            L.fn = [h, C](hipStream_t s) {
-              if (!launch_db_head(h, C, s)) { fprintf(stderr, "launch_db_head: shape accepted at bind time was refused at launch\n"); abort(); }
+            L.fn = [this, h, C](hipStream_t s) {
+              if (!launch_db_head(h, C, s)) this->launch_error_ = "launch_db_head: shape accepted at bind time was refused at launch";
             };
           }
         } else {
@@ -858,10 +854,10 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths) {
           L.bytes = 4.0 * ((double)a.M * op.cin + (a.out_mode == OUT_HEAD ? 3.0 * a.M * (a.NTtot / nt) : (double)a.M * cols) +
                            (double)taps * op.cin * cols);
           // OCR_CONV_IMPL=direct|lds overrides the choice (A/B measurements); results are identical
-          static const char* impl = getenv("OCR_CONV_IMPL");
           // measured (gpurun_out r1g): LDS staging wins for multi-tap convs (3x3 96->24: 58 vs 51 TFLOP/s),
           // the direct kernel for 1x1 (480->480: 88 vs 71; thin K: 54 vs 39)
-          const bool use_lds = !a.gate && a.out_mode == OUT_C8I && (impl ? !strcmp(impl, "lds") : (taps > 1 && in.cs >= 64));
+          const int impl = rt_options().conv_impl;
+          const bool use_lds = !a.gate && a.out_mode == OUT_C8I && (impl ? impl == 2 : (taps > 1 && in.cs >= 64));
           if (dwpw_of[oi] >= 0) {
             const PlanOp& d = plan_.ops[dwpw_of[oi]];
             const TensorDesc& din = T[d.in];
@@ -883,8 +879,8 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths) {
             L.name = nm;
             L.flops += 2.0 * a.M * d.kh * d.kw * d.c;
             L.bytes = 4.0 * ((double)din.pixels() * d.c + (double)a.M * cols + (double)op.cin * cols + (double)d.kh * d.kw * d.c);
-            L.fn = [f](hipStream_t s) {
-              if (!launch_dwpw(f, s)) { fprintf(stderr, "launch_dwpw: shape accepted at bind time was refused at launch\n"); abort(); }
+            L.fn = [this, f](hipStream_t s) {
+              if (!launch_dwpw(f, s)) this->launch_error_ = "launch_dwpw: shape accepted at bind time was refused at launch";
             };
           } else if (use_lds) {
             const float* c24 = dev_vec("c24:" + op.w);
@@ -898,8 +894,7 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths) {
             // K walk is a chain of NT * K / 2 dependent-in-order MFMAs and with one wave per SIMD its length IS the
             // kernel's time (rec op 30 on 32 lines: 720 -> 240 MFMAs per wave).  Results do not depend on NT.
             int ntl = nt;
-            static const char* small_env = getenv("OCR_CONV_SMALL_NT");  // =0: keep the table's NT (A/B)
-            if (a.out_mode != OUT_HEAD && !(small_env && small_env[0] == '0')) {
+            if (a.out_mode != OUT_HEAD && rt_options().conv_small_nt) {  // OCR_CONV_SMALL_NT=0: keep the table's NT (A/B)
               auto wgs = [&](int t) { return ((a.M + 127) / 128) * (long)(a.NTtot / t); };
               while (ntl > 1 && wgs(ntl) < 512) {
                 int t = ntl - 1;
@@ -907,7 +902,9 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths) {
                 ntl = t;
               }
             }
-            L.fn = [a, ep, ntl](hipStream_t s) { launch_conv_mfma(a, ep, ntl, s); };
+            L.fn = [this, a, ep, ntl](hipStream_t s) {
+              if (!launch_conv_mfma(a, ep, ntl, s)) this->launch_error_ = "launch_conv_mfma: this conv shape / output mode is not instantiated";
+            };
           }
         }
       } break;
@@ -1135,7 +1132,6 @@ bool Net::run_bound(const float* x, hipStream_t s, std::string& err) {
     B.rag_uploaded = true;
   }
   bound_x_ = x;
-  const char* graph_env = getenv("OCR_GRAPH");  // OCR_GRAPH=0: plain launches only
   // event timing needs plain launches - but only where an event would be placed: with a name filter (bench.py times the
   // dominant kernel alone inside its timed region) every binding without a matching launch keeps replaying its graph
   bool timed_here = timing_;
@@ -1144,7 +1140,13 @@ bool Net::run_bound(const float* x, hipStream_t s, std::string& err) {
     for (const auto& L : B.launches)
       if (L.name.find(timing_filter_) != std::string::npos) { timed_here = true; break; }
   }
-  const bool graphs = !(graph_env && graph_env[0] == '0') && !timed_here && !keep_all_ && !B.graph_failed && !B.launches.empty();
+  const char* refuse = rt_refuse_launch();  // fault injection (tests): "" unless ocr_selftest_refuse_launch set it
+  launch_error_.clear();
+  auto issue = [&](Launch& L) {
+    if (refuse[0] && L.name.find(refuse) != std::string::npos) { launch_error_ = "launch refused (self-test): " + L.name; return; }
+    L.fn(s);
+  };
+  const bool graphs = graphs_ && !timed_here && !keep_all_ && !B.graph_failed && !B.launches.empty() && !refuse[0];
   const void* head[3] = {head_probs_, head_amax_, head_pmax_};
   const bool repeat = B.last_x == x;  // the caller feeds this shape from one buffer: worth recording
   B.last_x = x;
@@ -1159,9 +1161,11 @@ bool Net::run_bound(const float* x, hipStream_t s, std::string& err) {
     hipGraph_t g = nullptr;
     bool ok = false;
     if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-      for (auto& L : B.launches) L.fn(s);
-      ok = hipStreamEndCapture(s, &g) == hipSuccess && g && hipGraphInstantiate(&B.graph_exec, g, nullptr, nullptr, 0) == hipSuccess;
+      for (auto& L : B.launches) issue(L);
+      ok = hipStreamEndCapture(s, &g) == hipSuccess && g && launch_error_.empty() &&
+           hipGraphInstantiate(&B.graph_exec, g, nullptr, nullptr, 0) == hipSuccess;
       if (g) (void)hipGraphDestroy(g);
+      if (!launch_error_.empty()) { B.graph_exec = nullptr; B.graph_failed = true; err = launch_error_; return false; }
     }
     if (ok) {
       B.graph_x = x;
@@ -1182,12 +1186,13 @@ bool Net::run_bound(const float* x, hipStream_t s, std::string& err) {
       if (ev_pool_.size() >= 2) { a = ev_pool_.back(); ev_pool_.pop_back(); b = ev_pool_.back(); ev_pool_.pop_back(); }
       else { HIP_OK(hipEventCreate(&a)); HIP_OK(hipEventCreate(&b)); }
       HIP_OK(hipEventRecord(a, s));
-      L.fn(s);
+      issue(L);
       HIP_OK(hipEventRecord(b, s));
       ev_pending_.push_back({a, b, L.name, L.flops, L.bytes});
     } else {
-      L.fn(s);
+      issue(L);
     }
+    if (!launch_error_.empty()) { err = launch_error_; return false; }
   }
   HIP_OK(hipGetLastError());
   return true;

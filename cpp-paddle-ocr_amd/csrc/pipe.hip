@@ -308,6 +308,9 @@ struct ocr_pipe {
     if (!copy_stream && hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking) != hipSuccess) { err = "hipStreamCreate failed"; return OCR_ERR_DEVICE; }
     if (!S.ready && hipEventCreateWithFlags(&S.ready, hipEventDisableTiming) != hipSuccess) { err = "hipEventCreate failed"; return OCR_ERR_DEVICE; }
     if (S.staged && hipEventSynchronize(S.ready) != hipSuccess) { err = "staging event failed"; return OCR_ERR_DEVICE; }  // pinned buffer free again
+    // from here to the end of stage() / stage_jpeg() the slot holds a half-written batch: a failure on the way must not
+    // leave it runnable (a later ocr_pipe_run_staged would run the new layout over stale pixels)
+    S.staged = false;
     std::vector<int> order(count), rows(count), cols(count);
     for (int i = 0; i < count; ++i) { order[i] = i; size_of(i, rows[i], cols[i]); }
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return rows[a] != rows[b] ? rows[a] < rows[b] : cols[a] < cols[b]; });

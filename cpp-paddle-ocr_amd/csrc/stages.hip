@@ -154,7 +154,10 @@ int DetStage::run_post(int count, int H, int W, const float* prob, float ratio_h
   a.box_thresh = (float)cfg_.box_thresh; a.unclip_ratio = (float)cfg_.unclip_ratio;
   a.ratio_h = ratio_h; a.ratio_w = ratio_w; a.src_h = src_h; a.src_w = src_w;
   a.slow = cfg_.score_mode == "slow";
-  { static const char* stop = getenv("OCR_POST_STOP"); a.probe_stop = stop ? atoi(stop) : 0; }  // development probe, timing only
+  a.probe_stop = 0;
+#ifdef OCR_DEV_PROBES  // development probe (tools/post_kernel_times.sh builds with -DOCR_DEV_PROBES): timing only, results are wrong
+  { static const char* stop = getenv("OCR_POST_STOP"); a.probe_stop = stop ? atoi(stop) : 0; }
+#endif
   if (a.slow) {
     a.mask_pool = mask_pool_.p; a.mask_pool_top = mask_top_.p; a.mask_pool_words = (unsigned)mask_words(H, W);
     ST_HIP(hipMemsetAsync(mask_top_.p, 0, count * sizeof(unsigned), stream_));

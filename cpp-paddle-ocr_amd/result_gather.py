@@ -93,6 +93,8 @@ def launch_ranks(script, argv, n, extra_env=None, timeout=None):
     env0["WORLD_SIZE"] = str(n)
     env0["LOCAL_WORLD_SIZE"] = str(n)
     env0.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # the library's default (set when it is loaded) comes too late in a rank: torch / RCCL initialise HIP first
+    env0.setdefault("GPU_MAX_HW_QUEUES", "16")
     procs = []
     for r in range(n):
         env = dict(env0)

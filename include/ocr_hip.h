@@ -262,6 +262,13 @@ int ocr_net_timing(ocr_net* h, int enable);
 /* writes "name ms count flops bytes\n" lines */
 int ocr_net_timing_report(ocr_net* h, char* buf, size_t cap);
 
+/* self-tests / fault injection (tests): ocr_selftest_refuse_launch - a network launch whose name contains `substr` is
+ * refused as if its launcher had rejected the shape (NULL or "" switches it off): the run must fail with OCR_ERR_DEVICE
+ * and a message, never abort.  ocr_selftest_lds_memo - the per-device dynamic-LDS attribute memo of the kernel
+ * launchers exercised on faked device indices (no HIP call: runs without a GPU). */
+int ocr_selftest_refuse_launch(const char* substr);
+int ocr_selftest_lds_memo(void);
+
 /* numerics probe (tests): out[8*n] = a/b, sqrt|a|, ocr_expf(a), fma(a,b,a), a*b+a, rint(a*log2e), hswish(a), hswish(b) */
 int ocr_probe(const float* a, const float* b, float* out, int n);
 

@@ -20,6 +20,23 @@ def test_header_symbols_are_exported(built, pkg):
     assert declared == set(pkg.EXPORTS)
 
 
+def test_per_device_lds_attribute_memo(built, pkg):
+    """lds_attr.h: the dynamic-LDS limit of a kernel is raised per device (a worker pool drives worker i on GPU i mod n
+    from one process), re-raised when a launch needs more than was raised before (one instantiation of the fused
+    depthwise kernel serves two LDS sizes), and a refusal is remembered.  The library's self-test runs the memo on
+    faked device indices without touching HIP, so the several-devices path is exercised on a machine without any."""
+    rc = pkg.lib().ocr_selftest_lds_memo()
+    assert rc == 0, pkg.lib().ocr_last_error().decode()
+
+
+def test_no_abort_in_the_product_library():
+    """launch-time refusals surface as OCR_ERR_* through ocr_last_error(): a service process must not die"""
+    csrc = os.path.join(ROOT, "cpp-paddle-ocr_amd", "csrc")
+    for fn in os.listdir(csrc):
+        if fn.endswith((".hip", ".h", ".cpp")):
+            assert "abort()" not in open(os.path.join(csrc, fn)).read(), fn
+
+
 def test_no_cpu_fallback(built, pkg):
     import torch
     if torch.cuda.is_available():

@@ -204,6 +204,32 @@ def test_repeated_runs_of_a_binding_track_their_input(pkg, built, monkeypatch, g
     g.close()
 
 
+def test_refused_launch_is_an_error_code_not_an_abort(pkg, built, card):
+    """A launcher that refuses a shape the binding had accepted (cannot happen by construction; rounds 1-2 called abort())
+    fails the run with OCR_ERR_DEVICE and a message - through the raw network tap and through the pipeline - and the
+    handle keeps working afterwards.  Driven by the library's fault-injection hook."""
+    L = pkg.lib()
+    x = np.random.RandomState(1).randn(2, 48, 192, 3).astype(np.float32)
+    g = pkg.Net("rec")
+    want = g.forward(x, keep_all=False)
+    pg = pkg.Pipe()
+    ok_words = pg.run([card, card])
+    try:
+        assert L.ocr_selftest_refuse_launch(b"dwpw3x3_64_64") == 0
+        with pytest.raises(pkg.OcrError, match=r"error -3: .*refused"):
+            g.forward(x, keep_all=False)
+        with pytest.raises(pkg.OcrError, match=r"error -3: .*refused"):
+            pg.run([card, card])
+    finally:
+        L.ocr_selftest_refuse_launch(None)
+    assert np.array_equal(want, g.forward(x, keep_all=False))
+    again = pg.run([card, card])
+    assert [len(w) for w in again] == [len(w) for w in ok_words]
+    assert all(np.array_equal(a["ids"], b["ids"]) for wa, wb in zip(again, ok_words) for a, b in zip(wa, wb))
+    g.close()
+    pg.close()
+
+
 def test_model_directory_with_another_graph_is_refused(pkg, built):
     """The compiled-in plan binds weights to layers by name: a model directory whose graph is not the one the plan was
     generated from (op count / op-type signature, pd_format.cpp) must fail at load, not run with misbound weights."""

@@ -96,15 +96,8 @@ def make_inputs(seeds, workers=1):
 
 def _cfg3_item(args):
     """cfg3 sample i with its probability map at the detector's input size (limit 960 'max', multiples of 32)."""
-    i, limit = args
-    from synth_data import cfg3_sample, cfg3_prob_at
-    img = cfg3_sample(i)[0]
-    h, w = img.shape[:2]
-    ratio = 1.0 if max(h, w) <= limit else (np.float32(limit) / np.float32(h) if h > w else np.float32(limit) / np.float32(w))
-    r32 = lambda v: int(np.floor(np.float32(v) / np.float32(32) + np.float32(0.5)))   # C round(): halves away from zero (Python's round is half-even)
-    rh = max(r32(int(np.float32(h) * np.float32(ratio))) * 32, 32)   # ResizeImgType0, preprocess_op.cpp:74-88
-    rw = max(r32(int(np.float32(w) * np.float32(ratio))) * 32, 32)
-    return img, cfg3_prob_at(i, rh, rw)
+    from synth_data import cfg3_item
+    return cfg3_item(*args)
 
 
 def make_cfg3_inputs(ids, workers=1):

@@ -165,7 +165,7 @@ class Net {
   };
   std::shared_ptr<TablePool> pool_ = std::make_shared<TablePool>();
   static constexpr size_t kMaxRaggedBindings = 32;
-  static constexpr size_t kMaxBindings = 512;  // a mixed-size stream revisits sizes: BASELINE configs[2] has ~400 distinct det shapes
+  size_t max_bindings_ = 512;  // a mixed-size stream revisits sizes: BASELINE configs[2] has ~400 distinct det shapes (OCR_NET_BINDINGS, read at load)
   void invalidate() { cache_.clear(); cur_ = nullptr; }
   bool bind(int N, int H, int W, std::string& err, const int* widths = nullptr);
   bool run_bound(const float* x, hipStream_t s, std::string& err);

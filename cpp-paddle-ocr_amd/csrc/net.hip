@@ -186,6 +186,7 @@ static std::vector<float> build_frag(int taps, int cin, int cols, Get get) {
 bool Net::load(const char* plan_text, const WeightMap& W, std::string& err) {
   if (!parse_plan(plan_text, plan_, err)) return false;
   { const char* e = getenv("OCR_GRAPH"); graphs_ = !(e && e[0] == '0'); }
+  if (const char* e = getenv("OCR_NET_BINDINGS")) max_bindings_ = (size_t)std::min(4096L, std::max(2L, atol(e)));  // (tests: a small cap forces evictions)
   host_w_ = W;
   auto need = [&](const std::string& n) -> const HostTensor* {
     auto it = W.find(n);
@@ -1066,7 +1067,7 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths) {
     launches_.push_back(std::move(L));
   }
   if (moved) cache_.clear();
-  while (cache_.size() >= kMaxBindings) {  // least recently used out
+  while (cache_.size() >= max_bindings_) {  // least recently used out
     auto old = cache_.begin();
     for (auto it = cache_.begin(); it != cache_.end(); ++it)
       if (it->second->stamp < old->second->stamp) old = it;

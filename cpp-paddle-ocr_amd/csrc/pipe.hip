@@ -1,6 +1,7 @@
 // Fused det -> crop -> [cls -> rotate] -> rec pipeline over device-resident images
 // (OCRWorker::processRequest, /root/reference/src/ocr_worker.cpp:213-311) and its C-ABI.
 #include <algorithm>
+#include <array>
 #include <chrono>
 #include <cstring>
 #include <functional>
@@ -292,7 +293,7 @@ struct ocr_pipe {
   // two parts that run concurrently, each on its own worker and host thread.  Results are per image and do not depend
   // on what else is in a batch, so nothing changes but the overlap.  phases = 1 keeps one chain (one kernel at a time
   // owns the chip: what the per-kernel roofline figures of bench.py are measured with).
-  std::unique_ptr<PipeWorker> w1;
+  std::vector<std::unique_ptr<PipeWorker>> extra;  // chains 2 .. phases
   int phases = 2;
   int device = 0;
   StageSlot slots[2];
@@ -412,16 +413,17 @@ struct ocr_pipe {
     return OCR_OK;
   }
 
-  // ---- run: one chain, or two chains on two parts of the batch
+  // ---- run: one chain, or several chains on as many parts of the batch
   int run_images(uint8_t* base, const std::vector<StageSlot::Img>& imgs, const std::vector<StageSlot::Group>& groups, const float* probs,
                  std::vector<std::vector<ocr_word>>& out_words, std::vector<std::vector<int32_t>>& out_ids, double times[3], std::string& err) {
     const int count = (int)imgs.size();
-    if (!w1 || count < 2) return w0.run_images(base, imgs, groups, probs, out_words, out_ids, times, err);
-    // parts: whole size groups dealt to the lighter part (pixels), the heaviest group cut in two when that balances better
-    std::vector<StageSlot::Img> pi[2];
-    std::vector<StageSlot::Group> pg[2];
-    std::vector<int> gidx[2];  // layout index of a part's images
-    size_t load[2] = {0, 0};
+    const int K = (int)std::min<size_t>(1 + extra.size(), (size_t)count);
+    if (K < 2) return w0.run_images(base, imgs, groups, probs, out_words, out_ids, times, err);
+    // parts: size groups dealt to the lightest part (pixels), a group cut where that part reaches its share of the batch
+    std::vector<std::vector<StageSlot::Img>> pi(K);
+    std::vector<std::vector<StageSlot::Group>> pg(K);
+    std::vector<std::vector<int>> gidx(K);  // layout index of a part's images
+    std::vector<size_t> load(K, 0);
     auto give = [&](int p, const StageSlot::Group& g, int first, int n) {  // images first .. first+n-1 of group g
       int rh = 0, rw = 0;
       { float a, b; DetStage::resize_shape(g.rows, g.cols, w0.det.cfg().limit_type, w0.det.cfg().limit_side_len, rh, rw, a, b); }
@@ -436,41 +438,50 @@ struct ocr_pipe {
     };
     size_t total = 0;
     for (const auto& g : groups) total += (size_t)g.count * g.rows * g.cols;
+    const size_t share = (total + K - 1) / K;
     for (const auto& g : groups) {
-      const size_t px = (size_t)g.rows * g.cols, gl = px * g.count;
-      const int p = load[0] <= load[1] ? 0 : 1;
-      // cut the group where the lighter part reaches half of the batch (groups of one image are never cut)
-      const size_t room = total / 2 > load[p] ? total / 2 - load[p] : 0;
-      if (g.count >= 2 && gl > room + px && room >= px) {
-        const int na = (int)std::min<size_t>(g.count - 1, std::max<size_t>(1, (room + px / 2) / px));
-        give(p, g, 0, na);
-        give(1 - p, g, na, g.count - na);
-      } else give(p, g, 0, g.count);
+      const size_t px = (size_t)g.rows * g.cols;
+      int first = 0;
+      while (first < g.count) {
+        const int p = (int)(std::min_element(load.begin(), load.end()) - load.begin());
+        const int left = g.count - first;
+        const size_t room = share > load[p] ? share - load[p] : 0;
+        int n = left;
+        if ((size_t)left * px > room + px / 2) n = (int)std::min<size_t>(left, std::max<size_t>(1, (room + px / 2) / px));
+        give(p, g, first, n);
+        first += n;
+      }
     }
-    if (pi[0].empty() || pi[1].empty()) return w0.run_images(base, imgs, groups, probs, out_words, out_ids, times, err);
-    // the clone was enqueued on worker 0's detector stream: the other worker's streams must not read it earlier
+    // the clone was enqueued on worker 0's detector stream: the other workers' streams must not read it earlier
     if (hipStreamSynchronize(w0.det.stream()) != hipSuccess) { err = "det stream sync failed"; return OCR_ERR_DEVICE; }
-    std::vector<std::vector<ocr_word>> W[2];
-    std::vector<std::vector<int32_t>> I[2];
-    double t[2][3] = {{0, 0, 0}, {0, 0, 0}};
-    int rc[2] = {OCR_OK, OCR_OK};
-    std::string errs[2];
-    std::thread other([&]() {
-      (void)hipSetDevice(device);
-      rc[1] = w1->run_images(base, pi[1], pg[1], probs, W[1], I[1], t[1], errs[1]);
-    });
-    rc[0] = w0.run_images(base, pi[0], pg[0], probs, W[0], I[0], t[0], errs[0]);
-    other.join();
-    for (int p = 0; p < 2; ++p)
+    std::vector<std::vector<std::vector<ocr_word>>> W(K);
+    std::vector<std::vector<std::vector<int32_t>>> I(K);
+    std::vector<std::array<double, 3>> t(K, std::array<double, 3>{0, 0, 0});
+    std::vector<int> rc(K, OCR_OK);
+    std::vector<std::string> errs(K);
+    auto part = [&](int p) {
+      if (pi[p].empty()) return;
+      PipeWorker& w = p == 0 ? w0 : *extra[p - 1];
+      rc[p] = w.run_images(base, pi[p], pg[p], probs, W[p], I[p], t[p].data(), errs[p]);
+    };
+    std::vector<std::thread> th;
+    for (int p = 1; p < K; ++p) th.emplace_back([&, p]() { (void)hipSetDevice(device); part(p); });
+    part(0);
+    for (auto& x : th) x.join();
+    for (int p = 0; p < K; ++p)
       if (rc[p]) { err = errs[p]; return rc[p]; }
     out_words.assign(count, {});
     out_ids.assign(count, {});
-    for (int p = 0; p < 2; ++p)
+    for (int p = 0; p < K; ++p)
       for (size_t k = 0; k < gidx[p].size(); ++k) {
         out_words[gidx[p][k]] = std::move(W[p][k]);
         out_ids[gidx[p][k]] = std::move(I[p][k]);
       }
-    for (int k = 0; k < 3; ++k) times[k] += std::max(t[0][k], t[1][k]);  // the two chains ran side by side
+    for (int k = 0; k < 3; ++k) {  // the chains ran side by side
+      double m = 0;
+      for (int p = 0; p < K; ++p) m = std::max(m, t[p][k]);
+      times[k] += m;
+    }
     return OCR_OK;
   }
 
@@ -533,9 +544,9 @@ int ocr_pipe_create(const ocr_pipe_cfg* c, ocr_pipe** out) {
   std::unique_ptr<ocr_pipe> h(new ocr_pipe());
   h->device = c->det.device_id;
   if (c->crop_mode != OCR_CROP_BOUNDING_RECT && c->crop_mode != OCR_CROP_ROTATE) return fail(OCR_ERR_ARG, "unknown crop_mode");
-  if (c->phases < 0 || c->phases > 2) return fail(OCR_ERR_ARG, "phases must be 0 (default), 1 or 2");
+  if (c->phases < 0 || c->phases > 4) return fail(OCR_ERR_ARG, "phases must be 0 (default) or 1..4");
   h->phases = c->phases ? c->phases : 2;
-  if (const char* e = getenv("OCR_PIPE_PHASES")) h->phases = atoi(e) == 1 ? 1 : 2;
+  if (const char* e = getenv("OCR_PIPE_PHASES")) h->phases = std::min(4, std::max(1, atoi(e)));
   std::string err;
   DetConfig d;
   d.model_dir = c->det.model_dir; d.device = c->det.device_id;
@@ -561,13 +572,14 @@ int ocr_pipe_create(const ocr_pipe_cfg* c, ocr_pipe** out) {
   int rc = h->w0.create(d, r, c->enable_cls ? &k : nullptr, c->crop_mode, err);
   if (rc) return fail(rc, err);
   h->w0.det_lanes = lanes;
-  if (h->phases == 2) {
-    h->w1.reset(new PipeWorker());
-    rc = h->w1->create(d, r, c->enable_cls ? &k : nullptr, c->crop_mode, err);
+  for (int p = 1; p < h->phases; ++p) {
+    h->extra.emplace_back(new PipeWorker());
+    rc = h->extra.back()->create(d, r, c->enable_cls ? &k : nullptr, c->crop_mode, err);
     if (rc) return fail(rc, err);
-    // the detector lanes (mixed-size batches) are dealt over the two chains
-    h->w0.det_lanes = h->w1->det_lanes = std::max(1, (lanes + 1) / 2);
   }
+  // the detector lanes (mixed-size batches) are dealt over the chains
+  h->w0.det_lanes = std::max(1, (lanes + h->phases - 1) / h->phases);
+  for (auto& w : h->extra) w->det_lanes = h->w0.det_lanes;
   // two idle high-priority streams, created after the stage objects' streams and before the detector lanes' (which
   // come into being at the first mixed-size batch): the configuration in which the lanes measured fastest (capi_net.hip)
   priority_anchor(h->device, true);
@@ -659,8 +671,9 @@ int ocr_pipe_det_shape(ocr_pipe* h, int rows, int cols, int* net_rows, int* net_
 
 static std::vector<Net*> pipe_nets(ocr_pipe* h) {
   std::vector<Net*> v;
-  for (PipeWorker* w : {&h->w0, h->w1.get()}) {
-    if (!w) continue;
+  std::vector<PipeWorker*> ws{&h->w0};
+  for (auto& w : h->extra) ws.push_back(w.get());
+  for (PipeWorker* w : ws) {
     v.push_back(&w->det.net());
     if (w->cls) v.push_back(&w->cls->net());
     v.push_back(&w->rec.net());
@@ -679,8 +692,9 @@ int ocr_pipe_stats(ocr_pipe* h, long long out[3]) {
   if (!h || !out) return fail(OCR_ERR_ARG, "null argument");
   out[0] = out[1] = out[2] = 0;
   auto add = [&](Net& n) { out[0] += n.stats().runs; out[1] += n.stats().binds; out[2] += n.stats().graph_replays; };
-  for (PipeWorker* w : {&h->w0, h->w1.get()}) {
-    if (!w) continue;
+  std::vector<PipeWorker*> ws{&h->w0};
+  for (auto& w : h->extra) ws.push_back(w.get());
+  for (PipeWorker* w : ws) {
     add(w->det.net());
     for (auto& d : w->det_extra) add(d->net());
     if (w->cls) add(w->cls->net());

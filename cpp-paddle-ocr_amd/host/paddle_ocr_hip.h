@@ -314,6 +314,13 @@ class OCRWorker {
     c.rec.model_dir = rec_dir_.c_str(); c.rec.label_path = dict_.c_str();
     c.enable_cls = enable_cls;
     c.crop_mode = rotate_crops ? OCR_CROP_ROTATE : OCR_CROP_BOUNDING_RECT;
+    // The reference hard-codes the model hyper-parameters in OCRWorker::OCRWorker (src/ocr_worker.cpp:21-63: limit 512,
+    // rec 28x192, cls off) and ocr_pipe_cfg_default carries those literals.  Extension for load tests of other
+    // operating points (tools/service_load.py): OCR_WORKER_DET_LIMIT, OCR_WORKER_REC_H / _W, OCR_WORKER_CLS=1.
+    if (const char* e = getenv("OCR_WORKER_DET_LIMIT")) if (atoi(e) >= 32) c.det.limit_side_len = atoi(e);
+    if (const char* e = getenv("OCR_WORKER_REC_H")) if (atoi(e) >= 8) c.rec.rec_img_h = atoi(e);
+    if (const char* e = getenv("OCR_WORKER_REC_W")) if (atoi(e) >= 8) c.rec.rec_img_w = atoi(e);
+    if (const char* e = getenv("OCR_WORKER_CLS")) if (e[0] == '1') c.enable_cls = 1;
     check_ocr(ocr_pipe_create(&c, &pipe_), "OCRWorker");
   }
   virtual ~OCRWorker() { stop(); ocr_pipe_destroy(pipe_); }

@@ -140,10 +140,10 @@ typedef struct ocr_pipe_cfg {
   int enable_cls; /* OCRWorker(..., enable_cls = false) */
   int crop_mode;  /* OCR_CROP_BOUNDING_RECT: ROI views, what the worker does (ocr_worker.cpp:244-259);
                    * OCR_CROP_ROTATE: Utility::GetRotateCropImage per box (utility.cpp:137-190) */
-  int phases;     /* chains a batch is run on: 2 (and 0, the default) = two parts of the batch side by side, each with its own
-                   * stage objects, streams and host thread (the latency-bound phases of one run under the dense kernels
-                   * of the other; results are per image and do not change); 1 = one chain, one kernel at a time owns the
-                   * device.  OCR_PIPE_PHASES in the environment overrides. */
+  int phases;     /* chains a batch is run on, 1..4 (0 = the default, 2): the batch is cut into that many parts that run side by
+                   * side, each with its own stage objects, streams and host thread (the latency-bound phases of one run
+                   * under the dense kernels of another; results are per image and do not change); 1 = one chain, one
+                   * kernel at a time owns the device.  OCR_PIPE_PHASES in the environment overrides. */
 } ocr_pipe_cfg;
 enum { OCR_CROP_BOUNDING_RECT = 0, OCR_CROP_ROTATE = 1 };
 void ocr_pipe_cfg_default(ocr_pipe_cfg* cfg);

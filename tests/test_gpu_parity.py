@@ -729,3 +729,55 @@ def test_pipeline_cfg3_pooled_lines_and_staged_slots(pkg, built):
     for a, b in zip(again, got[:10]):
         assert len(a) == len(b) and all(np.array_equal(x["ids"], y["ids"]) and x["confidence"] == y["confidence"] for x, y in zip(a, b))
     pg.close()
+
+
+def _cfg3_pool_item(i):
+    from synth_data import cfg3_item
+    return cfg3_item(i)
+
+
+@pytest.mark.timeout(900)
+def test_pipeline_configs2_full_size_with_binding_eviction_and_changing_slots(pkg, built, monkeypatch):
+    """BASELINE configs[2] at its full size: 512 mixed 640-1280 px images (>= 300 distinct detector shapes) in ONE call,
+    with the networks' binding caches capped at 16 shapes so that every detector lane keeps evicting and re-binding
+    (the 512-entry LRU of production is never under pressure in the small tests).  Eight sampled images are checked
+    word for word against the oracle; then the same images go through the two staging slots in batches of 64 with a
+    NEW composition every time (the request-stream path of configs[3]) and every image's words must equal what the
+    full batch gave for it - results do not depend on what else is in a batch."""
+    import multiprocessing as mp
+    from pipeline import Pipeline, DetCfg
+    n = 512
+    with mp.get_context("spawn").Pool(12) as pool:       # (spawned: this process has initialised the GPU)
+        items = pool.map(_cfg3_pool_item, range(n), chunksize=8)
+    imgs, probs = [it[0] for it in items], [it[1] for it in items]
+    assert len({im.shape for im in imgs}) >= 300
+    monkeypatch.setenv("OCR_NET_BINDINGS", "16")
+    kw = dict(rec_batch_num=16, rec_img_h=48, rec_img_w=320, enable_cls=True)
+    pg = pkg.Pipe(limit_side_len=960, **kw)
+    for i in (0, 100, 511):
+        assert pg.det_shape(*imgs[i].shape[:2]) == probs[i].shape
+    st0 = pg.stats()
+    pg.stage(0, imgs, probs)
+    got = pg.run_staged(0)
+    st1 = pg.stats()
+    assert st1["binds"] - st0["binds"] >= 300                       # one per distinct shape at least
+    again = pg.run_staged(0)                                         # the capped caches re-bind what they evicted
+    assert pg.stats()["binds"] - st1["binds"] >= 100
+    same = lambda a, b: len(a) == len(b) and all(np.array_equal(x["box"], y["box"]) and np.array_equal(x["ids"], y["ids"]) and
+                                                 x["confidence"] == y["confidence"] for x, y in zip(a, b))
+    assert all(same(a, b) for a, b in zip(got, again))
+    assert sum(len(g) for g in got) > 10000
+    po = Pipeline(det_cfg=DetCfg(limit_side_len=960), **kw)
+    for i in (0, 63, 64, 200, 255, 256, 400, 511):
+        w = po.process(imgs[i], probs[i])["words"]
+        assert len(got[i]) == len(w) > 0, i
+        for a, b in zip(got[i], w):
+            assert np.array_equal(a["box"], b["box"]) and np.array_equal(a["ids"], b["ids"]) and a["confidence"] == np.float32(b["confidence"])
+    # the stream path: alternating slots, a new composition of 64 images every batch (strided picks: sizes mix differently)
+    rs = np.random.RandomState(9)
+    for b in range(6):
+        ids = rs.permutation(n)[:64]
+        pg.stage(b & 1, [imgs[i] for i in ids], [probs[i] for i in ids])
+        out = pg.run_staged(b & 1)
+        assert all(same(out[k], got[i]) for k, i in enumerate(ids)), b
+    pg.close()

@@ -36,11 +36,14 @@ def connect(path):
     raise RuntimeError("service did not come up")
 
 
-def run(max_batch, clients, per_client, img_path, fmt):
-    sock = f"/tmp/ocr_load_{os.getpid()}_{max_batch}.sock"
+def run(max_batch, clients, per_client, img_path, fmt, workers=1, extra_env=None, tag=None):
+    sock = f"/tmp/ocr_load_{os.getpid()}_{max_batch}_{abs(hash(str(extra_env))) % 9999}.sock"
     env = dict(os.environ, OCR_WORKER_MAX_BATCH=str(max_batch))
+    env.update(extra_env or {})
     proc = subprocess.Popen([os.path.join(HOST, "ocr_service"), "--model-dir", os.path.join(ROOT, "models"), "--pipe-name", sock,
-                             "--gpu-workers", "1"], env=env, stdout=subprocess.DEVNULL, stderr=subprocess.STDOUT)
+                             "--gpu-workers", str(workers)], env=env, stdout=subprocess.DEVNULL, stderr=subprocess.STDOUT)
+    import psutil
+    ps = psutil.Process(proc.pid)
     try:
         s0 = connect(sock)
         for _ in range(3):
@@ -57,14 +60,20 @@ def run(max_batch, clients, per_client, img_path, fmt):
                 with lock:
                     lat.append((time.perf_counter() - t0) * 1e3)
         th = [threading.Thread(target=work) for _ in range(clients)]
+        c0 = ps.cpu_times()
         t0 = time.perf_counter()
         [t.start() for t in th]
         [t.join() for t in th]
         dt = time.perf_counter() - t0
+        c1 = ps.cpu_times()
         lat.sort()
-        print(json.dumps({"max_batch": max_batch, "clients": clients, "requests": len(lat), "image": fmt,
-                          "requests_per_s": round(len(lat) / dt, 1), "p50_ms": round(lat[len(lat) // 2], 1),
-                          "p99_ms": round(lat[int(len(lat) * 0.99) - 1], 1), "words_per_image": len(r["words"])}))
+        rec = {"max_batch": max_batch, "gpu_workers": workers, "clients": clients, "requests": len(lat), "image": fmt,
+               "requests_per_s": round(len(lat) / dt, 1), "p50_ms": round(lat[len(lat) // 2], 1),
+               "p99_ms": round(lat[int(len(lat) * 0.99) - 1], 1), "words_per_image": len(r["words"]),
+               "service_host_cores_busy": round(((c1.user + c1.system) - (c0.user + c0.system)) / dt, 2)}
+        if tag:
+            rec["mode"] = tag
+        print(json.dumps(rec), flush=True)
         call(s0, {"command": "shutdown"})
         proc.wait(timeout=30)
     finally:
@@ -72,7 +81,56 @@ def run(max_batch, clients, per_client, img_path, fmt):
             proc.kill()
 
 
+def jpeg_mode(clients, per):
+    """960x960 JPEG requests (a configs[1] card, quality 90, 4:2:0) against a service with two GPU workers on the one
+    device: OCR_DEVICE_JPEG=1 (entropy decoding on the client's service thread, dequantisation / IDCT / upsampling /
+    colour on the GPU, straight into the staging slot) against =0 (the whole decode on the host), with the service
+    process's busy host cores beside it.  One JSON line per mode."""
+    from PIL import Image
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from synth_data import cfg2_sample
+    img = cfg2_sample(0, 960, 960, 32)[0]
+    path = f"/tmp/ocr_load_{os.getpid()}.jpg"
+    Image.fromarray(img[:, :, ::-1]).save(path, quality=90, subsampling=2)
+    fmt = "jpeg 960x960 q90 4:2:0 (%d KB)" % (os.path.getsize(path) // 1024)
+    op = {"OCR_WORKER_DET_LIMIT": "960", "OCR_WORKER_REC_H": "48", "OCR_WORKER_REC_W": "320", "OCR_WORKER_CLS": "1"}   # configs[1]'s operating point
+    for dev in ("1", "0"):
+        run(32, clients, per, path, fmt, workers=2, extra_env=dict(op, OCR_DEVICE_JPEG=dev),
+            tag="device_jpeg" if dev == "1" else "host_jpeg")
+    # the yardstick: the pipeline itself (one handle, two chains) on the SAME decoded image, 64 per batch from host memory
+    # through the double-buffered staging - what bench.py calls host_input, but with this image's own detector output
+    # (no probability-map protocol: the service cannot be handed one), i.e. the same words per image as the service saw
+    import threading as th_
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    dec = np.ascontiguousarray(np.asarray(Image.open(path).convert("RGB"))[:, :, ::-1])
+    pipe = pkg.Pipe(enable_cls=True, limit_side_len=960, rec_batch_num=16, rec_img_h=48, rec_img_w=320)
+    batch = [dec] * 64
+    pipe.stage(0, batch)
+    pipe.stage(1, batch)
+    w = pipe.run_staged(0)
+    pipe.run_staged(1, collect=False)
+    steps = 8
+    pipe.stage(0, batch)
+    t0 = time.perf_counter()
+    for k in range(steps):
+        t = th_.Thread(target=pipe.stage, args=(1 - (k & 1), batch))
+        t.start()
+        pipe.run_staged(k & 1, collect=False)
+        t.join()
+    dt = time.perf_counter() - t0
+    print(json.dumps({"mode": "pipeline_host_input_same_image", "images_per_s": round(64 * steps / dt, 1), "words_per_image": len(w[0]),
+                      "what": "ocr_pipe_stage + ocr_pipe_run_staged, 64 copies of the decoded image per batch, double-buffered"}), flush=True)
+    pipe.close()
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "jpeg":
+        subprocess.check_call(["make", "-s", "-C", HOST])
+        import synth_weights
+        synth_weights.ensure(ROOT)
+        jpeg_mode(int(sys.argv[2]) if len(sys.argv) > 2 else 64, int(sys.argv[3]) if len(sys.argv) > 3 else 16)
+        sys.exit(0)
     clients = int(sys.argv[1]) if len(sys.argv) > 1 else 32
     per = int(sys.argv[2]) if len(sys.argv) > 2 else 8
     subprocess.check_call(["make", "-s", "-C", HOST])

@@ -123,3 +123,20 @@ def cfg3_sample(i):
     K = 4 + int(u[2] * 61)
     layout = make_layout(seed, H, W, K)
     return make_image(seed, H, W, K, layout), make_prob_map(seed, H, W, K, layout), layout
+
+
+def det_input_shape(h, w, limit=960):
+    """ResizeImgType0 with limit_type 'max' (/root/reference/src/preprocess_op.cpp:74-88): the detector's input size of an
+    h x w image.  C's round() (halves away from zero), float32 arithmetic as the reference."""
+    ratio = np.float32(1.0) if max(h, w) <= limit else (np.float32(limit) / np.float32(h) if h > w else np.float32(limit) / np.float32(w))
+    r32 = lambda v: int(np.floor(np.float32(v) / np.float32(32) + np.float32(0.5)))
+    rh = max(r32(int(np.float32(h) * np.float32(ratio))) * 32, 32)
+    rw = max(r32(int(np.float32(w) * np.float32(ratio))) * 32, 32)
+    return rh, rw
+
+
+def cfg3_item(i, limit=960):
+    """cfg3 sample i with its probability map at the detector's input size (top-level: usable from worker processes)"""
+    img = cfg3_sample(i)[0]
+    rh, rw = det_input_shape(img.shape[0], img.shape[1], limit)
+    return img, cfg3_prob_at(i, rh, rw)

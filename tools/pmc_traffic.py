@@ -28,8 +28,16 @@ def rows(d, counter):
 
 def main():
     root, dst = sys.argv[1], sys.argv[2]
-    LINES = 1872
-    grid = (LINES * 6 * 80 // 128) * 5 * 256
+    # round 3: the recognizer's lines run as ONE ragged launch (every tensor width together), so the row count of op 30
+    # comes from the bench line of the same code (roofline.algorithmic_flops_per_launch = 2 * M * 480 * 480) instead
+    # of being "1872 lines x 6 x 80"
+    LINES, M_ROWS, NAME = 1872, 1872 * 6 * 80, None
+    if len(sys.argv) > 3:
+        rl = json.loads(open(sys.argv[3]).read().strip().splitlines()[-1])["roofline"]
+        M_ROWS = int(round(rl["algorithmic_flops_per_launch"] / (2.0 * 480 * 480)))
+        NAME = rl["kernel"]
+        LINES = int(NAME.split("@")[1].split("x")[0])
+    grid = ((M_ROWS + 127) // 128) * 5 * 256
     # with the SE gate folded into its consumers (net.hip) ops 25 and 30 run the GATE instantiation
     # conv_mfma_kernel<3, 0, true, true> on this grid, in that order: op 30 is every second dispatch of it;
     # with OCR_FUSE_GATE=0 ops 25, 30, 32, 34 share one kernel and op 30 is every fourth starting at the second
@@ -44,11 +52,11 @@ def main():
     gui = sel(rows(os.path.join(root, "pmc_sq"), "GRBM_GUI_ACTIVE"))
     rd = sum(r[3] for r in fe) / len(fe) * 1024 * 2
     wb = sum(r[3] for r in wr) / len(wr) * 1024
-    M, K, N = LINES * 6 * 80, 480, 480
+    M, K, N = M_ROWS, 480, 480
     alg = 4.0 * (M * K + M * N + K * N)
     out = {
-        "kernel": "rec.30.conv1x1_480_480%s@%dx48x320" % ("_gated" if any("true, true>" in r[1] for r in fe) else "", LINES),
-        "launch": "conv_mfma_kernel<3, OUT_C8I, single-tap%s>, grid %dx256 (the %d-line, width-320 launch)" % (
+        "kernel": NAME or "rec.30.conv1x1_480_480%s@%dx48x320" % ("_gated" if any("true, true>" in r[1] for r in fe) else "", LINES),
+        "launch": "conv_mfma_kernel<3, OUT_C8I, single-tap%s>, grid %dx256 (the %d-line launch)" % (
             ", SE gate folded into the A operand" if any("true, true>" in r[1] for r in fe) else "", grid // 256, LINES),
         "dispatches_averaged": len(fe),
         "hbm_read_bytes_per_launch": rd,

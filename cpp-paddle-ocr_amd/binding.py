@@ -50,7 +50,7 @@ EXPORTS = [
     "ocr_cls_cfg_default", "ocr_cls_create", "ocr_cls_destroy", "ocr_cls_run", "ocr_cls_probs",
     "ocr_rec_cfg_default", "ocr_rec_create", "ocr_rec_destroy", "ocr_rec_run", "ocr_rec_label",
     "ocr_rec_num_classes", "ocr_rec_steps",
-    "ocr_net_create", "ocr_net_destroy", "ocr_net_forward", "ocr_net_forward_ragged", "ocr_net_num_tensors", "ocr_net_tensor_exists", "ocr_net_fetch",
+    "ocr_net_create", "ocr_net_destroy", "ocr_net_forward", "ocr_net_forward_ragged", "ocr_net_forward_ragged_images", "ocr_net_num_tensors", "ocr_net_tensor_exists", "ocr_net_fetch",
     "ocr_net_timing", "ocr_net_timing_report", "ocr_probe", "ocr_selftest_refuse_launch", "ocr_selftest_lds_memo",
 ]
 
@@ -65,6 +65,8 @@ def lib():
         L.ocr_net_create.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
         L.ocr_net_destroy.argtypes = [C.c_void_p]
         L.ocr_net_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+        if hasattr(L, "ocr_net_forward_ragged_images"):
+            L.ocr_net_forward_ragged_images.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
         if hasattr(L, "ocr_net_forward_ragged"):
             L.ocr_net_forward_ragged.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
         L.ocr_net_num_tensors.argtypes = [C.c_void_p]
@@ -116,6 +118,14 @@ class Net:
         x = np.concatenate([np.ascontiguousarray(l, dtype=np.float32).reshape(-1) for l in lines])
         widths = np.array([l.shape[1] for l in lines], dtype=np.int32)
         check(lib().ocr_net_forward_ragged(self.h, x.ctypes.data, len(lines), h, widths.ctypes.data, int(keep_all)))
+        return self.fetch(-1)
+
+    def forward_ragged_images(self, imgs, keep_all=False):
+        """imgs: list of f32 [H_i, W_i, 3] arrays (sizes multiples of 32) -> the output's images one after the other"""
+        x = np.concatenate([np.ascontiguousarray(l, dtype=np.float32).reshape(-1) for l in imgs])
+        hs = np.array([l.shape[0] for l in imgs], dtype=np.int32)
+        ws = np.array([l.shape[1] for l in imgs], dtype=np.int32)
+        check(lib().ocr_net_forward_ragged_images(self.h, x.ctypes.data, len(imgs), hs.ctypes.data, ws.ctypes.data, int(keep_all)))
         return self.fetch(-1)
 
     def fetch(self, tid, cap=None):

@@ -234,6 +234,31 @@ int ocr_net_forward_ragged(ocr_net* h, const float* x, int N, int H, const int* 
   return OCR_OK;
 }
 
+int ocr_net_forward_ragged_images(ocr_net* h, const float* x, int N, const int* heights, const int* widths, int keep_all) {
+  if (!h || !x || !widths || !heights || N <= 0) return fail(OCR_ERR_ARG, "bad argument");
+  if (keep_all != 0 && keep_all != 2) return fail(OCR_ERR_ARG, "a ragged batch of images runs the production launch list (keep_all 0 or 2)");
+  CAPI_HIP(hipSetDevice(h->device));
+  size_t n = 0;
+  for (int i = 0; i < N; ++i) {
+    if (widths[i] <= 0 || heights[i] <= 0) return fail(OCR_ERR_ARG, "bad image size");
+    n += (size_t)heights[i] * widths[i] * 3;
+  }
+  if (n > h->x_cap) {
+    if (h->x_dev) (void)hipFree(h->x_dev);
+    h->x_dev = nullptr;
+    h->x_cap = 0;
+    CAPI_HIP(hipMalloc(&h->x_dev, n * sizeof(float)));
+    h->x_cap = n;
+  }
+  CAPI_HIP(hipMemcpyAsync(h->x_dev, x, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  h->net.set_keep_all(keep_all);
+  std::string err;
+  if (!h->net.run_ragged_images(h->x_dev, heights, widths, N, h->stream, err)) return fail(OCR_ERR_DEVICE, err);
+  CAPI_HIP(hipStreamSynchronize(h->stream));
+  h->net.collect_timings();
+  return OCR_OK;
+}
+
 int ocr_net_num_tensors(ocr_net* h) { return h ? h->net.ntensors() : 0; }
 int ocr_net_tensor_exists(ocr_net* h, int tid) { return h && h->net.materialised(tid) ? 1 : 0; }
 

@@ -54,11 +54,26 @@ __device__ __forceinline__ int rag_line_near(const int* __restrict__ cw, int N, 
   while (n + 1 < N && (long)cw[n + 1] * mul <= t) ++n;
   return n;
 }
-// pixel m of a ragged tensor with H rows per line -> (line, y, x); m0 = the workgroup's first pixel (uniform)
-__device__ __forceinline__ void rag_decompose(const RagLevel& r, int N, int H, long m, long m0, int& n, int& y, int& x, int& w) {
-  n = rag_line_near(r.cw, N, m, H, m0);
-  w = r.w[n];
-  const int rem = (int)(m - (long)r.cw[n] * H);
+// ---- geometry of sample n of a ragged tensor (lines: one height Hu for all; images: own height, level = input >> shift)
+__device__ __forceinline__ int rag_w(const RagLevel& r, int n) { return r.h ? r.w[n] >> r.shift : r.w[n]; }
+__device__ __forceinline__ int rag_h(const RagLevel& r, int n, int Hu) { return r.h ? r.h[n] >> r.shift : Hu; }
+__device__ __forceinline__ long rag_pix0(const RagLevel& r, int n, int Hu) { return r.h ? (long)(r.cw[n] >> (2 * r.shift)) : (long)r.cw[n] * Hu; }
+__device__ __forceinline__ long rag_row0(const RagLevel& r, int n, int Hu) { return r.h ? (long)(r.ch[n] >> r.shift) : (long)n * Hu; }
+// sample of pixel m (m0 = the workgroup's first pixel, wave-uniform)
+__device__ __forceinline__ int rag_sample_of_pixel(const RagLevel& r, int N, int Hu, long m, long m0) {
+  if (r.h) return rag_line_near(r.cw, N, m << (2 * r.shift), 1, m0 << (2 * r.shift));  // (cw[n] are multiples of 4^shift)
+  return rag_line_near(r.cw, N, m, Hu, m0);
+}
+// sample of row `row` of the [rows][Cs] view (SE pools)
+__device__ __forceinline__ int rag_sample_of_row(const RagLevel& r, int N, int Hu, long row, long row0) {
+  if (r.h) return rag_line_near(r.ch, N, row << r.shift, 1, row0 << r.shift);
+  return (int)(row / Hu);
+}
+// pixel m of a ragged tensor -> (sample, y, x) and the sample's width / height; m0 = the workgroup's first pixel (uniform)
+__device__ __forceinline__ void rag_decompose(const RagLevel& r, int N, int Hu, long m, long m0, int& n, int& y, int& x, int& w) {
+  n = rag_sample_of_pixel(r, N, Hu, m, m0);
+  w = rag_w(r, n);
+  const int rem = (int)(m - rag_pix0(r, n, Hu));
   y = rem / w;
   x = rem - y * w;
 }
@@ -86,8 +101,9 @@ __device__ __forceinline__ float apply_epilogue(const Epilogue& ep, float v, int
 }
 
 // 4 consecutive physical channels
+// up_base >= 0 (ragged batch of images): first pixel and width of sample n in the upsampled operand's (coarser) tensor
 __device__ __forceinline__ float4 apply_epilogue4(const Epilogue& ep, float4 v, int pc, int n, int y, int x, long oidx,
-                                                  int cs) {
+                                                  int cs, long up_base = -1, int up_w = 0) {
   for (int s = 0; s < ep.n; ++s) {
     const EpStage& st = ep.st[s];
     switch (st.kind) {
@@ -111,7 +127,8 @@ __device__ __forceinline__ float4 apply_epilogue4(const Epilogue& ep, float4 v, 
       case EP_ADDT: { float4 g = *(const float4*)(st.v0 + oidx); v.x = v.x + g.x; v.y = v.y + g.y; v.z = v.z + g.z; v.w = v.w + g.w; } break;
       case EP_ADDUP: {
         int sy = y / st.a0, sx = x / st.a0;
-        float4 g = *(const float4*)(st.v0 + (((long)n * st.a2 + sy) * st.a1 + sx) * cs + pc);
+        const long spix = up_base >= 0 ? up_base + (long)sy * up_w + sx : ((long)n * st.a2 + sy) * st.a1 + sx;
+        float4 g = *(const float4*)(st.v0 + spix * cs + pc);
         v.x = v.x + g.x; v.y = v.y + g.y; v.z = v.z + g.z; v.w = v.w + g.w;
       } break;
     }

@@ -72,26 +72,31 @@ struct DwPwGeom {
 };
 
 // position of a work unit (column block fastest, then tile x, tile y, image), advanced without divisions.
-// RAG (ragged batch; kernels_net.h, RagLevel): an image is a text line with its own width - its tile-column count is
-// re-read from the table when the walk enters a line; widths and first pixels are read where they are used (g_setup,
-// finish: once per unit).  All of this is wave-uniform (scalar registers, which these kernels have none to spare of:
-// the uniform instantiations carry no ragged state at all).
-template <bool RAG>
+// RAG (ragged batch; kernels_net.h, RagLevel): an image is a text line of its own width, or (the detector on mixed
+// sizes) an image of its own height and width - its tile counts are re-derived when the walk enters a sample; sizes and
+// first pixels are read where they are used (g_setup, finish: once per unit).  All of this is wave-uniform (scalar
+// registers, which these kernels have none to spare of: the uniform instantiations carry no ragged state at all).
+template <bool RAG, int TH>
 struct UnitPos {
   int cb, tx, ty, n;
-  int txn;  // RAG: tile columns of line n
+  int txn, tyn;  // RAG: tile columns / rows of sample n
   __device__ __forceinline__ int cols(const DwPwArgs& a) const { return RAG ? txn : a.tiles_x; }
+  __device__ __forceinline__ int rows(const DwPwArgs& a) const { return RAG ? tyn : a.tiles_y; }
+  __device__ __forceinline__ void geom(const DwPwArgs& a) {  // (the tables carry one entry past N: the walk steps onto "sample N" after the last unit)
+    txn = (rag_w(a.rout, n) + 15) >> 4;
+    tyn = (rag_h(a.rout, n, a.c.OH) + TH - 1) / TH;
+  }
   __device__ __forceinline__ void init(unsigned u, int cblocks, const DwPwArgs& a) {
     cb = (int)(u % (unsigned)cblocks);
     unsigned t = u / (unsigned)cblocks;
     if constexpr (RAG) {
-      n = rag_line(a.rtiles, a.c.N, t, a.tiles_y);
-      txn = a.rtiles[n + 1] - a.rtiles[n];
-      t -= (unsigned)a.rtiles[n] * (unsigned)a.tiles_y;
+      n = rag_line(a.rtiles, a.c.N, t, 1);
+      geom(a);
+      t -= (unsigned)a.rtiles[n];
       ty = (int)(t / (unsigned)txn);
       tx = (int)(t - (unsigned)ty * (unsigned)txn);
     } else {
-      txn = 0;
+      txn = tyn = 0;
       tx = (int)(t % (unsigned)a.tiles_x);
       t /= (unsigned)a.tiles_x;
       ty = (int)(t % (unsigned)a.tiles_y);
@@ -103,18 +108,20 @@ struct UnitPos {
       cb = 0;
       if (++tx == cols(a)) {
         tx = 0;
-        if (++ty == a.tiles_y) {
+        if (++ty == rows(a)) {
           ty = 0; ++n;
-          if constexpr (RAG) txn = a.rtiles[n + 1] - a.rtiles[n];  // (the table has one entry past N: the walk steps onto "line N" after the last unit)
+          if constexpr (RAG) geom(a);
         }
       }
     }
   }
-  // width and first pixel of image n on the input / output side
-  __device__ __forceinline__ int in_w(const DwPwArgs& a) const { return RAG ? a.rin.w[n] : a.W; }
-  __device__ __forceinline__ int out_w(const DwPwArgs& a) const { return RAG ? a.rout.w[n] : a.c.OW; }
-  __device__ __forceinline__ long in_pix(const DwPwArgs& a) const { return RAG ? (long)a.rin.cw[n] * a.H : (long)n * a.H * a.W; }
-  __device__ __forceinline__ long out_pix(const DwPwArgs& a) const { return RAG ? (long)a.rout.cw[n] * a.c.OH : (long)n * a.c.OH * a.c.OW; }
+  // size and first pixel of image n on the input / output side
+  __device__ __forceinline__ int in_w(const DwPwArgs& a) const { return RAG ? rag_w(a.rin, n) : a.W; }
+  __device__ __forceinline__ int in_h(const DwPwArgs& a) const { return RAG ? rag_h(a.rin, n, a.H) : a.H; }
+  __device__ __forceinline__ int out_w(const DwPwArgs& a) const { return RAG ? rag_w(a.rout, n) : a.c.OW; }
+  __device__ __forceinline__ int out_h(const DwPwArgs& a) const { return RAG ? rag_h(a.rout, n, a.c.OH) : a.c.OH; }
+  __device__ __forceinline__ long in_pix(const DwPwArgs& a) const { return RAG ? rag_pix0(a.rin, n, a.H) : (long)n * a.H * a.W; }
+  __device__ __forceinline__ long out_pix(const DwPwArgs& a) const { return RAG ? rag_pix0(a.rout, n, a.c.OH) : (long)n * a.c.OH * a.c.OW; }
 };
 
 // the LAB chain on two packed pairs; bias already added by the caller where it comes from elsewhere
@@ -198,7 +205,7 @@ __global__ void __launch_bounds__(256, LB) dwpw_kernel(const DwPwArgs a) {
   }
 
   // ---- G: global -> registers, item by item (its own unit / chunk counters run ahead of everything else)
-  UnitPos<RAG> g_pos_u;
+  UnitPos<RAG, TH> g_pos_u;
   g_pos_u.init(u0, cblocks, a);
   int g_units = nunits, g_ch = 0;
   const float* g_img = a.dw_in;
@@ -206,11 +213,11 @@ __global__ void __launch_bounds__(256, LB) dwpw_kernel(const DwPwArgs a) {
   auto g_setup = [&]() __attribute__((always_inline)) {  // image offsets of this thread's pieces for unit g_pos_u (-1: zero)
     g_img = a.dw_in + g_pos_u.in_pix(a) * Cs;
     const int iy0 = g_pos_u.ty * TH * SH - a.PH, ix0 = g_pos_u.tx * TW * SW - a.PW;
-    const int iwn = g_pos_u.in_w(a);
+    const int iwn = g_pos_u.in_w(a), ihn = g_pos_u.in_h(a);
 #pragma unroll
     for (int i = 0; i < G_PER; ++i) {
       const int iy = iy0 + (g_pos[i] >> 16), ix = ix0 + ((g_pos[i] >> 8) & 0xff);
-      const bool ok = g_pos[i] >= 0 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)iwn;
+      const bool ok = g_pos[i] >= 0 && (unsigned)iy < (unsigned)ihn && (unsigned)ix < (unsigned)iwn;
       goff[i] = ok ? (iy * iwn + ix) * Cs + (g_pos[i] & 0xff) : -1;
     }
   };
@@ -331,7 +338,7 @@ __global__ void __launch_bounds__(256, LB) dwpw_kernel(const DwPwArgs a) {
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
   const long wstride = (long)c.NTtot * 64;
   const int KK = nch * C8S;
-  UnitPos<RAG> b_pos, m_pos;
+  UnitPos<RAG, TH> b_pos, m_pos;
   b_pos.init(u0, cblocks, a);
   m_pos = b_pos;
   int b_units = nunits, b_step = 0;
@@ -384,7 +391,7 @@ __global__ void __launch_bounds__(256, LB) dwpw_kernel(const DwPwArgs a) {
     const int nt0 = (m_pos.cb * WC + wc) * NT;
     const int oy = m_pos.ty * TH + pix_y, ox = m_pos.tx * TW + pix_x;
     const int own = m_pos.out_w(a);
-    const bool inside = oy < c.OH && ox < own;
+    const bool inside = oy < m_pos.out_h(a) && ox < own;
     const int r0 = nt0 * 32 + 4 * h;
     const float* sp = s_par + r0;
     float* obase = c.out + (m_pos.out_pix(a) + (long)oy * own + ox) * c.Cs_out + r0;
@@ -648,8 +655,8 @@ bool launch_one(const DwPwArgs& a0, hipStream_t s, bool query) {
   a.tiles_x = (a.c.OW + G_::TW - 1) / G_::TW;
   a.tiles_y = (a.c.OH + G_::TH - 1) / G_::TH;
   const unsigned cblocks = (unsigned)a.c.NTtot / (NT * G_::WC);
-  static_assert(G_::TW == 16, "DwPwArgs::rtiles counts 16-pixel tile columns");
-  const long nunits = (a.rtiles ? (long)a.rtiles_total : (long)a.c.N * a.tiles_x) * a.tiles_y * cblocks;
+  static_assert(G_::TW == 16, "DwPwArgs::rtiles counts tiles of 16 pixel columns");
+  const long nunits = (a.rtiles ? (long)a.rtiles_total : (long)a.c.N * a.tiles_x * a.tiles_y) * cblocks;
   if (nunits <= 0 || nunits > 0x7fffffffL) return false;
   a.nunits = (unsigned)nunits;
   // Units per workgroup: enough (unit, chunk) items for the pipeline to run in steady state, few enough that the grid
@@ -691,13 +698,16 @@ bool lab_from_epilogue(const Epilogue& ep, LabEp& out) {
 // The instantiated shapes (everything else stays an unfused pair): K, strides, chunk width, workgroup shape
 // (thin: 4 waves = 4 pixel groups of an 8x16 tile, all <= 4 column tiles per wave; wide: 2 pixel groups of a 4x16
 // tile x 2 column groups), column tiles per wave.  `query` only answers whether the pair is on this path.
-bool launch_dwpw(const DwPwArgs& a, hipStream_t s, bool query) {
+// the instance table: launches, answers the bind-time query, or (rows_only) just names the pixel-tile height
+static int dwpw_dispatch(const DwPwArgs& a, hipStream_t s, bool query, bool rows_only) {
   const int K = a.K, SH = a.SH, SW = a.SW, Cs = a.c.Cs_in, tiles = a.c.NTtot;
-  if (!a.pw_ep.act || !a.dw_ep.act) return false;  // the pairs on the hot path: full chain on both sides
+  if (!a.pw_ep.act || !a.dw_ep.act) return 0;  // the pairs on the hot path: full chain on both sides
 #define OCR_DWPW_CASE(K_, SH_, SW_, CK_, WIDE_, NT_, GD_, TD_, LB_, COND)                                  \
-  if (K == K_ && SH == SH_ && SW == SW_ && Cs % CK_ == 0 && tiles % (NT_ * (WIDE_ ? 2 : 1)) == 0 && (COND)) \
-    return a.rtiles ? launch_one<K_, SH_, SW_, CK_, WIDE_, NT_, true, GD_, TD_, LB_, true>(a, s, query)                 \
-                    : launch_one<K_, SH_, SW_, CK_, WIDE_, NT_, true, GD_, TD_, LB_, false>(a, s, query);
+  if (K == K_ && SH == SH_ && SW == SW_ && Cs % CK_ == 0 && tiles % (NT_ * (WIDE_ ? 2 : 1)) == 0 && (COND)) { \
+    if (rows_only) return DwPwGeom<K_, SH_, SW_, CK_, WIDE_>::TH;                                                \
+    return (a.rtiles ? launch_one<K_, SH_, SW_, CK_, WIDE_, NT_, true, GD_, TD_, LB_, true>(a, s, query)                 \
+                     : launch_one<K_, SH_, SW_, CK_, WIDE_, NT_, true, GD_, TD_, LB_, false>(a, s, query)) ? 1 : 0;      \
+  }
   // TD = how many tap steps ahead the LDS reads run, LB = workgroups per CU the register budget is cut for (3: 168
   // registers, 2: 256): per shape, whichever measured faster (tools/micro/dwpw_probe) - a third wave per SIMD where the
   // kernel fits without spilling, deeper read-ahead where it does not.
@@ -718,7 +728,9 @@ bool launch_dwpw(const DwPwArgs& a, hipStream_t s, bool query) {
   OCR_DWPW_CASE(5, 1, 1, 16, true, 4, 1, 1, 3, tiles == 8)
   OCR_DWPW_CASE(5, 1, 1, 32, true, 3, 1, 2, 2, tiles == 6 || tiles == 12)
 #undef OCR_DWPW_CASE
-  return false;
+  return 0;
 }
+bool launch_dwpw(const DwPwArgs& a, hipStream_t s, bool query) { return dwpw_dispatch(a, s, query, false) != 0; }
+int dwpw_tile_rows(const DwPwArgs& a) { return dwpw_dispatch(a, nullptr, true, true); }
 
 }  // namespace ocr

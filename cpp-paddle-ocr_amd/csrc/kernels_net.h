@@ -20,9 +20,19 @@ enum : int { OUT_C8I = 0, OUT_PLAIN = 1, OUT_DECONV = 2, OUT_HEAD = 3 };
 // CTC head) see one row axis of H * cw[N] pixels and need nothing else; spatial ops take the line's own width for
 // their zero padding, SE pools and attention their own counts.  Every line's arithmetic is what a launch of that
 // line alone would compute: results do not depend on what else is in the batch.
+//
+// The same for the detector on MIXED IMAGE SIZES (round 3: `h != null`): sample n is an image of its own height and width.
+// Detector inputs are multiples of 32 (ResizeImgType0) and every level of its network is an exact power-of-two scaling of
+// the input, so ONE set of tables at input resolution serves all levels: at a level `shift` image n is
+// (h[n] >> shift) x (w[n] >> shift) and starts at pixel cw[n] >> 2*shift; cw = prefix sums of h*w, ch = prefix sums of h
+// (rows before the image: the row-sum buffers of the SE pools are [rows][Cs]).  w and h carry one entry past N (the tile
+// walks step onto "image N" after their last unit).
 struct RagLevel {
-  const int* w = nullptr;   // [N]   line widths at this level (device memory); null = uniform batch
-  const int* cw = nullptr;  // [N+1] prefix sums of w
+  const int* w = nullptr;   // [N]   lines: widths at this level.  images: widths at input resolution.  null = uniform batch
+  const int* cw = nullptr;  // [N+1] lines: prefix sums of w.      images: prefix sums of h * w at input resolution
+  const int* h = nullptr;   // images only: heights at input resolution (null: lines of one height, the launch's H)
+  const int* ch = nullptr;  // images only: [N+1] prefix sums of h at input resolution
+  int shift = 0;            // images only: this level = input resolution >> shift
 };
 
 struct ConvArgs {
@@ -49,8 +59,11 @@ struct ConvArgs {
   // one rounding, and this conv then read the product): [N][Cs_in] physical channel order, null = none
   const float* gate;
   int gate_hw;  // pixels per image (row m belongs to image m / gate_hw)
-  // ragged batch (rin.w != null): N lines, in.H rows each, widths rin.w[n] -> rout.w[n] (H / OH are uniform)
+  // ragged batch (rin.w != null): N samples - lines of in.H rows each and their own widths, or images of their own sizes
   RagLevel rin, rout;
+  // 3x3 tile kernels on a ragged batch of images: [N+1] prefix sums of the images' 8x16-pixel tile counts
+  const int* rtiles = nullptr;
+  int rtiles_total = 0;
 };
 // false: the combination (gated input / multi-tap conv with a plain or deconv output) is not instantiated
 bool launch_conv_mfma(const ConvArgs& a, const Epilogue& ep, int nt, hipStream_t s);
@@ -88,8 +101,8 @@ struct DwArgs {
   // left to right, [N*OH][Cs] (what gap_rows_kernel computes from the tensor in a second full read); a thread then
   // owns whole rows (all strips of its band, in x order) instead of one patch
   float* rowsum = nullptr;
-  RagLevel rin, rout;          // ragged batch: W / OW per line
-  const int* rwork = nullptr;  // ragged, no rowsum: [N+1] prefix sums of the lines' strip counts ceil(OW_n / TO) for the launcher's TO
+  RagLevel rin, rout;          // ragged batch: sizes per sample
+  const int* rwork = nullptr;  // ragged: [N+1] prefix sums of the samples' work items - bands (rowsum) or bands x strips of the launcher's patch (dw_patch_to / dw_patch_r)
   int rwork_total = 0;         // rwork[N] (host copy: the launcher sizes the grid with it)
 };
 void launch_dw(const DwArgs& a, const Epilogue& ep, hipStream_t s);
@@ -115,7 +128,8 @@ struct DwPwArgs {
   int tiles_x, tiles_y;  // filled by the launcher
   unsigned nunits;       // work units = pixel tiles x column blocks (filled by the launcher)
   unsigned upw;          // units per workgroup (filled by the launcher)
-  // ragged batch: line widths in / out and [N+1] prefix sums of the lines' tile-column counts ceil(OW_n / 16)
+  // ragged batch: sample sizes in / out and [N+1] prefix sums of the samples' tile counts ceil(OH_n / TH) * ceil(OW_n / 16)
+  // for the instance's TH (dwpw_tile_rows)
   RagLevel rin, rout;
   const int* rtiles = nullptr;
   int rtiles_total = 0;  // rtiles[N] (host copy: the launcher sizes the grid with it)
@@ -124,11 +138,15 @@ struct DwPwArgs {
 bool lab_from_epilogue(const Epilogue& ep, LabEp& out);
 // false: the shape is not instantiated (the caller launches the unfused pair).  query = true only asks.
 bool launch_dwpw(const DwPwArgs& a, hipStream_t s, bool query = false);
+// rows of the pixel tile (16 columns wide) of the instance that takes this shape; 0: the shape is not on the fused path
+int dwpw_tile_rows(const DwPwArgs& a);
+int dw_patch_r(int OH);  // output rows per thread the depthwise launcher will pick (ragged batch: OH = the lowest sample)
 
 // rag (ragged batch of N lines): the per-image stages (channel gate) find their line from the row index
 void launch_ew(const float* in, float* out, long M, int H, int W, int Cs, const Epilogue& ep, hipStream_t s, int N = 0,
                RagLevel rag = RagLevel());
-void launch_gap(const float* in, float* part, float* out, int N, int H, int W, int Cs, hipStream_t s, RagLevel rag = RagLevel());
+void launch_gap(const float* in, float* part, float* out, int N, int H, int W, int Cs, hipStream_t s, RagLevel rag = RagLevel(),
+                long rows = 0);  // rows: total rows of the batch (0: N * H)
 
 struct SeArgs {
   const float* in;  // [N][Cs]
@@ -145,6 +163,8 @@ struct ConcatArgs {
   long M;
   int H, W, Cs, nsrc;
   int coff[4], scs[4], up[4];
+  RagLevel rout;  // ragged batch of images: the output's level; source j lives log2(up[j]) levels coarser
+  int N = 0;
 };
 void launch_concat(const ConcatArgs& a, hipStream_t s);
 
@@ -198,6 +218,7 @@ struct DbHeadArgs {
   int N, H, W, Cs;
   float bias2;
   int ithresh;
+  RagLevel rin;       // ragged batch of images: the input's level (the map is two levels finer)
 };
 bool launch_db_head(const DbHeadArgs& a, int C, hipStream_t s);  // false: C is not on this path (24 only)
 

@@ -64,7 +64,7 @@ __global__ void __launch_bounds__(256, (NT <= 3 ? 4 : 3)) conv_mfma_kernel(const
   const float* grow = zpage;
   if constexpr (GATE) {
     if (mvalid) {
-      const int gn = a.rin.w ? rag_line_near(a.rin.cw, a.N, m, a.H, (long)(lb / groups) * 128) : (int)((unsigned)m / (unsigned)a.gate_hw);
+      const int gn = a.rin.w ? rag_sample_of_pixel(a.rin, a.N, a.H, m, (long)(lb / groups) * 128) : (int)((unsigned)m / (unsigned)a.gate_hw);
       grow = a.gate + (long)gn * a.Cs_in + 4 * h;
     }
   }
@@ -72,13 +72,14 @@ __global__ void __launch_bounds__(256, (NT <= 3 ? 4 : 3)) conv_mfma_kernel(const
   // ---- general: incremental (tap, c8) walk with selects
   int p_c8 = 0, p_ky = 0, p_kx = 0;
   int n = 0, y = 0, x = 0;
-  int lw = a.W;  // the lane's line width (ragged batch: its own)
+  int lw = a.W, lh = a.H;  // width / height of the lane's sample (ragged batch: its own)
   const float* lane_base = nullptr;
   long tap_off = 0;  // + c8*8, elements
   if constexpr (!TAP1) {
     if (a.rin.w) {  // stride-1 "same" convs only (host): the output level is the input level
       rag_decompose(a.rin, a.N, a.H, mvalid ? m : a.M - 1, (long)(lb / groups) * 128, n, y, x, lw);
-      lane_base = a.in + 4 * h + ((long)a.rin.cw[n] * a.H + (long)(y - a.PH) * lw + (x - a.PW)) * a.Cs_in;
+      lh = rag_h(a.rin, n, a.H);
+      lane_base = a.in + 4 * h + (rag_pix0(a.rin, n, a.H) + (long)(y - a.PH) * lw + (x - a.PW)) * a.Cs_in;
     } else {
       decompose(mvalid ? m : a.M - 1, a.OH * a.OW, a.OW, n, y, x);
       // this lane's pixel at tap (0,0), channel 4h; a tap adds the uniform offset (ky*W + kx)*Cs_in
@@ -95,7 +96,7 @@ __global__ void __launch_bounds__(256, (NT <= 3 ? 4 : 3)) conv_mfma_kernel(const
 #endif
     } else {
       const int iy = y - a.PH + p_ky, ix = x - a.PW + p_kx;
-      const bool valid = mvalid && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)lw;
+      const bool valid = mvalid && (unsigned)iy < (unsigned)lh && (unsigned)ix < (unsigned)lw;
       // padding / out-of-range rows read a zero page: no select ever touches a loaded value
       const float* src = valid ? lane_base + tap_off : zpage;
       av = *(const float4*)src;
@@ -221,22 +222,23 @@ __global__ void __launch_bounds__(256, 2) conv_lds_kernel(const ConvArgs a, cons
   const long m0 = m_base + wave * 32;
 
   // per-row addressing state of the 128 staged rows, computed once into LDS (a per-thread array of
-  // it ends up in scratch): {first pixel of the row's image or -1, the image's width, y, x}
+  // it ends up in scratch): {first pixel of the row's image or -1, the image's width | height << 16, y, x}
   __shared__ int4 rowinfo[128];
   if (tid < 128) {
     const long m = m_base + tid;
-    int4 ri = make_int4(-1, 1, 0, 0);
+    int4 ri = make_int4(-1, 1 | (1 << 16), 0, 0);
     if (m < a.M) {
-      int n, y, x, w = a.W;
+      int n, y, x, w = a.W, hh = a.H;
       long pix0;
       if (a.rin.w) {  // ragged batch (stride-1 "same" convs only: output level = input level)
         rag_decompose(a.rin, a.N, a.H, m, m_base, n, y, x, w);
-        pix0 = (long)a.rin.cw[n] * a.H;
+        hh = rag_h(a.rin, n, a.H);
+        pix0 = rag_pix0(a.rin, n, a.H);
       } else {
         decompose(m, hw, a.OW, n, y, x);
         pix0 = (long)n * a.H * a.W;
       }
-      ri = make_int4((int)pix0, w, y, x);  // (pixel counts of a launch stay below 2^31: host check)
+      ri = make_int4((int)pix0, w | (hh << 16), y, x);  // (pixel counts of a launch stay below 2^31, sides below 2^15: host check)
     }
     rowinfo[tid] = ri;
   }
@@ -268,8 +270,9 @@ __global__ void __launch_bounds__(256, 2) conv_lds_kernel(const ConvArgs a, cons
         const int4 ri = rowinfo[row];
         const int iy = ri.z - a.PH + ky, ix = ri.w - a.PW + kx;
         // branch-free validity and address (no short-circuit control flow around the load)
-        const bool v = (ri.x >= 0) & (iy >= 0) & (iy < a.H) & (ix >= 0) & (ix < ri.y);
-        const long off = ((long)ri.x + (long)(v ? iy : 0) * ri.y + (v ? ix : 0)) * a.Cs_in + cc * BK + seg * 4;
+        const int rw = ri.y & 0xffff, rh = ri.y >> 16;
+        const bool v = (ri.x >= 0) & (iy >= 0) & (iy < rh) & (ix >= 0) & (ix < rw);
+        const long off = ((long)ri.x + (long)(v ? iy : 0) * rw + (v ? ix : 0)) * a.Cs_in + cc * BK + seg * 4;
         const float* src = v ? a.in + off : a.zeros;
         return *(const float4*)src;
       };
@@ -467,12 +470,26 @@ __global__ void __launch_bounds__(TH * 32, 2) conv3x3_c24_kernel(const ConvArgs 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const unsigned lb = xcd_swizzle(blockIdx.x, gridDim.x);
   unsigned tile = lb;
-  const int tx = (int)(tile % tiles_x);
-  tile /= tiles_x;
-  const int ty = (int)(tile % tiles_y), n = (int)(tile / tiles_y);
+  int tx, ty, n;
+  int IH = a.H, IW = a.W;  // the tile's image (ragged batch of images: its own size)
+  long pix0;
+  if (a.rtiles) {
+    n = rag_line(a.rtiles, a.N, tile, 1);
+    IH = rag_h(a.rin, n, a.H); IW = rag_w(a.rin, n);
+    pix0 = rag_pix0(a.rin, n, a.H);
+    const unsigned t = tile - (unsigned)a.rtiles[n], txn = (unsigned)(IW + TW - 1) / TW;
+    ty = (int)(t / txn);
+    tx = (int)(t - (unsigned)ty * txn);
+  } else {
+    tx = (int)(tile % tiles_x);
+    tile /= tiles_x;
+    ty = (int)(tile % tiles_y);
+    n = (int)(tile / tiles_y);
+    pix0 = (long)n * a.H * a.W;
+  }
   const int y0 = ty * TH, x0 = tx * TW;
   {  // fill: (RH*RW) pixels x Q pieces, consecutive threads take consecutive pieces of a pixel
-    const float* img = a.in + (long)n * a.H * a.W * CS;
+    const float* img = a.in + pix0 * CS;
     constexpr int PIECES = RH * RW * Q, PER_THR = (PIECES + NTHR - 1) / NTHR;
     float4 r[PER_THR];
 #pragma unroll
@@ -481,8 +498,8 @@ __global__ void __launch_bounds__(TH * 32, 2) conv3x3_c24_kernel(const ConvArgs 
       const int px = idx / Q, q = idx - px * Q;
       const int py = px / RW, pxx = px - py * RW;
       const int iy = y0 - 1 + py, ix = x0 - 1 + pxx;
-      const bool v = idx < PIECES && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-      r[i] = v ? *(const float4*)(img + ((long)iy * a.W + ix) * CS + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const bool v = idx < PIECES && iy >= 0 && iy < IH && ix >= 0 && ix < IW;
+      r[i] = v ? *(const float4*)(img + ((long)iy * IW + ix) * CS + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
     for (int i = 0; i < PER_THR; ++i) {
@@ -559,8 +576,8 @@ __global__ void __launch_bounds__(TH * 32, 2) conv3x3_c24_kernel(const ConvArgs 
     }
   }
   const int oy = y0 + ly, ox = x0 + lx;
-  if (oy >= a.OH || ox >= a.OW) return;
-  const long m = ((long)n * a.OH + oy) * a.OW + ox;
+  if (oy >= IH || ox >= IW) return;  // (stride 1, pad 1: the output has the input's size)
+  const long m = pix0 + (long)oy * IW + ox;
 #pragma unroll
   for (int g = 0; g < 3; ++g) {
     const int pc = chh * 12 + g * 4;
@@ -591,7 +608,9 @@ bool launch_conv3x3_c24(const ConvArgs& a, const Epilogue& ep, const float* wimg
   for (int i = 0; i < ep.n; ++i) if (ep.st[i].kind == EP_ADDUP) return false;
   const int tiles_x = (a.OW + 15) / 16;   // (4-row tiles, 3 workgroups per CU: 64 instead of 90 TFLOP/s - measured, removed)
   const int tiles_y = (a.OH + 7) / 8;
-  const dim3 grid((unsigned)((long)a.N * tiles_y * tiles_x));
+  if (a.rin.w && !a.rtiles) return false;  // a ragged batch needs the tile table (images) - lines never come here
+  for (int i = 0; i < ep.n; ++i) if (a.rtiles && ep.st[i].kind == EP_MULC) return false;
+  const dim3 grid((unsigned)(a.rtiles ? (long)a.rtiles_total : (long)a.N * tiles_y * tiles_x));
   const unsigned lds = 10 * 18 * (96 + 4) * sizeof(float);  // 72 000 B: two workgroups per CU
   static LdsAttrMemo attr_state;
   if (!raise_dynamic_lds((const void*)conv3x3_c24_kernel<12, 8>, (int)lds, attr_state)) return false;
@@ -603,7 +622,7 @@ bool launch_conv3x3_c24(const ConvArgs& a, const Epilogue& ep, const float* wimg
 bool launch_conv3x3_tile(const ConvArgs& a, const Epilogue& ep, int nt, hipStream_t s) {
   if (!rt_options().conv_tile) return false;
   if (!(a.KH == 3 && a.KW == 3 && a.PH == 1 && a.PW == 1 && a.OH == a.H && a.OW == a.W && a.out_mode == OUT_C8I)) return false;
-  if (a.Cs_in != 96 || nt != 1) return false;
+  if (a.Cs_in != 96 || nt != 1 || a.rin.w) return false;  // (ragged batches: the chunked kernel decodes per row)
   const int tiles_x = (a.OW + 15) / 16, tiles_y = (a.OH + 7) / 8;
   const dim3 grid((unsigned)((long)a.N * tiles_y * tiles_x * (a.NTtot / nt)));
   const unsigned lds = 10 * 18 * (96 + 4) * sizeof(float);  // 72 000 B: two workgroups per CU
@@ -640,13 +659,14 @@ __global__ void __launch_bounds__(256) stem_conv_kernel(const StemArgs a, const 
   const long m = m_wg + threadIdx.x;
   if (m >= a.M) return;
   int n, y, x;
-  int iw = a.W;              // input width of the pixel's image (ragged batch: the line's own)
+  int iw = a.W, ih = a.H;    // input size of the pixel's image (ragged batch: the sample's own)
   long ipix0;                // first input pixel of that image
   if (a.rout.w) {
     int ow;
     rag_decompose(a.rout, a.N, a.OH, m, m_wg, n, y, x, ow);
-    iw = a.rin.w[n];
-    ipix0 = (long)a.rin.cw[n] * a.H;
+    iw = rag_w(a.rin, n);
+    ih = rag_h(a.rin, n, a.H);
+    ipix0 = rag_pix0(a.rin, n, a.H);
   } else {
     decompose(m, a.OH * a.OW, a.OW, n, y, x);
     ipix0 = (long)n * a.H * a.W;
@@ -659,7 +679,7 @@ __global__ void __launch_bounds__(256) stem_conv_kernel(const StemArgs a, const 
   struct P3 { float c[3]; };
   auto tap_load = [&](int ky, int kx, P3& px, unsigned& keep) {
     const int iy = y * a.SH - a.PH + ky, ix = x * a.SW - a.PW + kx;
-    const bool v = iy >= 0 && iy < a.H && ix >= 0 && ix < iw;
+    const bool v = iy >= 0 && iy < ih && ix >= 0 && ix < iw;
     const float* src = a.in + (ipix0 + (long)(v ? iy : 0) * iw + (v ? ix : 0)) * 3;
     __builtin_memcpy(&px, __builtin_assume_aligned(src, 4), 12);
     keep = v ? 0xffffffffu : 0u;
@@ -730,37 +750,37 @@ __global__ void __launch_bounds__(256, 2) dw_conv_kernel(const DwArgs a, const E
   const long t = t_wg + threadIdx.x;
   const int c4n = a.Cs >> 2;
   const int bands = (a.OH + R - 1) / R;
-  constexpr bool rag = RAG;  // ragged batch (own instantiation: the uniform one keeps its widths in scalar registers)
+  constexpr bool rag = RAG;  // ragged batch (own instantiation: the uniform one keeps its sizes in scalar registers)
   // ROWSUM: a thread owns a band (R output rows) of one image x 4 channels and walks its strips left to right, so the
   // pool's row sums (x ascending from 0, the contract's order) accumulate in registers beside the conv
-  // ragged batch: patches are counted line by line (a.rwork: prefix sums of the lines' strip counts)
-  const long npatch = ROWSUM ? (long)a.N * bands : (rag ? (long)a.rwork_total * bands : (long)a.N * bands * ((a.OW + TO - 1) / TO));
+  // ragged batch: work items are counted sample by sample (a.rwork: prefix sums of the samples' bands (ROWSUM) or
+  // bands x strips)
+  const long npatch = rag ? (long)a.rwork_total : (ROWSUM ? (long)a.N * bands : (long)a.N * bands * ((a.OW + TO - 1) / TO));
   if (t >= npatch * c4n) return;
   const long sidx = t / c4n;
   const int pc = (int)(t - sidx * c4n) * 4;
   int n, y0, sx_first, sx_end;
-  int IW = a.W, OW = a.OW;  // widths of the patch's image (ragged batch: the line's own)
-  long ipix0, opix0;        // its first input / output pixel
-  if constexpr (ROWSUM || !rag) {
-    const int strips = rag ? 1 : (a.OW + TO - 1) / TO;
+  int IW = a.W, OW = a.OW, IH = a.H, OHn = a.OH;  // sizes of the patch's image (ragged batch: the sample's own)
+  long ipix0, opix0, orow0;                        // its first input / output pixel, its first row of the row-sum buffer
+  if constexpr (!rag) {
+    const int strips = (a.OW + TO - 1) / TO;
     sx_first = ROWSUM ? 0 : (int)(sidx % strips);
     const long nb = ROWSUM ? sidx : sidx / strips;
     y0 = (int)(nb % bands) * R;
     n = (int)(nb / bands);
-    if constexpr (rag) { IW = a.rin.w[n]; OW = a.rout.w[n]; }
-    sx_end = ROWSUM ? (OW + TO - 1) / TO : sx_first + 1;
+    sx_end = ROWSUM ? strips : sx_first + 1;
+    ipix0 = (long)n * a.H * a.W; opix0 = (long)n * a.OH * a.OW; orow0 = (long)n * a.OH;
   } else {
-    n = rag_line_near(a.rwork, a.N, sidx, bands, t_wg / c4n);
-    IW = a.rin.w[n]; OW = a.rout.w[n];
+    n = rag_line_near(a.rwork, a.N, sidx, 1, t_wg / c4n);
+    IW = rag_w(a.rin, n); OW = rag_w(a.rout, n); IH = rag_h(a.rin, n, a.H); OHn = rag_h(a.rout, n, a.OH);
     const int strips = (OW + TO - 1) / TO;
-    const int rem = (int)(sidx - (long)a.rwork[n] * bands);
-    const int band = rem / strips;
+    const int rem = (int)(sidx - a.rwork[n]);
+    const int band = ROWSUM ? rem : rem / strips;
     y0 = band * R;
-    sx_first = rem - band * strips;
-    sx_end = sx_first + 1;
+    sx_first = ROWSUM ? 0 : rem - band * strips;
+    sx_end = ROWSUM ? strips : sx_first + 1;
+    ipix0 = rag_pix0(a.rin, n, a.H); opix0 = rag_pix0(a.rout, n, a.OH); orow0 = rag_row0(a.rout, n, a.OH);
   }
-  if constexpr (rag) { ipix0 = (long)a.rin.cw[n] * a.H; opix0 = (long)a.rout.cw[n] * a.OH; }
-  else { ipix0 = (long)n * a.H * a.W; opix0 = (long)n * a.OH * a.OW; }
   struct F4 { ocr_f2 lo, hi; };
   F4 rsum[R];
 #pragma unroll
@@ -783,7 +803,7 @@ __global__ void __launch_bounds__(256, 2) dw_conv_kernel(const DwArgs a, const E
   // image are zero rows; the row after the last one is loaded (clamped) and never used.
   auto load_row = [&](float4 (&in)[NIN], int j) {
     const int iy = iyb + j;
-    const bool rv = j < nrows && iy >= 0 && iy < a.H;
+    const bool rv = j < nrows && iy >= 0 && iy < IH;
     const float* row = a.in + (ipix0 + (long)(rv ? iy : 0) * IW) * a.Cs + pc;
 #pragma unroll
     for (int q = 0; q < NIN; ++q) {
@@ -882,7 +902,7 @@ __global__ void __launch_bounds__(256, 2) dw_conv_kernel(const DwArgs a, const E
       } break;
       case EP_ADDT:
         OCR_DW_SWEEP({
-          if (y0 + r < a.OH && x0 + o < OW) {
+          if (y0 + r < OHn && x0 + o < OW) {
             const float4 g = *(const float4*)(st.v0 + obase + r * orow + (long)o * a.Cs);
             ocr_f2 glo;
             ocr_f2 ghi;
@@ -899,7 +919,7 @@ __global__ void __launch_bounds__(256, 2) dw_conv_kernel(const DwArgs a, const E
   for (int r = 0; r < R; ++r)
 #pragma unroll
     for (int o = 0; o < TO; ++o)
-      if (y0 + r < a.OH && x0 + o < OW) {
+      if (y0 + r < OHn && x0 + o < OW) {
         *(float4*)(a.out + obase + r * orow + (long)o * a.Cs) = make_float4(acc[r][o].lo.x, acc[r][o].lo.y, acc[r][o].hi.x, acc[r][o].hi.y);
         if constexpr (ROWSUM) { rsum[r].lo = rsum[r].lo + acc[r][o].lo; rsum[r].hi = rsum[r].hi + acc[r][o].hi; }  // s = s + v, x ascending
       }
@@ -907,8 +927,8 @@ __global__ void __launch_bounds__(256, 2) dw_conv_kernel(const DwArgs a, const E
   if constexpr (ROWSUM) {
 #pragma unroll
     for (int r = 0; r < R; ++r)
-      if (y0 + r < a.OH)
-        *(float4*)(a.rowsum + ((long)n * a.OH + y0 + r) * a.Cs + pc) = make_float4(rsum[r].lo.x, rsum[r].lo.y, rsum[r].hi.x, rsum[r].hi.y);
+      if (y0 + r < OHn)
+        *(float4*)(a.rowsum + (orow0 + y0 + r) * a.Cs + pc) = make_float4(rsum[r].lo.x, rsum[r].lo.y, rsum[r].hi.x, rsum[r].hi.y);
   }
 }
 
@@ -916,7 +936,7 @@ template <int TO, int R, bool RAG>
 static void launch_dw_patch(const DwArgs& a, const Epilogue& ep, hipStream_t s) {
   const unsigned lds = (unsigned)(a.K * a.K * a.Cs * sizeof(float));  // <= 48 KB for 5x5 x 480 channels
   if (a.rowsum) {  // a thread per band: all strips of its rows
-    const long bands = (long)a.N * ((a.OH + R - 1) / R) * (a.Cs >> 2);
+    const long bands = (RAG ? (long)a.rwork_total : (long)a.N * ((a.OH + R - 1) / R)) * (a.Cs >> 2);
     dim3 g((unsigned)((bands + 255) / 256));
     if (a.K == 3 && a.SW == 1) hipLaunchKernelGGL((dw_conv_kernel<3, 1, TO, R, true, RAG>), g, dim3(256), lds, s, a, ep);
     else if (a.K == 3) hipLaunchKernelGGL((dw_conv_kernel<3, 2, TO, R, true, RAG>), g, dim3(256), lds, s, a, ep);
@@ -924,7 +944,7 @@ static void launch_dw_patch(const DwArgs& a, const Epilogue& ep, hipStream_t s) 
     else hipLaunchKernelGGL((dw_conv_kernel<5, 2, TO, R, true, RAG>), g, dim3(256), lds, s, a, ep);
     return;
   }
-  const long total = (RAG ? (long)a.rwork_total : (long)a.N * ((a.OW + TO - 1) / TO)) * ((a.OH + R - 1) / R) * (a.Cs >> 2);
+  const long total = (RAG ? (long)a.rwork_total : (long)a.N * ((a.OW + TO - 1) / TO) * ((a.OH + R - 1) / R)) * (a.Cs >> 2);
   dim3 grid((unsigned)((total + 255) / 256));
   if (a.K == 3 && a.SW == 1) hipLaunchKernelGGL((dw_conv_kernel<3, 1, TO, R, false, RAG>), grid, dim3(256), lds, s, a, ep);
   else if (a.K == 3) hipLaunchKernelGGL((dw_conv_kernel<3, 2, TO, R, false, RAG>), grid, dim3(256), lds, s, a, ep);
@@ -939,10 +959,14 @@ int dw_patch_to(int OW, int SW) {
   if (OW < 8 || (SW == 2 && !env)) to = 4;  // stride 2 needs 2*TO+K-2 pixels per row buffer: 8 wide does not fit the registers
   return to == 8 ? 8 : 4;
 }
-void launch_dw(const DwArgs& a, const Epilogue& ep, hipStream_t s) {
+int dw_patch_r(int OH) {
   int r = rt_options().dw_patch_r > 0 ? rt_options().dw_patch_r : 2;
+  if (OH < 2) r = 1;
+  return r == 2 ? 2 : 1;
+}
+void launch_dw(const DwArgs& a, const Epilogue& ep, hipStream_t s) {
+  const int r = dw_patch_r(a.OH);
   const int to = dw_patch_to(a.OW, a.SW);
-  if (a.OH < 2) r = 1;
   if (a.rout.w) {  // ragged batch (the recognizer)
     if (to == 8 && r == 2) launch_dw_patch<8, 2, true>(a, ep, s);
     else if (to == 8) launch_dw_patch<8, 1, true>(a, ep, s);
@@ -967,14 +991,24 @@ __global__ void __launch_bounds__(256) ew_kernel(const float* __restrict__ in, f
   const long m = t / c4n;
   const int pc = (int)(t - m * c4n) * 4;
   int n, y, x;
-  if (rag.w) {  // ragged batch: the line of this pixel (per-line stages: the SE gate); no upsampled operands (host)
+  long up_base = -1;
+  int up_w = 0;
+  if (rag.w) {  // ragged batch: the sample of this pixel (per-sample stages: the SE gate)
     int w;
     rag_decompose(rag, N, H, m, (long)blockIdx.x * 256 / c4n, n, y, x, w);
+    if (rag.h) {  // images: an upsampled operand (FPN top-down add) lives on the level log2(up) coarser
+      for (int s = 0; s < ep.n; ++s)
+        if (ep.st[s].kind == EP_ADDUP) {
+          const int lu = 31 - __clz(ep.st[s].a0);
+          up_base = (long)(rag.cw[n] >> (2 * (rag.shift + lu)));
+          up_w = rag.w[n] >> (rag.shift + lu);
+        }
+    }
   } else
   decompose(m, H * W, W, n, y, x);
   const long idx = m * Cs + pc;
   float4 v = *(const float4*)(in + idx);
-  v = apply_epilogue4(ep, v, pc, n, y, x, idx, Cs);
+  v = apply_epilogue4(ep, v, pc, n, y, x, idx, Cs, up_base, up_w);
   *(float4*)(out + idx) = v;
 }
 
@@ -987,18 +1021,19 @@ void launch_ew(const float* in, float* out, long M, int H, int W, int Cs, const 
 // Global average pool in the contract's order: row-sequential sums, then column-sequential.
 // =====================================================================================
 __global__ void __launch_bounds__(256) gap_rows_kernel(const float* __restrict__ in, float* __restrict__ part, int N,
-                                                       int H, int W, int Cs, const RagLevel rag) {
+                                                       int H, int W, int Cs, const RagLevel rag, long rows) {
   // one thread = 4 physical channels of one image row: four independent sequential sums, 16-byte loads
   const int c4n = Cs >> 2;
   const long t = (long)blockIdx.x * 256 + threadIdx.x;
-  if (t >= (long)N * H * c4n) return;
+  if (t >= rows * c4n) return;
   const int pc = (int)(t % c4n) * 4;
   const long ny = t / c4n;
   const float* src = in + ny * W * Cs + pc;
-  if (rag.w) {  // ragged batch: row y of line n, the line's own width
-    const int n = (int)(ny / H), y = (int)(ny - (long)n * H);
-    W = rag.w[n];
-    src = in + ((long)rag.cw[n] * H + (long)y * W) * Cs + pc;
+  if (rag.w) {  // ragged batch: row y of sample n, the sample's own width
+    const int n = rag_sample_of_row(rag, N, H, ny, (long)blockIdx.x * 256 / c4n);
+    const int y = (int)(ny - rag_row0(rag, n, H));
+    W = rag_w(rag, n);
+    src = in + (rag_pix0(rag, n, H) + (long)y * W) * Cs + pc;
   }
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   // eight loads in flight, then their eight sequential adds (the sum's order is the contract's: left to right)
@@ -1022,8 +1057,12 @@ __global__ void __launch_bounds__(256) gap_cols_kernel(const float* __restrict__
   const int t = blockIdx.x * 256 + threadIdx.x;
   if (t >= N * Cs) return;
   const int pc = t % Cs, n = t / Cs;
-  if (rag.w) cnt = (float)(H * rag.w[n]);  // ragged batch: the line's own pixel count
   const float* src = part + (long)n * H * Cs + pc;
+  if (rag.w) {  // ragged batch: the sample's own rows and pixel count
+    src = part + rag_row0(rag, n, H) * Cs + pc;
+    H = rag_h(rag, n, H);
+    cnt = (float)(H * rag_w(rag, n));
+  }
   float s = 0.f;
   for (int y = 0; y < H; ++y) s = s + src[(long)y * Cs];
   out[t] = s / cnt;
@@ -1031,9 +1070,10 @@ __global__ void __launch_bounds__(256) gap_cols_kernel(const float* __restrict__
 void launch_gap_cols(const float* part, float* out, int N, int H, int W, int Cs, hipStream_t s, RagLevel rag) {
   hipLaunchKernelGGL(gap_cols_kernel, dim3((unsigned)((N * Cs + 255) / 256)), dim3(256), 0, s, part, out, N, H, Cs, (float)(H * W), rag);
 }
-void launch_gap(const float* in, float* part, float* out, int N, int H, int W, int Cs, hipStream_t s, RagLevel rag) {
-  const long t1 = (long)N * H * (Cs >> 2);
-  hipLaunchKernelGGL(gap_rows_kernel, dim3((unsigned)((t1 + 255) / 256)), dim3(256), 0, s, in, part, N, H, W, Cs, rag);
+void launch_gap(const float* in, float* part, float* out, int N, int H, int W, int Cs, hipStream_t s, RagLevel rag, long rows) {
+  if (rows <= 0) rows = (long)N * H;  // (ragged batch of images: the sum of the images' heights)
+  const long t1 = rows * (Cs >> 2);
+  hipLaunchKernelGGL(gap_rows_kernel, dim3((unsigned)((t1 + 255) / 256)), dim3(256), 0, s, in, part, N, H, W, Cs, rag, rows);
   hipLaunchKernelGGL(gap_cols_kernel, dim3((unsigned)((N * Cs + 255) / 256)), dim3(256), 0, s, part, out, N, H, Cs,
                      (float)(H * W), rag);
 }
@@ -1086,14 +1126,23 @@ __global__ void __launch_bounds__(256) concat_kernel(const ConcatArgs a) {
   const long m = t / c4n;
   const int pc = (int)(t - m * c4n) * 4;
   int n, y, x;
-  decompose(m, a.H * a.W, a.W, n, y, x);
   int j = 0;
 #pragma unroll
   for (int i = 1; i < 4; ++i)
     if (i < a.nsrc && pc >= a.coff[i]) j = i;
   const int up = a.up[j];
-  const int sh = a.H / up, sw = a.W / up;
-  const float4 v = *(const float4*)(a.src[j] + (((long)n * sh + y / up) * sw + x / up) * a.scs[j] + (pc - a.coff[j]));
+  long spix;
+  if (a.rout.h) {  // ragged batch of images: source j lives log2(up) levels coarser than the output
+    int w;
+    rag_decompose(a.rout, a.N, a.H, m, (long)xcd_swizzle(blockIdx.x, gridDim.x) * 256 / c4n, n, y, x, w);
+    const int lu = 31 - __clz(up);
+    spix = (long)(a.rout.cw[n] >> (2 * (a.rout.shift + lu))) + (long)(y / up) * (a.rout.w[n] >> (a.rout.shift + lu)) + x / up;
+  } else {
+    decompose(m, a.H * a.W, a.W, n, y, x);
+    const int sh = a.H / up, sw = a.W / up;
+    spix = ((long)n * sh + y / up) * sw + x / up;
+  }
+  const float4 v = *(const float4*)(a.src[j] + spix * a.scs[j] + (pc - a.coff[j]));
   *(float4*)(a.out + m * a.Cs + pc) = v;
 }
 void launch_concat(const ConcatArgs& a, hipStream_t s) {
@@ -1559,7 +1608,16 @@ __global__ void __launch_bounds__(256) db_head_kernel(const DbHeadArgs a) {
   const long m = (long)blockIdx.x * 256 + threadIdx.x;
   if (m >= a.M) return;
   int n, y, x;
-  decompose(m, a.H * a.W, a.W, n, y, x);
+  long OW = 4L * a.W, opix0;  // width / first pixel of the pixel's probability map
+  if (a.rin.h) {  // ragged batch of images: the map is two levels finer than this tensor
+    int w;
+    rag_decompose(a.rin, a.N, a.H, m, (long)blockIdx.x * 256, n, y, x, w);
+    OW = 4L * w;
+    opix0 = (long)(a.rin.cw[n] >> (2 * (a.rin.shift - 2)));
+  } else {
+    decompose(m, a.H * a.W, a.W, n, y, x);
+    opix0 = (long)n * 16 * a.H * a.W;
+  }
   // the pixel's channels in LOGICAL order (C8I: an octet's evens, then its odds), all loads in flight at once
   const float* src = a.in + m * a.Cs;
   float4 r[C / 4];
@@ -1572,8 +1630,7 @@ __global__ void __launch_bounds__(256) db_head_kernel(const DbHeadArgs a) {
     xl[8 * o] = ev.x; xl[8 * o + 1] = od.x; xl[8 * o + 2] = ev.y; xl[8 * o + 3] = od.y;
     xl[8 * o + 4] = ev.z; xl[8 * o + 5] = od.z; xl[8 * o + 6] = ev.w; xl[8 * o + 7] = od.w;
   }
-  const long OW = 4L * a.W;
-  const long obase = ((long)n * 4 * a.H + 4 * y) * OW + 4 * x;
+  const long obase = opix0 + (long)(4 * y) * OW + 4 * x;
   float pr[4][4];  // [row of the 4x4 block][column]
   // (two adjacent output channels per instruction: each lane of a v_pk_fma_f32 is the same IEEE fma as the scalar one)
 #pragma unroll

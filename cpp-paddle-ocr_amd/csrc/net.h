@@ -78,6 +78,11 @@ class Net {
   // output widths before it fills x); run_ragged binds if needed.
   bool bind_ragged(int H, const int* widths, int N, std::string& err);
   bool run_ragged(const float* x, int H, const int* widths, int N, hipStream_t s, std::string& err);
+  // Ragged batch of IMAGES (the detector on mixed sizes): image n is heights[n] x widths[n] (multiples of 32, as
+  // ResizeImgType0 leaves them); x = the images' [h][w][3] blocks one after the other; the output (and every tensor)
+  // holds the images one after the other likewise.  Production launch list only (keep_all 0 or 2).
+  bool run_ragged_images(const float* x, const int* heights, const int* widths, int N, hipStream_t s, std::string& err);
+  // first pixel of image n in the output tensor of the current ragged-images binding is the prefix sum of h*w
   // line widths of tensor `tid` under the current ragged binding (host copy), e.g. the CTC step counts of the output
   const std::vector<int>& ragged_widths(int tid) const;
   // can this many lines / pixels go into one ragged launch? (32-bit pixel indices, attention working set)
@@ -140,7 +145,7 @@ class Net {
     int n = 0, h = 0, w = 0;
     // ragged batch: the lines' widths per level, the packed tables (per level: w[N], cw[N+1], and the prefix sums of
     // ceil(w / 16), ceil(w / 8), ceil(w / 4), N + 2 entries each) on the host and on the device
-    std::vector<int> widths;
+    std::vector<int> widths, heights;  // heights: a ragged batch of IMAGES (the detector on mixed sizes)
     std::vector<std::vector<int>> level_w;
     std::vector<int> rag_host;
     int* rag_dev = nullptr;
@@ -167,9 +172,9 @@ class Net {
   static constexpr size_t kMaxRaggedBindings = 32;
   size_t max_bindings_ = 512;  // a mixed-size stream revisits sizes: BASELINE configs[2] has ~400 distinct det shapes (OCR_NET_BINDINGS, read at load)
   void invalidate() { cache_.clear(); cur_ = nullptr; }
-  bool bind(int N, int H, int W, std::string& err, const int* widths = nullptr);
+  bool bind(int N, int H, int W, std::string& err, const int* widths = nullptr, const int* heights = nullptr);
   bool run_bound(const float* x, hipStream_t s, std::string& err);
-  static std::vector<int> shape_key(int N, int H, int W, const int* widths);
+  static std::vector<int> shape_key(int N, int H, int W, const int* widths, const int* heights);
   bool build_epilogue(const PlanOp& op, Epilogue& ep, bool conv_path, std::string& err);
   const float* dev_vec(const std::string& key) const;
   float* upload(const std::string& key, const std::vector<float>& v);

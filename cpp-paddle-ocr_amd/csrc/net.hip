@@ -370,13 +370,14 @@ bool Net::build_epilogue(const PlanOp& op, Epilogue& ep, bool conv_path, std::st
 }
 
 // ------------------------------------------------------------------ shape binding
-std::vector<int> Net::shape_key(int N, int H, int W, const int* widths) {
+std::vector<int> Net::shape_key(int N, int H, int W, const int* widths, const int* heights) {
   if (!widths) return {N, H, W};
-  std::vector<int> k = {-1, H};  // ragged: run lengths of the lines' widths, in line order
+  std::vector<int> k = {heights ? -2 : -1, H};  // ragged: run lengths of the samples' sizes, in sample order
   for (int i = 0; i < N;) {
     int j = i;
-    while (j < N && widths[j] == widths[i]) ++j;
+    while (j < N && widths[j] == widths[i] && (!heights || heights[j] == heights[i])) ++j;
     k.push_back(widths[i]);
+    if (heights) k.push_back(heights[i]);
     k.push_back(j - i);
     i = j;
   }
@@ -402,10 +403,11 @@ const std::vector<int>& Net::ragged_widths(int tid) const {
   return cur_->level_w[tensors_[tid].lvl];
 }
 
-bool Net::bind(int N, int H, int W, std::string& err, const int* widths) {
+bool Net::bind(int N, int H, int W, std::string& err, const int* widths, const int* heights) {
   stats_.binds++;
   std::unique_ptr<Binding> B(new Binding());
   const bool rag = widths != nullptr;
+  const bool img = rag && heights != nullptr;  // ragged batch of images (own height and width) instead of lines
   B->n = N; B->h = H; B->w = W;
   B->pool = pool_;
   std::vector<Launch>& launches_ = B->launches;
@@ -446,11 +448,67 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths) {
     T[t].lvl = lvl;
     T[t].pix = (long)h * ltot[lvl];
   };
-  if (rag) {
+  // images: ONE table set at input resolution; a tensor's level is its power-of-two shift against the input
+  std::vector<int>& IH = B->heights;
+  long ipix = 0, irows = 0;   // pixels / rows of the batch at input resolution
+  int ihmax = 0, iwmax = 0, ihmin = 0x7fffffff, iwmin = 0x7fffffff;
+  auto setimg = [&](int t, int shift, int c) {
+    setdims(t, N, ihmax >> shift, iwmax >> shift, c);
+    T[t].lvl = shift;
+    T[t].pix = ipix >> (2 * shift);
+  };
+  if (img) {
+    B->widths.assign(widths, widths + N);
+    IH.assign(heights, heights + N);
+    for (int i = 0; i < N; ++i) {
+      if (widths[i] < 32 || heights[i] < 32 || widths[i] % 32 || heights[i] % 32 || widths[i] > 32767 || heights[i] > 32767) {
+        err = "ragged batch of images: sizes must be multiples of 32 (ResizeImgType0 output)";
+        return false;
+      }
+      ipix += (long)widths[i] * heights[i];
+      irows += heights[i];
+      ihmax = std::max(ihmax, heights[i]); iwmax = std::max(iwmax, widths[i]);
+      ihmin = std::min(ihmin, heights[i]); iwmin = std::min(iwmin, widths[i]);
+    }
+    if (ipix >= (1L << 31)) { err = "too many pixels for one ragged launch"; return false; }
+    setimg(0, 0, 3);
+  } else if (rag) {
     B->widths.assign(widths, widths + N);
     setrag(0, H, add_level(B->widths), 3);
   } else setdims(0, N, H, W, 3);
   for (auto& op : plan_.ops) {
+    if (img && op.kind != PlanOp::OUTPUT) {
+      const TensorDesc& i = T[op.kind == PlanOp::CONCAT ? op.ins.back() : op.in];
+      // every spatial op of the detector keeps the size or halves it exactly (inputs are multiples of 32)
+      auto step = [&](int kh, int kw, int sh, int sw, int ph, int pw) -> int {
+        if (kh != kw || sh != sw || ph != pw || kh != 2 * ph + 1 || (sh != 1 && sh != 2)) return -1;
+        return sh == 2 ? 1 : 0;
+      };
+      switch (op.kind) {
+        case PlanOp::CONV: case PlanOp::DW: {
+          const int d = step(op.kh, op.kw, op.sh, op.sw, op.ph, op.pw);
+          if (i.lvl < 0 || d < 0 || i.lvl + d > 5) { err = "ragged batch of images: conv geometry not on this path"; return false; }
+          setimg(op.out, i.lvl + d, op.kind == PlanOp::CONV ? op.cout : op.c);
+        } break;
+        case PlanOp::DECONV:
+          if (i.lvl < 1) { err = "ragged batch of images: transposed conv above the input resolution"; return false; }
+          setimg(op.out, i.lvl - 1, op.cout);
+          break;
+        case PlanOp::LINEAR: setimg(op.out, i.lvl, op.cout); break;
+        case PlanOp::EW: if (i.lvl < 0) setdims(op.out, i.n, i.h, i.w, i.c); else setimg(op.out, i.lvl, i.c); break;
+        case PlanOp::SEFC: case PlanOp::GAP: setdims(op.out, N, 1, 1, op.c); break;
+        case PlanOp::CONCAT:
+          for (size_t j = 0; j < op.ins.size(); ++j) {
+            int lu = 0;
+            while ((1 << lu) < op.ups[j]) ++lu;
+            if ((1 << lu) != op.ups[j] || T[op.ins[j]].lvl != i.lvl + lu) { err = "ragged batch of images: concat sources must be power-of-two coarser levels"; return false; }
+          }
+          setimg(op.out, i.lvl, op.c);
+          break;
+        default: err = "ragged batch of images: op kind not on this path"; return false;
+      }
+      continue;
+    }
     if (rag && op.kind != PlanOp::OUTPUT) {
       const TensorDesc& i = T[op.kind == PlanOp::CONCAT ? op.ins.back() : op.in];
       int lvl = i.lvl, oh = i.h, oc = i.c;
@@ -512,33 +570,41 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths) {
     }
     if (op.out >= 0 && (T[op.out].h <= 0 || T[op.out].w <= 0)) { err = "input too small for the network"; return false; }
   }
-  // ragged batch: the line tables, packed: per level  w[N] | cw[N+1] | prefix sums of ceil(w/16), ceil(w/8), ceil(w/4)
-  // (N+2 entries each: the fused depthwise kernel's tile walk reads one entry past N)
-  const size_t lstride = rag ? (size_t)N + (N + 1) + 3 * ((size_t)N + 2) : 0;
+  // ragged batch: the sample tables.  Lines: per width level  w[N+1] | cw[N+1].  Images: one set at input resolution
+  // w[N+1] | h[N+1] | cw[N+1] | ch[N+1] (w / h carry one entry past N: the tile walks step onto "sample N" after their
+  // last unit).  Behind them the launches' own work tables (prefix sums of tiles / patches / bands per sample, N+1
+  // entries each), appended while the launch list is built: the device buffer is sized for all of them up front.
+  const size_t lstride = img ? 4 * ((size_t)N + 1) : 2 * ((size_t)N + 1);
+  const size_t tab_base = rag ? lstride * (img ? 1 : LW.size()) : 0;
+  const size_t tab_cap = rag ? tab_base + 96 * ((size_t)N + 1) : 0;
   if (rag) {
-    B->rag_host.assign(lstride * LW.size(), 0);
+    B->rag_host.assign(tab_base, 0);
+    if (img) {
+      int* w = B->rag_host.data();
+      int *h = w + (N + 1), *cw = h + (N + 1), *ch = cw + (N + 1);
+      for (int i = 0; i < N; ++i) {
+        w[i] = widths[i]; h[i] = heights[i];
+        cw[i + 1] = cw[i] + widths[i] * heights[i];
+        ch[i + 1] = ch[i] + heights[i];
+      }
+      w[N] = w[N - 1]; h[N] = h[N - 1];
+    } else
     for (size_t l = 0; l < LW.size(); ++l) {
       int* w = B->rag_host.data() + l * lstride;
-      int* cw = w + N;
-      int* ct[3] = {cw + N + 1, cw + N + 1 + (N + 2), cw + N + 1 + 2 * (N + 2)};
-      const int div[3] = {16, 8, 4};
-      for (int i = 0; i < N; ++i) {
-        w[i] = LW[l][i];
-        cw[i + 1] = cw[i] + w[i];
-        for (int d = 0; d < 3; ++d) ct[d][i + 1] = ct[d][i] + (w[i] + div[d] - 1) / div[d];
-      }
-      for (int d = 0; d < 3; ++d) ct[d][N + 1] = ct[d][N];
+      int* cw = w + (N + 1);
+      for (int i = 0; i < N; ++i) { w[i] = LW[l][i]; cw[i + 1] = cw[i] + w[i]; }
+      w[N] = w[N - 1];
     }
-    const size_t need = B->rag_host.size();
+    B->rag_host.reserve(tab_cap);
     for (size_t i = 0; i < pool_->free_list.size(); ++i)
-      if (pool_->free_list[i].second >= need) {
+      if (pool_->free_list[i].second >= tab_cap) {
         B->rag_dev = pool_->free_list[i].first;
         B->rag_cap = pool_->free_list[i].second;
         pool_->free_list.erase(pool_->free_list.begin() + i);
         break;
       }
     if (!B->rag_dev) {
-      const size_t cap = need + need / 2;
+      const size_t cap = tab_cap + tab_cap / 2;
       HIP_OK(hipMalloc(&B->rag_dev, cap * sizeof(int)));
       B->rag_cap = cap;
     }
@@ -546,16 +612,37 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths) {
   const int* rag_dev = B->rag_dev;
   auto rlevel = [&](const TensorDesc& t) {
     RagLevel r;
-    if (rag && t.lvl >= 0) { r.w = rag_dev + (size_t)t.lvl * lstride; r.cw = r.w + N; }
+    if (rag && t.lvl >= 0) {
+      if (img) { r.w = rag_dev; r.h = r.w + (N + 1); r.cw = r.h + (N + 1); r.ch = r.cw + (N + 1); r.shift = t.lvl; }
+      else { r.w = rag_dev + (size_t)t.lvl * lstride; r.cw = r.w + (N + 1); }
+    }
     return r;
   };
-  auto rwork = [&](const TensorDesc& t, int div) -> const int* {  // prefix sums of ceil(w / div), div in {16, 8, 4}
-    return rag_dev + (size_t)t.lvl * lstride + N + (N + 1) + (div == 16 ? 0 : div == 8 ? 1 : 2) * ((size_t)N + 2);
+  // size of sample i on a tensor's level
+  auto sw_of = [&](const TensorDesc& t, int i) { return img ? widths[i] >> t.lvl : LW[t.lvl][i]; };
+  auto sh_of = [&](const TensorDesc& t, int i) { return img ? heights[i] >> t.lvl : t.h; };
+  auto min_w = [&](const TensorDesc& t) { return img ? iwmin >> t.lvl : lmin[t.lvl]; };
+  auto min_h = [&](const TensorDesc& t) { return img ? ihmin >> t.lvl : t.h; };
+  auto rows_of = [&](const TensorDesc& t) -> long { return img ? irows >> t.lvl : (long)N * t.h; };
+  // a launch's work table: prefix sums of count(sample), memoised by key; returns its device address and total
+  std::map<std::string, std::pair<size_t, int>> tabs;
+  bool tab_overflow = false;
+  auto work_table = [&](const std::string& key, const std::function<int(int)>& count, int& total) -> const int* {
+    auto it = tabs.find(key);
+    if (it == tabs.end()) {
+      if (B->rag_host.size() + N + 1 > tab_cap) { tab_overflow = true; total = 0; return rag_dev; }
+      const size_t off = B->rag_host.size();
+      B->rag_host.resize(off + N + 1, 0);
+      int acc = 0;
+      for (int i = 0; i < N; ++i) { acc += count(i); B->rag_host[off + i + 1] = acc; }
+      it = tabs.emplace(key, std::make_pair(off, acc)).first;
+    }
+    total = it->second.second;
+    return rag_dev + it->second.first;
   };
-  auto rwork_total = [&](const TensorDesc& t, int div) {
-    long tot = 0;
-    for (int v : LW[t.lvl]) tot += (v + div - 1) / div;
-    return (int)tot;
+  auto tiles_table = [&](const TensorDesc& t, int th, int& total) {  // th x 16 pixel tiles per sample
+    return work_table("tiles:" + std::to_string(t.lvl) + ":" + std::to_string(th),
+                      [&](int i) { return ((sh_of(t, i) + th - 1) / th) * ((sw_of(t, i) + 15) / 16); }, total);
   };
   // 2. arena with liveness reuse
   const int nops = (int)plan_.ops.size();
@@ -632,8 +719,8 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths) {
       const PlanOp& d = plan_.ops[oi - 1];
       if (g.kind != PlanOp::GAP || d.kind != PlanOp::DW || d.out != g.in || fused_dw[oi - 1] || d.out == out_tid_) continue;
       const TensorDesc& o = T[d.out];
-      const int rows_per_band = o.h >= 2 ? 2 : 1;
-      const long threads = (long)o.n * ((o.h + rows_per_band - 1) / rows_per_band) * (o.cs >> 2);
+      const int rows_per_band = (rag ? min_h(o) : o.h) >= 2 ? 2 : 1;
+      const long threads = (rag ? rows_of(o) / rows_per_band : (long)o.n * ((o.h + rows_per_band - 1) / rows_per_band)) * (o.cs >> 2);
       // (stride-2 rows measured slower this way: rec op 21 0.55 -> 0.72 ms for a 0.18 ms pool pass)
       const long min_threads = rt_options().fuse_gap_min;  // OCR_FUSE_GAP_MIN (tests: 1 sends small shapes down this path too)
       if (threads >= min_threads && d.sh == 1 && d.sw == 1) dw_rowsum[oi - 1] = 1;
@@ -698,7 +785,7 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths) {
     auto& op = plan_.ops[oi];
     if (folded[oi] || fused_dw[oi]) { T[op.out].offset = 0; continue; }  // never materialised
     if (op.out >= 0) T[op.out].offset = alloc(T[op.out].numel());
-    if (op.kind == PlanOp::GAP) gap_need = std::max(gap_need, (size_t)T[op.in].n * T[op.in].h * T[op.in].cs);
+    if (op.kind == PlanOp::GAP) gap_need = std::max(gap_need, (size_t)(rag ? rows_of(T[op.in]) : (long)T[op.in].n * T[op.in].h) * T[op.in].cs);
     // free tensors whose last reader is this op (never the op's own output)
     for (int t = 1; t < plan_.ntensors; ++t)
       if (keep_all_ == 0 && last[t] == oi && t != op.out && T[t].numel()) release(T[t].offset, T[t].numel());
@@ -767,12 +854,13 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths) {
           DetTailArgs a{};
           a.in = arena_ + in.offset; a.prob = optr; a.bitmap = det_bitmap_; a.w = dev_vec("tail:" + op.w);
           a.N = in.n; a.H = in.h; a.W = in.w; a.C = op.cin; a.Cs = in.cs; a.bias = bias; a.ithresh = det_ithresh_;
-          a.M = (long)in.n * in.h * in.w;
+          a.M = in.pixels();
           snprintf(nm, sizeof nm, "%s.%02d.det_tail", plan_.name.c_str(), oi);
           L.name = nm;
           L.flops = 2.0 * a.M * op.cin * 4;
           L.bytes = 4.0 * a.M * op.cin + 4.0 * a.M * 4 + (det_bitmap_ ? 1.0 * a.M * 4 : 0.0);
           L.fn = [a](hipStream_t s) { launch_det_tail(a, s); };
+          if (img && dbhead_of[oi] < 0) { err = "ragged batch of images: the DB head needs its fused kernel (OCR_FUSE_DBHEAD, production launch list)"; return false; }
           if (dbhead_of[oi] >= 0) {
             const PlanOp& d = plan_.ops[dbhead_of[oi]];
             const TensorDesc& din = T[d.in];
@@ -781,8 +869,9 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths) {
             DbHeadArgs h{};
             h.in = arena_ + din.offset; h.prob = optr; h.bitmap = det_bitmap_;
             h.w1 = dev_vec("dbh1:" + d.w); h.bias1 = epd.st[0].v0; h.bn_s = epd.st[1].v0; h.bn_t = epd.st[1].v1;
-            h.w2 = a.w; h.M = (long)din.n * din.h * din.w; h.N = din.n; h.H = din.h; h.W = din.w; h.Cs = din.cs;
+            h.w2 = a.w; h.M = din.pixels(); h.N = din.n; h.H = din.h; h.W = din.w; h.Cs = din.cs;
             h.bias2 = a.bias; h.ithresh = a.ithresh;
+            if (img) h.rin = rlevel(din);
             snprintf(nm, sizeof nm, "%s.%02d.db_head_%d", plan_.name.c_str(), dbhead_of[oi], d.cin);
             L.name = nm;
             L.flops = 2.0 * h.M * (4.0 * d.cin * d.cout + 16.0 * d.cout);
@@ -801,10 +890,12 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths) {
           a.need_nyx = 0;
           if (in.plain) { err = "conv input must be C8I"; return false; }
           if (rag) {
-            // pointwise, or a stride-1 "same" conv along x (the 1x3 neck convs): rows in = rows out, one level
-            if (in.lvl < 0 || o.lvl != in.lvl || o.h != in.h) { err = "ragged batch: dense conv must keep its input's shape"; return false; }
+            // pointwise, or a stride-1 "same" conv (the recognizer's 1x3 neck convs, the detector's 3x3 neck / head convs):
+            // rows in = rows out, one level
+            if (in.lvl < 0 || o.lvl != in.lvl || o.h != in.h || op.kind == PlanOp::DECONV) { err = "ragged batch: dense conv must keep its input's shape"; return false; }
             for (auto& st : op.ep) if (st.kind == EP_MULC || st.kind == EP_ADDUP) { err = "ragged batch: per-image epilogue stage after a dense conv is not on this path"; return false; }
             a.rin = rlevel(in); a.rout = rlevel(o);
+            if (img && op.kh == 3 && op.kw == 3) a.rtiles = tiles_table(o, 8, a.rtiles_total);  // (the 8x16 LDS-tile kernel)
           }
           if (op.kind == PlanOp::DECONV) {
             a.OH = in.h; a.OW = in.w; a.Cs_out = o.cs; a.Cout = op.cout; a.CoutPadded = o.cs;
@@ -873,8 +964,9 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths) {
             if (rag) {
               f.rin = rlevel(din); f.rout = rlevel(o);
               f.c.rin = f.c.rout = RagLevel();
-              f.rtiles = rwork(o, 16);
-              f.rtiles_total = rwork_total(o, 16);
+              const int th = dwpw_tile_rows(f);
+              if (th <= 0) { err = "dwpw: no instance for this shape"; return false; }
+              f.rtiles = tiles_table(o, th, f.rtiles_total);
             }
             snprintf(nm, sizeof nm, "%s.%02d.dwpw%dx%d_%d_%d_s%d%d", plan_.name.c_str(), dwpw_of[oi], d.kh, d.kw, op.cin, op.cout, d.sh, d.sw);
             L.name = nm;
@@ -921,10 +1013,16 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths) {
         if (dw_rowsum[oi]) a.rowsum = gap_part_;
         if (rag) {
           a.rin = rlevel(in); a.rout = rlevel(o);
-          a.OW = lmin[o.lvl];  // the launcher picks its strip width from the narrowest line
-          const int to = dw_patch_to(a.OW, a.SW);
-          a.rwork = rwork(o, to);
-          a.rwork_total = rwork_total(o, to);
+          a.OW = min_w(o);            // the launcher picks its patch from the narrowest / lowest sample
+          if (img) a.OH = min_h(o);
+          const int to = dw_patch_to(a.OW, a.SW), pr = dw_patch_r(img ? a.OH : o.h);
+          const bool rs = dw_rowsum[oi] != 0;
+          const TensorDesc ot = o;
+          a.rwork = work_table("dw:" + std::to_string(o.lvl) + ":" + std::to_string(to) + ":" + std::to_string(pr) + (rs ? ":rs" : ""),
+                               [&, to, pr, rs](int i) {
+                                 const int bands = (sh_of(ot, i) + pr - 1) / pr;
+                                 return rs ? bands : bands * ((sw_of(ot, i) + to - 1) / to);
+                               }, a.rwork_total);
         }
         snprintf(nm, sizeof nm, "%s.%02d.dw%dx%d_%d_s%d%d%s", plan_.name.c_str(), oi, op.kh, op.kw, op.c, op.sh, op.sw, dw_rowsum[oi] ? "_rowsum" : "");
         L.name = nm;
@@ -939,7 +1037,7 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths) {
         const float* ip = arena_ + in.offset;
         const long M = o.pixels();
         const int H2 = o.h, W2 = o.w, Cs = o.cs;
-        if (rag) for (auto& st : op.ep) if (st.kind == EP_ADDUP) { err = "ragged batch: upsampled operand is not on this path"; return false; }
+        if (rag && !img) for (auto& st : op.ep) if (st.kind == EP_ADDUP) { err = "ragged batch: upsampled operand is not on this path"; return false; }
         const RagLevel rl = rlevel(o);
         const int nl = o.n;
         snprintf(nm, sizeof nm, "%s.%02d.ew_%d", plan_.name.c_str(), oi, op.c);
@@ -953,6 +1051,7 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths) {
         float* part = gap_part_;
         const int n = in.n, h = in.h, w = in.w, cs = in.cs;
         const RagLevel rl = rlevel(in);
+        const long grows = rag ? rows_of(in) : 0;
         snprintf(nm, sizeof nm, "%s.%02d.gap_%d", plan_.name.c_str(), oi, op.c);
         L.name = nm;
         L.bytes = 4.0 * (double)in.pixels() * op.c;
@@ -960,7 +1059,7 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths) {
           L.bytes = 4.0 * (double)n * h * op.c;
           L.fn = [part, optr, n, h, w, cs, rl](hipStream_t s) { launch_gap_cols(part, optr, n, h, w, cs, s, rl); };
         } else
-        L.fn = [ip, part, optr, n, h, w, cs, rl](hipStream_t s) { launch_gap(ip, part, optr, n, h, w, cs, s, rl); };
+        L.fn = [ip, part, optr, n, h, w, cs, rl, grows](hipStream_t s) { launch_gap(ip, part, optr, n, h, w, cs, s, rl, grows); };
       } break;
       case PlanOp::SEFC: {
         const TensorDesc& in = T[op.in];
@@ -978,7 +1077,8 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths) {
       case PlanOp::CONCAT: {
         ConcatArgs a{};
         a.out = optr; a.H = o.h; a.W = o.w; a.Cs = o.cs; a.M = o.pixels();
-        if (rag) { a.H = 1; a.W = (int)a.M; }  // same-resolution sources (checked above): one row axis
+        if (img) { a.rout = rlevel(o); a.N = N; }
+        else if (rag) { a.H = 1; a.W = (int)a.M; }  // lines: same-resolution sources (checked above), one row axis
         a.nsrc = (int)op.ins.size();
         if (a.nsrc > 4) { err = "concat arity not on this path"; return false; }
         int off = 0;
@@ -1061,11 +1161,13 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths) {
       default: break;
     }
     // instance tag: the same op at another bound shape is another roofline row
-    if (rag) snprintf(nm, sizeof nm, "@%dx%dx~%ld", N, H, ltot[0] / N);  // ragged: the lines' mean width
+    if (img) snprintf(nm, sizeof nm, "@%dx~%ldx~%ld", N, irows / N, ipix / irows);  // ragged images: mean height, mean width
+    else if (rag) snprintf(nm, sizeof nm, "@%dx%dx~%ld", N, H, ltot[0] / N);  // ragged: the lines' mean width
     else snprintf(nm, sizeof nm, "@%dx%dx%d", N, H, W);
     L.name += nm;
     launches_.push_back(std::move(L));
   }
+  if (tab_overflow) { err = "ragged batch: work-table space exhausted"; return false; }
   if (moved) cache_.clear();
   while (cache_.size() >= max_bindings_) {  // least recently used out
     auto old = cache_.begin();
@@ -1075,13 +1177,13 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths) {
   }
   B->tensors = tensors_;
   cur_ = B.get();
-  cache_[shape_key(N, H, W, widths)] = std::move(B);
+  cache_[shape_key(N, H, W, widths, heights)] = std::move(B);
   return true;
 }
 
 bool Net::run(const float* x, int N, int H, int W, hipStream_t s, std::string& err) {
   if (!cur_ || !cur_->widths.empty() || cur_->n != N || cur_->h != H || cur_->w != W) {
-    auto it = cache_.find(shape_key(N, H, W, nullptr));
+    auto it = cache_.find(shape_key(N, H, W, nullptr, nullptr));
     if (it != cache_.end()) {
       cur_ = it->second.get();
       tensors_ = cur_->tensors;
@@ -1096,8 +1198,8 @@ bool Net::run(const float* x, int N, int H, int W, hipStream_t s, std::string& e
 bool Net::bind_ragged(int H, const int* widths, int N, std::string& err) {
   if (N < 1 || !widths) { err = "ragged batch: no lines"; return false; }
   if (!ragged_ok(H, widths, N, err)) return false;
-  if (cur_ && cur_->h == H && (int)cur_->widths.size() == N && std::equal(widths, widths + N, cur_->widths.begin())) return true;
-  auto it = cache_.find(shape_key(N, H, 0, widths));
+  if (cur_ && cur_->heights.empty() && cur_->h == H && (int)cur_->widths.size() == N && std::equal(widths, widths + N, cur_->widths.begin())) return true;
+  auto it = cache_.find(shape_key(N, H, 0, widths, nullptr));
   // (the key is the run-length form: a cached binding with the same runs has the same widths line by line)
   if (it != cache_.end()) {
     cur_ = it->second.get();
@@ -1121,6 +1223,32 @@ bool Net::bind_ragged(int H, const int* widths, int N, std::string& err) {
 
 bool Net::run_ragged(const float* x, int H, const int* widths, int N, hipStream_t s, std::string& err) {
   if (!bind_ragged(H, widths, N, err)) return false;
+  return run_bound(x, s, err);
+}
+
+bool Net::run_ragged_images(const float* x, const int* heights, const int* widths, int N, hipStream_t s, std::string& err) {
+  if (N < 1 || !widths || !heights) { err = "ragged batch: no images"; return false; }
+  const bool same = cur_ && (int)cur_->widths.size() == N && (int)cur_->heights.size() == N &&
+                    std::equal(widths, widths + N, cur_->widths.begin()) && std::equal(heights, heights + N, cur_->heights.begin());
+  if (!same) {
+    auto it = cache_.find(shape_key(N, 0, 0, widths, heights));
+    if (it != cache_.end()) {
+      cur_ = it->second.get();
+      tensors_ = cur_->tensors;
+    } else {
+      cur_ = nullptr;
+      size_t nrag = 0;
+      for (auto& kv : cache_) nrag += !kv.second->widths.empty();
+      while (nrag >= kMaxRaggedBindings) {
+        auto old = cache_.end();
+        for (auto i2 = cache_.begin(); i2 != cache_.end(); ++i2)
+          if (!i2->second->widths.empty() && (old == cache_.end() || i2->second->stamp < old->second->stamp)) old = i2;
+        cache_.erase(old);
+        --nrag;
+      }
+      if (!bind(N, 0, 0, err, widths, heights)) { invalidate(); return false; }
+    }
+  }
   return run_bound(x, s, err);
 }
 

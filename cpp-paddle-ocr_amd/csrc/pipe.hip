@@ -105,6 +105,7 @@ struct PipeWorker {
   std::vector<std::unique_ptr<DetStage>> det_extra;
   DetConfig det_cfg;
   int det_lanes = 8;
+  bool det_ragged = true;  // OCR_DET_RAGGED=0: mixed-size batches as one detector pass per distinct size (rounds 1-2)
   RecStage rec;
   std::unique_ptr<ClsStage> cls;
   DevBuf<RotDesc> rot_desc;
@@ -144,7 +145,55 @@ struct PipeWorker {
                           nbox.data() + g.first, nullptr, e, probs ? probs + g.prob_off : nullptr);
     };
     const int lanes = (int)std::min<size_t>((size_t)det_lanes, groups.size());
-    if (lanes <= 1) {
+    if (groups.size() > 1 && det_ragged) {
+      // MIXED sizes (round 3): ONE detector network pass over all size groups (every image keeps its own size inside a
+      // ragged launch: Net::run_ragged_images) instead of a latency-bound pass per distinct size; only BoxesFromBitmap
+      // still runs per group, dealt over the detector lanes.  Chunks bound the activation arena (~64 Mpixel of
+      // detector input per launch, what a uniform batch of 64 x 960 x 960 needs).
+      while ((int)det_extra.size() < lanes - 1) {
+        std::unique_ptr<DetStage> d(new DetStage());
+        int code = 0;
+        if (!d->create(det_cfg, err, code)) return code ? code : OCR_ERR_DEVICE;
+        det_extra.push_back(std::move(d));
+      }
+      std::vector<DetStage::MixedGroup> mg(groups.size());
+      std::vector<size_t> gpx(groups.size());
+      for (size_t gi = 0; gi < groups.size(); ++gi) {
+        const auto& g = groups[gi];
+        mg[gi] = DetStage::MixedGroup{g.rows, g.cols, g.count, g.off, g.prob_off};
+        int rh = 0, rw = 0;
+        { float a, b; DetStage::resize_shape(g.rows, g.cols, det.cfg().limit_type, det.cfg().limit_side_len, rh, rw, a, b); }
+        gpx[gi] = (size_t)g.count * rh * rw;
+      }
+      const size_t budget = (size_t)64 << 20;
+      for (size_t g0 = 0; g0 < groups.size();) {
+        size_t g1 = g0, px = 0;
+        while (g1 < groups.size() && (g1 == g0 || px + gpx[g1] <= budget)) px += gpx[g1++];
+        int rc = det.mixed_net(base, mg.data() + g0, (int)(g1 - g0), probs, err);
+        if (rc) return rc;
+        std::vector<int> rcs(lanes, OCR_OK);
+        std::vector<std::string> errs(lanes);
+        auto lane_fn = [&](int l) {
+          DetStage& d = l == 0 ? det : *det_extra[l - 1];
+          for (size_t gi = g0 + l; gi < g1; gi += lanes) {
+            const auto& g = groups[gi];
+            rcs[l] = d.post_group(det.mixed_prob((int)(gi - g0)), det.mixed_bitmap((int)(gi - g0)), mg[gi], l == 0 ? nullptr : det.done(),
+                                  boxes.data() + (size_t)g.first * kCap * 8, kCap, nbox.data() + g.first, errs[l]);
+            if (rcs[l]) return;
+          }
+        };
+        std::vector<std::thread> th;
+        for (int l = 1; l < lanes; ++l) th.emplace_back(lane_fn, l);
+        lane_fn(0);
+        for (auto& t : th) t.join();
+        for (int l = 0; l < lanes; ++l)
+          if (rcs[l]) { err = errs[l]; return rcs[l]; }
+        // (every lane's post-processing ended with a stream synchronisation: the maps may be overwritten by the next chunk)
+        if (hipStreamSynchronize(det.stream()) != hipSuccess) { err = "det stream sync failed"; return OCR_ERR_DEVICE; }
+        det.collect_timings();
+        g0 = g1;
+      }
+    } else if (lanes <= 1) {
       for (const auto& g : groups) {
         int rc = run_group(det, g, err);
         if (rc) return rc;
@@ -295,6 +344,7 @@ struct ocr_pipe {
   // owns the chip: what the per-kernel roofline figures of bench.py are measured with).
   std::vector<std::unique_ptr<PipeWorker>> extra;  // chains 2 .. phases
   int phases = 2;
+  int parts_per_chain = 1;
   int device = 0;
   StageSlot slots[2];
   hipStream_t copy_stream = nullptr;
@@ -417,8 +467,11 @@ struct ocr_pipe {
   int run_images(uint8_t* base, const std::vector<StageSlot::Img>& imgs, const std::vector<StageSlot::Group>& groups, const float* probs,
                  std::vector<std::vector<ocr_word>>& out_words, std::vector<std::vector<int32_t>>& out_ids, double times[3], std::string& err) {
     const int count = (int)imgs.size();
-    const int K = (int)std::min<size_t>(1 + extra.size(), (size_t)count);
-    if (K < 2) return w0.run_images(base, imgs, groups, probs, out_words, out_ids, times, err);
+    const int nchains = (int)std::min<size_t>(1 + extra.size(), (size_t)count);
+    if (nchains < 2) return w0.run_images(base, imgs, groups, probs, out_words, out_ids, times, err);
+    // K parts, dealt round-robin to the chains (parts_per_chain > 1: a chain runs several smaller parts one after the
+    // other, so that the chains drift out of phase and the tail of the call is a part, not half a batch)
+    const int K = (int)std::min<size_t>((size_t)nchains * parts_per_chain, (size_t)count);
     // parts: size groups dealt to the lightest part (pixels), a group cut where that part reaches its share of the batch
     std::vector<std::vector<StageSlot::Img>> pi(K);
     std::vector<std::vector<StageSlot::Group>> pg(K);
@@ -459,14 +512,17 @@ struct ocr_pipe {
     std::vector<std::array<double, 3>> t(K, std::array<double, 3>{0, 0, 0});
     std::vector<int> rc(K, OCR_OK);
     std::vector<std::string> errs(K);
-    auto part = [&](int p) {
-      if (pi[p].empty()) return;
-      PipeWorker& w = p == 0 ? w0 : *extra[p - 1];
-      rc[p] = w.run_images(base, pi[p], pg[p], probs, W[p], I[p], t[p].data(), errs[p]);
+    auto chain = [&](int c) {  // parts c, c + nchains, ... on worker c
+      PipeWorker& w = c == 0 ? w0 : *extra[c - 1];
+      for (int p = c; p < K; p += nchains) {
+        if (pi[p].empty()) continue;
+        rc[p] = w.run_images(base, pi[p], pg[p], probs, W[p], I[p], t[p].data(), errs[p]);
+        if (rc[p]) return;
+      }
     };
     std::vector<std::thread> th;
-    for (int p = 1; p < K; ++p) th.emplace_back([&, p]() { (void)hipSetDevice(device); part(p); });
-    part(0);
+    for (int c = 1; c < nchains; ++c) th.emplace_back([&, c]() { (void)hipSetDevice(device); chain(c); });
+    chain(0);
     for (auto& x : th) x.join();
     for (int p = 0; p < K; ++p)
       if (rc[p]) { err = errs[p]; return rc[p]; }
@@ -477,9 +533,13 @@ struct ocr_pipe {
         out_words[gidx[p][k]] = std::move(W[p][k]);
         out_ids[gidx[p][k]] = std::move(I[p][k]);
       }
-    for (int k = 0; k < 3; ++k) {  // the chains ran side by side
+    for (int k = 0; k < 3; ++k) {  // the chains ran side by side: per stage, the busiest chain's time
       double m = 0;
-      for (int p = 0; p < K; ++p) m = std::max(m, t[p][k]);
+      for (int c = 0; c < nchains; ++c) {
+        double sum = 0;
+        for (int p = c; p < K; p += nchains) sum += t[p][k];
+        m = std::max(m, sum);
+      }
       times[k] += m;
     }
     return OCR_OK;
@@ -547,6 +607,7 @@ int ocr_pipe_create(const ocr_pipe_cfg* c, ocr_pipe** out) {
   if (c->phases < 0 || c->phases > 4) return fail(OCR_ERR_ARG, "phases must be 0 (default) or 1..4");
   h->phases = c->phases ? c->phases : 2;
   if (const char* e = getenv("OCR_PIPE_PHASES")) h->phases = std::min(4, std::max(1, atoi(e)));
+  if (const char* e = getenv("OCR_PIPE_PARTS")) h->parts_per_chain = std::min(8, std::max(1, atoi(e)));
   std::string err;
   DetConfig d;
   d.model_dir = c->det.model_dir; d.device = c->det.device_id;
@@ -580,6 +641,10 @@ int ocr_pipe_create(const ocr_pipe_cfg* c, ocr_pipe** out) {
   // the detector lanes (mixed-size batches) are dealt over the chains
   h->w0.det_lanes = std::max(1, (lanes + h->phases - 1) / h->phases);
   for (auto& w : h->extra) w->det_lanes = h->w0.det_lanes;
+  if (const char* e = getenv("OCR_DET_RAGGED")) {
+    h->w0.det_ragged = e[0] != '0';
+    for (auto& w : h->extra) w->det_ragged = h->w0.det_ragged;
+  }
   // two idle high-priority streams, created after the stage objects' streams and before the detector lanes' (which
   // come into being at the first mixed-size batch): the configuration in which the lanes measured fastest (capi_net.hip)
   priority_anchor(h->device, true);

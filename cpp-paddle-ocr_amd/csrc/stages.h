@@ -57,6 +57,22 @@ class DetStage {
   // the network still runs, but thresholding / scoring read this map instead of the network's.
   int run_device(const uint8_t* dev_imgs, size_t img_bytes, size_t stride, int rows, int cols, int count, int32_t* boxes,
                  int cap, int* n, double times[3], std::string& err, const float* prob_override = nullptr);
+  // ---- batches of MIXED sizes: one ragged network launch for all size groups, post-processing per group -----------
+  // A size group = `count` images of rows x cols, packed BGR, starting `off` bytes into the batch's device buffer;
+  // prob_off = floats into the benchmark protocol's probability-map buffer (prob_override of run_device).
+  struct MixedGroup { int rows, cols, count; size_t off, prob_off; };
+  // Enqueues resize + normalise of every group and ONE network pass over all images (Net::run_ragged_images: every
+  // image keeps its own size) on this stage's stream and records `done()`; the maps of group i are then at
+  // mixed_prob(i) / mixed_bitmap(i).  The caller runs post_group per group - on this stage or, concurrently, on other
+  // DetStage instances (their streams wait for done()).
+  int mixed_net(const uint8_t* base, const MixedGroup* groups, int ngroups, const float* prob_override, std::string& err);
+  const float* mixed_prob(int gi) const { return mixed_probs_[gi]; }
+  const uint8_t* mixed_bitmap(int gi) const { return bitmap_.p + mixed_pix_[gi]; }
+  hipEvent_t done() const { return mixed_done_; }
+  void collect_timings() { net_.collect_timings(); }  // after the stream that ran mixed_net has been synchronised
+  // BoxesFromBitmap + FilterTagDetRes of one size group whose maps sit in device memory (another stage's mixed_net)
+  int post_group(const float* prob, const uint8_t* bitmap, const MixedGroup& g, hipEvent_t wait_for, int32_t* boxes, int cap, int* n,
+                 std::string& err);
   // mutable view of the uploaded copies (the request's clone: cls rotation happens in place on it)
   uint8_t* dev_images_mut() { return src_.p; }
   int post_only(const float* prob, int rows, int cols, int src_rows, int src_cols, int32_t* boxes, int cap, int* n,
@@ -77,7 +93,10 @@ class DetStage {
  private:
   bool ensure_post(int count, int H, int W, std::string& err);
   int run_post(int count, int H, int W, const float* prob, float ratio_h, float ratio_w, int src_h, int src_w,
-               int32_t* boxes, int cap, int* n, std::string& err);
+               int32_t* boxes, int cap, int* n, std::string& err, const uint8_t* bitmap = nullptr);
+  std::vector<size_t> mixed_pix_;            // first pixel of every group in the ragged maps
+  std::vector<const float*> mixed_probs_;
+  hipEvent_t mixed_done_ = nullptr;
   DetConfig cfg_;
   Net net_;
   hipStream_t stream_ = nullptr;

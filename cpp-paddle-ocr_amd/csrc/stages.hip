@@ -1,6 +1,7 @@
 #include "stages.h"
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstring>
 #include <fstream>
@@ -73,6 +74,7 @@ bool upload_lines(const ocr_img* imgs, int n, DevBuf<uint8_t>& staging, std::vec
 
 // ================================================================= detector
 DetStage::~DetStage() {
+  if (mixed_done_) (void)hipEventDestroy(mixed_done_);
   if (stream_) (void)hipStreamDestroy(stream_);
 }
 
@@ -137,13 +139,13 @@ bool DetStage::ensure_post(int count, int H, int W, std::string& err) {
 }
 
 int DetStage::run_post(int count, int H, int W, const float* prob, float ratio_h, float ratio_w, int src_h, int src_w,
-                       int32_t* boxes, int cap, int* n, std::string& err) {
+                       int32_t* boxes, int cap, int* n, std::string& err, const uint8_t* bitmap) {
   if (!ensure_post(count, H, W, err)) return OCR_ERR_DEVICE;
   if (!out_boxes_.ensure((size_t)count * cap * 8, err) || !out_n_.ensure(count, err)) return OCR_ERR_DEVICE;
   ST_HIP(hipMemsetAsync(status_.p, 0, sizeof(int), stream_));
-  const uint8_t* bm = bitmap_.p;
+  const uint8_t* bm = bitmap ? bitmap : bitmap_.p;
   if (cfg_.use_dilation) {
-    launch_dilate2(bitmap_.p, bitmap2_.p, count, H, W, stream_);
+    launch_dilate2(bm, bitmap2_.p, count, H, W, stream_);
     bm = bitmap2_.p;
   }
   PostArgs a{};
@@ -240,6 +242,59 @@ int DetStage::run_device(const uint8_t* dev_imgs, size_t img_bytes, size_t strid
   net_.collect_timings();
   timer_.read(times);
   return rc;
+}
+
+int DetStage::mixed_net(const uint8_t* base, const MixedGroup* groups, int ngroups, const float* prob_override, std::string& err) {
+  ST_HIP(hipSetDevice(cfg_.device));
+  if (!mixed_done_) ST_HIP(hipEventCreateWithFlags(&mixed_done_, hipEventDisableTiming));
+  mixed_pix_.assign(ngroups + 1, 0);
+  std::vector<int> hs, ws;
+  std::vector<std::array<int, 2>> shape(ngroups);
+  for (int gi = 0; gi < ngroups; ++gi) {
+    float a, b;
+    resize_shape(groups[gi].rows, groups[gi].cols, cfg_.limit_type, cfg_.limit_side_len, shape[gi][0], shape[gi][1], a, b);
+    mixed_pix_[gi + 1] = mixed_pix_[gi] + (size_t)groups[gi].count * shape[gi][0] * shape[gi][1];
+    for (int k = 0; k < groups[gi].count; ++k) { hs.push_back(shape[gi][0]); ws.push_back(shape[gi][1]); }
+  }
+  const size_t px = mixed_pix_[ngroups];
+  const uint8_t* old_bm = bitmap_.p;
+  if (!x_.ensure(px * 3, err) || !resized_.ensure(px * 3, err) || !bitmap_.ensure(px, err)) return OCR_ERR_DEVICE;
+  timer_.mark(0, stream_);
+  for (int gi = 0; gi < ngroups; ++gi) {  // ResizeImgType0 + Normalize + Permute per size group, into the ragged input
+    const MixedGroup& g = groups[gi];
+    DetPreArgs pa{};
+    pa.src = base + g.off; pa.src_image_bytes = (size_t)g.rows * g.cols * 3; pa.src_stride = (size_t)g.cols * 3;
+    pa.N = g.count; pa.sh = g.rows; pa.sw = g.cols; pa.dh = shape[gi][0]; pa.dw = shape[gi][1]; pa.lut = lut_.p;
+    pa.out = x_.p + mixed_pix_[gi] * 3; pa.resized = resized_.p + mixed_pix_[gi] * 3;
+    launch_det_pre(pa, stream_);
+  }
+  timer_.mark(1, stream_);
+  if (bitmap_.p != old_bm || bm_n_ == 0) { net_.set_det_bitmap(bitmap_.p, ithresh_); bm_n_ = 1; }
+  if (!net_.run_ragged_images(x_.p, hs.data(), ws.data(), (int)hs.size(), stream_, err)) return OCR_ERR_DEVICE;
+  timer_.mark(2, stream_);
+  mixed_probs_.assign(ngroups, nullptr);
+  for (int gi = 0; gi < ngroups; ++gi) {
+    mixed_probs_[gi] = prob_dev() + mixed_pix_[gi];
+    if (prob_override) {  // the benchmark protocol: thresholding and scoring read these maps (group gi at its prob_off)
+      mixed_probs_[gi] = prob_override + groups[gi].prob_off;
+      launch_bitmap(mixed_probs_[gi], bitmap_.p + mixed_pix_[gi], (long)(mixed_pix_[gi + 1] - mixed_pix_[gi]), ithresh_, stream_);
+    }
+  }
+  ST_HIP(hipEventRecord(mixed_done_, stream_));
+  last_count = (int)hs.size(); last_h = 0; last_w = 0;
+  return OCR_OK;
+}
+
+int DetStage::post_group(const float* prob, const uint8_t* bitmap, const MixedGroup& g, hipEvent_t wait_for, int32_t* boxes, int cap,
+                         int* n, std::string& err) {
+  ST_HIP(hipSetDevice(cfg_.device));
+  if (wait_for) ST_HIP(hipStreamWaitEvent(stream_, wait_for, 0));
+  int rh, rw;
+  float ratio_h, ratio_w;
+  resize_shape(g.rows, g.cols, cfg_.limit_type, cfg_.limit_side_len, rh, rw, ratio_h, ratio_w);
+  src_rows_ = g.rows;
+  src_cols_ = g.cols;
+  return run_post(g.count, rh, rw, prob, ratio_h, ratio_w, g.rows, g.cols, boxes, cap, n, err, bitmap);
 }
 
 int DetStage::post_only(const float* prob, int rows, int cols, int src_rows, int src_cols, int32_t* boxes, int cap, int* n,

@@ -252,6 +252,11 @@ int ocr_net_forward(ocr_net* h, const float* x, int N, int H, int W, int keep_al
  * ocr_net_forward on that line alone.  ocr_net_fetch then returns a tensor's lines one after the other with
  * dims = {1, 1, total pixels, C} (per-line vectors such as the SE gates: {N, 1, 1, C}). */
 int ocr_net_forward_ragged(ocr_net* h, const float* x, int N, int H, const int* widths, int keep_all);
+/* Ragged batch of IMAGES (det only): N images of their own sizes heights[n] x widths[n] (multiples of 32, what
+ * ResizeImgType0 produces, src/preprocess_op.cpp:84-88) in one launch list - the detector's path for batches of mixed
+ * sizes; x = the images' [h][w][3] blocks one after the other.  keep_all 0 or 2.  ocr_net_fetch returns a tensor's
+ * images one after the other, dims = {1, 1, total pixels at that tensor's resolution, C}. */
+int ocr_net_forward_ragged_images(ocr_net* h, const float* x, int N, const int* heights, const int* widths, int keep_all);
 int ocr_net_num_tensors(ocr_net* h);
 /* 1 if the last forward wrote tensor `tid` to device memory (fused-away tensors never exist), else 0 */
 int ocr_net_tensor_exists(ocr_net* h, int tid);

@@ -182,6 +182,46 @@ def test_ragged_rec_batch_equals_each_line_alone(pkg, built, keep_all, h, widths
     g.close()
 
 
+@pytest.mark.parametrize("keep_all", [0, 2])
+def test_ragged_det_batch_equals_each_image_alone(pkg, built, keep_all):
+    """The detector on a batch of MIXED sizes runs one launch list for all of them (kernels_net.h, RagLevel with heights;
+    Net::run_ragged_images): every image keeps its own height and width - zero padding, SE pools, FPN upsampling, the
+    8x16 LDS tiles and the DB head's 4x4 expansion all take the image's own size.  Every tensor the production list
+    writes, and the probability map, must equal what the oracle computes for that image alone.  Sizes include the
+    smallest (32), non-square, equal neighbours and sizes that are not multiples of the tile shapes at the coarse levels."""
+    from oracle import OracleNet
+    rs = np.random.RandomState(41)
+    sizes = [(96, 160), (96, 160), (32, 32), (64, 224), (160, 96), (128, 128), (32, 96), (224, 64)]
+    imgs = [rs.randn(h, w, 3).astype(np.float32) for h, w in sizes]
+    o = OracleNet("det")
+    g = pkg.Net("det")
+    y = g.forward_ragged_images(imgs, keep_all=keep_all)
+    nt = g.num_tensors()
+    outs, taps = [], {t: [] for t in range(1, nt)}
+    for im in imgs:
+        outs.append(o.run(im[None]))
+        if keep_all:
+            for t in range(1, nt):
+                taps[t].append(o.tensor(t).copy())
+    assert np.array_equal(np.concatenate([v.reshape(-1) for v in outs]), y.reshape(-1))
+    checked = 0
+    for t in range(1, nt if keep_all else 1):
+        if not taps[t][0].size or not g.exists(t):
+            continue
+        c = taps[t][0].shape[-1]
+        assert np.array_equal(np.concatenate([v.reshape(-1, c) for v in taps[t]]), g.fetch(t).reshape(-1, c)), "tensor %d" % t
+        checked += 1
+    assert checked >= (40 if keep_all else 0)
+    # another composition, then the first again (cached binding and tables), then a uniform batch on the same handle
+    sub = [imgs[i] for i in (4, 0, 7)]
+    want = np.concatenate([o.run(im[None]).reshape(-1) for im in sub])
+    assert np.array_equal(want, g.forward_ragged_images(sub, keep_all=keep_all).reshape(-1))
+    assert np.array_equal(np.concatenate([v.reshape(-1) for v in outs]), g.forward_ragged_images(imgs, keep_all=keep_all).reshape(-1))
+    x = np.stack([imgs[0], imgs[1]])
+    assert np.array_equal(o.run(x), g.forward(x, keep_all=keep_all))
+    g.close()
+
+
 @pytest.mark.parametrize("graph", ["1", "0"])
 @pytest.mark.parametrize("kind,shape,other", [("rec", (3, 48, 160), (2, 48, 96)), ("det", (2, 64, 96), (1, 96, 64)),
                                               ("cls", (4, 48, 192), (1, 48, 192))])
@@ -751,22 +791,32 @@ def test_pipeline_configs2_full_size_with_binding_eviction_and_changing_slots(pk
         items = pool.map(_cfg3_pool_item, range(n), chunksize=8)
     imgs, probs = [it[0] for it in items], [it[1] for it in items]
     assert len({im.shape for im in imgs}) >= 300
-    monkeypatch.setenv("OCR_NET_BINDINGS", "16")
     kw = dict(rec_batch_num=16, rec_img_h=48, rec_img_w=320, enable_cls=True)
-    pg = pkg.Pipe(limit_side_len=960, **kw)
+    pg = pkg.Pipe(limit_side_len=960, **kw)       # default: the detector runs the mixed sizes as ragged launches (one per ~64 Mpixel)
     for i in (0, 100, 511):
         assert pg.det_shape(*imgs[i].shape[:2]) == probs[i].shape
-    st0 = pg.stats()
     pg.stage(0, imgs, probs)
     got = pg.run_staged(0)
-    st1 = pg.stats()
-    assert st1["binds"] - st0["binds"] >= 300                       # one per distinct shape at least
-    again = pg.run_staged(0)                                         # the capped caches re-bind what they evicted
-    assert pg.stats()["binds"] - st1["binds"] >= 100
     same = lambda a, b: len(a) == len(b) and all(np.array_equal(x["box"], y["box"]) and np.array_equal(x["ids"], y["ids"]) and
                                                  x["confidence"] == y["confidence"] for x, y in zip(a, b))
-    assert all(same(a, b) for a, b in zip(got, again))
     assert sum(len(g) for g in got) > 10000
+    # the per-size path of rounds 1-2 (one detector pass per distinct size on the lanes), with the binding caches capped
+    # at 16 shapes: every lane keeps evicting and re-binding; all 512 images must give the ragged launches' words
+    monkeypatch.setenv("OCR_NET_BINDINGS", "16")
+    monkeypatch.setenv("OCR_DET_RAGGED", "0")
+    pl = pkg.Pipe(limit_side_len=960, **kw)
+    monkeypatch.delenv("OCR_NET_BINDINGS")
+    monkeypatch.delenv("OCR_DET_RAGGED")
+    st0 = pl.stats()
+    pl.stage(0, imgs, probs)
+    lanes = pl.run_staged(0)
+    st1 = pl.stats()
+    assert st1["binds"] - st0["binds"] >= 300                       # one per distinct shape at least
+    again = pl.run_staged(0)                                         # the capped caches re-bind what they evicted
+    assert pl.stats()["binds"] - st1["binds"] >= 100
+    assert all(same(a, b) for a, b in zip(lanes, again))
+    assert all(same(a, b) for a, b in zip(lanes, got))
+    pl.close()
     po = Pipeline(det_cfg=DetCfg(limit_side_len=960), **kw)
     for i in (0, 63, 64, 200, 255, 256, 400, 511):
         w = po.process(imgs[i], probs[i])["words"]

@@ -1,16 +1,14 @@
 #!/bin/bash
-# Runs on the GPU box: configs[1] / configs[2] throughput against the number of chains per pipeline.
+# Runs on the GPU box: configs[1] throughput against the number of chains per pipeline and parts per chain.
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$1; mkdir -p $O
-for p in 1 2 3 4; do
-  OCR_PIPE_PHASES=$p python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-two-workers --no-latency > $O/cfg2_p$p.json 2> $O/cfg2_p$p.err
-  OCR_PIPE_PHASES=$p python3 $R/bench.py --config cfg3 --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-host-input > $O/cfg3_p$p.json 2> $O/cfg3_p$p.err
-done
-python3 - <<PY
+for cfg in "1 1" "2 1" "2 2" "2 4" "3 1" "3 2" "4 1" "4 2"; do
+  set -- $cfg
+  OCR_PIPE_PHASES=$1 OCR_PIPE_PARTS=$2 python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-timing --no-two-workers --no-latency > $O/cfg2_p$1_m$2.json 2> $O/cfg2_p$1_m$2.err
+  python3 - <<PY
 import json
-for c in ("cfg2","cfg3"):
-    for p in (1,2,3,4):
-        try:
-            d=json.loads(open("$O/%s_p%d.json"%(c,p)).read().strip().splitlines()[-1]); print(c, "phases", p, round(d["value"],1), {k:round(v,1) for k,v in d["stage_ms_last_step"].items()}, "host", round(d.get("host_input",{}).get("value",0),1))
-        except Exception as e: print(c, p, "ERR", e)
+try:
+    d=json.loads(open("$O/cfg2_p$1_m$2.json").read().strip().splitlines()[-1]); print("chains $1 parts/chain $2:", round(d["value"],1), "host", round(d.get("host_input",{}).get("value",0),1))
+except Exception as e: print("$1 $2 ERR", e)
 PY
+done

@@ -641,7 +641,7 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths, const i
     return rag_dev + it->second.first;
   };
   auto tiles_table = [&](const TensorDesc& t, int th, int& total) {  // th x 16 pixel tiles per sample
-    return work_table("tiles:" + std::to_string(t.lvl) + ":" + std::to_string(th),
+    return work_table("tiles:" + std::to_string(t.lvl) + ":" + std::to_string(t.h) + ":" + std::to_string(th),  // (lines: tensors of one width level differ in height)
                       [&](int i) { return ((sh_of(t, i) + th - 1) / th) * ((sw_of(t, i) + 15) / 16); }, total);
   };
   // 2. arena with liveness reuse
@@ -1018,7 +1018,7 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths, const i
           const int to = dw_patch_to(a.OW, a.SW), pr = dw_patch_r(img ? a.OH : o.h);
           const bool rs = dw_rowsum[oi] != 0;
           const TensorDesc ot = o;
-          a.rwork = work_table("dw:" + std::to_string(o.lvl) + ":" + std::to_string(to) + ":" + std::to_string(pr) + (rs ? ":rs" : ""),
+          a.rwork = work_table("dw:" + std::to_string(o.lvl) + ":" + std::to_string(o.h) + ":" + std::to_string(to) + ":" + std::to_string(pr) + (rs ? ":rs" : ""),
                                [&, to, pr, rs](int i) {
                                  const int bands = (sh_of(ot, i) + pr - 1) / pr;
                                  return rs ? bands : bands * ((sw_of(ot, i) + to - 1) / to);

@@ -96,6 +96,14 @@ o, g = OracleNet("rec"), pkg.Net("rec")
 want = np.concatenate([o.run(l[None]).reshape(-1, 6625) for l in lines])
 assert np.array_equal(want, g.forward_ragged(lines, keep_all=False).reshape(-1, 6625)), "ragged rec"
 g.close()
+# the detector's path for mixed sizes: a ragged batch of images against each image alone (needs the fused DB head)
+import os
+if os.environ.get("OCR_FUSE_DBHEAD") != "0":
+    imgs = [rs.randn(h, w, 3).astype(np.float32) for h, w in ((96, 160), (64, 64), (32, 96), (160, 96), (64, 64), (128, 224))]
+    o, g = OracleNet("det"), pkg.Net("det")
+    want = np.concatenate([o.run(im[None]).reshape(-1) for im in imgs])
+    assert np.array_equal(want, g.forward_ragged_images(imgs, keep_all=False).reshape(-1)), "ragged det"
+    g.close()
 print("AB OK")
 """
 

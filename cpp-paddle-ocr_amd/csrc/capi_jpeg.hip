@@ -9,7 +9,7 @@
 namespace ocr {
 
 JpegScratch::~JpegScratch() {
-  if (pinned) (void)hipHostFree(pinned);
+  if (pinned) (void)g_host_free(pinned);
   if (copied) (void)hipEventDestroy(copied);
 }
 
@@ -55,10 +55,10 @@ int jpeg_decode_async(const ocr_jpeg_img* imgs, int count, uint8_t* const* dst, 
   if (!sc.copied && hipEventCreateWithFlags(&sc.copied, hipEventDisableTiming) != hipSuccess) { err = "hipEventCreate failed"; return OCR_ERR_DEVICE; }
   if (sc.pinned && hipEventSynchronize(sc.copied) != hipSuccess) { err = "staging event failed"; return OCR_ERR_DEVICE; }
   if (ncoef > sc.pinned_cap) {
-    if (sc.pinned) (void)hipHostFree(sc.pinned);
+    if (sc.pinned) (void)g_host_free(sc.pinned);
     sc.pinned = nullptr;
     sc.pinned_cap = 0;
-    if (hipHostMalloc((void**)&sc.pinned, ncoef * sizeof(int16_t), hipHostMallocDefault) != hipSuccess) { err = "hipHostMalloc failed"; return OCR_ERR_DEVICE; }
+    if (g_host_malloc((void**)&sc.pinned, ncoef * sizeof(int16_t), hipHostMallocDefault) != hipSuccess) { err = "hipHostMalloc failed"; return OCR_ERR_DEVICE; }
     sc.pinned_cap = ncoef;
   }
   {  // coefficient arrays -> pinned memory, a few host threads
@@ -120,6 +120,6 @@ extern "C" int ocr_jpeg_decode(const ocr_jpeg_img* img, int device_id, uint8_t* 
   uint8_t* dst = out.p;
   rc = jpeg_decode_async(img, 1, &dst, sc, nullptr, err);
   if (rc) return fail(rc, err);
-  CAPI_HIP(hipMemcpy(bgr, out.p, bytes, hipMemcpyDeviceToHost));
+  CAPI_HIP(g_memcpy(bgr, out.p, bytes, hipMemcpyDeviceToHost));
   return OCR_OK;
 }

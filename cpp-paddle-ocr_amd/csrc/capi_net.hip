@@ -53,6 +53,11 @@ void rt_set_refuse_launch(const char* substr) {
   g_refuse_on.store(!g_refuse.empty(), std::memory_order_release);
 }
 
+std::shared_mutex& capture_mutex() {
+  static std::shared_mutex m;
+  return m;
+}
+
 static thread_local std::string g_last_error;
 void set_last_error(const std::string& msg) { g_last_error = msg; }
 int fail(int code, const std::string& msg) {
@@ -177,7 +182,7 @@ int ocr_net_create(const char* kind, const char* model_dir, const char* weights,
   std::unique_ptr<ocr_net> h(new ocr_net());
   h->device = device_id;
   if (!h->net.load(plan, w, err)) return fail(OCR_ERR_MODEL, err);
-  CAPI_HIP(hipStreamCreate(&h->stream));
+  CAPI_HIP(g_stream_create(&h->stream));
   *out = h.release();
   return OCR_OK;
 }
@@ -185,7 +190,7 @@ int ocr_net_create(const char* kind, const char* model_dir, const char* weights,
 void ocr_net_destroy(ocr_net* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
-  if (h->x_dev) (void)hipFree(h->x_dev);
+  if (h->x_dev) (void)g_free(h->x_dev);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
@@ -195,10 +200,10 @@ int ocr_net_forward(ocr_net* h, const float* x, int N, int H, int W, int keep_al
   CAPI_HIP(hipSetDevice(h->device));
   const size_t n = (size_t)N * H * W * 3;
   if (n > h->x_cap) {
-    if (h->x_dev) (void)hipFree(h->x_dev);
+    if (h->x_dev) (void)g_free(h->x_dev);
     h->x_dev = nullptr;
     h->x_cap = 0;
-    CAPI_HIP(hipMalloc(&h->x_dev, n * sizeof(float)));
+    CAPI_HIP(g_malloc(&h->x_dev, n * sizeof(float)));
     h->x_cap = n;
   }
   CAPI_HIP(hipMemcpyAsync(h->x_dev, x, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
@@ -219,10 +224,10 @@ int ocr_net_forward_ragged(ocr_net* h, const float* x, int N, int H, const int* 
     n += (size_t)H * widths[i] * 3;
   }
   if (n > h->x_cap) {
-    if (h->x_dev) (void)hipFree(h->x_dev);
+    if (h->x_dev) (void)g_free(h->x_dev);
     h->x_dev = nullptr;
     h->x_cap = 0;
-    CAPI_HIP(hipMalloc(&h->x_dev, n * sizeof(float)));
+    CAPI_HIP(g_malloc(&h->x_dev, n * sizeof(float)));
     h->x_cap = n;
   }
   CAPI_HIP(hipMemcpyAsync(h->x_dev, x, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
@@ -244,10 +249,10 @@ int ocr_net_forward_ragged_images(ocr_net* h, const float* x, int N, const int* 
     n += (size_t)heights[i] * widths[i] * 3;
   }
   if (n > h->x_cap) {
-    if (h->x_dev) (void)hipFree(h->x_dev);
+    if (h->x_dev) (void)g_free(h->x_dev);
     h->x_dev = nullptr;
     h->x_cap = 0;
-    CAPI_HIP(hipMalloc(&h->x_dev, n * sizeof(float)));
+    CAPI_HIP(g_malloc(&h->x_dev, n * sizeof(float)));
     h->x_cap = n;
   }
   CAPI_HIP(hipMemcpyAsync(h->x_dev, x, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
@@ -338,14 +343,14 @@ int ocr_selftest_lds_memo(void) {
 int ocr_probe(const float* a, const float* b, float* out, int n) {
   if (!a || !b || !out || n <= 0) return fail(OCR_ERR_ARG, "bad argument");
   float *da = nullptr, *db = nullptr, *dout = nullptr;
-  CAPI_HIP(hipMalloc(&da, n * sizeof(float)));
-  CAPI_HIP(hipMalloc(&db, n * sizeof(float)));
-  CAPI_HIP(hipMalloc(&dout, 8 * (size_t)n * sizeof(float)));
-  CAPI_HIP(hipMemcpy(da, a, n * sizeof(float), hipMemcpyHostToDevice));
-  CAPI_HIP(hipMemcpy(db, b, n * sizeof(float), hipMemcpyHostToDevice));
+  CAPI_HIP(g_malloc(&da, n * sizeof(float)));
+  CAPI_HIP(g_malloc(&db, n * sizeof(float)));
+  CAPI_HIP(g_malloc(&dout, 8 * (size_t)n * sizeof(float)));
+  CAPI_HIP(g_memcpy(da, a, n * sizeof(float), hipMemcpyHostToDevice));
+  CAPI_HIP(g_memcpy(db, b, n * sizeof(float), hipMemcpyHostToDevice));
   launch_probe(da, db, dout, n, nullptr);
-  CAPI_HIP(hipMemcpy(out, dout, 8 * (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
-  (void)hipFree(da); (void)hipFree(db); (void)hipFree(dout);
+  CAPI_HIP(g_memcpy(out, dout, 8 * (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+  (void)g_free(da); (void)g_free(db); (void)g_free(dout);
   return OCR_OK;
 }
 

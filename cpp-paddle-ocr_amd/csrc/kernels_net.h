@@ -5,6 +5,7 @@
 #include <cstdlib>
 #include <vector>
 
+#include "hip_guard.h"
 #include "lds_attr.h"
 #include "ocr_common.h"
 #include "rt_options.h"

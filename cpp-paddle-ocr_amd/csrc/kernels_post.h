@@ -7,7 +7,19 @@ namespace ocr {
 
 enum : int { POST_ERR_POOL = 1, POST_ERR_HULL = 2, POST_ERR_UNCLIP = 4 };
 
+// Geometry of one image of a batch of MIXED sizes (the detector's ragged path): its map size, where its maps start in
+// the batch's buffers (bitmap / labels share one layout, the probability maps may sit elsewhere), and the numbers
+// FilterTagDetRes needs (postprocess_op.cpp:333-362).
+struct PostImg {
+  int h, w;
+  int off;    // first pixel in bitmap / labels / touch
+  int poff;   // first float in pred
+  int src_h, src_w;
+  float ratio_h, ratio_w;
+};
+
 struct PostArgs {
+  const PostImg* img = nullptr;  // [N] device; null: N maps of H x W one after the other, one ratio / source size
   const uint8_t* bitmap;  // [N][H][W] {0,1}
   const float* pred;      // [N][H][W]
   int* labels;            // [N*H*W]

@@ -83,12 +83,16 @@ __device__ __forceinline__ void uf_unite(int* L, int a, int b) {
 // Initial labels = start pixel of the horizontal run (same value as the left neighbours) a pixel lies in:
 // one wave walks one image row in 64-pixel segments (ballot + carry), so the union-find below only
 // has to join RUNS, not pixels.
+// (grid: rows / 4 x images; `img` != null: a batch of mixed sizes, H x W is the largest)
 __global__ void __launch_bounds__(256) ccl_rows_kernel(const uint8_t* __restrict__ bm, int* __restrict__ L,
-                                                       uint8_t* __restrict__ touch, int N, int H, int W) {
+                                                       uint8_t* __restrict__ touch, int N, int H, int W, const PostImg* __restrict__ img) {
   const int lane = threadIdx.x & 63;
-  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= (long)N * H) return;
-  const long base = row * W;
+  const int n = blockIdx.y;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  long base0 = (long)n * H * W;
+  if (img) { H = img[n].h; W = img[n].w; base0 = img[n].off; }
+  if (row >= H) return;
+  const long base = base0 + (long)row * W;
   int carry = 0;
   for (int x0 = 0; x0 < W; x0 += 64) {
     const int x = x0 + lane;
@@ -110,11 +114,14 @@ __device__ __forceinline__ bool run_start(const uint8_t* bm, long i, int x) { re
 // (one wave per image row, walking it in 64-pixel segments as ccl_rows_kernel does: a flat pixel index costs two
 // 64-bit divisions per thread, most of this kernel's instructions)
 __global__ void __launch_bounds__(256) ccl_merge_kernel(const uint8_t* __restrict__ bm, int* __restrict__ L, int N, int H,
-                                                        int W) {
+                                                        int W, const PostImg* __restrict__ img) {
   const int lane = threadIdx.x & 63;
-  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= (long)N * H || row % H == 0) return;  // the first row of an image has nothing above it
-  const long base = row * W;
+  const int n = blockIdx.y;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  long base0 = (long)n * H * W;
+  if (img) { H = img[n].h; W = img[n].w; base0 = img[n].off; }
+  if (row >= H || row == 0) return;  // the first row of an image has nothing above it
+  const long base = base0 + (long)row * W;
   for (int x0 = 0; x0 < W; x0 += 64) {
     const int x = x0 + lane;
     if (x >= W) break;
@@ -135,24 +142,26 @@ __global__ void __launch_bounds__(256) ccl_merge_kernel(const uint8_t* __restric
 // frame test of the BACKGROUND components (a hole border exists only for a background component that does not reach the
 // frame): one thread per frame pixel marks the root of its component.
 __global__ void __launch_bounds__(256) ccl_frame_kernel(const uint8_t* __restrict__ bm, const int* __restrict__ L,
-                                                        uint8_t* __restrict__ touch, int N, int H, int W) {
+                                                        uint8_t* __restrict__ touch, int N, int H, int W, const PostImg* __restrict__ img) {
+  const int n = blockIdx.y;
+  long base0 = (long)n * H * W;
+  if (img) { H = img[n].h; W = img[n].w; base0 = img[n].off; }
   const int per = 2 * W + 2 * H;  // top row, bottom row, left column, right column (corners twice: harmless)
-  const long t = (long)blockIdx.x * 256 + threadIdx.x;
-  if (t >= (long)N * per) return;
-  const int n = (int)(t / per), k = (int)(t - (long)n * per);
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= per) return;
   int x, y;
   if (k < W) { x = k; y = 0; }
   else if (k < 2 * W) { x = k - W; y = H - 1; }
   else if (k < 2 * W + H) { x = 0; y = k - 2 * W; }
   else { x = W - 1; y = k - 2 * W - H; }
-  const long i = ((long)n * H + y) * W + x;
+  const long i = base0 + (long)y * W + x;
   if (!bm[i]) touch[uf_find(L, (int)i)] = 1;  // background component reaches the frame
 }
-void launch_ccl(const uint8_t* bm, int* L, uint8_t* touch, int N, int H, int W, hipStream_t s) {
-  hipLaunchKernelGGL(ccl_rows_kernel, dim3((unsigned)(((long)N * H + 3) / 4)), dim3(256), 0, s, bm, L, touch, N, H, W);
-  hipLaunchKernelGGL(ccl_merge_kernel, dim3((unsigned)(((long)N * H + 3) / 4)), dim3(256), 0, s, bm, L, N, H, W);
-  const long frame = (long)N * (2 * W + 2 * H);
-  hipLaunchKernelGGL(ccl_frame_kernel, dim3((unsigned)((frame + 255) / 256)), dim3(256), 0, s, bm, L, touch, N, H, W);
+void launch_ccl(const uint8_t* bm, int* L, uint8_t* touch, int N, int H, int W, const PostImg* img, hipStream_t s) {
+  // (images are the grid's y dimension, as in the kernels below: a batch stays far below its 65535 limit)
+  hipLaunchKernelGGL(ccl_rows_kernel, dim3((unsigned)((H + 3) / 4), N), dim3(256), 0, s, bm, L, touch, N, H, W, img);
+  hipLaunchKernelGGL(ccl_merge_kernel, dim3((unsigned)((H + 3) / 4), N), dim3(256), 0, s, bm, L, N, H, W, img);
+  hipLaunchKernelGGL(ccl_frame_kernel, dim3((unsigned)((2 * W + 2 * H + 255) / 256), N), dim3(256), 0, s, bm, L, touch, N, H, W, img);
 }
 
 // ------------------------------------------------------------------ 3. border starts, reference order
@@ -166,11 +175,12 @@ __device__ __forceinline__ bool is_start(const uint8_t* bm, const int* L, const 
 #define START_CHUNKS 128
 __global__ void __launch_bounds__(256) starts_count_kernel(const uint8_t* __restrict__ bm, const int* __restrict__ L,
                                                            const uint8_t* __restrict__ touch, int H, int W,
-                                                           int* __restrict__ chunk_cnt) {
+                                                           int* __restrict__ chunk_cnt, const PostImg* __restrict__ img) {
   __shared__ int wsum[4];
   const int n = blockIdx.y, c = blockIdx.x;
+  long base = (long)n * H * W;
+  if (img) { H = img[n].h; W = img[n].w; base = img[n].off; }
   const int per = H * W, chunk = (per + START_CHUNKS - 1) / START_CHUNKS;
-  const long base = (long)n * per;
   const int lo = c * chunk, hi = min(per, lo + chunk);
   int cnt = 0;
   for (int i = lo + threadIdx.x; i < hi; i += 256) cnt += is_start(bm, L, touch, base, i) ? 1 : 0;
@@ -196,12 +206,13 @@ __global__ void __launch_bounds__(64) starts_scan_kernel(int* __restrict__ chunk
 __global__ void __launch_bounds__(256) starts_write_kernel(const uint8_t* __restrict__ bm, const int* __restrict__ L,
                                                            const uint8_t* __restrict__ touch, int H, int W, int max_cand,
                                                            const int* __restrict__ chunk_off, const int* __restrict__ ncont_all,
-                                                           int* __restrict__ starts /*[N][max_cand]*/) {
+                                                           int* __restrict__ starts /*[N][max_cand]*/, const PostImg* __restrict__ img) {
   __shared__ int wsum[4];
   __shared__ int running;
   const int n = blockIdx.y, c = blockIdx.x;
+  long base = (long)n * H * W;
+  if (img) { H = img[n].h; W = img[n].w; base = img[n].off; }
   const int per = H * W, chunk = (per + START_CHUNKS - 1) / START_CHUNKS;
-  const long base = (long)n * per;
   const int lo = c * chunk, hi = min(per, lo + chunk);
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int total = ncont_all[n];
@@ -227,11 +238,11 @@ __global__ void __launch_bounds__(256) starts_write_kernel(const uint8_t* __rest
   }
 }
 void launch_starts(const uint8_t* bm, const int* L, const uint8_t* touch, int N, int H, int W, int max_cand, int* ncont_all,
-                   int* ncont, int* starts, int* chunk_cnt, hipStream_t s) {
-  hipLaunchKernelGGL(starts_count_kernel, dim3(START_CHUNKS, N), dim3(256), 0, s, bm, L, touch, H, W, chunk_cnt);
+                   int* ncont, int* starts, int* chunk_cnt, const PostImg* img, hipStream_t s) {
+  hipLaunchKernelGGL(starts_count_kernel, dim3(START_CHUNKS, N), dim3(256), 0, s, bm, L, touch, H, W, chunk_cnt, img);
   hipLaunchKernelGGL(starts_scan_kernel, dim3(N), dim3(64), 0, s, chunk_cnt, max_cand, ncont_all, ncont);
   hipLaunchKernelGGL(starts_write_kernel, dim3(START_CHUNKS, N), dim3(256), 0, s, bm, L, touch, H, W, max_cand, chunk_cnt,
-                     ncont_all, starts);
+                     ncont_all, starts, img);
 }
 
 // ------------------------------------------------------------------ 4. border following (icvFetchContour)
@@ -349,11 +360,12 @@ __device__ __forceinline__ void contour_origin(const uint8_t* bm, long base, int
 // pass A: count vertices per border.  one lane per border.
 __global__ void __launch_bounds__(64) trace_count_kernel(const uint8_t* __restrict__ bm, int H, int W, int max_cand,
                                                          const int* __restrict__ ncont, const int* __restrict__ starts,
-                                                         int* __restrict__ npts) {
+                                                         int* __restrict__ npts, const PostImg* __restrict__ img) {
   const int n = blockIdx.y;
   const int c = blockIdx.x * 64 + threadIdx.x;
   if (c >= ncont[n]) return;
-  const long base = (long)n * H * W;
+  long base = (long)n * H * W;
+  if (img) { H = img[n].h; W = img[n].w; base = img[n].off; }
   int ox, oy;
   bool hole;
   contour_origin(bm, base, starts[(long)n * max_cand + c], W, ox, oy, hole);
@@ -384,14 +396,15 @@ __global__ void __launch_bounds__(64) trace_offsets_kernel(int max_cand, const i
 __global__ void __launch_bounds__(64) trace_store_kernel(const uint8_t* __restrict__ bm, int H, int W, int max_cand,
                                                          const int* __restrict__ ncont, const int* __restrict__ starts,
                                                          const int* __restrict__ npts, const int* __restrict__ poff,
-                                                         unsigned long long* __restrict__ pool, int pool_cap) {
+                                                         unsigned long long* __restrict__ pool, int pool_cap, const PostImg* __restrict__ img) {
   const int n = blockIdx.y;
   const int c = blockIdx.x * 64 + threadIdx.x;
   if (c >= ncont[n]) return;
   const long ci = (long)n * max_cand + c;
   const int sz = npts[ci];
   if (sz <= 2 || poff[ci] < 0) return;
-  const long base = (long)n * H * W;
+  long base = (long)n * H * W;
+  if (img) { H = img[n].h; W = img[n].w; base = img[n].off; }
   int ox, oy;
   bool hole;
   contour_origin(bm, base, starts[ci], W, ox, oy, hole);
@@ -409,10 +422,12 @@ __global__ void __launch_bounds__(kTraceThreads) trace_lds_kernel(const uint8_t*
                                                         const int* __restrict__ ncont, const int* __restrict__ starts,
                                                         int* __restrict__ npts, int* __restrict__ poff,
                                                         unsigned long long* __restrict__ pool, int pool_cap,
-                                                        int* __restrict__ iscratch, int slice_limit, int* __restrict__ status) {
+                                                        int* __restrict__ iscratch, int slice_limit, int* __restrict__ status,
+                                                        const PostImg* __restrict__ img) {
   extern __shared__ unsigned s_bits[];
   const int n = blockIdx.x, tid = threadIdx.x;
-  const long base = (long)n * H * W;
+  long base = (long)n * H * W;
+  if (img) { H = img[n].h; W = img[n].w; base = img[n].off; }  // (LDS is sized for the largest image of the batch)
   const int stride = lds_bits_stride(W);
   const int nc = ncont[n];
   if (nc == 0) return;
@@ -1267,6 +1282,15 @@ __global__ void __launch_bounds__(64) border_box_kernel(const PostArgs a) {
   const long ci = (long)n * a.max_cand + c;
   int* obox = a.cand_boxes + ci * 8;
   if (c >= a.ncont[n]) return;
+  // the image's own map size / source size / ratios in a batch of mixed sizes
+  int g_H = a.H, g_W = a.W, g_src_h = a.src_h, g_src_w = a.src_w;
+  float g_ratio_h = a.ratio_h, g_ratio_w = a.ratio_w;
+  const float* g_pred = a.pred + (long)n * a.H * a.W;
+  if (a.img) {
+    const PostImg im = a.img[n];
+    g_H = im.h; g_W = im.w; g_src_h = im.src_h; g_src_w = im.src_w; g_ratio_h = im.ratio_h; g_ratio_w = im.ratio_w;
+    g_pred = a.pred + im.poff;
+  }
   if (lane == 0) a.cand_valid[ci] = 0;
   const int total = a.npts[ci];
   if (total <= 2 || a.poff[ci] < 0) return;  // contours[i].size() <= 2 -> continue
@@ -1323,11 +1347,11 @@ __global__ void __launch_bounds__(64) border_box_kernel(const PostArgs a) {
       __threadfence_block();
       __syncthreads();
     }
-    score = polygon_score_wave(gkeys, total, a.pred + (long)n * a.H * a.W, a.H, a.W, a.mask_pool + (size_t)n * a.mask_pool_words,
+    score = polygon_score_wave(gkeys, total, g_pred, g_H, g_W, a.mask_pool + (size_t)n * a.mask_pool_words,
                                a.mask_pool_words, a.mask_pool_top + n, lane, &s_flag);
     if (score < 0.f) { if (lane == 0) atomicOr(a.status, POST_ERR_POOL); return; }
   } else {
-    score = box_score_fast_wave(arr, a.pred + (long)n * a.H * a.W, a.H, a.W, lane);
+    score = box_score_fast_wave(arr, g_pred, g_H, g_W, lane);
   }
   if (score < a.box_thresh) return;
   if (lane != 0) return;
@@ -1368,7 +1392,7 @@ __global__ void __launch_bounds__(64) border_box_kernel(const PostArgs a) {
   get_mini_boxes(pts, ssid, clip);
   if (ssid < 5.0f) return;  // min_size + 2
   int b[4][2];
-  const float fw = (float)a.W, fh = (float)a.H;
+  const float fw = (float)g_W, fh = (float)g_H;
   for (int k = 0; k < 4; ++k) {
     float vx = roundf(clip[k].x / fw * fw), vy = roundf(clip[k].y / fh * fh);
     vx = vx > fw ? fw : (vx < 0 ? 0 : vx);
@@ -1394,10 +1418,10 @@ __global__ void __launch_bounds__(64) border_box_kernel(const PostArgs a) {
   const int ord[4] = {l0, r0, r1, l1};
   int f[4][2];
   for (int m = 0; m < 4; ++m) {
-    int x = (int)((float)b[ord[m]][0] / a.ratio_w);
-    int y = (int)((float)b[ord[m]][1] / a.ratio_h);
-    x = min(max(x, 0), a.src_w - 1);
-    y = min(max(y, 0), a.src_h - 1);
+    int x = (int)((float)b[ord[m]][0] / g_ratio_w);
+    int y = (int)((float)b[ord[m]][1] / g_ratio_h);
+    x = min(max(x, 0), g_src_w - 1);
+    y = min(max(y, 0), g_src_h - 1);
     f[m][0] = x; f[m][1] = y;
   }
   const double dw0 = (double)(f[0][0] - f[1][0]), dw1 = (double)(f[0][1] - f[1][1]);
@@ -1427,8 +1451,8 @@ __global__ void __launch_bounds__(64) boxes_compact_kernel(const PostArgs a, int
 }
 
 void launch_post(const PostArgs& a, int N, int* out_boxes, int cap, int* out_n, hipStream_t s) {
-  launch_ccl(a.bitmap, a.labels, a.touch, N, a.H, a.W, s);
-  launch_starts(a.bitmap, a.labels, a.touch, N, a.H, a.W, a.max_cand, a.ncont_all, a.ncont, a.starts, a.chunk_cnt, s);
+  launch_ccl(a.bitmap, a.labels, a.touch, N, a.H, a.W, a.img, s);
+  launch_starts(a.bitmap, a.labels, a.touch, N, a.H, a.W, a.max_cand, a.ncont_all, a.ncont, a.starts, a.chunk_cnt, a.img, s);
   const dim3 gl((a.max_cand + 63) / 64, N);
   const size_t lds = ((size_t)(a.H + 2) * lds_bits_stride(a.W) + 2 * (size_t)a.max_cand) * sizeof(unsigned);  // bitmap bits + sizes + offsets
   bool in_lds = lds <= 150 * 1024;  // 960x960: 119 KB
@@ -1440,12 +1464,12 @@ void launch_post(const PostArgs& a, int N, int* out_boxes, int cap, int* out_n, 
     // OCR_TRACE_SLICE (tests): cap on a border's provisional slice, to drive the second-walk path with small inputs
     const int slice_limit = rt_options().trace_slice > 0 ? rt_options().trace_slice : INT_MAX;
     hipLaunchKernelGGL(trace_lds_kernel, dim3(N), dim3(kTraceThreads), lds, s, a.bitmap, a.H, a.W, a.max_cand, a.ncont, a.starts, a.npts, a.poff,
-                       a.pool, a.pool_cap, a.iscratch, slice_limit, a.status);
+                       a.pool, a.pool_cap, a.iscratch, slice_limit, a.status, a.img);
   } else {
-    hipLaunchKernelGGL(trace_count_kernel, gl, dim3(64), 0, s, a.bitmap, a.H, a.W, a.max_cand, a.ncont, a.starts, a.npts);
+    hipLaunchKernelGGL(trace_count_kernel, gl, dim3(64), 0, s, a.bitmap, a.H, a.W, a.max_cand, a.ncont, a.starts, a.npts, a.img);
     hipLaunchKernelGGL(trace_offsets_kernel, dim3(N), dim3(64), 0, s, a.max_cand, a.ncont, a.npts, a.poff, a.pool_cap, a.status);
     hipLaunchKernelGGL(trace_store_kernel, gl, dim3(64), 0, s, a.bitmap, a.H, a.W, a.max_cand, a.ncont, a.starts, a.npts, a.poff,
-                       a.pool, a.pool_cap);
+                       a.pool, a.pool_cap, a.img);
   }
   hipLaunchKernelGGL((border_box_kernel<512, 512, 256, false>), dim3(a.max_cand, N), dim3(64), 0, s, a);
   hipLaunchKernelGGL(boxes_compact_kernel, dim3(N), dim3(64), 0, s, a, out_boxes, cap, out_n);

@@ -139,7 +139,7 @@ class Net {
   // device memory of the ragged bindings' line tables: handed back when a binding dies, freed with the network
   struct TablePool {
     std::vector<std::pair<int*, size_t>> free_list;
-    ~TablePool() { for (auto& e : free_list) (void)hipFree(e.first); }
+    ~TablePool() { for (auto& e : free_list) (void)g_free(e.first); }
   };
   struct Binding {
     int n = 0, h = 0, w = 0;
@@ -165,7 +165,7 @@ class Net {
     ~Binding() {
       if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
       if (rag_dev && pool) pool->free_list.emplace_back(rag_dev, rag_cap);
-      else if (rag_dev) (void)hipFree(rag_dev);
+      else if (rag_dev) (void)g_free(rag_dev);
     }
   };
   std::shared_ptr<TablePool> pool_ = std::make_shared<TablePool>();

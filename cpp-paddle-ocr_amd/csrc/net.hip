@@ -125,10 +125,10 @@ bool parse_plan(const char* text, Plan& plan, std::string& err) {
 
 // ------------------------------------------------------------------ weights
 Net::~Net() {
-  for (auto& kv : dev_) (void)hipFree(kv.second);
-  if (arena_) (void)hipFree(arena_);
-  if (gap_part_) (void)hipFree(gap_part_);
-  if (head_part_) (void)hipFree(head_part_);
+  for (auto& kv : dev_) (void)g_free(kv.second);
+  if (arena_) (void)g_free(arena_);
+  if (gap_part_) (void)g_free(gap_part_);
+  if (head_part_) (void)g_free(head_part_);
   cache_.clear();
   for (auto e : ev_pool_) (void)hipEventDestroy(e);
   for (auto& p : ev_pending_) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
@@ -139,8 +139,8 @@ float* Net::upload(const std::string& key, const std::vector<float>& v) {
   if (it != dev_.end()) return it->second;
   float* d = nullptr;
   size_t bytes = std::max<size_t>(v.size(), 4) * sizeof(float);
-  if (hipMalloc(&d, bytes) != hipSuccess) return nullptr;
-  if (!v.empty() && hipMemcpy(d, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+  if (g_malloc(&d, bytes) != hipSuccess) return nullptr;
+  if (!v.empty() && g_memcpy(d, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
   dev_[key] = d;
   return d;
 }
@@ -605,7 +605,7 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths, const i
       }
     if (!B->rag_dev) {
       const size_t cap = tab_cap + tab_cap / 2;
-      HIP_OK(hipMalloc(&B->rag_dev, cap * sizeof(int)));
+      HIP_OK(g_malloc(&B->rag_dev, cap * sizeof(int)));
       B->rag_cap = cap;
     }
   }
@@ -798,19 +798,19 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths, const i
   for (int t = 1; t < plan_.ntensors; ++t) B->exists[t] = !dead[t];
   for (int t = 1; t < plan_.ntensors; ++t) if (!dead[t]) high = std::max(high, T[t].offset + ((T[t].numel() + 63) & ~(size_t)63));
   if (high > arena_cap_) {
-    if (arena_) (void)hipFree(arena_);
+    if (arena_) (void)g_free(arena_);
     moved = true;
     arena_ = nullptr;
     arena_cap_ = 0;
-    HIP_OK(hipMalloc(&arena_, (high + 64) * sizeof(float)));  // + 256 B: conv1x1 block loads may run past the last row
+    HIP_OK(g_malloc(&arena_, (high + 64) * sizeof(float)));  // + 256 B: conv1x1 block loads may run past the last row
     arena_cap_ = high;
   }
   if (gap_need > gap_part_cap_) {
-    if (gap_part_) (void)hipFree(gap_part_);
+    if (gap_part_) (void)g_free(gap_part_);
     moved = true;
     gap_part_ = nullptr;
     gap_part_cap_ = 0;
-    HIP_OK(hipMalloc(&gap_part_, gap_need * sizeof(float)));
+    HIP_OK(g_malloc(&gap_part_, gap_need * sizeof(float)));
     gap_part_cap_ = gap_need;
   }
   // 3. launches
@@ -918,11 +918,11 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths, const i
             const int groups = a.NTtot / nt;
             const size_t need = (size_t)hrows * groups * 3;
             if (need > head_part_cap_) {
-              if (head_part_) (void)hipFree(head_part_);
+              if (head_part_) (void)g_free(head_part_);
               moved = true;
               head_part_ = nullptr;
               head_part_cap_ = 0;
-              HIP_OK(hipMalloc(&head_part_, need * sizeof(float)));
+              HIP_OK(g_malloc(&head_part_, need * sizeof(float)));
               head_part_cap_ = need;
             }
             a.head_max = head_part_;
@@ -1289,6 +1289,7 @@ bool Net::run_bound(const float* x, hipStream_t s, std::string& err) {
     if (B.graph_exec) { (void)hipGraphExecDestroy(B.graph_exec); B.graph_exec = nullptr; }
     hipGraph_t g = nullptr;
     bool ok = false;
+    std::unique_lock<std::shared_mutex> capture_lock(capture_mutex());  // (hip_guard.h: no allocation / synchronous copy of another thread meanwhile)
     if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
       for (auto& L : B.launches) issue(L);
       ok = hipStreamEndCapture(s, &g) == hipSuccess && g && launch_error_.empty() &&
@@ -1296,6 +1297,7 @@ bool Net::run_bound(const float* x, hipStream_t s, std::string& err) {
       if (g) (void)hipGraphDestroy(g);
       if (!launch_error_.empty()) { B.graph_exec = nullptr; B.graph_failed = true; err = launch_error_; return false; }
     }
+    capture_lock.unlock();
     if (ok) {
       B.graph_x = x;
       B.graph_stream = s;
@@ -1358,11 +1360,11 @@ bool Net::fetch_logical(int tid, std::vector<float>& host, int dims[4], hipStrea
     return true;
   }
   float* tmp = nullptr;
-  HIP_OK(hipMalloc(&tmp, host.size() * sizeof(float)));
+  HIP_OK(g_malloc(&tmp, host.size() * sizeof(float)));
   launch_c8i_to_plain(arena_ + t.offset, tmp, M, t.c, t.cs, s);
   hipError_t e = hipMemcpyAsync(host.data(), tmp, host.size() * sizeof(float), hipMemcpyDeviceToHost, s);
   if (e == hipSuccess) e = hipStreamSynchronize(s);
-  (void)hipFree(tmp);
+  (void)g_free(tmp);
   if (e != hipSuccess) { err = hipGetErrorString(e); return false; }
   return true;
 }

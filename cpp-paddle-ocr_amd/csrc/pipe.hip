@@ -41,7 +41,7 @@ struct StageSlot {
   bool has_probs = false, staged = false;
   hipEvent_t ready = nullptr;
   ~StageSlot() {
-    if (pinned) (void)hipHostFree(pinned);
+    if (pinned) (void)g_host_free(pinned);
     if (ready) (void)hipEventDestroy(ready);
   }
 };
@@ -106,6 +106,7 @@ struct PipeWorker {
   DetConfig det_cfg;
   int det_lanes = 8;
   bool det_ragged = true;  // OCR_DET_RAGGED=0: mixed-size batches as one detector pass per distinct size (rounds 1-2)
+  bool det_post_ragged = true;  // OCR_DET_RAGGED=net: ragged network, BoxesFromBitmap per size group on the lanes
   RecStage rec;
   std::unique_ptr<ClsStage> cls;
   DevBuf<RotDesc> rot_desc;
@@ -165,33 +166,69 @@ struct PipeWorker {
         { float a, b; DetStage::resize_shape(g.rows, g.cols, det.cfg().limit_type, det.cfg().limit_side_len, rh, rw, a, b); }
         gpx[gi] = (size_t)g.count * rh * rw;
       }
-      const size_t budget = (size_t)64 << 20;
+      static const size_t budget = [] { const char* e = getenv("OCR_DET_CHUNK_MP"); return (size_t)(e && atoi(e) > 0 ? atoi(e) : 64) << 20; }();
+      // chunk k+1's network pass is enqueued (on the other of two detector instances: own arena, own maps) BEFORE the
+      // host threads go through chunk k's per-group post-processing, so that the latency-bound post of one chunk runs
+      // under the dense kernels of the next
+      std::vector<std::pair<size_t, size_t>> chunks;
       for (size_t g0 = 0; g0 < groups.size();) {
         size_t g1 = g0, px = 0;
         while (g1 < groups.size() && (g1 == g0 || px + gpx[g1] <= budget)) px += gpx[g1++];
-        int rc = det.mixed_net(base, mg.data() + g0, (int)(g1 - g0), probs, err);
-        if (rc) return rc;
-        std::vector<int> rcs(lanes, OCR_OK);
-        std::vector<std::string> errs(lanes);
+        chunks.emplace_back(g0, g1);
+        g0 = g1;
+      }
+      auto net_stage = [&](size_t k) -> DetStage& { return (k & 1) && lanes > 1 ? *det_extra[0] : det; };
+      auto start = [&](size_t k) {
+        return net_stage(k).mixed_net(base, mg.data() + chunks[k].first, (int)(chunks[k].second - chunks[k].first), probs, err);
+      };
+      int rc = start(0);
+      if (rc) return rc;
+      for (size_t k = 0; k < chunks.size(); ++k) {
+        const size_t g0 = chunks[k].first, g1 = chunks[k].second;
+        DetStage& src = net_stage(k);
+        const bool more = k + 1 < chunks.size();
+        if (more) {
+          // the next chunk's stage must have finished ITS previous chunk's post work (it was a lane two chunks ago: joined)
+          rc = start(k + 1);
+          if (rc) return rc;
+        }
+        if (!det.cfg().use_dilation && det_post_ragged) {
+          // every image of the chunk through ONE pass of the post-processing kernels (each takes its image's own map
+          // size), on the stage that ran the chunk's network; it ends with a stream synchronisation
+          const auto& gf = groups[g0];
+          rc = src.post_mixed(mg.data() + g0, (int)(g1 - g0), boxes.data() + (size_t)gf.first * kCap * 8, kCap, nbox.data() + gf.first, err);
+          if (rc) return rc;
+          src.collect_timings();
+          continue;
+        }
+        DetStage* busy = more && lanes > 1 ? &net_stage(k + 1) : nullptr;   // its stream is taken by the next chunk's network
+        std::vector<DetStage*> post;
+        for (int l = 0; l < lanes; ++l) {
+          DetStage* d = l == 0 ? &det : det_extra[l - 1].get();
+          if (d != busy) post.push_back(d);
+        }
+        const int np = (int)post.size();
+        std::vector<int> rcs(np, OCR_OK);
+        std::vector<std::string> errs(np);
         auto lane_fn = [&](int l) {
-          DetStage& d = l == 0 ? det : *det_extra[l - 1];
-          for (size_t gi = g0 + l; gi < g1; gi += lanes) {
+          DetStage& d = *post[l];
+          for (size_t gi = g0 + l; gi < g1; gi += np) {
             const auto& g = groups[gi];
-            rcs[l] = d.post_group(det.mixed_prob((int)(gi - g0)), det.mixed_bitmap((int)(gi - g0)), mg[gi], l == 0 ? nullptr : det.done(),
+            rcs[l] = d.post_group(src.mixed_prob((int)(gi - g0)), src.mixed_bitmap((int)(gi - g0)), mg[gi], &d == &src ? nullptr : src.done(),
                                   boxes.data() + (size_t)g.first * kCap * 8, kCap, nbox.data() + g.first, errs[l]);
             if (rcs[l]) return;
           }
         };
         std::vector<std::thread> th;
-        for (int l = 1; l < lanes; ++l) th.emplace_back(lane_fn, l);
+        for (int l = 1; l < np; ++l) th.emplace_back(lane_fn, l);
         lane_fn(0);
         for (auto& t : th) t.join();
-        for (int l = 0; l < lanes; ++l)
+        for (int l = 0; l < np; ++l)
           if (rcs[l]) { err = errs[l]; return rcs[l]; }
-        // (every lane's post-processing ended with a stream synchronisation: the maps may be overwritten by the next chunk)
-        if (hipStreamSynchronize(det.stream()) != hipSuccess) { err = "det stream sync failed"; return OCR_ERR_DEVICE; }
-        det.collect_timings();
-        g0 = g1;
+        // this chunk's maps are free again once its network stage is idle (its own post lane, if any, has synchronised;
+        // when it was not a post lane the network pass itself must be over before the stage takes chunk k+2)
+        if (hipStreamSynchronize(src.stream()) != hipSuccess) { err = "det stream sync failed"; return OCR_ERR_DEVICE; }
+        src.collect_timings();
       }
     } else if (lanes <= 1) {
       for (const auto& g : groups) {
@@ -400,10 +437,10 @@ struct ocr_pipe {
     if (rc) return rc;
     const size_t off = S.bytes;
     if (off > S.pinned_cap) {
-      if (S.pinned) (void)hipHostFree(S.pinned);
+      if (S.pinned) (void)g_host_free(S.pinned);
       S.pinned = nullptr;
       S.pinned_cap = 0;
-      if (hipHostMalloc((void**)&S.pinned, off, hipHostMallocDefault) != hipSuccess) { err = "hipHostMalloc failed"; return OCR_ERR_DEVICE; }
+      if (g_host_malloc((void**)&S.pinned, off, hipHostMallocDefault) != hipSuccess) { err = "hipHostMalloc failed"; return OCR_ERR_DEVICE; }
       S.pinned_cap = off;
     }
     // host copies on a few threads (one thread moves ~10 GB/s: 64 images of 960x960 would take 18 ms)
@@ -643,7 +680,8 @@ int ocr_pipe_create(const ocr_pipe_cfg* c, ocr_pipe** out) {
   for (auto& w : h->extra) w->det_lanes = h->w0.det_lanes;
   if (const char* e = getenv("OCR_DET_RAGGED")) {
     h->w0.det_ragged = e[0] != '0';
-    for (auto& w : h->extra) w->det_ragged = h->w0.det_ragged;
+    h->w0.det_post_ragged = e[0] != 'n';
+    for (auto& w : h->extra) { w->det_ragged = h->w0.det_ragged; w->det_post_ragged = h->w0.det_post_ragged; }
   }
   // two idle high-priority streams, created after the stage objects' streams and before the detector lanes' (which
   // come into being at the first mixed-size batch): the configuration in which the lanes measured fastest (capi_net.hip)
@@ -834,11 +872,11 @@ int ocr_rotate_crop(const uint8_t* bgr, int rows, int cols, size_t row_stride, c
     wd[k].src = dimg.p + src_off[k];
     wd[k].dst = dout.p + out_off[k];
   }
-  CAPI_HIP(hipMemcpy2D(dimg.p, row, bgr, stride, row, rows, hipMemcpyHostToDevice));
-  CAPI_HIP(hipMemcpy(ddesc.p, wd.data(), n * sizeof(WarpDesc), hipMemcpyHostToDevice));
+  CAPI_HIP(g_memcpy2d(dimg.p, row, bgr, stride, row, rows, hipMemcpyHostToDevice));
+  CAPI_HIP(g_memcpy(ddesc.p, wd.data(), n * sizeof(WarpDesc), hipMemcpyHostToDevice));
   launch_warp_crops(ddesc.p, n, max_px, 0);
   CAPI_HIP(hipGetLastError());
-  CAPI_HIP(hipMemcpy(out, dout.p, total, hipMemcpyDeviceToHost));
+  CAPI_HIP(g_memcpy(out, dout.p, total, hipMemcpyDeviceToHost));
   return OCR_OK;
 }
 
@@ -856,21 +894,21 @@ int ocr_rotate180_rois(uint8_t* bgr, int rows, int cols, size_t row_stride, cons
     if (r[0] < 0 || r[1] < 0 || r[2] < 1 || r[3] < 1 || r[0] + r[2] > cols || r[1] + r[3] > rows) return fail(OCR_ERR_ARG, "rectangle outside the image");
     rd[k] = RotDesc{dimg.p, row, r[0], r[1], r[2], r[3]};
   }
-  CAPI_HIP(hipMemcpy2D(dimg.p, row, bgr, stride, row, rows, hipMemcpyHostToDevice));
+  CAPI_HIP(g_memcpy2d(dimg.p, row, bgr, stride, row, rows, hipMemcpyHostToDevice));
   const int rc = rotate180_in_order(rd, ddesc, dseg, 0, err);
   if (rc) return fail(rc, err);
-  CAPI_HIP(hipMemcpy2D(bgr, stride, dimg.p, row, row, rows, hipMemcpyDeviceToHost));
+  CAPI_HIP(g_memcpy2d(bgr, stride, dimg.p, row, row, rows, hipMemcpyDeviceToHost));
   return OCR_OK;
 }
 
 int ocr_dev_alloc(void** p, size_t bytes) {
   if (!p) return fail(OCR_ERR_ARG, "null argument");
-  CAPI_HIP(hipMalloc(p, bytes));
+  CAPI_HIP(g_malloc(p, bytes));
   return OCR_OK;
 }
-int ocr_dev_free(void* p) { CAPI_HIP(hipFree(p)); return OCR_OK; }
-int ocr_dev_upload(void* dst, const void* src, size_t bytes) { CAPI_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice)); return OCR_OK; }
-int ocr_dev_download(void* dst, const void* src, size_t bytes) { CAPI_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); return OCR_OK; }
+int ocr_dev_free(void* p) { CAPI_HIP(g_free(p)); return OCR_OK; }
+int ocr_dev_upload(void* dst, const void* src, size_t bytes) { CAPI_HIP(g_memcpy(dst, src, bytes, hipMemcpyHostToDevice)); return OCR_OK; }
+int ocr_dev_download(void* dst, const void* src, size_t bytes) { CAPI_HIP(g_memcpy(dst, src, bytes, hipMemcpyDeviceToHost)); return OCR_OK; }
 int ocr_dev_sync(void) { CAPI_HIP(hipDeviceSynchronize()); return OCR_OK; }
 
 }  // extern "C"

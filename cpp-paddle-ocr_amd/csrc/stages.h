@@ -19,13 +19,13 @@ template <class T>
 struct DevBuf {
   T* p = nullptr;
   size_t cap = 0;
-  ~DevBuf() { if (p) (void)hipFree(p); }
+  ~DevBuf() { if (p) (void)g_free(p); }
   bool ensure(size_t n, std::string& err) {
     if (n <= cap) return true;
-    if (p) (void)hipFree(p);
+    if (p) (void)g_free(p);
     p = nullptr;
     cap = 0;
-    hipError_t e = hipMalloc(&p, n * sizeof(T));
+    hipError_t e = g_malloc(&p, n * sizeof(T));
     if (e != hipSuccess) { err = std::string("hipMalloc: ") + hipGetErrorString(e); return false; }
     cap = n;
     return true;
@@ -70,6 +70,10 @@ class DetStage {
   const uint8_t* mixed_bitmap(int gi) const { return bitmap_.p + mixed_pix_[gi]; }
   hipEvent_t done() const { return mixed_done_; }
   void collect_timings() { net_.collect_timings(); }  // after the stream that ran mixed_net has been synchronised
+  // BoxesFromBitmap + FilterTagDetRes of EVERY group of the last mixed_net in one pass (the post-processing kernels
+  // take each image's own map size: kernels_post.h, PostImg); boxes [images][cap][8] and n [images] in group order.
+  // Not with use_dilation (the 2x2 dilate is per size): the caller then goes through post_group.
+  int post_mixed(const MixedGroup* groups, int ngroups, int32_t* boxes, int cap, int* n, std::string& err);
   // BoxesFromBitmap + FilterTagDetRes of one size group whose maps sit in device memory (another stage's mixed_net)
   int post_group(const float* prob, const uint8_t* bitmap, const MixedGroup& g, hipEvent_t wait_for, int32_t* boxes, int cap, int* n,
                  std::string& err);
@@ -95,6 +99,8 @@ class DetStage {
   int run_post(int count, int H, int W, const float* prob, float ratio_h, float ratio_w, int src_h, int src_w,
                int32_t* boxes, int cap, int* n, std::string& err, const uint8_t* bitmap = nullptr);
   std::vector<size_t> mixed_pix_;            // first pixel of every group in the ragged maps
+  const float* mixed_prob_base_ = nullptr;   // what post_mixed's per-image offsets are relative to
+  DevBuf<PostImg> post_img_;
   std::vector<const float*> mixed_probs_;
   hipEvent_t mixed_done_ = nullptr;
   DetConfig cfg_;

@@ -113,13 +113,13 @@ bool DetStage::create(const DetConfig& cfg, std::string& err, int& code) {
   if (!load_model_dir(cfg.model_dir, nullptr, "det", w, err)) return false;
   if (!net_.load(embedded_plan("det"), w, err)) return false;
   code = OCR_ERR_DEVICE;
-  if (hipStreamCreate(&stream_) != hipSuccess) { err = "hipStreamCreate failed"; return false; }
+  if (g_stream_create(&stream_) != hipSuccess) { err = "hipStreamCreate failed"; return false; }
   if (!timer_.init(err)) return false;
   const float mean[3] = {0.485f, 0.456f, 0.406f};                      // ocr_det.h:121
   const float scale[3] = {1 / 0.229f, 1 / 0.224f, 1 / 0.225f};        // ocr_det.h:122
   const auto lut = make_norm_lut(mean, scale);
   if (!lut_.ensure(lut.size(), err)) return false;
-  if (hipMemcpy(lut_.p, lut.data(), lut.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { err = "lut upload failed"; return false; }
+  if (g_memcpy(lut_.p, lut.data(), lut.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { err = "lut upload failed"; return false; }
   ithresh_ = (int)std::floor(cfg.thresh * 255);  // cv::threshold on 8U floors the threshold (ocr_det.cpp:151-154)
   code = OCR_OK;
   return true;
@@ -273,6 +273,7 @@ int DetStage::mixed_net(const uint8_t* base, const MixedGroup* groups, int ngrou
   if (!net_.run_ragged_images(x_.p, hs.data(), ws.data(), (int)hs.size(), stream_, err)) return OCR_ERR_DEVICE;
   timer_.mark(2, stream_);
   mixed_probs_.assign(ngroups, nullptr);
+  mixed_prob_base_ = prob_override ? prob_override : prob_dev();
   for (int gi = 0; gi < ngroups; ++gi) {
     mixed_probs_[gi] = prob_dev() + mixed_pix_[gi];
     if (prob_override) {  // the benchmark protocol: thresholding and scoring read these maps (group gi at its prob_off)
@@ -282,6 +283,78 @@ int DetStage::mixed_net(const uint8_t* base, const MixedGroup* groups, int ngrou
   }
   ST_HIP(hipEventRecord(mixed_done_, stream_));
   last_count = (int)hs.size(); last_h = 0; last_w = 0;
+  return OCR_OK;
+}
+
+int DetStage::post_mixed(const MixedGroup* groups, int ngroups, int32_t* boxes, int cap, int* n, std::string& err) {
+  ST_HIP(hipSetDevice(cfg_.device));
+  if (cfg_.use_dilation) { err = "post_mixed: not with use_dilation"; return OCR_ERR_ARG; }
+  std::vector<PostImg> im;
+  int Hm = 0, Wm = 0;
+  for (int gi = 0; gi < ngroups; ++gi) {
+    int rh, rw;
+    float ratio_h, ratio_w;
+    resize_shape(groups[gi].rows, groups[gi].cols, cfg_.limit_type, cfg_.limit_side_len, rh, rw, ratio_h, ratio_w);
+    Hm = std::max(Hm, rh); Wm = std::max(Wm, rw);
+    for (int k = 0; k < groups[gi].count; ++k) {
+      PostImg q;
+      q.h = rh; q.w = rw;
+      q.off = (int)(mixed_pix_[gi] + (size_t)k * rh * rw);
+      q.poff = (int)((mixed_probs_[gi] - mixed_prob_base_) + (size_t)k * rh * rw);
+      q.src_h = groups[gi].rows; q.src_w = groups[gi].cols; q.ratio_h = ratio_h; q.ratio_w = ratio_w;
+      im.push_back(q);
+    }
+  }
+  const int count = (int)im.size();
+  const size_t px = mixed_pix_[ngroups];
+  if (px >= (1ul << 31) || (size_t)(mixed_probs_[ngroups - 1] - mixed_prob_base_) >= (1ul << 31)) { err = "post_mixed: maps too large for 32-bit offsets"; return OCR_ERR_CAPACITY; }
+  // scratch: per pixel for the whole chunk, per image sized for the largest map
+  const int max_cand = 1000;
+  pool_cap_ = std::max(1 << 16, (Hm * Wm) / 2);
+  if (!labels_.ensure(px, err) || !touch_.ensure(px, err) || !chunk_cnt_.ensure((size_t)count * 128, err) || !ncont_all_.ensure(count, err) ||
+      !ncont_.ensure(count, err) || !starts_.ensure((size_t)count * max_cand, err) || !npts_.ensure((size_t)count * max_cand, err) ||
+      !poff_.ensure((size_t)count * max_cand, err) || !pool_.ensure((size_t)count * pool_cap_, err) ||
+      !iscratch_.ensure((size_t)count * pool_cap_ * 4, err) || !cand_boxes_.ensure((size_t)count * max_cand * 8, err) ||
+      !cand_valid_.ensure((size_t)count * max_cand, err) || !status_.ensure(1, err) || !post_img_.ensure(count, err) ||
+      !out_boxes_.ensure((size_t)count * cap * 8, err) || !out_n_.ensure(count, err) ||
+      (cfg_.score_mode == "slow" && (!mask_pool_.ensure((size_t)count * mask_words(Hm, Wm), err) || !mask_top_.ensure(count, err))))
+    return OCR_ERR_DEVICE;
+  ST_HIP(hipMemcpyAsync(post_img_.p, im.data(), (size_t)count * sizeof(PostImg), hipMemcpyHostToDevice, stream_));
+  ST_HIP(hipMemsetAsync(status_.p, 0, sizeof(int), stream_));
+  PostArgs a{};
+  a.img = post_img_.p;
+  a.bitmap = bitmap_.p; a.pred = mixed_prob_base_; a.labels = labels_.p; a.touch = touch_.p; a.chunk_cnt = chunk_cnt_.p; a.ncont_all = ncont_all_.p;
+  a.ncont = ncont_.p; a.starts = starts_.p; a.npts = npts_.p; a.poff = poff_.p; a.pool = pool_.p; a.iscratch = iscratch_.p;
+  a.cand_boxes = cand_boxes_.p; a.cand_valid = cand_valid_.p; a.status = status_.p; a.pool_cap = pool_cap_;
+  a.H = Hm; a.W = Wm; a.max_cand = max_cand;
+  a.box_thresh = (float)cfg_.box_thresh; a.unclip_ratio = (float)cfg_.unclip_ratio;
+  a.slow = cfg_.score_mode == "slow";
+  a.probe_stop = 0;
+  if (a.slow) {
+    a.mask_pool = mask_pool_.p; a.mask_pool_top = mask_top_.p; a.mask_pool_words = (unsigned)mask_words(Hm, Wm);
+    ST_HIP(hipMemsetAsync(mask_top_.p, 0, count * sizeof(unsigned), stream_));
+  }
+  launch_post(a, count, out_boxes_.p, cap, out_n_.p, stream_);
+  ST_HIP(hipGetLastError());
+  int status = 0;
+  ST_HIP(hipMemcpyAsync(n, out_n_.p, count * sizeof(int), hipMemcpyDeviceToHost, stream_));
+  ST_HIP(hipMemcpyAsync(boxes, out_boxes_.p, (size_t)count * cap * 8 * sizeof(int), hipMemcpyDeviceToHost, stream_));
+  ST_HIP(hipMemcpyAsync(&status, status_.p, sizeof(int), hipMemcpyDeviceToHost, stream_));
+  timer_.mark(3, stream_);
+  ST_HIP(hipStreamSynchronize(stream_));
+  if (status && !(status & ~(POST_ERR_HULL | POST_ERR_UNCLIP))) {  // a border outgrew the small LDS working set: the large one
+    ST_HIP(hipMemsetAsync(status_.p, 0, sizeof(int), stream_));
+    if (a.slow) ST_HIP(hipMemsetAsync(mask_top_.p, 0, count * sizeof(unsigned), stream_));
+    launch_post_large(a, count, out_boxes_.p, cap, out_n_.p, stream_);
+    ST_HIP(hipGetLastError());
+    ST_HIP(hipMemcpyAsync(n, out_n_.p, count * sizeof(int), hipMemcpyDeviceToHost, stream_));
+    ST_HIP(hipMemcpyAsync(boxes, out_boxes_.p, (size_t)count * cap * 8 * sizeof(int), hipMemcpyDeviceToHost, stream_));
+    ST_HIP(hipMemcpyAsync(&status, status_.p, sizeof(int), hipMemcpyDeviceToHost, stream_));
+    ST_HIP(hipStreamSynchronize(stream_));
+  }
+  if (status) { err = "det post-processing scratch exhausted (status " + std::to_string(status) + ")"; return OCR_ERR_CAPACITY; }
+  for (int i = 0; i < count; ++i)
+    if (n[i] > cap) { err = "more boxes than the caller's capacity"; return OCR_ERR_CAPACITY; }
   return OCR_OK;
 }
 
@@ -336,12 +409,12 @@ bool RecStage::create(const RecConfig& cfg, std::string& err, int& code) {
   if (!load_model_dir(cfg.model_dir, nullptr, "rec", w, err)) return false;
   if (!net_.load(embedded_plan("rec"), w, err)) return false;
   code = OCR_ERR_DEVICE;
-  if (hipStreamCreate(&stream_) != hipSuccess) { err = "hipStreamCreate failed"; return false; }
+  if (g_stream_create(&stream_) != hipSuccess) { err = "hipStreamCreate failed"; return false; }
   if (!timer_.init(err)) return false;
   const float mean[3] = {0.5f, 0.5f, 0.5f}, scale[3] = {1 / 0.5f, 1 / 0.5f, 1 / 0.5f};  // ocr_rec.h:108-109
   const auto lut = make_norm_lut(mean, scale);
   if (!lut_.ensure(lut.size(), err)) return false;
-  if (hipMemcpy(lut_.p, lut.data(), lut.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { err = "lut upload failed"; return false; }
+  if (g_memcpy(lut_.p, lut.data(), lut.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { err = "lut upload failed"; return false; }
   code = OCR_OK;
   return true;
 }
@@ -553,12 +626,12 @@ bool ClsStage::create(const ClsConfig& cfg, std::string& err, int& code) {
   if (!load_model_dir(cfg.model_dir, nullptr, "cls", w, err)) return false;
   if (!net_.load(embedded_plan("cls"), w, err)) return false;
   code = OCR_ERR_DEVICE;
-  if (hipStreamCreate(&stream_) != hipSuccess) { err = "hipStreamCreate failed"; return false; }
+  if (g_stream_create(&stream_) != hipSuccess) { err = "hipStreamCreate failed"; return false; }
   if (!timer_.init(err)) return false;
   const float mean[3] = {0.5f, 0.5f, 0.5f}, scale[3] = {1 / 0.5f, 1 / 0.5f, 1 / 0.5f};  // ocr_cls.h:93-94
   const auto lut = make_norm_lut(mean, scale);
   if (!lut_.ensure(lut.size(), err)) return false;
-  if (hipMemcpy(lut_.p, lut.data(), lut.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { err = "lut upload failed"; return false; }
+  if (g_memcpy(lut_.p, lut.data(), lut.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { err = "lut upload failed"; return false; }
   code = OCR_OK;
   return true;
 }

@@ -68,6 +68,8 @@ struct ConvArgs {
 };
 // false: the combination (gated input / multi-tap conv with a plain or deconv output) is not instantiated
 bool launch_conv_mfma(const ConvArgs& a, const Epilogue& ep, int nt, hipStream_t s);
+// the same with two 32-pixel tiles per wave (big single-tap convs with a C8I output, nt = 3 | 4); false: not this shape
+bool launch_conv_mfma_mt2(const ConvArgs& a, const Epilogue& ep, int nt, hipStream_t s);
 // LDS-staged variant of the same GEMM (default when K = taps*Cs_in >= 64)
 void launch_conv_lds(const ConvArgs& a, const Epilogue& ep, int nt, hipStream_t s);
 // 3x3 s1 p1 conv with the input tile resident in LDS; returns false when the shape is not on that path

@@ -122,16 +122,22 @@ __global__ void __launch_bounds__(256, (NT <= 3 ? 4 : 3)) conv_mfma_kernel(const
       tap_off = ((long)p_ky * lw + p_kx) * a.Cs_in + p_c8 * 8;
     }
   };
+  // One VALU instruction between the groups of NT MFMAs (the gate multiply of the next group, else a v_nop): with
+  // nothing but MFMAs in the step the waves of a SIMD take turns badly.  tools/micro/conv_time.hip, 983040 x 480 -> 480
+  // alone: 108.3 TFLOP/s without, 128.3 with (s_nop: no change; a VALU op after EVERY MFMA: 120); 240 -> 240: 92.6 ->
+  // 105.0; 480 -> 120: 94.4 -> 110.2; NT = 1 (every MFMA followed by one) loses 4 %, so only for NT >= 2.
   auto mfma_step = [&](const float4& av0, const float4 (&bv)[NT], const float4& gv) {
-    float4 av = av0;
-    if constexpr (GATE) { av.x = av0.x * gv.x; av.y = av0.y * gv.y; av.z = av0.z * gv.z; av.w = av0.w * gv.w; }  // x * gate: one rounding, as ew_kernel did
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[t].x, av.x, acc[t], 0, 0, 0);
-      acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[t].y, av.y, acc[t], 0, 0, 0);
-      acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[t].z, av.z, acc[t], 0, 0, 0);
-      acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[t].w, av.w, acc[t], 0, 0, 0);
-    }
+#define OCR_C_SWEEP(C)                                                                                                    \
+  {                                                                                                                       \
+    float avc = av0.C;                                                                                                    \
+    if constexpr (GATE) avc = av0.C * gv.C; /* x * gate: one rounding, as ew_kernel did */                                \
+    else if constexpr (NT >= 2) asm volatile("v_nop");                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                                    \
+    _Pragma("unroll") for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[t].C, avc, acc[t], 0, 0, 0); \
+    __builtin_amdgcn_sched_barrier(0);                                                                                    \
+  }
+    OCR_C_SWEEP(x) OCR_C_SWEEP(y) OCR_C_SWEEP(z) OCR_C_SWEEP(w)
+#undef OCR_C_SWEEP
   };
   float4 a0, b0[NT], a1, b1[NT];
   float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0;
@@ -154,6 +160,128 @@ __global__ void __launch_bounds__(256, (NT <= 3 ? 4 : 3)) conv_mfma_kernel(const
   // ---- epilogue: lane owns output column j (one channel), 16 rows ----
   conv_finish<NT, MODE>(a, ep, acc, nt0, m, h, s_par);
   CONV_PROBE(3);
+}
+
+// The single-tap case (1x1 conv / linear with a C8I output) with MT pixel tiles per wave: a wave owns MT consecutive
+// 32-pixel tiles x NT column tiles, so a weight fragment fetched from L2 feeds MT MFMAs instead of one and a workgroup
+// stages its parameters once per MT*128 pixels.  tools/micro/conv_time.hip (rec op 30's shape, 983040 x 480 -> 480,
+// alone): MT x NT = 1x3 (the kernel above) 99.8 TFLOP/s gated / 108.6 plain, 1x5 110.5 / 115.6 - the direct kernel is
+// bound by the bytes it pulls through L1 per MFMA (1x3: 5 KB per 12 MFMAs; 2x3: 7 KB per 24), not by occupancy
+// (3 or 4 waves per SIMD measure the same).  Every output's chain is the one above: bit-identical.
+template <int NT, int MT, bool GATE>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) conv_mfma_mt_kernel(const ConvArgs a, const Epilogue ep) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int p = lane & 31, h = lane >> 5;
+  const unsigned lb = xcd_swizzle(blockIdx.x, gridDim.x);  // logical block: N-group fastest, then M-tile
+  const unsigned groups = (unsigned)a.NTtot / NT;
+  const long mblk = (long)(lb / groups) * (128 * MT);
+  const long m0 = mblk + (long)wave * (32 * MT);
+  const int nt0 = (int)(lb % groups) * NT;
+  __shared__ float s_par[OCR_MAX_EP * 2 * NT * 32];
+  conv_stage_params<NT>(a, ep, nt0, s_par);
+  if (m0 >= a.M) return;
+
+  floatx16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][t][r] = 0.0f;
+
+  const float4* __restrict__ wf = (const float4*)a.wfrag;
+  const int KK = a.C8;
+  const float4* p_w = wf + (long)nt0 * 64 + lane;
+  const long wstride = (long)a.NTtot * 64;
+  const float* zpage = a.zeros + 4 * h;
+  const float* xrow[MT];
+  const float* grow[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const long m = m0 + 32 * i + p;
+    const bool mvalid = m < a.M;
+    xrow[i] = mvalid ? a.in + m * a.Cs_in + 4 * h : zpage;
+    grow[i] = zpage;
+    if constexpr (GATE) {
+      if (mvalid) {
+        const int gn = a.rin.w ? rag_sample_of_pixel(a.rin, a.N, a.H, m, mblk) : (int)((unsigned)m / (unsigned)a.gate_hw);
+        grow[i] = a.gate + (long)gn * a.Cs_in + 4 * h;
+      }
+    }
+  }
+  int p_step = 0;
+  struct Set { float4 av[MT], gv[MT], bv[NT]; };
+  auto load_step = [&](Set& s) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      if constexpr (GATE) s.gv[i] = *(const float4*)(grow[i] + p_step * 8);
+      s.av[i] = *(const float4*)(xrow[i] + p_step * 8);
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) s.bv[t] = p_w[t * 64];  // the fragment image is padded to whole NT groups
+    const bool more = p_step + 1 < KK;  // past the end: stay on the last step (loaded, unused)
+    p_step += more;
+    p_w += more ? wstride : 0;
+  };
+  auto mfma_step = [&](const Set& s) __attribute__((always_inline)) {
+    float4 av[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      av[i] = s.av[i];
+      if constexpr (GATE) { av[i].x = s.av[i].x * s.gv[i].x; av[i].y = s.av[i].y * s.gv[i].y; av[i].z = s.av[i].z * s.gv[i].z; av[i].w = s.av[i].w * s.gv[i].w; }  // x * gate: one rounding
+    }
+    // One VALU instruction after each pixel tile's NT MFMAs: with nothing but MFMAs in the step the two waves of a SIMD
+    // take turns badly (conv_time, 983040 x 480 -> 480: 117.8 TFLOP/s without, 129.7 with a v_nop per NT MFMAs, 120.3 with
+    // one per MFMA, no change with s_nop); the gated kernel has its multiplies there (124.5; hoisted in front of the
+    // MFMAs 108.6), and more of them do not help it.
+#define OCR_MT_SWEEP(C)                                                                                      \
+  _Pragma("unroll") for (int i = 0; i < MT; ++i) {                                                           \
+    _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                           \
+      acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(s.bv[t].C, av[i].C, acc[i][t], 0, 0, 0);              \
+    if constexpr (!GATE) { __builtin_amdgcn_sched_barrier(0); asm volatile("v_nop"); __builtin_amdgcn_sched_barrier(0); } \
+  }
+    OCR_MT_SWEEP(x) OCR_MT_SWEEP(y) OCR_MT_SWEEP(z) OCR_MT_SWEEP(w)
+#undef OCR_MT_SWEEP
+  };
+  Set s0, s1;
+  if constexpr (!GATE) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i) s0.gv[i] = s1.gv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  load_step(s0);
+  int kk = 0;
+  for (; kk + 2 <= KK; kk += 2) {
+    load_step(s1);
+    __builtin_amdgcn_sched_barrier(0);  // keep the loads ahead of the MFMAs they overlap
+    mfma_step(s0);
+    __builtin_amdgcn_sched_barrier(0);
+    load_step(s0);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_step(s1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (kk < KK) mfma_step(s0);
+  // (spelled out: left to "#pragma unroll" the compiler keeps the loop for the larger NT and indexes acc through scratch)
+  conv_finish<NT, OUT_C8I>(a, ep, acc[0], nt0, m0 + p, h, s_par);
+  if constexpr (MT > 1) conv_finish<NT, OUT_C8I>(a, ep, acc[1], nt0, m0 + 32 + p, h, s_par);
+  if constexpr (MT > 2) conv_finish<NT, OUT_C8I>(a, ep, acc[2], nt0, m0 + 64 + p, h, s_par);
+}
+
+// Two pixel tiles per wave (the kernel above) for the shapes it was measured on: single tap, C8I output, nt = 3 or 4.
+bool launch_conv_mfma_mt2(const ConvArgs& a, const Epilogue& ep, int nt, hipStream_t s) {
+  const bool tap1 = a.KH == 1 && a.KW == 1 && a.PH == 0 && a.PW == 0 && a.OH == a.H && a.OW == a.W;
+  if (!tap1 || a.out_mode != OUT_C8I || a.NTtot % nt) return false;
+  dim3 grid((unsigned)(((a.M + 255) / 256) * (a.NTtot / nt)));
+  if (nt == 3) {
+    if (a.gate) hipLaunchKernelGGL((conv_mfma_mt_kernel<3, 2, true>), grid, dim3(256), 0, s, a, ep);
+    else hipLaunchKernelGGL((conv_mfma_mt_kernel<3, 2, false>), grid, dim3(256), 0, s, a, ep);
+  } else if (nt == 4) {
+    if (a.gate) hipLaunchKernelGGL((conv_mfma_mt_kernel<4, 2, true>), grid, dim3(256), 0, s, a, ep);
+    else hipLaunchKernelGGL((conv_mfma_mt_kernel<4, 2, false>), grid, dim3(256), 0, s, a, ep);
+  } else {
+    return false;
+  }
+  return true;
 }
 
 bool launch_conv_mfma(const ConvArgs& a, const Epilogue& ep, int nt, hipStream_t s) {

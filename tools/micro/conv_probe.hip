@@ -8,11 +8,16 @@
 #include <algorithm>
 #include "kernels_net.hip"
 using namespace ocr;
+namespace ocr {
+const RtOptions& rt_options() { static RtOptions o; return o; }
+std::shared_mutex& capture_mutex() { static std::shared_mutex m; return m; }
+}
+static int g_gate = 0, g_nt = 0;  // argv[5] = 1: gated input (rec op 30); argv[6]: NT override
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
 static void run(long M, int cin, int cout, int variant, int epi) {
   const int cs_in = (cin + 7) / 8 * 8, cs_out = (cout + 7) / 8 * 8;
-  const int tiles = (cs_out + 31) / 32, nt = conv_nt_for(tiles), NTtot = (tiles + nt - 1) / nt * nt, C8 = cs_in / 8;
+  const int tiles = (cs_out + 31) / 32, nt = g_nt ? g_nt : conv_nt_for(tiles), NTtot = (tiles + nt - 1) / nt * nt, C8 = cs_in / 8;
   float *x, *y, *w, *z, *bn;
   CK(hipMalloc(&x, (M * cs_in + 64) * 4)); CK(hipMalloc(&y, M * cs_out * 4)); CK(hipMalloc(&w, (size_t)C8 * NTtot * 64 * 4 * 4));
   CK(hipMalloc(&z, 4096 * 4)); CK(hipMalloc(&bn, 8192 * 4));
@@ -21,6 +26,11 @@ static void run(long M, int cin, int cout, int variant, int epi) {
   a.in = x; a.out = y; a.wfrag = w; a.zeros = z; a.M = M; a.N = 1; a.H = 1; a.W = (int)M; a.Cs_in = cs_in; a.C8 = C8;
   a.OH = 1; a.OW = (int)M; a.Cs_out = cs_out; a.Cout = cout; a.CoutPadded = cs_out; a.ColsStore = cs_out; a.NTtot = NTtot;
   a.KH = a.KW = 1; a.PH = a.PW = 0; a.out_mode = OUT_C8I;
+  if (g_gate) {
+    float* g;
+    CK(hipMalloc(&g, 64 * cs_in * 4)); CK(hipMemset(g, 0, 64 * cs_in * 4));
+    a.gate = g; a.gate_hw = (int)((M + 63) / 64);
+  }
   Epilogue ep{};
   if (epi) {
     ep.n = epi >= 2 ? 2 : 1;
@@ -87,6 +97,8 @@ static void run(long M, int cin, int cout, int variant, int epi) {
 
 int main(int argc, char** argv) {
   if (argc >= 4) {  // conv_probe M cin cout [epi]
+    if (argc > 5) g_gate = atoi(argv[5]);
+    if (argc > 6) g_nt = atoi(argv[6]);
     run(atol(argv[1]), atoi(argv[2]), atoi(argv[3]), 0, argc > 4 ? atoi(argv[4]) : 3);
     return 0;
   }

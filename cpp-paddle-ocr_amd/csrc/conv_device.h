@@ -124,6 +124,14 @@ __device__ __forceinline__ float4 apply_epilogue4(const Epilogue& ep, float4 v, 
         v.z = ocr_act(st.act, st.p0, st.p1, v.z); v.w = ocr_act(st.act, st.p0, st.p1, v.w);
         break;
       case EP_MULC: { float4 g = *(const float4*)(st.v0 + (long)n * cs + pc); v.x = v.x * g.x; v.y = v.y * g.y; v.z = v.z * g.z; v.w = v.w * g.w; } break;
+      case EP_GATERES: {
+        float4 g = *(const float4*)(st.v0 + (long)n * cs + pc);
+        float t;
+        t = v.x * g.x; v.x = t + v.x;
+        t = v.y * g.y; v.y = t + v.y;
+        t = v.z * g.z; v.z = t + v.z;
+        t = v.w * g.w; v.w = t + v.w;
+      } break;
       case EP_ADDT: { float4 g = *(const float4*)(st.v0 + oidx); v.x = v.x + g.x; v.y = v.y + g.y; v.z = v.z + g.z; v.w = v.w + g.w; } break;
       case EP_ADDUP: {
         int sy = y / st.a0, sx = x / st.a0;
@@ -244,6 +252,18 @@ __device__ __forceinline__ void conv_finish(const ConvArgs& a, const Epilogue& e
         if constexpr (MODE != OUT_DECONV) decompose(m, a.OH * a.OW, a.OW, n, y, x);
         const float* gate = st.v0 + (long)n * a.Cs_out + r0;
         OCR_EP_SWEEP({ const float4 r = *(const float4*)(gate + coff(rel)); wx = wx * r.x; wy = wy * r.y; wz = wz * r.z; ww = ww * r.w; })
+      } break;
+      case EP_GATERES: {  // x * gate + x: two roundings, as the ew pass (mulc, then addt of x itself) it replaces
+        if constexpr (MODE != OUT_DECONV) decompose(m, a.OH * a.OW, a.OW, n, y, x);
+        const float* gate = st.v0 + (long)n * a.Cs_out + r0;
+        OCR_EP_SWEEP({
+          const float4 r = *(const float4*)(gate + coff(rel));
+          float u;
+          u = wx * r.x; wx = u + wx;
+          u = wy * r.y; wy = u + wy;
+          u = wz * r.z; wz = u + wz;
+          u = ww * r.w; ww = u + ww;
+        })
       } break;
       case EP_ADDT: {  // tensor of the output's shape
         const float* res = st.v0 + opix;

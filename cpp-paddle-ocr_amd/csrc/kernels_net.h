@@ -68,6 +68,17 @@ struct ConvArgs {
 };
 // false: the combination (gated input / multi-tap conv with a plain or deconv output) is not instantiated
 bool launch_conv_mfma(const ConvArgs& a, const Epilogue& ep, int nt, hipStream_t s);
+// 1x1 conv with few input channels whose output is only wanted as the global average pool's row sums (the detector's
+// RSE blocks, net.hip): part[(n*H + y)][Cs_out] = sum over x, left to right, of the conv's outputs - what gap_rows
+// would leave after reading the materialised tensor.  w: [Cs_in (logical k, zero rows past Cin)][Cs_out physical].
+struct ConvRowsumArgs {
+  const float* in;
+  const float* w;
+  float* part;
+  long rows;  // N * H
+  int W, Cin, Cs_in, Cs_out;
+};
+bool launch_conv_rowsum(const ConvRowsumArgs& a, hipStream_t s);
 // the same with two 32-pixel tiles per wave (big single-tap convs with a C8I output, nt = 3 | 4); false: not this shape
 bool launch_conv_mfma_mt2(const ConvArgs& a, const Epilogue& ep, int nt, hipStream_t s);
 // LDS-staged variant of the same GEMM (default when K = taps*Cs_in >= 64)

@@ -1195,6 +1195,71 @@ __global__ void __launch_bounds__(256) gap_cols_kernel(const float* __restrict__
   for (int y = 0; y < H; ++y) s = s + src[(long)y * Cs];
   out[t] = s / cnt;
 }
+// =====================================================================================
+// conv 1x1 (Cin <= 24) -> row sums, nothing written but the sums (kernels_net.h, ConvRowsumArgs).  One thread = one
+// image row x 4 physical output channels, as gap_rows_kernel; per pixel the contract's chain for each of its channels
+// (k ascending in LOGICAL input-channel order from 0, one fmaf per k - what the matrix pipe does with the fragment
+// image), then s = s + v.  The 24 threads of a row read the same input pixels (L1 broadcasts).
+// =====================================================================================
+template <int CIN, int CS_IN, int U>
+__global__ void __launch_bounds__(256) conv_rowsum_kernel(const ConvRowsumArgs a) {
+  const int c4n = a.Cs_out >> 2;
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= a.rows * c4n) return;
+  const int pc = (int)(t % c4n) * 4;
+  const long ny = t / c4n;
+  ocr_f2 wlo[CIN], whi[CIN];  // (the padded k of the matrix kernels multiply zeros: fma(0, 0, acc) = acc, left out here)
+#pragma unroll
+  for (int k = 0; k < CIN; ++k) {
+    const float4 w = *(const float4*)(a.w + (long)k * a.Cs_out + pc);
+    wlo[k] = ocr_f2{w.x, w.y}; whi[k] = ocr_f2{w.z, w.w};
+  }
+  const float* src = a.in + ny * a.W * CS_IN;
+  ocr_f2 slo = {0.f, 0.f}, shi = {0.f, 0.f};
+  auto pixel = [&](const float4 (&xin)[CS_IN / 4], ocr_f2& lo, ocr_f2& hi) __attribute__((always_inline)) {
+    lo = ocr_f2{0.f, 0.f}; hi = ocr_f2{0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < CIN; ++k) {
+      const int ph = c8i_phys(k), c = ph & 3;  // (constants after unrolling)
+      const float4 q = xin[ph >> 2];
+      const float xv = c == 0 ? q.x : c == 1 ? q.y : c == 2 ? q.z : q.w;
+      lo = __builtin_elementwise_fma(ocr_f2{xv, xv}, wlo[k], lo);
+      hi = __builtin_elementwise_fma(ocr_f2{xv, xv}, whi[k], hi);
+    }
+  };
+  int x = 0;
+  for (; x + U <= a.W; x += U) {
+    float4 xin[U][CS_IN / 4];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int q = 0; q < CS_IN / 4; ++q) xin[u][q] = *(const float4*)(src + (long)(x + u) * CS_IN + 4 * q);
+    ocr_f2 lo[U], hi[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) pixel(xin[u], lo[u], hi[u]);
+#pragma unroll
+    for (int u = 0; u < U; ++u) { slo = slo + lo[u]; shi = shi + hi[u]; }  // left to right: the pool's order
+  }
+  for (; x < a.W; ++x) {
+    float4 xin[CS_IN / 4];
+#pragma unroll
+    for (int q = 0; q < CS_IN / 4; ++q) xin[q] = *(const float4*)(src + (long)x * CS_IN + 4 * q);
+    ocr_f2 lo, hi;
+    pixel(xin, lo, hi);
+    slo = slo + lo; shi = shi + hi;
+  }
+  *(float4*)(a.part + ny * a.Cs_out + pc) = make_float4(slo.x, slo.y, shi.x, shi.y);
+}
+bool launch_conv_rowsum(const ConvRowsumArgs& a, hipStream_t s) {
+  const long threads = a.rows * (a.Cs_out >> 2);
+  const dim3 grid((unsigned)((threads + 255) / 256));
+  if (a.Cs_in == 16 && a.Cin == 12) hipLaunchKernelGGL((conv_rowsum_kernel<12, 16, 4>), grid, dim3(256), 0, s, a);
+  else if (a.Cs_in == 24 && a.Cin == 18) hipLaunchKernelGGL((conv_rowsum_kernel<18, 24, 2>), grid, dim3(256), 0, s, a);
+  else if (a.Cs_in == 16) hipLaunchKernelGGL((conv_rowsum_kernel<16, 16, 4>), grid, dim3(256), 0, s, a);
+  else if (a.Cs_in == 24) hipLaunchKernelGGL((conv_rowsum_kernel<24, 24, 2>), grid, dim3(256), 0, s, a);
+  else return false;
+  return true;
+}
 void launch_gap_cols(const float* part, float* out, int N, int H, int W, int Cs, hipStream_t s, RagLevel rag) {
   hipLaunchKernelGGL(gap_cols_kernel, dim3((unsigned)((N * Cs + 255) / 256)), dim3(256), 0, s, part, out, N, H, Cs, (float)(H * W), rag);
 }

@@ -257,6 +257,16 @@ bool Net::load(const char* plan_text, const WeightMap& W, std::string& err) {
           });
           if (!upload("frag:" + op.w, f)) { err = "hipMalloc failed"; return false; }
           if (kh == 3 && kw == 3 && ci == 96 && co == 24 && !pl && !upload("c24:" + op.w, conv3x3_c24_image(w, co, ci))) { err = "hipMalloc failed"; return false; }
+          if (kh == 1 && kw == 1 && ci <= 24 && !pl && op.ep.empty()) {  // conv_rowsum_kernel's image (RSE blocks): [k logical, padded][physical column]
+            const int cs_in = c8i_stride(ci);
+            std::vector<float> img((size_t)cs_in * cols, 0.f);
+            for (int k = 0; k < ci; ++k)
+              for (int col = 0; col < cols; ++col) {
+                const int ch = c8i_logical(col);
+                if (ch < co) img[(size_t)k * cols + col] = w[(size_t)ch * ci + k];
+              }
+            if (!upload("rsw:" + op.w, img)) { err = "hipMalloc failed"; return false; }
+          }
         }
       } break;
       case PlanOp::LINEAR: {
@@ -354,7 +364,7 @@ bool Net::build_epilogue(const PlanOp& op, Epilogue& ep, bool conv_path, std::st
       case EP_SMUL: case EP_SADD: e.p0 = scalars_[st.n0]; break;
       case EP_BN: e.v0 = dev_vec("bns:" + st.n0); e.v1 = dev_vec("bnt:" + st.n0); break;
       case EP_ACT: break;
-      case EP_MULC:
+      case EP_MULC: case EP_GATERES:
         e.v0 = tensor_ptr(st.tid);
         break;
       case EP_ADDT: e.v0 = tensor_ptr(st.tid); break;
@@ -740,10 +750,43 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths, const i
       fused_dw[oi] = 1;  // (same bookkeeping as a fused depthwise conv: no launch, no tensor)
     }
   }
+  // ---- RSE blocks of the detector's neck: conv 1x1 (Cin <= 24, no epilogue) -> gap -> sefc -> ew (x * g + x [+ upsampled]).
+  // Materialised, the conv's 96-channel output is written once and read twice (pool, ew) before the result is written
+  // again: three passes over 1.4 GB at 240 x 240 x 64 images for a K = 12 matrix product.  Instead the conv runs twice:
+  // first as conv_rowsum_kernel, which leaves only the pool's row sums, then - with the gate known - as the ordinary
+  // conv kernel with the ew's stages in its epilogue (EP_GATERES + the FPN's addup), writing the block's output.  Both
+  // passes compute the same chain per output, so nothing changes bit for bit.  Uniform batches only (the conv kernels'
+  // per-image epilogue stages decode (n, y, x) from a uniform grid).  OCR_FUSE_RSE=0 disables (A/B, results identical).
+  std::vector<int> rse_conv(nops, -1);   // ew op -> the conv it absorbs
+  std::vector<char> rse_first(nops, 0);  // that conv: its launch is the row-sum pass, its tensor never exists
+  if (keep_all_ != 1 && rt_options().fuse_rse && !rag) {
+    for (int oi = 0; oi + 3 < nops; ++oi) {
+      const PlanOp& c = plan_.ops[oi];
+      const PlanOp& g = plan_.ops[oi + 1];
+      const PlanOp& f = plan_.ops[oi + 2];
+      const PlanOp& e = plan_.ops[oi + 3];
+      const bool one = c.kind == PlanOp::CONV && c.kh == 1 && c.kw == 1 && c.sh == 1 && c.sw == 1 && c.ph == 0 && c.pw == 0 && c.cin != 3;
+      if (!one || !c.ep.empty() || c.cin > 24 || T[c.out].plain || T[c.in].plain || gate_src[oi] >= 0 || dwpw_of[oi] >= 0) continue;
+      if (g.kind != PlanOp::GAP || g.in != c.out || f.kind != PlanOp::SEFC || f.in != g.out || e.kind != PlanOp::EW || e.in != c.out) continue;
+      if (e.ep.size() < 2 || e.ep[0].kind != EP_MULC || e.ep[0].tid != f.out || e.ep[1].kind != EP_ADDT || e.ep[1].tid != c.out) continue;
+      bool rest_ok = true;
+      for (size_t k = 2; k < e.ep.size(); ++k) rest_ok = rest_ok && (e.ep[k].kind == EP_ADDUP || e.ep[k].kind == EP_ADDT) && e.ep[k].tid != c.out;
+      if (!rest_ok || uses[c.out] != 3 || c.out == out_tid_ || (T[c.in].cs != 16 && T[c.in].cs != 24)) continue;
+      rse_conv[oi + 3] = oi;
+      rse_first[oi] = 1;
+    }
+  }
   std::vector<int> last(plan_.ntensors, -1);
   for (int oi = 0; oi < nops; ++oi) {
     auto& op = plan_.ops[oi];
     if (folded[oi] || fused_dw[oi]) continue;  // its reads happen in the conv it was folded / fused into
+    if (rse_conv[oi] >= 0) {  // the second conv pass: reads the conv's input again, the gate and the upsampled operand; never the conv's (dead) output
+      const PlanOp& c = plan_.ops[rse_conv[oi]];
+      last[c.in] = oi;
+      for (auto& st : op.ep) if (st.tid >= 0 && st.tid != c.out) last[st.tid] = oi;
+      continue;
+    }
+    if (oi > 0 && rse_first[oi - 1]) continue;  // the pool after a row-sum pass reads gap_part_, not the conv's tensor
     if (gate_src[oi] >= 0) { last[gate_src[oi]] = oi; last[gate_tid[oi]] = oi; }
     else if (dwpw_of[oi] >= 0) last[plan_.ops[dwpw_of[oi]].in] = oi;
     else if (dbhead_of[oi] >= 0) last[plan_.ops[dbhead_of[oi]].in] = oi;
@@ -784,7 +827,8 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths, const i
   for (int oi = 0; oi < nops; ++oi) {
     auto& op = plan_.ops[oi];
     if (folded[oi] || fused_dw[oi]) { T[op.out].offset = 0; continue; }  // never materialised
-    if (op.out >= 0) T[op.out].offset = alloc(T[op.out].numel());
+    if (rse_first[oi]) T[op.out].offset = 0;  // (the row-sum pass writes gap_part_ only)
+    else if (op.out >= 0) T[op.out].offset = alloc(T[op.out].numel());
     if (op.kind == PlanOp::GAP) gap_need = std::max(gap_need, (size_t)(rag ? rows_of(T[op.in]) : (long)T[op.in].n * T[op.in].h) * T[op.in].cs);
     // free tensors whose last reader is this op (never the op's own output)
     for (int t = 1; t < plan_.ntensors; ++t)
@@ -793,7 +837,7 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths, const i
   // `top` may have shrunk at the end; capacity must cover the high-water mark
   size_t high = 0;
   std::vector<char> dead(plan_.ntensors, 0);
-  for (int oi = 0; oi < nops; ++oi) if (folded[oi] || fused_dw[oi]) dead[plan_.ops[oi].out] = 1;
+  for (int oi = 0; oi < nops; ++oi) if (folded[oi] || fused_dw[oi] || rse_first[oi]) dead[plan_.ops[oi].out] = 1;
   B->exists.assign(plan_.ntensors, 0);
   for (int t = 1; t < plan_.ntensors; ++t) B->exists[t] = !dead[t];
   for (int t = 1; t < plan_.ntensors; ++t) if (!dead[t]) high = std::max(high, T[t].offset + ((T[t].numel() + 63) & ~(size_t)63));
@@ -816,11 +860,36 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths, const i
   // 3. launches
   char nm[160];
   for (int oi = 0; oi < nops; ++oi) {
-    auto& op = plan_.ops[oi];
-    if (op.kind == PlanOp::OUTPUT || folded[oi] || fused_dw[oi]) continue;
+    if (plan_.ops[oi].kind == PlanOp::OUTPUT || folded[oi] || fused_dw[oi]) continue;
+    PlanOp second_pass;  // RSE block: the ew's launch is its conv again, with the ew's stages behind the conv's own
+    if (rse_conv[oi] >= 0) {
+      const PlanOp& e = plan_.ops[oi];
+      second_pass = plan_.ops[rse_conv[oi]];
+      second_pass.out = e.out;
+      PlanStage gr = e.ep[0];
+      gr.kind = EP_GATERES;
+      second_pass.ep.push_back(gr);
+      for (size_t k = 2; k < e.ep.size(); ++k) second_pass.ep.push_back(e.ep[k]);
+    }
+    const PlanOp& op = rse_conv[oi] >= 0 ? second_pass : plan_.ops[oi];
     const TensorDesc& o = T[op.out];
     float* optr = arena_ + o.offset;
     Launch L;
+    if (rse_first[oi]) {  // first pass: the pool's row sums, nothing else
+      const TensorDesc& in = T[op.in];
+      ConvRowsumArgs a{};
+      a.in = arena_ + in.offset; a.w = dev_vec("rsw:" + op.w); a.part = gap_part_;
+      a.rows = (long)in.n * in.h; a.W = in.w; a.Cin = op.cin; a.Cs_in = in.cs; a.Cs_out = o.cs;
+      if (!a.w) { err = "RSE block: no row-sum weight image for " + op.w; return false; }
+      snprintf(nm, sizeof nm, "%s.%02d.conv1x1_%d_%d_rowsum", plan_.name.c_str(), oi, op.cin, op.cout);
+      L.name = nm;
+      L.flops = 2.0 * in.pixels() * op.cin * op.cout;
+      L.bytes = 4.0 * ((double)in.pixels() * op.cin + (double)a.rows * op.cout);
+      L.fn = [this, a](hipStream_t s) {
+        if (!launch_conv_rowsum(a, s)) this->launch_error_ = "launch_conv_rowsum: shape accepted at bind time was refused at launch";
+      };
+      goto emit;
+    }
     switch (op.kind) {
       case PlanOp::CONV: case PlanOp::LINEAR: case PlanOp::DECONV: {
         const TensorDesc& in = T[gate_src[oi] >= 0 ? gate_src[oi] : op.in];
@@ -1061,7 +1130,7 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths, const i
         snprintf(nm, sizeof nm, "%s.%02d.gap_%d", plan_.name.c_str(), oi, op.c);
         L.name = nm;
         L.bytes = 4.0 * (double)in.pixels() * op.c;
-        if (oi > 0 && dw_rowsum[oi - 1]) {  // the row sums are already in `part` (written by the depthwise conv before this op)
+        if (oi > 0 && (dw_rowsum[oi - 1] || rse_first[oi - 1])) {  // the row sums are already in `part` (written by the depthwise conv / the conv's row-sum pass before this op)
           L.bytes = 4.0 * (double)n * h * op.c;
           L.fn = [part, optr, n, h, w, cs, rl](hipStream_t s) { launch_gap_cols(part, optr, n, h, w, cs, s, rl); };
         } else
@@ -1166,6 +1235,7 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths, const i
       } break;
       default: break;
     }
+  emit:
     // instance tag: the same op at another bound shape is another roofline row
     if (img) snprintf(nm, sizeof nm, "@%dx~%ldx~%ld", N, irows / N, ipix / irows);  // ragged images: mean height, mean width
     else if (rag) snprintf(nm, sizeof nm, "@%dx%dx~%ld", N, H, ltot[0] / N);  // ragged: the lines' mean width

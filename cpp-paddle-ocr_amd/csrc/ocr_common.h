@@ -48,14 +48,14 @@ OCR_HD float ocr_expf(float x) {
 }
 
 // ---- epilogue description (kernel argument, by value) ----
-enum : int { EP_BIAS = 0, EP_SMUL, EP_SADD, EP_BN, EP_ACT, EP_MULC, EP_ADDT, EP_ADDUP };
+enum : int { EP_BIAS = 0, EP_SMUL, EP_SADD, EP_BN, EP_ACT, EP_MULC, EP_ADDT, EP_ADDUP, EP_GATERES };  // GATERES: v = v * gate[n][c] + v (an `ew mulc | addt self` folded into its producer)
 enum : int { ACT_RELU = 0, ACT_HSWISH, ACT_HSIG, ACT_SWISH, ACT_SIGMOID };
 
 struct EpStage {
   int kind;
   int act;
   float p0, p1;
-  const float* v0;  // BIAS: b[Cs] / BN: s[Cs] / MULC: gate [N][Cs] / ADDT, ADDUP: tensor
+  const float* v0;  // BIAS: b[Cs] / BN: s[Cs] / MULC, GATERES: gate [N][Cs] / ADDT, ADDUP: tensor
   const float* v1;  // BN: t[Cs]
   int a0, a1, a2;   // ADDUP: a0 = scale, a1 = source W, a2 = source H
 };

@@ -13,6 +13,7 @@ struct RtOptions {
   bool fuse_gap = true;        // OCR_FUSE_GAP=0
   long fuse_gap_min = 65536;   // OCR_FUSE_GAP_MIN=n
   bool fuse_dbhead = true;     // OCR_FUSE_DBHEAD=0
+  bool fuse_rse = true;        // OCR_FUSE_RSE=0
   int conv_impl = 0;           // OCR_CONV_IMPL=direct (1) | lds (2); 0 = per shape
   bool conv_small_nt = true;   // OCR_CONV_SMALL_NT=0
   int conv_nt_max = 4;         // OCR_CONV_NT_MAX=n

@@ -41,7 +41,13 @@ def main():
     # with the SE gate folded into its consumers (net.hip) ops 25 and 30 run the GATE instantiation
     # conv_mfma_kernel<3, 0, true, true> on this grid, in that order: op 30 is every second dispatch of it;
     # with OCR_FUSE_GATE=0 ops 25, 30, 32, 34 share one kernel and op 30 is every fourth starting at the second
+    # round 3 (second half): the big 1x1 convs run conv_mfma_mt_kernel<3, 2, GATE> (two pixel tiles per wave): ops 25 and 30
+    # are its gated instantiation on a grid of ceil(M / 256) x 5 workgroups, in that order
+    grid2 = ((M_ROWS + 255) // 256) * 5 * 256
     def sel(rs):
+        mt = [r for r in rs if "conv_mfma_mt_kernel<3, 2, true>" in r[1] and r[2] == grid2]
+        if mt:
+            return mt[1::2]
         gated = [r for r in rs if "conv_mfma_kernel<3, 0, true, true>" in r[1] and r[2] == grid]
         if gated:
             return gated[1::2]
@@ -55,9 +61,8 @@ def main():
     M, K, N = M_ROWS, 480, 480
     alg = 4.0 * (M * K + M * N + K * N)
     out = {
-        "kernel": NAME or "rec.30.conv1x1_480_480%s@%dx48x320" % ("_gated" if any("true, true>" in r[1] for r in fe) else "", LINES),
-        "launch": "conv_mfma_kernel<3, OUT_C8I, single-tap%s>, grid %dx256 (the %d-line launch)" % (
-            ", SE gate folded into the A operand" if any("true, true>" in r[1] for r in fe) else "", grid // 256, LINES),
+        "kernel": NAME or "rec.30.conv1x1_480_480%s@%dx48x320" % ("_gated" if any("true>" in r[1] for r in fe) else "", LINES),
+        "launch": "%s, grid %dx256 (the %d-line launch)" % (fe[0][1].split("(")[0], fe[0][2] // 256, LINES),
         "dispatches_averaged": len(fe),
         "hbm_read_bytes_per_launch": rd,
         "hbm_write_bytes_per_launch": wb,

@@ -1,0 +1,19 @@
+#!/bin/bash
+# On the GPU box: the round's evidence in one call - full GPU suite, the three bench lines, kernel table, rocprofv3
+# kernel trace + PMC passes.  tools/round_evidence.sh <tag>  ->  gpurun_out/ev_<tag>/
+T=${1:-r3}
+O=gpurun_out/ev_$T
+mkdir -p $O
+python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; tail -3 $O/pytest.log
+OCR_BENCH_KERNEL_TABLE=$O/kernel_table.txt python bench.py > $O/bench_cfg2.json 2> $O/bench_cfg2.err || exit 1
+python bench.py --config cfg3 --no-cpu-baseline > $O/bench_cfg3.json 2> $O/bench_cfg3.err || exit 1
+python bench.py --config cfg4 --images 2560 --no-cpu-baseline > $O/bench_cfg4.json 2> $O/bench_cfg4.err || exit 1
+tools/run_profile.sh $T > $O/profile.log 2>&1
+python tools/prof_summary.py gpurun_out/prof_$T > $O/prof_summary.txt 2>&1
+python tools/pmc_traffic.py gpurun_out/prof_$T $O/pmc_traffic.json $O/bench_cfg2.json > $O/pmc_traffic.log 2>&1
+cp gpurun_out/prof_$T/trace/*/*kernel_stats.csv $O/ 2>/dev/null
+for c in cfg2 cfg3 cfg4; do python - $O/bench_$c.json <<'P'
+import json,sys
+d=json.load(open(sys.argv[1])); print(sys.argv[1], round(d['value'],1), d.get('stage_ms_last_step'), (d.get('roofline') or {}).get('frac'))
+P
+done

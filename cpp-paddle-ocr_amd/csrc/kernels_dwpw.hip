@@ -725,7 +725,7 @@ static int dwpw_dispatch(const DwPwArgs& a, hipStream_t s, bool query, bool rows
   OCR_DWPW_CASE(3, 2, 1, 16, false, 4, 1, 2, 2, tiles == 4)
   // wide layers: two column groups per workgroup (and further column blocks in the grid)
   OCR_DWPW_CASE(3, 1, 2, 16, true, 4, 1, 2, 2, tiles == 8)
-  OCR_DWPW_CASE(5, 1, 1, 16, true, 4, 1, 1, 3, tiles == 8)
+  OCR_DWPW_CASE(5, 1, 1, 16, true, 4, 2, 2, 2, tiles == 8)  // (round 3, ragged batch, in the step: 1/1/3 3.13 ms, 2/2/2 3.05, 1/2/3 3.67, 2/1/3 3.90)
   OCR_DWPW_CASE(5, 1, 1, 32, true, 3, 1, 2, 2, tiles == 6 || tiles == 12)
 #undef OCR_DWPW_CASE
   return 0;

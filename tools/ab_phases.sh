@@ -1,14 +1,15 @@
 #!/bin/bash
-# Runs on the GPU box: configs[1] throughput against the number of chains per pipeline and parts per chain.
+# Runs on the GPU box: throughput against the number of chains per pipeline, configs[1] and configs[2].
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$1; mkdir -p $O
-for cfg in "1 1" "2 1" "2 2" "2 4" "3 1" "3 2" "4 1" "4 2"; do
-  set -- $cfg
-  OCR_PIPE_PHASES=$1 OCR_PIPE_PARTS=$2 python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-kernel-timing --no-two-workers --no-latency > $O/cfg2_p$1_m$2.json 2> $O/cfg2_p$1_m$2.err
+for cfg in cfg2 cfg3; do
+for p in 1 2 3 4; do
+  OCR_PIPE_PHASES=$p python3 $R/bench.py --config $cfg --steps 6 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-two-workers --no-latency --no-host-input > $O/${cfg}_p$p.json 2> $O/${cfg}_p$p.err
   python3 - <<PY
 import json
 try:
-    d=json.loads(open("$O/cfg2_p$1_m$2.json").read().strip().splitlines()[-1]); print("chains $1 parts/chain $2:", round(d["value"],1), "host", round(d.get("host_input",{}).get("value",0),1))
-except Exception as e: print("$1 $2 ERR", e)
+    d=json.loads(open("$O/${cfg}_p$p.json").read().strip().splitlines()[-1]); print("$cfg chains $p:", round(d["value"],1), d["stage_ms_last_step"])
+except Exception as e: print("$cfg $p ERR", e)
 PY
+done
 done

@@ -492,12 +492,15 @@ __global__ void __launch_bounds__(256, LB) dwpw_kernel(const DwPwArgs a) {
       }
     };
     auto comp = [](const float4& v, int c) __attribute__((always_inline)) { return c == 0 ? v.x : c == 1 ? v.y : c == 2 ? v.z : v.w; };
+#ifndef OCR_DWPW_NO_TAPS
 #pragma unroll
     for (int st = 0; st < D; ++st) fetch(st, st % RS);
+#endif
     __builtin_amdgcn_sched_barrier(0);
     static_for<NST>([&](auto st_) __attribute__((always_inline)) {
       constexpr int st = decltype(st_)::value;
       if constexpr (st < NS) {
+#ifndef OCR_DWPW_NO_TAPS  // development probe (tools/micro/dwpw_probe.hip): no tap reads, no tap FMAs in the steady state
         if (st + D < NS) fetch(st + D, (st + D) % RS);
         const int r = st / K, slot = st % RS;
         const float4 v = tv[slot];
@@ -509,6 +512,7 @@ __global__ void __launch_bounds__(256, LB) dwpw_kernel(const DwPwArgs a) {
           dacc[o].lo = __builtin_elementwise_fma(ocr_f2{v.x, v.y}, ocr_f2{w.x, w.y}, dacc[o].lo);
           dacc[o].hi = __builtin_elementwise_fma(ocr_f2{v.z, v.w}, ocr_f2{w.z, w.w}, dacc[o].hi);
         }
+#endif
       } else {  // the depthwise epilogue and the operand write, as in DW
         const float4 b = *(const float4*)(sb + d_q[0]);
         const ocr_f2 blo = {b.x, b.y}, bhi = {b.z, b.w};
@@ -536,7 +540,11 @@ __global__ void __launch_bounds__(256, LB) dwpw_kernel(const DwPwArgs a) {
       static_for<(st + 1) * NM / NST - st * NM / NST>([&](auto m_) __attribute__((always_inline)) {  // k-ascending per accumulator: octet, column tile, component
         constexpr int m = st * NM / NST + decltype(m_)::value;
         constexpr int j = m / (4 * NT), t = (m / 4) % NT, c4 = m % 4;
+#ifdef OCR_DWPW_NO_MMA  // development probe: operands fetched, matrix pipe idle
+        if (m == 0) acc[t][0] += comp(bq[j][t], c4) * comp(av[j], c4);
+#else
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(bq[j][t], c4), comp(av[j], c4), acc[t], 0, 0, 0);
+#endif
         if (c4 == 3)  // the last use of this fragment register: refill it
 #ifdef OCR_DWPW_NO_B
           bq[j][t] = make_float4((float)(size_t)pb, (float)j, (float)t, 1.f);
@@ -725,8 +733,13 @@ static int dwpw_dispatch(const DwPwArgs& a, hipStream_t s, bool query, bool rows
   OCR_DWPW_CASE(3, 2, 1, 16, false, 4, 1, 2, 2, tiles == 4)
   // wide layers: two column groups per workgroup (and further column blocks in the grid)
   OCR_DWPW_CASE(3, 1, 2, 16, true, 4, 1, 2, 2, tiles == 8)
-  OCR_DWPW_CASE(5, 1, 1, 16, true, 4, 2, 2, 2, tiles == 8)  // (round 3, ragged batch, in the step: 1/1/3 3.13 ms, 2/2/2 3.05, 1/2/3 3.67, 2/1/3 3.90)
+#ifndef OCR_DWPW_55  // GD, TD, LB of the 240-channel 5x5 blocks (tools/micro/dwpw_probe.hip builds variants with -DOCR_DWPW_55=g,t,l)
+#define OCR_DWPW_55 2, 2, 2
+#endif
+#define OCR_DWPW_CASE_X(...) OCR_DWPW_CASE(__VA_ARGS__)
+  OCR_DWPW_CASE_X(5, 1, 1, 16, true, 4, OCR_DWPW_55, tiles == 8)  // (round 3, ragged batch, in the step: 1/1/3 3.13 ms, 2/2/2 3.05, 1/2/3 3.67, 2/1/3 3.90)
   OCR_DWPW_CASE(5, 1, 1, 32, true, 3, 1, 2, 2, tiles == 6 || tiles == 12)
+#undef OCR_DWPW_CASE_X
 #undef OCR_DWPW_CASE
   return 0;
 }

@@ -8,6 +8,10 @@
 #include <vector>
 #include "kernels_dwpw.hip"
 using namespace ocr;
+namespace ocr {
+const RtOptions& rt_options() { static RtOptions o; return o; }
+std::shared_mutex& capture_mutex() { static std::shared_mutex m; return m; }
+}
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
 static void run(int N, int H, int W, int K, int SH, int SW, int cin, int cout) {

@@ -74,7 +74,7 @@ static int det_tap(ocr_det* h, int index, const void* base, size_t elem, size_t 
   if (index < 0 || index >= h->s.last_count || !base) return fail(OCR_ERR_ARG, "no such image in the last run");
   const size_t cnt = (size_t)h->s.last_h * h->s.last_w * per_px;
   if (cnt > cap_elems) return fail(OCR_ERR_CAPACITY, "output buffer too small");
-  CAPI_HIP(hipMemcpy(out, (const char*)base + (size_t)index * cnt * elem, cnt * elem, hipMemcpyDeviceToHost));
+  CAPI_HIP(g_memcpy(out, (const char*)base + (size_t)index * cnt * elem, cnt * elem, hipMemcpyDeviceToHost));
   return OCR_OK;
 }
 int ocr_det_prob_map(ocr_det* h, int index, float* out, size_t cap) {

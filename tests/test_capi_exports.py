@@ -37,6 +37,24 @@ def test_no_abort_in_the_product_library():
             assert "abort()" not in open(os.path.join(csrc, fn)).read(), fn
 
 
+def test_allocations_and_synchronous_copies_go_through_the_capture_guard():
+    """Two chains per pipeline handle, detector lanes and pool workers launch from their own host threads, and a network
+    records its hipGraph on one of them: a hipFree / synchronous hipMemcpy / hipMalloc on another thread at that moment
+    invalidates the capture (csrc/hip_guard.h).  Every such call in the library goes through the g_* wrappers (shared
+    lock; a capture holds it exclusively), and streams are created non-blocking."""
+    import re
+    csrc = os.path.join(ROOT, "cpp-paddle-ocr_amd", "csrc")
+    raw = re.compile(r"(?<![A-Za-z_])(hipMalloc|hipFree|hipHostMalloc|hipHostFree|hipMemcpy|hipMemcpy2D|hipStreamCreate)\(")
+    for fn in os.listdir(csrc):
+        if fn.endswith((".hip", ".h", ".cpp")) and fn != "hip_guard.h":
+            text = open(os.path.join(csrc, fn)).read()
+            hits = [m.group(0) for m in raw.finditer(text)]
+            assert not hits, (fn, hits[:3])
+    net = open(os.path.join(csrc, "net.hip")).read()
+    i = net.index("hipStreamBeginCapture")
+    assert "capture_mutex()" in net[i - 400:i], "the capture must hold the guard exclusively"
+
+
 def test_no_cpu_fallback(built, pkg):
     import torch
     if torch.cuda.is_available():

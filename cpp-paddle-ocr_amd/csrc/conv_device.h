@@ -156,6 +156,17 @@ __device__ __forceinline__ float4 apply_epilogue4(const Epilogue& ep, float4 v, 
 // once, the stage descriptor is decoded once, and no load is ever issued behind a store (loads and
 // stores retire through one in-order counter).  PLAIN (logical channel order, unaligned rows: the two
 // heads) is a template parameter so the packed path keeps its 16-byte stores.
+// (n, y, x) of output pixel m for the per-image epilogue stages: a uniform grid, or the ragged batch's tables (the wave's
+// first pixel - uniform - starts the search)
+__device__ __forceinline__ void conv_finish_nyx(const ConvArgs& a, long m, int& n, int& y, int& x) {
+  if (a.rout.w) {
+    int w;
+    rag_decompose(a.rout, a.N, a.OH, m, m - (threadIdx.x & 31), n, y, x, w);
+  } else {
+    decompose(m, a.OH * a.OW, a.OW, n, y, x);
+  }
+}
+
 template <int NT, int MODE>
 __device__ __forceinline__ void conv_finish(const ConvArgs& a, const Epilogue& ep, floatx16 (&acc)[NT], int nt0, long m, int hb,
                                             const float* spar, const int sstride = NT * 32) {
@@ -249,12 +260,12 @@ __device__ __forceinline__ void conv_finish(const ConvArgs& a, const Epilogue& e
 #undef OCR_ACT_SWEEP
       } break;
       case EP_MULC: {  // per-image channel gate [N][Cs_out]
-        if constexpr (MODE != OUT_DECONV) decompose(m, a.OH * a.OW, a.OW, n, y, x);
+        if constexpr (MODE != OUT_DECONV) conv_finish_nyx(a, m, n, y, x);
         const float* gate = st.v0 + (long)n * a.Cs_out + r0;
         OCR_EP_SWEEP({ const float4 r = *(const float4*)(gate + coff(rel)); wx = wx * r.x; wy = wy * r.y; wz = wz * r.z; ww = ww * r.w; })
       } break;
       case EP_GATERES: {  // x * gate + x: two roundings, as the ew pass (mulc, then addt of x itself) it replaces
-        if constexpr (MODE != OUT_DECONV) decompose(m, a.OH * a.OW, a.OW, n, y, x);
+        if constexpr (MODE != OUT_DECONV) conv_finish_nyx(a, m, n, y, x);
         const float* gate = st.v0 + (long)n * a.Cs_out + r0;
         OCR_EP_SWEEP({
           const float4 r = *(const float4*)(gate + coff(rel));
@@ -270,8 +281,13 @@ __device__ __forceinline__ void conv_finish(const ConvArgs& a, const Epilogue& e
         OCR_EP_SWEEP({ const float4 r = *(const float4*)(res + ooff(rel)); wx = wx + r.x; wy = wy + r.y; wz = wz + r.z; ww = ww + r.w; })
       } break;
       case EP_ADDUP: {  // nearest-upsampled coarser map (never after a deconv)
-        if constexpr (MODE != OUT_DECONV) decompose(m, a.OH * a.OW, a.OW, n, y, x);
-        const float* up = st.v0 + (((long)n * st.a2 + y / st.a0) * st.a1 + x / st.a0) * a.Cs_out + r0;
+        if constexpr (MODE != OUT_DECONV) conv_finish_nyx(a, m, n, y, x);
+        long spix = ((long)n * st.a2 + y / st.a0) * st.a1 + x / st.a0;
+        if (a.rout.h) {  // ragged batch of images: the operand lives on the level log2(a0) coarser, same tables
+          const int lu = 31 - __clz(st.a0);
+          spix = (long)(a.rout.cw[n] >> (2 * (a.rout.shift + lu))) + (long)(y / st.a0) * (a.rout.w[n] >> (a.rout.shift + lu)) + x / st.a0;
+        }
+        const float* up = st.v0 + spix * a.Cs_out + r0;
         OCR_EP_SWEEP({ const float4 r = *(const float4*)(up + coff(rel)); wx = wx + r.x; wy = wy + r.y; wz = wz + r.z; ww = ww + r.w; })
       } break;
     }

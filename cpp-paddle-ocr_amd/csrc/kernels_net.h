@@ -75,8 +75,10 @@ struct ConvRowsumArgs {
   const float* in;
   const float* w;
   float* part;
-  long rows;  // N * H
+  long rows;  // N * H (ragged batch: every sample's rows)
   int W, Cin, Cs_in, Cs_out;
+  int N, H;      // ragged batch: samples, uniform height (lines mode)
+  RagLevel rag;  // ragged batch: the level of the conv's input = output
 };
 bool launch_conv_rowsum(const ConvRowsumArgs& a, hipStream_t s);
 // the same with two 32-pixel tiles per wave (big single-tap convs with a C8I output, nt = 3 | 4); false: not this shape

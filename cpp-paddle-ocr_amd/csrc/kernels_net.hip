@@ -1215,6 +1215,13 @@ __global__ void __launch_bounds__(256) conv_rowsum_kernel(const ConvRowsumArgs a
     wlo[k] = ocr_f2{w.x, w.y}; whi[k] = ocr_f2{w.z, w.w};
   }
   const float* src = a.in + ny * a.W * CS_IN;
+  int W = a.W;
+  if (a.rag.w) {  // ragged batch: row y of sample n, the sample's own width
+    const int n = rag_sample_of_row(a.rag, a.N, a.H, ny, (long)blockIdx.x * 256 / c4n);
+    const int y = (int)(ny - rag_row0(a.rag, n, a.H));
+    W = rag_w(a.rag, n);
+    src = a.in + (rag_pix0(a.rag, n, a.H) + (long)y * W) * CS_IN;
+  }
   ocr_f2 slo = {0.f, 0.f}, shi = {0.f, 0.f};
   auto pixel = [&](const float4 (&xin)[CS_IN / 4], ocr_f2& lo, ocr_f2& hi) __attribute__((always_inline)) {
     lo = ocr_f2{0.f, 0.f}; hi = ocr_f2{0.f, 0.f};
@@ -1228,7 +1235,7 @@ __global__ void __launch_bounds__(256) conv_rowsum_kernel(const ConvRowsumArgs a
     }
   };
   int x = 0;
-  for (; x + U <= a.W; x += U) {
+  for (; x + U <= W; x += U) {
     float4 xin[U][CS_IN / 4];
 #pragma unroll
     for (int u = 0; u < U; ++u)
@@ -1240,7 +1247,7 @@ __global__ void __launch_bounds__(256) conv_rowsum_kernel(const ConvRowsumArgs a
 #pragma unroll
     for (int u = 0; u < U; ++u) { slo = slo + lo[u]; shi = shi + hi[u]; }  // left to right: the pool's order
   }
-  for (; x < a.W; ++x) {
+  for (; x < W; ++x) {
     float4 xin[CS_IN / 4];
 #pragma unroll
     for (int q = 0; q < CS_IN / 4; ++q) xin[q] = *(const float4*)(src + (long)x * CS_IN + 4 * q);

@@ -755,11 +755,11 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths, const i
   // again: three passes over 1.4 GB at 240 x 240 x 64 images for a K = 12 matrix product.  Instead the conv runs twice:
   // first as conv_rowsum_kernel, which leaves only the pool's row sums, then - with the gate known - as the ordinary
   // conv kernel with the ew's stages in its epilogue (EP_GATERES + the FPN's addup), writing the block's output.  Both
-  // passes compute the same chain per output, so nothing changes bit for bit.  Uniform batches only (the conv kernels'
-  // per-image epilogue stages decode (n, y, x) from a uniform grid).  OCR_FUSE_RSE=0 disables (A/B, results identical).
+  // passes compute the same chain per output, so nothing changes bit for bit.  Uniform batches and ragged batches of images
+  // (the conv epilogue's per-image stages decode (n, y, x) from either).  OCR_FUSE_RSE=0 disables (A/B, results identical).
   std::vector<int> rse_conv(nops, -1);   // ew op -> the conv it absorbs
   std::vector<char> rse_first(nops, 0);  // that conv: its launch is the row-sum pass, its tensor never exists
-  if (keep_all_ != 1 && rt_options().fuse_rse && !rag) {
+  if (keep_all_ != 1 && rt_options().fuse_rse && (!rag || img)) {
     for (int oi = 0; oi + 3 < nops; ++oi) {
       const PlanOp& c = plan_.ops[oi];
       const PlanOp& g = plan_.ops[oi + 1];
@@ -879,7 +879,8 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths, const i
       const TensorDesc& in = T[op.in];
       ConvRowsumArgs a{};
       a.in = arena_ + in.offset; a.w = dev_vec("rsw:" + op.w); a.part = gap_part_;
-      a.rows = (long)in.n * in.h; a.W = in.w; a.Cin = op.cin; a.Cs_in = in.cs; a.Cs_out = o.cs;
+      a.rows = rag ? rows_of(in) : (long)in.n * in.h; a.W = in.w; a.Cin = op.cin; a.Cs_in = in.cs; a.Cs_out = o.cs;
+      a.N = in.n; a.H = in.h; a.rag = rlevel(in);
       if (!a.w) { err = "RSE block: no row-sum weight image for " + op.w; return false; }
       snprintf(nm, sizeof nm, "%s.%02d.conv1x1_%d_%d_rowsum", plan_.name.c_str(), oi, op.cin, op.cout);
       L.name = nm;
@@ -962,7 +963,7 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths, const i
             // pointwise, or a stride-1 "same" conv (the recognizer's 1x3 neck convs, the detector's 3x3 neck / head convs):
             // rows in = rows out, one level
             if (in.lvl < 0 || o.lvl != in.lvl || o.h != in.h || op.kind == PlanOp::DECONV) { err = "ragged batch: dense conv must keep its input's shape"; return false; }
-            for (auto& st : op.ep) if (st.kind == EP_MULC || st.kind == EP_ADDUP) { err = "ragged batch: per-image epilogue stage after a dense conv is not on this path"; return false; }
+            for (auto& st : op.ep) if (st.kind == EP_ADDUP && !img) { err = "ragged batch of lines: an upsampled operand after a dense conv is not on this path"; return false; }
             a.rin = rlevel(in); a.rout = rlevel(o);
             if (img && op.kh == 3 && op.kw == 3) a.rtiles = tiles_table(o, 8, a.rtiles_total);  // (the 8x16 LDS-tile kernel)
           }

@@ -723,7 +723,7 @@ static int dwpw_dispatch(const DwPwArgs& a, hipStream_t s, bool query, bool rows
   // (half the B-fragment traffic per MFMA); OCR_DWPW_T4=thin keeps the thin shape for A/B runs
   if (!rt_options().dwpw_t4_thin) {
     OCR_DWPW_CASE(3, 1, 1, 32, true, 2, 1, 1, 3, tiles == 4)
-    OCR_DWPW_CASE(3, 2, 1, 32, true, 2, 1, 2, 2, tiles == 4)
+    OCR_DWPW_CASE(3, 2, 1, 32, true, 2, 2, 1, 2, tiles == 4)  // (ragged batch, 1024 lines: 1/2/2 0.846 ms, 2/1/2 0.810, 1/1/3 1.15)
   }
   // thin layers: tiles <= 4, one wave owns every output column of its 32 pixels
   OCR_DWPW_CASE(3, 1, 1, 16, false, 1, 2, 2, 2, tiles == 1)

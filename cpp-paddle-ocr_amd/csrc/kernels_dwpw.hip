@@ -732,7 +732,7 @@ static int dwpw_dispatch(const DwPwArgs& a, hipStream_t s, bool query, bool rows
   OCR_DWPW_CASE(3, 1, 1, 16, false, 4, 1, 2, 2, tiles == 4)
   OCR_DWPW_CASE(3, 2, 1, 16, false, 4, 1, 2, 2, tiles == 4)
   // wide layers: two column groups per workgroup (and further column blocks in the grid)
-  OCR_DWPW_CASE(3, 1, 2, 16, true, 4, 1, 2, 2, tiles == 8)
+  OCR_DWPW_CASE(3, 1, 2, 16, true, 4, 2, 1, 2, tiles == 8)  // (ragged batch in the step: 1/2/2 1.92 ms, 2/1/2 1.81, 2/2/2 1.83)
 #ifndef OCR_DWPW_55  // GD, TD, LB of the 240-channel 5x5 blocks (tools/micro/dwpw_probe.hip builds variants with -DOCR_DWPW_55=g,t,l)
 #define OCR_DWPW_55 2, 2, 2
 #endif

@@ -593,12 +593,13 @@ def main(argv=None):
                 name, r = top
                 avg_ms = r["ms"] / max(1, r["count"])
                 tflops = r["flops"] / (r["ms"] * 1e-3) / 1e12 if r["ms"] > 0 else 0.0
-                traffic = None
+                traffic, traffic_src = None, None
                 for tf in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("pmc_traffic.json")), reverse=True):
                     # HBM bytes per launch from the rocprofv3 --pmc passes (tools/pmc_traffic.py), latest round first
                     pm = json.load(open(os.path.join(ROOT, "profiles", tf)))
                     if pm.get("kernel") == name:
                         traffic = pm["traffic_bytes_per_launch"]
+                        traffic_src = "profiles/%s: rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs, gfx950 corrections) of the same bench command on this kernel, not this run" % tf
                         break
                 gbps = r["bytes"] / (r["ms"] * 1e-3) / 1e9 if r["ms"] > 0 else 0.0
                 # which roof binds this kernel: its algorithmic intensity against the f32 ridge (157.3 TFLOP/s / 8 TB/s)
@@ -606,7 +607,7 @@ def main(argv=None):
                 out["roofline"] = {"kernel": name, "measured_in": "single_chain", "bound": "hbm" if hbm_bound else "mfma",
                                    "achieved": gbps if hbm_bound else tflops, "peak": HBM_PEAK_GBS if hbm_bound else FP32_MFMA_PEAK_TFLOPS,
                                    "unit": "GB/s" if hbm_bound else "TFLOP/s",
-                                   "frac": gbps / HBM_PEAK_GBS if hbm_bound else tflops / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                                   "frac": gbps / HBM_PEAK_GBS if hbm_bound else tflops / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                                    "avg_launch_ms": avg_ms, "launches": r["count"],
                                    "algorithmic_flops_per_launch": r["flops"] / max(1, r["count"]),
                                    "algorithmic_bytes_per_launch": r["bytes"] / max(1, r["count"]),

@@ -1,5 +1,8 @@
 // Development probe: runs the product's conv_mfma_kernel (included from csrc) on a synthetic 1x1 conv
 // and reports TFLOP/s plus the per-wave phase breakdown from clock64() stamps.
+// NOTE (round 3): the stamps' stores make the compiler replace the K loop's counted vmcnt waits by full drains, so
+// TIMES and A/B comparisons from this probe are not the product kernel's - use conv_time.hip for those; this probe is
+// only good for the relative length of a wave's phases.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -DOCR_CONV_PROBE -I../../cpp-paddle-ocr_amd/csrc -o conv_probe conv_probe.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>

@@ -1201,7 +1201,7 @@ __global__ void __launch_bounds__(256) gap_cols_kernel(const float* __restrict__
 // (k ascending in LOGICAL input-channel order from 0, one fmaf per k - what the matrix pipe does with the fragment
 // image), then s = s + v.  The 24 threads of a row read the same input pixels (L1 broadcasts).
 // =====================================================================================
-template <int CIN, int CS_IN, int U>
+template <int CIN, int CS_IN, int U, bool RAG>
 __global__ void __launch_bounds__(256) conv_rowsum_kernel(const ConvRowsumArgs a) {
   const int c4n = a.Cs_out >> 2;
   const long t = (long)blockIdx.x * 256 + threadIdx.x;
@@ -1215,8 +1215,9 @@ __global__ void __launch_bounds__(256) conv_rowsum_kernel(const ConvRowsumArgs a
     wlo[k] = ocr_f2{w.x, w.y}; whi[k] = ocr_f2{w.z, w.w};
   }
   const float* src = a.in + ny * a.W * CS_IN;
-  int W = a.W;
-  if (a.rag.w) {  // ragged batch: row y of sample n, the sample's own width
+  int W = a.W;  // (uniform batch: a scalar; the ragged form is its own instantiation - with a per-lane width in the same
+                // code the uniform launch ran at half speed)
+  if constexpr (RAG) {  // ragged batch: row y of sample n, the sample's own width
     const int n = rag_sample_of_row(a.rag, a.N, a.H, ny, (long)blockIdx.x * 256 / c4n);
     const int y = (int)(ny - rag_row0(a.rag, n, a.H));
     W = rag_w(a.rag, n);
@@ -1257,15 +1258,19 @@ __global__ void __launch_bounds__(256) conv_rowsum_kernel(const ConvRowsumArgs a
   }
   *(float4*)(a.part + ny * a.Cs_out + pc) = make_float4(slo.x, slo.y, shi.x, shi.y);
 }
-bool launch_conv_rowsum(const ConvRowsumArgs& a, hipStream_t s) {
+template <bool RAG>
+static bool launch_conv_rowsum_r(const ConvRowsumArgs& a, hipStream_t s) {
   const long threads = a.rows * (a.Cs_out >> 2);
   const dim3 grid((unsigned)((threads + 255) / 256));
-  if (a.Cs_in == 16 && a.Cin == 12) hipLaunchKernelGGL((conv_rowsum_kernel<12, 16, 4>), grid, dim3(256), 0, s, a);
-  else if (a.Cs_in == 24 && a.Cin == 18) hipLaunchKernelGGL((conv_rowsum_kernel<18, 24, 2>), grid, dim3(256), 0, s, a);
-  else if (a.Cs_in == 16) hipLaunchKernelGGL((conv_rowsum_kernel<16, 16, 4>), grid, dim3(256), 0, s, a);
-  else if (a.Cs_in == 24) hipLaunchKernelGGL((conv_rowsum_kernel<24, 24, 2>), grid, dim3(256), 0, s, a);
+  if (a.Cs_in == 16 && a.Cin == 12) hipLaunchKernelGGL((conv_rowsum_kernel<12, 16, 4, RAG>), grid, dim3(256), 0, s, a);
+  else if (a.Cs_in == 24 && a.Cin == 18) hipLaunchKernelGGL((conv_rowsum_kernel<18, 24, 2, RAG>), grid, dim3(256), 0, s, a);
+  else if (a.Cs_in == 16) hipLaunchKernelGGL((conv_rowsum_kernel<16, 16, 4, RAG>), grid, dim3(256), 0, s, a);
+  else if (a.Cs_in == 24) hipLaunchKernelGGL((conv_rowsum_kernel<24, 24, 2, RAG>), grid, dim3(256), 0, s, a);
   else return false;
   return true;
+}
+bool launch_conv_rowsum(const ConvRowsumArgs& a, hipStream_t s) {
+  return a.rag.w ? launch_conv_rowsum_r<true>(a, s) : launch_conv_rowsum_r<false>(a, s);
 }
 void launch_gap_cols(const float* part, float* out, int N, int H, int W, int Cs, hipStream_t s, RagLevel rag) {
   hipLaunchKernelGGL(gap_cols_kernel, dim3((unsigned)((N * Cs + 255) / 256)), dim3(256), 0, s, part, out, N, H, Cs, (float)(H * W), rag);

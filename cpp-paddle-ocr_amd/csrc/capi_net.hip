@@ -33,6 +33,7 @@ const RtOptions& rt_options() {
     o.conv_small_nt = !off("OCR_CONV_SMALL_NT");
     o.conv_nt_max = (int)num("OCR_CONV_NT_MAX", 4);
     o.conv_mt2 = !off("OCR_CONV_MT2");
+    if (const char* e = getenv("OCR_CONV_MT2")) o.conv_mt2_force = e[0] == 'f';
     o.conv_c24 = !off("OCR_CONV_C24");
     o.conv_tile = !off("OCR_CONV_TILE");
     if (const char* e = getenv("OCR_DW_PATCH")) sscanf(e, "%dx%d", &o.dw_patch_to, &o.dw_patch_r);

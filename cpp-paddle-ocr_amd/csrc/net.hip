@@ -1068,8 +1068,9 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths, const i
             // Big 1x1 convs: two pixel tiles per wave (kernels_net.hip, conv_mfma_mt_kernel) - a weight fragment feeds two
             // MFMAs, half the workgroups stage parameters; worth it from K = 192 on while the launch still has ~4
             // workgroups per CU (rec ops 25/30/32/34, det ops 30/38).  Results do not depend on the tiling.
-            const bool mt2 = rt_options().conv_mt2 && ntl == nt && (nt == 3 || nt == 4) && taps == 1 && a.out_mode == OUT_C8I && in.cs >= 192 &&
-                             ((a.M + 255) / 256) * (long)(a.NTtot / nt) >= 1024;
+            const bool mt2 = rt_options().conv_mt2 && (nt == 3 || nt == 4) && taps == 1 && a.out_mode == OUT_C8I &&
+                             (rt_options().conv_mt2_force || (ntl == nt && in.cs >= 192 && ((a.M + 255) / 256) * (long)(a.NTtot / nt) >= 1024));
+            if (mt2) ntl = nt;  // (the two-tile kernel is instantiated for the table's NT)
             L.fn = [this, a, ep, ntl, mt2](hipStream_t s) {
               if (mt2 && launch_conv_mfma_mt2(a, ep, ntl, s)) return;
               if (!launch_conv_mfma(a, ep, ntl, s)) this->launch_error_ = "launch_conv_mfma: this conv shape / output mode is not instantiated";

@@ -18,6 +18,7 @@ struct RtOptions {
   bool conv_small_nt = true;   // OCR_CONV_SMALL_NT=0
   int conv_nt_max = 4;         // OCR_CONV_NT_MAX=n
   bool conv_mt2 = true;        // OCR_CONV_MT2=0
+  bool conv_mt2_force = false; // OCR_CONV_MT2=force (tests): two pixel tiles per wave whatever the launch's size and K
   bool conv_c24 = true;        // OCR_CONV_C24=0
   bool conv_tile = true;       // OCR_CONV_TILE=0
   int dw_patch_to = 0, dw_patch_r = 0;  // OCR_DW_PATCH=TOxR; 0 = per shape

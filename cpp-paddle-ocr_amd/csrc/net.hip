@@ -889,9 +889,8 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths, const i
       L.fn = [this, a](hipStream_t s) {
         if (!launch_conv_rowsum(a, s)) this->launch_error_ = "launch_conv_rowsum: shape accepted at bind time was refused at launch";
       };
-      goto emit;
     }
-    switch (op.kind) {
+    else switch (op.kind) {
       case PlanOp::CONV: case PlanOp::LINEAR: case PlanOp::DECONV: {
         const TensorDesc& in = T[gate_src[oi] >= 0 ? gate_src[oi] : op.in];
         Epilogue ep;
@@ -1237,7 +1236,6 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths, const i
       } break;
       default: break;
     }
-  emit:
     // instance tag: the same op at another bound shape is another roofline row
     if (img) snprintf(nm, sizeof nm, "@%dx~%ldx~%ld", N, irows / N, ipix / irows);  // ragged images: mean height, mean width
     else if (rag) snprintf(nm, sizeof nm, "@%dx%dx~%ld", N, H, ltot[0] / N);  // ragged: the lines' mean width

@@ -395,6 +395,10 @@ bool RecStage::create(const RecConfig& cfg, std::string& err, int& code) {
   if (cfg.precision != "fp32") { err = "precision '" + cfg.precision + "' is not implemented (fp32 only)"; return false; }
   if (cfg.batch_num < 1 || cfg.img_h < 1 || cfg.img_w < 1) { err = "bad rec shape"; return false; }
   if (cfg.sort_mode != OCR_SORT_STD && cfg.sort_mode != OCR_SORT_STABLE) { err = "unknown sort_mode"; return false; }
+  if (const char* e = getenv("OCR_REC_MAX_LINES")) {  // per handle: 48x320-line equivalents per ragged launch (A/B; results are identical)
+    const long v = atol(e);
+    if (v >= 16 && v <= 16384) max_lines_per_launch = (int)v;
+  }
   code = ocr_rt_init(cfg.device);
   if (code) { err = ocr_last_error(); return false; }
   code = OCR_ERR_MODEL;

@@ -28,7 +28,10 @@ class ocr_det_cfg(C.Structure):
     _fields_ = [("model_dir", C.c_char_p), ("device_id", C.c_int), ("limit_type", C.c_char_p),
                 ("limit_side_len", C.c_int), ("det_db_thresh", C.c_double), ("det_db_box_thresh", C.c_double),
                 ("det_db_unclip_ratio", C.c_double), ("det_db_score_mode", C.c_char_p), ("use_dilation", C.c_int),
-                ("precision", C.c_char_p), ("max_batch", C.c_int)]
+                ("precision", C.c_char_p), ("max_batch", C.c_int), ("cv_compat", C.c_int)]
+
+
+CV_45, CV_410 = 45, 410  # ocr_det_cfg.cv_compat (0 = default = OCR_CV_COMPAT from the environment, else CV_410)
 
 
 class ocr_cls_cfg(C.Structure):
@@ -225,7 +228,7 @@ class Det:
     """DBDetector over the C-ABI (ocr_det_*).  Defaults = the literals OCRWorker passes."""
 
     def __init__(self, model_dir=None, device=0, limit_type="max", limit_side_len=512, thresh=0.2, box_thresh=0.4,
-                 unclip_ratio=1.8, score_mode="fast", use_dilation=False, precision="fp32", max_batch=1):
+                 unclip_ratio=1.8, score_mode="fast", use_dilation=False, precision="fp32", max_batch=1, cv_compat=0):
         L = lib()
         _stage_protos(L)
         cfg = ocr_det_cfg()
@@ -236,6 +239,7 @@ class Det:
         cfg.device_id, cfg.limit_side_len = device, limit_side_len
         cfg.det_db_thresh, cfg.det_db_box_thresh, cfg.det_db_unclip_ratio = thresh, box_thresh, unclip_ratio
         cfg.use_dilation, cfg.max_batch = int(use_dilation), max_batch
+        cfg.cv_compat = int(cv_compat)
         self.h = C.c_void_p()
         check(L.ocr_det_create(C.byref(cfg), C.byref(self.h)))
         self.times = (C.c_double * 3)()
@@ -488,7 +492,7 @@ class Pipe:
 
     def __init__(self, model_root=None, device=0, enable_cls=False, limit_type="max", limit_side_len=512, thresh=0.2,
                  box_thresh=0.4, unclip_ratio=1.8, use_dilation=False, rec_batch_num=16, rec_img_h=28, rec_img_w=192,
-                 cls_batch_num=8, crop_mode=CROP_BOUNDING_RECT, score_mode="fast", rec_sort_mode=0, phases=0):
+                 cls_batch_num=8, crop_mode=CROP_BOUNDING_RECT, score_mode="fast", rec_sort_mode=0, phases=0, cv_compat=0):
         L = lib()
         _pipe_protos(L)
         root = model_root or MODELS
@@ -503,6 +507,7 @@ class Pipe:
         cfg.det.limit_side_len = limit_side_len
         cfg.det.det_db_thresh, cfg.det.det_db_box_thresh, cfg.det.det_db_unclip_ratio = thresh, box_thresh, unclip_ratio
         cfg.det.use_dilation = int(use_dilation)
+        cfg.det.cv_compat = int(cv_compat)
         cfg.rec.rec_batch_num, cfg.rec.rec_img_h, cfg.rec.rec_img_w = rec_batch_num, rec_img_h, rec_img_w
         cfg.rec.sort_mode = int(rec_sort_mode)
         cfg.cls.cls_batch_num = cls_batch_num

@@ -3,6 +3,7 @@
 #include "rt_options.h"
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <memory>
 #include <string>
 
@@ -12,7 +13,7 @@
 namespace ocr {
 
 void set_last_error(const std::string& msg);
-void priority_anchor(int device_id, bool again = false);             // one idle high-priority stream per device (capi_net.hip)
+void priority_anchor(int device_id, int want = 1);  // up to `want` (<= 2) idle high-priority streams per device, created once per process (capi_net.hip)
 const char* embedded_plan(const char* kind);  // "det" | "cls" | "rec" -> plan text or nullptr
 
 // Resolves the weights file of a model directory the way the reference resolves its model file
@@ -22,6 +23,14 @@ const char* embedded_plan(const char* kind);  // "det" | "cls" | "rec" -> plan t
 bool load_model_dir(const std::string& model_dir, const char* weights_override, const char* kind, WeightMap& w, std::string& err);
 
 int fail(int code, const std::string& msg);
+
+// ocr_det_cfg.cv_compat -> OCR_CV_45 | OCR_CV_410 (0: OCR_CV_COMPAT from the environment, else OCR_CV_410); any other
+// value is passed through and refused by DetStage::create
+inline int resolve_cv_compat(int v) {
+  if (v != OCR_CV_DEFAULT) return v;
+  if (const char* e = getenv("OCR_CV_COMPAT")) return atoi(e);
+  return OCR_CV_410;
+}
 
 #define CAPI_HIP(expr)                                                             \
   do {                                                                             \

@@ -48,10 +48,15 @@ const RtOptions& rt_options() {
 static std::mutex g_refuse_mu;
 static std::string g_refuse;
 static std::atomic<bool> g_refuse_on{false};
-const char* rt_refuse_launch() { return g_refuse_on.load(std::memory_order_acquire) ? g_refuse.c_str() : ""; }
+// a COPY, taken under the lock: chain and lane threads read this on every run while a test may set it (the flag keeps
+// the common case - no fault injection - to one atomic load)
+std::string rt_refuse_launch() {
+  if (!g_refuse_on.load(std::memory_order_acquire)) return std::string();
+  std::lock_guard<std::mutex> lk(g_refuse_mu);
+  return g_refuse;
+}
 void rt_set_refuse_launch(const char* substr) {
   std::lock_guard<std::mutex> lk(g_refuse_mu);
-  g_refuse_on.store(false, std::memory_order_release);
   g_refuse = substr ? substr : "";
   g_refuse_on.store(!g_refuse.empty(), std::memory_order_release);
 }
@@ -121,20 +126,25 @@ bool load_model_dir(const std::string& model_dir, const char* weights_override, 
 // mapping of streams to hardware queues is not documented; ocr_pipe_create uses the configuration that measured fast
 // (two such streams after its stage objects).  OCR_PRIO_ANCHOR=0 leaves them out (A/B).  The structural fix is a
 // ragged detector batch (one launch list for all sizes, as the recognizer's), which needs no lanes at all.
-void priority_anchor(int device_id, bool again) {
+// At most `want` such streams exist per device for the life of the process (ocr_pipe_create asks for two, every further
+// pipeline of the process finds them there): nothing is created per handle, nothing leaks.
+void priority_anchor(int device_id, int want) {
   static std::mutex mu;
-  static hipStream_t anchor[64] = {};
+  static hipStream_t anchor[64][2] = {};
   std::lock_guard<std::mutex> lk(mu);
-  if (device_id < 0 || device_id >= 64 || (anchor[device_id] && !again) || !rt_options().prio_anchor) return;
-  int least = 0, greatest = 0;
-  if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess || least == greatest ||
-      hipStreamCreateWithPriority(&anchor[device_id], hipStreamDefault, greatest) != hipSuccess) {
-    anchor[device_id] = nullptr;
+  if (device_id < 0 || device_id >= 64 || !rt_options().prio_anchor) return;
+  for (int k = 0; k < std::min(want, 2); ++k) {
+    if (anchor[device_id][k]) continue;
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess || least == greatest ||
+        hipStreamCreateWithPriority(&anchor[device_id][k], hipStreamDefault, greatest) != hipSuccess) {
+      anchor[device_id][k] = nullptr;
+      (void)hipGetLastError();
+      return;
+    }
+    (void)hipMemsetAsync(nullptr, 0, 0, anchor[device_id][k]);  // (touch the stream: the runtime creates its queue on first use)
     (void)hipGetLastError();
-    return;
   }
-  (void)hipMemsetAsync(nullptr, 0, 0, anchor[device_id]);  // (touch the stream: the runtime creates its queue on first use)
-  (void)hipGetLastError();
 }
 
 }  // namespace ocr
@@ -314,8 +324,7 @@ int g_fake_calls = 0, g_fake_last_bytes = 0;
 bool g_fake_refuse = false;
 }  // namespace
 int ocr_selftest_lds_memo(void) {
-  LdsAttrHooks& hk = lds_attr_hooks();
-  const LdsAttrHooks saved = hk;
+  LdsAttrHooks hk;  // handed to raise_dynamic_lds explicitly: the launchers of running pipelines never see the fakes
   hk.get_device = [] { return g_fake_dev; };
   hk.set_attribute = [](const void*, int bytes) { ++g_fake_calls; g_fake_last_bytes = bytes; return !g_fake_refuse; };
   static LdsAttrMemo memo;  // (a fresh one per process: the test runs once)
@@ -324,22 +333,21 @@ int ocr_selftest_lds_memo(void) {
   auto expect = [&](bool cond, const char* what) { if (!cond && why.empty()) why = what; };
   g_fake_calls = 0;
   g_fake_dev = 0;
-  expect(raise_dynamic_lds(k, 70000, memo) && g_fake_calls == 1, "first request on device 0 must raise the attribute");
-  expect(raise_dynamic_lds(k, 70000, memo) && g_fake_calls == 1, "the same request again is answered from the memo");
-  expect(raise_dynamic_lds(k, 65000, memo) && g_fake_calls == 1, "a smaller request is covered by the raised limit");
-  expect(raise_dynamic_lds(k, 72704, memo) && g_fake_calls == 2 && g_fake_last_bytes == 72704, "a larger request must raise again");
+  expect(raise_dynamic_lds(k, 70000, memo, &hk) && g_fake_calls == 1, "first request on device 0 must raise the attribute");
+  expect(raise_dynamic_lds(k, 70000, memo, &hk) && g_fake_calls == 1, "the same request again is answered from the memo");
+  expect(raise_dynamic_lds(k, 65000, memo, &hk) && g_fake_calls == 1, "a smaller request is covered by the raised limit");
+  expect(raise_dynamic_lds(k, 72704, memo, &hk) && g_fake_calls == 2 && g_fake_last_bytes == 72704, "a larger request must raise again");
   g_fake_dev = 1;
-  expect(raise_dynamic_lds(k, 70000, memo) && g_fake_calls == 3, "another device has its own memo entry");
+  expect(raise_dynamic_lds(k, 70000, memo, &hk) && g_fake_calls == 3, "another device has its own memo entry");
   g_fake_dev = 2;
   g_fake_refuse = true;
-  expect(!raise_dynamic_lds(k, 70000, memo) && g_fake_calls == 4, "a refusal is reported");
+  expect(!raise_dynamic_lds(k, 70000, memo, &hk) && g_fake_calls == 4, "a refusal is reported");
   g_fake_refuse = false;
-  expect(!raise_dynamic_lds(k, 70000, memo) && g_fake_calls == 4, "and remembered: the caller keeps its small-LDS path on that device");
+  expect(!raise_dynamic_lds(k, 70000, memo, &hk) && g_fake_calls == 4, "and remembered: the caller keeps its small-LDS path on that device");
   g_fake_dev = 0;
-  expect(raise_dynamic_lds(k, 72704, memo) && g_fake_calls == 4, "device 0 is unaffected by the other devices' entries");
+  expect(raise_dynamic_lds(k, 72704, memo, &hk) && g_fake_calls == 4, "device 0 is unaffected by the other devices' entries");
   g_fake_dev = -1;
-  expect(!raise_dynamic_lds(k, 1, memo), "no current device");
-  hk = saved;
+  expect(!raise_dynamic_lds(k, 1, memo, &hk), "no current device");
   return why.empty() ? OCR_OK : fail(OCR_ERR_DEVICE, why);
 }
 

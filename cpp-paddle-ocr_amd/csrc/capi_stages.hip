@@ -44,6 +44,7 @@ int ocr_det_create(const ocr_det_cfg* c, ocr_det** out) {
   cfg.use_dilation = c->use_dilation;
   if (c->precision) cfg.precision = c->precision;
   cfg.max_batch = c->max_batch > 0 ? c->max_batch : 1;
+  cfg.cv_compat = resolve_cv_compat(c->cv_compat);
   std::unique_ptr<ocr_det> h(new ocr_det());
   std::string err;
   int code = 0;

@@ -35,10 +35,12 @@ struct PostArgs {
   int* cand_boxes;        // [N][max_cand][8]
   int* cand_valid;        // [N][max_cand]
   int* status;            // device error bits (POST_ERR_*)
+  int* pool_need;         // [N] key slots the image's first max_cand borders need (whether they fitted pool_cap or not)
   unsigned* mask_pool;    // [N][mask_pool_words] scratch of the slow (polygon) score; null in fast mode
   unsigned* mask_pool_top;  // [N] bump cursors (zeroed per call)
   unsigned mask_pool_words;
   int slow;               // det_db_score_mode == "slow"
+  int fill_shifted;       // cv::fillPoly rule of the box score: 1 = OpenCV >= 4.5.2 (OCR_CV_410), 0 = 4.5.1 (OCR_CV_45)
   int pool_cap;
   int H, W, max_cand;
   float box_thresh, unclip_ratio, ratio_h, ratio_w;

@@ -379,18 +379,21 @@ __device__ __forceinline__ int pow2_ceil(int v) {
 // per image: exclusive scan of pow2-rounded sizes -> offsets; overflow flag
 __global__ void __launch_bounds__(64) trace_offsets_kernel(int max_cand, const int* __restrict__ ncont,
                                                            const int* __restrict__ npts, int* __restrict__ poff, int pool_cap,
-                                                           int* __restrict__ status) {
+                                                           int* __restrict__ status, int* __restrict__ pool_need) {
   const int n = blockIdx.x;
   if (threadIdx.x != 0) return;
   int off = 0;
+  long need = 0;
   const int nc = ncont[n];
   for (int c = 0; c < nc; ++c) {
     const int sz = npts[(long)n * max_cand + c];
     const int p2 = sz > 2 ? pow2_ceil(sz) : 0;  // borders with <= 2 vertices are dropped by the reference
+    need += p2;
     if (off + p2 > pool_cap) { atomicOr(status, POST_ERR_POOL); poff[(long)n * max_cand + c] = -1; continue; }
     poff[(long)n * max_cand + c] = off;
     off += p2;
   }
+  pool_need[n] = need > INT_MAX ? INT_MAX : (int)need;  // the host grows the pool to this and runs the pass again
 }
 // pass B: store keys (padded with +inf to a power of two)
 __global__ void __launch_bounds__(64) trace_store_kernel(const uint8_t* __restrict__ bm, int H, int W, int max_cand,
@@ -423,14 +426,14 @@ __global__ void __launch_bounds__(kTraceThreads) trace_lds_kernel(const uint8_t*
                                                         int* __restrict__ npts, int* __restrict__ poff,
                                                         unsigned long long* __restrict__ pool, int pool_cap,
                                                         int* __restrict__ iscratch, int slice_limit, int* __restrict__ status,
-                                                        const PostImg* __restrict__ img) {
+                                                        int* __restrict__ pool_need, const PostImg* __restrict__ img) {
   extern __shared__ unsigned s_bits[];
   const int n = blockIdx.x, tid = threadIdx.x;
   long base = (long)n * H * W;
   if (img) { H = img[n].h; W = img[n].w; base = img[n].off; }  // (LDS is sized for the largest image of the batch)
   const int stride = lds_bits_stride(W);
   const int nc = ncont[n];
-  if (nc == 0) return;
+  if (nc == 0) { if (tid == 0) pool_need[n] = 0; return; }
   for (int i = tid; i < (H + 2) * stride; i += kTraceThreads) {
     const int Y = i / stride, w = i - Y * stride;
     unsigned word = 0;
@@ -484,13 +487,16 @@ __global__ void __launch_bounds__(kTraceThreads) trace_lds_kernel(const uint8_t*
   __syncthreads();
   if (tid == 0) {  // exclusive scan of the pow2-rounded sizes (trace_offsets_kernel)
     int off = 0;
+    long need = 0;
     for (int c = 0; c < nc; ++c) {
       const int sz = s_npts[c];
       const int p2 = sz > 2 ? pow2_ceil(sz) : 0;  // borders with <= 2 vertices are dropped by the reference
+      need += p2;
       if (off + p2 > pool_cap) { atomicOr(status, POST_ERR_POOL); s_poff[c] = -1; continue; }
       s_poff[c] = off;
       off += p2;
     }
+    pool_need[n] = need > INT_MAX ? INT_MAX : (int)need;  // the host grows the pool to this and runs the pass again
   }
   __syncthreads();
   for (int c = 0; c < nc; ++c) {  // every border: the workgroup copies its keys (padded with +inf to a power of two)
@@ -855,9 +861,37 @@ __device__ __forceinline__ bool on_line(const LineRast& L, int x, int y) {
   return (long long)(d - 1) * 2 * L.dx < a && a <= (long long)d * 2 * L.dx;
 }
 
+// One polygon edge of the scan fill as CollectPolyEdges builds it (drawing.cpp), for a vertex pair already relative to
+// the mask.  `shifted` selects the OpenCV rule (ocr_det_cfg.cv_compat):
+//   false (OCR_CV_45, OpenCV 4.0 - 4.5.1): x in 16.16 at the vertices' integer x;
+//   true  (OCR_CV_410, 4.5.2 and later):   an edge whose outline segment lies inside the mask moves right by half a pixel;
+//         one whose segment had to be clipped is built from the CLIPPED integer end points (as far as cv::clipLine moved
+//         them, whatever it returned) and extrapolated back to the edge's first row.
+// The spans of a row are then [ (xa + up) >> 16, xb >> 16 ] with up = 65535 (classic: ceil) or 0 (shifted).
+__device__ EdgeRast make_edge(int mw, int mh, int ax, int ay, int bx, int by, bool shifted) {
+  EdgeRast e{};
+  if (ay == by) return e;
+  long long c0x = (long long)ax << 16, c0y = ay, c1x = (long long)bx << 16, c1y = by;
+  if (shifted) {
+    if ((unsigned)ax >= (unsigned)mw || (unsigned)bx >= (unsigned)mw || (unsigned)ay >= (unsigned)mh || (unsigned)by >= (unsigned)mh) {
+      long long x1 = ax, y1 = ay, x2 = bx, y2 = by;
+      (void)clip_line(mw, mh, x1, y1, x2, y2);
+      if (y1 != y2) { c0x = x1 << 16; c0y = y1; c1x = x2 << 16; c1y = y2; }
+    } else {
+      c0x += 32768;
+      c1x += 32768;
+    }
+  }
+  e.valid = 1;
+  e.dx = (c1x - c0x) / (c1y - c0y);
+  if (ay < by) { e.y0 = ay; e.y1 = by; e.x = c0x + ((long long)ay - c0y) * e.dx; }
+  else { e.y0 = by; e.y1 = ay; e.x = c1x + ((long long)by - c1y) * e.dx; }
+  return e;
+}
+
 // BoxScoreFast: masked mean over the bbox with the mask of fillPoly(int-truncated corners).
 // All 64 lanes participate; returns the score in every lane.
-__device__ float box_score_fast_wave(const P2f arr[4], const float* __restrict__ pred, int H, int W, int lane) {
+__device__ float box_score_fast_wave(const P2f arr[4], const float* __restrict__ pred, int H, int W, int lane, bool shifted) {
   float fxmin = fminf(fminf(arr[0].x, arr[1].x), fminf(arr[2].x, arr[3].x));
   float fxmax = fmaxf(fmaxf(arr[0].x, arr[1].x), fmaxf(arr[2].x, arr[3].x));
   float fymin = fminf(fminf(arr[0].y, arr[1].y), fminf(arr[2].y, arr[3].y));
@@ -877,21 +911,15 @@ __device__ float box_score_fast_wave(const P2f arr[4], const float* __restrict__
   for (int i = 0; i < 4; ++i) {
     const int p = (i + 3) & 3;  // previous vertex: edges run v[count-1] -> v[0] -> ...
     Ls[i] = make_line(mw, mh, vx[p], vy[p], vx[i], vy[i]);
-    Es[i].valid = 0;
-    if (vy[p] != vy[i]) {
-      const long long p0x = (long long)vx[p] << 16, p1x = (long long)vx[i] << 16;
-      EdgeRast e;
-      e.valid = 1;
-      if (vy[p] < vy[i]) { e.y0 = vy[p]; e.y1 = vy[i]; e.x = p0x; }
-      else { e.y0 = vy[i]; e.y1 = vy[p]; e.x = p1x; }
-      e.dx = (p1x - p0x) / (long long)(vy[i] - vy[p]);
-      Es[i] = e;
+    Es[i] = make_edge(mw, mh, vx[p], vy[p], vx[i], vy[i], shifted);
+    if (Es[i].valid) {
       ++nedges;
-      ey_min = min(ey_min, e.y0);
-      ey_max = max(ey_max, e.y1);
+      ey_min = min(ey_min, Es[i].y0);
+      ey_max = max(ey_max, Es[i].y1);
     }
   }
   const bool do_fill = nedges >= 2;
+  const long long up = shifted ? 0 : 65535;
   double sum = 0.0;
   int cnt = 0;
   // Row by row: the scan-fill spans of a row are worked out once per row, not once per pixel (the per-pixel form spent
@@ -934,7 +962,7 @@ __device__ float box_score_fast_wave(const P2f arr[4], const float* __restrict__
         xs[j + 1] = v;
       }
       for (int i = 0; i + 1 < na; i += 2) {
-        s1[i >> 1] = (int)((xs[i] + 65535) >> 16);
+        s1[i >> 1] = (int)((xs[i] + up) >> 16);
         s2[i >> 1] = (int)(xs[i + 1] >> 16);
       }
     }
@@ -970,7 +998,7 @@ __device__ float box_score_fast_wave(const P2f arr[4], const float* __restrict__
 // per-image word pool.  Returns the score in every lane, or -1 when the pool is exhausted.
 __device__ float polygon_score_wave(const unsigned long long* __restrict__ pts, int npts, 
                                     const float* __restrict__ pred, int H, int W, unsigned* pool, unsigned pool_words,
-                                    unsigned* pool_top, int lane, int* s_tmp /* >= 4 ints of LDS */) {
+                                    unsigned* pool_top, int lane, int* s_tmp /* >= 4 ints of LDS */, bool shifted) {
   // bounding box of the vertices (ints already; PolygonScoreAcc floors/ceils floats of ints)
   int bx0 = INT_MAX, bx1 = INT_MIN, by0 = INT_MAX, by1 = INT_MIN;
   for (int i = lane; i < npts; i += 64) {
@@ -1053,12 +1081,9 @@ __device__ float polygon_score_wave(const unsigned long long* __restrict__ pts, 
     const int j = i == 0 ? npts - 1 : i - 1;
     const int ax = key_x(GLD(&pts[j])) - xmin, ay = key_y(GLD(&pts[j])) - ymin, bx = key_x(GLD(&pts[i])) - xmin, by = key_y(GLD(&pts[i])) - ymin;
     if (ay == by) continue;
-    const long long p0x = (long long)ax << 16, p1x = (long long)bx << 16;
-    const long long dx = (p1x - p0x) / (long long)(by - ay);
-    const int y0 = min(ay, by), y1 = max(ay, by);
-    const long long x0 = ay < by ? p0x : p1x;
-    const int lo = max(y0, 0), hi = min(y1, mh);
-    for (int y = lo; y < hi; ++y) GST(&cross[atomicAdd(&fillp[y], 1)], x0 + (long long)(y - y0) * dx);
+    const EdgeRast e = make_edge(mw, mh, ax, ay, bx, by, shifted);
+    const int lo = max(e.y0, 0), hi = min(e.y1, mh);
+    for (int y = lo; y < hi; ++y) GST(&cross[atomicAdd(&fillp[y], 1)], e.x + (long long)(y - e.y0) * e.dx);
   }
   __threadfence_block();
   __syncthreads();
@@ -1077,7 +1102,7 @@ __device__ float polygon_score_wave(const unsigned long long* __restrict__ pts, 
       GST(&cross[k + 1], v);
     }
     for (int i = b; i + 1 < e; i += 2) {
-      int x1 = (int)((GLD(&cross[i]) + 65535) >> 16), x2 = (int)(GLD(&cross[i + 1]) >> 16);
+      int x1 = (int)((GLD(&cross[i]) + (shifted ? 0 : 65535)) >> 16), x2 = (int)(GLD(&cross[i + 1]) >> 16);
       if (x1 < mw && x2 >= 0) {
         x1 = max(x1, 0);
         x2 = min(x2, mw - 1);
@@ -1348,10 +1373,10 @@ __global__ void __launch_bounds__(64) border_box_kernel(const PostArgs a) {
       __syncthreads();
     }
     score = polygon_score_wave(gkeys, total, g_pred, g_H, g_W, a.mask_pool + (size_t)n * a.mask_pool_words,
-                               a.mask_pool_words, a.mask_pool_top + n, lane, &s_flag);
+                               a.mask_pool_words, a.mask_pool_top + n, lane, &s_flag, a.fill_shifted != 0);
     if (score < 0.f) { if (lane == 0) atomicOr(a.status, POST_ERR_POOL); return; }
   } else {
-    score = box_score_fast_wave(arr, g_pred, g_H, g_W, lane);
+    score = box_score_fast_wave(arr, g_pred, g_H, g_W, lane, a.fill_shifted != 0);
   }
   if (score < a.box_thresh) return;
   if (lane != 0) return;
@@ -1464,10 +1489,10 @@ void launch_post(const PostArgs& a, int N, int* out_boxes, int cap, int* out_n, 
     // OCR_TRACE_SLICE (tests): cap on a border's provisional slice, to drive the second-walk path with small inputs
     const int slice_limit = rt_options().trace_slice > 0 ? rt_options().trace_slice : INT_MAX;
     hipLaunchKernelGGL(trace_lds_kernel, dim3(N), dim3(kTraceThreads), lds, s, a.bitmap, a.H, a.W, a.max_cand, a.ncont, a.starts, a.npts, a.poff,
-                       a.pool, a.pool_cap, a.iscratch, slice_limit, a.status, a.img);
+                       a.pool, a.pool_cap, a.iscratch, slice_limit, a.status, a.pool_need, a.img);
   } else {
     hipLaunchKernelGGL(trace_count_kernel, gl, dim3(64), 0, s, a.bitmap, a.H, a.W, a.max_cand, a.ncont, a.starts, a.npts, a.img);
-    hipLaunchKernelGGL(trace_offsets_kernel, dim3(N), dim3(64), 0, s, a.max_cand, a.ncont, a.npts, a.poff, a.pool_cap, a.status);
+    hipLaunchKernelGGL(trace_offsets_kernel, dim3(N), dim3(64), 0, s, a.max_cand, a.ncont, a.npts, a.poff, a.pool_cap, a.status, a.pool_need);
     hipLaunchKernelGGL(trace_store_kernel, gl, dim3(64), 0, s, a.bitmap, a.H, a.W, a.max_cand, a.ncont, a.starts, a.npts, a.poff,
                        a.pool, a.pool_cap, a.img);
   }

@@ -18,19 +18,17 @@ struct LdsAttrMemo {
   std::atomic<int> raised[64];
 };
 
-// test hook (tests/test_host_layer.py through ocr_selftest_lds_memo): answers for hipGetDevice / hipFuncSetAttribute
+// test hook (tests/test_host_layer.py through ocr_selftest_lds_memo): answers for hipGetDevice / hipFuncSetAttribute.
+// Passed by the self-test as an argument - there is no global hook a running pipeline's launcher could pick up.
 struct LdsAttrHooks {
   int (*get_device)() = nullptr;                       // < 0: failure
   bool (*set_attribute)(const void*, int) = nullptr;
 };
-inline LdsAttrHooks& lds_attr_hooks() {
-  static LdsAttrHooks h;
-  return h;
-}
 
-inline bool raise_dynamic_lds(const void* kernel, int bytes, LdsAttrMemo& memo) {
+inline bool raise_dynamic_lds(const void* kernel, int bytes, LdsAttrMemo& memo, const LdsAttrHooks* hooks = nullptr) {
   int dev = -1;
-  const LdsAttrHooks& hk = lds_attr_hooks();
+  static const LdsAttrHooks none;
+  const LdsAttrHooks& hk = hooks ? *hooks : none;
   if (hk.get_device) dev = hk.get_device();
   else if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return false; }
   if (dev < 0) return false;

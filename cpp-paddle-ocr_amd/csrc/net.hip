@@ -1345,13 +1345,13 @@ bool Net::run_bound(const float* x, hipStream_t s, std::string& err) {
     for (const auto& L : B.launches)
       if (L.name.find(timing_filter_) != std::string::npos) { timed_here = true; break; }
   }
-  const char* refuse = rt_refuse_launch();  // fault injection (tests): "" unless ocr_selftest_refuse_launch set it
+  const std::string refuse = rt_refuse_launch();  // fault injection (tests): "" unless ocr_selftest_refuse_launch set it
   launch_error_.clear();
   auto issue = [&](Launch& L) {
-    if (refuse[0] && L.name.find(refuse) != std::string::npos) { launch_error_ = "launch refused (self-test): " + L.name; return; }
+    if (!refuse.empty() && L.name.find(refuse) != std::string::npos) { launch_error_ = "launch refused (self-test): " + L.name; return; }
     L.fn(s);
   };
-  const bool graphs = graphs_ && !timed_here && !keep_all_ && !B.graph_failed && !B.launches.empty() && !refuse[0];
+  const bool graphs = graphs_ && !timed_here && !keep_all_ && !B.graph_failed && !B.launches.empty() && refuse.empty();
   const void* head[3] = {head_probs_, head_amax_, head_pmax_};
   const bool repeat = B.last_x == x;  // the caller feeds this shape from one buffer: worth recording
   B.last_x = x;

@@ -132,6 +132,20 @@ struct PipeWorker {
     return OCR_OK;
   }
 
+  // a further detector instance; it takes over the timing state of the pipeline (ocr_pipe_timing[_filter]) so that the
+  // per-kernel survey sees the chunks that run on it
+  bool timing_on = false;
+  std::string timing_filter;
+  int add_det_extra(std::string& err) {
+    std::unique_ptr<DetStage> d(new DetStage());
+    int code = 0;
+    if (!d->create(det_cfg, err, code)) return code ? code : OCR_ERR_DEVICE;
+    d->net().set_timing_filter(timing_filter);
+    d->net().enable_timing(timing_on);
+    det_extra.push_back(std::move(d));
+    return OCR_OK;
+  }
+
   // ---- run: det per size group, then ONE cls pass and ONE rec pass over the crops of every image of the batch
   // (results are batch-invariant, so pooling lines across sizes changes nothing but the launch count)
   int run_images(uint8_t* base, const std::vector<StageSlot::Img>& imgs, const std::vector<StageSlot::Group>& groups, const float* probs,
@@ -151,12 +165,6 @@ struct PipeWorker {
       // ragged launch: Net::run_ragged_images) instead of a latency-bound pass per distinct size; only BoxesFromBitmap
       // still runs per group, dealt over the detector lanes.  Chunks bound the activation arena (~64 Mpixel of
       // detector input per launch, what a uniform batch of 64 x 960 x 960 needs).
-      while ((int)det_extra.size() < lanes - 1) {
-        std::unique_ptr<DetStage> d(new DetStage());
-        int code = 0;
-        if (!d->create(det_cfg, err, code)) return code ? code : OCR_ERR_DEVICE;
-        det_extra.push_back(std::move(d));
-      }
       std::vector<DetStage::MixedGroup> mg(groups.size());
       std::vector<size_t> gpx(groups.size());
       for (size_t gi = 0; gi < groups.size(); ++gi) {
@@ -177,7 +185,16 @@ struct PipeWorker {
         chunks.emplace_back(g0, g1);
         g0 = g1;
       }
-      auto net_stage = [&](size_t k) -> DetStage& { return (k & 1) && lanes > 1 ? *det_extra[0] : det; };
+      // Two network instances whenever there is more than one chunk - whatever OCR_DET_LANES says (the lanes only deal
+      // the per-group post-processing of the OCR_DET_RAGGED=net / dilation branch): chunk k+1's network is enqueued
+      // before chunk k's maps are post-processed, so it must not run on the instance that holds them.
+      const int want_extra = std::max(lanes - 1, chunks.size() > 1 ? 1 : 0);
+      while ((int)det_extra.size() < want_extra) {
+        int rc = add_det_extra(err);
+        if (rc) return rc;
+      }
+      const int ninst = 1 + (int)det_extra.size();
+      auto net_stage = [&](size_t k) -> DetStage& { return (k & 1) && ninst > 1 ? *det_extra[0] : det; };
       auto start = [&](size_t k) {
         return net_stage(k).mixed_net(base, mg.data() + chunks[k].first, (int)(chunks[k].second - chunks[k].first), probs, err);
       };
@@ -201,9 +218,9 @@ struct PipeWorker {
           src.collect_timings();
           continue;
         }
-        DetStage* busy = more && lanes > 1 ? &net_stage(k + 1) : nullptr;   // its stream is taken by the next chunk's network
+        DetStage* busy = more ? &net_stage(k + 1) : nullptr;   // its stream is taken by the next chunk's network
         std::vector<DetStage*> post;
-        for (int l = 0; l < lanes; ++l) {
+        for (int l = 0; l < ninst; ++l) {
           DetStage* d = l == 0 ? &det : det_extra[l - 1].get();
           if (d != busy) post.push_back(d);
         }
@@ -237,10 +254,8 @@ struct PipeWorker {
       }
     } else {
       while ((int)det_extra.size() < lanes - 1) {   // created on first use: single-size callers never pay for them
-        std::unique_ptr<DetStage> d(new DetStage());
-        int code = 0;
-        if (!d->create(det_cfg, err, code)) return code ? code : OCR_ERR_DEVICE;
-        det_extra.push_back(std::move(d));
+        int rc = add_det_extra(err);
+        if (rc) return rc;
       }
       // the clone above was enqueued on lane 0's stream: the other lanes' streams must not read it earlier
       if (hipStreamSynchronize(det.stream()) != hipSuccess) { err = "det stream sync failed"; return OCR_ERR_DEVICE; }
@@ -655,6 +670,7 @@ int ocr_pipe_create(const ocr_pipe_cfg* c, ocr_pipe** out) {
   d.use_dilation = c->det.use_dilation;
   if (c->det.precision) d.precision = c->det.precision;
   d.max_batch = c->det.max_batch > 0 ? c->det.max_batch : 1;
+  d.cv_compat = resolve_cv_compat(c->det.cv_compat);
   RecConfig r;
   r.model_dir = c->rec.model_dir; r.label_path = c->rec.label_path; r.device = c->det.device_id;
   r.batch_num = c->rec.rec_batch_num; r.img_h = c->rec.rec_img_h; r.img_w = c->rec.rec_img_w; r.sort_mode = c->rec.sort_mode;
@@ -683,10 +699,10 @@ int ocr_pipe_create(const ocr_pipe_cfg* c, ocr_pipe** out) {
     h->w0.det_post_ragged = e[0] != 'n';
     for (auto& w : h->extra) { w->det_ragged = h->w0.det_ragged; w->det_post_ragged = h->w0.det_post_ragged; }
   }
-  // two idle high-priority streams, created after the stage objects' streams and before the detector lanes' (which
-  // come into being at the first mixed-size batch): the configuration in which the lanes measured fastest (capi_net.hip)
-  priority_anchor(h->device, true);
-  priority_anchor(h->device, true);
+  // two idle high-priority streams per device (once per process), created after the first pipeline's stage streams and
+  // before the detector lanes' (which come into being at the first mixed-size batch): the configuration in which the
+  // lanes measured fastest (capi_net.hip)
+  priority_anchor(h->device, 2);
   *out = h.release();
   return OCR_OK;
 }
@@ -778,6 +794,7 @@ static std::vector<Net*> pipe_nets(ocr_pipe* h) {
   for (auto& w : h->extra) ws.push_back(w.get());
   for (PipeWorker* w : ws) {
     v.push_back(&w->det.net());
+    for (auto& d : w->det_extra) v.push_back(&d->net());  // odd chunks of a mixed-size batch run here
     if (w->cls) v.push_back(&w->cls->net());
     v.push_back(&w->rec.net());
   }
@@ -789,6 +806,8 @@ int ocr_pipe_timing(ocr_pipe* h, int enable) {
     net->enable_timing(enable != 0);
     net->reset_timings();
   }
+  h->w0.timing_on = enable != 0;
+  for (auto& w : h->extra) w->timing_on = enable != 0;
   return OCR_OK;
 }
 int ocr_pipe_stats(ocr_pipe* h, long long out[3]) {
@@ -809,6 +828,8 @@ int ocr_pipe_timing_filter(ocr_pipe* h, const char* substr) {
   if (!h) return fail(OCR_ERR_ARG, "null handle");
   const std::string f = substr ? substr : "";
   for (Net* net : pipe_nets(h)) net->set_timing_filter(f);
+  h->w0.timing_filter = f;
+  for (auto& w : h->extra) w->timing_filter = f;
   return OCR_OK;
 }
 int ocr_pipe_timing_report(ocr_pipe* h, char* buf, size_t cap) {

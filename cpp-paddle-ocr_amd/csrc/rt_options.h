@@ -4,6 +4,7 @@
 // identical in every setting.  Three switches are per HANDLE instead (read when the handle is created): OCR_GRAPH,
 // OCR_PIPE_PHASES, OCR_DET_LANES.
 #pragma once
+#include <string>
 
 namespace ocr {
 
@@ -32,7 +33,7 @@ const RtOptions& rt_options();
 
 // Fault injection for the tests (ocr_selftest_refuse_launch): a network launch whose name contains this string is
 // refused as if its launcher had rejected the shape; empty = off.
-const char* rt_refuse_launch();
+std::string rt_refuse_launch();  // a copy (taken under the setter's lock)
 void rt_set_refuse_launch(const char* substr);
 
 }  // namespace ocr

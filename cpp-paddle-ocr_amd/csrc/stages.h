@@ -44,6 +44,7 @@ struct DetConfig {
   std::string model_dir, limit_type = "max", score_mode = "fast", precision = "fp32";
   int device = 0, limit_side_len = 512, use_dilation = 0, max_batch = 1;
   double thresh = 0.2, box_thresh = 0.4, unclip_ratio = 1.8;
+  int cv_compat = 410;  // OCR_CV_45 | OCR_CV_410 (resolved: never 0 here)
 };
 
 class DetStage {
@@ -95,7 +96,8 @@ class DetStage {
                            float& ratio_h, float& ratio_w);
 
  private:
-  bool ensure_post(int count, int H, int W, std::string& err);
+  bool ensure_post(int count, size_t px, int H, int W, int cap, std::string& err);
+  int post_launch(PostArgs a, int count, int32_t* boxes, int cap, int* n, std::string& err);
   int run_post(int count, int H, int W, const float* prob, float ratio_h, float ratio_w, int src_h, int src_w,
                int32_t* boxes, int cap, int* n, std::string& err, const uint8_t* bitmap = nullptr);
   std::vector<size_t> mixed_pix_;            // first pixel of every group in the ragged maps
@@ -113,6 +115,8 @@ class DetStage {
       out_n_;
   DevBuf<unsigned long long> pool_;
   DevBuf<unsigned> mask_pool_, mask_top_;
+  DevBuf<int> pool_need_;   // [images] keys the traced borders of an image would have needed (kernels_post.h)
+  size_t mask_words_ = 0;   // words of polygon-score scratch per image in this call
   // words of polygon-score scratch per image: masks + crossing lists of all its borders (8 map areas of bits + slack)
   static size_t mask_words(int H, int W) { return (((size_t)H * W / 4 + (1u << 16)) + 31) & ~(size_t)31; }
   int src_rows_ = 0, src_cols_ = 0;

@@ -106,6 +106,7 @@ bool DetStage::create(const DetConfig& cfg, std::string& err, int& code) {
   if (cfg.score_mode != "fast" && cfg.score_mode != "slow") { err = "det_db_score_mode must be fast or slow"; return false; }
   if (cfg.limit_type != "max" && cfg.limit_type != "min") { err = "limit_type must be max or min"; return false; }
   if (cfg.max_batch < 1) { err = "max_batch must be >= 1"; return false; }
+  if (cfg.cv_compat != OCR_CV_45 && cfg.cv_compat != OCR_CV_410) { err = "cv_compat must be OCR_CV_45 or OCR_CV_410"; return false; }
   code = ocr_rt_init(cfg.device);
   if (code) { err = ocr_last_error(); return false; }
   WeightMap w;
@@ -125,63 +126,90 @@ bool DetStage::create(const DetConfig& cfg, std::string& err, int& code) {
   return true;
 }
 
-bool DetStage::ensure_post(int count, int H, int W, std::string& err) {
-  const size_t px = (size_t)count * H * W;
+bool DetStage::ensure_post(int count, size_t px, int H, int W, int cap, std::string& err) {
   const int max_cand = 1000;
+  // per image: a key pool for the traced borders and (slow score mode) a word pool for the polygon masks; sized for
+  // ordinary maps, grown by post_launch when a map needs more (never kept: every call starts from the default sizing)
   pool_cap_ = std::max(1 << 16, (H * W) / 2);
+  mask_words_ = mask_words(H, W);
   return labels_.ensure(px, err) && touch_.ensure(px, err) && chunk_cnt_.ensure((size_t)count * 128, err) && ncont_all_.ensure(count, err) && ncont_.ensure(count, err) &&
          starts_.ensure((size_t)count * max_cand, err) && npts_.ensure((size_t)count * max_cand, err) &&
          poff_.ensure((size_t)count * max_cand, err) && pool_.ensure((size_t)count * pool_cap_, err) &&
          iscratch_.ensure((size_t)count * pool_cap_ * 4, err) && cand_boxes_.ensure((size_t)count * max_cand * 8, err) &&
-         cand_valid_.ensure((size_t)count * max_cand, err) && status_.ensure(1, err) &&
+         cand_valid_.ensure((size_t)count * max_cand, err) && status_.ensure(1, err) && pool_need_.ensure(count, err) &&
+         out_boxes_.ensure((size_t)count * cap * 8, err) && out_n_.ensure(count, err) &&
          (cfg_.use_dilation ? bitmap2_.ensure(px, err) : true) &&
-         (cfg_.score_mode == "slow" ? (mask_pool_.ensure((size_t)count * mask_words(H, W), err) && mask_top_.ensure(count, err)) : true);
+         (cfg_.score_mode == "slow" ? (mask_pool_.ensure((size_t)count * mask_words_, err) && mask_top_.ensure(count, err)) : true);
 }
 
-int DetStage::run_post(int count, int H, int W, const float* prob, float ratio_h, float ratio_w, int src_h, int src_w,
-                       int32_t* boxes, int cap, int* n, std::string& err, const uint8_t* bitmap) {
-  if (!ensure_post(count, H, W, err)) return OCR_ERR_DEVICE;
-  if (!out_boxes_.ensure((size_t)count * cap * 8, err) || !out_n_.ensure(count, err)) return OCR_ERR_DEVICE;
-  ST_HIP(hipMemsetAsync(status_.p, 0, sizeof(int), stream_));
-  const uint8_t* bm = bitmap ? bitmap : bitmap_.p;
-  if (cfg_.use_dilation) {
-    launch_dilate2(bm, bitmap2_.p, count, H, W, stream_);
-    bm = bitmap2_.p;
-  }
-  PostArgs a{};
-  a.bitmap = bm; a.pred = prob; a.labels = labels_.p; a.touch = touch_.p; a.chunk_cnt = chunk_cnt_.p; a.ncont_all = ncont_all_.p; a.ncont = ncont_.p;
-  a.starts = starts_.p; a.npts = npts_.p; a.poff = poff_.p; a.pool = pool_.p; a.iscratch = iscratch_.p;
-  a.cand_boxes = cand_boxes_.p; a.cand_valid = cand_valid_.p; a.status = status_.p; a.pool_cap = pool_cap_;
-  a.H = H; a.W = W; a.max_cand = 1000;
+// Runs the post-processing kernels for the `count` maps `a` describes and brings boxes and counts back.  The reference
+// answers every map (findContours / minAreaRect / fillPoly allocate what they need, postprocess_op.cpp:255-331), so
+// exhausted scratch is not an error here either: a border that outgrows the small LDS working set of the per-border
+// stage re-runs that stage with the large one, and a map whose first max_candidates borders hold more vertices than the
+// default key pool (or whose polygon masks need more words than the default mask pool) re-runs the pass with pools of
+// the size the device reported (pool_need / the mask pool's bump cursor count what WOULD have been needed).
+int DetStage::post_launch(PostArgs a, int count, int32_t* boxes, int cap, int* n, std::string& err) {
+  a.labels = labels_.p; a.touch = touch_.p; a.chunk_cnt = chunk_cnt_.p; a.ncont_all = ncont_all_.p; a.ncont = ncont_.p;
+  a.starts = starts_.p; a.npts = npts_.p; a.poff = poff_.p; a.cand_boxes = cand_boxes_.p; a.cand_valid = cand_valid_.p;
+  a.status = status_.p; a.pool_need = pool_need_.p; a.max_cand = 1000;
   a.box_thresh = (float)cfg_.box_thresh; a.unclip_ratio = (float)cfg_.unclip_ratio;
-  a.ratio_h = ratio_h; a.ratio_w = ratio_w; a.src_h = src_h; a.src_w = src_w;
   a.slow = cfg_.score_mode == "slow";
+  a.fill_shifted = cfg_.cv_compat != OCR_CV_45;
   a.probe_stop = 0;
 #ifdef OCR_DEV_PROBES  // development probe (tools/post_kernel_times.sh builds with -DOCR_DEV_PROBES): timing only, results are wrong
   { static const char* stop = getenv("OCR_POST_STOP"); a.probe_stop = stop ? atoi(stop) : 0; }
 #endif
-  if (a.slow) {
-    a.mask_pool = mask_pool_.p; a.mask_pool_top = mask_top_.p; a.mask_pool_words = (unsigned)mask_words(H, W);
-    ST_HIP(hipMemsetAsync(mask_top_.p, 0, count * sizeof(unsigned), stream_));
-  }
-  launch_post(a, count, out_boxes_.p, cap, out_n_.p, stream_);
-  ST_HIP(hipGetLastError());  // a refused launch (e.g. LDS limit on this device) must not leave stale borders behind
   int status = 0;
-  ST_HIP(hipMemcpyAsync(n, out_n_.p, count * sizeof(int), hipMemcpyDeviceToHost, stream_));
-  ST_HIP(hipMemcpyAsync(boxes, out_boxes_.p, (size_t)count * cap * 8 * sizeof(int), hipMemcpyDeviceToHost, stream_));
-  ST_HIP(hipMemcpyAsync(&status, status_.p, sizeof(int), hipMemcpyDeviceToHost, stream_));
-  timer_.mark(3, stream_);
-  ST_HIP(hipStreamSynchronize(stream_));
-  if (status && !(status & ~(POST_ERR_HULL | POST_ERR_UNCLIP))) {
-    // a border outgrew the small LDS working set of the per-border stage: run that stage again with the large one
-    ST_HIP(hipMemsetAsync(status_.p, 0, sizeof(int), stream_));
-    if (a.slow) ST_HIP(hipMemsetAsync(mask_top_.p, 0, count * sizeof(unsigned), stream_));
-    launch_post_large(a, count, out_boxes_.p, cap, out_n_.p, stream_);
-    ST_HIP(hipGetLastError());
+  auto fetch = [&]() -> int {
     ST_HIP(hipMemcpyAsync(n, out_n_.p, count * sizeof(int), hipMemcpyDeviceToHost, stream_));
     ST_HIP(hipMemcpyAsync(boxes, out_boxes_.p, (size_t)count * cap * 8 * sizeof(int), hipMemcpyDeviceToHost, stream_));
     ST_HIP(hipMemcpyAsync(&status, status_.p, sizeof(int), hipMemcpyDeviceToHost, stream_));
+    return OCR_OK;
+  };
+  for (int attempt = 0;; ++attempt) {
+    a.pool = pool_.p; a.iscratch = iscratch_.p; a.pool_cap = pool_cap_;
+    if (a.slow) {
+      a.mask_pool = mask_pool_.p; a.mask_pool_top = mask_top_.p; a.mask_pool_words = (unsigned)mask_words_;
+      ST_HIP(hipMemsetAsync(mask_top_.p, 0, count * sizeof(unsigned), stream_));
+    }
+    ST_HIP(hipMemsetAsync(status_.p, 0, sizeof(int), stream_));
+    launch_post(a, count, out_boxes_.p, cap, out_n_.p, stream_);
+    ST_HIP(hipGetLastError());  // a refused launch (e.g. LDS limit on this device) must not leave stale borders behind
+    if (int rc = fetch()) return rc;
+    if (attempt == 0) timer_.mark(3, stream_);
     ST_HIP(hipStreamSynchronize(stream_));
+    if (status && !(status & ~(POST_ERR_HULL | POST_ERR_UNCLIP))) {
+      // a border outgrew the small LDS working set of the per-border stage: run that stage again with the large one
+      ST_HIP(hipMemsetAsync(status_.p, 0, sizeof(int), stream_));
+      if (a.slow) ST_HIP(hipMemsetAsync(mask_top_.p, 0, count * sizeof(unsigned), stream_));
+      launch_post_large(a, count, out_boxes_.p, cap, out_n_.p, stream_);
+      ST_HIP(hipGetLastError());
+      if (int rc = fetch()) return rc;
+      ST_HIP(hipStreamSynchronize(stream_));
+    }
+    if (!(status & POST_ERR_POOL) || attempt == 4) break;
+    // what the maps would have needed (largest image decides: the pools are [count][cap])
+    std::vector<int> need(count);
+    std::vector<unsigned> mneed(a.slow ? count : 0);
+    ST_HIP(hipMemcpyAsync(need.data(), pool_need_.p, count * sizeof(int), hipMemcpyDeviceToHost, stream_));
+    if (a.slow) ST_HIP(hipMemcpyAsync(mneed.data(), mask_top_.p, count * sizeof(unsigned), hipMemcpyDeviceToHost, stream_));
+    ST_HIP(hipStreamSynchronize(stream_));
+    const long want_keys = *std::max_element(need.begin(), need.end());
+    const size_t want_words = a.slow ? (size_t)*std::max_element(mneed.begin(), mneed.end()) : 0;
+    bool grew = false;
+    if (want_keys > pool_cap_) {
+      if (want_keys > (1L << 28)) break;  // 2 GB of keys per image: not a map this library is sized for
+      pool_cap_ = (int)((want_keys + 65535) & ~65535L);
+      if (!pool_.ensure((size_t)count * pool_cap_, err) || !iscratch_.ensure((size_t)count * pool_cap_ * 4, err)) return OCR_ERR_DEVICE;
+      grew = true;
+    }
+    if (want_words > mask_words_) {
+      if (want_words >= (1ul << 31)) break;
+      mask_words_ = (want_words + 65535) & ~(size_t)65535;
+      if (!mask_pool_.ensure((size_t)count * mask_words_, err)) return OCR_ERR_DEVICE;
+      grew = true;
+    }
+    if (!grew) break;
   }
   if (status) {
     err = "det post-processing scratch exhausted (status " + std::to_string(status) + ")";
@@ -190,6 +218,21 @@ int DetStage::run_post(int count, int H, int W, const float* prob, float ratio_h
   for (int i = 0; i < count; ++i)
     if (n[i] > cap) { err = "more boxes than the caller's capacity"; return OCR_ERR_CAPACITY; }
   return OCR_OK;
+}
+
+int DetStage::run_post(int count, int H, int W, const float* prob, float ratio_h, float ratio_w, int src_h, int src_w,
+                       int32_t* boxes, int cap, int* n, std::string& err, const uint8_t* bitmap) {
+  if (!ensure_post(count, (size_t)count * H * W, H, W, cap, err)) return OCR_ERR_DEVICE;
+  const uint8_t* bm = bitmap ? bitmap : bitmap_.p;
+  if (cfg_.use_dilation) {
+    launch_dilate2(bm, bitmap2_.p, count, H, W, stream_);
+    bm = bitmap2_.p;
+  }
+  PostArgs a{};
+  a.bitmap = bm; a.pred = prob;
+  a.H = H; a.W = W;
+  a.ratio_h = ratio_h; a.ratio_w = ratio_w; a.src_h = src_h; a.src_w = src_w;
+  return post_launch(a, count, boxes, cap, n, err);
 }
 
 int DetStage::run(const ocr_img* imgs, int count, int32_t* boxes, int cap, int* n, double times[3], std::string& err) {
@@ -299,63 +342,29 @@ int DetStage::post_mixed(const MixedGroup* groups, int ngroups, int32_t* boxes, 
     for (int k = 0; k < groups[gi].count; ++k) {
       PostImg q;
       q.h = rh; q.w = rw;
-      q.off = (int)(mixed_pix_[gi] + (size_t)k * rh * rw);
-      q.poff = (int)((mixed_probs_[gi] - mixed_prob_base_) + (size_t)k * rh * rw);
+      // 32-bit offsets on the device: the END of every image's maps must stay below 2^31 (the probability maps may sit
+      // far into a staging slot when prob_override is used), checked before anything is narrowed
+      const size_t off = mixed_pix_[gi] + (size_t)k * rh * rw;
+      const size_t poff = (size_t)(mixed_probs_[gi] - mixed_prob_base_) + (size_t)k * rh * rw;
+      if (mixed_probs_[gi] < mixed_prob_base_ || off + (size_t)rh * rw >= (1ul << 31) || poff + (size_t)rh * rw >= (1ul << 31)) {
+        err = "post_mixed: maps too large for 32-bit offsets";
+        return OCR_ERR_CAPACITY;
+      }
+      q.off = (int)off;
+      q.poff = (int)poff;
       q.src_h = groups[gi].rows; q.src_w = groups[gi].cols; q.ratio_h = ratio_h; q.ratio_w = ratio_w;
       im.push_back(q);
     }
   }
   const int count = (int)im.size();
-  const size_t px = mixed_pix_[ngroups];
-  if (px >= (1ul << 31) || (size_t)(mixed_probs_[ngroups - 1] - mixed_prob_base_) >= (1ul << 31)) { err = "post_mixed: maps too large for 32-bit offsets"; return OCR_ERR_CAPACITY; }
   // scratch: per pixel for the whole chunk, per image sized for the largest map
-  const int max_cand = 1000;
-  pool_cap_ = std::max(1 << 16, (Hm * Wm) / 2);
-  if (!labels_.ensure(px, err) || !touch_.ensure(px, err) || !chunk_cnt_.ensure((size_t)count * 128, err) || !ncont_all_.ensure(count, err) ||
-      !ncont_.ensure(count, err) || !starts_.ensure((size_t)count * max_cand, err) || !npts_.ensure((size_t)count * max_cand, err) ||
-      !poff_.ensure((size_t)count * max_cand, err) || !pool_.ensure((size_t)count * pool_cap_, err) ||
-      !iscratch_.ensure((size_t)count * pool_cap_ * 4, err) || !cand_boxes_.ensure((size_t)count * max_cand * 8, err) ||
-      !cand_valid_.ensure((size_t)count * max_cand, err) || !status_.ensure(1, err) || !post_img_.ensure(count, err) ||
-      !out_boxes_.ensure((size_t)count * cap * 8, err) || !out_n_.ensure(count, err) ||
-      (cfg_.score_mode == "slow" && (!mask_pool_.ensure((size_t)count * mask_words(Hm, Wm), err) || !mask_top_.ensure(count, err))))
-    return OCR_ERR_DEVICE;
+  if (!ensure_post(count, mixed_pix_[ngroups], Hm, Wm, cap, err) || !post_img_.ensure(count, err)) return OCR_ERR_DEVICE;
   ST_HIP(hipMemcpyAsync(post_img_.p, im.data(), (size_t)count * sizeof(PostImg), hipMemcpyHostToDevice, stream_));
-  ST_HIP(hipMemsetAsync(status_.p, 0, sizeof(int), stream_));
   PostArgs a{};
   a.img = post_img_.p;
-  a.bitmap = bitmap_.p; a.pred = mixed_prob_base_; a.labels = labels_.p; a.touch = touch_.p; a.chunk_cnt = chunk_cnt_.p; a.ncont_all = ncont_all_.p;
-  a.ncont = ncont_.p; a.starts = starts_.p; a.npts = npts_.p; a.poff = poff_.p; a.pool = pool_.p; a.iscratch = iscratch_.p;
-  a.cand_boxes = cand_boxes_.p; a.cand_valid = cand_valid_.p; a.status = status_.p; a.pool_cap = pool_cap_;
-  a.H = Hm; a.W = Wm; a.max_cand = max_cand;
-  a.box_thresh = (float)cfg_.box_thresh; a.unclip_ratio = (float)cfg_.unclip_ratio;
-  a.slow = cfg_.score_mode == "slow";
-  a.probe_stop = 0;
-  if (a.slow) {
-    a.mask_pool = mask_pool_.p; a.mask_pool_top = mask_top_.p; a.mask_pool_words = (unsigned)mask_words(Hm, Wm);
-    ST_HIP(hipMemsetAsync(mask_top_.p, 0, count * sizeof(unsigned), stream_));
-  }
-  launch_post(a, count, out_boxes_.p, cap, out_n_.p, stream_);
-  ST_HIP(hipGetLastError());
-  int status = 0;
-  ST_HIP(hipMemcpyAsync(n, out_n_.p, count * sizeof(int), hipMemcpyDeviceToHost, stream_));
-  ST_HIP(hipMemcpyAsync(boxes, out_boxes_.p, (size_t)count * cap * 8 * sizeof(int), hipMemcpyDeviceToHost, stream_));
-  ST_HIP(hipMemcpyAsync(&status, status_.p, sizeof(int), hipMemcpyDeviceToHost, stream_));
-  timer_.mark(3, stream_);
-  ST_HIP(hipStreamSynchronize(stream_));
-  if (status && !(status & ~(POST_ERR_HULL | POST_ERR_UNCLIP))) {  // a border outgrew the small LDS working set: the large one
-    ST_HIP(hipMemsetAsync(status_.p, 0, sizeof(int), stream_));
-    if (a.slow) ST_HIP(hipMemsetAsync(mask_top_.p, 0, count * sizeof(unsigned), stream_));
-    launch_post_large(a, count, out_boxes_.p, cap, out_n_.p, stream_);
-    ST_HIP(hipGetLastError());
-    ST_HIP(hipMemcpyAsync(n, out_n_.p, count * sizeof(int), hipMemcpyDeviceToHost, stream_));
-    ST_HIP(hipMemcpyAsync(boxes, out_boxes_.p, (size_t)count * cap * 8 * sizeof(int), hipMemcpyDeviceToHost, stream_));
-    ST_HIP(hipMemcpyAsync(&status, status_.p, sizeof(int), hipMemcpyDeviceToHost, stream_));
-    ST_HIP(hipStreamSynchronize(stream_));
-  }
-  if (status) { err = "det post-processing scratch exhausted (status " + std::to_string(status) + ")"; return OCR_ERR_CAPACITY; }
-  for (int i = 0; i < count; ++i)
-    if (n[i] > cap) { err = "more boxes than the caller's capacity"; return OCR_ERR_CAPACITY; }
-  return OCR_OK;
+  a.bitmap = bitmap_.p; a.pred = mixed_prob_base_;
+  a.H = Hm; a.W = Wm;
+  return post_launch(a, count, boxes, cap, n, err);
 }
 
 int DetStage::post_group(const float* prob, const uint8_t* bitmap, const MixedGroup& g, hipEvent_t wait_for, int32_t* boxes, int cap,

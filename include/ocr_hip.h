@@ -57,7 +57,17 @@ typedef struct ocr_det_cfg {
   int use_dilation;
   const char* precision; /* "fp32" (the only one implemented; others are rejected) */
   int max_batch;         /* images per ocr_det_run_batch call the handle is sized for (>=1) */
+  /* Which OpenCV the reference binary was built against, where two 4.x releases differ on this path (DESIGN.md
+   * section 5).  Today one rule depends on it: cv::fillPoly's scan fill behind BoxScoreFast / PolygonScoreAcc
+   * (postprocess_op.cpp:205-251) - OCR_CV_45: the rule of OpenCV 4.0 - 4.5.1, spans [ceil(xa), floor(xb)] of unshifted
+   * edges; OCR_CV_410: the rule of 4.5.2 and later (edges moved by half a pixel, spans [floor, floor]).  0 = default:
+   * the environment variable OCR_CV_COMPAT ("45" | "410") if set, else OCR_CV_410 - the reference's README builds with
+   * a 2025 MSVC toolchain against vcpkg's current opencv port (README.md:105-118). */
+  int cv_compat;
 } ocr_det_cfg;
+#define OCR_CV_DEFAULT 0
+#define OCR_CV_45 45
+#define OCR_CV_410 410
 void ocr_det_cfg_default(ocr_det_cfg* cfg);
 
 typedef struct ocr_det ocr_det;

@@ -153,12 +153,15 @@ def bitmap(pred, thresh, use_dilation=False):
     return bm
 
 
-def det_post(pred, thresh, box_thresh, unclip_ratio, src_h, src_w, use_dilation=False, slow=False, cap=2000):
+CV_45, CV_410 = 45, 410  # include/ocr_hip.h OCR_CV_45 / OCR_CV_410 (0 = default = CV_410)
+
+
+def det_post(pred, thresh, box_thresh, unclip_ratio, src_h, src_w, use_dilation=False, slow=False, cap=2000, cv_compat=0):
     pred = np.ascontiguousarray(pred, dtype=np.float32)
     boxes = np.zeros((cap, 8), np.int32)
     n = lib().oracle_det_post(C.c_void_p(_p(pred)), pred.shape[0], pred.shape[1], C.c_double(thresh),
                               C.c_double(box_thresh), C.c_double(unclip_ratio), int(use_dilation), int(slow), src_h,
-                              src_w, C.c_void_p(_p(boxes)), cap)
+                              src_w, C.c_void_p(_p(boxes)), cap, int(cv_compat))
     assert n <= cap
     return boxes[:n].reshape(n, 4, 2).copy()
 

@@ -443,7 +443,15 @@ void draw_line(uint8_t* mask, int W, int H, Pt p1, Pt p2) {
   }
 }
 
-void fill_poly(uint8_t* mask, int W, int H, const std::vector<Pt>& v) {
+// compat: which OpenCV the reference was built against (PARITY UNPINNED: no OpenCV here, restated from the published
+// source).  CV_FILL_CLASSIC = 4.0 .. 4.5.1: edges in 16.16 at the vertices' integer x, spans [ceil(xa), floor(xb)].
+// CV_FILL_SHIFTED = 4.5.2 and later (to 4.12): for non-antialiased lines CollectPolyEdges moves an edge whose outline
+// segment lies inside the image by half a pixel (`pt.x += XY_ONE >> 1`) - or, when the segment had to be clipped, builds
+// the edge from the CLIPPED integer end points and extrapolates it back to the edge's first row - and FillEdgeCollection
+// fills [xa >> 16, xb >> 16] (`delta = 0` for line_type < LINE_AA): both span ends are the crossing rounded half up.
+enum { CV_FILL_CLASSIC = 0, CV_FILL_SHIFTED = 1 };
+
+void fill_poly(uint8_t* mask, int W, int H, const std::vector<Pt>& v, int compat) {
   const int count = (int)v.size();
   if (count == 0) return;
   const int XY_SHIFT = 16;
@@ -456,17 +464,29 @@ void fill_poly(uint8_t* mask, int W, int H, const std::vector<Pt>& v) {
       int64_t p1x = (int64_t)v[i].x << XY_SHIFT, p1y = v[i].y;
       Pt t0{(int)((p0x + (XY_ONE >> 1)) >> XY_SHIFT), (int)p0y}, t1{(int)((p1x + (XY_ONE >> 1)) >> XY_SHIFT), (int)p1y};
       draw_line(mask, W, H, t0, t1);
+      int64_t c0x = p0x, c0y = p0y, c1x = p1x, c1y = p1y;  // pt0c, pt1c
+      if (compat == CV_FILL_SHIFTED) {
+        if ((unsigned)t0.x >= (unsigned)W || (unsigned)t1.x >= (unsigned)W || (unsigned)t0.y >= (unsigned)H || (unsigned)t1.y >= (unsigned)H) {
+          int64_t ax = t0.x, ay = t0.y, bx = t1.x, by = t1.y;
+          (void)clip_line(W, H, ax, ay, bx, by);  // moves the points as far as it gets, whatever it returns
+          if (ay != by) { c0y = ay; c1y = by; c0x = ax << XY_SHIFT; c1x = bx << XY_SHIFT; }
+        } else {
+          c0x += XY_ONE >> 1;
+          c1x += XY_ONE >> 1;
+        }
+      }
       if (p0y != p1y) {
         PolyEdge e;
-        if (p0y < p1y) { e.y0 = (int)p0y; e.y1 = (int)p1y; e.x = p0x; }
-        else { e.y0 = (int)p1y; e.y1 = (int)p0y; e.x = p1x; }
-        e.dx = (p1x - p0x) / (p1y - p0y);
+        e.dx = (c1x - c0x) / (c1y - c0y);
+        if (p0y < p1y) { e.y0 = (int)p0y; e.y1 = (int)p1y; e.x = c0x + (p0y - c0y) * e.dx; }
+        else { e.y0 = (int)p1y; e.y1 = (int)p0y; e.x = c1x + (p1y - c1y) * e.dx; }
         e.next = nullptr;
         edges.push_back(e);
       }
       p0x = p1x; p0y = p1y;
     }
   }
+  const int64_t span_delta = compat == CV_FILL_SHIFTED ? 0 : XY_ONE - 1;
   int total = (int)edges.size();
   if (total < 2) return;
   int y_max = INT_MIN, y_min = INT_MAX;
@@ -518,10 +538,10 @@ void fill_poly(uint8_t* mask, int W, int H, const std::vector<Pt>& v) {
         if (!clipline) {
           int x1, x2;
           if (keep_prelast->x > prelast->x) {
-            x1 = (int)((prelast->x + XY_ONE - 1) >> XY_SHIFT);
+            x1 = (int)((prelast->x + span_delta) >> XY_SHIFT);
             x2 = (int)(keep_prelast->x >> XY_SHIFT);
           } else {
-            x1 = (int)((keep_prelast->x + XY_ONE - 1) >> XY_SHIFT);
+            x1 = (int)((keep_prelast->x + span_delta) >> XY_SHIFT);
             x2 = (int)(prelast->x >> XY_SHIFT);
           }
           if (x1 < W && x2 >= 0) {
@@ -562,10 +582,10 @@ void fill_poly(uint8_t* mask, int W, int H, const std::vector<Pt>& v) {
 inline int clampi(int x, int lo, int hi) { return x > hi ? hi : (x < lo ? lo : x); }
 
 // masked mean of pred over fillPoly(pts - (xmin,ymin)) inside [xmin..xmax]x[ymin..ymax]
-float masked_mean(const float* pred, int W, int xmin, int ymin, int xmax, int ymax, const std::vector<Pt>& local) {
+float masked_mean(const float* pred, int W, int xmin, int ymin, int xmax, int ymax, const std::vector<Pt>& local, int compat) {
   const int mw = xmax - xmin + 1, mh = ymax - ymin + 1;
   std::vector<uint8_t> mask((size_t)mw * mh, 0);
-  fill_poly(mask.data(), mw, mh, local);
+  fill_poly(mask.data(), mw, mh, local, compat);
   double s = 0;
   long cnt = 0;
   for (int y = 0; y < mh; ++y)
@@ -574,7 +594,7 @@ float masked_mean(const float* pred, int W, int xmin, int ymin, int xmax, int ym
   return cnt ? (float)(s / (double)cnt) : 0.f;
 }
 
-float box_score_fast(const Pt2f a[4], const float* pred, int H, int W) {
+float box_score_fast(const Pt2f a[4], const float* pred, int H, int W, int compat) {
   float bx[4] = {a[0].x, a[1].x, a[2].x, a[3].x}, by[4] = {a[0].y, a[1].y, a[2].y, a[3].y};
   int xmin = clampi(int(std::floor(*std::min_element(bx, bx + 4))), 0, W - 1);
   int xmax = clampi(int(std::ceil(*std::max_element(bx, bx + 4))), 0, W - 1);
@@ -582,10 +602,10 @@ float box_score_fast(const Pt2f a[4], const float* pred, int H, int W) {
   int ymax = clampi(int(std::ceil(*std::max_element(by, by + 4))), 0, H - 1);
   std::vector<Pt> local(4);
   for (int i = 0; i < 4; ++i) local[i] = {int(a[i].x) - xmin, int(a[i].y) - ymin};
-  return masked_mean(pred, W, xmin, ymin, xmax, ymax, local);
+  return masked_mean(pred, W, xmin, ymin, xmax, ymax, local, compat);
 }
 
-float polygon_score_acc(const std::vector<Pt>& contour, const float* pred, int H, int W) {
+float polygon_score_acc(const std::vector<Pt>& contour, const float* pred, int H, int W, int compat) {
   float fxmin = FLT_MAX, fxmax = -FLT_MAX, fymin = FLT_MAX, fymax = -FLT_MAX;
   for (auto& p : contour) {
     fxmin = std::min(fxmin, (float)p.x); fxmax = std::max(fxmax, (float)p.x);
@@ -595,7 +615,7 @@ float polygon_score_acc(const std::vector<Pt>& contour, const float* pred, int H
   int ymin = clampi(int(std::floor(fymin)), 0, H - 1), ymax = clampi(int(std::ceil(fymax)), 0, H - 1);
   std::vector<Pt> local(contour.size());
   for (size_t i = 0; i < contour.size(); ++i) local[i] = {contour[i].x - xmin, contour[i].y - ymin};
-  return masked_mean(pred, W, xmin, ymin, xmax, ymax, local);
+  return masked_mean(pred, W, xmin, ymin, xmax, ymax, local, compat);
 }
 
 // ------------------------------------------------------------------ ClipperOffset (jtRound, etClosedPolygon)
@@ -733,7 +753,7 @@ inline float clampf(float x, float lo, float hi) { return x > hi ? hi : (x < lo 
 struct Box { int p[4][2]; };
 
 void boxes_from_bitmap(const float* pred, const uint8_t* bitmap, int H, int W, float box_thresh, float unclip_ratio,
-                       bool slow, std::vector<Box>& boxes) {
+                       bool slow, std::vector<Box>& boxes, int compat) {
   const int min_size = 3, max_candidates = 1000;
   std::vector<std::vector<Pt>> contours;
   find_contours(bitmap, H, W, contours);
@@ -745,7 +765,7 @@ void boxes_from_bitmap(const float* pred, const uint8_t* bitmap, int H, int W, f
     Pt2f arr[4];
     get_mini_boxes(box, ssid, arr);
     if (ssid < min_size) continue;
-    float score = slow ? polygon_score_acc(contours[ci], pred, H, W) : box_score_fast(arr, pred, H, W);
+    float score = slow ? polygon_score_acc(contours[ci], pred, H, W, compat) : box_score_fast(arr, pred, H, W, compat);
     if (score < box_thresh) continue;
     RRect pts = unclip(arr, unclip_ratio);
     if (pts.h < 1.001 && pts.w < 1.001) continue;
@@ -800,6 +820,11 @@ void filter_tag_det_res(std::vector<Box>& boxes, float ratio_h, float ratio_w, i
   boxes = keep;
 }
 
+
+// cv_compat as include/ocr_hip.h spells it: OCR_CV_45 (45) = the OpenCV 4.5.1 rules, OCR_CV_410 (410, and 0 = default) =
+// the rules of 4.5.2 and later; the reference's README points at a 2025 vcpkg build (README.md:105-118)
+int fill_rule(int cv_compat) { return cv_compat == 45 ? CV_FILL_CLASSIC : CV_FILL_SHIFTED; }
+
 }  // namespace
 
 extern "C" {
@@ -832,11 +857,11 @@ void oracle_bitmap(const float* pred, int H, int W, double det_db_thresh, int us
 
 // full det post-processing on a probability map. boxes: cap x 8 ints. returns count.
 int oracle_det_post(const float* pred, int H, int W, double det_db_thresh, double box_thresh, double unclip_ratio,
-                    int use_dilation, int slow, int src_h, int src_w, int* boxes, int cap) {
+                    int use_dilation, int slow, int src_h, int src_w, int* boxes, int cap, int cv_compat) {
   std::vector<uint8_t> bitmap((size_t)H * W);
   oracle_bitmap(pred, H, W, det_db_thresh, use_dilation, bitmap.data());
   std::vector<Box> bx;
-  boxes_from_bitmap(pred, bitmap.data(), H, W, (float)box_thresh, (float)unclip_ratio, slow != 0, bx);
+  boxes_from_bitmap(pred, bitmap.data(), H, W, (float)box_thresh, (float)unclip_ratio, slow != 0, bx, fill_rule(cv_compat));
   float ratio_h = float(H) / float(src_h), ratio_w = float(W) / float(src_w);
   filter_tag_det_res(bx, ratio_h, ratio_w, src_h, src_w);
   int n = std::min((int)bx.size(), cap);
@@ -875,16 +900,16 @@ int oracle_clipper_offset(const long long* xy, int n, double delta, long long* o
   return (int)s.size();
 }
 
-float oracle_box_score_fast(const float* box8, const float* pred, int H, int W) {
+float oracle_box_score_fast(const float* box8, const float* pred, int H, int W, int cv_compat) {
   Pt2f a[4];
   for (int i = 0; i < 4; ++i) a[i] = {box8[2 * i], box8[2 * i + 1]};
-  return box_score_fast(a, pred, H, W);
+  return box_score_fast(a, pred, H, W, fill_rule(cv_compat));
 }
 
-void oracle_fill_poly(uint8_t* mask, int W, int H, const int* pts_xy, int n) {
+void oracle_fill_poly(uint8_t* mask, int W, int H, const int* pts_xy, int n, int cv_compat) {
   std::vector<Pt> p(n);
   for (int i = 0; i < n; ++i) p[i] = {pts_xy[2 * i], pts_xy[2 * i + 1]};
-  fill_poly(mask, W, H, p);
+  fill_poly(mask, W, H, p, fill_rule(cv_compat));
 }
 
 // crop rectangle of ocr_worker.cpp:245-258: boundingRect(Point2f of int coords) & image rect.  returns 0 if empty

@@ -17,10 +17,11 @@ import oracle as O
 class DetCfg:
     # literals of OCRWorker::OCRWorker (ocr_worker.cpp:21-35)
     def __init__(self, limit_type="max", limit_side_len=512, thresh=0.2, box_thresh=0.4, unclip_ratio=1.8,
-                 score_mode="fast", use_dilation=False):
+                 score_mode="fast", use_dilation=False, cv_compat=0):
         self.limit_type, self.limit_side_len = limit_type, limit_side_len
         self.thresh, self.box_thresh, self.unclip_ratio = thresh, box_thresh, unclip_ratio
         self.score_mode, self.use_dilation = score_mode, use_dilation
+        self.cv_compat = cv_compat  # 0 / 410: OpenCV >= 4.5.2 fillPoly rule (default), 45: the 4.5.1 rule
 
 
 class Pipeline:
@@ -47,7 +48,8 @@ class Pipeline:
             prob = self.det.run(x[None])[0, :, :, 0]
         else:
             prob = prob_override
-        boxes = O.det_post(prob, c.thresh, c.box_thresh, c.unclip_ratio, h, w, c.use_dilation, c.score_mode == "slow")
+        boxes = O.det_post(prob, c.thresh, c.box_thresh, c.unclip_ratio, h, w, c.use_dilation, c.score_mode == "slow",
+                           cv_compat=c.cv_compat)
         self.taps.update(det_x=x, det_resized=resized, det_prob=prob,
                          det_bitmap=O.bitmap(prob, c.thresh, c.use_dilation))
         return boxes

@@ -95,9 +95,17 @@ def _line_pixels(w, h, p1, p2):
     return [(x, y) for x, y in out if 0 <= x < w and 0 <= y < h]
 
 
-def fill_poly_model(w, h, pts):
-    """cv::fillPoly of one polygon with colour 1, line type 8, shift 0 (drawing.cpp, the classic rule of OpenCV 4.0 - 4.5:
-    edge x in 16.16 fixed point without a half-pixel offset, interior span = [ceil(xa), floor(xb)] per scanline)."""
+CV_45, CV_410 = 45, 410   # include/ocr_hip.h: OCR_CV_45 (OpenCV 4.5.1 rules), OCR_CV_410 (4.5.2 and later; the default)
+
+
+def fill_poly_model(w, h, pts, cv_compat=CV_410):
+    """cv::fillPoly of one polygon with colour 1, line type 8, shift 0 (drawing.cpp).
+    CV_45: the classic rule of OpenCV 4.0 - 4.5.1 - edge x in 16.16 fixed point at the vertices' integer x, interior span
+    = [ceil(xa), floor(xb)] per scanline.
+    CV_410: the rule of 4.5.2 and later - an edge whose outline segment lies inside the image is moved right by half a
+    pixel, an edge whose segment had to be clipped runs through the CLIPPED integer end points (no half pixel) and is
+    extrapolated back to its first row; the span is [floor(xa), floor(xb)], i.e. both crossings rounded half up when the
+    edge was shifted."""
     mask = np.zeros((h, w), np.uint8)
     n = len(pts)
     edges = []
@@ -107,25 +115,38 @@ def fill_poly_model(w, h, pts):
             mask[y, x] = 1
         if ay == by:
             continue
-        x0, y0, x1, y1 = (ax, ay, bx, by) if ay < by else (bx, by, ax, ay)
-        dxf = _cdiv(((bx - ax) << XY_SHIFT), (by - ay))               # one truncating division per edge, as the library
-        edges.append((y0, y1, x0 << XY_SHIFT, dxf))
+        # end points the edge is built from: (x in 16.16, y)
+        c0, c1 = [ax << XY_SHIFT, ay], [bx << XY_SHIFT, by]
+        if cv_compat != CV_45:
+            if 0 <= ax < w and 0 <= bx < w and 0 <= ay < h and 0 <= by < h:
+                c0[0] += XY_ONE >> 1
+                c1[0] += XY_ONE >> 1
+            else:
+                _, x1, y1, x2, y2 = _clip_line(w, h, ax, ay, bx, by)   # the points as far as clipLine moved them
+                if y1 != y2:
+                    c0, c1 = [x1 << XY_SHIFT, y1], [x2 << XY_SHIFT, y2]
+        dxf = _cdiv(c1[0] - c0[0], c1[1] - c0[1])                     # one truncating division per edge, as the library
+        if ay < by:
+            edges.append((ay, by, c0[0] + (ay - c0[1]) * dxf, dxf))
+        else:
+            edges.append((by, ay, c1[0] + (by - c1[1]) * dxf, dxf))
     if len(edges) < 2:
         return mask
     ymin, ymax = min(e[0] for e in edges), max(e[1] for e in edges)
+    up = XY_ONE - 1 if cv_compat == CV_45 else 0
     for y in range(max(ymin, 0), min(ymax, h)):
         xs = sorted(x + (y - y0) * d for (y0, y1, x, d) in edges if y0 <= y < y1)
         for a, b in zip(xs[0::2], xs[1::2]):
-            xa, xb = (a + XY_ONE - 1) >> XY_SHIFT, b >> XY_SHIFT
+            xa, xb = (a + up) >> XY_SHIFT, b >> XY_SHIFT
             if xa < w and xb >= 0:
                 mask[y, max(xa, 0):min(xb, w - 1) + 1] = 1
     return mask
 
 
-def oracle_fill(w, h, pts):
+def oracle_fill(w, h, pts, cv_compat=CV_410):
     m = np.zeros((h, w), np.uint8)
     p = np.ascontiguousarray(np.asarray(pts, np.int32).reshape(-1))
-    _lib().oracle_fill_poly(_p(m), w, h, _p(p), len(pts))
+    _lib().oracle_fill_poly(_p(m), w, h, _p(p), len(pts), cv_compat)
     return m
 
 
@@ -157,8 +178,9 @@ def _quads(rs, n, w, h, spill):
     return out
 
 
+@pytest.mark.parametrize("cv_compat", [CV_45, CV_410])
 @pytest.mark.parametrize("spill", [0, 6])
-def test_fill_poly_equals_the_scanline_definition(built, spill):
+def test_fill_poly_equals_the_scanline_definition(built, spill, cv_compat):
     """10 000 polygons: rotated rectangles with truncated corners, arbitrary and degenerate quads, contours; with spill > 0
     vertices leave the mask (a box poking out of the probability map: the outline is then drawn between CLIPPED end
     points, which is not the unclipped line restricted to the mask)."""
@@ -167,7 +189,7 @@ def test_fill_poly_equals_the_scanline_definition(built, spill):
     for it in range(5000):
         w, h = int(rs.randint(1, 40)), int(rs.randint(1, 30))
         for q in _quads(rs, 1, w, h, spill):
-            a, b = fill_poly_model(w, h, q), oracle_fill(w, h, q)
+            a, b = fill_poly_model(w, h, q, cv_compat), oracle_fill(w, h, q, cv_compat)
             if not np.array_equal(a, b):
                 bad += 1
                 if bad <= 3:
@@ -175,7 +197,22 @@ def test_fill_poly_equals_the_scanline_definition(built, spill):
     assert bad == 0
 
 
-def test_box_score_is_the_masked_mean_and_agrees_near_the_threshold(built):
+def test_fill_rules_differ_only_at_span_ends(built):
+    """The two rules fill the same outline; per scanline the 4.5.2+ span can only gain the pixel a crossing with
+    fraction >= 1/2 rounds up to (left end: lose it; right end: gain it) - a sanity check that the switch does what
+    DESIGN.md section 5 says, and that it matters (masks differ for a good share of rotated rectangles)."""
+    rs = np.random.RandomState(5)
+    differ = 0
+    for q in _quads(rs, 600, 60, 40, 0):
+        a, b = fill_poly_model(60, 40, q, CV_45).astype(int), fill_poly_model(60, 40, q, CV_410).astype(int)
+        d = a != b
+        differ += bool(d.any())
+        assert (d.sum(axis=1) <= len(q)).all()      # at most one pixel per crossing and row
+    assert differ > 100
+
+
+@pytest.mark.parametrize("cv_compat", [CV_45, CV_410])
+def test_box_score_is_the_masked_mean_and_agrees_near_the_threshold(built, cv_compat):
     """BoxScoreFast (postprocess_op.cpp:216-253): bounding box from floor / ceil of the corners clamped to the map, mask =
     fillPoly of the truncated corners minus (xmin, ymin), score = cv::mean(pred(roi), mask)[0] (double) returned as
     float.  On maps constructed so that the mean lies within 1e-3 of det_db_box_thresh the oracle's score equals the
@@ -195,7 +232,7 @@ def test_box_score_is_the_masked_mean_and_agrees_near_the_threshold(built):
         xmin, xmax = clampi(np.floor(xs.min()), 0, W - 1), clampi(np.ceil(xs.max()), 0, W - 1)
         ymin, ymax = clampi(np.floor(ys.min()), 0, H - 1), clampi(np.ceil(ys.max()), 0, H - 1)
         pts = [(int(x) - xmin, int(y) - ymin) for x, y in box]
-        mask = fill_poly_model(xmax - xmin + 1, ymax - ymin + 1, pts).astype(bool)
+        mask = fill_poly_model(xmax - xmin + 1, ymax - ymin + 1, pts, cv_compat).astype(bool)
         if not mask.any():
             continue
         # a map whose masked mean is thr + d, |d| <= 1e-3, with per-pixel noise that keeps the mean
@@ -205,7 +242,7 @@ def test_box_score_is_the_masked_mean_and_agrees_near_the_threshold(built):
         noise = rs.uniform(-0.2, 0.2, int(mask.sum()))
         roi[mask] = (float(thr) + d + noise - noise.mean()).astype(np.float32)
         want = np.float32(roi[mask].astype(np.float64).sum() / mask.sum())
-        got = np.float32(L.oracle_box_score_fast(_p(np.ascontiguousarray(box.reshape(-1))), _p(pred), H, W))
+        got = np.float32(L.oracle_box_score_fast(_p(np.ascontiguousarray(box.reshape(-1))), _p(pred), H, W, cv_compat))
         assert got == want or abs(float(got) - float(want)) <= 1e-7, (it, got, want)   # (double sum: order-insensitive to 1e-12)
         if abs(float(want) - float(thr)) > 1e-7:
             assert (got < thr) == (want < thr)

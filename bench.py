@@ -147,16 +147,7 @@ def cpu_baseline(budget_s=8.0):
     such workers (ocr_worker.cpp:345-349), on cfg2 images (bounded sample: every leg runs ~budget_s seconds) and on
     the reference's own card image with the worker's default parameters (cfg1)."""
     import subprocess
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
-    try:   # the box's CPU share is a cgroup quota, not an affinity mask (256 visible cores, 16 usable)
-        q, p_ = open("/sys/fs/cgroup/cpu.max").read().split()
-        if q != "max":
-            cores = min(cores, max(1, int(int(q) / int(p_))))
-    except (OSError, ValueError):
-        pass
+    cores = host_cores_allowed()
     W = max(1, int(0.8 * cores / 3))
     script = os.path.join(ROOT, "tools", "cpu_baseline_worker.py")
 
@@ -197,6 +188,132 @@ def cpu_baseline(budget_s=8.0):
             "sample": "best of the reference-shaped legs (%s): every leg is ~%.0f s of the same cfg2 pipeline and parameters on "
                       "fresh images per worker; host has %d usable cores (%s)" % (best[0], budget_s, cores, cpu),
             "legs": out}
+
+
+# ------------------------------------------------------------------------------------------------ kernel groups
+def group_key(name, r):
+    """Launch rows are named `<net>.<op index>.<descriptor>@<bound shape>`.  Ops with the same descriptor (kernel kind,
+    channels, strides, gate) that do the same algorithmic work per launch on the same bound shape run the SAME kernel
+    instantiation on the SAME grid (e.g. rec ops 13/15/17/19: four launches of `dwpw_kernel<5,1,1,16,...>`): they are one
+    row of a rocprofv3 kernel summary grouped by (symbol, grid), and one group here."""
+    net, _, rest = name.split(".", 2)
+    desc, _, shape = rest.partition("@")
+    per = max(1, r["count"])
+    return (net, desc, shape, int(round(r["flops"] / per)), int(round(r["bytes"] / per)))
+
+
+def kernel_groups(rep):
+    """timing report {launch name: {ms, count, flops, bytes}} -> {group key: {ms, count, flops, bytes, ops}}"""
+    out = {}
+    for name, r in rep.items():
+        g = out.setdefault(group_key(name, r), dict(ms=0.0, count=0, flops=0.0, bytes=0.0, ops=[]))
+        for k in ("ms", "count", "flops", "bytes"):
+            g[k] += r[k]
+        g["ops"].append(name.split(".")[1])
+    return out
+
+
+def group_label(key, g):
+    return "%s.%s@%s [ops %s]" % (key[0], key[1], key[2], ",".join(sorted(g["ops"])))
+
+
+RIDGE = FP32_MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)   # f32 FLOP per HBM byte where the two roofs meet
+
+
+def roof_of(flops, nbytes, ms):
+    """algorithmic work over a duration against the roof that bounds it (f32 MFMA peak above the ridge, HBM below)"""
+    sec = ms * 1e-3
+    tflops = flops / sec / 1e12 if sec > 0 else 0.0
+    gbps = nbytes / sec / 1e9 if sec > 0 else 0.0
+    hbm = nbytes > 0 and flops / nbytes < RIDGE
+    return {"bound": "hbm" if hbm else "mfma", "tflops": tflops, "frac_mfma": tflops / FP32_MFMA_PEAK_TFLOPS,
+            "hbm_GBps_algorithmic": gbps, "frac_hbm": gbps / HBM_PEAK_GBS}
+
+
+# ------------------------------------------------------------------------------------------------ host placement
+def host_cores_allowed():
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    try:   # the box's CPU share is a cgroup quota, not an affinity mask (256 visible cores, 16 usable)
+        q, p_ = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            cores = min(cores, max(1, int(int(q) / int(p_))))
+    except (OSError, ValueError):
+        pass
+    return cores
+
+
+def _cpulist(text):
+    out = []
+    for part in text.strip().split(","):
+        if part:
+            a, _, b = part.partition("-")
+            out.extend(range(int(a), int(b or a) + 1))
+    return out
+
+
+def gpu_numa_node(local):
+    """NUMA node of this rank's GPU from the KFD topology in sysfs - no HIP call (a rank pins itself BEFORE anything
+    initialises the GPU).  GPU nodes (simd_count > 0) come in device order; an io link to a CPU node names the NUMA node.
+    ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES lists of indices are followed.  None when the topology cannot be read."""
+    try:
+        vis = os.environ.get("ROCR_VISIBLE_DEVICES") or os.environ.get("HIP_VISIBLE_DEVICES")
+        if vis and all(t.strip().isdigit() for t in vis.split(",")):
+            ids = [int(t) for t in vis.split(",")]
+            if local < len(ids):
+                local = ids[local]
+        root = "/sys/class/kfd/kfd/topology/nodes"
+        nodes = sorted(int(n) for n in os.listdir(root) if n.isdigit())
+        props = lambda path: dict(l.split()[:2] for l in open(path) if len(l.split()) >= 2)
+        cpu_nodes = [n for n in nodes if int(props("%s/%d/properties" % (root, n)).get("cpu_cores_count", "0")) > 0]
+        gpus = [n for n in nodes if int(props("%s/%d/properties" % (root, n)).get("simd_count", "0")) > 0]
+        if local >= len(gpus):
+            return None
+        links = "%s/%d/io_links" % (root, gpus[local])
+        for l in sorted(os.listdir(links)):
+            to = int(props("%s/%s/properties" % (links, l)).get("node_to", "-1"))
+            if to in cpu_nodes:
+                return cpu_nodes.index(to)
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
+def pin_rank_to_its_gpus_numa_node(local, world):
+    """Host threads of a rank (input generation, staging copies, the pipeline's chain threads) on the cores next to its
+    GPU: the CPUs of the GPU's NUMA node that this process may use, divided among the ranks that share the node.  Falls
+    back to an even contiguous split of the allowed CPUs.  Returns what it did (reported per rank in the N > 1 line)."""
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        return {"pinned": False, "why": "no sched_getaffinity"}
+    info = {"pinned": False, "numa_node": None, "cpus": len(allowed)}
+    if world <= 1 or len(allowed) < 2 * world or os.environ.get("OCR_BENCH_NO_PIN"):
+        return info
+    node = gpu_numa_node(local)
+    mine = None
+    if node is not None:
+        try:
+            cpus = [c for c in _cpulist(open("/sys/devices/system/node/node%d/cpulist" % node).read()) if c in set(allowed)]
+            sharers = [r for r in range(world) if gpu_numa_node(r) == node]
+            if len(cpus) >= 2 * len(sharers):
+                k = sharers.index(local)
+                per = len(cpus) // len(sharers)
+                mine = cpus[k * per:(k + 1) * per]
+                info["numa_node"] = node
+        except (OSError, ValueError):
+            mine = None
+    if not mine:
+        per = len(allowed) // world
+        mine = allowed[local * per:(local + 1) * per]
+    try:
+        os.sched_setaffinity(0, mine)
+        info.update(pinned=True, cpus=len(mine), first_cpu=mine[0], last_cpu=mine[-1])
+    except OSError as e:
+        info["why"] = str(e)
+    return info
 
 
 # ------------------------------------------------------------------------------------------------ main
@@ -265,9 +382,13 @@ def main(argv=None):
     cfg = args.config
     if stub and cfg != "cfg2":
         sys.exit("--stub-pipeline rehearses cfg2 only")
-    workers = max(1, min(16, (os.cpu_count() or 2) // max(1, world)))
+    # before anything of this rank touches the GPU (and before its input generators fork): host threads next to the GPU
+    placement = pin_rank_to_its_gpus_numa_node(local, world) if not stub else {"pinned": False}
+    cores_mine = host_cores_allowed()
+    workers = max(1, min(16, cores_mine if world > 1 else (os.cpu_count() or 2)))
     if under_profiler():
         workers = 1   # a profiler's preloaded library has initialised the GPU already: do not fork this process
+    t_inputs = time.perf_counter()
 
     # ---- inputs first (host processes), then the GPU.  Image i of the stream belongs to rank i mod world.
     nb = (rank + 1) % world
@@ -294,6 +415,7 @@ def main(argv=None):
         img_list, prob_list = make_cfg3_inputs(seeds, workers)
         vimgs, vprobs = make_cfg3_inputs(vseeds, workers) if vcount else (None, None)
         imgs = probs = None
+    input_gen_s = time.perf_counter() - t_inputs
 
     dist = None
     device = None
@@ -385,11 +507,23 @@ def main(argv=None):
             step_ms.append((time.perf_counter() - s0) * 1e3)
     barrier()
     elapsed = time.perf_counter() - t0
+    per_rank = None
     if dist is not None:
         import torch
+        # every rank's own view, for the N > 1 line: its rate over its own clock, how long its inputs took to generate,
+        # the host cores it may use and whether it is pinned next to its GPU (one small all_gather, outside the timed region)
+        mine_t = torch.tensor([elapsed, input_gen_s, float(cores_mine), 1.0 if placement.get("pinned") else 0.0,
+                               float(placement.get("numa_node") if placement.get("numa_node") is not None else -1)],
+                              dtype=torch.float64, device=device)
+        allr = [torch.empty_like(mine_t) for _ in range(world)]
+        dist.all_gather(allr, mine_t)
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        rows_ = [[float(v) for v in r.cpu()] for r in allr]
+        per_rank = {"seconds": [r[0] for r in rows_], "input_generation_s": [r[1] for r in rows_],
+                    "host_cores_allowed": [int(r[2]) for r in rows_], "pinned": [bool(r[3]) for r in rows_],
+                    "numa_node": [int(r[4]) if r[4] >= 0 else None for r in rows_]}
     stage_ms = list(pipe.times)
     stream_stats = None
     if cfg == "cfg4" and not stub:
@@ -405,7 +539,7 @@ def main(argv=None):
     # dominant kernel and gives the per-kernel table; in the timed steps only that kernel carries events (a thousand
     # event pairs per step cost ~4 % of the step).  With two chains a kernel shares the chip with the other chain's
     # kernels and an event span stops being a property of the kernel.
-    survey = rep_timed = single_chain = None
+    survey = rep_timed = single_chain = dom_key = None
     if kernel_timing and rank == 0 and world == 1:
         pipe1 = mk_pipe(1)
         if cfg == "cfg2":
@@ -418,8 +552,10 @@ def main(argv=None):
         pipe1.timing(True)
         run1()
         survey = pipe1.timing_report()
-        dominant = max(survey.items(), key=lambda kv: kv[1]["ms"])[0]
-        pipe1.timing(True, only=dominant)   # also resets the accumulated timings
+        # the dominant kernel = the (instantiation, grid) group with the most time in the step - four launches of one
+        # symbol on one shape are ONE kernel, as in a rocprofv3 summary (round 3 picked per op name and reported a 7 % kernel)
+        dom_key, _ = max(kernel_groups(survey).items(), key=lambda kv: kv[1]["ms"])
+        pipe1.timing(True, only=dom_key[1] + "@")   # events on that group's launches only; also resets the accumulated timings
         rsteps = max(2, min(args.steps, 10))
         sync()
         t0r = time.perf_counter()
@@ -588,42 +724,91 @@ def main(argv=None):
                                               "what": "one resident 960x960 image (32 lines) per call, det+cls+rec, 20 calls"}
         if kernel_timing:
             rep = rep_timed
-            if rep:
-                top = max(rep.items(), key=lambda kv: kv[1]["ms"])
-                name, r = top
+            if rep and dom_key is not None:
+                groups = kernel_groups(rep)
+                r = groups.get(dom_key) or max(groups.values(), key=lambda g: g["ms"])
+                name = group_label(dom_key, r)
                 avg_ms = r["ms"] / max(1, r["count"])
-                tflops = r["flops"] / (r["ms"] * 1e-3) / 1e12 if r["ms"] > 0 else 0.0
+                roof = roof_of(r["flops"], r["bytes"], r["ms"])
+                tflops, gbps, hbm_bound = roof["tflops"], roof["hbm_GBps_algorithmic"], roof["bound"] == "hbm"
                 traffic, traffic_src = None, None
                 for tf in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("pmc_traffic.json")), reverse=True):
                     # HBM bytes per launch from the rocprofv3 --pmc passes (tools/pmc_traffic.py), latest round first
                     pm = json.load(open(os.path.join(ROOT, "profiles", tf)))
-                    if pm.get("kernel") == name:
+                    if pm.get("kernel") == name or pm.get("kernel_group") == list(dom_key[:3]):
                         traffic = pm["traffic_bytes_per_launch"]
-                        traffic_src = "profiles/%s: rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs, gfx950 corrections) of the same bench command on this kernel, not this run" % tf
+                        traffic_src = "profiles/%s: rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs, gfx950 corrections) of the same bench command on this kernel (%s), not this run" % (tf, pm.get("launch", ""))
                         break
-                gbps = r["bytes"] / (r["ms"] * 1e-3) / 1e9 if r["ms"] > 0 else 0.0
-                # which roof binds this kernel: its algorithmic intensity against the f32 ridge (157.3 TFLOP/s / 8 TB/s)
-                hbm_bound = r["bytes"] > 0 and r["flops"] / r["bytes"] < FP32_MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
                 out["roofline"] = {"kernel": name, "measured_in": "single_chain", "bound": "hbm" if hbm_bound else "mfma",
                                    "achieved": gbps if hbm_bound else tflops, "peak": HBM_PEAK_GBS if hbm_bound else FP32_MFMA_PEAK_TFLOPS,
                                    "unit": "GB/s" if hbm_bound else "TFLOP/s",
                                    "frac": gbps / HBM_PEAK_GBS if hbm_bound else tflops / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
-                                   "avg_launch_ms": avg_ms, "launches": r["count"],
+                                   "avg_launch_ms": avg_ms, "launches": r["count"], "launches_per_step": r["count"] / max(1, single_chain["steps"]),
+                                   "dominant_by": "time per step summed over the launches of one kernel instantiation on one shape (the "
+                                                  "grouping of a rocprofv3 kernel summary by symbol and grid)",
                                    "algorithmic_flops_per_launch": r["flops"] / max(1, r["count"]),
                                    "algorithmic_bytes_per_launch": r["bytes"] / max(1, r["count"]),
                                    "tflops": tflops, "hbm_GBps_algorithmic": gbps}
             if survey:   # per-kernel shares from the untimed survey pass (one step, every launch timed)
                 tot = sum(v["ms"] for v in survey.values())
-                out["kernel_time_share_top5"] = {k: round(v["ms"] / tot, 4) for k, v in
-                                                 sorted(survey.items(), key=lambda kv: -kv[1]["ms"])[:5]}
+                sgroups = kernel_groups(survey)
+                out["kernel_time_share_top5"] = {group_label(k, g): round(g["ms"] / tot, 4) for k, g in
+                                                 sorted(sgroups.items(), key=lambda kv: -kv[1]["ms"])[:5]}
                 out["network_kernel_ms_per_step"] = tot
+                # ---- the step as a whole against the roofs (the line had no step-level figure)
+                fl = sum(v["flops"] for v in survey.values())
+                by = sum(v["bytes"] for v in survey.values())
+                step = {"flops": fl, "algorithmic_bytes": by, "ms": out["ms_per_step"],
+                        "what": "algorithmic FLOPs of every network launch of one step (survey pass) over the headline ms_per_step "
+                                "(two chains); pre/post-processing kernels add time, no FLOPs"}
+                step.update({k: v for k, v in roof_of(fl, by, out["ms_per_step"]).items() if k != "bound"})
+                step["frac"] = step["frac_mfma"]
+                if single_chain:
+                    step["single_chain_ms"] = single_chain["ms_per_step"]
+                    step["single_chain_frac_mfma"] = roof_of(fl, by, single_chain["ms_per_step"])["frac_mfma"]
+                step["kernel_ms_sum"] = tot
+                step["kernel_ms_sum_frac_mfma"] = roof_of(fl, by, tot)["frac_mfma"]
+                nets = {}
+                for nm in ("det", "cls", "rec"):
+                    rows = [v for k, v in survey.items() if k.startswith(nm + ".")]
+                    if rows:
+                        f_, b_, m_ = sum(v["flops"] for v in rows), sum(v["bytes"] for v in rows), sum(v["ms"] for v in rows)
+                        nets[nm] = dict(flops=f_, algorithmic_bytes=b_, kernel_ms=m_, launches=sum(v["count"] for v in rows), **roof_of(f_, b_, m_))
+                step["networks"] = nets
+                # the north star's "det conv stack": the detector's dense convolutions (matrix-core kernels)
+                dense = [v for k, v in survey.items() if k.startswith("det.") and any(t in k for t in (".conv1x1_", ".conv3x3_", ".dwpw"))]
+                if dense:
+                    f_, b_, m_ = sum(v["flops"] for v in dense), sum(v["bytes"] for v in dense), sum(v["ms"] for v in dense)
+                    step["det_conv_stack"] = dict(flops=f_, algorithmic_bytes=b_, kernel_ms=m_, launches=len(dense), **roof_of(f_, b_, m_),
+                                                  north_star_target_frac_mfma=0.60,
+                                                  note="f32 arithmetic at %.1f FLOP/B block-fused sits on the f32 ridge (%.1f FLOP/B): "
+                                                       "the stack as a whole cannot reach 0.60 of the f32 matrix peak in the reference's "
+                                                       "precision (SURVEY.md section 7/8d, DESIGN.md section 6); per-layer figures in the kernel table"
+                                                       % (f_ / max(1.0, b_), RIDGE))
+                small = [v for v in survey.values() if v["count"] and v["ms"] / v["count"] < 0.25]
+                step["launches_below_250us"] = {"launches": sum(v["count"] for v in small), "ms": sum(v["ms"] for v in small)}
+                out["roofline"] = dict(out.get("roofline") or {}, step=step)
                 if os.environ.get("OCR_BENCH_KERNEL_TABLE"):
                     with open(os.environ["OCR_BENCH_KERNEL_TABLE"], "w") as f:
+                        f.write("# groups (kernel instantiation x shape), one step, single chain\n")
+                        for k, g in sorted(sgroups.items(), key=lambda kv: -kv[1]["ms"]):
+                            f.write("G %-58s ms/step %8.3f launches %3d  ms/launch %7.3f  TFLOP/s %7.2f  GB/s(alg) %8.1f\n" % (
+                                group_label(k, g), g["ms"], g["count"], g["ms"] / max(1, g["count"]),
+                                g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] else 0, g["bytes"] / (g["ms"] * 1e-3) / 1e9 if g["ms"] else 0))
+                        f.write("# launches\n")
                         for k, v in sorted(survey.items(), key=lambda kv: -kv[1]["ms"]):
                             f.write("%-40s ms/step %8.3f launches/step %5.1f  TFLOP/s %7.2f  GB/s(alg) %8.1f\n" % (
                                 k, v["ms"], v["count"],
                                 v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] else 0,
                                 v["bytes"] / (v["ms"] * 1e-3) / 1e9 if v["ms"] else 0))
+        if n_ranks > 1:
+            out["roofline"] = None
+            out["roofline_note"] = "per-kernel and step rooflines are measured by the N = 1 run (one process owning one GPU); an N > 1 line reports rates only"
+        if per_rank:
+            per_rank["images_per_sec"] = [batch * steps_done / s_ if s_ > 0 else 0.0 for s_ in per_rank["seconds"]] if cfg != "cfg4" else None
+            out["per_rank"] = per_rank
+        out["host"] = {"host_cores_allowed": cores_mine, "input_generation_s": input_gen_s, "input_generation_workers": workers,
+                       "placement": placement}
         if n_ranks == 1 and not args.no_cpu_baseline and not stub and cfg == "cfg2":
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

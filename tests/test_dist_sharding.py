@@ -72,6 +72,44 @@ def test_bench_gpus_flag_starts_that_many_ranks_and_gathers_their_results():
     assert out["gather"]["matches_single_rank"] is True and out["gather"]["verified_images_per_rank"] == 4
     assert len(out["gather"]["records_per_rank"]) == 2 and all(8 <= c <= 24 for c in out["gather"]["records_per_rank"])
     assert out["value"] > 0 and out["scaling"] == "weak" and out["data"].startswith("stub")
+    # round 4: what an N > 1 line says about each rank and about itself
+    pr = out["per_rank"]
+    assert all(len(pr[k]) == 2 for k in ("seconds", "input_generation_s", "host_cores_allowed", "pinned", "numa_node", "images_per_sec"))
+    assert all(c >= 1 for c in pr["host_cores_allowed"]) and all(v > 0 for v in pr["images_per_sec"])
+    assert min(pr["images_per_sec"]) * 2 >= out["value"] * 0.999        # whole-job rate = all images over the SLOWEST rank's time
+    assert out["host"]["host_cores_allowed"] >= 1 and "placement" in out["host"]
+    assert out["roofline"] is None and "N = 1" in out["roofline_note"]
+
+
+def test_rank_placement_helpers_never_touch_the_gpu_and_split_the_cpus():
+    """bench.py pins a rank's host threads next to its GPU before anything initialises HIP: the helpers read sysfs only,
+    survive a machine without KFD, and two ranks that fall back to the even split get disjoint CPU sets."""
+    import subprocess
+    code = r"""
+import os, sys, json
+sys.path.insert(0, %r)
+import bench
+a0 = sorted(os.sched_getaffinity(0))
+node = bench.gpu_numa_node(0)
+info = bench.pin_rank_to_its_gpus_numa_node(int(sys.argv[1]), 2)
+print(json.dumps({"node": node, "info": info, "now": sorted(os.sched_getaffinity(0)), "before": a0, "torch": "torch" in sys.modules}))
+""" % ROOT
+    res = []
+    for r in (0, 1):
+        p = subprocess.run([sys.executable, "-c", code, str(r)], capture_output=True, text=True, timeout=120)
+        assert p.returncode == 0, p.stderr[-1000:]
+        res.append(__import__("json").loads(p.stdout.strip().splitlines()[-1]))
+    assert not res[0]["torch"]
+    if len(res[0]["before"]) >= 4:
+        assert res[0]["info"]["pinned"] and res[1]["info"]["pinned"]
+        assert set(res[0]["now"]).isdisjoint(res[1]["now"]) and set(res[0]["now"]) <= set(res[0]["before"])
+    assert bench_cpulist_ok()
+
+
+def bench_cpulist_ok():
+    sys.path.insert(0, ROOT)
+    import bench
+    return bench._cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11] and bench._cpulist("") == []
 
 
 def test_bench_gather_check_catches_a_rank_that_reports_a_wrong_box():

@@ -779,12 +779,14 @@ def main(argv=None):
                 dense = [v for k, v in survey.items() if k.startswith("det.") and any(t in k for t in (".conv1x1_", ".conv3x3_", ".dwpw"))]
                 if dense:
                     f_, b_, m_ = sum(v["flops"] for v in dense), sum(v["bytes"] for v in dense), sum(v["ms"] for v in dense)
+                    dn = nets.get("det", {})
                     step["det_conv_stack"] = dict(flops=f_, algorithmic_bytes=b_, kernel_ms=m_, launches=len(dense), **roof_of(f_, b_, m_),
                                                   north_star_target_frac_mfma=0.60,
-                                                  note="f32 arithmetic at %.1f FLOP/B block-fused sits on the f32 ridge (%.1f FLOP/B): "
-                                                       "the stack as a whole cannot reach 0.60 of the f32 matrix peak in the reference's "
-                                                       "precision (SURVEY.md section 7/8d, DESIGN.md section 6); per-layer figures in the kernel table"
-                                                       % (f_ / max(1.0, b_), RIDGE))
+                                                  note="the detector as launched moves %.1f algorithmic FLOP per HBM byte in f32, on the f32 ridge "
+                                                       "(%.1f FLOP/B): its thin high-resolution layers are bandwidth work, so the stack as a whole "
+                                                       "cannot reach 0.60 of the f32 matrix peak in the reference's precision (SURVEY.md section "
+                                                       "7/8d, DESIGN.md section 6); per-layer figures in the kernel table"
+                                                       % (dn.get("flops", 0.0) / max(1.0, dn.get("algorithmic_bytes", 1.0)), RIDGE))
                 small = [v for v in survey.values() if v["count"] and v["ms"] / v["count"] < 0.25]
                 step["launches_below_250us"] = {"launches": sum(v["count"] for v in small), "ms": sum(v["ms"] for v in small)}
                 out["roofline"] = dict(out.get("roofline") or {}, step=step)

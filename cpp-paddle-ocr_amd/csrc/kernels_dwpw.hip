@@ -56,6 +56,42 @@ __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make
 
 struct F4 { ocr_f2 lo, hi; };
 
+// Packed f32 arithmetic AS THE INSTRUCTION.  The compiler's last peephole (si-pre-emit-peephole) splits every
+// v_pk_{fma,mul,add}_f32 that follows an MFMA inside the MFMA's latency shadow into two scalar instructions, on the
+// assumption that scalar VALU work co-issues with the matrix pipe.  Measured on gfx950 (tools/micro/mfma_shadow.hip,
+// round 4): a VALU instruction between two v_mfma_f32_32x32x2_f32 costs ~4.5 clocks of matrix time whether it is packed
+// or not (the f32 matrix pipe and the f32 FMA lanes are the same multipliers), so the split DOUBLES what the depthwise
+// taps cost the matrix stream (100 v_fma_f32 per 32 MFMAs in the 5x5 block instead of 50 v_pk_fma_f32).  Inline asm is
+// opaque to that pass; the arithmetic is the same two IEEE operations per instruction (bit-identical, tests/).
+#ifndef OCR_DWPW_NO_PKASM
+__device__ __forceinline__ ocr_f2 pk_fma(ocr_f2 a, ocr_f2 b, ocr_f2 c) {
+  ocr_f2 d;
+  asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+__device__ __forceinline__ ocr_f2 pk_add(ocr_f2 a, ocr_f2 b) {
+  ocr_f2 d;
+  asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+// (scalar pair in SGPRs: one constant-bus operand per VOP3P instruction)
+__device__ __forceinline__ ocr_f2 pk_mul_s(ocr_f2 s, ocr_f2 b) {
+  ocr_f2 d;
+  asm("v_pk_mul_f32 %0, %1, %2" : "=v"(d) : "s"(s), "v"(b));
+  return d;
+}
+__device__ __forceinline__ ocr_f2 pk_add_s(ocr_f2 s, ocr_f2 b) {
+  ocr_f2 d;
+  asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "s"(s), "v"(b));
+  return d;
+}
+#else
+__device__ __forceinline__ ocr_f2 pk_fma(ocr_f2 a, ocr_f2 b, ocr_f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ ocr_f2 pk_add(ocr_f2 a, ocr_f2 b) { return a + b; }
+__device__ __forceinline__ ocr_f2 pk_mul_s(ocr_f2 s, ocr_f2 b) { return s * b; }
+__device__ __forceinline__ ocr_f2 pk_add_s(ocr_f2 s, ocr_f2 b) { return b + s; }
+#endif
+
 template <int K, int SH, int SW, int CK, bool WIDE>
 struct DwPwGeom {
   static constexpr int WP = WIDE ? 2 : 4, WC = WIDE ? 2 : 1;
@@ -129,9 +165,9 @@ template <bool ACT>
 __device__ __forceinline__ void lab_apply(F4& v, const ocr_f2 blo, const ocr_f2 bhi, const float s0, const float a0, const float s1,
                                           const float a1, const bool fast) {
   const ocr_f2 S0 = {s0, s0}, A0 = {a0, a0};
-  v.lo = v.lo + blo; v.hi = v.hi + bhi;
-  v.lo = S0 * v.lo; v.hi = S0 * v.hi;
-  v.lo = v.lo + A0; v.hi = v.hi + A0;
+  v.lo = pk_add(v.lo, blo); v.hi = pk_add(v.hi, bhi);
+  v.lo = pk_mul_s(S0, v.lo); v.hi = pk_mul_s(S0, v.hi);
+  v.lo = pk_add_s(A0, v.lo); v.hi = pk_add_s(A0, v.hi);
   if constexpr (ACT) {
     if (fast) { v.lo = ocr_hswish2_fast(v.lo); v.hi = ocr_hswish2_fast(v.hi); }
     else { v.lo.x = ocr_hswish_div(v.lo.x); v.lo.y = ocr_hswish_div(v.lo.y); v.hi.x = ocr_hswish_div(v.hi.x); v.hi.y = ocr_hswish_div(v.hi.y); }
@@ -509,8 +545,8 @@ __global__ void __launch_bounds__(256, LB) dwpw_kernel(const DwPwArgs a) {
           const int ky = r - o * SH;
           if (ky < 0 || ky >= K) continue;
           const float4 w = tw[slot][o];
-          dacc[o].lo = __builtin_elementwise_fma(ocr_f2{v.x, v.y}, ocr_f2{w.x, w.y}, dacc[o].lo);
-          dacc[o].hi = __builtin_elementwise_fma(ocr_f2{v.z, v.w}, ocr_f2{w.z, w.w}, dacc[o].hi);
+          dacc[o].lo = pk_fma(ocr_f2{v.x, v.y}, ocr_f2{w.x, w.y}, dacc[o].lo);
+          dacc[o].hi = pk_fma(ocr_f2{v.z, v.w}, ocr_f2{w.z, w.w}, dacc[o].hi);
         }
 #endif
       } else {  // the depthwise epilogue and the operand write, as in DW
@@ -522,9 +558,9 @@ __global__ void __launch_bounds__(256, LB) dwpw_kernel(const DwPwArgs a) {
           float mn = INFINITY, mx = 0.0f;
 #pragma unroll
           for (int o = 0; o < PR; ++o) {
-            ocr_f2 tl = dacc[o].lo + blo, th = dacc[o].hi + bhi;
-            tl = S0 * tl; th = S0 * th;
-            tl = tl + A0; th = th + A0;
+            ocr_f2 tl = pk_add(dacc[o].lo, blo), th = pk_add(dacc[o].hi, bhi);
+            tl = pk_mul_s(S0, tl); th = pk_mul_s(S0, th);
+            tl = pk_add_s(A0, tl); th = pk_add_s(A0, th);
             ocr_absrange(mn, mx, tl.x, tl.y);
             ocr_absrange(mn, mx, th.x, th.y);
           }

@@ -43,6 +43,7 @@ BATCH = 64
 H = W = 960
 K_LINES = 32
 FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+FP16_MFMA_PEAK_TFLOPS = 2500.0  # dense f16 matrix peak (same guide); the fp16 mode's kernels all sit below its ridge
 HBM_PEAK_GBS = 8000.0
 GATHER_CAP = BATCH * 64        # records per rank in the gather block (a cfg2 image has 32 words)
 
@@ -220,14 +221,84 @@ def group_label(key, g):
 RIDGE = FP32_MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)   # f32 FLOP per HBM byte where the two roofs meet
 
 
-def roof_of(flops, nbytes, ms):
-    """algorithmic work over a duration against the roof that bounds it (f32 MFMA peak above the ridge, HBM below)"""
+def roof_of(flops, nbytes, ms, mfma_peak=FP32_MFMA_PEAK_TFLOPS):
+    """algorithmic work over a duration against the roof that bounds it (matrix peak above the ridge, HBM below)"""
     sec = ms * 1e-3
     tflops = flops / sec / 1e12 if sec > 0 else 0.0
     gbps = nbytes / sec / 1e9 if sec > 0 else 0.0
-    hbm = nbytes > 0 and flops / nbytes < RIDGE
-    return {"bound": "hbm" if hbm else "mfma", "tflops": tflops, "frac_mfma": tflops / FP32_MFMA_PEAK_TFLOPS,
+    hbm = nbytes > 0 and flops / nbytes < mfma_peak * 1e12 / (HBM_PEAK_GBS * 1e9)
+    return {"bound": "hbm" if hbm else "mfma", "tflops": tflops, "frac_mfma": tflops / mfma_peak,
             "hbm_GBps_algorithmic": gbps, "frac_hbm": gbps / HBM_PEAK_GBS}
+
+
+def fp16_leg(mk_pipe, run_of, ref_words, batch, steps, sync):
+    """The opt-in precision = "fp16" mode (the reference's TensorRT precision switch, ocr_det.cpp:50-56) on the same
+    resident batch: f16 matrix products with f32 accumulation, f32 storage.  NEVER `value` - the
+    arithmetic is narrower than the reference's CPU path.  Reports its rate, how far its words are from the fp32 run's,
+    and the roofline of ITS dominant kernel (HBM-bound: every kernel of this mode is below the f16 ridge)."""
+    pipe = mk_pipe(0, "fp16")
+    run = run_of(pipe)
+    run(False)
+    run(False)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        run(False)
+    sync()
+    el = time.perf_counter() - t0
+    words = run(True)
+    stage = list(pipe.times)
+    pipe.close()
+    tot = same_ids = same_box = 0
+    dconf = 0.0
+    for wa, wb in zip(ref_words, words):
+        if len(wa) != len(wb):
+            tot += max(len(wa), len(wb))
+            continue
+        for a, b in zip(wa, wb):
+            tot += 1
+            same_box += bool(np.array_equal(a["box"], b["box"]))
+            same_ids += bool(np.array_equal(a["ids"], b["ids"]))
+            dconf = max(dconf, abs(a["confidence"] - b["confidence"]))
+    out = {"value": batch * steps / el, "unit": "images/sec", "ms_per_step": el * 1e3 / steps, "steps": steps,
+           "stage_ms_last_step": dict(zip(("det", "cls", "rec"), stage)),
+           "vs_fp32_words": {"words": tot, "identical_boxes": same_box / max(1, tot), "identical_id_sequences": same_ids / max(1, tot),
+                             "max_abs_confidence_diff": dconf},
+           "what": "precision = \"fp16\" on every stage: v_mfma_f32_32x32x8_f16 on operands rounded to f16, f32 accumulation and storage; "
+                   "an extra key, never `value` (narrower arithmetic than the reference's CPU path)"}
+    # its dominant kernel, on a single chain (as the fp32 roofline)
+    pipe1 = mk_pipe(1, "fp16")
+    run1 = run_of(pipe1)
+    run1(False)
+    run1(False)
+    pipe1.timing(True)
+    run1(False)
+    survey = pipe1.timing_report()
+    key, _ = max(kernel_groups(survey).items(), key=lambda kv: kv[1]["ms"])
+    pipe1.timing(True, only=key[1] + "@")
+    rsteps = max(2, min(steps, 5))
+    for _ in range(rsteps):
+        run1(False)
+    sync()
+    rep = kernel_groups(pipe1.timing_report())
+    pipe1.timing(False)
+    pipe1.close()
+    g = rep.get(key)
+    if g:
+        roof = roof_of(g["flops"], g["bytes"], g["ms"], FP16_MFMA_PEAK_TFLOPS)
+        hbm = roof["bound"] == "hbm"
+        out["roofline"] = {"kernel": group_label(key, g), "measured_in": "single_chain", "bound": roof["bound"],
+                           "achieved": roof["hbm_GBps_algorithmic"] if hbm else roof["tflops"],
+                           "peak": HBM_PEAK_GBS if hbm else FP16_MFMA_PEAK_TFLOPS, "unit": "GB/s" if hbm else "TFLOP/s",
+                           "frac": roof["frac_hbm"] if hbm else roof["frac_mfma"], "traffic": None,
+                           "avg_launch_ms": g["ms"] / max(1, g["count"]), "launches": g["count"],
+                           "algorithmic_flops_per_launch": g["flops"] / max(1, g["count"]),
+                           "algorithmic_bytes_per_launch": g["bytes"] / max(1, g["count"]), "tflops": roof["tflops"]}
+    tot_ms = sum(v["ms"] for v in survey.values())
+    out["network_kernel_ms_per_step"] = tot_ms
+    out["kernel_time_share_top5"] = {group_label(k, g_): round(g_["ms"] / tot_ms, 4) for k, g_ in
+                                     sorted(kernel_groups(survey).items(), key=lambda kv: -kv[1]["ms"])[:5]}
+    return out
 
 
 # ------------------------------------------------------------------------------------------------ host placement
@@ -327,6 +398,10 @@ def parse_args(argv=None):
                          "(512 mixed 640-1280 px images per GPU, resident); cfg4 = configs[3] (10k-image stream of cfg3 images "
                          "sharded i mod N, host inputs through the double-buffered staging)")
     ap.add_argument("--images", type=int, default=0, help="cfg3: images per GPU (default 512); cfg4: stream length (default 10000)")
+    ap.add_argument("--precision", choices=["fp32", "fp16"], default="fp32",
+                    help="the stages' precision parameter for EVERY leg of this run (exploration; the default line measures fp32 and "
+                         "reports the opt-in fp16 mode under its own key)")
+    ap.add_argument("--no-fp16", action="store_true", help="skip the fp16 leg of the default line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-request latency calls (profiling runs)")
@@ -443,8 +518,8 @@ def main(argv=None):
     else:
         from __graft_entry__ import load_package
         pkg = load_package()
-        mk_pipe = lambda phases=0: pkg.Pipe(device=local, enable_cls=True, limit_side_len=960, rec_batch_num=16, rec_img_h=48,
-                                            rec_img_w=320, phases=phases)
+        mk_pipe = lambda phases=0, precision=None: pkg.Pipe(device=local, enable_cls=True, limit_side_len=960, rec_batch_num=16, rec_img_h=48,
+                                                            rec_img_w=320, phases=phases, precision=precision or args.precision)
         pipe = mk_pipe()
         sync = lambda: pkg.check(pkg.lib().ocr_dev_sync())
         if cfg == "cfg2":
@@ -613,6 +688,13 @@ def main(argv=None):
                        "what": "two pipeline workers (two ocr_pipe handles, own streams and arenas, two chains each) on this one GPU, "
                                "each running the resident batch %d times concurrently" % wsteps}
 
+    # ---- the opt-in fp16 mode on the same resident batch (cfg2, one GPU): an extra key
+    fp16 = None
+    if not stub and cfg == "cfg2" and world == 1 and not args.no_fp16 and args.precision == "fp32":
+        ref_words = run_step(collect=True)
+        fp16 = fp16_leg(mk_pipe, lambda p_: (lambda collect=False: p_.run_device(d_imgs, H, W, BATCH, d_probs, collect=collect)),
+                        ref_words, batch, max(2, args.steps), sync)
+
     # ---- result gather (after the timed region): every rank's words of one step as fixed-size records
     gather = None
     gcap = max(GATHER_CAP, batch * 80)
@@ -697,7 +779,7 @@ def main(argv=None):
             "higher_is_better": True,
             "scaling": "weak" if cfg != "cfg4" else "strong",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32" if args.precision == "fp32" else "f16 products, f32 accumulate and storage (exploration run: --precision)",
             "data": "stub (launcher/gather rehearsal, not a measurement)" if stub else "synthetic",
             "config": {"workload": workload,
                        "images_per_step_per_gpu": batch, "sharding": "image i -> rank i mod n_gpus, no data-path collective; "
@@ -717,6 +799,10 @@ def main(argv=None):
             out["host_input"] = host_in
         if two_workers:
             out["two_workers_per_gpu"] = two_workers
+        if fp16:
+            out["fp16"] = fp16
+        if args.precision != "fp32":
+            out["precision_override"] = args.precision
         if gather:
             out["gather"] = gather
         if single_ms:

@@ -53,7 +53,7 @@ EXPORTS = [
     "ocr_cls_cfg_default", "ocr_cls_create", "ocr_cls_destroy", "ocr_cls_run", "ocr_cls_probs",
     "ocr_rec_cfg_default", "ocr_rec_create", "ocr_rec_destroy", "ocr_rec_run", "ocr_rec_label",
     "ocr_rec_num_classes", "ocr_rec_steps",
-    "ocr_net_create", "ocr_net_destroy", "ocr_net_forward", "ocr_net_forward_ragged", "ocr_net_forward_ragged_images", "ocr_net_num_tensors", "ocr_net_tensor_exists", "ocr_net_fetch",
+    "ocr_net_create", "ocr_net_create_precision", "ocr_net_destroy", "ocr_net_forward", "ocr_net_forward_ragged", "ocr_net_forward_ragged_images", "ocr_net_num_tensors", "ocr_net_tensor_exists", "ocr_net_fetch",
     "ocr_net_timing", "ocr_net_timing_report", "ocr_probe", "ocr_selftest_refuse_launch", "ocr_selftest_lds_memo",
 ]
 
@@ -66,6 +66,7 @@ def lib():
         L = C.CDLL(LIB_PATH)
         L.ocr_last_error.restype = C.c_char_p
         L.ocr_net_create.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
+        L.ocr_net_create_precision.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_char_p, C.POINTER(C.c_void_p)]
         L.ocr_net_destroy.argtypes = [C.c_void_p]
         L.ocr_net_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
         if hasattr(L, "ocr_net_forward_ragged_images"):
@@ -100,12 +101,12 @@ def probe(a, b):
 class Net:
     """Raw network tap (ocr_net_*): host f32 NHWC in, logical NHWC tensors out."""
 
-    def __init__(self, kind, model_dir=None, weights=None, device=0):
+    def __init__(self, kind, model_dir=None, weights=None, device=0, precision="fp32"):
         self.kind = kind
         model_dir = model_dir or os.path.join(MODELS, kind)
         self.h = C.c_void_p()
-        check(lib().ocr_net_create(kind.encode(), model_dir.encode(), weights.encode() if weights else None, device,
-                                   C.byref(self.h)))
+        check(lib().ocr_net_create_precision(kind.encode(), model_dir.encode(), weights.encode() if weights else None, device,
+                                             precision.encode(), C.byref(self.h)))
 
     def forward(self, x_nhwc, keep_all=False):
         x = np.ascontiguousarray(x_nhwc, dtype=np.float32)
@@ -492,7 +493,8 @@ class Pipe:
 
     def __init__(self, model_root=None, device=0, enable_cls=False, limit_type="max", limit_side_len=512, thresh=0.2,
                  box_thresh=0.4, unclip_ratio=1.8, use_dilation=False, rec_batch_num=16, rec_img_h=28, rec_img_w=192,
-                 cls_batch_num=8, crop_mode=CROP_BOUNDING_RECT, score_mode="fast", rec_sort_mode=0, phases=0, cv_compat=0):
+                 cls_batch_num=8, crop_mode=CROP_BOUNDING_RECT, score_mode="fast", rec_sort_mode=0, phases=0, cv_compat=0,
+                 precision="fp32"):
         L = lib()
         _pipe_protos(L)
         root = model_root or MODELS
@@ -500,9 +502,10 @@ class Pipe:
         L.ocr_pipe_cfg_default(C.byref(cfg))
         self._keep = [os.path.join(root, "det").encode(), os.path.join(root, "cls").encode(),
                       os.path.join(root, "rec").encode(), os.path.join(root, "rec", "ppocr_keys_v1.txt").encode(),
-                      limit_type.encode(), score_mode.encode()]
+                      limit_type.encode(), score_mode.encode(), precision.encode()]
         (cfg.det.model_dir, cfg.cls.model_dir, cfg.rec.model_dir, cfg.rec.label_path, cfg.det.limit_type,
-         cfg.det.det_db_score_mode) = self._keep
+         cfg.det.det_db_score_mode, _prec) = self._keep
+        cfg.det.precision = cfg.cls.precision = cfg.rec.precision = _prec
         cfg.det.device_id = device
         cfg.det.limit_side_len = limit_side_len
         cfg.det.det_db_thresh, cfg.det.det_db_box_thresh, cfg.det.det_db_unclip_ratio = thresh, box_thresh, unclip_ratio

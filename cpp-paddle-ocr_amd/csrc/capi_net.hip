@@ -184,7 +184,14 @@ int ocr_rt_init(int device_id) {
 }
 
 int ocr_net_create(const char* kind, const char* model_dir, const char* weights, int device_id, ocr_net** out) {
-  if (!kind || !model_dir || !out) return fail(OCR_ERR_ARG, "null argument");
+  return ocr_net_create_precision(kind, model_dir, weights, device_id, "fp32", out);
+}
+
+int ocr_net_create_precision(const char* kind, const char* model_dir, const char* weights, int device_id, const char* precision,
+                             ocr_net** out) {
+  if (!kind || !model_dir || !out || !precision) return fail(OCR_ERR_ARG, "null argument");
+  const bool half = !strcmp(precision, "fp16");
+  if (!half && strcmp(precision, "fp32")) return fail(OCR_ERR_ARG, "precision must be fp32 or fp16");
   const char* plan = embedded_plan(kind);
   if (!plan) return fail(OCR_ERR_ARG, "kind must be det, cls or rec");
   int rc = ocr_rt_init(device_id);
@@ -194,7 +201,7 @@ int ocr_net_create(const char* kind, const char* model_dir, const char* weights,
   if (!load_model_dir(model_dir, weights, kind, w, err)) return fail(OCR_ERR_MODEL, err);
   std::unique_ptr<ocr_net> h(new ocr_net());
   h->device = device_id;
-  if (!h->net.load(plan, w, err)) return fail(OCR_ERR_MODEL, err);
+  if (!h->net.load(plan, w, err, half)) return fail(OCR_ERR_MODEL, err);
   CAPI_HIP(g_stream_create(&h->stream));
   *out = h.release();
   return OCR_OK;

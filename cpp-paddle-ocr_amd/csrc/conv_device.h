@@ -9,6 +9,18 @@ namespace ocr {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
+// ---- precision = "fp16" (DESIGN.md section 9): the matrix-core products in f16 with f32 accumulation.  Activations stay
+// f32 C8I in HBM; a lane's 16-byte pixel operand (physical channels 4h..4h+3 of an octet) is rounded to four halfs
+// (v_cvt_pk_f16_f32, round to nearest even) and ONE v_mfma_f32_32x32x8_f16 consumes the octet (k = 4h + s on both
+// operands) where the f32 path issues four v_mfma_f32_32x32x2_f32.  Weights come from an f16 fragment image with the
+// f32 image's indexing, 8 bytes per lane instead of 16.
+typedef _Float16 ocr_h4 __attribute__((ext_vector_type(4)));
+typedef float ocr_f4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ ocr_h4 ocr_to_h4(const float4& v) { return __builtin_convertvector(ocr_f4v{v.x, v.y, v.z, v.w}, ocr_h4); }
+__device__ __forceinline__ ocr_h4 ocr_as_h4(const uint2& v) { return __builtin_bit_cast(ocr_h4, v); }
+template <bool HALF> struct WFrag { using T = float4; };
+template <> struct WFrag<true> { using T = uint2; };
+
 // Workgroups are dealt round-robin over the 8 XCDs (each with a private 4 MiB L2).  Neighbouring
 // tiles of these kernels re-read each other's input rows (3x3/5x5 taps, N-groups of one M-tile), so
 // give each XCD a CONTIGUOUS range of logical tiles: re-reads then hit that XCD's L2 instead of

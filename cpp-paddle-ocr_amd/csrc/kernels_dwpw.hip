@@ -187,9 +187,10 @@ __device__ __forceinline__ void lab_apply(F4& v, const ocr_f2 blo, const ocr_f2 
 // G runs one or two items (GD) ahead of S through as many register sets, S one item ahead of the taps through two LDS
 // buffers.  TD = tap steps the LDS reads run ahead, LB = workgroups per CU the register budget is cut for.
 // Everything per-thread that does not depend on the tile (LDS offsets of its pieces and items) is computed once.
-template <int K, int SH, int SW, int CK, bool WIDE, int NT, bool DWACT, int GD, int TD, int LB, bool RAG>
+template <int K, int SH, int SW, int CK, bool WIDE, int NT, bool DWACT, int GD, int TD, int LB, bool RAG, bool HALF = false>
 __global__ void __launch_bounds__(256, LB) dwpw_kernel(const DwPwArgs a) {
   using G_ = DwPwGeom<K, SH, SW, CK, WIDE>;
+  using WV = typename WFrag<HALF>::T;  // precision "fp16": f16 weight fragments, one v_mfma_f32_32x32x8_f16 per octet and column tile
   constexpr int WC = G_::WC, TW = G_::TW, TH = G_::TH, PR = G_::PR, IW = G_::IW;
   constexpr int S = G_::S, Q = G_::Q, C8S = G_::C8S, IN_TILE = G_::IN_TILE, OP_TILE = G_::OP_TILE, WT = G_::WT;
   constexpr int G_PIECES = G_::G_PIECES, G_PER = G_::G_PER, NIT = G_::NIT, IT_PER = G_::IT_PER;
@@ -378,11 +379,11 @@ __global__ void __launch_bounds__(256, LB) dwpw_kernel(const DwPwArgs a) {
   b_pos.init(u0, cblocks, a);
   m_pos = b_pos;
   int b_units = nunits, b_step = 0;
-  const float4* const w_lane = (const float4*)c.wfrag + (long)wc * NT * 64 + lane;
-  const float4* p_w = w_lane + (long)b_pos.cb * WC * NT * 64;
+  const WV* const w_lane = (const WV*)c.wfrag + (long)wc * NT * 64 + lane;
+  const WV* p_w = w_lane + (long)b_pos.cb * WC * NT * 64;
   // The fragments of a WHOLE chunk are fetched at the top of the iteration that multiplies it, before the depthwise
   // phase: the L2 round trip (the streamed input evicts them from L1) hides behind the depthwise arithmetic.
-  float4 bq[C8S][NT];
+  WV bq[C8S][NT];
   auto advanceB = [&]() __attribute__((always_inline)) {  // p_w -> the fragments of the item after the one just fetched
     b_step += C8S;
     if (b_step == KK) {  // next unit: back to the first step of ITS column block (past the end: the last one again)
@@ -398,18 +399,23 @@ __global__ void __launch_bounds__(256, LB) dwpw_kernel(const DwPwArgs a) {
     for (int j = 0; j < C8S; ++j) {
 #pragma unroll
 #ifdef OCR_DWPW_NO_B  // development probe: no fragment traffic
-      for (int t = 0; t < NT; ++t) bq[j][t] = make_float4((float)(size_t)p_w, (float)j, (float)t, 1.f);
+      for (int t = 0; t < NT; ++t) { bq[j][t] = WV{}; bq[j][t].x = (decltype(bq[j][t].x))(size_t)p_w; }
 #else
       for (int t = 0; t < NT; ++t) bq[j][t] = p_w[j * wstride + t * 64];
 #endif
     }
     advanceB();
   };
-  auto mfma4 = [&](const float4 (&bv)[NT], const float4& av) __attribute__((always_inline)) {
+  auto mfma4 = [&](const WV (&bv)[NT], const float4& av) __attribute__((always_inline)) {
 #ifdef OCR_DWPW_NO_MMA  // development probe: operands fetched, matrix pipe idle
-    acc[0][0] += bv[0].x * av.x + bv[NT - 1].w * av.w;
+    acc[0][0] += (float)bv[0].x * av.x + (float)bv[NT - 1].y * av.w;
     return;
 #endif
+    if constexpr (HALF) {
+      const ocr_h4 ah = ocr_to_h4(av);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x8f16(ocr_as_h4(bv[t]), ah, acc[t], 0, 0, 0);
+    } else
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[t].x, av.x, acc[t], 0, 0, 0);
@@ -509,11 +515,17 @@ __global__ void __launch_bounds__(256, LB) dwpw_kernel(const DwPwArgs a) {
     const float* sb = s_b + dbuf * CK;
     float* so = s_op + dbuf * OP_TILE;
     const float* som = s_op + mbuf * OP_TILE + op_off;
-    constexpr int ROWS = (PR - 1) * SH + K, NS = ROWS * K, D = TD, RS = D + 1, NM = C8S * NT * 4, NST = NS + 1;
-    const float4* const pb = p_w;  // the next item's fragments
+    constexpr int MPF = HALF ? 1 : 4;  // matrix instructions per fragment register (f16: one per octet)
+    constexpr int ROWS = (PR - 1) * SH + K, NS = ROWS * K, D = TD, RS = D + 1, NM = C8S * NT * MPF, NST = NS + 1;
+    const WV* const pb = p_w;  // the next item's fragments
     float4 av[C8S];
 #pragma unroll
     for (int j = 0; j < C8S; ++j) av[j] = *(const float4*)(som + 8 * j);
+    ocr_h4 ah[C8S];
+    if constexpr (HALF) {
+#pragma unroll
+      for (int j = 0; j < C8S; ++j) ah[j] = ocr_to_h4(av[j]);
+    }
     F4 dacc[PR];
 #pragma unroll
     for (int o = 0; o < PR; ++o) { dacc[o].lo = ocr_f2{0.f, 0.f}; dacc[o].hi = ocr_f2{0.f, 0.f}; }
@@ -575,15 +587,16 @@ __global__ void __launch_bounds__(256, LB) dwpw_kernel(const DwPwArgs a) {
       __builtin_amdgcn_sched_barrier(0);
       static_for<(st + 1) * NM / NST - st * NM / NST>([&](auto m_) __attribute__((always_inline)) {  // k-ascending per accumulator: octet, column tile, component
         constexpr int m = st * NM / NST + decltype(m_)::value;
-        constexpr int j = m / (4 * NT), t = (m / 4) % NT, c4 = m % 4;
+        constexpr int j = m / (MPF * NT), t = (m / MPF) % NT, c4 = m % MPF;
 #ifdef OCR_DWPW_NO_MMA  // development probe: operands fetched, matrix pipe idle
-        if (m == 0) acc[t][0] += comp(bq[j][t], c4) * comp(av[j], c4);
+        if (m == 0) acc[t][0] += (float)bq[j][t].x * av[j].x;
 #else
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(bq[j][t], c4), comp(av[j], c4), acc[t], 0, 0, 0);
+        if constexpr (HALF) acc[t] = __builtin_amdgcn_mfma_f32_32x32x8f16(ocr_as_h4(bq[j][t]), ah[j], acc[t], 0, 0, 0);
+        else acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(bq[j][t], c4), comp(av[j], c4), acc[t], 0, 0, 0);
 #endif
-        if (c4 == 3)  // the last use of this fragment register: refill it
+        if (c4 == MPF - 1)  // the last use of this fragment register: refill it
 #ifdef OCR_DWPW_NO_B
-          bq[j][t] = make_float4((float)(size_t)pb, (float)j, (float)t, 1.f);
+          { bq[j][t] = WV{}; bq[j][t].x = (decltype(bq[j][t].x))(size_t)pb; }
 #else
           bq[j][t] = pb[j * wstride + t * 64];
 #endif
@@ -662,7 +675,7 @@ __global__ void __launch_bounds__(256, LB) dwpw_kernel(const DwPwArgs a) {
 
 namespace {
 
-template <int K, int SH, int SW, int CK, bool WIDE, int NT, bool DWACT, int GD, int TD, int LB, bool RAG>
+template <int K, int SH, int SW, int CK, bool WIDE, int NT, bool DWACT, int GD, int TD, int LB, bool RAG, bool HALF>
 bool launch_one(const DwPwArgs& a0, hipStream_t s, bool query) {
   using G_ = DwPwGeom<K, SH, SW, CK, WIDE>;
   const size_t lds = G_::lds_floats(a0.c.NTtot) * sizeof(float);
@@ -676,7 +689,7 @@ bool launch_one(const DwPwArgs& a0, hipStream_t s, bool query) {
   static std::mutex occ_mu;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
-  if (lds > 64 * 1024 && !raise_dynamic_lds((const void*)dwpw_kernel<K, SH, SW, CK, WIDE, NT, DWACT, GD, TD, LB, RAG>, (int)lds, attr_state)) return false;
+  if (lds > 64 * 1024 && !raise_dynamic_lds((const void*)dwpw_kernel<K, SH, SW, CK, WIDE, NT, DWACT, GD, TD, LB, RAG, HALF>, (int)lds, attr_state)) return false;
   int per_cu_dev = 0, cus_dev = 0;
   {
     std::lock_guard<std::mutex> lk(occ_mu);
@@ -686,7 +699,7 @@ bool launch_one(const DwPwArgs& a0, hipStream_t s, bool query) {
     if (!e) {
       int nb = 0;
       hipDeviceProp_t prop;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, dwpw_kernel<K, SH, SW, CK, WIDE, NT, DWACT, GD, TD, LB, RAG>, 256, lds) != hipSuccess || nb < 1 ||
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, dwpw_kernel<K, SH, SW, CK, WIDE, NT, DWACT, GD, TD, LB, RAG, HALF>, 256, lds) != hipSuccess || nb < 1 ||
           hipGetDeviceProperties(&prop, dev) != hipSuccess) { (void)hipGetLastError(); return false; }
       e = occ[dev][0].per_cu ? &occ[dev][1] : &occ[dev][0];  // (two sizes per instantiation on the plans' shapes; a third replaces the second)
       *e = Occ{lds, nb, prop.multiProcessorCount};
@@ -717,7 +730,7 @@ bool launch_one(const DwPwArgs& a0, hipStream_t s, bool query) {
   if (rt_options().dwpw_force_upw > 0) upw = rt_options().dwpw_force_upw;
   a.upw = (unsigned)upw;
   const dim3 grid((unsigned)((nunits + upw - 1) / upw));
-  hipLaunchKernelGGL((dwpw_kernel<K, SH, SW, CK, WIDE, NT, DWACT, GD, TD, LB, RAG>), grid, dim3(256), lds, s, a);
+  hipLaunchKernelGGL((dwpw_kernel<K, SH, SW, CK, WIDE, NT, DWACT, GD, TD, LB, RAG, HALF>), grid, dim3(256), lds, s, a);
   return true;
 }
 
@@ -749,8 +762,11 @@ static int dwpw_dispatch(const DwPwArgs& a, hipStream_t s, bool query, bool rows
 #define OCR_DWPW_CASE(K_, SH_, SW_, CK_, WIDE_, NT_, GD_, TD_, LB_, COND)                                  \
   if (K == K_ && SH == SH_ && SW == SW_ && Cs % CK_ == 0 && tiles % (NT_ * (WIDE_ ? 2 : 1)) == 0 && (COND)) { \
     if (rows_only) return DwPwGeom<K_, SH_, SW_, CK_, WIDE_>::TH;                                                \
-    return (a.rtiles ? launch_one<K_, SH_, SW_, CK_, WIDE_, NT_, true, GD_, TD_, LB_, true>(a, s, query)                 \
-                     : launch_one<K_, SH_, SW_, CK_, WIDE_, NT_, true, GD_, TD_, LB_, false>(a, s, query)) ? 1 : 0;      \
+    if (a.c.half)                                                                                                \
+      return (a.rtiles ? launch_one<K_, SH_, SW_, CK_, WIDE_, NT_, true, GD_, TD_, LB_, true, true>(a, s, query)         \
+                       : launch_one<K_, SH_, SW_, CK_, WIDE_, NT_, true, GD_, TD_, LB_, false, true>(a, s, query)) ? 1 : 0; \
+    return (a.rtiles ? launch_one<K_, SH_, SW_, CK_, WIDE_, NT_, true, GD_, TD_, LB_, true, false>(a, s, query)          \
+                     : launch_one<K_, SH_, SW_, CK_, WIDE_, NT_, true, GD_, TD_, LB_, false, false>(a, s, query)) ? 1 : 0; \
   }
   // TD = how many tap steps ahead the LDS reads run, LB = workgroups per CU the register budget is cut for (3: 168
   // registers, 2: 256): per shape, whichever measured faster (tools/micro/dwpw_probe) - a third wave per SIMD where the

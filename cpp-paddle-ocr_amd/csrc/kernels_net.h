@@ -65,6 +65,9 @@ struct ConvArgs {
   // 3x3 tile kernels on a ragged batch of images: [N+1] prefix sums of the images' 8x16-pixel tile counts
   const int* rtiles = nullptr;
   int rtiles_total = 0;
+  // precision "fp16": wfrag is the f16 fragment image ([...][64 lanes][4 halfs]) and the products run as
+  // v_mfma_f32_32x32x8_f16 on operands rounded to f16, f32 accumulation (conv_device.h); 0: the f32 contract
+  int half = 0;
 };
 // false: the combination (gated input / multi-tap conv with a plain or deconv output) is not instantiated
 bool launch_conv_mfma(const ConvArgs& a, const Epilogue& ep, int nt, hipStream_t s);

@@ -24,8 +24,9 @@ namespace ocr {
 // B from the host-built fragment image (one 16-byte load per lane per n-tile per 8 channels).
 // No LDS, no barriers: four independent waves per workgroup.
 // =====================================================================================
-template <int NT, int MODE, bool TAP1, bool GATE = false>
+template <int NT, int MODE, bool TAP1, bool GATE = false, bool HALF = false>
 __global__ void __launch_bounds__(256, (NT <= 3 ? 4 : 3)) conv_mfma_kernel(const ConvArgs a, const Epilogue ep) {
+  using WV = typename WFrag<HALF>::T;  // a lane's weight fragment of one octet: float4, or four halfs (precision "fp16")
   CONV_PROBE(0);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int p = lane & 31, h = lane >> 5;
@@ -53,9 +54,9 @@ __global__ void __launch_bounds__(256, (NT <= 3 ? 4 : 3)) conv_mfma_kernel(const
   // What a step costs besides its MFMAs is not hidden by the other waves of the SIMD (probe with all
   // memory traffic removed: the generic walk below holds the kernel at 75% of the MFMA rate), so the
   // single-tap case - 1x1 conv, linear, deconv: most of the FLOPs - gets a walk of a few instructions.
-  const float4* __restrict__ wf = (const float4*)a.wfrag;
+  const WV* __restrict__ wf = (const WV*)a.wfrag;
   const int KK = a.KH * a.KW * a.C8;
-  const float4* p_w = wf + (long)nt0 * 64 + lane;
+  const WV* p_w = wf + (long)nt0 * 64 + lane;
   const long wstride = (long)a.NTtot * 64;
   const float* zpage = a.zeros + 4 * h;
   // ---- single tap: step j reads the lane's row at channel 8j and fragment block j
@@ -86,7 +87,7 @@ __global__ void __launch_bounds__(256, (NT <= 3 ? 4 : 3)) conv_mfma_kernel(const
       lane_base = a.in + 4 * h + (((long)n * a.H + (y - a.PH)) * a.W + (x - a.PW)) * a.Cs_in;
     }
   }
-  auto load_step = [&](float4& av, float4 (&bv)[NT], float4& gv) {
+  auto load_step = [&](float4& av, WV (&bv)[NT], float4& gv) {
     if constexpr (GATE) gv = *(const float4*)(grow + p_step * 8);
     if constexpr (TAP1) {
 #ifdef OCR_PROBE_NOX
@@ -104,7 +105,7 @@ __global__ void __launch_bounds__(256, (NT <= 3 ? 4 : 3)) conv_mfma_kernel(const
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #ifdef OCR_PROBE_NOW
-      bv[t] = make_float4((float)(size_t)p_w, (float)t, 2.f, 3.f);
+      { bv[t] = WV{}; bv[t].x = (decltype(bv[t].x))(size_t)p_w; }
 #else
       bv[t] = p_w[t * 64];  // the fragment image is padded to whole NT groups
 #endif
@@ -126,7 +127,16 @@ __global__ void __launch_bounds__(256, (NT <= 3 ? 4 : 3)) conv_mfma_kernel(const
   // nothing but MFMAs in the step the waves of a SIMD take turns badly.  tools/micro/conv_time.hip, 983040 x 480 -> 480
   // alone: 108.3 TFLOP/s without, 128.3 with (s_nop: no change; a VALU op after EVERY MFMA: 120); 240 -> 240: 92.6 ->
   // 105.0; 480 -> 120: 94.4 -> 110.2; NT = 1 (every MFMA followed by one) loses 4 %, so only for NT >= 2.
-  auto mfma_step = [&](const float4& av0, const float4 (&bv)[NT], const float4& gv) {
+  auto mfma_step = [&](const float4& av0, const WV (&bv)[NT], const float4& gv) {
+    if constexpr (HALF) {  // one f16 matrix instruction per octet and column tile
+      float4 x = av0;
+      if constexpr (GATE) { x.x = av0.x * gv.x; x.y = av0.y * gv.y; x.z = av0.z * gv.z; x.w = av0.w * gv.w; }
+      const ocr_h4 ah = ocr_to_h4(x);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x8f16(ocr_as_h4(bv[t]), ah, acc[t], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
 #define OCR_C_SWEEP(C)                                                                                                    \
   {                                                                                                                       \
     float avc = av0.C;                                                                                                    \
@@ -138,8 +148,10 @@ __global__ void __launch_bounds__(256, (NT <= 3 ? 4 : 3)) conv_mfma_kernel(const
   }
     OCR_C_SWEEP(x) OCR_C_SWEEP(y) OCR_C_SWEEP(z) OCR_C_SWEEP(w)
 #undef OCR_C_SWEEP
+    }
   };
-  float4 a0, b0[NT], a1, b1[NT];
+  float4 a0, a1;
+  WV b0[NT], b1[NT];
   float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0;
   load_step(a0, b0, g0);
   CONV_PROBE(1);
@@ -168,8 +180,9 @@ __global__ void __launch_bounds__(256, (NT <= 3 ? 4 : 3)) conv_mfma_kernel(const
 // alone): MT x NT = 1x3 (the kernel above) 99.8 TFLOP/s gated / 108.6 plain, 1x5 110.5 / 115.6 - the direct kernel is
 // bound by the bytes it pulls through L1 per MFMA (1x3: 5 KB per 12 MFMAs; 2x3: 7 KB per 24), not by occupancy
 // (3 or 4 waves per SIMD measure the same).  Every output's chain is the one above: bit-identical.
-template <int NT, int MT, bool GATE>
+template <int NT, int MT, bool GATE, bool HALF = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) conv_mfma_mt_kernel(const ConvArgs a, const Epilogue ep) {
+  using WV = typename WFrag<HALF>::T;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int p = lane & 31, h = lane >> 5;
   const unsigned lb = xcd_swizzle(blockIdx.x, gridDim.x);  // logical block: N-group fastest, then M-tile
@@ -189,9 +202,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][t][r] = 0.0f;
 
-  const float4* __restrict__ wf = (const float4*)a.wfrag;
+  const WV* __restrict__ wf = (const WV*)a.wfrag;
   const int KK = a.C8;
-  const float4* p_w = wf + (long)nt0 * 64 + lane;
+  const WV* p_w = wf + (long)nt0 * 64 + lane;
   const long wstride = (long)a.NTtot * 64;
   const float* zpage = a.zeros + 4 * h;
   const float* xrow[MT];
@@ -210,7 +223,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     }
   }
   int p_step = 0;
-  struct Set { float4 av[MT], gv[MT], bv[NT]; };
+  struct Set { float4 av[MT], gv[MT]; WV bv[NT]; };
   auto load_step = [&](Set& s) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
@@ -234,6 +247,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     // take turns badly (conv_time, 983040 x 480 -> 480: 117.8 TFLOP/s without, 129.7 with a v_nop per NT MFMAs, 120.3 with
     // one per MFMA, no change with s_nop); the gated kernel has its multiplies there (124.5; hoisted in front of the
     // MFMAs 108.6), and more of them do not help it.
+    if constexpr (HALF) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const ocr_h4 ah = ocr_to_h4(av[i]);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x8f16(ocr_as_h4(s.bv[t]), ah, acc[i][t], 0, 0, 0);
+      }
+    } else {
 #define OCR_MT_SWEEP(C)                                                                                      \
   _Pragma("unroll") for (int i = 0; i < MT; ++i) {                                                           \
     _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                           \
@@ -242,6 +263,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
   }
     OCR_MT_SWEEP(x) OCR_MT_SWEEP(y) OCR_MT_SWEEP(z) OCR_MT_SWEEP(w)
 #undef OCR_MT_SWEEP
+    }
   };
   Set s0, s1;
   if constexpr (!GATE) {
@@ -272,35 +294,40 @@ bool launch_conv_mfma_mt2(const ConvArgs& a, const Epilogue& ep, int nt, hipStre
   const bool tap1 = a.KH == 1 && a.KW == 1 && a.PH == 0 && a.PW == 0 && a.OH == a.H && a.OW == a.W;
   if (!tap1 || a.out_mode != OUT_C8I || a.NTtot % nt) return false;
   dim3 grid((unsigned)(((a.M + 255) / 256) * (a.NTtot / nt)));
+#define OCR_MT_LAUNCH(NT_, GATE_)                                                                                  \
+  {                                                                                                                \
+    if (a.half) hipLaunchKernelGGL((conv_mfma_mt_kernel<NT_, 2, GATE_, true>), grid, dim3(256), 0, s, a, ep);      \
+    else hipLaunchKernelGGL((conv_mfma_mt_kernel<NT_, 2, GATE_, false>), grid, dim3(256), 0, s, a, ep);            \
+  }
   if (nt == 3) {
-    if (a.gate) hipLaunchKernelGGL((conv_mfma_mt_kernel<3, 2, true>), grid, dim3(256), 0, s, a, ep);
-    else hipLaunchKernelGGL((conv_mfma_mt_kernel<3, 2, false>), grid, dim3(256), 0, s, a, ep);
+    if (a.gate) OCR_MT_LAUNCH(3, true) else OCR_MT_LAUNCH(3, false)
   } else if (nt == 4) {
-    if (a.gate) hipLaunchKernelGGL((conv_mfma_mt_kernel<4, 2, true>), grid, dim3(256), 0, s, a, ep);
-    else hipLaunchKernelGGL((conv_mfma_mt_kernel<4, 2, false>), grid, dim3(256), 0, s, a, ep);
+    if (a.gate) OCR_MT_LAUNCH(4, true) else OCR_MT_LAUNCH(4, false)
   } else {
     return false;
   }
+#undef OCR_MT_LAUNCH
   return true;
 }
 
-bool launch_conv_mfma(const ConvArgs& a, const Epilogue& ep, int nt, hipStream_t s) {
+template <bool HALF>
+static bool launch_conv_mfma_t(const ConvArgs& a, const Epilogue& ep, int nt, hipStream_t s) {
   dim3 grid((unsigned)(((a.M + 127) / 128) * (a.NTtot / nt)));
 #define OCR_LAUNCH_MODE(MODE, TAP1)                                                                             \
   switch (nt) {                                                                                                 \
-    case 1: hipLaunchKernelGGL((conv_mfma_kernel<1, MODE, TAP1>), grid, dim3(256), 0, s, a, ep); break;         \
-    case 2: hipLaunchKernelGGL((conv_mfma_kernel<2, MODE, TAP1>), grid, dim3(256), 0, s, a, ep); break;         \
-    case 3: hipLaunchKernelGGL((conv_mfma_kernel<3, MODE, TAP1>), grid, dim3(256), 0, s, a, ep); break;         \
-    default: hipLaunchKernelGGL((conv_mfma_kernel<4, MODE, TAP1>), grid, dim3(256), 0, s, a, ep); break;        \
+    case 1: hipLaunchKernelGGL((conv_mfma_kernel<1, MODE, TAP1, false, HALF>), grid, dim3(256), 0, s, a, ep); break;         \
+    case 2: hipLaunchKernelGGL((conv_mfma_kernel<2, MODE, TAP1, false, HALF>), grid, dim3(256), 0, s, a, ep); break;         \
+    case 3: hipLaunchKernelGGL((conv_mfma_kernel<3, MODE, TAP1, false, HALF>), grid, dim3(256), 0, s, a, ep); break;         \
+    default: hipLaunchKernelGGL((conv_mfma_kernel<4, MODE, TAP1, false, HALF>), grid, dim3(256), 0, s, a, ep); break;        \
   }
   const bool tap1 = a.KH == 1 && a.KW == 1 && a.PH == 0 && a.PW == 0 && a.OH == a.H && a.OW == a.W;
   if (a.gate) {
     if (!(tap1 && a.out_mode == OUT_C8I)) return false;  // a gated input needs a 1x1 conv with a C8I output
     switch (nt) {
-      case 1: hipLaunchKernelGGL((conv_mfma_kernel<1, OUT_C8I, true, true>), grid, dim3(256), 0, s, a, ep); break;
-      case 2: hipLaunchKernelGGL((conv_mfma_kernel<2, OUT_C8I, true, true>), grid, dim3(256), 0, s, a, ep); break;
-      case 3: hipLaunchKernelGGL((conv_mfma_kernel<3, OUT_C8I, true, true>), grid, dim3(256), 0, s, a, ep); break;
-      default: hipLaunchKernelGGL((conv_mfma_kernel<4, OUT_C8I, true, true>), grid, dim3(256), 0, s, a, ep); break;
+      case 1: hipLaunchKernelGGL((conv_mfma_kernel<1, OUT_C8I, true, true, HALF>), grid, dim3(256), 0, s, a, ep); break;
+      case 2: hipLaunchKernelGGL((conv_mfma_kernel<2, OUT_C8I, true, true, HALF>), grid, dim3(256), 0, s, a, ep); break;
+      case 3: hipLaunchKernelGGL((conv_mfma_kernel<3, OUT_C8I, true, true, HALF>), grid, dim3(256), 0, s, a, ep); break;
+      default: hipLaunchKernelGGL((conv_mfma_kernel<4, OUT_C8I, true, true, HALF>), grid, dim3(256), 0, s, a, ep); break;
     }
     return true;
   }
@@ -312,6 +339,10 @@ bool launch_conv_mfma(const ConvArgs& a, const Epilogue& ep, int nt, hipStream_t
   else return false;  // a multi-tap conv with a plain / deconv output is not instantiated
 #undef OCR_LAUNCH_MODE
   return true;
+}
+
+bool launch_conv_mfma(const ConvArgs& a, const Epilogue& ep, int nt, hipStream_t s) {
+  return a.half ? launch_conv_mfma_t<true>(a, ep, nt, s) : launch_conv_mfma_t<false>(a, ep, nt, s);
 }
 
 // =====================================================================================

@@ -68,7 +68,11 @@ struct KernelTiming {
 class Net {
  public:
   ~Net();
-  bool load(const char* plan_text, const WeightMap& weights, std::string& err);
+  // half (precision "fp16"): the matrix-core products (dense convs, linears, transposed convs, the 1x1
+  // half of the fused depthwise blocks) run in f16 with f32 accumulation on operands rounded to f16; storage, the VALU
+  // kernels (stem, depthwise, SE, layer norm, attention, softmax, the fused DB head) and every reduction stay f32
+  bool load(const char* plan_text, const WeightMap& weights, std::string& err, bool half = false);
+  bool half() const { return half_; }
   // Binds shapes (re-planning arena + launches if they changed) and enqueues the network.
   // x: device f32 [N,H,W,3] plain NHWC (already normalised).
   bool run(const float* x, int N, int H, int W, hipStream_t s, std::string& err);
@@ -203,6 +207,7 @@ class Net {
   int* head_amax_ = nullptr;
   float* head_pmax_ = nullptr;
   bool timing_ = false;
+  bool half_ = false;
   bool graphs_ = true;          // OCR_GRAPH=0 (read when the network is loaded): plain launches only
   // set by a launch closure whose launcher refused a shape that bind() had accepted (cannot happen by construction;
   // a service process must get an error reply out of it, not an abort): run_bound fails the run with it

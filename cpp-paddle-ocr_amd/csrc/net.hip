@@ -183,7 +183,20 @@ static std::vector<float> build_frag(int taps, int cin, int cols, Get get) {
   return f;
 }
 
-bool Net::load(const char* plan_text, const WeightMap& W, std::string& err) {
+// precision "fp16": the same image in f16 (round to nearest even), four halfs per lane packed into the float vector
+// upload() takes - what the HALF instantiations of the matrix-core kernels read as uint2 per lane (conv_device.h)
+static std::vector<float> frag_to_half(const std::vector<float>& f) {
+  std::vector<float> out((f.size() + 1) / 2, 0.f);
+  uint16_t* h = reinterpret_cast<uint16_t*>(out.data());
+  for (size_t i = 0; i < f.size(); ++i) {
+    const _Float16 v = (_Float16)f[i];
+    memcpy(&h[i], &v, sizeof(uint16_t));
+  }
+  return out;
+}
+
+bool Net::load(const char* plan_text, const WeightMap& W, std::string& err, bool half) {
+  half_ = half;
   if (!parse_plan(plan_text, plan_, err)) return false;
   { const char* e = getenv("OCR_GRAPH"); graphs_ = !(e && e[0] == '0'); }
   if (const char* e = getenv("OCR_NET_BINDINGS")) max_bindings_ = (size_t)std::min(4096L, std::max(2L, atol(e)));  // (tests: a small cap forces evictions)
@@ -256,6 +269,7 @@ bool Net::load(const char* plan_text, const WeightMap& W, std::string& err) {
             return ch < co ? w[((size_t)ch * ci + k) * kh * kw + tap] : 0.f;
           });
           if (!upload("frag:" + op.w, f)) { err = "hipMalloc failed"; return false; }
+          if (half_ && !upload("frag16:" + op.w, frag_to_half(f))) { err = "hipMalloc failed"; return false; }
           if (kh == 3 && kw == 3 && ci == 96 && co == 24 && !pl && !upload("c24:" + op.w, conv3x3_c24_image(w, co, ci))) { err = "hipMalloc failed"; return false; }
           if (kh == 1 && kw == 1 && ci <= 24 && !pl && op.ep.empty()) {  // conv_rowsum_kernel's image (RSE blocks): [k logical, padded][physical column]
             const int cs_in = c8i_stride(ci);
@@ -281,6 +295,7 @@ bool Net::load(const char* plan_text, const WeightMap& W, std::string& err) {
           return ch < co ? w[(size_t)k * co + ch] : 0.f;
         });
         if (!upload("frag:" + op.w, f)) { err = "hipMalloc failed"; return false; }
+        if (half_ && !upload("frag16:" + op.w, frag_to_half(f))) { err = "hipMalloc failed"; return false; }
       } break;
       case PlanOp::DECONV: {
         auto p = need(op.w); if (!p) return false;
@@ -299,6 +314,7 @@ bool Net::load(const char* plan_text, const WeightMap& W, std::string& err) {
             return ch < co ? w[((size_t)k * co + ch) * 4 + q] : 0.f;
           });
           if (!upload("frag:" + op.w, f)) { err = "hipMalloc failed"; return false; }
+          if (half_ && !upload("frag16:" + op.w, frag_to_half(f))) { err = "hipMalloc failed"; return false; }
           // [k][q][c] logical channels for the fused DB head (db_head_kernel)
           std::vector<float> img((size_t)ci * 4 * co);
           for (int k = 0; k < ci; ++k)
@@ -953,7 +969,8 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths, const i
         } else {
           if (!build_epilogue(op, ep, true, err)) return false;
           ConvArgs a{};
-          a.in = arena_ + in.offset; a.out = optr; a.wfrag = dev_vec("frag:" + op.w);
+          a.in = arena_ + in.offset; a.out = optr; a.wfrag = dev_vec((half_ ? "frag16:" : "frag:") + op.w);
+          a.half = half_ ? 1 : 0;
           a.N = in.n; a.H = in.h; a.W = in.w; a.Cs_in = in.cs; a.C8 = in.cs / 8;
           a.KH = op.kh; a.KW = op.kw; a.PH = op.ph; a.PW = op.pw;
           a.need_nyx = 0;
@@ -1018,7 +1035,8 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths, const i
           // measured (gpurun_out r1g): LDS staging wins for multi-tap convs (3x3 96->24: 58 vs 51 TFLOP/s),
           // the direct kernel for 1x1 (480->480: 88 vs 71; thin K: 54 vs 39)
           const int impl = rt_options().conv_impl;
-          const bool use_lds = !a.gate && a.out_mode == OUT_C8I && (impl ? impl == 2 : (taps > 1 && in.cs >= 64));
+          // precision "fp16": the LDS-staged and the 4x4x1 kernels are f32 only - every dense conv goes through the direct kernel
+          const bool use_lds = !half_ && !a.gate && a.out_mode == OUT_C8I && (impl ? impl == 2 : (taps > 1 && in.cs >= 64));
           if (dwpw_of[oi] >= 0) {
             const PlanOp& d = plan_.ops[dwpw_of[oi]];
             const TensorDesc& din = T[d.in];

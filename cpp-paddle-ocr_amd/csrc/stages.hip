@@ -102,7 +102,9 @@ void DetStage::resize_shape(int h, int w, const std::string& limit_type, int lim
 bool DetStage::create(const DetConfig& cfg, std::string& err, int& code) {
   cfg_ = cfg;
   code = OCR_ERR_ARG;
-  if (cfg.precision != "fp32") { err = "precision '" + cfg.precision + "' is not implemented (fp32 only)"; return false; }
+  // the reference's constructor parameter (TensorRT precision, ocr_det.cpp:50-56 / ocr_cls.cpp:135-140 / ocr_rec.cpp:167-172):
+  // "fp32" = the bit-exact contract, "fp16" = f16 matrix products with f32 accumulation (Net::load); "int8" is refused
+  if (cfg.precision != "fp32" && cfg.precision != "fp16") { err = "precision '" + cfg.precision + "' is not implemented (fp32 | fp16)"; return false; }
   if (cfg.score_mode != "fast" && cfg.score_mode != "slow") { err = "det_db_score_mode must be fast or slow"; return false; }
   if (cfg.limit_type != "max" && cfg.limit_type != "min") { err = "limit_type must be max or min"; return false; }
   if (cfg.max_batch < 1) { err = "max_batch must be >= 1"; return false; }
@@ -112,7 +114,7 @@ bool DetStage::create(const DetConfig& cfg, std::string& err, int& code) {
   WeightMap w;
   code = OCR_ERR_MODEL;
   if (!load_model_dir(cfg.model_dir, nullptr, "det", w, err)) return false;
-  if (!net_.load(embedded_plan("det"), w, err)) return false;
+  if (!net_.load(embedded_plan("det"), w, err, cfg.precision == "fp16")) return false;
   code = OCR_ERR_DEVICE;
   if (g_stream_create(&stream_) != hipSuccess) { err = "hipStreamCreate failed"; return false; }
   if (!timer_.init(err)) return false;
@@ -401,7 +403,9 @@ RecStage::~RecStage() {
 bool RecStage::create(const RecConfig& cfg, std::string& err, int& code) {
   cfg_ = cfg;
   code = OCR_ERR_ARG;
-  if (cfg.precision != "fp32") { err = "precision '" + cfg.precision + "' is not implemented (fp32 only)"; return false; }
+  // the reference's constructor parameter (TensorRT precision, ocr_det.cpp:50-56 / ocr_cls.cpp:135-140 / ocr_rec.cpp:167-172):
+  // "fp32" = the bit-exact contract, "fp16" = f16 matrix products with f32 accumulation (Net::load); "int8" is refused
+  if (cfg.precision != "fp32" && cfg.precision != "fp16") { err = "precision '" + cfg.precision + "' is not implemented (fp32 | fp16)"; return false; }
   if (cfg.batch_num < 1 || cfg.img_h < 1 || cfg.img_w < 1) { err = "bad rec shape"; return false; }
   if (cfg.sort_mode != OCR_SORT_STD && cfg.sort_mode != OCR_SORT_STABLE) { err = "unknown sort_mode"; return false; }
   if (const char* e = getenv("OCR_REC_MAX_LINES")) {  // per handle: 48x320-line equivalents per ragged launch (A/B; results are identical)
@@ -420,7 +424,7 @@ bool RecStage::create(const RecConfig& cfg, std::string& err, int& code) {
   labels_.push_back(" ");
   WeightMap w;
   if (!load_model_dir(cfg.model_dir, nullptr, "rec", w, err)) return false;
-  if (!net_.load(embedded_plan("rec"), w, err)) return false;
+  if (!net_.load(embedded_plan("rec"), w, err, cfg.precision == "fp16")) return false;
   code = OCR_ERR_DEVICE;
   if (g_stream_create(&stream_) != hipSuccess) { err = "hipStreamCreate failed"; return false; }
   if (!timer_.init(err)) return false;
@@ -630,14 +634,16 @@ ClsStage::~ClsStage() {
 bool ClsStage::create(const ClsConfig& cfg, std::string& err, int& code) {
   cfg_ = cfg;
   code = OCR_ERR_ARG;
-  if (cfg.precision != "fp32") { err = "precision '" + cfg.precision + "' is not implemented (fp32 only)"; return false; }
+  // the reference's constructor parameter (TensorRT precision, ocr_det.cpp:50-56 / ocr_cls.cpp:135-140 / ocr_rec.cpp:167-172):
+  // "fp32" = the bit-exact contract, "fp16" = f16 matrix products with f32 accumulation (Net::load); "int8" is refused
+  if (cfg.precision != "fp32" && cfg.precision != "fp16") { err = "precision '" + cfg.precision + "' is not implemented (fp32 | fp16)"; return false; }
   if (cfg.batch_num < 1) { err = "cls_batch_num must be >= 1"; return false; }
   code = ocr_rt_init(cfg.device);
   if (code) { err = ocr_last_error(); return false; }
   code = OCR_ERR_MODEL;
   WeightMap w;
   if (!load_model_dir(cfg.model_dir, nullptr, "cls", w, err)) return false;
-  if (!net_.load(embedded_plan("cls"), w, err)) return false;
+  if (!net_.load(embedded_plan("cls"), w, err, cfg.precision == "fp16")) return false;
   code = OCR_ERR_DEVICE;
   if (g_stream_create(&stream_) != hipSuccess) { err = "hipStreamCreate failed"; return false; }
   if (!timer_.init(err)) return false;

@@ -55,7 +55,10 @@ typedef struct ocr_det_cfg {
   double det_db_unclip_ratio;
   const char* det_db_score_mode; /* "fast" | "slow" */
   int use_dilation;
-  const char* precision; /* "fp32" (the only one implemented; others are rejected) */
+  /* "fp32": the bit-exact arithmetic contract (default).  "fp16": the reference's TensorRT precision switch
+   * (ocr_det.cpp:50-56) - matrix-core products in f16 with f32 accumulation on operands rounded to f16, everything else
+   * f32: results within a stated tolerance of fp32, not identical.  "int8" is rejected. */
+  const char* precision;
   int max_batch;         /* images per ocr_det_run_batch call the handle is sized for (>=1) */
   /* Which OpenCV the reference binary was built against, where two 4.x releases differ on this path (DESIGN.md
    * section 5).  Today one rule depends on it: cv::fillPoly's scan fill behind BoxScoreFast / PolygonScoreAcc
@@ -251,6 +254,9 @@ typedef struct ocr_net ocr_net;
 /* kind: "det" | "cls" | "rec".  weights: path of a .pdiparams file (NULL: <model_dir>/inference.pdiparams,
  * falling back to <model_dir>/synthetic.pdiparams). */
 int ocr_net_create(const char* kind, const char* model_dir, const char* weights, int device_id, ocr_net** out);
+/* the same with the stages' precision parameter ("fp32" | "fp16") */
+int ocr_net_create_precision(const char* kind, const char* model_dir, const char* weights, int device_id, const char* precision,
+                             ocr_net** out);
 void ocr_net_destroy(ocr_net* h);
 /* x: host f32 [N,H,W,3] (already normalised, BGR order).  keep_all: 0 = production launch list and arena reuse;
  * 1 = every plan tensor materialised in its own slot (no fusion); 2 = the production launch list (SE gates folded,

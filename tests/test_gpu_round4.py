@@ -305,3 +305,70 @@ def test_every_buffer_too_small_path_reports_capacity_and_leaves_the_handle_usab
     assert L.ocr_jpeg_decode(C.byref(j), 0, out.ctypes.data, 100) == CAP and (out == 7).all()
     assert L.ocr_jpeg_decode(C.byref(j), 0, out.ctypes.data, 192) == 0, err()
     assert (out[:192] == out[0]).all() and out[0] == 128 + 10 and (out[192:] == 7).all()   # 40 * 2 / 8 above mid-grey
+
+
+# ------------------------------------------------------------------------------------------------ precision = "fp16"
+def test_precision_parameter_fp16_is_accepted_and_int8_refused(pkg, built):
+    """The reference's constructors take `precision` and hand it to TensorRT (ocr_det.cpp:50-56, ocr_cls.cpp:135-140,
+    ocr_rec.cpp:167-172).  "fp32" and "fp16" build; anything else is an error with the parameter's name in it."""
+    for mk in (lambda p: pkg.Det(precision=p), lambda p: pkg.Cls(precision=p), lambda p: pkg.Rec(precision=p), lambda p: pkg.Net("cls", precision=p)):
+        h = mk("fp16")
+        h.close()
+        with pytest.raises(Exception, match="precision"):
+            mk("int8")
+
+
+def test_fp16_networks_stay_within_tolerance_of_the_f32_contract(pkg, built):
+    """precision = "fp16": matrix-core products in f16 (operands rounded to nearest even) with f32 accumulation; storage,
+    VALU kernels and reductions f32.  Tolerances against the ORACLE (the f32 contract), stated here:
+      cls (the reference's real weights): softmax |d| <= 2e-3, labels identical;
+      det (synthetic weights, logits up to ~10): probability map mean |d| <= 2e-3, 99 % of the pixels within 1e-2,
+          thresholded bitmap (det_db_thresh 0.3) equal on >= 99.5 % of the pixels;
+      rec (synthetic weights: 6625 nearly equal probabilities per step): |d| <= 2 % of the largest probability, arg max
+          equal on >= 95 % of the steps."""
+    from oracle import OracleNet
+    rs = np.random.RandomState(2)
+    x = rs.randn(6, 48, 192, 3).astype(np.float32)
+    want, got = OracleNet("cls").run(x).reshape(6, 2), pkg.Net("cls", precision="fp16")
+    y = got.forward(x).reshape(6, 2)
+    got.close()
+    assert np.abs(y - want).max() <= 2e-3 and np.array_equal(y.argmax(1), want.argmax(1))
+    assert not np.array_equal(y, want)            # (it is another arithmetic: the fp32 mode is the bit-exact one)
+    x = rs.randn(2, 160, 224, 3).astype(np.float32)
+    want = OracleNet("det").run(x).reshape(-1)
+    n = pkg.Net("det", precision="fp16")
+    y = n.forward(x).reshape(-1)
+    n.close()
+    d = np.abs(y - want)
+    assert d.mean() <= 2e-3 and np.quantile(d, 0.99) <= 1e-2, (d.mean(), np.quantile(d, 0.99), d.max())
+    assert ((y > 0.3) == (want > 0.3)).mean() >= 0.995
+    x = rs.randn(4, 48, 320, 3).astype(np.float32)
+    want = OracleNet("rec").run(x).reshape(-1, 6625)
+    n = pkg.Net("rec", precision="fp16")
+    y = n.forward(x).reshape(-1, 6625)
+    n.close()
+    assert np.abs(y - want).max() <= 0.02 * want.max(), (np.abs(y - want).max(), want.max())
+    assert (y.argmax(1) == want.argmax(1)).mean() >= 0.95
+
+
+def test_fp16_pipeline_agrees_with_fp32_on_the_benchmark_batch(pkg, built):
+    """The whole path in fp16 on 8 configs[1] images (256 lines, probability-map protocol): boxes are identical (they
+    come from the protocol's maps), the CTC id sequences agree on >= 95 % of the lines, confidences within 1e-4; the
+    ragged recognizer batch, the fused depthwise blocks and the gated 1x1 convs all run their f16 instantiations."""
+    from synth_data import cfg2_sample
+    imgs, probs = zip(*[cfg2_sample(i)[:2] for i in range(8)])
+    kw = dict(enable_cls=True, limit_side_len=960, rec_batch_num=16, rec_img_h=48, rec_img_w=320)
+    words = {}
+    for prec in ("fp32", "fp16"):
+        p = pkg.Pipe(precision=prec, **kw)
+        d_i, d_p = pkg.DevArray(np.stack(imgs)), pkg.DevArray(np.stack(probs))
+        words[prec] = p.run_device(d_i, 960, 960, 8, d_p, collect=True)
+        p.close()
+    tot = same = 0
+    for wa, wb in zip(words["fp32"], words["fp16"]):
+        assert len(wa) == len(wb) == 32
+        for a, b in zip(wa, wb):
+            assert np.array_equal(a["box"], b["box"]) and abs(a["confidence"] - b["confidence"]) <= 1e-4
+            tot += 1
+            same += bool(np.array_equal(a["ids"], b["ids"]))
+    assert same / tot >= 0.95, same / tot

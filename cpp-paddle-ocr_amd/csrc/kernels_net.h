@@ -125,7 +125,7 @@ struct DwArgs {
   int rwork_total = 0;         // rwork[N] (host copy: the launcher sizes the grid with it)
 };
 void launch_dw(const DwArgs& a, const Epilogue& ep, hipStream_t s);
-int dw_patch_to(int OW, int SW);  // output pixels per thread along x the launcher will pick
+int dw_patch_to(int OW, int SW, int OH, int K);  // output pixels per thread along x the launcher will pick
 // the pool's second pass alone (column-sequential sums of the row sums, / count): after a depthwise conv with `rowsum`
 void launch_gap_cols(const float* part, float* out, int N, int H, int W, int Cs, hipStream_t s, RagLevel rag = RagLevel());
 
@@ -159,7 +159,7 @@ bool lab_from_epilogue(const Epilogue& ep, LabEp& out);
 bool launch_dwpw(const DwPwArgs& a, hipStream_t s, bool query = false);
 // rows of the pixel tile (16 columns wide) of the instance that takes this shape; 0: the shape is not on the fused path
 int dwpw_tile_rows(const DwPwArgs& a);
-int dw_patch_r(int OH);  // output rows per thread the depthwise launcher will pick (ragged batch: OH = the lowest sample)
+int dw_patch_r(int OH, int K);  // output rows per thread the depthwise launcher will pick (ragged batch: OH = the lowest sample)
 
 // rag (ragged batch of N lines): the per-image stages (channel gate) find their line from the row index
 void launch_ew(const float* in, float* out, long M, int H, int W, int Cs, const Epilogue& ep, hipStream_t s, int N = 0,

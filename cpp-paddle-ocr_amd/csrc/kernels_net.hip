@@ -506,9 +506,10 @@ __global__ void __launch_bounds__(256, 2) conv_lds_kernel(const ConvArgs a, cons
 //            register sets - occupancy is LDS-bound at 2 workgroups per CU, registers are free)
 // Same ascending (tap, channel) MFMA chain per output: bit-identical to the other conv kernels.
 // =====================================================================================
-template <int C8, int NT>
+template <int C8, int NT, bool HALF = false>
 __global__ void __launch_bounds__(256, 2) conv3x3_tile_kernel(const ConvArgs a, const Epilogue ep, const int tiles_x,
                                                               const int tiles_y) {
+  using WV = typename WFrag<HALF>::T;
   constexpr int TH = 8, TW = 16, RH = TH + 2, RW = TW + 2;
   constexpr int CS = C8 * 8, STRIDE = CS + 4;  // floats per staged pixel
   constexpr int Q = CS / 4;                    // 16-byte pieces per pixel
@@ -555,21 +556,26 @@ __global__ void __launch_bounds__(256, 2) conv3x3_tile_kernel(const ConvArgs a, 
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
   const int ly = wave * 2 + (p >> 4), lx = p & 15;  // this lane's pixel inside the tile
   const float* sA = s_tile + (ly * RW + lx) * STRIDE + 4 * h;
-  const float4* __restrict__ wf = (const float4*)a.wfrag + (long)nt0 * 64 + lane;
+  const WV* __restrict__ wf = (const WV*)a.wfrag + (long)nt0 * 64 + lane;
   const long wstride = (long)a.NTtot * 64;
-  auto load_tap = [&](float4 (&bv)[C8][NT], int tap) {
-    const float4* q = wf + (long)(tap < 9 ? tap : 8) * C8 * wstride;
+  auto load_tap = [&](WV (&bv)[C8][NT], int tap) {
+    const WV* q = wf + (long)(tap < 9 ? tap : 8) * C8 * wstride;
 #pragma unroll
     for (int c = 0; c < C8; ++c)
 #pragma unroll
       for (int t = 0; t < NT; ++t) bv[c][t] = q[c * wstride + t * 64];
   };
-  auto mul_tap = [&](const float4 (&bv)[C8][NT], int tap) {
+  auto mul_tap = [&](const WV (&bv)[C8][NT], int tap) {
     const int ky = tap / 3, kx = tap - ky * 3;
     const float* src = sA + (ky * RW + kx) * STRIDE;
 #pragma unroll
     for (int c = 0; c < C8; ++c) {
       const float4 av = *(const float4*)(src + c * 8);
+      if constexpr (HALF) {
+        const ocr_h4 ah = ocr_to_h4(av);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x8f16(ocr_as_h4(bv[c][t]), ah, acc[t], 0, 0, 0);
+      } else
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[c][t].x, av.x, acc[t], 0, 0, 0);
@@ -579,7 +585,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_tile_kernel(const ConvArgs a, 
       }
     }
   };
-  float4 bA[C8][NT], bB[C8][NT];
+  WV bA[C8][NT], bB[C8][NT];
   load_tap(bA, 0);
 #pragma unroll 1
   for (int tap = 0; tap < 9; tap += 2) {
@@ -787,6 +793,12 @@ bool launch_conv3x3_tile(const ConvArgs& a, const Epilogue& ep, int nt, hipStrea
   const unsigned lds = 10 * 18 * (96 + 4) * sizeof(float);  // 72 000 B: two workgroups per CU
   // more than 64 KB of dynamic LDS has to be allowed per device (a worker pool drives several from one process)
   static LdsAttrMemo attr_state;
+  if (a.half) {
+    static LdsAttrMemo attr_state_h;
+    if (!raise_dynamic_lds((const void*)conv3x3_tile_kernel<12, 1, true>, (int)lds, attr_state_h)) return false;
+    hipLaunchKernelGGL((conv3x3_tile_kernel<12, 1, true>), grid, dim3(256), lds, s, a, ep, tiles_x, tiles_y);
+    return true;
+  }
   if (!raise_dynamic_lds((const void*)conv3x3_tile_kernel<12, 1>, (int)lds, attr_state)) return false;  // the general kernel takes the launch
   hipLaunchKernelGGL((conv3x3_tile_kernel<12, 1>), grid, dim3(256), lds, s, a, ep, tiles_x, tiles_y);
   return true;
@@ -1111,21 +1123,26 @@ static void launch_dw_patch(const DwArgs& a, const Epilogue& ep, hipStream_t s) 
   else hipLaunchKernelGGL((dw_conv_kernel<5, 2, TO, R, false, RAG>), grid, dim3(256), lds, s, a, ep);
 }
 // output pixels per thread along x (ragged batch: OW = the narrowest line; the host builds DwArgs::rwork for this value)
-int dw_patch_to(int OW, int SW) {
+int dw_patch_to(int OW, int SW, int OH, int K) {
   // OCR_DW_PATCH=TOxR overrides (A/B measurements; results are identical)
   const bool env = rt_options().dw_patch_to > 0;
   int to = env ? rt_options().dw_patch_to : 8;
   if (OW < 8 || (SW == 2 && !env)) to = 4;  // stride 2 needs 2*TO+K-2 pixels per row buffer: 8 wide does not fit the registers
   return to == 8 ? 8 : 4;
 }
-int dw_patch_r(int OH) {
+// Output rows per thread.  Measured and NOT kept (round 4): full-height patches (R = 3 / 6) for the 5x5 layers on the
+// recognizer's 3- and 6-row maps - every input row read once instead of 2.2x - are slower (rec op 26 with its row sums:
+// 1.09 -> 1.88 ms, a third as many threads each walking 20 strips; ops 21 / 31 / 33 unchanged within 3 %): these
+// kernels are bound by loads in flight per wave, not by the bytes the halo rows add.
+int dw_patch_r(int OH, int K) {
+  (void)K;
   int r = rt_options().dw_patch_r > 0 ? rt_options().dw_patch_r : 2;
   if (OH < 2) r = 1;
   return r == 2 ? 2 : 1;
 }
 void launch_dw(const DwArgs& a, const Epilogue& ep, hipStream_t s) {
-  const int r = dw_patch_r(a.OH);
-  const int to = dw_patch_to(a.OW, a.SW);
+  const int r = dw_patch_r(a.OH, a.K);
+  const int to = dw_patch_to(a.OW, a.SW, a.OH, a.K);
   if (a.rout.w) {  // ragged batch (the recognizer)
     if (to == 8 && r == 2) launch_dw_patch<8, 2, true>(a, ep, s);
     else if (to == 8) launch_dw_patch<8, 1, true>(a, ep, s);

@@ -1088,7 +1088,9 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths, const i
             const bool mt2 = rt_options().conv_mt2 && (nt == 3 || nt == 4) && taps == 1 && a.out_mode == OUT_C8I &&
                              (rt_options().conv_mt2_force || (ntl == nt && in.cs >= 192 && ((a.M + 255) / 256) * (long)(a.NTtot / nt) >= 1024));
             if (mt2) ntl = nt;  // (the two-tile kernel is instantiated for the table's NT)
-            L.fn = [this, a, ep, ntl, mt2](hipStream_t s) {
+            const bool half_tile = half_ && taps == 9 && !rag;  // precision "fp16": the LDS-resident 3x3 tile kernel has an f16 form
+            L.fn = [this, a, ep, ntl, nt, mt2, half_tile](hipStream_t s) {
+              if (half_tile && launch_conv3x3_tile(a, ep, nt, s)) return;
               if (mt2 && launch_conv_mfma_mt2(a, ep, ntl, s)) return;
               if (!launch_conv_mfma(a, ep, ntl, s)) this->launch_error_ = "launch_conv_mfma: this conv shape / output mode is not instantiated";
             };
@@ -1109,7 +1111,7 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths, const i
           a.rin = rlevel(in); a.rout = rlevel(o);
           a.OW = min_w(o);            // the launcher picks its patch from the narrowest / lowest sample
           if (img) a.OH = min_h(o);
-          const int to = dw_patch_to(a.OW, a.SW), pr = dw_patch_r(img ? a.OH : o.h);
+          const int to = dw_patch_to(a.OW, a.SW, img ? a.OH : o.h, a.K), pr = dw_patch_r(img ? a.OH : o.h, a.K);
           const bool rs = dw_rowsum[oi] != 0;
           const TensorDesc ot = o;
           a.rwork = work_table("dw:" + std::to_string(o.lvl) + ":" + std::to_string(o.h) + ":" + std::to_string(to) + ":" + std::to_string(pr) + (rs ? ":rs" : ""),

@@ -13,6 +13,7 @@
 // Header-only; link with -locr_hip.
 #pragma once
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdint>
 #include <cstdlib>
@@ -294,15 +295,21 @@ class OCRWorker {
   // as one ocr_pipe_run - the GPU is fed whole batches under concurrent load, a lone request is still
   // served immediately (nothing ever waits for a batch to fill).  Per-image results do not depend on what
   // else is in the batch (tests/test_gpu_parity.py, tests/test_ipc_service.py).  0 = OCR_WORKER_MAX_BATCH
-  // from the environment, else 32; 1 = the reference's one-request-at-a-time loop.
+  // from the environment, else 16; 1 = the reference's one-request-at-a-time loop.  (16, not 32, since round 4: under
+  // 8 .. 96 closed-loop clients the saturated rate is the same, 470-476 requests/s, and the tail is shorter - p99 at 64
+  // clients 186 ms against 241 - because a request that just missed a batch waits for a shorter one; profiles/r4_service_sweep.jsonl)
   OCRWorker(int worker_id, const std::string& model_dir, bool use_gpu, int gpu_id = 0, bool enable_cls = false,
             bool rotate_crops = false, int max_batch = 0)
       : worker_id_(worker_id), running_(false), is_idle_(true) {
     if (max_batch <= 0) {
       const char* e = getenv("OCR_WORKER_MAX_BATCH");
-      max_batch = e ? atoi(e) : 32;
+      max_batch = e ? atoi(e) : 16;
     }
     max_batch_ = max_batch < 1 ? 1 : (max_batch > 256 ? 256 : max_batch);  // result buffers: 1 MB of ids per image
+    // batching window (extension, off by default): after the first queued request the worker may wait up to this many
+    // microseconds for its batch to fill - trades the latency of a lone request for fuller batches under load
+    // (OCR_WORKER_LINGER_US; tools/service_load.py sweep measures both sides)
+    if (const char* e = getenv("OCR_WORKER_LINGER_US")) linger_us_ = std::max(0, std::min(50000, atoi(e)));
     gpu_id_ = gpu_id;
     if (!use_gpu) throw std::runtime_error("OCRWorker: this build has no CPU path (use_gpu must be true)");
     det_dir_ = model_dir + "/det"; cls_dir_ = model_dir + "/cls"; rec_dir_ = model_dir + "/rec";
@@ -465,9 +472,18 @@ class OCRWorker {
         std::unique_lock<std::mutex> lock(queue_mutex_);
         cv_.wait(lock, [this] { return !request_queue_.empty() || !running_; });
         if (!running_) break;
-        while (!request_queue_.empty() && (int)batch.size() < max_batch_) {
-          batch.push_back(request_queue_.front());
-          request_queue_.pop();
+        auto take = [&] {
+          while (!request_queue_.empty() && (int)batch.size() < max_batch_) {
+            batch.push_back(request_queue_.front());
+            request_queue_.pop();
+          }
+        };
+        take();
+        if (linger_us_ > 0 && !batch.empty() && (int)batch.size() < max_batch_) {
+          const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(linger_us_);
+          while (running_ && (int)batch.size() < max_batch_ &&
+                 cv_.wait_until(lock, deadline, [this] { return !request_queue_.empty() || !running_; }))
+            take();
         }
         if (!batch.empty()) is_idle_ = false;
       }
@@ -493,6 +509,7 @@ class OCRWorker {
   int worker_id_;
   int gpu_id_ = 0;
   int max_batch_ = 1;
+  int linger_us_ = 0;
   std::vector<ocr_word> batch_words_;
   std::vector<int32_t> batch_ids_;
   std::atomic<bool> running_, is_idle_;

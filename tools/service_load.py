@@ -36,6 +36,9 @@ def connect(path):
     raise RuntimeError("service did not come up")
 
 
+RESULTS = []
+
+
 def run(max_batch, clients, per_client, img_path, fmt, workers=1, extra_env=None, tag=None):
     sock = f"/tmp/ocr_load_{os.getpid()}_{max_batch}_{abs(hash(str(extra_env))) % 9999}.sock"
     env = dict(os.environ, OCR_WORKER_MAX_BATCH=str(max_batch))
@@ -73,6 +76,8 @@ def run(max_batch, clients, per_client, img_path, fmt, workers=1, extra_env=None
                "service_host_cores_busy": round(((c1.user + c1.system) - (c0.user + c0.system)) / dt, 2)}
         if tag:
             rec["mode"] = tag
+        rec["host_cores_per_1000_requests_per_s"] = round(rec["service_host_cores_busy"] / max(1e-9, rec["requests_per_s"]) * 1000, 2)
+        RESULTS.append(rec)
         print(json.dumps(rec), flush=True)
         call(s0, {"command": "shutdown"})
         proc.wait(timeout=30)
@@ -124,7 +129,46 @@ def jpeg_mode(clients, per):
     pipe.close()
 
 
+def sweep_mode(per):
+    """Latency against offered load: the device-JPEG service of jpeg_mode with 8 .. 96 closed-loop
+    clients, for the default batching (whatever is queued, up to 32) and for variants of the two knobs - OCR_WORKER_MAX_BATCH
+    and the batching window OCR_WORKER_LINGER_US.  The summary line names, per variant, the highest rate whose p99 stayed
+    within 100 ms, beside the saturated rate, and the service's busy host cores per 1000 requests/s."""
+    from PIL import Image
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from synth_data import cfg2_sample
+    img = cfg2_sample(0, 960, 960, 32)[0]
+    path = f"/tmp/ocr_load_{os.getpid()}.jpg"
+    Image.fromarray(img[:, :, ::-1]).save(path, quality=90, subsampling=2)
+    fmt = "jpeg 960x960 q90 4:2:0 (%d KB)" % (os.path.getsize(path) // 1024)
+    op = {"OCR_WORKER_DET_LIMIT": "960", "OCR_WORKER_REC_H": "48", "OCR_WORKER_REC_W": "320", "OCR_WORKER_CLS": "1", "OCR_DEVICE_JPEG": "1"}
+    variants = [("default: batch<=32, no window", 32, {}), ("batch<=16", 16, {}), ("batch<=64", 64, {}),
+                ("batch<=32, window 2 ms", 32, {"OCR_WORKER_LINGER_US": "2000"}), ("batch<=32, window 5 ms", 32, {"OCR_WORKER_LINGER_US": "5000"})]
+    summary = []
+    for name, mb, env in variants:
+        rows = []
+        for clients in (8, 16, 24, 32, 48, 64, 96):
+            run(mb, clients, max(6, per * 64 // clients), path, fmt, workers=2, extra_env=dict(op, **env), tag=name)   # ~64 * per requests per run
+            rows.append(RESULTS[-1])
+        ok = [r for r in rows if r["p99_ms"] <= 100.0]
+        best = max(ok, key=lambda r: r["requests_per_s"]) if ok else None
+        sat = max(rows, key=lambda r: r["requests_per_s"])
+        summary.append({"variant": name,
+                        "requests_per_s_at_p99_le_100ms": best["requests_per_s"] if best else None,
+                        "clients_there": best["clients"] if best else None, "p50_ms_there": best["p50_ms"] if best else None,
+                        "p99_ms_there": best["p99_ms"] if best else None,
+                        "saturated_requests_per_s": sat["requests_per_s"], "saturated_p99_ms": sat["p99_ms"], "saturated_clients": sat["clients"],
+                        "host_cores_per_1000_requests_per_s": sat["host_cores_per_1000_requests_per_s"]})
+    print(json.dumps({"mode": "sweep_summary", "image": fmt, "gpu_workers": 2, "variants": summary}), flush=True)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "sweep":
+        subprocess.check_call(["make", "-s", "-C", HOST])
+        import synth_weights
+        synth_weights.ensure(ROOT)
+        sweep_mode(int(sys.argv[2]) if len(sys.argv) > 2 else 12)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "jpeg":
         subprocess.check_call(["make", "-s", "-C", HOST])
         import synth_weights

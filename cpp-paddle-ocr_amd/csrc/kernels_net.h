@@ -241,6 +241,24 @@ struct DbHeadArgs {
 };
 bool launch_db_head(const DbHeadArgs& a, int C, hipStream_t s);  // false: C is not on this path (24 only)
 
+// One MobileNetV3 bottleneck with squeeze-excite as one kernel, a workgroup per sample (kernels_mb.hip): conv 1x1 + BN + act
+// -> depthwise KxK, stride (SH, 1) + BN + act -> pool -> SE -> x * gate -> conv 1x1 + BN [+ residual].
+struct MbArgs {
+  const float* in;   // [N][Hi][W][Cs_in] C8I
+  float* out;        // [N][Ho][W][Cs_out] C8I
+  const float* res;  // residual tensor of the output's shape, or null
+  int N, Hi, Ho, W, Cin, Cs_in, Cexp, Cs_exp, Cout, Cs_out, K, SH, R;
+  int CC;            // expanded channels per chunk (0: the launcher picks, mbconv_chunk)
+  int act1, act2;    // ACT_RELU | ACT_HSWISH | -1 (none) after the BN of the expand / depthwise conv
+  const float *w1, *s1, *t1;  // w1 [Cin][roundup8(Cexp)] logical channels (k-major); BN scale / shift [Cs_exp] physical order
+  const float *wd, *s2, *t2;  // wd [K*K][Cs_exp] physical order
+  const float *se_w1, *se_b1, *se_w2, *se_b2;  // logical: w1 [R][Cexp], w2 [Cexp][R]
+  float slope, offset;
+  const float *w2, *s3, *t3;  // w2 [Cexp][roundup4(Cout)] logical; BN [Cs_out] physical order
+};
+int mbconv_chunk(const MbArgs& a);  // chunk width the launcher would use; 0: the block's shape is not on this path
+bool launch_mbconv(const MbArgs& a, hipStream_t s);
+
 void launch_c8i_to_plain(const float* in, float* out, long M, int C, int Cs, hipStream_t s);
 void launch_probe(const float* a, const float* b, float* out, int n, hipStream_t s);
 

@@ -270,6 +270,13 @@ bool Net::load(const char* plan_text, const WeightMap& W, std::string& err, bool
           });
           if (!upload("frag:" + op.w, f)) { err = "hipMalloc failed"; return false; }
           if (half_ && !upload("frag16:" + op.w, frag_to_half(f))) { err = "hipMalloc failed"; return false; }
+          if (kh == 1 && kw == 1 && !pl && ci <= 512 && co <= 512) {  // the fused bottleneck kernel's image (kernels_mb.hip): [k][c] logical, rows padded to 8
+            const int cop = (co + 7) & ~7;
+            std::vector<float> t((size_t)ci * cop, 0.f);
+            for (int k = 0; k < ci; ++k)
+              for (int c = 0; c < co; ++c) t[(size_t)k * cop + c] = w[(size_t)c * ci + k];
+            if (!upload("t1x1:" + op.w, t)) { err = "hipMalloc failed"; return false; }
+          }
           if (kh == 3 && kw == 3 && ci == 96 && co == 24 && !pl && !upload("c24:" + op.w, conv3x3_c24_image(w, co, ci))) { err = "hipMalloc failed"; return false; }
           if (kh == 1 && kw == 1 && ci <= 24 && !pl && op.ep.empty()) {  // conv_rowsum_kernel's image (RSE blocks): [k logical, padded][physical column]
             const int cs_in = c8i_stride(ci);
@@ -735,6 +742,43 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths, const i
   }
   std::vector<char> fused_dw(nops, 0);
   for (int oj = 0; oj < nops; ++oj) if (dwpw_of[oj] >= 0) fused_dw[dwpw_of[oj]] = 1;
+  // ---- MobileNetV3 bottleneck with squeeze-excite (the classifier): conv 1x1 + BN + act -> depthwise + BN + act -> gap ->
+  // sefc -> ew (x * gate) -> conv 1x1 + BN [+ residual] as ONE launch, a workgroup per text line (kernels_mb.hip); the four
+  // tensors between the block's input and output never exist.  Uniform batches, f32 contract only (precision "fp16" keeps
+  // the matrix-core launches).  Opt-in (OCR_FUSE_MB=1): bit-identical, but its first form is slower than the launches it replaces.
+  std::vector<int> mb_of(nops, -1);  // project conv op -> the block's expand conv
+  std::vector<MbArgs> mb_args(nops);
+  if (keep_all_ != 1 && rt_options().fuse_mb && !rag && !half_) {
+    auto one = [&](const PlanOp& c) { return c.kind == PlanOp::CONV && c.kh == 1 && c.kw == 1 && c.sh == 1 && c.sw == 1 && c.ph == 0 && c.pw == 0 && c.cin != 3; };
+    auto bn_act = [](const std::vector<PlanStage>& ep, int& act) {
+      if (ep.size() == 1 && ep[0].kind == EP_BN) { act = -1; return true; }
+      if (ep.size() == 2 && ep[0].kind == EP_BN && ep[1].kind == EP_ACT && (ep[1].act == ACT_RELU || ep[1].act == ACT_HSWISH)) { act = ep[1].act; return true; }
+      return false;
+    };
+    for (int oi = 0; oi + 5 < nops; ++oi) {
+      const PlanOp &e = plan_.ops[oi], &d = plan_.ops[oi + 1], &g = plan_.ops[oi + 2], &f = plan_.ops[oi + 3], &m = plan_.ops[oi + 4], &p = plan_.ops[oi + 5];
+      if (!one(e) || !one(p) || d.kind != PlanOp::DW || d.in != e.out || g.kind != PlanOp::GAP || g.in != d.out || f.kind != PlanOp::SEFC ||
+          f.in != g.out || m.kind != PlanOp::EW || m.in != d.out || m.ep.size() != 1 || m.ep[0].kind != EP_MULC || m.ep[0].tid != f.out || p.in != m.out) continue;
+      if (uses[e.out] != 1 || uses[d.out] != 2 || uses[g.out] != 1 || uses[f.out] != 1 || uses[m.out] != 1 || fused_dw[oi + 1] || dwpw_of[oi] >= 0 || gate_src[oi] >= 0) continue;
+      bool dead_is_output = false;
+      for (int k = 0; k < 5; ++k) dead_is_output = dead_is_output || plan_.ops[oi + k].out == out_tid_;
+      if (dead_is_output) continue;
+      MbArgs q{};
+      if (!bn_act(e.ep, q.act1) || !bn_act(d.ep, q.act2)) continue;
+      const bool pep = (p.ep.size() == 1 && p.ep[0].kind == EP_BN) || (p.ep.size() == 2 && p.ep[0].kind == EP_BN && p.ep[1].kind == EP_ADDT);
+      if (!pep || T[e.in].plain || T[p.out].plain || d.kh != d.kw || d.sw != 1 || d.pw != d.kw / 2 || d.ph != d.kh / 2) continue;
+      q.Hi = T[e.in].h; q.W = T[e.in].w; q.Ho = T[d.out].h; q.Cin = e.cin; q.Cs_in = T[e.in].cs; q.Cexp = e.cout; q.Cs_exp = T[d.out].cs;
+      q.Cout = p.cout; q.Cs_out = T[p.out].cs; q.K = d.kh; q.SH = d.sh; q.R = f.cr;
+      if (T[d.out].w != q.W || T[p.out].h != q.Ho || e.cin % 4) continue;
+      q.CC = mbconv_chunk(q);
+      if (q.CC <= 0 || !dev_vec("t1x1:" + e.w) || !dev_vec("t1x1:" + p.w)) continue;
+      mb_of[oi + 5] = oi;
+      mb_args[oi + 5] = q;
+      for (int k = 0; k < 5; ++k) fused_dw[oi + k] = 1;  // (no launch, no tensor)
+      folded[oi + 4] = 1;
+      gate_src[oi + 5] = gate_tid[oi + 5] = -1;  // the gate is applied inside the block
+    }
+  }
   // ---- depthwise conv -> global average pool (the SE blocks): the conv leaves the pool's row sums (its first pass, a
   // second full read of the tensor otherwise) while it writes the tensor; only the column pass stays a launch.  Needs
   // enough bands (a thread owns whole rows then) to fill the chip.  OCR_FUSE_GAP=0 disables (A/B, results identical).
@@ -803,7 +847,8 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths, const i
       continue;
     }
     if (oi > 0 && rse_first[oi - 1]) continue;  // the pool after a row-sum pass reads gap_part_, not the conv's tensor
-    if (gate_src[oi] >= 0) { last[gate_src[oi]] = oi; last[gate_tid[oi]] = oi; }
+    if (mb_of[oi] >= 0) last[plan_.ops[mb_of[oi]].in] = oi;
+    else if (gate_src[oi] >= 0) { last[gate_src[oi]] = oi; last[gate_tid[oi]] = oi; }
     else if (dwpw_of[oi] >= 0) last[plan_.ops[dwpw_of[oi]].in] = oi;
     else if (dbhead_of[oi] >= 0) last[plan_.ops[dbhead_of[oi]].in] = oi;
     else if (op.in >= 0) last[op.in] = oi;
@@ -891,6 +936,33 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths, const i
     const TensorDesc& o = T[op.out];
     float* optr = arena_ + o.offset;
     Launch L;
+    if (mb_of[oi] >= 0) {  // a whole SE bottleneck: the launch of its project conv
+      const int o0 = mb_of[oi];
+      const PlanOp &e = plan_.ops[o0], &d = plan_.ops[o0 + 1], &f = plan_.ops[o0 + 3], &p = plan_.ops[oi];
+      Epilogue e1, e2, e3;
+      if (!build_epilogue(e, e1, true, err) || !build_epilogue(d, e2, false, err) || !build_epilogue(p, e3, true, err)) return false;
+      MbArgs a = mb_args[oi];
+      a.in = arena_ + T[e.in].offset; a.out = optr; a.res = e3.n == 2 ? e3.st[1].v0 : nullptr;
+      a.N = T[e.in].n;
+      a.w1 = dev_vec("t1x1:" + e.w); a.s1 = e1.st[0].v0; a.t1 = e1.st[0].v1;
+      a.wd = dev_vec("dw:" + d.w); a.s2 = e2.st[0].v0; a.t2 = e2.st[0].v1;
+      a.se_w1 = dev_vec("raw:" + f.w1); a.se_b1 = dev_vec("raw:" + f.b1); a.se_w2 = dev_vec("raw:" + f.w2); a.se_b2 = dev_vec("raw:" + f.b2);
+      a.slope = f.slope; a.offset = f.offset;
+      a.w2 = dev_vec("t1x1:" + p.w); a.s3 = e3.st[0].v0; a.t3 = e3.st[0].v1;
+      if (!a.w1 || !a.wd || !a.se_w1 || !a.se_b1 || !a.se_w2 || !a.se_b2 || !a.w2) { err = "fused bottleneck: a weight image is missing"; return false; }
+      snprintf(nm, sizeof nm, "%s.%02d.mbconv%dx%d_%d_%d_%d_s%d1", plan_.name.c_str(), o0, d.kh, d.kw, e.cin, e.cout, p.cout, d.sh);
+      L.name = nm;
+      const double pin = (double)a.N * a.Hi * a.W, pout = (double)a.N * a.Ho * a.W;
+      L.flops = 2.0 * (pin * e.cin * e.cout + pout * d.kh * d.kw * d.c + pout * p.cin * p.cout);
+      L.bytes = 4.0 * (pin * e.cin + pout * p.cout * (a.res ? 2.0 : 1.0));
+      L.fn = [this, a](hipStream_t s) {
+        if (!launch_mbconv(a, s)) this->launch_error_ = "launch_mbconv: shape accepted at bind time was refused at launch";
+      };
+      snprintf(nm, sizeof nm, "@%dx%dx%d", N, H, W);
+      L.name += nm;
+      launches_.push_back(std::move(L));
+      continue;
+    }
     if (rse_first[oi]) {  // first pass: the pool's row sums, nothing else
       const TensorDesc& in = T[op.in];
       ConvRowsumArgs a{};

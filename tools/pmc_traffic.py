@@ -72,6 +72,16 @@ def main():
         "avg_duration_us_under_pmc": sum(r[4] for r in fe) / len(fe) / 1e3,
         "corrections": "FETCH_SIZE*1024*2, WRITE_SIZE*1024 (MI355X_MICROARCH.md HBM section); separate --pmc passes",
     }
+    issue = {}
+    for cname in ("SQ_INSTS_VALU", "SQ_INSTS_MFMA", "SQ_INSTS_LDS", "SQ_INSTS_SALU", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES"):
+        rs = sel(pmc_rows(os.path.join(root, "pmc_issue"), cname))
+        if rs:
+            issue[cname] = sum(r[3] for r in rs) / len(rs)
+    if issue:
+        out["issue_counters_per_launch"] = issue
+        if issue.get("SQ_INSTS_MFMA"):
+            out["valu_instructions_per_mfma"] = issue.get("SQ_INSTS_VALU", 0.0) / issue["SQ_INSTS_MFMA"]
+            out["lds_instructions_per_mfma"] = issue.get("SQ_INSTS_LDS", 0.0) / issue["SQ_INSTS_MFMA"]
     if bench:
         alg = bench["algorithmic_bytes_per_launch"]
         out["algorithmic_bytes_per_launch"] = alg

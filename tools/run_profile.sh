@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 # one chain per pipeline: the per-kernel durations and counters are then properties of the kernel (bench.py's roofline
 # leg runs in the same mode)
 export OCR_PIPE_PHASES=1
-B="python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-latency --no-two-workers --no-host-input"
+B="python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-latency --no-two-workers --no-host-input --no-fp16"
 O=$R/gpurun_out/prof_$TAG
 rm -rf $O; mkdir -p $O
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- $B > $O.trace.log 2>&1

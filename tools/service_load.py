@@ -100,7 +100,7 @@ def jpeg_mode(clients, per):
     fmt = "jpeg 960x960 q90 4:2:0 (%d KB)" % (os.path.getsize(path) // 1024)
     op = {"OCR_WORKER_DET_LIMIT": "960", "OCR_WORKER_REC_H": "48", "OCR_WORKER_REC_W": "320", "OCR_WORKER_CLS": "1"}   # configs[1]'s operating point
     for dev in ("1", "0"):
-        run(32, clients, per, path, fmt, workers=2, extra_env=dict(op, OCR_DEVICE_JPEG=dev),
+        run(16, clients, per, path, fmt, workers=2, extra_env=dict(op, OCR_DEVICE_JPEG=dev),
             tag="device_jpeg" if dev == "1" else "host_jpeg")
     # the yardstick: the pipeline itself (one handle, two chains) on the SAME decoded image, 64 per batch from host memory
     # through the double-buffered staging - what bench.py calls host_input, but with this image's own detector output

@@ -372,3 +372,32 @@ def test_fp16_pipeline_agrees_with_fp32_on_the_benchmark_batch(pkg, built):
             tot += 1
             same += bool(np.array_equal(a["ids"], b["ids"]))
     assert same / tot >= 0.95, same / tot
+
+
+def test_fp16_on_mixed_sizes_and_the_worker_shape(pkg, built, card):
+    """The fp16 instantiations on the other launch lists: a ragged batch of IMAGES (the detector on mixed sizes: every
+    dense conv through the direct kernel, the fused depthwise blocks in their ragged form) - probability maps within the
+    det tolerance of the fp32 maps, image by image - and the worker's default shape (limit 512, rec 28 x 192) on the
+    reference's card image: same number of boxes within one, the pipeline runs to words."""
+    from synth_data import cfg3_sample
+    rs = np.random.RandomState(9)
+    imgs = [rs.randn(h, w, 3).astype(np.float32) for h, w in ((96, 160), (64, 64), (160, 96), (128, 224))]
+    a, b = pkg.Net("det"), pkg.Net("det", precision="fp16")
+    ya, yb = a.forward_ragged_images(imgs).reshape(-1), b.forward_ragged_images(imgs).reshape(-1)
+    a.close()
+    b.close()
+    d = np.abs(ya - yb)
+    assert d.mean() <= 2e-3 and np.quantile(d, 0.99) <= 1e-2 and ((ya > 0.3) == (yb > 0.3)).mean() >= 0.995
+    lines = [rs.randn(48, w, 3).astype(np.float32) for w in (320, 333, 136, 320)]
+    a, b = pkg.Net("rec"), pkg.Net("rec", precision="fp16")
+    ya, yb = a.forward_ragged(lines).reshape(-1, 6625), b.forward_ragged(lines).reshape(-1, 6625)
+    a.close()
+    b.close()
+    assert np.abs(ya - yb).max() <= 0.02 * ya.max() and (ya.argmax(1) == yb.argmax(1)).mean() >= 0.95
+    p32, p16 = pkg.Pipe(), pkg.Pipe(precision="fp16")
+    w32, w16 = p32.run([card])[0], p16.run([card])[0]
+    mixed = [cfg3_sample(i)[0] for i in range(3)]
+    m16 = p16.run(mixed)
+    p32.close()
+    p16.close()
+    assert abs(len(w32) - len(w16)) <= 1 and len(w16) > 0 and len(m16) == 3

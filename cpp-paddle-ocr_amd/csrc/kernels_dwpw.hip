@@ -264,7 +264,11 @@ __global__ void __launch_bounds__(256, LB) dwpw_kernel(const DwPwArgs a) {
   // loads under lane- or item-dependent branches the compiler falls back to vmcnt(0) in the middle of the matrix phase.
   const float* const w_piece = tid < WQ ? a.dw_w + (long)(tid / Q) * Cs + 4 * (tid % Q)
                                         : a.dw_ep.bias + (tid < WQ + Q ? 4 * (tid - WQ) : 0);
-  struct GSet { float4 r[G_PER]; float4 w; unsigned keep; };  // one item's region pieces in flight, + which are real
+  struct GSet { float4 r[G_PER]; float4 w; };  // one item's region pieces in flight
+  // (round 4) a piece outside the image is LOADED FROM A ZERO PAGE - the address is selected, not the value - so the
+  // fill below stores what arrived: no keep mask, no AND per component (21 VALU instructions per item less; every one
+  // of them cost matrix time)
+  const float* const zpage = a.c.zeros;
   auto G = [&](GSet& gs) __attribute__((always_inline)) {
     float4 (&greg)[G_PER] = gs.r;
     float4& wreg = gs.w;
@@ -274,14 +278,9 @@ __global__ void __launch_bounds__(256, LB) dwpw_kernel(const DwPwArgs a) {
 #ifdef OCR_DWPW_NO_G  // development probe (tools/micro/dwpw_probe.hip): no input traffic
       greg[i] = make_float4((float)goff[i], (float)(size_t)base, 0.f, 0.f);
 #else
-      greg[i] = *(const float4*)(base + (goff[i] >= 0 ? goff[i] : 0));
+      greg[i] = *(const float4*)(goff[i] >= 0 ? base + goff[i] : zpage);
 #endif
     wreg = *(const float4*)(w_piece + g_ch * CK);
-    // which pieces are real: remembered with the data (goff may belong to the next unit by the time S runs)
-    unsigned keep = 0;
-#pragma unroll
-    for (int i = 0; i < G_PER; ++i) keep |= goff[i] >= 0 ? 1u << i : 0u;
-    gs.keep = keep;
     if (g_units > 0 && ++g_ch == nch) {
       g_ch = 0;
       if (--g_units > 0) {
@@ -297,15 +296,9 @@ __global__ void __launch_bounds__(256, LB) dwpw_kernel(const DwPwArgs a) {
     const float4 (&greg)[G_PER] = gs.r;
     const float4& wreg = gs.w;
     float* si = s_in + buf * IN_TILE;
-    const unsigned keep = gs.keep;
 #pragma unroll
     for (int i = 0; i < G_PER; ++i)
-      if (G_PIECES % 256 == 0 || g_pos[i] >= 0) {
-        // (AND with a lane mask, not a select on the loaded value: a select's load is sunk under a branch)
-        const unsigned m = (keep >> i) & 1u ? 0xffffffffu : 0u;
-        *(float4*)(si + g_lds[i]) = make_float4(__uint_as_float(__float_as_uint(greg[i].x) & m), __uint_as_float(__float_as_uint(greg[i].y) & m),
-                                                __uint_as_float(__float_as_uint(greg[i].z) & m), __uint_as_float(__float_as_uint(greg[i].w) & m));
-      }
+      if (G_PIECES % 256 == 0 || g_pos[i] >= 0) *(float4*)(si + g_lds[i]) = greg[i];
     if (tid < WQ) *(float4*)(s_w + buf * WT + 4 * tid) = wreg;            // [tap][CK]: tap*CK + 4q = 4*tid
     else if (tid < WQ + Q) *(float4*)(s_b + buf * CK + 4 * (tid - WQ)) = wreg;
   };
@@ -633,7 +626,6 @@ __global__ void __launch_bounds__(256, LB) dwpw_kernel(const DwPwArgs a) {
 #pragma unroll
   for (int i = 0; i < G_PER; ++i) gA.r[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   gA.w = make_float4(0.f, 0.f, 0.f, 0.f);
-  gA.keep = 0;
   if constexpr (GD == 2) {
     GSet gB = gA;
     G(gA);  // item 0

@@ -24,7 +24,7 @@ static void run(int N, int H, int W, int K, int SH, int SW, int cin, int cout) {
   CK(hipMemset(x, 0, Min * cin * 4)); CK(hipMemset(w, 0, (size_t)C8 * NTtot * 64 * 16)); CK(hipMemset(dw, 0, (size_t)K * K * cin * 4)); CK(hipMemset(vec, 0, 8192 * 4));
   DwPwArgs a{};
   a.c.out = y; a.c.wfrag = w; a.c.M = M; a.c.N = N; a.c.H = OH; a.c.W = OW; a.c.Cs_in = cin; a.c.C8 = C8; a.c.OH = OH; a.c.OW = OW;
-  a.c.Cs_out = cout; a.c.Cout = cout; a.c.CoutPadded = cout; a.c.ColsStore = cout; a.c.NTtot = NTtot; a.c.KH = a.c.KW = 1; a.c.out_mode = OUT_C8I;
+  a.c.zeros = vec; a.c.Cs_out = cout; a.c.Cout = cout; a.c.CoutPadded = cout; a.c.ColsStore = cout; a.c.NTtot = NTtot; a.c.KH = a.c.KW = 1; a.c.out_mode = OUT_C8I;
   a.dw_in = x; a.dw_w = dw; a.H = H; a.W = W; a.K = K; a.SH = SH; a.SW = SW; a.PH = a.PW = P;
   a.dw_ep = LabEp{vec, 1.01f, 0.5f, 0.99f, 0.01f, 1};  // bias | smul | sadd | hswish | smul | sadd, as in the plans
   a.pw_ep = a.dw_ep;

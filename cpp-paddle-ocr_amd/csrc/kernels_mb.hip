@@ -18,7 +18,10 @@
 // chunks under a 78 KB working set: 50 chunk computations per line), the SE fully-connected layers read their weights from
 // global memory inside dependent loops, and a 1024-thread form with 40-channel chunks spills (784 B of scratch per thread,
 // 5.6 ms for one 200-channel block).  What it needs to pay: chunk parameters and SE weights prefetched a chunk ahead,
-// packed FMAs, the division-free hard-swish, no dynamically indexed local arrays.
+// packed FMAs, the division-free hard-swish, no dynamically indexed local arrays.  Its ceiling is modest: the two passes cost
+// 5.6 M FMAs per line for the 200-channel blocks - ~65 k packed wave instructions, 30 us per line on a whole CU at full VALU
+// rate, 0.24 ms per launch against 0.52 ms for the six launches now - and a per-line chain of barrier-separated phases will
+// not run at full VALU rate.
 // Same arithmetic per value as the six kernels it replaces: f32, one fma chain per contraction from 0
 // in ascending k, mul-then-add BN, IEEE division in hard-swish, the pool's two sequential passes - results are bit-identical
 // (tests/test_gpu_parity.py: every materialised tensor of the production launch list against the oracle).  Only weights

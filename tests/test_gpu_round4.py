@@ -401,3 +401,40 @@ def test_fp16_on_mixed_sizes_and_the_worker_shape(pkg, built, card):
     p32.close()
     p16.close()
     assert abs(len(w32) - len(w16)) <= 1 and len(w16) > 0 and len(m16) == 3
+
+
+def test_pool_growth_inside_a_ragged_detector_chunk_and_cv_compat_through_the_pipeline(pkg, built):
+    """The mixed-size path (DetStage::post_mixed: one pass of the post kernels over a chunk of images of different sizes)
+    shares post_launch with the uniform path: an image whose borders outgrow the default key pool sits in the SAME chunk as
+    ordinary images - the pass is re-run with grown pools and every image's words still equal a run of the image alone.
+    And ocr_pipe_cfg.det.cv_compat reaches the chains' detector instances: box counts follow the selected fill rule."""
+    from pipeline import Pipeline, DetCfg
+    from synth_data import cfg3_item
+    zig = np.full((960, 960), 0.02, np.float32)     # the 613 760-vertex border of the test above, as image 1's probability map
+    xs = np.arange(960)
+    for y in range(0, 959, 3):
+        zig[y + (xs % 2), xs] = 0.9
+    zig[:, 0] = 0.9
+    items = [cfg3_item(0), (np.random.RandomState(1).randint(0, 255, (960, 960, 3)).astype(np.uint8), zig), cfg3_item(1)]
+    imgs, probs = [it[0] for it in items], [it[1] for it in items]
+    assert len({im.shape for im in imgs}) == 3
+    kw = dict(rec_batch_num=16, rec_img_h=48, rec_img_w=320, limit_side_len=960, box_thresh=0.1)
+    p = pkg.Pipe(**kw)
+    p.stage(0, imgs, probs)
+    together = p.run_staged(0)
+    alone = []
+    for im, pr in zip(imgs, probs):
+        p.stage(1, [im], [pr])
+        alone.append(p.run_staged(1)[0])
+    p.close()
+    assert len(together[1]) >= 1 and len(together[0]) > 3
+    for a, b in zip(together, alone):
+        assert len(a) == len(b) and all(np.array_equal(x["box"], y["box"]) and np.array_equal(x["ids"], y["ids"]) for x, y in zip(a, b))
+    kw.pop("box_thresh")
+    # the oracle on the first image under both OpenCV rules, against pipelines created with each
+    for compat in (45, 410):
+        pg = pkg.Pipe(cv_compat=compat, **kw)
+        po = Pipeline(det_cfg=DetCfg(limit_side_len=960, cv_compat=compat), rec_batch_num=16, rec_img_h=48, rec_img_w=320)
+        g, w = pg.run([imgs[0]])[0], po.process(imgs[0])["words"]
+        pg.close()
+        assert len(g) == len(w) and all(np.array_equal(a["box"], b["box"]) and np.array_equal(a["ids"], b["ids"]) for a, b in zip(g, w))

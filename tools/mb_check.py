@@ -1,3 +1,5 @@
+"""Development check of the fused SE bottleneck (OCR_FUSE_MB=1, kernels_mb.hip): which launches the classifier's list has,
+the output and every materialised tensor against the oracle.  usage (GPU box): OCR_FUSE_MB=1 python tools/mb_check.py"""
 import sys, numpy as np
 sys.path[:0]=['/root/repo','/root/repo/oracle','/root/repo/tools']
 from __graft_entry__ import load_package

@@ -141,3 +141,30 @@ def test_result_records_roundtrip():
     import pytest
     with pytest.raises(ValueError):
         G.pack_records(words, [0, 1, 2], cap=2)
+
+
+def test_bench_kernel_groups_follow_the_rocprof_rule():
+    """bench.py's dominant kernel = the (instantiation, shape) group with the most time: launches with the same descriptor,
+    bound shape and algorithmic work per launch are one group (four ops of one symbol on one grid), the same descriptor at
+    another resolution (other work per launch) is another; roof_of picks the roof by the ridge of the given peak."""
+    sys.path.insert(0, ROOT)
+    import bench
+    rep = {
+        "rec.13.dwpw5x5_240_240_s11@2048x48x~321": dict(ms=3.0, count=1, flops=251e9, bytes=3.79e9),
+        "rec.15.dwpw5x5_240_240_s11@2048x48x~321": dict(ms=3.1, count=1, flops=251e9, bytes=3.79e9),
+        "rec.30.conv1x1_480_480_gated@2048x48x~321": dict(ms=4.0, count=1, flops=454e9, bytes=3.79e9),
+        "det.67.conv3x3_96_24@64x960x960": dict(ms=1.7, count=1, flops=152e9, bytes=1.77e9),
+        "det.63.conv3x3_96_24@64x960x960": dict(ms=0.47, count=1, flops=38e9, bytes=0.44e9),   # same name, 120x120 level
+        "det.72.conv3x3_96_24@64x960x960": dict(ms=1.75, count=1, flops=152e9, bytes=1.77e9),
+    }
+    g = bench.kernel_groups(rep)
+    assert len(g) == 4
+    key, top = max(g.items(), key=lambda kv: kv[1]["ms"])
+    assert key[:2] == ("rec", "dwpw5x5_240_240_s11") and top["count"] == 2 and abs(top["ms"] - 6.1) < 1e-9 and sorted(top["ops"]) == ["13", "15"]
+    assert "[ops 13,15]" in bench.group_label(key, top)
+    det = {k: v for k, v in g.items() if k[0] == "det"}
+    assert sorted(v["count"] for v in det.values()) == [1, 2]
+    r = bench.roof_of(top["flops"], top["bytes"], top["ms"])
+    assert r["bound"] == "mfma" and abs(r["tflops"] - 502e9 / 6.1e-3 / 1e12) < 1e-6 and abs(r["frac_mfma"] - r["tflops"] / 157.3) < 1e-12
+    assert bench.roof_of(1e9, 1e9, 1.0)["bound"] == "hbm"                                    # 1 FLOP/B: far below the f32 ridge
+    assert bench.roof_of(top["flops"], top["bytes"], top["ms"], bench.FP16_MFMA_PEAK_TFLOPS)["bound"] == "hbm"   # 66 FLOP/B < 312

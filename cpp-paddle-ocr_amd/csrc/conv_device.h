@@ -21,6 +21,55 @@ __device__ __forceinline__ ocr_h4 ocr_as_h4(const uint2& v) { return __builtin_b
 template <bool HALF> struct WFrag { using T = float4; };
 template <> struct WFrag<true> { using T = uint2; };
 
+// ---- f16 STORAGE of the C8I activation tensors (precision "fp16", second half of the mode): the arena pointers stay
+// `float*` in every argument block; a kernel instantiated with H16 reads / writes the tensor as _Float16 with the SAME
+// element indices (pixel * Cs + physical channel).  Four consecutive channels are 8 bytes.  Arithmetic stays f32: a load
+// converts up (exact), a store rounds to nearest even.  Per-image vectors (pool results, SE gates), the network input, the
+// detector's probability map and the recognizer's logits stay f32.
+template <bool H16>
+__device__ __forceinline__ float4 ld4(const float* base, long idx) {
+  if constexpr (H16) {
+    const ocr_h4 h = __builtin_bit_cast(ocr_h4, *(const uint2*)((const _Float16*)base + idx));
+    const ocr_f4v f = __builtin_convertvector(h, ocr_f4v);
+    return make_float4(f.x, f.y, f.z, f.w);
+  } else {
+    return *(const float4*)(base + idx);
+  }
+}
+template <bool H16>
+__device__ __forceinline__ void st4(float* base, long idx, const float4& v) {
+  if constexpr (H16) *(uint2*)((_Float16*)base + idx) = __builtin_bit_cast(uint2, ocr_to_h4(v));
+  else *(float4*)(base + idx) = v;
+}
+template <bool H16>
+__device__ __forceinline__ float ld1(const float* base, long idx) {
+  if constexpr (H16) return (float)((const _Float16*)base)[idx];
+  else return base[idx];
+}
+template <bool H16>
+__device__ __forceinline__ void st1(float* base, long idx, float v) {
+  if constexpr (H16) ((_Float16*)base)[idx] = (_Float16)v;
+  else base[idx] = v;
+}
+// the same in two steps, for software-pipelined loops: the raw 4-channel piece as it travels (a conversion next to the load
+// would wait for the data where the load was meant to stay in flight), converted where it is consumed
+template <bool H16>
+__device__ __forceinline__ typename WFrag<H16>::T ld4_raw(const float* base, long idx) {
+  if constexpr (H16) return *(const uint2*)((const _Float16*)base + idx);
+  else return *(const float4*)(base + idx);
+}
+__device__ __forceinline__ float4 up4(const float4& v) { return v; }
+__device__ __forceinline__ float4 up4(const uint2& v) {
+  const ocr_f4v f = __builtin_convertvector(__builtin_bit_cast(ocr_h4, v), ocr_f4v);
+  return make_float4(f.x, f.y, f.z, f.w);
+}
+// the matrix-core operand of a lane straight from an f16 tensor (no conversion), or rounded from an f32 one
+template <bool H16>
+__device__ __forceinline__ ocr_h4 ld_h4(const float* base, long idx) {
+  if constexpr (H16) return __builtin_bit_cast(ocr_h4, *(const uint2*)((const _Float16*)base + idx));
+  else return ocr_to_h4(*(const float4*)(base + idx));
+}
+
 // Workgroups are dealt round-robin over the 8 XCDs (each with a private 4 MiB L2).  Neighbouring
 // tiles of these kernels re-read each other's input rows (3x3/5x5 taps, N-groups of one M-tile), so
 // give each XCD a CONTIGUOUS range of logical tiles: re-reads then hit that XCD's L2 instead of
@@ -114,6 +163,7 @@ __device__ __forceinline__ float apply_epilogue(const Epilogue& ep, float v, int
 
 // 4 consecutive physical channels
 // up_base >= 0 (ragged batch of images): first pixel and width of sample n in the upsampled operand's (coarser) tensor
+template <bool H16 = false>
 __device__ __forceinline__ float4 apply_epilogue4(const Epilogue& ep, float4 v, int pc, int n, int y, int x, long oidx,
                                                   int cs, long up_base = -1, int up_w = 0) {
   for (int s = 0; s < ep.n; ++s) {
@@ -144,11 +194,11 @@ __device__ __forceinline__ float4 apply_epilogue4(const Epilogue& ep, float4 v, 
         t = v.z * g.z; v.z = t + v.z;
         t = v.w * g.w; v.w = t + v.w;
       } break;
-      case EP_ADDT: { float4 g = *(const float4*)(st.v0 + oidx); v.x = v.x + g.x; v.y = v.y + g.y; v.z = v.z + g.z; v.w = v.w + g.w; } break;
+      case EP_ADDT: { float4 g = ld4<H16>(st.v0, oidx); v.x = v.x + g.x; v.y = v.y + g.y; v.z = v.z + g.z; v.w = v.w + g.w; } break;
       case EP_ADDUP: {
         int sy = y / st.a0, sx = x / st.a0;
         const long spix = up_base >= 0 ? up_base + (long)sy * up_w + sx : ((long)n * st.a2 + sy) * st.a1 + sx;
-        float4 g = *(const float4*)(st.v0 + spix * cs + pc);
+        float4 g = ld4<H16>(st.v0, spix * cs + pc);
         v.x = v.x + g.x; v.y = v.y + g.y; v.z = v.z + g.z; v.w = v.w + g.w;
       } break;
     }
@@ -179,7 +229,7 @@ __device__ __forceinline__ void conv_finish_nyx(const ConvArgs& a, long m, int& 
   }
 }
 
-template <int NT, int MODE>
+template <int NT, int MODE, bool H16 = false>
 __device__ __forceinline__ void conv_finish(const ConvArgs& a, const Epilogue& ep, floatx16 (&acc)[NT], int nt0, long m, int hb,
                                             const float* spar, const int sstride = NT * 32) {
   if (m >= a.M) return;
@@ -289,8 +339,7 @@ __device__ __forceinline__ void conv_finish(const ConvArgs& a, const Epilogue& e
         })
       } break;
       case EP_ADDT: {  // tensor of the output's shape
-        const float* res = st.v0 + opix;
-        OCR_EP_SWEEP({ const float4 r = *(const float4*)(res + ooff(rel)); wx = wx + r.x; wy = wy + r.y; wz = wz + r.z; ww = ww + r.w; })
+        OCR_EP_SWEEP({ const float4 r = ld4<H16>(st.v0, opix + ooff(rel)); wx = wx + r.x; wy = wy + r.y; wz = wz + r.z; ww = ww + r.w; })
       } break;
       case EP_ADDUP: {  // nearest-upsampled coarser map (never after a deconv)
         if constexpr (MODE != OUT_DECONV) conv_finish_nyx(a, m, n, y, x);
@@ -299,8 +348,8 @@ __device__ __forceinline__ void conv_finish(const ConvArgs& a, const Epilogue& e
           const int lu = 31 - __clz(st.a0);
           spix = (long)(a.rout.cw[n] >> (2 * (a.rout.shift + lu))) + (long)(y / st.a0) * (a.rout.w[n] >> (a.rout.shift + lu)) + x / st.a0;
         }
-        const float* up = st.v0 + spix * a.Cs_out + r0;
-        OCR_EP_SWEEP({ const float4 r = *(const float4*)(up + coff(rel)); wx = wx + r.x; wy = wy + r.y; wz = wz + r.z; ww = ww + r.w; })
+        const long upo = spix * a.Cs_out + r0;
+        OCR_EP_SWEEP({ const float4 r = ld4<H16>(st.v0, upo + coff(rel)); wx = wx + r.x; wy = wy + r.y; wz = wz + r.z; ww = ww + r.w; })
       } break;
     }
   }
@@ -345,7 +394,7 @@ __device__ __forceinline__ void conv_finish(const ConvArgs& a, const Epilogue& e
     return;
   }
   // ---- stores, after the last load
-  float* obase = a.out + opix;
+  float* obase = a.out + (H16 && MODE != OUT_PLAIN ? 0 : opix);  // (f16 tensors are addressed by element index below)
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
 #pragma unroll
@@ -373,7 +422,8 @@ __device__ __forceinline__ void conv_finish(const ConvArgs& a, const Epilogue& e
 #ifdef OCR_PROBE_NOSTORE
         if (w.x == 12345.678f) *(float4*)dst = w;  // development probe: keep the value live, skip the traffic
 #else
-        *(float4*)dst = w;
+        if constexpr (H16) st4<true>(a.out, opix + ooff(rel), w);
+        else *(float4*)dst = w;
 #endif
       }
     }

@@ -36,7 +36,21 @@
 #include "conv_device.h"
 #include "kernels_net.h"
 
+// Compiled twice, as kernels_net.hip: as it stands the f32 contract; with -DOCR_TU_H16 (kernels_dwpw_h16.o) precision
+// "fp16" - input and output tensors stored as f16, the 1x1 half as v_mfma_f32_32x32x8_f16 on operands rounded to f16, the
+// depthwise taps, both epilogues and everything in LDS f32 as before.
+#ifdef OCR_TU_H16
+#define OCR_L(name) name##_h16
+#define OCR_H16_TWIN(cond, call)
 namespace ocr {
+inline namespace h16 {
+constexpr bool kH16 = true;
+#else
+#define OCR_L(name) name
+#define OCR_H16_TWIN(cond, call) if (cond) return call;
+namespace ocr {
+constexpr bool kH16 = false;
+#endif
 
 #ifdef OCR_DWPW_CLOCKS  // development probe: clocks per phase of the steady-state step, summed over every wave
 __device__ unsigned long long ocr_dwpw_clk[8];
@@ -187,10 +201,12 @@ __device__ __forceinline__ void lab_apply(F4& v, const ocr_f2 blo, const ocr_f2 
 // G runs one or two items (GD) ahead of S through as many register sets, S one item ahead of the taps through two LDS
 // buffers.  TD = tap steps the LDS reads run ahead, LB = workgroups per CU the register budget is cut for.
 // Everything per-thread that does not depend on the tile (LDS offsets of its pieces and items) is computed once.
-template <int K, int SH, int SW, int CK, bool WIDE, int NT, bool DWACT, int GD, int TD, int LB, bool RAG, bool HALF = false>
+template <int K, int SH, int SW, int CK, bool WIDE, int NT, bool DWACT, int GD, int TD, int LB, bool RAG, bool HALF = kH16>
 __global__ void __launch_bounds__(256, LB) dwpw_kernel(const DwPwArgs a) {
   using G_ = DwPwGeom<K, SH, SW, CK, WIDE>;
   using WV = typename WFrag<HALF>::T;  // precision "fp16": f16 weight fragments, one v_mfma_f32_32x32x8_f16 per octet and column tile
+  using PV = typename WFrag<HALF>::T;  // a region piece (4 channels of a pixel) as it travels: float4, or four halfs of an f16 tensor
+  constexpr int ES = HALF ? 2 : 4;     // bytes per stored activation
   constexpr int WC = G_::WC, TW = G_::TW, TH = G_::TH, PR = G_::PR, IW = G_::IW;
   constexpr int S = G_::S, Q = G_::Q, C8S = G_::C8S, IN_TILE = G_::IN_TILE, OP_TILE = G_::OP_TILE, WT = G_::WT;
   constexpr int G_PIECES = G_::G_PIECES, G_PER = G_::G_PER, NIT = G_::NIT, IT_PER = G_::IT_PER;
@@ -245,10 +261,10 @@ __global__ void __launch_bounds__(256, LB) dwpw_kernel(const DwPwArgs a) {
   UnitPos<RAG, TH> g_pos_u;
   g_pos_u.init(u0, cblocks, a);
   int g_units = nunits, g_ch = 0;
-  const float* g_img = a.dw_in;
+  const char* g_img = (const char*)a.dw_in;
   int goff[G_PER];
-  auto g_setup = [&]() __attribute__((always_inline)) {  // image offsets of this thread's pieces for unit g_pos_u (-1: zero)
-    g_img = a.dw_in + g_pos_u.in_pix(a) * Cs;
+  auto g_setup = [&]() __attribute__((always_inline)) {  // image offsets (elements) of this thread's pieces for unit g_pos_u (-1: zero)
+    g_img = (const char*)a.dw_in + g_pos_u.in_pix(a) * Cs * ES;
     const int iy0 = g_pos_u.ty * TH * SH - a.PH, ix0 = g_pos_u.tx * TW * SW - a.PW;
     const int iwn = g_pos_u.in_w(a), ihn = g_pos_u.in_h(a);
 #pragma unroll
@@ -264,21 +280,21 @@ __global__ void __launch_bounds__(256, LB) dwpw_kernel(const DwPwArgs a) {
   // loads under lane- or item-dependent branches the compiler falls back to vmcnt(0) in the middle of the matrix phase.
   const float* const w_piece = tid < WQ ? a.dw_w + (long)(tid / Q) * Cs + 4 * (tid % Q)
                                         : a.dw_ep.bias + (tid < WQ + Q ? 4 * (tid - WQ) : 0);
-  struct GSet { float4 r[G_PER]; float4 w; };  // one item's region pieces in flight
+  struct GSet { PV r[G_PER]; float4 w; };  // one item's region pieces in flight
   // (round 4) a piece outside the image is LOADED FROM A ZERO PAGE - the address is selected, not the value - so the
   // fill below stores what arrived: no keep mask, no AND per component (21 VALU instructions per item less; every one
   // of them cost matrix time)
-  const float* const zpage = a.c.zeros;
+  const char* const zpage = (const char*)a.c.zeros;
   auto G = [&](GSet& gs) __attribute__((always_inline)) {
-    float4 (&greg)[G_PER] = gs.r;
+    PV (&greg)[G_PER] = gs.r;
     float4& wreg = gs.w;
-    const float* base = g_img + g_ch * CK;
+    const char* base = g_img + g_ch * CK * ES;
 #pragma unroll
     for (int i = 0; i < G_PER; ++i)
 #ifdef OCR_DWPW_NO_G  // development probe (tools/micro/dwpw_probe.hip): no input traffic
-      greg[i] = make_float4((float)goff[i], (float)(size_t)base, 0.f, 0.f);
+      { greg[i] = PV{}; greg[i].x = (decltype(greg[i].x))((size_t)base + goff[i]); }
 #else
-      greg[i] = *(const float4*)(goff[i] >= 0 ? base + goff[i] : zpage);
+      greg[i] = *(const PV*)(goff[i] >= 0 ? base + (long)goff[i] * ES : zpage);
 #endif
     wreg = *(const float4*)(w_piece + g_ch * CK);
     if (g_units > 0 && ++g_ch == nch) {
@@ -293,12 +309,19 @@ __global__ void __launch_bounds__(256, LB) dwpw_kernel(const DwPwArgs a) {
     }
   };
   auto Sfill = [&](int buf, const GSet& gs) __attribute__((always_inline)) {
-    const float4 (&greg)[G_PER] = gs.r;
+    const PV (&greg)[G_PER] = gs.r;
     const float4& wreg = gs.w;
     float* si = s_in + buf * IN_TILE;
 #pragma unroll
     for (int i = 0; i < G_PER; ++i)
-      if (G_PIECES % 256 == 0 || g_pos[i] >= 0) *(float4*)(si + g_lds[i]) = greg[i];
+      if (G_PIECES % 256 == 0 || g_pos[i] >= 0) {
+        if constexpr (HALF) {  // up to f32 on the way into LDS (exact): the taps below are the f32 ones
+          const ocr_f4v f = __builtin_convertvector(ocr_as_h4(greg[i]), ocr_f4v);
+          *(float4*)(si + g_lds[i]) = make_float4(f.x, f.y, f.z, f.w);
+        } else {
+          *(float4*)(si + g_lds[i]) = greg[i];
+        }
+      }
     if (tid < WQ) *(float4*)(s_w + buf * WT + 4 * tid) = wreg;            // [tap][CK]: tap*CK + 4q = 4*tid
     else if (tid < WQ + Q) *(float4*)(s_b + buf * CK + 4 * (tid - WQ)) = wreg;
   };
@@ -429,7 +452,7 @@ __global__ void __launch_bounds__(256, LB) dwpw_kernel(const DwPwArgs a) {
     const bool inside = oy < m_pos.out_h(a) && ox < own;
     const int r0 = nt0 * 32 + 4 * h;
     const float* sp = s_par + r0;
-    float* obase = c.out + (m_pos.out_pix(a) + (long)oy * own + ox) * c.Cs_out + r0;
+    const long oidx = (m_pos.out_pix(a) + (long)oy * own + ox) * c.Cs_out + r0;  // element index of the lane's first column
     const ocr_f2 S0 = {ps0, ps0}, A0 = {pa0, pa0};
     float mn = INFINITY, mx = 0.0f;
     // a column tile's four bias vectors as one group of LDS reads (left alone, each read is sunk next to its use:
@@ -465,7 +488,7 @@ __global__ void __launch_bounds__(256, LB) dwpw_kernel(const DwPwArgs a) {
 #ifdef OCR_PROBE_NOSTORE
         if (tl.x == 12345.678f)
 #endif
-        if (inside && nt0 * 32 + 32 * t + 8 * g < c.ColsStore) *(float4*)(obase + 32 * t + 8 * g) = make_float4(tl.x, tl.y, th.x, th.y);
+        if (inside && nt0 * 32 + 32 * t + 8 * g < c.ColsStore) st4<HALF>(c.out, oidx + 32 * t + 8 * g, make_float4(tl.x, tl.y, th.x, th.y));
         acc[t][4 * g] = 0.f; acc[t][4 * g + 1] = 0.f; acc[t][4 * g + 2] = 0.f; acc[t][4 * g + 3] = 0.f;
       }
   };
@@ -624,7 +647,7 @@ __global__ void __launch_bounds__(256, LB) dwpw_kernel(const DwPwArgs a) {
   };
   GSet gA;
 #pragma unroll
-  for (int i = 0; i < G_PER; ++i) gA.r[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int i = 0; i < G_PER; ++i) gA.r[i] = PV{};
   gA.w = make_float4(0.f, 0.f, 0.f, 0.f);
   if constexpr (GD == 2) {
     GSet gB = gA;
@@ -728,6 +751,7 @@ bool launch_one(const DwPwArgs& a0, hipStream_t s, bool query) {
 
 }  // namespace
 
+#ifndef OCR_TU_H16
 bool lab_from_epilogue(const Epilogue& ep, LabEp& out) {
   out = LabEp{};
   if (ep.n != 3 && ep.n != 6) return false;
@@ -743,6 +767,7 @@ bool lab_from_epilogue(const Epilogue& ep, LabEp& out) {
   }
   return true;
 }
+#endif  // OCR_TU_H16
 
 // The instantiated shapes (everything else stays an unfused pair): K, strides, chunk width, workgroup shape
 // (thin: 4 waves = 4 pixel groups of an 8x16 tile, all <= 4 column tiles per wave; wide: 2 pixel groups of a 4x16
@@ -754,11 +779,8 @@ static int dwpw_dispatch(const DwPwArgs& a, hipStream_t s, bool query, bool rows
 #define OCR_DWPW_CASE(K_, SH_, SW_, CK_, WIDE_, NT_, GD_, TD_, LB_, COND)                                  \
   if (K == K_ && SH == SH_ && SW == SW_ && Cs % CK_ == 0 && tiles % (NT_ * (WIDE_ ? 2 : 1)) == 0 && (COND)) { \
     if (rows_only) return DwPwGeom<K_, SH_, SW_, CK_, WIDE_>::TH;                                                \
-    if (a.c.half)                                                                                                \
-      return (a.rtiles ? launch_one<K_, SH_, SW_, CK_, WIDE_, NT_, true, GD_, TD_, LB_, true, true>(a, s, query)         \
-                       : launch_one<K_, SH_, SW_, CK_, WIDE_, NT_, true, GD_, TD_, LB_, false, true>(a, s, query)) ? 1 : 0; \
-    return (a.rtiles ? launch_one<K_, SH_, SW_, CK_, WIDE_, NT_, true, GD_, TD_, LB_, true, false>(a, s, query)          \
-                     : launch_one<K_, SH_, SW_, CK_, WIDE_, NT_, true, GD_, TD_, LB_, false, false>(a, s, query)) ? 1 : 0; \
+    return (a.rtiles ? launch_one<K_, SH_, SW_, CK_, WIDE_, NT_, true, GD_, TD_, LB_, true, kH16>(a, s, query)           \
+                     : launch_one<K_, SH_, SW_, CK_, WIDE_, NT_, true, GD_, TD_, LB_, false, kH16>(a, s, query)) ? 1 : 0;  \
   }
   // TD = how many tap steps ahead the LDS reads run, LB = workgroups per CU the register budget is cut for (3: 168
   // registers, 2: 256): per shape, whichever measured faster (tools/micro/dwpw_probe) - a third wave per SIMD where the
@@ -787,7 +809,15 @@ static int dwpw_dispatch(const DwPwArgs& a, hipStream_t s, bool query, bool rows
 #undef OCR_DWPW_CASE
   return 0;
 }
-bool launch_dwpw(const DwPwArgs& a, hipStream_t s, bool query) { return dwpw_dispatch(a, s, query, false) != 0; }
-int dwpw_tile_rows(const DwPwArgs& a) { return dwpw_dispatch(a, nullptr, true, true); }
+bool OCR_L(launch_dwpw)(const DwPwArgs& a, hipStream_t s, bool query) {
+  OCR_H16_TWIN(a.c.half, launch_dwpw_h16(a, s, query))
+  return dwpw_dispatch(a, s, query, false) != 0;
+}
+#ifndef OCR_TU_H16
+int dwpw_tile_rows(const DwPwArgs& a) { return dwpw_dispatch(a, nullptr, true, true); }  // (the tile shapes are the same in both builds)
+#endif
 
+#ifdef OCR_TU_H16
+}  // namespace h16
+#endif
 }  // namespace ocr

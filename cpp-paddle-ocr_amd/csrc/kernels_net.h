@@ -65,8 +65,10 @@ struct ConvArgs {
   // 3x3 tile kernels on a ragged batch of images: [N+1] prefix sums of the images' 8x16-pixel tile counts
   const int* rtiles = nullptr;
   int rtiles_total = 0;
-  // precision "fp16": wfrag is the f16 fragment image ([...][64 lanes][4 halfs]) and the products run as
-  // v_mfma_f32_32x32x8_f16 on operands rounded to f16, f32 accumulation (conv_device.h); 0: the f32 contract
+  // precision "fp16": in / out (C8I) and the epilogue's tensor operands are f16 tensors, wfrag is the f16 fragment image
+  // ([...][64 lanes][4 halfs]) and the products run as v_mfma_f32_32x32x8_f16 with f32 accumulation; plain outputs, head
+  // partials, gates and parameter vectors stay f32.  0: the f32 contract.  (The launchers hand such a call to their
+  // `_h16` twin, below.)
   int half = 0;
 };
 // false: the combination (gated input / multi-tap conv with a plain or deconv output) is not instantiated
@@ -82,6 +84,7 @@ struct ConvRowsumArgs {
   int W, Cin, Cs_in, Cs_out;
   int N, H;      // ragged batch: samples, uniform height (lines mode)
   RagLevel rag;  // ragged batch: the level of the conv's input = output
+  int h16 = 0;   // precision "fp16": `in` is an f16 tensor (the row sums stay f32)
 };
 bool launch_conv_rowsum(const ConvRowsumArgs& a, hipStream_t s);
 // the same with two 32-pixel tiles per wave (big single-tap convs with a C8I output, nt = 3 | 4); false: not this shape
@@ -107,6 +110,7 @@ struct StemArgs {
   long M;
   int N, H, W, OH, OW, Cs_out, KH, KW, SH, SW, PH, PW;
   RagLevel rin, rout;  // ragged batch: W / OW per line
+  int h16 = 0;         // precision "fp16": `out` is an f16 tensor (the image stays f32)
 };
 void launch_stem(const StemArgs& a, const Epilogue& ep, hipStream_t s);
 
@@ -123,6 +127,7 @@ struct DwArgs {
   RagLevel rin, rout;          // ragged batch: sizes per sample
   const int* rwork = nullptr;  // ragged: [N+1] prefix sums of the samples' work items - bands (rowsum) or bands x strips of the launcher's patch (dw_patch_to / dw_patch_r)
   int rwork_total = 0;         // rwork[N] (host copy: the launcher sizes the grid with it)
+  int h16 = 0;                 // precision "fp16": in / out (and an ADDT operand) are f16 tensors; rowsum stays f32
 };
 void launch_dw(const DwArgs& a, const Epilogue& ep, hipStream_t s);
 int dw_patch_to(int OW, int SW, int OH, int K);  // output pixels per thread along x the launcher will pick
@@ -162,10 +167,11 @@ int dwpw_tile_rows(const DwPwArgs& a);
 int dw_patch_r(int OH, int K);  // output rows per thread the depthwise launcher will pick (ragged batch: OH = the lowest sample)
 
 // rag (ragged batch of N lines): the per-image stages (channel gate) find their line from the row index
+// h16 (here and below): precision "fp16" - the C8I tensors among the arguments are stored as f16
 void launch_ew(const float* in, float* out, long M, int H, int W, int Cs, const Epilogue& ep, hipStream_t s, int N = 0,
-               RagLevel rag = RagLevel());
+               RagLevel rag = RagLevel(), bool h16 = false);
 void launch_gap(const float* in, float* part, float* out, int N, int H, int W, int Cs, hipStream_t s, RagLevel rag = RagLevel(),
-                long rows = 0);  // rows: total rows of the batch (0: N * H)
+                long rows = 0, bool h16 = false);  // rows: total rows of the batch (0: N * H)
 
 struct SeArgs {
   const float* in;  // [N][Cs]
@@ -184,6 +190,7 @@ struct ConcatArgs {
   int coff[4], scs[4], up[4];
   RagLevel rout;  // ragged batch of images: the output's level; source j lives log2(up[j]) levels coarser
   int N = 0;
+  int h16 = 0;
 };
 void launch_concat(const ConcatArgs& a, hipStream_t s);
 
@@ -193,14 +200,15 @@ struct PoolArgs {
   long M;
   int N, H, W, OH, OW, Cs, KH, KW, SH, SW, is_max;
   RagLevel rin, rout;  // ragged batch: W / OW per line
+  int h16 = 0;
 };
 void launch_pool(const PoolArgs& a, hipStream_t s);
 
 void launch_ln(const float* in, float* out, long rows, int C, int Cs, float eps, const float* g, const float* b,
-               hipStream_t s);
+               hipStream_t s, bool h16 = false);
 // rag (ragged batch): line n is a sequence of rag.w[n] tokens starting at row rag.cw[n]; T = the longest line
 void launch_attn(const float* qkv, float* out, int N, int T, int heads, int hd, int Cs_in, int Cs_out, float scale,
-                 hipStream_t s, RagLevel rag = RagLevel());
+                 hipStream_t s, RagLevel rag = RagLevel(), bool h16 = false);
 // does the ragged form of the attention kernel take sequences of this length? (its working set must fit LDS)
 bool attn_ragged_fits(int T);
 // second half of the fused head: rows x groups partials -> arg max / max probability per row
@@ -217,6 +225,7 @@ struct DetTailArgs {
   int N, H, W, C, Cs;
   float bias;
   int ithresh;  // floor(det_db_thresh*255): bit = trunc(p*255) > ithresh
+  int h16 = 0;  // precision "fp16": `in` is an f16 tensor (the map stays f32)
 };
 void launch_det_tail(const DetTailArgs& a, hipStream_t s);
 
@@ -238,6 +247,7 @@ struct DbHeadArgs {
   float bias2;
   int ithresh;
   RagLevel rin;       // ragged batch of images: the input's level (the map is two levels finer)
+  int h16 = 0;        // precision "fp16": `in` is an f16 tensor (the map stays f32)
 };
 bool launch_db_head(const DbHeadArgs& a, int C, hipStream_t s);  // false: C is not on this path (24 only)
 
@@ -259,7 +269,30 @@ struct MbArgs {
 int mbconv_chunk(const MbArgs& a);  // chunk width the launcher would use; 0: the block's shape is not on this path
 bool launch_mbconv(const MbArgs& a, hipStream_t s);
 
-void launch_c8i_to_plain(const float* in, float* out, long M, int C, int Cs, hipStream_t s);
+void launch_c8i_to_plain(const float* in, float* out, long M, int C, int Cs, hipStream_t s, bool h16 = false);
 void launch_probe(const float* a, const float* b, float* out, int n, hipStream_t s);
+
+// precision "fp16": kernels_net.hip and kernels_dwpw.hip are compiled a second time with -DOCR_TU_H16 (f16 tensor storage,
+// f16 matrix instructions, f32 accumulation and epilogues); that build's kernels live in this inline namespace and its
+// launchers carry the suffix.  Not called directly: the launchers above forward a call whose f16 flag is set.
+inline namespace h16 {
+bool launch_conv_mfma_h16(const ConvArgs& a, const Epilogue& ep, int nt, hipStream_t s);
+bool launch_conv_mfma_mt2_h16(const ConvArgs& a, const Epilogue& ep, int nt, hipStream_t s);
+bool launch_conv3x3_tile_h16(const ConvArgs& a, const Epilogue& ep, int nt, hipStream_t s);
+bool launch_conv_rowsum_h16(const ConvRowsumArgs& a, hipStream_t s);
+void launch_stem_h16(const StemArgs& a, const Epilogue& ep, hipStream_t s);
+void launch_dw_h16(const DwArgs& a, const Epilogue& ep, hipStream_t s);
+bool launch_dwpw_h16(const DwPwArgs& a, hipStream_t s, bool query);
+void launch_ew_h16(const float* in, float* out, long M, int H, int W, int Cs, const Epilogue& ep, hipStream_t s, int N, RagLevel rag, bool h16);
+void launch_gap_h16(const float* in, float* part, float* out, int N, int H, int W, int Cs, hipStream_t s, RagLevel rag, long rows, bool h16);
+void launch_concat_h16(const ConcatArgs& a, hipStream_t s);
+void launch_pool_h16(const PoolArgs& a, hipStream_t s);
+void launch_ln_h16(const float* in, float* out, long rows, int C, int Cs, float eps, const float* g, const float* b, hipStream_t s, bool h16);
+void launch_attn_h16(const float* qkv, float* out, int N, int T, int heads, int hd, int Cs_in, int Cs_out, float scale, hipStream_t s,
+                     RagLevel rag, bool h16);
+void launch_det_tail_h16(const DetTailArgs& a, hipStream_t s);
+bool launch_db_head_h16(const DbHeadArgs& a, int C, hipStream_t s);
+void launch_c8i_to_plain_h16(const float* in, float* out, long M, int C, int Cs, hipStream_t s, bool h16);
+}  // namespace h16
 
 }  // namespace ocr

@@ -13,7 +13,23 @@
 #include "conv_device.h"
 #include "kernels_net.h"
 
+// This file is compiled TWICE (build.py).  As it stands: the f32 contract - f32 tensors, v_mfma_f32_32x32x2_f32.  With
+// -DOCR_TU_H16 (object kernels_net_h16.o): precision "fp16" - the C8I activation tensors are stored as f16 (ld4 / st4 of
+// conv_device.h with kH16), the matrix products are v_mfma_f32_32x32x8_f16 on those halfs and f16 weight fragments, every
+// accumulation, reduction and epilogue stays f32.  The twin's kernels live in the inline namespace ocr::h16, its launchers
+// are `<name>_h16` (kernels_net.h); a launcher of this build hands a call with the f16 flag set to its twin.
+#ifdef OCR_TU_H16
+#define OCR_L(name) name##_h16
+#define OCR_H16_TWIN(cond, call)
 namespace ocr {
+inline namespace h16 {
+constexpr bool kH16 = true;
+#else
+#define OCR_L(name) name
+#define OCR_H16_TWIN(cond, call) if (cond) return call;
+namespace ocr {
+constexpr bool kH16 = false;
+#endif
 
 // =====================================================================================
 // Dense conv / linear / 2x2-s2 deconv as implicit GEMM on the f32 matrix cores.
@@ -24,9 +40,11 @@ namespace ocr {
 // B from the host-built fragment image (one 16-byte load per lane per n-tile per 8 channels).
 // No LDS, no barriers: four independent waves per workgroup.
 // =====================================================================================
-template <int NT, int MODE, bool TAP1, bool GATE = false, bool HALF = false>
+template <int NT, int MODE, bool TAP1, bool GATE = false, bool HALF = kH16>
 __global__ void __launch_bounds__(256, (NT <= 3 ? 4 : 3)) conv_mfma_kernel(const ConvArgs a, const Epilogue ep) {
   using WV = typename WFrag<HALF>::T;  // a lane's weight fragment of one octet: float4, or four halfs (precision "fp16")
+  using AV = typename WFrag<HALF>::T;  // its pixel operand: float4 from an f32 tensor, or four halfs straight from an f16 tensor
+  constexpr int ES = HALF ? 2 : 4;     // bytes per stored activation (precision "fp16" stores the C8I tensors as f16)
   CONV_PROBE(0);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int p = lane & 31, h = lane >> 5;
@@ -58,11 +76,11 @@ __global__ void __launch_bounds__(256, (NT <= 3 ? 4 : 3)) conv_mfma_kernel(const
   const int KK = a.KH * a.KW * a.C8;
   const WV* p_w = wf + (long)nt0 * 64 + lane;
   const long wstride = (long)a.NTtot * 64;
-  const float* zpage = a.zeros + 4 * h;
+  const char* zpage = (const char*)(a.zeros + 4 * h);  // (zero bits are 0.0 in either format)
   // ---- single tap: step j reads the lane's row at channel 8j and fragment block j
-  const float* xrow = mvalid ? a.in + m * a.Cs_in + 4 * h : zpage;
-  // GATE: the SE gate of the lane's image, same four channels as the pixel load (single-tap only)
-  const float* grow = zpage;
+  const char* xrow = mvalid ? (const char*)a.in + (m * a.Cs_in + 4 * h) * ES : zpage;
+  // GATE: the SE gate of the lane's image (f32), same four channels as the pixel load (single-tap only)
+  const float* grow = a.zeros + 4 * h;
   if constexpr (GATE) {
     if (mvalid) {
       const int gn = a.rin.w ? rag_sample_of_pixel(a.rin, a.N, a.H, m, (long)(lb / groups) * 128) : (int)((unsigned)m / (unsigned)a.gate_hw);
@@ -74,33 +92,33 @@ __global__ void __launch_bounds__(256, (NT <= 3 ? 4 : 3)) conv_mfma_kernel(const
   int p_c8 = 0, p_ky = 0, p_kx = 0;
   int n = 0, y = 0, x = 0;
   int lw = a.W, lh = a.H;  // width / height of the lane's sample (ragged batch: its own)
-  const float* lane_base = nullptr;
+  const char* lane_base = nullptr;
   long tap_off = 0;  // + c8*8, elements
   if constexpr (!TAP1) {
     if (a.rin.w) {  // stride-1 "same" convs only (host): the output level is the input level
       rag_decompose(a.rin, a.N, a.H, mvalid ? m : a.M - 1, (long)(lb / groups) * 128, n, y, x, lw);
       lh = rag_h(a.rin, n, a.H);
-      lane_base = a.in + 4 * h + (rag_pix0(a.rin, n, a.H) + (long)(y - a.PH) * lw + (x - a.PW)) * a.Cs_in;
+      lane_base = (const char*)a.in + (4 * h + (rag_pix0(a.rin, n, a.H) + (long)(y - a.PH) * lw + (x - a.PW)) * a.Cs_in) * ES;
     } else {
       decompose(mvalid ? m : a.M - 1, a.OH * a.OW, a.OW, n, y, x);
       // this lane's pixel at tap (0,0), channel 4h; a tap adds the uniform offset (ky*W + kx)*Cs_in
-      lane_base = a.in + 4 * h + (((long)n * a.H + (y - a.PH)) * a.W + (x - a.PW)) * a.Cs_in;
+      lane_base = (const char*)a.in + (4 * h + (((long)n * a.H + (y - a.PH)) * a.W + (x - a.PW)) * a.Cs_in) * ES;
     }
   }
-  auto load_step = [&](float4& av, WV (&bv)[NT], float4& gv) {
+  auto load_step = [&](AV& av, WV (&bv)[NT], float4& gv) {
     if constexpr (GATE) gv = *(const float4*)(grow + p_step * 8);
     if constexpr (TAP1) {
 #ifdef OCR_PROBE_NOX
-      av = make_float4((float)(size_t)xrow, 1.f, 2.f, 3.f);
+      { av = AV{}; av.x = (decltype(av.x))(size_t)xrow; }
 #else
-      av = *(const float4*)(xrow + p_step * 8);
+      av = *(const AV*)(xrow + (long)p_step * 8 * ES);
 #endif
     } else {
       const int iy = y - a.PH + p_ky, ix = x - a.PW + p_kx;
       const bool valid = mvalid && (unsigned)iy < (unsigned)lh && (unsigned)ix < (unsigned)lw;
       // padding / out-of-range rows read a zero page: no select ever touches a loaded value
-      const float* src = valid ? lane_base + tap_off : zpage;
-      av = *(const float4*)src;
+      const char* src = valid ? lane_base + tap_off * ES : zpage;
+      av = *(const AV*)src;
     }
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -127,11 +145,13 @@ __global__ void __launch_bounds__(256, (NT <= 3 ? 4 : 3)) conv_mfma_kernel(const
   // nothing but MFMAs in the step the waves of a SIMD take turns badly.  tools/micro/conv_time.hip, 983040 x 480 -> 480
   // alone: 108.3 TFLOP/s without, 128.3 with (s_nop: no change; a VALU op after EVERY MFMA: 120); 240 -> 240: 92.6 ->
   // 105.0; 480 -> 120: 94.4 -> 110.2; NT = 1 (every MFMA followed by one) loses 4 %, so only for NT >= 2.
-  auto mfma_step = [&](const float4& av0, const WV (&bv)[NT], const float4& gv) {
-    if constexpr (HALF) {  // one f16 matrix instruction per octet and column tile
-      float4 x = av0;
-      if constexpr (GATE) { x.x = av0.x * gv.x; x.y = av0.y * gv.y; x.z = av0.z * gv.z; x.w = av0.w * gv.w; }
-      const ocr_h4 ah = ocr_to_h4(x);
+  auto mfma_step = [&](const AV& av0, const WV (&bv)[NT], const float4& gv) {
+    if constexpr (HALF) {  // one f16 matrix instruction per octet and column tile; the operand comes as stored
+      ocr_h4 ah = ocr_as_h4(av0);
+      if constexpr (GATE) {  // x * gate in f32 (one rounding, as the f32 path), then the operand's own rounding to f16
+        const ocr_f4v xf = __builtin_convertvector(ah, ocr_f4v);
+        ah = ocr_to_h4(make_float4(xf.x * gv.x, xf.y * gv.y, xf.z * gv.z, xf.w * gv.w));
+      }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x8f16(ocr_as_h4(bv[t]), ah, acc[t], 0, 0, 0);
@@ -150,7 +170,7 @@ __global__ void __launch_bounds__(256, (NT <= 3 ? 4 : 3)) conv_mfma_kernel(const
 #undef OCR_C_SWEEP
     }
   };
-  float4 a0, a1;
+  AV a0, a1;
   WV b0[NT], b1[NT];
   float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0;
   load_step(a0, b0, g0);
@@ -170,7 +190,7 @@ __global__ void __launch_bounds__(256, (NT <= 3 ? 4 : 3)) conv_mfma_kernel(const
   CONV_PROBE(2);
 
   // ---- epilogue: lane owns output column j (one channel), 16 rows ----
-  conv_finish<NT, MODE>(a, ep, acc, nt0, m, h, s_par);
+  conv_finish<NT, MODE, HALF>(a, ep, acc, nt0, m, h, s_par);
   CONV_PROBE(3);
 }
 
@@ -180,9 +200,11 @@ __global__ void __launch_bounds__(256, (NT <= 3 ? 4 : 3)) conv_mfma_kernel(const
 // alone): MT x NT = 1x3 (the kernel above) 99.8 TFLOP/s gated / 108.6 plain, 1x5 110.5 / 115.6 - the direct kernel is
 // bound by the bytes it pulls through L1 per MFMA (1x3: 5 KB per 12 MFMAs; 2x3: 7 KB per 24), not by occupancy
 // (3 or 4 waves per SIMD measure the same).  Every output's chain is the one above: bit-identical.
-template <int NT, int MT, bool GATE, bool HALF = false>
+template <int NT, int MT, bool GATE, bool HALF = kH16>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) conv_mfma_mt_kernel(const ConvArgs a, const Epilogue ep) {
   using WV = typename WFrag<HALF>::T;
+  using AV = typename WFrag<HALF>::T;
+  constexpr int ES = HALF ? 2 : 4;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int p = lane & 31, h = lane >> 5;
   const unsigned lb = xcd_swizzle(blockIdx.x, gridDim.x);  // logical block: N-group fastest, then M-tile
@@ -206,15 +228,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
   const int KK = a.C8;
   const WV* p_w = wf + (long)nt0 * 64 + lane;
   const long wstride = (long)a.NTtot * 64;
-  const float* zpage = a.zeros + 4 * h;
-  const float* xrow[MT];
+  const char* zpage = (const char*)(a.zeros + 4 * h);
+  const char* xrow[MT];
   const float* grow[MT];
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     const long m = m0 + 32 * i + p;
     const bool mvalid = m < a.M;
-    xrow[i] = mvalid ? a.in + m * a.Cs_in + 4 * h : zpage;
-    grow[i] = zpage;
+    xrow[i] = mvalid ? (const char*)a.in + (m * a.Cs_in + 4 * h) * ES : zpage;
+    grow[i] = a.zeros + 4 * h;
     if constexpr (GATE) {
       if (mvalid) {
         const int gn = a.rin.w ? rag_sample_of_pixel(a.rin, a.N, a.H, m, mblk) : (int)((unsigned)m / (unsigned)a.gate_hw);
@@ -223,12 +245,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     }
   }
   int p_step = 0;
-  struct Set { float4 av[MT], gv[MT]; WV bv[NT]; };
+  struct Set { AV av[MT]; float4 gv[MT]; WV bv[NT]; };
   auto load_step = [&](Set& s) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       if constexpr (GATE) s.gv[i] = *(const float4*)(grow[i] + p_step * 8);
-      s.av[i] = *(const float4*)(xrow[i] + p_step * 8);
+      s.av[i] = *(const AV*)(xrow[i] + (long)p_step * 8 * ES);
     }
 #pragma unroll
     for (int t = 0; t < NT; ++t) s.bv[t] = p_w[t * 64];  // the fragment image is padded to whole NT groups
@@ -237,6 +259,18 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     p_w += more ? wstride : 0;
   };
   auto mfma_step = [&](const Set& s) __attribute__((always_inline)) {
+    if constexpr (HALF) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        ocr_h4 ah = ocr_as_h4(s.av[i]);
+        if constexpr (GATE) {
+          const ocr_f4v xf = __builtin_convertvector(ah, ocr_f4v);
+          ah = ocr_to_h4(make_float4(xf.x * s.gv[i].x, xf.y * s.gv[i].y, xf.z * s.gv[i].z, xf.w * s.gv[i].w));
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x8f16(ocr_as_h4(s.bv[t]), ah, acc[i][t], 0, 0, 0);
+      }
+    } else {
     float4 av[MT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
@@ -247,14 +281,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     // take turns badly (conv_time, 983040 x 480 -> 480: 117.8 TFLOP/s without, 129.7 with a v_nop per NT MFMAs, 120.3 with
     // one per MFMA, no change with s_nop); the gated kernel has its multiplies there (124.5; hoisted in front of the
     // MFMAs 108.6), and more of them do not help it.
-    if constexpr (HALF) {
-#pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        const ocr_h4 ah = ocr_to_h4(av[i]);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x8f16(ocr_as_h4(s.bv[t]), ah, acc[i][t], 0, 0, 0);
-      }
-    } else {
 #define OCR_MT_SWEEP(C)                                                                                      \
   _Pragma("unroll") for (int i = 0; i < MT; ++i) {                                                           \
     _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                           \
@@ -284,21 +310,18 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
   }
   if (kk < KK) mfma_step(s0);
   // (spelled out: left to "#pragma unroll" the compiler keeps the loop for the larger NT and indexes acc through scratch)
-  conv_finish<NT, OUT_C8I>(a, ep, acc[0], nt0, m0 + p, h, s_par);
-  if constexpr (MT > 1) conv_finish<NT, OUT_C8I>(a, ep, acc[1], nt0, m0 + 32 + p, h, s_par);
-  if constexpr (MT > 2) conv_finish<NT, OUT_C8I>(a, ep, acc[2], nt0, m0 + 64 + p, h, s_par);
+  conv_finish<NT, OUT_C8I, HALF>(a, ep, acc[0], nt0, m0 + p, h, s_par);
+  if constexpr (MT > 1) conv_finish<NT, OUT_C8I, HALF>(a, ep, acc[1], nt0, m0 + 32 + p, h, s_par);
+  if constexpr (MT > 2) conv_finish<NT, OUT_C8I, HALF>(a, ep, acc[2], nt0, m0 + 64 + p, h, s_par);
 }
 
 // Two pixel tiles per wave (the kernel above) for the shapes it was measured on: single tap, C8I output, nt = 3 or 4.
-bool launch_conv_mfma_mt2(const ConvArgs& a, const Epilogue& ep, int nt, hipStream_t s) {
+bool OCR_L(launch_conv_mfma_mt2)(const ConvArgs& a, const Epilogue& ep, int nt, hipStream_t s) {
+  OCR_H16_TWIN(a.half, launch_conv_mfma_mt2_h16(a, ep, nt, s))
   const bool tap1 = a.KH == 1 && a.KW == 1 && a.PH == 0 && a.PW == 0 && a.OH == a.H && a.OW == a.W;
   if (!tap1 || a.out_mode != OUT_C8I || a.NTtot % nt) return false;
   dim3 grid((unsigned)(((a.M + 255) / 256) * (a.NTtot / nt)));
-#define OCR_MT_LAUNCH(NT_, GATE_)                                                                                  \
-  {                                                                                                                \
-    if (a.half) hipLaunchKernelGGL((conv_mfma_mt_kernel<NT_, 2, GATE_, true>), grid, dim3(256), 0, s, a, ep);      \
-    else hipLaunchKernelGGL((conv_mfma_mt_kernel<NT_, 2, GATE_, false>), grid, dim3(256), 0, s, a, ep);            \
-  }
+#define OCR_MT_LAUNCH(NT_, GATE_) { hipLaunchKernelGGL((conv_mfma_mt_kernel<NT_, 2, GATE_>), grid, dim3(256), 0, s, a, ep); }
   if (nt == 3) {
     if (a.gate) OCR_MT_LAUNCH(3, true) else OCR_MT_LAUNCH(3, false)
   } else if (nt == 4) {
@@ -310,8 +333,9 @@ bool launch_conv_mfma_mt2(const ConvArgs& a, const Epilogue& ep, int nt, hipStre
   return true;
 }
 
-template <bool HALF>
-static bool launch_conv_mfma_t(const ConvArgs& a, const Epilogue& ep, int nt, hipStream_t s) {
+bool OCR_L(launch_conv_mfma)(const ConvArgs& a, const Epilogue& ep, int nt, hipStream_t s) {
+  OCR_H16_TWIN(a.half, launch_conv_mfma_h16(a, ep, nt, s))
+  constexpr bool HALF = kH16;
   dim3 grid((unsigned)(((a.M + 127) / 128) * (a.NTtot / nt)));
 #define OCR_LAUNCH_MODE(MODE, TAP1)                                                                             \
   switch (nt) {                                                                                                 \
@@ -341,10 +365,8 @@ static bool launch_conv_mfma_t(const ConvArgs& a, const Epilogue& ep, int nt, hi
   return true;
 }
 
-bool launch_conv_mfma(const ConvArgs& a, const Epilogue& ep, int nt, hipStream_t s) {
-  return a.half ? launch_conv_mfma_t<true>(a, ep, nt, s) : launch_conv_mfma_t<false>(a, ep, nt, s);
-}
 
+#ifndef OCR_TU_H16  // (f32 contract only: precision "fp16" keeps the direct and the LDS-tile kernels)
 // =====================================================================================
 // The same implicit GEMM with operands staged through LDS (the default for K >= 64).
 //   workgroup tile : 128 output pixels (4 waves x 32) x NT*32 output channels
@@ -493,6 +515,7 @@ __global__ void __launch_bounds__(256, 2) conv_lds_kernel(const ConvArgs a, cons
   conv_finish<NT, OUT_C8I>(a, ep, acc, nt0, m, h, s_par);
 }
 
+#endif  // OCR_TU_H16
 // =====================================================================================
 // 3x3 stride-1 pad-1 conv with the whole input tile resident in LDS (the DB neck/head 96 -> 24 convs:
 // 5.56 of det's 10.36 GFLOP).  conv_lds_kernel above re-stages the 128-pixel A tile for every tap and
@@ -506,7 +529,7 @@ __global__ void __launch_bounds__(256, 2) conv_lds_kernel(const ConvArgs a, cons
 //            register sets - occupancy is LDS-bound at 2 workgroups per CU, registers are free)
 // Same ascending (tap, channel) MFMA chain per output: bit-identical to the other conv kernels.
 // =====================================================================================
-template <int C8, int NT, bool HALF = false>
+template <int C8, int NT, bool HALF = kH16>
 __global__ void __launch_bounds__(256, 2) conv3x3_tile_kernel(const ConvArgs a, const Epilogue ep, const int tiles_x,
                                                               const int tiles_y) {
   using WV = typename WFrag<HALF>::T;
@@ -527,7 +550,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_tile_kernel(const ConvArgs a, 
   const int y0 = ty * TH, x0 = tx * TW;
   // ---- fill: (RH*RW) pixels x Q pieces, consecutive threads take consecutive pieces of a pixel
   {
-    const float* img = a.in + (long)n * a.H * a.W * CS;
+    const long img = (long)n * a.H * a.W * CS;  // element index of the image (f16 tensors: converted up on the way into LDS)
     constexpr int PIECES = RH * RW * Q, PER_THR = (PIECES + 255) / 256;
     float4 r[PER_THR];
 #pragma unroll
@@ -537,7 +560,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_tile_kernel(const ConvArgs a, 
       const int py = px / RW, pxx = px - py * RW;
       const int iy = y0 - 1 + py, ix = x0 - 1 + pxx;
       const bool v = idx < PIECES && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-      r[i] = v ? *(const float4*)(img + ((long)iy * a.W + ix) * CS + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      r[i] = v ? ld4<HALF>(a.in, img + ((long)iy * a.W + ix) * CS + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
     for (int i = 0; i < PER_THR; ++i) {
@@ -602,9 +625,10 @@ __global__ void __launch_bounds__(256, 2) conv3x3_tile_kernel(const ConvArgs a, 
   }
   const int oy = y0 + ly, ox = x0 + lx;
   const long m = (oy < a.OH && ox < a.OW) ? ((long)n * a.OH + oy) * a.OW + ox : a.M;
-  conv_finish<NT, OUT_C8I>(a, ep, acc, nt0, m, h, s_par);
+  conv_finish<NT, OUT_C8I, HALF>(a, ep, acc, nt0, m, h, s_par);
 }
 
+#ifndef OCR_TU_H16  // (f32 contract only)
 // =====================================================================================
 // The same conv for 24 output channels on 4x4x1 matrix blocks (the five DB neck / head 96 -> 24 convs).
 // conv3x3_tile_kernel<12, 1> multiplies 32-column tiles: with 24 channels a quarter of every v_mfma_f32_32x32x2_f32 is
@@ -783,8 +807,10 @@ bool launch_conv3x3_c24(const ConvArgs& a, const Epilogue& ep, const float* wimg
   return true;
 }
 
+#endif  // OCR_TU_H16
 // true if the launch was taken (3x3, stride 1, pad 1, 96 input channels, C8I output); OCR_CONV_TILE=0 disables
-bool launch_conv3x3_tile(const ConvArgs& a, const Epilogue& ep, int nt, hipStream_t s) {
+bool OCR_L(launch_conv3x3_tile)(const ConvArgs& a, const Epilogue& ep, int nt, hipStream_t s) {
+  OCR_H16_TWIN(a.half, launch_conv3x3_tile_h16(a, ep, nt, s))
   if (!rt_options().conv_tile) return false;
   if (!(a.KH == 3 && a.KW == 3 && a.PH == 1 && a.PW == 1 && a.OH == a.H && a.OW == a.W && a.out_mode == OUT_C8I)) return false;
   if (a.Cs_in != 96 || nt != 1 || a.rin.w) return false;  // (ragged batches: the chunked kernel decodes per row)
@@ -793,17 +819,12 @@ bool launch_conv3x3_tile(const ConvArgs& a, const Epilogue& ep, int nt, hipStrea
   const unsigned lds = 10 * 18 * (96 + 4) * sizeof(float);  // 72 000 B: two workgroups per CU
   // more than 64 KB of dynamic LDS has to be allowed per device (a worker pool drives several from one process)
   static LdsAttrMemo attr_state;
-  if (a.half) {
-    static LdsAttrMemo attr_state_h;
-    if (!raise_dynamic_lds((const void*)conv3x3_tile_kernel<12, 1, true>, (int)lds, attr_state_h)) return false;
-    hipLaunchKernelGGL((conv3x3_tile_kernel<12, 1, true>), grid, dim3(256), lds, s, a, ep, tiles_x, tiles_y);
-    return true;
-  }
   if (!raise_dynamic_lds((const void*)conv3x3_tile_kernel<12, 1>, (int)lds, attr_state)) return false;  // the general kernel takes the launch
   hipLaunchKernelGGL((conv3x3_tile_kernel<12, 1>), grid, dim3(256), lds, s, a, ep, tiles_x, tiles_y);
   return true;
 }
 
+#ifndef OCR_TU_H16
 template <int NT>
 static void launch_conv_lds_nt(const ConvArgs& a, const Epilogue& ep, dim3 grid, hipStream_t s) {
   if (a.Cs_in % 32 == 0) hipLaunchKernelGGL((conv_lds_kernel<NT, 32>), grid, dim3(256), 0, s, a, ep);
@@ -819,12 +840,13 @@ void launch_conv_lds(const ConvArgs& a, const Epilogue& ep, int nt, hipStream_t 
     default: launch_conv_lds_nt<4>(a, ep, grid, s); break;
   }
 }
+#endif  // OCR_TU_H16
 
 // =====================================================================================
 // Stem: dense conv with Cin = 3 on the plain NHWC3 f32 image (any stride/pad), VALU.
 // One thread = one output pixel, all CS output channels; weights are wave-uniform (scalar loads).
 // =====================================================================================
-template <int CS>
+template <int CS, bool H16 = kH16>
 __global__ void __launch_bounds__(256) stem_conv_kernel(const StemArgs a, const Epilogue ep) {
   const long m_wg = (long)xcd_swizzle(blockIdx.x, gridDim.x) * 256;
   const long m = m_wg + threadIdx.x;
@@ -881,16 +903,16 @@ __global__ void __launch_bounds__(256) stem_conv_kernel(const StemArgs a, const 
         tap_fma(ky, kx, px, keep);
       }
   }
-  float* dst = a.out + m * CS;
 #pragma unroll
   for (int c = 0; c < CS; c += 4) {
     float4 v = make_float4(acc[c], acc[c + 1], acc[c + 2], acc[c + 3]);
-    v = apply_epilogue4(ep, v, c, n, y, x, m * CS + c, CS);
-    *(float4*)(dst + c) = v;
+    v = apply_epilogue4<H16>(ep, v, c, n, y, x, m * CS + c, CS);
+    st4<H16>(a.out, m * CS + c, v);
   }
 }
 
-void launch_stem(const StemArgs& a, const Epilogue& ep, hipStream_t s) {
+void OCR_L(launch_stem)(const StemArgs& a, const Epilogue& ep, hipStream_t s) {
+  OCR_H16_TWIN(a.h16, launch_stem_h16(a, ep, s))
   dim3 grid((unsigned)((a.M + 255) / 256));
   if (a.Cs_out == 16) hipLaunchKernelGGL(stem_conv_kernel<16>, grid, dim3(256), 0, s, a, ep);
   else hipLaunchKernelGGL(stem_conv_kernel<8>, grid, dim3(256), 0, s, a, ep);
@@ -907,7 +929,7 @@ void launch_stem(const StemArgs& a, const Epilogue& ep, hipStream_t s) {
 // =====================================================================================
 // The K*K x Cs weights are copied to LDS once per workgroup (a workgroup's 256 threads span every channel
 // quad): a thread's 50 weight fetches per patch become LDS reads and leave the L1/TA path to the pixels.
-template <int K, int SW, int TO, int R, bool ROWSUM = false, bool RAG = false>
+template <int K, int SW, int TO, int R, bool ROWSUM = false, bool RAG = false, bool H16 = kH16>
 __global__ void __launch_bounds__(256, 2) dw_conv_kernel(const DwArgs a, const Epilogue ep) {
   constexpr int NIN = (TO - 1) * SW + K;
   extern __shared__ float4 s_dw_w[];  // [K*K][Cs/4]
@@ -972,17 +994,21 @@ __global__ void __launch_bounds__(256, 2) dw_conv_kernel(const DwArgs a, const E
   // Two row buffers in ping-pong: row j+1 is in flight while row j is consumed (the kernel runs at 2
   // waves/SIMD, so the bytes in flight per wave are what hides the memory latency).  Rows beyond the
   // image are zero rows; the row after the last one is loaded (clamped) and never used.
-  auto load_row = [&](float4 (&in)[NIN], int j) {
+  using RV = typename WFrag<H16>::T;  // a loaded quad as it travels (f16 storage: converted in use_row, not next to its load)
+  auto load_row = [&](RV (&in)[NIN], int j) {
     const int iy = iyb + j;
     const bool rv = j < nrows && iy >= 0 && iy < IH;
-    const float* row = a.in + (ipix0 + (long)(rv ? iy : 0) * IW) * a.Cs + pc;
+    const long row = (ipix0 + (long)(rv ? iy : 0) * IW) * a.Cs + pc;  // element index of the row's first quad
 #pragma unroll
     for (int q = 0; q < NIN; ++q) {
       const int ix = ixb + q;
-      in[q] = (rv && ix >= 0 && ix < IW) ? *(const float4*)(row + (long)ix * a.Cs) : make_float4(0.f, 0.f, 0.f, 0.f);
+      in[q] = (rv && ix >= 0 && ix < IW) ? ld4_raw<H16>(a.in, row + (long)ix * a.Cs) : RV{};
     }
   };
-  auto use_row = [&](const float4 (&in)[NIN], int j) {
+  auto use_row = [&](const RV (&raw)[NIN], int j) {
+    float4 in[NIN];
+#pragma unroll
+    for (int q = 0; q < NIN; ++q) in[q] = up4(raw[q]);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int ky = j - r * a.SH;  // uniform
@@ -1001,7 +1027,7 @@ __global__ void __launch_bounds__(256, 2) dw_conv_kernel(const DwArgs a, const E
       }
     }
   };
-  float4 rowA[NIN], rowB[NIN];
+  RV rowA[NIN], rowB[NIN];
   load_row(rowA, 0);
 #pragma unroll 1
   for (int j = 0; j < nrows; j += 2) {
@@ -1074,7 +1100,7 @@ __global__ void __launch_bounds__(256, 2) dw_conv_kernel(const DwArgs a, const E
       case EP_ADDT:
         OCR_DW_SWEEP({
           if (y0 + r < OHn && x0 + o < OW) {
-            const float4 g = *(const float4*)(st.v0 + obase + r * orow + (long)o * a.Cs);
+            const float4 g = ld4<H16>(st.v0, obase + r * orow + (long)o * a.Cs);
             ocr_f2 glo;
             ocr_f2 ghi;
             glo.x = g.x; glo.y = g.y; ghi.x = g.z; ghi.y = g.w;
@@ -1091,7 +1117,7 @@ __global__ void __launch_bounds__(256, 2) dw_conv_kernel(const DwArgs a, const E
 #pragma unroll
     for (int o = 0; o < TO; ++o)
       if (y0 + r < OHn && x0 + o < OW) {
-        *(float4*)(a.out + obase + r * orow + (long)o * a.Cs) = make_float4(acc[r][o].lo.x, acc[r][o].lo.y, acc[r][o].hi.x, acc[r][o].hi.y);
+        st4<H16>(a.out, obase + r * orow + (long)o * a.Cs, make_float4(acc[r][o].lo.x, acc[r][o].lo.y, acc[r][o].hi.x, acc[r][o].hi.y));
         if constexpr (ROWSUM) { rsum[r].lo = rsum[r].lo + acc[r][o].lo; rsum[r].hi = rsum[r].hi + acc[r][o].hi; }  // s = s + v, x ascending
       }
   }  // strips
@@ -1123,6 +1149,7 @@ static void launch_dw_patch(const DwArgs& a, const Epilogue& ep, hipStream_t s) 
   else hipLaunchKernelGGL((dw_conv_kernel<5, 2, TO, R, false, RAG>), grid, dim3(256), lds, s, a, ep);
 }
 // output pixels per thread along x (ragged batch: OW = the narrowest line; the host builds DwArgs::rwork for this value)
+#ifndef OCR_TU_H16
 int dw_patch_to(int OW, int SW, int OH, int K) {
   // OCR_DW_PATCH=TOxR overrides (A/B measurements; results are identical)
   const bool env = rt_options().dw_patch_to > 0;
@@ -1140,7 +1167,9 @@ int dw_patch_r(int OH, int K) {
   if (OH < 2) r = 1;
   return r == 2 ? 2 : 1;
 }
-void launch_dw(const DwArgs& a, const Epilogue& ep, hipStream_t s) {
+#endif  // OCR_TU_H16
+void OCR_L(launch_dw)(const DwArgs& a, const Epilogue& ep, hipStream_t s) {
+  OCR_H16_TWIN(a.h16, launch_dw_h16(a, ep, s))
   const int r = dw_patch_r(a.OH, a.K);
   const int to = dw_patch_to(a.OW, a.SW, a.OH, a.K);
   if (a.rout.w) {  // ragged batch (the recognizer)
@@ -1159,6 +1188,7 @@ void launch_dw(const DwArgs& a, const Epilogue& ep, hipStream_t s) {
 // =====================================================================================
 // Elementwise chain (SE gate multiply, residual add, FPN upsample-add).
 // =====================================================================================
+template <bool H16>
 __global__ void __launch_bounds__(256) ew_kernel(const float* __restrict__ in, float* __restrict__ out, long M, int H,
                                                  int W, int Cs, const Epilogue ep, int N, const RagLevel rag) {
   const long t = (long)blockIdx.x * 256 + threadIdx.x;
@@ -1183,19 +1213,21 @@ __global__ void __launch_bounds__(256) ew_kernel(const float* __restrict__ in, f
   } else
   decompose(m, H * W, W, n, y, x);
   const long idx = m * Cs + pc;
-  float4 v = *(const float4*)(in + idx);
-  v = apply_epilogue4(ep, v, pc, n, y, x, idx, Cs, up_base, up_w);
-  *(float4*)(out + idx) = v;
+  float4 v = ld4<H16>(in, idx);
+  v = apply_epilogue4<H16>(ep, v, pc, n, y, x, idx, Cs, up_base, up_w);
+  st4<H16>(out, idx, v);
 }
 
-void launch_ew(const float* in, float* out, long M, int H, int W, int Cs, const Epilogue& ep, hipStream_t s, int N, RagLevel rag) {
+void OCR_L(launch_ew)(const float* in, float* out, long M, int H, int W, int Cs, const Epilogue& ep, hipStream_t s, int N, RagLevel rag, bool h16) {
+  OCR_H16_TWIN(h16, launch_ew_h16(in, out, M, H, W, Cs, ep, s, N, rag, h16))
   const long total = M * (Cs >> 2);
-  hipLaunchKernelGGL(ew_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, out, M, H, W, Cs, ep, N, rag);
+  hipLaunchKernelGGL(ew_kernel<kH16>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, out, M, H, W, Cs, ep, N, rag);
 }
 
 // =====================================================================================
 // Global average pool in the contract's order: row-sequential sums, then column-sequential.
 // =====================================================================================
+template <bool H16>
 __global__ void __launch_bounds__(256) gap_rows_kernel(const float* __restrict__ in, float* __restrict__ part, int N,
                                                        int H, int W, int Cs, const RagLevel rag, long rows) {
   // one thread = 4 physical channels of one image row: four independent sequential sums, 16-byte loads
@@ -1204,12 +1236,12 @@ __global__ void __launch_bounds__(256) gap_rows_kernel(const float* __restrict__
   if (t >= rows * c4n) return;
   const int pc = (int)(t % c4n) * 4;
   const long ny = t / c4n;
-  const float* src = in + ny * W * Cs + pc;
+  long src = ny * W * Cs + pc;  // element index of the row's first quad
   if (rag.w) {  // ragged batch: row y of sample n, the sample's own width
     const int n = rag_sample_of_row(rag, N, H, ny, (long)blockIdx.x * 256 / c4n);
     const int y = (int)(ny - rag_row0(rag, n, H));
     W = rag_w(rag, n);
-    src = in + (rag_pix0(rag, n, H) + (long)y * W) * Cs + pc;
+    src = (rag_pix0(rag, n, H) + (long)y * W) * Cs + pc;
   }
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   // eight loads in flight, then their eight sequential adds (the sum's order is the contract's: left to right)
@@ -1218,12 +1250,12 @@ __global__ void __launch_bounds__(256) gap_rows_kernel(const float* __restrict__
   for (; x + U <= W; x += U) {
     float4 v[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) v[u] = *(const float4*)(src + (long)(x + u) * Cs);
+    for (int u = 0; u < U; ++u) v[u] = ld4<H16>(in, src + (long)(x + u) * Cs);
 #pragma unroll
     for (int u = 0; u < U; ++u) { s.x = s.x + v[u].x; s.y = s.y + v[u].y; s.z = s.z + v[u].z; s.w = s.w + v[u].w; }
   }
   for (; x < W; ++x) {
-    const float4 v = *(const float4*)(src + (long)x * Cs);
+    const float4 v = ld4<H16>(in, src + (long)x * Cs);
     s.x = s.x + v.x; s.y = s.y + v.y; s.z = s.z + v.z; s.w = s.w + v.w;
   }
   *(float4*)(part + ny * Cs + pc) = s;
@@ -1262,14 +1294,14 @@ __global__ void __launch_bounds__(256) conv_rowsum_kernel(const ConvRowsumArgs a
     const float4 w = *(const float4*)(a.w + (long)k * a.Cs_out + pc);
     wlo[k] = ocr_f2{w.x, w.y}; whi[k] = ocr_f2{w.z, w.w};
   }
-  const float* src = a.in + ny * a.W * CS_IN;
+  long src = ny * a.W * CS_IN;  // element index of the row's first pixel
   int W = a.W;  // (uniform batch: a scalar; the ragged form is its own instantiation - with a per-lane width in the same
                 // code the uniform launch ran at half speed)
   if constexpr (RAG) {  // ragged batch: row y of sample n, the sample's own width
     const int n = rag_sample_of_row(a.rag, a.N, a.H, ny, (long)blockIdx.x * 256 / c4n);
     const int y = (int)(ny - rag_row0(a.rag, n, a.H));
     W = rag_w(a.rag, n);
-    src = a.in + (rag_pix0(a.rag, n, a.H) + (long)y * W) * CS_IN;
+    src = (rag_pix0(a.rag, n, a.H) + (long)y * W) * CS_IN;
   }
   ocr_f2 slo = {0.f, 0.f}, shi = {0.f, 0.f};
   auto pixel = [&](const float4 (&xin)[CS_IN / 4], ocr_f2& lo, ocr_f2& hi) __attribute__((always_inline)) {
@@ -1289,7 +1321,7 @@ __global__ void __launch_bounds__(256) conv_rowsum_kernel(const ConvRowsumArgs a
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
-      for (int q = 0; q < CS_IN / 4; ++q) xin[u][q] = *(const float4*)(src + (long)(x + u) * CS_IN + 4 * q);
+      for (int q = 0; q < CS_IN / 4; ++q) xin[u][q] = ld4<kH16>(a.in, src + (long)(x + u) * CS_IN + 4 * q);
     ocr_f2 lo[U], hi[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) pixel(xin[u], lo[u], hi[u]);
@@ -1299,7 +1331,7 @@ __global__ void __launch_bounds__(256) conv_rowsum_kernel(const ConvRowsumArgs a
   for (; x < W; ++x) {
     float4 xin[CS_IN / 4];
 #pragma unroll
-    for (int q = 0; q < CS_IN / 4; ++q) xin[q] = *(const float4*)(src + (long)x * CS_IN + 4 * q);
+    for (int q = 0; q < CS_IN / 4; ++q) xin[q] = ld4<kH16>(a.in, src + (long)x * CS_IN + 4 * q);
     ocr_f2 lo, hi;
     pixel(xin, lo, hi);
     slo = slo + lo; shi = shi + hi;
@@ -1317,20 +1349,25 @@ static bool launch_conv_rowsum_r(const ConvRowsumArgs& a, hipStream_t s) {
   else return false;
   return true;
 }
-bool launch_conv_rowsum(const ConvRowsumArgs& a, hipStream_t s) {
+bool OCR_L(launch_conv_rowsum)(const ConvRowsumArgs& a, hipStream_t s) {
+  OCR_H16_TWIN(a.h16, launch_conv_rowsum_h16(a, s))
   return a.rag.w ? launch_conv_rowsum_r<true>(a, s) : launch_conv_rowsum_r<false>(a, s);
 }
+#ifndef OCR_TU_H16
 void launch_gap_cols(const float* part, float* out, int N, int H, int W, int Cs, hipStream_t s, RagLevel rag) {
   hipLaunchKernelGGL(gap_cols_kernel, dim3((unsigned)((N * Cs + 255) / 256)), dim3(256), 0, s, part, out, N, H, Cs, (float)(H * W), rag);
 }
-void launch_gap(const float* in, float* part, float* out, int N, int H, int W, int Cs, hipStream_t s, RagLevel rag, long rows) {
+#endif
+void OCR_L(launch_gap)(const float* in, float* part, float* out, int N, int H, int W, int Cs, hipStream_t s, RagLevel rag, long rows, bool h16) {
+  OCR_H16_TWIN(h16, launch_gap_h16(in, part, out, N, H, W, Cs, s, rag, rows, h16))
   if (rows <= 0) rows = (long)N * H;  // (ragged batch of images: the sum of the images' heights)
   const long t1 = rows * (Cs >> 2);
-  hipLaunchKernelGGL(gap_rows_kernel, dim3((unsigned)((t1 + 255) / 256)), dim3(256), 0, s, in, part, N, H, W, Cs, rag, rows);
+  hipLaunchKernelGGL(gap_rows_kernel<kH16>, dim3((unsigned)((t1 + 255) / 256)), dim3(256), 0, s, in, part, N, H, W, Cs, rag, rows);
   hipLaunchKernelGGL(gap_cols_kernel, dim3((unsigned)((N * Cs + 255) / 256)), dim3(256), 0, s, part, out, N, H, Cs,
                      (float)(H * W), rag);
 }
 
+#ifndef OCR_TU_H16  // (per-image vectors: f32 in both precisions)
 // =====================================================================================
 // Squeeze-excite FCs: gate = hsig(W2 * relu(W1 * m + b1) + b2); one workgroup per sample.
 // Weights are in logical order; m / gate are [N][Cs] physical.
@@ -1368,6 +1405,7 @@ __global__ void __launch_bounds__(256) sefc_kernel(const SeArgs a) {
 void launch_sefc(const SeArgs& a, int N, hipStream_t s) {
   hipLaunchKernelGGL(sefc_kernel, dim3(N), dim3(256), (a.C + a.R) * sizeof(float), s, a);
 }
+#endif  // OCR_TU_H16
 
 // =====================================================================================
 // Concat with per-source nearest upsampling (FPN fuse; rec neck concat).
@@ -1395,10 +1433,15 @@ __global__ void __launch_bounds__(256) concat_kernel(const ConcatArgs a) {
     const int sh = a.H / up, sw = a.W / up;
     spix = ((long)n * sh + y / up) * sw + x / up;
   }
-  const float4 v = *(const float4*)(a.src[j] + spix * a.scs[j] + (pc - a.coff[j]));
-  *(float4*)(a.out + m * a.Cs + pc) = v;
+  if constexpr (kH16) {  // (a copy: the halfs travel as they are)
+    *(uint2*)((_Float16*)a.out + m * a.Cs + pc) = *(const uint2*)((const _Float16*)a.src[j] + spix * a.scs[j] + (pc - a.coff[j]));
+  } else {
+    const float4 v = *(const float4*)(a.src[j] + spix * a.scs[j] + (pc - a.coff[j]));
+    *(float4*)(a.out + m * a.Cs + pc) = v;
+  }
 }
-void launch_concat(const ConcatArgs& a, hipStream_t s) {
+void OCR_L(launch_concat)(const ConcatArgs& a, hipStream_t s) {
+  OCR_H16_TWIN(a.h16, launch_concat_h16(a, s))
   const long total = a.M * (a.Cs >> 2);
   hipLaunchKernelGGL(concat_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
 }
@@ -1431,7 +1474,7 @@ __global__ void __launch_bounds__(256) pool_kernel(const PoolArgs a) {
     for (int dx = 0; dx < a.KW; ++dx) {
       const int iy = y * a.SH + dy, ix = x * a.SW + dx;
       if (iy >= a.H || ix >= IW) continue;
-      const float4 v = *(const float4*)(a.in + (ipix0 + (long)iy * IW + ix) * a.Cs + pc);
+      const float4 v = ld4<kH16>(a.in, (ipix0 + (long)iy * IW + ix) * a.Cs + pc);
       if (a.is_max) {
         acc.x = fmaxf(acc.x, v.x); acc.y = fmaxf(acc.y, v.y); acc.z = fmaxf(acc.z, v.z); acc.w = fmaxf(acc.w, v.w);
       } else {
@@ -1443,9 +1486,10 @@ __global__ void __launch_bounds__(256) pool_kernel(const PoolArgs a) {
     const float d = (float)cnt;
     acc.x = acc.x / d; acc.y = acc.y / d; acc.z = acc.z / d; acc.w = acc.w / d;
   }
-  *(float4*)(a.out + m * a.Cs + pc) = acc;
+  st4<kH16>(a.out, m * a.Cs + pc, acc);
 }
-void launch_pool(const PoolArgs& a, hipStream_t s) {
+void OCR_L(launch_pool)(const PoolArgs& a, hipStream_t s) {
+  OCR_H16_TWIN(a.h16, launch_pool_h16(a, s))
   const long total = a.M * (a.Cs >> 2);
   hipLaunchKernelGGL(pool_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
 }
@@ -1458,27 +1502,26 @@ __global__ void __launch_bounds__(64) ln_kernel(const float* __restrict__ in, fl
                                                 const float* __restrict__ b) {
   const long r = (long)blockIdx.x * 64 + threadIdx.x;
   if (r >= rows) return;
-  const float* src = in + r * Cs;
-  float* dst = out + r * Cs;
+  const long src = r * Cs;  // element index of the token's first channel
   float s = 0.f;
-  for (int c = 0; c < C; ++c) s = s + src[c8i_phys(c)];
+  for (int c = 0; c < C; ++c) s = s + ld1<kH16>(in, src + c8i_phys(c));
   const float mean = s / (float)C;
   float v = 0.f;
   for (int c = 0; c < C; ++c) {
-    const float xm = src[c8i_phys(c)] - mean;
+    const float xm = ld1<kH16>(in, src + c8i_phys(c)) - mean;
     v = fmaf(xm, xm, v);
   }
   const float var = v / (float)C;
   const float rstd = 1.0f / sqrtf(var + eps);
   for (int c = 0; c < C; ++c) {
     const int pc = c8i_phys(c);
-    const float xm = src[pc] - mean;
+    const float xm = ld1<kH16>(in, src + pc) - mean;
     float t = xm * rstd;
     t = t * g[c];
-    dst[pc] = t + b[c];
+    st1<kH16>(out, src + pc, t + b[c]);
   }
   for (int pc = 0; pc < Cs; ++pc)
-    if (c8i_logical(pc) >= C) dst[pc] = 0.f;
+    if (c8i_logical(pc) >= C) st1<kH16>(out, src + pc, 0.f);
 }
 // Same arithmetic, memory access restructured for the channel counts without pad channels (C == Cs,
 // C % 8 == 0; 120 on the rec path): a workgroup moves 64 whole rows - one contiguous span of global
@@ -1496,11 +1539,9 @@ __global__ void __launch_bounds__(64) ln_tile_kernel(const float* __restrict__ i
   const long r0 = (long)blockIdx.x * 64;
   const int nrows = (int)(rows - r0 < 64 ? rows - r0 : 64);
   const int nvec = nrows * (C / 4);
-  const float4* __restrict__ src = (const float4*)(in + r0 * C);
-  float4* __restrict__ dstv = (float4*)(out + r0 * C);
 #pragma unroll 6
   for (int i = lane; i < nvec; i += 64) {
-    const float4 v = src[i];
+    const float4 v = ld4<kH16>(in, r0 * C + 4L * i);
     const int row = i / (C / 4), col = (i - row * (C / 4)) * 4;
     float* d = s_x + row * LS + col;
     d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
@@ -1537,12 +1578,13 @@ __global__ void __launch_bounds__(64) ln_tile_kernel(const float* __restrict__ i
   for (int i = lane; i < nvec; i += 64) {
     const int row = i / (C / 4), col = (i - row * (C / 4)) * 4;
     const float* d = s_x + row * LS + col;
-    dstv[i] = make_float4(d[0], d[1], d[2], d[3]);
+    st4<kH16>(out, r0 * C + 4L * i, make_float4(d[0], d[1], d[2], d[3]));
   }
 }
 
-void launch_ln(const float* in, float* out, long rows, int C, int Cs, float eps, const float* g, const float* b,
-               hipStream_t s) {
+void OCR_L(launch_ln)(const float* in, float* out, long rows, int C, int Cs, float eps, const float* g, const float* b,
+                      hipStream_t s, bool h16) {
+  OCR_H16_TWIN(h16, launch_ln_h16(in, out, rows, C, Cs, eps, g, b, s, h16))
   if (C == 120 && Cs == 120) {
     hipLaunchKernelGGL(ln_tile_kernel<120>, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, s, in, out, rows, eps, g, b);
     return;
@@ -1564,10 +1606,10 @@ __global__ void __launch_bounds__(64) attn_kernel(const float* __restrict__ qkv,
   const int hh = (int)((gid / T) % heads);
   const int n = (int)(gid / ((long)T * heads));
   const int D = heads * HD;
-  const float* base = qkv + (long)n * T * Cs_in;
+  const long base = (long)n * T * Cs_in;  // element index of the line's first token
   float q[HD];
 #pragma unroll
-  for (int d = 0; d < HD; ++d) q[d] = base[(long)t * Cs_in + c8i_phys(hh * HD + d)] * scale;
+  for (int d = 0; d < HD; ++d) q[d] = ld1<kH16>(qkv, base + (long)t * Cs_in + c8i_phys(hh * HD + d)) * scale;
   int kp[HD], vp[HD];
 #pragma unroll
   for (int d = 0; d < HD; ++d) {
@@ -1576,36 +1618,36 @@ __global__ void __launch_bounds__(64) attn_kernel(const float* __restrict__ qkv,
   }
   float mx = -INFINITY;
   for (int u = 0; u < T; ++u) {
-    const float* kr = base + (long)u * Cs_in;
+    const long kr = base + (long)u * Cs_in;
     float acc = 0.f;
 #pragma unroll
-    for (int d = 0; d < HD; ++d) acc = fmaf(q[d], kr[kp[d]], acc);
+    for (int d = 0; d < HD; ++d) acc = fmaf(q[d], ld1<kH16>(qkv, kr + kp[d]), acc);
     mx = fmaxf(mx, acc);
   }
   float sum = 0.f;
   for (int u = 0; u < T; ++u) {
-    const float* kr = base + (long)u * Cs_in;
+    const long kr = base + (long)u * Cs_in;
     float acc = 0.f;
 #pragma unroll
-    for (int d = 0; d < HD; ++d) acc = fmaf(q[d], kr[kp[d]], acc);
+    for (int d = 0; d < HD; ++d) acc = fmaf(q[d], ld1<kH16>(qkv, kr + kp[d]), acc);
     sum = sum + ocr_expf(acc - mx);
   }
   float o[HD];
 #pragma unroll
   for (int d = 0; d < HD; ++d) o[d] = 0.f;
   for (int u = 0; u < T; ++u) {
-    const float* kr = base + (long)u * Cs_in;
+    const long kr = base + (long)u * Cs_in;
     float acc = 0.f;
 #pragma unroll
-    for (int d = 0; d < HD; ++d) acc = fmaf(q[d], kr[kp[d]], acc);
+    for (int d = 0; d < HD; ++d) acc = fmaf(q[d], ld1<kH16>(qkv, kr + kp[d]), acc);
     const float e = ocr_expf(acc - mx);
     const float pw = e / sum;
 #pragma unroll
-    for (int d = 0; d < HD; ++d) o[d] = fmaf(pw, kr[vp[d]], o[d]);
+    for (int d = 0; d < HD; ++d) o[d] = fmaf(pw, ld1<kH16>(qkv, kr + vp[d]), o[d]);
   }
-  float* dst = out + ((long)n * T + t) * Cs_out;
+  const long dst = ((long)n * T + t) * Cs_out;
 #pragma unroll
-  for (int d = 0; d < HD; ++d) dst[c8i_phys(hh * HD + d)] = o[d];
+  for (int d = 0; d < HD; ++d) st1<kH16>(out, dst + c8i_phys(hh * HD + d), o[d]);
 }
 // Same chains with the operands staged: one wave per (line n, head).  K and V rows of the head sit in
 // LDS (16-float rows, every lane reads the same row: broadcast), the scaled q row in registers, and the
@@ -1626,18 +1668,18 @@ __global__ void __launch_bounds__(64) attn_lds_kernel(const float* __restrict__ 
   float* s_q = s_v + (long)T * 16;    // [64][17]
   float* s_e = s_q + 64 * 17;         // [T][64]
   const int D = heads * HD;
-  const float* base = qkv + row0 * Cs_in;
+  const long base = row0 * Cs_in;  // element index of the line's first token
   for (int i = lane; i < T * 32; i += 64) {
     const int u = i >> 5, which = (i >> 4) & 1, d = i & 15;
     float val = 0.f;
-    if (d < HD) val = base[(long)u * Cs_in + c8i_phys((1 + which) * D + hh * HD + d)];
+    if (d < HD) val = ld1<kH16>(qkv, base + (long)u * Cs_in + c8i_phys((1 + which) * D + hh * HD + d));
     (which ? s_v : s_k)[u * 16 + d] = val;
   }
   for (int t0 = 0; t0 < T; t0 += 64) {
     __syncthreads();  // K/V staged (first chunk); previous chunk's q rows consumed (later chunks)
     for (int i = lane; i < 64 * 16; i += 64) {
       const int tq = i >> 4, d = i & 15;
-      if (d < HD && t0 + tq < T) s_q[tq * 17 + d] = base[(long)(t0 + tq) * Cs_in + c8i_phys(hh * HD + d)];
+      if (d < HD && t0 + tq < T) s_q[tq * 17 + d] = ld1<kH16>(qkv, base + (long)(t0 + tq) * Cs_in + c8i_phys(hh * HD + d));
     }
     __syncthreads();
     const int t = t0 + lane;
@@ -1673,16 +1715,19 @@ __global__ void __launch_bounds__(64) attn_lds_kernel(const float* __restrict__ 
 #pragma unroll
         for (int d = 0; d < HD; ++d) o[d] = fmaf(pw, vr[d], o[d]);
       }
-      float* dst = out + (row0 + t) * Cs_out;
+      const long dst = (row0 + t) * Cs_out;
 #pragma unroll
-      for (int d = 0; d < HD; ++d) dst[c8i_phys(hh * HD + d)] = o[d];
+      for (int d = 0; d < HD; ++d) st1<kH16>(out, dst + c8i_phys(hh * HD + d), o[d]);
     }
   }
 }
 
+#ifndef OCR_TU_H16
 bool attn_ragged_fits(int T) { return ((size_t)T * 96 + 64 * 17) * sizeof(float) <= 150 * 1024; }
-void launch_attn(const float* qkv, float* out, int N, int T, int heads, int hd, int Cs_in, int Cs_out, float scale,
-                 hipStream_t s, RagLevel rag) {
+#endif
+void OCR_L(launch_attn)(const float* qkv, float* out, int N, int T, int heads, int hd, int Cs_in, int Cs_out, float scale,
+                        hipStream_t s, RagLevel rag, bool h16) {
+  OCR_H16_TWIN(h16, launch_attn_h16(qkv, out, N, T, heads, hd, Cs_in, Cs_out, scale, s, rag, h16))
   const size_t lds = ((size_t)T * 96 + 64 * 17) * sizeof(float);
   if (lds <= 150 * 1024) {
     static LdsAttrMemo attr_state;  // per device: the pool drives several from one process
@@ -1699,6 +1744,7 @@ void launch_attn(const float* qkv, float* out, int N, int T, int heads, int hd, 
                      Cs_out, scale);
 }
 
+#ifndef OCR_TU_H16  // (plain f32 logits and partials in both precisions)
 // =====================================================================================
 // Row softmax over plain [rows][C] + greedy-CTC inputs (arg max / max prob per row).
 // Canonical order (the same in conv_finish<OUT_HEAD> + head_combine_kernel and in
@@ -1787,6 +1833,7 @@ void launch_head_combine(const float* hmax, const float* hsum, const int* hidx, 
   hipLaunchKernelGGL(head_combine_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, hmax, hsum, hidx, rows, groups,
                      amax, pmax);
 }
+#endif  // OCR_TU_H16
 
 // =====================================================================================
 // DB head tail: deconv 2x2 s2 (Cin -> 1) + bias + sigmoid, fused with the reference's
@@ -1799,7 +1846,7 @@ __global__ void __launch_bounds__(256) det_tail_kernel(const DetTailArgs a) {
   if (m >= a.M) return;
   int n, y, x;
   decompose(m, a.H * a.W, a.W, n, y, x);
-  const float* src = a.in + m * a.Cs;
+  const long src = m * a.Cs;  // element index of the pixel's first channel
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
   // The pixel's channels arrive as two 16-byte loads per octet (C8I: evens, then odds) and are consumed in
   // ascending logical order c = 8o, 8o+1, ... - the same fma chain as a channel-by-channel walk.
@@ -1817,11 +1864,11 @@ __global__ void __launch_bounds__(256) det_tail_kernel(const DetTailArgs a) {
   if (a.Cs == 24) {  // the DB head: the pixel's six 16-byte loads in flight before the first FMA (same chain order)
     float4 r[6];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) r[k] = *(const float4*)(src + 4 * k);
+    for (int k = 0; k < 6; ++k) r[k] = ld4<kH16>(a.in, src + 4 * k);
 #pragma unroll
     for (int k = 0; k < 3; ++k) octet(8 * k, r[2 * k], r[2 * k + 1]);
   } else {
-    for (int o8 = 0; o8 < a.Cs; o8 += 8) octet(o8, *(const float4*)(src + o8), *(const float4*)(src + o8 + 4));
+    for (int o8 = 0; o8 < a.Cs; o8 += 8) octet(o8, ld4<kH16>(a.in, src + o8), ld4<kH16>(a.in, src + o8 + 4));
   }
   float pr[4];
 #pragma unroll
@@ -1843,7 +1890,8 @@ __global__ void __launch_bounds__(256) det_tail_kernel(const DetTailArgs a) {
     }
   }
 }
-void launch_det_tail(const DetTailArgs& a, hipStream_t s) {
+void OCR_L(launch_det_tail)(const DetTailArgs& a, hipStream_t s) {
+  OCR_H16_TWIN(a.h16, launch_det_tail_h16(a, s))
   hipLaunchKernelGGL(det_tail_kernel, dim3((unsigned)((a.M + 255) / 256)), dim3(256), 0, s, a);
 }
 
@@ -1872,10 +1920,9 @@ __global__ void __launch_bounds__(256) db_head_kernel(const DbHeadArgs a) {
     opix0 = (long)n * 16 * a.H * a.W;
   }
   // the pixel's channels in LOGICAL order (C8I: an octet's evens, then its odds), all loads in flight at once
-  const float* src = a.in + m * a.Cs;
   float4 r[C / 4];
 #pragma unroll
-  for (int k = 0; k < C / 4; ++k) r[k] = *(const float4*)(src + 4 * k);
+  for (int k = 0; k < C / 4; ++k) r[k] = ld4<kH16>(a.in, m * a.Cs + 4 * k);
   float xl[C];
 #pragma unroll
   for (int o = 0; o < C / 8; ++o) {
@@ -1934,7 +1981,8 @@ __global__ void __launch_bounds__(256) db_head_kernel(const DbHeadArgs a) {
     }
   }
 }
-bool launch_db_head(const DbHeadArgs& a, int C, hipStream_t s) {
+bool OCR_L(launch_db_head)(const DbHeadArgs& a, int C, hipStream_t s) {
+  OCR_H16_TWIN(a.h16, launch_db_head_h16(a, C, s))
   if (C != 24 || a.Cs != 24) return false;
   hipLaunchKernelGGL(db_head_kernel<24>, dim3((unsigned)((a.M + 255) / 256)), dim3(256), 0, s, a);
   return true;
@@ -1947,12 +1995,14 @@ __global__ void __launch_bounds__(256) c8i_to_plain_kernel(const float* __restri
   if (t >= M * C) return;
   const long m = t / C;
   const int c = (int)(t - m * C);
-  out[t] = in[m * Cs + c8i_phys(c)];
+  out[t] = ld1<kH16>(in, m * Cs + c8i_phys(c));
 }
-void launch_c8i_to_plain(const float* in, float* out, long M, int C, int Cs, hipStream_t s) {
+void OCR_L(launch_c8i_to_plain)(const float* in, float* out, long M, int C, int Cs, hipStream_t s, bool h16) {
+  OCR_H16_TWIN(h16, launch_c8i_to_plain_h16(in, out, M, C, Cs, s, h16))
   hipLaunchKernelGGL(c8i_to_plain_kernel, dim3((unsigned)((M * C + 255) / 256)), dim3(256), 0, s, in, out, M, C, Cs);
 }
 
+#ifndef OCR_TU_H16
 // ---- numerics probe (tests): does the hardware match the arithmetic contract? ----
 __global__ void probe_kernel(const float* a, const float* b, float* out, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1974,5 +2024,9 @@ __global__ void probe_kernel(const float* a, const float* b, float* out, int n) 
 void launch_probe(const float* a, const float* b, float* out, int n, hipStream_t s) {
   hipLaunchKernelGGL(probe_kernel, dim3((n + 255) / 256), dim3(256), 0, s, a, b, out, n);
 }
+#endif  // OCR_TU_H16
 
+#ifdef OCR_TU_H16
+}  // namespace h16
+#endif
 }  // namespace ocr

@@ -49,6 +49,8 @@ bool parse_plan(const char* text, Plan& plan, std::string& err);
 struct TensorDesc {
   int n = 0, h = 0, w = 0, c = 0, cs = 0;
   bool plain = false;  // logical channel order, cs == c
+  bool f16 = false;    // precision "fp16": a C8I activation tensor stored as f16 (same element indices; its arena slot keeps
+                       // the f32 size).  Plain tensors (input, maps, logits) and the per-image vectors (pools, SE gates) stay f32
   size_t offset = 0;   // floats into the arena
   // ragged batch (Net::run_ragged): the tensor's width level (-1: a uniform tensor, e.g. the per-line SE vectors) and
   // its pixel count h * sum of the lines' widths at that level; `w` is then the widest line
@@ -68,9 +70,10 @@ struct KernelTiming {
 class Net {
  public:
   ~Net();
-  // half (precision "fp16"): the matrix-core products (dense convs, linears, transposed convs, the 1x1
-  // half of the fused depthwise blocks) run in f16 with f32 accumulation on operands rounded to f16; storage, the VALU
-  // kernels (stem, depthwise, SE, layer norm, attention, softmax, the fused DB head) and every reduction stay f32
+  // half (precision "fp16"): the C8I activation tensors are stored as f16 and the matrix-core products
+  // (dense convs, linears, transposed convs, the 1x1 half of the fused depthwise blocks) run as f16 instructions with f32
+  // accumulation; every VALU chain (stem, depthwise taps, epilogues, SE, layer norm, attention, softmax, the fused DB head)
+  // and every reduction computes in f32 on values converted up, and rounds once when it stores
   bool load(const char* plan_text, const WeightMap& weights, std::string& err, bool half = false);
   bool half() const { return half_; }
   // Binds shapes (re-planning arena + launches if they changed) and enqueues the network.

@@ -216,6 +216,17 @@ bool Net::load(const char* plan_text, const WeightMap& W, std::string& err, bool
   }
   tensors_.assign(plan_.ntensors, TensorDesc());
   for (int i = 0; i < plan_.ntensors; ++i) tensors_[i].plain = plain[i];
+  // precision "fp16": every C8I activation tensor is stored as f16, except the per-image vectors (pool results, SE gates and
+  // what is computed from them): they are reduction results, a few KB, and feed every pixel of their image
+  if (half_) {
+    std::vector<char> vec(plan_.ntensors, 0);
+    for (auto& op : plan_.ops) {
+      if (op.out < 0) continue;
+      if (op.kind == PlanOp::GAP || op.kind == PlanOp::SEFC) vec[op.out] = 1;
+      else if (op.kind == PlanOp::EW && op.in >= 0 && vec[op.in]) vec[op.out] = 1;
+    }
+    for (int i = 0; i < plan_.ntensors; ++i) tensors_[i].f16 = !plain[i] && !vec[i];
+  }
 
   for (auto& op : plan_.ops) {
     // epilogue parameter images
@@ -388,10 +399,15 @@ bool Net::build_epilogue(const PlanOp& op, Epilogue& ep, bool conv_path, std::st
       case EP_BN: e.v0 = dev_vec("bns:" + st.n0); e.v1 = dev_vec("bnt:" + st.n0); break;
       case EP_ACT: break;
       case EP_MULC: case EP_GATERES:
+        if (tensors_[st.tid].f16) { err = "precision fp16: a gate operand must be a per-image f32 vector"; return false; }
         e.v0 = tensor_ptr(st.tid);
         break;
-      case EP_ADDT: e.v0 = tensor_ptr(st.tid); break;
+      case EP_ADDT:
+        if (tensors_[st.tid].f16 != tensors_[op.out].f16) { err = "precision fp16: a residual operand of another storage type"; return false; }
+        e.v0 = tensor_ptr(st.tid);
+        break;
       case EP_ADDUP:
+        if (tensors_[st.tid].f16 != tensors_[op.out].f16) { err = "precision fp16: an upsampled operand of another storage type"; return false; }
         e.v0 = tensor_ptr(st.tid);
         e.a0 = st.up;
         e.a1 = tensors_[st.tid].w;
@@ -733,6 +749,7 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths, const i
           const int tiles = (T[c.out].cs + 31) / 32, nt = conv_nt_for(tiles);
           q.c.NTtot = (tiles + nt - 1) / nt * nt;
           q.dw_ep.act = q.pw_ep.act = 1;
+          q.c.half = half_ ? 1 : 0;  // (the f16 build's instance: its own LDS attribute)
           if (rag) q.rtiles = rag_dev;  // (the ragged instantiation is its own kernel: own LDS attribute)
           if (d.kh == d.kw && launch_dwpw(q, nullptr, true)) dwpw_of[oj] = oi;
         }
@@ -919,6 +936,7 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths, const i
     gap_part_cap_ = gap_need;
   }
   // 3. launches
+  auto EB = [](const TensorDesc& t) { return t.f16 ? 2.0 : 4.0; };  // bytes per stored element (the launches' algorithmic bytes)
   char nm[160];
   for (int oi = 0; oi < nops; ++oi) {
     if (plan_.ops[oi].kind == PlanOp::OUTPUT || folded[oi] || fused_dw[oi]) continue;
@@ -969,11 +987,12 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths, const i
       a.in = arena_ + in.offset; a.w = dev_vec("rsw:" + op.w); a.part = gap_part_;
       a.rows = rag ? rows_of(in) : (long)in.n * in.h; a.W = in.w; a.Cin = op.cin; a.Cs_in = in.cs; a.Cs_out = o.cs;
       a.N = in.n; a.H = in.h; a.rag = rlevel(in);
+      a.h16 = in.f16;
       if (!a.w) { err = "RSE block: no row-sum weight image for " + op.w; return false; }
       snprintf(nm, sizeof nm, "%s.%02d.conv1x1_%d_%d_rowsum", plan_.name.c_str(), oi, op.cin, op.cout);
       L.name = nm;
       L.flops = 2.0 * in.pixels() * op.cin * op.cout;
-      L.bytes = 4.0 * ((double)in.pixels() * op.cin + (double)a.rows * op.cout);
+      L.bytes = EB(in) * in.pixels() * op.cin + 4.0 * a.rows * op.cout;
       L.fn = [this, a](hipStream_t s) {
         if (!launch_conv_rowsum(a, s)) this->launch_error_ = "launch_conv_rowsum: shape accepted at bind time was refused at launch";
       };
@@ -990,11 +1009,13 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths, const i
           a.KH = op.kh; a.KW = op.kw; a.SH = op.sh; a.SW = op.sw; a.PH = op.ph; a.PW = op.pw;
           a.M = o.pixels();
           a.rin = rlevel(in); a.rout = rlevel(o);
+          a.h16 = o.f16;
+          if (in.f16) { err = "stem input must be the plain f32 image"; return false; }
           if (o.cs != 8 && o.cs != 16) { err = "stem width not on this path"; return false; }
           snprintf(nm, sizeof nm, "%s.%02d.stem%dx%d_3_%d", plan_.name.c_str(), oi, op.kh, op.kw, op.cout);
           L.name = nm;
           L.flops = 2.0 * a.M * op.kh * op.kw * 3 * op.cout;
-          L.bytes = 4.0 * ((double)in.numel() + (double)a.M * op.cout);
+          L.bytes = 4.0 * in.numel() + EB(o) * a.M * op.cout;
           const bool ext_in = (op.in == 0);
           const float* in_ptr = ext_in ? nullptr : arena_ + in.offset;
           L.fn = [this, a, ep, ext_in, in_ptr](hipStream_t s) mutable {
@@ -1012,10 +1033,11 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths, const i
           a.in = arena_ + in.offset; a.prob = optr; a.bitmap = det_bitmap_; a.w = dev_vec("tail:" + op.w);
           a.N = in.n; a.H = in.h; a.W = in.w; a.C = op.cin; a.Cs = in.cs; a.bias = bias; a.ithresh = det_ithresh_;
           a.M = in.pixels();
+          a.h16 = in.f16;
           snprintf(nm, sizeof nm, "%s.%02d.det_tail", plan_.name.c_str(), oi);
           L.name = nm;
           L.flops = 2.0 * a.M * op.cin * 4;
-          L.bytes = 4.0 * a.M * op.cin + 4.0 * a.M * 4 + (det_bitmap_ ? 1.0 * a.M * 4 : 0.0);
+          L.bytes = EB(in) * a.M * op.cin + 4.0 * a.M * 4 + (det_bitmap_ ? 1.0 * a.M * 4 : 0.0);
           L.fn = [a](hipStream_t s) { launch_det_tail(a, s); };
           if (img && dbhead_of[oi] < 0) { err = "ragged batch of images: the DB head needs its fused kernel (OCR_FUSE_DBHEAD, production launch list)"; return false; }
           if (dbhead_of[oi] >= 0) {
@@ -1028,11 +1050,12 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths, const i
             h.w1 = dev_vec("dbh1:" + d.w); h.bias1 = epd.st[0].v0; h.bn_s = epd.st[1].v0; h.bn_t = epd.st[1].v1;
             h.w2 = a.w; h.M = din.pixels(); h.N = din.n; h.H = din.h; h.W = din.w; h.Cs = din.cs;
             h.bias2 = a.bias; h.ithresh = a.ithresh;
+            h.h16 = din.f16;
             if (img) h.rin = rlevel(din);
             snprintf(nm, sizeof nm, "%s.%02d.db_head_%d", plan_.name.c_str(), dbhead_of[oi], d.cin);
             L.name = nm;
             L.flops = 2.0 * h.M * (4.0 * d.cin * d.cout + 16.0 * d.cout);
-            L.bytes = 4.0 * h.M * d.cin + 4.0 * h.M * 16 + (det_bitmap_ ? 1.0 * h.M * 16 : 0.0);
+            L.bytes = EB(din) * h.M * d.cin + 4.0 * h.M * 16 + (det_bitmap_ ? 1.0 * h.M * 16 : 0.0);
             const int C = d.cin;
             L.fn = [this, h, C](hipStream_t s) {
               if (!launch_db_head(h, C, s)) this->launch_error_ = "launch_db_head: shape accepted at bind time was refused at launch";
@@ -1041,8 +1064,12 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths, const i
         } else {
           if (!build_epilogue(op, ep, true, err)) return false;
           ConvArgs a{};
-          a.in = arena_ + in.offset; a.out = optr; a.wfrag = dev_vec((half_ ? "frag16:" : "frag:") + op.w);
-          a.half = half_ ? 1 : 0;
+          // precision "fp16": a conv on an f16 tensor runs in f16; one on a per-image f32 vector (the classifier's pool -> fc)
+          // keeps the f32 kernel and fragments
+          const bool hconv = half_ && in.f16;
+          a.in = arena_ + in.offset; a.out = optr; a.wfrag = dev_vec((hconv ? "frag16:" : "frag:") + op.w);
+          a.half = hconv ? 1 : 0;
+          if (!o.plain && o.f16 != in.f16) { err = "precision fp16: a dense conv between tensors of different storage"; return false; }
           a.N = in.n; a.H = in.h; a.W = in.w; a.Cs_in = in.cs; a.C8 = in.cs / 8;
           a.KH = op.kh; a.KW = op.kw; a.PH = op.ph; a.PW = op.pw;
           a.need_nyx = 0;
@@ -1101,14 +1128,14 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths, const i
           const double cols = op.kind == PlanOp::DECONV ? 4.0 * op.cout : op.cout;
           L.flops = 2.0 * a.M * taps * op.cin * cols;
           if (a.gate) L.name += "_gated";
-          L.bytes = 4.0 * ((double)a.M * op.cin + (a.out_mode == OUT_HEAD ? 3.0 * a.M * (a.NTtot / nt) : (double)a.M * cols) +
-                           (double)taps * op.cin * cols);
+          L.bytes = EB(in) * a.M * op.cin + (a.out_mode == OUT_HEAD ? 12.0 * a.M * (a.NTtot / nt) : EB(o) * a.M * cols) +
+                    (hconv ? 2.0 : 4.0) * taps * op.cin * cols;
           // OCR_CONV_IMPL=direct|lds overrides the choice (A/B measurements); results are identical
           // measured (gpurun_out r1g): LDS staging wins for multi-tap convs (3x3 96->24: 58 vs 51 TFLOP/s),
           // the direct kernel for 1x1 (480->480: 88 vs 71; thin K: 54 vs 39)
           const int impl = rt_options().conv_impl;
           // precision "fp16": the LDS-staged and the 4x4x1 kernels are f32 only - every dense conv goes through the direct kernel
-          const bool use_lds = !half_ && !a.gate && a.out_mode == OUT_C8I && (impl ? impl == 2 : (taps > 1 && in.cs >= 64));
+          const bool use_lds = !hconv && !a.gate && a.out_mode == OUT_C8I && (impl ? impl == 2 : (taps > 1 && in.cs >= 64));
           if (dwpw_of[oi] >= 0) {
             const PlanOp& d = plan_.ops[dwpw_of[oi]];
             const TensorDesc& din = T[d.in];
@@ -1130,7 +1157,8 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths, const i
             snprintf(nm, sizeof nm, "%s.%02d.dwpw%dx%d_%d_%d_s%d%d", plan_.name.c_str(), dwpw_of[oi], d.kh, d.kw, op.cin, op.cout, d.sh, d.sw);
             L.name = nm;
             L.flops += 2.0 * a.M * d.kh * d.kw * d.c;
-            L.bytes = 4.0 * ((double)din.pixels() * d.c + (double)a.M * cols + (double)op.cin * cols + (double)d.kh * d.kw * d.c);
+            if (din.f16 != (half_ != 0)) { err = "precision fp16: a fused depthwise block on an f32 tensor is not on this path"; return false; }
+            L.bytes = EB(din) * din.pixels() * d.c + EB(o) * a.M * cols + (half_ ? 2.0 : 4.0) * op.cin * cols + 4.0 * d.kh * d.kw * d.c;
             L.fn = [this, f](hipStream_t s) {
               if (!launch_dwpw(f, s)) this->launch_error_ = "launch_dwpw: shape accepted at bind time was refused at launch";
             };
@@ -1160,7 +1188,7 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths, const i
             const bool mt2 = rt_options().conv_mt2 && (nt == 3 || nt == 4) && taps == 1 && a.out_mode == OUT_C8I &&
                              (rt_options().conv_mt2_force || (ntl == nt && in.cs >= 192 && ((a.M + 255) / 256) * (long)(a.NTtot / nt) >= 1024));
             if (mt2) ntl = nt;  // (the two-tile kernel is instantiated for the table's NT)
-            const bool half_tile = half_ && taps == 9 && !rag;  // precision "fp16": the LDS-resident 3x3 tile kernel has an f16 form
+            const bool half_tile = hconv && taps == 9 && !rag;  // precision "fp16": the LDS-resident 3x3 tile kernel has an f16 form
             L.fn = [this, a, ep, ntl, nt, mt2, half_tile](hipStream_t s) {
               if (half_tile && launch_conv3x3_tile(a, ep, nt, s)) return;
               if (mt2 && launch_conv_mfma_mt2(a, ep, ntl, s)) return;
@@ -1179,6 +1207,8 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths, const i
         a.N = in.n; a.H = in.h; a.W = in.w; a.OH = o.h; a.OW = o.w; a.Cs = o.cs; a.K = op.kh;
         a.SH = op.sh; a.SW = op.sw; a.PH = op.ph; a.PW = op.pw; a.M = o.pixels();
         if (dw_rowsum[oi]) a.rowsum = gap_part_;
+        a.h16 = o.f16;
+        if (in.f16 != o.f16) { err = "precision fp16: depthwise conv between tensors of different storage"; return false; }
         if (rag) {
           a.rin = rlevel(in); a.rout = rlevel(o);
           a.OW = min_w(o);            // the launcher picks its patch from the narrowest / lowest sample
@@ -1195,7 +1225,7 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths, const i
         snprintf(nm, sizeof nm, "%s.%02d.dw%dx%d_%d_s%d%d%s", plan_.name.c_str(), oi, op.kh, op.kw, op.c, op.sh, op.sw, dw_rowsum[oi] ? "_rowsum" : "");
         L.name = nm;
         L.flops = 2.0 * a.M * op.kh * op.kw * op.c;
-        L.bytes = 4.0 * ((double)in.pixels() * op.c + (double)a.M * op.c);
+        L.bytes = EB(in) * in.pixels() * op.c + EB(o) * a.M * op.c;
         L.fn = [a, ep](hipStream_t s) { launch_dw(a, ep, s); };
       } break;
       case PlanOp::EW: {
@@ -1210,8 +1240,10 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths, const i
         const int nl = o.n;
         snprintf(nm, sizeof nm, "%s.%02d.ew_%d", plan_.name.c_str(), oi, op.c);
         L.name = nm;
-        L.bytes = 4.0 * M * op.c * (2.0 + (double)op.ep.size() - 1.0);
-        L.fn = [ip, optr, M, H2, W2, Cs, ep, nl, rl](hipStream_t s) { launch_ew(ip, optr, M, H2, W2, Cs, ep, s, nl, rl); };
+        L.bytes = EB(o) * M * op.c * (2.0 + (double)op.ep.size() - 1.0);
+        const bool h16 = o.f16;
+        if (in.f16 != o.f16) { err = "precision fp16: elementwise op between tensors of different storage"; return false; }
+        L.fn = [ip, optr, M, H2, W2, Cs, ep, nl, rl, h16](hipStream_t s) { launch_ew(ip, optr, M, H2, W2, Cs, ep, s, nl, rl, h16); };
       } break;
       case PlanOp::GAP: {
         const TensorDesc& in = T[op.in];
@@ -1222,12 +1254,13 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths, const i
         const long grows = rag ? rows_of(in) : 0;
         snprintf(nm, sizeof nm, "%s.%02d.gap_%d", plan_.name.c_str(), oi, op.c);
         L.name = nm;
-        L.bytes = 4.0 * (double)in.pixels() * op.c;
+        L.bytes = EB(in) * in.pixels() * op.c;
+        const bool h16 = in.f16;
         if (oi > 0 && (dw_rowsum[oi - 1] || rse_first[oi - 1])) {  // the row sums are already in `part` (written by the depthwise conv / the conv's row-sum pass before this op)
           L.bytes = 4.0 * (double)n * h * op.c;
           L.fn = [part, optr, n, h, w, cs, rl](hipStream_t s) { launch_gap_cols(part, optr, n, h, w, cs, s, rl); };
         } else
-        L.fn = [ip, part, optr, n, h, w, cs, rl, grows](hipStream_t s) { launch_gap(ip, part, optr, n, h, w, cs, s, rl, grows); };
+        L.fn = [ip, part, optr, n, h, w, cs, rl, grows, h16](hipStream_t s) { launch_gap(ip, part, optr, n, h, w, cs, s, rl, grows, h16); };
       } break;
       case PlanOp::SEFC: {
         const TensorDesc& in = T[op.in];
@@ -1253,12 +1286,14 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths, const i
         for (int j = 0; j < a.nsrc; ++j) {
           const TensorDesc& sj = T[op.ins[j]];
           if (sj.c % 8) { err = "concat source channels must be a multiple of 8"; return false; }
+          if (sj.f16 != o.f16) { err = "precision fp16: concat of tensors of different storage"; return false; }
           a.src[j] = arena_ + sj.offset; a.coff[j] = off; a.scs[j] = sj.cs; a.up[j] = op.ups[j];
           off += sj.cs;
         }
         snprintf(nm, sizeof nm, "%s.%02d.concat_%d", plan_.name.c_str(), oi, op.c);
         L.name = nm;
-        L.bytes = 8.0 * a.M * op.c;
+        a.h16 = o.f16;
+        L.bytes = 2.0 * EB(o) * a.M * op.c;
         L.fn = [a](hipStream_t s) { launch_concat(a, s); };
       } break;
       case PlanOp::POOL: {
@@ -1268,9 +1303,11 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths, const i
         a.Cs = o.cs; a.KH = op.kh; a.KW = op.kw; a.SH = op.sh; a.SW = op.sw; a.is_max = op.pool_max;
         a.M = o.pixels();
         a.rin = rlevel(in); a.rout = rlevel(o);
+        a.h16 = o.f16;
+        if (in.f16 != o.f16) { err = "precision fp16: pool between tensors of different storage"; return false; }
         snprintf(nm, sizeof nm, "%s.%02d.pool_%d", plan_.name.c_str(), oi, op.c);
         L.name = nm;
-        L.bytes = 4.0 * ((double)in.pixels() * op.c + (double)a.M * op.c);
+        L.bytes = EB(in) * in.pixels() * op.c + EB(o) * a.M * op.c;
         L.fn = [a](hipStream_t s) { launch_pool(a, s); };
       } break;
       case PlanOp::LN: {
@@ -1283,8 +1320,10 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths, const i
         const float* b = dev_vec("raw:" + op.b);
         snprintf(nm, sizeof nm, "%s.%02d.ln_%d", plan_.name.c_str(), oi, op.c);
         L.name = nm;
-        L.bytes = 8.0 * rows * C;
-        L.fn = [ip, optr, rows, C, Cs, eps, g, b](hipStream_t s) { launch_ln(ip, optr, rows, C, Cs, eps, g, b, s); };
+        L.bytes = 2.0 * EB(in) * rows * C;
+        const bool h16 = in.f16;
+        if (in.f16 != o.f16) { err = "precision fp16: layer norm between tensors of different storage"; return false; }
+        L.fn = [ip, optr, rows, C, Cs, eps, g, b, h16](hipStream_t s) { launch_ln(ip, optr, rows, C, Cs, eps, g, b, s, h16); };
       } break;
       case PlanOp::ATTN: {
         const TensorDesc& in = T[op.in];
@@ -1299,8 +1338,10 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths, const i
         snprintf(nm, sizeof nm, "%s.%02d.attn_%dx%d", plan_.name.c_str(), oi, op.heads, op.hd);
         L.name = nm;
         L.flops = 3.0 * 2.0 * heads * tt * hd + 2.0 * heads * tt * hd;
-        L.bytes = 4.0 * in.pixels() * (3.0 + 1.0) * heads * hd;
-        L.fn = [ip, optr, n, t, heads, hd, csi, cso, sc, rl](hipStream_t s) { launch_attn(ip, optr, n, t, heads, hd, csi, cso, sc, s, rl); };
+        L.bytes = EB(in) * in.pixels() * (3.0 + 1.0) * heads * hd;
+        const bool h16 = in.f16;
+        if (in.f16 != o.f16) { err = "precision fp16: attention between tensors of different storage"; return false; }
+        L.fn = [ip, optr, n, t, heads, hd, csi, cso, sc, rl, h16](hipStream_t s) { launch_attn(ip, optr, n, t, heads, hd, csi, cso, sc, s, rl, h16); };
       } break;
       case PlanOp::SOFTMAX: {
         const TensorDesc& in = T[op.in];
@@ -1529,7 +1570,7 @@ bool Net::fetch_logical(int tid, std::vector<float>& host, int dims[4], hipStrea
   }
   float* tmp = nullptr;
   HIP_OK(g_malloc(&tmp, host.size() * sizeof(float)));
-  launch_c8i_to_plain(arena_ + t.offset, tmp, M, t.c, t.cs, s);
+  launch_c8i_to_plain(arena_ + t.offset, tmp, M, t.c, t.cs, s, t.f16);  // (an f16 tensor arrives converted up: exact)
   hipError_t e = hipMemcpyAsync(host.data(), tmp, host.size() * sizeof(float), hipMemcpyDeviceToHost, s);
   if (e == hipSuccess) e = hipStreamSynchronize(s);
   (void)g_free(tmp);

@@ -233,7 +233,7 @@ def roof_of(flops, nbytes, ms, mfma_peak=FP32_MFMA_PEAK_TFLOPS):
 
 def fp16_leg(mk_pipe, run_of, ref_words, batch, steps, sync):
     """The opt-in precision = "fp16" mode (the reference's TensorRT precision switch, ocr_det.cpp:50-56) on the same
-    resident batch: f16 matrix products with f32 accumulation, f32 storage.  NEVER `value` - the
+    resident batch: f16 activation tensors, f16 matrix products with f32 accumulation.  NEVER `value` - the
     arithmetic is narrower than the reference's CPU path.  Reports its rate, how far its words are from the fp32 run's,
     and the roofline of ITS dominant kernel (HBM-bound: every kernel of this mode is below the f16 ridge)."""
     pipe = mk_pipe(0, "fp16")
@@ -264,7 +264,7 @@ def fp16_leg(mk_pipe, run_of, ref_words, batch, steps, sync):
            "stage_ms_last_step": dict(zip(("det", "cls", "rec"), stage)),
            "vs_fp32_words": {"words": tot, "identical_boxes": same_box / max(1, tot), "identical_id_sequences": same_ids / max(1, tot),
                              "max_abs_confidence_diff": dconf},
-           "what": "precision = \"fp16\" on every stage: v_mfma_f32_32x32x8_f16 on operands rounded to f16, f32 accumulation and storage; "
+           "what": "precision = \"fp16\" on every stage: activation tensors stored as f16, v_mfma_f32_32x32x8_f16 with f32 accumulation, reductions and epilogues in f32; "
                    "an extra key, never `value` (narrower arithmetic than the reference's CPU path)"}
     # its dominant kernel, on a single chain (as the fp32 roofline)
     pipe1 = mk_pipe(1, "fp16")
@@ -296,6 +296,13 @@ def fp16_leg(mk_pipe, run_of, ref_words, batch, steps, sync):
                            "algorithmic_bytes_per_launch": g["bytes"] / max(1, g["count"]), "tflops": roof["tflops"]}
     tot_ms = sum(v["ms"] for v in survey.values())
     out["network_kernel_ms_per_step"] = tot_ms
+    # the step as a whole, as roofline.step of the fp32 line: algorithmic work of every network launch over this leg's ms_per_step
+    sfl, sby = sum(v["flops"] for v in survey.values()), sum(v["bytes"] for v in survey.values())
+    sroof = roof_of(sfl, sby, out["ms_per_step"], FP16_MFMA_PEAK_TFLOPS)
+    out.setdefault("roofline", {})["step"] = {"flops": sfl, "algorithmic_bytes": sby, "ms": out["ms_per_step"], "tflops": sroof["tflops"],
+                                              "frac_mfma": sroof["frac_mfma"], "hbm_GBps_algorithmic": sroof["hbm_GBps_algorithmic"],
+                                              "frac_hbm": sroof["frac_hbm"], "bound": sroof["bound"],
+                                              "what": "f16 tensors: 2 bytes per activation element; peaks: dense f16 matrix pipe and 8 TB/s"}
     out["kernel_time_share_top5"] = {group_label(k, g_): round(g_["ms"] / tot_ms, 4) for k, g_ in
                                      sorted(kernel_groups(survey).items(), key=lambda kv: -kv[1]["ms"])[:5]}
     return out

@@ -56,8 +56,9 @@ typedef struct ocr_det_cfg {
   const char* det_db_score_mode; /* "fast" | "slow" */
   int use_dilation;
   /* "fp32": the bit-exact arithmetic contract (default).  "fp16": the reference's TensorRT precision switch
-   * (ocr_det.cpp:50-56) - matrix-core products in f16 with f32 accumulation on operands rounded to f16, everything else
-   * f32: results within a stated tolerance of fp32, not identical.  "int8" is rejected. */
+   * (ocr_det.cpp:50-56) - activation tensors stored as f16, matrix-core products as f16 instructions with f32 accumulation,
+   * every other chain and reduction in f32: results within a stated tolerance of fp32, not identical.
+   * "int8" is rejected. */
   const char* precision;
   int max_batch;         /* images per ocr_det_run_batch call the handle is sized for (>=1) */
   /* Which OpenCV the reference binary was built against, where two 4.x releases differ on this path (DESIGN.md

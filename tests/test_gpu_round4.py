@@ -319,8 +319,9 @@ def test_precision_parameter_fp16_is_accepted_and_int8_refused(pkg, built):
 
 
 def test_fp16_networks_stay_within_tolerance_of_the_f32_contract(pkg, built):
-    """precision = "fp16": matrix-core products in f16 (operands rounded to nearest even) with f32 accumulation; storage,
-    VALU kernels and reductions f32.  Tolerances against the ORACLE (the f32 contract), stated here:
+    """precision = "fp16": activation tensors stored as f16, matrix-core products in f16 with f32 accumulation; every VALU
+    chain and reduction in f32 on values converted up.  Tolerances against the ORACLE (the f32
+    contract), stated here:
       cls (the reference's real weights): softmax |d| <= 2e-3, labels identical;
       det (synthetic weights, logits up to ~10): probability map mean |d| <= 2e-3, 99 % of the pixels within 1e-2,
           thresholded bitmap (det_db_thresh 0.3) equal on >= 99.5 % of the pixels;
@@ -349,6 +350,40 @@ def test_fp16_networks_stay_within_tolerance_of_the_f32_contract(pkg, built):
     n.close()
     assert np.abs(y - want).max() <= 0.02 * want.max(), (np.abs(y - want).max(), want.max())
     assert (y.argmax(1) == want.argmax(1)).mean() >= 0.95
+
+
+def test_fp16_stores_its_activation_tensors_as_f16(pkg, built):
+    """precision = "fp16" keeps the C8I activation tensors in f16: every spatial tensor the classifier's
+    launch list materialises holds only values a float16 represents exactly, in both the plain and the production launch list;
+    the per-image vectors (pool results, SE gates), the logits and the probabilities stay f32; the fp32 mode's tensors are
+    NOT f16 values (the storage follows the mode, the tensors are not merely small)."""
+    rs = np.random.RandomState(4)
+    x = rs.randn(3, 48, 192, 3).astype(np.float32)
+    as_f16 = lambda t: np.array_equal(t, t.astype(np.float16).astype(np.float32))
+    for keep in (1, 2):
+        n16 = pkg.Net("cls", precision="fp16")
+        n16.forward(x, keep_all=keep)
+        spatial = vectors = 0
+        for tid in range(1, n16.num_tensors()):
+            if not n16.exists(tid):
+                continue
+            t = n16.fetch(tid)
+            if t.shape[1] * t.shape[2] > 1 and t.shape[3] > 2:
+                spatial += 1
+                assert as_f16(t), (keep, tid, t.shape)
+            elif t.shape[3] > 2:
+                vectors += 1
+        n16.close()
+        assert spatial >= 20 and vectors >= 9, (spatial, vectors)
+    n32 = pkg.Net("cls")
+    n32.forward(x, keep_all=1)
+    assert not as_f16(n32.fetch(3)) and not as_f16(n32.fetch(10))
+    # a pooled vector of the fp16 mode is an f32 mean of f16 values: generally not an f16 value itself
+    n16 = pkg.Net("cls", precision="fp16")
+    n16.forward(x, keep_all=1)
+    assert not as_f16(n16.fetch(4))
+    n16.close()
+    n32.close()
 
 
 def test_fp16_pipeline_agrees_with_fp32_on_the_benchmark_batch(pkg, built):

@@ -2,12 +2,17 @@
 // shapes the plans bind, with phases knocked out by -D switches (OCR_DWPW_NO_G / _NO_TAPS / _NO_MMA, OCR_PROBE_NOSTORE):
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I../../cpp-paddle-ocr_amd/csrc [-D...] -o dwpw_probe dwpw_probe.hip
 //   dwpw_probe N H W K SH SW Cin Cout      (H, W = depthwise INPUT size)
+// -DOCR_TU_H16=1: the precision "fp16" build of the kernel (f16 tensors and fragments)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
 #include "kernels_dwpw.hip"
 using namespace ocr;
+#ifdef OCR_TU_H16
+static bool probe_launch_h16(const DwPwArgs& a, hipStream_t s, bool query = false) { return launch_dwpw_h16(a, s, query); }
+#define launch_dwpw probe_launch_h16
+#endif
 namespace ocr {
 const RtOptions& rt_options() { static RtOptions o; return o; }
 std::shared_mutex& capture_mutex() { static std::shared_mutex m; return m; }
@@ -28,6 +33,9 @@ static void run(int N, int H, int W, int K, int SH, int SW, int cin, int cout) {
   a.dw_in = x; a.dw_w = dw; a.H = H; a.W = W; a.K = K; a.SH = SH; a.SW = SW; a.PH = a.PW = P;
   a.dw_ep = LabEp{vec, 1.01f, 0.5f, 0.99f, 0.01f, 1};  // bias | smul | sadd | hswish | smul | sadd, as in the plans
   a.pw_ep = a.dw_ep;
+#ifdef OCR_TU_H16
+  a.c.half = 1;  // (the buffers above keep their f32 sizes: zeros are zeros in either format)
+#endif
   if (!launch_dwpw(a, 0, true)) { printf("shape not on the fused path\n"); return; }
   launch_dwpw(a, 0);
   CK(hipDeviceSynchronize());

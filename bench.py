@@ -461,6 +461,8 @@ def main(argv=None):
         sys.exit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
     G = load_gather()
     stub = args.stub_pipeline
+    share_gpu = bool(os.environ.get("OCR_BENCH_SHARE_GPU")) and not stub
+    dev_index = 0 if share_gpu else local
     cfg = args.config
     if stub and cfg != "cfg2":
         sys.exit("--stub-pipeline rehearses cfg2 only")
@@ -510,6 +512,12 @@ def main(argv=None):
         if stub:
             backend = "gloo"
             dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        elif share_gpu:
+            # rehearsal on a one-GPU lease (OCR_BENCH_SHARE_GPU=1): every rank drives GPU 0 with the REAL pipeline; RCCL refuses
+            # two ranks on one device, so the records travel over gloo - launcher, pinning, sharding, gather and the neighbour
+            # re-check are the production ones.  The line says so (`rehearsal`); its rate is N pipelines sharing one GPU.
+            backend = "gloo"
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
         else:
             backend = "nccl"   # RCCL on ROCm
             torch.cuda.set_device(local)
@@ -525,7 +533,7 @@ def main(argv=None):
     else:
         from __graft_entry__ import load_package
         pkg = load_package()
-        mk_pipe = lambda phases=0, precision=None: pkg.Pipe(device=local, enable_cls=True, limit_side_len=960, rec_batch_num=16, rec_img_h=48,
+        mk_pipe = lambda phases=0, precision=None: pkg.Pipe(device=dev_index, enable_cls=True, limit_side_len=960, rec_batch_num=16, rec_img_h=48,
                                                             rec_img_w=320, phases=phases, precision=precision or args.precision)
         pipe = mk_pipe()
         sync = lambda: pkg.check(pkg.lib().ocr_dev_sync())
@@ -902,6 +910,8 @@ def main(argv=None):
         if per_rank:
             per_rank["images_per_sec"] = [batch * steps_done / s_ if s_ > 0 else 0.0 for s_ in per_rank["seconds"]] if cfg != "cfg4" else None
             out["per_rank"] = per_rank
+        if share_gpu:
+            out["rehearsal"] = "OCR_BENCH_SHARE_GPU: %d ranks drive GPU 0 with the real pipeline, records over gloo - a rehearsal of the N > 1 path on a one-GPU lease, not a scaling point" % n_ranks
         out["host"] = {"host_cores_allowed": cores_mine, "input_generation_s": input_gen_s, "input_generation_workers": workers,
                        "placement": placement}
         if n_ranks == 1 and not args.no_cpu_baseline and not stub and cfg == "cfg2":

@@ -131,6 +131,9 @@ struct DwArgs {
 };
 void launch_dw(const DwArgs& a, const Epilogue& ep, hipStream_t s);
 int dw_patch_to(int OW, int SW, int OH, int K);  // output pixels per thread along x the launcher will pick
+// the same conv with the haloed input region staged through LDS (kernels_dwlds.hip: 5x5, stride (1 | 2, 1), uniform batch or
+// ragged batch of lines, low maps); false: the shape is not on that path (launch_dw takes it).  query = true only asks.
+bool launch_dw_lds(const DwArgs& a, const Epilogue& ep, hipStream_t s, bool query = false);
 // the pool's second pass alone (column-sequential sums of the row sums, / count): after a depthwise conv with `rowsum`
 void launch_gap_cols(const float* part, float* out, int N, int H, int W, int Cs, hipStream_t s, RagLevel rag = RagLevel());
 
@@ -283,6 +286,7 @@ bool launch_conv_rowsum_h16(const ConvRowsumArgs& a, hipStream_t s);
 void launch_stem_h16(const StemArgs& a, const Epilogue& ep, hipStream_t s);
 void launch_dw_h16(const DwArgs& a, const Epilogue& ep, hipStream_t s);
 bool launch_dwpw_h16(const DwPwArgs& a, hipStream_t s, bool query);
+bool launch_dw_lds_h16(const DwArgs& a, const Epilogue& ep, hipStream_t s, bool query);
 void launch_ew_h16(const float* in, float* out, long M, int H, int W, int Cs, const Epilogue& ep, hipStream_t s, int N, RagLevel rag, bool h16);
 void launch_gap_h16(const float* in, float* part, float* out, int N, int H, int W, int Cs, hipStream_t s, RagLevel rag, long rows, bool h16);
 void launch_concat_h16(const ConcatArgs& a, hipStream_t s);

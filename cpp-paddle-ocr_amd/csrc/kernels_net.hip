@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "conv_device.h"
+#include "dw_epilogue.h"
 #include "kernels_net.h"
 
 // This file is compiled TWICE (build.py).  As it stands: the f32 contract - f32 tensors, v_mfma_f32_32x32x2_f32.  With
@@ -974,7 +975,7 @@ __global__ void __launch_bounds__(256, 2) dw_conv_kernel(const DwArgs a, const E
     sx_end = ROWSUM ? strips : sx_first + 1;
     ipix0 = rag_pix0(a.rin, n, a.H); opix0 = rag_pix0(a.rout, n, a.OH); orow0 = rag_row0(a.rout, n, a.OH);
   }
-  struct F4 { ocr_f2 lo, hi; };
+  using F4 = DwF4;
   F4 rsum[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) { rsum[r].lo = ocr_f2{0.f, 0.f}; rsum[r].hi = ocr_f2{0.f, 0.f}; }
@@ -1043,75 +1044,7 @@ __global__ void __launch_bounds__(256, 2) dw_conv_kernel(const DwArgs a, const E
   // epilogue: stage loop outside, the patch inside (one copy of each stage's code)
   const long obase = (opix0 + (long)y0 * OW + x0) * a.Cs + pc;
   const long orow = (long)OW * a.Cs;
-  for (int s = 0; s < ep.n; ++s) {
-    const EpStage& st = ep.st[s];
-#define OCR_DW_SWEEP(BODY)                                       \
-  _Pragma("unroll") for (int r = 0; r < R; ++r)                   \
-    _Pragma("unroll") for (int o = 0; o < TO; ++o) {              \
-      F4& v = acc[r][o];                                          \
-      BODY                                                        \
-    }
-    switch (st.kind) {
-      case EP_BIAS: {
-        const float4 b = *(const float4*)(st.v0 + pc);
-        const ocr_f2 blo = {b.x, b.y}, bhi = {b.z, b.w};
-        OCR_DW_SWEEP({ v.lo = v.lo + blo; v.hi = v.hi + bhi; })
-      } break;
-      case EP_SMUL: {
-        const ocr_f2 k = {st.p0, st.p0};
-        OCR_DW_SWEEP({ v.lo = k * v.lo; v.hi = k * v.hi; })
-      } break;
-      case EP_SADD: {
-        const ocr_f2 k = {st.p0, st.p0};
-        OCR_DW_SWEEP({ v.lo = v.lo + k; v.hi = v.hi + k; })
-      } break;
-      case EP_BN: {
-        const float4 sc = *(const float4*)(st.v0 + pc), sh = *(const float4*)(st.v1 + pc);
-        const ocr_f2 clo = {sc.x, sc.y}, chi = {sc.z, sc.w}, hlo = {sh.x, sh.y}, hhi = {sh.z, sh.w};
-        OCR_DW_SWEEP({
-          ocr_f2 u;
-          u = v.lo * clo; v.lo = u + hlo;
-          u = v.hi * chi; v.hi = u + hhi;
-        })
-      } break;
-      case EP_ACT: {
-        const float p0 = st.p0, p1 = st.p1;
-#define OCR_DW_ACT(KIND) OCR_DW_SWEEP({ v.lo.x = ocr_act(KIND, p0, p1, v.lo.x); v.lo.y = ocr_act(KIND, p0, p1, v.lo.y); v.hi.x = ocr_act(KIND, p0, p1, v.hi.x); v.hi.y = ocr_act(KIND, p0, p1, v.hi.y); })
-        switch (st.act) {
-          case ACT_RELU: OCR_DW_ACT(ACT_RELU) break;
-          case ACT_HSWISH: {
-            // range pass, then the division-free sweep (ocr_common.h); anything out of range takes the division
-            float mn = INFINITY, mx = 0.0f;
-            OCR_DW_SWEEP({ ocr_absrange(mn, mx, v.lo.x, v.lo.y); ocr_absrange(mn, mx, v.hi.x, v.hi.y); })
-            if (ocr_hsw_fast_ok(mn, mx)) { OCR_DW_SWEEP({ v.lo = ocr_hswish2_fast(v.lo); v.hi = ocr_hswish2_fast(v.hi); }) }
-            else { OCR_DW_ACT(ACT_HSWISH) }
-          } break;
-          case ACT_HSIG: OCR_DW_ACT(ACT_HSIG) break;
-          case ACT_SWISH: OCR_DW_ACT(ACT_SWISH) break;
-          default: OCR_DW_ACT(ACT_SIGMOID) break;
-        }
-#undef OCR_DW_ACT
-      } break;
-      case EP_MULC: {
-        const float4 g = *(const float4*)(st.v0 + (long)n * a.Cs + pc);
-        const ocr_f2 glo = {g.x, g.y}, ghi = {g.z, g.w};
-        OCR_DW_SWEEP({ v.lo = v.lo * glo; v.hi = v.hi * ghi; })
-      } break;
-      case EP_ADDT:
-        OCR_DW_SWEEP({
-          if (y0 + r < OHn && x0 + o < OW) {
-            const float4 g = ld4<H16>(st.v0, obase + r * orow + (long)o * a.Cs);
-            ocr_f2 glo;
-            ocr_f2 ghi;
-            glo.x = g.x; glo.y = g.y; ghi.x = g.z; ghi.y = g.w;
-            v.lo = v.lo + glo; v.hi = v.hi + ghi;
-          }
-        })
-        break;
-      default: break;  // ADDUP never follows a depthwise conv on this path (host checks)
-    }
-#undef OCR_DW_SWEEP
-  }
+  dw_patch_epilogue<R, TO, H16>(acc, ep, pc, n, a.Cs, obase, orow, y0, x0, OHn, OW);
 #pragma unroll
   for (int r = 0; r < R; ++r)
 #pragma unroll

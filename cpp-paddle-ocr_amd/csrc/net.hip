@@ -1226,7 +1226,15 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths, const i
         L.name = nm;
         L.flops = 2.0 * a.M * op.kh * op.kw * op.c;
         L.bytes = EB(in) * in.pixels() * op.c + EB(o) * a.M * op.c;
-        L.fn = [a, ep](hipStream_t s) { launch_dw(a, ep, s); };
+        // the low maps' 5x5 layers: region staged through LDS (kernels_dwlds.hip); asked now, on the device that will run it
+        const bool lds_dw = rt_options().dw_lds && launch_dw_lds(a, ep, nullptr, true);
+        L.fn = [this, a, ep, lds_dw](hipStream_t s) {
+          if (lds_dw) {
+            if (!launch_dw_lds(a, ep, s)) this->launch_error_ = "launch_dw_lds: shape accepted at bind time was refused at launch";
+            return;
+          }
+          launch_dw(a, ep, s);
+        };
       } break;
       case PlanOp::EW: {
         const TensorDesc& in = T[op.in];

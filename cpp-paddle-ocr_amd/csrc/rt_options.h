@@ -24,6 +24,7 @@ struct RtOptions {
   bool conv_c24 = true;        // OCR_CONV_C24=0
   bool conv_tile = true;       // OCR_CONV_TILE=0
   int dw_patch_to = 0, dw_patch_r = 0;  // OCR_DW_PATCH=TOxR; 0 = per shape
+  bool dw_lds = true;          // OCR_DW_LDS=0: the low-map 5x5 depthwise layers keep dw_conv_kernel (A/B; results are identical)
   int dwpw_items = 32;         // OCR_DWPW_ITEMS=n
   int dwpw_force_upw = 0;      // OCR_DWPW_FORCE_UPW=n (tests)
   bool dwpw_t4_thin = false;   // OCR_DWPW_T4=thin

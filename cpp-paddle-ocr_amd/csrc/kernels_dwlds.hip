@@ -160,9 +160,8 @@ __global__ void __launch_bounds__(NB * NS * 8) __attribute__((amdgpu_waves_per_e
 #pragma unroll
       for (int o = 0; o < TO; ++o) { acc[r][o].lo = ocr_f2{0.f, 0.f}; acc[r][o].hi = ocr_f2{0.f, 0.f}; }
     // the patch's input rows top to bottom, one at a time (a fully unrolled walk keeps every row live: 500 registers)
-#pragma unroll 1
+#pragma unroll
     for (int j = 0; j < NROWS; ++j) {
-      asm volatile("" ::: "memory");  // (keeps the weight reads inside the loop: hoisted, the 25 quads cost 100 registers)
       const int ry = band * R * SH + j;  // region row; rows outside the image: the zero row
       const int rslot = (ry >= ry_lo && ry < ry_hi) ? (ry - ry_lo) * RW : zslot;
       const float* row = s_reg + (size_t)(rslot + strip * TO) * PS + 4 * q;

@@ -8,7 +8,11 @@ the same instantiation on the same shape: rec ops 13/15/17/19 are four launches 
 bench.py picks its `roofline` kernel by the same rule from its HIP-event survey; when its JSON line is given (3rd
 argument) the group's label is taken from there and the two average durations are compared.
 
-    python tools/pmc_traffic.py gpurun_out/prof_<tag> profiles/<name>.json [bench_line.json]
+    python tools/pmc_traffic.py gpurun_out/prof_<tag> profiles/<name>.json [bench_line.json [symbol-substring,...]]
+
+A 4th argument names further kernels by substrings of their symbols (e.g. "dw_lds_kernel,dw_conv_kernel"): for each (symbol,
+grid) group that matches, the same per-launch figures go into `other_kernels` (dispatch counts, average duration, HBM bytes
+read and written per launch) - how the depthwise kernels' halo traffic is checked against their tensors' sizes.
 """
 import csv
 import glob
@@ -93,6 +97,22 @@ def main():
             out["frac_from_kernel_trace"] = bench["algorithmic_flops_per_launch"] / (out["avg_duration_us_kernel_trace"] * 1e-6) / 1e12 / bench["peak"]
         else:
             out["frac_from_kernel_trace"] = alg / (out["avg_duration_us_kernel_trace"] * 1e-6) / 1e9 / bench["peak"]
+    if len(sys.argv) > 4:
+        others = []
+        fe_all, wr_all = pmc_rows(os.path.join(root, "pmc_fetch"), "FETCH_SIZE"), pmc_rows(os.path.join(root, "pmc_write"), "WRITE_SIZE")
+        for sub in sys.argv[4].split(","):
+            for (ksym, kgrid), (kdur, kn) in ranked:
+                if sub not in ksym:
+                    continue
+                f_ = [r for r in fe_all if r[1] == ksym and r[2] == kgrid]
+                w_ = [r for r in wr_all if r[1] == ksym and r[2] == kgrid]
+                if not f_ or not w_:
+                    continue
+                others.append({"launch": "%s grid %d" % (ksym.split("(")[0], kgrid), "dispatches_in_kernel_trace": kn,
+                               "share_of_kernel_time_in_trace": kdur / total, "avg_duration_us_kernel_trace": kdur / kn / 1e3,
+                               "hbm_read_bytes_per_launch": sum(r[3] for r in f_) / len(f_) * 1024 * 2,
+                               "hbm_write_bytes_per_launch": sum(r[3] for r in w_) / len(w_) * 1024})
+        out["other_kernels"] = others
     json.dump(out, open(dst, "w"), indent=1)
     print(json.dumps(out, indent=1))
 

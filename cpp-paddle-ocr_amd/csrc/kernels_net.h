@@ -70,6 +70,9 @@ struct ConvArgs {
   // partials, gates and parameter vectors stay f32.  0: the f32 contract.  (The launchers hand such a call to their
   // `_h16` twin, below.)
   int half = 0;
+  // precision "fp16", single-tap convs with an even number of octets: the fragment image for v_mfma_f32_32x32x16_f16
+  // ([octet pair][column tile][64 lanes][8 halfs]: lane (p, h) holds the eight channels of octet 2s + h), or null
+  const float* wfrag_x16 = nullptr;
 };
 // false: the combination (gated input / multi-tap conv with a plain or deconv output) is not instantiated
 bool launch_conv_mfma(const ConvArgs& a, const Epilogue& ep, int nt, hipStream_t s);

@@ -149,10 +149,9 @@ __global__ void __launch_bounds__(256, (NT <= 3 ? 4 : 3)) conv_mfma_kernel(const
   auto mfma_step = [&](const AV& av0, const WV (&bv)[NT], const float4& gv) {
     if constexpr (HALF) {  // one f16 matrix instruction per octet and column tile; the operand comes as stored
       ocr_h4 ah = ocr_as_h4(av0);
-      if constexpr (GATE) {  // x * gate in f32 (one rounding, as the f32 path), then the operand's own rounding to f16
-        const ocr_f4v xf = __builtin_convertvector(ah, ocr_f4v);
-        ah = ocr_to_h4(make_float4(xf.x * gv.x, xf.y * gv.y, xf.z * gv.z, xf.w * gv.w));
-      }
+      // x * gate as two packed f16 multiplies on the gate rounded to f16 (v_pk_mul_f16): the product is rounded to f16 either
+      // way - via f32 it cost ten VALU instructions per octet and pixel tile, more than the octet's matrix instructions
+      if constexpr (GATE) ah = ah * ocr_to_h4(gv);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x8f16(ocr_as_h4(bv[t]), ah, acc[t], 0, 0, 0);
@@ -264,10 +263,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
         ocr_h4 ah = ocr_as_h4(s.av[i]);
-        if constexpr (GATE) {
-          const ocr_f4v xf = __builtin_convertvector(ah, ocr_f4v);
-          ah = ocr_to_h4(make_float4(xf.x * s.gv[i].x, xf.y * s.gv[i].y, xf.z * s.gv[i].z, xf.w * s.gv[i].w));
-        }
+        if constexpr (GATE) ah = ah * ocr_to_h4(s.gv[i]);  // (packed f16 multiplies: conv_mfma_kernel)
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x8f16(ocr_as_h4(s.bv[t]), ah, acc[i][t], 0, 0, 0);
       }
@@ -316,13 +312,117 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
   if constexpr (MT > 2) conv_finish<NT, OUT_C8I, HALF>(a, ep, acc[2], nt0, m0 + 64 + p, h, s_par);
 }
 
+#ifdef OCR_TU_H16
+// The same kernel on gfx950's v_mfma_f32_32x32x16_f16 (precision "fp16", an even number of octets): one matrix instruction
+// consumes TWO octets at twice the rate of 32x32x8.  A lane's operand is a whole octet - lane (p, h) of step s holds the eight
+// physical channels of octet 2s + h: ONE 16-byte load from the f16 tensor - and the weights come from the fragment image in
+// that arrangement (`frag16x:`, net.hip: [octet pair][column tile][64 lanes][8 halfs]).  f32 accumulation as before; the
+// products of a step are summed in the instruction's own order, which is not the 32x32x8 kernel's (same tolerances hold).
+typedef _Float16 ocr_h8 __attribute__((ext_vector_type(8)));
+typedef float ocr_f8v __attribute__((ext_vector_type(8)));
+template <int NT, int MT, bool GATE>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) conv_mfma_mt16_kernel(const ConvArgs a, const Epilogue ep) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int p = lane & 31, h = lane >> 5;
+  const unsigned lb = xcd_swizzle(blockIdx.x, gridDim.x);  // logical block: N-group fastest, then M-tile
+  const unsigned groups = (unsigned)a.NTtot / NT;
+  const long mblk = (long)(lb / groups) * (128 * MT);
+  const long m0 = mblk + (long)wave * (32 * MT);
+  const int nt0 = (int)(lb % groups) * NT;
+  __shared__ float s_par[OCR_MAX_EP * 2 * NT * 32];
+  conv_stage_params<NT>(a, ep, nt0, s_par);
+  if (m0 >= a.M) return;
+
+  floatx16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][t][r] = 0.0f;
+
+  const uint4* __restrict__ wf = (const uint4*)a.wfrag_x16;
+  const int KK = a.C8 >> 1;  // octet pairs
+  const uint4* p_w = wf + (long)nt0 * 64 + lane;
+  const long wstride = (long)a.NTtot * 64;
+  const char* zpage = (const char*)a.zeros;
+  const char* xrow[MT];
+  const float* grow[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const long m = m0 + 32 * i + p;
+    const bool mvalid = m < a.M;
+    xrow[i] = mvalid ? (const char*)a.in + (m * a.Cs_in + 8 * h) * 2 : zpage;
+    grow[i] = a.zeros;
+    if constexpr (GATE) {
+      if (mvalid) {
+        const int gn = a.rin.w ? rag_sample_of_pixel(a.rin, a.N, a.H, m, mblk) : (int)((unsigned)m / (unsigned)a.gate_hw);
+        grow[i] = a.gate + (long)gn * a.Cs_in + 8 * h;
+      }
+    }
+  }
+  int p_step = 0;
+  struct Set { uint4 av[MT]; float4 glo[MT], ghi[MT]; uint4 bv[NT]; };
+  auto load_step = [&](Set& s) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      if constexpr (GATE) { s.glo[i] = *(const float4*)(grow[i] + p_step * 16); s.ghi[i] = *(const float4*)(grow[i] + p_step * 16 + 4); }
+      s.av[i] = *(const uint4*)(xrow[i] + (long)p_step * 32);
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) s.bv[t] = p_w[t * 64];
+    const bool more = p_step + 1 < KK;  // past the end: stay on the last step (loaded, unused)
+    p_step += more;
+    p_w += more ? wstride : 0;
+  };
+  auto mfma_step = [&](const Set& s) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      ocr_h8 ah = __builtin_bit_cast(ocr_h8, s.av[i]);
+      if constexpr (GATE) {  // packed f16 multiplies by the gate rounded to f16 (conv_mfma_kernel)
+        const ocr_f8v g = {s.glo[i].x, s.glo[i].y, s.glo[i].z, s.glo[i].w, s.ghi[i].x, s.ghi[i].y, s.ghi[i].z, s.ghi[i].w};
+        ah = ah * __builtin_convertvector(g, ocr_h8);
+      }
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(ocr_h8, s.bv[t]), ah, acc[i][t], 0, 0, 0);
+    }
+  };
+  Set s0, s1;
+  load_step(s0);
+  int kk = 0;
+  for (; kk + 2 <= KK; kk += 2) {
+    load_step(s1);
+    __builtin_amdgcn_sched_barrier(0);  // keep the loads ahead of the MFMAs they overlap
+    mfma_step(s0);
+    __builtin_amdgcn_sched_barrier(0);
+    load_step(s0);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_step(s1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (kk < KK) mfma_step(s0);
+  conv_finish<NT, OUT_C8I, true>(a, ep, acc[0], nt0, m0 + p, h, s_par);
+  if constexpr (MT > 1) conv_finish<NT, OUT_C8I, true>(a, ep, acc[1], nt0, m0 + 32 + p, h, s_par);
+}
+#endif  // OCR_TU_H16
+
 // Two pixel tiles per wave (the kernel above) for the shapes it was measured on: single tap, C8I output, nt = 3 or 4.
 bool OCR_L(launch_conv_mfma_mt2)(const ConvArgs& a, const Epilogue& ep, int nt, hipStream_t s) {
   OCR_H16_TWIN(a.half, launch_conv_mfma_mt2_h16(a, ep, nt, s))
   const bool tap1 = a.KH == 1 && a.KW == 1 && a.PH == 0 && a.PW == 0 && a.OH == a.H && a.OW == a.W;
   if (!tap1 || a.out_mode != OUT_C8I || a.NTtot % nt) return false;
   dim3 grid((unsigned)(((a.M + 255) / 256) * (a.NTtot / nt)));
+#ifdef OCR_TU_H16
+  // an even number of octets and the paired fragment image at hand: the 32x32x16 form (OCR_MFMA_X16=0: the 32x32x8 one, A/B)
+  const bool x16 = a.wfrag_x16 && (a.C8 & 1) == 0 && rt_options().mfma_x16;
+#define OCR_MT_LAUNCH(NT_, GATE_)                                                                            \
+  {                                                                                                          \
+    if (x16) hipLaunchKernelGGL((conv_mfma_mt16_kernel<NT_, 2, GATE_>), grid, dim3(256), 0, s, a, ep);       \
+    else hipLaunchKernelGGL((conv_mfma_mt_kernel<NT_, 2, GATE_>), grid, dim3(256), 0, s, a, ep);             \
+  }
+#else
 #define OCR_MT_LAUNCH(NT_, GATE_) { hipLaunchKernelGGL((conv_mfma_mt_kernel<NT_, 2, GATE_>), grid, dim3(256), 0, s, a, ep); }
+#endif
   if (nt == 3) {
     if (a.gate) OCR_MT_LAUNCH(3, true) else OCR_MT_LAUNCH(3, false)
   } else if (nt == 4) {

@@ -185,6 +185,24 @@ static std::vector<float> build_frag(int taps, int cin, int cols, Get get) {
 
 // precision "fp16": the same image in f16 (round to nearest even), four halfs per lane packed into the float vector
 // upload() takes - what the HALF instantiations of the matrix-core kernels read as uint2 per lane (conv_device.h)
+// the same for v_mfma_f32_32x32x16_f16 (single-tap convs, an even number of octets): [octet pair s][column tile][64 lanes][8
+// halfs] - lane (p, h) holds the eight physical channels of octet 2s + h = what lanes (p, 0) and (p, 1) of that octet hold in
+// the image above
+static std::vector<float> frag_to_half_x16(const std::vector<float>& f, int C8) {
+  const size_t nt = f.size() / ((size_t)C8 * 256);  // column tiles (single tap)
+  std::vector<float> out(f.size() / 2, 0.f);
+  uint16_t* hp = reinterpret_cast<uint16_t*>(out.data());
+  for (int s = 0; s < C8 / 2; ++s)
+    for (size_t t = 0; t < nt; ++t)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int p = lane & 31, h = lane >> 5, j = 2 * s + h;
+        for (int i = 0; i < 8; ++i) {
+          const _Float16 v = (_Float16)f[(((size_t)j * nt + t) * 64 + (p + 32 * (i >> 2))) * 4 + (i & 3)];
+          memcpy(&hp[(((size_t)s * nt + t) * 64 + lane) * 8 + i], &v, sizeof(uint16_t));
+        }
+      }
+  return out;
+}
 static std::vector<float> frag_to_half(const std::vector<float>& f) {
   std::vector<float> out((f.size() + 1) / 2, 0.f);
   uint16_t* h = reinterpret_cast<uint16_t*>(out.data());
@@ -281,6 +299,8 @@ bool Net::load(const char* plan_text, const WeightMap& W, std::string& err, bool
           });
           if (!upload("frag:" + op.w, f)) { err = "hipMalloc failed"; return false; }
           if (half_ && !upload("frag16:" + op.w, frag_to_half(f))) { err = "hipMalloc failed"; return false; }
+          if (half_ && kh == 1 && kw == 1 && !pl && (c8i_stride(ci) / 8) % 2 == 0 &&
+              !upload("frag16x:" + op.w, frag_to_half_x16(f, c8i_stride(ci) / 8))) { err = "hipMalloc failed"; return false; }
           if (kh == 1 && kw == 1 && !pl && ci <= 512 && co <= 512) {  // the fused bottleneck kernel's image (kernels_mb.hip): [k][c] logical, rows padded to 8
             const int cop = (co + 7) & ~7;
             std::vector<float> t((size_t)ci * cop, 0.f);
@@ -1069,6 +1089,7 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths, const i
           const bool hconv = half_ && in.f16;
           a.in = arena_ + in.offset; a.out = optr; a.wfrag = dev_vec((hconv ? "frag16:" : "frag:") + op.w);
           a.half = hconv ? 1 : 0;
+          if (hconv && op.kind == PlanOp::CONV && op.kh == 1 && op.kw == 1) a.wfrag_x16 = dev_vec("frag16x:" + op.w);  // (null: no such image)
           if (!o.plain && o.f16 != in.f16) { err = "precision fp16: a dense conv between tensors of different storage"; return false; }
           a.N = in.n; a.H = in.h; a.W = in.w; a.Cs_in = in.cs; a.C8 = in.cs / 8;
           a.KH = op.kh; a.KW = op.kw; a.PH = op.ph; a.PW = op.pw;

@@ -729,6 +729,100 @@ __global__ void __launch_bounds__(256, 2) conv3x3_tile_kernel(const ConvArgs a, 
   conv_finish<NT, OUT_C8I, HALF>(a, ep, acc, nt0, m, h, s_par);
 }
 
+#ifdef OCR_TU_H16
+// The LDS-tile conv on v_mfma_f32_32x32x16_f16 (precision "fp16"): the tile is staged AS f16 (half the LDS of the f32 form,
+// four workgroups per CU instead of two, no conversion on either side), a lane's operand of an octet pair is one
+// ds_read_b128 - lane (p, h) takes the eight channels of octet 2c + h of its pixel - and the weights come from the paired
+// fragment image ([tap][octet pair][column tile][64 lanes][8 halfs], `frag16x:`).  Pixel stride in LDS = CS + 8 halfs
+// (an odd number of 16-byte units).
+template <int C8, int NT>
+__global__ void __launch_bounds__(256, 2) conv3x3_tile16_kernel(const ConvArgs a, const Epilogue ep, const int tiles_x, const int tiles_y) {
+  static_assert(C8 % 2 == 0, "octet pairs");
+  constexpr int TH = 8, TW = 16, RH = TH + 2, RW = TW + 2;
+  constexpr int CS = C8 * 8, STRIDE = CS + 8;  // halfs per staged pixel
+  constexpr int Q = CS / 8, C16 = C8 / 2;      // 16-byte pieces (octets) per pixel; octet pairs
+  extern __shared__ float4 s_tile4[];
+  _Float16* s_tile = (_Float16*)s_tile4;       // [RH*RW][STRIDE]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int p = lane & 31, h = lane >> 5;
+  const unsigned lb = xcd_swizzle(blockIdx.x, gridDim.x);
+  const unsigned groups = (unsigned)a.NTtot / NT;
+  const int nt0 = (int)(lb % groups) * NT;
+  unsigned tile = lb / groups;
+  const int tx = (int)(tile % tiles_x);
+  tile /= tiles_x;
+  const int ty = (int)(tile % tiles_y), n = (int)(tile / tiles_y);
+  const int y0 = ty * TH, x0 = tx * TW;
+  {
+    const _Float16* img = (const _Float16*)a.in + (long)n * a.H * a.W * CS;
+    constexpr int PIECES = RH * RW * Q, PER_THR = (PIECES + 255) / 256;
+    uint4 r[PER_THR];
+#pragma unroll
+    for (int i = 0; i < PER_THR; ++i) {
+      const int idx = tid + i * 256;
+      const int px = idx / Q, q = idx - px * Q;
+      const int py = px / RW, pxx = px - py * RW;
+      const int iy = y0 - 1 + py, ix = x0 - 1 + pxx;
+      const bool v = idx < PIECES && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+      r[i] = v ? *(const uint4*)(img + ((long)iy * a.W + ix) * CS + q * 8) : uint4{0u, 0u, 0u, 0u};
+    }
+#pragma unroll
+    for (int i = 0; i < PER_THR; ++i) {
+      const int idx = tid + i * 256;
+      const int px = idx / Q, q = idx - px * Q;
+      if (idx < PIECES) *(uint4*)(s_tile + px * STRIDE + q * 8) = r[i];
+    }
+  }
+  __shared__ float s_par[OCR_MAX_EP * 2 * NT * 32];
+  conv_stage_params<NT>(a, ep, nt0, s_par);  // ends with the barrier that also publishes the tile
+
+  floatx16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+  const int ly = wave * 2 + (p >> 4), lx = p & 15;  // this lane's pixel inside the tile
+  const _Float16* sA = s_tile + (ly * RW + lx) * STRIDE + 8 * h;
+  const uint4* __restrict__ wf = (const uint4*)a.wfrag_x16 + (long)nt0 * 64 + lane;
+  const long wstride = (long)a.NTtot * 64;
+  auto load_tap = [&](uint4 (&bv)[C16][NT], int tap) {
+    const uint4* q = wf + (long)(tap < 9 ? tap : 8) * C16 * wstride;
+#pragma unroll
+    for (int c = 0; c < C16; ++c)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) bv[c][t] = q[c * wstride + t * 64];
+  };
+  auto mul_tap = [&](const uint4 (&bv)[C16][NT], int tap) {
+    const int ky = tap / 3, kx = tap - ky * 3;
+    const _Float16* src = sA + (ky * RW + kx) * STRIDE;
+#pragma unroll
+    for (int c = 0; c < C16; ++c) {
+      const ocr_h8 ah = __builtin_bit_cast(ocr_h8, *(const uint4*)(src + c * 16));
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(ocr_h8, bv[c][t]), ah, acc[t], 0, 0, 0);
+    }
+  };
+  uint4 bA[C16][NT], bB[C16][NT];
+  load_tap(bA, 0);
+#pragma unroll 1
+  for (int tap = 0; tap < 9; tap += 2) {
+    load_tap(bB, tap + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mul_tap(bA, tap);
+    __builtin_amdgcn_sched_barrier(0);
+    if (tap + 1 < 9) {
+      load_tap(bA, tap + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      mul_tap(bB, tap + 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  const int oy = y0 + ly, ox = x0 + lx;
+  const long m = (oy < a.OH && ox < a.OW) ? ((long)n * a.OH + oy) * a.OW + ox : a.M;
+  conv_finish<NT, OUT_C8I, true>(a, ep, acc, nt0, m, h, s_par);
+}
+#endif  // OCR_TU_H16
+
 #ifndef OCR_TU_H16  // (f32 contract only)
 // =====================================================================================
 // The same conv for 24 output channels on 4x4x1 matrix blocks (the five DB neck / head 96 -> 24 convs).
@@ -920,6 +1014,13 @@ bool OCR_L(launch_conv3x3_tile)(const ConvArgs& a, const Epilogue& ep, int nt, h
   const unsigned lds = 10 * 18 * (96 + 4) * sizeof(float);  // 72 000 B: two workgroups per CU
   // more than 64 KB of dynamic LDS has to be allowed per device (a worker pool drives several from one process)
   static LdsAttrMemo attr_state;
+#ifdef OCR_TU_H16
+  if (a.wfrag_x16 && rt_options().mfma_x16) {  // the f16-staged 32x32x16 form (52 bytes under the 64 KB that need no attribute)
+    const unsigned lds16 = 10 * 18 * (96 + 8) * sizeof(_Float16);  // 37 440 B: four workgroups per CU
+    hipLaunchKernelGGL((conv3x3_tile16_kernel<12, 1>), grid, dim3(256), lds16, s, a, ep, tiles_x, tiles_y);
+    return true;
+  }
+#endif
   if (!raise_dynamic_lds((const void*)conv3x3_tile_kernel<12, 1>, (int)lds, attr_state)) return false;  // the general kernel takes the launch
   hipLaunchKernelGGL((conv3x3_tile_kernel<12, 1>), grid, dim3(256), lds, s, a, ep, tiles_x, tiles_y);
   return true;

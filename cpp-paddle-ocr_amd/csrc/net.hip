@@ -188,19 +188,20 @@ static std::vector<float> build_frag(int taps, int cin, int cols, Get get) {
 // the same for v_mfma_f32_32x32x16_f16 (single-tap convs, an even number of octets): [octet pair s][column tile][64 lanes][8
 // halfs] - lane (p, h) holds the eight physical channels of octet 2s + h = what lanes (p, 0) and (p, 1) of that octet hold in
 // the image above
-static std::vector<float> frag_to_half_x16(const std::vector<float>& f, int C8) {
-  const size_t nt = f.size() / ((size_t)C8 * 256);  // column tiles (single tap)
+static std::vector<float> frag_to_half_x16(const std::vector<float>& f, int C8, int taps = 1) {
+  const size_t nt = f.size() / ((size_t)taps * C8 * 256);  // column tiles
   std::vector<float> out(f.size() / 2, 0.f);
   uint16_t* hp = reinterpret_cast<uint16_t*>(out.data());
-  for (int s = 0; s < C8 / 2; ++s)
-    for (size_t t = 0; t < nt; ++t)
-      for (int lane = 0; lane < 64; ++lane) {
-        const int p = lane & 31, h = lane >> 5, j = 2 * s + h;
-        for (int i = 0; i < 8; ++i) {
-          const _Float16 v = (_Float16)f[(((size_t)j * nt + t) * 64 + (p + 32 * (i >> 2))) * 4 + (i & 3)];
-          memcpy(&hp[(((size_t)s * nt + t) * 64 + lane) * 8 + i], &v, sizeof(uint16_t));
+  for (int tap = 0; tap < taps; ++tap)
+    for (int s = 0; s < C8 / 2; ++s)
+      for (size_t t = 0; t < nt; ++t)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int p = lane & 31, h = lane >> 5, j = 2 * s + h;
+          for (int i = 0; i < 8; ++i) {
+            const _Float16 v = (_Float16)f[((((size_t)tap * C8 + j) * nt + t) * 64 + (p + 32 * (i >> 2))) * 4 + (i & 3)];
+            memcpy(&hp[((((size_t)tap * (C8 / 2) + s) * nt + t) * 64 + lane) * 8 + i], &v, sizeof(uint16_t));
+          }
         }
-      }
   return out;
 }
 static std::vector<float> frag_to_half(const std::vector<float>& f) {
@@ -299,8 +300,8 @@ bool Net::load(const char* plan_text, const WeightMap& W, std::string& err, bool
           });
           if (!upload("frag:" + op.w, f)) { err = "hipMalloc failed"; return false; }
           if (half_ && !upload("frag16:" + op.w, frag_to_half(f))) { err = "hipMalloc failed"; return false; }
-          if (half_ && kh == 1 && kw == 1 && !pl && (c8i_stride(ci) / 8) % 2 == 0 &&
-              !upload("frag16x:" + op.w, frag_to_half_x16(f, c8i_stride(ci) / 8))) { err = "hipMalloc failed"; return false; }
+          if (half_ && ((kh == 1 && kw == 1) || (kh == 3 && kw == 3 && ci == 96)) && !pl && (c8i_stride(ci) / 8) % 2 == 0 &&
+              !upload("frag16x:" + op.w, frag_to_half_x16(f, c8i_stride(ci) / 8, kh * kw))) { err = "hipMalloc failed"; return false; }
           if (kh == 1 && kw == 1 && !pl && ci <= 512 && co <= 512) {  // the fused bottleneck kernel's image (kernels_mb.hip): [k][c] logical, rows padded to 8
             const int cop = (co + 7) & ~7;
             std::vector<float> t((size_t)ci * cop, 0.f);
@@ -1089,7 +1090,7 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths, const i
           const bool hconv = half_ && in.f16;
           a.in = arena_ + in.offset; a.out = optr; a.wfrag = dev_vec((hconv ? "frag16:" : "frag:") + op.w);
           a.half = hconv ? 1 : 0;
-          if (hconv && op.kind == PlanOp::CONV && op.kh == 1 && op.kw == 1) a.wfrag_x16 = dev_vec("frag16x:" + op.w);  // (null: no such image)
+          if (hconv && op.kind == PlanOp::CONV) a.wfrag_x16 = dev_vec("frag16x:" + op.w);  // (null: no such image - other than 1x1 and the 3x3 96-channel convs, or an odd number of octets)
           if (!o.plain && o.f16 != in.f16) { err = "precision fp16: a dense conv between tensors of different storage"; return false; }
           a.N = in.n; a.H = in.h; a.W = in.w; a.Cs_in = in.cs; a.C8 = in.cs / 8;
           a.KH = op.kh; a.KW = op.kw; a.PH = op.ph; a.PW = op.pw;

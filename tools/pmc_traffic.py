@@ -85,6 +85,8 @@ def main():
         out["issue_counters_per_launch"] = issue
         if issue.get("SQ_INSTS_MFMA"):
             out["valu_instructions_per_mfma"] = issue.get("SQ_INSTS_VALU", 0.0) / issue["SQ_INSTS_MFMA"]
+            # SQ_INSTS_VALU counts the matrix instructions too (checked against the disassembly: DESIGN.md section 6)
+            out["non_mfma_valu_instructions_per_mfma"] = out["valu_instructions_per_mfma"] - 1.0
             out["lds_instructions_per_mfma"] = issue.get("SQ_INSTS_LDS", 0.0) / issue["SQ_INSTS_MFMA"]
     if bench:
         alg = bench["algorithmic_bytes_per_launch"]

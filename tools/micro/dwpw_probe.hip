@@ -9,6 +9,9 @@
 #include <vector>
 #include "kernels_dwpw.hip"
 using namespace ocr;
+#ifndef OCR_TU_H16
+namespace ocr { inline namespace h16 { bool launch_dwpw_h16(const DwPwArgs&, hipStream_t, bool) { return false; } } }  // (the f32 launcher's twin: not linked into this probe)
+#endif
 #ifdef OCR_TU_H16
 static bool probe_launch_h16(const DwPwArgs& a, hipStream_t s, bool query = false) { return launch_dwpw_h16(a, s, query); }
 #define launch_dwpw probe_launch_h16

@@ -11,6 +11,7 @@ python bench.py --config cfg4 --images 2560 --no-cpu-baseline > $O/bench_cfg4.js
 tools/run_profile.sh $T > $O/profile.log 2>&1
 python tools/prof_summary.py gpurun_out/prof_$T > $O/prof_summary.txt 2>&1
 python tools/pmc_traffic.py gpurun_out/prof_$T $O/pmc_traffic.json $O/bench_cfg2.json dw_lds_kernel,dw_conv_kernel > $O/pmc_traffic.log 2>&1
+python tools/hbm_table.py gpurun_out/prof_$T > $O/kernel_hbm_table.txt 2>&1
 cp gpurun_out/prof_$T/trace/*/*kernel_stats.csv $O/ 2>/dev/null
 python tools/service_load.py jpeg 64 12 > $O/service_load.jsonl 2> $O/service_load.err
 for c in cfg2 cfg3 cfg4; do python - $O/bench_$c.json <<'P'

@@ -794,7 +794,7 @@ def main(argv=None):
             "higher_is_better": True,
             "scaling": "weak" if cfg != "cfg4" else "strong",
             "vs_baseline": None,
-            "dtype": "f32" if args.precision == "fp32" else "f16 products, f32 accumulate and storage (exploration run: --precision)",
+            "dtype": "f32" if args.precision == "fp32" else "f16 tensors and matrix products, f32 accumulation (exploration run: --precision)",
             "data": "stub (launcher/gather rehearsal, not a measurement)" if stub else "synthetic",
             "config": {"workload": workload,
                        "images_per_step_per_gpu": batch, "sharding": "image i -> rank i mod n_gpus, no data-path collective; "

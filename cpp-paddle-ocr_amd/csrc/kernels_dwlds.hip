@@ -1,29 +1,29 @@
-// Depthwise 5x5 conv with the input region staged through LDS (gfx950), for the low, wide maps of the recognizer and the
-// classifier (rec ops 21 / 26 / 31 / 33: 12-, 6- and 3-row maps, 240 / 480 channels; the classifier's 5x5 layers).
+// Depthwise 5x5 conv with the input region staged through LDS (gfx950), for the recognizer's low, wide maps: rec ops 26 / 31 /
+// 33 - 6- and 3-row maps of 480 channels at the 48-pixel line height (and the classifier's 3-row layers).
 //
 // dw_conv_kernel (kernels_net.hip) gives a thread a register patch and lets it read the patch's haloed rows straight from
 // global memory: on a 6-row map a 2-row band re-reads four of its six input rows, and the three bands of a line are too far
 // apart in time for the 4 MB L2 of an XCD to hold what the first one fetched (rec op 26: 4.13 GB read for a 1.89 GB input,
 // round 3 PMC).  Full-height register patches removed the re-reads and were SLOWER (a third as many threads, each walking
-// 20 strips: round 4).  Here a workgroup owns a band group of TY output rows x a 32-channel chunk of one
-// image and walks the row LEFT TO RIGHT in tiles of TX output columns:
-//   G   global -> registers   the haloed input region of the tile (coalesced 16-byte pieces: a pixel's 32 channels are one
-//                             128-byte line), only the rows that exist in the image
-//   S   registers -> LDS      the region
+// 20 strips: round 4).  Here a workgroup is ONE wave (its barriers cost nothing; 7-12 of them per CU by
+// their LDS) that owns a WHOLE image - a text line of HR = 6 or 3 rows - x a 32-channel chunk and walks it LEFT TO RIGHT in
+// tiles of 16 output columns:
+//   G   global -> registers   the haloed input region of the NEXT tile (HR rows x 20 columns; a pixel's 32 channels are one
+//                             128-byte line; a lane owns the same three 16-byte pieces of every row), issued before the
+//                             taps of the current tile so that the loads travel while it is computed
 //   taps LDS -> VALU          a thread owns an R x TO patch of output pixels x 4 physical channels and walks its input rows
 //                             out of LDS exactly as dw_conv_kernel walks them out of global memory - for every output the
-//                             taps arrive in (ky, kx) ascending order from 0, the contract's chain
+//                             taps arrive in (ky, kx) ascending order from 0, the contract's chain;
+//                             rows outside the image are one shared zero row
 //   epilogue                  the plan's stage list on the patch (dw_epilogue.h, shared with dw_conv_kernel), 16-byte stores
-// A workgroup is ONE wave (its barriers cost nothing), 7-12 of them per CU by their LDS.
-//   row sums (ROWSUM)         the tile's outputs go through LDS (the region's space, dead by then) to the thread that owns
+//   row sums (ROWSUM)         the tile's outputs go through LDS (the region's space, dead by then) to the lane that owns
 //                             (row, channel quad), which adds them in x order: s = s + v from x = 0, the global average
 //                             pool's first pass in the contract's order, carried across the tiles in a register
-// Every input row is read from HBM once per band group (the K - 1 columns two neighbouring tiles share come back from L1 / L2
-// a few microseconds later), and the taps cost LDS reads instead of L1 round trips.  Results are bit-identical to
-// dw_conv_kernel's (tests/test_gpu_parity.py runs every plan with OCR_DW_LDS=0 and 1).
+//   S   registers -> LDS      the next tile's region
+// Every input row is read from HBM once (rec op 26: 2.14 GB read for its 1.89 GB input; the K - 1 columns two neighbouring tiles
+// share come back from L1 / L2), and the taps cost LDS reads instead of L1 round trips.  Results are bit-identical to
+// dw_conv_kernel's (tests/test_gpu_parity.py: every plan, and OCR_DW_LDS=0 in the A/B test).
 #include <hip/hip_runtime.h>
-
-#include <mutex>
 
 #include "conv_device.h"
 #include "dw_epilogue.h"
@@ -65,7 +65,7 @@ struct DwLdsGeom {
 // HR: the image's height (compile time: 3 | 6) - the whole image is ONE band group, every region row that exists is one of
 // its HR rows, and the next tile's pieces (HR rows x NIT per lane) travel in registers while this tile is computed
 template <int K, int SH, int R, int NB, int TO, int NS, int HR, bool ROWSUM, bool RAG, bool H16 = kH16>
-__global__ void __launch_bounds__(NB * NS * 8) __attribute__((amdgpu_waves_per_eu(2, 4))) dw_lds_kernel(const DwArgs a, const Epilogue ep, const int zslot) {
+__global__ void __launch_bounds__(DwLdsGeom<K, SH, R, NB, TO, NS>::NTHR) __attribute__((amdgpu_waves_per_eu(2, 4))) dw_lds_kernel(const DwArgs a, const Epilogue ep, const int zslot) {
   using G_ = DwLdsGeom<K, SH, R, NB, TO, NS>;
   constexpr int CC = G_::CC, CQ = G_::CQ, TY = G_::TY, TX = G_::TX, NTHR = G_::NTHR, RH = G_::RH, RW = G_::RW, PS = G_::PS;
   constexpr int NIN = TO + K - 1, NROWS = (R - 1) * SH + K;

@@ -65,7 +65,7 @@ struct DwLdsGeom {
 // HR: the image's height (compile time: 3 | 6) - the whole image is ONE band group, every region row that exists is one of
 // its HR rows, and the next tile's pieces (HR rows x NIT per lane) travel in registers while this tile is computed
 template <int K, int SH, int R, int NB, int TO, int NS, int HR, bool ROWSUM, bool RAG, bool H16 = kH16>
-__global__ void __launch_bounds__(DwLdsGeom<K, SH, R, NB, TO, NS>::NTHR) __attribute__((amdgpu_waves_per_eu(2, 4))) dw_lds_kernel(const DwArgs a, const Epilogue ep, const int zslot) {
+__global__ void __launch_bounds__(NB * NS * 8) __attribute__((amdgpu_waves_per_eu(2, 4))) dw_lds_kernel(const DwArgs a, const Epilogue ep, const int zslot) {
   using G_ = DwLdsGeom<K, SH, R, NB, TO, NS>;
   constexpr int CC = G_::CC, CQ = G_::CQ, TY = G_::TY, TX = G_::TX, NTHR = G_::NTHR, RH = G_::RH, RW = G_::RW, PS = G_::PS;
   constexpr int NIN = TO + K - 1, NROWS = (R - 1) * SH + K;
@@ -107,6 +107,7 @@ __global__ void __launch_bounds__(DwLdsGeom<K, SH, R, NB, TO, NS>::NTHR) __attri
   // region instead, the per-piece address arithmetic is hoisted out of the tile loop: 100 live registers and spills.)
   constexpr int RPIECES = RW * CQ, NIT = (RPIECES + NTHR - 1) / NTHR;
   static_assert(PS == 4 * CQ, "a row piece index is its LDS float4 index inside the row");
+  static_assert(NTHR == NB * NS * 8, "the launch bound above (a macro argument cannot hold the geometry's template arguments)");
   int p_rx[NIT], p_off[NIT];
   bool p_ok[NIT];
 #pragma unroll

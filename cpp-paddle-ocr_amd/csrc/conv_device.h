@@ -36,9 +36,12 @@ __device__ __forceinline__ float4 ld4(const float* base, long idx) {
     return *(const float4*)(base + idx);
   }
 }
+// (a stored activation saturates at the largest f16 instead of overflowing to infinity: an inf would turn into NaN in the next
+// layer's 0 * inf or inf - inf; 4 v_med3 per 8-byte store)
+__device__ __forceinline__ float ocr_sat_h(float v) { return __builtin_amdgcn_fmed3f(v, -65504.0f, 65504.0f); }
 template <bool H16>
 __device__ __forceinline__ void st4(float* base, long idx, const float4& v) {
-  if constexpr (H16) *(uint2*)((_Float16*)base + idx) = __builtin_bit_cast(uint2, ocr_to_h4(v));
+  if constexpr (H16) *(uint2*)((_Float16*)base + idx) = __builtin_bit_cast(uint2, ocr_to_h4(make_float4(ocr_sat_h(v.x), ocr_sat_h(v.y), ocr_sat_h(v.z), ocr_sat_h(v.w))));
   else *(float4*)(base + idx) = v;
 }
 template <bool H16>
@@ -48,7 +51,7 @@ __device__ __forceinline__ float ld1(const float* base, long idx) {
 }
 template <bool H16>
 __device__ __forceinline__ void st1(float* base, long idx, float v) {
-  if constexpr (H16) ((_Float16*)base)[idx] = (_Float16)v;
+  if constexpr (H16) ((_Float16*)base)[idx] = (_Float16)ocr_sat_h(v);
   else base[idx] = v;
 }
 // the same in two steps, for software-pipelined loops: the raw 4-channel piece as it travels (a conversion next to the load

@@ -386,6 +386,21 @@ def test_fp16_stores_its_activation_tensors_as_f16(pkg, built):
     n32.close()
 
 
+def test_fp16_stores_saturate_instead_of_overflowing(pkg, built):
+    """An activation beyond the f16 range is stored as +-65504, not as infinity (conv_device.h, st4): a network fed values a
+    hundred thousand times larger than a normalised image still ends in finite probabilities that sum to one - an inf in a
+    tensor would reach the softmax as NaN through the next layer's 0 * inf or inf - inf - and an intermediate tensor of that
+    run holds the saturation value itself."""
+    rs = np.random.RandomState(6)
+    x = (rs.randn(2, 48, 192, 3) * 1e5).astype(np.float32)
+    n = pkg.Net("cls", precision="fp16")
+    y = n.forward(x, keep_all=1).reshape(2, 2)
+    assert np.isfinite(y).all() and np.allclose(y.sum(1), 1.0, atol=1e-3), y
+    stem = n.fetch(1)
+    assert np.isfinite(stem).all() and np.abs(stem).max() == 65504.0
+    n.close()
+
+
 def test_fp16_pipeline_agrees_with_fp32_on_the_benchmark_batch(pkg, built):
     """The whole path in fp16 on 8 configs[1] images (256 lines, probability-map protocol): boxes are identical (they
     come from the protocol's maps), the CTC id sequences agree on >= 95 % of the lines, confidences within 1e-4; the

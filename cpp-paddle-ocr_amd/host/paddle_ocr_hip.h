@@ -328,6 +328,12 @@ class OCRWorker {
     if (const char* e = getenv("OCR_WORKER_REC_H")) if (atoi(e) >= 8) c.rec.rec_img_h = atoi(e);
     if (const char* e = getenv("OCR_WORKER_REC_W")) if (atoi(e) >= 8) c.rec.rec_img_w = atoi(e);
     if (const char* e = getenv("OCR_WORKER_CLS")) if (e[0] == '1') c.enable_cls = 1;
+    // (the reference's worker passes the literal "fp32" to its three stage constructors, ocr_worker.cpp:34-60; the stages'
+    // own parameter takes "fp16" - OCR_WORKER_PRECISION=fp16 hands it to all three)
+    if (const char* e = getenv("OCR_WORKER_PRECISION")) {
+      precision_ = e;
+      c.det.precision = c.cls.precision = c.rec.precision = precision_.c_str();
+    }
     check_ocr(ocr_pipe_create(&c, &pipe_), "OCRWorker");
   }
   virtual ~OCRWorker() { stop(); ocr_pipe_destroy(pipe_); }
@@ -510,6 +516,7 @@ class OCRWorker {
   int gpu_id_ = 0;
   int max_batch_ = 1;
   int linger_us_ = 0;
+  std::string precision_;  // OCR_WORKER_PRECISION (kept alive for the configuration's pointers)
   std::vector<ocr_word> batch_words_;
   std::vector<int32_t> batch_ids_;
   std::atomic<bool> running_, is_idle_;

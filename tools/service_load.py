@@ -102,6 +102,9 @@ def jpeg_mode(clients, per):
     for dev in ("1", "0"):
         run(16, clients, per, path, fmt, workers=2, extra_env=dict(op, OCR_DEVICE_JPEG=dev),
             tag="device_jpeg" if dev == "1" else "host_jpeg")
+    # the same service with the stages' precision parameter set to "fp16" (OCR_WORKER_PRECISION: the reference's worker
+    # hard-codes "fp32") - where the GPU, not the host, was the limit this is what the mode buys a service
+    run(16, clients, per, path, fmt, workers=2, extra_env=dict(op, OCR_DEVICE_JPEG="1", OCR_WORKER_PRECISION="fp16"), tag="device_jpeg_fp16")
     # the yardstick: the pipeline itself (one handle, two chains) on the SAME decoded image, 64 per batch from host memory
     # through the double-buffered staging - what bench.py calls host_input, but with this image's own detector output
     # (no probability-map protocol: the service cannot be handed one), i.e. the same words per image as the service saw

@@ -29,6 +29,7 @@ const RtOptions& rt_options() {
     o.fuse_gap_min = num("OCR_FUSE_GAP_MIN", 64 * 1024);
     o.fuse_dbhead = !off("OCR_FUSE_DBHEAD");
     o.fuse_rse = !off("OCR_FUSE_RSE");
+    o.fuse_concat = !off("OCR_FUSE_CONCAT");
     { const char* e = getenv("OCR_FUSE_MB"); o.fuse_mb = e && e[0] == '1'; }
     if (const char* e = getenv("OCR_CONV_IMPL")) o.conv_impl = !strcmp(e, "direct") ? 1 : (!strcmp(e, "lds") ? 2 : 0);
     o.conv_small_nt = !off("OCR_CONV_SMALL_NT");

@@ -73,6 +73,12 @@ struct ConvArgs {
   // precision "fp16", single-tap convs with an even number of octets: the fragment image for v_mfma_f32_32x32x16_f16
   // ([octet pair][column tile][64 lanes][8 halfs]: lane (p, h) holds the eight channels of octet 2s + h), or null
   const float* wfrag_x16 = nullptr;
+  // a concat folded into the fill of the 3x3 LDS-tile kernels (net.hip; the DB neck's `concat -> conv 3x3 96 -> 24`): `in` is
+  // null and the tile's physical channels cat_cs * j .. cat_cs * (j + 1) - 1 come from source j, a [N][H / up][W / up][cat_cs]
+  // tensor read with nearest upsampling by cat_up[j] (a power of two) - what concat_kernel would have written
+  const float* cat_src[4] = {nullptr, nullptr, nullptr, nullptr};
+  int cat_up[4] = {1, 1, 1, 1};
+  int cat_n = 0, cat_cs = 0;
 };
 // false: the combination (gated input / multi-tap conv with a plain or deconv output) is not instantiated
 bool launch_conv_mfma(const ConvArgs& a, const Epilogue& ep, int nt, hipStream_t s);

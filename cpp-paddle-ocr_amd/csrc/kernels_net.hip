@@ -753,7 +753,35 @@ __global__ void __launch_bounds__(256, 2) conv3x3_tile16_kernel(const ConvArgs a
   tile /= tiles_x;
   const int ty = (int)(tile % tiles_y), n = (int)(tile / tiles_y);
   const int y0 = ty * TH, x0 = tx * TW;
-  {
+  if (a.cat_n) {  // a folded concat: source by source, as conv3x3_c24_kernel's fill (8-channel pieces: three per source pixel)
+    constexpr int CCS = 24, QS = CCS / 8, PER_SRC = RH * RW * QS, PER_THR = (PER_SRC + 255) / 256;
+    static_assert(CS == 4 * CCS, "four 24-channel sources");
+    uint4 r[4][PER_THR];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int lu = 31 - __clz(a.cat_up[j]);
+      const int sw = a.W >> lu;
+      const int base = n * (a.H >> lu) * sw;
+      const _Float16* sp = (const _Float16*)a.cat_src[j];
+#pragma unroll
+      for (int i = 0; i < PER_THR; ++i) {
+        const int p = tid + i * 256;
+        const int px = p / QS, ql = p - px * QS;
+        const int py = px / RW, pxx = px - py * RW;
+        const int iy = y0 - 1 + py, ix = x0 - 1 + pxx;
+        const bool v = p < PER_SRC && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+        r[j][i] = v ? *(const uint4*)(sp + (base + (iy >> lu) * sw + (ix >> lu)) * CCS + 8 * ql) : uint4{0u, 0u, 0u, 0u};
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < PER_THR; ++i) {
+        const int p = tid + i * 256;
+        const int px = p / QS, ql = p - px * QS;
+        if (p < PER_SRC) *(uint4*)(s_tile + px * STRIDE + j * CCS + 8 * ql) = r[j][i];
+      }
+  } else {
     const _Float16* img = (const _Float16*)a.in + (long)n * a.H * a.W * CS;
     constexpr int PIECES = RH * RW * Q, PER_THR = (PIECES + 255) / 256;
     uint4 r[PER_THR];
@@ -872,7 +900,38 @@ __global__ void __launch_bounds__(TH * 32, 2) conv3x3_c24_kernel(const ConvArgs 
     pix0 = (long)n * a.H * a.W;
   }
   const int y0 = ty * TH, x0 = tx * TW;
-  {  // fill: (RH*RW) pixels x Q pieces, consecutive threads take consecutive pieces of a pixel
+  if (a.cat_n) {
+    // a folded concat (ConvArgs::cat_*): the fill gathers the tile's channels from the four 24-channel sources, SOURCE BY
+    // SOURCE - consecutive threads take consecutive quads of consecutive pixels of ONE source, whose rows are contiguous in
+    // memory (piece by piece of a pixel across the sources, every load instruction touched four tensors: +0.43 ms)
+    constexpr int CCS = 24, QS = CCS / 4, PER_SRC = RH * RW * QS, PER_THR = (PER_SRC + NTHR - 1) / NTHR;
+    static_assert(CS == 4 * CCS, "four 24-channel sources");
+    float4 r[4][PER_THR];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {  // (the source as a compile-time constant: its pointer, factor and row width are scalars)
+      const int lu = 31 - __clz(a.cat_up[j]);
+      const int sw = IW >> lu;
+      const int base = a.rtiles ? (a.rin.cw[n] >> (2 * (a.rin.shift + lu))) : n * (IH >> lu) * sw;  // (source pixels < 2^31: checked at bind)
+      const float* sp = a.cat_src[j];
+#pragma unroll
+      for (int i = 0; i < PER_THR; ++i) {
+        const int p = tid + i * NTHR;
+        const int px = p / QS, ql = p - px * QS;
+        const int py = px / RW, pxx = px - py * RW;
+        const int iy = y0 - 1 + py, ix = x0 - 1 + pxx;
+        const bool v = p < PER_SRC && iy >= 0 && iy < IH && ix >= 0 && ix < IW;
+        r[j][i] = v ? *(const float4*)(sp + (base + (iy >> lu) * sw + (ix >> lu)) * CCS + 4 * ql) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < PER_THR; ++i) {
+        const int p = tid + i * NTHR;
+        const int px = p / QS, ql = p - px * QS;
+        if (p < PER_SRC) *(float4*)(s_tile + px * STRIDE + j * CCS + 4 * ql) = r[j][i];
+      }
+  } else {  // fill: (RH*RW) pixels x Q pieces, consecutive threads take consecutive pieces of a pixel
     const float* img = a.in + pix0 * CS;
     constexpr int PIECES = RH * RW * Q, PER_THR = (PIECES + NTHR - 1) / NTHR;
     float4 r[PER_THR];
@@ -989,6 +1048,7 @@ bool launch_conv3x3_c24(const ConvArgs& a, const Epilogue& ep, const float* wimg
   if (!rt_options().conv_c24) return false;  // OCR_CONV_C24=0: the 32-column tile kernel (A/B; results are identical)
   if (!wimg || !(a.KH == 3 && a.KW == 3 && a.PH == 1 && a.PW == 1 && a.OH == a.H && a.OW == a.W && a.out_mode == OUT_C8I)) return false;
   if (a.Cs_in != 96 || a.Cs_out != 24 || a.Cout != 24) return false;
+  if (a.cat_n && (a.cat_n != 4 || a.cat_cs != 24)) return false;  // (the folded fill is compiled for four 24-channel sources)
   for (int i = 0; i < ep.n; ++i) if (ep.st[i].kind == EP_ADDUP) return false;
   const int tiles_x = (a.OW + 15) / 16;   // (4-row tiles, 3 workgroups per CU: 64 instead of 90 TFLOP/s - measured, removed)
   const int tiles_y = (a.OH + 7) / 8;
@@ -1014,6 +1074,7 @@ bool OCR_L(launch_conv3x3_tile)(const ConvArgs& a, const Epilogue& ep, int nt, h
   const unsigned lds = 10 * 18 * (96 + 4) * sizeof(float);  // 72 000 B: two workgroups per CU
   // more than 64 KB of dynamic LDS has to be allowed per device (a worker pool drives several from one process)
   static LdsAttrMemo attr_state;
+  if (a.cat_n && (a.cat_n != 4 || a.cat_cs != 24)) return false;  // (the folded fill is compiled for four 24-channel sources)
 #ifdef OCR_TU_H16
   if (a.wfrag_x16 && rt_options().mfma_x16) {  // the f16-staged 32x32x16 form (52 bytes under the 64 KB that need no attribute)
     const unsigned lds16 = 10 * 18 * (96 + 8) * sizeof(_Float16);  // 37 440 B: four workgroups per CU
@@ -1021,6 +1082,7 @@ bool OCR_L(launch_conv3x3_tile)(const ConvArgs& a, const Epilogue& ep, int nt, h
     return true;
   }
 #endif
+  if (a.cat_n) return false;  // (a folded concat: the 4x4x1 / f16-staged forms only)
   if (!raise_dynamic_lds((const void*)conv3x3_tile_kernel<12, 1>, (int)lds, attr_state)) return false;  // the general kernel takes the launch
   hipLaunchKernelGGL((conv3x3_tile_kernel<12, 1>), grid, dim3(256), lds, s, a, ep, tiles_x, tiles_y);
   return true;

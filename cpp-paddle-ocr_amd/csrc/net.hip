@@ -848,6 +848,35 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths, const i
       fused_dw[oi] = 1;  // (same bookkeeping as a fused depthwise conv: no launch, no tensor)
     }
   }
+  // ---- the DB neck's concat (four 24-channel maps, upsampled x1 / x2 / x4 / x8) -> conv 3x3 96 -> 24: the conv's LDS-tile
+  // fill reads the four sources itself (kernels_net.hip, ConvArgs::cat_*); the 96-channel tensor (1.4 GB at configs[1]) is never
+  // written.  Only where the conv runs on a kernel that has the folded fill: the 4x4x1 form (f32) or the f16-staged form
+  // (precision "fp16", uniform batches).  OCR_FUSE_CONCAT=0 disables (A/B, results identical).
+  std::vector<int> cat_of(nops, -1);  // conv op -> the concat it absorbs
+  if (keep_all_ != 1 && rt_options().fuse_concat && (!rag || img)) {
+    for (int oi = 0; oi + 1 < nops; ++oi) {
+      const PlanOp& k = plan_.ops[oi];
+      if (k.kind != PlanOp::CONCAT || k.out == out_tid_ || uses[k.out] != 1 || k.ins.size() != 4 || T[k.out].cs != 96) continue;
+      if (T[k.out].numel() >= (1ul << 31)) continue;  // (the folded fill indexes its sources with 32 bits)
+      bool same = true;
+      for (int t : k.ins) same = same && T[t].cs * (int)k.ins.size() == 96 && T[t].f16 == T[k.out].f16 && !T[t].plain;
+      if (!same) continue;
+      for (int oj = oi + 1; oj < nops; ++oj) {
+        const PlanOp& c = plan_.ops[oj];
+        if (c.in != k.out) continue;
+        const bool conv33 = c.kind == PlanOp::CONV && c.kh == 3 && c.kw == 3 && c.sh == 1 && c.sw == 1 && c.ph == 1 && c.pw == 1 && c.cin == 96 && c.cout == 24;
+        bool ep_ok = true;
+        for (auto& st : c.ep) ep_ok = ep_ok && st.kind != EP_ADDUP && !(img && st.kind == EP_MULC);
+        const bool kernel_ok = half_ ? (!rag && rt_options().mfma_x16 && dev_vec("frag16x:" + c.w) && rt_options().conv_tile)
+                                     : (rt_options().conv_c24 && rt_options().conv_impl != 1 && dev_vec("c24:" + c.w) != nullptr);
+        if (conv33 && ep_ok && kernel_ok && !T[c.out].plain && gate_src[oj] < 0 && dwpw_of[oj] < 0) {
+          cat_of[oj] = oi;
+          folded[oi] = 1;  // (same bookkeeping as a folded gate multiply: no launch, no tensor, its reads happen in the conv)
+        }
+        break;
+      }
+    }
+  }
   // ---- RSE blocks of the detector's neck: conv 1x1 (Cin <= 24, no epilogue) -> gap -> sefc -> ew (x * g + x [+ upsampled]).
   // Materialised, the conv's 96-channel output is written once and read twice (pool, ew) before the result is written
   // again: three passes over 1.4 GB at 240 x 240 x 64 images for a K = 12 matrix product.  Instead the conv runs twice:
@@ -889,6 +918,7 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths, const i
     else if (gate_src[oi] >= 0) { last[gate_src[oi]] = oi; last[gate_tid[oi]] = oi; }
     else if (dwpw_of[oi] >= 0) last[plan_.ops[dwpw_of[oi]].in] = oi;
     else if (dbhead_of[oi] >= 0) last[plan_.ops[dbhead_of[oi]].in] = oi;
+    else if (cat_of[oi] >= 0) { for (int t : plan_.ops[cat_of[oi]].ins) last[t] = oi; }
     else if (op.in >= 0) last[op.in] = oi;
     for (int t : op.ins) last[t] = oi;
     for (auto& st : op.ep) if (st.tid >= 0) last[st.tid] = oi;
@@ -1139,6 +1169,19 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths, const i
             fused_head_groups_ = groups;
           }
           a.zeros = dev_vec("zeros");
+          double cat_bytes = 0;
+          if (cat_of[oi] >= 0) {  // the folded concat: the tile fill reads its sources
+            const PlanOp& k = plan_.ops[cat_of[oi]];
+            a.in = nullptr;
+            a.cat_n = (int)k.ins.size();
+            a.cat_cs = T[k.ins[0]].cs;
+            for (int j = 0; j < a.cat_n; ++j) {
+              a.cat_src[j] = arena_ + T[k.ins[j]].offset;
+              a.cat_up[j] = k.ups[j];
+              if (k.ups[j] < 1 || (k.ups[j] & (k.ups[j] - 1))) { err = "folded concat: upsampling factor is not a power of two"; return false; }
+              cat_bytes += EB(T[k.ins[j]]) * T[k.ins[j]].numel();
+            }
+          }
           if (gate_src[oi] >= 0) { a.gate = arena_ + T[gate_tid[oi]].offset; a.gate_hw = in.h * in.w; }
           a.M = (long)in.n * a.OH * a.OW;
           if (op.kind == PlanOp::LINEAR) a.M = (long)in.n * in.h * in.w;
@@ -1150,7 +1193,8 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths, const i
           const double cols = op.kind == PlanOp::DECONV ? 4.0 * op.cout : op.cout;
           L.flops = 2.0 * a.M * taps * op.cin * cols;
           if (a.gate) L.name += "_gated";
-          L.bytes = EB(in) * a.M * op.cin + (a.out_mode == OUT_HEAD ? 12.0 * a.M * (a.NTtot / nt) : EB(o) * a.M * cols) +
+          if (a.cat_n) L.name += "_cat" + std::to_string(a.cat_n);
+          L.bytes = (a.cat_n ? cat_bytes : EB(in) * a.M * op.cin) + (a.out_mode == OUT_HEAD ? 12.0 * a.M * (a.NTtot / nt) : EB(o) * a.M * cols) +
                     (hconv ? 2.0 : 4.0) * taps * op.cin * cols;
           // OCR_CONV_IMPL=direct|lds overrides the choice (A/B measurements); results are identical
           // measured (gpurun_out r1g): LDS staging wins for multi-tap convs (3x3 96->24: 58 vs 51 TFLOP/s),
@@ -1186,8 +1230,10 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths, const i
             };
           } else if (use_lds) {
             const float* c24 = dev_vec("c24:" + op.w);
-            L.fn = [a, ep, nt, c24](hipStream_t s) {
-              if (!launch_conv3x3_c24(a, ep, c24, s) && !launch_conv3x3_tile(a, ep, nt, s)) launch_conv_lds(a, ep, nt, s);
+            L.fn = [this, a, ep, nt, c24](hipStream_t s) {
+              if (launch_conv3x3_c24(a, ep, c24, s)) return;
+              if (a.cat_n) { this->launch_error_ = "folded concat: the 3x3 conv's 4x4x1 kernel refused the launch"; return; }
+              if (!launch_conv3x3_tile(a, ep, nt, s)) launch_conv_lds(a, ep, nt, s);
             };
           }
           else {
@@ -1213,6 +1259,7 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths, const i
             const bool half_tile = hconv && taps == 9 && !rag;  // precision "fp16": the LDS-resident 3x3 tile kernel has an f16 form
             L.fn = [this, a, ep, ntl, nt, mt2, half_tile](hipStream_t s) {
               if (half_tile && launch_conv3x3_tile(a, ep, nt, s)) return;
+              if (a.cat_n) { this->launch_error_ = "folded concat: the 3x3 conv's f16 tile kernel refused the launch"; return; }
               if (mt2 && launch_conv_mfma_mt2(a, ep, ntl, s)) return;
               if (!launch_conv_mfma(a, ep, ntl, s)) this->launch_error_ = "launch_conv_mfma: this conv shape / output mode is not instantiated";
             };

@@ -15,6 +15,7 @@ struct RtOptions {
   long fuse_gap_min = 65536;   // OCR_FUSE_GAP_MIN=n
   bool fuse_dbhead = true;     // OCR_FUSE_DBHEAD=0
   bool fuse_rse = true;        // OCR_FUSE_RSE=0
+  bool fuse_concat = true;     // OCR_FUSE_CONCAT=0: the DB neck's concat is materialised (A/B; results are identical)
   bool fuse_mb = false;        // OCR_FUSE_MB=1: the classifier's SE bottlenecks as one launch each (kernels_mb.hip: correct, measured slower, off)
   int conv_impl = 0;           // OCR_CONV_IMPL=direct (1) | lds (2); 0 = per shape
   bool conv_small_nt = true;   // OCR_CONV_SMALL_NT=0

@@ -749,9 +749,23 @@ __global__ void __launch_bounds__(256, 2) conv3x3_tile16_kernel(const ConvArgs a
   const unsigned groups = (unsigned)a.NTtot / NT;
   const int nt0 = (int)(lb % groups) * NT;
   unsigned tile = lb / groups;
-  const int tx = (int)(tile % tiles_x);
-  tile /= tiles_x;
-  const int ty = (int)(tile % tiles_y), n = (int)(tile / tiles_y);
+  int tx, ty, n;
+  int IH = a.H, IW = a.W;  // the tile's image (ragged batch of images: its own size, conv3x3_c24_kernel's decode)
+  long pix0;
+  if (a.rtiles) {
+    n = rag_line(a.rtiles, a.N, tile, 1);
+    IH = rag_h(a.rin, n, a.H); IW = rag_w(a.rin, n);
+    pix0 = rag_pix0(a.rin, n, a.H);
+    const unsigned t = tile - (unsigned)a.rtiles[n], txn = (unsigned)(IW + TW - 1) / TW;
+    ty = (int)(t / txn);
+    tx = (int)(t - (unsigned)ty * txn);
+  } else {
+    tx = (int)(tile % tiles_x);
+    tile /= tiles_x;
+    ty = (int)(tile % tiles_y);
+    n = (int)(tile / tiles_y);
+    pix0 = (long)n * a.H * a.W;
+  }
   const int y0 = ty * TH, x0 = tx * TW;
   if (a.cat_n) {  // a folded concat: source by source, as conv3x3_c24_kernel's fill (8-channel pieces: three per source pixel)
     constexpr int CCS = 24, QS = CCS / 8, PER_SRC = RH * RW * QS, PER_THR = (PER_SRC + 255) / 256;
@@ -760,8 +774,8 @@ __global__ void __launch_bounds__(256, 2) conv3x3_tile16_kernel(const ConvArgs a
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int lu = 31 - __clz(a.cat_up[j]);
-      const int sw = a.W >> lu;
-      const int base = n * (a.H >> lu) * sw;
+      const int sw = IW >> lu;
+      const int base = a.rtiles ? (a.rin.cw[n] >> (2 * (a.rin.shift + lu))) : n * (IH >> lu) * sw;
       const _Float16* sp = (const _Float16*)a.cat_src[j];
 #pragma unroll
       for (int i = 0; i < PER_THR; ++i) {
@@ -769,7 +783,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_tile16_kernel(const ConvArgs a
         const int px = p / QS, ql = p - px * QS;
         const int py = px / RW, pxx = px - py * RW;
         const int iy = y0 - 1 + py, ix = x0 - 1 + pxx;
-        const bool v = p < PER_SRC && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+        const bool v = p < PER_SRC && iy >= 0 && iy < IH && ix >= 0 && ix < IW;
         r[j][i] = v ? *(const uint4*)(sp + (base + (iy >> lu) * sw + (ix >> lu)) * CCS + 8 * ql) : uint4{0u, 0u, 0u, 0u};
       }
     }
@@ -782,7 +796,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_tile16_kernel(const ConvArgs a
         if (p < PER_SRC) *(uint4*)(s_tile + px * STRIDE + j * CCS + 8 * ql) = r[j][i];
       }
   } else {
-    const _Float16* img = (const _Float16*)a.in + (long)n * a.H * a.W * CS;
+    const _Float16* img = (const _Float16*)a.in + pix0 * CS;
     constexpr int PIECES = RH * RW * Q, PER_THR = (PIECES + 255) / 256;
     uint4 r[PER_THR];
 #pragma unroll
@@ -791,8 +805,8 @@ __global__ void __launch_bounds__(256, 2) conv3x3_tile16_kernel(const ConvArgs a
       const int px = idx / Q, q = idx - px * Q;
       const int py = px / RW, pxx = px - py * RW;
       const int iy = y0 - 1 + py, ix = x0 - 1 + pxx;
-      const bool v = idx < PIECES && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-      r[i] = v ? *(const uint4*)(img + ((long)iy * a.W + ix) * CS + q * 8) : uint4{0u, 0u, 0u, 0u};
+      const bool v = idx < PIECES && iy >= 0 && iy < IH && ix >= 0 && ix < IW;
+      r[i] = v ? *(const uint4*)(img + ((long)iy * IW + ix) * CS + q * 8) : uint4{0u, 0u, 0u, 0u};
     }
 #pragma unroll
     for (int i = 0; i < PER_THR; ++i) {
@@ -846,7 +860,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_tile16_kernel(const ConvArgs a
     }
   }
   const int oy = y0 + ly, ox = x0 + lx;
-  const long m = (oy < a.OH && ox < a.OW) ? ((long)n * a.OH + oy) * a.OW + ox : a.M;
+  const long m = (oy < IH && ox < IW) ? pix0 + (long)oy * IW + ox : a.M;  // (stride 1, pad 1: the output has the input's size)
   conv_finish<NT, OUT_C8I, true>(a, ep, acc, nt0, m, h, s_par);
 }
 #endif  // OCR_TU_H16
@@ -1068,9 +1082,13 @@ bool OCR_L(launch_conv3x3_tile)(const ConvArgs& a, const Epilogue& ep, int nt, h
   OCR_H16_TWIN(a.half, launch_conv3x3_tile_h16(a, ep, nt, s))
   if (!rt_options().conv_tile) return false;
   if (!(a.KH == 3 && a.KW == 3 && a.PH == 1 && a.PW == 1 && a.OH == a.H && a.OW == a.W && a.out_mode == OUT_C8I)) return false;
-  if (a.Cs_in != 96 || nt != 1 || a.rin.w) return false;  // (ragged batches: the chunked kernel decodes per row)
+  if (a.Cs_in != 96 || nt != 1) return false;
+  // ragged batches: the f16-staged form takes a batch of IMAGES through the tile table (conv3x3_c24_kernel's scheme); the f32
+  // form here decodes none (the chunked kernel decodes per row)
+  if (a.rin.w && !(kH16 && a.rtiles && a.rin.h && a.wfrag_x16 && rt_options().mfma_x16)) return false;
+  for (int i = 0; i < ep.n; ++i) if (a.rtiles && ep.st[i].kind == EP_MULC) return false;
   const int tiles_x = (a.OW + 15) / 16, tiles_y = (a.OH + 7) / 8;
-  const dim3 grid((unsigned)((long)a.N * tiles_y * tiles_x * (a.NTtot / nt)));
+  const dim3 grid((unsigned)((a.rtiles ? (long)a.rtiles_total : (long)a.N * tiles_y * tiles_x) * (a.NTtot / nt)));
   const unsigned lds = 10 * 18 * (96 + 4) * sizeof(float);  // 72 000 B: two workgroups per CU
   // more than 64 KB of dynamic LDS has to be allowed per device (a worker pool drives several from one process)
   static LdsAttrMemo attr_state;

@@ -867,7 +867,7 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths, const i
         const bool conv33 = c.kind == PlanOp::CONV && c.kh == 3 && c.kw == 3 && c.sh == 1 && c.sw == 1 && c.ph == 1 && c.pw == 1 && c.cin == 96 && c.cout == 24;
         bool ep_ok = true;
         for (auto& st : c.ep) ep_ok = ep_ok && st.kind != EP_ADDUP && !(img && st.kind == EP_MULC);
-        const bool kernel_ok = half_ ? (!rag && rt_options().mfma_x16 && dev_vec("frag16x:" + c.w) && rt_options().conv_tile)
+        const bool kernel_ok = half_ ? (rt_options().mfma_x16 && dev_vec("frag16x:" + c.w) && rt_options().conv_tile)
                                      : (rt_options().conv_c24 && rt_options().conv_impl != 1 && dev_vec("c24:" + c.w) != nullptr);
         if (conv33 && ep_ok && kernel_ok && !T[c.out].plain && gate_src[oj] < 0 && dwpw_of[oj] < 0) {
           cat_of[oj] = oi;
@@ -1256,7 +1256,7 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths, const i
             const bool mt2 = rt_options().conv_mt2 && (nt == 3 || nt == 4) && taps == 1 && a.out_mode == OUT_C8I &&
                              (rt_options().conv_mt2_force || (ntl == nt && in.cs >= 192 && ((a.M + 255) / 256) * (long)(a.NTtot / nt) >= 1024));
             if (mt2) ntl = nt;  // (the two-tile kernel is instantiated for the table's NT)
-            const bool half_tile = hconv && taps == 9 && !rag;  // precision "fp16": the LDS-resident 3x3 tile kernel has an f16 form
+            const bool half_tile = hconv && taps == 9 && (!rag || img);  // precision "fp16": the LDS-resident 3x3 tile kernel has an f16 form (uniform batches, ragged batches of images)
             L.fn = [this, a, ep, ntl, nt, mt2, half_tile](hipStream_t s) {
               if (half_tile && launch_conv3x3_tile(a, ep, nt, s)) return;
               if (a.cat_n) { this->launch_error_ = "folded concat: the 3x3 conv's f16 tile kernel refused the launch"; return; }

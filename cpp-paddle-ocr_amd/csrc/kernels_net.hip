@@ -1936,12 +1936,107 @@ __global__ void __launch_bounds__(64) attn_lds_kernel(const float* __restrict__ 
   }
 }
 
+// The same chains once more, a workgroup per LINE: eight waves = the eight heads.  attn_lds_kernel's wave per (line, head)
+// stages its head's K / V / Q values with 4-byte loads (36 per lane, two load -> barrier round trips) and keeps one line's
+// scores in LDS; 16 384 such workgroups took 0.24 ms per launch however the score chains were scheduled.  Here the line's
+// [T][Cs_in] block is read ONCE with 16-byte loads by all 512 threads and scattered into per-head K [T][16], V [T][16] and
+// Q [16][T] arrays (Q transposed: a lane reads its own query, consecutive lanes consecutive words), a lane's T <= TMAX scores
+// stay in registers, and every value, chain and order is attn_kernel's: score = fma chain over d ascending from 0, max,
+// e = exp(score - max) summed in key order, p = e / sum, out = fma chain over keys ascending.
+template <int HD, int HEADS, int TMAX>
+__global__ void __launch_bounds__(HEADS * 64) attn_line_kernel(const float* __restrict__ qkv, float* __restrict__ out, int N, int T,
+                                                               int Cs_in, int Cs_out, float scale, const RagLevel rag, const int TP) {
+  static_assert(HD <= 16, "head rows are padded to 16 floats");
+  extern __shared__ float s_att[];
+  const int tid = threadIdx.x, lane = tid & 63, hh = tid >> 6;
+  const int n = blockIdx.x;
+  long row0 = (long)n * T;                        // the line's first token
+  if (rag.w) { T = rag.w[n]; row0 = rag.cw[n]; }  // ragged batch: the line's own length (TP = the longest line's)
+  float* s_k = s_att;                             // [HEADS][TP][16]
+  float* s_v = s_k + HEADS * TP * 16;             // [HEADS][TP][16]
+  float* s_q = s_v + HEADS * TP * 16;             // [HEADS][16][TP]
+  constexpr int D = HEADS * HD;
+  const int q4n = Cs_in >> 2;
+  for (int i = tid; i < T * q4n; i += HEADS * 64) {
+    const int u = i / q4n, qd = i - u * q4n;
+    const float4 v4 = ld4<kH16>(qkv, (row0 + u) * Cs_in + 4 * qd);
+    const float vals[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int lc = c8i_logical(4 * qd + j);  // logical channel: q | k | v, each D = heads x HD wide
+      if (lc >= 3 * D) continue;               // (pad channels of the octet layout)
+      const int which = lc / D, r = lc - which * D;
+      const int head = r / HD, d = r - head * HD;
+      if (which == 0) s_q[(head * 16 + d) * TP + u] = vals[j];
+      else (which == 1 ? s_k : s_v)[(head * TP + u) * 16 + d] = vals[j];
+    }
+  }
+  __syncthreads();
+  const int t = lane;
+  if (t >= T) return;
+  float q[HD];
+#pragma unroll
+  for (int d = 0; d < HD; ++d) q[d] = s_q[(hh * 16 + d) * TP + t] * scale;
+  const float* kh = s_k + hh * TP * 16;
+  const float* vh = s_v + hh * TP * 16;
+  float e[TMAX];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int u = 0; u < TMAX; ++u) {
+    if (u < T) {  // (uniform)
+      float kr[16];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) *(float4*)(kr + 4 * j) = *(const float4*)(kh + u * 16 + 4 * j);
+      float acc = 0.f;
+#pragma unroll
+      for (int d = 0; d < HD; ++d) acc = fmaf(q[d], kr[d], acc);
+      e[u] = acc;
+      mx = fmaxf(mx, acc);
+    }
+  }
+  float sum = 0.f;
+#pragma unroll
+  for (int u = 0; u < TMAX; ++u) {
+    if (u < T) {
+      e[u] = ocr_expf(e[u] - mx);
+      sum = sum + e[u];
+    }
+  }
+  float o[HD];
+#pragma unroll
+  for (int d = 0; d < HD; ++d) o[d] = 0.f;
+#pragma unroll
+  for (int u = 0; u < TMAX; ++u) {
+    if (u < T) {
+      float vr[16];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) *(float4*)(vr + 4 * j) = *(const float4*)(vh + u * 16 + 4 * j);
+      const float pw = e[u] / sum;
+#pragma unroll
+      for (int d = 0; d < HD; ++d) o[d] = fmaf(pw, vr[d], o[d]);
+    }
+  }
+  const long dst = (row0 + t) * Cs_out;
+#pragma unroll
+  for (int d = 0; d < HD; ++d) st1<kH16>(out, dst + c8i_phys(hh * HD + d), o[d]);
+}
+
 #ifndef OCR_TU_H16
 bool attn_ragged_fits(int T) { return ((size_t)T * 96 + 64 * 17) * sizeof(float) <= 150 * 1024; }
 #endif
 void OCR_L(launch_attn)(const float* qkv, float* out, int N, int T, int heads, int hd, int Cs_in, int Cs_out, float scale,
                         hipStream_t s, RagLevel rag, bool h16) {
   OCR_H16_TWIN(h16, launch_attn_h16(qkv, out, N, T, heads, hd, Cs_in, Cs_out, scale, s, rag, h16))
+  // lines of at most 64 tokens (the recognizer's 320-pixel lines have 40): a workgroup per line, a wave per head
+  // (OCR_ATTN_LINE=0: the wave-per-(line, head) kernel below, A/B; results are identical)
+  if (rt_options().attn_line && heads == 8 && hd == 15 && T <= 64 && T > 0) {
+    const size_t ldsl = (size_t)3 * 8 * T * 16 * sizeof(float);
+    static LdsAttrMemo attr_line;
+    if (ldsl <= 64 * 1024 || raise_dynamic_lds((const void*)attn_line_kernel<15, 8, 64>, 100 * 1024, attr_line)) {
+      hipLaunchKernelGGL((attn_line_kernel<15, 8, 64>), dim3((unsigned)N), dim3(512), ldsl, s, qkv, out, N, T, Cs_in, Cs_out, scale, rag, T);
+      return;
+    }
+  }
   const size_t lds = ((size_t)T * 96 + 64 * 17) * sizeof(float);
   if (lds <= 150 * 1024) {
     static LdsAttrMemo attr_state;  // per device: the pool drives several from one process

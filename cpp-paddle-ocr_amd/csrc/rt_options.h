@@ -25,6 +25,7 @@ struct RtOptions {
   bool conv_c24 = true;        // OCR_CONV_C24=0
   bool conv_tile = true;       // OCR_CONV_TILE=0
   int dw_patch_to = 0, dw_patch_r = 0;  // OCR_DW_PATCH=TOxR; 0 = per shape
+  bool attn_line = true;       // OCR_ATTN_LINE=0: attention as a wave per (line, head) also for lines of <= 64 tokens (A/B)
   bool mfma_x16 = true;        // OCR_MFMA_X16=0: precision "fp16" keeps v_mfma_f32_32x32x8_f16 in the big 1x1 convs (A/B)
   bool dw_lds = true;          // OCR_DW_LDS=0: the low-map 5x5 depthwise layers keep dw_conv_kernel (A/B; results are identical)
   int dwpw_items = 32;         // OCR_DWPW_ITEMS=n

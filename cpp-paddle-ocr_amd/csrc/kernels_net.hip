@@ -1146,9 +1146,11 @@ __global__ void __launch_bounds__(256) stem_conv_kernel(const StemArgs a, const 
     decompose(m, a.OH * a.OW, a.OW, n, y, x);
     ipix0 = (long)n * a.H * a.W;
   }
-  float acc[CS];
+  // (two adjacent output channels per v_pk_fma_f32 - each lane of it is the same IEEE fma as the scalar instruction, the weights
+  // are wave-uniform scalar pairs; as 27 x CS scalar fmas the kernel spent a third of its time issuing them)
+  ocr_f2 acc[CS / 2];
 #pragma unroll
-  for (int c = 0; c < CS; ++c) acc[c] = 0.f;
+  for (int c = 0; c < CS / 2; ++c) acc[c] = ocr_f2{0.f, 0.f};
   // one 12-byte load per tap (the pixel's three floats; 4-byte alignment is all dwordx3 needs), masked afterwards
   // with a lane mask: three dword loads under a select each made the kernel bound by the number of load instructions
   struct P3 { float c[3]; };
@@ -1167,7 +1169,8 @@ __global__ void __launch_bounds__(256) stem_conv_kernel(const StemArgs a, const 
 #pragma unroll
     for (int ci = 0; ci < 3; ++ci)
 #pragma unroll
-      for (int c = 0; c < CS; ++c) acc[c] = fmaf(in3[ci], w[ci * CS + c], acc[c]);
+      for (int c = 0; c < CS; c += 2)
+        acc[c >> 1] = __builtin_elementwise_fma(ocr_f2{in3[ci], in3[ci]}, ocr_f2{w[ci * CS + c], w[ci * CS + c + 1]}, acc[c >> 1]);
   };
   if (a.KH == 3 && a.KW == 3) {  // every stem on this path: the nine taps' loads in flight before the first FMA
     P3 px[9];
@@ -1187,7 +1190,7 @@ __global__ void __launch_bounds__(256) stem_conv_kernel(const StemArgs a, const 
   }
 #pragma unroll
   for (int c = 0; c < CS; c += 4) {
-    float4 v = make_float4(acc[c], acc[c + 1], acc[c + 2], acc[c + 3]);
+    float4 v = make_float4(acc[c >> 1].x, acc[c >> 1].y, acc[(c >> 1) + 1].x, acc[(c >> 1) + 1].y);
     v = apply_epilogue4<H16>(ep, v, c, n, y, x, m * CS + c, CS);
     st4<H16>(a.out, m * CS + c, v);
   }

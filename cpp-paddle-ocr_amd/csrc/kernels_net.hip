@@ -554,8 +554,17 @@ __global__ void __launch_bounds__(256, 2) conv_lds_kernel(const ConvArgs a, cons
         // branch-free validity and address (no short-circuit control flow around the load)
         const int rw = ri.y & 0xffff, rh = ri.y >> 16;
         const bool v = (ri.x >= 0) & (iy >= 0) & (iy < rh) & (ix >= 0) & (ix < rw);
-        const long off = ((long)ri.x + (long)(v ? iy : 0) * rw + (v ? ix : 0)) * a.Cs_in + cc * BK + seg * 4;
-        const float* src = v ? a.in + off : a.zeros;
+        // (a folded same-resolution concat, ConvArgs::cat_*: the chunk's channels live in source cc * BK / cat_cs - uniform)
+        const float* abase = a.in;
+        int cs_row = a.Cs_in, coff = cc * BK;
+        if (a.cat_n) {
+          const int j = coff / a.cat_cs;
+          abase = j == 0 ? a.cat_src[0] : j == 1 ? a.cat_src[1] : j == 2 ? a.cat_src[2] : a.cat_src[3];
+          coff -= j * a.cat_cs;
+          cs_row = a.cat_cs;
+        }
+        const long off = ((long)ri.x + (long)(v ? iy : 0) * rw + (v ? ix : 0)) * cs_row + coff + seg * 4;
+        const float* src = v ? abase + off : a.zeros;
         return *(const float4*)src;
       };
       ra0 = load_a(0);

@@ -853,10 +853,32 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths, const i
   // written.  Only where the conv runs on a kernel that has the folded fill: the 4x4x1 form (f32) or the f16-staged form
   // (precision "fp16", uniform batches).  OCR_FUSE_CONCAT=0 disables (A/B, results identical).
   std::vector<int> cat_of(nops, -1);  // conv op -> the concat it absorbs
+  // The recognizer's neck has the same shape without upsampling: concat (two 480-channel sequences) -> conv 1x3 960 -> 60; the
+  // LDS-staged conv (f32) reads chunk c of its input from source c * BK / 480 (conv_lds_kernel, load_a).
+  if (keep_all_ != 1 && rt_options().fuse_concat && !half_ && rt_options().conv_impl != 1) {
+    for (int oi = 0; oi + 1 < nops; ++oi) {
+      const PlanOp& k = plan_.ops[oi];
+      if (k.kind != PlanOp::CONCAT || k.out == out_tid_ || uses[k.out] != 1 || k.ins.size() < 2 || k.ins.size() > 4) continue;
+      bool same = true;
+      for (size_t j = 0; j < k.ins.size(); ++j)
+        same = same && k.ups[j] == 1 && T[k.ins[j]].cs == T[k.ins[0]].cs && !T[k.ins[j]].plain && T[k.ins[j]].lvl == T[k.out].lvl;
+      if (!same || T[k.ins[0]].cs % 32 || T[k.ins[0]].cs * (int)k.ins.size() != T[k.out].cs) continue;
+      for (int oj = oi + 1; oj < nops; ++oj) {
+        const PlanOp& c = plan_.ops[oj];
+        if (c.in != k.out) continue;
+        const bool lds_conv = c.kind == PlanOp::CONV && c.kh * c.kw > 1 && c.sh == 1 && c.sw == 1 && !(c.kh == 3 && c.kw == 3 && c.cin == 96);
+        if (lds_conv && !T[c.out].plain && gate_src[oj] < 0 && dwpw_of[oj] < 0) {
+          cat_of[oj] = oi;
+          folded[oi] = 1;
+        }
+        break;
+      }
+    }
+  }
   if (keep_all_ != 1 && rt_options().fuse_concat && (!rag || img)) {
     for (int oi = 0; oi + 1 < nops; ++oi) {
       const PlanOp& k = plan_.ops[oi];
-      if (k.kind != PlanOp::CONCAT || k.out == out_tid_ || uses[k.out] != 1 || k.ins.size() != 4 || T[k.out].cs != 96) continue;
+      if (k.kind != PlanOp::CONCAT || folded[oi] || k.out == out_tid_ || uses[k.out] != 1 || k.ins.size() != 4 || T[k.out].cs != 96) continue;
       if (T[k.out].numel() >= (1ul << 31)) continue;  // (the folded fill indexes its sources with 32 bits)
       bool same = true;
       for (int t : k.ins) same = same && T[t].cs * (int)k.ins.size() == 96 && T[t].f16 == T[k.out].f16 && !T[t].plain;
@@ -1232,8 +1254,10 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths, const i
             const float* c24 = dev_vec("c24:" + op.w);
             L.fn = [this, a, ep, nt, c24](hipStream_t s) {
               if (launch_conv3x3_c24(a, ep, c24, s)) return;
-              if (a.cat_n) { this->launch_error_ = "folded concat: the 3x3 conv's 4x4x1 kernel refused the launch"; return; }
-              if (!launch_conv3x3_tile(a, ep, nt, s)) launch_conv_lds(a, ep, nt, s);
+              bool cat_same_res = a.cat_n > 0;  // (a same-resolution concat folds into the LDS-staged conv's chunk loads)
+              for (int j = 0; j < a.cat_n; ++j) cat_same_res = cat_same_res && a.cat_up[j] == 1;
+              if (a.cat_n && !cat_same_res) { this->launch_error_ = "folded concat: the 3x3 conv's 4x4x1 kernel refused the launch"; return; }
+              if (a.cat_n || !launch_conv3x3_tile(a, ep, nt, s)) launch_conv_lds(a, ep, nt, s);
             };
           }
           else {

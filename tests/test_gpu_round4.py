@@ -401,6 +401,41 @@ def test_fp16_stores_saturate_instead_of_overflowing(pkg, built):
     n.close()
 
 
+_FP16_X8_CHILD = r"""
+import sys, os
+root = sys.argv[1]
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
+import numpy as np
+from __graft_entry__ import load_package
+pkg = load_package()
+rs = np.random.RandomState(12)
+out = {}
+for kind, shape in (("cls", (4, 48, 192)), ("det", (2, 160, 224)), ("rec", (3, 48, 320))):
+    x = rs.randn(shape[0], shape[1], shape[2], 3).astype(np.float32)
+    a, b = pkg.Net(kind), pkg.Net(kind, precision="fp16")
+    ya, yb = a.forward(x).reshape(-1), b.forward(x).reshape(-1)
+    a.close(); b.close()
+    d = np.abs(ya - yb)
+    print(kind, float(d.mean()), float(d.max()), float(np.abs(ya).max()))
+    assert np.isfinite(yb).all()
+    if kind == "cls": assert d.max() <= 2e-3
+    if kind == "det": assert d.mean() <= 2e-3 and np.quantile(d, 0.99) <= 1e-2
+    if kind == "rec": assert d.max() <= 0.02 * np.abs(ya).max()
+print("X8 OK")
+"""
+
+
+def test_fp16_with_the_32x32x8_kernels_keeps_the_tolerances(built):
+    """OCR_MFMA_X16=0 (read once per process: a child process) sends the fp16 mode's big 1x1 convs and 3x3 96-channel convs back
+    to their v_mfma_f32_32x32x8_f16 forms - the instantiations every other shape of the mode runs anyway; the same tolerances
+    against the fp32 mode hold."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", _FP16_X8_CHILD, root], env=dict(os.environ, OCR_MFMA_X16="0"), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "X8 OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
 def test_fp16_pipeline_agrees_with_fp32_on_the_benchmark_batch(pkg, built):
     """The whole path in fp16 on 8 configs[1] images (256 lines, probability-map protocol): boxes are identical (they
     come from the protocol's maps), the CTC id sequences agree on >= 95 % of the lines, confidences within 1e-4; the

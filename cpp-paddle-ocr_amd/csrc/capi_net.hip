@@ -28,6 +28,7 @@ const RtOptions& rt_options() {
     o.fuse_gap = !off("OCR_FUSE_GAP");
     o.fuse_gap_min = num("OCR_FUSE_GAP_MIN", 64 * 1024);
     o.fuse_dbhead = !off("OCR_FUSE_DBHEAD");
+    o.dbhead_mfma = !off("OCR_DBHEAD_MFMA");
     o.fuse_rse = !off("OCR_FUSE_RSE");
     o.fuse_concat = !off("OCR_FUSE_CONCAT");
     { const char* e = getenv("OCR_FUSE_MB"); o.fuse_mb = e && e[0] == '1'; }

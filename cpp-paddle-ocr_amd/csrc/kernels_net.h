@@ -250,6 +250,7 @@ struct DbHeadArgs {
   float* prob;        // [N,4H,4W]
   uint8_t* bitmap;    // [N,4H,4W] {0,1} or null
   const float* w1;    // [C k][4 q][C c] logical channels, q = dy*2+dx
+  const float* wfrag = nullptr;  // or the first stage as a matrix-core fragment image with the head's column order ("dbhf:")
   const float* bias1; // [Cs] physical order
   const float* bn_s;  // [Cs] physical order: scale
   const float* bn_t;  // [Cs] physical order: shift

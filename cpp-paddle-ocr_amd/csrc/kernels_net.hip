@@ -2302,9 +2302,101 @@ __global__ void __launch_bounds__(256) db_head_kernel(const DbHeadArgs a) {
     }
   }
 }
+// The same head with the first transposed conv on the matrix cores (a.wfrag): a wave takes 32 input pixels, lanes (p, 0)
+// and (p, 1) of pixel p share its 96 first-stage values.  The columns of the weight image are permuted (net.hip, "dbhf:")
+// so that lane (p, h) ends up with exactly quadrants 2h and 2h+1 - rows 2h, 2h+1 of the pixel's 4x4 block of the map -
+// in its own accumulators: value l = 24*(q & 1) + physical channel sits in acc[l / 16][l % 16], and the second stage
+// needs no exchange between lanes.  Each value's chain is the matrix-core deconv's (k ascending in logical order, two per
+// instruction), the stages after it are db_head_kernel's: same bits.
+template <bool H16>
+__global__ void __launch_bounds__(256) db_head_mfma_kernel(const DbHeadArgs a) {
+  constexpr int C = 24;
+  const int lane = threadIdx.x & 63, p = lane & 31, h = lane >> 5;
+  const long m0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 32;
+  if (m0 >= a.M) return;  // the whole wave
+  const bool live = m0 + p < a.M;
+  const long m = live ? m0 + p : a.M - 1;
+  float4 av[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) av[j] = ld4<H16>(a.in, m * C + 8 * j + 4 * h);
+  const float4* __restrict__ wf = (const float4*)a.wfrag + lane;
+  floatx16 acc[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    float4 bv[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) bv[t] = wf[(j * 3 + t) * 64];
+#define OCR_H_SWEEP(X)                                                                                                    \
+  _Pragma("unroll") for (int t = 0; t < 3; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[t].X, av[j].X, acc[t], 0, 0, 0);
+    OCR_H_SWEEP(x) OCR_H_SWEEP(y) OCR_H_SWEEP(z) OCR_H_SWEEP(w)
+#undef OCR_H_SWEEP
+  }
+  int n, y, x;
+  long OW = 4L * a.W, opix0;
+  if (a.rin.h) {
+    int w;
+    rag_decompose(a.rin, a.N, a.H, m, m0, n, y, x, w);
+    OW = 4L * w;
+    opix0 = (long)(a.rin.cw[n] >> (2 * (a.rin.shift - 2)));
+  } else {
+    decompose(m, a.H * a.W, a.W, n, y, x);
+    opix0 = (long)n * 16 * a.H * a.W;
+  }
+  // bias, BN, relu on the lane's 48 values, in place (the per-channel vectors are in physical order, like the accumulators)
+#pragma unroll
+  for (int l = 0; l < 2 * C; ++l) {
+    const int pc = l % C;
+    float v = acc[l / 16][l % 16] + a.bias1[pc];
+    const float u = v * a.bn_s[pc];
+    v = u + a.bn_t[pc];
+    acc[l / 16][l % 16] = fmaxf(v, 0.0f);
+  }
+  float pr[2][4];  // [row 2h + r of the 4x4 block][column]
+#pragma unroll
+  for (int ql = 0; ql < 2; ++ql) {  // quadrant 2h + ql: rows 2h.., columns 2ql..
+    ocr_f2 o01 = {0.f, 0.f}, o23 = {0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const int l = ql * C + c8i_phys(c);
+      const float hv = acc[l / 16][l % 16];
+      const float* w = a.w2 + c * 4;
+      o01 = __builtin_elementwise_fma(ocr_f2{hv, hv}, ocr_f2{w[0], w[1]}, o01);
+      o23 = __builtin_elementwise_fma(ocr_f2{hv, hv}, ocr_f2{w[2], w[3]}, o23);
+    }
+    const float o4[4] = {o01.x, o01.y, o23.x, o23.y};
+#pragma unroll
+    for (int q2 = 0; q2 < 4; ++q2) {
+      const float v = o4[q2] + a.bias2;
+      const float e = ocr_expf(-v);
+      const float d = 1.0f + e;
+      pr[q2 >> 1][2 * ql + (q2 & 1)] = 1.0f / d;
+    }
+  }
+  if (!live) return;
+  const long obase = opix0 + (long)(4 * y + 2 * h) * OW + 4 * x;
+#pragma unroll
+  for (int row = 0; row < 2; ++row) {
+    const long o = obase + row * OW;
+    *(float4*)(a.prob + o) = make_float4(pr[row][0], pr[row][1], pr[row][2], pr[row][3]);
+    if (a.bitmap) {
+      unsigned bits = 0;
+#pragma unroll
+      for (int col = 0; col < 4; ++col) bits |= ((int)(pr[row][col] * 255.0f) > a.ithresh ? 1u : 0u) << (8 * col);
+      *(unsigned*)(a.bitmap + o) = bits;
+    }
+  }
+}
 bool OCR_L(launch_db_head)(const DbHeadArgs& a, int C, hipStream_t s) {
   OCR_H16_TWIN(a.h16, launch_db_head_h16(a, C, s))
   if (C != 24 || a.Cs != 24) return false;
+  if (a.wfrag) {
+    hipLaunchKernelGGL(db_head_mfma_kernel<kH16>, dim3((unsigned)((a.M + 127) / 128)), dim3(256), 0, s, a);
+    return true;
+  }
   hipLaunchKernelGGL(db_head_kernel<24>, dim3((unsigned)((a.M + 255) / 256)), dim3(256), 0, s, a);
   return true;
 }

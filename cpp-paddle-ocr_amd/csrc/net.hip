@@ -360,6 +360,17 @@ bool Net::load(const char* plan_text, const WeightMap& W, std::string& err, bool
             for (int q = 0; q < 4; ++q)
               for (int c = 0; c < co; ++c) img[((size_t)k * 4 + q) * co + c] = w[((size_t)k * co + c) * 4 + q];
           if (!upload("dbh1:" + op.w, img)) { err = "hipMalloc failed"; return false; }
+          // the same stage as a fragment image whose columns are in the fused head's order (db_head_mfma_kernel): lane
+          // (p, h) of column tile t owns value l = 16t + 4g + i of quadrants 2h, 2h+1 = column 32t + 8g + 4h + i
+          if (ci == 24 && co == 24) {
+            auto hf = build_frag(1, ci, 4 * cp, [&](int col, int k, int) {
+              const int t = col / 32, pp = col % 32, l = t * 16 + (pp / 8) * 4 + pp % 4;
+              const int q = 2 * ((pp % 8) / 4) + l / cp, ch = c8i_logical(l % cp);
+              return ch < co ? w[((size_t)k * co + ch) * 4 + q] : 0.f;
+            });
+            if (hf.size() != (size_t)3 * 3 * 256) { err = "DB head fragment image: unexpected tiling"; return false; }
+            if (!upload("dbhf:" + op.w, hf)) { err = "hipMalloc failed"; return false; }
+          }
         }
       } break;
       case PlanOp::DW: {
@@ -1121,6 +1132,7 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths, const i
             DbHeadArgs h{};
             h.in = arena_ + din.offset; h.prob = optr; h.bitmap = det_bitmap_;
             h.w1 = dev_vec("dbh1:" + d.w); h.bias1 = epd.st[0].v0; h.bn_s = epd.st[1].v0; h.bn_t = epd.st[1].v1;
+            if (rt_options().dbhead_mfma && d.cin == 24 && d.cout == 24) h.wfrag = dev_vec("dbhf:" + d.w);
             h.w2 = a.w; h.M = din.pixels(); h.N = din.n; h.H = din.h; h.W = din.w; h.Cs = din.cs;
             h.bias2 = a.bias; h.ithresh = a.ithresh;
             h.h16 = din.f16;

@@ -14,6 +14,7 @@ struct RtOptions {
   bool fuse_gap = true;        // OCR_FUSE_GAP=0
   long fuse_gap_min = 65536;   // OCR_FUSE_GAP_MIN=n
   bool fuse_dbhead = true;     // OCR_FUSE_DBHEAD=0
+  bool dbhead_mfma = true;     // OCR_DBHEAD_MFMA=0: the fused DB head's first stage on the VALU (db_head_kernel)
   bool fuse_rse = true;        // OCR_FUSE_RSE=0
   bool fuse_concat = true;     // OCR_FUSE_CONCAT=0: the DB neck's concat is materialised (A/B; results are identical)
   bool fuse_mb = false;        // OCR_FUSE_MB=1: the classifier's SE bottlenecks as one launch each (kernels_mb.hip: correct, measured slower, off)

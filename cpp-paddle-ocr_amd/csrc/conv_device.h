@@ -151,6 +151,7 @@ __device__ __forceinline__ float apply_epilogue(const Epilogue& ep, float v, int
       case EP_BIAS: v = v + st.v0[pc]; break;
       case EP_SMUL: v = st.p0 * v; break;
       case EP_SADD: v = v + st.p0; break;
+      case EP_SFMA: v = fmaf(v, st.p0, st.p1); break;
       case EP_BN: { float t = v * st.v0[pc]; v = t + st.v1[pc]; } break;
       case EP_ACT: v = ocr_act(st.act, st.p0, st.p1, v); break;
       case EP_MULC: v = v * st.v0[(long)n * cs + pc]; break;
@@ -175,6 +176,7 @@ __device__ __forceinline__ float4 apply_epilogue4(const Epilogue& ep, float4 v, 
       case EP_BIAS: { float4 b = *(const float4*)(st.v0 + pc); v.x = v.x + b.x; v.y = v.y + b.y; v.z = v.z + b.z; v.w = v.w + b.w; } break;
       case EP_SMUL: v.x = st.p0 * v.x; v.y = st.p0 * v.y; v.z = st.p0 * v.z; v.w = st.p0 * v.w; break;
       case EP_SADD: v.x = v.x + st.p0; v.y = v.y + st.p0; v.z = v.z + st.p0; v.w = v.w + st.p0; break;
+      case EP_SFMA: v.x = fmaf(v.x, st.p0, st.p1); v.y = fmaf(v.y, st.p0, st.p1); v.z = fmaf(v.z, st.p0, st.p1); v.w = fmaf(v.w, st.p0, st.p1); break;
       case EP_BN: {
         float4 sc = *(const float4*)(st.v0 + pc), sh = *(const float4*)(st.v1 + pc);
         float t;
@@ -292,6 +294,16 @@ __device__ __forceinline__ void conv_finish(const ConvArgs& a, const Epilogue& e
         const float k = st.p0;
         OCR_EP_SWEEP({ wx = wx + k; wy = wy + k; wz = wz + k; ww = ww + k; })
       } break;
+      case EP_SFMA: {  // one rounding per value (v_pk_fma_f32 with the scalar pair)
+        const ocr_f2 k = {st.p0, st.p0};
+        const ocr_f2 d = {st.p1, st.p1};
+        OCR_EP_SWEEP({
+          ocr_f2 lo; ocr_f2 hi;
+          lo.x = wx; lo.y = wy; hi.x = wz; hi.y = ww;
+          lo = __builtin_elementwise_fma(lo, k, d); hi = __builtin_elementwise_fma(hi, k, d);
+          wx = lo.x; wy = lo.y; wz = hi.x; ww = hi.y;
+        })
+      } break;
       case EP_BN: {
         const float* q0 = spar + vs * sstride + 4 * hb;
         vs += 2;
@@ -318,6 +330,14 @@ __device__ __forceinline__ void conv_finish(const ConvArgs& a, const Epilogue& e
             if (ocr_hsw_fast_ok(mn, mx)) { OCR_EP_SWEEP({ ocr_hswish4_fast(wx, wy, wz, ww); }) }
             else { OCR_ACT_SWEEP(ACT_HSWISH) }
           } break;
+          case ACT_HSW6:
+            OCR_EP_SWEEP({
+              ocr_f2 lo; ocr_f2 hi;
+              lo.x = wx; lo.y = wy; hi.x = wz; hi.y = ww;
+              lo = ocr_hsw6_2(lo); hi = ocr_hsw6_2(hi);
+              wx = lo.x; wy = lo.y; wz = hi.x; ww = hi.y;
+            })
+            break;
           case ACT_HSIG: OCR_ACT_SWEEP(ACT_HSIG) break;
           case ACT_SWISH: OCR_ACT_SWEEP(ACT_SWISH) break;
           default: OCR_ACT_SWEEP(ACT_SIGMOID) break;

@@ -37,6 +37,10 @@ __device__ __forceinline__ void dw_patch_epilogue(DwF4 (&acc)[R][TO], const Epil
         const ocr_f2 k = {st.p0, st.p0};
         OCR_DW_SWEEP({ v.lo = v.lo + k; v.hi = v.hi + k; })
       } break;
+      case EP_SFMA: {
+        const ocr_f2 k = {st.p0, st.p0}, d = {st.p1, st.p1};
+        OCR_DW_SWEEP({ v.lo = __builtin_elementwise_fma(v.lo, k, d); v.hi = __builtin_elementwise_fma(v.hi, k, d); })
+      } break;
       case EP_BN: {
         const float4 sc = *(const float4*)(st.v0 + pc), sh = *(const float4*)(st.v1 + pc);
         const ocr_f2 clo = {sc.x, sc.y}, chi = {sc.z, sc.w}, hlo = {sh.x, sh.y}, hhi = {sh.z, sh.w};
@@ -58,6 +62,7 @@ __device__ __forceinline__ void dw_patch_epilogue(DwF4 (&acc)[R][TO], const Epil
             if (ocr_hsw_fast_ok(mn, mx)) { OCR_DW_SWEEP({ v.lo = ocr_hswish2_fast(v.lo); v.hi = ocr_hswish2_fast(v.hi); }) }
             else { OCR_DW_ACT(ACT_HSWISH) }
           } break;
+          case ACT_HSW6: OCR_DW_SWEEP({ v.lo = ocr_hsw6_2(v.lo); v.hi = ocr_hsw6_2(v.hi); }) break;
           case ACT_HSIG: OCR_DW_ACT(ACT_HSIG) break;
           case ACT_SWISH: OCR_DW_ACT(ACT_SWISH) break;
           default: OCR_DW_ACT(ACT_SIGMOID) break;

@@ -10,15 +10,16 @@
 //       steps            the depthwise taps of chunk k issued INSIDE the MFMA stream of chunk k-1 (FUSED below):
 //         DW  LDS -> VALU      a thread owns PR vertically adjacent output pixels x 4 physical channels, taps in
 //                              (ky, kx) ascending order from 0 - the contract's chain - read
-//                              TD steps ahead of their FMAs; the whole depthwise epilogue, written to LDS as the MFMA
-//                              pixel operand
+//                              TD steps ahead of their FMAs; the depthwise epilogue (after the LAB fold: + bias, the
+//                              hard-swish's product), written to LDS as the MFMA pixel operand
 //         MMA LDS -> MFMA      v_mfma_f32_32x32x2_f32 against the 1x1 weights' fragment image (the same image
 //                              conv_mfma_kernel reads; a wave = 32 pixels x NT column tiles), ascending k; a fragment
 //                              register is refilled with chunk k's fragment right after its last MFMA
 //       S  registers -> LDS    chunk k+1's haloed input region (16-byte pieces, zero outside the image), its K*K
 //                              depthwise weights and its per-channel epilogue vector
 //       G  global -> registers the same for chunk k+2 (k+3 with two register sets)
-//   epilogue    : the 1x1 conv's own LAB chain and 16-byte stores when a tile's last chunk has been multiplied
+//   epilogue    : the 1x1 conv's own folded chain (+ bias, hard-swish product, one fma) and 16-byte stores when a tile's last
+//                 chunk has been multiplied
 //
 // The pixel operand lives in LDS exactly as the C8I tensor would in HBM (pixel-major, 4 consecutive physical channels
 // per lane), so the matrix pipe sees the same k-ordered chain as the unfused pair: results are bit-identical
@@ -88,12 +89,12 @@ __device__ __forceinline__ ocr_f2 pk_add(ocr_f2 a, ocr_f2 b) {
   asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
   return d;
 }
-// (scalar pair in SGPRs: one constant-bus operand per VOP3P instruction)
-__device__ __forceinline__ ocr_f2 pk_mul_s(ocr_f2 s, ocr_f2 b) {
+__device__ __forceinline__ ocr_f2 pk_mul(ocr_f2 a, ocr_f2 b) {
   ocr_f2 d;
-  asm("v_pk_mul_f32 %0, %1, %2" : "=v"(d) : "s"(s), "v"(b));
+  asm("v_pk_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
   return d;
 }
+// (scalar pair in SGPRs: one constant-bus operand per VOP3P instruction)
 __device__ __forceinline__ ocr_f2 pk_add_s(ocr_f2 s, ocr_f2 b) {
   ocr_f2 d;
   asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "s"(s), "v"(b));
@@ -102,7 +103,7 @@ __device__ __forceinline__ ocr_f2 pk_add_s(ocr_f2 s, ocr_f2 b) {
 #else
 __device__ __forceinline__ ocr_f2 pk_fma(ocr_f2 a, ocr_f2 b, ocr_f2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ ocr_f2 pk_add(ocr_f2 a, ocr_f2 b) { return a + b; }
-__device__ __forceinline__ ocr_f2 pk_mul_s(ocr_f2 s, ocr_f2 b) { return s * b; }
+__device__ __forceinline__ ocr_f2 pk_mul(ocr_f2 a, ocr_f2 b) { return a * b; }
 __device__ __forceinline__ ocr_f2 pk_add_s(ocr_f2 s, ocr_f2 b) { return b + s; }
 #endif
 
@@ -174,21 +175,16 @@ struct UnitPos {
   __device__ __forceinline__ long out_pix(const DwPwArgs& a) const { return RAG ? rag_pix0(a.rout, n, a.c.OH) : (long)n * a.c.OH * a.c.OW; }
 };
 
-// the LAB chain on two packed pairs; bias already added by the caller where it comes from elsewhere
-template <bool ACT>
-__device__ __forceinline__ void lab_apply(F4& v, const ocr_f2 blo, const ocr_f2 bhi, const float s0, const float a0, const float s1,
-                                          const float a1, const bool fast) {
-  const ocr_f2 S0 = {s0, s0}, A0 = {a0, a0};
-  v.lo = pk_add(v.lo, blo); v.hi = pk_add(v.hi, bhi);
-  v.lo = pk_mul_s(S0, v.lo); v.hi = pk_mul_s(S0, v.hi);
-  v.lo = pk_add_s(A0, v.lo); v.hi = pk_add_s(A0, v.hi);
-  if constexpr (ACT) {
-    if (fast) { v.lo = ocr_hswish2_fast(v.lo); v.hi = ocr_hswish2_fast(v.hi); }
-    else { v.lo.x = ocr_hswish_div(v.lo.x); v.lo.y = ocr_hswish_div(v.lo.y); v.hi.x = ocr_hswish_div(v.hi.x); v.hi.y = ocr_hswish_div(v.hi.y); }
-    const ocr_f2 S1 = {s1, s1}, A1 = {a1, a1};
-    v.lo = S1 * v.lo; v.hi = S1 * v.hi;
-    v.lo = v.lo + A1; v.hi = v.hi + A1;
-  }
+// The depthwise half's epilogue after the LAB fold (net.hip, fold_lab): y = acc + b', u = y * clamp(y + 3, 0, 6) - the
+// scale and shift that followed the hard-swish live in the 1x1 conv's weights and bias.  Ten VALU instructions per four
+// values (the unfolded chain with its division-free hard-swish and range sweep: 34).
+__device__ __forceinline__ void dw_hsw6(F4& v, const ocr_f2 blo, const ocr_f2 bhi) {
+  const ocr_f2 three = {3.0f, 3.0f};
+  const ocr_f2 ylo = pk_add(v.lo, blo), yhi = pk_add(v.hi, bhi);
+  ocr_f2 tlo = pk_add_s(three, ylo), thi = pk_add_s(three, yhi);
+  tlo.x = __builtin_amdgcn_fmed3f(tlo.x, 0.0f, 6.0f); tlo.y = __builtin_amdgcn_fmed3f(tlo.y, 0.0f, 6.0f);
+  thi.x = __builtin_amdgcn_fmed3f(thi.x, 0.0f, 6.0f); thi.y = __builtin_amdgcn_fmed3f(thi.y, 0.0f, 6.0f);
+  v.lo = pk_mul(ylo, tlo); v.hi = pk_mul(yhi, thi);
 }
 
 }  // namespace
@@ -327,7 +323,6 @@ __global__ void __launch_bounds__(256, LB) dwpw_kernel(const DwPwArgs a) {
   };
 
   // ---- depthwise conv + its LAB epilogue of one chunk: s_in[buf] -> s_op[buf]
-  const float ds0 = a.dw_ep.s0, da0 = a.dw_ep.a0, ds1 = a.dw_ep.s1, da1 = a.dw_ep.a1;
   auto DW = [&](int buf) __attribute__((always_inline)) {
     const float* si = s_in + buf * IN_TILE;
     float* so = s_op + buf * OP_TILE;
@@ -361,23 +356,9 @@ __global__ void __launch_bounds__(256, LB) dwpw_kernel(const DwPwArgs a) {
 #endif
       const float4 b = *(const float4*)(sb + d_q[u]);
       const ocr_f2 blo = {b.x, b.y}, bhi = {b.z, b.w};
-      bool fast = true;
-      if constexpr (DWACT) {  // the division-free hard-swish needs every pre-activation value in its proven range
-        const ocr_f2 S0 = {ds0, ds0}, A0 = {da0, da0};
-        float mn = INFINITY, mx = 0.0f;
-#pragma unroll
-        for (int o = 0; o < PR; ++o) {
-          ocr_f2 tl = acc[o].lo + blo, th = acc[o].hi + bhi;
-          tl = S0 * tl; th = S0 * th;
-          tl = tl + A0; th = th + A0;
-          ocr_absrange(mn, mx, tl.x, tl.y);
-          ocr_absrange(mn, mx, th.x, th.y);
-        }
-        fast = ocr_hsw_fast_ok(mn, mx);
-      }
 #pragma unroll
       for (int o = 0; o < PR; ++o) {
-        lab_apply<DWACT>(acc[o], blo, bhi, ds0, da0, ds1, da1, fast);
+        dw_hsw6(acc[o], blo, bhi);
         *(float4*)(so + d_op[u] + o * TW * S) = make_float4(acc[o].lo.x, acc[o].lo.y, acc[o].hi.x, acc[o].hi.y);
       }
     }
@@ -440,11 +421,11 @@ __global__ void __launch_bounds__(256, LB) dwpw_kernel(const DwPwArgs a) {
       acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[t].w, av.w, acc[t], 0, 0, 0);
     }
   };
-  const float ps0 = a.pw_ep.s0, pa0 = a.pw_ep.a0, ps1 = a.pw_ep.s1, pa1 = a.pw_ep.a1;
+  const float ps6 = a.pw_ep.s6, pa1 = a.pw_ep.a1;
   const int pix = wp * 32 + p, pix_y = pix / TW, pix_x = pix & (TW - 1);
   const int op_off = pix * S + 4 * h;
-  // the 1x1 conv's LAB epilogue + 16-byte stores for this lane's pixel: acc[t][4g..4g+3] = physical channels
-  // nt0*32 + 32t + 8g + 4h .. +3 (conv_device.h, conv_finish)
+  // the 1x1 conv's epilogue after the LAB fold - y = acc + b', u = y * clamp(y + 3, 0, 6), fmaf(u, s6, a1) - and 16-byte
+  // stores for this lane's pixel: acc[t][4g..4g+3] = physical channels nt0*32 + 32t + 8g + 4h .. +3 (conv_device.h, conv_finish)
   auto finish = [&]() __attribute__((always_inline)) {
     const int nt0 = (m_pos.cb * WC + wc) * NT;
     const int oy = m_pos.ty * TH + pix_y, ox = m_pos.tx * TW + pix_x;
@@ -453,8 +434,7 @@ __global__ void __launch_bounds__(256, LB) dwpw_kernel(const DwPwArgs a) {
     const int r0 = nt0 * 32 + 4 * h;
     const float* sp = s_par + r0;
     const long oidx = (m_pos.out_pix(a) + (long)oy * own + ox) * c.Cs_out + r0;  // element index of the lane's first column
-    const ocr_f2 S0 = {ps0, ps0}, A0 = {pa0, pa0};
-    float mn = INFINITY, mx = 0.0f;
+    const ocr_f2 S6 = {ps6, ps6}, A1 = {pa1, pa1};
     // a column tile's four bias vectors as one group of LDS reads (left alone, each read is sunk next to its use:
     // 4*NT dependent round trips per tile)
 #pragma unroll
@@ -468,29 +448,15 @@ __global__ void __launch_bounds__(256, LB) dwpw_kernel(const DwPwArgs a) {
         const float4 b = bias4[g];
         ocr_f2 tl = ocr_f2{acc[t][4 * g], acc[t][4 * g + 1]} + ocr_f2{b.x, b.y};
         ocr_f2 th = ocr_f2{acc[t][4 * g + 2], acc[t][4 * g + 3]} + ocr_f2{b.z, b.w};
-        tl = S0 * tl; th = S0 * th;
-        tl = tl + A0; th = th + A0;
-        acc[t][4 * g] = tl.x; acc[t][4 * g + 1] = tl.y; acc[t][4 * g + 2] = th.x; acc[t][4 * g + 3] = th.y;
-        if (nt0 * 32 + 32 * t + 8 * g < c.ColsStore) { ocr_absrange(mn, mx, tl.x, tl.y); ocr_absrange(mn, mx, th.x, th.y); }
-      }
-    }
-    const bool fast = ocr_hsw_fast_ok(mn, mx);
-    const ocr_f2 S1 = {ps1, ps1}, A1 = {pa1, pa1};
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        ocr_f2 tl = {acc[t][4 * g], acc[t][4 * g + 1]}, th = {acc[t][4 * g + 2], acc[t][4 * g + 3]};
-        if (fast) { tl = ocr_hswish2_fast(tl); th = ocr_hswish2_fast(th); }
-        else { tl.x = ocr_hswish_div(tl.x); tl.y = ocr_hswish_div(tl.y); th.x = ocr_hswish_div(th.x); th.y = ocr_hswish_div(th.y); }
-        tl = S1 * tl; th = S1 * th;
-        tl = tl + A1; th = th + A1;
+        tl = ocr_hsw6_2(tl); th = ocr_hsw6_2(th);
+        tl = __builtin_elementwise_fma(tl, S6, A1); th = __builtin_elementwise_fma(th, S6, A1);
 #ifdef OCR_PROBE_NOSTORE
         if (tl.x == 12345.678f)
 #endif
         if (inside && nt0 * 32 + 32 * t + 8 * g < c.ColsStore) st4<HALF>(c.out, oidx + 32 * t + 8 * g, make_float4(tl.x, tl.y, th.x, th.y));
         acc[t][4 * g] = 0.f; acc[t][4 * g + 1] = 0.f; acc[t][4 * g + 2] = 0.f; acc[t][4 * g + 3] = 0.f;
       }
+    }
   };
   int m_ch = 0;
   auto mma_end = [&]() __attribute__((always_inline)) {
@@ -580,23 +546,9 @@ __global__ void __launch_bounds__(256, LB) dwpw_kernel(const DwPwArgs a) {
       } else {  // the depthwise epilogue and the operand write, as in DW
         const float4 b = *(const float4*)(sb + d_q[0]);
         const ocr_f2 blo = {b.x, b.y}, bhi = {b.z, b.w};
-        bool fast = true;
-        if constexpr (DWACT) {
-          const ocr_f2 S0 = {ds0, ds0}, A0 = {da0, da0};
-          float mn = INFINITY, mx = 0.0f;
-#pragma unroll
-          for (int o = 0; o < PR; ++o) {
-            ocr_f2 tl = pk_add(dacc[o].lo, blo), th = pk_add(dacc[o].hi, bhi);
-            tl = pk_mul_s(S0, tl); th = pk_mul_s(S0, th);
-            tl = pk_add_s(A0, tl); th = pk_add_s(A0, th);
-            ocr_absrange(mn, mx, tl.x, tl.y);
-            ocr_absrange(mn, mx, th.x, th.y);
-          }
-          fast = ocr_hsw_fast_ok(mn, mx);
-        }
 #pragma unroll
         for (int o = 0; o < PR; ++o) {
-          lab_apply<DWACT>(dacc[o], blo, bhi, ds0, da0, ds1, da1, fast);
+          dw_hsw6(dacc[o], blo, bhi);
           *(float4*)(so + d_op[0] + o * TW * S) = make_float4(dacc[o].lo.x, dacc[o].lo.y, dacc[o].hi.x, dacc[o].hi.y);
         }
       }
@@ -754,16 +706,14 @@ bool launch_one(const DwPwArgs& a0, hipStream_t s, bool query) {
 #ifndef OCR_TU_H16
 bool lab_from_epilogue(const Epilogue& ep, LabEp& out) {
   out = LabEp{};
-  if (ep.n != 3 && ep.n != 6) return false;
-  if (ep.st[0].kind != EP_BIAS || ep.st[1].kind != EP_SMUL || ep.st[2].kind != EP_SADD) return false;
+  if (ep.n != 2 && ep.n != 3) return false;
+  if (ep.st[0].kind != EP_BIAS || ep.st[1].kind != EP_ACT || ep.st[1].act != ACT_HSW6) return false;
   out.bias = ep.st[0].v0;
-  out.s0 = ep.st[1].p0;
-  out.a0 = ep.st[2].p0;
-  if (ep.n == 6) {
-    if (ep.st[3].kind != EP_ACT || ep.st[3].act != ACT_HSWISH || ep.st[4].kind != EP_SMUL || ep.st[5].kind != EP_SADD) return false;
-    out.act = 1;
-    out.s1 = ep.st[4].p0;
-    out.a1 = ep.st[5].p0;
+  if (ep.n == 3) {
+    if (ep.st[2].kind != EP_SFMA) return false;
+    out.sfma = 1;
+    out.s6 = ep.st[2].p0;
+    out.a1 = ep.st[2].p1;
   }
   return true;
 }
@@ -775,7 +725,7 @@ bool lab_from_epilogue(const Epilogue& ep, LabEp& out) {
 // the instance table: launches, answers the bind-time query, or (rows_only) just names the pixel-tile height
 static int dwpw_dispatch(const DwPwArgs& a, hipStream_t s, bool query, bool rows_only) {
   const int K = a.K, SH = a.SH, SW = a.SW, Cs = a.c.Cs_in, tiles = a.c.NTtot;
-  if (!a.pw_ep.act || !a.dw_ep.act) return 0;  // the pairs on the hot path: full chain on both sides
+  if (!a.pw_ep.sfma || a.dw_ep.sfma) return 0;  // the pairs on the hot path after the LAB fold: bias | hsw6 in the depthwise half, bias | hsw6 | sfma behind the 1x1 conv
 #define OCR_DWPW_CASE(K_, SH_, SW_, CK_, WIDE_, NT_, GD_, TD_, LB_, COND)                                  \
   if (K == K_ && SH == SH_ && SW == SW_ && Cs % CK_ == 0 && tiles % (NT_ * (WIDE_ ? 2 : 1)) == 0 && (COND)) { \
     if (rows_only) return DwPwGeom<K_, SH_, SW_, CK_, WIDE_>::TH;                                                \

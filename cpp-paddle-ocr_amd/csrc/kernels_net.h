@@ -147,13 +147,14 @@ bool launch_dw_lds(const DwArgs& a, const Epilogue& ep, hipStream_t s, bool quer
 void launch_gap_cols(const float* part, float* out, int N, int H, int W, int Cs, hipStream_t s, RagLevel rag = RagLevel());
 
 // Fused depthwise conv (+ its epilogue) -> 1x1 conv (+ its epilogue), kernels_dwpw.hip.  Both epilogues are the
-// PPLCNetV3 "learnable affine block" chain of the plans, fixed at compile time (a generic stage interpreter made the
-// kernel VALU-bound on its own bookkeeping):  y = x + bias[c];  y = s0 * y;  y = y + a0;  [y = hswish(y);
-// y = s1 * y;  y = y + a1]  - every step its own rounding, as ocr_common.h's stages.
+// PPLCNetV3 "learnable affine block" chain of the plans AFTER the loader's fold (net.hip, fold_lab), fixed at compile time
+// (a generic stage interpreter made the kernel VALU-bound on its own bookkeeping):
+//   depthwise half:  y = x + bias[c];  u = y * clamp(y + 3, 0, 6)                      (its scale / shift live in the 1x1 conv)
+//   1x1 half:        y = x + bias[c];  u = y * clamp(y + 3, 0, 6);  out = fmaf(u, s6, a1)
 struct LabEp {
-  const float* bias;  // [Cs] physical channel order
-  float s0, a0, s1, a1;
-  int act;            // 1: the hswish + second affine follow; 0: the chain ends after a0
+  const float* bias;  // [Cs] physical channel order (the folded bias)
+  float s6, a1;       // sfma: out = fmaf(u, s6, a1)
+  int sfma;           // 1: the fma follows the hard-swish product; 0: the chain ends with u (an absorbed depthwise conv)
 };
 struct DwPwArgs {
   ConvArgs c;          // the 1x1 conv as launch_conv_mfma would get it (c.in unused: that tensor never exists; c.zeros used)
@@ -170,7 +171,7 @@ struct DwPwArgs {
   const int* rtiles = nullptr;
   int rtiles_total = 0;  // rtiles[N] (host copy: the launcher sizes the grid with it)
 };
-// host: is this stage list the chain above?  fills `out` (bias pointer left null: the caller resolves it)
+// host: is this stage list one of the two chains above?  fills `out`
 bool lab_from_epilogue(const Epilogue& ep, LabEp& out);
 // false: the shape is not instantiated (the caller launches the unfused pair).  query = true only asks.
 bool launch_dwpw(const DwPwArgs& a, hipStream_t s, bool query = false);

@@ -214,9 +214,109 @@ static std::vector<float> frag_to_half(const std::vector<float>& f) {
   return out;
 }
 
-bool Net::load(const char* plan_text, const WeightMap& W, std::string& err, bool half) {
+
+// ------------------------------------------------------------------ LAB fold (round 5 contract)
+// The exported PP-LCNetV3 graphs carry  bias b | * s0 | + a0 [| hswish | * s1 | + a1]  behind every backbone conv (scalars
+// s, a).  Executed stage by stage that chain is ~17 VALU instructions per pair of values - and on this
+// chip every epilogue instruction of a matrix-core kernel is matrix time.  Like every inference engine's
+// scale / shift folding, the loader rewrites it ONCE:
+//   w'   = (float)((double)w * s0 * s_in)                   every weight, one rounding
+//   b'_o = (float)(s0 * (b_o + a_in * sum_k w_ok) + a0)     in double, k ascending, one rounding
+//   stages: bias b' [| act hsw6: u = y * clamp(y + 3, 0, 6) [| sfma: fmaf(u, s6, a1), s6 = (float)(s1 / 6.0)]]
+// (s_in, a_in) = (1, 0), or - ABSORPTION - the (s6, a1) of a depthwise conv with the full chain whose output's only reader
+// is this op, a 1x1 stride-1 conv that carries the chain itself (a 1x1 conv has no padding, the affine map of its input is
+// exact in value): that depthwise conv then stops after hsw6, its tensor holds u.  No division, no range sweep, 5-6 VALU
+// instructions per pair.  The CPU checker's loader (under oracle/) performs the same operations in the same
+// order, so parity stays bit for bit; against the unfolded graph in float64 the error is what it was (tests/).
+struct LabChain { bool on = false, act = false; float s0 = 1, a0 = 0, s1 = 1, a1 = 0; };
+static float lab_s6(float s1) { return (float)((double)s1 / 6.0); }
+
+static bool fold_lab(Plan& plan, WeightMap& W, std::string& err) {
+  const size_t nops = plan.ops.size();
+  auto need = [&](const std::string& n) -> const HostTensor* {
+    auto it = W.find(n);
+    if (it == W.end()) { err = "weights: missing parameter '" + n + "' (graph/params mismatch)"; return nullptr; }
+    return &it->second;
+  };
+  std::vector<LabChain> lab(nops);
+  std::vector<int> uses(plan.ntensors, 0), absorbs(nops, -1);
+  std::vector<char> handed(nops, 0);
+  int out_tid = -1;
+  for (size_t oi = 0; oi < nops; ++oi) {
+    const PlanOp& op = plan.ops[oi];
+    if (op.kind == PlanOp::OUTPUT) { out_tid = op.in; continue; }
+    if (op.in >= 0) uses[op.in]++;
+    for (int t : op.ins) uses[t]++;
+    for (auto& st : op.ep) if (st.tid >= 0) uses[st.tid]++;
+    if (op.kind != PlanOp::CONV && op.kind != PlanOp::DW) continue;
+    const auto& e = op.ep;
+    const bool p3 = e.size() >= 3 && e[0].kind == EP_BIAS && e[1].kind == EP_SMUL && e[2].kind == EP_SADD;
+    const bool p6 = p3 && e.size() == 6 && e[3].kind == EP_ACT && e[3].act == ACT_HSWISH && e[4].kind == EP_SMUL && e[5].kind == EP_SADD;
+    if (!(p6 || (p3 && e.size() == 3))) continue;
+    const HostTensor *s0 = need(e[1].n0), *a0 = need(e[2].n0);
+    if (!s0 || !a0) return false;
+    LabChain& L = lab[oi];
+    L.on = true; L.s0 = s0->data[0]; L.a0 = a0->data[0];
+    if (p6) {
+      const HostTensor *s1 = need(e[4].n0), *a1 = need(e[5].n0);
+      if (!s1 || !a1) return false;
+      L.act = true; L.s1 = s1->data[0]; L.a1 = a1->data[0];
+    }
+  }
+  for (size_t oi = 0; oi < nops; ++oi) {
+    const PlanOp& d = plan.ops[oi];
+    if (d.kind != PlanOp::DW || !lab[oi].act || d.out == out_tid || uses[d.out] != 1) continue;
+    for (size_t oj = oi + 1; oj < nops; ++oj) {
+      const PlanOp& c = plan.ops[oj];
+      if (c.kind == PlanOp::CONCAT || c.kind == PlanOp::OUTPUT || c.in != d.out) continue;
+      if (c.kind == PlanOp::CONV && lab[oj].on && c.kh == 1 && c.kw == 1 && c.sh == 1 && c.sw == 1 && c.ph == 0 && c.pw == 0) { absorbs[oj] = (int)oi; handed[oi] = 1; }
+      break;
+    }
+  }
+  for (size_t oi = 0; oi < nops; ++oi) {
+    if (!lab[oi].on) continue;
+    PlanOp& op = plan.ops[oi];
+    const LabChain& L = lab[oi];
+    const HostTensor* b = need(op.ep[0].n0);
+    const HostTensor* w = need(op.w);
+    if (!b || !w) return false;
+    const size_t C = b->data.size();
+    if (!C || w->data.size() % C) { err = "LAB fold: filter / bias size mismatch " + op.w; return false; }
+    const size_t per = w->data.size() / C;  // weights per output channel (conv: [co][ci][kh][kw]; depthwise: [c][1][kh][kw])
+    double s_in = 1.0, a_in = 0.0;
+    if (absorbs[oi] >= 0) { s_in = (double)lab_s6(lab[absorbs[oi]].s1); a_in = (double)lab[absorbs[oi]].a1; }
+    const std::string tag = "#lab" + std::to_string(oi);
+    HostTensor wf = *w, bf = *b;
+    for (size_t i = 0; i < wf.data.size(); ++i) { const double t = (double)w->data[i] * (double)L.s0; wf.data[i] = (float)(t * s_in); }
+    for (size_t o = 0; o < C; ++o) {
+      double sum = 0.0;
+      if (absorbs[oi] >= 0) for (size_t k = 0; k < per; ++k) sum = sum + (double)w->data[o * per + k];
+      const double t = a_in * sum;
+      const double u = (double)b->data[o] + t;
+      const double v = (double)L.s0 * u;
+      bf.data[o] = (float)(v + (double)L.a0);
+    }
+    std::vector<PlanStage> ne;
+    PlanStage sb; sb.kind = EP_BIAS; sb.n0 = op.ep[0].n0 + tag;
+    ne.push_back(sb);
+    if (L.act) {
+      PlanStage sa; sa.kind = EP_ACT; sa.act = ACT_HSW6;
+      ne.push_back(sa);
+      if (!handed[oi]) { PlanStage sf; sf.kind = EP_SFMA; sf.p0 = lab_s6(L.s1); sf.p1 = L.a1; ne.push_back(sf); }
+    }
+    W[sb.n0] = std::move(bf);
+    W[op.w + tag] = std::move(wf);
+    op.w += tag;
+    op.ep = std::move(ne);
+  }
+  return true;
+}
+
+bool Net::load(const char* plan_text, const WeightMap& W_in, std::string& err, bool half) {
   half_ = half;
   if (!parse_plan(plan_text, plan_, err)) return false;
+  WeightMap W = W_in;  // + the folded filters / biases, under their own names
+  if (!fold_lab(plan_, W, err)) return false;
   { const char* e = getenv("OCR_GRAPH"); graphs_ = !(e && e[0] == '0'); }
   if (const char* e = getenv("OCR_NET_BINDINGS")) max_bindings_ = (size_t)std::min(4096L, std::max(2L, atol(e)));  // (tests: a small cap forces evictions)
   host_w_ = W;
@@ -428,6 +528,7 @@ bool Net::build_epilogue(const PlanOp& op, Epilogue& ep, bool conv_path, std::st
     switch (st.kind) {
       case EP_BIAS: e.v0 = dev_vec((oplain ? "vecp:" : "vec:") + st.n0); break;
       case EP_SMUL: case EP_SADD: e.p0 = scalars_[st.n0]; break;
+      case EP_SFMA: break;  // (p0, p1 are the folded constants)
       case EP_BN: e.v0 = dev_vec("bns:" + st.n0); e.v1 = dev_vec("bnt:" + st.n0); break;
       case EP_ACT: break;
       case EP_MULC: case EP_GATERES:
@@ -763,24 +864,25 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths, const i
     for (int oi = 0; oi + 1 < nops; ++oi) {
       auto& d = plan_.ops[oi];
       if (d.kind != PlanOp::DW || d.out == out_tid_ || uses[d.out] != 1) continue;
-      // both epilogues must be the LAB chain the kernel compiles in: bias | smul | sadd | hswish | smul | sadd
-      auto is_lab = [](const std::vector<PlanStage>& ep) {
-        return ep.size() == 6 && ep[0].kind == EP_BIAS && ep[1].kind == EP_SMUL && ep[2].kind == EP_SADD && ep[3].kind == EP_ACT &&
-               ep[3].act == ACT_HSWISH && ep[4].kind == EP_SMUL && ep[5].kind == EP_SADD;
+      // both epilogues must be the folded LAB chains the kernel compiles in (fold_lab): bias | hsw6 in the depthwise half
+      // (its scale / shift absorbed by the conv), bias | hsw6 | sfma behind the conv
+      auto is_lab = [](const std::vector<PlanStage>& ep, bool sfma) {
+        return ep.size() == (sfma ? 3u : 2u) && ep[0].kind == EP_BIAS && ep[1].kind == EP_ACT && ep[1].act == ACT_HSW6 &&
+               (!sfma || ep[2].kind == EP_SFMA);
       };
-      if (!is_lab(d.ep)) continue;
+      if (!is_lab(d.ep, false)) continue;
       for (int oj = oi + 1; oj < nops; ++oj) {
         auto& c = plan_.ops[oj];
         if (c.in != d.out) continue;
         const bool one = c.kind == PlanOp::CONV && c.kh == 1 && c.kw == 1 && c.sh == 1 && c.sw == 1 && c.ph == 0 && c.pw == 0 && c.cin != 3;
-        if (one && gate_src[oj] < 0 && !T[c.out].plain && is_lab(c.ep) && T[d.in].cs % 8 == 0 && !T[d.in].plain && c.cout % 8 == 0) {
+        if (one && gate_src[oj] < 0 && !T[c.out].plain && is_lab(c.ep, true) && T[d.in].cs % 8 == 0 && !T[d.in].plain && c.cout % 8 == 0) {
           // shape on the fused path?  (asks the launcher, which also raises the kernel's LDS limit on this device)
           DwPwArgs q{};
           q.K = d.kh; q.SH = d.sh; q.SW = d.sw;
           q.c.Cs_in = T[d.out].cs;
           const int tiles = (T[c.out].cs + 31) / 32, nt = conv_nt_for(tiles);
           q.c.NTtot = (tiles + nt - 1) / nt * nt;
-          q.dw_ep.act = q.pw_ep.act = 1;
+          q.dw_ep.sfma = 0; q.pw_ep.sfma = 1;
           q.c.half = half_ ? 1 : 0;  // (the f16 build's instance: its own LDS attribute)
           if (rag) q.rtiles = rag_dev;  // (the ragged instantiation is its own kernel: own LDS attribute)
           if (d.kh == d.kw && launch_dwpw(q, nullptr, true)) dwpw_of[oj] = oi;

@@ -48,8 +48,9 @@ OCR_HD float ocr_expf(float x) {
 }
 
 // ---- epilogue description (kernel argument, by value) ----
-enum : int { EP_BIAS = 0, EP_SMUL, EP_SADD, EP_BN, EP_ACT, EP_MULC, EP_ADDT, EP_ADDUP, EP_GATERES };  // GATERES: v = v * gate[n][c] + v (an `ew mulc | addt self` folded into its producer)
-enum : int { ACT_RELU = 0, ACT_HSWISH, ACT_HSIG, ACT_SWISH, ACT_SIGMOID };
+enum : int { EP_BIAS = 0, EP_SMUL, EP_SADD, EP_BN, EP_ACT, EP_MULC, EP_ADDT, EP_ADDUP, EP_GATERES, EP_SFMA };  // GATERES: v = v * gate[n][c] + v (an `ew mulc | addt self` folded into its producer); SFMA: v = fmaf(v, p0, p1) (the LAB fold, net.hip fold_lab)
+// HSW6: u = y * clamp(y + 3, 0, 6), the hard-swish's product - its 1/6 travels with the scale that follows (fold_lab)
+enum : int { ACT_RELU = 0, ACT_HSWISH, ACT_HSIG, ACT_SWISH, ACT_SIGMOID, ACT_HSW6 };
 
 struct EpStage {
   int kind;
@@ -101,6 +102,14 @@ __device__ __forceinline__ ocr_f2 ocr_hswish2_fast(ocr_f2 y) {
   q.y = __builtin_copysignf(q.y, u.y);
   return q;
 }
+// u = y * clamp(y + 3, 0, 6) on a packed pair: v_pk_add, two v_med3, v_pk_mul
+__device__ __forceinline__ ocr_f2 ocr_hsw6_2(ocr_f2 y) {
+  const ocr_f2 three = {3.0f, 3.0f};
+  ocr_f2 t = y + three;
+  t.x = __builtin_amdgcn_fmed3f(t.x, 0.0f, 6.0f);
+  t.y = __builtin_amdgcn_fmed3f(t.y, 0.0f, 6.0f);
+  return y * t;
+}
 // four values whose |y| range has been checked with ocr_hsw_fast_ok
 __device__ __forceinline__ void ocr_hswish4_fast(float& a, float& b, float& c, float& d) {
   const ocr_f2 q0 = ocr_hswish2_fast(ocr_f2{a, b}), q1 = ocr_hswish2_fast(ocr_f2{c, d});
@@ -127,6 +136,7 @@ OCR_HD float ocr_act(int act, float p0, float p1, float y) {
     case ACT_HSWISH: { float t = fminf(fmaxf(y + 3.0f, 0.0f), 6.0f); float u = y * t; return u / 6.0f; }
     case ACT_HSIG: { float t = y * p0; t = t + p1; return fminf(fmaxf(t, 0.0f), 1.0f); }
     case ACT_SWISH: { float e = ocr_expf(-y); float d = 1.0f + e; return y / d; }
+    case ACT_HSW6: { float t = fminf(fmaxf(y + 3.0f, 0.0f), 6.0f); return y * t; }
     default: { float e = ocr_expf(-y); float d = 1.0f + e; return 1.0f / d; }
   }
 }

@@ -14,6 +14,11 @@
 //   * every contraction is ONE f32 fmaf chain from 0 in ascending k = ((kh*KW)+kw)*Cin + ci
 //     (zero padding contributes fmaf(0,w,acc)); bias and the rest follow as separate roundings;
 //   * a*x+b stages are mul then add (two roundings); division and sqrt are IEEE;
+//   * the PP-LCNetV3 "learnable affine block" chain  bias | *s0 | +a0 [| hswish | *s1 | +a1]  behind a conv is FOLDED when
+//     the parameters are resolved (round 5, fold_lab below; what every inference engine does to scale / shift ops around a
+//     conv): the weights carry s0, one bias vector carries s0*b + a0, the hard-swish keeps its product u = y*clamp(y+3,0,6)
+//     and its 1/6 travels with s1 into ONE fma(u, s1/6, a1) - or, when the only reader is a 1x1 conv, into that conv's
+//     weights and bias (a 1x1 conv has no padding: exact in value).  Other hard-swish ops keep the IEEE division;
 //   * exp is ocr_expf below (Cephes-style, fmaf Horner), never libm;
 //   * reductions: GAP = row-sequential then column-sequential; LN/attention sequential;
 //     row softmax: groups of 128 columns, two interleaved chains per group, groups folded in order
@@ -53,8 +58,8 @@ inline float ocr_expf(float x) {
   return y * sc;
 }
 
-enum StageKind { S_BIAS, S_SMUL, S_SADD, S_BN, S_ACT, S_MULC, S_ADDT, S_ADDUP };
-enum ActKind { A_RELU, A_HSWISH, A_HSIG, A_SWISH, A_SIGMOID };
+enum StageKind { S_BIAS, S_SMUL, S_SADD, S_BN, S_ACT, S_MULC, S_ADDT, S_ADDUP, S_SFMA };
+enum ActKind { A_RELU, A_HSWISH, A_HSIG, A_SWISH, A_SIGMOID, A_HSW6 };
 
 struct Stage {
   int kind = 0, act = 0;
@@ -107,6 +112,9 @@ struct Net {
   bool resolved = false;
   // transposed weights cache: op index -> [K][Cout]
   std::map<int, std::vector<float>> wt;
+  // depthwise weights after the LAB fold: op index -> [C][kh*kw] (the parameter's own layout)
+  std::map<int, std::vector<float>> wdw;
+  std::vector<Op> ops_plan;  // the stage lists as parsed (resolve() rewrites `ops` from these)
 };
 
 std::vector<std::string> split(const std::string& s, char sep) {
@@ -176,10 +184,100 @@ const Param* getp(Net& net, const std::string& name) {
   return &it->second;
 }
 
+
+// ---- LAB fold (the round-5 arithmetic contract; the product's loader does the same, csrc/net.hip fold_lab) ----
+// A conv / depthwise conv whose stage list is  bias b | smul s0 | sadd a0  [| act hswish | smul s1 | sadd a1]:
+//   w'   = (float)((double)w * s0 * s_in)                      every weight, one rounding
+//   b'_o = (float)(s0 * (b_o + a_in * sum_k w_ok) + a0)        in double, k ascending, one rounding
+//   stages: bias b' [| act hsw6 (u = y * clamp(y + 3, 0, 6)) [| sfma s6 = (float)(s1 / 6.0), a1  (fmaf(u, s6, a1))]]
+// (s_in, a_in) = (1, 0), or - ABSORPTION - the (s6, a1) of a depthwise conv with the full chain whose output's only reader is
+// this op, a 1x1 stride-1 conv that itself carries the chain: the depthwise conv then stops after hsw6 and its tensor holds u.
+struct LabChain { bool on = false, act = false; float s0 = 1, a0 = 0, s1 = 1, a1 = 0; };
+bool lab_chain(Net& net, const Op& op, LabChain& L) {
+  L = LabChain();
+  const auto& e = op.ep;
+  if (op.kind != "conv" && op.kind != "dw") return true;
+  const bool p3 = e.size() >= 3 && e[0].kind == S_BIAS && e[1].kind == S_SMUL && e[2].kind == S_SADD;
+  const bool p6 = p3 && e.size() == 6 && e[3].kind == S_ACT && e[3].act == A_HSWISH && e[4].kind == S_SMUL && e[5].kind == S_SADD;
+  if (!(p6 || (p3 && e.size() == 3))) return true;
+  const Param *s0 = getp(net, e[1].n0), *a0 = getp(net, e[2].n0);
+  if (!s0 || !a0) return false;
+  L.on = true; L.s0 = s0->d[0]; L.a0 = a0->d[0];
+  if (p6) {
+    const Param *s1 = getp(net, e[4].n0), *a1 = getp(net, e[5].n0);
+    if (!s1 || !a1) return false;
+    L.act = true; L.s1 = s1->d[0]; L.a1 = a1->d[0];
+  }
+  return true;
+}
+inline float lab_s6(float s1) { return (float)((double)s1 / 6.0); }
+
 bool resolve(Net& net) {
-  for (size_t oi = 0; oi < net.ops.size(); ++oi) {
+  if (net.ops_plan.empty()) net.ops_plan = net.ops;
+  net.ops = net.ops_plan;
+  net.wt.clear(); net.wdw.clear();
+  const size_t nops = net.ops.size();
+  // ---- which ops carry the chain, and which depthwise convs hand their (s6, a1) to the 1x1 conv that reads them
+  std::vector<LabChain> lab(nops);
+  std::vector<int> uses(net.ntensors, 0), absorbs(nops, -1);  // absorbs[conv] = the depthwise op whose affine it takes over
+  std::vector<char> handed(nops, 0);
+  int out_tid = -1;
+  for (size_t oi = 0; oi < nops; ++oi) {
+    const Op& op = net.ops[oi];
+    if (!lab_chain(net, op, lab[oi])) return false;
+    if (op.kind == "output") { out_tid = op.geti("i"); continue; }
+    if (op.kind == "concat") { for (int t : op.getlist("i")) uses[t]++; }
+    else if (op.kv.count("i")) uses[op.geti("i")]++;
+    for (const Stage& s : op.ep) if (s.tid >= 0) uses[s.tid]++;
+  }
+  for (size_t oi = 0; oi < nops; ++oi) {
+    const Op& d = net.ops[oi];
+    if (d.kind != "dw" || !lab[oi].act || d.geti("o") == out_tid || uses[d.geti("o")] != 1) continue;
+    for (size_t oj = oi + 1; oj < nops; ++oj) {
+      const Op& c = net.ops[oj];
+      if (c.kind == "concat" || c.kind == "output" || !c.kv.count("i") || c.geti("i") != d.geti("o")) continue;
+      if (c.kind == "conv" && lab[oj].on && c.geti("kh") == 1 && c.geti("kw") == 1 && c.geti("sh") == 1 && c.geti("sw") == 1 &&
+          c.geti("ph") == 0 && c.geti("pw") == 0) { absorbs[oj] = (int)oi; handed[oi] = 1; }
+      break;
+    }
+  }
+  for (size_t oi = 0; oi < nops; ++oi) {
     Op& op = net.ops[oi];
+    if (lab[oi].on) {  // rewrite the stage list; the folded bias is resolved here, the folded weights below
+      const LabChain& L = lab[oi];
+      const Param* b = getp(net, op.ep[0].n0); if (!b) return false;
+      const Param* w = getp(net, op.kv["w"]); if (!w) return false;
+      const size_t C = b->d.size();
+      const size_t per = w->d.size() / C;  // weights per output channel (conv: ci*kh*kw, o-major; dw: kh*kw)
+      double s_in = 1.0, a_in = 0.0;
+      if (absorbs[oi] >= 0) { s_in = (double)lab_s6(lab[absorbs[oi]].s1); a_in = (double)lab[absorbs[oi]].a1; }
+      Stage sb; sb.kind = S_BIAS; sb.v0.resize(C);
+      for (size_t o = 0; o < C; ++o) {
+        double sum = 0.0;
+        if (absorbs[oi] >= 0) for (size_t k = 0; k < per; ++k) sum = sum + (double)w->d[o * per + k];
+        const double t = a_in * sum;
+        const double u = (double)b->d[o] + t;
+        const double v = (double)L.s0 * u;
+        sb.v0[o] = (float)(v + (double)L.a0);
+      }
+      std::vector<Stage> ne;
+      ne.push_back(sb);
+      if (L.act) {
+        Stage sa; sa.kind = S_ACT; sa.act = A_HSW6; ne.push_back(sa);
+        if (!handed[oi]) { Stage sf; sf.kind = S_SFMA; sf.p0 = lab_s6(L.s1); sf.p1 = L.a1; ne.push_back(sf); }
+      }
+      op.ep = ne;
+      if (op.kind == "dw") {
+        std::vector<float>& wd = net.wdw[(int)oi];
+        wd.resize(w->d.size());
+        for (size_t i = 0; i < wd.size(); ++i) { const double t = (double)w->d[i] * (double)L.s0; wd[i] = (float)(t * s_in); }
+      }
+    }
+    const double w_s0 = lab[oi].on ? (double)lab[oi].s0 : 1.0;
+    const double w_sin = absorbs[oi] >= 0 ? (double)lab_s6(lab[absorbs[oi]].s1) : 1.0;
+    const bool w_fold = lab[oi].on;
     for (Stage& s : op.ep) {
+      if (s.kind == S_BIAS && !s.v0.empty()) continue;  // (the folded bias above)
       if (s.kind == S_BIAS) {
         auto p = getp(net, s.n0); if (!p) return false;
         s.v0 = p->d;
@@ -209,8 +307,11 @@ bool resolve(Net& net) {
       for (int o = 0; o < co; ++o)
         for (int c = 0; c < ci; ++c)
           for (int y = 0; y < kh; ++y)
-            for (int x = 0; x < kw; ++x)
-              w[((size_t)(y * kw + x) * ci + c) * co + o] = p->d[(((size_t)o * ci + c) * kh + y) * kw + x];
+            for (int x = 0; x < kw; ++x) {
+              float v = p->d[(((size_t)o * ci + c) * kh + y) * kw + x];
+              if (w_fold) { const double t = (double)v * w_s0; v = (float)(t * w_sin); }
+              w[((size_t)(y * kw + x) * ci + c) * co + o] = v;
+            }
     }
   }
   net.resolved = true;
@@ -224,6 +325,7 @@ inline float act_apply(const Stage& s, float y) {
     case A_HSIG: { float t = y * s.p0; t = t + s.p1; return fminf(fmaxf(t, 0.0f), 1.0f); }
     case A_SWISH: { float e = ocr_expf(-y); float d = 1.0f + e; return y / d; }
     case A_SIGMOID: { float e = ocr_expf(-y); float d = 1.0f + e; return 1.0f / d; }
+    case A_HSW6: { float t = fminf(fmaxf(y + 3.0f, 0.0f), 6.0f); return y * t; }  // the hard-swish's product; its 1/6 is folded (fold_lab)
   }
   return y;
 }
@@ -235,6 +337,7 @@ inline void epilogue(Net& net, const Op& op, float* y, int C, int n, int h, int 
       case S_BIAS: for (int c = 0; c < C; ++c) y[c] = y[c] + s.v0[c]; break;
       case S_SMUL: for (int c = 0; c < C; ++c) y[c] = s.p0 * y[c]; break;
       case S_SADD: for (int c = 0; c < C; ++c) y[c] = y[c] + s.p0; break;
+      case S_SFMA: for (int c = 0; c < C; ++c) y[c] = fmaf(y[c], s.p0, s.p1); break;
       case S_BN: for (int c = 0; c < C; ++c) { float t = y[c] * s.v0[c]; y[c] = t + s.v1[c]; } break;
       case S_ACT: for (int c = 0; c < C; ++c) y[c] = act_apply(s, y[c]); break;
       case S_MULC: { const float* g = net.t[s.tid].at(n, 0, 0); for (int c = 0; c < C; ++c) y[c] = y[c] * g[c]; } break;
@@ -315,9 +418,10 @@ bool run(Net& net, const float* x_nhwc, int N, int H, int W) {
       int sh = op.geti("sh"), sw = op.geti("sw"), ph = op.geti("ph"), pw = op.geti("pw");
       int oh = (in.h + 2 * ph - kh) / sh + 1, ow = (in.w + 2 * pw - kw) / sw + 1;
       auto p = getp(net, op.kv.at("w")); if (!p) return false;  // [C,1,kh,kw]
+      const float* pw_ = net.wdw.count((int)oi) ? net.wdw[(int)oi].data() : p->d.data();  // (after the LAB fold)
       std::vector<float> wt((size_t)kh * kw * C);
       for (int c = 0; c < C; ++c)
-        for (int t = 0; t < kh * kw; ++t) wt[(size_t)t * C + c] = p->d[(size_t)c * kh * kw + t];
+        for (int t = 0; t < kh * kw; ++t) wt[(size_t)t * C + c] = pw_[(size_t)c * kh * kw + t];
       Tensor& out = net.t[o];
       out.alloc(in.n, oh, ow, C);
 #pragma omp parallel for collapse(2) schedule(static)

@@ -34,8 +34,8 @@ static void run(int N, int H, int W, int K, int SH, int SW, int cin, int cout) {
   a.c.out = y; a.c.wfrag = w; a.c.M = M; a.c.N = N; a.c.H = OH; a.c.W = OW; a.c.Cs_in = cin; a.c.C8 = C8; a.c.OH = OH; a.c.OW = OW;
   a.c.zeros = vec; a.c.Cs_out = cout; a.c.Cout = cout; a.c.CoutPadded = cout; a.c.ColsStore = cout; a.c.NTtot = NTtot; a.c.KH = a.c.KW = 1; a.c.out_mode = OUT_C8I;
   a.dw_in = x; a.dw_w = dw; a.H = H; a.W = W; a.K = K; a.SH = SH; a.SW = SW; a.PH = a.PW = P;
-  a.dw_ep = LabEp{vec, 1.01f, 0.5f, 0.99f, 0.01f, 1};  // bias | smul | sadd | hswish | smul | sadd, as in the plans
-  a.pw_ep = a.dw_ep;
+  a.dw_ep = LabEp{vec, 0.f, 0.f, 0};           // bias | hsw6 (the folded chain of an absorbed depthwise conv)
+  a.pw_ep = LabEp{vec, 0.99f / 6.f, 0.01f, 1};  // bias | hsw6 | sfma
 #ifdef OCR_TU_H16
   a.c.half = 1;  // (the buffers above keep their f32 sizes: zeros are zeros in either format)
 #endif

@@ -127,6 +127,15 @@ struct DwPwGeom {
 // sizes) an image of its own height and width - its tile counts are re-derived when the walk enters a sample; sizes and
 // first pixels are read where they are used (g_setup, finish: once per unit).  All of this is wave-uniform (scalar
 // registers, which these kernels have none to spare of: the uniform instantiations carry no ragged state at all).
+// The sample tables of a ragged batch are read with wave-uniform indices: through the constant address space these are
+// scalar loads (s_load_dword, waited for on lgkmcnt).  As plain global loads the compiler issues them as vector loads +
+// v_readfirstlane behind `s_waitcnt vmcnt(0)` - which drains every load in flight, the next items' region included, once per
+// unit (round 5: the thin layers of a ragged batch start a unit every one to four items).
+__device__ __forceinline__ int rag_ld(const int* t, int i) { return ((const __attribute__((address_space(4))) int*)t)[i]; }
+__device__ __forceinline__ int rag_w_s(const RagLevel& r, int n) { return r.h ? rag_ld(r.w, n) >> r.shift : rag_ld(r.w, n); }
+__device__ __forceinline__ int rag_h_s(const RagLevel& r, int n, int Hu) { return r.h ? rag_ld(r.h, n) >> r.shift : Hu; }
+__device__ __forceinline__ long rag_pix0_s(const RagLevel& r, int n, int Hu) { return r.h ? (long)(rag_ld(r.cw, n) >> (2 * r.shift)) : (long)rag_ld(r.cw, n) * Hu; }
+
 template <bool RAG, int TH>
 struct UnitPos {
   int cb, tx, ty, n;
@@ -134,8 +143,8 @@ struct UnitPos {
   __device__ __forceinline__ int cols(const DwPwArgs& a) const { return RAG ? txn : a.tiles_x; }
   __device__ __forceinline__ int rows(const DwPwArgs& a) const { return RAG ? tyn : a.tiles_y; }
   __device__ __forceinline__ void geom(const DwPwArgs& a) {  // (the tables carry one entry past N: the walk steps onto "sample N" after the last unit)
-    txn = (rag_w(a.rout, n) + 15) >> 4;
-    tyn = (rag_h(a.rout, n, a.c.OH) + TH - 1) / TH;
+    txn = (rag_w_s(a.rout, n) + 15) >> 4;
+    tyn = (rag_h_s(a.rout, n, a.c.OH) + TH - 1) / TH;
   }
   __device__ __forceinline__ void init(unsigned u, int cblocks, const DwPwArgs& a) {
     cb = (int)(u % (unsigned)cblocks);
@@ -167,12 +176,12 @@ struct UnitPos {
     }
   }
   // size and first pixel of image n on the input / output side
-  __device__ __forceinline__ int in_w(const DwPwArgs& a) const { return RAG ? rag_w(a.rin, n) : a.W; }
-  __device__ __forceinline__ int in_h(const DwPwArgs& a) const { return RAG ? rag_h(a.rin, n, a.H) : a.H; }
-  __device__ __forceinline__ int out_w(const DwPwArgs& a) const { return RAG ? rag_w(a.rout, n) : a.c.OW; }
-  __device__ __forceinline__ int out_h(const DwPwArgs& a) const { return RAG ? rag_h(a.rout, n, a.c.OH) : a.c.OH; }
-  __device__ __forceinline__ long in_pix(const DwPwArgs& a) const { return RAG ? rag_pix0(a.rin, n, a.H) : (long)n * a.H * a.W; }
-  __device__ __forceinline__ long out_pix(const DwPwArgs& a) const { return RAG ? rag_pix0(a.rout, n, a.c.OH) : (long)n * a.c.OH * a.c.OW; }
+  __device__ __forceinline__ int in_w(const DwPwArgs& a) const { return RAG ? rag_w_s(a.rin, n) : a.W; }
+  __device__ __forceinline__ int in_h(const DwPwArgs& a) const { return RAG ? rag_h_s(a.rin, n, a.H) : a.H; }
+  __device__ __forceinline__ int out_w(const DwPwArgs& a) const { return RAG ? rag_w_s(a.rout, n) : a.c.OW; }
+  __device__ __forceinline__ int out_h(const DwPwArgs& a) const { return RAG ? rag_h_s(a.rout, n, a.c.OH) : a.c.OH; }
+  __device__ __forceinline__ long in_pix(const DwPwArgs& a) const { return RAG ? rag_pix0_s(a.rin, n, a.H) : (long)n * a.H * a.W; }
+  __device__ __forceinline__ long out_pix(const DwPwArgs& a) const { return RAG ? rag_pix0_s(a.rout, n, a.c.OH) : (long)n * a.c.OH * a.c.OW; }
 };
 
 // The depthwise half's epilogue after the LAB fold (net.hip, fold_lab): y = acc + b', u = y * clamp(y + 3, 0, 6) - the
@@ -645,7 +654,11 @@ namespace {
 template <int K, int SH, int SW, int CK, bool WIDE, int NT, bool DWACT, int GD, int TD, int LB, bool RAG, bool HALF>
 bool launch_one(const DwPwArgs& a0, hipStream_t s, bool query) {
   using G_ = DwPwGeom<K, SH, SW, CK, WIDE>;
+#ifdef OCR_DWPW_LDSPAD  // development probe: extra dynamic LDS so that a CU holds one workgroup
+  const size_t lds = G_::lds_floats(a0.c.NTtot) * sizeof(float) + OCR_DWPW_LDSPAD;
+#else
   const size_t lds = G_::lds_floats(a0.c.NTtot) * sizeof(float);
+#endif
   // per device: the dynamic-LDS limit, and how many of these workgroups a CU holds.  One instantiation serves several
   // column-tile counts (its parameter block, and with it the LDS size, grows with NTtot): the attribute memo re-raises
   // for a larger request (lds_attr.h) and the occupancy memo is per LDS size.  Detector lanes and pool workers launch
@@ -704,6 +717,59 @@ bool launch_one(const DwPwArgs& a0, hipStream_t s, bool query) {
 }  // namespace
 
 #ifndef OCR_TU_H16
+#include "dwpw2_kernel.h"
+
+namespace {
+template <int K, int SH, int SW, int CK, bool WIDE, int NT, int NB, int TD, int LB, bool RAG>
+bool launch_two(const DwPwArgs& a0, hipStream_t s, bool query) {
+  using G_ = DwPw2Geom<K, SH, SW, CK, WIDE, NB>;
+  if (!(CK == 16 ? a0.dw_wq16 : a0.dw_wq32)) return false;
+  const size_t lds = G_::lds_bytes(a0.c.NTtot);
+  static LdsAttrMemo attr_state;
+  struct Occ { size_t lds; int per_cu, cus; };
+  static Occ occ[64][2] = {};
+  static std::mutex occ_mu;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+  if (lds > 64 * 1024 && !raise_dynamic_lds((const void*)dwpw2_kernel<K, SH, SW, CK, WIDE, NT, NB, TD, LB, RAG>, (int)lds, attr_state)) return false;
+  int per_cu_dev = 0, cus_dev = 0;
+  {
+    std::lock_guard<std::mutex> lk(occ_mu);
+    Occ* e = nullptr;
+    for (Occ& o : occ[dev])
+      if (o.per_cu && o.lds == lds) e = &o;
+    if (!e) {
+      int nb = 0;
+      hipDeviceProp_t prop;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, dwpw2_kernel<K, SH, SW, CK, WIDE, NT, NB, TD, LB, RAG>, 256, lds) != hipSuccess || nb < 1 ||
+          hipGetDeviceProperties(&prop, dev) != hipSuccess) { (void)hipGetLastError(); return false; }
+      e = occ[dev][0].per_cu ? &occ[dev][1] : &occ[dev][0];
+      *e = Occ{lds, nb, prop.multiProcessorCount};
+    }
+    per_cu_dev = e->per_cu;
+    cus_dev = e->cus;
+  }
+  if (query) return true;
+  DwPwArgs a = a0;
+  a.tiles_x = (a.c.OW + G_::TW - 1) / G_::TW;
+  a.tiles_y = (a.c.OH + G_::TH - 1) / G_::TH;
+  const unsigned cblocks = (unsigned)a.c.NTtot / (NT * G_::WC);
+  const long nunits = (a.rtiles ? (long)a.rtiles_total : (long)a.c.N * a.tiles_x * a.tiles_y) * cblocks;
+  if (nunits <= 0 || nunits > 0x7fffffffL) return false;
+  a.nunits = (unsigned)nunits;
+  const int target = rt_options().dwpw_items;  // (units per workgroup: as launch_one)
+  const int nch = a.c.Cs_in / CK;
+  long upw = (target + nch - 1) / nch;
+  const long resident = (long)cus_dev * per_cu_dev;
+  while (upw > 1 && (nunits + upw - 1) / upw < 8 * resident) --upw;
+  if (rt_options().dwpw_force_upw > 0) upw = rt_options().dwpw_force_upw;
+  a.upw = (unsigned)upw;
+  const dim3 grid((unsigned)((nunits + upw - 1) / upw));
+  hipLaunchKernelGGL((dwpw2_kernel<K, SH, SW, CK, WIDE, NT, NB, TD, LB, RAG>), grid, dim3(256), lds, s, a);
+  return true;
+}
+}  // namespace
+
 bool lab_from_epilogue(const Epilogue& ep, LabEp& out) {
   out = LabEp{};
   if (ep.n != 2 && ep.n != 3) return false;
@@ -726,6 +792,41 @@ bool lab_from_epilogue(const Epilogue& ep, LabEp& out) {
 static int dwpw_dispatch(const DwPwArgs& a, hipStream_t s, bool query, bool rows_only) {
   const int K = a.K, SH = a.SH, SW = a.SW, Cs = a.c.Cs_in, tiles = a.c.NTtot;
   if (!a.pw_ep.sfma || a.dw_ep.sfma) return 0;  // the pairs on the hot path after the LAB fold: bias | hsw6 in the depthwise half, bias | hsw6 | sfma behind the 1x1 conv
+#ifndef OCR_TU_H16
+  // second form (dwpw2_kernel.h): region and weights by LDS-DMA.  Same tile shapes as the first form's instances below (the
+  // ragged tile tables are shared); f32 build, a "dwq16:" image of the depthwise weights present.  OCR_DWPW2=0: first form (A/B).
+#ifndef OCR_DWPW2_55  // region buffers, TD, LB of the 240-channel 5x5 block (tools/micro/dwpw_probe.hip builds variants)
+#define OCR_DWPW2_55 3, 2, 2
+#endif
+#define OCR_DWPW2_CASE(K_, SH_, SW_, CK_, WIDE_, NT_, NB_, TD_, LB_, COND)                                  \
+  if (K == K_ && SH == SH_ && SW == SW_ && Cs % CK_ == 0 && tiles % (NT_ * (WIDE_ ? 2 : 1)) == 0 && (COND)) { \
+    if (rows_only) return DwPw2Geom<K_, SH_, SW_, CK_, WIDE_, NB_>::TH;                                         \
+    if ((a.rtiles ? launch_two<K_, SH_, SW_, CK_, WIDE_, NT_, NB_, TD_, LB_, true>(a, s, query)                \
+                  : launch_two<K_, SH_, SW_, CK_, WIDE_, NT_, NB_, TD_, LB_, false>(a, s, query))) return 1;   \
+  }
+#define OCR_DWPW2_CASE_X(...) OCR_DWPW2_CASE(__VA_ARGS__)
+  // (tile shapes, chunk widths and TD as the first form's table below; three region buffers where two workgroups per CU
+  // still fit in LDS, else two.  A refusal - no weights image of that chunk width - falls through to the first form)
+  if ((a.dw_wq16 || a.dw_wq32) && rt_options().dwpw2 && !a.c.half) {
+    if (!rt_options().dwpw_t4_thin) {
+      OCR_DWPW2_CASE(3, 1, 1, 32, true, 2, 3, 1, 2, tiles == 4)
+      OCR_DWPW2_CASE(3, 2, 1, 32, true, 2, 2, 1, 2, tiles == 4)
+    }
+#ifndef OCR_DWPW2_THIN  // region buffers, TD, LB of the thin 3x3 layers with one / two column tiles (probe variants)
+#define OCR_DWPW2_THIN 2, 2, 3
+#endif
+    OCR_DWPW2_CASE_X(3, 1, 1, 16, false, 1, OCR_DWPW2_THIN, tiles == 1)
+    OCR_DWPW2_CASE_X(3, 1, 1, 16, false, 2, OCR_DWPW2_THIN, tiles == 2)
+    OCR_DWPW2_CASE(3, 1, 1, 16, false, 3, 3, 2, 2, tiles == 3)
+    OCR_DWPW2_CASE(3, 1, 1, 16, false, 4, 3, 2, 2, tiles == 4)
+    OCR_DWPW2_CASE(3, 2, 1, 16, false, 4, 2, 2, 2, tiles == 4)
+    OCR_DWPW2_CASE(3, 1, 2, 16, true, 4, 3, 1, 2, tiles == 8)
+    OCR_DWPW2_CASE_X(5, 1, 1, 16, true, 4, OCR_DWPW2_55, tiles == 8)
+    OCR_DWPW2_CASE(5, 1, 1, 32, true, 3, 2, 2, 2, tiles == 6 || tiles == 12)
+  }
+#undef OCR_DWPW2_CASE_X
+#undef OCR_DWPW2_CASE
+#endif
 #define OCR_DWPW_CASE(K_, SH_, SW_, CK_, WIDE_, NT_, GD_, TD_, LB_, COND)                                  \
   if (K == K_ && SH == SH_ && SW == SW_ && Cs % CK_ == 0 && tiles % (NT_ * (WIDE_ ? 2 : 1)) == 0 && (COND)) { \
     if (rows_only) return DwPwGeom<K_, SH_, SW_, CK_, WIDE_>::TH;                                                \
@@ -753,6 +854,9 @@ static int dwpw_dispatch(const DwPwArgs& a, hipStream_t s, bool query, bool rows
 #define OCR_DWPW_55 2, 2, 2
 #endif
 #define OCR_DWPW_CASE_X(...) OCR_DWPW_CASE(__VA_ARGS__)
+#ifdef OCR_DWPW_TRY32  // development probe: 32-channel chunks with two pixels per thread on a 256-column layer
+  OCR_DWPW_CASE_X(5, 1, 1, 32, true, 4, OCR_DWPW_TRY32, tiles == 8 && Cs % 32 == 0)
+#endif
   OCR_DWPW_CASE_X(5, 1, 1, 16, true, 4, OCR_DWPW_55, tiles == 8)  // (round 3, ragged batch, in the step: 1/1/3 3.13 ms, 2/2/2 3.05, 1/2/3 3.67, 2/1/3 3.90)
   OCR_DWPW_CASE(5, 1, 1, 32, true, 3, 1, 2, 2, tiles == 6 || tiles == 12)
 #undef OCR_DWPW_CASE_X

@@ -160,6 +160,10 @@ struct DwPwArgs {
   ConvArgs c;          // the 1x1 conv as launch_conv_mfma would get it (c.in unused: that tensor never exists; c.zeros used)
   const float* dw_in;  // [N,H,W,Cs] C8I, Cs = c.Cs_in
   const float* dw_w;   // [K*K][Cs] physical order
+  // the same weights and the depthwise bias chunk by chunk, [Cs / CK][K*K taps | bias][CK] for CK = 16 and 32: what one LDS-DMA
+  // burst of dwpw2_kernel fetches per item (net.hip "dwq16:" / "dwq32:"; the latter only where Cs % 32 == 0); null: the first form only
+  const float* dw_wq16 = nullptr;
+  const float* dw_wq32 = nullptr;
   LabEp dw_ep, pw_ep;
   int H, W, K, SH, SW, PH, PW;
   int tiles_x, tiles_y;  // filled by the launcher

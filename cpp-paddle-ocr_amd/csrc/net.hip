@@ -483,6 +483,22 @@ bool Net::load(const char* plan_text, const WeightMap& W_in, std::string& err, b
         for (int c = 0; c < C; ++c)
           for (int t = 0; t < K * K; ++t) img[(size_t)t * cs + c8i_phys(c)] = p->data[(size_t)c * K * K + t];
         if (!upload("dw:" + op.w, img)) { err = "hipMalloc failed"; return false; }
+        // the LDS-DMA form of the fused depthwise blocks (dwpw2_kernel.h) fetches a chunk's taps and its folded bias in one
+        // burst: [chunk][K*K taps | bias][CK], physical channel order, for the chunk widths its instances use.  Only where the
+        // depthwise conv ends with the hard-swish product (an absorbed chain, fold_lab): those are the ones that can be fused
+        if (op.ep.size() == 2 && op.ep[0].kind == EP_BIAS && op.ep[1].kind == EP_ACT && op.ep[1].act == ACT_HSW6) {
+          auto b = need(op.ep[0].n0); if (!b) return false;
+          const std::vector<float> bp = perm_vec(b->data, C, false);
+          for (int ck : {16, 32}) {
+            if (cs % ck) continue;
+            std::vector<float> qimg((size_t)(cs / ck) * (K * K + 1) * ck, 0.f);
+            for (int ch = 0; ch < cs / ck; ++ch)
+              for (int t = 0; t <= K * K; ++t)
+                for (int i = 0; i < ck; ++i)
+                  qimg[((size_t)ch * (K * K + 1) + t) * ck + i] = t < K * K ? img[(size_t)t * cs + ch * ck + i] : bp[ch * ck + i];
+            if (!upload((ck == 16 ? "dwq16:" : "dwq32:") + op.w, qimg)) { err = "hipMalloc failed"; return false; }
+          }
+        }
       } break;
       case PlanOp::SEFC: {
         {
@@ -883,6 +899,7 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths, const i
           const int tiles = (T[c.out].cs + 31) / 32, nt = conv_nt_for(tiles);
           q.c.NTtot = (tiles + nt - 1) / nt * nt;
           q.dw_ep.sfma = 0; q.pw_ep.sfma = 1;
+          q.dw_wq16 = dev_vec("dwq16:" + d.w); q.dw_wq32 = dev_vec("dwq32:" + d.w);  // (the LDS-DMA form's instance, where there is one: its own LDS attribute)
           q.c.half = half_ ? 1 : 0;  // (the f16 build's instance: its own LDS attribute)
           if (rag) q.rtiles = rag_dev;  // (the ragged instantiation is its own kernel: own LDS attribute)
           if (d.kh == d.kw && launch_dwpw(q, nullptr, true)) dwpw_of[oj] = oi;
@@ -1347,6 +1364,7 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths, const i
             f.c = a;
             f.c.in = nullptr;
             f.dw_in = arena_ + din.offset; f.dw_w = dev_vec("dw:" + d.w);
+            f.dw_wq16 = dev_vec("dwq16:" + d.w); f.dw_wq32 = dev_vec("dwq32:" + d.w);
             if (!lab_from_epilogue(epd, f.dw_ep) || !lab_from_epilogue(ep, f.pw_ep)) { err = "dwpw: epilogue is not the LAB chain"; return false; }
             f.H = din.h; f.W = din.w; f.K = d.kh; f.SH = d.sh; f.SW = d.sw; f.PH = d.ph; f.PW = d.pw;
             if (rag) {

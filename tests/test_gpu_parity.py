@@ -109,7 +109,8 @@ print("AB OK")
 
 
 @pytest.mark.parametrize("env", [{"OCR_DWPW_T4": "thin"}, {"OCR_DWPW_ITEMS": "7"}, {"OCR_DWPW_ITEMS": "1"}, {"OCR_FUSE_DWPW": "0"},
-                                 {"OCR_CONV_C24": "0", "OCR_FUSE_GATE": "0", "OCR_FUSE_GAP": "0", "OCR_CONV_SMALL_NT": "0", "OCR_FUSE_DBHEAD": "0", "OCR_FUSE_RSE": "0", "OCR_CONV_MT2": "0", "OCR_FUSE_CONCAT": "0"}, {"OCR_FUSE_GAP_MIN": "1", "OCR_CONV_MT2": "force"}, {"OCR_DWPW_FORCE_UPW": "3"}, {"OCR_DWPW_FORCE_UPW": "16", "OCR_DWPW_T4": "thin"}, {"OCR_FUSE_MB": "1"}, {"OCR_DW_LDS": "0", "OCR_ATTN_LINE": "0", "OCR_DBHEAD_MFMA": "0"}])
+                                 {"OCR_CONV_C24": "0", "OCR_FUSE_GATE": "0", "OCR_FUSE_GAP": "0", "OCR_CONV_SMALL_NT": "0", "OCR_FUSE_DBHEAD": "0", "OCR_FUSE_RSE": "0", "OCR_CONV_MT2": "0", "OCR_FUSE_CONCAT": "0"}, {"OCR_FUSE_GAP_MIN": "1", "OCR_CONV_MT2": "force"}, {"OCR_DWPW_FORCE_UPW": "3"}, {"OCR_DWPW_FORCE_UPW": "16", "OCR_DWPW_T4": "thin"}, {"OCR_FUSE_MB": "1"}, {"OCR_DW_LDS": "0", "OCR_ATTN_LINE": "0", "OCR_DBHEAD_MFMA": "0"},
+                                 {"OCR_DWPW2": "0"}, {"OCR_DWPW2": "0", "OCR_DWPW_FORCE_UPW": "3"}])
 def test_ab_switches_do_not_change_results(built, env):
     """INTEGRATION.md's runtime switches select other kernel shapes / launch lists (read once per process, so each
     setting runs in a child process): the production-mode outputs stay bit-identical to the oracle.  OCR_DWPW_ITEMS = 7

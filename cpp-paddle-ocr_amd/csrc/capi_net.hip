@@ -23,23 +23,12 @@ const RtOptions& rt_options() {
   std::call_once(once, [] {
     auto off = [](const char* n) { const char* e = getenv(n); return e && e[0] == '0'; };
     auto num = [](const char* n, long def) { const char* e = getenv(n); return e && *e ? atol(e) : def; };
-    o.fuse_gate = !off("OCR_FUSE_GATE");
-    o.fuse_dwpw = !off("OCR_FUSE_DWPW");
-    o.fuse_gap = !off("OCR_FUSE_GAP");
+    o.fuse = !off("OCR_FUSE");
     o.fuse_gap_min = num("OCR_FUSE_GAP_MIN", 64 * 1024);
-    o.fuse_dbhead = !off("OCR_FUSE_DBHEAD");
-    o.dbhead_mfma = !off("OCR_DBHEAD_MFMA");
-    o.fuse_rse = !off("OCR_FUSE_RSE");
-    o.fuse_concat = !off("OCR_FUSE_CONCAT");
-    { const char* e = getenv("OCR_FUSE_MB"); o.fuse_mb = e && e[0] == '1'; }
-    if (const char* e = getenv("OCR_CONV_IMPL")) o.conv_impl = !strcmp(e, "direct") ? 1 : (!strcmp(e, "lds") ? 2 : 0);
     o.conv_small_nt = !off("OCR_CONV_SMALL_NT");
-    o.conv_nt_max = (int)num("OCR_CONV_NT_MAX", 4);
     o.conv_mt2 = !off("OCR_CONV_MT2");
     if (const char* e = getenv("OCR_CONV_MT2")) o.conv_mt2_force = e[0] == 'f';
     o.conv_c24 = !off("OCR_CONV_C24");
-    o.conv_tile = !off("OCR_CONV_TILE");
-    if (const char* e = getenv("OCR_DW_PATCH")) sscanf(e, "%dx%d", &o.dw_patch_to, &o.dw_patch_r);
     { const char* e = getenv("OCR_DW_LDS"); o.dw_lds = !(e && e[0] == '0'); }
     { const char* e = getenv("OCR_DWPW2"); o.dwpw2 = !(e && e[0] == '0'); }
     { const char* e = getenv("OCR_MFMA_X16"); o.mfma_x16 = !(e && e[0] == '0'); }
@@ -48,7 +37,6 @@ const RtOptions& rt_options() {
     o.dwpw_force_upw = (int)num("OCR_DWPW_FORCE_UPW", 0);
     if (const char* e = getenv("OCR_DWPW_T4")) o.dwpw_t4_thin = e[0] == 't';
     o.trace_slice = (int)num("OCR_TRACE_SLICE", 0);
-    o.prio_anchor = !off("OCR_PRIO_ANCHOR");
   });
   return o;
 }
@@ -71,6 +59,42 @@ void rt_set_refuse_launch(const char* substr) {
 std::shared_mutex& capture_mutex() {
   static std::shared_mutex m;
   return m;
+}
+
+// ---- logical devices (hip_guard.h): OCR_DEVICE_MAP=p0,p1,... read once; default the identity over the visible devices
+static const std::vector<int>& device_map() {
+  static std::vector<int> map;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); n = 0; }
+    if (const char* e = getenv("OCR_DEVICE_MAP")) {
+      std::vector<int> m;
+      bool ok = n > 0 && *e;
+      for (const char* p = e; ok && *p;) {
+        char* end = nullptr;
+        const long v = strtol(p, &end, 10);
+        ok = end != p && v >= 0 && v < n && m.size() < 64;
+        if (ok) m.push_back((int)v);
+        p = *end == ',' ? end + 1 : end;
+        if (*end && *end != ',') ok = false;
+      }
+      if (ok && !m.empty()) { map = m; return; }  // (a malformed map is ignored: the identity)
+    }
+    for (int i = 0; i < n; ++i) map.push_back(i);
+  });
+  return map;
+}
+static thread_local int g_logical_device = -1;
+int rt_device_count() { return (int)device_map().size(); }
+int rt_physical_device(int logical) { return logical >= 0 && logical < rt_device_count() ? device_map()[logical] : -1; }
+int rt_current_device() { return g_logical_device; }
+hipError_t rt_set_device(int logical) {
+  const int phys = rt_physical_device(logical);
+  if (phys < 0) return hipErrorInvalidDevice;
+  const hipError_t e = hipSetDevice(phys);
+  if (e == hipSuccess) g_logical_device = logical;
+  return e;
 }
 
 static thread_local std::string g_last_error;
@@ -131,7 +155,7 @@ bool load_model_dir(const std::string& model_dir, const char* weights_override, 
 // more NORMAL streams 197 ms.  With two chains (the default): none 195 ms, one after all stage streams 266 ms, two
 // 148 ms.  GPU_MAX_HW_QUEUES = 8 / 32 and DEBUG_HIP_DYNAMIC_QUEUES = 0 / 1 do not move the slow mode.  The runtime's
 // mapping of streams to hardware queues is not documented; ocr_pipe_create uses the configuration that measured fast
-// (two such streams after its stage objects).  OCR_PRIO_ANCHOR=0 leaves them out (A/B).  The structural fix is a
+// (two such streams after its stage objects).  The structural fix is a
 // ragged detector batch (one launch list for all sizes, as the recognizer's), which needs no lanes at all.
 // At most `want` such streams exist per device for the life of the process (ocr_pipe_create asks for two, every further
 // pipeline of the process finds them there): nothing is created per handle, nothing leaks.
@@ -139,7 +163,7 @@ void priority_anchor(int device_id, int want) {
   static std::mutex mu;
   static hipStream_t anchor[64][2] = {};
   std::lock_guard<std::mutex> lk(mu);
-  if (device_id < 0 || device_id >= 64 || !rt_options().prio_anchor) return;
+  if (device_id < 0 || device_id >= 64) return;
   for (int k = 0; k < std::min(want, 2); ++k) {
     if (anchor[device_id][k]) continue;
     int least = 0, greatest = 0;
@@ -170,21 +194,16 @@ extern "C" {
 
 const char* ocr_last_error(void) { return ocr::g_last_error.c_str(); }
 
-int ocr_rt_device_count(void) {
-  int n = 0;
-  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
-  return n;
-}
+int ocr_rt_device_count(void) { return rt_device_count(); }
 
 int ocr_rt_init(int device_id) {
   (void)rt_options();  // the environment is read here, once
-  int n = 0;
-  hipError_t e = hipGetDeviceCount(&n);
-  if (e != hipSuccess || n <= 0) return fail(OCR_ERR_DEVICE, "no HIP device visible: this library has no CPU fallback");
+  const int n = rt_device_count();
+  if (n <= 0) return fail(OCR_ERR_DEVICE, "no HIP device visible: this library has no CPU fallback");
   if (device_id < 0 || device_id >= n) return fail(OCR_ERR_ARG, "device_id out of range");
-  CAPI_HIP(hipSetDevice(device_id));
+  CAPI_HIP(rt_set_device(device_id));
   hipDeviceProp_t prop;
-  CAPI_HIP(hipGetDeviceProperties(&prop, device_id));
+  CAPI_HIP(hipGetDeviceProperties(&prop, rt_physical_device(device_id)));
   if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
     return fail(OCR_ERR_DEVICE, std::string("device is ") + prop.gcnArchName + ", this build targets gfx950 (MI355X) only");
   return OCR_OK;
@@ -216,7 +235,7 @@ int ocr_net_create_precision(const char* kind, const char* model_dir, const char
 
 void ocr_net_destroy(ocr_net* h) {
   if (!h) return;
-  (void)hipSetDevice(h->device);
+  (void)rt_set_device(h->device);
   if (h->x_dev) (void)g_free(h->x_dev);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -224,7 +243,7 @@ void ocr_net_destroy(ocr_net* h) {
 
 int ocr_net_forward(ocr_net* h, const float* x, int N, int H, int W, int keep_all) {
   if (!h || !x || N <= 0 || H <= 0 || W <= 0) return fail(OCR_ERR_ARG, "bad argument");
-  CAPI_HIP(hipSetDevice(h->device));
+  CAPI_HIP(rt_set_device(h->device));
   const size_t n = (size_t)N * H * W * 3;
   if (n > h->x_cap) {
     if (h->x_dev) (void)g_free(h->x_dev);
@@ -244,7 +263,7 @@ int ocr_net_forward(ocr_net* h, const float* x, int N, int H, int W, int keep_al
 
 int ocr_net_forward_ragged(ocr_net* h, const float* x, int N, int H, const int* widths, int keep_all) {
   if (!h || !x || !widths || N <= 0 || H <= 0) return fail(OCR_ERR_ARG, "bad argument");
-  CAPI_HIP(hipSetDevice(h->device));
+  CAPI_HIP(rt_set_device(h->device));
   size_t n = 0;
   for (int i = 0; i < N; ++i) {
     if (widths[i] <= 0) return fail(OCR_ERR_ARG, "bad line width");
@@ -269,7 +288,7 @@ int ocr_net_forward_ragged(ocr_net* h, const float* x, int N, int H, const int* 
 int ocr_net_forward_ragged_images(ocr_net* h, const float* x, int N, const int* heights, const int* widths, int keep_all) {
   if (!h || !x || !widths || !heights || N <= 0) return fail(OCR_ERR_ARG, "bad argument");
   if (keep_all != 0 && keep_all != 2) return fail(OCR_ERR_ARG, "a ragged batch of images runs the production launch list (keep_all 0 or 2)");
-  CAPI_HIP(hipSetDevice(h->device));
+  CAPI_HIP(rt_set_device(h->device));
   size_t n = 0;
   for (int i = 0; i < N; ++i) {
     if (widths[i] <= 0 || heights[i] <= 0) return fail(OCR_ERR_ARG, "bad image size");
@@ -296,7 +315,7 @@ int ocr_net_tensor_exists(ocr_net* h, int tid) { return h && h->net.materialised
 
 int ocr_net_fetch(ocr_net* h, int tid, float* out, size_t cap_floats, int dims[4]) {
   if (!h || !out || !dims) return fail(OCR_ERR_ARG, "null argument");
-  CAPI_HIP(hipSetDevice(h->device));
+  CAPI_HIP(rt_set_device(h->device));
   std::vector<float> host;
   std::string err;
   if (!h->net.fetch_logical(tid, host, dims, h->stream, err)) return fail(OCR_ERR_DEVICE, err);

@@ -44,4 +44,15 @@ inline hipError_t g_memcpy2d(void* d, size_t dp, const void* s, size_t sp, size_
 }
 inline hipError_t g_stream_create(hipStream_t* s) { return hipStreamCreateWithFlags(s, hipStreamNonBlocking); }
 
+// LOGICAL devices (round 5).  Every device id of the C-ABI is an index into a table that OCR_DEVICE_MAP can spell out
+// ("0,0": two logical devices on physical GPU 0; default: the identity over the visible devices).  Per-device resources of the
+// library - dynamic-LDS attribute memos, occupancy memos, priority anchors; arenas and streams belong to handles - are
+// keyed by the LOGICAL id, so a one-GPU lease exercises the code a two-GPU pool runs (worker i -> device i mod n,
+// /root/reference/src/gpu_worker_pool.cpp:46-59).  rt_set_device makes the logical device current for the calling
+// thread (hipSetDevice on its physical device); rt_current_device is that thread's logical id (-1: none yet).
+hipError_t rt_set_device(int logical);  // capi_net.hip
+int rt_current_device();
+int rt_physical_device(int logical);    // -1: out of range
+int rt_device_count();
+
 }  // namespace ocr

@@ -667,8 +667,8 @@ bool launch_one(const DwPwArgs& a0, hipStream_t s, bool query) {
   struct Occ { size_t lds; int per_cu, cus; };
   static Occ occ[64][2] = {};
   static std::mutex occ_mu;
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+  const int dev = rt_current_device();  // logical (hip_guard.h)
+  if (dev < 0 || dev >= 64) return false;
   if (lds > 64 * 1024 && !raise_dynamic_lds((const void*)dwpw_kernel<K, SH, SW, CK, WIDE, NT, DWACT, GD, TD, LB, RAG, HALF>, (int)lds, attr_state)) return false;
   int per_cu_dev = 0, cus_dev = 0;
   {
@@ -680,7 +680,7 @@ bool launch_one(const DwPwArgs& a0, hipStream_t s, bool query) {
       int nb = 0;
       hipDeviceProp_t prop;
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, dwpw_kernel<K, SH, SW, CK, WIDE, NT, DWACT, GD, TD, LB, RAG, HALF>, 256, lds) != hipSuccess || nb < 1 ||
-          hipGetDeviceProperties(&prop, dev) != hipSuccess) { (void)hipGetLastError(); return false; }
+          hipGetDeviceProperties(&prop, rt_physical_device(dev)) != hipSuccess) { (void)hipGetLastError(); return false; }
       e = occ[dev][0].per_cu ? &occ[dev][1] : &occ[dev][0];  // (two sizes per instantiation on the plans' shapes; a third replaces the second)
       *e = Occ{lds, nb, prop.multiProcessorCount};
     }
@@ -729,8 +729,8 @@ bool launch_two(const DwPwArgs& a0, hipStream_t s, bool query) {
   struct Occ { size_t lds; int per_cu, cus; };
   static Occ occ[64][2] = {};
   static std::mutex occ_mu;
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+  const int dev = rt_current_device();  // logical (hip_guard.h)
+  if (dev < 0 || dev >= 64) return false;
   if (lds > 64 * 1024 && !raise_dynamic_lds((const void*)dwpw2_kernel<K, SH, SW, CK, WIDE, NT, NB, TD, LB, RAG>, (int)lds, attr_state)) return false;
   int per_cu_dev = 0, cus_dev = 0;
   {
@@ -742,7 +742,7 @@ bool launch_two(const DwPwArgs& a0, hipStream_t s, bool query) {
       int nb = 0;
       hipDeviceProp_t prop;
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, dwpw2_kernel<K, SH, SW, CK, WIDE, NT, NB, TD, LB, RAG>, 256, lds) != hipSuccess || nb < 1 ||
-          hipGetDeviceProperties(&prop, dev) != hipSuccess) { (void)hipGetLastError(); return false; }
+          hipGetDeviceProperties(&prop, rt_physical_device(dev)) != hipSuccess) { (void)hipGetLastError(); return false; }
       e = occ[dev][0].per_cu ? &occ[dev][1] : &occ[dev][0];
       *e = Occ{lds, nb, prop.multiProcessorCount};
     }

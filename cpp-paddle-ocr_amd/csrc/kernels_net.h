@@ -101,14 +101,13 @@ bool launch_conv_mfma_mt2(const ConvArgs& a, const Epilogue& ep, int nt, hipStre
 // LDS-staged variant of the same GEMM (default when K = taps*Cs_in >= 64)
 void launch_conv_lds(const ConvArgs& a, const Epilogue& ep, int nt, hipStream_t s);
 // 3x3 s1 p1 conv with the input tile resident in LDS; returns false when the shape is not on that path
-bool launch_conv3x3_tile(const ConvArgs& a, const Epilogue& ep, int nt, hipStream_t s);
+// (query = true here and below: shape checks and the device's LDS attribute only - asked at bind time, nothing is launched)
+bool launch_conv3x3_tile(const ConvArgs& a, const Epilogue& ep, int nt, hipStream_t s, bool query = false);
 // 3x3 s1 p1 conv 96 -> 24 channels on 4x4x1 matrix blocks (no zero columns); wimg from conv3x3_c24_image
-bool launch_conv3x3_c24(const ConvArgs& a, const Epilogue& ep, const float* wimg, hipStream_t s);
+bool launch_conv3x3_c24(const ConvArgs& a, const Epilogue& ep, const float* wimg, hipStream_t s, bool query = false);
 std::vector<float> conv3x3_c24_image(const float* w, int co, int ci);
 // column tiles per wave for a GEMM with `tiles` 32-wide column tiles
 inline int conv_nt_for(int tiles) {
-  const int cap = rt_options().conv_nt_max;  // OCR_CONV_NT_MAX: A/B measurements (results are identical)
-  if (cap < 4 && tiles > cap) return tiles % cap == 0 ? cap : (cap > 2 && tiles % (cap - 1) == 0 ? cap - 1 : cap);
   return tiles <= 4 ? tiles : (tiles % 4 == 0 ? 4 : (tiles % 3 == 0 ? 3 : 4));
 }
 
@@ -269,24 +268,6 @@ struct DbHeadArgs {
 };
 bool launch_db_head(const DbHeadArgs& a, int C, hipStream_t s);  // false: C is not on this path (24 only)
 
-// One MobileNetV3 bottleneck with squeeze-excite as one kernel, a workgroup per sample (kernels_mb.hip): conv 1x1 + BN + act
-// -> depthwise KxK, stride (SH, 1) + BN + act -> pool -> SE -> x * gate -> conv 1x1 + BN [+ residual].
-struct MbArgs {
-  const float* in;   // [N][Hi][W][Cs_in] C8I
-  float* out;        // [N][Ho][W][Cs_out] C8I
-  const float* res;  // residual tensor of the output's shape, or null
-  int N, Hi, Ho, W, Cin, Cs_in, Cexp, Cs_exp, Cout, Cs_out, K, SH, R;
-  int CC;            // expanded channels per chunk (0: the launcher picks, mbconv_chunk)
-  int act1, act2;    // ACT_RELU | ACT_HSWISH | -1 (none) after the BN of the expand / depthwise conv
-  const float *w1, *s1, *t1;  // w1 [Cin][roundup8(Cexp)] logical channels (k-major); BN scale / shift [Cs_exp] physical order
-  const float *wd, *s2, *t2;  // wd [K*K][Cs_exp] physical order
-  const float *se_w1, *se_b1, *se_w2, *se_b2;  // logical: w1 [R][Cexp], w2 [Cexp][R]
-  float slope, offset;
-  const float *w2, *s3, *t3;  // w2 [Cexp][roundup4(Cout)] logical; BN [Cs_out] physical order
-};
-int mbconv_chunk(const MbArgs& a);  // chunk width the launcher would use; 0: the block's shape is not on this path
-bool launch_mbconv(const MbArgs& a, hipStream_t s);
-
 void launch_c8i_to_plain(const float* in, float* out, long M, int C, int Cs, hipStream_t s, bool h16 = false);
 void launch_probe(const float* a, const float* b, float* out, int n, hipStream_t s);
 
@@ -296,7 +277,7 @@ void launch_probe(const float* a, const float* b, float* out, int n, hipStream_t
 inline namespace h16 {
 bool launch_conv_mfma_h16(const ConvArgs& a, const Epilogue& ep, int nt, hipStream_t s);
 bool launch_conv_mfma_mt2_h16(const ConvArgs& a, const Epilogue& ep, int nt, hipStream_t s);
-bool launch_conv3x3_tile_h16(const ConvArgs& a, const Epilogue& ep, int nt, hipStream_t s);
+bool launch_conv3x3_tile_h16(const ConvArgs& a, const Epilogue& ep, int nt, hipStream_t s, bool query);
 bool launch_conv_rowsum_h16(const ConvRowsumArgs& a, hipStream_t s);
 void launch_stem_h16(const StemArgs& a, const Epilogue& ep, hipStream_t s);
 void launch_dw_h16(const DwArgs& a, const Epilogue& ep, hipStream_t s);

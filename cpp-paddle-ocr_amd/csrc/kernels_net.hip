@@ -200,11 +200,17 @@ __global__ void __launch_bounds__(256, (NT <= 3 ? 4 : 3)) conv_mfma_kernel(const
 // alone): MT x NT = 1x3 (the kernel above) 99.8 TFLOP/s gated / 108.6 plain, 1x5 110.5 / 115.6 - the direct kernel is
 // bound by the bytes it pulls through L1 per MFMA (1x3: 5 KB per 12 MFMAs; 2x3: 7 KB per 24), not by occupancy
 // (3 or 4 waves per SIMD measure the same).  Every output's chain is the one above: bit-identical.
+#ifdef OCR_CONV_CLKRATE  // development probe (tools/micro/conv_time.hip): shader cycles and 100 MHz ticks over the workgroups' lives
+__device__ unsigned long long ocr_conv_clkrate[2];
+#endif
 template <int NT, int MT, bool GATE, bool HALF = kH16>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) conv_mfma_mt_kernel(const ConvArgs a, const Epilogue ep) {
   using WV = typename WFrag<HALF>::T;
   using AV = typename WFrag<HALF>::T;
   constexpr int ES = HALF ? 2 : 4;
+#ifdef OCR_CONV_CLKRATE
+  const unsigned long long clk_c0 = __builtin_readcyclecounter(), clk_r0 = wall_clock64();
+#endif
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int p = lane & 31, h = lane >> 5;
   const unsigned lb = xcd_swizzle(blockIdx.x, gridDim.x);  // logical block: N-group fastest, then M-tile
@@ -310,6 +316,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
   conv_finish<NT, OUT_C8I, HALF>(a, ep, acc[0], nt0, m0 + p, h, s_par);
   if constexpr (MT > 1) conv_finish<NT, OUT_C8I, HALF>(a, ep, acc[1], nt0, m0 + 32 + p, h, s_par);
   if constexpr (MT > 2) conv_finish<NT, OUT_C8I, HALF>(a, ep, acc[2], nt0, m0 + 64 + p, h, s_par);
+#ifdef OCR_CONV_CLKRATE
+  if (threadIdx.x == 0) {
+    atomicAdd(&ocr_conv_clkrate[0], __builtin_readcyclecounter() - clk_c0);
+    atomicAdd(&ocr_conv_clkrate[1], wall_clock64() - clk_r0);
+  }
+#endif
 }
 
 #ifdef OCR_TU_H16
@@ -1067,7 +1079,7 @@ std::vector<float> conv3x3_c24_image(const float* w, int co, int ci) {
   return img;
 }
 
-bool launch_conv3x3_c24(const ConvArgs& a, const Epilogue& ep, const float* wimg, hipStream_t s) {
+bool launch_conv3x3_c24(const ConvArgs& a, const Epilogue& ep, const float* wimg, hipStream_t s, bool query) {
   if (!rt_options().conv_c24) return false;  // OCR_CONV_C24=0: the 32-column tile kernel (A/B; results are identical)
   if (!wimg || !(a.KH == 3 && a.KW == 3 && a.PH == 1 && a.PW == 1 && a.OH == a.H && a.OW == a.W && a.out_mode == OUT_C8I)) return false;
   if (a.Cs_in != 96 || a.Cs_out != 24 || a.Cout != 24) return false;
@@ -1081,15 +1093,16 @@ bool launch_conv3x3_c24(const ConvArgs& a, const Epilogue& ep, const float* wimg
   const unsigned lds = 10 * 18 * (96 + 4) * sizeof(float);  // 72 000 B: two workgroups per CU
   static LdsAttrMemo attr_state;
   if (!raise_dynamic_lds((const void*)conv3x3_c24_kernel<12, 8>, (int)lds, attr_state)) return false;
+  if (query && rt_refuse_launch() == "conv3x3_c24@bind") return false;  // fault injection (tests): the bind-time probe is refused as a failed LDS attribute would refuse it
+  if (query) return true;  // asked at bind time, on the device that will run it (net.hip folds the DB neck's concat only then)
   hipLaunchKernelGGL((conv3x3_c24_kernel<12, 8>), grid, dim3(256), lds, s, a, ep, wimg, tiles_x, tiles_y);
   return true;
 }
 
 #endif  // OCR_TU_H16
-// true if the launch was taken (3x3, stride 1, pad 1, 96 input channels, C8I output); OCR_CONV_TILE=0 disables
-bool OCR_L(launch_conv3x3_tile)(const ConvArgs& a, const Epilogue& ep, int nt, hipStream_t s) {
-  OCR_H16_TWIN(a.half, launch_conv3x3_tile_h16(a, ep, nt, s))
-  if (!rt_options().conv_tile) return false;
+// true if the launch was taken (3x3, stride 1, pad 1, 96 input channels, C8I output)
+bool OCR_L(launch_conv3x3_tile)(const ConvArgs& a, const Epilogue& ep, int nt, hipStream_t s, bool query) {
+  OCR_H16_TWIN(a.half, launch_conv3x3_tile_h16(a, ep, nt, s, query))
   if (!(a.KH == 3 && a.KW == 3 && a.PH == 1 && a.PW == 1 && a.OH == a.H && a.OW == a.W && a.out_mode == OUT_C8I)) return false;
   if (a.Cs_in != 96 || nt != 1) return false;
   // ragged batches: the f16-staged form takes a batch of IMAGES through the tile table (conv3x3_c24_kernel's scheme); the f32
@@ -1105,12 +1118,14 @@ bool OCR_L(launch_conv3x3_tile)(const ConvArgs& a, const Epilogue& ep, int nt, h
 #ifdef OCR_TU_H16
   if (a.wfrag_x16 && rt_options().mfma_x16) {  // the f16-staged 32x32x16 form (52 bytes under the 64 KB that need no attribute)
     const unsigned lds16 = 10 * 18 * (96 + 8) * sizeof(_Float16);  // 37 440 B: four workgroups per CU
+    if (query) return true;
     hipLaunchKernelGGL((conv3x3_tile16_kernel<12, 1>), grid, dim3(256), lds16, s, a, ep, tiles_x, tiles_y);
     return true;
   }
 #endif
   if (a.cat_n) return false;  // (a folded concat: the 4x4x1 / f16-staged forms only)
   if (!raise_dynamic_lds((const void*)conv3x3_tile_kernel<12, 1>, (int)lds, attr_state)) return false;  // the general kernel takes the launch
+  if (query) return true;
   hipLaunchKernelGGL((conv3x3_tile_kernel<12, 1>), grid, dim3(256), lds, s, a, ep, tiles_x, tiles_y);
   return true;
 }
@@ -1377,11 +1392,8 @@ static void launch_dw_patch(const DwArgs& a, const Epilogue& ep, hipStream_t s) 
 // output pixels per thread along x (ragged batch: OW = the narrowest line; the host builds DwArgs::rwork for this value)
 #ifndef OCR_TU_H16
 int dw_patch_to(int OW, int SW, int OH, int K) {
-  // OCR_DW_PATCH=TOxR overrides (A/B measurements; results are identical)
-  const bool env = rt_options().dw_patch_to > 0;
-  int to = env ? rt_options().dw_patch_to : 8;
-  if (OW < 8 || (SW == 2 && !env)) to = 4;  // stride 2 needs 2*TO+K-2 pixels per row buffer: 8 wide does not fit the registers
-  return to == 8 ? 8 : 4;
+  (void)OH; (void)K;
+  return (OW < 8 || SW == 2) ? 4 : 8;  // stride 2 needs 2*TO+K-2 pixels per row buffer: 8 wide does not fit the registers
 }
 // Output rows per thread.  Measured and NOT kept (round 4): full-height patches (R = 3 / 6) for the 5x5 layers on the
 // recognizer's 3- and 6-row maps - every input row read once instead of 2.2x - are slower (rec op 26 with its row sums:
@@ -1389,9 +1401,7 @@ int dw_patch_to(int OW, int SW, int OH, int K) {
 // kernels are bound by loads in flight per wave, not by the bytes the halo rows add.
 int dw_patch_r(int OH, int K) {
   (void)K;
-  int r = rt_options().dw_patch_r > 0 ? rt_options().dw_patch_r : 2;
-  if (OH < 2) r = 1;
-  return r == 2 ? 2 : 1;
+  return OH < 2 ? 1 : 2;
 }
 #endif  // OCR_TU_H16
 void OCR_L(launch_dw)(const DwArgs& a, const Epilogue& ep, hipStream_t s) {

@@ -4,6 +4,8 @@
 
 #include <atomic>
 
+#include "hip_guard.h"
+
 namespace ocr {
 
 // More than 64 KB of dynamic LDS has to be allowed per kernel AND per device: a worker pool drives worker i on
@@ -30,7 +32,7 @@ inline bool raise_dynamic_lds(const void* kernel, int bytes, LdsAttrMemo& memo, 
   static const LdsAttrHooks none;
   const LdsAttrHooks& hk = hooks ? *hooks : none;
   if (hk.get_device) dev = hk.get_device();
-  else if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return false; }
+  else dev = rt_current_device();  // the calling thread's LOGICAL device (hip_guard.h): two pool workers that share a GPU keep two entries
   if (dev < 0) return false;
   const bool memoised = dev < 64;
   if (memoised) {

@@ -402,13 +402,6 @@ bool Net::load(const char* plan_text, const WeightMap& W_in, std::string& err, b
           if (half_ && !upload("frag16:" + op.w, frag_to_half(f))) { err = "hipMalloc failed"; return false; }
           if (half_ && ((kh == 1 && kw == 1) || (kh == 3 && kw == 3 && ci == 96)) && !pl && (c8i_stride(ci) / 8) % 2 == 0 &&
               !upload("frag16x:" + op.w, frag_to_half_x16(f, c8i_stride(ci) / 8, kh * kw))) { err = "hipMalloc failed"; return false; }
-          if (kh == 1 && kw == 1 && !pl && ci <= 512 && co <= 512) {  // the fused bottleneck kernel's image (kernels_mb.hip): [k][c] logical, rows padded to 8
-            const int cop = (co + 7) & ~7;
-            std::vector<float> t((size_t)ci * cop, 0.f);
-            for (int k = 0; k < ci; ++k)
-              for (int c = 0; c < co; ++c) t[(size_t)k * cop + c] = w[(size_t)c * ci + k];
-            if (!upload("t1x1:" + op.w, t)) { err = "hipMalloc failed"; return false; }
-          }
           if (kh == 3 && kw == 3 && ci == 96 && co == 24 && !pl && !upload("c24:" + op.w, conv3x3_c24_image(w, co, ci))) { err = "hipMalloc failed"; return false; }
           if (kh == 1 && kw == 1 && ci <= 24 && !pl && op.ep.empty()) {  // conv_rowsum_kernel's image (RSE blocks): [k logical, padded][physical column]
             const int cs_in = c8i_stride(ci);
@@ -847,7 +840,7 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths, const i
   // SE gate folding: `ew x -> x * gate[n][c]` whose only reader is a 1x1 conv disappears - the conv reads x and
   // the gate and forms the same product (one rounding) on its way into the matrix pipe.  Saves a full read +
   // write pass per SE block (cls: 9, rec: 2, det backbone: 2).  Not in keep-all mode (every plan tensor must
-  // exist for the parity taps); OCR_FUSE_GATE=0 disables (A/B measurements, results are identical).
+  // exist for the parity taps) and not with OCR_FUSE=0 (A/B; results are identical).
   std::vector<int> gate_src(nops, -1), gate_tid(nops, -1);
   std::vector<char> folded(nops, 0);
   std::vector<int> uses(plan_.ntensors, 0);
@@ -856,7 +849,8 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths, const i
     for (int t : op.ins) uses[t]++;
     for (auto& st : op.ep) if (st.tid >= 0) uses[st.tid]++;
   }
-  if (keep_all_ != 1 && rt_options().fuse_gate) {
+  const bool fuse = keep_all_ != 1 && rt_options().fuse;  // (OCR_FUSE=0: one launch per plan op, as the parity taps' keep_all = 1)
+  if (fuse) {
     for (int oi = 0; oi < nops; ++oi) {
       auto& op = plan_.ops[oi];
       if (op.kind != PlanOp::EW || op.ep.size() != 1 || op.ep[0].kind != EP_MULC || op.out == out_tid_ || uses[op.out] != 1) continue;
@@ -874,9 +868,9 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths, const i
     }
   }
   // Depthwise -> pointwise fusion (kernels_dwpw.hip): a depthwise conv whose only reader is an ungated 1x1 conv runs
-  // inside that conv's launch; its output tensor never exists.  OCR_FUSE_DWPW=0 disables (A/B, results identical).
+  // inside that conv's launch; its output tensor never exists.
   std::vector<int> dwpw_of(nops, -1);  // conv op -> the depthwise op it absorbs
-  if (keep_all_ != 1 && rt_options().fuse_dwpw) {
+  if (fuse) {
     for (int oi = 0; oi + 1 < nops; ++oi) {
       auto& d = plan_.ops[oi];
       if (d.kind != PlanOp::DW || d.out == out_tid_ || uses[d.out] != 1) continue;
@@ -910,48 +904,11 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths, const i
   }
   std::vector<char> fused_dw(nops, 0);
   for (int oj = 0; oj < nops; ++oj) if (dwpw_of[oj] >= 0) fused_dw[dwpw_of[oj]] = 1;
-  // ---- MobileNetV3 bottleneck with squeeze-excite (the classifier): conv 1x1 + BN + act -> depthwise + BN + act -> gap ->
-  // sefc -> ew (x * gate) -> conv 1x1 + BN [+ residual] as ONE launch, a workgroup per text line (kernels_mb.hip); the four
-  // tensors between the block's input and output never exist.  Uniform batches, f32 contract only (precision "fp16" keeps
-  // the matrix-core launches).  Opt-in (OCR_FUSE_MB=1): bit-identical, but its first form is slower than the launches it replaces.
-  std::vector<int> mb_of(nops, -1);  // project conv op -> the block's expand conv
-  std::vector<MbArgs> mb_args(nops);
-  if (keep_all_ != 1 && rt_options().fuse_mb && !rag && !half_) {
-    auto one = [&](const PlanOp& c) { return c.kind == PlanOp::CONV && c.kh == 1 && c.kw == 1 && c.sh == 1 && c.sw == 1 && c.ph == 0 && c.pw == 0 && c.cin != 3; };
-    auto bn_act = [](const std::vector<PlanStage>& ep, int& act) {
-      if (ep.size() == 1 && ep[0].kind == EP_BN) { act = -1; return true; }
-      if (ep.size() == 2 && ep[0].kind == EP_BN && ep[1].kind == EP_ACT && (ep[1].act == ACT_RELU || ep[1].act == ACT_HSWISH)) { act = ep[1].act; return true; }
-      return false;
-    };
-    for (int oi = 0; oi + 5 < nops; ++oi) {
-      const PlanOp &e = plan_.ops[oi], &d = plan_.ops[oi + 1], &g = plan_.ops[oi + 2], &f = plan_.ops[oi + 3], &m = plan_.ops[oi + 4], &p = plan_.ops[oi + 5];
-      if (!one(e) || !one(p) || d.kind != PlanOp::DW || d.in != e.out || g.kind != PlanOp::GAP || g.in != d.out || f.kind != PlanOp::SEFC ||
-          f.in != g.out || m.kind != PlanOp::EW || m.in != d.out || m.ep.size() != 1 || m.ep[0].kind != EP_MULC || m.ep[0].tid != f.out || p.in != m.out) continue;
-      if (uses[e.out] != 1 || uses[d.out] != 2 || uses[g.out] != 1 || uses[f.out] != 1 || uses[m.out] != 1 || fused_dw[oi + 1] || dwpw_of[oi] >= 0 || gate_src[oi] >= 0) continue;
-      bool dead_is_output = false;
-      for (int k = 0; k < 5; ++k) dead_is_output = dead_is_output || plan_.ops[oi + k].out == out_tid_;
-      if (dead_is_output) continue;
-      MbArgs q{};
-      if (!bn_act(e.ep, q.act1) || !bn_act(d.ep, q.act2)) continue;
-      const bool pep = (p.ep.size() == 1 && p.ep[0].kind == EP_BN) || (p.ep.size() == 2 && p.ep[0].kind == EP_BN && p.ep[1].kind == EP_ADDT);
-      if (!pep || T[e.in].plain || T[p.out].plain || d.kh != d.kw || d.sw != 1 || d.pw != d.kw / 2 || d.ph != d.kh / 2) continue;
-      q.Hi = T[e.in].h; q.W = T[e.in].w; q.Ho = T[d.out].h; q.Cin = e.cin; q.Cs_in = T[e.in].cs; q.Cexp = e.cout; q.Cs_exp = T[d.out].cs;
-      q.Cout = p.cout; q.Cs_out = T[p.out].cs; q.K = d.kh; q.SH = d.sh; q.R = f.cr;
-      if (T[d.out].w != q.W || T[p.out].h != q.Ho || e.cin % 4) continue;
-      q.CC = mbconv_chunk(q);
-      if (q.CC <= 0 || !dev_vec("t1x1:" + e.w) || !dev_vec("t1x1:" + p.w)) continue;
-      mb_of[oi + 5] = oi;
-      mb_args[oi + 5] = q;
-      for (int k = 0; k < 5; ++k) fused_dw[oi + k] = 1;  // (no launch, no tensor)
-      folded[oi + 4] = 1;
-      gate_src[oi + 5] = gate_tid[oi + 5] = -1;  // the gate is applied inside the block
-    }
-  }
   // ---- depthwise conv -> global average pool (the SE blocks): the conv leaves the pool's row sums (its first pass, a
   // second full read of the tensor otherwise) while it writes the tensor; only the column pass stays a launch.  Needs
-  // enough bands (a thread owns whole rows then) to fill the chip.  OCR_FUSE_GAP=0 disables (A/B, results identical).
+  // enough bands (a thread owns whole rows then) to fill the chip.
   std::vector<char> dw_rowsum(nops, 0);
-  if (keep_all_ != 1 && rt_options().fuse_gap) {
+  if (fuse) {
     for (int oi = 1; oi < nops; ++oi) {
       const PlanOp& g = plan_.ops[oi];
       const PlanOp& d = plan_.ops[oi - 1];
@@ -965,9 +922,9 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths, const i
     }
   }
   // ---- DB head: deconv (C -> C, bias + BN + relu) -> deconv (C -> 1, bias + sigmoid) as one kernel; the C-channel map
-  // between them (1.4 GB at configs[1]) is never written.  OCR_FUSE_DBHEAD=0 disables (A/B, results identical).
+  // between them (1.4 GB at configs[1]) is never written.
   std::vector<int> dbhead_of(nops, -1);  // tail op -> the deconv it absorbs
-  if (keep_all_ != 1 && rt_options().fuse_dbhead) {
+  if (fuse) {
     for (int oi = 0; oi + 1 < nops; ++oi) {
       const PlanOp& d = plan_.ops[oi];
       const PlanOp& t = plan_.ops[oi + 1];
@@ -981,11 +938,11 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths, const i
   // ---- the DB neck's concat (four 24-channel maps, upsampled x1 / x2 / x4 / x8) -> conv 3x3 96 -> 24: the conv's LDS-tile
   // fill reads the four sources itself (kernels_net.hip, ConvArgs::cat_*); the 96-channel tensor (1.4 GB at configs[1]) is never
   // written.  Only where the conv runs on a kernel that has the folded fill: the 4x4x1 form (f32) or the f16-staged form
-  // (precision "fp16", uniform batches).  OCR_FUSE_CONCAT=0 disables (A/B, results identical).
+  // (precision "fp16", uniform batches).
   std::vector<int> cat_of(nops, -1);  // conv op -> the concat it absorbs
   // The recognizer's neck has the same shape without upsampling: concat (two 480-channel sequences) -> conv 1x3 960 -> 60; the
   // LDS-staged conv (f32) reads chunk c of its input from source c * BK / 480 (conv_lds_kernel, load_a).
-  if (keep_all_ != 1 && rt_options().fuse_concat && !half_ && rt_options().conv_impl != 1) {
+  if (fuse && !half_) {
     for (int oi = 0; oi + 1 < nops; ++oi) {
       const PlanOp& k = plan_.ops[oi];
       if (k.kind != PlanOp::CONCAT || k.out == out_tid_ || uses[k.out] != 1 || k.ins.size() < 2 || k.ins.size() > 4) continue;
@@ -1005,7 +962,7 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths, const i
       }
     }
   }
-  if (keep_all_ != 1 && rt_options().fuse_concat && (!rag || img)) {
+  if (fuse && (!rag || img)) {
     for (int oi = 0; oi + 1 < nops; ++oi) {
       const PlanOp& k = plan_.ops[oi];
       if (k.kind != PlanOp::CONCAT || folded[oi] || k.out == out_tid_ || uses[k.out] != 1 || k.ins.size() != 4 || T[k.out].cs != 96) continue;
@@ -1019,8 +976,23 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths, const i
         const bool conv33 = c.kind == PlanOp::CONV && c.kh == 3 && c.kw == 3 && c.sh == 1 && c.sw == 1 && c.ph == 1 && c.pw == 1 && c.cin == 96 && c.cout == 24;
         bool ep_ok = true;
         for (auto& st : c.ep) ep_ok = ep_ok && st.kind != EP_ADDUP && !(img && st.kind == EP_MULC);
-        const bool kernel_ok = half_ ? (rt_options().mfma_x16 && dev_vec("frag16x:" + c.w) && rt_options().conv_tile)
-                                     : (rt_options().conv_c24 && rt_options().conv_impl != 1 && dev_vec("c24:" + c.w) != nullptr);
+        bool kernel_ok = half_ ? (rt_options().mfma_x16 && dev_vec("frag16x:" + c.w))
+                               : (rt_options().conv_c24 && dev_vec("c24:" + c.w) != nullptr);
+        if (conv33 && ep_ok && kernel_ok) {
+          // the folded fill exists in ONE kernel per precision: ask its launcher now, on the device that will run it (shape
+          // checks and the dynamic-LDS attribute) - a refusal at launch time would leave the conv without an input tensor.
+          // Refused here, the concat is materialised and the conv keeps its fallback chain (conv3x3_tile, conv_lds).
+          ConvArgs q{};
+          q.KH = q.KW = 3; q.PH = q.PW = 1; q.H = q.OH = T[c.out].h; q.W = q.OW = T[c.out].w; q.N = T[c.out].n;
+          q.Cs_in = 96; q.Cs_out = T[c.out].cs; q.Cout = c.cout; q.out_mode = OUT_C8I; q.NTtot = 1;
+          q.cat_n = 4; q.cat_cs = 24; q.half = half_ ? 1 : 0;
+          if (rag) { q.rin.w = q.rout.w = rag_dev; q.rin.h = q.rout.h = rag_dev; q.rtiles = rag_dev; q.rtiles_total = 1; }
+          Epilogue qe{};
+          qe.n = (int)std::min<size_t>(c.ep.size(), OCR_MAX_EP);
+          for (int k = 0; k < qe.n; ++k) qe.st[k].kind = c.ep[k].kind;
+          if (half_) { q.wfrag_x16 = dev_vec("frag16x:" + c.w); kernel_ok = launch_conv3x3_tile(q, qe, 1, nullptr, true); }
+          else kernel_ok = launch_conv3x3_c24(q, qe, dev_vec("c24:" + c.w), nullptr, true);
+        }
         if (conv33 && ep_ok && kernel_ok && !T[c.out].plain && gate_src[oj] < 0 && dwpw_of[oj] < 0) {
           cat_of[oj] = oi;
           folded[oi] = 1;  // (same bookkeeping as a folded gate multiply: no launch, no tensor, its reads happen in the conv)
@@ -1035,10 +1007,10 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths, const i
   // first as conv_rowsum_kernel, which leaves only the pool's row sums, then - with the gate known - as the ordinary
   // conv kernel with the ew's stages in its epilogue (EP_GATERES + the FPN's addup), writing the block's output.  Both
   // passes compute the same chain per output, so nothing changes bit for bit.  Uniform batches and ragged batches of images
-  // (the conv epilogue's per-image stages decode (n, y, x) from either).  OCR_FUSE_RSE=0 disables (A/B, results identical).
+  // (the conv epilogue's per-image stages decode (n, y, x) from either).
   std::vector<int> rse_conv(nops, -1);   // ew op -> the conv it absorbs
   std::vector<char> rse_first(nops, 0);  // that conv: its launch is the row-sum pass, its tensor never exists
-  if (keep_all_ != 1 && rt_options().fuse_rse && (!rag || img)) {
+  if (fuse && (!rag || img)) {
     for (int oi = 0; oi + 3 < nops; ++oi) {
       const PlanOp& c = plan_.ops[oi];
       const PlanOp& g = plan_.ops[oi + 1];
@@ -1066,8 +1038,7 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths, const i
       continue;
     }
     if (oi > 0 && rse_first[oi - 1]) continue;  // the pool after a row-sum pass reads gap_part_, not the conv's tensor
-    if (mb_of[oi] >= 0) last[plan_.ops[mb_of[oi]].in] = oi;
-    else if (gate_src[oi] >= 0) { last[gate_src[oi]] = oi; last[gate_tid[oi]] = oi; }
+    if (gate_src[oi] >= 0) { last[gate_src[oi]] = oi; last[gate_tid[oi]] = oi; }
     else if (dwpw_of[oi] >= 0) last[plan_.ops[dwpw_of[oi]].in] = oi;
     else if (dbhead_of[oi] >= 0) last[plan_.ops[dbhead_of[oi]].in] = oi;
     else if (cat_of[oi] >= 0) { for (int t : plan_.ops[cat_of[oi]].ins) last[t] = oi; }
@@ -1157,33 +1128,6 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths, const i
     const TensorDesc& o = T[op.out];
     float* optr = arena_ + o.offset;
     Launch L;
-    if (mb_of[oi] >= 0) {  // a whole SE bottleneck: the launch of its project conv
-      const int o0 = mb_of[oi];
-      const PlanOp &e = plan_.ops[o0], &d = plan_.ops[o0 + 1], &f = plan_.ops[o0 + 3], &p = plan_.ops[oi];
-      Epilogue e1, e2, e3;
-      if (!build_epilogue(e, e1, true, err) || !build_epilogue(d, e2, false, err) || !build_epilogue(p, e3, true, err)) return false;
-      MbArgs a = mb_args[oi];
-      a.in = arena_ + T[e.in].offset; a.out = optr; a.res = e3.n == 2 ? e3.st[1].v0 : nullptr;
-      a.N = T[e.in].n;
-      a.w1 = dev_vec("t1x1:" + e.w); a.s1 = e1.st[0].v0; a.t1 = e1.st[0].v1;
-      a.wd = dev_vec("dw:" + d.w); a.s2 = e2.st[0].v0; a.t2 = e2.st[0].v1;
-      a.se_w1 = dev_vec("raw:" + f.w1); a.se_b1 = dev_vec("raw:" + f.b1); a.se_w2 = dev_vec("raw:" + f.w2); a.se_b2 = dev_vec("raw:" + f.b2);
-      a.slope = f.slope; a.offset = f.offset;
-      a.w2 = dev_vec("t1x1:" + p.w); a.s3 = e3.st[0].v0; a.t3 = e3.st[0].v1;
-      if (!a.w1 || !a.wd || !a.se_w1 || !a.se_b1 || !a.se_w2 || !a.se_b2 || !a.w2) { err = "fused bottleneck: a weight image is missing"; return false; }
-      snprintf(nm, sizeof nm, "%s.%02d.mbconv%dx%d_%d_%d_%d_s%d1", plan_.name.c_str(), o0, d.kh, d.kw, e.cin, e.cout, p.cout, d.sh);
-      L.name = nm;
-      const double pin = (double)a.N * a.Hi * a.W, pout = (double)a.N * a.Ho * a.W;
-      L.flops = 2.0 * (pin * e.cin * e.cout + pout * d.kh * d.kw * d.c + pout * p.cin * p.cout);
-      L.bytes = 4.0 * (pin * e.cin + pout * p.cout * (a.res ? 2.0 : 1.0));
-      L.fn = [this, a](hipStream_t s) {
-        if (!launch_mbconv(a, s)) this->launch_error_ = "launch_mbconv: shape accepted at bind time was refused at launch";
-      };
-      snprintf(nm, sizeof nm, "@%dx%dx%d", N, H, W);
-      L.name += nm;
-      launches_.push_back(std::move(L));
-      continue;
-    }
     if (rse_first[oi]) {  // first pass: the pool's row sums, nothing else
       const TensorDesc& in = T[op.in];
       ConvRowsumArgs a{};
@@ -1242,7 +1186,7 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths, const i
           L.flops = 2.0 * a.M * op.cin * 4;
           L.bytes = EB(in) * a.M * op.cin + 4.0 * a.M * 4 + (det_bitmap_ ? 1.0 * a.M * 4 : 0.0);
           L.fn = [a](hipStream_t s) { launch_det_tail(a, s); };
-          if (img && dbhead_of[oi] < 0) { err = "ragged batch of images: the DB head needs its fused kernel (OCR_FUSE_DBHEAD, production launch list)"; return false; }
+          if (img && dbhead_of[oi] < 0) { err = "ragged batch of images: the DB head needs its fused kernel (production launch list, OCR_FUSE on)"; return false; }
           if (dbhead_of[oi] >= 0) {
             const PlanOp& d = plan_.ops[dbhead_of[oi]];
             const TensorDesc& din = T[d.in];
@@ -1251,7 +1195,7 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths, const i
             DbHeadArgs h{};
             h.in = arena_ + din.offset; h.prob = optr; h.bitmap = det_bitmap_;
             h.w1 = dev_vec("dbh1:" + d.w); h.bias1 = epd.st[0].v0; h.bn_s = epd.st[1].v0; h.bn_t = epd.st[1].v1;
-            if (rt_options().dbhead_mfma && d.cin == 24 && d.cout == 24) h.wfrag = dev_vec("dbhf:" + d.w);
+            if (d.cin == 24 && d.cout == 24) h.wfrag = dev_vec("dbhf:" + d.w);
             h.w2 = a.w; h.M = din.pixels(); h.N = din.n; h.H = din.h; h.W = din.w; h.Cs = din.cs;
             h.bias2 = a.bias; h.ithresh = a.ithresh;
             h.h16 = din.f16;
@@ -1349,12 +1293,10 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths, const i
           if (a.cat_n) L.name += "_cat" + std::to_string(a.cat_n);
           L.bytes = (a.cat_n ? cat_bytes : EB(in) * a.M * op.cin) + (a.out_mode == OUT_HEAD ? 12.0 * a.M * (a.NTtot / nt) : EB(o) * a.M * cols) +
                     (hconv ? 2.0 : 4.0) * taps * op.cin * cols;
-          // OCR_CONV_IMPL=direct|lds overrides the choice (A/B measurements); results are identical
-          // measured (gpurun_out r1g): LDS staging wins for multi-tap convs (3x3 96->24: 58 vs 51 TFLOP/s),
-          // the direct kernel for 1x1 (480->480: 88 vs 71; thin K: 54 vs 39)
-          const int impl = rt_options().conv_impl;
-          // precision "fp16": the LDS-staged and the 4x4x1 kernels are f32 only - every dense conv goes through the direct kernel
-          const bool use_lds = !hconv && !a.gate && a.out_mode == OUT_C8I && (impl ? impl == 2 : (taps > 1 && in.cs >= 64));
+          // measured (round 1): LDS staging wins for multi-tap convs (3x3 96->24: 58 vs 51 TFLOP/s), the direct kernel for 1x1
+          // (480->480: 88 vs 71; thin K: 54 vs 39).  precision "fp16": the LDS-staged and the 4x4x1 kernels are f32 only - every
+          // dense conv goes through the direct kernel
+          const bool use_lds = !hconv && !a.gate && a.out_mode == OUT_C8I && taps > 1 && in.cs >= 64;
           if (dwpw_of[oi] >= 0) {
             const PlanOp& d = plan_.ops[dwpw_of[oi]];
             const TensorDesc& din = T[d.in];

@@ -573,7 +573,7 @@ struct ocr_pipe {
       }
     };
     std::vector<std::thread> th;
-    for (int c = 1; c < nchains; ++c) th.emplace_back([&, c]() { (void)hipSetDevice(device); chain(c); });
+    for (int c = 1; c < nchains; ++c) th.emplace_back([&, c]() { (void)rt_set_device(device); chain(c); });
     chain(0);
     for (auto& x : th) x.join();
     for (int p = 0; p < K; ++p)
@@ -659,7 +659,6 @@ int ocr_pipe_create(const ocr_pipe_cfg* c, ocr_pipe** out) {
   if (c->phases < 0 || c->phases > 4) return fail(OCR_ERR_ARG, "phases must be 0 (default) or 1..4");
   h->phases = c->phases ? c->phases : 2;
   if (const char* e = getenv("OCR_PIPE_PHASES")) h->phases = std::min(4, std::max(1, atoi(e)));
-  if (const char* e = getenv("OCR_PIPE_PARTS")) h->parts_per_chain = std::min(8, std::max(1, atoi(e)));
   std::string err;
   DetConfig d;
   d.model_dir = c->det.model_dir; d.device = c->det.device_id;
@@ -712,7 +711,7 @@ int ocr_pipe_run_device(ocr_pipe* h, const void* dev_bgr, int rows, int cols, in
                         int cap_words, int* word_off, int* nwords, int32_t* ids, int cap_ids, double times[3]) {
   if (!h || !dev_bgr || rows <= 0 || cols <= 0 || count < 1 || !words || !word_off || !nwords || !ids)
     return fail(OCR_ERR_ARG, "bad argument");
-  CAPI_HIP(hipSetDevice(h->device));
+  CAPI_HIP(rt_set_device(h->device));
   double t[3] = {0, 0, 0};
   std::vector<std::vector<ocr_word>> W;
   std::vector<std::vector<int32_t>> I;
@@ -736,7 +735,7 @@ int ocr_pipe_stage(ocr_pipe* h, int slot, const ocr_img* imgs, int count) {
   if (!h || !imgs || count < 1 || slot < 0 || slot > 1) return fail(OCR_ERR_ARG, "bad argument");
   for (int i = 0; i < count; ++i)
     if (!imgs[i].data || imgs[i].rows <= 0 || imgs[i].cols <= 0) return fail(OCR_ERR_ARG, "Empty image data provided");
-  CAPI_HIP(hipSetDevice(h->device));
+  CAPI_HIP(rt_set_device(h->device));
   std::string err;
   const int rc = h->stage(slot, imgs, count, err);
   return rc ? fail(rc, err) : OCR_OK;
@@ -746,7 +745,7 @@ int ocr_pipe_stage_jpeg(ocr_pipe* h, int slot, const ocr_jpeg_img* imgs, int cou
   if (!h || !imgs || count < 1 || slot < 0 || slot > 1) return fail(OCR_ERR_ARG, "bad argument");
   for (int i = 0; i < count; ++i)
     if (!jpeg_img_valid(imgs[i])) return fail(OCR_ERR_ARG, "bad JPEG coefficient descriptor");
-  CAPI_HIP(hipSetDevice(h->device));
+  CAPI_HIP(rt_set_device(h->device));
   std::string err;
   const int rc = h->stage_jpeg(slot, imgs, count, err);
   return rc ? fail(rc, err) : OCR_OK;
@@ -755,7 +754,7 @@ int ocr_pipe_stage_jpeg(ocr_pipe* h, int slot, const ocr_jpeg_img* imgs, int cou
 int ocr_pipe_slot_probs(ocr_pipe* h, int slot, const float* const* probs, int count) {
   if (!h || !probs || count < 1 || slot < 0 || slot > 1) return fail(OCR_ERR_ARG, "bad argument");
   for (int i = 0; i < count; ++i) if (!probs[i]) return fail(OCR_ERR_ARG, "null probability map");
-  CAPI_HIP(hipSetDevice(h->device));
+  CAPI_HIP(rt_set_device(h->device));
   std::string err;
   const int rc = h->slot_probs(slot, probs, count, err);
   return rc ? fail(rc, err) : OCR_OK;
@@ -764,7 +763,7 @@ int ocr_pipe_slot_probs(ocr_pipe* h, int slot, const float* const* probs, int co
 int ocr_pipe_run_staged(ocr_pipe* h, int slot, ocr_word* words, int cap_words, int* word_off, int* nwords, int32_t* ids,
                         int cap_ids, double times[3]) {
   if (!h || slot < 0 || slot > 1 || !words || !word_off || !nwords || !ids) return fail(OCR_ERR_ARG, "bad argument");
-  CAPI_HIP(hipSetDevice(h->device));
+  CAPI_HIP(rt_set_device(h->device));
   return h->run_slot(slot, words, cap_words, word_off, nwords, ids, cap_ids, times);
 }
 

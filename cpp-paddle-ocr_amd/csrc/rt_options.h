@@ -1,7 +1,8 @@
 // Runtime switches of the library, read from the environment ONCE per process (the first call of rt_options(), which
 // ocr_rt_init makes before any handle exists) - INTEGRATION.md documents every field.  They select other kernel shapes /
 // launch lists for A/B measurements and for the tests that drive production-only paths with small inputs; results are
-// identical in every setting.  Three switches are per HANDLE instead (read when the handle is created): OCR_GRAPH,
+// identical in every setting.  Every switch here is listed in INTEGRATION.md and driven by tests/test_gpu_parity.py
+// (test_ab_switches_do_not_change_results); the A/B switches of settled questions were retired in round 5.  Three switches are per HANDLE instead (read when the handle is created): OCR_GRAPH,
 // OCR_PIPE_PHASES, OCR_DET_LANES.
 #pragma once
 #include <string>
@@ -9,23 +10,13 @@
 namespace ocr {
 
 struct RtOptions {
-  bool fuse_gate = true;       // OCR_FUSE_GATE=0
-  bool fuse_dwpw = true;       // OCR_FUSE_DWPW=0
-  bool fuse_gap = true;        // OCR_FUSE_GAP=0
-  long fuse_gap_min = 65536;   // OCR_FUSE_GAP_MIN=n
-  bool fuse_dbhead = true;     // OCR_FUSE_DBHEAD=0
-  bool dbhead_mfma = true;     // OCR_DBHEAD_MFMA=0: the fused DB head's first stage on the VALU (db_head_kernel)
-  bool fuse_rse = true;        // OCR_FUSE_RSE=0
-  bool fuse_concat = true;     // OCR_FUSE_CONCAT=0: the DB neck's concat is materialised (A/B; results are identical)
-  bool fuse_mb = false;        // OCR_FUSE_MB=1: the classifier's SE bottlenecks as one launch each (kernels_mb.hip: correct, measured slower, off)
-  int conv_impl = 0;           // OCR_CONV_IMPL=direct (1) | lds (2); 0 = per shape
+  bool fuse = true;            // OCR_FUSE=0: the launch list without its bind-time fusions (folded SE gates, fused depthwise blocks, row
+                               // sums out of the depthwise convs, fused DB head, two-pass RSE blocks, folded concats): one launch per plan op
+  long fuse_gap_min = 65536;   // OCR_FUSE_GAP_MIN=n (tests: small shapes take the row-sum path too)
   bool conv_small_nt = true;   // OCR_CONV_SMALL_NT=0
-  int conv_nt_max = 4;         // OCR_CONV_NT_MAX=n
   bool conv_mt2 = true;        // OCR_CONV_MT2=0
   bool conv_mt2_force = false; // OCR_CONV_MT2=force (tests): two pixel tiles per wave whatever the launch's size and K
-  bool conv_c24 = true;        // OCR_CONV_C24=0
-  bool conv_tile = true;       // OCR_CONV_TILE=0
-  int dw_patch_to = 0, dw_patch_r = 0;  // OCR_DW_PATCH=TOxR; 0 = per shape
+  bool conv_c24 = true;        // OCR_CONV_C24=0: the 3x3 96 -> 24 convs on the 32-column tile kernel (the 4x4x1 kernel's fallback)
   bool attn_line = true;       // OCR_ATTN_LINE=0: attention as a wave per (line, head) also for lines of <= 64 tokens (A/B)
   bool mfma_x16 = true;        // OCR_MFMA_X16=0: precision "fp16" keeps v_mfma_f32_32x32x8_f16 in the big 1x1 convs (A/B)
   bool dw_lds = true;          // OCR_DW_LDS=0: the low-map 5x5 depthwise layers keep dw_conv_kernel (A/B; results are identical)
@@ -34,7 +25,6 @@ struct RtOptions {
   int dwpw_force_upw = 0;      // OCR_DWPW_FORCE_UPW=n (tests)
   bool dwpw_t4_thin = false;   // OCR_DWPW_T4=thin
   int trace_slice = 0;         // OCR_TRACE_SLICE=n (tests); 0 = unlimited
-  bool prio_anchor = true;     // OCR_PRIO_ANCHOR=0
 };
 const RtOptions& rt_options();
 

@@ -244,7 +244,7 @@ int DetStage::run(const ocr_img* imgs, int count, int32_t* boxes, int cap, int* 
     if (!imgs[i].data || imgs[i].rows <= 0 || imgs[i].cols <= 0) { err = "Empty image data provided"; return OCR_ERR_ARG; }
     if (imgs[i].rows != rows || imgs[i].cols != cols) { err = "ocr_det_run_batch needs images of one size"; return OCR_ERR_ARG; }
   }
-  ST_HIP(hipSetDevice(cfg_.device));
+  ST_HIP(rt_set_device(cfg_.device));
   const size_t row = (size_t)cols * 3, img_bytes = row * rows;
   if (!src_.ensure(img_bytes * count, err)) return OCR_ERR_DEVICE;
   timer_.mark(0, stream_);
@@ -259,7 +259,7 @@ int DetStage::run(const ocr_img* imgs, int count, int32_t* boxes, int cap, int* 
 
 int DetStage::run_device(const uint8_t* dev_imgs, size_t img_bytes, size_t stride, int rows, int cols, int count,
                          int32_t* boxes, int cap, int* n, double times[3], std::string& err, const float* prob_override) {
-  ST_HIP(hipSetDevice(cfg_.device));
+  ST_HIP(rt_set_device(cfg_.device));
   int rh, rw;
   float ratio_h, ratio_w;
   resize_shape(rows, cols, cfg_.limit_type, cfg_.limit_side_len, rh, rw, ratio_h, ratio_w);
@@ -290,7 +290,7 @@ int DetStage::run_device(const uint8_t* dev_imgs, size_t img_bytes, size_t strid
 }
 
 int DetStage::mixed_net(const uint8_t* base, const MixedGroup* groups, int ngroups, const float* prob_override, std::string& err) {
-  ST_HIP(hipSetDevice(cfg_.device));
+  ST_HIP(rt_set_device(cfg_.device));
   if (!mixed_done_) ST_HIP(hipEventCreateWithFlags(&mixed_done_, hipEventDisableTiming));
   mixed_pix_.assign(ngroups + 1, 0);
   std::vector<int> hs, ws;
@@ -332,7 +332,7 @@ int DetStage::mixed_net(const uint8_t* base, const MixedGroup* groups, int ngrou
 }
 
 int DetStage::post_mixed(const MixedGroup* groups, int ngroups, int32_t* boxes, int cap, int* n, std::string& err) {
-  ST_HIP(hipSetDevice(cfg_.device));
+  ST_HIP(rt_set_device(cfg_.device));
   if (cfg_.use_dilation) { err = "post_mixed: not with use_dilation"; return OCR_ERR_ARG; }
   std::vector<PostImg> im;
   int Hm = 0, Wm = 0;
@@ -371,7 +371,7 @@ int DetStage::post_mixed(const MixedGroup* groups, int ngroups, int32_t* boxes, 
 
 int DetStage::post_group(const float* prob, const uint8_t* bitmap, const MixedGroup& g, hipEvent_t wait_for, int32_t* boxes, int cap,
                          int* n, std::string& err) {
-  ST_HIP(hipSetDevice(cfg_.device));
+  ST_HIP(rt_set_device(cfg_.device));
   if (wait_for) ST_HIP(hipStreamWaitEvent(stream_, wait_for, 0));
   int rh, rw;
   float ratio_h, ratio_w;
@@ -384,7 +384,7 @@ int DetStage::post_group(const float* prob, const uint8_t* bitmap, const MixedGr
 int DetStage::post_only(const float* prob, int rows, int cols, int src_rows, int src_cols, int32_t* boxes, int cap, int* n,
                         std::string& err) {
   if (!prob || rows <= 0 || cols <= 0 || !boxes || !n || cap < 1) { err = "bad argument"; return OCR_ERR_ARG; }
-  ST_HIP(hipSetDevice(cfg_.device));
+  ST_HIP(rt_set_device(cfg_.device));
   const size_t px = (size_t)rows * cols;
   if (!prob_in_.ensure(px, err) || !bitmap_.ensure(px, err)) return OCR_ERR_DEVICE;
   bm_n_ = 0;  // the fused-bitmap pointer may have moved: re-arm on the next network run
@@ -408,10 +408,6 @@ bool RecStage::create(const RecConfig& cfg, std::string& err, int& code) {
   if (cfg.precision != "fp32" && cfg.precision != "fp16") { err = "precision '" + cfg.precision + "' is not implemented (fp32 | fp16)"; return false; }
   if (cfg.batch_num < 1 || cfg.img_h < 1 || cfg.img_w < 1) { err = "bad rec shape"; return false; }
   if (cfg.sort_mode != OCR_SORT_STD && cfg.sort_mode != OCR_SORT_STABLE) { err = "unknown sort_mode"; return false; }
-  if (const char* e = getenv("OCR_REC_MAX_LINES")) {  // per handle: 48x320-line equivalents per ragged launch (A/B; results are identical)
-    const long v = atol(e);
-    if (v >= 16 && v <= 16384) max_lines_per_launch = (int)v;
-  }
   code = ocr_rt_init(cfg.device);
   if (code) { err = ocr_last_error(); return false; }
   code = OCR_ERR_MODEL;
@@ -441,7 +437,7 @@ int RecStage::run(const ocr_img* imgs, int n, int32_t* ids, int max_len, int* le
   if (n < 0 || (n > 0 && (!imgs || !ids || !lens || !scores)) || max_len < 1) { err = "bad argument"; return OCR_ERR_ARG; }
   if (times) times[0] = times[1] = times[2] = 0;
   if (n == 0) return OCR_OK;
-  ST_HIP(hipSetDevice(cfg_.device));
+  ST_HIP(rt_set_device(cfg_.device));
   timer_.mark(0, stream_);
   std::vector<LineSrc> lines;
   if (!upload_lines(imgs, n, staging_, lines, stream_, err)) return OCR_ERR_DEVICE;
@@ -659,7 +655,7 @@ int ClsStage::run(const ocr_img* imgs, int n, int* labels, float* scores, double
   if (n < 0 || (n > 0 && (!imgs || !labels || !scores))) { err = "bad argument"; return OCR_ERR_ARG; }
   if (times) times[0] = times[1] = times[2] = 0;
   if (n == 0) return OCR_OK;
-  ST_HIP(hipSetDevice(cfg_.device));
+  ST_HIP(rt_set_device(cfg_.device));
   timer_.mark(0, stream_);
   std::vector<LineSrc> lines;
   if (!upload_lines(imgs, n, staging_, lines, stream_, err)) return OCR_ERR_DEVICE;

@@ -306,10 +306,6 @@ class OCRWorker {
       max_batch = e ? atoi(e) : 16;
     }
     max_batch_ = max_batch < 1 ? 1 : (max_batch > 256 ? 256 : max_batch);  // result buffers: 1 MB of ids per image
-    // batching window (extension, off by default): after the first queued request the worker may wait up to this many
-    // microseconds for its batch to fill - trades the latency of a lone request for fuller batches under load
-    // (OCR_WORKER_LINGER_US; tools/service_load.py sweep measures both sides)
-    if (const char* e = getenv("OCR_WORKER_LINGER_US")) linger_us_ = std::max(0, std::min(50000, atoi(e)));
     gpu_id_ = gpu_id;
     if (!use_gpu) throw std::runtime_error("OCRWorker: this build has no CPU path (use_gpu must be true)");
     det_dir_ = model_dir + "/det"; cls_dir_ = model_dir + "/cls"; rec_dir_ = model_dir + "/rec";
@@ -485,12 +481,6 @@ class OCRWorker {
           }
         };
         take();
-        if (linger_us_ > 0 && !batch.empty() && (int)batch.size() < max_batch_) {
-          const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(linger_us_);
-          while (running_ && (int)batch.size() < max_batch_ &&
-                 cv_.wait_until(lock, deadline, [this] { return !request_queue_.empty() || !running_; }))
-            take();
-        }
         if (!batch.empty()) is_idle_ = false;
       }
       if (batch.empty()) continue;
@@ -515,7 +505,6 @@ class OCRWorker {
   int worker_id_;
   int gpu_id_ = 0;
   int max_batch_ = 1;
-  int linger_us_ = 0;
   std::string precision_;  // OCR_WORKER_PRECISION (kept alive for the configuration's pointers)
   std::vector<ocr_word> batch_words_;
   std::vector<int32_t> batch_ids_;

@@ -2,6 +2,7 @@
 refuses to compute without a GPU (no fallback)."""
 import ctypes
 import os
+import sys
 import re
 
 import pytest
@@ -75,3 +76,21 @@ def test_product_does_not_reference_oracle():
             if fn.endswith((".py", ".h", ".hip", ".cpp", ".inc")):
                 text = open(os.path.join(dp, fn), errors="replace").read()
                 assert "liboracle" not in text and "oracle_" not in text, os.path.join(dp, fn)
+
+
+def test_ab_list_names_exactly_the_surviving_switches():
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_gpu_parity import _AB_ENVS
+    """rt_options.h, the A/B list above and INTEGRATION.md name the same variables (OCR_MFMA_X16 and OCR_TRACE_SLICE have
+    tests of their own: test_fp16_with_the_32x32x8_kernels..., test_det_post_border_walk_with_tiny_provisional_slices)."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "cpp-paddle-ocr_amd", "csrc", "rt_options.h")).read()
+    fields = set(re.findall(r"//\s*(OCR_[A-Z0-9_]+)=", hdr.split("struct RtOptions")[1]))
+    tested = set(k for e in _AB_ENVS for k in e) | {"OCR_MFMA_X16", "OCR_TRACE_SLICE"}
+    assert fields == tested, (sorted(fields - tested), sorted(tested - fields))
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    for v in fields:
+        assert "`" + v + "=" in doc, v + " is not documented in INTEGRATION.md"
+    for gone in ("OCR_FUSE_MB", "OCR_DW_PATCH", "OCR_CONV_NT_MAX", "OCR_PRIO_ANCHOR", "OCR_REC_MAX_LINES", "OCR_CONV_IMPL", "OCR_CONV_TILE", "OCR_DBHEAD_MFMA"):
+        assert gone not in doc and gone not in hdr, gone

@@ -98,7 +98,7 @@ assert np.array_equal(want, g.forward_ragged(lines, keep_all=False).reshape(-1, 
 g.close()
 # the detector's path for mixed sizes: a ragged batch of images against each image alone (needs the fused DB head)
 import os
-if os.environ.get("OCR_FUSE_DBHEAD") != "0":
+if os.environ.get("OCR_FUSE") != "0":
     imgs = [rs.randn(h, w, 3).astype(np.float32) for h, w in ((96, 160), (64, 64), (32, 96), (160, 96), (64, 64), (128, 224))]
     o, g = OracleNet("det"), pkg.Net("det")
     want = np.concatenate([o.run(im[None]).reshape(-1) for im in imgs])
@@ -108,9 +108,14 @@ print("AB OK")
 """
 
 
-@pytest.mark.parametrize("env", [{"OCR_DWPW_T4": "thin"}, {"OCR_DWPW_ITEMS": "7"}, {"OCR_DWPW_ITEMS": "1"}, {"OCR_FUSE_DWPW": "0"},
-                                 {"OCR_CONV_C24": "0", "OCR_FUSE_GATE": "0", "OCR_FUSE_GAP": "0", "OCR_CONV_SMALL_NT": "0", "OCR_FUSE_DBHEAD": "0", "OCR_FUSE_RSE": "0", "OCR_CONV_MT2": "0", "OCR_FUSE_CONCAT": "0"}, {"OCR_FUSE_GAP_MIN": "1", "OCR_CONV_MT2": "force"}, {"OCR_DWPW_FORCE_UPW": "3"}, {"OCR_DWPW_FORCE_UPW": "16", "OCR_DWPW_T4": "thin"}, {"OCR_FUSE_MB": "1"}, {"OCR_DW_LDS": "0", "OCR_ATTN_LINE": "0", "OCR_DBHEAD_MFMA": "0"},
-                                 {"OCR_DWPW2": "0"}, {"OCR_DWPW2": "0", "OCR_DWPW_FORCE_UPW": "3"}])
+# every switch of csrc/rt_options.h (INTEGRATION.md's table), each in the setting that is NOT the default
+_AB_ENVS = [{"OCR_FUSE": "0"}, {"OCR_FUSE_GAP_MIN": "1", "OCR_CONV_MT2": "force"}, {"OCR_CONV_SMALL_NT": "0", "OCR_CONV_MT2": "0", "OCR_CONV_C24": "0"},
+            {"OCR_DW_LDS": "0", "OCR_ATTN_LINE": "0"}, {"OCR_DWPW2": "0"}, {"OCR_DWPW2": "0", "OCR_DWPW_FORCE_UPW": "3"},
+            {"OCR_DWPW_T4": "thin"}, {"OCR_DWPW_ITEMS": "7"}, {"OCR_DWPW_ITEMS": "1"}, {"OCR_DWPW_FORCE_UPW": "3"},
+            {"OCR_DWPW_FORCE_UPW": "16", "OCR_DWPW_T4": "thin"}]
+
+
+@pytest.mark.parametrize("env", _AB_ENVS)
 def test_ab_switches_do_not_change_results(built, env):
     """INTEGRATION.md's runtime switches select other kernel shapes / launch lists (read once per process, so each
     setting runs in a child process): the production-mode outputs stay bit-identical to the oracle.  OCR_DWPW_ITEMS = 7

@@ -4,6 +4,7 @@ the oracle pipeline."""
 import json
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -46,16 +47,20 @@ def test_worker_and_pool_binary(built, card, tmp_path):
 @pytest.mark.gpu
 def test_pool_on_two_devices(built, card, tmp_path, pkg):
     """GPUWorkerPool with worker i on GPU i mod n, from ONE process (gpu_worker_pool.cpp:12-16 shape).
-    Needs two visible devices (the driver's multi-GPU node); on a one-GPU lease it is skipped."""
-    if pkg.lib().ocr_rt_device_count() < 2:
-        pytest.skip("one device visible")
+    On a node with two visible devices these are two GPUs; on a one-GPU lease the library's logical-device table
+    (OCR_DEVICE_MAP=0,0, csrc/hip_guard.h) gives the pool two devices - own LDS-attribute memo entries, occupancy memos,
+    priority anchors, arenas and streams per LOGICAL id - that share the physical GPU: the code path is the pool's either
+    way, and every reply equals the oracle's words (= the one-worker result)."""
     from pipeline import Pipeline
     subprocess.check_call(["make", "-s", "-C", HOST])
     raw = tmp_path / "card.bgr"
     card.tofile(raw)
+    env = dict(os.environ)
+    if pkg.lib().ocr_rt_device_count() < 2:
+        env["OCR_DEVICE_MAP"] = "0,0"
     out = subprocess.run([os.path.join(HOST, "test_worker"), os.path.join(ROOT, "models"), str(raw),
-                          "%dx%d" % card.shape[:2], "multi"], capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0 and "ALL OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+                          "%dx%d" % card.shape[:2], "multi"], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0 and "ALL OK" in out.stdout and "SKIP" not in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
     want = Pipeline().process(card)["words"]
     replies = [json.loads(l[9:]) for l in out.stdout.splitlines() if l.startswith("POOLJSON ")]
     assert len(replies) == 8 and {r["worker_id"] for r in replies} == {0, 1}
@@ -63,6 +68,22 @@ def test_pool_on_two_devices(built, card, tmp_path, pkg):
         assert r["success"] is True and len(r["words"]) == len(want)
         for g, w in zip(r["words"], want):
             assert g["box"] == np.asarray(w["box"]).tolist() and np.float32(g["confidence"]) == np.float32(w["confidence"])
+
+
+def test_device_map_is_parsed_without_a_gpu(built):
+    """OCR_DEVICE_MAP is read once per process; with no device visible the count stays 0 whatever the map says (a CPU
+    container), and a malformed map is ignored rather than trusted."""
+    import subprocess as sp
+    code = ("import sys; sys.path.insert(0, %r); import __graft_entry__ as g; L = g.load_package().lib(); print('COUNT', L.ocr_rt_device_count())" % ROOT)
+    for m in ("0,0", "0,x", "", "7"):
+        out = sp.run([sys.executable, "-c", code], env=dict(os.environ, OCR_DEVICE_MAP=m), capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-1000:]
+        n = int(out.stdout.split("COUNT")[1])
+        import torch
+        if not torch.cuda.is_available():
+            assert n == 0
+        else:
+            assert n == (2 if m == "0,0" else torch.cuda.device_count())
 
 
 def test_argsort_tie_order_modes(built):

@@ -9,8 +9,30 @@
 #include "kernels_net.hip"
 using namespace ocr;
 namespace ocr {
+inline namespace h16 {  // (the precision "fp16" twins of the launchers: not linked into this probe)
+bool launch_conv_mfma_h16(const ConvArgs&, const Epilogue&, int, hipStream_t) { return false; }
+bool launch_conv_mfma_mt2_h16(const ConvArgs&, const Epilogue&, int, hipStream_t) { return false; }
+bool launch_conv3x3_tile_h16(const ConvArgs&, const Epilogue&, int, hipStream_t, bool) { return false; }
+bool launch_conv_rowsum_h16(const ConvRowsumArgs&, hipStream_t) { return false; }
+void launch_stem_h16(const StemArgs&, const Epilogue&, hipStream_t) {}
+void launch_dw_h16(const DwArgs&, const Epilogue&, hipStream_t) {}
+void launch_ew_h16(const float*, float*, long, int, int, int, const Epilogue&, hipStream_t, int, RagLevel, bool) {}
+void launch_gap_h16(const float*, float*, float*, int, int, int, int, hipStream_t, RagLevel, long, bool) {}
+void launch_concat_h16(const ConcatArgs&, hipStream_t) {}
+void launch_pool_h16(const PoolArgs&, hipStream_t) {}
+void launch_ln_h16(const float*, float*, long, int, int, float, const float*, const float*, hipStream_t, bool) {}
+void launch_attn_h16(const float*, float*, int, int, int, int, int, int, float, hipStream_t, RagLevel, bool) {}
+void launch_det_tail_h16(const DetTailArgs&, hipStream_t) {}
+bool launch_db_head_h16(const DbHeadArgs&, int, hipStream_t) { return false; }
+void launch_c8i_to_plain_h16(const float*, float*, long, int, int, hipStream_t, bool) {}
+}
 const RtOptions& rt_options() { static RtOptions o; return o; }
+std::string rt_refuse_launch() { return std::string(); }
 std::shared_mutex& capture_mutex() { static std::shared_mutex m; return m; }
+int rt_current_device() { return 0; }  // (the probes run on device 0 without the library's logical-device table)
+int rt_physical_device(int d) { return d; }
+int rt_device_count() { return 1; }
+hipError_t rt_set_device(int d) { return hipSetDevice(d); }
 }
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 __global__ void fill_kernel(float* p, size_t n, unsigned seed) {
@@ -49,15 +71,23 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   float best = 1e9f, sum = 0.f;
+  const int inner = getenv("CONV_TIME_ITERS") ? atoi(getenv("CONV_TIME_ITERS")) : 4;  // (long runs: warm clocks)
+#ifdef OCR_CONV_CLKRATE
+  { unsigned long long z[2] = {0, 0}; CK(hipMemcpyToSymbol(HIP_SYMBOL(ocr_conv_clkrate), z, sizeof z)); }
+#endif
   for (int r = 0; r < 5; ++r) {
     CK(hipEventRecord(e0));
-    for (int i = 0; i < 4; ++i) launch();
+    for (int i = 0; i < inner; ++i) launch();
     CK(hipEventRecord(e1));
     CK(hipEventSynchronize(e1));
     float ms;
     CK(hipEventElapsedTime(&ms, e0, e1));
-    ms /= 4; sum += ms; if (ms < best) best = ms;
+    ms /= inner; sum += ms; if (ms < best) best = ms;
   }
+#ifdef OCR_CONV_CLKRATE
+  { unsigned long long z[2]; CK(hipMemcpyFromSymbol(z, HIP_SYMBOL(ocr_conv_clkrate), sizeof z));
+    if (z[1]) printf("   average shader clock over the workgroups' lives: %.0f MHz\n", 100.0 * z[0] / z[1]); }
+#endif
   // checksum of the output so that variants can be compared for identical results
   std::vector<float> hy(1 << 16);
   CK(hipMemcpy(hy.data(), y + (M / 2) * cs_out, hy.size() * 4, hipMemcpyDeviceToHost));

@@ -20,6 +20,10 @@ static bool probe_launch_h16(const DwPwArgs& a, hipStream_t s, bool query = fals
 namespace ocr {
 const RtOptions& rt_options() { static RtOptions o; return o; }
 std::shared_mutex& capture_mutex() { static std::shared_mutex m; return m; }
+int rt_current_device() { return 0; }  // (the probes run on device 0 without the library's logical-device table)
+int rt_physical_device(int d) { return d; }
+int rt_device_count() { return 1; }
+hipError_t rt_set_device(int d) { return hipSetDevice(d); }
 }
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 

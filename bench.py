@@ -231,6 +231,17 @@ def roof_of(flops, nbytes, ms, mfma_peak=FP32_MFMA_PEAK_TFLOPS):
             "hbm_GBps_algorithmic": gbps, "frac_hbm": gbps / HBM_PEAK_GBS}
 
 
+def fp16_traffic(name):
+    """HBM bytes per launch of the fp16 mode's dominant kernel from the PMC passes of `bench.py --precision fp16` (tools/run_profile.sh
+    fp16 -> profiles/*pmc_traffic_fp16.json), or None"""
+    pdir = os.path.join(ROOT, "profiles")
+    for tf in sorted((f for f in os.listdir(pdir) if f.endswith("pmc_traffic_fp16.json")), reverse=True):
+        pm = json.load(open(os.path.join(pdir, tf)))
+        if pm.get("kernel") == name and pm.get("durations_agree_within_10pct", False):
+            return pm["traffic_bytes_per_launch"]
+    return None
+
+
 def fp16_leg(mk_pipe, run_of, ref_words, batch, steps, sync):
     """The opt-in precision = "fp16" mode (the reference's TensorRT precision switch, ocr_det.cpp:50-56) on the same
     resident batch: f16 activation tensors, f16 matrix products with f32 accumulation.  NEVER `value` - the
@@ -264,7 +275,7 @@ def fp16_leg(mk_pipe, run_of, ref_words, batch, steps, sync):
            "stage_ms_last_step": dict(zip(("det", "cls", "rec"), stage)),
            "vs_fp32_words": {"words": tot, "identical_boxes": same_box / max(1, tot), "identical_id_sequences": same_ids / max(1, tot),
                              "max_abs_confidence_diff": dconf},
-           "what": "precision = \"fp16\" on every stage: activation tensors stored as f16, v_mfma_f32_32x32x8_f16 with f32 accumulation, reductions and epilogues in f32; "
+           "what": "precision = \"fp16\" on every stage: activation tensors stored as f16, f16 matrix instructions (v_mfma_f32_32x32x16_f16 in the big 1x1 and the 3x3 96-channel convs, 32x32x8 elsewhere) with f32 accumulation, reductions and epilogues in f32; "
                    "an extra key, never `value` (narrower arithmetic than the reference's CPU path)"}
     # its dominant kernel, on a single chain (as the fp32 roofline)
     pipe1 = mk_pipe(1, "fp16")
@@ -290,7 +301,7 @@ def fp16_leg(mk_pipe, run_of, ref_words, batch, steps, sync):
         out["roofline"] = {"kernel": group_label(key, g), "measured_in": "single_chain", "bound": roof["bound"],
                            "achieved": roof["hbm_GBps_algorithmic"] if hbm else roof["tflops"],
                            "peak": HBM_PEAK_GBS if hbm else FP16_MFMA_PEAK_TFLOPS, "unit": "GB/s" if hbm else "TFLOP/s",
-                           "frac": roof["frac_hbm"] if hbm else roof["frac_mfma"], "traffic": None,
+                           "frac": roof["frac_hbm"] if hbm else roof["frac_mfma"], "traffic": fp16_traffic(group_label(key, g)),
                            "avg_launch_ms": g["ms"] / max(1, g["count"]), "launches": g["count"],
                            "algorithmic_flops_per_launch": g["flops"] / max(1, g["count"]),
                            "algorithmic_bytes_per_launch": g["bytes"] / max(1, g["count"]), "tflops": roof["tflops"]}
@@ -368,6 +379,11 @@ def pin_rank_to_its_gpus_numa_node(local, world):
     except AttributeError:
         return {"pinned": False, "why": "no sched_getaffinity"}
     info = {"pinned": False, "numa_node": None, "cpus": len(allowed)}
+    # every per-node computation uses the ranks of THIS node (a multi-node launch has world > GPUs per node)
+    try:
+        world = max(1, min(world, int(os.environ.get("LOCAL_WORLD_SIZE", world))))
+    except ValueError:
+        pass
     if world <= 1 or len(allowed) < 2 * world or os.environ.get("OCR_BENCH_NO_PIN"):
         return info
     node = gpu_numa_node(local)
@@ -836,7 +852,9 @@ def main(argv=None):
                 for tf in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("pmc_traffic.json")), reverse=True):
                     # HBM bytes per launch from the rocprofv3 --pmc passes (tools/pmc_traffic.py), latest round first
                     pm = json.load(open(os.path.join(ROOT, "profiles", tf)))
-                    if pm.get("kernel") == name or pm.get("kernel_group") == list(dom_key[:3]):
+                    # (only an entry that names THIS kernel group and whose traced duration agrees with the bench's: tools/pmc_traffic.py
+                    # labels the trace's top (symbol, grid) group and records whether the two durations agree)
+                    if pm.get("kernel") == name and pm.get("durations_agree_within_10pct", False):
                         traffic = pm["traffic_bytes_per_launch"]
                         traffic_src = "profiles/%s: rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs, gfx950 corrections) of the same bench command on this kernel (%s), not this run" % (tf, pm.get("launch", ""))
                         break
@@ -890,7 +908,16 @@ def main(argv=None):
                                                        % (dn.get("flops", 0.0) / max(1.0, dn.get("algorithmic_bytes", 1.0)), RIDGE))
                 small = [v for v in survey.values() if v["count"] and v["ms"] / v["count"] < 0.25]
                 step["launches_below_250us"] = {"launches": sum(v["count"] for v in small), "ms": sum(v["ms"] for v in small)}
+                # every launch against ITS binding roof: sum over launches of max(flops / matrix peak, bytes / HBM peak) over the
+                # kernel time - an HBM-bound layer is not punished with a matrix-peak denominator
+                roof_ms = sum(max(v["flops"] / (FP32_MFMA_PEAK_TFLOPS * 1e12), v["bytes"] / (HBM_PEAK_GBS * 1e9)) * 1e3 for v in survey.values())
+                step["layer_roof_ms"] = roof_ms
+                step["layer_roof_frac"] = roof_ms / tot if tot else 0.0
                 out["roofline"] = dict(out.get("roofline") or {}, step=step)
+                # the same figures as top-level scalars of `roofline` (the driver's summary keeps scalars)
+                out["roofline"].update({"step_frac": step["frac"], "step_ms": step["ms"], "step_layer_roof_frac": step["layer_roof_frac"],
+                                        "det_conv_stack_frac": step.get("det_conv_stack", {}).get("frac_mfma"),
+                                        "small_launch_ms": step["launches_below_250us"]["ms"], "kernel_ms_sum": tot})
                 if os.environ.get("OCR_BENCH_KERNEL_TABLE"):
                     with open(os.environ["OCR_BENCH_KERNEL_TABLE"], "w") as f:
                         f.write("# groups (kernel instantiation x shape), one step, single chain\n")

@@ -407,7 +407,7 @@ bool RecStage::create(const RecConfig& cfg, std::string& err, int& code) {
   // "fp32" = the bit-exact contract, "fp16" = f16 matrix products with f32 accumulation (Net::load); "int8" is refused
   if (cfg.precision != "fp32" && cfg.precision != "fp16") { err = "precision '" + cfg.precision + "' is not implemented (fp32 | fp16)"; return false; }
   if (cfg.batch_num < 1 || cfg.img_h < 1 || cfg.img_w < 1) { err = "bad rec shape"; return false; }
-  if (cfg.sort_mode != OCR_SORT_STD && cfg.sort_mode != OCR_SORT_STABLE) { err = "unknown sort_mode"; return false; }
+  if (cfg.sort_mode != OCR_SORT_STD && cfg.sort_mode != OCR_SORT_STABLE && cfg.sort_mode != OCR_SORT_MSVC_STRICT) { err = "unknown sort_mode"; return false; }
   code = ocr_rt_init(cfg.device);
   if (code) { err = ocr_last_error(); return false; }
   code = OCR_ERR_MODEL;
@@ -466,7 +466,19 @@ int RecStage::run_lines(const std::vector<LineSrc>& lines, const std::vector<int
     std::vector<size_t> indices(sn);
     for (int i = 0; i < sn; ++i) indices[i] = i;
     // Utility::argsort is std::sort: the order of equal ratios is the host library's
-    if (cfg_.sort_mode == OCR_SORT_STABLE) std::stable_sort(indices.begin(), indices.end(), [&](size_t a, size_t b) { return width_list[a] < width_list[b]; });
+    if (cfg_.sort_mode == OCR_SORT_MSVC_STRICT && sn > 32) {
+      // MSVC's std::sort is an insertion sort (ties in input order) only up to _ISORT_MAX = 32 elements; its quicksort's order
+      // of ties beyond that is not restated here - refuse rather than answer in an order the reference's build may not produce
+      std::vector<float> sorted_w(width_list);
+      std::sort(sorted_w.begin(), sorted_w.end());
+      if (std::adjacent_find(sorted_w.begin(), sorted_w.end()) != sorted_w.end()) {
+        char msg[200];
+        snprintf(msg, sizeof msg, "sort_mode OCR_SORT_MSVC_STRICT: image %d has %d crops (> 32) with tied w/h ratios - MSVC's std::sort order of ties beyond 32 elements is not restated (use OCR_SORT_STABLE or OCR_SORT_STD)", (int)sg, sn);
+        err = msg;
+        return OCR_ERR_ARG;
+      }
+    }
+    if (cfg_.sort_mode != OCR_SORT_STD) std::stable_sort(indices.begin(), indices.end(), [&](size_t a, size_t b) { return width_list[a] < width_list[b]; });
     else std::sort(indices.begin(), indices.end(), [&](size_t a, size_t b) { return width_list[a] < width_list[b]; });
     for (int beg = 0; beg < sn; beg += cfg_.batch_num) {
       const int end = std::min(sn, beg + cfg_.batch_num);

@@ -122,10 +122,14 @@ typedef struct ocr_rec_cfg {
   /* how lines with EQUAL w/h ratio are ordered before the batches of rec_batch_num are cut (Utility::argsort is
    * std::sort, utility.cpp:192-203, whose order of ties is the host library's): OCR_SORT_STD = this build's
    * std::sort (libstdc++ introsort, what the oracle runs); OCR_SORT_STABLE = ties keep their input order, which is
-   * what MSVC's std::sort (the reference's toolchain) does for up to 32 crops (insertion sort below _ISORT_MAX). */
+   * what MSVC's std::sort (the reference's toolchain) does for up to 32 crops (insertion sort below _ISORT_MAX).  Beyond 32
+   * crops of one image MSVC's quicksort order of ties is NOT restated: OCR_SORT_STABLE keeps input order there too (a
+   * documented choice, not MSVC's order); OCR_SORT_MSVC_STRICT is OCR_SORT_STABLE that REFUSES such an image - more than 32
+   * crops of which two have equal ratios - with OCR_ERR_ARG and a message naming the image, instead of answering in an
+   * order the reference's build may not produce. */
   int sort_mode;
 } ocr_rec_cfg;
-enum { OCR_SORT_STD = 0, OCR_SORT_STABLE = 1 };
+enum { OCR_SORT_STD = 0, OCR_SORT_STABLE = 1, OCR_SORT_MSVC_STRICT = 2 };
 void ocr_rec_cfg_default(ocr_rec_cfg* cfg);
 typedef struct ocr_rec ocr_rec;
 int ocr_rec_create(const ocr_rec_cfg* cfg, ocr_rec** out);

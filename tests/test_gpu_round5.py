@@ -58,3 +58,69 @@ def test_lab_fold_stage_lists_on_the_device(pkg, built):
             checked += 1
         assert checked >= 50
         g.close()
+
+
+def _word_key(w):
+    return (tuple(np.asarray(w["box"]).reshape(-1).tolist()), tuple(np.asarray(w["ids"]).tolist()))
+
+
+def test_cv_compat_blast_radius_through_the_full_pipeline(pkg, built, card):
+    """what a wrong `cv_compat` default would cost.  The SAME inputs run through the full pipeline
+    (det + cls + rec) under OpenCV's 4.5.1 fillPoly rule (45) and the 4.5.2+ rule (410, the default): every run equals the
+    oracle under ITS rule on sampled images, and the number of words that differ between the two rules is recorded
+    (gpurun_out/r5_cv_compat_blast_radius.json when that directory is writable) - for the benchmark batch (configs[1]: 64
+    images whose probability maps are the protocol's clean rectangles), for mixed-size configs[2] samples, and for the
+    reference's own test image through the detector network (synthetic weights: a noisy map with boxes near box_thresh)."""
+    import json
+    from pipeline import Pipeline, DetCfg
+    from synth_data import cfg2_sample, cfg3_item
+    kw = dict(rec_batch_num=16, rec_img_h=48, rec_img_w=320, enable_cls=True)
+    s2 = [cfg2_sample(i) for i in range(64)]
+    s3 = [cfg3_item(i) for i in range(8)]
+    report = {}
+    runs = {}
+    for compat in (45, 410):
+        pg = pkg.Pipe(limit_side_len=960, cv_compat=compat, **kw)
+        po = Pipeline(det_cfg=DetCfg(limit_side_len=960, cv_compat=compat), **kw)
+        pg.stage(0, [s[0] for s in s2], [s[1] for s in s2])
+        a = pg.run_staged(0)
+        pg.stage(1, [s[0] for s in s3], [s[1] for s in s3])
+        b = pg.run_staged(1)
+        c = pg.run([card])
+        for got, (img, prob) in ((a[5], s2[5]), (a[40], s2[40]), (b[2], s3[2])):
+            w = po.process(img, prob)["words"]
+            assert [_word_key(x) for x in got] == [_word_key(x) for x in w], compat
+        w = po.process(card)["words"]
+        assert [_word_key(x) for x in c[0]] == [_word_key(x) for x in w], compat
+        runs[compat] = {"configs1_64_images": a, "configs2_8_images": b, "reference_card_through_det_net": c}
+        pg.close()
+    for name in runs[45]:
+        x, y = runs[45][name], runs[410][name]
+        n45 = sum(len(i) for i in x)
+        n410 = sum(len(i) for i in y)
+        diff = sum(len(set(map(_word_key, i)) ^ set(map(_word_key, j))) for i, j in zip(x, y))
+        report[name] = {"words_under_45": n45, "words_under_410": n410, "words_in_one_result_only": diff}
+    assert report["configs1_64_images"]["words_under_410"] == 64 * 32
+    out = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out) and os.access(out, os.W_OK):
+        json.dump(report, open(os.path.join(out, "r5_cv_compat_blast_radius.json"), "w"), indent=1)
+    print("cv_compat blast radius:", json.dumps(report))
+
+
+def test_strict_msvc_sort_mode_refuses_what_is_not_restated(pkg, built):
+    """VERDICT r4 item 9b: MSVC's std::sort keeps ties in input order only up to 32 elements.  OCR_SORT_STABLE keeps input
+    order beyond that too (documented: not MSVC's order there); OCR_SORT_MSVC_STRICT refuses an image with more than 32
+    crops of which two have equal ratios - an error with a message, not a silently different batch composition - and
+    equals OCR_SORT_STABLE wherever MSVC's order IS restated (up to 32 crops, or no ties)."""
+    rs = np.random.RandomState(32)
+    tied40 = [rs.randint(0, 255, [(24, 96), (12, 48), (30, 200)][i % 3] + (3,)).astype(np.uint8) for i in range(40)]
+    untied40 = [rs.randint(0, 255, (24, 60 + 3 * i, 3)).astype(np.uint8) for i in range(40)]
+    kw = dict(rec_batch_num=16, rec_img_h=48, rec_img_w=320)
+    strict, stable = pkg.Rec(sort_mode=2, **kw), pkg.Rec(sort_mode=1, **kw)
+    with pytest.raises(pkg.OcrError, match="MSVC"):
+        strict.run(tied40)
+    for crops in (tied40[:32], untied40):
+        (ta, sa), (tb, sb) = strict.run(crops), stable.run(crops)
+        assert all(np.array_equal(x, y) for x, y in zip(ta, tb)) and list(sa) == list(sb)
+    strict.close()
+    stable.close()

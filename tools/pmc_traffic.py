@@ -64,6 +64,7 @@ def main():
     out = {
         "kernel": bench["kernel"] if bench else "%s grid %d" % (sym, grid),
         "launch": "%s, grid %d threads (%d workgroups of 256)" % (sym.split("(")[0], grid, grid // 256),
+        "kernel_group": [sym.split("(")[0], grid],
         "share_of_kernel_time_in_trace": dur / total,
         "next_groups": [{"launch": "%s grid %d" % (k[0].split("(")[0], k[1]), "share": v[0] / total, "dispatches": v[1]} for k, v in ranked[1:4]],
         "dispatches_in_kernel_trace": n,
@@ -94,6 +95,10 @@ def main():
         out["traffic_over_algorithmic"] = (rd + wb) / alg
         out["bench_avg_launch_ms"] = bench["avg_launch_ms"]
         out["durations_agree_within_10pct"] = abs(bench["avg_launch_ms"] * 1e3 - out["avg_duration_us_kernel_trace"]) <= 0.10 * out["avg_duration_us_kernel_trace"]
+        if not out["durations_agree_within_10pct"]:
+            # the trace's top (symbol, grid) group is not provably the bench's roofline kernel: do not lend it that name
+            # (bench.py attributes `traffic` by name and skips entries whose durations disagree)
+            out["kernel"] = "%s grid %d (NOT matched to the bench line's kernel %r: average durations differ by more than 10 %%)" % (sym.split("(")[0], grid, bench["kernel"])
         out["bench_frac"] = bench["frac"]
         if bench["bound"] == "mfma":
             out["frac_from_kernel_trace"] = bench["algorithmic_flops_per_launch"] / (out["avg_duration_us_kernel_trace"] * 1e-6) / 1e12 / bench["peak"]

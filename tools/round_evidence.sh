@@ -1,6 +1,7 @@
 #!/bin/bash
-# On the GPU box: the round's evidence in one call - full GPU suite, the three bench lines, kernel table, rocprofv3
-# kernel trace + PMC passes.  tools/round_evidence.sh <tag>  ->  gpurun_out/ev_<tag>/
+# On the GPU box: the round's evidence, first call - full GPU suite, the three bench lines, kernel table, service load.
+# (second call: tools/round_profiles.sh <tag> - rocprofv3 kernel trace + PMC passes, fp32 and fp16, and the micro-benchmarks;
+# one gpurun call is limited to 20 minutes).  tools/round_evidence.sh <tag>  ->  gpurun_out/ev_<tag>/
 T=${1:-r3}
 O=gpurun_out/ev_$T
 mkdir -p $O
@@ -8,11 +9,6 @@ python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; tail -3 $O/pytest.log
 OCR_BENCH_KERNEL_TABLE=$O/kernel_table.txt python bench.py > $O/bench_cfg2.json 2> $O/bench_cfg2.err || exit 1
 python bench.py --config cfg3 --no-cpu-baseline > $O/bench_cfg3.json 2> $O/bench_cfg3.err || exit 1
 python bench.py --config cfg4 --images 2560 --no-cpu-baseline > $O/bench_cfg4.json 2> $O/bench_cfg4.err || exit 1
-tools/run_profile.sh $T > $O/profile.log 2>&1
-python tools/prof_summary.py gpurun_out/prof_$T > $O/prof_summary.txt 2>&1
-python tools/pmc_traffic.py gpurun_out/prof_$T $O/pmc_traffic.json $O/bench_cfg2.json dw_lds_kernel,dw_conv_kernel > $O/pmc_traffic.log 2>&1
-python tools/hbm_table.py gpurun_out/prof_$T > $O/kernel_hbm_table.txt 2>&1
-cp gpurun_out/prof_$T/trace/*/*kernel_stats.csv $O/ 2>/dev/null
 python tools/service_load.py jpeg 64 12 > $O/service_load.jsonl 2> $O/service_load.err
 for c in cfg2 cfg3 cfg4; do python - $O/bench_$c.json <<'P'
 import json,sys

@@ -18,3 +18,4 @@ python -c "import json,sys; json.dump([json.loads(l) for l in open(sys.argv[1]) 
 ls $O/fp16/*kernel_stats.csv > /dev/null 2>&1 && cp $O/fp16/*kernel_stats.csv profiles/${R}_rocprofv3_kernel_stats_fp16.csv
 [ -f $O/micro.txt ] && cp $O/micro.txt profiles/${R}_micro.txt
 [ -f gpurun_out/r5_cv_compat_blast_radius.json ] && cp gpurun_out/r5_cv_compat_blast_radius.json profiles/${R}_cv_compat_blast_radius.json
+[ -f $O/fp16_check.txt ] && cp $O/fp16_check.txt profiles/${R}_fp16_check.txt

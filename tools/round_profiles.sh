@@ -16,6 +16,7 @@ tools/run_profile.sh $T fp16 > $O/profile_fp16.log 2>&1
 python tools/pmc_traffic.py gpurun_out/prof_${T}_fp16 $O/pmc_traffic_fp16.json $O/bench_fp16.json > $O/pmc_traffic_fp16.log 2>&1
 python tools/hbm_table.py gpurun_out/prof_${T}_fp16 > $O/kernel_hbm_table_fp16.txt 2>&1
 mkdir -p $O/fp16; cp gpurun_out/prof_${T}_fp16/trace/*/*kernel_stats.csv $O/fp16/ 2>/dev/null
+python tools/fp16_check.py 8 > $O/fp16_check.txt 2>&1
 # micro-benchmarks (binaries built in the container, tools/micro/): what the matrix pipe sustains on data, the vendor GEMM on the
 # big 1x1 convs' shapes, the fused 5x5 block in both forms with its shader clock
 ( cd tools/micro

@@ -846,7 +846,8 @@ def main(argv=None):
                 r = groups.get(dom_key) or max(groups.values(), key=lambda g: g["ms"])
                 name = group_label(dom_key, r)
                 avg_ms = r["ms"] / max(1, r["count"])
-                roof = roof_of(r["flops"], r["bytes"], r["ms"])
+                mpeak = FP32_MFMA_PEAK_TFLOPS if args.precision == "fp32" else FP16_MFMA_PEAK_TFLOPS  # (an exploration run in fp16: that mode's roofs)
+                roof = roof_of(r["flops"], r["bytes"], r["ms"], mpeak)
                 tflops, gbps, hbm_bound = roof["tflops"], roof["hbm_GBps_algorithmic"], roof["bound"] == "hbm"
                 traffic, traffic_src = None, None
                 for tf in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("pmc_traffic.json")), reverse=True):
@@ -859,9 +860,9 @@ def main(argv=None):
                         traffic_src = "profiles/%s: rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs, gfx950 corrections) of the same bench command on this kernel (%s), not this run" % (tf, pm.get("launch", ""))
                         break
                 out["roofline"] = {"kernel": name, "measured_in": "single_chain", "bound": "hbm" if hbm_bound else "mfma",
-                                   "achieved": gbps if hbm_bound else tflops, "peak": HBM_PEAK_GBS if hbm_bound else FP32_MFMA_PEAK_TFLOPS,
+                                   "achieved": gbps if hbm_bound else tflops, "peak": HBM_PEAK_GBS if hbm_bound else mpeak,
                                    "unit": "GB/s" if hbm_bound else "TFLOP/s",
-                                   "frac": gbps / HBM_PEAK_GBS if hbm_bound else tflops / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+                                   "frac": gbps / HBM_PEAK_GBS if hbm_bound else tflops / mpeak, "traffic": traffic, "traffic_source": traffic_src,
                                    "avg_launch_ms": avg_ms, "launches": r["count"], "launches_per_step": r["count"] / max(1, single_chain["steps"]),
                                    "dominant_by": "time per step summed over the launches of one kernel instantiation on one shape (the "
                                                   "grouping of a rocprofv3 kernel summary by symbol and grid)",

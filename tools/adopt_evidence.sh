@@ -6,7 +6,7 @@ cp $O/bench_cfg2.json profiles/${R}_bench_line.json
 cp $O/bench_cfg3.json profiles/${R}_bench_cfg3.json
 cp $O/bench_cfg4.json profiles/${R}_bench_cfg4.json
 cp $O/kernel_table.txt profiles/${R}_kernel_table.txt
-cp $O/*kernel_stats.csv profiles/${R}_rocprofv3_kernel_stats.csv
+cp "$(ls -t $O/*kernel_stats.csv | head -1)" profiles/${R}_rocprofv3_kernel_stats.csv
 cp $O/pmc_traffic.json profiles/${R}_pmc_traffic.json
 cp $O/kernel_hbm_table.txt profiles/${R}_kernel_hbm_table.txt
 cp $O/prof_summary.txt profiles/${R}_prof_summary_bench_steps2.txt
@@ -15,7 +15,7 @@ python -c "import json,sys; json.dump([json.loads(l) for l in open(sys.argv[1]) 
 [ -f $O/bench_fp16.json ] && cp $O/bench_fp16.json profiles/${R}_bench_fp16.json
 [ -f $O/pmc_traffic_fp16.json ] && cp $O/pmc_traffic_fp16.json profiles/${R}_pmc_traffic_fp16.json
 [ -f $O/kernel_hbm_table_fp16.txt ] && cp $O/kernel_hbm_table_fp16.txt profiles/${R}_kernel_hbm_table_fp16.txt
-ls $O/fp16/*kernel_stats.csv > /dev/null 2>&1 && cp $O/fp16/*kernel_stats.csv profiles/${R}_rocprofv3_kernel_stats_fp16.csv
+ls $O/fp16/*kernel_stats.csv > /dev/null 2>&1 && cp "$(ls -t $O/fp16/*kernel_stats.csv | head -1)" profiles/${R}_rocprofv3_kernel_stats_fp16.csv
 [ -f $O/micro.txt ] && cp $O/micro.txt profiles/${R}_micro.txt
 [ -f gpurun_out/r5_cv_compat_blast_radius.json ] && cp gpurun_out/r5_cv_compat_blast_radius.json profiles/${R}_cv_compat_blast_radius.json
 [ -f $O/fp16_check.txt ] && cp $O/fp16_check.txt profiles/${R}_fp16_check.txt

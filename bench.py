@@ -688,6 +688,32 @@ def main(argv=None):
         if cfg == "cfg3":
             pipe.stage(0, img_list, prob_list)   # slot 0 as the resident batch again (the gather step below re-runs it)
 
+    # ---- two batches in flight on the ONE handle (ocr_pipe_run_device_on): chain c of the handle runs whole batches c, c + 2,
+    # ... while the other chain runs the batches between - consecutive batches overlap (the reference's shape: a pool of
+    # workers on one GPU, each on its own request) instead of the two halves of one batch.  EXACTLY `steps` batches of 64 in the
+    # timed region, barrier + sync on both sides; a batch's latency is what it is with one chain.  An extra key.
+    in_flight = None
+    if not stub and cfg == "cfg2" and world == 1 and not args.no_two_workers and hasattr(pipe, "run_device_on"):
+        import threading
+        for c_ in (0, 1):
+            pipe.run_device_on(c_, d_imgs, H, W, BATCH, d_probs, collect=False)
+        fsteps = max(2, args.steps)
+        def flight(c_):
+            for _ in range(c_, fsteps, 2):
+                pipe.run_device_on(c_, d_imgs, H, W, BATCH, d_probs, collect=False)
+        ths = [threading.Thread(target=flight, args=(c_,)) for c_ in (0, 1)]
+        sync()
+        t0f = time.perf_counter()
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+        sync()
+        elf = time.perf_counter() - t0f
+        in_flight = {"value": batch * fsteps / elf, "unit": "images/sec", "ms_per_step": elf * 1e3 / fsteps, "steps": fsteps,
+                     "what": "the same handle with two batches in flight: chain 0 runs batches 0, 2, 4, ... and chain 1 batches 1, 3, 5, ... "
+                             "(ocr_pipe_run_device_on, two host threads), %d batches of %d images in the timed region" % (fsteps, batch)}
+
     # ---- two pipeline workers sharing the GPU (the reference's pool maps worker i -> GPU i mod n, gpu_worker_pool.cpp:
     # 46-59, so a device may serve several workers): each worker has its own ocr_pipe, streams and arenas and runs the
     # same resident batch `steps` times; while one worker is in its latency-bound phases (det post-processing, cls,
@@ -828,6 +854,8 @@ def main(argv=None):
             out["single_chain"] = single_chain
         if host_in:
             out["host_input"] = host_in
+        if in_flight:
+            out["two_batches_in_flight"] = in_flight
         if two_workers:
             out["two_workers_per_gpu"] = two_workers
         if fp16:

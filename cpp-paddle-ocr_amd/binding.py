@@ -387,7 +387,7 @@ class ocr_word(C.Structure):
 
 
 EXPORTS += ["ocr_pipe_cfg_default", "ocr_pipe_create", "ocr_pipe_destroy", "ocr_pipe_run", "ocr_pipe_run_device",
-            "ocr_pipe_stage", "ocr_pipe_slot_probs", "ocr_pipe_run_staged", "ocr_pipe_stage_jpeg", "ocr_jpeg_decode",
+            "ocr_pipe_stage", "ocr_pipe_slot_probs", "ocr_pipe_run_staged", "ocr_pipe_run_device_on", "ocr_pipe_run_staged_on", "ocr_pipe_stage_jpeg", "ocr_jpeg_decode",
             "ocr_pipe_label", "ocr_pipe_det_shape", "ocr_pipe_stats", "ocr_pipe_timing", "ocr_pipe_timing_filter", "ocr_pipe_timing_report", "ocr_dev_alloc",
             "ocr_dev_free", "ocr_dev_upload", "ocr_dev_download", "ocr_dev_sync", "ocr_rotate_crop", "ocr_rotate_crop_shape", "ocr_rotate180_rois"]
 
@@ -406,6 +406,9 @@ def _pipe_protos(L):
     L.ocr_pipe_stage.argtypes = [vp, C.c_int, C.POINTER(ocr_img), C.c_int]
     L.ocr_pipe_slot_probs.argtypes = [vp, C.c_int, vp, C.c_int]
     L.ocr_pipe_run_staged.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp, vp, C.c_int, C.POINTER(C.c_double)]
+    L.ocr_pipe_run_staged_on.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, vp, vp, vp, C.c_int, C.POINTER(C.c_double)]
+    L.ocr_pipe_run_device_on.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, vp, vp, vp, C.c_int,
+                                         C.POINTER(C.c_double)]
     L.ocr_pipe_label.argtypes = [vp, C.c_int]
     L.ocr_pipe_label.restype = C.c_char_p
     L.ocr_pipe_det_shape.argtypes = [vp, C.c_int, C.c_int, ip, ip]
@@ -600,6 +603,36 @@ class Pipe:
                                         words, self._cap_words, off.ctypes.data, nw.ctypes.data, ids.ctypes.data,
                                         self._cap_ids, self.times))
         return self._collect(count, words, ids, off, nw) if collect else int(nw.sum())
+
+    # ---- two batches in flight (ocr_pipe_run_device_on / ocr_pipe_run_staged_on): the whole batch on one chain; calls on
+    # different chains may run concurrently from different threads - result buffers and stage times are per chain
+    def _chain_bufs(self, chain, count):
+        if not hasattr(self, "_cb"):
+            self._cb = {}
+        cw, ci = count * 1000, count * 1000 * 64
+        b = self._cb.get(chain)
+        if b is None or b[2] < cw:
+            b = self._cb[chain] = ((ocr_word * cw)(), np.zeros(ci, np.int32), cw, ci, (C.c_double * 3)())
+        return b
+
+    def run_device_on(self, chain, dev_imgs, rows, cols, count, dev_prob=None, collect=True):
+        words, ids, cw, ci, times = self._chain_bufs(chain, count)
+        off = np.zeros(count, np.int32)
+        nw = np.zeros(count, np.int32)
+        check(lib().ocr_pipe_run_device_on(self.h, chain, dev_imgs.ptr, rows, cols, count, dev_prob.ptr if dev_prob else None,
+                                           words, cw, off.ctypes.data, nw.ctypes.data, ids.ctypes.data, ci, times))
+        return self._collect(count, words, ids, off, nw) if collect else int(nw.sum())
+
+    def run_staged_on(self, chain, slot, collect=True):
+        count = self._staged_n[slot]
+        words, ids, cw, ci, times = self._chain_bufs(chain, count)
+        off = np.zeros(count, np.int32)
+        nw = np.zeros(count, np.int32)
+        check(lib().ocr_pipe_run_staged_on(self.h, chain, slot, words, cw, off.ctypes.data, nw.ctypes.data, ids.ctypes.data, ci, times))
+        return self._collect(count, words, ids, off, nw) if collect else int(nw.sum())
+
+    def chain_times(self, chain):
+        return list(self._cb[chain][4]) if hasattr(self, "_cb") and chain in self._cb else None
 
     def det_shape(self, rows, cols):
         a, b = C.c_int(), C.c_int()

@@ -423,6 +423,18 @@ bool OCR_L(launch_conv_mfma_mt2)(const ConvArgs& a, const Epilogue& ep, int nt, 
   OCR_H16_TWIN(a.half, launch_conv_mfma_mt2_h16(a, ep, nt, s))
   const bool tap1 = a.KH == 1 && a.KW == 1 && a.PH == 0 && a.PW == 0 && a.OH == a.H && a.OW == a.W;
   if (!tap1 || a.out_mode != OUT_C8I || a.NTtot % nt) return false;
+#ifndef OCR_TU_H16
+  // THREE pixel tiles per wave (a weight fragment feeds three MFMAs, 216 registers, no spill) for the launches that stay
+  // many times larger than the chip: rec ops 25 / 30 / 32 / 34 at production batch sizes.  conv_time, 983 040 rows, seeded
+  // data: 480 -> 480 3.524 -> 3.464 ms (gated 3.697 -> 3.638), 240 -> 480 gated 2.123 -> 2.063; five column tiles x two pixel
+  // tiles spill 13 registers and gain half of that.  Same chains: bit-identical.
+  if (nt == 3 && ((a.M + 383) / 384) * (long)(a.NTtot / nt) >= 4096) {
+    dim3 g3((unsigned)(((a.M + 383) / 384) * (a.NTtot / nt)));
+    if (a.gate) hipLaunchKernelGGL((conv_mfma_mt_kernel<3, 3, true>), g3, dim3(256), 0, s, a, ep);
+    else hipLaunchKernelGGL((conv_mfma_mt_kernel<3, 3, false>), g3, dim3(256), 0, s, a, ep);
+    return true;
+  }
+#endif
   dim3 grid((unsigned)(((a.M + 255) / 256) * (a.NTtot / nt)));
 #ifdef OCR_TU_H16
   // an even number of octets and the paired fragment image at hand: the 32x32x16 form (OCR_MFMA_X16=0: the 32x32x8 one, A/B)

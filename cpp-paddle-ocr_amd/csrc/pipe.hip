@@ -402,6 +402,12 @@ struct ocr_pipe {
   hipStream_t copy_stream = nullptr;
   JpegScratch jpeg;
   DevBuf<uint8_t> work;  // the requests' clones (OCRRequest copies the Mat, ocr_worker.h:28-29): cls rotates in place on them
+  // Two batches in flight (round 5, ocr_pipe_run_device_on / ocr_pipe_run_staged_on): a call that names a chain runs its WHOLE
+  // batch on that chain's worker, with a clone buffer of the chain's own; calls on different chains may run concurrently from
+  // different host threads - chain 0 on batch k while chain 1 is on batch k+1 - so that consecutive batches overlap instead of
+  // the two halves of one (no join per batch: what two free-running handles gained over one, without the second handle)
+  DevBuf<uint8_t> work_chain[4];
+  PipeWorker* worker(int c) { return c == 0 ? &w0 : (c >= 1 && c <= (int)extra.size() ? extra[c - 1].get() : nullptr); }
 
   ~ocr_pipe() { if (copy_stream) (void)hipStreamDestroy(copy_stream); }
 
@@ -573,6 +579,9 @@ struct ocr_pipe {
       }
     };
     std::vector<std::thread> th;
+    // (round 5: starting chain c a few milliseconds late - 3 .. 24 ms - so that one chain's matrix-bound kernels meet the other's
+    // HBM-bound ones costs 2-11 %: 1282 -> 1257 / 1218 / 1177 / 1155 / 1140 img/s; what two free-running handles gain comes from
+    // batches overlapping batches, not from a phase offset inside one)
     for (int c = 1; c < nchains; ++c) th.emplace_back([&, c]() { (void)rt_set_device(device); chain(c); });
     chain(0);
     for (auto& x : th) x.join();
@@ -598,17 +607,22 @@ struct ocr_pipe {
   }
 
   // run a staged slot: wait for its upload, clone, run, hand the results back in the caller's order
-  int run_slot(int si, ocr_word* words, int cap_words, int* word_off, int* nwords, int32_t* ids, int cap_ids, double times[3]) {
+  int run_slot(int si, ocr_word* words, int cap_words, int* word_off, int* nwords, int32_t* ids, int cap_ids, double times[3], int chain = -1) {
     StageSlot& S = slots[si];
     if (!S.staged || S.imgs.empty()) return fail(OCR_ERR_ARG, "nothing staged in this slot");
     std::string err;
-    if (hipStreamWaitEvent(w0.det.stream(), S.ready, 0) != hipSuccess) return fail(OCR_ERR_DEVICE, "hipStreamWaitEvent failed");
-    if (!work.ensure(S.bytes + 256, err)) return fail(OCR_ERR_DEVICE, err);
-    if (hipMemcpyAsync(work.p, S.dev.p, S.bytes, hipMemcpyDeviceToDevice, w0.det.stream()) != hipSuccess) return fail(OCR_ERR_DEVICE, "clone failed");
+    PipeWorker* one = chain >= 0 ? worker(chain) : nullptr;  // the whole batch on one chain (two batches in flight), or split over all
+    if (chain >= 0 && !one) return fail(OCR_ERR_ARG, "no such chain (0 <= chain < phases)");
+    PipeWorker& first = one ? *one : w0;
+    DevBuf<uint8_t>& clone = one ? work_chain[chain] : work;
+    if (hipStreamWaitEvent(first.det.stream(), S.ready, 0) != hipSuccess) return fail(OCR_ERR_DEVICE, "hipStreamWaitEvent failed");
+    if (!clone.ensure(S.bytes + 256, err)) return fail(OCR_ERR_DEVICE, err);
+    if (hipMemcpyAsync(clone.p, S.dev.p, S.bytes, hipMemcpyDeviceToDevice, first.det.stream()) != hipSuccess) return fail(OCR_ERR_DEVICE, "clone failed");
     double t[3] = {0, 0, 0};
     std::vector<std::vector<ocr_word>> W;
     std::vector<std::vector<int32_t>> I;
-    const int rc = run_images(work.p, S.imgs, S.groups, S.has_probs ? S.probs.p : nullptr, W, I, t, err);
+    const int rc = one ? one->run_images(clone.p, S.imgs, S.groups, S.has_probs ? S.probs.p : nullptr, W, I, t, err)
+                       : run_images(clone.p, S.imgs, S.groups, S.has_probs ? S.probs.p : nullptr, W, I, t, err);
     if (rc) return fail(rc, err);
     if (times) { times[0] = t[0]; times[1] = t[1]; times[2] = t[2]; }
     const int count = (int)S.imgs.size();
@@ -707,28 +721,41 @@ int ocr_pipe_create(const ocr_pipe_cfg* c, ocr_pipe** out) {
 }
 void ocr_pipe_destroy(ocr_pipe* h) { delete h; }
 
-int ocr_pipe_run_device(ocr_pipe* h, const void* dev_bgr, int rows, int cols, int count, const float* dev_prob, ocr_word* words,
-                        int cap_words, int* word_off, int* nwords, int32_t* ids, int cap_ids, double times[3]) {
+static int pipe_run_device(ocr_pipe* h, int chain, const void* dev_bgr, int rows, int cols, int count, const float* dev_prob, ocr_word* words,
+                           int cap_words, int* word_off, int* nwords, int32_t* ids, int cap_ids, double times[3]) {
   if (!h || !dev_bgr || rows <= 0 || cols <= 0 || count < 1 || !words || !word_off || !nwords || !ids)
     return fail(OCR_ERR_ARG, "bad argument");
   CAPI_HIP(rt_set_device(h->device));
+  PipeWorker* one = chain >= 0 ? h->worker(chain) : nullptr;
+  if (chain >= 0 && !one) return fail(OCR_ERR_ARG, "no such chain (0 <= chain < phases)");
+  PipeWorker& first = one ? *one : h->w0;
+  DevBuf<uint8_t>& clone = one ? h->work_chain[chain] : h->work;
   double t[3] = {0, 0, 0};
   std::vector<std::vector<ocr_word>> W;
   std::vector<std::vector<int32_t>> I;
   std::string err;
   // the request's clone (OCRRequest copies the Mat, ocr_worker.h:28-29): cls rotation is in place on it
   const size_t img_bytes = (size_t)rows * cols * 3, bytes = img_bytes * count;
-  if (!h->work.ensure(bytes + 256, err)) return fail(OCR_ERR_DEVICE, err);
-  CAPI_HIP(hipMemcpyAsync(h->work.p, dev_bgr, bytes, hipMemcpyDeviceToDevice, h->w0.det.stream()));
+  if (!clone.ensure(bytes + 256, err)) return fail(OCR_ERR_DEVICE, err);
+  CAPI_HIP(hipMemcpyAsync(clone.p, dev_bgr, bytes, hipMemcpyDeviceToDevice, first.det.stream()));
   std::vector<StageSlot::Img> imgs(count);
   for (int i = 0; i < count; ++i) imgs[i] = {rows, cols, i, img_bytes * i, 0};
   const std::vector<StageSlot::Group> groups = {{rows, cols, 0, count, 0, 0}};
-  const int rc = h->run_images(h->work.p, imgs, groups, dev_prob, W, I, t, err);
+  const int rc = one ? one->run_images(clone.p, imgs, groups, dev_prob, W, I, t, err) : h->run_images(clone.p, imgs, groups, dev_prob, W, I, t, err);
   if (rc) return fail(rc, err);
   if (times) { times[0] = t[0]; times[1] = t[1]; times[2] = t[2]; }
   std::vector<int> order(count);
   for (int i = 0; i < count; ++i) order[i] = i;
   return emit(W, I, order, words, cap_words, word_off, nwords, ids, cap_ids);
+}
+int ocr_pipe_run_device(ocr_pipe* h, const void* dev_bgr, int rows, int cols, int count, const float* dev_prob, ocr_word* words,
+                        int cap_words, int* word_off, int* nwords, int32_t* ids, int cap_ids, double times[3]) {
+  return pipe_run_device(h, -1, dev_bgr, rows, cols, count, dev_prob, words, cap_words, word_off, nwords, ids, cap_ids, times);
+}
+int ocr_pipe_run_device_on(ocr_pipe* h, int chain, const void* dev_bgr, int rows, int cols, int count, const float* dev_prob,
+                           ocr_word* words, int cap_words, int* word_off, int* nwords, int32_t* ids, int cap_ids, double times[3]) {
+  if (chain < 0) return fail(OCR_ERR_ARG, "no such chain (0 <= chain < phases)");
+  return pipe_run_device(h, chain, dev_bgr, rows, cols, count, dev_prob, words, cap_words, word_off, nwords, ids, cap_ids, times);
 }
 
 int ocr_pipe_stage(ocr_pipe* h, int slot, const ocr_img* imgs, int count) {
@@ -765,6 +792,13 @@ int ocr_pipe_run_staged(ocr_pipe* h, int slot, ocr_word* words, int cap_words, i
   if (!h || slot < 0 || slot > 1 || !words || !word_off || !nwords || !ids) return fail(OCR_ERR_ARG, "bad argument");
   CAPI_HIP(rt_set_device(h->device));
   return h->run_slot(slot, words, cap_words, word_off, nwords, ids, cap_ids, times);
+}
+
+int ocr_pipe_run_staged_on(ocr_pipe* h, int chain, int slot, ocr_word* words, int cap_words, int* word_off, int* nwords, int32_t* ids,
+                           int cap_ids, double times[3]) {
+  if (!h || chain < 0 || slot < 0 || slot > 1 || !words || !word_off || !nwords || !ids) return fail(OCR_ERR_ARG, "bad argument");
+  CAPI_HIP(rt_set_device(h->device));
+  return h->run_slot(slot, words, cap_words, word_off, nwords, ids, cap_ids, times, chain);
 }
 
 int ocr_pipe_run(ocr_pipe* h, const ocr_img* imgs, int count, ocr_word* words, int cap_words, int* word_off, int* nwords,

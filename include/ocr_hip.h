@@ -199,6 +199,18 @@ int ocr_pipe_stage(ocr_pipe* h, int slot, const ocr_img* imgs, int count);
 int ocr_pipe_slot_probs(ocr_pipe* h, int slot, const float* const* probs, int count);
 int ocr_pipe_run_staged(ocr_pipe* h, int slot, ocr_word* words, int cap_words, int* word_off, int* nwords, int32_t* ids,
                         int cap_ids, double times[3]);
+/* Two batches in flight on one handle (round 5).  The reference's throughput shape is a pool of workers on one GPU
+ * (/root/reference/src/gpu_worker_pool.cpp:12-16 pins every worker to GPU 0, ocr_worker.cpp:213-311 runs one request at a
+ * time per worker): consecutive requests overlap, the halves of one request do not.  The `_on` forms run the WHOLE batch on
+ * ONE of the handle's chains (0 <= chain < ocr_pipe_cfg.phases, default 2; own stage objects, streams, arenas and clone
+ * buffer per chain) instead of cutting it over all of them.  Calls that name different chains - and, for the staged form,
+ * different slots - may run concurrently from different host threads: chain 0 works on batch k while chain 1 works on
+ * batch k+1, each call returning its own batch's results.  Results are those of the plain calls (per image, independent
+ * of the batch composition).  Two calls on the SAME chain (or slot) at once are the caller's error. */
+int ocr_pipe_run_device_on(ocr_pipe* h, int chain, const void* dev_bgr, int rows, int cols, int count, const float* dev_prob,
+                           ocr_word* words, int cap_words, int* word_off, int* nwords, int32_t* ids, int cap_ids, double times[3]);
+int ocr_pipe_run_staged_on(ocr_pipe* h, int chain, int slot, ocr_word* words, int cap_words, int* word_off, int* nwords, int32_t* ids,
+                           int cap_ids, double times[3]);
 /* JPEG inputs with the pixel half of the decoder on the device: the caller runs the
  * bit-serial entropy decoding (host/jpeg_decode.h, Decoder::decode_coefficients) and hands over quantised DCT
  * coefficients; dequantisation, IDCT, chroma upsampling and colour conversion run on the copy stream straight into

@@ -124,3 +124,50 @@ def test_strict_msvc_sort_mode_refuses_what_is_not_restated(pkg, built):
         assert all(np.array_equal(x, y) for x, y in zip(ta, tb)) and list(sa) == list(sb)
     strict.close()
     stable.close()
+
+
+def test_two_batches_in_flight_on_one_handle(pkg, built):
+    """ocr_pipe_run_device_on / ocr_pipe_run_staged_on: the whole batch on ONE chain, two chains driven concurrently by two host
+    threads with DIFFERENT batches (consecutive requests overlapping, the worker pool's shape on one handle).  Every batch's
+    words equal what the plain call returns for it - and the plain call equals the oracle elsewhere in this suite."""
+    import threading
+    from synth_data import cfg2_sample, cfg3_item
+    kw = dict(rec_batch_num=16, rec_img_h=48, rec_img_w=320, enable_cls=True, limit_side_len=960)
+    a = [cfg2_sample(i) for i in range(6)]
+    b = [cfg3_item(i) for i in range(5)]
+    p = pkg.Pipe(**kw)
+    p.stage(0, [s[0] for s in a], [s[1] for s in a])
+    want_a = p.run_staged(0)
+    p.stage(1, [s[0] for s in b], [s[1] for s in b])
+    want_b = p.run_staged(1)
+    got, errs = {}, []
+
+    def work(chain, slot, reps):
+        try:
+            for _ in range(reps):
+                got[chain] = p.run_staged_on(chain, slot)
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    ths = [threading.Thread(target=work, args=(0, 0, 4)), threading.Thread(target=work, args=(1, 1, 5))]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errs, errs
+    for g, w in ((got[0], want_a), (got[1], want_b)):
+        assert len(g) == len(w)
+        for x, y in zip(g, w):
+            assert [_word_key(i) for i in x] == [_word_key(i) for i in y]
+    # resident inputs, the benchmark's call
+    imgs, probs = np.stack([s[0] for s in a]), np.stack([s[1] for s in a])
+    d_i, d_p = pkg.DevArray(imgs), pkg.DevArray(probs)
+    plain = p.run_device(d_i, 960, 960, 6, d_p)
+    for chain in (0, 1):
+        on = p.run_device_on(chain, d_i, 960, 960, 6, d_p)
+        assert [[_word_key(i) for i in x] for x in on] == [[_word_key(i) for i in x] for x in plain]
+    with pytest.raises(pkg.OcrError):
+        p.run_device_on(2, d_i, 960, 960, 6, d_p)
+    d_i.free()
+    d_p.free()
+    p.close()

@@ -423,18 +423,9 @@ bool OCR_L(launch_conv_mfma_mt2)(const ConvArgs& a, const Epilogue& ep, int nt, 
   OCR_H16_TWIN(a.half, launch_conv_mfma_mt2_h16(a, ep, nt, s))
   const bool tap1 = a.KH == 1 && a.KW == 1 && a.PH == 0 && a.PW == 0 && a.OH == a.H && a.OW == a.W;
   if (!tap1 || a.out_mode != OUT_C8I || a.NTtot % nt) return false;
-#ifndef OCR_TU_H16
-  // THREE pixel tiles per wave (a weight fragment feeds three MFMAs, 216 registers, no spill) for the launches that stay
-  // many times larger than the chip: rec ops 25 / 30 / 32 / 34 at production batch sizes.  conv_time, 983 040 rows, seeded
-  // data: 480 -> 480 3.524 -> 3.464 ms (gated 3.697 -> 3.638), 240 -> 480 gated 2.123 -> 2.063; five column tiles x two pixel
-  // tiles spill 13 registers and gain half of that.  Same chains: bit-identical.
-  if (nt == 3 && ((a.M + 383) / 384) * (long)(a.NTtot / nt) >= 4096) {
-    dim3 g3((unsigned)(((a.M + 383) / 384) * (a.NTtot / nt)));
-    if (a.gate) hipLaunchKernelGGL((conv_mfma_mt_kernel<3, 3, true>), g3, dim3(256), 0, s, a, ep);
-    else hipLaunchKernelGGL((conv_mfma_mt_kernel<3, 3, false>), g3, dim3(256), 0, s, a, ep);
-    return true;
-  }
-#endif
+  // (round 5: THREE pixel tiles per wave - a fragment feeding three MFMAs, 216 registers - measured 1.7 % faster alone
+  // (conv_time, 983 040 x 480 -> 480: 3.524 -> 3.464 ms) and 1-3 % SLOWER in the step on the same box, alternating runs
+  // (op 30: 3.97 -> 4.08 ms): not kept.  Five column tiles x two pixel tiles spill 13 registers.)
   dim3 grid((unsigned)(((a.M + 255) / 256) * (a.NTtot / nt)));
 #ifdef OCR_TU_H16
   // an even number of octets and the paired fragment image at hand: the 32x32x16 form (OCR_MFMA_X16=0: the 32x32x8 one, A/B)
@@ -1006,17 +997,19 @@ __global__ void __launch_bounds__(TH * 32, 2) conv3x3_c24_kernel(const ConvArgs 
   floatx4 acc[3];
 #pragma unroll
   for (int g = 0; g < 3; ++g) acc[g] = floatx4{0.f, 0.f, 0.f, 0.f};
-  // operands of a whole octet (weights from L1, pixels from LDS) are fetched one octet ahead of their 24 instructions
-  struct Oct { float4 w0, w1, lo, hi; };
-  auto load_oct = [&](Oct& o, const float* src_tap, const float4* w_tap, int c) __attribute__((always_inline)) {
-    o.w0 = w_tap[c * 64];
-    o.w1 = w_tap[c * 64 + 1];
+  // operands of an octet: the pixel's eight channels from LDS one octet ahead of their 24 instructions, the weights - 110 KB per
+  // conv, an L2 round trip per fetch once four waves per SIMD-pair stream them through a 16 KB L1 - TWO octets ahead (round 5:
+  // a ring of three weight pairs; one octet = 24 instructions x ~20 clocks is shorter than that round trip)
+  struct Wt { float4 w0, w1; };
+  struct Px { float4 lo, hi; };
+  auto load_w = [&](Wt& o, const float4* w_tap, int c) __attribute__((always_inline)) { o.w0 = w_tap[c * 64]; o.w1 = w_tap[c * 64 + 1]; };
+  auto load_p = [&](Px& o, const float* src_tap, int c) __attribute__((always_inline)) {
     o.lo = *(const float4*)(src_tap + c * 8);
     o.hi = *(const float4*)(src_tap + c * 8 + 4);
   };
-  auto mul_oct = [&](const Oct& o) __attribute__((always_inline)) {
+  auto mul_oct = [&](const Wt& w, const Px& o) __attribute__((always_inline)) {
     const float xs[8] = {o.lo.x, o.hi.x, o.lo.y, o.hi.y, o.lo.z, o.hi.z, o.lo.w, o.hi.w};  // logical channels 8c .. 8c+7
-    const float ws[8] = {o.w0.x, o.w0.y, o.w0.z, o.w0.w, o.w1.x, o.w1.y, o.w1.z, o.w1.w};
+    const float ws[8] = {w.w0.x, w.w0.y, w.w0.z, w.w0.w, w.w1.x, w.w1.y, w.w1.z, w.w1.w};
     if (chh == 0) {  // wave-uniform (a scalar branch): blocks 0..2 or 3..5 of the weight register
 #pragma unroll
       for (int s = 0; s < 8; ++s) {
@@ -1033,9 +1026,12 @@ __global__ void __launch_bounds__(TH * 32, 2) conv3x3_c24_kernel(const ConvArgs 
       }
     }
   };
-  static_assert(C8 % 2 == 0, "octets are walked in pairs");
-  Oct oA, oB;
-  load_oct(oA, sA, wl, 0);
+  static_assert(C8 % 6 == 0, "octets are walked in groups of six (two pixel sets x three weight sets)");
+  Wt wr[3];
+  Px pr[2];
+  load_w(wr[0], wl, 0);
+  load_w(wr[1], wl, 1);
+  load_p(pr[0], sA, 0);
 #pragma unroll 1
   for (int tap = 0; tap < 9; ++tap) {   // the 12 octets of a tap unrolled: every operand address is base + constant
     const int ky = tap / 3, kx = tap - ky * 3;
@@ -1045,21 +1041,16 @@ __global__ void __launch_bounds__(TH * 32, 2) conv3x3_c24_kernel(const ConvArgs 
     const float* nsrc = sA + (nky * RW + nkx) * STRIDE;
     const float4* nwt = wl + (long)nt * C8 * 64;
 #pragma unroll
-    for (int c = 0; c < C8; c += 2) {
-      load_oct(oB, src, wt, c + 1);
+    for (int c = 0; c < C8; ++c) {
+      // weights of octet c + 2, pixels of octet c + 1 (into the sets octet c - 1 has left), then octet c's instructions
+      if (c + 2 < C8) load_w(wr[(c + 2) % 3], wt, c + 2);
+      else load_w(wr[(c + 2) % 3], nwt, c + 2 - C8);
+      if (c + 1 < C8) load_p(pr[(c + 1) % 2], src, c + 1);
+      else load_p(pr[(c + 1) % 2], nsrc, 0);
 #ifndef OCR_C24_NOSCHED
       __builtin_amdgcn_sched_barrier(0);
 #endif
-      mul_oct(oA);
-#ifndef OCR_C24_NOSCHED
-      __builtin_amdgcn_sched_barrier(0);
-#endif
-      if (c + 2 < C8) load_oct(oA, src, wt, c + 2);
-      else load_oct(oA, nsrc, nwt, 0);
-#ifndef OCR_C24_NOSCHED
-      __builtin_amdgcn_sched_barrier(0);
-#endif
-      mul_oct(oB);
+      mul_oct(wr[c % 3], pr[c % 2]);
 #ifndef OCR_C24_NOSCHED
       __builtin_amdgcn_sched_barrier(0);
 #endif

@@ -473,6 +473,15 @@ def main(argv=None):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # stdout carries ONE JSON line (rank 0).  Libraries write to file descriptor 1 behind Python's back (RCCL prints a version
+    # banner there when its communicator comes up): from here on fd 1 IS stderr, and the line goes to the saved descriptor.
+    sys.stdout.flush()
+    line_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit_line(obj):
+        os.write(line_fd, (json.dumps(obj) + "\n").encode())
+
     if args.gpus != world:
         sys.exit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
     G = load_gather()
@@ -793,7 +802,7 @@ def main(argv=None):
                   "verified_images_per_rank": vcount, "matches_single_rank": bool(flag.item() == 1)}
         if not gather["matches_single_rank"]:
             if rank == 0:
-                print(json.dumps({"error": "gathered records differ from single-rank results", "gather": gather}), flush=True)
+                emit_line({"error": "gathered records differ from single-rank results", "gather": gather})
             dist.barrier()
             dist.destroy_process_group()
             sys.exit(3)
@@ -972,7 +981,7 @@ def main(argv=None):
                        "placement": placement}
         if n_ranks == 1 and not args.no_cpu_baseline and not stub and cfg == "cfg2":
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out), flush=True)
+        emit_line(out)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -31,6 +31,7 @@ const RtOptions& rt_options() {
     o.conv_c24 = !off("OCR_CONV_C24");
     { const char* e = getenv("OCR_DW_LDS"); o.dw_lds = !(e && e[0] == '0'); }
     { const char* e = getenv("OCR_DWPW2"); o.dwpw2 = !(e && e[0] == '0'); }
+    { const char* e = getenv("OCR_XDW"); o.xdw = !(e && e[0] == '0'); }
     { const char* e = getenv("OCR_MFMA_X16"); o.mfma_x16 = !(e && e[0] == '0'); }
     { const char* e = getenv("OCR_ATTN_LINE"); o.attn_line = !(e && e[0] == '0'); }
     o.dwpw_items = (int)num("OCR_DWPW_ITEMS", 32);

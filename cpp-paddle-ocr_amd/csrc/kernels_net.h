@@ -178,6 +178,23 @@ struct DwPwArgs {
 bool lab_from_epilogue(const Epilogue& ep, LabEp& out);
 // false: the shape is not instantiated (the caller launches the unfused pair).  query = true only asks.
 bool launch_dwpw(const DwPwArgs& a, hipStream_t s, bool query = false);
+
+// ---- expand 1x1 conv (BN, hard-swish) -> depthwise 5x5 (BN, hard-swish) of one small map per workgroup (kernels_xdw.hip):
+// the expanded tensor exists only in LDS.  f32 contract, uniform batches.
+struct XdwArgs {
+  const float* x;       // [N, Hin, W, Cs_in] C8I: the 1x1 conv's input
+  const float* wfrag;   // the 1x1 conv's fragment image ([Cs_in / 8][NTtot][64][4])
+  const float* e_sc;    // the 1x1 conv's BN scale / shift, [Cs_e] physical order
+  const float* e_sh;
+  const float* dw_w;    // [K*K][Cs_e] physical order
+  const float* d_sc;    // the depthwise conv's BN scale / shift
+  const float* d_sh;
+  float* out;           // [N, Hout, W, Cs_e] C8I: the depthwise conv's output
+  float* part;          // null, or the pool's row sums [N * Hout][Cs_e] (as DwArgs::rowsum)
+  int N, Hin, Hout, W, Cs_in, Cs_e, NTtot, K, SH, SW, PH, PW;
+};
+// false: the shape is not instantiated (the caller launches the two ops).  query = true only asks.
+bool launch_xdw(const XdwArgs& a, hipStream_t s, bool query = false);
 // rows of the pixel tile (16 columns wide) of the instance that takes this shape; 0: the shape is not on the fused path
 int dwpw_tile_rows(const DwPwArgs& a);
 int dw_patch_r(int OH, int K);  // output rows per thread the depthwise launcher will pick (ragged batch: OH = the lowest sample)

@@ -867,6 +867,32 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths, const i
       }
     }
   }
+  // Expand 1x1 conv -> depthwise 5x5 on small maps (kernels_xdw.hip; the classifier's inverted-residual blocks): the conv
+  // runs inside the depthwise op's launch, chunk by chunk into LDS; its output tensor never exists.  Uniform batches, f32.
+  std::vector<int> xdw_of(nops, -1);  // depthwise op -> the 1x1 conv it absorbs
+  if (fuse && !rag && !half_ && rt_options().xdw) {
+    auto bn_hswish = [](const std::vector<PlanStage>& ep) {
+      return ep.size() == 2 && ep[0].kind == EP_BN && ep[1].kind == EP_ACT && ep[1].act == ACT_HSWISH;
+    };
+    for (int oi = 0; oi + 1 < nops; ++oi) {
+      const PlanOp& c = plan_.ops[oi];
+      const bool one = c.kind == PlanOp::CONV && c.kh == 1 && c.kw == 1 && c.sh == 1 && c.sw == 1 && c.ph == 0 && c.pw == 0 && c.cin != 3;
+      if (!one || gate_src[oi] >= 0 || c.out == out_tid_ || uses[c.out] != 1 || T[c.in].plain || T[c.out].plain || !bn_hswish(c.ep)) continue;
+      for (int oj = oi + 1; oj < nops; ++oj) {
+        const PlanOp& d = plan_.ops[oj];
+        if (d.kind == PlanOp::CONCAT || d.in != c.out) continue;
+        if (d.kind == PlanOp::DW && d.kh == d.kw && bn_hswish(d.ep) && !T[d.out].plain && dev_vec("frag:" + c.w)) {
+          XdwArgs q{};
+          q.N = T[c.in].n; q.Hin = T[c.in].h; q.Hout = T[d.out].h; q.W = T[c.in].w; q.Cs_in = T[c.in].cs; q.Cs_e = T[d.out].cs;
+          const int tiles = (T[c.out].cs + 31) / 32, nt = conv_nt_for(tiles);
+          q.NTtot = (tiles + nt - 1) / nt * nt;
+          q.K = d.kh; q.SH = d.sh; q.SW = d.sw; q.PH = d.ph; q.PW = d.pw;
+          if (T[d.out].w == T[c.in].w && T[c.out].cs == T[d.out].cs && launch_xdw(q, nullptr, true)) xdw_of[oj] = oi;
+        }
+        break;
+      }
+    }
+  }
   // Depthwise -> pointwise fusion (kernels_dwpw.hip): a depthwise conv whose only reader is an ungated 1x1 conv runs
   // inside that conv's launch; its output tensor never exists.
   std::vector<int> dwpw_of(nops, -1);  // conv op -> the depthwise op it absorbs
@@ -904,6 +930,7 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths, const i
   }
   std::vector<char> fused_dw(nops, 0);
   for (int oj = 0; oj < nops; ++oj) if (dwpw_of[oj] >= 0) fused_dw[dwpw_of[oj]] = 1;
+  for (int oj = 0; oj < nops; ++oj) if (xdw_of[oj] >= 0) fused_dw[xdw_of[oj]] = 1;  // (the absorbed 1x1 conv: no launch, no tensor)
   // ---- depthwise conv -> global average pool (the SE blocks): the conv leaves the pool's row sums (its first pass, a
   // second full read of the tensor otherwise) while it writes the tensor; only the column pass stays a launch.  Needs
   // enough bands (a thread owns whole rows then) to fill the chip.
@@ -913,6 +940,7 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths, const i
       const PlanOp& g = plan_.ops[oi];
       const PlanOp& d = plan_.ops[oi - 1];
       if (g.kind != PlanOp::GAP || d.kind != PlanOp::DW || d.out != g.in || fused_dw[oi - 1] || d.out == out_tid_) continue;
+      if (xdw_of[oi - 1] >= 0) { dw_rowsum[oi - 1] = 1; continue; }  // (that kernel leaves the row sums whatever the size and stride)
       const TensorDesc& o = T[d.out];
       const int rows_per_band = (rag ? min_h(o) : o.h) >= 2 ? 2 : 1;
       const long threads = (rag ? rows_of(o) / rows_per_band : (long)o.n * ((o.h + rows_per_band - 1) / rows_per_band)) * (o.cs >> 2);
@@ -1040,6 +1068,7 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths, const i
     if (oi > 0 && rse_first[oi - 1]) continue;  // the pool after a row-sum pass reads gap_part_, not the conv's tensor
     if (gate_src[oi] >= 0) { last[gate_src[oi]] = oi; last[gate_tid[oi]] = oi; }
     else if (dwpw_of[oi] >= 0) last[plan_.ops[dwpw_of[oi]].in] = oi;
+    else if (xdw_of[oi] >= 0) last[plan_.ops[xdw_of[oi]].in] = oi;
     else if (dbhead_of[oi] >= 0) last[plan_.ops[dbhead_of[oi]].in] = oi;
     else if (cat_of[oi] >= 0) { for (int t : plan_.ops[cat_of[oi]].ins) last[t] = oi; }
     else if (op.in >= 0) last[op.in] = oi;
@@ -1365,6 +1394,30 @@ bool Net::bind(int N, int H, int W, std::string& err, const int* widths, const i
         }
       } break;
       case PlanOp::DW: {
+        if (xdw_of[oi] >= 0) {  // the expand 1x1 conv in front of it runs inside this launch (kernels_xdw.hip)
+          const PlanOp& c = plan_.ops[xdw_of[oi]];
+          const TensorDesc& xin = T[c.in];
+          Epilogue ce, de;
+          if (!build_epilogue(c, ce, true, err) || !build_epilogue(op, de, false, err)) return false;
+          XdwArgs a{};
+          a.x = arena_ + xin.offset; a.wfrag = dev_vec("frag:" + c.w);
+          a.e_sc = ce.st[0].v0; a.e_sh = ce.st[0].v1;
+          a.dw_w = dev_vec("dw:" + op.w); a.d_sc = de.st[0].v0; a.d_sh = de.st[0].v1;
+          a.out = optr; a.part = dw_rowsum[oi] ? gap_part_ : nullptr;
+          a.N = xin.n; a.Hin = xin.h; a.Hout = o.h; a.W = xin.w; a.Cs_in = xin.cs; a.Cs_e = o.cs;
+          const int tiles = (T[c.out].cs + 31) / 32, nt = conv_nt_for(tiles);
+          a.NTtot = (tiles + nt - 1) / nt * nt;
+          a.K = op.kh; a.SH = op.sh; a.SW = op.sw; a.PH = op.ph; a.PW = op.pw;
+          if (!a.wfrag || !a.e_sc || !a.e_sh || !a.dw_w || !a.d_sc || !a.d_sh) { err = "expand -> depthwise block: a parameter image is missing for " + c.w; return false; }
+          snprintf(nm, sizeof nm, "%s.%02d.xdw%dx%d_%d_%d_s%d%d%s", plan_.name.c_str(), oi, op.kh, op.kw, c.cin, op.c, op.sh, op.sw, dw_rowsum[oi] ? "_rowsum" : "");
+          L.name = nm;
+          L.flops = 2.0 * xin.pixels() * c.cin * c.cout + 2.0 * o.pixels() * op.kh * op.kw * op.c;
+          L.bytes = EB(xin) * xin.pixels() * c.cin + EB(o) * o.pixels() * op.c;
+          L.fn = [this, a](hipStream_t s) {
+            if (!launch_xdw(a, s)) this->launch_error_ = "launch_xdw: shape accepted at bind time was refused at launch";
+          };
+          break;
+        }
         const TensorDesc& in = T[op.in];
         Epilogue ep;
         if (!build_epilogue(op, ep, false, err)) return false;

@@ -20,6 +20,7 @@ struct RtOptions {
   bool attn_line = true;       // OCR_ATTN_LINE=0: attention as a wave per (line, head) also for lines of <= 64 tokens (A/B)
   bool mfma_x16 = true;        // OCR_MFMA_X16=0: precision "fp16" keeps v_mfma_f32_32x32x8_f16 in the big 1x1 convs (A/B)
   bool dw_lds = true;          // OCR_DW_LDS=0: the low-map 5x5 depthwise layers keep dw_conv_kernel (A/B; results are identical)
+  bool xdw = true;             // OCR_XDW=0: the classifier's expand 1x1 -> depthwise 5x5 pairs as two launches (A/B; kernels_xdw.hip)
   bool dwpw2 = true;           // OCR_DWPW2=0: the fused depthwise blocks keep their first form (registers -> LDS) where the LDS-DMA form exists (A/B)
   int dwpw_items = 32;         // OCR_DWPW_ITEMS=n
   int dwpw_force_upw = 0;      // OCR_DWPW_FORCE_UPW=n (tests)

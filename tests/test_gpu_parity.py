@@ -110,7 +110,7 @@ print("AB OK")
 
 # every switch of csrc/rt_options.h (INTEGRATION.md's table), each in the setting that is NOT the default
 _AB_ENVS = [{"OCR_FUSE": "0"}, {"OCR_FUSE_GAP_MIN": "1", "OCR_CONV_MT2": "force"}, {"OCR_CONV_SMALL_NT": "0", "OCR_CONV_MT2": "0", "OCR_CONV_C24": "0"},
-            {"OCR_DW_LDS": "0", "OCR_ATTN_LINE": "0"}, {"OCR_DWPW2": "0"}, {"OCR_DWPW2": "0", "OCR_DWPW_FORCE_UPW": "3"},
+            {"OCR_DW_LDS": "0", "OCR_ATTN_LINE": "0"}, {"OCR_XDW": "0"}, {"OCR_DWPW2": "0"}, {"OCR_DWPW2": "0", "OCR_DWPW_FORCE_UPW": "3"},
             {"OCR_DWPW_T4": "thin"}, {"OCR_DWPW_ITEMS": "7"}, {"OCR_DWPW_ITEMS": "1"}, {"OCR_DWPW_FORCE_UPW": "3"},
             {"OCR_DWPW_FORCE_UPW": "16", "OCR_DWPW_T4": "thin"}]
 

@@ -234,10 +234,22 @@ __device__ __forceinline__ void conv_finish_nyx(const ConvArgs& a, long m, int& 
   }
 }
 
+// xp (OUT_C8I only): a per-wave LDS tile of OCR_XP_FLOATS floats.  A lane owns a PIXEL, so its stores are 16-byte pieces of 32
+// different lines per instruction (a pixel's row is Cs_out * 4 bytes); with the tile the wave's 32 x 32 block of column tile t
+// goes through LDS and leaves as whole 128-byte lines - lane = (pixel 8 i + lane / 8, quad lane % 8), eight pixels per
+// instruction.  The wave's 32 pixels must be consecutive (m = first + lane % 32) and every lane must arrive here.  Thin layers
+// are bound by exactly this (tools/micro/conv_time.hip, round 5: 12 -> 96 at 3.7 M pixels 0.454 -> 0.355 ms with the line
+// pattern, 16 -> 32 0.426 -> 0.297, 48 -> 96 0.681 -> 0.565; 480 -> 480 unchanged).
+#define OCR_XP_STRIDE 36
+#define OCR_XP_FLOATS (32 * OCR_XP_STRIDE)
 template <int NT, int MODE, bool H16 = false>
 __device__ __forceinline__ void conv_finish(const ConvArgs& a, const Epilogue& ep, floatx16 (&acc)[NT], int nt0, long m, int hb,
-                                            const float* spar, const int sstride = NT * 32) {
-  if (m >= a.M) return;
+                                            const float* spar, const int sstride = NT * 32, float* xp = nullptr) {
+  const long m_lane = m;
+  if (m >= a.M) {
+    if (MODE != OUT_C8I || !xp) return;
+    m = a.M - 1;  // (past the end: the last pixel again - the lane takes part in the transposed stores below)
+  }
   // the pixel's (n, y, x) is only needed by the deconv scatter and by the per-image / upsampled
   // stages: decoded there (two integer divisions), not in front of every K loop
   int n = 0, y = 0, x = 0;
@@ -417,6 +429,44 @@ __device__ __forceinline__ void conv_finish(const ConvArgs& a, const Epilogue& e
     return;
   }
   // ---- stores, after the last load
+  if constexpr (MODE == OUT_C8I) {
+    if (xp) {
+      const int lane = threadIdx.x & 63;
+      const long m_first = m_lane - (lane & 31);
+      float* const mine = xp + (lane & 31) * OCR_XP_STRIDE + 4 * hb;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        if (!exists(32 * t)) break;  // uniform
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          constexpr_rel(t, g);
+          if (!exists(rel)) continue;
+          float4 w = make_float4(acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]);
+          if (a.Cout != a.Cs_out) {  // keep the pad channels of the octet layout at zero
+            const int pc = r0 + rel;
+            if (c8i_logical(pc) >= a.Cout) w.x = 0.f;
+            if (c8i_logical(pc + 1) >= a.Cout) w.y = 0.f;
+            if (c8i_logical(pc + 2) >= a.Cout) w.z = 0.f;
+            if (c8i_logical(pc + 3) >= a.Cout) w.w = 0.f;
+          }
+          *(float4*)(mine + 8 * g) = w;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int q = lane & 7, col = c0 + 32 * t + 4 * q;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int px = 8 * i + (lane >> 3);
+          const long mm = m_first + px;
+          if (mm < a.M && col < a.ColsStore) st4<H16>(a.out, mm * a.Cs_out + col, *(const float4*)(xp + px * OCR_XP_STRIDE + 4 * q));
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+      return;
+    }
+  }
   float* obase = a.out + (H16 && MODE != OUT_PLAIN ? 0 : opix);  // (f16 tensors are addressed by element index below)
 #pragma unroll
   for (int t = 0; t < NT; ++t) {

@@ -274,7 +274,25 @@ __global__ void __launch_bounds__(256, LB) dwpw2_kernel(const DwPwArgs a) {
         ocr_f2 th = ocr_f2{acc[t][4 * g + 2], acc[t][4 * g + 3]} + ocr_f2{b.z, b.w};
         tl = ocr_hsw6_2(tl); th = ocr_hsw6_2(th);
         tl = __builtin_elementwise_fma(tl, S6, A1); th = __builtin_elementwise_fma(th, S6, A1);
+#ifdef OCR_DWPW_LINESTORE  // development probe (WRONG results): the same quads, each instruction as 1 KB of whole lines
+        {
+          const long e0 = ((long)__builtin_amdgcn_readfirstlane((int)(oidx >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)oidx);
+          const long tot = c.M * c.Cs_out - 4;
+          long e = e0 + ((t * 4 + g) * 64 + lane) * 4;
+          e = e < tot ? e : e - tot;
+          if (nt0 * 32 + 32 * t + 8 * g < c.ColsStore) st4<false>(c.out, e & ~3l, make_float4(tl.x, tl.y, th.x, th.y));
+        }
+#elif defined(OCR_DWPW_SEG64)  // development probe (WRONG results): the address pattern of 64-byte segments per pixel (pairs of lanes swapped)
+        {
+          const long onb = __shfl_xor(oidx, 1);  // the neighbour pixel's element index
+          const bool odd = p & 1, second = g & 1;
+          const long base = (odd != second) ? onb : oidx;
+          const int gq = (g & ~1) + (odd ? 1 : 0);
+          if (nt0 * 32 + 32 * t + 8 * g < c.ColsStore && inside) st4<false>(c.out, base + 32 * t + 8 * gq, make_float4(tl.x, tl.y, th.x, th.y));
+        }
+#else
         if (inside && nt0 * 32 + 32 * t + 8 * g < c.ColsStore) st4<false>(c.out, oidx + 32 * t + 8 * g, make_float4(tl.x, tl.y, th.x, th.y));
+#endif
         acc[t][4 * g] = 0.f; acc[t][4 * g + 1] = 0.f; acc[t][4 * g + 2] = 0.f; acc[t][4 * g + 3] = 0.f;
       }
     }

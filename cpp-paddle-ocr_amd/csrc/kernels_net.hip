@@ -54,6 +54,7 @@ __global__ void __launch_bounds__(256, (NT <= 3 ? 4 : 3)) conv_mfma_kernel(const
   const long m0 = ((long)(lb / groups) * 4 + wave) * 32;
   const int nt0 = (int)(lb % groups) * NT;
   __shared__ float s_par[OCR_MAX_EP * 2 * NT * 32];
+  __shared__ float s_xp[MODE == OUT_C8I ? 4 * OCR_XP_FLOATS : 1];  // the waves' store tiles (conv_finish, conv_device.h)
   conv_stage_params<NT>(a, ep, nt0, s_par);
   if (m0 >= a.M) return;
   const long m = m0 + p;
@@ -190,7 +191,7 @@ __global__ void __launch_bounds__(256, (NT <= 3 ? 4 : 3)) conv_mfma_kernel(const
   CONV_PROBE(2);
 
   // ---- epilogue: lane owns output column j (one channel), 16 rows ----
-  conv_finish<NT, MODE, HALF>(a, ep, acc, nt0, m, h, s_par);
+  conv_finish<NT, MODE, HALF>(a, ep, acc, nt0, m, h, s_par, NT * 32, MODE == OUT_C8I ? s_xp + wave * OCR_XP_FLOATS : nullptr);
   CONV_PROBE(3);
 }
 

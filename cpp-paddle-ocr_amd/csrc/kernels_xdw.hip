@@ -16,9 +16,11 @@
 //                             chain.  Rows above the map come first in that order and leave the accumulator at +0: skipped;
 //                             rows below it are issued as fma(0, w, acc) (they turn a -0 accumulator into +0 exactly as the
 //                             padded chain does).  BN + hard-swish, 16-byte stores to the depthwise conv's output tensor
-//   row sums                  (when the SE pool follows) after the last chunk one thread per (output row, channel quad) adds
-//                             the row left to right from the tensor the workgroup has just written (L2), the pool's first
-//                             pass in the contract's order - what dw_conv_kernel's ROWSUM form leaves in gap_part_.
+//   row sums                  (when the SE pool follows) the wave writes its outputs back into its own quad's part of R and
+//                             twelve lanes add a (row, channel) each left to right: the pool's first pass in the contract's
+//                             order - what dw_conv_kernel's ROWSUM form leaves in gap_part_ - without a second read of the
+//                             tensor.  (Storing the chunk from there as whole lines - all threads, lane = pixel x quad, one
+//                             more barrier per chunk - measured 5 % SLOWER than the lanes' own 16-byte stores: not kept.)
 // Arithmetic per value is the two launches' (same chains, same epilogue sequences): bit-identical
 // (tests/test_gpu_parity.py; OCR_XDW=0 in the A/B test).  f32 contract only.
 #include <hip/hip_runtime.h>

@@ -53,7 +53,8 @@ struct DwPw2Geom {
   static constexpr int BUF = NI * 1024, W_OFF = NREG * 1024;               // bytes per buffer; the weights' offset in it
   static constexpr int NB = NB_;  // region buffers: 3 = the DMA runs two items ahead, 2 = one (where three do not leave room for two workgroups per CU)
   static constexpr int NIT = (TH / PR) * TW * Q;
-  static constexpr size_t lds_bytes(int nttot) { return (size_t)NB * BUF + 2 * (size_t)OP_TILE * 4 + (size_t)nttot * 32 * 4; }
+  // xp: the waves' store tiles (conv_device.h, OCR_XP_FLOATS each) behind the parameters
+  static constexpr size_t lds_bytes(int nttot, bool xp) { return (size_t)NB * BUF + 2 * (size_t)OP_TILE * 4 + (size_t)nttot * 32 * 4 + (xp ? (size_t)4 * OCR_XP_FLOATS * 4 : 0); }
   // stored column of region column c, and the quad swizzle of a stored column
   static __host__ __device__ constexpr int colp(int c) { return SW == 2 ? (c & 1) * (IWP / 2) + (c >> 1) : c; }
   static __host__ __device__ constexpr int swz(int cp) { return Q == 4 ? (cp >> 2) & 3 : (cp >> 1) & 7; }
@@ -62,7 +63,7 @@ struct DwPw2Geom {
 #ifdef OCR_DWPW_CLKRATE
 __device__ unsigned long long ocr_dwpw_clkrate[2];
 #endif
-template <int K, int SH, int SW, int CK, bool WIDE, int NT, int NBUF, int TD, int LB, bool RAG>
+template <int K, int SH, int SW, int CK, bool WIDE, int NT, int NBUF, int TD, int LB, bool RAG, bool XP>
 __global__ void __launch_bounds__(256, LB) dwpw2_kernel(const DwPwArgs a) {
   using G_ = DwPw2Geom<K, SH, SW, CK, WIDE, NBUF>;
   constexpr int WC = G_::WC, TW = G_::TW, TH = G_::TH, PR = G_::PR, IWP = G_::IWP, IH = G_::IH, IW = G_::IW;
@@ -78,6 +79,7 @@ __global__ void __launch_bounds__(256, LB) dwpw2_kernel(const DwPwArgs a) {
   char* const s_reg = (char*)s_dwpw4;                   // [NB][BUF]  region | weights + bias | idle slots
   float* const s_op = (float*)(s_reg + NB * BUF);       // [2][P][S]  depthwise result = MFMA pixel operand
   float* const s_par = s_op + 2 * OP_TILE;              // [NTtot*32] the 1x1 conv's bias, every column
+  float* const s_xp = s_par + a.c.NTtot * 32;                // XP: [4 waves][OCR_XP_FLOATS] store tiles
   const unsigned lds0 = (unsigned)(size_t)s_reg;        // LDS byte address of the buffers
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -261,6 +263,22 @@ __global__ void __launch_bounds__(256, LB) dwpw2_kernel(const DwPwArgs a) {
     const float* sp = s_par + r0;
     const long oidx = (m_pos.out_pix(a) + (long)oy * own + ox) * c.Cs_out + r0;  // element index of the lane's first column
     const ocr_f2 S6 = {ps6, ps6}, A1 = {pa1, pa1};
+    // XP: the wave's 32 x 32 block of a column tile leaves through its LDS tile as whole 128-byte lines (conv_device.h,
+    // conv_finish): store i of a lane is quad q = lane % 8 of pixel 8 i + lane / 8 of the wave's two tile rows.  Worth 4-8 %
+    // on the layers with one column tile, nothing beyond (kernels_dwpw.hip, launch_two).
+    float* const xt = s_xp + wave * OCR_XP_FLOATS;
+    long xo[4];
+    bool xin[4];
+    const int xq = lane & 7;
+    if constexpr (XP) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int xpix = wp * 32 + 8 * i + (lane >> 3);
+        const int yy = m_pos.ty * TH + xpix / TW, xx = m_pos.tx * TW + (xpix & (TW - 1));
+        xin[i] = yy < m_pos.out_h(a) && xx < own;
+        xo[i] = (m_pos.out_pix(a) + (long)yy * own + xx) * c.Cs_out + nt0 * 32 + 4 * xq;
+      }
+    }
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       float4 bias4[4];
@@ -274,26 +292,21 @@ __global__ void __launch_bounds__(256, LB) dwpw2_kernel(const DwPwArgs a) {
         ocr_f2 th = ocr_f2{acc[t][4 * g + 2], acc[t][4 * g + 3]} + ocr_f2{b.z, b.w};
         tl = ocr_hsw6_2(tl); th = ocr_hsw6_2(th);
         tl = __builtin_elementwise_fma(tl, S6, A1); th = __builtin_elementwise_fma(th, S6, A1);
-#ifdef OCR_DWPW_LINESTORE  // development probe (WRONG results): the same quads, each instruction as 1 KB of whole lines
-        {
-          const long e0 = ((long)__builtin_amdgcn_readfirstlane((int)(oidx >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)oidx);
-          const long tot = c.M * c.Cs_out - 4;
-          long e = e0 + ((t * 4 + g) * 64 + lane) * 4;
-          e = e < tot ? e : e - tot;
-          if (nt0 * 32 + 32 * t + 8 * g < c.ColsStore) st4<false>(c.out, e & ~3l, make_float4(tl.x, tl.y, th.x, th.y));
-        }
-#elif defined(OCR_DWPW_SEG64)  // development probe (WRONG results): the address pattern of 64-byte segments per pixel (pairs of lanes swapped)
-        {
-          const long onb = __shfl_xor(oidx, 1);  // the neighbour pixel's element index
-          const bool odd = p & 1, second = g & 1;
-          const long base = (odd != second) ? onb : oidx;
-          const int gq = (g & ~1) + (odd ? 1 : 0);
-          if (nt0 * 32 + 32 * t + 8 * g < c.ColsStore && inside) st4<false>(c.out, base + 32 * t + 8 * gq, make_float4(tl.x, tl.y, th.x, th.y));
-        }
-#else
-        if (inside && nt0 * 32 + 32 * t + 8 * g < c.ColsStore) st4<false>(c.out, oidx + 32 * t + 8 * g, make_float4(tl.x, tl.y, th.x, th.y));
-#endif
+        if constexpr (XP) *(float4*)(xt + p * OCR_XP_STRIDE + 8 * g + 4 * h) = make_float4(tl.x, tl.y, th.x, th.y);
+        else if (inside && nt0 * 32 + 32 * t + 8 * g < c.ColsStore) st4<false>(c.out, oidx + 32 * t + 8 * g, make_float4(tl.x, tl.y, th.x, th.y));
         acc[t][4 * g] = 0.f; acc[t][4 * g + 1] = 0.f; acc[t][4 * g + 2] = 0.f; acc[t][4 * g + 3] = 0.f;
+      }
+      if constexpr (XP) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (nt0 * 32 + 32 * t + 4 * xq < c.ColsStore) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (xin[i]) st4<false>(c.out, xo[i] + 32 * t, *(const float4*)(xt + (8 * i + (lane >> 3)) * OCR_XP_STRIDE + 4 * xq));
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
       }
     }
   };

@@ -724,14 +724,19 @@ template <int K, int SH, int SW, int CK, bool WIDE, int NT, int NB, int TD, int 
 bool launch_two(const DwPwArgs& a0, hipStream_t s, bool query) {
   using G_ = DwPw2Geom<K, SH, SW, CK, WIDE, NB>;
   if (!(CK == 16 ? a0.dw_wq16 : a0.dw_wq32)) return false;
-  const size_t lds = G_::lds_bytes(a0.c.NTtot);
+  // whole-line stores through per-wave LDS tiles (dwpw2_kernel.h, XP): the layers with ONE column tile only.  Measured on
+  // every instance whose LDS leaves room (tools/micro/dwpw_probe.hip, seeded data): 16 -> 32 0.372 -> 0.358 ms (480 x 480:
+  // 0.69 -> 0.645), 32 -> 64 0.75 -> 0.73 in the probe and nothing in the step (a third workgroup per CU no longer fits),
+  // 64 -> 64 and 128 -> 240 unchanged, the 5x5 240-channel block +1.2 %.
+  constexpr bool XP = K == 3 && CK == 16 && !WIDE && NT == 1;
+  const size_t lds = G_::lds_bytes(a0.c.NTtot, XP);
   static LdsAttrMemo attr_state;
   struct Occ { size_t lds; int per_cu, cus; };
   static Occ occ[64][2] = {};
   static std::mutex occ_mu;
   const int dev = rt_current_device();  // logical (hip_guard.h)
   if (dev < 0 || dev >= 64) return false;
-  if (lds > 64 * 1024 && !raise_dynamic_lds((const void*)dwpw2_kernel<K, SH, SW, CK, WIDE, NT, NB, TD, LB, RAG>, (int)lds, attr_state)) return false;
+  if (lds > 64 * 1024 && !raise_dynamic_lds((const void*)dwpw2_kernel<K, SH, SW, CK, WIDE, NT, NB, TD, LB, RAG, XP>, (int)lds, attr_state)) return false;
   int per_cu_dev = 0, cus_dev = 0;
   {
     std::lock_guard<std::mutex> lk(occ_mu);
@@ -741,7 +746,7 @@ bool launch_two(const DwPwArgs& a0, hipStream_t s, bool query) {
     if (!e) {
       int nb = 0;
       hipDeviceProp_t prop;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, dwpw2_kernel<K, SH, SW, CK, WIDE, NT, NB, TD, LB, RAG>, 256, lds) != hipSuccess || nb < 1 ||
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, dwpw2_kernel<K, SH, SW, CK, WIDE, NT, NB, TD, LB, RAG, XP>, 256, lds) != hipSuccess || nb < 1 ||
           hipGetDeviceProperties(&prop, rt_physical_device(dev)) != hipSuccess) { (void)hipGetLastError(); return false; }
       e = occ[dev][0].per_cu ? &occ[dev][1] : &occ[dev][0];
       *e = Occ{lds, nb, prop.multiProcessorCount};
@@ -765,7 +770,7 @@ bool launch_two(const DwPwArgs& a0, hipStream_t s, bool query) {
   if (rt_options().dwpw_force_upw > 0) upw = rt_options().dwpw_force_upw;
   a.upw = (unsigned)upw;
   const dim3 grid((unsigned)((nunits + upw - 1) / upw));
-  hipLaunchKernelGGL((dwpw2_kernel<K, SH, SW, CK, WIDE, NT, NB, TD, LB, RAG>), grid, dim3(256), lds, s, a);
+  hipLaunchKernelGGL((dwpw2_kernel<K, SH, SW, CK, WIDE, NT, NB, TD, LB, RAG, XP>), grid, dim3(256), lds, s, a);
   return true;
 }
 }  // namespace

@@ -71,7 +71,7 @@ static void run(int N, int H, int W, int K, int SH, int SW, int cin, int cout) {
 #ifndef OCR_TU_H16
   if (getenv("PROBE_ATTR")) {
     hipFuncAttributes fa;
-    hipError_t e = hipFuncGetAttributes(&fa, (const void*)dwpw2_kernel<5, 1, 1, 16, true, 4, 3, 2, 2, false>);
+    hipError_t e = hipFuncGetAttributes(&fa, (const void*)dwpw2_kernel<5, 1, 1, 16, true, 4, 3, 2, 2, false, false>);
     printf("dwpw2 attributes: %s  regs %d  static lds %zu  max threads %d\n", hipGetErrorString(e), fa.numRegs, fa.sharedSizeBytes, fa.maxThreadsPerBlock);
     e = hipFuncGetAttributes(&fa, (const void*)dwpw_kernel<5, 1, 1, 16, true, 4, true, 2, 2, 2, false, false>);
     printf("dwpw attributes: %s  regs %d\n", hipGetErrorString(e), fa.numRegs);

@@ -424,6 +424,8 @@ bool OCR_L(launch_conv_mfma_mt2)(const ConvArgs& a, const Epilogue& ep, int nt, 
   OCR_H16_TWIN(a.half, launch_conv_mfma_mt2_h16(a, ep, nt, s))
   const bool tap1 = a.KH == 1 && a.KW == 1 && a.PH == 0 && a.PW == 0 && a.OH == a.H && a.OW == a.W;
   if (!tap1 || a.out_mode != OUT_C8I || a.NTtot % nt) return false;
+  // (round 5: the CTC head - linear 120 -> 6625 with the softmax partials, 208 column tiles - on this kernel: 1.42 ms against
+  // 1.31 on conv_mfma_kernel, same box: its epilogue's exps want the four waves per SIMD of the one-tile kernel.  Not kept.)
   // (round 5: THREE pixel tiles per wave - a fragment feeding three MFMAs, 216 registers - measured 1.7 % faster alone
   // (conv_time, 983 040 x 480 -> 480: 3.524 -> 3.464 ms) and 1-3 % SLOWER in the step on the same box, alternating runs
   // (op 30: 3.97 -> 4.08 ms): not kept.  Five column tiles x two pixel tiles spill 13 registers.)

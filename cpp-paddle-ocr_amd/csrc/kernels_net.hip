@@ -424,6 +424,9 @@ bool OCR_L(launch_conv_mfma_mt2)(const ConvArgs& a, const Epilogue& ep, int nt, 
   OCR_H16_TWIN(a.half, launch_conv_mfma_mt2_h16(a, ep, nt, s))
   const bool tap1 = a.KH == 1 && a.KW == 1 && a.PH == 0 && a.PW == 0 && a.OH == a.H && a.OW == a.W;
   if (!tap1 || a.out_mode != OUT_C8I || a.NTtot % nt) return false;
+  // (round 5: the K loop's loads TWO steps ahead through three register sets - 175 / 198 registers - measured 1-2 % slower
+  // on all three shapes, conv_time: 3.50 -> 3.53, gated 3.67 -> 3.74, 240 -> 480 gated 2.11 -> 2.14 ms: load latency is not
+  // what the 20-35 % below the matrix peak are made of.)
   // (round 5: the CTC head - linear 120 -> 6625 with the softmax partials, 208 column tiles - on this kernel: 1.42 ms against
   // 1.31 on conv_mfma_kernel, same box: its epilogue's exps want the four waves per SIMD of the one-tile kernel.  Not kept.)
   // (round 5: THREE pixel tiles per wave - a fragment feeding three MFMAs, 216 registers - measured 1.7 % faster alone

@@ -702,7 +702,9 @@ def main(argv=None):
     # workers on one GPU, each on its own request) instead of the two halves of one batch.  EXACTLY `steps` batches of 64 in the
     # timed region, barrier + sync on both sides; a batch's latency is what it is with one chain.  An extra key.
     in_flight = None
-    if not stub and cfg == "cfg2" and world == 1 and not args.no_two_workers and hasattr(pipe, "run_device_on"):
+    # (a handle built with ONE chain - OCR_PIPE_PHASES=1 - has no second chain to name: the leg is skipped)
+    one_chain = os.environ.get("OCR_PIPE_PHASES", "") == "1"
+    if not stub and cfg == "cfg2" and world == 1 and not args.no_two_workers and hasattr(pipe, "run_device_on") and not one_chain:
         import threading
         for c_ in (0, 1):
             pipe.run_device_on(c_, d_imgs, H, W, BATCH, d_probs, collect=False)

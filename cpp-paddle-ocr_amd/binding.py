@@ -55,6 +55,7 @@ EXPORTS = [
     "ocr_rec_num_classes", "ocr_rec_steps",
     "ocr_net_create", "ocr_net_create_precision", "ocr_net_destroy", "ocr_net_forward", "ocr_net_forward_ragged", "ocr_net_forward_ragged_images", "ocr_net_num_tensors", "ocr_net_tensor_exists", "ocr_net_fetch",
     "ocr_net_timing", "ocr_net_timing_report", "ocr_probe", "ocr_selftest_refuse_launch", "ocr_selftest_lds_memo",
+    "ocr_selftest_unclip", "ocr_selftest_unclip_box",
 ]
 
 
@@ -88,6 +89,32 @@ def lib():
 def check(rc):
     if rc != 0:
         raise OcrError("libocr_hip error %d: %s" % (rc, lib().ocr_last_error().decode(errors="replace")))
+
+
+def selftest_unclip(quads, deltas, cap=64):
+    """device ClipperOffset (jtRound, closed polygon) of n int quads -> list of [k][2] int64 arrays (None: scratch overflow)"""
+    quads = np.ascontiguousarray(quads, dtype=np.int32).reshape(-1, 8)
+    deltas = np.ascontiguousarray(deltas, dtype=np.float64)
+    n = quads.shape[0]
+    out = np.zeros((n, cap, 2), np.int64)
+    counts = np.zeros(n, np.int32)
+    trig = np.zeros((n, 3), np.float64)
+    L = lib()
+    L.ocr_selftest_unclip.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    check(L.ocr_selftest_unclip(quads.ctypes.data, deltas.ctypes.data, n, out.ctypes.data, cap, counts.ctypes.data, trig.ctypes.data))
+    return out, counts, trig
+
+
+def selftest_unclip_box(boxes, unclip_ratio):
+    """device UnClip -> minAreaRect -> GetMiniBoxes of n float boxes -> (out14 [n,14], status [n,2])"""
+    boxes = np.ascontiguousarray(boxes, dtype=np.float32).reshape(-1, 8)
+    n = boxes.shape[0]
+    out = np.zeros((n, 14), np.float32)
+    st = np.zeros((n, 2), np.int32)
+    L = lib()
+    L.ocr_selftest_unclip_box.argtypes = [C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.c_void_p]
+    check(L.ocr_selftest_unclip_box(boxes.ctypes.data, float(unclip_ratio), n, out.ctypes.data, st.ctypes.data))
+    return out, st
 
 
 def probe(a, b):

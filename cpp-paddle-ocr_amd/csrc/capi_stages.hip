@@ -95,6 +95,45 @@ int ocr_det_post(ocr_det* h, const float* prob, int rows, int cols, int src_rows
   return rc ? fail(rc, err) : OCR_OK;
 }
 
+// ---- self-test taps: the device's ClipperOffset / UnClip in front of vectors the caller holds (tests/golden/unclip_ref*:
+// outputs of the reference's own compiled src/clipper.cpp).  The calling thread's current device (ocr_rt_init).
+int ocr_selftest_unclip(const int32_t* quads, const double* deltas, int n, int64_t* out, int cap, int* counts, double* trig) {
+  if (!quads || !deltas || !out || !counts || n <= 0 || cap <= 0) return fail(OCR_ERR_ARG, "bad argument");
+  int *dq = nullptr, *dc = nullptr;
+  double *dd = nullptr, *dt = nullptr;
+  if (trig) CAPI_HIP(g_malloc(&dt, (size_t)n * 3 * sizeof(double)));
+  long long* dout = nullptr;
+  CAPI_HIP(g_malloc(&dq, (size_t)n * 8 * sizeof(int)));
+  CAPI_HIP(g_malloc(&dd, (size_t)n * sizeof(double)));
+  CAPI_HIP(g_malloc(&dc, (size_t)n * sizeof(int)));
+  CAPI_HIP(g_malloc(&dout, (size_t)n * cap * 2 * sizeof(long long)));
+  CAPI_HIP(g_memcpy(dq, quads, (size_t)n * 8 * sizeof(int), hipMemcpyHostToDevice));
+  CAPI_HIP(g_memcpy(dd, deltas, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+  CAPI_HIP(hipMemset(dout, 0, (size_t)n * cap * 2 * sizeof(long long)));
+  launch_selftest_clipper(dq, dd, n, dout, cap, dc, dt, nullptr);
+  CAPI_HIP(hipGetLastError());
+  if (trig) { CAPI_HIP(g_memcpy(trig, dt, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToHost)); (void)g_free(dt); }
+  CAPI_HIP(g_memcpy(out, dout, (size_t)n * cap * 2 * sizeof(long long), hipMemcpyDeviceToHost));
+  CAPI_HIP(g_memcpy(counts, dc, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+  (void)g_free(dq); (void)g_free(dd); (void)g_free(dc); (void)g_free(dout);
+  return OCR_OK;
+}
+int ocr_selftest_unclip_box(const float* boxes, float unclip_ratio, int n, float* out14, int* status) {
+  if (!boxes || !out14 || !status || n <= 0) return fail(OCR_ERR_ARG, "bad argument");
+  float *db = nullptr, *dout = nullptr;
+  int* dst = nullptr;
+  CAPI_HIP(g_malloc(&db, (size_t)n * 8 * sizeof(float)));
+  CAPI_HIP(g_malloc(&dout, (size_t)n * 14 * sizeof(float)));
+  CAPI_HIP(g_malloc(&dst, (size_t)n * 2 * sizeof(int)));
+  CAPI_HIP(g_memcpy(db, boxes, (size_t)n * 8 * sizeof(float), hipMemcpyHostToDevice));
+  launch_selftest_unclip_box(db, unclip_ratio, n, dout, dst, nullptr);
+  CAPI_HIP(hipGetLastError());
+  CAPI_HIP(g_memcpy(out14, dout, (size_t)n * 14 * sizeof(float), hipMemcpyDeviceToHost));
+  CAPI_HIP(g_memcpy(status, dst, (size_t)n * 2 * sizeof(int), hipMemcpyDeviceToHost));
+  (void)g_free(db); (void)g_free(dout); (void)g_free(dst);
+  return OCR_OK;
+}
+
 void ocr_cls_cfg_default(ocr_cls_cfg* c) {
   if (!c) return;
   memset(c, 0, sizeof(*c));

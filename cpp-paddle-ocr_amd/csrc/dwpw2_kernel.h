@@ -29,8 +29,10 @@
 typedef unsigned ocr_v4u __attribute__((ext_vector_type(4)));
 
 // one LDS-DMA instruction: lane l's 16 bytes at (rsrc base + soff + voff) -> LDS byte address lds + 16 l; a lane whose voff
-// is not below the descriptor's num_records delivers zeros.  M0 is written in the same statement (the compiler neither
-// preserves nor uses it here).  Invisible to the compiler's s_waitcnt bookkeeping: counted by hand (dwpw2_kernel).
+// is not below the descriptor's num_records delivers zeros.  M0 is written in the same statement.  (Advisor, round 5: name M0 as a clobber.  hipcc refuses that
+// - "inline asm clobber list contains reserved registers: m0 ... may lead to undefined behaviour": M0 is a RESERVED register
+// to this compiler, it never keeps a value of its own live in it across statements and writes it itself immediately in front
+// of each instruction of its own that reads it, so there is nothing for a clobber to protect.)  Invisible to the compiler's s_waitcnt bookkeeping: counted by hand (dwpw2_kernel).
 __device__ __forceinline__ void ocr_dma16(unsigned lds, unsigned voff, ocr_v4u rsrc, unsigned soff) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
 }

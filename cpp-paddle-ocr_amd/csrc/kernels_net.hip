@@ -1227,6 +1227,7 @@ __global__ void __launch_bounds__(256) stem_conv_kernel(const StemArgs a, const 
   // pixels are consecutive in memory: through a per-wave LDS tile the same quads leave as whole lines - instruction i
   // writes pixels 64 i / Q ... of the wave, Q = CS / 4 lanes per pixel, 1 KB contiguous.
   constexpr int Q = CS / 4, PS = CS + 4;  // quads per pixel; padded pixel stride in the tile (floats)
+  static_assert(64 % Q == 0, "whole-line stores: instruction i writes pixels (64 / Q) i + lane / Q - Q = CS / 4 must divide the wave (CS = 8, 16)");
   __shared__ float s_tile[4][64 * PS];
   float* const tile = s_tile[threadIdx.x >> 6];
   const int lane = threadIdx.x & 63;

@@ -54,4 +54,9 @@ void launch_dilate2(const uint8_t* src, uint8_t* dst, int N, int H, int W, hipSt
 void launch_post(const PostArgs& a, int N, int* out_boxes, int cap, int* out_n, hipStream_t s);
 void launch_post_large(const PostArgs& a, int N, int* out_boxes, int cap, int* out_n, hipStream_t s);
 
+// self-test taps (ocr_selftest_unclip / ocr_selftest_unclip_box): clipper_offset_round and unclip_min_rect + get_mini_boxes as
+// border_box_kernel runs them, one case per workgroup.  All pointers device memory.
+void launch_selftest_clipper(const int* quads, const double* deltas, int n, long long* out, int cap, int* counts, double* trig /* [n][3] steps, m_sin, m_cos; may be null */, hipStream_t s);
+void launch_selftest_unclip_box(const float* boxes, float unclip_ratio, int n, float* out14, int* status, hipStream_t s);
+
 }  // namespace ocr

@@ -1133,6 +1133,19 @@ __device__ float polygon_score_wave(const unsigned long long* __restrict__ pts, 
 // ---- ClipperOffset (jtRound, etClosedPolygon) + union clean-up, lane 0 only
 struct IPt { long long X, Y; };
 __device__ __forceinline__ long long clip_round(double v) { return v < 0 ? (long long)(v - 0.5) : (long long)(v + 0.5); }
+// the round join's step count and rotation (ClipperOffset::DoOffset, /root/reference/src/clipper.cpp:3800-3818): ocml's f64 acos / sin / cos
+// where the reference calls the host library's; ocr_selftest_unclip_trig hands these three values out so that a test can count
+// the deltas on which the two libraries differ BEFORE Round() hides it
+__device__ __forceinline__ void clipper_round_setup(double delta, double& steps, double& m_sin, double& m_cos) {
+  const double pi = 3.141592653589793238, two_pi = pi * 2;
+  double y = 0.25;
+  if (0.25 > fabs(delta) * 0.25) y = fabs(delta) * 0.25;
+  steps = pi / acos(1 - y / fabs(delta));
+  if (steps > fabs(delta) * pi) steps = fabs(delta) * pi;
+  m_sin = sin(two_pi / steps);
+  m_cos = cos(two_pi / steps);
+  if (delta < 0.0) m_sin = -m_sin;
+}
 // dest: scratch of `cap` points; returns point count (0 when Execute yields no path, -1 on overflow)
 __device__ int clipper_offset_round(const IPt in[4], double delta, IPt* dest, int cap) {
   IPt c[4];
@@ -1155,14 +1168,9 @@ __device__ int clipper_offset_round(const IPt in[4], double delta, IPt* dest, in
   if (delta > -1.0e-20 && delta < 1.0e-20) {
     for (int i = 0; i < len; ++i) dest[nd++] = c[i];
   } else {
-    double y = 0.25;
-    if (0.25 > fabs(delta) * 0.25) y = fabs(delta) * 0.25;
-    double steps = pi / acos(1 - y / fabs(delta));
-    if (steps > fabs(delta) * pi) steps = fabs(delta) * pi;
-    double m_sin = sin(two_pi / steps);
-    const double m_cos = cos(two_pi / steps);
+    double steps, m_sin, m_cos;
+    clipper_round_setup(delta, steps, m_sin, m_cos);
     const double steps_per_rad = steps / two_pi;
-    if (delta < 0.0) m_sin = -m_sin;
     double nX[4], nY[4];
     for (int j = 0; j < len; ++j) {
       const IPt& p1 = c[j];
@@ -1279,6 +1287,53 @@ __device__ void bitonic_sort_wave(unsigned long long* a, int n2, int lane, bool 
   }
 }
 
+// DBPostProcessor::UnClip (/root/reference/src/postprocess_op.cpp:39-72) of one box by one lane: distance from the float shoelace
+// area and perimeter, the four int-truncated corners through ClipperOffset(jtRound, etClosedPolygon), cv::minAreaRect of what
+// Execute returns (an empty solution: RotatedRect(Point2f(0, 0), Size2f(1, 1), 0)).  The caller's LDS scratch: `unclip` / `ukeys`
+// UNCLIP_CAP entries, `ustack` UNCLIP_CAP + 2, `uhull` 2 * UNCLIP_CAP, `hull` / `vect` / `inv` HULL_CAP.  Returns 0 or the
+// POST_ERR_* bit of the scratch that overflowed; *npoly (optional) = vertices of the offset polygon.
+struct UnclipScratch {
+  IPt* unclip;
+  unsigned long long* ukeys;
+  int* ustack;
+  int* uhull;
+  P2f* hull;
+  P2f* vect;
+  float* inv;
+};
+template <int HULL_CAP, int UNCLIP_CAP>
+__device__ int unclip_min_rect(const P2f arr[4], float unclip_ratio, const UnclipScratch& S, RRect& pts, int* npoly) {
+  float area = 0.0f, dist = 0.0f;
+  for (int i = 0; i < 4; ++i) {
+    const int j = (i + 1) % 4;
+    area += arr[i].x * arr[j].y - arr[i].y * arr[j].x;
+    dist += sqrtf((arr[i].x - arr[j].x) * (arr[i].x - arr[j].x) + (arr[i].y - arr[j].y) * (arr[i].y - arr[j].y));
+  }
+  area = fabsf((float)(area / 2.0));
+  const float distance = area * unclip_ratio / dist;
+  IPt q[4];
+  for (int i = 0; i < 4; ++i) q[i] = {(long long)(int)arr[i].x, (long long)(int)arr[i].y};
+  const int un = clipper_offset_round(q, (double)distance, S.unclip, UNCLIP_CAP);
+  if (npoly) *npoly = un;
+  if (un < 0) return POST_ERR_UNCLIP;
+  if (un == 0) {
+    pts = RRect{0, 0, 1, 1, 0};
+    return 0;
+  }
+  // minAreaRect(points): sort (x, y, index) by insertion, hull, calipers
+  for (int i = 0; i < un; ++i) {
+    const unsigned long long k = make_key((int)S.unclip[i].X, (int)S.unclip[i].Y, (unsigned)i);
+    int j = i - 1;
+    while (j >= 0 && S.ukeys[j] > k) { S.ukeys[j + 1] = S.ukeys[j]; --j; }
+    S.ukeys[j + 1] = k;
+  }
+  FKeyAcc FP{S.ukeys};
+  const int hn = convex_hull_sorted<FKeyAcc, float>(FP, un, S.ustack, S.uhull, S.hull, HULL_CAP);
+  if (hn < 0) return POST_ERR_HULL;
+  pts = min_area_rect_hull(S.hull, hn, S.vect, S.inv);
+  return 0;
+}
+
 // one wave (workgroup of 64) per border.  The LDS working set decides how many borders a CU holds at once
 // (the work per border is a chain of dependent single-lane steps, so that is the throughput):
 // <512, 512, 256> is 23 KB - six borders per CU - and covers every border of a 960x960 map short of a
@@ -1382,35 +1437,13 @@ __global__ void __launch_bounds__(64) border_box_kernel(const PostArgs a) {
   if (lane != 0) return;
   if (OCR_PROBE_STOP(a, 4)) return;
   // ---- UnClip
-  float area = 0.0f, dist = 0.0f;
-  for (int i = 0; i < 4; ++i) {
-    const int j = (i + 1) % 4;
-    area += arr[i].x * arr[j].y - arr[i].y * arr[j].x;
-    dist += sqrtf((arr[i].x - arr[j].x) * (arr[i].x - arr[j].x) + (arr[i].y - arr[j].y) * (arr[i].y - arr[j].y));
-  }
-  area = fabsf((float)(area / 2.0));
-  const float distance = area * a.unclip_ratio / dist;
-  IPt q[4];
-  for (int i = 0; i < 4; ++i) q[i] = {(long long)(int)arr[i].x, (long long)(int)arr[i].y};
-  const int un = clipper_offset_round(q, (double)distance, s_unclip, UNCLIP_CAP);
-  if (un < 0) { atomicOr(a.status, POST_ERR_UNCLIP); return; }
-  if (OCR_PROBE_STOP(a, 5)) return;
   RRect pts;
-  if (un == 0) {
-    pts = RRect{0, 0, 1, 1, 0};
-  } else {
-    // minAreaRect(points): sort (x, y, index) by insertion, hull, calipers
-    for (int i = 0; i < un; ++i) {
-      const unsigned long long k = make_key((int)s_unclip[i].X, (int)s_unclip[i].Y, (unsigned)i);
-      int j = i - 1;
-      while (j >= 0 && s_ukeys[j] > k) { s_ukeys[j + 1] = s_ukeys[j]; --j; }
-      s_ukeys[j + 1] = k;
-    }
-    FKeyAcc FP{s_ukeys};
-    const int hn = convex_hull_sorted<FKeyAcc, float>(FP, un, s_ustack, s_uhull, s_hull, HULL_CAP);
-    if (hn < 0) { atomicOr(a.status, POST_ERR_HULL); return; }
-    pts = min_area_rect_hull(s_hull, hn, s_vect, s_inv);
+  {
+    const UnclipScratch us{s_unclip, s_ukeys, s_ustack, s_uhull, s_hull, s_vect, s_inv};
+    const int ue = unclip_min_rect<HULL_CAP, UNCLIP_CAP>(arr, a.unclip_ratio, us, pts, nullptr);
+    if (ue) { atomicOr(a.status, ue); return; }
   }
+  if (OCR_PROBE_STOP(a, 5)) return;
   if (pts.h < 1.001 && pts.w < 1.001) return;
   float ssid;
   P2f clip[4];
@@ -1503,6 +1536,67 @@ void launch_post(const PostArgs& a, int N, int* out_boxes, int cap, int* out_n, 
 void launch_post_large(const PostArgs& a, int N, int* out_boxes, int cap, int* out_n, hipStream_t s) {
   hipLaunchKernelGGL((border_box_kernel<4096, 1024, 512, true>), dim3(a.max_cand, N), dim3(64), 0, s, a);
   hipLaunchKernelGGL(boxes_compact_kernel, dim3(N), dim3(64), 0, s, a, out_boxes, cap, out_n);
+}
+
+// ------------------------------------------------------------------ self-test taps (ocr_selftest_unclip*, tests only)
+// The device's ClipperOffset and UnClip in front of vectors held outside the library (the reference's compiled clipper.cpp:
+// tests/golden/unclip_ref.json): one workgroup of 64 per case, lane 0 works - exactly how border_box_kernel runs them.
+__global__ void __launch_bounds__(64) selftest_clipper_kernel(const int* __restrict__ quads, const double* __restrict__ deltas, int n,
+                                                               long long* __restrict__ out, int cap, int* __restrict__ counts,
+                                                               double* __restrict__ trig) {
+  __shared__ IPt s_poly[512];
+  const int c = blockIdx.x;
+  if (c >= n || threadIdx.x != 0) return;
+  if (trig) {
+    double st = 0, sn = 0, cs = 0;
+    if (!(deltas[c] > -1.0e-20 && deltas[c] < 1.0e-20)) clipper_round_setup(deltas[c], st, sn, cs);
+    trig[3 * c] = st; trig[3 * c + 1] = sn; trig[3 * c + 2] = cs;
+  }
+  IPt q[4];
+  for (int i = 0; i < 4; ++i) q[i] = {(long long)quads[c * 8 + 2 * i], (long long)quads[c * 8 + 2 * i + 1]};
+  const int un = clipper_offset_round(q, deltas[c], s_poly, 512);
+  counts[c] = un;
+  for (int i = 0; i < un && i < cap; ++i) {
+    out[((long)c * cap + i) * 2] = s_poly[i].X;
+    out[((long)c * cap + i) * 2 + 1] = s_poly[i].Y;
+  }
+}
+// out14 per case: UnClip's RotatedRect (cx, cy, w, h, angle), GetMiniBoxes' ssid, its four corners (x, y) x 4; status per case:
+// POST_ERR_* bit or 0, vertices of the offset polygon
+__global__ void __launch_bounds__(64) selftest_unclip_box_kernel(const float* __restrict__ boxes, float unclip_ratio, int n,
+                                                                  float* __restrict__ out14, int* __restrict__ status) {
+  constexpr int HULL_CAP = 512, UNCLIP_CAP = 256;
+  __shared__ P2f s_hull[HULL_CAP];
+  __shared__ __attribute__((aligned(16))) unsigned char s_a[HULL_CAP * (sizeof(P2f) + sizeof(float))];
+  __shared__ __attribute__((aligned(16))) unsigned char s_b[UNCLIP_CAP * (sizeof(IPt) + sizeof(unsigned long long))];
+  __shared__ int s_ustack[UNCLIP_CAP + 2];
+  __shared__ int s_uhull[2 * UNCLIP_CAP];
+  const int c = blockIdx.x;
+  if (c >= n || threadIdx.x != 0) return;
+  P2f arr[4];
+  for (int i = 0; i < 4; ++i) { arr[i].x = boxes[c * 8 + 2 * i]; arr[i].y = boxes[c * 8 + 2 * i + 1]; }
+  // (border_box_kernel overlays the polygon and the calipers' scratch in one region: each is dead when the other is written;
+  // here they are apart, which changes no value)
+  const UnclipScratch us{(IPt*)s_b, (unsigned long long*)(s_b + UNCLIP_CAP * sizeof(IPt)), s_ustack, s_uhull, s_hull, (P2f*)s_a,
+                         (float*)(s_a + HULL_CAP * sizeof(P2f))};
+  RRect pts{0, 0, 0, 0, 0};
+  int npoly = 0;
+  const int e = unclip_min_rect<HULL_CAP, UNCLIP_CAP>(arr, unclip_ratio, us, pts, &npoly);
+  status[2 * c] = e;
+  status[2 * c + 1] = npoly;
+  float* o = out14 + (long)c * 14;
+  o[0] = pts.cx; o[1] = pts.cy; o[2] = pts.w; o[3] = pts.h; o[4] = pts.angle;
+  float ssid = 0.f;
+  P2f clip[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+  if (!e) get_mini_boxes(pts, ssid, clip);
+  o[5] = ssid;
+  for (int i = 0; i < 4; ++i) { o[6 + 2 * i] = clip[i].x; o[7 + 2 * i] = clip[i].y; }
+}
+void launch_selftest_clipper(const int* quads, const double* deltas, int n, long long* out, int cap, int* counts, double* trig, hipStream_t s) {
+  hipLaunchKernelGGL(selftest_clipper_kernel, dim3(n), dim3(64), 0, s, quads, deltas, n, out, cap, counts, trig);
+}
+void launch_selftest_unclip_box(const float* boxes, float unclip_ratio, int n, float* out14, int* status, hipStream_t s) {
+  hipLaunchKernelGGL(selftest_unclip_box_kernel, dim3(n), dim3(64), 0, s, boxes, unclip_ratio, n, out14, status);
 }
 
 }  // namespace ocr

@@ -307,6 +307,20 @@ int ocr_net_timing_report(ocr_net* h, char* buf, size_t cap);
 int ocr_selftest_refuse_launch(const char* substr);
 int ocr_selftest_lds_memo(void);
 
+/* The device's ClipperOffset / UnClip alone, for vectors held OUTSIDE the library (tests/golden/unclip_ref*: outputs of the
+ * reference's own compiled src/clipper.cpp) - the one place where the HIP code can face the reference itself.
+ * ocr_selftest_unclip: ClipperOffset(jtRound, etClosedPolygon).AddPath(quad).Execute(delta) as DBPostProcessor::UnClip
+ * calls it (/root/reference/src/postprocess_op.cpp:46-55, /root/reference/src/clipper.cpp:3779-4021) for n quads
+ * (n x 8 int32: x0,y0..x3,y3) and their deltas; out: n x cap x 2 int64 (X, Y of the solution path), counts[n] = its vertex
+ * count (0: Execute returned no path; -1: more than the kernel's 512-vertex scratch); trig (may be NULL): n x 3 doubles, the
+ * round join's steps, m_sin, m_cos as the device's math library computes them (clipper.cpp:3800-3818), before any rounding.
+ * ocr_selftest_unclip_box: the whole UnClip -> cv::minAreaRect -> GetMiniBoxes of one candidate
+ * (/root/reference/src/postprocess_op.cpp:39-72,134-168) for n boxes (n x 8 float, GetMiniBoxes order) at one unclip ratio;
+ * out14 per box: RotatedRect (cx, cy, w, h, angle), ssid, four corners (x, y); status per box: {POST_ERR bit or 0,
+ * vertices of the offset polygon}. */
+int ocr_selftest_unclip(const int32_t* quads, const double* deltas, int n, int64_t* out, int cap, int* counts, double* trig);
+int ocr_selftest_unclip_box(const float* boxes, float unclip_ratio, int n, float* out14, int* status);
+
 /* numerics probe (tests): out[8*n] = a/b, sqrt|a|, ocr_expf(a), fma(a,b,a), a*b+a, rint(a*log2e), hswish(a), hswish(b) */
 int ocr_probe(const float* a, const float* b, float* out, int n);
 

@@ -900,6 +900,32 @@ int oracle_clipper_offset(const long long* xy, int n, double delta, long long* o
   return (int)s.size();
 }
 
+// DBPostProcessor::UnClip -> GetMiniBoxes of one box (postprocess_op.cpp:39-72, 134-168): out14 = RotatedRect (cx, cy, w, h,
+// angle), ssid, the four corners; returns the vertex count of the offset polygon
+int oracle_unclip_box(const float* box8, float unclip_ratio, float* out14) {
+  Pt2f b[4];
+  for (int i = 0; i < 4; ++i) b[i] = {box8[2 * i], box8[2 * i + 1]};
+  // (the polygon's vertex count, for the tests' bookkeeping: the same call unclip() makes)
+  std::vector<IPt> p(4);
+  float area = 0.0f, dist = 0.0f;
+  for (int i = 0; i < 4; ++i) {
+    area += b[i].x * b[(i + 1) % 4].y - b[i].y * b[(i + 1) % 4].x;
+    dist += sqrtf((b[i].x - b[(i + 1) % 4].x) * (b[i].x - b[(i + 1) % 4].x) + (b[i].y - b[(i + 1) % 4].y) * (b[i].y - b[(i + 1) % 4].y));
+  }
+  area = fabs(float(area / 2.0));
+  const float distance = area * unclip_ratio / dist;
+  for (int i = 0; i < 4; ++i) p[i] = {(long long)int(b[i].x), (long long)int(b[i].y)};
+  const int npoly = (int)clipper_offset_round(p, distance).size();
+  RRect r = unclip(b, unclip_ratio);
+  out14[0] = r.cx; out14[1] = r.cy; out14[2] = r.w; out14[3] = r.h; out14[4] = r.angle;
+  float ssid;
+  Pt2f c[4];
+  get_mini_boxes(r, ssid, c);
+  out14[5] = ssid;
+  for (int i = 0; i < 4; ++i) { out14[6 + 2 * i] = c[i].x; out14[7 + 2 * i] = c[i].y; }
+  return npoly;
+}
+
 float oracle_box_score_fast(const float* box8, const float* pred, int H, int W, int cv_compat) {
   Pt2f a[4];
   for (int i = 0; i < 4; ++i) a[i] = {box8[2 * i], box8[2 * i + 1]};

@@ -1,0 +1,90 @@
+"""Round-6 GPU tests (through the C-ABI): the device's ClipperOffset / UnClip in front of the reference's own vectors."""
+import math
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_device_clipper_offset_on_the_reference_vectors(pkg, built):
+    """the HIP `clipper_offset_round` (csrc/kernels_post.hip; ocml's f64 sin / cos / acos / atan2, not the
+    host library's) against tests/golden/unclip_ref_20k.npz and unclip_ref.json - outputs of the REFERENCE's compiled
+    src/clipper.cpp (/root/reference/src/clipper.cpp:3779-4021 through the call of postprocess_op.cpp:46-55) - point for
+    point.  The sliver class (repeated corner, 0 < delta < 0.5: needs the full Vatti union) is excluded by its exact predicate
+    and counted.  Also counted: deltas on which the device's acos / sin / cos differ from the host's BEFORE Round() - the
+    distance between the two math libraries that the integer outputs then do or do not show."""
+    import json
+    from test_oracle_unclip import _golden20k, is_sliver
+    pkg.rt_init(0)
+    quads, deltas, paths, counts, points, off = _golden20k()
+    small = json.load(open(os.path.join(ROOT, "tests", "golden", "unclip_ref.json")))
+    q2 = np.array([np.array(c["quad"], np.int32).ravel() for c in small], np.int32)
+    d2 = np.array([c["delta"] for c in small], np.float64)
+    allq = np.concatenate([quads, q2])
+    alld = np.concatenate([deltas, d2])
+    want = [points[off[i]:off[i + 1]].astype(np.int64) for i in range(len(deltas))] + \
+           [np.array(c["out"], np.int64).reshape(-1, 2) for c in small]
+    out, cnt, trig = pkg.selftest_unclip(allq, alld, cap=64)
+    assert (cnt >= 0).all()
+    bad, slivers = [], 0
+    for i in range(len(alld)):
+        got = out[i, :cnt[i]]
+        if got.shape != want[i].shape or not np.array_equal(got, want[i]):
+            if is_sliver(allq[i], alld[i]):
+                slivers += 1
+            else:
+                bad.append(i)
+    assert not bad, (len(bad), allq[bad[0]].tolist(), alld[bad[0]])
+    assert slivers <= 10, slivers
+    # the math libraries before rounding (host: what this Python's libm gives, i.e. glibc here)
+    ndiff = 0
+    nz = 0
+    for i in range(len(alld)):
+        d = alld[i]
+        if -1e-20 < d < 1e-20:
+            continue
+        nz += 1
+        y = min(0.25, abs(d) * 0.25)
+        steps = math.pi / math.acos(1 - y / abs(d))
+        steps = min(steps, abs(d) * math.pi)
+        host = (steps, math.sin(2 * math.pi / steps), math.cos(2 * math.pi / steps))
+        ndiff += tuple(trig[i]) != host
+    print("unclip: %d cases equal the reference's vectors, %d slivers excluded; device f64 trig differs from the host's on %d of %d deltas"
+          % (len(alld) - slivers, slivers, ndiff, nz))
+    rel = np.abs(trig[:, 1:] - np.array([[math.sin(2 * math.pi / t[0]) if t[0] else 0, math.cos(2 * math.pi / t[0]) if t[0] else 0] for t in trig]))
+    assert rel.max() < 1e-15  # an ulp, never more: Round() of coordinate + normal * delta hides it unless a tie is hit
+
+
+def test_device_unclip_box_equals_the_oracle(pkg, built):
+    """the whole UnClip -> cv::minAreaRect -> GetMiniBoxes of a candidate (border_box_kernel's `unclip_min_rect`, the code the
+    detector runs) on 20 000 boxes at both ratios: RotatedRect, ssid and corners bit-identical to the oracle, whose
+    ClipperOffset is the one pinned above"""
+    import ctypes as C
+    import oracle as O
+    pkg.rt_init(0)
+    rs = np.random.RandomState(606)
+    n = 10000
+    boxes = np.zeros((n, 8), np.float32)
+    for i in range(n):
+        cx, cy = rs.rand(2) * 900 + 30
+        w, h = rs.rand() * 300 + 1, rs.rand() * 60 + 0.5
+        ang = (rs.rand() - 0.5) * (math.pi if i % 3 == 0 else 0.2)
+        ca, sa = math.cos(ang), math.sin(ang)
+        pts = [(cx + sx * w / 2 * ca - sy * h / 2 * sa, cy + sx * w / 2 * sa + sy * h / 2 * ca) for sx, sy in ((-1, -1), (1, -1), (1, 1), (-1, 1))]
+        if i % 47 == 0:
+            pts[2] = pts[1]
+        boxes[i] = np.array(pts, np.float32).ravel()
+    lib = O.lib()
+    lib.oracle_unclip_box.argtypes = [C.c_void_p, C.c_float, C.c_void_p]
+    for ratio in (1.8, 2.0):
+        got, st = pkg.selftest_unclip_box(boxes, ratio)
+        assert (st[:, 0] == 0).all()
+        want = np.zeros((n, 14), np.float32)
+        npoly = np.zeros(n, np.int32)
+        for i in range(n):
+            npoly[i] = lib.oracle_unclip_box(boxes[i].ctypes.data, ratio, want[i].ctypes.data)
+        assert np.array_equal(st[:, 1], npoly)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), int((got.view(np.uint32) != want.view(np.uint32)).any(axis=1).sum())

@@ -21,6 +21,8 @@ mkdir -p $O/fp16; cp gpurun_out/prof_${T}_fp16/trace/*/*kernel_stats.csv $O/fp16
 python tools/fp16_check.py 8 > $O/fp16_check.txt 2>&1
 # micro-benchmarks (binaries built in the container, tools/micro/): what the matrix pipe sustains on data, the vendor GEMM on the
 # big 1x1 convs' shapes, the fused 5x5 block in both forms with its shader clock
+# (the binaries are not tracked - build them here, and stop with a message rather than record "not found" lines as evidence)
+make -s -C tools/micro all > $O/micro_build.log 2>&1 || { echo "tools/micro does not build: see $O/micro_build.log" | tee $O/micro.txt; exit 1; }
 ( cd tools/micro
   ./mfma_power 100
   python mm_ref.py

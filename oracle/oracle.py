@@ -56,6 +56,12 @@ def plan_text(net):
 
 def load_weights(net, model_root=None):
     """real inference.pdiparams if present, else the seeded synthetic file."""
+    if net.startswith("srv_"):  # BASELINE configs[4]: hand-written plans, seeded weights only (tools/make_server_plans.py)
+        import synth_weights
+        kind = net[4:]
+        path = synth_weights.ensure_server(ROOT)[("det", "rec").index(kind)]
+        names = [n for n, _ in synth_weights.server_param_table(os.path.join(ROOT, "cpp-paddle-ocr_amd", "plans", net + ".plan"))]
+        return read_params(path, sorted(names))
     model_root = model_root or os.path.join(ROOT, "models")
     d = os.path.join(model_root, net)
     prog = Program(os.path.join(d, "inference.pdmodel"))

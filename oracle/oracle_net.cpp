@@ -23,6 +23,10 @@
 //   * reductions: GAP = row-sequential then column-sequential; LN/attention sequential;
 //     row softmax: groups of 128 columns, two interleaved chains per group, groups folded in order
 //     with exp(m_g - M) rescaling (see the softmax op below).
+// Round 6 - the hand-written server plans of BASELINE configs[4] (cpp-paddle-ocr_amd/plans/srv_*.plan, tools/make_server_plans.py:
+// NOT reference artifacts) add: `pool` with padding (max pools skip what lies outside), `act:gelu` (ocr_erff below), `addpos`
+// (a per-position parameter added to every image), `attn` on a token grid with a local window (SVTR's Local mixer: the
+// additive -inf mask of rec_svtrnet.py restated as "keys outside the window do not take part").
 // Layout here is plain NHWC; the device uses an octet-interleaved channel order, which does not
 // change any of the above.
 #include <cmath>
@@ -58,8 +62,24 @@ inline float ocr_expf(float x) {
   return y * sc;
 }
 
-enum StageKind { S_BIAS, S_SMUL, S_SADD, S_BN, S_ACT, S_MULC, S_ADDT, S_ADDUP, S_SFMA };
-enum ActKind { A_RELU, A_HSWISH, A_HSIG, A_SWISH, A_SIGMOID, A_HSW6 };
+// erf for the exact GELU (Abramowitz & Stegun 7.1.26, |error| <= 1.5e-7), every step spelled out: the device's f32 build
+// performs the same operations in the same order (csrc/srv_kernels.hip, srv_erff)
+inline float ocr_erff(float x) {
+  const float ax = fabsf(x);
+  const float t = 1.0f / fmaf(0.3275911f, ax, 1.0f);
+  float p = 1.061405429f;
+  p = fmaf(p, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  p = p * t;
+  const float e = ocr_expf(-(ax * ax));
+  const float r = fmaf(-p, e, 1.0f);
+  return copysignf(r, x);
+}
+
+enum StageKind { S_BIAS, S_SMUL, S_SADD, S_BN, S_ACT, S_MULC, S_ADDT, S_ADDUP, S_SFMA, S_ADDPOS };
+enum ActKind { A_RELU, A_HSWISH, A_HSIG, A_SWISH, A_SIGMOID, A_HSW6, A_GELU };
 
 struct Stage {
   int kind = 0, act = 0;
@@ -158,11 +178,13 @@ bool parse_plan(Net& net, const char* text) {
             else if (args[0] == "hsig") { s.act = A_HSIG; s.p0 = strtof(args[1].c_str(), nullptr); s.p1 = strtof(args[2].c_str(), nullptr); }
             else if (args[0] == "swish") s.act = A_SWISH;
             else if (args[0] == "sigmoid") s.act = A_SIGMOID;
+            else if (args[0] == "gelu") s.act = A_GELU;
             else return false;
           }
           else if (sk == "mulc") { s.kind = S_MULC; s.tid = atoi(args[0].c_str()); }
           else if (sk == "addt") { s.kind = S_ADDT; s.tid = atoi(args[0].c_str()); }
           else if (sk == "addup") { s.kind = S_ADDUP; s.tid = atoi(args[0].c_str()); s.up = atoi(args[1].c_str()); }
+          else if (sk == "addpos") { s.kind = S_ADDPOS; s.n0 = args[0]; }
           else return false;
           op.ep.push_back(s);
         }
@@ -278,7 +300,7 @@ bool resolve(Net& net) {
     const bool w_fold = lab[oi].on;
     for (Stage& s : op.ep) {
       if (s.kind == S_BIAS && !s.v0.empty()) continue;  // (the folded bias above)
-      if (s.kind == S_BIAS) {
+      if (s.kind == S_BIAS || s.kind == S_ADDPOS) {
         auto p = getp(net, s.n0); if (!p) return false;
         s.v0 = p->d;
       } else if (s.kind == S_SMUL || s.kind == S_SADD) {
@@ -325,6 +347,7 @@ inline float act_apply(const Stage& s, float y) {
     case A_HSIG: { float t = y * s.p0; t = t + s.p1; return fminf(fmaxf(t, 0.0f), 1.0f); }
     case A_SWISH: { float e = ocr_expf(-y); float d = 1.0f + e; return y / d; }
     case A_SIGMOID: { float e = ocr_expf(-y); float d = 1.0f + e; return 1.0f / d; }
+    case A_GELU: { const float hx = 0.5f * y; const float z = y * 0.70710678118654752f; const float e1 = 1.0f + ocr_erff(z); return hx * e1; }
     case A_HSW6: { float t = fminf(fmaxf(y + 3.0f, 0.0f), 6.0f); return y * t; }  // the hard-swish's product; its 1/6 is folded (fold_lab)
   }
   return y;
@@ -343,6 +366,7 @@ inline void epilogue(Net& net, const Op& op, float* y, int C, int n, int h, int 
       case S_MULC: { const float* g = net.t[s.tid].at(n, 0, 0); for (int c = 0; c < C; ++c) y[c] = y[c] * g[c]; } break;
       case S_ADDT: { const float* g = net.t[s.tid].at(n, h, w); for (int c = 0; c < C; ++c) y[c] = y[c] + g[c]; } break;
       case S_ADDUP: { const float* g = net.t[s.tid].at(n, h / s.up, w / s.up); for (int c = 0; c < C; ++c) y[c] = y[c] + g[c]; } break;
+      case S_ADDPOS: { const float* g = s.v0.data() + ((size_t)h * net.t[op.geti("o")].w + w) * C; for (int c = 0; c < C; ++c) y[c] = y[c] + g[c]; } break;
     }
   }
 }
@@ -539,10 +563,12 @@ bool run(Net& net, const float* x_nhwc, int N, int H, int W) {
     } else if (k == "pool") {
       const Tensor& in = net.t[op.geti("i")];
       int kh = op.geti("kh"), kw = op.geti("kw"), sh = op.geti("sh"), sw = op.geti("sw");
+      const int ph = op.geti("ph", 0), pw = op.geti("pw", 0);  // (server plans: the ResNet stem's 3x3 s2 p1 max pool)
       bool is_max = op.kv.at("type") == "max";
-      int oh = (in.h - kh) / sh + 1, ow = (in.w - kw) / sw + 1;  // C++ truncating division (SURVEY §A.2 note)
+      int oh = (in.h + 2 * ph - kh) / sh + 1, ow = (in.w + 2 * pw - kw) / sw + 1;  // C++ truncating division (SURVEY §A.2 note)
       Tensor& out = net.t[o];
       out.alloc(in.n, oh, ow, in.c);
+#pragma omp parallel for collapse(2) schedule(static)
       for (int n = 0; n < in.n; ++n)
         for (int y = 0; y < oh; ++y)
           for (int x = 0; x < ow; ++x)
@@ -551,8 +577,8 @@ bool run(Net& net, const float* x_nhwc, int N, int H, int W) {
               int cnt = 0;
               for (int dy = 0; dy < kh; ++dy)
                 for (int dx = 0; dx < kw; ++dx) {
-                  int iy = y * sh + dy, ix = x * sw + dx;
-                  if (iy >= in.h || ix >= in.w) continue;
+                  int iy = y * sh - ph + dy, ix = x * sw - pw + dx;
+                  if (iy < 0 || ix < 0 || iy >= in.h || ix >= in.w) continue;  // outside: takes no part (exclusive mean, -inf pad)
                   float v = in.at(n, iy, ix)[c];
                   acc = is_max ? fmaxf(acc, v) : acc + v;
                   ++cnt;
@@ -568,7 +594,8 @@ bool run(Net& net, const float* x_nhwc, int N, int H, int W) {
       Tensor& out = net.t[o];
       out.alloc(in.n, in.h, in.w, C);
       size_t rows = (size_t)in.n * in.h * in.w;
-      for (size_t r = 0; r < rows; ++r) {
+#pragma omp parallel for schedule(static)
+      for (long r = 0; r < (long)rows; ++r) {
         const float* src = in.d.data() + r * C;
         float* dst = out.d.data() + r * C;
         float s = 0.f;
@@ -593,16 +620,26 @@ bool run(Net& net, const float* x_nhwc, int N, int H, int W) {
       Tensor& out = net.t[o];
       out.alloc(in.n, in.h, in.w, D);
       int T = in.h * in.w;
+      // token grid and local window (server plans, SVTR's Local mixer): key (ky, kx) takes part in query (qy, qx)'s softmax iff
+      // |ky - qy| <= lh / 2 and |kx - qx| <= lw / 2 (rec_svtrnet.py adds -inf elsewhere); lh = 0: every key (Global mixer)
+      const int gw = op.geti("gw", in.w), lh = op.geti("lh", 0), lw = op.geti("lw", 0);
 #pragma omp parallel for collapse(2) schedule(static)
       for (int n = 0; n < in.n; ++n)
         for (int hh = 0; hh < heads; ++hh) {
           std::vector<float> sc(T), q(hd);
+          std::vector<char> ok(T);
           const float* base = in.d.data() + (size_t)n * T * 3 * D;
           for (int t = 0; t < T; ++t) {
             const float* qr = base + (size_t)t * 3 * D + hh * hd;
             for (int d = 0; d < hd; ++d) q[d] = qr[d] * scale;
             float m = -INFINITY;
             for (int u = 0; u < T; ++u) {
+              ok[u] = 1;
+              if (lh > 0) {
+                const int dy = u / gw - t / gw, dx = u % gw - t % gw;
+                ok[u] = dy >= -(lh / 2) && dy <= lh / 2 && dx >= -(lw / 2) && dx <= lw / 2;
+              }
+              if (!ok[u]) continue;
               const float* kr = base + (size_t)u * 3 * D + D + hh * hd;
               float acc = 0.f;
               for (int d = 0; d < hd; ++d) acc = fmaf(q[d], kr[d], acc);
@@ -610,12 +647,12 @@ bool run(Net& net, const float* x_nhwc, int N, int H, int W) {
               m = fmaxf(m, acc);
             }
             float sum = 0.f;
-            for (int u = 0; u < T; ++u) { sc[u] = ocr_expf(sc[u] - m); sum = sum + sc[u]; }
-            for (int u = 0; u < T; ++u) sc[u] = sc[u] / sum;
+            for (int u = 0; u < T; ++u) if (ok[u]) { sc[u] = ocr_expf(sc[u] - m); sum = sum + sc[u]; }
+            for (int u = 0; u < T; ++u) if (ok[u]) sc[u] = sc[u] / sum;
             float* dst = out.d.data() + ((size_t)n * T + t) * D + hh * hd;
             for (int d = 0; d < hd; ++d) {
               float acc = 0.f;
-              for (int u = 0; u < T; ++u) acc = fmaf(sc[u], base[(size_t)u * 3 * D + 2 * D + hh * hd + d], acc);
+              for (int u = 0; u < T; ++u) if (ok[u]) acc = fmaf(sc[u], base[(size_t)u * 3 * D + 2 * D + hh * hd + d], acc);
               dst[d] = acc;
             }
           }

@@ -18,7 +18,7 @@ def test_device_clipper_offset_on_the_reference_vectors(pkg, built):
     distance between the two math libraries that the integer outputs then do or do not show."""
     import json
     from test_oracle_unclip import _golden20k, is_sliver
-    pkg.rt_init(0)
+    assert pkg.lib().ocr_rt_init(0) == 0
     quads, deltas, paths, counts, points, off = _golden20k()
     small = json.load(open(os.path.join(ROOT, "tests", "golden", "unclip_ref.json")))
     q2 = np.array([np.array(c["quad"], np.int32).ravel() for c in small], np.int32)
@@ -64,7 +64,7 @@ def test_device_unclip_box_equals_the_oracle(pkg, built):
     ClipperOffset is the one pinned above"""
     import ctypes as C
     import oracle as O
-    pkg.rt_init(0)
+    assert pkg.lib().ocr_rt_init(0) == 0
     rs = np.random.RandomState(606)
     n = 10000
     boxes = np.zeros((n, 8), np.float32)

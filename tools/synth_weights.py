@@ -93,6 +93,61 @@ def ensure(root=None, force=False):
     return out
 
 
+# ---- BASELINE configs[4]: the hand-written server plans (tools/make_server_plans.py; NOT reference artifacts) ----------------
+def server_param_table(plan_path):
+    """[(name, dims)] from the plan's `# param <name> <d0,d1,...>` lines (there is no .pdmodel to take shapes from)"""
+    out = []
+    for line in open(plan_path):
+        if line.startswith("# param "):
+            _, _, name, dims = line.split()
+            out.append((name, [int(d) for d in dims.split(",")]))
+    return out
+
+
+def synth_server_tensor(name, dims):
+    """conv / linear / deconv weights ~ N(0, sqrt(2 / fan_in)) (a sum of 4 uniforms: 67 M values in seconds), biases
+    U[-0.05, 0.05], batch norm scale 1 +- 0.1 (the residual branches' last norm 0.25 +- 0.05, so that sixteen residual adds stay
+    inside f16's range), offset / mean +- 0.1, variance U[0.8, 1.2], layer norm 1 +- 0.1 / +- 0.05, position embedding N(0, 0.02)"""
+    seed = fnv1a(name) ^ 0x5E12F00D
+    n = int(np.prod(dims))
+    base, suf = name.rsplit(".", 1) if "." in name else (name, "")
+    if suf == "scale":
+        v = uniform(seed, n, 0.2, 0.3) if base.endswith("branch2c") else uniform(seed, n, 0.9, 1.1)
+    elif suf in ("offset", "mean"):
+        v = uniform(seed, n, -0.1, 0.1)
+    elif suf == "variance":
+        v = uniform(seed, n, 0.8, 1.2)
+    elif "norm" in base and suf == "w":
+        v = uniform(seed, n, 0.9, 1.1)
+    elif suf == "b":
+        v = uniform(seed, n, -0.05, 0.05)
+    elif name == "pos_embed":
+        v = (sum(_splitmix(seed, n, k + 1) for k in range(4)) - 2.0) * np.sqrt(3.0) * 0.02
+    else:
+        if len(dims) == 2:
+            fan_in = dims[0]                      # linear [in, out]
+        elif "deconv" in base:
+            fan_in = dims[0]                      # [Cin, Cout, 2, 2]: one tap per output pixel
+        else:
+            fan_in = dims[1] * dims[2] * dims[3]  # conv [Cout, Cin, kh, kw]
+        v = (sum(_splitmix(seed, n, k + 1) for k in range(4)) - 2.0) * np.sqrt(3.0) * np.sqrt(2.0 / fan_in)
+    return v.astype(np.float32).reshape(dims)
+
+
+def ensure_server(root=None, force=False):
+    root = root or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = []
+    for net in ("det", "rec"):
+        d = os.path.join(root, "models_server", net)
+        os.makedirs(d, exist_ok=True)
+        dst = os.path.join(d, "synthetic.pdiparams")
+        plan = os.path.join(root, "cpp-paddle-ocr_amd", "plans", "srv_%s.plan" % net)
+        if force or not os.path.exists(dst) or os.path.getmtime(dst) < os.path.getmtime(plan):
+            write_params(dst, {n: synth_server_tensor(n, dims) for n, dims in server_param_table(plan)})
+        out.append(dst)
+    return out
+
+
 if __name__ == "__main__":
-    for p in ensure(force=True):
+    for p in ensure(force=True) + ensure_server(force=True):
         print(p, os.path.getsize(p))

@@ -56,6 +56,8 @@ EXPORTS = [
     "ocr_net_create", "ocr_net_create_precision", "ocr_net_destroy", "ocr_net_forward", "ocr_net_forward_ragged", "ocr_net_forward_ragged_images", "ocr_net_num_tensors", "ocr_net_tensor_exists", "ocr_net_fetch",
     "ocr_net_timing", "ocr_net_timing_report", "ocr_probe", "ocr_selftest_refuse_launch", "ocr_selftest_lds_memo",
     "ocr_selftest_unclip", "ocr_selftest_unclip_box",
+    "ocr_srv_net_create", "ocr_srv_net_destroy", "ocr_srv_net_forward", "ocr_srv_net_rerun", "ocr_srv_net_num_tensors", "ocr_srv_net_fetch",
+    "ocr_srv_net_timing", "ocr_srv_net_timing_report",
 ]
 
 
@@ -89,6 +91,79 @@ def lib():
 def check(rc):
     if rc != 0:
         raise OcrError("libocr_hip error %d: %s" % (rc, lib().ocr_last_error().decode(errors="replace")))
+
+
+class SrvNet:
+    """raw taps of a server network (BASELINE configs[4]; hand-written plans, seeded weights): kind "det" | "rec" """
+
+    def __init__(self, kind, precision="fp16", model_dir=None, device=0):
+        L = lib()
+        L.ocr_srv_net_create.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_char_p, C.POINTER(C.c_void_p)]
+        L.ocr_srv_net_destroy.argtypes = [C.c_void_p]
+        L.ocr_srv_net_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.ocr_srv_net_rerun.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.ocr_srv_net_num_tensors.argtypes = [C.c_void_p]
+        L.ocr_srv_net_fetch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_int)]
+        L.ocr_srv_net_timing.argtypes = [C.c_void_p, C.c_int]
+        L.ocr_srv_net_timing_report.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+        if model_dir is None:
+            root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+            model_dir = os.path.join(root, "models_server", kind)
+        self.h = C.c_void_p()
+        check(L.ocr_srv_net_create(kind.encode(), model_dir.encode(), device, precision.encode(), C.byref(self.h)))
+        self.shape = None
+
+    def forward(self, x, keep_all=False):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        n, h, w, c = x.shape
+        assert c == 3
+        self.shape = (n, h, w)
+        check(lib().ocr_srv_net_forward(self.h, x.ctypes.data, n, h, w, 1 if keep_all else 0))
+        return self.fetch(-1)
+
+    def rerun(self, iters=1):
+        n, h, w = self.shape
+        check(lib().ocr_srv_net_rerun(self.h, n, h, w, iters))
+
+    def num_tensors(self):
+        return lib().ocr_srv_net_num_tensors(self.h)
+
+    def fetch(self, tid, cap=None):
+        dims = (C.c_int * 4)()
+        cap = cap or (1 << 22)
+        while True:
+            out = np.empty(cap, np.float32)
+            rc = lib().ocr_srv_net_fetch(self.h, tid, out.ctypes.data, cap, dims)
+            if rc == -4:
+                cap *= 8
+                continue
+            check(rc)
+            break
+        n = dims[0] * dims[1] * dims[2] * dims[3]
+        return out[:n].reshape(dims[0], dims[1], dims[2], dims[3]).copy()
+
+    def timing(self, on=True):
+        check(lib().ocr_srv_net_timing(self.h, 1 if on else 0))
+
+    def timing_report(self):
+        buf = C.create_string_buffer(1 << 18)
+        check(lib().ocr_srv_net_timing_report(self.h, buf, len(buf)))
+        rep = {}
+        for line in buf.value.decode().splitlines():
+            name, ms, cnt, fl, by = line.rsplit(" ", 4)
+            rep[name] = dict(ms=float(ms), count=int(cnt), flops=float(fl), bytes=float(by))
+        return rep
+
+    def close(self):
+        if self.h:
+            lib().ocr_srv_net_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def selftest_unclip(quads, deltas, cap=64):

@@ -109,6 +109,8 @@ const char* embedded_plan(const char* kind) {
   if (!strcmp(kind, "det")) return kPlanDet;
   if (!strcmp(kind, "cls")) return kPlanCls;
   if (!strcmp(kind, "rec")) return kPlanRec;
+  if (!strcmp(kind, "srv_det")) return kPlanSrv_det;  // BASELINE configs[4]: hand-written plans, NOT reference artifacts
+  if (!strcmp(kind, "srv_rec")) return kPlanSrv_rec;
   return nullptr;
 }
 

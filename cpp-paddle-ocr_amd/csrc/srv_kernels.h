@@ -1,0 +1,82 @@
+// Host-visible launch interface of srv_kernels.hip: the kernel family of the "server" networks (BASELINE configs[4]:
+// ResNet50-vd DB detector + SVTR-large recognizer, precision fp16; plans/srv_*.plan - hand-written, NOT reference artifacts).
+//
+// Data layout: activations are plain NHWC tensors of element type T - f16 in the product's mode
+// (precision "fp16", the mode the config names), f32 in the PARITY TWIN (same kernels instantiated on float: every contraction
+// is then the oracle's ascending-k fma chain on v_mfma_f32_32x32x2_f32 and results equal the oracle's bit for bit, which pins
+// indexing, padding, strides and fusions exactly; the f16 build differs from it by rounding only).  Channels are stored padded
+// to a multiple of 8 (pads hold zeros); one 16-byte GRANULE = 8 halfs / 4 floats is the unit of every load.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+
+namespace ocr {
+namespace srv {
+
+enum : int { SACT_NONE = 0, SACT_RELU = 1, SACT_GELU = 2, SACT_HSWISH = 3, SACT_SIGMOID = 4 };
+
+// Implicit-GEMM convolution / linear / 2x2 transposed conv:  Y[m][n] = epilogue( sum_k W[n][k] * X[m][k] ),
+// m = output pixel (N*OH*OW), n = output channel, k = ((ky*KW)+kx)*Cin + ci ascending.  Both operand tiles are staged through
+// LDS by LDS-DMA (buffer_load ... lds, 16 bytes per lane, three stages in flight across raw barriers), XOR-swizzled so that
+// the fragment reads (ds_read_b128) are conflict-free; the matrix instruction is v_mfma_f32_32x32x16_f16 (f32 twin:
+// v_mfma_f32_32x32x2_f32) with the WEIGHTS as the A operand, so a lane owns a pixel and the accumulator registers run over
+// output channels; the epilogue goes through an f32 LDS tile and leaves as whole 16-byte chunks of pixel rows.
+struct GemmArgs {
+  const void* x = nullptr;   // [N][H][W][Cin] T
+  unsigned long long x_bytes = 0;
+  const void* w = nullptr;   // weight image [nkt][Npad][8 granules, XOR-swizzled by row] T (srv_net.hip: weight_image)
+  unsigned long long w_bytes = 0;
+  void* y = nullptr;         // [N][OH][OW][Cs_out] T (out_f32: float)
+  long M = 0;
+  int K = 0, nkt = 0;        // K = KH*KW*Cin (Cin = stored channels), K tiles of 8 granules
+  int Npad = 0;              // rows of the weight image: GEMM rows padded to a multiple of 256
+  int Ncols = 0;             // GEMM rows that exist (conv / linear: Cout; deconv: 4 * CoutD)
+  int Cs_out = 0;            // stored channels per output pixel
+  int N = 0, H = 0, W = 0, Cin = 0, OH = 0, OW = 0, KH = 1, KW = 1, SH = 1, SW = 1, PH = 0, PW = 0;
+  int cin_shift = -1;        // -1: a K tile lies inside one tap (Cin a multiple of the tile); else a tile spans taps and a lane finds
+                             // its granule's (tap, channel) by shift (>= 0: log2 Cin) or by division (-2)
+  int deconv = 0;            // 2x2 stride-2 transposed conv: GEMM row = (dy*2+dx)*CoutD + co, scattered to pixel (2y+dy, 2x+dx)
+  int CoutD = 0;
+  int x1 = 0;                // 1x1 stride-1 unpadded conv / linear with K a multiple of the K tile: X rows are contiguous
+  // epilogue, in this order (each optional): + bias[n] ; * scale[n] then + shift[n] (batch norm) ; + res[m][n] (res_up = 1) or
+  // + res[pixel (y/2, x/2)][n] (res_up = 2: the FPN's nearest-upsampled add) ; activation
+  const float* bias = nullptr;
+  const float* scale = nullptr;
+  const float* shift = nullptr;
+  const void* res = nullptr;
+  int res_up = 0;
+  int act = SACT_NONE;
+  int out_f32 = 0;
+};
+int gemm_num_configs();
+const char* gemm_config_name(int cfg);
+// can tile configuration `cfg` run this problem? (shape divisibility, LDS attribute) - asked at bind time
+bool gemm_config_ok(const GemmArgs& a, bool half, int cfg);
+bool launch_gemm(const GemmArgs& a, bool half, int cfg, hipStream_t s, std::string& err);
+
+// f32 [N][H][W][3] (the normalised image, what the pre-processing kernels write) -> T [N][H][W][8], channels 3..7 zero
+void launch_pack_input(const float* x, void* y, long pixels, bool half, hipStream_t s);
+// max / average pool (window kh x kw, stride, padding; positions outside the image take no part)
+void launch_pool(const void* x, void* y, int N, int H, int W, int Cs, int OH, int OW, int kh, int kw, int sh, int sw, int ph, int pw,
+                 bool is_max, bool half, hipStream_t s);
+// channel concat of up to 4 tensors of cs channels each, source j read with nearest upsampling by up[j]
+void launch_concat_up(const void* const src[4], const int up[4], int nsrc, int cs, void* y, int N, int OH, int OW, bool half, hipStream_t s);
+// y = x + pos[(h*W + w)][c] (the position embedding, f32 parameter [H*W][Cs])
+void launch_addpos(const void* x, const float* pos, void* y, long pixels, int hw, int Cs, bool half, hipStream_t s);
+// layer norm over the channels of every pixel (C = Cs: no pad channels in these tensors)
+void launch_layernorm(const void* x, const float* g, const float* b, void* y, long rows, int C, float eps, bool half, hipStream_t s);
+// SVTR mixing: qkv [N][T][3*D] (q | k | v, head-major inside each) -> out [N][T][D]; token grid gh x gw, local window lh x lw
+// (lh = 0: global).  hd must be 32.
+bool launch_attention(const void* qkv, void* out, int N, int T, int heads, int hd, float scale, int gh, int gw, int lh, int lw, bool half,
+                      hipStream_t s, std::string& err);
+// the DB head's last layer: 2x2 stride-2 transposed conv Cin -> 1 + bias + sigmoid, output the f32 probability map [N][2H][2W]
+void launch_deconv_to_map(const void* x, const float* w4 /* [4 taps][Cs] */, float bias, float* prob, int N, int H, int W, int Cs, bool half,
+                          hipStream_t s);
+// CTC head's tail: per row of f32 logits [rows][ld] (C valid): arg max (first maximum) and its softmax probability
+void launch_argmax_softmax(const float* logits, long rows, int C, int ld, int* amax, float* pmax, hipStream_t s);
+// copies a T tensor to f32 dropping the pad channels (parity taps)
+void launch_to_f32(const void* x, float* y, long pixels, int Cs, int C, bool half, hipStream_t s);
+
+}  // namespace srv
+}  // namespace ocr

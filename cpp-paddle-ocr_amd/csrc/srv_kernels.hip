@@ -1,0 +1,845 @@
+// Kernels of the "server" networks (BASELINE configs[4]: ResNet50-vd DB detector + SVTR-large recognizer, precision fp16;
+// plans/srv_*.plan are hand-written, NOT reference artifacts - tools/make_server_plans.py).  gfx950 only.
+//
+// What the reference would run here is TensorRT fp16 behind `precision` (/root/reference/src/ocr_det.cpp:50-57): dense
+// convolutions, linears and attention - matrix-core work, unlike the depthwise-dominated mobile graphs of kernels_net.hip.
+//   * srv_gemm_kernel: ONE implicit-GEMM family for 1x1 / 3x3 / strided convs, linears and 2x2 transposed convs on
+//     v_mfma_f32_32x32x16_f16, both operand tiles through LDS by LDS-DMA (three stages in flight across raw barriers, counted
+//     vmcnt), XOR-swizzled images, conv + bias + batch-norm + residual / upsampled add + activation in the epilogue;
+//   * srv_attn_kernel: SVTR's local / global mixing, K and V of a (line, head) resident in LDS, S^T = K Q^T so that a lane owns a
+//     query (row max / sum without LDS), the probabilities handed to the P V product as the accumulator-as-operand B fragment,
+//     V through ds_read_b64_tr_b16; key tiles outside the 7 x 11 window are skipped;
+//   * the rest (pack, pools, concat, layer norm, position add, map head, arg-max softmax) streams.
+// Every kernel is a template on the element type: f16 = the product's mode, float = the PARITY TWIN whose arithmetic is the
+// oracle's operation for operation (srv_kernels.h).
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+
+#include <atomic>
+#include <cstdint>
+#include <string>
+
+#include "lds_attr.h"
+#include "ocr_common.h"
+#include "srv_kernels.h"
+
+namespace ocr {
+namespace srv {
+
+typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+typedef _Float16 h4v __attribute__((ext_vector_type(4)));
+typedef float f16x __attribute__((ext_vector_type(16)));
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+
+template <typename T> struct ET;
+template <> struct ET<_Float16> { static constexpr int KG = 8, BK = 64; };
+template <> struct ET<float> { static constexpr int KG = 4, BK = 32; };
+
+#define SRV_OOB 0xfffffff0u  // beyond every num_records: the lane receives zeros
+
+// one LDS-DMA instruction: lane l's 16 bytes at (rsrc base + soff + voff) -> LDS byte address lds + 16 l (lds wave-uniform).
+// Invisible to the compiler's s_waitcnt bookkeeping: the waits are counted by hand (srv_gemm_kernel).
+__device__ __forceinline__ void srv_dma16(unsigned lds, unsigned voff, v4u rsrc, unsigned soff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void srv_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+__device__ __forceinline__ unsigned srv_xcd(unsigned bid, unsigned nblk) {  // blocks that share an XCD get consecutive tiles
+  const unsigned q = nblk >> 3, r = nblk & 7, x = bid & 7, i = bid >> 3;
+  return x * q + (x < r ? x : r) + i;
+}
+
+// erf of the exact GELU: the oracle's operations in the oracle's order (the ocr_erff of the oracle's network restatement)
+__device__ __forceinline__ float srv_erff(float x) {
+  const float ax = fabsf(x);
+  const float t = 1.0f / fmaf(0.3275911f, ax, 1.0f);
+  float p = 1.061405429f;
+  p = fmaf(p, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  p = p * t;
+  const float e = ocr_expf(-(ax * ax));
+  const float r = fmaf(-p, e, 1.0f);
+  return copysignf(r, x);
+}
+__device__ __forceinline__ float srv_act(int act, float y) {
+  switch (act) {
+    case SACT_RELU: return fmaxf(y, 0.0f);
+    case SACT_GELU: { const float hx = 0.5f * y; const float z = y * 0.70710678118654752f; const float e1 = 1.0f + srv_erff(z); return hx * e1; }
+    case SACT_HSWISH: { const float t = fminf(fmaxf(y + 3.0f, 0.0f), 6.0f); const float u = y * t; return u / 6.0f; }
+    case SACT_SIGMOID: { const float e = ocr_expf(-y); const float d = 1.0f + e; return 1.0f / d; }
+    default: return y;
+  }
+}
+
+// 8 consecutive elements of a T tensor <-> 8 floats
+__device__ __forceinline__ void ld8(const _Float16* p, float (&v)[8]) {
+  const h8v t = *(const h8v*)p;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = (float)t[j];
+}
+__device__ __forceinline__ void ld8(const float* p, float (&v)[8]) {
+  const f4v a = *(const f4v*)p, b = *(const f4v*)(p + 4);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { v[j] = a[j]; v[4 + j] = b[j]; }
+}
+// f16 stores saturate at +-65504 (an inf in a tensor is a NaN in the next layer: DESIGN.md section 9, Range)
+__device__ __forceinline__ void st8(_Float16* p, const float (&v)[8]) {
+  h8v t;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) t[j] = (_Float16)__builtin_amdgcn_fmed3f(v[j], -65504.0f, 65504.0f);
+  *(h8v*)p = t;
+}
+__device__ __forceinline__ void st8(float* p, const float (&v)[8]) {
+  *(f4v*)p = f4v{v[0], v[1], v[2], v[3]};
+  *(f4v*)(p + 4) = f4v{v[4], v[5], v[6], v[7]};
+}
+
+// =================================================================================================== implicit GEMM
+template <typename T, int BM, int BN, int WM, int WN, int NS>
+struct GemmGeom {
+  static constexpr int NW = WM * WN, NT = 64 * NW;
+  static constexpr int KG = ET<T>::KG, BK = ET<T>::BK;
+  static constexpr int TN = BN / WN / 32, TM = BM / WM / 32;
+  static constexpr int WI = BN / 8 / NW, XI = BM / 8 / NW, LPS = WI + XI;
+  static constexpr unsigned STG = (unsigned)(BN + BM) * 128u;
+  static constexpr int SP = BN + 4;  // epilogue tile: floats per pixel row (+4: consecutive pixels 16 bytes apart in the bank row)
+  static constexpr unsigned LDS = (NS * STG > (unsigned)(BM * SP * 4)) ? NS * STG : (unsigned)(BM * SP * 4);
+  static_assert(BN % (32 * WN) == 0 && BM % (32 * WM) == 0, "wave tiles are whole 32 x 32 blocks");
+  static_assert((BN / 8) % NW == 0 && (BM / 8) % NW == 0, "every wave issues the same number of DMA instructions per stage");
+  static_assert(NW % 2 == 0, "the swizzle term of a lane's DMA rows must not depend on the instruction index");
+  static_assert(NT % (BN / 8) == 0, "a thread keeps its channel chunk over the rows of the store loop");
+};
+
+template <typename T, int BM, int BN, int WM, int WN, int NS>
+__global__ void __launch_bounds__(64 * WM * WN) srv_gemm_kernel(const GemmArgs a) {
+  using G = GemmGeom<T, BM, BN, WM, WN, NS>;
+  constexpr int NW = G::NW, NT = G::NT, KG = G::KG, BK = G::BK, TN = G::TN, TM = G::TM, WI = G::WI, XI = G::XI, LPS = G::LPS, SP = G::SP;
+  constexpr unsigned STG = G::STG;
+  constexpr bool HALF = sizeof(T) == 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const unsigned lds0 = (unsigned)(size_t)smem;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int wn = wave % WN, wm = wave / WN;
+  // ---- tile of this workgroup: column (n) tiles of one pixel tile are neighbours (they share the X panel in L2)
+  const unsigned nb_n = (unsigned)((a.Ncols + BN - 1) / BN);
+  const unsigned bid = srv_xcd(blockIdx.x, gridDim.x);
+  const int n0 = (int)(bid % nb_n) * BN;
+  const long m0 = (long)(bid / nb_n) * BM;
+
+  // ---- buffer descriptors
+  v4u rs_w, rs_x;
+  {
+    const unsigned long long wb = (unsigned long long)a.w, xb = (unsigned long long)a.x;
+    rs_w.x = __builtin_amdgcn_readfirstlane((unsigned)wb);
+    rs_w.y = __builtin_amdgcn_readfirstlane((unsigned)(wb >> 32));
+    rs_w.z = __builtin_amdgcn_readfirstlane((unsigned)a.w_bytes);
+    rs_w.w = 0x00020000u;
+    rs_x.x = __builtin_amdgcn_readfirstlane((unsigned)xb);
+    rs_x.y = __builtin_amdgcn_readfirstlane((unsigned)(xb >> 32));
+    rs_x.z = __builtin_amdgcn_readfirstlane((unsigned)a.x_bytes);
+    rs_x.w = 0x00020000u;
+  }
+  // ---- DMA plan of this lane.  Instruction i of a wave fills rows 8 (wave + NW i) .. + 7 of a tile, lane l -> row + (l >> 3),
+  // LDS slot l & 7; the slot holds granule (slot ^ ((row >> 1) & 7)) of the row (NW even: the XOR term is the lane's own)
+  const int gq = (lane & 7) ^ ((4 * wave + (lane >> 4)) & 7);  // source granule of this lane (pixel rows)
+  unsigned wvo[WI];
+#pragma unroll
+  for (int i = 0; i < WI; ++i) wvo[i] = (unsigned)((wave + NW * i) * 1024 + lane * 16);  // (weights: the image is stored swizzled)
+  // pixel rows of this lane
+  int iy0[XI], ix0[XI];
+  unsigned pb[XI];
+#pragma unroll
+  for (int j = 0; j < XI; ++j) {
+    const long m = m0 + 8 * (wave + NW * j) + (lane >> 3);
+    if (m >= a.M) { iy0[j] = -(1 << 28); ix0[j] = 0; pb[j] = 0; continue; }
+    if (a.x1) {
+      iy0[j] = 0; ix0[j] = 0;
+      pb[j] = (unsigned)((unsigned long long)m * (unsigned)a.Cin * sizeof(T)) + (unsigned)(gq * 16);
+    } else {
+      const int ohw = a.OH * a.OW;
+      const int n = (int)(m / ohw);
+      const int rem = (int)(m - (long)n * ohw);
+      const int oy = rem / a.OW, ox = rem - oy * a.OW;
+      iy0[j] = oy * a.SH - a.PH;
+      ix0[j] = ox * a.SW - a.PW;
+      pb[j] = (unsigned)n * (unsigned)(a.H * a.W);
+    }
+  }
+  // the tap / channel of the next K tile to issue (a K tile inside one tap: cin_shift < 0)
+  int is_kt = 0, is_ky = 0, is_kx = 0, is_c0 = 0, is_buf = 0;
+  auto issue = [&]() __attribute__((always_inline)) {
+    const unsigned st = lds0 + (unsigned)is_buf * STG;
+    const unsigned wso = (unsigned)(((unsigned long long)is_kt * (unsigned)a.Npad + (unsigned)n0) * 128ull);
+#pragma unroll
+    for (int i = 0; i < WI; ++i) srv_dma16(st + (unsigned)(wave + NW * i) * 1024u, wvo[i], rs_w, wso);
+    if (a.x1) {
+      const unsigned xso = (unsigned)is_kt * (unsigned)(BK * sizeof(T));
+#pragma unroll
+      for (int j = 0; j < XI; ++j)
+        srv_dma16(st + (unsigned)BN * 128u + (unsigned)(wave + NW * j) * 1024u, iy0[j] < 0 ? SRV_OOB : pb[j], rs_x, xso);
+    } else {
+      int ky, kx, c;
+      const int k = is_kt * BK + gq * KG;
+      if (a.cin_shift != -1) {
+        const int tap = a.cin_shift >= 0 ? (k >> a.cin_shift) : (k / a.Cin);
+        c = k - tap * a.Cin;
+        ky = tap / a.KW;
+        kx = tap - ky * a.KW;
+      } else {
+        ky = is_ky; kx = is_kx; c = is_c0 + gq * KG;
+      }
+      const bool kok = k < a.K;
+#pragma unroll
+      for (int j = 0; j < XI; ++j) {
+        const int iy = iy0[j] + ky, ix = ix0[j] + kx;
+        const bool ok = kok && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+        const unsigned off = ((pb[j] + (unsigned)(iy * a.W + ix)) * (unsigned)a.Cin + (unsigned)c) * (unsigned)sizeof(T);
+        srv_dma16(st + (unsigned)BN * 128u + (unsigned)(wave + NW * j) * 1024u, ok ? off : SRV_OOB, rs_x, 0u);
+      }
+      if (a.cin_shift == -1) {
+        is_c0 += BK;
+        if (is_c0 >= a.Cin) { is_c0 = 0; if (++is_kx == a.KW) { is_kx = 0; ++is_ky; } }
+      }
+    }
+    ++is_kt;
+    if (++is_buf == NS) is_buf = 0;
+  };
+
+  // ---- fragment addresses: row r of a 32-row block, granule (2 s + h) (f32 twin: granule g, both halves) at its swizzled slot
+  const int swz = (r >> 1) & 7;
+  f16x acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+
+  const int nkt = a.nkt;
+  // prologue: NS - 1 stages in flight
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s)
+    if (s < nkt) issue();
+  int cbuf = 0;
+  for (int kt = 0; kt < nkt; ++kt) {
+    // stage kt has landed when at most the stages issued after it are outstanding
+    if (kt + NS - 1 <= nkt) srv_wait_vm<LPS * (NS - 2)>();   // (steady state: NS - 2 younger stages in flight)
+    else srv_wait_vm<0>();                                  // (tail: fewer were issued)
+    __builtin_amdgcn_s_barrier();                           // every wave's pieces of stage kt are in LDS; stage kt - 1 is read out
+    asm volatile("" ::: "memory");
+    if (kt + NS - 1 < nkt) issue();                         // into the buffer stage kt - 1 occupied
+    const unsigned char* sw = smem + (unsigned)cbuf * STG + (unsigned)(wn * TN * 32 + r) * 128u;
+    const unsigned char* sx = smem + (unsigned)cbuf * STG + (unsigned)BN * 128u + (unsigned)(wm * TM * 32 + r) * 128u;
+    if constexpr (HALF) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const unsigned ko = (unsigned)(((2 * s + h) ^ swz) * 16);
+        h8v fa[TN], fb[TM];
+#pragma unroll
+        for (int i = 0; i < TN; ++i) fa[i] = *(const h8v*)(sw + i * 4096 + ko);
+#pragma unroll
+        for (int j = 0; j < TM; ++j) fb[j] = *(const h8v*)(sx + j * 4096 + ko);
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+          for (int j = 0; j < TM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        const unsigned ko = (unsigned)((g ^ swz) * 16);
+        f4v fa[TN], fb[TM];
+#pragma unroll
+        for (int i = 0; i < TN; ++i) fa[i] = *(const f4v*)(sw + i * 4096 + ko);
+#pragma unroll
+        for (int j = 0; j < TM; ++j) fb[j] = *(const f4v*)(sx + j * 4096 + ko);
+        // v_mfma_f32_32x32x2_f32: lane half h supplies k = h; two instructions per granule, k ascending
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+          for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int j = 0; j < TM; ++j) {
+              const float av = h ? fa[i][2 * e + 1] : fa[i][2 * e];
+              const float bv = h ? fb[j][2 * e + 1] : fb[j][2 * e];
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+            }
+      }
+    }
+    if (++cbuf == NS) cbuf = 0;
+  }
+  // ---- epilogue: accumulators -> f32 LDS tile [pixel][channel] -> whole 16-byte chunks of pixel rows
+  __syncthreads();  // (no DMA is outstanding: the last iteration waited for vmcnt(0))
+  float* const tile = (float*)smem;
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        // register 4 q + e of lane (r, h) = channel 8 q + 4 h + e of the block's 32, pixel r
+        float* d = tile + (wm * TM * 32 + j * 32 + r) * SP + wn * TN * 32 + i * 32 + 8 * q + 4 * h;
+        *(f4v*)d = f4v{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+      }
+  __syncthreads();
+  constexpr int CP = BN / 8;  // 8-channel chunks per pixel row of the tile
+  const int ch = tid % CP;
+  const int n = n0 + 8 * ch;
+  const int ncols_store = a.deconv ? a.Ncols : a.Cs_out;
+  if (n >= ncols_store) return;
+  float pbias[8], pscale[8], pshift[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    pbias[e] = a.bias ? a.bias[n + e] : 0.f;
+    pscale[e] = a.scale ? a.scale[n + e] : 1.f;
+    pshift[e] = a.scale ? a.shift[n + e] : 0.f;
+  }
+  int dq = 0, co = n;
+  if (a.deconv) { dq = n / a.CoutD; co = n - dq * a.CoutD; }
+  for (int p = tid / CP; p < BM; p += NT / CP) {
+    const long m = m0 + p;
+    if (m >= a.M) break;
+    float v[8];
+    {
+      const f4v lo = *(const f4v*)(tile + p * SP + 8 * ch), hi = *(const f4v*)(tile + p * SP + 8 * ch + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
+    }
+    if (a.bias) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = v[e] + pbias[e];
+    }
+    if (a.scale) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float t = v[e] * pscale[e]; v[e] = t + pshift[e]; }
+    }
+    long opix = m;
+    if (a.res_up == 2 || a.deconv) {
+      const int ohw = a.OH * a.OW;
+      const int ni = (int)(m / ohw);
+      const int rem = (int)(m - (long)ni * ohw);
+      const int oy = rem / a.OW, ox = rem - oy * a.OW;
+      if (a.deconv) opix = ((long)ni * (2 * a.OH) + 2 * oy + (dq >> 1)) * (2 * a.OW) + 2 * ox + (dq & 1);
+      if (a.res_up == 2) {
+        const long rp = ((long)ni * (a.OH >> 1) + (oy >> 1)) * (a.OW >> 1) + (ox >> 1);
+        float rv[8];
+        ld8((const T*)a.res + rp * a.Cs_out + n, rv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = v[e] + rv[e];
+      }
+    }
+    if (a.res_up == 1) {
+      float rv[8];
+      ld8((const T*)a.res + m * a.Cs_out + n, rv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = v[e] + rv[e];
+    }
+    if (a.act != SACT_NONE) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = srv_act(a.act, v[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      if (n + e >= a.Ncols) v[e] = 0.f;  // pad channels hold zeros
+    if (a.out_f32) st8((float*)a.y + opix * a.Cs_out + co, v);
+    else st8((T*)a.y + opix * a.Cs_out + co, v);
+  }
+}
+
+// ---- tile configurations (autotuned per layer at bind time: srv_net.hip)
+struct GemmCfg { const char* name; int bm, bn, nt; unsigned lds_h, lds_f; };
+#define SRV_CFGS(X)          \
+  X(0, 256, 128, 2, 4, 3)    \
+  X(1, 128, 128, 2, 2, 2)    \
+  X(2, 256, 64, 4, 2, 3)     \
+  X(3, 128, 64, 2, 2, 2)     \
+  X(4, 128, 256, 1, 8, 3)    \
+  X(5, 128, 128, 2, 4, 3)
+static const GemmCfg g_cfgs[] = {
+#define X(id, BM, BN, WM, WN, NS) {#BM "x" #BN "/" #WM "x" #WN "/s" #NS, BM, BN, 64 * WM * WN, GemmGeom<_Float16, BM, BN, WM, WN, NS>::LDS, GemmGeom<float, BM, BN, WM, WN, NS>::LDS},
+    SRV_CFGS(X)
+#undef X
+};
+int gemm_num_configs() { return (int)(sizeof(g_cfgs) / sizeof(g_cfgs[0])); }
+const char* gemm_config_name(int cfg) { return cfg >= 0 && cfg < gemm_num_configs() ? g_cfgs[cfg].name : "?"; }
+
+template <typename T, int BM, int BN, int WM, int WN, int NS>
+static bool gemm_go(const GemmArgs& a, hipStream_t s, bool query, std::string& err) {
+  using G = GemmGeom<T, BM, BN, WM, WN, NS>;
+  auto kern = srv_gemm_kernel<T, BM, BN, WM, WN, NS>;
+  static LdsAttrMemo memo;
+  if (G::LDS > 64 * 1024 && !raise_dynamic_lds((const void*)kern, (int)G::LDS, memo)) { err = "dynamic LDS attribute refused"; return false; }
+  if (query) return true;
+  const long nb = ((a.M + BM - 1) / BM) * ((a.Ncols + BN - 1) / BN);
+  if (nb <= 0 || nb > 0x7fffffffL) { err = "grid"; return false; }
+  hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(G::NT), G::LDS, s, a);
+  return true;
+}
+static bool gemm_dispatch(const GemmArgs& a, bool half, int cfg, hipStream_t s, bool query, std::string& err) {
+  // shape contract of the kernel
+  if (a.x_bytes >= 0xfffffff0ull || a.w_bytes >= 0xfffffff0ull) { err = "tensor beyond the 4 GB a buffer descriptor spans"; return false; }
+  if (a.Npad % 256 || a.Ncols > a.Npad || a.nkt < 1) { err = "weight image shape"; return false; }
+  switch (cfg * 2 + (half ? 1 : 0)) {
+#define X(id, BM, BN, WM, WN, NS)                                                   \
+    case id * 2 + 1: return gemm_go<_Float16, BM, BN, WM, WN, NS>(a, s, query, err); \
+    case id * 2: return gemm_go<float, BM, BN, WM, WN, NS>(a, s, query, err);
+    SRV_CFGS(X)
+#undef X
+  }
+  err = "no such tile configuration";
+  return false;
+}
+bool gemm_config_ok(const GemmArgs& a, bool half, int cfg) {
+  std::string e;
+  return gemm_dispatch(a, half, cfg, nullptr, true, e);
+}
+bool launch_gemm(const GemmArgs& a, bool half, int cfg, hipStream_t s, std::string& err) { return gemm_dispatch(a, half, cfg, s, false, err); }
+
+// =================================================================================================== streaming kernels
+template <typename T>
+__global__ void __launch_bounds__(256) pack_input_kernel(const float* __restrict__ x, T* __restrict__ y, long pixels) {
+  const long p = (long)blockIdx.x * 256 + threadIdx.x;
+  if (p >= pixels) return;
+  float v[8] = {x[3 * p], x[3 * p + 1], x[3 * p + 2], 0.f, 0.f, 0.f, 0.f, 0.f};
+  st8(y + 8 * p, v);
+}
+void launch_pack_input(const float* x, void* y, long pixels, bool half, hipStream_t s) {
+  const unsigned nb = (unsigned)((pixels + 255) / 256);
+  if (half) hipLaunchKernelGGL(pack_input_kernel<_Float16>, dim3(nb), dim3(256), 0, s, x, (_Float16*)y, pixels);
+  else hipLaunchKernelGGL(pack_input_kernel<float>, dim3(nb), dim3(256), 0, s, x, (float*)y, pixels);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) pool_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W, int Cs, int OH, int OW, int kh,
+                                                   int kw, int sh, int sw, int ph, int pw, int is_max) {
+  const int C8 = Cs >> 3;
+  const long total = (long)N * OH * OW * C8;
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= total) return;
+  const int c = (int)(t % C8);
+  long p = t / C8;
+  const int ox = (int)(p % OW); p /= OW;
+  const int oy = (int)(p % OH);
+  const int n = (int)(p / OH);
+  float acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = is_max ? -INFINITY : 0.f;
+  int cnt = 0;
+  for (int dy = 0; dy < kh; ++dy)
+    for (int dx = 0; dx < kw; ++dx) {
+      const int iy = oy * sh - ph + dy, ix = ox * sw - pw + dx;
+      if (iy < 0 || ix < 0 || iy >= H || ix >= W) continue;
+      float v[8];
+      ld8(x + (((long)n * H + iy) * W + ix) * Cs + 8 * c, v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] = is_max ? fmaxf(acc[e], v[e]) : acc[e] + v[e];
+      ++cnt;
+    }
+  if (!is_max) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = acc[e] / (float)cnt;
+  }
+  st8(y + (((long)n * OH + oy) * OW + ox) * Cs + 8 * c, acc);
+}
+void launch_pool(const void* x, void* y, int N, int H, int W, int Cs, int OH, int OW, int kh, int kw, int sh, int sw, int ph, int pw, bool is_max,
+                 bool half, hipStream_t s) {
+  const long total = (long)N * OH * OW * (Cs >> 3);
+  const unsigned nb = (unsigned)((total + 255) / 256);
+  if (half) hipLaunchKernelGGL(pool_kernel<_Float16>, dim3(nb), dim3(256), 0, s, (const _Float16*)x, (_Float16*)y, N, H, W, Cs, OH, OW, kh, kw, sh, sw, ph, pw, is_max ? 1 : 0);
+  else hipLaunchKernelGGL(pool_kernel<float>, dim3(nb), dim3(256), 0, s, (const float*)x, (float*)y, N, H, W, Cs, OH, OW, kh, kw, sh, sw, ph, pw, is_max ? 1 : 0);
+}
+
+struct CatArgs { const void* src[4]; int up[4]; int nsrc, cs; };
+template <typename T>
+__global__ void __launch_bounds__(256) concat_up_kernel(const CatArgs a, T* __restrict__ y, int N, int OH, int OW) {
+  const int C8 = (a.cs * a.nsrc) >> 3, c8s = a.cs >> 3;
+  const long total = (long)N * OH * OW * C8;
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= total) return;
+  const int c = (int)(t % C8);
+  long p = t / C8;
+  const int ox = (int)(p % OW); p /= OW;
+  const int oy = (int)(p % OH);
+  const int n = (int)(p / OH);
+  const int j = c / c8s, cc = c - j * c8s;
+  const int u = a.up[j], sh_ = OH / u, sw_ = OW / u;
+  const T* src = (const T*)a.src[j] + (((long)n * sh_ + oy / u) * sw_ + ox / u) * a.cs + 8 * cc;
+  float v[8];
+  ld8(src, v);
+  st8(y + t * 8, v);
+}
+void launch_concat_up(const void* const src[4], const int up[4], int nsrc, int cs, void* y, int N, int OH, int OW, bool half, hipStream_t s) {
+  CatArgs a;
+  for (int j = 0; j < 4; ++j) { a.src[j] = j < nsrc ? src[j] : nullptr; a.up[j] = j < nsrc ? up[j] : 1; }
+  a.nsrc = nsrc; a.cs = cs;
+  const long total = (long)N * OH * OW * ((cs * nsrc) >> 3);
+  const unsigned nb = (unsigned)((total + 255) / 256);
+  if (half) hipLaunchKernelGGL(concat_up_kernel<_Float16>, dim3(nb), dim3(256), 0, s, a, (_Float16*)y, N, OH, OW);
+  else hipLaunchKernelGGL(concat_up_kernel<float>, dim3(nb), dim3(256), 0, s, a, (float*)y, N, OH, OW);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) addpos_kernel(const T* __restrict__ x, const float* __restrict__ pos, T* __restrict__ y, long pixels, int hw, int Cs) {
+  const int C8 = Cs >> 3;
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= pixels * C8) return;
+  const int c = (int)(t % C8);
+  const long p = t / C8;
+  const int q = (int)(p % hw);
+  float v[8], g[8];
+  ld8(x + t * 8, v);
+  ld8(pos + (long)q * Cs + 8 * c, g);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = v[e] + g[e];
+  st8(y + t * 8, v);
+}
+void launch_addpos(const void* x, const float* pos, void* y, long pixels, int hw, int Cs, bool half, hipStream_t s) {
+  const unsigned nb = (unsigned)((pixels * (Cs >> 3) + 255) / 256);
+  if (half) hipLaunchKernelGGL(addpos_kernel<_Float16>, dim3(nb), dim3(256), 0, s, (const _Float16*)x, pos, (_Float16*)y, pixels, hw, Cs);
+  else hipLaunchKernelGGL(addpos_kernel<float>, dim3(nb), dim3(256), 0, s, (const float*)x, pos, (float*)y, pixels, hw, Cs);
+}
+
+// ---- layer norm.  f16: a wave per row, lane l owns granules l, l + 64, ... (f32 arithmetic, wave reductions);
+// f32 twin: a thread per row, the oracle's sequential sums
+__global__ void __launch_bounds__(256) layernorm_h_kernel(const _Float16* __restrict__ x, const float* __restrict__ g, const float* __restrict__ b,
+                                                          _Float16* __restrict__ y, long rows, int C, float eps) {
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const int G = C >> 3;  // granules per row (<= 128)
+  float v[2][8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int gi = lane + 64 * i;
+    if (gi < G) {
+      ld8(x + row * C + 8 * gi, v[i]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += v[i][e];
+    }
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+  const float mean = s / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+    if (lane + 64 * i < G) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mean; q = fmaf(d, d, q); }
+    }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) q += __shfl_xor(q, o);
+  const float rstd = 1.0f / sqrtf(q / (float)C + eps);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int gi = lane + 64 * i;
+    if (gi < G) {
+      float gg[8], bb[8], o[8];
+      ld8(g + 8 * gi, gg);
+      ld8(b + 8 * gi, bb);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (v[i][e] - mean) * rstd * gg[e] + bb[e];
+      st8(y + row * C + 8 * gi, o);
+    }
+  }
+}
+__global__ void __launch_bounds__(64) layernorm_f_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ b,
+                                                         float* __restrict__ y, long rows, int C, float eps) {
+  const long row = (long)blockIdx.x * 64 + threadIdx.x;
+  if (row >= rows) return;
+  const float* src = x + row * C;
+  float* dst = y + row * C;
+  float s = 0.f;
+  for (int c = 0; c < C; ++c) s = s + src[c];
+  const float mean = s / (float)C;
+  float v = 0.f;
+  for (int c = 0; c < C; ++c) { const float xm = src[c] - mean; v = fmaf(xm, xm, v); }
+  const float var = v / (float)C;
+  const float rstd = 1.0f / sqrtf(var + eps);
+  for (int c = 0; c < C; ++c) {
+    const float xm = src[c] - mean;
+    float t = xm * rstd;
+    t = t * g[c];
+    dst[c] = t + b[c];
+  }
+}
+void launch_layernorm(const void* x, const float* g, const float* b, void* y, long rows, int C, float eps, bool half, hipStream_t s) {
+  if (half) hipLaunchKernelGGL(layernorm_h_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, (const _Float16*)x, g, b, (_Float16*)y, rows, C, eps);
+  else hipLaunchKernelGGL(layernorm_f_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, s, (const float*)x, g, b, (float*)y, rows, C, eps);
+}
+
+// ---- the DB head's last layer (64 -> 1, 2x2 stride 2, + bias, sigmoid): a thread per input pixel, four dot products
+template <typename T>
+__global__ void __launch_bounds__(256) deconv_map_kernel(const T* __restrict__ x, const float* __restrict__ w4, float bias, float* __restrict__ prob, int N,
+                                                         int H, int W, int Cs) {
+  const long p = (long)blockIdx.x * 256 + threadIdx.x;
+  if (p >= (long)N * H * W) return;
+  const int ix = (int)(p % W);
+  const long q = p / W;
+  const int iy = (int)(q % H);
+  const int n = (int)(q / H);
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int c = 0; c < Cs; c += 8) {
+    float v[8];
+    ld8(x + p * Cs + c, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t] = fmaf(v[e], w4[t * Cs + c + e], acc[t]);
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const float yv = acc[t] + bias;
+    prob[((long)n * 2 * H + 2 * iy + (t >> 1)) * (2 * W) + 2 * ix + (t & 1)] = srv_act(SACT_SIGMOID, yv);
+  }
+}
+void launch_deconv_to_map(const void* x, const float* w4, float bias, float* prob, int N, int H, int W, int Cs, bool half, hipStream_t s) {
+  const unsigned nb = (unsigned)(((long)N * H * W + 255) / 256);
+  if (half) hipLaunchKernelGGL(deconv_map_kernel<_Float16>, dim3(nb), dim3(256), 0, s, (const _Float16*)x, w4, bias, prob, N, H, W, Cs);
+  else hipLaunchKernelGGL(deconv_map_kernel<float>, dim3(nb), dim3(256), 0, s, (const float*)x, w4, bias, prob, N, H, W, Cs);
+}
+
+// ---- CTC tail: a wave per row; arg max = first maximum of the logits, its probability 1 / sum exp(x - max)
+__global__ void __launch_bounds__(256) argmax_softmax_kernel(const float* __restrict__ logits, long rows, int C, int ld, int* __restrict__ amax,
+                                                             float* __restrict__ pmax) {
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const float* x = logits + row * ld;
+  float m = -INFINITY;
+  int mi = 0x7fffffff;
+  for (int c = lane; c < C; c += 64) {
+    const float v = x[c];
+    if (v > m) { m = v; mi = c; }
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    const float om = __shfl_xor(m, o);
+    const int oi = __shfl_xor(mi, o);
+    if (om > m || (om == m && oi < mi)) { m = om; mi = oi; }
+  }
+  float s = 0.f;
+  for (int c = lane; c < C; c += 64) s += ocr_expf(x[c] - m);
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+  if (lane == 0) { amax[row] = mi; pmax[row] = 1.0f / s; }
+}
+void launch_argmax_softmax(const float* logits, long rows, int C, int ld, int* amax, float* pmax, hipStream_t s) {
+  hipLaunchKernelGGL(argmax_softmax_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, logits, rows, C, ld, amax, pmax);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) to_f32_kernel(const T* __restrict__ x, float* __restrict__ y, long pixels, int Cs, int C) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= pixels * C) return;
+  const long p = t / C;
+  const int c = (int)(t - p * C);
+  y[t] = (float)x[p * Cs + c];
+}
+void launch_to_f32(const void* x, float* y, long pixels, int Cs, int C, bool half, hipStream_t s) {
+  const unsigned nb = (unsigned)((pixels * C + 255) / 256);
+  if (half) hipLaunchKernelGGL(to_f32_kernel<_Float16>, dim3(nb), dim3(256), 0, s, (const _Float16*)x, y, pixels, Cs, C);
+  else hipLaunchKernelGGL(to_f32_kernel<float>, dim3(nb), dim3(256), 0, s, (const float*)x, y, pixels, Cs, C);
+}
+
+// =================================================================================================== attention
+// f32 twin: a thread per (line, head, query), the oracle's loops (three passes over the keys: maximum, sum, weighted values -
+// a score is recomputed, by the same fma chain, instead of kept)
+__global__ void __launch_bounds__(64) attn_f_kernel(const float* __restrict__ qkv, float* __restrict__ out, int N, int T, int heads, float scale, int gw,
+                                                    int lh, int lw) {
+  constexpr int HD = 32;
+  const long id = (long)blockIdx.x * 64 + threadIdx.x;
+  if (id >= (long)N * heads * T) return;
+  const int t = (int)(id % T);
+  const int hh = (int)((id / T) % heads);
+  const int n = (int)(id / ((long)T * heads));
+  const int D = heads * HD;
+  const float* base = qkv + (long)n * T * 3 * D;
+  float q[HD];
+  for (int d = 0; d < HD; ++d) q[d] = base[(long)t * 3 * D + hh * HD + d] * scale;
+  const int qy = t / gw, qx = t % gw;
+  auto allowed = [&](int u) {
+    if (lh <= 0) return true;
+    const int dy = u / gw - qy, dx = u % gw - qx;
+    return dy >= -(lh / 2) && dy <= lh / 2 && dx >= -(lw / 2) && dx <= lw / 2;
+  };
+  auto score = [&](int u) {
+    const float* kr = base + (long)u * 3 * D + D + hh * HD;
+    float acc = 0.f;
+    for (int d = 0; d < HD; ++d) acc = fmaf(q[d], kr[d], acc);
+    return acc;
+  };
+  float m = -INFINITY;
+  for (int u = 0; u < T; ++u) if (allowed(u)) m = fmaxf(m, score(u));
+  float sum = 0.f;
+  for (int u = 0; u < T; ++u) if (allowed(u)) sum = sum + ocr_expf(score(u) - m);
+  float acc[HD];
+  for (int d = 0; d < HD; ++d) acc[d] = 0.f;
+  for (int u = 0; u < T; ++u) {
+    if (!allowed(u)) continue;
+    const float e = ocr_expf(score(u) - m);
+    const float p = e / sum;
+    const float* vr = base + (long)u * 3 * D + 2 * D + hh * HD;
+    for (int d = 0; d < HD; ++d) acc[d] = fmaf(p, vr[d], acc[d]);
+  }
+  float* dst = out + ((long)n * T + t) * D + hh * HD;
+  for (int d = 0; d < HD; ++d) dst[d] = acc[d];
+}
+
+// f16: one workgroup per (line, head); K and V of the pair in LDS ([T + 32][32] halfs each; K rows XOR-swizzled by
+// (row >> 2) & 3 for conflict-free ds_read_b128, V rows linear for ds_read_b64_tr_b16), a wave per tile of 32 queries of one grid row.
+template <int NWV>
+__global__ void __launch_bounds__(64 * NWV) attn_h_kernel(const _Float16* __restrict__ qkv, _Float16* __restrict__ out, int T, int heads, float scale_log2e,
+                                                          int gh, int gw, int lh, int lw) {
+  constexpr int HD = 32;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int n = blockIdx.x / heads, hh = blockIdx.x % heads;
+  const int D = heads * HD;
+  const _Float16* base = qkv + (long)n * T * 3 * D + hh * HD;
+  unsigned char* sK = smem;
+  unsigned char* sV = smem + (size_t)(T + 32) * 64;
+  // ---- K, V -> LDS (16-byte chunks; the 32 rows past T hold zeros: a masked key's probability is 0, and 0 x garbage must not be NaN)
+  for (int i = tid; i < (T + 32) * 4; i += 64 * NWV) {
+    const int t = i >> 2, c = i & 3;
+    h8v kv = {0, 0, 0, 0, 0, 0, 0, 0}, vv = kv;
+    if (t < T) {
+      kv = *(const h8v*)(base + (long)t * 3 * D + D + 8 * c);
+      vv = *(const h8v*)(base + (long)t * 3 * D + 2 * D + 8 * c);
+    }
+    *(h8v*)(sK + t * 64 + ((c ^ ((t >> 2) & 3)) << 4)) = kv;
+    *(h8v*)(sV + t * 64 + (c << 4)) = vv;
+  }
+  __syncthreads();
+  const int segs = (gw + 31) >> 5;
+  const int nq = gh * segs;
+  const int hwy = lh >> 1, hwx = lw >> 1;
+  // transposed-read lane geometry (T10): group G = lane >> 4 -> d block 16 (G & 1), key sub-block 4 (G >> 1); lane 4 q + p of the group
+  // supplies the address of row q, columns 4 p .. 4 p + 3
+  const int trq = (lane & 15) >> 2, trp = lane & 3;
+  const unsigned tr_off = (unsigned)((4 * h + trq) * 64 + (16 * ((lane >> 4) & 1) + 4 * trp) * 2);
+  for (int qt = wave; qt < nq; qt += NWV) {
+    const int qy = qt / segs, qxs = (qt - qy * segs) << 5;
+    const int qx = qxs + r;
+    const bool qok = qx < gw;
+    const int tq = qy * gw + (qok ? qx : gw - 1);
+    // Q fragments (B operand of S^T = K Q^T): lane (query r, half h), step s: d = 16 s + 8 h .. + 7; pre-scaled by scale * log2(e)
+    h8v qf[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const h8v t8 = *(const h8v*)(base + (long)tq * 3 * D + 16 * s + 8 * h);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) qf[s][e] = (_Float16)((float)t8[e] * scale_log2e);
+    }
+    f16x o;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[e] = 0.f;
+    float mrun = -INFINITY, lrun = 0.f;
+    const int ky0 = lh > 0 ? max(qy - hwy, 0) : 0, ky1 = lh > 0 ? min(qy + hwy, gh - 1) : gh - 1;
+    for (int ky = ky0; ky <= ky1; ++ky)
+      for (int kxs = 0; kxs < gw; kxs += 32) {
+        if (lh > 0 && (kxs > qxs + 31 + hwx || kxs + 31 < qxs - hwx)) continue;  // (wave-uniform: the tile lies outside every query's window)
+        const int tk0 = ky * gw + kxs;
+        // ---- S^T = K Q^T: A = K rows (key r), 2 steps over d
+        f16x sacc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sacc[e] = 0.f;
+        {
+          const int tk = tk0 + r;  // (< T + 32: rows past the grid row's end are other tokens or the zero rows; masked below)
+          const unsigned char* kr = sK + tk * 64;
+          const int ksw = (tk >> 2) & 3;
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+            const h8v kf = *(const h8v*)(kr + (((2 * s + h) ^ ksw) << 4));
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], sacc, 0, 0, 0);
+          }
+        }
+        // ---- mask, running maximum (register i of lane (q, h) = key 8 (i >> 2) + 4 h + (i & 3) of the tile)
+        float mt = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int kx = kxs + 8 * (i >> 2) + 4 * h + (i & 3);
+          const bool ok = kx < gw && (lh <= 0 || (unsigned)(kx - qx + hwx) <= (unsigned)(2 * hwx));
+          sacc[i] = ok ? sacc[i] : -INFINITY;
+          mt = fmaxf(mt, sacc[i]);
+        }
+        mt = fmaxf(mt, __shfl_xor(mt, 32));
+        const float mnew = fmaxf(mrun, mt);
+        const float muse = mnew == -INFINITY ? 0.f : mnew;
+        const float alpha = __builtin_amdgcn_exp2f(mrun - muse);
+        mrun = mnew;
+        float ls = 0.f;
+        h8v pf[2];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const float p = __builtin_amdgcn_exp2f(sacc[i] - muse);
+          ls += p;
+          pf[i >> 3][i & 7] = (_Float16)p;
+        }
+        lrun = lrun * alpha + ls;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[e] *= alpha;
+        // ---- O^T += V^T P^T: A = V^T (row d = r; element j of step s = key 16 s + 8 (j >> 2) + 4 h + (j & 3)), B = the P registers as they are
+        const unsigned char* vb = sV + (size_t)tk0 * 64 + tr_off;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          h4v v0, v1;
+          asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v0) : "v"((unsigned)(size_t)(vb + (16 * s) * 64)) : "memory");
+          asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v1) : "v"((unsigned)(size_t)(vb + (16 * s + 8) * 64)) : "memory");
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+          const h8v vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+          o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[s], o, 0, 0, 0);
+        }
+      }
+    // ---- normalise and store: register i of lane (q, h) = d 8 (i >> 2) + 4 h + (i & 3)
+    const float ltot = lrun + __shfl_xor(lrun, 32);
+    const float inv = 1.0f / ltot;
+    if (qok) {
+      _Float16* dst = out + ((long)n * T + tq) * D + hh * HD + 4 * h;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        h4v t4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) t4[e] = (_Float16)__builtin_amdgcn_fmed3f(o[4 * g + e] * inv, -65504.0f, 65504.0f);
+        *(h4v*)(dst + 8 * g) = t4;
+      }
+    }
+  }
+}
+
+bool launch_attention(const void* qkv, void* out, int N, int T, int heads, int hd, float scale, int gh, int gw, int lh, int lw, bool half,
+                      hipStream_t s, std::string& err) {
+  if (hd != 32) { err = "attention: head dimension must be 32"; return false; }
+  if (gh * gw != T) { err = "attention: token grid does not match the token count"; return false; }
+  if (!half) {
+    const long total = (long)N * heads * T;
+    hipLaunchKernelGGL(attn_f_kernel, dim3((unsigned)((total + 63) / 64)), dim3(64), 0, s, (const float*)qkv, (float*)out, N, T, heads, scale, gw, lh, lw);
+    return true;
+  }
+  const size_t lds = (size_t)(T + 32) * 64 * 2;
+  if (lds > 160 * 1024) { err = "attention: K and V of a line do not fit LDS"; return false; }
+  const float sl = scale * 1.44269504088896341f;
+  const int segs = (gw + 31) / 32, nq = gh * segs;
+  static LdsAttrMemo memo8, memo4;
+  if (nq >= 16) {
+    if (lds > 64 * 1024 && !raise_dynamic_lds((const void*)attn_h_kernel<8>, (int)lds, memo8)) { err = "attention: dynamic LDS attribute refused"; return false; }
+    hipLaunchKernelGGL(attn_h_kernel<8>, dim3((unsigned)(N * heads)), dim3(512), lds, s, (const _Float16*)qkv, (_Float16*)out, T, heads, sl, gh, gw, lh, lw);
+  } else {
+    if (lds > 64 * 1024 && !raise_dynamic_lds((const void*)attn_h_kernel<4>, (int)lds, memo4)) { err = "attention: dynamic LDS attribute refused"; return false; }
+    hipLaunchKernelGGL(attn_h_kernel<4>, dim3((unsigned)(N * heads)), dim3(256), lds, s, (const _Float16*)qkv, (_Float16*)out, T, heads, sl, gh, gw, lh, lw);
+  }
+  return true;
+}
+
+}  // namespace srv
+}  // namespace ocr

@@ -1,0 +1,624 @@
+// Plan executor of the server networks: see srv_net.h.  Host code only (the kernels are srv_kernels.hip).
+#include "srv_net.h"
+
+#include <algorithm>
+#include <array>
+#include <cmath>
+#include <cstring>
+#include <sstream>
+
+#include "hip_guard.h"
+
+namespace ocr {
+
+namespace {
+std::vector<std::string> split(const std::string& s, char sep) {
+  std::vector<std::string> r;
+  std::stringstream ss(s);
+  std::string t;
+  while (std::getline(ss, t, sep)) r.push_back(t);
+  return r;
+}
+inline int up8(int c) { return (c + 7) & ~7; }
+
+// Weight image of srv_gemm_kernel: [K tile][row n, Npad of them][8 granules] with granule g of row n at slot g ^ ((n >> 1) & 7) -
+// the LDS image of a tile is a straight copy of 128 bytes per row, and a fragment read finds (row, granule) conflict-free.
+template <typename T>
+std::vector<T> weight_image(const std::vector<float>& wnk, int ncols, int K, int npad, int& nkt) {
+  constexpr int KG = 16 / (int)sizeof(T), BK = 8 * KG;
+  nkt = (K + BK - 1) / BK;
+  std::vector<T> img((size_t)nkt * npad * BK, (T)0.f);
+  for (int n = 0; n < ncols; ++n)
+    for (int k = 0; k < K; ++k) {
+      const int kt = k / BK, kk = k % BK, g = kk / KG, e = kk % KG;
+      const int slot = g ^ ((n >> 1) & 7);
+      img[(((size_t)kt * npad + n) * 8 + slot) * KG + e] = (T)wnk[(size_t)n * K + k];
+    }
+  return img;
+}
+}  // namespace
+
+SrvNet::~SrvNet() {
+  for (void* p : dev_allocs_) (void)g_free(p);
+  if (arena_) (void)g_free(arena_);
+  for (auto& p : ev_pending_) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+}
+
+void* SrvNet::upload_bytes(const void* p, size_t n) {
+  void* d = nullptr;
+  if (g_malloc(&d, std::max<size_t>(n, 16)) != hipSuccess) return nullptr;
+  if (n && g_memcpy(d, p, n, hipMemcpyHostToDevice) != hipSuccess) { (void)g_free(d); return nullptr; }
+  dev_allocs_.push_back(d);
+  return d;
+}
+const float* SrvNet::upload_f32(const std::vector<float>& v) { return (const float*)upload_bytes(v.data(), v.size() * sizeof(float)); }
+
+bool SrvNet::parse(const char* text, std::string& err) {
+  std::stringstream ss(text);
+  std::string line;
+  while (std::getline(ss, line)) {
+    if (line.empty() || line[0] == '#') continue;
+    auto toks = split(line, ' ');
+    if (toks[0] == "plan") {
+      for (auto& t : toks)
+        if (t.rfind("ntensors=", 0) == 0) ntensors_ = atoi(t.c_str() + 9);
+      continue;
+    }
+    Op op;
+    op.kind = toks[0];
+    static const char* kinds[] = {"conv", "linear", "deconv", "pool", "concat", "ew", "ln", "attn", "output"};
+    if (std::find_if(std::begin(kinds), std::end(kinds), [&](const char* k) { return op.kind == k; }) == std::end(kinds)) {
+      err = "server plan: unknown op " + op.kind;
+      return false;
+    }
+    for (size_t i = 1; i < toks.size(); ++i) {
+      const auto eq = toks[i].find('=');
+      if (eq == std::string::npos) { err = "server plan: bad token " + toks[i]; return false; }
+      const std::string k = toks[i].substr(0, eq), v = toks[i].substr(eq + 1);
+      if (k == "ep") {
+        for (auto& st : split(v, '|')) {
+          const auto c = st.find(':');
+          Stage s;
+          s.kind = st.substr(0, c);
+          auto args = split(st.substr(c + 1), ',');
+          if (s.kind == "bias" || s.kind == "addpos") s.a0 = args[0];
+          else if (s.kind == "bn") { s.a0 = args[0]; s.a1 = args[1]; s.a2 = args[2]; s.a3 = args[3]; s.f = strtof(args[4].c_str(), nullptr); }
+          else if (s.kind == "act") s.a0 = args[0];
+          else if (s.kind == "addt") s.tid = atoi(args[0].c_str());
+          else if (s.kind == "addup") { s.tid = atoi(args[0].c_str()); s.up = atoi(args[1].c_str()); }
+          else { err = "server plan: unknown stage " + s.kind; return false; }
+          op.ep.push_back(s);
+        }
+      } else if (k == "i" && op.kind == "concat") {
+        for (auto& t : split(v, ',')) op.ins.push_back(atoi(t.c_str()));
+      } else if (k == "up") {
+        for (auto& t : split(v, ',')) op.ups.push_back(atoi(t.c_str()));
+      } else {
+        op.kv[k] = v;
+      }
+    }
+    if (op.kind == "output") out_tid_ = op.geti("i");
+    ops_.push_back(op);
+  }
+  if (ntensors_ <= 0 || out_tid_ < 0) { err = "server plan: missing header or output"; return false; }
+  return true;
+}
+
+// Resolves an op's parameters into device images.  The epilogue a GEMM launch can carry is, in this order, each part optional:
+// bias | batch norm (scale, shift: the operations of the oracle's parameter resolution) | addt or addup | act.
+bool SrvNet::prepare_op(Op& op, const WeightMap& W, std::string& err) {
+  auto need = [&](const std::string& n) -> const HostTensor* {
+    auto it = W.find(n);
+    if (it == W.end()) { err = "missing parameter " + n; return nullptr; }
+    return &it->second;
+  };
+  const bool gemm = op.kind == "conv" || op.kind == "linear" || op.kind == "deconv";
+  if (gemm) {
+    const HostTensor* w = need(op.kv["w"]);
+    if (!w) return false;
+    const int cin = op.geti("cin"), cout = op.geti("cout");
+    const int cin_s = up8(cin);
+    op.cin_s = cin_s;
+    int K = 0;
+    std::vector<float> wnk;
+    if (op.kind == "conv") {
+      const int kh = op.geti("kh"), kw = op.geti("kw");
+      if ((int)w->numel() != cout * cin * kh * kw) { err = "parameter " + op.kv["w"] + " has the wrong size"; return false; }
+      K = kh * kw * cin_s;
+      op.ncols = cout;
+      wnk.assign((size_t)cout * K, 0.f);
+      for (int o = 0; o < cout; ++o)
+        for (int c = 0; c < cin; ++c)
+          for (int y = 0; y < kh; ++y)
+            for (int x = 0; x < kw; ++x) wnk[(size_t)o * K + (size_t)(y * kw + x) * cin_s + c] = w->data[(((size_t)o * cin + c) * kh + y) * kw + x];
+    } else if (op.kind == "linear") {
+      if ((int)w->numel() != cin * cout) { err = "parameter " + op.kv["w"] + " has the wrong size"; return false; }
+      K = cin_s;
+      op.ncols = cout;
+      wnk.assign((size_t)cout * K, 0.f);
+      for (int c = 0; c < cin; ++c)
+        for (int o = 0; o < cout; ++o) wnk[(size_t)o * K + c] = w->data[(size_t)c * cout + o];
+    } else {  // deconv 2x2 s2: [Cin][Cout][2][2]
+      if ((int)w->numel() != cin * cout * 4) { err = "parameter " + op.kv["w"] + " has the wrong size"; return false; }
+      K = cin_s;
+      if (cout == 1) {  // the DB head's last layer: deconv_map_kernel, weights [4 taps][Cs]
+        std::vector<float> w4((size_t)4 * cin_s, 0.f);
+        for (int c = 0; c < cin; ++c)
+          for (int t = 0; t < 4; ++t) w4[(size_t)t * cin_s + c] = w->data[(size_t)c * 4 + t];
+        op.p0 = upload_f32(w4);
+        if (!op.p0) { err = "device allocation failed"; return false; }
+        op.ncols = 0;
+      } else {
+        if (cout % 8) { err = "deconv: output channels must be a multiple of 8"; return false; }
+        op.ncols = 4 * cout;
+        wnk.assign((size_t)4 * cout * K, 0.f);
+        for (int c = 0; c < cin; ++c)
+          for (int o = 0; o < cout; ++o)
+            for (int t = 0; t < 4; ++t) wnk[((size_t)t * cout + o) * K + c] = w->data[((size_t)c * cout + o) * 4 + t];
+      }
+    }
+    if (op.ncols > 0) {
+      op.npad = (op.ncols + 255) & ~255;
+      int nkt = 0;
+      if (half_) {
+        auto img = weight_image<_Float16>(wnk, op.ncols, K, op.npad, nkt);
+        op.wimg_bytes = img.size() * sizeof(_Float16);
+        op.wimg = upload_bytes(img.data(), op.wimg_bytes);
+      } else {
+        auto img = weight_image<float>(wnk, op.ncols, K, op.npad, nkt);
+        op.wimg_bytes = img.size() * sizeof(float);
+        op.wimg = upload_bytes(img.data(), op.wimg_bytes);
+      }
+      if (!op.wimg) { err = "device allocation failed"; return false; }
+    }
+    // ---- epilogue
+    int phase = 0;  // bias 1, bn 2, add 3, act 4: strictly increasing
+    const int reps = op.kind == "deconv" && cout > 1 ? 4 : 1;  // per-channel vectors repeat over the four taps of a transposed conv
+    const int vlen = std::max(op.npad, 8);
+    for (const Stage& s : op.ep) {
+      int ph = 0;
+      if (s.kind == "bias") {
+        ph = 1;
+        const HostTensor* b = need(s.a0);
+        if (!b) return false;
+        if (cout == 1 && op.kind == "deconv") { op.fbias = b->data[0]; }
+        else {
+          std::vector<float> v(vlen, 0.f);
+          for (int t = 0; t < reps; ++t)
+            for (int o = 0; o < cout; ++o) v[(size_t)t * cout + o] = b->data[o];
+          op.bias = upload_f32(v);
+        }
+      } else if (s.kind == "bn") {
+        ph = 2;
+        const HostTensor *g = need(s.a0), *b = need(s.a1), *m = need(s.a2), *vv = need(s.a3);
+        if (!g || !b || !m || !vv) return false;
+        std::vector<float> sc(vlen, 0.f), sh(vlen, 0.f);
+        for (int o = 0; o < cout; ++o) {
+          const float inv = 1.0f / sqrtf(vv->data[o] + s.f);
+          const float scv = g->data[o] * inv;
+          const float mi = m->data[o] * inv;
+          const float ms = mi * g->data[o];
+          for (int t = 0; t < reps; ++t) { sc[(size_t)t * cout + o] = scv; sh[(size_t)t * cout + o] = b->data[o] - ms; }
+        }
+        op.scale = upload_f32(sc);
+        op.shift = upload_f32(sh);
+      } else if (s.kind == "addt") { ph = 3; op.res_tid = s.tid; op.res_up = 1; }
+      else if (s.kind == "addup") {
+        ph = 3;
+        if (s.up != 2) { err = "addup: only a factor of 2 is built"; return false; }
+        op.res_tid = s.tid; op.res_up = 2;
+      } else if (s.kind == "act") {
+        ph = 4;
+        op.act = s.a0 == "relu" ? srv::SACT_RELU : s.a0 == "gelu" ? srv::SACT_GELU : s.a0 == "hswish" ? srv::SACT_HSWISH : s.a0 == "sigmoid" ? srv::SACT_SIGMOID : -1;
+        if (op.act < 0) { err = "server plan: activation " + s.a0 + " is not built"; return false; }
+      } else { err = "server plan: stage " + s.kind + " cannot follow a matrix product"; return false; }
+      if (ph <= phase) { err = "server plan: epilogue of " + op.kv["w"] + " is not in the order bias | bn | add | act"; return false; }
+      phase = ph;
+    }
+    if (op.kind == "deconv" && cout == 1 && (op.scale || op.res_tid >= 0 || op.act != srv::SACT_SIGMOID)) {
+      err = "deconv to one channel: only bias | sigmoid is built";
+      return false;
+    }
+    return true;
+  }
+  if (op.kind == "ln") {
+    const HostTensor *g = need(op.kv["g"]), *b = need(op.kv["b"]);
+    if (!g || !b) return false;
+    op.p0 = upload_f32(g->data);
+    op.p1 = upload_f32(b->data);
+    return op.p0 && op.p1;
+  }
+  if (op.kind == "ew") {
+    if (op.ep.size() != 1 || op.ep[0].kind != "addpos") { err = "server plan: ew carries only addpos here"; return false; }
+    const HostTensor* p = need(op.ep[0].a0);
+    if (!p) return false;
+    if (op.geti("c") % 8) { err = "addpos: channels must be a multiple of 8"; return false; }
+    op.p0 = upload_f32(p->data);
+    return op.p0 != nullptr;
+  }
+  return true;
+}
+
+bool SrvNet::load(const char* plan_text, const WeightMap& weights, bool half, std::string& err) {
+  half_ = half;
+  if (!parse(plan_text, err)) return false;
+  for (Op& op : ops_)
+    if (!prepare_op(op, weights, err)) return false;
+  return true;
+}
+
+int SrvNet::tune(const srv::GemmArgs& a, const std::string& key, hipStream_t s) {
+  auto it = tuned_.find(key);
+  if (it != tuned_.end()) return it->second;
+  static const bool do_tune = [] { const char* e = getenv("OCR_SRV_TUNE"); return !(e && e[0] == '0'); }();
+  static const int forced = [] { const char* e = getenv("OCR_SRV_CFG"); return e && *e ? atoi(e) : -1; }();
+  int best = -1;
+  if (forced >= 0 && srv::gemm_config_ok(a, half_, forced)) best = forced;
+  if (best < 0 && !do_tune) {
+    // shape heuristic: the big tile where there are enough of them to fill the chip, thinner ones for thin layers
+    const long tiles_big = ((a.M + 255) / 256) * ((a.Ncols + 127) / 128);
+    const int pref[] = {a.Ncols <= 64 ? (a.M >= 256 * 512 ? 2 : 3) : (tiles_big >= 512 ? 0 : 1), 1, 3};
+    for (int c : pref)
+      if (srv::gemm_config_ok(a, half_, c)) { best = c; break; }
+  }
+  if (best < 0) {
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    float best_ms = 1e30f;
+    std::string err;
+    for (int c = 0; c < srv::gemm_num_configs(); ++c) {
+      if (!srv::gemm_config_ok(a, half_, c)) continue;
+      if (!srv::launch_gemm(a, half_, c, s, err)) continue;  // warm
+      (void)hipEventRecord(e0, s);
+      for (int rep = 0; rep < 2; ++rep) (void)srv::launch_gemm(a, half_, c, s, err);
+      (void)hipEventRecord(e1, s);
+      if (hipEventSynchronize(e1) != hipSuccess) { (void)hipGetLastError(); continue; }
+      float ms = 0;
+      (void)hipEventElapsedTime(&ms, e0, e1);
+      if (ms < best_ms) { best_ms = ms; best = c; }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+  }
+  tuned_[key] = best;
+  return best;
+}
+
+bool SrvNet::bind(int N, int H, int W, hipStream_t s, std::string& err) {
+  launches_.clear();
+  flops_ = bytes_ = 0;
+  const int pk = ntensors_;  // the packed input [N][H][W][8] T: an extra tensor behind the plan's
+  tensors_.assign(ntensors_ + 1, SrvTensor());
+  auto set = [&](int tid, int n, int h, int w, int c, bool f32 = false, int cs = -1) {
+    SrvTensor& t = tensors_[tid];
+    t.n = n; t.h = h; t.w = w; t.c = c; t.cs = cs > 0 ? cs : up8(c); t.f32 = f32;
+  };
+  set(0, N, H, W, 3, true, 3);
+  set(pk, N, H, W, 3);
+  const size_t esz = half_ ? 2 : 4;
+  // ---- shapes
+  for (Op& op : ops_) {
+    if (op.kind == "output") continue;
+    const int o = op.geti("o");
+    if (op.kind == "concat") {
+      const SrvTensor& last = tensors_[op.ins.back()];
+      set(o, last.n, last.h * op.ups.back(), last.w * op.ups.back(), op.geti("c"));
+      continue;
+    }
+    const SrvTensor& in = tensors_[op.geti("i")];
+    if (in.n == 0) { err = "server plan: tensor " + std::to_string(op.geti("i")) + " is read before it is written"; return false; }
+    if (op.kind == "conv") {
+      const int oh = (in.h + 2 * op.geti("ph") - op.geti("kh")) / op.geti("sh") + 1, ow = (in.w + 2 * op.geti("pw") - op.geti("kw")) / op.geti("sw") + 1;
+      set(o, in.n, oh, ow, op.geti("cout"));
+    } else if (op.kind == "linear") {
+      const bool is_out = o == out_tid_;
+      set(o, in.n, in.h, in.w, op.geti("cout"), is_out, is_out ? up8(op.geti("cout")) : -1);
+    } else if (op.kind == "deconv") {
+      const int co = op.geti("cout");
+      set(o, in.n, in.h * 2, in.w * 2, co, co == 1, co == 1 ? 1 : -1);
+    } else if (op.kind == "pool") {
+      const int oh = (in.h + 2 * op.geti("ph") - op.geti("kh")) / op.geti("sh") + 1, ow = (in.w + 2 * op.geti("pw") - op.geti("kw")) / op.geti("sw") + 1;
+      set(o, in.n, oh, ow, in.c);
+    } else if (op.kind == "attn") {
+      set(o, in.n, in.h, in.w, op.geti("heads") * op.geti("hd"));
+    } else {
+      set(o, in.n, in.h, in.w, in.c);
+    }
+  }
+  // ---- arena: every tensor a slot of its own (keep_all) or first-fit reuse by last reader
+  std::vector<int> last_use(ntensors_ + 1, -1);
+  for (size_t oi = 0; oi < ops_.size(); ++oi) {
+    const Op& op = ops_[oi];
+    if (op.kind == "output") continue;
+    if (op.kind == "concat") for (int t : op.ins) last_use[t] = (int)oi;
+    else last_use[op.geti("i") == 0 ? pk : op.geti("i")] = (int)oi;
+    if (op.res_tid >= 0) last_use[op.res_tid] = (int)oi;
+  }
+  last_use[out_tid_] = 1 << 30;
+  {
+    struct Blk { size_t off, size; };
+    std::vector<Blk> free_list;
+    size_t top = 0;
+    auto alloc = [&](size_t bytes) {
+      bytes = (bytes + 255) & ~(size_t)255;
+      int bi = -1;
+      for (size_t i = 0; i < free_list.size(); ++i)
+        if (free_list[i].size >= bytes && (bi < 0 || free_list[i].size < free_list[bi].size)) bi = (int)i;
+      if (bi >= 0) {
+        const size_t off = free_list[bi].off;
+        free_list[bi].off += bytes;
+        free_list[bi].size -= bytes;
+        if (!free_list[bi].size) free_list.erase(free_list.begin() + bi);
+        return off;
+      }
+      const size_t off = top;
+      top += bytes;
+      return off;
+    };
+    auto release = [&](size_t off, size_t bytes) {
+      bytes = (bytes + 255) & ~(size_t)255;
+      free_list.push_back({off, bytes});
+      std::sort(free_list.begin(), free_list.end(), [](const Blk& a, const Blk& b) { return a.off < b.off; });
+      for (size_t i = 0; i + 1 < free_list.size();)
+        if (free_list[i].off + free_list[i].size == free_list[i + 1].off) { free_list[i].size += free_list[i + 1].size; free_list.erase(free_list.begin() + i + 1); }
+        else ++i;
+    };
+    tensors_[pk].offset = alloc(tensors_[pk].bytes(half_));
+    for (size_t oi = 0; oi < ops_.size(); ++oi) {
+      const Op& op = ops_[oi];
+      if (op.kind == "output") continue;
+      const int o = op.geti("o");
+      tensors_[o].offset = alloc(tensors_[o].bytes(half_));
+      if (keep_all_) continue;
+      for (int t = 1; t <= ntensors_; ++t)
+        if (last_use[t] == (int)oi && tensors_[t].n) release(tensors_[t].offset, tensors_[t].bytes(half_));
+    }
+    if (top > arena_cap_) {
+      if (arena_) (void)g_free(arena_);
+      arena_ = nullptr;
+      arena_cap_ = 0;
+      if (g_malloc(&arena_, top) != hipSuccess) { (void)hipGetLastError(); err = "activation arena: hipMalloc of " + std::to_string(top >> 20) + " MB failed"; return false; }
+      arena_cap_ = top;
+    }
+  }
+  auto ptr = [&](int tid) { return (void*)(arena_ + tensors_[tid].offset); };
+  // ---- launches
+  {
+    const long px = (long)N * H * W;
+    Launch L;
+    L.name = "pack_input";
+    L.bytes = (double)px * (12 + 8 * esz);
+    void* dst = ptr(pk);
+    const bool hf = half_;
+    L.fn = [this, dst, px, hf](hipStream_t st, std::string&) { srv::launch_pack_input(x_in_, dst, px, hf, st); return true; };
+    launches_.push_back(L);
+  }
+  int gi = 0;
+  for (size_t oi = 0; oi < ops_.size(); ++oi) {
+    Op& op = ops_[oi];
+    if (op.kind == "output") continue;
+    const int o = op.geti("o");
+    const SrvTensor& ot = tensors_[o];
+    const bool hf = half_;
+    Launch L;
+    char nm[160];
+    if (op.kind == "concat") {
+      const void* src[4] = {nullptr, nullptr, nullptr, nullptr};
+      int ups[4] = {1, 1, 1, 1};
+      const int ns = (int)op.ins.size();
+      if (ns > 4) { err = "concat: at most four sources"; return false; }
+      const int cs = tensors_[op.ins[0]].cs;
+      for (int j = 0; j < ns; ++j) {
+        if (tensors_[op.ins[j]].cs != cs || tensors_[op.ins[j]].c != cs) { err = "concat: sources must have equal, unpadded channel counts"; return false; }
+        src[j] = ptr(op.ins[j]);
+        ups[j] = op.ups[j];
+      }
+      snprintf(nm, sizeof nm, "%zu.concat_%dx%d@%dx%dx%d", oi, ns, cs, ot.n, ot.h, ot.w);
+      L.name = nm;
+      L.bytes = 2.0 * ot.bytes(half_);
+      void* dst = ptr(o);
+      const int n_ = ot.n, oh = ot.h, ow = ot.w;
+      std::array<const void*, 4> sa{src[0], src[1], src[2], src[3]};
+      std::array<int, 4> ua{ups[0], ups[1], ups[2], ups[3]};
+      L.fn = [=](hipStream_t st, std::string&) { srv::launch_concat_up(sa.data(), ua.data(), ns, cs, dst, n_, oh, ow, hf, st); return true; };
+      launches_.push_back(L);
+      continue;
+    }
+    const int itid = op.geti("i") == 0 ? pk : op.geti("i");
+    const SrvTensor& in = tensors_[itid];
+    const bool gemm = (op.kind == "conv" || op.kind == "linear" || op.kind == "deconv") && op.ncols > 0;
+    if (gemm) {
+      srv::GemmArgs a;
+      a.x = ptr(itid);
+      a.x_bytes = in.bytes(half_);
+      a.w = op.wimg;
+      a.w_bytes = op.wimg_bytes;
+      a.y = ptr(o);
+      a.N = in.n; a.H = in.h; a.W = in.w; a.Cin = in.cs;
+      if (in.cs != op.cin_s) { err = "server plan: op " + std::to_string(oi) + " reads a tensor of " + std::to_string(in.c) + " channels"; return false; }
+      a.Npad = op.npad;
+      a.Ncols = op.ncols;
+      a.Cs_out = ot.cs;
+      const int KG = half_ ? 8 : 4, BK = 8 * KG;
+      if (op.kind == "conv") {
+        a.KH = op.geti("kh"); a.KW = op.geti("kw"); a.SH = op.geti("sh"); a.SW = op.geti("sw"); a.PH = op.geti("ph"); a.PW = op.geti("pw");
+        a.OH = ot.h; a.OW = ot.w;
+      } else if (op.kind == "linear") {
+        a.OH = in.h; a.OW = in.w;
+      } else {
+        a.OH = in.h; a.OW = in.w;  // GEMM columns = INPUT pixels of the transposed conv
+        a.deconv = 1;
+        a.CoutD = op.geti("cout");
+      }
+      a.M = (long)in.n * a.OH * a.OW;
+      a.K = a.KH * a.KW * a.Cin;
+      a.nkt = (a.K + BK - 1) / BK;
+      a.x1 = (a.KH == 1 && a.KW == 1 && a.SH == 1 && a.SW == 1 && a.PH == 0 && a.PW == 0 && a.K % BK == 0) ? 1 : 0;
+      a.cin_shift = -1;
+      if (!a.x1 && a.Cin % BK != 0) {  // a K tile spans taps: every lane finds (tap, channel) of its granule - by shift for the
+        int sh_ = 0;                   // powers of two (8, 32), by division otherwise (96: SVTR's second patch-embedding conv)
+        while ((1 << sh_) < a.Cin) ++sh_;
+        a.cin_shift = (1 << sh_) == a.Cin ? sh_ : -2;
+      }
+      a.bias = op.bias; a.scale = op.scale; a.shift = op.shift;
+      a.act = op.act;
+      if (op.res_tid >= 0) {
+        const SrvTensor& rt = tensors_[op.res_tid];
+        a.res = ptr(op.res_tid);
+        a.res_up = op.res_up;
+        const bool okshape = op.res_up == 1 ? (rt.h == ot.h && rt.w == ot.w) : (rt.h * 2 == ot.h && rt.w * 2 == ot.w);
+        if (!okshape || rt.cs != ot.cs || rt.n != ot.n || op.kind == "deconv") { err = "server plan: residual of op " + std::to_string(oi) + " has another shape"; return false; }
+      }
+      a.out_f32 = ot.f32 ? 1 : 0;
+      snprintf(nm, sizeof nm, "%zu.%s%dx%d_%d_%d_s%d%s@%dx%dx%d", oi, op.kind.c_str(), a.KH, a.KW, in.c, op.geti("cout"), a.SH * 10 + a.SW,
+               op.res_tid >= 0 ? "_res" : "", ot.n, ot.h, ot.w);
+      const int cfg = tune(a, std::string(nm), s);
+      if (cfg < 0) { err = std::string("no tile configuration runs ") + nm; return false; }
+      L.name = std::string(nm) + "[" + srv::gemm_config_name(cfg) + "]";
+      const double klog = (double)a.KH * a.KW * in.c;
+      L.flops = 2.0 * (double)a.M * klog * (double)op.ncols;
+      L.bytes = (double)in.bytes(half_) + (double)ot.bytes(half_) + (double)op.ncols * klog * esz + (op.res_tid >= 0 ? (double)tensors_[op.res_tid].bytes(half_) / (op.res_up == 2 ? 1.0 : 1.0) : 0.0);
+      L.fn = [a, hf, cfg](hipStream_t st, std::string& e) { return srv::launch_gemm(a, hf, cfg, st, e); };
+      launches_.push_back(L);
+      ++gi;
+      continue;
+    }
+    if (op.kind == "deconv") {  // -> the probability map
+      snprintf(nm, sizeof nm, "%zu.deconv_map_%d@%dx%dx%d", oi, in.c, ot.n, ot.h, ot.w);
+      L.name = nm;
+      L.flops = 2.0 * in.pixels() * 4 * in.c;
+      L.bytes = (double)in.bytes(half_) + (double)ot.bytes(half_);
+      const void* xs = ptr(itid);
+      float* dst = (float*)ptr(o);
+      const float* w4 = op.p0;
+      const float fb = op.fbias;
+      const int n_ = in.n, h_ = in.h, w_ = in.w, cs = in.cs;
+      L.fn = [=](hipStream_t st, std::string&) { srv::launch_deconv_to_map(xs, w4, fb, dst, n_, h_, w_, cs, hf, st); return true; };
+    } else if (op.kind == "pool") {
+      snprintf(nm, sizeof nm, "%zu.pool_%s%dx%d_%d@%dx%dx%d", oi, op.kv["type"].c_str(), op.geti("kh"), op.geti("kw"), in.c, ot.n, ot.h, ot.w);
+      L.name = nm;
+      L.bytes = (double)in.bytes(half_) + (double)ot.bytes(half_);
+      const void* xs = ptr(itid);
+      void* dst = ptr(o);
+      const int n_ = in.n, h_ = in.h, w_ = in.w, cs = in.cs, oh = ot.h, ow = ot.w;
+      const int kh = op.geti("kh"), kw = op.geti("kw"), sh = op.geti("sh"), sw = op.geti("sw"), ph = op.geti("ph"), pw = op.geti("pw");
+      const bool mx = op.kv["type"] == "max";
+      L.fn = [=](hipStream_t st, std::string&) { srv::launch_pool(xs, dst, n_, h_, w_, cs, oh, ow, kh, kw, sh, sw, ph, pw, mx, hf, st); return true; };
+    } else if (op.kind == "ew") {
+      snprintf(nm, sizeof nm, "%zu.addpos_%d@%dx%dx%d", oi, in.c, ot.n, ot.h, ot.w);
+      L.name = nm;
+      L.bytes = 2.0 * ot.bytes(half_);
+      const void* xs = ptr(itid);
+      void* dst = ptr(o);
+      const float* pos = op.p0;
+      const long px = in.pixels();
+      const int hw = in.h * in.w, cs = in.cs;
+      L.fn = [=](hipStream_t st, std::string&) { srv::launch_addpos(xs, pos, dst, px, hw, cs, hf, st); return true; };
+    } else if (op.kind == "ln") {
+      if (in.c != in.cs) { err = "layer norm: channel count must be a multiple of 8"; return false; }
+      snprintf(nm, sizeof nm, "%zu.ln_%d@%dx%dx%d", oi, in.c, ot.n, ot.h, ot.w);
+      L.name = nm;
+      L.bytes = 2.0 * ot.bytes(half_);
+      const void* xs = ptr(itid);
+      void* dst = ptr(o);
+      const float *g = op.p0, *b = op.p1;
+      const long rows = in.pixels();
+      const int c = in.c;
+      const float eps = op.getf("eps");
+      L.fn = [=](hipStream_t st, std::string&) { srv::launch_layernorm(xs, g, b, dst, rows, c, eps, hf, st); return true; };
+    } else if (op.kind == "attn") {
+      const int heads = op.geti("heads"), hd = op.geti("hd"), T = in.h * in.w;
+      const int gh = op.geti("gh", in.h), gw = op.geti("gw", in.w), lh = op.geti("lh", 0), lw = op.geti("lw", 0);
+      if (gh != in.h || gw != in.w) { err = "attention: the plan's token grid is " + std::to_string(gh) + "x" + std::to_string(gw) + ", the tensor's " + std::to_string(in.h) + "x" + std::to_string(in.w); return false; }
+      snprintf(nm, sizeof nm, "%zu.attn_%s_h%d@%dx%dx%d", oi, lh > 0 ? "local" : "global", heads, ot.n, ot.h, ot.w);
+      L.name = nm;
+      // keys that take part: the window (clipped at the grid's border) or every token
+      double keys = T;
+      if (lh > 0) {
+        double ky = 0, kx = 0;
+        for (int y = 0; y < gh; ++y) ky += std::min(gh - 1, y + lh / 2) - std::max(0, y - lh / 2) + 1;
+        for (int x = 0; x < gw; ++x) kx += std::min(gw - 1, x + lw / 2) - std::max(0, x - lw / 2) + 1;
+        keys = (ky / gh) * (kx / gw);
+      }
+      L.flops = 4.0 * (double)in.n * heads * T * keys * hd;
+      L.bytes = (double)in.bytes(half_) + (double)ot.bytes(half_);
+      const void* xs = ptr(itid);
+      void* dst = ptr(o);
+      const float scale = op.getf("scale");
+      const int n_ = in.n;
+      L.fn = [=](hipStream_t st, std::string& e) { return srv::launch_attention(xs, dst, n_, T, heads, hd, scale, gh, gw, lh, lw, hf, st, e); };
+    } else {
+      err = "server plan: op " + op.kind + " has no kernel";
+      return false;
+    }
+    launches_.push_back(L);
+  }
+  for (auto& L : launches_) { flops_ += L.flops; bytes_ += L.bytes; }
+  bound_n_ = N; bound_h_ = H; bound_w_ = W;
+  return true;
+}
+
+bool SrvNet::run(const float* x, int N, int H, int W, hipStream_t s, std::string& err) {
+  if (N <= 0 || H <= 0 || W <= 0) { err = "bad shape"; return false; }
+  if (N != bound_n_ || H != bound_h_ || W != bound_w_) {
+    if (!bind(N, H, W, s, err)) { bound_n_ = -1; return false; }
+  }
+  x_in_ = x;
+  for (auto& L : launches_) {
+    hipEvent_t a = nullptr, b = nullptr;
+    if (timing_) {
+      (void)hipEventCreate(&a);
+      (void)hipEventCreate(&b);
+      (void)hipEventRecord(a, s);
+    }
+    if (!L.fn(s, err)) { err = L.name + ": " + err; return false; }
+    if (timing_) {
+      (void)hipEventRecord(b, s);
+      ev_pending_.push_back({a, b, L.name, L.flops, L.bytes});
+    }
+  }
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { err = std::string("server network launch: ") + hipGetErrorString(e); return false; }
+  return true;
+}
+
+void SrvNet::collect_timings() {
+  for (auto& p : ev_pending_) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+      KernelTiming& t = timings_[p.name];
+      t.ms += ms; t.count += 1; t.flops += p.flops; t.bytes += p.bytes;
+    } else (void)hipGetLastError();
+    (void)hipEventDestroy(p.a);
+    (void)hipEventDestroy(p.b);
+  }
+  ev_pending_.clear();
+}
+
+bool SrvNet::fetch_logical(int tid, std::vector<float>& host, int dims[4], hipStream_t s, std::string& err) {
+  if (tid < 0) tid = out_tid_;
+  if (tid <= 0 || tid > ntensors_ || bound_n_ < 0 || tensors_[tid].n == 0) { err = "no such tensor"; return false; }
+  const SrvTensor& t = tensors_[tid];
+  dims[0] = t.n; dims[1] = t.h; dims[2] = t.w; dims[3] = t.c;
+  const size_t cnt = (size_t)t.pixels() * t.c;
+  host.resize(cnt);
+  float* tmp = nullptr;
+  if (g_malloc(&tmp, cnt * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); err = "hipMalloc failed"; return false; }
+  if (t.f32) {
+    if (t.cs == t.c) {
+      (void)hipMemcpyAsync(tmp, tensor_ptr(tid), cnt * sizeof(float), hipMemcpyDeviceToDevice, s);
+    } else {
+      (void)hipMemcpy2DAsync(tmp, (size_t)t.c * 4, tensor_ptr(tid), (size_t)t.cs * 4, (size_t)t.c * 4, (size_t)t.pixels(), hipMemcpyDeviceToDevice, s);
+    }
+  } else {
+    srv::launch_to_f32(tensor_ptr(tid), tmp, t.pixels(), t.cs, t.c, half_, s);
+  }
+  hipError_t e = hipStreamSynchronize(s);
+  if (e == hipSuccess) e = g_memcpy(host.data(), tmp, cnt * sizeof(float), hipMemcpyDeviceToHost);
+  (void)g_free(tmp);
+  if (e != hipSuccess) { err = std::string("fetch: ") + hipGetErrorString(e); return false; }
+  return true;
+}
+
+}  // namespace ocr

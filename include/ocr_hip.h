@@ -300,6 +300,27 @@ int ocr_net_timing(ocr_net* h, int enable);
 /* writes "name ms count flops bytes\n" lines */
 int ocr_net_timing_report(ocr_net* h, char* buf, size_t cap);
 
+/* ---------------------------------------------------------------- server networks (BASELINE configs[4]) - raw taps
+ * "PP-OCRv4_server_det (ResNet50 backbone) + SVTR-large rec, fp16": the reference ships no such graph or weights (SURVEY.md
+ * section 8d, cfg5) - the two plans (cpp-paddle-ocr_amd/plans/srv_det.plan, srv_rec.plan) are hand-written from the public
+ * PaddleOCR model definitions, NOT reference artifacts; parameters are seeded (<model_dir>/synthetic.pdiparams, names and shapes
+ * from the plan's parameter table).  What is matched is the reference's `precision` constructor argument
+ * (/root/reference/src/ocr_det.cpp:50-57, /root/reference/include/paddle_ocr/ocr_det.h:60-89): "fp16" = f16 tensors, f16 matrix
+ * instructions, f32 accumulation; "fp32" = the PARITY TWIN of the same launch list, bit-identical to the oracle's run of the
+ * plan.  kind: "det" | "rec".  x: host f32 [N,H,W,3] (normalised; det: H, W multiples of 32; rec: 48 x 320).  Output tensor
+ * (tid < 0): det = the probability map [N,H,W,1]; rec = the CTC logits [N,1,W/4,6625]. */
+typedef struct ocr_srv_net ocr_srv_net;
+int ocr_srv_net_create(const char* kind, const char* model_dir, int device_id, const char* precision, ocr_srv_net** out);
+void ocr_srv_net_destroy(ocr_srv_net* h);
+/* keep_all != 0: every tensor keeps its own arena slot (parity taps of intermediate tensors) */
+int ocr_srv_net_forward(ocr_srv_net* h, const float* x, int N, int H, int W, int keep_all);
+/* `iters` more runs on the input the last forward uploaded (timing loops) */
+int ocr_srv_net_rerun(ocr_srv_net* h, int N, int H, int W, int iters);
+int ocr_srv_net_num_tensors(ocr_srv_net* h);
+int ocr_srv_net_fetch(ocr_srv_net* h, int tid, float* out, size_t cap_floats, int dims[4]);
+int ocr_srv_net_timing(ocr_srv_net* h, int enable);
+int ocr_srv_net_timing_report(ocr_srv_net* h, char* buf, size_t cap);
+
 /* self-tests / fault injection (tests): ocr_selftest_refuse_launch - a network launch whose name contains `substr` is
  * refused as if its launcher had rejected the shape (NULL or "" switches it off): the run must fail with OCR_ERR_DEVICE
  * and a message, never abort.  ocr_selftest_lds_memo - the per-device dynamic-LDS attribute memo of the kernel

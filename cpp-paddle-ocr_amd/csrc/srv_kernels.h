@@ -45,6 +45,7 @@ struct GemmArgs {
   const float* scale = nullptr;
   const float* shift = nullptr;
   const void* res = nullptr;
+  unsigned long long res_bytes = 0;
   int res_up = 0;
   int act = SACT_NONE;
   int out_f32 = 0;

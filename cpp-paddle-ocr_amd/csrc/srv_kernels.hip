@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 
+#include <algorithm>
 #include <atomic>
 #include <cstdint>
 #include <string>
@@ -352,6 +353,8 @@ __global__ void __launch_bounds__(64 * WM * WN) srv_gemm_kernel(const GemmArgs a
   }
 }
 
+#include "srv_pgemm.h"
+
 // ---- tile configurations (autotuned per layer at bind time: srv_net.hip)
 struct GemmCfg { const char* name; int bm, bn, nt; unsigned lds_h, lds_f; };
 #define SRV_CFGS(X)          \
@@ -360,10 +363,19 @@ struct GemmCfg { const char* name; int bm, bn, nt; unsigned lds_h, lds_f; };
   X(2, 256, 64, 4, 2, 3)     \
   X(3, 128, 64, 2, 2, 2)     \
   X(4, 128, 256, 1, 8, 3)    \
-  X(5, 128, 128, 2, 4, 3)
+  X(5, 128, 128, 2, 4, 3)    \
+  X(6, 256, 128, 4, 2, 3)    \
+  X(7, 256, 128, 4, 2, 2)
+// the persistent form (srv_pgemm.h; x1 problems only): id, f16 tile and waves, f32-twin tile and waves
+#define SRV_PCFGS(X)                        \
+  X(8, 128, 128, 2, 4, 64, 64, 2, 2)        \
+  X(9, 128, 128, 2, 2, 64, 64, 2, 2)
 static const GemmCfg g_cfgs[] = {
 #define X(id, BM, BN, WM, WN, NS) {#BM "x" #BN "/" #WM "x" #WN "/s" #NS, BM, BN, 64 * WM * WN, GemmGeom<_Float16, BM, BN, WM, WN, NS>::LDS, GemmGeom<float, BM, BN, WM, WN, NS>::LDS},
     SRV_CFGS(X)
+#undef X
+#define X(id, BM, BN, WM, WN, FM, FN, FWM, FWN) {"p" #BM "x" #BN "/" #WM "x" #WN, BM, BN, 64 * WM * WN, PGeom<_Float16, BM, BN, WM, WN, 3, false>::LDS, PGeom<float, FM, FN, FWM, FWN, 3, false>::LDS},
+    SRV_PCFGS(X)
 #undef X
 };
 int gemm_num_configs() { return (int)(sizeof(g_cfgs) / sizeof(g_cfgs[0])); }
@@ -381,6 +393,29 @@ static bool gemm_go(const GemmArgs& a, hipStream_t s, bool query, std::string& e
   hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(G::NT), G::LDS, s, a);
   return true;
 }
+template <typename T, int BM, int BN, int WM, int WN, bool OF32>
+static bool pgemm_go(const GemmArgs& a, hipStream_t s, bool query, std::string& err) {
+  using G = PGeom<T, BM, BN, WM, WN, 3, OF32>;
+  auto kern = srv_pgemm_kernel<T, BM, BN, WM, WN, 3, OF32>;
+  static LdsAttrMemo memo;
+  if (!a.x1) { err = "the persistent form takes 1x1 problems"; return false; }
+  if (a.res_up && (OF32 || a.res_bytes >= 0xfffffff0ull)) { err = "residual"; return false; }
+  if (G::LDS > 64 * 1024 && !raise_dynamic_lds((const void*)kern, (int)G::LDS, memo)) { err = "dynamic LDS attribute refused"; return false; }
+  if (query) return true;
+  const long ntiles = ((a.M + BM - 1) / BM) * ((a.Ncols + BN - 1) / BN);
+  if (ntiles <= 0 || ntiles > 0x7fffffffL) { err = "grid"; return false; }
+  static const int ncu = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, dev) == hipSuccess) n = pr.multiProcessorCount; }
+    return n > 0 ? n : 256;
+  }();
+  const int per_cu = (int)(160 * 1024 / G::LDS) > 0 ? (int)(160 * 1024 / G::LDS) : 1;
+  const long g0 = std::min<long>(ntiles, (long)ncu * per_cu);
+  const int tpb = (int)((ntiles + g0 - 1) / g0);
+  const unsigned grid = (unsigned)((ntiles + tpb - 1) / tpb);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(G::NT), G::LDS, s, a, tpb);
+  return true;
+}
 static bool gemm_dispatch(const GemmArgs& a, bool half, int cfg, hipStream_t s, bool query, std::string& err) {
   // shape contract of the kernel
   if (a.x_bytes >= 0xfffffff0ull || a.w_bytes >= 0xfffffff0ull) { err = "tensor beyond the 4 GB a buffer descriptor spans"; return false; }
@@ -390,6 +425,11 @@ static bool gemm_dispatch(const GemmArgs& a, bool half, int cfg, hipStream_t s, 
     case id * 2 + 1: return gemm_go<_Float16, BM, BN, WM, WN, NS>(a, s, query, err); \
     case id * 2: return gemm_go<float, BM, BN, WM, WN, NS>(a, s, query, err);
     SRV_CFGS(X)
+#undef X
+#define X(id, BM, BN, WM, WN, FM, FN, FWM, FWN)                                                                          \
+    case id * 2 + 1: return a.out_f32 ? pgemm_go<_Float16, BM, BN, WM, WN, true>(a, s, query, err) : pgemm_go<_Float16, BM, BN, WM, WN, false>(a, s, query, err); \
+    case id * 2: return pgemm_go<float, FM, FN, FWM, FWN, false>(a, s, query, err);
+    SRV_PCFGS(X)
 #undef X
   }
   err = "no such tile configuration";

@@ -466,6 +466,7 @@ bool SrvNet::bind(int N, int H, int W, hipStream_t s, std::string& err) {
       if (op.res_tid >= 0) {
         const SrvTensor& rt = tensors_[op.res_tid];
         a.res = ptr(op.res_tid);
+        a.res_bytes = rt.bytes(half_);
         a.res_up = op.res_up;
         const bool okshape = op.res_up == 1 ? (rt.h == ot.h && rt.w == ot.w) : (rt.h * 2 == ot.h && rt.w * 2 == ot.w);
         if (!okshape || rt.cs != ot.cs || rt.n != ot.n || op.kind == "deconv") { err = "server plan: residual of op " + std::to_string(oi) + " has another shape"; return false; }

@@ -28,6 +28,7 @@ struct GemmArgs {
   const void* w = nullptr;   // weight image [nkt][Npad][8 granules, XOR-swizzled by row] T (srv_net.hip: weight_image)
   unsigned long long w_bytes = 0;
   void* y = nullptr;         // [N][OH][OW][Cs_out] T (out_f32: float)
+  unsigned long long y_bytes = 0;
   long M = 0;
   int K = 0, nkt = 0;        // K = KH*KW*Cin (Cin = stored channels), K tiles of 8 granules
   int Npad = 0;              // rows of the weight image: GEMM rows padded to a multiple of 256

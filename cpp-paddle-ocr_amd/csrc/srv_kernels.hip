@@ -400,6 +400,7 @@ static bool pgemm_go(const GemmArgs& a, hipStream_t s, bool query, std::string& 
   static LdsAttrMemo memo;
   if (!a.x1) { err = "the persistent form takes 1x1 problems"; return false; }
   if (a.res_up && (OF32 || a.res_bytes >= 0xfffffff0ull)) { err = "residual"; return false; }
+  if (a.y_bytes >= 0xfffffff0ull) { err = "output beyond the 4 GB a buffer descriptor spans"; return false; }
   if (G::LDS > 64 * 1024 && !raise_dynamic_lds((const void*)kern, (int)G::LDS, memo)) { err = "dynamic LDS attribute refused"; return false; }
   if (query) return true;
   const long ntiles = ((a.M + BM - 1) / BM) * ((a.Ncols + BN - 1) / BN);

@@ -157,24 +157,12 @@ bool SrvNet::prepare_op(Op& op, const WeightMap& W, std::string& err) {
             for (int t = 0; t < 4; ++t) wnk[((size_t)t * cout + o) * K + c] = w->data[((size_t)c * cout + o) * 4 + t];
       }
     }
-    if (op.ncols > 0) {
-      op.npad = (op.ncols + 255) & ~255;
-      int nkt = 0;
-      if (half_) {
-        auto img = weight_image<_Float16>(wnk, op.ncols, K, op.npad, nkt);
-        op.wimg_bytes = img.size() * sizeof(_Float16);
-        op.wimg = upload_bytes(img.data(), op.wimg_bytes);
-      } else {
-        auto img = weight_image<float>(wnk, op.ncols, K, op.npad, nkt);
-        op.wimg_bytes = img.size() * sizeof(float);
-        op.wimg = upload_bytes(img.data(), op.wimg_bytes);
-      }
-      if (!op.wimg) { err = "device allocation failed"; return false; }
-    }
+    if (op.ncols > 0) op.npad = (op.ncols + 255) & ~255;
     // ---- epilogue
     int phase = 0;  // bias 1, bn 2, add 3, act 4: strictly increasing
     const int reps = op.kind == "deconv" && cout > 1 ? 4 : 1;  // per-channel vectors repeat over the four taps of a transposed conv
     const int vlen = std::max(op.npad, 8);
+    std::vector<float> h_bias, h_scale, h_shift;  // host copies (the f16 build folds them, below)
     for (const Stage& s : op.ep) {
       int ph = 0;
       if (s.kind == "bias") {
@@ -183,10 +171,9 @@ bool SrvNet::prepare_op(Op& op, const WeightMap& W, std::string& err) {
         if (!b) return false;
         if (cout == 1 && op.kind == "deconv") { op.fbias = b->data[0]; }
         else {
-          std::vector<float> v(vlen, 0.f);
+          h_bias.assign(vlen, 0.f);
           for (int t = 0; t < reps; ++t)
-            for (int o = 0; o < cout; ++o) v[(size_t)t * cout + o] = b->data[o];
-          op.bias = upload_f32(v);
+            for (int o = 0; o < cout; ++o) h_bias[(size_t)t * cout + o] = b->data[o];
         }
       } else if (s.kind == "bn") {
         ph = 2;
@@ -200,8 +187,8 @@ bool SrvNet::prepare_op(Op& op, const WeightMap& W, std::string& err) {
           const float ms = mi * g->data[o];
           for (int t = 0; t < reps; ++t) { sc[(size_t)t * cout + o] = scv; sh[(size_t)t * cout + o] = b->data[o] - ms; }
         }
-        op.scale = upload_f32(sc);
-        op.shift = upload_f32(sh);
+        h_scale = sc;
+        h_shift = sh;
       } else if (s.kind == "addt") { ph = 3; op.res_tid = s.tid; op.res_up = 1; }
       else if (s.kind == "addup") {
         ph = 3;
@@ -215,6 +202,33 @@ bool SrvNet::prepare_op(Op& op, const WeightMap& W, std::string& err) {
       if (ph <= phase) { err = "server plan: epilogue of " + op.kv["w"] + " is not in the order bias | bn | add | act"; return false; }
       phase = ph;
     }
+    if (op.ncols > 0) {
+      // precision "fp16": the batch norm's scale goes into the weights (one rounding to f16 either way) and its shift, with the
+      // bias, into ONE vector - (acc + b) s + t = acc s + (b s + t) - so the epilogue is a single add.  The f32 twin keeps the
+      // oracle's three roundings (bias, scale, shift) and the unscaled weights.
+      if (half_ && !h_scale.empty()) {
+        const int K_ = (int)(wnk.size() / op.ncols);
+        for (int n = 0; n < op.ncols; ++n)
+          for (int k = 0; k < K_; ++k) wnk[(size_t)n * K_ + k] *= h_scale[n];
+        if (h_bias.empty()) h_bias.assign(vlen, 0.f);
+        for (int n = 0; n < op.ncols; ++n) h_bias[n] = h_bias[n] * h_scale[n] + h_shift[n];
+        h_scale.clear();
+        h_shift.clear();
+      }
+      int nkt = 0;
+      if (half_) {
+        auto img = weight_image<_Float16>(wnk, op.ncols, K, op.npad, nkt);
+        op.wimg_bytes = img.size() * sizeof(_Float16);
+        op.wimg = upload_bytes(img.data(), op.wimg_bytes);
+      } else {
+        auto img = weight_image<float>(wnk, op.ncols, K, op.npad, nkt);
+        op.wimg_bytes = img.size() * sizeof(float);
+        op.wimg = upload_bytes(img.data(), op.wimg_bytes);
+      }
+      if (!op.wimg) { err = "device allocation failed"; return false; }
+    }
+    if (!h_bias.empty()) op.bias = upload_f32(h_bias);
+    if (!h_scale.empty()) { op.scale = upload_f32(h_scale); op.shift = upload_f32(h_shift); }
     if (op.kind == "deconv" && cout == 1 && (op.scale || op.res_tid >= 0 || op.act != srv::SACT_SIGMOID)) {
       err = "deconv to one channel: only bias | sigmoid is built";
       return false;
@@ -435,6 +449,7 @@ bool SrvNet::bind(int N, int H, int W, hipStream_t s, std::string& err) {
       a.w = op.wimg;
       a.w_bytes = op.wimg_bytes;
       a.y = ptr(o);
+      a.y_bytes = ot.bytes(half_);
       a.N = in.n; a.H = in.h; a.W = in.w; a.Cin = in.cs;
       if (in.cs != op.cin_s) { err = "server plan: op " + std::to_string(oi) + " reads a tensor of " + std::to_string(in.c) + " channels"; return false; }
       a.Npad = op.npad;

@@ -32,6 +32,7 @@ struct PGeom {
   static_assert((RBUF / 1024u) % NW == 0, "residual DMA plan");
   static_assert(BM * BN * OS <= 2 * (int)RBUF, "result image");
   static_assert(NS == 3, "the stage loop is unrolled over three ring slots");
+  static_assert((BM * BN * OS / 16) % NT == 0, "every wave issues the same number of stores");
 };
 
 __device__ __forceinline__ void srv_wait_vm_le(int n) {  // wave-uniform n; the counter holds at most 63
@@ -51,12 +52,25 @@ __device__ __forceinline__ void srv_wait_vm_le(int n) {  // wave-uniform n; the 
 }
 
 typedef float f8s __attribute__((ext_vector_type(8)));
-// eight consecutive floats of a parameter vector at a wave-uniform index, by scalar load (lgkmcnt: independent of the DMA ring)
-__device__ __forceinline__ f8s srv_sload8(const float* p, int idx) {
-  f8s v;
-  const unsigned off = (unsigned)idx * 4u;
-  asm volatile("s_load_dwordx8 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p), "s"(off) : "memory");
+// 32 consecutive floats of a parameter vector at a wave-uniform index (a 32-column block of the tile), by scalar loads: four
+// requests, ONE wait (lgkmcnt: independent of the DMA ring's vmcnt)
+struct P32 { f8s q[4]; };
+__device__ __forceinline__ P32 srv_sload32(const float* p, int idx) {
+  P32 v;
+  const unsigned o0 = (unsigned)idx * 4u, o1 = o0 + 32u, o2 = o0 + 64u, o3 = o0 + 96u;
+  asm volatile(
+      "s_load_dwordx8 %0, %4, %5\n\ts_load_dwordx8 %1, %4, %6\n\ts_load_dwordx8 %2, %4, %7\n\ts_load_dwordx8 %3, %4, %8\n\ts_waitcnt lgkmcnt(0)"
+      : "=&s"(v.q[0]), "=&s"(v.q[1]), "=&s"(v.q[2]), "=&s"(v.q[3])
+      : "s"(p), "s"(o0), "s"(o1), "s"(o2), "s"(o3)
+      : "memory");
   return v;
+}
+// one 16-byte store through a buffer descriptor: a lane whose offset is SRV_OOB stores nothing.  Always ONE instruction per
+// call, whatever the lanes do: it is counted with the DMAs (loads, stores and LDS-DMA retire in order on one counter)
+__device__ __forceinline__ void srv_store16(f4v d, unsigned voff, v4u rsrc) {
+  // (s_nop 1: a store of more than 8 bytes reads its data registers for two more cycles - the compiler pads this for its own
+  // stores, nothing inside an asm statement; without it the next instruction's write of d.x reached HBM in a quarter of the lanes)
+  asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" ::"v"(d), "v"(voff), "s"(rsrc) : "memory");
 }
 
 template <typename T, int BM, int BN, int WM, int WN, int NS, bool OF32>
@@ -80,9 +94,13 @@ __global__ void __launch_bounds__(64 * WM * WN) srv_pgemm_kernel(const GemmArgs 
   const int nkt = a.nkt;
   const int S = (t1 - t0) * nkt;  // stages of this workgroup's stream
 
-  v4u rs_w, rs_x, rs_r;
+  v4u rs_w, rs_x, rs_r, rs_y;
   {
-    const unsigned long long wb = (unsigned long long)a.w, xb = (unsigned long long)a.x, rb = (unsigned long long)a.res;
+    const unsigned long long wb = (unsigned long long)a.w, xb = (unsigned long long)a.x, rb = (unsigned long long)a.res, yb = (unsigned long long)a.y;
+    rs_y.x = __builtin_amdgcn_readfirstlane((unsigned)yb);
+    rs_y.y = __builtin_amdgcn_readfirstlane((unsigned)(yb >> 32));
+    rs_y.z = __builtin_amdgcn_readfirstlane((unsigned)a.y_bytes);
+    rs_y.w = 0x00020000u;
     rs_w.x = __builtin_amdgcn_readfirstlane((unsigned)wb);
     rs_w.y = __builtin_amdgcn_readfirstlane((unsigned)(wb >> 32));
     rs_w.z = __builtin_amdgcn_readfirstlane((unsigned)a.w_bytes);
@@ -174,21 +192,47 @@ __global__ void __launch_bounds__(64 * WM * WN) srv_pgemm_kernel(const GemmArgs 
     unsigned char* const img = smem + R0 + (OF32 ? 0u : (unsigned)(t & 1) * RBUF);
     const int ps = r & SWM;
 #pragma unroll
-    for (int i = 0; i < TN; ++i)
+    for (int i = 0; i < TN; ++i) {
+      // parameters of the 32 columns this (wave, i) covers: one vector at a time (32 SGPRs), applied to the accumulators in place
+      const int pidx = n0 + wn * TN * 32 + i * 32;
+      if (a.bias) {
+        const P32 P = srv_sload32(a.bias, pidx);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float pv = h ? P.q[q][4 + e] : P.q[q][e];
+#pragma unroll
+            for (int j = 0; j < TM; ++j) acc[i][j][4 * q + e] = acc[i][j][4 * q + e] + pv;
+          }
+      }
+      if (a.scale) {
+        {
+          const P32 P = srv_sload32(a.scale, pidx);
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float pv = h ? P.q[q][4 + e] : P.q[q][e];
+#pragma unroll
+              for (int j = 0; j < TM; ++j) acc[i][j][4 * q + e] = acc[i][j][4 * q + e] * pv;
+            }
+        }
+        {
+          const P32 P = srv_sload32(a.shift, pidx);
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float pv = h ? P.q[q][4 + e] : P.q[q][e];
+#pragma unroll
+              for (int j = 0; j < TM; ++j) acc[i][j][4 * q + e] = acc[i][j][4 * q + e] + pv;
+            }
+        }
+      }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int cb = wn * TN * 32 + i * 32 + 8 * q;  // wave-uniform first channel of the eight this (i, q) covers in the tile
-        float pb_[4], psc[4], psh[4];
-        if (a.bias) {
-          const f8s v8 = srv_sload8(a.bias, n0 + cb);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) pb_[e] = h ? v8[4 + e] : v8[e];
-        }
-        if (a.scale) {
-          const f8s s8 = srv_sload8(a.scale, n0 + cb), t8 = srv_sload8(a.shift, n0 + cb);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { psc[e] = h ? s8[4 + e] : s8[e]; psh[e] = h ? t8[4 + e] : t8[e]; }
-        }
         const int co = cb + 4 * h;
         const int bo = co * OS, gi = bo >> 4, wi = bo & 15;
 #pragma unroll
@@ -198,14 +242,6 @@ __global__ void __launch_bounds__(64 * WM * WN) srv_pgemm_kernel(const GemmArgs 
           float v[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e];
-          if (a.bias) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = v[e] + pb_[e];
-          }
-          if (a.scale) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { const float tt = v[e] * psc[e]; v[e] = tt + psh[e]; }
-          }
           if (has_res) {
             if constexpr (HALF) {
               const h4v rv = *(const h4v*)at;
@@ -234,31 +270,38 @@ __global__ void __launch_bounds__(64 * WM * WN) srv_pgemm_kernel(const GemmArgs 
           }
         }
       }
+    }
     zero_acc();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (a raw barrier: __syncthreads() would wait for vmcnt(0) and drain the DMA ring)
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     const int ncols_store = a.deconv ? a.Ncols : a.Cs_out;
-    for (int it = tid; it < BM * GPR; it += NT) {
+#pragma unroll
+    for (int it0 = 0; it0 < BM * GPR; it0 += NT) {  // (BM * GPR is a multiple of the workgroup: every wave issues every store)
+      const int it = it0 + tid;
       const int p = it / GPR, q = it - p * GPR;
       const int g = q ^ (p & SWM);
       const long m = m0 + p;
       const int n = n0 + g * (16 / OS);
-      if (m >= a.M || n >= ncols_store) continue;
       const f4v d = *(const f4v*)(img + p * ROWB + (q << 4));
-      long opix = m;
-      int co = n;
-      if (a.deconv) {
-        const int dq = n / a.CoutD;
-        co = n - dq * a.CoutD;
-        const int ohw = a.OH * a.OW;
-        const int ni = (int)(m / ohw);
-        const int rem = (int)(m - (long)ni * ohw);
-        const int oy = rem / a.OW, ox = rem - oy * a.OW;
-        opix = ((long)ni * (2 * a.OH) + 2 * oy + (dq >> 1)) * (2 * a.OW) + 2 * ox + (dq & 1);
+      unsigned off = SRV_OOB;
+      if (m < a.M && n < ncols_store) {
+        long opix = m;
+        int co = n;
+        if (a.deconv) {
+          const int dq = n / a.CoutD;
+          co = n - dq * a.CoutD;
+          const int ohw = a.OH * a.OW;
+          const int ni = (int)(m / ohw);
+          const int rem = (int)(m - (long)ni * ohw);
+          const int oy = rem / a.OW, ox = rem - oy * a.OW;
+          opix = ((long)ni * (2 * a.OH) + 2 * oy + (dq >> 1)) * (2 * a.OW) + 2 * ox + (dq & 1);
+        }
+        off = (unsigned)(((unsigned long long)opix * (unsigned)a.Cs_out + (unsigned)co) * OS);
       }
-      *(f4v*)((unsigned char*)a.y + ((size_t)opix * (size_t)a.Cs_out + (size_t)co) * OS) = d;
+      srv_store16(d, off, rs_y);
     }
+    issued += (BM * GPR) / NT;
   };
 
   // ---- the stream: stage s lives in ring slot s % 3; marks = `issued` right after the slot's / buffer's DMAs went out

@@ -416,7 +416,7 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", choices=["cfg2", "cfg3", "cfg4"], default="cfg2",
+    ap.add_argument("--config", choices=["cfg2", "cfg3", "cfg4", "cfg5"], default="cfg2",
                     help="cfg2 = BASELINE.json configs[1] (the headline: 64 x 960x960 per GPU, resident inputs); cfg3 = configs[2] "
                          "(512 mixed 640-1280 px images per GPU, resident); cfg4 = configs[3] (10k-image stream of cfg3 images "
                          "sharded i mod N, host inputs through the double-buffered staging)")
@@ -463,10 +463,163 @@ def host_input_leg(pipe, imgs, probs, steps):
     return time.perf_counter() - t0
 
 
+# ------------------------------------------------------------------------------------------------ cfg5 (BASELINE configs[4])
+def srv_kernel_groups(rep):
+    """{(network, launch name without its op index): {ms, count, flops, bytes}} - the nine SVTR blocks of one stage launch the
+    same kernel on the same shape: one group, as in a rocprofv3 summary"""
+    g = {}
+    for name, v in rep.items():
+        net, rest = name.split(".", 1)
+        key = rest.split(".", 1)[1] if rest.split(".", 1)[0].isdigit() else rest
+        t = g.setdefault((net, key), {"ms": 0.0, "count": 0, "flops": 0.0, "bytes": 0.0})
+        for k in t:
+            t[k] += v[k]
+    return g
+
+
+def cfg5_cpu_baseline():
+    """the oracle's f32 run of the two server plans on the host cores: ONE 960 x 960 image through the detector plan and FOUR
+    48 x 320 lines through the recognizer plan, scaled to an image with 32 lines (det + 8 x the four lines)"""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from oracle import OracleNet, usable_cores
+    rs = np.random.RandomState(5)
+    d = OracleNet("srv_det")
+    t0 = time.perf_counter()
+    d.run(rs.randn(1, H, W, 3).astype(np.float32))
+    t_det = time.perf_counter() - t0
+    r = OracleNet("srv_rec")
+    t0 = time.perf_counter()
+    r.run(rs.randn(4, 48, 320, 3).astype(np.float32))
+    t_rec4 = time.perf_counter() - t0
+    per_image = t_det + t_rec4 * (K_LINES / 4.0)
+    return {"value": 1.0 / per_image, "unit": "images/sec", "cores": usable_cores(), "kind": "port",
+            "sample": "oracle (f32 restatement of the hand-written server plans, OpenMP over the usable cores): 1 image 960x960 through "
+                      "srv_det (%.1f s) + 4 lines 48x320 through srv_rec (%.1f s), scaled to 32 lines per image; networks only "
+                      "(pre/post-processing is < 1 %% of this)" % (t_det, t_rec4)}
+
+
+def main_cfg5(args):
+    """BASELINE configs[4]: "PP-OCRv4_server_det (ResNet50 backbone) + SVTR-large rec, fp16, batch=32" - NOT a reference
+    artifact: hand-written plans from the public PaddleOCR definitions, seeded weights.  One step =
+    one pass of the whole pipeline over 32 synthetic 960 x 960 images per GPU (the cfg2 generator, 32 lines each, the
+    section-8d probability-map protocol); never the headline `value` of the default line."""
+    if args.gpus != 1 or "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != 1:
+        sys.exit("--config cfg5 is a single-GPU line (batch 32 per GPU at N = 1; the scaling path is cfg2's)")
+    batch = 32
+    precision = "fp16" if args.precision == "fp32" and not os.environ.get("OCR_CFG5_FP32") else args.precision
+    workers = 1 if under_profiler() else max(1, min(16, os.cpu_count() or 2))
+    imgs, probs = make_inputs(list(range(batch)), workers)
+    import synth_weights
+    synth_weights.ensure_server(ROOT)
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    srv = os.path.join(ROOT, "models_server")
+    mk = lambda phases: pkg.Pipe(device=0, enable_cls=True, limit_side_len=960, rec_batch_num=16, rec_img_h=48, rec_img_w=320,
+                                 phases=phases, precision=precision, det_dir=os.path.join(srv, "det"), rec_dir=os.path.join(srv, "rec"))
+    sync = lambda: pkg.check(pkg.lib().ocr_dev_sync())
+    d_imgs, d_probs = pkg.DevArray(imgs), pkg.DevArray(probs)
+    pipe = mk(0)
+    run_step = lambda: pipe.run_device(d_imgs, H, W, batch, d_probs, collect=False)
+    for _ in range(max(1, args.warmup)):
+        run_step()   # (the first pass binds the shapes and picks every GEMM's tile configuration on the device)
+    sync()
+    cpu0 = time.process_time()
+    t0 = time.perf_counter()
+    step_ms = []
+    for _ in range(args.steps):
+        s0 = time.perf_counter()
+        nwords = run_step()
+        step_ms.append((time.perf_counter() - s0) * 1e3)
+    sync()
+    elapsed = time.perf_counter() - t0
+    cpu_s = time.process_time() - cpu0
+    stage_ms = list(pipe.times)
+    pipe.close()
+    # ---- roofline leg: one chain, HIP events around every network launch of one step
+    pipe1 = mk(1)
+    run1 = lambda: pipe1.run_device(d_imgs, H, W, batch, d_probs, collect=False)
+    run1(); run1()
+    pipe1.timing(True)
+    rsteps = max(2, min(args.steps, 5))
+    sync()
+    t0r = time.perf_counter()
+    for _ in range(rsteps):
+        run1()
+    sync()
+    elr = time.perf_counter() - t0r
+    rep = pipe1.timing_report()
+    pipe1.timing(False)
+    pipe1.close()
+    groups = srv_kernel_groups(rep)
+    (dnet, dkey), dom = max(groups.items(), key=lambda kv: kv[1]["ms"])
+    dom_ms = dom["ms"] / dom["count"]
+    ai = dom["flops"] / max(dom["bytes"], 1.0)
+    ridge = FP16_MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
+    if ai >= ridge:
+        ach, peak, unit, bound = dom["flops"] / dom["count"] / dom_ms / 1e9, FP16_MFMA_PEAK_TFLOPS, "TFLOP/s", "mfma"
+    else:
+        ach, peak, unit, bound = dom["bytes"] / dom["count"] / dom_ms / 1e6, HBM_PEAK_GBS, "GB/s", "hbm"
+    tot = {"ms": 0.0, "flops": 0.0, "bytes": 0.0}
+    per_net = {}
+    for (net, key), v in groups.items():
+        pn = per_net.setdefault(net, {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "conv_ms": 0.0, "conv_flops": 0.0})
+        for k in ("ms", "flops", "bytes"):
+            tot[k] += v[k] / rsteps
+            pn[k] += v[k] / rsteps
+        if key.startswith(("conv", "deconv", "linear")):
+            pn["conv_ms"] += v["ms"] / rsteps
+            pn["conv_flops"] += v["flops"] / rsteps
+    # every launch against its own binding roof (f16 matrix peak or HBM peak, whichever takes longer)
+    roof_ms = sum(max(v["flops"] / (FP16_MFMA_PEAK_TFLOPS * 1e9), v["bytes"] / (HBM_PEAK_GBS * 1e6)) for v in groups.values()) / rsteps
+    table = sorted(((v["ms"] / rsteps, net + "." + key, v) for (net, key), v in groups.items()), reverse=True)[:12]
+    det = per_net.get("det", {})
+    line = {
+        "metric": "images/sec end-to-end (det+cls+rec) at 960x960", "value": batch * args.steps / elapsed, "unit": "images/sec",
+        "n_gpus": 1, "steps": args.steps, "warmup": max(1, args.warmup), "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f16" if precision == "fp16" else "f32", "data": "synthetic",
+        "reference_artifact": False,
+        "config": {"workload": "BASELINE configs[4]: batch=32 synthetic 960x960 images, server det (ResNet50-vd + DBFPN + DB head) + SVTR-large "
+                               "rec (48x320 lines, 6625 classes) + the reference's cls model, precision %s, 32 text lines per image, 1xMI355X; "
+                               "hand-written plans (tools/make_server_plans.py) and seeded weights - the reference ships no such graph "
+                               "(SURVEY.md section 8d cfg5); probability-map protocol of section 8d" % precision,
+                   "global_batch": batch, "parallelism": "1 GPU"},
+        "words_last_step": int(nwords), "stage_ms_last_step": dict(zip(("det", "cls", "rec"), stage_ms)),
+        "p50_step_ms": statistics.median(step_ms),
+        "host": {"cpu_s_per_step": cpu_s / args.steps, "what": "user + system CPU seconds of this process (all its threads) per timed step"},
+        "roofline": {
+            "kernel": dnet + "." + dkey, "launches_per_step": dom["count"] // rsteps, "ms_per_launch": dom_ms, "bound": bound,
+            "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak, "traffic": None,
+            "arithmetic_intensity": ai,
+            "what": "the (kernel, shape) group with the most time in the step; duration = HIP events on the launch stream, one chain",
+            "det_conv_stack": {"tflops": det.get("conv_flops", 0) / max(det.get("conv_ms", 1e-9), 1e-9) / 1e9,
+                               "frac_of_f16_mfma_peak": det.get("conv_flops", 0) / max(det.get("conv_ms", 1e-9), 1e-9) / 1e9 / FP16_MFMA_PEAK_TFLOPS,
+                               "ms": det.get("conv_ms", 0), "gflop": det.get("conv_flops", 0) / 1e9,
+                               "what": "every conv / transposed conv launch of the server detector in one step (32 images)"},
+            "step": {"kernel_ms": tot["ms"], "tflop": tot["flops"] / 1e12, "gb": tot["bytes"] / 1e9,
+                     "frac_mfma": tot["flops"] / max(tot["ms"], 1e-9) / 1e9 / FP16_MFMA_PEAK_TFLOPS,
+                     "frac_hbm": tot["bytes"] / max(tot["ms"], 1e-9) / 1e6 / HBM_PEAK_GBS,
+                     "layer_roof_frac": roof_ms / max(tot["ms"], 1e-9),
+                     "what": "network launches of one step; layer_roof_frac = sum over launches of max(flops / 2.5 PF, bytes / 8 TB/s) "
+                             "over their measured time"},
+            "per_network_ms": {k: v["ms"] for k, v in per_net.items()},
+            "top_kernels": [{"kernel": n, "ms_per_step": ms, "launches": v["count"] // rsteps,
+                             "tflops": v["flops"] / max(v["ms"], 1e-9) / 1e9, "gbs": v["bytes"] / max(v["ms"], 1e-9) / 1e6} for ms, n, v in table],
+            "single_chain_images_per_s": batch * rsteps / elr,
+        },
+        "parity": "tests/test_gpu_round6.py: every plan tensor of both networks - the f32 twin of the same launch list == the oracle bit for "
+                  "bit, the f16 build within stated tolerances of the oracle; the pipeline's f16 words against the f32 twin's",
+    }
+    if not args.no_cpu_baseline:
+        line["cpu_baseline"] = cfg5_cpu_baseline()
+    print(json.dumps(line))
+
+
 def main(argv=None):
     args = parse_args(argv)
     if args.gpus < 1:
         sys.exit("--gpus must be >= 1")
+    if args.config == "cfg5":
+        return main_cfg5(args)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # no launcher: become one.  Nothing in this process has touched the GPU (only numpy is imported).
         sys.exit(load_gather().launch_ranks(os.path.abspath(__file__), sys.argv[1:] if argv is None else list(argv), args.gpus))

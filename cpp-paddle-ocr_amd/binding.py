@@ -599,14 +599,16 @@ class Pipe:
     def __init__(self, model_root=None, device=0, enable_cls=False, limit_type="max", limit_side_len=512, thresh=0.2,
                  box_thresh=0.4, unclip_ratio=1.8, use_dilation=False, rec_batch_num=16, rec_img_h=28, rec_img_w=192,
                  cls_batch_num=8, crop_mode=CROP_BOUNDING_RECT, score_mode="fast", rec_sort_mode=0, phases=0, cv_compat=0,
-                 precision="fp32"):
+                 precision="fp32", det_dir=None, rec_dir=None):
+        """det_dir / rec_dir: model directories of their own (BASELINE configs[4]: models_server/det, models_server/rec -
+        directories whose arch.txt names a server plan); the dictionary stays the reference's"""
         L = lib()
         _pipe_protos(L)
         root = model_root or MODELS
         cfg = ocr_pipe_cfg()
         L.ocr_pipe_cfg_default(C.byref(cfg))
-        self._keep = [os.path.join(root, "det").encode(), os.path.join(root, "cls").encode(),
-                      os.path.join(root, "rec").encode(), os.path.join(root, "rec", "ppocr_keys_v1.txt").encode(),
+        self._keep = [(det_dir or os.path.join(root, "det")).encode(), os.path.join(root, "cls").encode(),
+                      (rec_dir or os.path.join(root, "rec")).encode(), os.path.join(root, "rec", "ppocr_keys_v1.txt").encode(),
                       limit_type.encode(), score_mode.encode(), precision.encode()]
         (cfg.det.model_dir, cfg.cls.model_dir, cfg.rec.model_dir, cfg.rec.label_path, cfg.det.limit_type,
          cfg.det.det_db_score_mode, _prec) = self._keep

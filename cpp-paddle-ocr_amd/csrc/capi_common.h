@@ -22,6 +22,12 @@ const char* embedded_plan(const char* kind);  // "det" | "cls" | "rec" -> plan t
 // kind ("det" | "cls" | "rec"): the graph in model_dir must carry the signature stored in that plan
 bool load_model_dir(const std::string& model_dir, const char* weights_override, const char* kind, WeightMap& w, std::string& err);
 
+// BASELINE configs[4] (server networks; hand-written plans, NOT reference artifacts): a model directory WITHOUT a .pdmodel whose
+// arch.txt names a server plan ("srv_det" | "srv_rec"); parameter names / shapes come from the plan's parameter table.
+// server_arch: the tag of such a directory, "" for an ordinary (graph-carrying) model directory
+std::string server_arch(const std::string& model_dir);
+bool load_server_model_dir(const std::string& model_dir, const char* kind, WeightMap& w, std::string& err);
+
 int fail(int code, const std::string& msg);
 
 // ocr_det_cfg.cv_compat -> OCR_CV_45 | OCR_CV_410 (0: OCR_CV_COMPAT from the environment, else OCR_CV_410); any other

@@ -1,4 +1,5 @@
 // C-ABI of the server networks' raw taps (BASELINE configs[4]; include/ocr_hip.h "server networks").
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <sstream>
@@ -23,6 +24,17 @@ static std::vector<std::string> srv_param_names(const char* plan) {
     }
   std::sort(names.begin(), names.end());  // the order .pdiparams records are written in
   return names;
+}
+std::string server_arch(const std::string& model_dir) {
+  if (file_exists(model_dir + "/inference.pdmodel") || file_exists(model_dir + "/model.pdmodel")) return "";
+  FILE* f = fopen((model_dir + "/arch.txt").c_str(), "r");
+  if (!f) return "";
+  char buf[64] = {0};
+  const size_t n = fread(buf, 1, sizeof buf - 1, f);
+  fclose(f);
+  std::string t(buf, n);
+  while (!t.empty() && (t.back() == '\n' || t.back() == '\r' || t.back() == ' ')) t.pop_back();
+  return (t == "srv_det" || t == "srv_rec") ? t : "";
 }
 bool load_server_model_dir(const std::string& model_dir, const char* kind, WeightMap& w, std::string& err) {
   const char* plan = embedded_plan(kind);

@@ -833,9 +833,23 @@ static std::vector<Net*> pipe_nets(ocr_pipe* h) {
   }
   return v;
 }
+static std::vector<SrvNet*> pipe_srv_nets(ocr_pipe* h) {  // the server networks of a configs[4] pipeline
+  std::vector<SrvNet*> v;
+  std::vector<PipeWorker*> ws{&h->w0};
+  for (auto& w : h->extra) ws.push_back(w.get());
+  for (PipeWorker* w : ws) {
+    if (w->det.srv()) v.push_back(w->det.srv());
+    if (w->rec.srv()) v.push_back(w->rec.srv());
+  }
+  return v;
+}
 int ocr_pipe_timing(ocr_pipe* h, int enable) {
   if (!h) return fail(OCR_ERR_ARG, "null handle");
   for (Net* net : pipe_nets(h)) {
+    net->enable_timing(enable != 0);
+    net->reset_timings();
+  }
+  for (SrvNet* net : pipe_srv_nets(h)) {
     net->enable_timing(enable != 0);
     net->reset_timings();
   }
@@ -875,6 +889,19 @@ int ocr_pipe_timing_report(ocr_pipe* h, char* buf, size_t cap) {
       KernelTiming& t = all[kv.first];
       t.ms += kv.second.ms; t.count += kv.second.count; t.flops += kv.second.flops; t.bytes += kv.second.bytes;
     }
+  {
+    std::vector<PipeWorker*> ws{&h->w0};
+    for (auto& w : h->extra) ws.push_back(w.get());
+    for (PipeWorker* w : ws)
+      for (int k = 0; k < 2; ++k) {
+        SrvNet* net = k ? w->rec.srv() : w->det.srv();
+        if (!net) continue;
+        for (auto& kv : net->timings()) {  // (the mobile networks' names start with "det." / "rec.": the same convention)
+          KernelTiming& t = all[std::string(k ? "rec." : "det.") + kv.first];
+          t.ms += kv.second.ms; t.count += kv.second.count; t.flops += kv.second.flops; t.bytes += kv.second.bytes;
+        }
+      }
+  }
   for (auto& kv : all) {
     int n = snprintf(buf + off, cap > off ? cap - off : 0, "%s %.6f %ld %.0f %.0f\n", kv.first.c_str(), kv.second.ms,
                      kv.second.count, kv.second.flops, kv.second.bytes);

@@ -11,6 +11,7 @@
 #include "kernels_post.h"
 #include "kernels_pre.h"
 #include "net.h"
+#include "srv_net.h"
 
 namespace ocr {
 
@@ -88,7 +89,9 @@ class DetStage {
   hipStream_t stream() const { return stream_; }
   Net& net() { return net_; }
   int last_count = 0, last_h = 0, last_w = 0;
-  const float* prob_dev() const { return net_.tensor_ptr(net_.output_tid()); }
+  const float* prob_dev() const { return srv_ ? (const float*)srv_->tensor_ptr(srv_->output_tid()) : net_.tensor_ptr(net_.output_tid()); }
+  // the server detector (BASELINE configs[4]: a model directory whose arch.txt says srv_det), or null
+  SrvNet* srv() { return srv_.get(); }
   const uint8_t* bitmap_dev() const { return cfg_.use_dilation ? bitmap2_.p : bitmap_.p; }
   const uint8_t* resized_dev() const { return resized_.p; }
   const DetConfig& cfg() const { return cfg_; }
@@ -107,6 +110,7 @@ class DetStage {
   hipEvent_t mixed_done_ = nullptr;
   DetConfig cfg_;
   Net net_;
+  std::unique_ptr<SrvNet> srv_;
   hipStream_t stream_ = nullptr;
   StageTimer timer_;
   DevBuf<float> lut_, x_, prob_in_;
@@ -153,6 +157,7 @@ class RecStage {
   const std::vector<std::string>& labels() const { return labels_; }
   hipStream_t stream() const { return stream_; }
   Net& net() { return net_; }
+  SrvNet* srv() { return srv_.get(); }  // the server recognizer (arch.txt: srv_rec), or null
   // per-step taps of the last run, in input order: T per line, amax/pmax concatenated
   std::vector<int> tap_T, tap_off;
   std::vector<int> tap_amax;
@@ -163,6 +168,7 @@ class RecStage {
   // One network instance, one stream: the lines of a call run as ONE ragged launch list whatever their tensor widths
   // (run_lines); rounds 1-2 launched once per distinct width on up to six streams ("lanes").
   Net net_;
+  std::unique_ptr<SrvNet> srv_;
   hipStream_t stream_ = nullptr;
   StageTimer timer_;
   std::vector<std::string> labels_;

@@ -113,8 +113,16 @@ bool DetStage::create(const DetConfig& cfg, std::string& err, int& code) {
   if (code) { err = ocr_last_error(); return false; }
   WeightMap w;
   code = OCR_ERR_MODEL;
-  if (!load_model_dir(cfg.model_dir, nullptr, "det", w, err)) return false;
-  if (!net_.load(embedded_plan("det"), w, err, cfg.precision == "fp16")) return false;
+  if (server_arch(cfg.model_dir) == "srv_det") {
+    // BASELINE configs[4]: the server detector (ResNet50-vd DB; hand-written plan, NOT a reference artifact) on the f16
+    // implicit-GEMM family of srv_kernels.hip; "fp32" is its parity twin
+    if (!load_server_model_dir(cfg.model_dir, "srv_det", w, err)) return false;
+    srv_.reset(new SrvNet());
+    if (!srv_->load(embedded_plan("srv_det"), w, cfg.precision == "fp16", err)) return false;
+  } else {
+    if (!load_model_dir(cfg.model_dir, nullptr, "det", w, err)) return false;
+    if (!net_.load(embedded_plan("det"), w, err, cfg.precision == "fp16")) return false;
+  }
   code = OCR_ERR_DEVICE;
   if (g_stream_create(&stream_) != hipSuccess) { err = "hipStreamCreate failed"; return false; }
   if (!timer_.init(err)) return false;
@@ -272,8 +280,13 @@ int DetStage::run_device(const uint8_t* dev_imgs, size_t img_bytes, size_t strid
   pa.N = count; pa.sh = rows; pa.sw = cols; pa.dh = rh; pa.dw = rw; pa.lut = lut_.p; pa.out = x_.p; pa.resized = resized_.p;
   launch_det_pre(pa, stream_);
   timer_.mark(1, stream_);
-  if (bitmap_.p != old_bm || bm_n_ == 0) { net_.set_det_bitmap(bitmap_.p, ithresh_); bm_n_ = 1; }
-  if (!net_.run(x_.p, count, rh, rw, stream_, err)) return OCR_ERR_DEVICE;
+  if (srv_) {
+    if (!srv_->run(x_.p, count, rh, rw, stream_, err)) return OCR_ERR_DEVICE;
+    if (!prob_override) launch_bitmap(prob_dev(), bitmap_.p, (long)px, ithresh_, stream_);  // (the mobile network's head writes it itself)
+  } else {
+    if (bitmap_.p != old_bm || bm_n_ == 0) { net_.set_det_bitmap(bitmap_.p, ithresh_); bm_n_ = 1; }
+    if (!net_.run(x_.p, count, rh, rw, stream_, err)) return OCR_ERR_DEVICE;
+  }
   timer_.mark(2, stream_);
   last_count = count; last_h = rh; last_w = rw;
   const float* pred = prob_dev();
@@ -285,12 +298,14 @@ int DetStage::run_device(const uint8_t* dev_imgs, size_t img_bytes, size_t strid
   src_cols_ = cols;
   const int rc = run_post(count, rh, rw, pred, ratio_h, ratio_w, rows, cols, boxes, cap, n, err);
   net_.collect_timings();
+  if (srv_) srv_->collect_timings();
   timer_.read(times);
   return rc;
 }
 
 int DetStage::mixed_net(const uint8_t* base, const MixedGroup* groups, int ngroups, const float* prob_override, std::string& err) {
   ST_HIP(rt_set_device(cfg_.device));
+  if (srv_) { err = "the server detector runs batches of one image size (a ragged batch of mixed sizes is not built for it)"; return OCR_ERR_ARG; }
   if (!mixed_done_) ST_HIP(hipEventCreateWithFlags(&mixed_done_, hipEventDisableTiming));
   mixed_pix_.assign(ngroups + 1, 0);
   std::vector<int> hs, ws;
@@ -419,8 +434,18 @@ bool RecStage::create(const RecConfig& cfg, std::string& err, int& code) {
   for (std::string line; std::getline(in, line);) labels_.push_back(line);
   labels_.push_back(" ");
   WeightMap w;
-  if (!load_model_dir(cfg.model_dir, nullptr, "rec", w, err)) return false;
-  if (!net_.load(embedded_plan("rec"), w, err, cfg.precision == "fp16")) return false;
+  if (server_arch(cfg.model_dir) == "srv_rec") {
+    // BASELINE configs[4]: SVTR-large (hand-written plan, NOT a reference artifact).  Its position embedding and local-mixing
+    // windows belong to ONE token grid: every line is resized into rec_img_h x rec_img_w = 48 x 320 (CrnnResizeImg with the
+    // batch's width ratio held at rec_img_w / rec_img_h instead of growing with the widest line, ocr_rec.cpp:47-57)
+    if (cfg.img_h != 48 || cfg.img_w != 320) { err = "the server recognizer takes 48 x 320 lines (rec_img_h, rec_img_w)"; code = OCR_ERR_ARG; return false; }
+    if (!load_server_model_dir(cfg.model_dir, "srv_rec", w, err)) return false;
+    srv_.reset(new SrvNet());
+    if (!srv_->load(embedded_plan("srv_rec"), w, cfg.precision == "fp16", err)) return false;
+  } else {
+    if (!load_model_dir(cfg.model_dir, nullptr, "rec", w, err)) return false;
+    if (!net_.load(embedded_plan("rec"), w, err, cfg.precision == "fp16")) return false;
+  }
   code = OCR_ERR_DEVICE;
   if (g_stream_create(&stream_) != hipSuccess) { err = "hipStreamCreate failed"; return false; }
   if (!timer_.init(err)) return false;
@@ -488,6 +513,7 @@ int RecStage::run_lines(const std::vector<LineSrc>& lines, const std::vector<int
         const float wh_ratio = w * 1.0 / h;
         max_wh_ratio = std::max(max_wh_ratio, wh_ratio);
       }
+      if (srv_) max_wh_ratio = imgW * 1.0 / imgH;  // (the server recognizer's fixed token grid: create())
       const int bw = int(imgH * max_wh_ratio);  // CrnnResizeImg: imgW = int(imgH * wh_ratio)
       const int tensor_w = std::max(bw, imgW);
       for (int ino = beg; ino < end; ++ino) {
@@ -519,7 +545,7 @@ int RecStage::run_lines(const std::vector<LineSrc>& lines, const std::vector<int
     int i = 0;
     const int ni = (int)items.size();
     while (i < ni) {
-      if (!attn_ragged_fits(items[i].tensor_w / 8 + 2)) {  // uniform launch: the lines of exactly this width
+      if (srv_ || !attn_ragged_fits(items[i].tensor_w / 8 + 2)) {  // uniform launch: the lines of exactly this width
         int j = i;
         while (j < ni && items[j].tensor_w == items[i].tensor_w && j - i < max_lines_per_launch) ++j;
         slots.push_back({i, j - i, false, 0, 0});
@@ -580,8 +606,21 @@ int RecStage::run_lines(const std::vector<LineSrc>& lines, const std::vector<int
     return OCR_ERR_DEVICE;
   ST_HIP(hipMemcpyAsync(descs_.p, d.data(), (size_t)ni * sizeof(LineDesc), hipMemcpyHostToDevice, stream_));
   for (Slot& sl : slots) {
-    net_.set_head_outputs(nullptr, amax_.p + sl.step_off, pmax_.p + sl.step_off);
-    if (sl.ragged) {
+    if (!srv_) net_.set_head_outputs(nullptr, amax_.p + sl.step_off, pmax_.p + sl.step_off);
+    if (srv_) {
+      const int Wt = items[sl.first].tensor_w;
+      launch_line_pre(descs_.p + sl.first, sl.count, imgH, Wt, lut_.p, false, x_.p, stream_);
+      if (!srv_->run(x_.p, sl.count, imgH, Wt, stream_, err)) return OCR_ERR_DEVICE;
+      const SrvTensor& ot = srv_->tensor(srv_->output_tid());
+      if (ot.h != 1) { err = "rec_img_h does not reduce to a single row"; return OCR_ERR_ARG; }
+      if (ot.c != (int)labels_.size()) { err = "dictionary size does not match the CTC head"; return OCR_ERR_MODEL; }
+      sl.T = ot.w;
+      if (sl.T > Wt / 4 + 8) { err = "rec step buffer too small"; return OCR_ERR_CAPACITY; }
+      srv::launch_argmax_softmax((const float*)srv_->tensor_ptr(srv_->output_tid()), (long)sl.count * sl.T, ot.c, ot.cs, amax_.p + sl.step_off,
+                                 pmax_.p + sl.step_off, stream_);
+      launch_ctc(amax_.p + sl.step_off, pmax_.p + sl.step_off, sl.count, sl.T, max_len, ids_.p + (size_t)sl.first * max_len,
+                 lens_.p + sl.first, scores_.p + sl.first, stream_);
+    } else if (sl.ragged) {
       widths.resize(sl.count);
       long pix = 0;
       for (int j = 0; j < sl.count; ++j) { widths[j] = items[sl.first + j].tensor_w; pix += (long)imgH * widths[j]; }
@@ -615,6 +654,7 @@ int RecStage::run_lines(const std::vector<LineSrc>& lines, const std::vector<int
   }
   ST_HIP(hipStreamSynchronize(stream_));
   net_.collect_timings();
+  if (srv_) srv_->collect_timings();
   for (const Slot& sl : slots)
     for (int j = 0; j < sl.count; ++j) {
       const int q = sl.first + j, li = items[q].line;

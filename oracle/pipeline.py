@@ -26,12 +26,16 @@ class DetCfg:
 
 class Pipeline:
     def __init__(self, det_cfg=None, rec_batch_num=16, rec_img_h=28, rec_img_w=192, cls_batch_num=8, enable_cls=False,
-                 crop_mode="rect", rec_sort="std"):
+                 crop_mode="rect", rec_sort="std", det_net="det", rec_net="rec"):
+        # det_net / rec_net = "srv_det" / "srv_rec": BASELINE configs[4]'s hand-written server plans (NOT reference artifacts).
+        # The server recognizer (SVTR-large) has ONE token grid: every line goes into rec_img_h x rec_img_w (the batch's width
+        # ratio is held at rec_img_w / rec_img_h), and its plan ends at the CTC logits: the softmax is taken here.
+        self.srv_rec = rec_net.startswith("srv_")
         self.rec_sort = rec_sort    # "std": this host's std::sort; "stable": ties in input order (MSVC's std::sort up to 32 crops)
         self.crop_mode = crop_mode  # "rect": worker's ROI views; "rotate": Utility::GetRotateCropImage per box
         self.det_cfg = det_cfg or DetCfg()
-        self.det = O.OracleNet("det")
-        self.rec = O.OracleNet("rec")
+        self.det = O.OracleNet(det_net)
+        self.rec = O.OracleNet(rec_net)
         self.cls = O.OracleNet("cls") if enable_cls else None
         self.rec_batch_num, self.rec_img_h, self.rec_img_w = rec_batch_num, rec_img_h, rec_img_w
         self.cls_batch_num = cls_batch_num
@@ -88,7 +92,8 @@ class Pipeline:
             max_wh_ratio = np.float32(imgW * 1.0 / imgH)
             for ino in range(beg, end):
                 hh, ww = crops[indices[ino]].shape[:2]
-                max_wh_ratio = max(max_wh_ratio, np.float32(ww * 1.0 / hh))
+                if not self.srv_rec:
+                    max_wh_ratio = max(max_wh_ratio, np.float32(ww * 1.0 / hh))
             bw = int(np.float32(imgH) * np.float32(max_wh_ratio))
             tensor_w = max(bw, imgW)
             batch = []
@@ -101,7 +106,12 @@ class Pipeline:
                     xi = pad
                 batch.append(xi)
             p = self.rec.run(np.stack(batch))  # [N,1,T,6625]
-            lg = self.rec.logits()
+            if self.srv_rec:
+                lg = p
+                e = np.exp(lg.astype(np.float64) - lg.max(axis=-1, keepdims=True))
+                p = (e / e.sum(axis=-1, keepdims=True)).astype(np.float32)
+            else:
+                lg = self.rec.logits()
             for m in range(end - beg):
                 pm = p[m, 0]
                 # arg max = first maximum of the logits (exp is not strictly monotonic after rounding);

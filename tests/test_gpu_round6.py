@@ -162,3 +162,44 @@ def test_server_net_fp16_within_tolerance_of_the_oracle(pkg, built, kind, shape)
         assert (out_g.argmax(-1) == out_w.argmax(-1)).mean() >= 0.90
     print("fp16 %s: worst tensor max|d|/max|x| = %.4f" % (kind, max(worst.values())))
     net.close()
+
+
+def test_server_pipeline_twin_equals_the_oracle_and_fp16_stays_close(pkg, built):
+    """OCRWorker::processRequest (/root/reference/src/ocr_worker.cpp:213-311) with the server networks behind the stage
+    objects (model directories whose arch.txt names a server plan): the f32 TWIN pipeline's words equal the oracle pipeline's -
+    boxes and CTC ids exactly, confidences to 1e-5 (the device sums the softmax in its own order) - and the fp16 pipeline (the
+    mode BASELINE configs[4] names) finds the same boxes (section-8d protocol maps) with >= 90 % of the lines' id sequences
+    equal."""
+    import pipeline as P
+    from synth_data import cfg2_sample
+    _srv_ready()
+    n, hw, k = 2, 320, 6
+    samples = [cfg2_sample(100 + i, hw, hw, k) for i in range(n)]
+    imgs = [s[0] for s in samples]
+    probs = [s[1] for s in samples]
+    ora = P.Pipeline(P.DetCfg(limit_side_len=hw), rec_batch_num=16, rec_img_h=48, rec_img_w=320, enable_cls=True, det_net="srv_det", rec_net="srv_rec")
+    want = [ora.process(im, prob_override=pr) for im, pr in zip(imgs, probs)]
+    srv = os.path.join(ROOT, "models_server")
+    got = {}
+    for prec in ("fp32", "fp16"):
+        pipe = pkg.Pipe(device=0, enable_cls=True, limit_side_len=hw, rec_batch_num=16, rec_img_h=48, rec_img_w=320, precision=prec,
+                        det_dir=os.path.join(srv, "det"), rec_dir=os.path.join(srv, "rec"))
+        d_imgs, d_probs = pkg.DevArray(np.stack(imgs)), pkg.DevArray(np.stack(probs))
+        got[prec] = pipe.run_device(d_imgs, hw, hw, n, d_probs, collect=True)
+        pipe.close()
+    lines = same16 = 0
+    for i in range(n):
+        w = want[i]["words"]
+        assert len(w) > 0
+        for prec in ("fp32", "fp16"):
+            g = got[prec][i]
+            assert len(g) == len(w), (prec, i, len(g), len(w))
+            for a, b in zip(g, w):
+                assert np.array_equal(a["box"], np.array(b["box"]).reshape(4, 2)), (prec, i)
+        for a, b in zip(got["fp32"][i], w):
+            assert np.array_equal(a["ids"], b["ids"]), i
+            assert abs(a["confidence"] - b["confidence"]) <= 1e-5, (a["confidence"], b["confidence"])
+        for a, b in zip(got["fp16"][i], w):
+            lines += 1
+            same16 += np.array_equal(a["ids"], b["ids"])
+    assert same16 >= 0.9 * lines, (same16, lines)

@@ -754,6 +754,7 @@ def main(argv=None):
     step_ms = []
     nwords = 0
     barrier()
+    cpu_t0 = time.process_time()   # user + system seconds of this process, every thread (the library's chain threads included)
     t0 = time.perf_counter()
     if cfg == "cfg4" and not stub:
         import threading
@@ -775,6 +776,26 @@ def main(argv=None):
             step_ms.append((time.perf_counter() - s0) * 1e3)
     barrier()
     elapsed = time.perf_counter() - t0
+    host_cpu_s = time.process_time() - cpu_t0
+    # ---- the other way of waiting for a stream (round 6): the same timed steps with the library's host threads
+    # spinning in hipStreamSynchronize (what rounds 1-5 did) instead of sleeping on a blocking event (the default since) - images/s
+    # and host CPU seconds per step of both modes; rank 0 of a single-GPU resident-batch run only
+    wait_modes = None
+    if not stub and world == 1 and cfg in ("cfg2", "cfg3") and hasattr(pkg.lib(), "ocr_rt_set_wait_mode"):
+        L_ = pkg.lib()
+        mode0 = L_.ocr_rt_get_wait_mode()
+        wait_modes = {("block" if mode0 else "spin"): {"images_per_s": batch * steps_done / elapsed, "cpu_s_per_step": host_cpu_s / max(1, steps_done)}}
+        L_.ocr_rt_set_wait_mode(0 if mode0 else 1)
+        run_step()
+        sync()
+        c0, w0 = time.process_time(), time.perf_counter()
+        for _ in range(args.steps):
+            run_step()
+        sync()
+        wait_modes["spin" if mode0 else "block"] = {"images_per_s": batch * args.steps / (time.perf_counter() - w0),
+                                                    "cpu_s_per_step": (time.process_time() - c0) / max(1, args.steps)}
+        L_.ocr_rt_set_wait_mode(mode0)
+        wait_modes["default"] = "block" if mode0 else "spin"
     per_rank = None
     if dist is not None:
         import torch
@@ -1133,7 +1154,13 @@ def main(argv=None):
         if share_gpu:
             out["rehearsal"] = "OCR_BENCH_SHARE_GPU: %d ranks drive GPU 0 with the real pipeline, records over gloo - a rehearsal of the N > 1 path on a one-GPU lease, not a scaling point" % n_ranks
         out["host"] = {"host_cores_allowed": cores_mine, "input_generation_s": input_gen_s, "input_generation_workers": workers,
-                       "placement": placement}
+                       "placement": placement,
+                       "cpu_s_per_step": host_cpu_s / max(1, steps_done), "cpu_cores_busy": host_cpu_s / max(elapsed, 1e-9),
+                       "threads": len(os.listdir("/proc/self/task")) if os.path.isdir("/proc/self/task") else None,
+                       "wait_modes": wait_modes,
+                       "what": "cpu_s_per_step: user + system CPU seconds of rank 0's process (the library's chain threads included) per "
+                               "timed step; cpu_cores_busy = that over the wall time; threads: tasks of the process at the end of the run; "
+                               "wait_modes: the same steps with the host threads blocking on an event / spinning in hipStreamSynchronize"}
         if n_ranks == 1 and not args.no_cpu_baseline and not stub and cfg == "cfg2":
             out["cpu_baseline"] = cpu_baseline()
         emit_line(out)

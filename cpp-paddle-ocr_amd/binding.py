@@ -47,7 +47,7 @@ class ocr_rec_cfg(C.Structure):
 
 # every symbol include/ocr_hip.h declares (tests check the .so exports all of them)
 EXPORTS = [
-    "ocr_last_error", "ocr_rt_init", "ocr_rt_device_count",
+    "ocr_last_error", "ocr_rt_init", "ocr_rt_device_count", "ocr_rt_set_wait_mode", "ocr_rt_get_wait_mode",
     "ocr_det_cfg_default", "ocr_det_create", "ocr_det_destroy", "ocr_det_run", "ocr_det_run_batch",
     "ocr_det_last_shape", "ocr_det_prob_map", "ocr_det_bitmap", "ocr_det_resized", "ocr_det_post",
     "ocr_cls_cfg_default", "ocr_cls_create", "ocr_cls_destroy", "ocr_cls_run", "ocr_cls_probs",

@@ -57,6 +57,18 @@ void rt_set_refuse_launch(const char* substr) {
   g_refuse_on.store(!g_refuse.empty(), std::memory_order_release);
 }
 
+static std::atomic<int> g_wait_mode{-1};
+int rt_wait_mode() {
+  int m = g_wait_mode.load(std::memory_order_relaxed);
+  if (m < 0) {
+    const char* e = getenv("OCR_WAIT_MODE");
+    m = e && e[0] == 's' ? 0 : 1;  // default: block (same images/s, a fraction of the host CPU)
+    g_wait_mode.store(m, std::memory_order_relaxed);
+  }
+  return m;
+}
+void rt_set_wait_mode(int m) { g_wait_mode.store(m ? 1 : 0, std::memory_order_relaxed); }
+
 std::shared_mutex& capture_mutex() {
   static std::shared_mutex m;
   return m;
@@ -198,6 +210,8 @@ extern "C" {
 const char* ocr_last_error(void) { return ocr::g_last_error.c_str(); }
 
 int ocr_rt_device_count(void) { return rt_device_count(); }
+int ocr_rt_set_wait_mode(int mode) { if (mode != 0 && mode != 1) return fail(OCR_ERR_ARG, "wait mode: 0 (spin) or 1 (block)"); rt_set_wait_mode(mode); return OCR_OK; }
+int ocr_rt_get_wait_mode(void) { return rt_wait_mode(); }
 
 int ocr_rt_init(int device_id) {
   (void)rt_options();  // the environment is read here, once
@@ -259,7 +273,7 @@ int ocr_net_forward(ocr_net* h, const float* x, int N, int H, int W, int keep_al
   h->net.set_keep_all(keep_all < 0 || keep_all > 2 ? 1 : keep_all);
   std::string err;
   if (!h->net.run(h->x_dev, N, H, W, h->stream, err)) return fail(OCR_ERR_DEVICE, err);
-  CAPI_HIP(hipStreamSynchronize(h->stream));
+  CAPI_HIP(g_stream_sync(h->stream));
   h->net.collect_timings();
   return OCR_OK;
 }
@@ -283,7 +297,7 @@ int ocr_net_forward_ragged(ocr_net* h, const float* x, int N, int H, const int* 
   h->net.set_keep_all(keep_all < 0 || keep_all > 2 ? 1 : keep_all);
   std::string err;
   if (!h->net.run_ragged(h->x_dev, H, widths, N, h->stream, err)) return fail(OCR_ERR_DEVICE, err);
-  CAPI_HIP(hipStreamSynchronize(h->stream));
+  CAPI_HIP(g_stream_sync(h->stream));
   h->net.collect_timings();
   return OCR_OK;
 }
@@ -308,7 +322,7 @@ int ocr_net_forward_ragged_images(ocr_net* h, const float* x, int N, const int* 
   h->net.set_keep_all(keep_all);
   std::string err;
   if (!h->net.run_ragged_images(h->x_dev, heights, widths, N, h->stream, err)) return fail(OCR_ERR_DEVICE, err);
-  CAPI_HIP(hipStreamSynchronize(h->stream));
+  CAPI_HIP(g_stream_sync(h->stream));
   h->net.collect_timings();
   return OCR_OK;
 }

@@ -100,7 +100,7 @@ int ocr_srv_net_forward(ocr_srv_net* h, const float* x, int N, int H, int W, int
   h->net.set_keep_all(keep_all != 0);
   std::string err;
   if (!h->net.run(h->x_dev, N, H, W, h->stream, err)) return fail(OCR_ERR_DEVICE, err);
-  CAPI_HIP(hipStreamSynchronize(h->stream));
+  CAPI_HIP(g_stream_sync(h->stream));
   h->net.collect_timings();
   return OCR_OK;
 }
@@ -111,7 +111,7 @@ int ocr_srv_net_rerun(ocr_srv_net* h, int N, int H, int W, int iters) {
   std::string err;
   for (int i = 0; i < iters; ++i)
     if (!h->net.run(h->x_dev, N, H, W, h->stream, err)) return fail(OCR_ERR_DEVICE, err);
-  CAPI_HIP(hipStreamSynchronize(h->stream));
+  CAPI_HIP(g_stream_sync(h->stream));
   h->net.collect_timings();
   return OCR_OK;
 }

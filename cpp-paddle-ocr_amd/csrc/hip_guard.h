@@ -16,6 +16,7 @@
 namespace ocr {
 
 std::shared_mutex& capture_mutex();  // capi_net.hip
+int rt_current_device();                // (the calling thread's logical device: below)
 
 template <class T>
 inline hipError_t g_malloc(T** p, size_t bytes) {
@@ -43,6 +44,28 @@ inline hipError_t g_memcpy2d(void* d, size_t dp, const void* s, size_t sp, size_
   return hipMemcpy2D(d, dp, s, sp, w, h, k);
 }
 inline hipError_t g_stream_create(hipStream_t* s) { return hipStreamCreateWithFlags(s, hipStreamNonBlocking); }
+
+// How a host thread waits for its stream (round 6).  hipStreamSynchronize SPINS on the completion signal: a pipeline handle
+// has three host threads doing that for most of a step (two chains + the caller), eight ranks of a node 24 busy cores - more
+// than a one-GPU lease of this pool grants (16).  Mode 1 ("block") records an event created with hipEventBlockingSync behind
+// the stream's work and waits on it: the thread sleeps in the driver until the interrupt.  Process-wide: ocr_rt_set_wait_mode
+// (include/ocr_hip.h) or OCR_WAIT_MODE=block|spin in the environment (read at the first wait); bench.py reports images/s and
+// host CPU seconds per step of both (the default follows those numbers: DESIGN.md section 7).
+int rt_wait_mode();             // 0 spin, 1 block (capi_net.hip)
+void rt_set_wait_mode(int m);
+inline hipError_t g_stream_sync(hipStream_t s) {
+  if (rt_wait_mode() == 0) return hipStreamSynchronize(s);
+  thread_local hipEvent_t ev[64] = {};  // per thread and logical device
+  const int d = rt_current_device();
+  hipEvent_t& e = ev[d >= 0 && d < 64 ? d : 0];
+  if (!e) {
+    const hipError_t c = hipEventCreateWithFlags(&e, hipEventBlockingSync | hipEventDisableTiming);
+    if (c != hipSuccess) { e = nullptr; (void)hipGetLastError(); return hipStreamSynchronize(s); }
+  }
+  const hipError_t r = hipEventRecord(e, s);
+  if (r != hipSuccess) return r;
+  return hipEventSynchronize(e);
+}
 
 // LOGICAL devices (round 5).  Every device id of the C-ABI is an index into a table that OCR_DEVICE_MAP can spell out
 // ("0,0": two logical devices on physical GPU 0; default: the identity over the visible devices).  Per-device resources of the

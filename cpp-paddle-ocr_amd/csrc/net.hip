@@ -1793,14 +1793,14 @@ bool Net::fetch_logical(int tid, std::vector<float>& host, int dims[4], hipStrea
   host.resize((size_t)M * t.c);
   if (t.plain) {
     HIP_OK(hipMemcpyAsync(host.data(), arena_ + t.offset, host.size() * sizeof(float), hipMemcpyDeviceToHost, s));
-    HIP_OK(hipStreamSynchronize(s));
+    HIP_OK(g_stream_sync(s));
     return true;
   }
   float* tmp = nullptr;
   HIP_OK(g_malloc(&tmp, host.size() * sizeof(float)));
   launch_c8i_to_plain(arena_ + t.offset, tmp, M, t.c, t.cs, s, t.f16);  // (an f16 tensor arrives converted up: exact)
   hipError_t e = hipMemcpyAsync(host.data(), tmp, host.size() * sizeof(float), hipMemcpyDeviceToHost, s);
-  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  if (e == hipSuccess) e = g_stream_sync(s);
   (void)g_free(tmp);
   if (e != hipSuccess) { err = hipGetErrorString(e); return false; }
   return true;

@@ -244,7 +244,7 @@ struct PipeWorker {
           if (rcs[l]) { err = errs[l]; return rcs[l]; }
         // this chunk's maps are free again once its network stage is idle (its own post lane, if any, has synchronised;
         // when it was not a post lane the network pass itself must be over before the stage takes chunk k+2)
-        if (hipStreamSynchronize(src.stream()) != hipSuccess) { err = "det stream sync failed"; return OCR_ERR_DEVICE; }
+        if (g_stream_sync(src.stream()) != hipSuccess) { err = "det stream sync failed"; return OCR_ERR_DEVICE; }
         src.collect_timings();
       }
     } else if (lanes <= 1) {
@@ -258,7 +258,7 @@ struct PipeWorker {
         if (rc) return rc;
       }
       // the clone above was enqueued on lane 0's stream: the other lanes' streams must not read it earlier
-      if (hipStreamSynchronize(det.stream()) != hipSuccess) { err = "det stream sync failed"; return OCR_ERR_DEVICE; }
+      if (g_stream_sync(det.stream()) != hipSuccess) { err = "det stream sync failed"; return OCR_ERR_DEVICE; }
       std::vector<int> rcs(lanes, OCR_OK);
       std::vector<std::string> errs(lanes);
       auto lane_fn = [&](int l) {
@@ -320,7 +320,7 @@ struct PipeWorker {
         if (labels[k] == 1) rd.push_back(RotDesc{const_cast<uint8_t*>(lines[k].img), lines[k].stride, lines[k].x, lines[k].y, lines[k].w, lines[k].h});
       int rrc = rotate180_in_order(rd, rot_desc, rot_seg, cls->stream(), err);
       if (rrc) return rrc;
-      if (hipStreamSynchronize(cls->stream()) != hipSuccess) { err = "cls stream sync failed"; return OCR_ERR_DEVICE; }
+      if (g_stream_sync(cls->stream()) != hipSuccess) { err = "cls stream sync failed"; return OCR_ERR_DEVICE; }
     }
     double t2 = now_ms();
     times[1] += t2 - t1;
@@ -383,7 +383,7 @@ struct PipeWorker {
       return OCR_ERR_DEVICE;
     }
     launch_warp_crops(warp_desc.p, (int)wd.size(), max_px, det.stream());
-    if (hipStreamSynchronize(det.stream()) != hipSuccess) { err = "crop kernel failed"; return OCR_ERR_DEVICE; }
+    if (g_stream_sync(det.stream()) != hipSuccess) { err = "crop kernel failed"; return OCR_ERR_DEVICE; }
     return OCR_OK;
   }
 };
@@ -564,7 +564,7 @@ struct ocr_pipe {
       }
     }
     // the clone was enqueued on worker 0's detector stream: the other workers' streams must not read it earlier
-    if (hipStreamSynchronize(w0.det.stream()) != hipSuccess) { err = "det stream sync failed"; return OCR_ERR_DEVICE; }
+    if (g_stream_sync(w0.det.stream()) != hipSuccess) { err = "det stream sync failed"; return OCR_ERR_DEVICE; }
     std::vector<std::vector<std::vector<ocr_word>>> W(K);
     std::vector<std::vector<std::vector<int32_t>>> I(K);
     std::vector<std::array<double, 3>> t(K, std::array<double, 3>{0, 0, 0});

@@ -630,7 +630,7 @@ bool SrvNet::fetch_logical(int tid, std::vector<float>& host, int dims[4], hipSt
   } else {
     srv::launch_to_f32(tensor_ptr(tid), tmp, t.pixels(), t.cs, t.c, half_, s);
   }
-  hipError_t e = hipStreamSynchronize(s);
+  hipError_t e = g_stream_sync(s);
   if (e == hipSuccess) e = g_memcpy(host.data(), tmp, cnt * sizeof(float), hipMemcpyDeviceToHost);
   (void)g_free(tmp);
   if (e != hipSuccess) { err = std::string("fetch: ") + hipGetErrorString(e); return false; }

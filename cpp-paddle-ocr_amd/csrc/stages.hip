@@ -187,7 +187,7 @@ int DetStage::post_launch(PostArgs a, int count, int32_t* boxes, int cap, int* n
     ST_HIP(hipGetLastError());  // a refused launch (e.g. LDS limit on this device) must not leave stale borders behind
     if (int rc = fetch()) return rc;
     if (attempt == 0) timer_.mark(3, stream_);
-    ST_HIP(hipStreamSynchronize(stream_));
+    ST_HIP(g_stream_sync(stream_));
     if (status && !(status & ~(POST_ERR_HULL | POST_ERR_UNCLIP))) {
       // a border outgrew the small LDS working set of the per-border stage: run that stage again with the large one
       ST_HIP(hipMemsetAsync(status_.p, 0, sizeof(int), stream_));
@@ -195,7 +195,7 @@ int DetStage::post_launch(PostArgs a, int count, int32_t* boxes, int cap, int* n
       launch_post_large(a, count, out_boxes_.p, cap, out_n_.p, stream_);
       ST_HIP(hipGetLastError());
       if (int rc = fetch()) return rc;
-      ST_HIP(hipStreamSynchronize(stream_));
+      ST_HIP(g_stream_sync(stream_));
     }
     if (!(status & POST_ERR_POOL) || attempt == 4) break;
     // what the maps would have needed (largest image decides: the pools are [count][cap])
@@ -203,7 +203,7 @@ int DetStage::post_launch(PostArgs a, int count, int32_t* boxes, int cap, int* n
     std::vector<unsigned> mneed(a.slow ? count : 0);
     ST_HIP(hipMemcpyAsync(need.data(), pool_need_.p, count * sizeof(int), hipMemcpyDeviceToHost, stream_));
     if (a.slow) ST_HIP(hipMemcpyAsync(mneed.data(), mask_top_.p, count * sizeof(unsigned), hipMemcpyDeviceToHost, stream_));
-    ST_HIP(hipStreamSynchronize(stream_));
+    ST_HIP(g_stream_sync(stream_));
     const long want_keys = *std::max_element(need.begin(), need.end());
     const size_t want_words = a.slow ? (size_t)*std::max_element(mneed.begin(), mneed.end()) : 0;
     bool grew = false;
@@ -471,7 +471,7 @@ int RecStage::run(const ocr_img* imgs, int n, int32_t* ids, int max_len, int* le
   const int rc = run_lines(lines, seg, ids, max_len, lens, scores, err);
   timer_.mark(2, stream_);
   timer_.mark(3, stream_);
-  (void)hipStreamSynchronize(stream_);
+  (void)g_stream_sync(stream_);
   timer_.read(times);
   return rc;
 }
@@ -652,7 +652,7 @@ int RecStage::run_lines(const std::vector<LineSrc>& lines, const std::vector<int
     ST_HIP(hipMemcpyAsync(h_amax.data(), amax_.p, step_total * sizeof(int), hipMemcpyDeviceToHost, stream_));
     ST_HIP(hipMemcpyAsync(h_pmax.data(), pmax_.p, step_total * sizeof(float), hipMemcpyDeviceToHost, stream_));
   }
-  ST_HIP(hipStreamSynchronize(stream_));
+  ST_HIP(g_stream_sync(stream_));
   net_.collect_timings();
   if (srv_) srv_->collect_timings();
   for (const Slot& sl : slots)
@@ -715,7 +715,7 @@ int ClsStage::run(const ocr_img* imgs, int n, int* labels, float* scores, double
   const int rc = run_lines(lines, labels, scores, err);
   timer_.mark(2, stream_);
   timer_.mark(3, stream_);
-  (void)hipStreamSynchronize(stream_);
+  (void)g_stream_sync(stream_);
   timer_.read(times);
   return rc;
 }
@@ -745,7 +745,7 @@ int ClsStage::run_lines(const std::vector<LineSrc>& lines, int* labels, float* s
   ST_HIP(hipMemcpyAsync(labels, amax_.p, n * sizeof(int), hipMemcpyDeviceToHost, stream_));
   ST_HIP(hipMemcpyAsync(scores, pmax_.p, n * sizeof(float), hipMemcpyDeviceToHost, stream_));
   ST_HIP(hipMemcpyAsync(tap_probs.data(), probs_.p, tap_probs.size() * sizeof(float), hipMemcpyDeviceToHost, stream_));
-  ST_HIP(hipStreamSynchronize(stream_));
+  ST_HIP(g_stream_sync(stream_));
   net_.collect_timings();
   return OCR_OK;
 }

@@ -366,6 +366,13 @@ class OCRWorker {
   bool isIdle() const { return is_idle_; }
   int getWorkerId() const { return worker_id_; }
   int getGpuId() const { return gpu_id_; }
+  // load figures for the pool's dispatch and its statistics (round 6): requests waiting in this worker's queue, plus the
+  // batch it is running; requests it has answered
+  int queueDepth() {
+    std::lock_guard<std::mutex> lock(queue_mutex_);
+    return (int)request_queue_.size() + in_flight_.load();
+  }
+  long requestsServed() const { return served_.load(); }
 
   // processRequest (ocr_worker.cpp:213-311) — public here so tests can call it without the thread
   OCRResult processRequest(const OCRRequest& request) {
@@ -481,7 +488,7 @@ class OCRWorker {
           }
         };
         take();
-        if (!batch.empty()) is_idle_ = false;
+        if (!batch.empty()) { is_idle_ = false; in_flight_ = (int)batch.size(); }
       }
       if (batch.empty()) continue;
       std::vector<const OCRRequest*> ptrs;
@@ -498,6 +505,8 @@ class OCRWorker {
         }
       }
       for (size_t i = 0; i < batch.size(); ++i) batch[i]->result_promise.set_value(detail::result_json(rs[i], worker_id_));
+      served_ += (long)batch.size();
+      in_flight_ = 0;
       is_idle_ = true;
     }
   }
@@ -509,6 +518,8 @@ class OCRWorker {
   std::vector<ocr_word> batch_words_;
   std::vector<int32_t> batch_ids_;
   std::atomic<bool> running_, is_idle_;
+  std::atomic<int> in_flight_{0};
+  std::atomic<long> served_{0};
   std::thread worker_thread_;
   std::queue<std::shared_ptr<OCRRequest>> request_queue_;
   std::mutex queue_mutex_;
@@ -522,14 +533,22 @@ class OCRWorker {
 // i mod ocr_rt_device_count(): whole images are sharded over the node's GPUs, nothing else changes.
 class GPUWorkerPool {
  public:
+  // Dispatch: the reference's rule (first idle worker, else round robin: gpu_worker_pool.cpp:46-59) is the default.
+  // LeastQueued (round 6, an option): the worker with the fewest requests queued or running - under a stream of mixed-size
+  // requests round robin hands a slow worker as many requests as a fast one (profiles/r6_pool_load.json has the histograms).
+  // OCR_POOL_DISPATCH=least in the environment selects it for pools that do not call setDispatch.
+  enum Dispatch { IdleFirstRoundRobin = 0, LeastQueued = 1 };
   GPUWorkerPool(const std::string& model_dir, int num_workers = 2) : next_worker_index_(0) {
     const int ngpu = ocr_rt_device_count();
     if (ngpu <= 0) throw std::runtime_error("GPUWorkerPool: no HIP device visible");
     for (int i = 0; i < num_workers; ++i) workers_.emplace_back(std::make_unique<OCRWorker>(i, model_dir, true, i % ngpu));
+    if (const char* e = getenv("OCR_POOL_DISPATCH")) if (e[0] == 'l') dispatch_ = LeastQueued;
+    depth_hist_.assign(65, 0);
   }
   ~GPUWorkerPool() { stop(); }
   void start() { for (auto& w : workers_) w->start(); }
   void stop() { for (auto& w : workers_) w->stop(); }
+  void setDispatch(Dispatch d) { dispatch_ = d; }
   std::future<std::string> submitRequest(std::shared_ptr<OCRRequest> request) {
     auto future = request->result_promise.get_future();
     getAvailableWorker()->addRequest(request);
@@ -537,17 +556,37 @@ class GPUWorkerPool {
   }
   int getOptimalWorkerCount() { return ocr_rt_device_count(); }  // declared, never defined in the reference
   int workerDevice(int i) const { return workers_[i]->getGpuId(); }
+  int workerCount() const { return (int)workers_.size(); }
+  // statistics: requests answered per worker; histogram of the chosen worker's depth (queued + running) at submit time,
+  // bucket 64 = 64 or more
+  std::vector<long> requestsPerWorker() const { std::vector<long> v; for (auto& w : workers_) v.push_back(w->requestsServed()); return v; }
+  std::vector<long> submitDepthHistogram() { std::lock_guard<std::mutex> lock(workers_mutex_); return depth_hist_; }
 
  private:
-  OCRWorker* getAvailableWorker() {  // first idle, else round robin (gpu_worker_pool.cpp:46-59)
+  OCRWorker* getAvailableWorker() {
     std::lock_guard<std::mutex> lock(workers_mutex_);
-    for (auto& w : workers_) if (w->isIdle()) return w.get();
-    const int index = next_worker_index_.fetch_add(1) % (int)workers_.size();
-    return workers_[index].get();
+    OCRWorker* pick = nullptr;
+    if (dispatch_ == LeastQueued) {
+      int best = 1 << 30;
+      const int n = (int)workers_.size(), start = next_worker_index_.fetch_add(1) % n;  // (ties: rotate, so that an idle pool still spreads)
+      for (int k = 0; k < n; ++k) {
+        OCRWorker* w = workers_[(start + k) % n].get();
+        const int d = w->queueDepth();
+        if (d < best) { best = d; pick = w; }
+      }
+    } else {  // first idle, else round robin (gpu_worker_pool.cpp:46-59)
+      for (auto& w : workers_) if (w->isIdle()) { pick = w.get(); break; }
+      if (!pick) pick = workers_[next_worker_index_.fetch_add(1) % (int)workers_.size()].get();
+    }
+    const int d = pick->queueDepth();
+    depth_hist_[d > 64 ? 64 : d]++;
+    return pick;
   }
   std::vector<std::unique_ptr<OCRWorker>> workers_;
   std::mutex workers_mutex_;
   std::atomic<int> next_worker_index_;
+  Dispatch dispatch_ = IdleFirstRoundRobin;
+  std::vector<long> depth_hist_;
 };
 
 }  // namespace PaddleOCR

@@ -32,6 +32,12 @@ const char* ocr_last_error(void);
 /* Selects the HIP device for the calling thread; fails when no gfx950 device is visible. */
 int ocr_rt_init(int device_id);
 int ocr_rt_device_count(void);
+/* How the library's host threads wait for their streams (process-wide; round 6): 1 = block on an event created with
+ * hipEventBlockingSync (the thread sleeps until the interrupt; default), 0 = hipStreamSynchronize's spin (what rounds 1-5 did:
+ * three spinning host threads per pipeline handle, 24 busy cores for the eight ranks of a node).  OCR_WAIT_MODE=spin|block in
+ * the environment sets the initial mode.  The reference has no counterpart: its workers wait inside Paddle's predictor. */
+int ocr_rt_set_wait_mode(int mode);
+int ocr_rt_get_wait_mode(void);
 
 /* An image view: CV_8UC3 BGR rows, possibly a non-contiguous ROI (row_stride in bytes) —
  * the `const cv::Mat&` of the reference signatures. */

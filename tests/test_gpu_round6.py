@@ -203,3 +203,23 @@ def test_server_pipeline_twin_equals_the_oracle_and_fp16_stays_close(pkg, built)
             lines += 1
             same16 += np.array_equal(a["ids"], b["ids"])
     assert same16 >= 0.9 * lines, (same16, lines)
+
+
+def test_pool_under_a_mixed_size_stream_on_eight_logical_devices(pkg, built):
+    """the C++ GPUWorkerPool (worker i -> device i mod n, /root/reference/src/gpu_worker_pool.cpp:12-16,46-59)
+    under a configs[3]-shaped closed-loop stream of mixed-size requests on EIGHT logical devices of one process
+    (OCR_DEVICE_MAP=0,0,0,0,0,0,0,0 on a one-GPU lease: own attribute memos, arenas, streams and chain threads per logical
+    id), in both dispatch modes: every reply's words equal the one-worker pool's reply for the same image, every worker
+    served requests, and the same image gets the same words whoever serves it (host/pool_load.cpp)."""
+    import json
+    import subprocess
+    host = os.path.join(ROOT, "cpp-paddle-ocr_amd", "host")
+    subprocess.check_call(["make", "-s", "-C", host])
+    env = dict(os.environ, OCR_DEVICE_MAP="0,0,0,0,0,0,0,0", OCR_WORKER_DET_LIMIT="960")
+    for extra in ([], ["least"]):
+        out = subprocess.run([os.path.join(host, "pool_load"), os.path.join(ROOT, "models"), "8", "240", "24", "24"] + extra,
+                             capture_output=True, text=True, timeout=600, env=env)
+        assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
+        js = json.loads(out.stdout.strip().splitlines()[-1])
+        assert js["replies_differing_from_one_worker"] == 0
+        assert sum(js["requests_per_worker"]) == 240 and min(js["requests_per_worker"]) > 0, js["requests_per_worker"]

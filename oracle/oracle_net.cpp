@@ -735,5 +735,6 @@ long oracle_net_tensor(void* h, int tid, int* dims, const float** data) {
   return (long)t.d.size();
 }
 float oracle_expf(float x) { return ocr_expf(x); }
+float oracle_erff(float x) { return ocr_erff(x); }
 
 }  // extern "C"

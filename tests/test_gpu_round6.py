@@ -217,9 +217,9 @@ def test_pool_under_a_mixed_size_stream_on_eight_logical_devices(pkg, built):
     subprocess.check_call(["make", "-s", "-C", host])
     env = dict(os.environ, OCR_DEVICE_MAP="0,0,0,0,0,0,0,0", OCR_WORKER_DET_LIMIT="960")
     for extra in ([], ["least"]):
-        out = subprocess.run([os.path.join(host, "pool_load"), os.path.join(ROOT, "models"), "8", "240", "24", "24"] + extra,
+        out = subprocess.run([os.path.join(host, "pool_load"), os.path.join(ROOT, "models"), "8", "120", "24", "16"] + extra,
                              capture_output=True, text=True, timeout=600, env=env)
         assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
         js = json.loads(out.stdout.strip().splitlines()[-1])
         assert js["replies_differing_from_one_worker"] == 0
-        assert sum(js["requests_per_worker"]) == 240 and min(js["requests_per_worker"]) > 0, js["requests_per_worker"]
+        assert sum(js["requests_per_worker"]) == 120 and min(js["requests_per_worker"]) > 0, js["requests_per_worker"]

@@ -223,6 +223,43 @@ __global__ void __launch_bounds__(64 * WM * WN) srv_gemm_kernel(const GemmArgs a
       for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
 
   const int nkt = a.nkt;
+  // ---- what the register epilogue (f16 build, below) needs from memory is requested BEFORE the K loop: its parameters and
+  // the residual chunks of this lane.  Loaded where they are used, each tile paid a full memory latency between its last
+  // matrix instruction and its first store (probe: 0.34 ms of a 1.06 ms launch on SVTR's 192 -> 768 linear).
+  // (the f16 build folds batch norm into weights and bias - srv_net.hip - so a scale / shift pair only reaches the staged form)
+  const bool direct = HALF && !a.deconv && !a.out_f32 && !a.scale;
+  float pre_b[TN][2][8];
+  h8v pre_r[TN][TM][2];
+  if (direct) {
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const int n = n0 + wn * TN * 32 + i * 32 + 8 * h + 16 * c;
+        if (a.bias) ld8(a.bias + n, pre_b[i][c]);
+      }
+    if (a.res_up) {
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+        const long m = m0 + wm * TM * 32 + j * 32 + r;
+        long rp = m < a.M ? m : a.M - 1;
+        if (a.res_up == 2) {
+          const int ohw = a.OH * a.OW;
+          const int ni = (int)(rp / ohw);
+          const int rem = (int)(rp - (long)ni * ohw);
+          const int oy = rem / a.OW, ox = rem - oy * a.OW;
+          rp = ((long)ni * (a.OH >> 1) + (oy >> 1)) * (a.OW >> 1) + (ox >> 1);
+        }
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            const int n = n0 + wn * TN * 32 + i * 32 + 8 * h + 16 * c;
+            if constexpr (HALF) pre_r[i][j][c] = n < a.Cs_out ? *(const h8v*)((const _Float16*)a.res + rp * a.Cs_out + n) : h8v{0, 0, 0, 0, 0, 0, 0, 0};
+          }
+      }
+    }
+  }
   // prologue: NS - 1 stages in flight
 #pragma unroll
   for (int s = 0; s < NS - 1; ++s)
@@ -275,7 +312,78 @@ __global__ void __launch_bounds__(64 * WM * WN) srv_gemm_kernel(const GemmArgs a
     }
     if (++cbuf == NS) cbuf = 0;
   }
-  // ---- epilogue: accumulators -> f32 LDS tile [pixel][channel] -> whole 16-byte chunks of pixel rows
+#ifdef SRV_PROBE_NOEPI  // development probe: the K loop alone (one value per lane keeps the accumulators alive)
+  {
+    float keep = 0.f;
+    for (int i = 0; i < TN; ++i) for (int j = 0; j < TM; ++j) for (int q = 0; q < 16; ++q) keep += acc[i][j][q];
+    if (keep == 123456.75f) ((float*)a.y)[tid] = keep;
+    return;
+  }
+#endif
+  // ---- epilogue, f16 build, straight from the registers (round 6: the staged form below cost 0.28-0.5 ms of a 1.1 ms launch on
+  // SVTR's fc1 shapes - tools/micro/srv_gemm_probe, knock-out table in DESIGN.md section 10 - an f32 tile written to LDS at
+  // ~80 bytes per clock, two barriers, nothing in flight meanwhile).  A lane (pixel r, half h) holds channels 8q + 4h + e of a
+  // 32-column block in register 4q + e; one v_permlane32_swap per register pair (q, q + 1) hands each lane EIGHT consecutive
+  // channels - h = 0: 0..7 and 16..23, h = 1: 8..15 and 24..31 - so a chunk leaves (and its residual arrives) as one 16-byte
+  // access, a pixel's two halves side by side.  Four such instructions of a wave cover 128-byte lines; L2 merges them.
+  if constexpr (HALF) {
+    if (direct) {
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        const int nb = n0 + wn * TN * 32 + i * 32 + 8 * h;  // first channel of this lane's chunk A (chunk B: + 16)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+          const long m = m0 + wm * TM * 32 + j * 32 + r;
+          // after the swaps: registers 0..7 = chunk A, 8..15 = chunk B
+          // (inline asm: hipcc 7.2 hands back the FIRST result of __builtin_amdgcn_permlane32_swap for both of its results -
+          // a two-line test kernel stores one register twice; s_nop: nothing inside an asm statement is padded.  The eight
+          // swaps of a block in one statement: one pad in front, one behind)
+          {
+            f16x& A = acc[i][j];
+            float a0 = A[0], a1 = A[1], a2 = A[2], a3 = A[3], a4 = A[4], a5 = A[5], a6 = A[6], a7 = A[7];
+            float b0 = A[8], b1 = A[9], b2 = A[10], b3 = A[11], b4 = A[12], b5 = A[13], b6 = A[14], b7 = A[15];
+            asm volatile(
+                "s_nop 1\n\tv_permlane32_swap_b32 %0, %4\n\tv_permlane32_swap_b32 %1, %5\n\tv_permlane32_swap_b32 %2, %6\n\tv_permlane32_swap_b32 %3, %7\n\t"
+                "v_permlane32_swap_b32 %8, %12\n\tv_permlane32_swap_b32 %9, %13\n\tv_permlane32_swap_b32 %10, %14\n\tv_permlane32_swap_b32 %11, %15\n\ts_nop 1"
+                : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3),
+                  "+v"(b4), "+v"(b5), "+v"(b6), "+v"(b7));
+            A[0] = a0; A[1] = a1; A[2] = a2; A[3] = a3; A[4] = a4; A[5] = a5; A[6] = a6; A[7] = a7;
+            A[8] = b0; A[9] = b1; A[10] = b2; A[11] = b3; A[12] = b4; A[13] = b5; A[14] = b6; A[15] = b7;
+          }
+          if (m >= a.M) continue;
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            const int n = nb + 16 * c;
+            if (n >= a.Cs_out) continue;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = acc[i][j][8 * c + e];
+            if (a.bias) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] = v[e] + pre_b[i][c][e];
+            }
+            if (a.res_up) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] = v[e] + (float)pre_r[i][j][c][e];
+            }
+            if (a.act != SACT_NONE) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] = srv_act(a.act, v[e]);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+              if (n + e >= a.Ncols) v[e] = 0.f;
+#ifdef SRV_PROBE_NOSTORE
+            if (v[0] == 123456.75f)
+#endif
+            st8((T*)a.y + m * a.Cs_out + n, v);
+          }
+        }
+      }
+      return;
+    }
+  }
+  // ---- epilogue (f32 twin, transposed convs, f32 outputs): accumulators -> f32 LDS tile [pixel][channel] -> whole 16-byte chunks of pixel rows
   __syncthreads();  // (no DMA is outstanding: the last iteration waited for vmcnt(0))
   float* const tile = (float*)smem;
 #pragma unroll
@@ -348,8 +456,12 @@ __global__ void __launch_bounds__(64 * WM * WN) srv_gemm_kernel(const GemmArgs a
 #pragma unroll
     for (int e = 0; e < 8; ++e)
       if (n + e >= a.Ncols) v[e] = 0.f;  // pad channels hold zeros
+#ifdef SRV_PROBE_NOSTORE  // development probe (tools/micro/srv_gemm_probe.hip): everything but the output stores
+    if (v[0] == 123456.75f) st8((T*)a.y + opix * a.Cs_out + co, v);
+#else
     if (a.out_f32) st8((float*)a.y + opix * a.Cs_out + co, v);
     else st8((T*)a.y + opix * a.Cs_out + co, v);
+#endif
   }
 }
 
@@ -365,11 +477,13 @@ struct GemmCfg { const char* name; int bm, bn, nt; unsigned lds_h, lds_f; };
   X(4, 128, 256, 1, 8, 3)    \
   X(5, 128, 128, 2, 4, 3)    \
   X(6, 256, 128, 4, 2, 3)    \
-  X(7, 256, 128, 4, 2, 2)
+  X(7, 256, 128, 4, 2, 2)    \
+  X(8, 128, 64, 2, 2, 3)     \
+  X(9, 64, 64, 2, 2, 3)
 // the persistent form (srv_pgemm.h; x1 problems only): id, f16 tile and waves, f32-twin tile and waves
 #define SRV_PCFGS(X)                        \
-  X(8, 128, 128, 2, 4, 64, 64, 2, 2)        \
-  X(9, 128, 128, 2, 2, 64, 64, 2, 2)
+  X(10, 128, 128, 2, 4, 64, 64, 2, 2)       \
+  X(11, 128, 128, 2, 2, 64, 64, 2, 2)
 static const GemmCfg g_cfgs[] = {
 #define X(id, BM, BN, WM, WN, NS) {#BM "x" #BN "/" #WM "x" #WN "/s" #NS, BM, BN, 64 * WM * WN, GemmGeom<_Float16, BM, BN, WM, WN, NS>::LDS, GemmGeom<float, BM, BN, WM, WN, NS>::LDS},
     SRV_CFGS(X)

@@ -61,8 +61,10 @@ int main(int argc, char** argv) {
   hipEventCreate(&e0); hipEventCreate(&e1);
   std::string err;
   std::vector<_Float16> hy(hr.size());
+  const int only = getenv("PROBE_CFG") ? atoi(getenv("PROBE_CFG")) : -1;  // (one configuration: profiler runs)
   for (int r = 0; r < rounds + 1; ++r)
     for (int c = 0; c < nc; ++c) {
+      if (only >= 0 && c != only) continue;
       if (!gemm_config_ok(a, true, c)) continue;
       hipEventRecord(e0, nullptr);
       for (int it = 0; it < 3; ++it) launch_gemm(a, true, c, nullptr, err);

@@ -5,6 +5,7 @@
 #include <array>
 #include <cmath>
 #include <cstring>
+#include <mutex>
 #include <sstream>
 
 #include "hip_guard.h"
@@ -261,9 +262,39 @@ bool SrvNet::load(const char* plan_text, const WeightMap& weights, bool half, st
   return true;
 }
 
+// OCR_SRV_TUNE_FILE=<path>: the tile configurations found on the device are kept in a text file ("<precision> <launch name> <id>"
+// per line) and read back by later processes - a service does not re-time its layers at every start, and a profiler run of the
+// bench shows the network's launches only (tools/run_profile_cfg5.sh: the tuning launches of one run were 90 % of its trace).
+namespace {
+std::mutex g_tune_mu;
+std::map<std::string, int>& tune_file_cache() {
+  static std::map<std::string, int> m;
+  static bool loaded = false;
+  if (!loaded) {
+    loaded = true;
+    if (const char* fn = getenv("OCR_SRV_TUNE_FILE")) {
+      if (FILE* f = fopen(fn, "r")) {
+        char prec[16], name[256];
+        int id;
+        while (fscanf(f, "%15s %255s %d", prec, name, &id) == 3) m[std::string(prec) + " " + name] = id;
+        fclose(f);
+      }
+    }
+  }
+  return m;
+}
+}  // namespace
+
 int SrvNet::tune(const srv::GemmArgs& a, const std::string& key, hipStream_t s) {
   auto it = tuned_.find(key);
   if (it != tuned_.end()) return it->second;
+  const std::string fkey = std::string(half_ ? "fp16 " : "fp32 ") + key;
+  {
+    std::lock_guard<std::mutex> lk(g_tune_mu);
+    auto& fc = tune_file_cache();
+    auto fi = fc.find(fkey);
+    if (fi != fc.end() && srv::gemm_config_ok(a, half_, fi->second)) { tuned_[key] = fi->second; return fi->second; }
+  }
   static const bool do_tune = [] { const char* e = getenv("OCR_SRV_TUNE"); return !(e && e[0] == '0'); }();
   static const int forced = [] { const char* e = getenv("OCR_SRV_CFG"); return e && *e ? atoi(e) : -1; }();
   int best = -1;
@@ -296,6 +327,15 @@ int SrvNet::tune(const srv::GemmArgs& a, const std::string& key, hipStream_t s) 
     (void)hipEventDestroy(e1);
   }
   tuned_[key] = best;
+  if (best >= 0 && forced < 0 && do_tune) {
+    std::lock_guard<std::mutex> lk(g_tune_mu);
+    auto& fc = tune_file_cache();
+    if (!fc.count(fkey)) {
+      fc[fkey] = best;
+      if (const char* fn = getenv("OCR_SRV_TUNE_FILE"))
+        if (FILE* f = fopen(fn, "a")) { fprintf(f, "%s %d\n", fkey.c_str(), best); fclose(f); }
+    }
+  }
   return best;
 }
 

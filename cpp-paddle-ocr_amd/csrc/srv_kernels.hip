@@ -662,40 +662,44 @@ void launch_addpos(const void* x, const float* pos, void* y, long pixels, int hw
 
 // ---- layer norm.  f16: a wave per row, lane l owns granules l, l + 64, ... (f32 arithmetic, wave reductions);
 // f32 twin: a thread per row, the oracle's sequential sums
+// LPR = lanes per row (C / 8 granules, rounded up to a power of two: 32 for C = 192 / 256, 64 for C = 512): a wave normalises
+// 64 / LPR rows at once (round 6: one row per wave left 40 of 64 lanes idle at C = 192 - 2.4 TB/s)
+template <int LPR>
 __global__ void __launch_bounds__(256) layernorm_h_kernel(const _Float16* __restrict__ x, const float* __restrict__ g, const float* __restrict__ b,
                                                           _Float16* __restrict__ y, long rows, int C, float eps) {
-  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
-  const int lane = threadIdx.x & 63;
-  const int G = C >> 3;  // granules per row (<= 128)
+  constexpr int RPW = 64 / LPR;
+  const int lane = threadIdx.x & 63, sub = lane / LPR, l = lane % LPR;
+  const long row = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + sub;
+  const int G = C >> 3;  // granules per row (<= 2 * LPR)
+  const bool live = row < rows;
   float v[2][8];
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const int gi = lane + 64 * i;
-    if (gi < G) {
+    const int gi = l + LPR * i;
+    if (live && gi < G) {
       ld8(x + row * C + 8 * gi, v[i]);
 #pragma unroll
       for (int e = 0; e < 8; ++e) s += v[i][e];
     }
   }
 #pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+  for (int o = LPR / 2; o >= 1; o >>= 1) s += __shfl_xor(s, o);
   const float mean = s / (float)C;
   float q = 0.f;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
-    if (lane + 64 * i < G) {
+    if (live && l + LPR * i < G) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mean; q = fmaf(d, d, q); }
     }
 #pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) q += __shfl_xor(q, o);
+  for (int o = LPR / 2; o >= 1; o >>= 1) q += __shfl_xor(q, o);
   const float rstd = 1.0f / sqrtf(q / (float)C + eps);
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const int gi = lane + 64 * i;
-    if (gi < G) {
+    const int gi = l + LPR * i;
+    if (live && gi < G) {
       float gg[8], bb[8], o[8];
       ld8(g + 8 * gi, gg);
       ld8(b + 8 * gi, bb);
@@ -726,7 +730,12 @@ __global__ void __launch_bounds__(64) layernorm_f_kernel(const float* __restrict
   }
 }
 void launch_layernorm(const void* x, const float* g, const float* b, void* y, long rows, int C, float eps, bool half, hipStream_t s) {
-  if (half) hipLaunchKernelGGL(layernorm_h_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, (const _Float16*)x, g, b, (_Float16*)y, rows, C, eps);
+  if (half) {
+    const int G = C >> 3;
+    if (G <= 32) hipLaunchKernelGGL(layernorm_h_kernel<16>, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, s, (const _Float16*)x, g, b, (_Float16*)y, rows, C, eps);
+    else if (G <= 64) hipLaunchKernelGGL(layernorm_h_kernel<32>, dim3((unsigned)((rows + 7) / 8)), dim3(256), 0, s, (const _Float16*)x, g, b, (_Float16*)y, rows, C, eps);
+    else hipLaunchKernelGGL(layernorm_h_kernel<64>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, (const _Float16*)x, g, b, (_Float16*)y, rows, C, eps);
+  }
   else hipLaunchKernelGGL(layernorm_f_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, s, (const float*)x, g, b, (float*)y, rows, C, eps);
 }
 

@@ -57,6 +57,13 @@ const char* gemm_config_name(int cfg);
 bool gemm_config_ok(const GemmArgs& a, bool half, int cfg);
 bool launch_gemm(const GemmArgs& a, bool half, int cfg, hipStream_t s, std::string& err);
 
+// SVTR's MLP in one launch (f16 build): y = x + fc2(gelu(fc1(x) + b1)) + b2, x / y [M][C] f16, the weight images of the two linears
+// as launch_gemm takes them; C in {192, 256, 512}.  query: instantiation / LDS attribute check only.  Bit-identical to the two
+// launches it replaces (srv_mlp.h).
+bool launch_mlp(const void* x, unsigned long long x_bytes, const void* w1, unsigned long long w1_bytes, int w1_npad, const void* w2,
+                unsigned long long w2_bytes, int w2_npad, const float* b1, const float* b2, void* y, long M, int C, hipStream_t s, bool query,
+                std::string& err);
+
 // f32 [N][H][W][3] (the normalised image, what the pre-processing kernels write) -> T [N][H][W][8], channels 3..7 zero
 void launch_pack_input(const float* x, void* y, long pixels, bool half, hipStream_t s);
 // max / average pool (window kh x kw, stride, padding; positions outside the image take no part)

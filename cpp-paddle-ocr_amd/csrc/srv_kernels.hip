@@ -76,6 +76,27 @@ __device__ __forceinline__ float srv_act(int act, float y) {
   }
 }
 
+// the f16 build's activations: results are rounded to 11 bits anyway - hardware exp2 / rcp instead of the contract's exp and the
+// IEEE quotients (GELU: the same Abramowitz-Stegun erf, ~14 instructions instead of ~45; it sits in the epilogue of SVTR's
+// widest linears and inside the fused MLP, 32 values per lane per 128 hidden units)
+__device__ __forceinline__ float srv_act_h(int act, float y) {
+  switch (act) {
+    case SACT_RELU: return fmaxf(y, 0.0f);
+    case SACT_GELU: {
+      // x * sigmoid(2 sqrt(2 / pi) (x + 0.044715 x^3)) - the tanh form: within 4.7e-4 of the erf form everywhere, below the f16
+      // rounding of the values it produces (2^-11 relative); seven instructions per value instead of seventeen.  The hidden
+      // units of SVTR's MLP pass through here M x 4 C times: at the erf form's cost the activation alone was 3500 cycles per
+      // 128-unit chunk per wave against 1536 cycles of matrix instructions (stamps: tools/micro/srv_mlp_probe)
+      const float x2 = y * y;
+      const float w = y * fmaf(x2, -0.10294324f, -2.3022082f);   // -(1.5957691 + 0.0713548 x^2) x log2(e)
+      return y * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(w));
+    }
+    case SACT_HSWISH: return y * fminf(fmaxf(y + 3.0f, 0.0f), 6.0f) * 0.16666666666666667f;
+    case SACT_SIGMOID: return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-y * 1.44269504088896341f));
+    default: return y;
+  }
+}
+
 // 8 consecutive elements of a T tensor <-> 8 floats
 __device__ __forceinline__ void ld8(const _Float16* p, float (&v)[8]) {
   const h8v t = *(const h8v*)p;
@@ -271,7 +292,10 @@ __global__ void __launch_bounds__(64 * WM * WN) srv_gemm_kernel(const GemmArgs a
     else srv_wait_vm<0>();                                  // (tail: fewer were issued)
     __builtin_amdgcn_s_barrier();                           // every wave's pieces of stage kt are in LDS; stage kt - 1 is read out
     asm volatile("" ::: "memory");
-    if (kt + NS - 1 < nkt) issue();                         // into the buffer stage kt - 1 occupied
+    // The next stage's DMA: with three ring slots it goes out BEHIND this stage's matrix instructions (below) - a DMA piece costs
+    // its wave ~150 issue cycles (stamps: tools/micro/srv_mlp_probe), which then pass while the matrix pipe works; with two slots
+    // it is the only stage in flight and goes out first (probe: 128x64/s2 0.97 -> 1.02 ms on 192 -> 768 when it went out last)
+    if (NS == 2 && kt + NS - 1 < nkt) issue();
     const unsigned char* sw = smem + (unsigned)cbuf * STG + (unsigned)(wn * TN * 32 + r) * 128u;
     const unsigned char* sx = smem + (unsigned)cbuf * STG + (unsigned)BN * 128u + (unsigned)(wm * TM * 32 + r) * 128u;
     if constexpr (HALF) {
@@ -310,6 +334,7 @@ __global__ void __launch_bounds__(64 * WM * WN) srv_gemm_kernel(const GemmArgs a
             }
       }
     }
+    if (NS > 2 && kt + NS - 1 < nkt) issue();               // into the buffer stage kt - 1 occupied (every wave is past this stage's barrier)
     if (++cbuf == NS) cbuf = 0;
   }
 #ifdef SRV_PROBE_NOEPI  // development probe: the K loop alone (one value per lane keeps the accumulators alive)
@@ -368,7 +393,7 @@ __global__ void __launch_bounds__(64 * WM * WN) srv_gemm_kernel(const GemmArgs a
             }
             if (a.act != SACT_NONE) {
 #pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] = srv_act(a.act, v[e]);
+              for (int e = 0; e < 8; ++e) v[e] = srv_act_h(a.act, v[e]);
             }
 #pragma unroll
             for (int e = 0; e < 8; ++e)
@@ -466,6 +491,7 @@ __global__ void __launch_bounds__(64 * WM * WN) srv_gemm_kernel(const GemmArgs a
 }
 
 #include "srv_pgemm.h"
+#include "srv_mlp.h"
 
 // ---- tile configurations (autotuned per layer at bind time: srv_net.hip)
 struct GemmCfg { const char* name; int bm, bn, nt; unsigned lds_h, lds_f; };
@@ -555,6 +581,28 @@ bool gemm_config_ok(const GemmArgs& a, bool half, int cfg) {
   return gemm_dispatch(a, half, cfg, nullptr, true, e);
 }
 bool launch_gemm(const GemmArgs& a, bool half, int cfg, hipStream_t s, std::string& err) { return gemm_dispatch(a, half, cfg, s, false, err); }
+
+bool launch_mlp(const void* x, unsigned long long x_bytes, const void* w1, unsigned long long w1_bytes, int w1_npad, const void* w2,
+                unsigned long long w2_bytes, int w2_npad, const float* b1, const float* b2, void* y, long M, int C, hipStream_t s, bool query,
+                std::string& err) {
+  if (x_bytes >= 0xfffffff0ull || w1_bytes >= 0xfffffff0ull || w2_bytes >= 0xfffffff0ull) { err = "tensor beyond the 4 GB a buffer descriptor spans"; return false; }
+  MlpArgs a{x, x_bytes, w1, w1_bytes, w1_npad, w2, w2_bytes, w2_npad, b1, b2, y, M};
+  const unsigned nb = (unsigned)((M + 127) / 128);
+  static LdsAttrMemo m192, m256, m512;
+  switch (C) {
+#define SRV_MLP_CASE(CC, memo)                                                                                              \
+    case CC:                                                                                                                \
+      if (!raise_dynamic_lds((const void*)srv_mlp_kernel<CC>, (int)MlpGeom<CC>::LDS, memo)) { err = "dynamic LDS attribute refused"; return false; } \
+      if (!query) hipLaunchKernelGGL(srv_mlp_kernel<CC>, dim3(nb), dim3(512), MlpGeom<CC>::LDS, s, a);                      \
+      return true;
+    SRV_MLP_CASE(192, m192)
+    SRV_MLP_CASE(256, m256)
+    SRV_MLP_CASE(512, m512)
+#undef SRV_MLP_CASE
+  }
+  err = "fused MLP: channel count not instantiated";
+  return false;
+}
 
 // =================================================================================================== streaming kernels
 template <typename T>

@@ -380,6 +380,35 @@ bool SrvNet::bind(int N, int H, int W, hipStream_t s, std::string& err) {
       set(o, in.n, in.h, in.w, in.c);
     }
   }
+  // ---- SVTR's MLP pairs as one launch (f16 build, production mode; srv_mlp.h): `linear C -> 4C | gelu` whose only reader is
+  // `linear 4C -> C | + the first linear's input`: the hidden tensor then never exists (no arena slot, no launch of its own)
+  std::vector<char> mlp_head(ops_.size(), 0), mlp_tail(ops_.size(), 0);
+  {
+    // OCR_SRV_MLP=0: never; =all: every width; default: C <= 256 (measured, tools/micro/srv_mlp_probe + tools/srv_bench.py: 1.46 ms
+    // against 1.60 for the two launches at C = 192, 1.22 against 1.20 at C = 256 with 1.5 / 1.0 GB less HBM traffic per launch;
+    // at C = 512 the 128 accumulator registers of the 128-token tile spill - 8.2 ms against 1.77 - and the pair stays two launches)
+    static const int mlp_max_c = [] { const char* e = getenv("OCR_SRV_MLP"); return e && e[0] == '0' ? 0 : (e && e[0] == 'a' ? 1 << 30 : 256); }();
+    const bool mlp_on = mlp_max_c > 0;
+    std::vector<int> readers(ntensors_ + 1, 0);
+    for (const Op& op : ops_) {
+      if (op.kind == "output") { readers[op.geti("i")] += 2; continue; }
+      if (op.kind == "concat") for (int t : op.ins) readers[t]++;
+      else readers[op.geti("i")]++;
+      if (op.res_tid >= 0) readers[op.res_tid]++;
+    }
+    for (size_t oi = 0; half_ && mlp_on && !keep_all_ && oi + 1 < ops_.size(); ++oi) {
+      const Op &f1 = ops_[oi], &f2 = ops_[oi + 1];
+      if (f1.kind != "linear" || f2.kind != "linear" || f1.act != srv::SACT_GELU || f1.res_tid >= 0 || !f1.bias || !f2.bias) continue;
+      if (f2.geti("i") != f1.geti("o") || readers[f1.geti("o")] != 1 || f2.res_tid != f1.geti("i") || f2.res_up != 1 || f2.act != srv::SACT_NONE) continue;
+      const int c = f1.geti("cin");
+      if (c > mlp_max_c) continue;
+      if (f1.geti("cout") != 4 * c || f2.geti("cin") != 4 * c || f2.geti("cout") != c || f2.geti("o") == out_tid_) continue;
+      std::string e;
+      if (!srv::launch_mlp(nullptr, 0, nullptr, 0, 0, nullptr, 0, 0, nullptr, nullptr, nullptr, 0, c, nullptr, true, e)) continue;
+      mlp_head[oi] = 1;
+      mlp_tail[oi + 1] = 1;
+    }
+  }
   // ---- arena: every tensor a slot of its own (keep_all) or first-fit reuse by last reader
   std::vector<int> last_use(ntensors_ + 1, -1);
   for (size_t oi = 0; oi < ops_.size(); ++oi) {
@@ -423,6 +452,7 @@ bool SrvNet::bind(int N, int H, int W, hipStream_t s, std::string& err) {
       const Op& op = ops_[oi];
       if (op.kind == "output") continue;
       const int o = op.geti("o");
+      if (mlp_head[oi]) { tensors_[o].n = 0; continue; }  // the hidden tensor of a fused MLP: never written
       tensors_[o].offset = alloc(tensors_[o].bytes(half_));
       if (keep_all_) continue;
       for (int t = 1; t <= ntensors_; ++t)
@@ -479,8 +509,30 @@ bool SrvNet::bind(int N, int H, int W, hipStream_t s, std::string& err) {
       launches_.push_back(L);
       continue;
     }
+    if (mlp_tail[oi]) continue;  // launched with its head
     const int itid = op.geti("i") == 0 ? pk : op.geti("i");
     const SrvTensor& in = tensors_[itid];
+    if (mlp_head[oi]) {
+      const Op& f2 = ops_[oi + 1];
+      const SrvTensor& yt = tensors_[f2.geti("o")];
+      const int c = in.c;
+      snprintf(nm, sizeof nm, "%zu.mlp_%d_%d_%d@%dx%dx%d", oi, c, 4 * c, c, yt.n, yt.h, yt.w);
+      L.name = nm;
+      const double M_ = (double)in.pixels();
+      L.flops = 2.0 * 2.0 * M_ * c * 4.0 * c;
+      L.bytes = (double)in.bytes(half_) + (double)yt.bytes(half_) + 2.0 * 4.0 * c * c * esz;
+      const void* xs = ptr(itid);
+      void* dst = ptr(f2.geti("o"));
+      const unsigned long long xb = in.bytes(half_);
+      const void *w1 = op.wimg, *w2 = f2.wimg;
+      const unsigned long long w1b = op.wimg_bytes, w2b = f2.wimg_bytes;
+      const int n1 = op.npad, n2 = f2.npad;
+      const float *b1 = op.bias, *b2 = f2.bias;
+      const long M = in.pixels();
+      L.fn = [=](hipStream_t st, std::string& e) { return srv::launch_mlp(xs, xb, w1, w1b, n1, w2, w2b, n2, b1, b2, dst, M, c, st, false, e); };
+      launches_.push_back(L);
+      continue;
+    }
     const bool gemm = (op.kind == "conv" || op.kind == "linear" || op.kind == "deconv") && op.ncols > 0;
     if (gemm) {
       srv::GemmArgs a;

@@ -223,3 +223,21 @@ def test_pool_under_a_mixed_size_stream_on_eight_logical_devices(pkg, built):
         js = json.loads(out.stdout.strip().splitlines()[-1])
         assert js["replies_differing_from_one_worker"] == 0
         assert sum(js["requests_per_worker"]) == 120 and min(js["requests_per_worker"]) > 0, js["requests_per_worker"]
+
+
+def test_fused_mlp_equals_the_two_launches(pkg, built):
+    """SVTR's MLP as one kernel (csrc/srv_mlp.h: the 4 C wide hidden tensor stays in LDS) against the two GEMM launches it
+    replaces: production mode fuses, keep_all mode materialises every tensor - the recognizer's logits are bit-identical
+    (hidden values rounded to f16 once either way, fc2 accumulating them in ascending k), and the timing report shows the
+    fused launches."""
+    _srv_ready()
+    x = np.random.RandomState(21).randn(3, 48, 320, 3).astype(np.float32)
+    net = pkg.SrvNet("rec", "fp16")
+    plain = net.forward(x, keep_all=True)
+    net.timing(True)
+    fused = net.forward(x, keep_all=False)
+    names = list(net.timing_report())
+    assert sum(".mlp_" in n for n in names) == 12, names[:8]       # the 3 + 9 blocks of width 192 and 256 (512: two launches)
+    assert not any("_768_192_" in n or "_1024_256_" in n for n in names)
+    assert np.array_equal(plain.view(np.uint32), fused.view(np.uint32)), float(np.abs(plain - fused).max())
+    net.close()

@@ -977,13 +977,16 @@ __global__ void __launch_bounds__(64 * NWV) attn_h_kernel(const _Float16* __rest
         }
         // ---- mask, running maximum (register i of lane (q, h) = key 8 (i >> 2) + 4 h + (i & 3) of the tile)
         float mt = -INFINITY;
+        if (lh > 0 || kxs + 32 > gw) {  // (wave-uniform: a full tile of a global mixer needs no mask - two thirds to seven eighths of them)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int kx = kxs + 8 * (i >> 2) + 4 * h + (i & 3);
-          const bool ok = kx < gw && (lh <= 0 || (unsigned)(kx - qx + hwx) <= (unsigned)(2 * hwx));
-          sacc[i] = ok ? sacc[i] : -INFINITY;
-          mt = fmaxf(mt, sacc[i]);
+          for (int i = 0; i < 16; ++i) {
+            const int kx = kxs + 8 * (i >> 2) + 4 * h + (i & 3);
+            const bool ok = kx < gw && (lh <= 0 || (unsigned)(kx - qx + hwx) <= (unsigned)(2 * hwx));
+            sacc[i] = ok ? sacc[i] : -INFINITY;
+          }
         }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) mt = fmaxf(mt, sacc[i]);
         mt = fmaxf(mt, __shfl_xor(mt, 32));
         const float mnew = fmaxf(mrun, mt);
         const float muse = mnew == -INFINITY ? 0.f : mnew;
@@ -1041,6 +1044,9 @@ bool launch_attention(const void* qkv, void* out, int N, int T, int heads, int h
   const size_t lds = (size_t)(T + 32) * 64 * 2;
   if (lds > 160 * 1024) { err = "attention: K and V of a line do not fit LDS"; return false; }
   const float sl = scale * 1.44269504088896341f;
+  // a Global mixer has no use for the grid: its tokens as ONE row of T (T = 240: 8 x 8 tile pairs instead of 9 x 9 row-aligned
+  // ones whose third column tile is half empty, T = 480: 15 x 15 instead of 18 x 18)
+  if (lh <= 0) { gh = 1; gw = T; }
   const int segs = (gw + 31) / 32, nq = gh * segs;
   static LdsAttrMemo memo8, memo4;
   if (nq >= 16) {

@@ -276,7 +276,9 @@ def fp16_leg(mk_pipe, run_of, ref_words, batch, steps, sync):
            "vs_fp32_words": {"words": tot, "identical_boxes": same_box / max(1, tot), "identical_id_sequences": same_ids / max(1, tot),
                              "max_abs_confidence_diff": dconf},
            "what": "precision = \"fp16\" on every stage: activation tensors stored as f16, f16 matrix instructions (v_mfma_f32_32x32x16_f16 in the big 1x1 and the 3x3 96-channel convs, 32x32x8 elsewhere) with f32 accumulation, reductions and epilogues in f32; "
-                   "an extra key, never `value` (narrower arithmetic than the reference's CPU path)"}
+                   "the depthwise taps of the fused blocks - the mode's dominant kernel - stay f32 VALU arithmetic on f16-stored operands, so this is a STORAGE and matrix-instruction mode, not f16 arithmetic throughout; "
+                   "measured distance from the fp32 path at the logits (tools/fp16_check.py, profiles/r5_fp16_check.txt): max |dlogit| 6.8e-3 classifier, 3.4e-3 recognizer - 3-7x outside the north star's 1e-3, "
+                   "which is why the mode is opt-in, tolerance-tested and an extra key, never `value` (narrower arithmetic than the reference's CPU path)"}
     # its dominant kernel, on a single chain (as the fp32 roofline)
     pipe1 = mk_pipe(1, "fp16")
     run1 = run_of(pipe1)
@@ -478,24 +480,28 @@ def srv_kernel_groups(rep):
 
 
 def cfg5_cpu_baseline():
-    """the oracle's f32 run of the two server plans on the host cores: ONE 960 x 960 image through the detector plan and FOUR
-    48 x 320 lines through the recognizer plan, scaled to an image with 32 lines (det + 8 x the four lines)"""
+    """the oracle's f32 run of the two server plans on the host cores, a bounded sample (about 10-20 s): FOUR 960 x 960 images through
+    the detector plan and 32 lines of 48 x 320 (one image's worth) through the recognizer plan, one at a time / four at a time as a
+    caller of the reference would; per image = det + 32 lines"""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     from oracle import OracleNet, usable_cores
     rs = np.random.RandomState(5)
     d = OracleNet("srv_det")
+    n_img, n_lines = 4, 32
     t0 = time.perf_counter()
-    d.run(rs.randn(1, H, W, 3).astype(np.float32))
-    t_det = time.perf_counter() - t0
+    for _ in range(n_img):
+        d.run(rs.randn(1, H, W, 3).astype(np.float32))
+    t_det = (time.perf_counter() - t0) / n_img
     r = OracleNet("srv_rec")
     t0 = time.perf_counter()
-    r.run(rs.randn(4, 48, 320, 3).astype(np.float32))
-    t_rec4 = time.perf_counter() - t0
-    per_image = t_det + t_rec4 * (K_LINES / 4.0)
+    for _ in range(n_lines // 4):
+        r.run(rs.randn(4, 48, 320, 3).astype(np.float32))
+    t_rec = time.perf_counter() - t0
+    per_image = t_det + t_rec * (K_LINES / float(n_lines))
     return {"value": 1.0 / per_image, "unit": "images/sec", "cores": usable_cores(), "kind": "port",
-            "sample": "oracle (f32 restatement of the hand-written server plans, OpenMP over the usable cores): 1 image 960x960 through "
-                      "srv_det (%.1f s) + 4 lines 48x320 through srv_rec (%.1f s), scaled to 32 lines per image; networks only "
-                      "(pre/post-processing is < 1 %% of this)" % (t_det, t_rec4)}
+            "sample": "oracle (f32 restatement of the hand-written server plans, OpenMP over the usable cores): %d images 960x960 through "
+                      "srv_det (%.2f s each) + %d lines 48x320 through srv_rec in batches of 4 (%.1f s), %.0f s of CPU work; per image = det + 32 "
+                      "lines; networks only (pre/post-processing is < 1 %% of this)" % (n_img, t_det, n_lines, t_rec, t_det * n_img + t_rec)}
 
 
 def main_cfg5(args):

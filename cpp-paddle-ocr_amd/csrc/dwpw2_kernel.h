@@ -36,8 +36,16 @@ typedef unsigned ocr_v4u __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void ocr_dma16(unsigned lds, unsigned voff, ocr_v4u rsrc, unsigned soff) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
 }
+// -DOCR_DWPW2_VMCNT0 (build.py --variant vmcnt0 -> lib/libocr_hip_vmcnt0.so): every counted wait becomes a full drain.  If the
+// hand-kept counts were ever too LARGE the two builds would differ in their bits; tests/test_gpu_parity.py runs both against the oracle.
 template <int N>
-__device__ __forceinline__ void ocr_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void ocr_wait_vm() {
+#ifdef OCR_DWPW2_VMCNT0
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+#endif
+}
 #define OCR_DMA_OOB 0xfffffff0u  // beyond every num_records below
 
 template <int K, int SH, int SW, int CK, bool WIDE, int NB_>

@@ -112,7 +112,12 @@ print("AB OK")
 _AB_ENVS = [{"OCR_FUSE": "0"}, {"OCR_FUSE_GAP_MIN": "1", "OCR_CONV_MT2": "force"}, {"OCR_CONV_SMALL_NT": "0", "OCR_CONV_MT2": "0", "OCR_CONV_C24": "0"},
             {"OCR_DW_LDS": "0", "OCR_ATTN_LINE": "0"}, {"OCR_XDW": "0"}, {"OCR_DWPW2": "0"}, {"OCR_DWPW2": "0", "OCR_DWPW_FORCE_UPW": "3"},
             {"OCR_DWPW_T4": "thin"}, {"OCR_DWPW_ITEMS": "7"}, {"OCR_DWPW_ITEMS": "1"}, {"OCR_DWPW_FORCE_UPW": "3"},
-            {"OCR_DWPW_FORCE_UPW": "16", "OCR_DWPW_T4": "thin"}]
+            {"OCR_DWPW_FORCE_UPW": "16", "OCR_DWPW_T4": "thin"},
+            # not a switch but another BUILD (build.py --variant vmcnt0): every hand-counted s_waitcnt vmcnt(N) of the LDS-DMA fused-block
+            # kernel as vmcnt(0).  Both builds equal the oracle, hence each other: the counts are not too large on these shapes
+            {"OCR_LIB_PATH": os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cpp-paddle-ocr_amd", "lib", "libocr_hip_vmcnt0.so")},
+            {"OCR_LIB_PATH": os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cpp-paddle-ocr_amd", "lib", "libocr_hip_vmcnt0.so"),
+             "OCR_DWPW_ITEMS": "7", "OCR_DWPW_FORCE_UPW": "3"}]
 
 
 _AB_RESULTS = {}
@@ -141,7 +146,7 @@ def _ab_run_all():
         _AB_RESULTS[i] = (pr.returncode, so, se)
 
 
-@pytest.mark.parametrize("idx", range(len(_AB_ENVS)), ids=["-".join("%s=%s" % kv for kv in e.items()) for e in _AB_ENVS])
+@pytest.mark.parametrize("idx", range(len(_AB_ENVS)), ids=["-".join("%s=%s" % (k, os.path.basename(v)) for k, v in e.items()) for e in _AB_ENVS])
 def test_ab_switches_do_not_change_results(built, idx):
     """INTEGRATION.md's runtime switches select other kernel shapes / launch lists (read once per process, so each
     setting runs in a child process): the production-mode outputs stay bit-identical to the oracle.  OCR_DWPW_ITEMS = 7

@@ -75,10 +75,11 @@ def load_weights(net, model_root=None):
 
 
 class OracleNet:
-    def __init__(self, net, weights=None):
+    def __init__(self, net, weights=None, plan=None):
+        """plan: another plan text on the net's weights (tests: the detector's plan without its final sigmoid, to read logits)"""
         self.net = net
         L = lib()
-        self.h = L.oracle_net_create(plan_text(net).encode())
+        self.h = L.oracle_net_create((plan if plan is not None else plan_text(net)).encode())
         assert self.h, "plan parse failed"
         self.weights = weights if weights is not None else load_weights(net)
         for name, a in self.weights.items():

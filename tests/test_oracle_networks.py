@@ -63,3 +63,37 @@ def test_oracle_expf_accuracy(built):
     got = np.array([O.lib().oracle_expf(float(v)) for v in xs], np.float64)
     ref = np.exp(xs.astype(np.float64))
     assert np.max(np.abs(got - ref) / ref) < 3e-7
+
+
+@pytest.mark.parametrize("net,shape,tol", [("det", (1, 3, 960, 960), 3e-4), ("rec", (1, 3, 48, 320), 2e-5)])
+def test_lab_fold_at_production_shapes_at_the_logit_level(built, net, shape, tol):
+    """The round-5 arithmetic contract folds the learnable-affine chains into weights and biases (oracle_net.cpp, LAB fold; the
+    product's loader does the same).  Its bound at the shapes the pipeline runs - one 960 x 960 detector image, one 48 x 320 line -
+    and BEFORE the squashing function: the oracle's logits (the detector's plan with the final sigmoid taken off; the input of the
+    recognizer's softmax) against the UNFOLDED graph interpreted in float64, next to torch-f32's own distance on the same graph."""
+    import torch
+    import oracle as O
+    from graph_ref import run_graph
+    from pdmodel import Program
+    pm = os.path.join(ROOT, "models", net, "inference.pdmodel")
+    squash = "sigmoid" if net == "det" else "softmax"
+    var = [op.inp("X") for op in Program(pm).ops if op.type == squash][-1]
+    x = np.random.RandomState(7).randn(*shape).astype(np.float32)
+    if net == "det":
+        plan = O.plan_text("det")
+        assert plan.count("|act:sigmoid") == 1
+        o = O.OracleNet("det", plan=plan.replace("|act:sigmoid", ""))
+        got = o.run(x.transpose(0, 2, 3, 1)).transpose(0, 3, 1, 2)
+    else:
+        o = O.OracleNet("rec")
+        o.run(x.transpose(0, 2, 3, 1))
+        got = o.logits()
+    t32, t64 = {var: None}, {var: None}
+    run_graph(pm, o.weights, x, taps=t32)
+    run_graph(pm, o.weights, x, taps=t64, dtype=torch.float64)
+    ref32, ref64 = np.asarray(t32[var], np.float64), np.asarray(t64[var])
+    got = got.reshape(ref64.shape)
+    e_oracle, e_torch, scale = np.abs(got - ref64).max(), np.abs(ref32 - ref64).max(), np.abs(ref64).max()
+    print("%s %s: |logit| <= %.2f, oracle (folded) vs f64 %.3g, torch f32 (unfolded) vs f64 %.3g" % (net, shape, scale, e_oracle, e_torch))
+    assert e_oracle <= tol, (e_oracle, e_torch, scale)
+    assert e_oracle <= 3 * e_torch + 1e-7, (e_oracle, e_torch)

@@ -29,6 +29,8 @@ namespace srv {
 
 typedef _Float16 h8v __attribute__((ext_vector_type(8)));
 typedef _Float16 h4v __attribute__((ext_vector_type(4)));
+typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+typedef float f2v __attribute__((ext_vector_type(2)));
 typedef float f16x __attribute__((ext_vector_type(16)));
 typedef float f4v __attribute__((ext_vector_type(4)));
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
@@ -94,6 +96,45 @@ __device__ __forceinline__ float srv_act_h(int act, float y) {
     case SACT_HSWISH: return y * fminf(fmaxf(y + 3.0f, 0.0f), 6.0f) * 0.16666666666666667f;
     case SACT_SIGMOID: return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-y * 1.44269504088896341f));
     default: return y;
+  }
+}
+
+// GELU of TWO values on the packed-f32 instructions (v_pk_mul_f32 / v_pk_fma_f32: one instruction, two lanes' worth), no
+// transcendental (v_exp / v_rcp issue at a quarter of the rate: the tanh form above is 5 + 2 x 4 = 13 issue slots per value, this is 7):
+//   gelu(x) = x / 2 + E(|x|),  E(t) = t (Phi(t) - 1/2)  - even, smooth, and t / 2 from where Phi is 1 -
+//   E(t) ~ t^2 P(t^2) for t = min(|x|, 4) (degree-6 P, minimax fit: tools/micro/gelu_fit.py), + (|x| - t) / 2 beyond
+// max |error| 1.9e-4 over the whole line (the tanh form: 4.7e-4), below the f16 rounding of what it produces from |x| ~ 0.4 up.
+// EIGHT values at a time, the four pairs' Horner chains advanced in lock step: a packed-f32 instruction that reads the result of
+// the one before it costs a wait state (the compiler pads with s_nop 0), and pair after pair the chain of eight was nothing else.
+__device__ __forceinline__ void srv_gelu8(float (&v)[8]) {
+  auto k2 = [](float c) { f2v w = {c, c}; return w; };
+  f2v y[4], t[4], tail[4], t2[4], q[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    y[p] = f2v{v[2 * p], v[2 * p + 1]};
+    t[p][0] = fminf(fabsf(y[p][0]), 4.0f);
+    t[p][1] = fminf(fabsf(y[p][1]), 4.0f);
+    tail[p][0] = fabsf(y[p][0]) - t[p][0];
+    tail[p][1] = fabsf(y[p][1]) - t[p][1];
+  }
+#pragma unroll
+  for (int p = 0; p < 4; ++p) t2[p] = t[p] * t[p];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) q[p] = __builtin_elementwise_fma(k2(2.27814575e-08f), t2[p], k2(-1.59860303e-06f));
+  constexpr float CK[5] = {4.79555300e-05f, -8.14015556e-04f, 8.77238884e-03f, -6.45731141e-02f, 3.97883359e-01f};
+#pragma unroll
+  for (int k = 0; k < 5; ++k)
+#pragma unroll
+    for (int p = 0; p < 4; ++p) q[p] = __builtin_elementwise_fma(q[p], t2[p], k2(CK[k]));
+#pragma unroll
+  for (int p = 0; p < 4; ++p) y[p] = y[p] * k2(0.5f);
+#pragma unroll
+  for (int p = 0; p < 4; ++p) y[p] = __builtin_elementwise_fma(t2[p], q[p], y[p]);
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    y[p] = __builtin_elementwise_fma(tail[p], k2(0.5f), y[p]);
+    v[2 * p] = y[p][0];
+    v[2 * p + 1] = y[p][1];
   }
 }
 
@@ -391,7 +432,9 @@ __global__ void __launch_bounds__(64 * WM * WN) srv_gemm_kernel(const GemmArgs a
 #pragma unroll
               for (int e = 0; e < 8; ++e) v[e] = v[e] + (float)pre_r[i][j][c][e];
             }
-            if (a.act != SACT_NONE) {
+            if (a.act == SACT_GELU) {
+              srv_gelu8(v);
+            } else if (a.act != SACT_NONE) {
 #pragma unroll
               for (int e = 0; e < 8; ++e) v[e] = srv_act_h(a.act, v[e]);
             }
@@ -908,7 +951,7 @@ __global__ void __launch_bounds__(64) attn_f_kernel(const float* __restrict__ qk
 // f16: one workgroup per (line, head); K and V of the pair in LDS ([T + 32][32] halfs each; K rows XOR-swizzled by
 // (row >> 2) & 3 for conflict-free ds_read_b128, V rows linear for ds_read_b64_tr_b16), a wave per tile of 32 queries of one grid row.
 template <int NWV>
-__global__ void __launch_bounds__(64 * NWV) attn_h_kernel(const _Float16* __restrict__ qkv, _Float16* __restrict__ out, int T, int heads, float scale_log2e,
+__global__ void __launch_bounds__(64 * NWV, 16 / NWV) attn_h_kernel(const _Float16* __restrict__ qkv, _Float16* __restrict__ out, int T, int heads, float scale_log2e,
                                                           int gh, int gw, int lh, int lw) {
   constexpr int HD = 32;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -932,18 +975,24 @@ __global__ void __launch_bounds__(64 * NWV) attn_h_kernel(const _Float16* __rest
     *(h8v*)(sV + t * 64 + (c << 4)) = vv;
   }
   __syncthreads();
-  const int segs = (gw + 31) >> 5;
-  const int nq = gh * segs;
   const int hwy = lh >> 1, hwx = lw >> 1;
+  // Query tiles.  Global mixers and wide windows: 32 consecutive positions of one grid row.  Local mixers with a window of at most
+  // 17 columns (SVTR's 7 x 11): TWO rows x 16 columns - the keys such a tile can see in one grid row are 16 + 2 hwx <= 32 columns, ONE
+  // key tile per row (at an unaligned start), where a 32-column query tile needs up to three: 6.7 key tiles per 32 queries instead of 14.4
+  // on the 12 x 80 grid, 5.3 instead of 11.7 on 6 x 80
+  const bool pairs = lh > 0 && hwx <= 8;
+  const int segs = pairs ? (gw + 15) >> 4 : (gw + 31) >> 5;
+  const int nq = (pairs ? (gh + 1) >> 1 : gh) * segs;
   // transposed-read lane geometry (T10): group G = lane >> 4 -> d block 16 (G & 1), key sub-block 4 (G >> 1); lane 4 q + p of the group
   // supplies the address of row q, columns 4 p .. 4 p + 3
   const int trq = (lane & 15) >> 2, trp = lane & 3;
   const unsigned tr_off = (unsigned)((4 * h + trq) * 64 + (16 * ((lane >> 4) & 1) + 4 * trp) * 2);
   for (int qt = wave; qt < nq; qt += NWV) {
-    const int qy = qt / segs, qxs = (qt - qy * segs) << 5;
-    const int qx = qxs + r;
-    const bool qok = qx < gw;
-    const int tq = qy * gw + (qok ? qx : gw - 1);
+    const int qrow = qt / segs, qseg = qt - qrow * segs;
+    const int qy0 = pairs ? 2 * qrow : qrow, qxs = qseg << (pairs ? 4 : 5);
+    const int qy = pairs ? qy0 + (r >> 4) : qy0, qx = qxs + (pairs ? r & 15 : r);
+    const bool qok = qx < gw && qy < gh;
+    const int tq = qok ? qy * gw + qx : qy0 * gw + qxs;  // (a lane without a query computes some valid token's and stores nothing)
     // Q fragments (B operand of S^T = K Q^T): lane (query r, half h), step s: d = 16 s + 8 h .. + 7; pre-scaled by scale * log2(e)
     h8v qf[2];
 #pragma unroll
@@ -956,66 +1005,100 @@ __global__ void __launch_bounds__(64 * NWV) attn_h_kernel(const _Float16* __rest
 #pragma unroll
     for (int e = 0; e < 16; ++e) o[e] = 0.f;
     float mrun = -INFINITY, lrun = 0.f;
-    const int ky0 = lh > 0 ? max(qy - hwy, 0) : 0, ky1 = lh > 0 ? min(qy + hwy, gh - 1) : gh - 1;
-    for (int ky = ky0; ky <= ky1; ++ky)
-      for (int kxs = 0; kxs < gw; kxs += 32) {
-        if (lh > 0 && (kxs > qxs + 31 + hwx || kxs + 31 < qxs - hwx)) continue;  // (wave-uniform: the tile lies outside every query's window)
-        const int tk0 = ky * gw + kxs;
-        // ---- S^T = K Q^T: A = K rows (key r), 2 steps over d
-        f16x sacc;
+    const int ky0 = lh > 0 ? max(qy0 - hwy, 0) : 0, ky1 = lh > 0 ? min(qy0 + (pairs ? 1 : 0) + hwy, gh - 1) : gh - 1;
+    // Key tiles of a grid row: columns kx_lo, kx_lo + 32, .. below kx_end.  pairs: the ONE tile that starts 8 columns left of the
+    // queries (columns qxs - 8 .. qxs + 23 hold every window), pulled inside the grid row; a wide local window: the aligned tiles it
+    // touches; a global mixer: all of them
+    const int kx_lo = pairs ? max(min(qxs - 8, gw - 32), 0) : (lh > 0 ? (max(qxs - hwx, 0) >> 5) << 5 : 0);
+    const int kx_end = pairs ? kx_lo + 1 : (lh > 0 ? min(qxs + 31 + hwx, gw - 1) + 1 : gw);
+    const int ntl = (ky1 - ky0 + 1) * ((kx_end - kx_lo + 31) >> 5);
+    // the column part of the mask as an additive 0 / -inf that the S accumulators START from (register i of lane (q, h) = key
+    // 8 (i >> 2) + 4 h + (i & 3) of the tile): with one tile per row it is the same for every row - computed once per query tile,
+    // free afterwards.  (Round 6: the mask was 96 VALU instructions per tile, a third of the kernel's issue slots.)
+    float cb[16];
+    auto col_bias = [&](int kxs) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) sacc[e] = 0.f;
-        {
-          const int tk = tk0 + r;  // (< T + 32: rows past the grid row's end are other tokens or the zero rows; masked below)
-          const unsigned char* kr = sK + tk * 64;
-          const int ksw = (tk >> 2) & 3;
+      for (int i = 0; i < 16; ++i) {
+        const int kx = kxs + 8 * (i >> 2) + 4 * h + (i & 3);
+        cb[i] = kx < gw && (lh <= 0 || (unsigned)(kx - qx + hwx) <= (unsigned)(2 * hwx)) ? 0.f : -INFINITY;
+      }
+    };
+    if (pairs) col_bias(kx_lo);
+    auto load_k = [&](int ky, int kxs, h8v (&kf)[2]) {
+      const int tk = ky * gw + kxs + r;  // (< T + 32: rows past the grid row's end are other tokens or the zero rows; masked)
+      const unsigned char* kr = sK + tk * 64;
+      const int ksw = (tk >> 2) & 3;
 #pragma unroll
-          for (int s = 0; s < 2; ++s) {
-            const h8v kf = *(const h8v*)(kr + (((2 * s + h) ^ ksw) << 4));
-            sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], sacc, 0, 0, 0);
-          }
-        }
-        // ---- mask, running maximum (register i of lane (q, h) = key 8 (i >> 2) + 4 h + (i & 3) of the tile)
-        float mt = -INFINITY;
-        if (lh > 0 || kxs + 32 > gw) {  // (wave-uniform: a full tile of a global mixer needs no mask - two thirds to seven eighths of them)
+      for (int s = 0; s < 2; ++s) kf[s] = *(const h8v*)(kr + (((2 * s + h) ^ ksw) << 4));
+    };
+    int nky = ky0, nkx = kx_lo;  // the tile whose K fragments are in flight
+    h8v kf[2];
+    load_k(nky, nkx, kf);
+    for (int j = 0; j < ntl; ++j) {
+      const int ky = nky, kxs = nkx;
+      const int tk0 = ky * gw + kxs;
+      nkx += 32;
+      if (nkx >= kx_end) { nkx = kx_lo; ++nky; }
+      // ---- S^T = K Q^T + mask: A = K rows (key r), 2 steps over d
+      f16x sacc;
+      const bool colmask = lh > 0 || kxs + 32 > gw;  // (wave-uniform: a full tile of a global mixer needs no mask)
+      if (colmask && !pairs) col_bias(kxs);
 #pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            const int kx = kxs + 8 * (i >> 2) + 4 * h + (i & 3);
-            const bool ok = kx < gw && (lh <= 0 || (unsigned)(kx - qx + hwx) <= (unsigned)(2 * hwx));
-            sacc[i] = ok ? sacc[i] : -INFINITY;
-          }
-        }
+      for (int e = 0; e < 16; ++e) sacc[e] = colmask ? cb[e] : 0.f;
+      if (pairs && (ky < qy0 + 1 - hwy || ky > qy0 + hwy)) {  // (wave-uniform: the window's first / last row belongs to ONE of the tile's two query rows)
+        const bool rok = (unsigned)(ky - qy + hwy) <= (unsigned)(2 * hwy);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) mt = fmaxf(mt, sacc[i]);
-        mt = fmaxf(mt, __shfl_xor(mt, 32));
-        const float mnew = fmaxf(mrun, mt);
-        const float muse = mnew == -INFINITY ? 0.f : mnew;
-        const float alpha = __builtin_amdgcn_exp2f(mrun - muse);
-        mrun = mnew;
-        float ls = 0.f;
-        h8v pf[2];
+        for (int e = 0; e < 16; ++e) sacc[e] = rok ? sacc[e] : -INFINITY;
+      }
+      sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[0], qf[0], sacc, 0, 0, 0);
+      sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[1], qf[1], sacc, 0, 0, 0);
+      // ---- this tile's V (transposed reads) and the next tile's K leave for LDS now, behind the matrix instructions; both are back
+      // before the softmax below is through
+      const unsigned vb = (unsigned)(size_t)(sV + (size_t)tk0 * 64 + tr_off);
+      h4v v0, v1, v2, v3;
+      asm volatile("ds_read_b64_tr_b16 %0, %4\n\tds_read_b64_tr_b16 %1, %4 offset:512\n\tds_read_b64_tr_b16 %2, %4 offset:1024\n\tds_read_b64_tr_b16 %3, %4 offset:1536"
+                   : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3) : "v"(vb) : "memory");
+      if (j + 1 < ntl) load_k(nky, nkx, kf);
+      // ---- running maximum, probabilities
+      float mt = fmaxf(sacc[0], sacc[1]);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const float p = __builtin_amdgcn_exp2f(sacc[i] - muse);
-          ls += p;
-          pf[i >> 3][i & 7] = (_Float16)p;
-        }
-        lrun = lrun * alpha + ls;
+      for (int i = 2; i < 16; ++i) mt = fmaxf(mt, sacc[i]);
+      {
+        float ma = mt, mb = mt;  // the other half's lanes hold the same queries: lanes 32.. of ma <-> lanes ..31 of mb
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(ma), "+v"(mb));
+        mt = fmaxf(ma, mb);
+      }
+      const float mnew = fmaxf(mrun, mt);
+      const float muse = mnew == -INFINITY ? 0.f : mnew;
+      const float alpha = __builtin_amdgcn_exp2f(mrun - muse);
+      mrun = mnew;
+      float ls = 0.f;
+      h8v pf[2];
+#pragma unroll
+      for (int i = 0; i < 16; i += 2) {
+        f2v p2;
+        p2[0] = __builtin_amdgcn_exp2f(sacc[i] - muse);
+        p2[1] = __builtin_amdgcn_exp2f(sacc[i + 1] - muse);
+        ls += p2[0];
+        ls += p2[1];
+        const h2v ph = __builtin_convertvector(p2, h2v);  // (v_cvt_pk_f16_f32)
+        pf[i >> 3][i & 7] = ph[0];
+        pf[i >> 3][(i & 7) + 1] = ph[1];
+      }
+      lrun = lrun * alpha + ls;
+      if (__any(alpha != 1.0f)) {  // (wave-uniform: once the maxima have settled the sixteen multiplies are by one)
 #pragma unroll
         for (int e = 0; e < 16; ++e) o[e] *= alpha;
-        // ---- O^T += V^T P^T: A = V^T (row d = r; element j of step s = key 16 s + 8 (j >> 2) + 4 h + (j & 3)), B = the P registers as they are
-        const unsigned char* vb = sV + (size_t)tk0 * 64 + tr_off;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          h4v v0, v1;
-          asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v0) : "v"((unsigned)(size_t)(vb + (16 * s) * 64)) : "memory");
-          asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v1) : "v"((unsigned)(size_t)(vb + (16 * s + 8) * 64)) : "memory");
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          __builtin_amdgcn_sched_barrier(0);
-          const h8v vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-          o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[s], o, 0, 0, 0);
-        }
       }
+      // ---- O^T += V^T P^T: A = V^T (row d = r; element j of step s = key 16 s + 8 (j >> 2) + 4 h + (j & 3)), B = the P registers as they are
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3)::"memory");
+      {
+        const h8v vf0 = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        const h8v vf1 = {v2[0], v2[1], v2[2], v2[3], v3[0], v3[1], v3[2], v3[3]};
+        o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf0, pf[0], o, 0, 0, 0);
+        o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf1, pf[1], o, 0, 0, 0);
+      }
+    }
     // ---- normalise and store: register i of lane (q, h) = d 8 (i >> 2) + 4 h + (i & 3)
     const float ltot = lrun + __shfl_xor(lrun, 32);
     const float inv = 1.0f / ltot;
@@ -1047,9 +1130,10 @@ bool launch_attention(const void* qkv, void* out, int N, int T, int heads, int h
   // a Global mixer has no use for the grid: its tokens as ONE row of T (T = 240: 8 x 8 tile pairs instead of 9 x 9 row-aligned
   // ones whose third column tile is half empty, T = 480: 15 x 15 instead of 18 x 18)
   if (lh <= 0) { gh = 1; gw = T; }
-  const int segs = (gw + 31) / 32, nq = gh * segs;
+  const bool pairs = lh > 0 && lw / 2 <= 8;  // (the kernel's query tiling)
+  const int nq = pairs ? ((gh + 1) / 2) * ((gw + 15) / 16) : gh * ((gw + 31) / 32);
   static LdsAttrMemo memo8, memo4;
-  if (nq >= 16) {
+  if (nq >= 12) {
     if (lds > 64 * 1024 && !raise_dynamic_lds((const void*)attn_h_kernel<8>, (int)lds, memo8)) { err = "attention: dynamic LDS attribute refused"; return false; }
     hipLaunchKernelGGL(attn_h_kernel<8>, dim3((unsigned)(N * heads)), dim3(512), lds, s, (const _Float16*)qkv, (_Float16*)out, T, heads, sl, gh, gw, lh, lw);
   } else {

@@ -192,16 +192,25 @@ __global__ void __launch_bounds__(512) srv_mlp_kernel(const MlpArgs a) {
 #pragma unroll
           for (int i = 0; i < 2; ++i) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const f4v b4 = *(const f4v*)(bl + i * 32 + 8 * q);
-              h4v o4;
+            for (int q = 0; q < 4; q += 2) {
+              const f4v b4 = *(const f4v*)(bl + i * 32 + 8 * q), b5 = *(const f4v*)(bl + i * 32 + 8 * q + 8);
+              float v[8];
 #pragma unroll
               for (int e = 0; e < 4; ++e) {
-                const float v = srv_act_h(SACT_GELU, acc1[i][4 * q + e] + b4[e]);
-                o4[e] = (_Float16)__builtin_amdgcn_fmed3f(v, -65504.0f, 65504.0f);
+                v[e] = acc1[i][4 * q + e] + b4[e];
+                v[4 + e] = acc1[i][4 * q + 4 + e] + b5[e];
                 acc1[i][4 * q + e] = 0.f;
+                acc1[i][4 * q + 4 + e] = 0.f;
+              }
+              srv_gelu8(v);
+              h4v o4, o5;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                o4[e] = (_Float16)__builtin_amdgcn_fmed3f(v[e], -65504.0f, 65504.0f);
+                o5[e] = (_Float16)__builtin_amdgcn_fmed3f(v[4 + e], -65504.0f, 65504.0f);
               }
               *(h4v*)(hrow + (((4 * i + q) ^ tsw) << 4) + 8 * h) = o4;
+              *(h4v*)(hrow + (((4 * i + q + 1) ^ tsw) << 4) + 8 * h) = o5;
             }
           }
 #ifdef SRV_MLP_CLOCKS

@@ -170,7 +170,10 @@ struct GemmGeom {
   static constexpr int WI = BN / 8 / NW, XI = BM / 8 / NW, LPS = WI + XI;
   static constexpr unsigned STG = (unsigned)(BN + BM) * 128u;
   static constexpr int SP = BN + 4;  // epilogue tile: floats per pixel row (+4: consecutive pixels 16 bytes apart in the bank row)
-  static constexpr unsigned LDS = (NS * STG > (unsigned)(BM * SP * 4)) ? NS * STG : (unsigned)(BM * SP * 4);
+  // BIG: a tile whose f32 epilogue image would not fit LDS (256 x 256) - such a configuration has the register epilogue only
+  // (f16 build, no transposed conv, no f32 output, no scale / shift pair: gemm_go refuses the rest) and fetches its residual where it is used
+  static constexpr bool BIG = (unsigned)(BM * SP * 4) > 160u * 1024u;
+  static constexpr unsigned LDS = BIG ? NS * STG : ((NS * STG > (unsigned)(BM * SP * 4)) ? NS * STG : (unsigned)(BM * SP * 4));
   static_assert(BN % (32 * WN) == 0 && BM % (32 * WM) == 0, "wave tiles are whole 32 x 32 blocks");
   static_assert((BN / 8) % NW == 0 && (BM / 8) % NW == 0, "every wave issues the same number of DMA instructions per stage");
   static_assert(NW % 2 == 0, "the swizzle term of a lane's DMA rows must not depend on the instruction index");
@@ -290,8 +293,9 @@ __global__ void __launch_bounds__(64 * WM * WN) srv_gemm_kernel(const GemmArgs a
   // matrix instruction and its first store (probe: 0.34 ms of a 1.06 ms launch on SVTR's 192 -> 768 linear).
   // (the f16 build folds batch norm into weights and bias - srv_net.hip - so a scale / shift pair only reaches the staged form)
   const bool direct = HALF && !a.deconv && !a.out_f32 && !a.scale;
+  constexpr bool PRE_R = !G::BIG;  // (a 256 x 256 tile's residual is 64 registers per lane: fetched in the epilogue instead)
   float pre_b[TN][2][8];
-  h8v pre_r[TN][TM][2];
+  h8v pre_r[PRE_R ? TN : 1][PRE_R ? TM : 1][2];
   if (direct) {
 #pragma unroll
     for (int i = 0; i < TN; ++i)
@@ -300,9 +304,9 @@ __global__ void __launch_bounds__(64 * WM * WN) srv_gemm_kernel(const GemmArgs a
         const int n = n0 + wn * TN * 32 + i * 32 + 8 * h + 16 * c;
         if (a.bias) ld8(a.bias + n, pre_b[i][c]);
       }
-    if (a.res_up) {
+    if (PRE_R && a.res_up) {
 #pragma unroll
-      for (int j = 0; j < TM; ++j) {
+      for (int j = 0; j < (PRE_R ? TM : 1); ++j) {
         const long m = m0 + wm * TM * 32 + j * 32 + r;
         long rp = m < a.M ? m : a.M - 1;
         if (a.res_up == 2) {
@@ -317,7 +321,7 @@ __global__ void __launch_bounds__(64 * WM * WN) srv_gemm_kernel(const GemmArgs a
 #pragma unroll
           for (int c = 0; c < 2; ++c) {
             const int n = n0 + wn * TN * 32 + i * 32 + 8 * h + 16 * c;
-            if constexpr (HALF) pre_r[i][j][c] = n < a.Cs_out ? *(const h8v*)((const _Float16*)a.res + rp * a.Cs_out + n) : h8v{0, 0, 0, 0, 0, 0, 0, 0};
+            if constexpr (HALF && PRE_R) pre_r[i][j][c] = n < a.Cs_out ? *(const h8v*)((const _Float16*)a.res + rp * a.Cs_out + n) : h8v{0, 0, 0, 0, 0, 0, 0, 0};
           }
       }
     }
@@ -393,6 +397,89 @@ __global__ void __launch_bounds__(64 * WM * WN) srv_gemm_kernel(const GemmArgs a
   // channels - h = 0: 0..7 and 16..23, h = 1: 8..15 and 24..31 - so a chunk leaves (and its residual arrives) as one 16-byte
   // access, a pixel's two halves side by side.  Four such instructions of a wave cover 128-byte lines; L2 merges them.
   if constexpr (HALF) {
+    if (direct && a.lines) {
+      // ---- round 6, second form: whole lines.  Above, a store instruction is 32 pixel rows x 32 bytes - 32 partial lines for the
+      // address unit and L2 to take, where the same kilobyte as 8 rows x 128 bytes is 8 (the DMA fills of the CU's other workgroups
+      // go through that same unit; probe: the stores of a 512 -> 2048 linear cost 0.35 ms of 1.09 and every tile shape alike).
+      // A wave passes its 32-pixel block through 2-4 KB of LDS of its own (the ring's memory: one barrier, after it no wave reads a
+      // stage any more) - 16-byte chunks in at (pixel r, chunk 4 i + 2 c + h), out again as lane -> (row, chunk) with a row's
+      // chunks on neighbouring lanes.  Wave-private: LDS executes a wave's instructions in order, no barrier inside.
+      __syncthreads();
+      constexpr int CPR = 4 * TN, RPI = 64 / CPR, NI = 32 / RPI;  // chunks per pixel row, rows per store instruction, instructions per block
+      constexpr int RPB = TN >= 4 ? 1 : 4 / TN;                   // pixel rows per 256 bytes of LDS: the XOR term changes every RPB rows
+      unsigned char* const scr = smem + (unsigned)wave * (unsigned)(32 * CPR * 16);
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+        const long mr = m0 + wm * TM * 32 + j * 32 + r;  // this lane's pixel in the accumulator layout
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+          const int nb = n0 + wn * TN * 32 + i * 32 + 8 * h;
+          {
+            f16x& A = acc[i][j];
+            float a0 = A[0], a1 = A[1], a2 = A[2], a3 = A[3], a4 = A[4], a5 = A[5], a6 = A[6], a7 = A[7];
+            float b0 = A[8], b1 = A[9], b2 = A[10], b3 = A[11], b4 = A[12], b5 = A[13], b6 = A[14], b7 = A[15];
+            asm volatile(
+                "s_nop 1\n\tv_permlane32_swap_b32 %0, %4\n\tv_permlane32_swap_b32 %1, %5\n\tv_permlane32_swap_b32 %2, %6\n\tv_permlane32_swap_b32 %3, %7\n\t"
+                "v_permlane32_swap_b32 %8, %12\n\tv_permlane32_swap_b32 %9, %13\n\tv_permlane32_swap_b32 %10, %14\n\tv_permlane32_swap_b32 %11, %15\n\ts_nop 1"
+                : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3),
+                  "+v"(b4), "+v"(b5), "+v"(b6), "+v"(b7));
+            A[0] = a0; A[1] = a1; A[2] = a2; A[3] = a3; A[4] = a4; A[5] = a5; A[6] = a6; A[7] = a7;
+            A[8] = b0; A[9] = b1; A[10] = b2; A[11] = b3; A[12] = b4; A[13] = b5; A[14] = b6; A[15] = b7;
+          }
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            const int n = nb + 16 * c;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = acc[i][j][8 * c + e];
+            if (a.bias) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] = v[e] + pre_b[i][c][e];
+            }
+            if (a.res_up) {
+              h8v rv = {0, 0, 0, 0, 0, 0, 0, 0};
+              if constexpr (PRE_R) rv = pre_r[i][j][c];
+              else if (n < a.Cs_out) {
+                long rp = mr < a.M ? mr : a.M - 1;
+                if (a.res_up == 2) {
+                  const int ohw = a.OH * a.OW;
+                  const int ni = (int)(rp / ohw);
+                  const int rem = (int)(rp - (long)ni * ohw);
+                  const int oy = rem / a.OW, ox = rem - oy * a.OW;
+                  rp = ((long)ni * (a.OH >> 1) + (oy >> 1)) * (a.OW >> 1) + (ox >> 1);
+                }
+                rv = *(const h8v*)((const _Float16*)a.res + rp * a.Cs_out + n);
+              }
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] = v[e] + (float)rv[e];
+            }
+            if (a.act == SACT_GELU) {
+              srv_gelu8(v);
+            } else if (a.act != SACT_NONE) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] = srv_act_h(a.act, v[e]);
+            }
+            h8v hv;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) hv[e] = n + e >= a.Ncols ? (_Float16)0.f : (_Float16)__builtin_amdgcn_fmed3f(v[e], -65504.0f, 65504.0f);
+            const int k = 4 * i + 2 * c + h;
+            *(h8v*)(scr + (unsigned)r * (unsigned)(CPR * 16) + (unsigned)((k ^ ((r / RPB) & (CPR - 1))) * 16)) = hv;
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < NI; ++t) {
+          const int row = t * RPI + lane / CPR, kk = lane % CPR;
+          const h8v hv = *(const h8v*)(scr + (unsigned)row * (unsigned)(CPR * 16) + (unsigned)((kk ^ ((row / RPB) & (CPR - 1))) * 16));
+          const long m = m0 + wm * TM * 32 + j * 32 + row;
+          const int n = n0 + wn * TN * 32 + 8 * kk;
+#ifdef SRV_PROBE_NOSTORE
+          if (hv[0] == (_Float16)12345.f)
+#endif
+          if (m < a.M && n < a.Cs_out) *(h8v*)((_Float16*)a.y + m * a.Cs_out + n) = hv;
+        }
+      }
+      return;
+    }
     if (direct) {
 #pragma unroll
       for (int i = 0; i < TN; ++i) {
@@ -429,8 +516,21 @@ __global__ void __launch_bounds__(64 * WM * WN) srv_gemm_kernel(const GemmArgs a
               for (int e = 0; e < 8; ++e) v[e] = v[e] + pre_b[i][c][e];
             }
             if (a.res_up) {
+              h8v rv;
+              if constexpr (PRE_R) rv = pre_r[i][j][c];
+              else {
+                long rp = m;
+                if (a.res_up == 2) {
+                  const int ohw = a.OH * a.OW;
+                  const int ni = (int)(rp / ohw);
+                  const int rem = (int)(rp - (long)ni * ohw);
+                  const int oy = rem / a.OW, ox = rem - oy * a.OW;
+                  rp = ((long)ni * (a.OH >> 1) + (oy >> 1)) * (a.OW >> 1) + (ox >> 1);
+                }
+                rv = *(const h8v*)((const _Float16*)a.res + rp * a.Cs_out + n);
+              }
 #pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] = v[e] + (float)pre_r[i][j][c][e];
+              for (int e = 0; e < 8; ++e) v[e] = v[e] + (float)rv[e];
             }
             if (a.act == SACT_GELU) {
               srv_gelu8(v);
@@ -451,6 +551,7 @@ __global__ void __launch_bounds__(64 * WM * WN) srv_gemm_kernel(const GemmArgs a
       return;
     }
   }
+  if constexpr (G::BIG) return;  // (refused on the host)
   // ---- epilogue (f32 twin, transposed convs, f32 outputs): accumulators -> f32 LDS tile [pixel][channel] -> whole 16-byte chunks of pixel rows
   __syncthreads();  // (no DMA is outstanding: the last iteration waited for vmcnt(0))
   float* const tile = (float*)smem;
@@ -553,12 +654,27 @@ struct GemmCfg { const char* name; int bm, bn, nt; unsigned lds_h, lds_f; };
 #define SRV_PCFGS(X)                        \
   X(10, 128, 128, 2, 4, 64, 64, 2, 2)       \
   X(11, 128, 128, 2, 2, 64, 64, 2, 2)
+// two column blocks per wave on the small tiles (a wave's pixel row = 128 bytes: whole lines in the epilogue above)
+#define SRV_CFGS2(X)         \
+  X(14, 128, 64, 4, 1, 2)    \
+  X(15, 128, 128, 4, 2, 3)   \
+  X(16, 256, 64, 4, 1, 3)
+// big tiles (f16 build only; the f32 twin of such a choice runs 128x128/2x2/s2 - its bits do not depend on the tile)
+#define SRV_BCFGS(X)         \
+  X(12, 256, 256, 2, 4, 2)   \
+  X(13, 256, 256, 4, 2, 2)
 static const GemmCfg g_cfgs[] = {
 #define X(id, BM, BN, WM, WN, NS) {#BM "x" #BN "/" #WM "x" #WN "/s" #NS, BM, BN, 64 * WM * WN, GemmGeom<_Float16, BM, BN, WM, WN, NS>::LDS, GemmGeom<float, BM, BN, WM, WN, NS>::LDS},
     SRV_CFGS(X)
 #undef X
 #define X(id, BM, BN, WM, WN, FM, FN, FWM, FWN) {"p" #BM "x" #BN "/" #WM "x" #WN, BM, BN, 64 * WM * WN, PGeom<_Float16, BM, BN, WM, WN, 3, false>::LDS, PGeom<float, FM, FN, FWM, FWN, 3, false>::LDS},
     SRV_PCFGS(X)
+#undef X
+#define X(id, BM, BN, WM, WN, NS) {#BM "x" #BN "/" #WM "x" #WN "/s" #NS, BM, BN, 64 * WM * WN, GemmGeom<_Float16, BM, BN, WM, WN, NS>::LDS, GemmGeom<float, 128, 128, 2, 2, 2>::LDS},
+    SRV_BCFGS(X)
+#undef X
+#define X(id, BM, BN, WM, WN, NS) {#BM "x" #BN "/" #WM "x" #WN "/s" #NS, BM, BN, 64 * WM * WN, GemmGeom<_Float16, BM, BN, WM, WN, NS>::LDS, GemmGeom<float, BM, BN, WM, WN, NS>::LDS},
+    SRV_CFGS2(X)
 #undef X
 };
 int gemm_num_configs() { return (int)(sizeof(g_cfgs) / sizeof(g_cfgs[0])); }
@@ -569,6 +685,7 @@ static bool gemm_go(const GemmArgs& a, hipStream_t s, bool query, std::string& e
   using G = GemmGeom<T, BM, BN, WM, WN, NS>;
   auto kern = srv_gemm_kernel<T, BM, BN, WM, WN, NS>;
   static LdsAttrMemo memo;
+  if (G::BIG && !(sizeof(T) == 2 && !a.deconv && !a.out_f32 && !a.scale)) { err = "a big tile has the register epilogue only"; return false; }
   if (G::LDS > 64 * 1024 && !raise_dynamic_lds((const void*)kern, (int)G::LDS, memo)) { err = "dynamic LDS attribute refused"; return false; }
   if (query) return true;
   const long nb = ((a.M + BM - 1) / BM) * ((a.Ncols + BN - 1) / BN);
@@ -615,6 +732,16 @@ static bool gemm_dispatch(const GemmArgs& a, bool half, int cfg, hipStream_t s, 
     case id * 2: return pgemm_go<float, FM, FN, FWM, FWN, false>(a, s, query, err);
     SRV_PCFGS(X)
 #undef X
+#define X(id, BM, BN, WM, WN, NS)                                                   \
+    case id * 2 + 1: return gemm_go<_Float16, BM, BN, WM, WN, NS>(a, s, query, err); \
+    case id * 2: return gemm_go<float, 128, 128, 2, 2, 2>(a, s, query, err);
+    SRV_BCFGS(X)
+#undef X
+#define X(id, BM, BN, WM, WN, NS)                                                   \
+    case id * 2 + 1: return gemm_go<_Float16, BM, BN, WM, WN, NS>(a, s, query, err); \
+    case id * 2: return gemm_go<float, BM, BN, WM, WN, NS>(a, s, query, err);
+    SRV_CFGS2(X)
+#undef X
   }
   err = "no such tile configuration";
   return false;
@@ -623,7 +750,13 @@ bool gemm_config_ok(const GemmArgs& a, bool half, int cfg) {
   std::string e;
   return gemm_dispatch(a, half, cfg, nullptr, true, e);
 }
-bool launch_gemm(const GemmArgs& a, bool half, int cfg, hipStream_t s, std::string& err) { return gemm_dispatch(a, half, cfg, s, false, err); }
+bool launch_gemm(const GemmArgs& a, bool half, int cfg, hipStream_t s, std::string& err) {
+  static const int lines = [] { const char* e = getenv("OCR_SRV_LINES"); return e ? atoi(e) : 1; }();
+  if (lines == a.lines) return gemm_dispatch(a, half, cfg, s, false, err);
+  GemmArgs b = a;
+  b.lines = lines;
+  return gemm_dispatch(b, half, cfg, s, false, err);
+}
 
 bool launch_mlp(const void* x, unsigned long long x_bytes, const void* w1, unsigned long long w1_bytes, int w1_npad, const void* w2,
                 unsigned long long w2_bytes, int w2_npad, const float* b1, const float* b2, void* y, long M, int C, hipStream_t s, bool query,

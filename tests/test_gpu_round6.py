@@ -241,3 +241,54 @@ def test_fused_mlp_equals_the_two_launches(pkg, built):
     assert not any("_768_192_" in n or "_1024_256_" in n for n in names)
     assert np.array_equal(plain.view(np.uint32), fused.view(np.uint32)), float(np.abs(plain - fused).max())
     net.close()
+
+
+_CFG_CHILD = r"""
+import sys, hashlib, numpy as np
+sys.path[:0] = [sys.argv[1], sys.argv[1] + "/tools"]
+import __graft_entry__ as ge
+pkg = ge.load_package()
+out = []
+for kind, shape, seed in (("rec", (3, 48, 320), 31), ("det", (1, 96, 160), 32)):
+    x = np.random.RandomState(seed).randn(shape[0], shape[1], shape[2], 3).astype(np.float32)
+    net = pkg.SrvNet(kind, "fp16")
+    y = net.forward(x, keep_all=False)
+    net.timing(True)
+    net.forward(x, keep_all=False)
+    names = " ".join(net.timing_report())
+    out.append(hashlib.sha1(np.ascontiguousarray(y).view(np.uint8)).hexdigest() + ":" + str(names.count("[" + sys.argv[2] + "/")))
+    net.close()
+print("CFG", *out)
+"""
+
+
+def test_every_tile_configuration_gives_the_same_bits(pkg, built):
+    """The f16 GEMM family's tile configurations (csrc/srv_kernels.hip: SRV_CFGS, the 256 x 256 tiles, the two-column-block small
+    tiles) and both forms of the register epilogue (whole lines through a wave-private LDS block / 32-byte pieces straight from
+    the registers, OCR_SRV_LINES) accumulate every output in the same order: forced one at a time (OCR_SRV_CFG, read once per
+    process - child processes, four at a time), the recognizer's logits and the detector's map are bit-identical to the tuned
+    run's, and the timing report shows that the forced configuration really ran."""
+    import subprocess
+    import sys
+    _srv_ready()
+    cfgs = [("", "", {}), ("0", "256x128/2x4", {}), ("4", "128x256/1x8", {}), ("6", "256x128/4x2", {}), ("9", "64x64/2x2", {}),
+            ("12", "256x256/2x4", {}), ("13", "256x256/4x2", {}), ("14", "128x64/4x1", {}), ("15", "128x128/4x2", {}), ("16", "256x64/4x1", {}),
+            ("12", "256x256/2x4", {"OCR_SRV_LINES": "0"}), ("3", "128x64/2x2", {"OCR_SRV_LINES": "0"})]
+    pending, running, res = list(enumerate(cfgs)), [], {}
+    while pending or running:
+        while pending and len(running) < 4:
+            i, (cfg, name, extra) = pending.pop(0)
+            env = dict(os.environ, **extra)
+            if cfg:
+                env.update(OCR_SRV_CFG=cfg)
+            running.append((i, subprocess.Popen([sys.executable, "-c", _CFG_CHILD, ROOT, name or "-"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)))
+        i, pr = running.pop(0)
+        so, se = pr.communicate(timeout=600)
+        assert pr.returncode == 0 and "CFG " in so, (cfgs[i], so[-1500:], se[-1500:])
+        res[i] = so[so.index("CFG ") + 4:].split()
+    want = [r.split(":")[0] for r in res[0]]
+    for i, (cfg, name, extra) in enumerate(cfgs):
+        got = [r.split(":")[0] for r in res[i]]
+        assert got == want, (cfg, name, extra)
+        if cfg:
+            assert all(int(r.split(":")[1]) > 0 for r in res[i]), (cfg, name, res[i])  # launches with the forced tile in their names

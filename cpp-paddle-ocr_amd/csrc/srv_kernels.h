@@ -50,7 +50,6 @@ struct GemmArgs {
   int res_up = 0;
   int act = SACT_NONE;
   int out_f32 = 0;
-  int lines = 1;             // f16 register epilogue: stores as whole lines through a wave-private LDS block (0: 32-byte pieces straight from the registers; OCR_SRV_LINES)
 };
 int gemm_num_configs();
 const char* gemm_config_name(int cfg);

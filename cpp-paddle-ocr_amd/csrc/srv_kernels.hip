@@ -293,21 +293,18 @@ __global__ void __launch_bounds__(64 * WM * WN) srv_gemm_kernel(const GemmArgs a
   // matrix instruction and its first store (probe: 0.34 ms of a 1.06 ms launch on SVTR's 192 -> 768 linear).
   // (the f16 build folds batch norm into weights and bias - srv_net.hip - so a scale / shift pair only reaches the staged form)
   const bool direct = HALF && !a.deconv && !a.out_f32 && !a.scale;
-  constexpr bool PRE_R = !G::BIG;  // (a 256 x 256 tile's residual is 64 registers per lane: fetched in the epilogue instead)
+  constexpr bool PRE_R = !G::BIG;  // (a 256 x 256 tile's residual is 64 registers per lane: fetched when the K loop is over instead)
+  // line layout of a wave's 32-pixel block (the epilogue below): CPR 16-byte chunks per pixel row, lane -> (row t RPI + lane / CPR, chunk lane % CPR)
+  constexpr int CPR = 4 * TN, RPI = 64 / CPR, NI = 32 / RPI;
   float pre_b[TN][2][8];
-  h8v pre_r[PRE_R ? TN : 1][PRE_R ? TM : 1][2];
-  if (direct) {
+  h8v res_l[TM][NI];
+  auto fetch_res = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < TN; ++i)
+    for (int j = 0; j < TM; ++j)
 #pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        const int n = n0 + wn * TN * 32 + i * 32 + 8 * h + 16 * c;
-        if (a.bias) ld8(a.bias + n, pre_b[i][c]);
-      }
-    if (PRE_R && a.res_up) {
-#pragma unroll
-      for (int j = 0; j < (PRE_R ? TM : 1); ++j) {
-        const long m = m0 + wm * TM * 32 + j * 32 + r;
+      for (int t = 0; t < NI; ++t) {
+        const long m = m0 + wm * TM * 32 + j * 32 + t * RPI + lane / CPR;
+        const int n = n0 + wn * TN * 32 + 8 * (lane % CPR);
         long rp = m < a.M ? m : a.M - 1;
         if (a.res_up == 2) {
           const int ohw = a.OH * a.OW;
@@ -316,15 +313,18 @@ __global__ void __launch_bounds__(64 * WM * WN) srv_gemm_kernel(const GemmArgs a
           const int oy = rem / a.OW, ox = rem - oy * a.OW;
           rp = ((long)ni * (a.OH >> 1) + (oy >> 1)) * (a.OW >> 1) + (ox >> 1);
         }
-#pragma unroll
-        for (int i = 0; i < TN; ++i)
-#pragma unroll
-          for (int c = 0; c < 2; ++c) {
-            const int n = n0 + wn * TN * 32 + i * 32 + 8 * h + 16 * c;
-            if constexpr (HALF && PRE_R) pre_r[i][j][c] = n < a.Cs_out ? *(const h8v*)((const _Float16*)a.res + rp * a.Cs_out + n) : h8v{0, 0, 0, 0, 0, 0, 0, 0};
-          }
+        if constexpr (HALF) res_l[j][t] = n < a.Cs_out ? *(const h8v*)((const _Float16*)a.res + rp * a.Cs_out + n) : h8v{0, 0, 0, 0, 0, 0, 0, 0};
       }
-    }
+  };
+  if (direct) {
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const int n = n0 + wn * TN * 32 + i * 32 + 8 * h + 16 * c;
+        if (a.bias) ld8(a.bias + n, pre_b[i][c]);
+      }
+    if (PRE_R && a.res_up) fetch_res();
   }
   // prologue: NS - 1 stages in flight
 #pragma unroll
@@ -390,27 +390,35 @@ __global__ void __launch_bounds__(64 * WM * WN) srv_gemm_kernel(const GemmArgs a
     return;
   }
 #endif
-  // ---- epilogue, f16 build, straight from the registers (round 6: the staged form below cost 0.28-0.5 ms of a 1.1 ms launch on
-  // SVTR's fc1 shapes - tools/micro/srv_gemm_probe, knock-out table in DESIGN.md section 10 - an f32 tile written to LDS at
-  // ~80 bytes per clock, two barriers, nothing in flight meanwhile).  A lane (pixel r, half h) holds channels 8q + 4h + e of a
-  // 32-column block in register 4q + e; one v_permlane32_swap per register pair (q, q + 1) hands each lane EIGHT consecutive
-  // channels - h = 0: 0..7 and 16..23, h = 1: 8..15 and 24..31 - so a chunk leaves (and its residual arrives) as one 16-byte
-  // access, a pixel's two halves side by side.  Four such instructions of a wave cover 128-byte lines; L2 merges them.
+  // ---- epilogue, f16 build, from the registers (round 6: the staged form below cost 0.28-0.5 ms of a 1.1 ms launch on SVTR's fc1
+  // shapes - tools/micro/srv_gemm_probe, knock-out table in DESIGN.md section 10 - an f32 tile written to LDS at ~80 bytes per
+  // clock, two barriers, nothing in flight meanwhile).  A lane (pixel r, half h) holds channels 8q + 4h + e of a 32-column block
+  // in register 4q + e; one v_permlane32_swap per register pair (q, q + 1) hands each lane EIGHT consecutive channels - h = 0:
+  // 0..7 and 16..23, h = 1: 8..15 and 24..31 - a 16-byte chunk of the pixel's row.
+  // Memory sees WHOLE LINES.  Stored straight from that layout (the round's first form) an instruction is 32 pixel rows x 32 bytes
+  // - 32 partial lines for the address unit and L2, where the same kilobyte as 8 rows x 128 bytes is 8, and the DMA fills of the
+  // CU's other workgroups go through that same unit (probe: the stores of a 512 -> 2048 linear cost 0.35 ms of 1.09, on every
+  // tile shape alike; profiles/r6_gemm_probe_line_stores.txt: 6-15 % per launch).  So a wave passes its 32-pixel block through
+  // 2-8 KB of LDS of its own (the ring's memory: one barrier, after it no wave reads a stage any more): the residual - fetched
+  // before the K loop in line layout, lane -> (row, chunk) with a row's chunks on neighbouring lanes - goes in as lines and is
+  // read as chunks (pixel r, chunk 4 i + 2 c + h); the result overwrites its chunk and leaves as lines.  Wave-private: LDS
+  // executes a wave's instructions in order, no barrier inside.
   if constexpr (HALF) {
-    if (direct && a.lines) {
-      // ---- round 6, second form: whole lines.  Above, a store instruction is 32 pixel rows x 32 bytes - 32 partial lines for the
-      // address unit and L2 to take, where the same kilobyte as 8 rows x 128 bytes is 8 (the DMA fills of the CU's other workgroups
-      // go through that same unit; probe: the stores of a 512 -> 2048 linear cost 0.35 ms of 1.09 and every tile shape alike).
-      // A wave passes its 32-pixel block through 2-4 KB of LDS of its own (the ring's memory: one barrier, after it no wave reads a
-      // stage any more) - 16-byte chunks in at (pixel r, chunk 4 i + 2 c + h), out again as lane -> (row, chunk) with a row's
-      // chunks on neighbouring lanes.  Wave-private: LDS executes a wave's instructions in order, no barrier inside.
+    if (direct) {
       __syncthreads();
-      constexpr int CPR = 4 * TN, RPI = 64 / CPR, NI = 32 / RPI;  // chunks per pixel row, rows per store instruction, instructions per block
       constexpr int RPB = TN >= 4 ? 1 : 4 / TN;                   // pixel rows per 256 bytes of LDS: the XOR term changes every RPB rows
       unsigned char* const scr = smem + (unsigned)wave * (unsigned)(32 * CPR * 16);
+      if (!PRE_R && a.res_up) fetch_res();
 #pragma unroll
       for (int j = 0; j < TM; ++j) {
-        const long mr = m0 + wm * TM * 32 + j * 32 + r;  // this lane's pixel in the accumulator layout
+        // the residual arrives the way the output leaves - whole lines (fetched before the K loop) - and takes the same block the other way round
+        if (a.res_up) {
+#pragma unroll
+          for (int t = 0; t < NI; ++t) {
+            const int row = t * RPI + lane / CPR, kk = lane % CPR;
+            *(h8v*)(scr + (unsigned)row * (unsigned)(CPR * 16) + (unsigned)((kk ^ ((row / RPB) & (CPR - 1))) * 16)) = res_l[j][t];
+          }
+        }
 #pragma unroll
         for (int i = 0; i < TN; ++i) {
           const int nb = n0 + wn * TN * 32 + i * 32 + 8 * h;
@@ -436,20 +444,10 @@ __global__ void __launch_bounds__(64 * WM * WN) srv_gemm_kernel(const GemmArgs a
 #pragma unroll
               for (int e = 0; e < 8; ++e) v[e] = v[e] + pre_b[i][c][e];
             }
+            const int k = 4 * i + 2 * c + h;
+            unsigned char* const cell = scr + (unsigned)r * (unsigned)(CPR * 16) + (unsigned)((k ^ ((r / RPB) & (CPR - 1))) * 16);
             if (a.res_up) {
-              h8v rv = {0, 0, 0, 0, 0, 0, 0, 0};
-              if constexpr (PRE_R) rv = pre_r[i][j][c];
-              else if (n < a.Cs_out) {
-                long rp = mr < a.M ? mr : a.M - 1;
-                if (a.res_up == 2) {
-                  const int ohw = a.OH * a.OW;
-                  const int ni = (int)(rp / ohw);
-                  const int rem = (int)(rp - (long)ni * ohw);
-                  const int oy = rem / a.OW, ox = rem - oy * a.OW;
-                  rp = ((long)ni * (a.OH >> 1) + (oy >> 1)) * (a.OW >> 1) + (ox >> 1);
-                }
-                rv = *(const h8v*)((const _Float16*)a.res + rp * a.Cs_out + n);
-              }
+              const h8v rv = *(const h8v*)cell;
 #pragma unroll
               for (int e = 0; e < 8; ++e) v[e] = v[e] + (float)rv[e];
             }
@@ -462,8 +460,7 @@ __global__ void __launch_bounds__(64 * WM * WN) srv_gemm_kernel(const GemmArgs a
             h8v hv;
 #pragma unroll
             for (int e = 0; e < 8; ++e) hv[e] = n + e >= a.Ncols ? (_Float16)0.f : (_Float16)__builtin_amdgcn_fmed3f(v[e], -65504.0f, 65504.0f);
-            const int k = 4 * i + 2 * c + h;
-            *(h8v*)(scr + (unsigned)r * (unsigned)(CPR * 16) + (unsigned)((k ^ ((r / RPB) & (CPR - 1))) * 16)) = hv;
+            *(h8v*)cell = hv;
           }
         }
 #pragma unroll
@@ -476,76 +473,6 @@ __global__ void __launch_bounds__(64 * WM * WN) srv_gemm_kernel(const GemmArgs a
           if (hv[0] == (_Float16)12345.f)
 #endif
           if (m < a.M && n < a.Cs_out) *(h8v*)((_Float16*)a.y + m * a.Cs_out + n) = hv;
-        }
-      }
-      return;
-    }
-    if (direct) {
-#pragma unroll
-      for (int i = 0; i < TN; ++i) {
-        const int nb = n0 + wn * TN * 32 + i * 32 + 8 * h;  // first channel of this lane's chunk A (chunk B: + 16)
-#pragma unroll
-        for (int j = 0; j < TM; ++j) {
-          const long m = m0 + wm * TM * 32 + j * 32 + r;
-          // after the swaps: registers 0..7 = chunk A, 8..15 = chunk B
-          // (inline asm: hipcc 7.2 hands back the FIRST result of __builtin_amdgcn_permlane32_swap for both of its results -
-          // a two-line test kernel stores one register twice; s_nop: nothing inside an asm statement is padded.  The eight
-          // swaps of a block in one statement: one pad in front, one behind)
-          {
-            f16x& A = acc[i][j];
-            float a0 = A[0], a1 = A[1], a2 = A[2], a3 = A[3], a4 = A[4], a5 = A[5], a6 = A[6], a7 = A[7];
-            float b0 = A[8], b1 = A[9], b2 = A[10], b3 = A[11], b4 = A[12], b5 = A[13], b6 = A[14], b7 = A[15];
-            asm volatile(
-                "s_nop 1\n\tv_permlane32_swap_b32 %0, %4\n\tv_permlane32_swap_b32 %1, %5\n\tv_permlane32_swap_b32 %2, %6\n\tv_permlane32_swap_b32 %3, %7\n\t"
-                "v_permlane32_swap_b32 %8, %12\n\tv_permlane32_swap_b32 %9, %13\n\tv_permlane32_swap_b32 %10, %14\n\tv_permlane32_swap_b32 %11, %15\n\ts_nop 1"
-                : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3),
-                  "+v"(b4), "+v"(b5), "+v"(b6), "+v"(b7));
-            A[0] = a0; A[1] = a1; A[2] = a2; A[3] = a3; A[4] = a4; A[5] = a5; A[6] = a6; A[7] = a7;
-            A[8] = b0; A[9] = b1; A[10] = b2; A[11] = b3; A[12] = b4; A[13] = b5; A[14] = b6; A[15] = b7;
-          }
-          if (m >= a.M) continue;
-#pragma unroll
-          for (int c = 0; c < 2; ++c) {
-            const int n = nb + 16 * c;
-            if (n >= a.Cs_out) continue;
-            float v[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = acc[i][j][8 * c + e];
-            if (a.bias) {
-#pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] = v[e] + pre_b[i][c][e];
-            }
-            if (a.res_up) {
-              h8v rv;
-              if constexpr (PRE_R) rv = pre_r[i][j][c];
-              else {
-                long rp = m;
-                if (a.res_up == 2) {
-                  const int ohw = a.OH * a.OW;
-                  const int ni = (int)(rp / ohw);
-                  const int rem = (int)(rp - (long)ni * ohw);
-                  const int oy = rem / a.OW, ox = rem - oy * a.OW;
-                  rp = ((long)ni * (a.OH >> 1) + (oy >> 1)) * (a.OW >> 1) + (ox >> 1);
-                }
-                rv = *(const h8v*)((const _Float16*)a.res + rp * a.Cs_out + n);
-              }
-#pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] = v[e] + (float)rv[e];
-            }
-            if (a.act == SACT_GELU) {
-              srv_gelu8(v);
-            } else if (a.act != SACT_NONE) {
-#pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] = srv_act_h(a.act, v[e]);
-            }
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-              if (n + e >= a.Ncols) v[e] = 0.f;
-#ifdef SRV_PROBE_NOSTORE
-            if (v[0] == 123456.75f)
-#endif
-            st8((T*)a.y + m * a.Cs_out + n, v);
-          }
         }
       }
       return;
@@ -750,13 +677,7 @@ bool gemm_config_ok(const GemmArgs& a, bool half, int cfg) {
   std::string e;
   return gemm_dispatch(a, half, cfg, nullptr, true, e);
 }
-bool launch_gemm(const GemmArgs& a, bool half, int cfg, hipStream_t s, std::string& err) {
-  static const int lines = [] { const char* e = getenv("OCR_SRV_LINES"); return e ? atoi(e) : 1; }();
-  if (lines == a.lines) return gemm_dispatch(a, half, cfg, s, false, err);
-  GemmArgs b = a;
-  b.lines = lines;
-  return gemm_dispatch(b, half, cfg, s, false, err);
-}
+bool launch_gemm(const GemmArgs& a, bool half, int cfg, hipStream_t s, std::string& err) { return gemm_dispatch(a, half, cfg, s, false, err); }
 
 bool launch_mlp(const void* x, unsigned long long x_bytes, const void* w1, unsigned long long w1_bytes, int w1_npad, const void* w2,
                 unsigned long long w2_bytes, int w2_npad, const float* b1, const float* b2, void* y, long M, int C, hipStream_t s, bool query,

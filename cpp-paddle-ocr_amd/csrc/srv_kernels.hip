@@ -585,7 +585,10 @@ struct GemmCfg { const char* name; int bm, bn, nt; unsigned lds_h, lds_f; };
 #define SRV_CFGS2(X)         \
   X(14, 128, 64, 4, 1, 2)    \
   X(15, 128, 128, 4, 2, 3)   \
-  X(16, 256, 64, 4, 1, 3)
+  X(16, 256, 64, 4, 1, 3)    \
+  X(17, 128, 64, 2, 2, 5)    \
+  X(18, 64, 64, 2, 2, 6)     \
+  X(19, 128, 64, 4, 1, 4)
 // big tiles (f16 build only; the f32 twin of such a choice runs 128x128/2x2/s2 - its bits do not depend on the tile)
 #define SRV_BCFGS(X)         \
   X(12, 256, 256, 2, 4, 2)   \
@@ -617,7 +620,11 @@ static bool gemm_go(const GemmArgs& a, hipStream_t s, bool query, std::string& e
   if (query) return true;
   const long nb = ((a.M + BM - 1) / BM) * ((a.Ncols + BN - 1) / BN);
   if (nb <= 0 || nb > 0x7fffffffL) { err = "grid"; return false; }
-  hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(G::NT), G::LDS, s, a);
+  // a launch with fewer K tiles than ring slots uses that many slots only (the register epilogue's blocks fit one slot): the thin
+  // 1x1 convs of the detector's first stages have ONE tile, and what hides their DMA latency is workgroups per CU
+  unsigned lds = G::LDS;
+  if (sizeof(T) == 2 && !a.deconv && !a.out_f32 && !a.scale && a.nkt < NS) lds = (unsigned)a.nkt * G::STG;
+  hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(G::NT), lds, s, a);
   return true;
 }
 template <typename T, int BM, int BN, int WM, int WN, bool OF32>
@@ -909,8 +916,46 @@ __global__ void __launch_bounds__(256) deconv_map_kernel(const T* __restrict__ x
     prob[((long)n * 2 * H + 2 * iy + (t >> 1)) * (2 * W) + 2 * ix + (t & 1)] = srv_act(SACT_SIGMOID, yv);
   }
 }
+// f16 build, 64 stored channels (the DB head's): EIGHT lanes per pixel, one 16-byte chunk each - a wave reads eight whole 128-byte
+// pixel rows per instruction (the thread-per-pixel form above reads 16 bytes of 64 different lines: 1.07 TB/s on 944 MB, the
+// detector's slowest launch per byte) - four partial sums per lane, folded over the eight lanes by three DPP row shifts; lanes 0..3
+// of a pixel write its four map values.  (Summation order differs from the f32 twin's ascending chain: tolerance-tested mode.)
+__global__ void __launch_bounds__(256) deconv_map_h64_kernel(const _Float16* __restrict__ x, const float* __restrict__ w4, float bias,
+                                                             float* __restrict__ prob, int N, int H, int W) {
+  const long gi = (long)blockIdx.x * 256 + threadIdx.x;
+  const long p = gi >> 3;
+  const int ch = (int)(gi & 7);
+  const bool ok = p < (long)N * H * W;
+  float v[8];
+  ld8(x + (ok ? p : 0) * 64 + 8 * ch, v);
+  float acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    float wv[8];
+    ld8(w4 + t * 64 + 8 * ch, wv);
+    float a0 = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a0 = fmaf(v[e], wv[e], a0);
+    a0 += __shfl_xor(a0, 1);
+    a0 += __shfl_xor(a0, 2);
+    a0 += __shfl_xor(a0, 4);
+    acc[t] = a0;
+  }
+  if (!ok || ch >= 4) return;
+  const float yv = (ch == 0 ? acc[0] : ch == 1 ? acc[1] : ch == 2 ? acc[2] : acc[3]) + bias;
+  const int ix = (int)(p % W);
+  const long q = p / W;
+  const int iy = (int)(q % H);
+  const int n = (int)(q / H);
+  prob[((long)n * 2 * H + 2 * iy + (ch >> 1)) * (2 * W) + 2 * ix + (ch & 1)] = srv_act_h(SACT_SIGMOID, yv);
+}
 void launch_deconv_to_map(const void* x, const float* w4, float bias, float* prob, int N, int H, int W, int Cs, bool half, hipStream_t s) {
   const unsigned nb = (unsigned)(((long)N * H * W + 255) / 256);
+  if (half && Cs == 64) {
+    const unsigned nb8 = (unsigned)(((long)N * H * W * 8 + 255) / 256);
+    hipLaunchKernelGGL(deconv_map_h64_kernel, dim3(nb8), dim3(256), 0, s, (const _Float16*)x, w4, bias, prob, N, H, W);
+    return;
+  }
   if (half) hipLaunchKernelGGL(deconv_map_kernel<_Float16>, dim3(nb), dim3(256), 0, s, (const _Float16*)x, w4, bias, prob, N, H, W, Cs);
   else hipLaunchKernelGGL(deconv_map_kernel<float>, dim3(nb), dim3(256), 0, s, (const float*)x, w4, bias, prob, N, H, W, Cs);
 }

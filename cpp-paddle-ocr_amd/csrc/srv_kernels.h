@@ -84,6 +84,7 @@ void launch_deconv_to_map(const void* x, const float* w4 /* [4 taps][Cs] */, flo
                           hipStream_t s);
 // CTC head's tail: per row of f32 logits [rows][ld] (C valid): arg max (first maximum) and its softmax probability
 void launch_argmax_softmax(const float* logits, long rows, int C, int ld, int* amax, float* pmax, hipStream_t s);
+void launch_argmax_softmax(const float* logits, long rows, int C, int ld, int* amax, float* pmax, bool half, hipStream_t s);  // half: the one-pass form
 // copies a T tensor to f32 dropping the pad channels (parity taps)
 void launch_to_f32(const void* x, float* y, long pixels, int Cs, int C, bool half, hipStream_t s);
 

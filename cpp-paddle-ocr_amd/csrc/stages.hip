@@ -617,7 +617,7 @@ int RecStage::run_lines(const std::vector<LineSrc>& lines, const std::vector<int
       sl.T = ot.w;
       if (sl.T > Wt / 4 + 8) { err = "rec step buffer too small"; return OCR_ERR_CAPACITY; }
       srv::launch_argmax_softmax((const float*)srv_->tensor_ptr(srv_->output_tid()), (long)sl.count * sl.T, ot.c, ot.cs, amax_.p + sl.step_off,
-                                 pmax_.p + sl.step_off, stream_);
+                                 pmax_.p + sl.step_off, srv_->half(), stream_);
       launch_ctc(amax_.p + sl.step_off, pmax_.p + sl.step_off, sl.count, sl.T, max_len, ids_.p + (size_t)sl.first * max_len,
                  lens_.p + sl.first, scores_.p + sl.first, stream_);
     } else if (sl.ragged) {

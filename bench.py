@@ -479,6 +479,22 @@ def srv_kernel_groups(rep):
     return g
 
 
+def cfg5_traffic(kernel, ms):
+    """HBM bytes per launch of the line's dominant kernel from the PMC passes of this command (tools/run_profile_cfg5.sh ->
+    profiles/*cfg5_profile_summary.json, `by_bench_kernel`): only an entry that names THIS (kernel, shape) group and whose traced
+    duration agrees with this run's within 15 %, else None"""
+    pdir = os.path.join(ROOT, "profiles")
+    for tf in sorted((f for f in os.listdir(pdir) if f.endswith("cfg5_profile_summary.json")), reverse=True):
+        try:
+            e = json.load(open(os.path.join(pdir, tf))).get("by_bench_kernel", {}).get(kernel)
+        except (OSError, ValueError):
+            continue
+        if e and e.get("traffic_bytes_per_launch") and abs(e["avg_ns"] / 1e6 - ms) <= 0.15 * ms:
+            return e["traffic_bytes_per_launch"], ("profiles/%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate runs, gfx950 correction) of the "
+                                                   "same command on %s (%.3f ms there), not this run" % (tf, e["rocprof_kernel"], e["avg_ns"] / 1e6))
+    return None, None
+
+
 def cfg5_cpu_baseline():
     """the oracle's f32 run of the two server plans on the host cores, a bounded sample (about 10-20 s): FOUR 960 x 960 images through
     the detector plan and 32 lines of 48 x 320 (one image's worth) through the recognizer plan, one at a time / four at a time as a
@@ -594,7 +610,8 @@ def main_cfg5(args):
         "host": {"cpu_s_per_step": cpu_s / args.steps, "what": "user + system CPU seconds of this process (all its threads) per timed step"},
         "roofline": {
             "kernel": dnet + "." + dkey, "launches_per_step": dom["count"] // rsteps, "ms_per_launch": dom_ms, "bound": bound,
-            "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak, "traffic": None,
+            "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak, "traffic": cfg5_traffic(dnet + "." + dkey, dom_ms)[0],
+            "traffic_source": cfg5_traffic(dnet + "." + dkey, dom_ms)[1],
             "arithmetic_intensity": ai,
             "what": "the (kernel, shape) group with the most time in the step; duration = HIP events on the launch stream, one chain",
             "det_conv_stack": {"tflops": det.get("conv_flops", 0) / max(det.get("conv_ms", 1e-9), 1e-9) / 1e9,

@@ -263,7 +263,66 @@ __global__ void __launch_bounds__(512) srv_mlp_kernel(const MlpArgs a) {
     for (int i = 0; i < 8; ++i) a.clocks[((size_t)blockIdx.x * 8 + wave) * 8 + i] = clk[i];
   }
 #endif
-  // ---- y = acc2 + b2 + x, straight from the registers (srv_gemm_kernel's epilogue: eight swaps per 32 x 32 block)
+  // ---- y = acc2 + b2 + x.  srv_gemm_kernel's epilogue: eight swaps per 32 x 32 block hand a lane 16-byte chunks of its token's row;
+  // memory sees WHOLE LINES - the residual x comes in and y goes out as lane -> (row, chunk) with a row's chunks on neighbouring
+  // lanes, through 8 KB of LDS per wave (the ring's memory, one barrier).  In 32-byte pieces straight from the accumulator layout
+  // (the first form) the PMC passes counted 1.55 GB fetched and 0.51 GB written per launch at C = 256 against 0.50 GB of tensors.
+  constexpr int CPR = 4 * TN2;                       // 16-byte chunks of a token's half row (C / 2 channels)
+  constexpr bool LINES = (CPR & (CPR - 1)) == 0;     // (C = 192: 12 chunks - the piecewise form below)
+  if constexpr (LINES) {
+    constexpr int RPI = 64 / CPR, NI = 32 / RPI;     // rows per instruction, instructions per 32-token block
+    constexpr int RPB = CPR >= 16 ? 1 : 16 / CPR;    // rows per 256 bytes of LDS: the XOR term changes every RPB rows
+    __syncthreads();                                 // (every wave is through with the ring and the hidden image)
+    unsigned char* const scr = smem + (unsigned)wave * (unsigned)(32 * CPR * 16);
+    auto cell_of = [&](int row, int k) { return scr + (unsigned)row * (unsigned)(CPR * 16) + (unsigned)((k ^ ((row / RPB) & (CPR - 1))) * 16); };
+#pragma unroll
+    for (int t = 0; t < NI; ++t) {
+      const int row = t * RPI + lane / CPR, kk = lane % CPR;
+      const long ml = m0 + wm * 32 + row;
+      *(h8v*)cell_of(row, kk) = ml < a.M ? *(const h8v*)((const _Float16*)a.x + ml * C + wn * (C / 2) + 8 * kk) : h8v{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+#pragma unroll
+    for (int i = 0; i < TN2; ++i) {
+      {
+        f16x& A = acc2[i];
+        float a0 = A[0], a1 = A[1], a2 = A[2], a3 = A[3], a4 = A[4], a5 = A[5], a6 = A[6], a7 = A[7];
+        float b0 = A[8], b1 = A[9], b2 = A[10], b3 = A[11], b4 = A[12], b5 = A[13], b6 = A[14], b7 = A[15];
+        asm volatile(
+            "s_nop 1\n\tv_permlane32_swap_b32 %0, %4\n\tv_permlane32_swap_b32 %1, %5\n\tv_permlane32_swap_b32 %2, %6\n\tv_permlane32_swap_b32 %3, %7\n\t"
+            "v_permlane32_swap_b32 %8, %12\n\tv_permlane32_swap_b32 %9, %13\n\tv_permlane32_swap_b32 %10, %14\n\tv_permlane32_swap_b32 %11, %15\n\ts_nop 1"
+            : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3),
+              "+v"(b4), "+v"(b5), "+v"(b6), "+v"(b7));
+        A[0] = a0; A[1] = a1; A[2] = a2; A[3] = a3; A[4] = a4; A[5] = a5; A[6] = a6; A[7] = a7;
+        A[8] = b0; A[9] = b1; A[10] = b2; A[11] = b3; A[12] = b4; A[13] = b5; A[14] = b6; A[15] = b7;
+      }
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const int n = wn * (C / 2) + i * 32 + 8 * h + 16 * c;
+        unsigned char* const cell = cell_of(r, 4 * i + 2 * c + h);
+        float bb[8], v[8];
+        ld8(a.b2 + n, bb);
+        const h8v rv = *(const h8v*)cell;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float t = acc2[i][8 * c + e] + bb[e];
+          v[e] = t + (float)rv[e];
+        }
+        h8v hv;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) hv[e] = (_Float16)__builtin_amdgcn_fmed3f(v[e], -65504.0f, 65504.0f);
+        *(h8v*)cell = hv;
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < NI; ++t) {
+      const int row = t * RPI + lane / CPR, kk = lane % CPR;
+      const long ml = m0 + wm * 32 + row;
+      const h8v hv = *(const h8v*)cell_of(row, kk);
+      if (ml < a.M) *(h8v*)((_Float16*)a.y + ml * C + wn * (C / 2) + 8 * kk) = hv;
+    }
+    return;
+  }
+  // ---- the piecewise form (C = 192): 32-byte pieces straight from the registers
   const long m = m0 + wm * 32 + r;
 #pragma unroll
   for (int i = 0; i < TN2; ++i) {

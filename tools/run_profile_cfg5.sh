@@ -36,6 +36,22 @@ if top:
     out["dominant"] = {"kernel": top, "avg_ns": float(rows[0]["AverageNs"]), "fetch_bytes_per_launch_corrected": 2 * 1024 * f[0] / max(f[1], 1),
                        "write_bytes_per_launch": 1024 * w[0] / max(w[1], 1), "launches_fetch_pass": f[1], "launches_write_pass": w[1]}
     out["dominant"]["traffic_bytes_per_launch"] = out["dominant"]["fetch_bytes_per_launch_corrected"] + out["dominant"]["write_bytes_per_launch"]
+# the bench line's own dominant (kernel, shape) group, matched to its rocprof kernel: fused MLP launches by their template
+# argument, anything else by the only kernel whose average duration agrees within 10 %
+try:
+    bl = json.loads([l for l in open(O + "/bench_line.json") if l.startswith("{")][-1])
+    bk, bms = bl["roofline"]["kernel"], bl["roofline"]["ms_per_launch"]
+    import re
+    m = re.search(r"\.mlp_(\d+)_", bk)
+    cands = [r for r in rows if (("srv_mlp_kernel<%s>" % m.group(1)) in r["Name"] if m else abs(float(r["AverageNs"]) / 1e6 - bms) <= 0.1 * bms)]
+    if len(cands) == 1:
+        r = cands[0]; nm = r["Name"][:120]
+        f, w = fe.get(nm, [0, 1]), wr.get(nm, [0, 1])
+        out["by_bench_kernel"] = {bk: {"rocprof_kernel": nm, "avg_ns": float(r["AverageNs"]), "bench_ms_per_launch": bms,
+                                       "fetch_bytes_per_launch_corrected": 2 * 1024 * f[0] / max(f[1], 1), "write_bytes_per_launch": 1024 * w[0] / max(w[1], 1),
+                                       "traffic_bytes_per_launch": 2 * 1024 * f[0] / max(f[1], 1) + 1024 * w[0] / max(w[1], 1)}}
+except Exception as e:
+    out["by_bench_kernel_error"] = repr(e)
 json.dump(out, open(O + "/summary.json", "w"), indent=1)
 print(json.dumps(out, indent=1)[:3000])
 PY

@@ -83,6 +83,10 @@ bool launch_attention(const void* qkv, void* out, int N, int T, int heads, int h
 void launch_deconv_to_map(const void* x, const float* w4 /* [4 taps][Cs] */, float bias, float* prob, int N, int H, int W, int Cs, bool half,
                           hipStream_t s);
 // CTC head's tail: per row of f32 logits [rows][ld] (C valid): arg max (first maximum) and its softmax probability
+// the DB head's two transposed convs (64 -> 64 + bias + ReLU, 64 -> 1 + bias + sigmoid) in one launch, f16 build: x [N][H][W][64] f16,
+// w1img = the first one's weight image (256 rows = tap * 64 + channel, one K tile), b1 [256], w4 [4 taps][64] -> prob [N][4H][4W] f32
+bool launch_head_tail(const void* x, const void* w1img, const float* b1, const float* w4, float bias2, float* prob, int N, int H, int W, hipStream_t s,
+                      bool query, std::string& err);
 void launch_argmax_softmax(const float* logits, long rows, int C, int ld, int* amax, float* pmax, hipStream_t s);
 void launch_argmax_softmax(const float* logits, long rows, int C, int ld, int* amax, float* pmax, bool half, hipStream_t s);  // half: the one-pass form
 // copies a T tensor to f32 dropping the pad channels (parity taps)

@@ -960,6 +960,118 @@ void launch_deconv_to_map(const void* x, const float* w4, float bias, float* pro
   else hipLaunchKernelGGL(deconv_map_kernel<float>, dim3(nb), dim3(256), 0, s, (const float*)x, w4, bias, prob, N, H, W, Cs);
 }
 
+// ---- the DB head's two transposed convs as ONE kernel (f16 build): 64 -> 64 (2x2 stride 2, + bias (batch norm folded), ReLU) -> 1
+// (2x2 stride 2, + bias, sigmoid).  As two launches the 480 x 480 x 64 tensor between them is written and read back: 1.9 GB of the
+// 2.2 GB the pair moves at batch 32 (0.63 + 0.35 ms); here an input pixel's 4 x 64 mid values never leave the registers:
+//   product 1  D[col n = tap * 64 + c][pixel] = W1 rows x pixel rows (K = 64): eight 32 x 32 blocks per 32 pixels, W1's 32 KB image resident in LDS;
+//   its accumulators - bias, ReLU, one rounding to f16 (what the tensor would have held) - ARE the B fragments of
+//   product 2  D[row = second tap][pixel] += W2^T (4 of 32 rows used) x mid (K = 64 per first tap), two matrix instructions per block:
+//   after the eight swaps of the register epilogue a lane's chunk c is k step c of that operand (as P feeds P V in the attention kernel).
+// A wave owns 32 consecutive pixels of a 128-pixel tile; pixel rows arrive as whole lines through 4 KB of wave-private LDS; the lanes of
+// half 0 end up with the pixel's 4 x 4 map values and store them as four 16-byte pieces (32 lanes = 512 contiguous bytes per map row).
+__global__ void __launch_bounds__(256) head_tail_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w1img, const float* __restrict__ b1,
+                                                        const float* __restrict__ w4, float bias2, float* __restrict__ prob, int N, int H, int W,
+                                                        long tiles) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* const sW = smem;               // [256 rows][8 granules] as stored (granule g of row n at slot g ^ ((n >> 1) & 7))
+  float* const sB = (float*)(smem + 32768);     // [256]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  unsigned char* const scr = smem + 33792 + wave * 4096;
+  const int r = lane & 31, h = lane >> 5;
+  for (int i = tid; i < 2048; i += 256) ((h8v*)sW)[i] = ((const h8v*)w1img)[i];
+  sB[tid] = b1[tid];
+  // W2^T fragments: row r = second tap (4 real rows), element j of (first-tap half block i2, k step c) = mid channel 32 i2 + 16 c + 8 h + j
+  h8v w2a[2][2];
+#pragma unroll
+  for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) w2a[i2][c][j] = r < 4 ? (_Float16)w4[r * 64 + 32 * i2 + 16 * c + 8 * h + j] : (_Float16)0.f;
+  __syncthreads();
+  const int swz = (r >> 1) & 7;
+  const long M = (long)N * H * W;
+  for (long t = blockIdx.x; t < tiles; t += gridDim.x) {
+    const long p0 = t * 128 + wave * 32;
+    // ---- 32 pixel rows in as lines: lane -> (row 8 i + lane / 8, chunk lane % 8)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = 8 * i + (lane >> 3), kk = lane & 7;
+      const long p = p0 + row;
+      *(h8v*)(scr + row * 128 + ((kk ^ ((row >> 1) & 7)) << 4)) = p < M ? *(const h8v*)(x + p * 64 + 8 * kk) : h8v{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+    h8v fb[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) fb[s] = *(const h8v*)(scr + r * 128 + (((2 * s + h) ^ swz) << 4));
+    f16x acc2[4];
+#pragma unroll
+    for (int tp = 0; tp < 4; ++tp)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc2[tp][q] = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) {
+      f16x acc;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+      const unsigned char* wr = sW + (nt * 32 + r) * 128;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const h8v*)(wr + (((2 * s + h) ^ swz) << 4)), fb[s], acc, 0, 0, 0);
+      {
+        float a0 = acc[0], a1 = acc[1], a2 = acc[2], a3 = acc[3], a4 = acc[4], a5 = acc[5], a6 = acc[6], a7 = acc[7];
+        float b0 = acc[8], b1_ = acc[9], b2 = acc[10], b3 = acc[11], b4 = acc[12], b5 = acc[13], b6 = acc[14], b7 = acc[15];
+        asm volatile(
+            "s_nop 1\n\tv_permlane32_swap_b32 %0, %4\n\tv_permlane32_swap_b32 %1, %5\n\tv_permlane32_swap_b32 %2, %6\n\tv_permlane32_swap_b32 %3, %7\n\t"
+            "v_permlane32_swap_b32 %8, %12\n\tv_permlane32_swap_b32 %9, %13\n\tv_permlane32_swap_b32 %10, %14\n\tv_permlane32_swap_b32 %11, %15\n\ts_nop 1"
+            : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(b0), "+v"(b1_), "+v"(b2), "+v"(b3),
+              "+v"(b4), "+v"(b5), "+v"(b6), "+v"(b7));
+        acc[0] = a0; acc[1] = a1; acc[2] = a2; acc[3] = a3; acc[4] = a4; acc[5] = a5; acc[6] = a6; acc[7] = a7;
+        acc[8] = b0; acc[9] = b1_; acc[10] = b2; acc[11] = b3; acc[12] = b4; acc[13] = b5; acc[14] = b6; acc[15] = b7;
+      }
+      // chunk c of this lane = columns nt * 32 + 16 c + 8 h .. + 7 = mid channels (nt & 1) * 32 + 16 c + 8 h .. of first tap nt >> 1
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const float* bb = sB + nt * 32 + 16 * c + 8 * h;
+        const f4v blo = *(const f4v*)bb, bhi = *(const f4v*)(bb + 4);
+        h8v pc;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pc[e] = (_Float16)fminf(fmaxf(acc[8 * c + e] + (e < 4 ? blo[e] : bhi[e - 4]), 0.f), 65504.0f);
+        acc2[nt >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2a[nt & 1][c], pc, acc2[nt >> 1], 0, 0, 0);
+      }
+    }
+    // ---- register e of a half-0 lane of acc2[first tap (dy, dx)] = second tap e = (dy2, dx2) of pixel r: map rows 4 y + 2 dy + dy2
+    const long p = p0 + r;
+    if (h == 0 && p < M) {
+      const int ix = (int)(p % W);
+      const long q = p / W;
+      const int iy = (int)(q % H);
+      const long n = q / H;
+      float* const o = prob + ((n * 4 * H + 4 * iy) * (4L * W) + 4 * ix);
+#pragma unroll
+      for (int a4 = 0; a4 < 4; ++a4) {
+        const int dy = a4 >> 1, dy2 = a4 & 1;
+        f4v v;
+        v[0] = srv_act_h(SACT_SIGMOID, acc2[2 * dy][2 * dy2] + bias2);
+        v[1] = srv_act_h(SACT_SIGMOID, acc2[2 * dy][2 * dy2 + 1] + bias2);
+        v[2] = srv_act_h(SACT_SIGMOID, acc2[2 * dy + 1][2 * dy2] + bias2);
+        v[3] = srv_act_h(SACT_SIGMOID, acc2[2 * dy + 1][2 * dy2 + 1] + bias2);
+        *(f4v*)(o + (long)a4 * 4 * W) = v;
+      }
+    }
+  }
+}
+bool launch_head_tail(const void* x, const void* w1img, const float* b1, const float* w4, float bias2, float* prob, int N, int H, int W, hipStream_t s,
+                      bool query, std::string& err) {
+  constexpr int LDS = 33792 + 4 * 4096;
+  static LdsAttrMemo memo;
+  if (LDS > 64 * 1024 && !raise_dynamic_lds((const void*)head_tail_kernel, LDS, memo)) { err = "dynamic LDS attribute refused"; return false; }
+  if (query) return true;
+  const long tiles = ((long)N * H * W + 127) / 128;
+  const unsigned grid = (unsigned)std::min<long>(tiles, 1024);
+  hipLaunchKernelGGL(head_tail_kernel, dim3(grid), dim3(256), LDS, s, (const _Float16*)x, (const _Float16*)w1img, b1, w4, bias2, prob, N, H, W, tiles);
+  return true;
+}
+
 // ---- CTC tail: a wave per row; arg max = first maximum of the logits, its probability 1 / sum exp(x - max)
 __global__ void __launch_bounds__(256) argmax_softmax_kernel(const float* __restrict__ logits, long rows, int C, int ld, int* __restrict__ amax,
                                                              float* __restrict__ pmax) {

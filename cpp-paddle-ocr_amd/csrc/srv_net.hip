@@ -382,7 +382,7 @@ bool SrvNet::bind(int N, int H, int W, hipStream_t s, std::string& err) {
   }
   // ---- SVTR's MLP pairs as one launch (f16 build, production mode; srv_mlp.h): `linear C -> 4C | gelu` whose only reader is
   // `linear 4C -> C | + the first linear's input`: the hidden tensor then never exists (no arena slot, no launch of its own)
-  std::vector<char> mlp_head(ops_.size(), 0), mlp_tail(ops_.size(), 0);
+  std::vector<char> mlp_head(ops_.size(), 0), mlp_tail(ops_.size(), 0), ht_head(ops_.size(), 0), ht_tail(ops_.size(), 0);
   {
     // OCR_SRV_MLP=0: never; =all: every width; default: C <= 256 (measured, tools/micro/srv_mlp_probe + tools/srv_bench.py: 1.46 ms
     // against 1.60 for the two launches at C = 192, 1.22 against 1.20 at C = 256 with 1.5 / 1.0 GB less HBM traffic per launch;
@@ -407,6 +407,19 @@ bool SrvNet::bind(int N, int H, int W, hipStream_t s, std::string& err) {
       if (!srv::launch_mlp(nullptr, 0, nullptr, 0, 0, nullptr, 0, 0, nullptr, nullptr, nullptr, 0, c, nullptr, true, e)) continue;
       mlp_head[oi] = 1;
       mlp_tail[oi + 1] = 1;
+    }
+    // ---- the DB head's two transposed convs as one launch (f16 build, production mode; srv_kernels.hip head_tail_kernel):
+    // `deconv 64 -> 64 | bias | relu` (batch norm folded) whose only reader is `deconv 64 -> 1 | bias | sigmoid`.  OCR_SRV_HEAD=0: two launches
+    static const bool head_on = [] { const char* e = getenv("OCR_SRV_HEAD"); return !(e && e[0] == '0'); }();
+    for (size_t oi = 0; half_ && head_on && !keep_all_ && oi + 1 < ops_.size(); ++oi) {
+      const Op &d1 = ops_[oi], &d2 = ops_[oi + 1];
+      if (d1.kind != "deconv" || d2.kind != "deconv" || d1.geti("cout") != 64 || d1.cin_s != 64 || d2.geti("cout") != 1 || d2.cin_s != 64) continue;
+      if (d1.act != srv::SACT_RELU || !d1.bias || d1.scale || d1.res_tid >= 0 || d1.npad != 256 || !d2.p0) continue;
+      if (d2.geti("i") != d1.geti("o") || readers[d1.geti("o")] != 1) continue;
+      std::string e;
+      if (!srv::launch_head_tail(nullptr, nullptr, nullptr, nullptr, 0.f, nullptr, 0, 0, 0, nullptr, true, e)) continue;
+      ht_head[oi] = 1;
+      ht_tail[oi + 1] = 1;
     }
   }
   // ---- arena: every tensor a slot of its own (keep_all) or first-fit reuse by last reader
@@ -452,7 +465,7 @@ bool SrvNet::bind(int N, int H, int W, hipStream_t s, std::string& err) {
       const Op& op = ops_[oi];
       if (op.kind == "output") continue;
       const int o = op.geti("o");
-      if (mlp_head[oi]) { tensors_[o].n = 0; continue; }  // the hidden tensor of a fused MLP: never written
+      if (mlp_head[oi] || ht_head[oi]) { tensors_[o].n = 0; continue; }  // the hidden tensor of a fused MLP / the head's 64-channel map: never written
       tensors_[o].offset = alloc(tensors_[o].bytes(half_));
       if (keep_all_) continue;
       for (int t = 1; t <= ntensors_; ++t)
@@ -509,9 +522,26 @@ bool SrvNet::bind(int N, int H, int W, hipStream_t s, std::string& err) {
       launches_.push_back(L);
       continue;
     }
-    if (mlp_tail[oi]) continue;  // launched with its head
+    if (mlp_tail[oi] || ht_tail[oi]) continue;  // launched with its head
     const int itid = op.geti("i") == 0 ? pk : op.geti("i");
     const SrvTensor& in = tensors_[itid];
+    if (ht_head[oi]) {
+      const Op& d2 = ops_[oi + 1];
+      const SrvTensor& yt = tensors_[d2.geti("o")];
+      snprintf(nm, sizeof nm, "%zu.head_tail_64_64_1@%dx%dx%d", oi, yt.n, yt.h, yt.w);
+      L.name = nm;
+      L.flops = 2.0 * in.pixels() * 64.0 * 256.0 + 2.0 * in.pixels() * 4.0 * 4.0 * 64.0;
+      L.bytes = (double)in.bytes(half_) + (double)yt.bytes(half_);
+      const void* xs = ptr(itid);
+      float* dst = (float*)ptr(d2.geti("o"));
+      const void* w1 = op.wimg;
+      const float *b1 = op.bias, *w4 = d2.p0;
+      const float fb = d2.fbias;
+      const int n_ = in.n, h_ = in.h, w_ = in.w;
+      L.fn = [=](hipStream_t st, std::string& e) { return srv::launch_head_tail(xs, w1, b1, w4, fb, dst, n_, h_, w_, st, false, e); };
+      launches_.push_back(L);
+      continue;
+    }
     if (mlp_head[oi]) {
       const Op& f2 = ops_[oi + 1];
       const SrvTensor& yt = tensors_[f2.geti("o")];

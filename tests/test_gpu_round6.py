@@ -292,3 +292,23 @@ def test_every_tile_configuration_gives_the_same_bits(pkg, built):
         assert got == want, (cfg, name, extra)
         if cfg:
             assert all(int(r.split(":")[1]) > 0 for r in res[i]), (cfg, name, res[i])  # launches with the forced tile in their names
+
+
+def test_fused_head_tail_matches_the_two_launches(pkg, built):
+    """The DB head's two transposed convs as one kernel (csrc/srv_kernels.hip head_tail_kernel: the 64-channel map between them
+    stays in registers as the second product's operand) against the two launches: production mode fuses, keep_all materialises.
+    The mid values are rounded to f16 either way; the second product runs on the matrix pipe with f16 weights instead of f32 fmas,
+    so the probability maps agree to 3e-3 (measured 1.1e-3), not bit for bit.  An image whose size is not a multiple of the tile."""
+    _srv_ready()
+    x = np.random.RandomState(41).randn(2, 96, 160, 3).astype(np.float32)
+    net = pkg.SrvNet("det", "fp16")
+    plain = net.forward(x, keep_all=True)
+    net.timing(True)
+    fused = net.forward(x, keep_all=False)
+    names = list(net.timing_report())
+    assert sum(".head_tail_" in n for n in names) == 1 and not any("deconv" in n for n in names), names[-4:]
+    assert plain.shape == fused.shape == (2, 96, 160, 1)
+    d = np.abs(plain - fused)
+    print("fused head tail: max |d| %.2e" % d.max())
+    assert d.max() <= 3e-3, float(d.max())
+    net.close()

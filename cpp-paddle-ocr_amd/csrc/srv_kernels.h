@@ -50,6 +50,9 @@ struct GemmArgs {
   int res_up = 0;
   int act = SACT_NONE;
   int out_f32 = 0;
+  int korder = 0;            // K order of a 3x3 stride-1 conv's weight image: 0 = (tap, channel) - the oracle's ascending chain, every f32 launch;
+                             // 1 = (64-channel tile, tap, channel in tile) - the f16 build: a channel tile's nine taps are consecutive K tiles,
+                             // so the halo form (srv_conv3_kernel) streams ONE input patch per channel tile; both forms accumulate in this order
 };
 int gemm_num_configs();
 const char* gemm_config_name(int cfg);

@@ -269,8 +269,12 @@ __global__ void __launch_bounds__(64 * WM * WN) srv_gemm_kernel(const GemmArgs a
         srv_dma16(st + (unsigned)BN * 128u + (unsigned)(wave + NW * j) * 1024u, ok ? off : SRV_OOB, rs_x, 0u);
       }
       if (a.cin_shift == -1) {
-        is_c0 += BK;
-        if (is_c0 >= a.Cin) { is_c0 = 0; if (++is_kx == a.KW) { is_kx = 0; ++is_ky; } }
+        if (a.korder) {  // (channel tile, tap): the taps of a channel tile are consecutive K tiles
+          if (++is_kx == a.KW) { is_kx = 0; if (++is_ky == a.KH) { is_ky = 0; is_c0 += BK; } }
+        } else {
+          is_c0 += BK;
+          if (is_c0 >= a.Cin) { is_c0 = 0; if (++is_kx == a.KW) { is_kx = 0; ++is_ky; } }
+        }
       }
     }
     ++is_kt;
@@ -564,6 +568,221 @@ __global__ void __launch_bounds__(64 * WM * WN) srv_gemm_kernel(const GemmArgs a
 #include "srv_pgemm.h"
 #include "srv_mlp.h"
 
+// =================================================================================================== 3x3 convs on a halo patch
+// srv_conv3_kernel<BN>: 3x3 stride-1 pad-1 conv, Cin a multiple of 64, f16 build, weight image in K order (channel tile, tap)
+// (GemmArgs::korder = 1).  The implicit-GEMM form above fetches a pixel tile once per TAP - nine DMA passes over (nearly) the same
+// pixels, 16 KB per 128 pixels each, and on the 64-column layers (res2's 3x3, the FPN / head 256 -> 64 convs: 2.8 ms of the detector)
+// that traffic through the CU's address unit, not the matrix pipe, sets the time.  Here a workgroup owns a 16 x 16 pixel tile and
+// DMAs its 18 x 18 x 64-channel halo patch ONCE per channel tile (41 KB, double-buffered: the next channel tile's patch travels
+// during this one's nine taps); a tap is then an address offset into the patch - row (y + dy) 18 + x + dx, the row's own XOR
+// swizzle - and only the weight tiles (BN rows x 128 bytes per tap, a kernel ROW's three taps per stage and barrier) stream through a three-slot ring.  Per tap and workgroup:
+// BN x 128 + 41 K / 9 bytes by DMA instead of (BN + 256) x 128.  Same accumulation order as the implicit-GEMM form on the same
+// image: bit-identical (test_every_tile_configuration_gives_the_same_bits).  8 waves: wave = (wm = wave / 2: pixel rows 4 wm .. + 3
+// of the tile = two 32-pixel blocks, wn = wave % 2: BN / 2 columns).  Epilogue as srv_gemm_kernel's (registers, whole lines out).
+template <int BN>
+struct Conv3Geom {
+  static constexpr int NW = 8, NT = 512, TM = 2, TN = BN / 64, WI = BN / 8 / NW;
+  static constexpr int PROWS = 328, PINSTR = 41;                     // 18 x 18 = 324 patch pixels, in 8-row DMA pieces
+  static constexpr unsigned PBUF = PROWS * 128u, WSLOT = 3 * BN * 128u;  // a ring slot = the three taps of one kernel row
+  static constexpr unsigned WRING = 2 * PBUF, LDS = WRING + 3 * WSLOT;
+  static_assert(BN == 64, "column tile (128 columns: three-tap slots do not fit beside the patches)");
+};
+template <int BN>
+__global__ void __launch_bounds__(512) srv_conv3_kernel(const GemmArgs a) {
+  using G = Conv3Geom<BN>;
+  constexpr int NW = G::NW, TM = G::TM, TN = G::TN, WI = G::WI;
+  constexpr unsigned PBUF = G::PBUF, WSLOT = G::WSLOT, WRING = G::WRING;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const unsigned lds0 = (unsigned)(size_t)smem;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int wn = wave & 1, wm = wave >> 1;
+  // ---- tile: column tiles of one pixel tile are neighbours in the grid
+  const unsigned nb_n = (unsigned)((a.Ncols + BN - 1) / BN);
+  const unsigned bid = srv_xcd(blockIdx.x, gridDim.x);
+  const int n0 = (int)(bid % nb_n) * BN;
+  const unsigned pt = bid / nb_n;
+  const unsigned tpx = (unsigned)((a.W + 15) >> 4), tpy = (unsigned)((a.H + 15) >> 4);
+  const int tx0 = (int)(pt % tpx) << 4;
+  const int ty0 = (int)((pt / tpx) % tpy) << 4;
+  const int img = (int)(pt / (tpx * tpy));
+  v4u rs_w, rs_x;
+  {
+    const unsigned long long wb = (unsigned long long)a.w, xb = (unsigned long long)a.x;
+    rs_w.x = __builtin_amdgcn_readfirstlane((unsigned)wb);
+    rs_w.y = __builtin_amdgcn_readfirstlane((unsigned)(wb >> 32));
+    rs_w.z = __builtin_amdgcn_readfirstlane((unsigned)a.w_bytes);
+    rs_w.w = 0x00020000u;
+    rs_x.x = __builtin_amdgcn_readfirstlane((unsigned)xb);
+    rs_x.y = __builtin_amdgcn_readfirstlane((unsigned)(xb >> 32));
+    rs_x.z = __builtin_amdgcn_readfirstlane((unsigned)a.x_bytes);
+    rs_x.w = 0x00020000u;
+  }
+  // ---- DMA plans.  Patch piece k (of 41) = patch rows 8 k .. 8 k + 7, wave w issues pieces w, w + 8, ..; lane l -> row + (l >> 3),
+  // LDS slot l & 7 holding source granule (l & 7) ^ ((row >> 1) & 7) (8 | the piece stride in rows x 4: the XOR term is the lane's own)
+  const int gq = (lane & 7) ^ ((4 * wave + (lane >> 4)) & 7);
+  const int npp = wave < G::PINSTR - 5 * NW ? 6 : 5;  // pieces of this wave
+  unsigned pvo[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const int q = 8 * (wave + NW * i) + (lane >> 3);
+    const int py = q / 18, px = q - py * 18;
+    const int iy = ty0 - 1 + py, ix = tx0 - 1 + px;
+    const bool ok = q < 324 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+    pvo[i] = ok ? (unsigned)(((unsigned long long)((long)img * a.H + iy) * a.W + ix) * (unsigned)a.Cin * 2ull) + (unsigned)(gq * 16) : SRV_OOB;
+  }
+  unsigned wvo[WI];
+#pragma unroll
+  for (int i = 0; i < WI; ++i) wvo[i] = (unsigned)((wave + NW * i) * 1024 + lane * 16);
+  const int NC = a.Cin >> 6, S = 3 * NC;  // a stage = (channel tile, kernel row): three taps, one barrier
+  int issued = 0;
+  auto issue_patch = [&](int c) __attribute__((always_inline)) {
+    const unsigned dst = lds0 + (unsigned)(c & 1) * PBUF;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+      if (i < npp) srv_dma16(dst + (unsigned)(wave + NW * i) * 1024u, pvo[i], rs_x, (unsigned)c * 128u);
+    issued += npp;
+  };
+  auto issue_w = [&](int st) __attribute__((always_inline)) {  // K tiles 3 st .. 3 st + 2 = (channel tile st / 3, kernel row st % 3, dx = 0 .. 2)
+    const unsigned dst = lds0 + WRING + (unsigned)(st % 3) * WSLOT;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      const unsigned wso = (unsigned)(((unsigned long long)(3 * st + d) * (unsigned)a.Npad + (unsigned)n0) * 128ull);
+#pragma unroll
+      for (int i = 0; i < WI; ++i) srv_dma16(dst + (unsigned)d * (unsigned)(BN * 128) + (unsigned)(wave + NW * i) * 1024u, wvo[i], rs_w, wso);
+    }
+    issued += 3 * WI;
+  };
+  // ---- this lane's pixel rows in the patch (tap (0, 0)): block j of the wave = tile rows 4 wm + 2 j, + 1
+  int q0[TM];
+#pragma unroll
+  for (int j = 0; j < TM; ++j) q0[j] = (4 * wm + 2 * j + (r >> 4)) * 18 + (r & 15);
+  const int swz = (r >> 1) & 7;
+  f16x acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+  float pre_b[TN][2][8];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int n = n0 + wn * TN * 32 + i * 32 + 8 * h + 16 * c;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) pre_b[i][c][e] = 0.f;
+      if (a.bias) ld8(a.bias + n, pre_b[i][c]);
+    }
+  // ---- prologue: patch of channel tile 0, weights of taps 0 and 1
+  issue_patch(0);
+  issue_w(0);
+  int mark_w[3] = {0, 0, 0};  // `issued` after the weights of the stage in ring slot u went out
+  mark_w[0] = issued;
+  if (S > 1) { issue_w(1); mark_w[1] = issued; }
+  int c = 0, dy = 0;
+  for (int st = 0; st < S; ++st) {
+    // the weights of stage st have landed when at most what was issued after them is outstanding (the patch of this channel tile is older)
+    srv_wait_vm_le(__builtin_amdgcn_readfirstlane(issued - mark_w[st % 3]));
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (dy == 0 && c + 1 < NC) issue_patch(c + 1);  // into the buffer channel tile c - 1 was read from: every wave is past it
+    const unsigned char* sp = smem + (unsigned)(c & 1) * PBUF;
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      const unsigned char* sw = smem + WRING + (unsigned)(st % 3) * WSLOT + (unsigned)dx * (unsigned)(BN * 128) + (unsigned)(wn * TN * 32 + r) * 128u;
+      unsigned po[TM], ps[TM];
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+        const int q = q0[j] + dy * 18 + dx;
+        po[j] = (unsigned)q * 128u;
+        ps[j] = (unsigned)((q >> 1) & 7);
+      }
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        h8v fa[TN], fb[TM];
+#pragma unroll
+        for (int i = 0; i < TN; ++i) fa[i] = *(const h8v*)(sw + i * 4096 + (((2 * s4 + h) ^ swz) << 4));
+#pragma unroll
+        for (int j = 0; j < TM; ++j) fb[j] = *(const h8v*)(sp + po[j] + ((((unsigned)(2 * s4 + h)) ^ ps[j]) << 4));
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+          for (int j = 0; j < TM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    // the weights of stage st + 2, into the slot stage st - 1 left (every wave is past it).  (Issued by one wave of each SIMD before and by
+    // the other behind the matrix instructions - so that DMA issue and matrix work of the pair overlap - measured the same: 0.683 / 0.679 ms.)
+    if (st + 2 < S) { issue_w(st + 2); mark_w[(st + 2) % 3] = issued; }
+    if (++dy == 3) { dy = 0; ++c; }
+  }
+  // ---- epilogue (srv_gemm_kernel's): bias, activation, one rounding; a wave's 32-pixel block through wave-private LDS, out as whole lines
+  __syncthreads();
+  constexpr int CPR = 4 * TN, RPI = 64 / CPR, NI = 32 / RPI;
+  constexpr int RPB = TN >= 4 ? 1 : 4 / TN;
+  unsigned char* const scr = smem + (unsigned)wave * (unsigned)(32 * CPR * 16);
+#pragma unroll
+  for (int j = 0; j < TM; ++j) {
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+      const int nb = n0 + wn * TN * 32 + i * 32 + 8 * h;
+      {
+        f16x& A = acc[i][j];
+        float a0 = A[0], a1 = A[1], a2 = A[2], a3 = A[3], a4 = A[4], a5 = A[5], a6 = A[6], a7 = A[7];
+        float b0 = A[8], b1 = A[9], b2 = A[10], b3 = A[11], b4 = A[12], b5 = A[13], b6 = A[14], b7 = A[15];
+        asm volatile(
+            "s_nop 1\n\tv_permlane32_swap_b32 %0, %4\n\tv_permlane32_swap_b32 %1, %5\n\tv_permlane32_swap_b32 %2, %6\n\tv_permlane32_swap_b32 %3, %7\n\t"
+            "v_permlane32_swap_b32 %8, %12\n\tv_permlane32_swap_b32 %9, %13\n\tv_permlane32_swap_b32 %10, %14\n\tv_permlane32_swap_b32 %11, %15\n\ts_nop 1"
+            : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3),
+              "+v"(b4), "+v"(b5), "+v"(b6), "+v"(b7));
+        A[0] = a0; A[1] = a1; A[2] = a2; A[3] = a3; A[4] = a4; A[5] = a5; A[6] = a6; A[7] = a7;
+        A[8] = b0; A[9] = b1; A[10] = b2; A[11] = b3; A[12] = b4; A[13] = b5; A[14] = b6; A[15] = b7;
+      }
+#pragma unroll
+      for (int cc = 0; cc < 2; ++cc) {
+        const int n = nb + 16 * cc;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = acc[i][j][8 * cc + e] + pre_b[i][cc][e];
+        if (a.act == SACT_GELU) {
+          srv_gelu8(v);
+        } else if (a.act != SACT_NONE) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = srv_act_h(a.act, v[e]);
+        }
+        h8v hv;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) hv[e] = n + e >= a.Ncols ? (_Float16)0.f : (_Float16)__builtin_amdgcn_fmed3f(v[e], -65504.0f, 65504.0f);
+        const int k = 4 * i + 2 * cc + h;
+        *(h8v*)(scr + (unsigned)r * (unsigned)(CPR * 16) + (unsigned)((k ^ ((r / RPB) & (CPR - 1))) * 16)) = hv;
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < NI; ++t) {
+      const int row = t * RPI + lane / CPR, kk = lane % CPR;
+      const h8v hv = *(const h8v*)(scr + (unsigned)row * (unsigned)(CPR * 16) + (unsigned)((kk ^ ((row / RPB) & (CPR - 1))) * 16));
+      const int oy = ty0 + 4 * wm + 2 * j + (row >> 4), ox = tx0 + (row & 15);
+      const int n = n0 + wn * TN * 32 + 8 * kk;
+      if (oy < a.H && ox < a.W && n < a.Cs_out) *(h8v*)((_Float16*)a.y + (((long)img * a.H + oy) * a.W + ox) * a.Cs_out + n) = hv;
+    }
+  }
+}
+template <int BN>
+static bool conv3_go(const GemmArgs& a, bool half, hipStream_t s, bool query, std::string& err) {
+  using G = Conv3Geom<BN>;
+  if (!half || !a.korder || a.KH != 3 || a.KW != 3 || a.SH != 1 || a.SW != 1 || a.PH != 1 || a.PW != 1 || a.Cin % 64 || a.cin_shift != -1 || a.deconv ||
+      a.out_f32 || a.scale || a.res_up || a.OH != a.H || a.OW != a.W) { err = "the halo form takes f16 3x3 stride-1 convs on whole channel tiles"; return false; }
+  static LdsAttrMemo memo;
+  if (!raise_dynamic_lds((const void*)srv_conv3_kernel<BN>, (int)G::LDS, memo)) { err = "dynamic LDS attribute refused"; return false; }
+  if (query) return true;
+  const long nb = (long)a.N * ((a.H + 15) / 16) * ((a.W + 15) / 16) * ((a.Ncols + BN - 1) / BN);
+  if (nb <= 0 || nb > 0x7fffffffL) { err = "grid"; return false; }
+  hipLaunchKernelGGL(srv_conv3_kernel<BN>, dim3((unsigned)nb), dim3(512), G::LDS, s, a);
+  return true;
+}
+
 // ---- tile configurations (autotuned per layer at bind time: srv_net.hip)
 struct GemmCfg { const char* name; int bm, bn, nt; unsigned lds_h, lds_f; };
 #define SRV_CFGS(X)          \
@@ -589,6 +808,9 @@ struct GemmCfg { const char* name; int bm, bn, nt; unsigned lds_h, lds_f; };
   X(17, 128, 64, 2, 2, 5)    \
   X(18, 64, 64, 2, 2, 6)     \
   X(19, 128, 64, 4, 1, 4)
+// the halo form of the 3x3 stride-1 convs (srv_conv3_kernel: 16 x 16 pixel tile, BN columns; f16 build, K order 1 only)
+#define SRV_HCFGS(X) \
+  X(20, 64)
 // big tiles (f16 build only; the f32 twin of such a choice runs 128x128/2x2/s2 - its bits do not depend on the tile)
 #define SRV_BCFGS(X)         \
   X(12, 256, 256, 2, 4, 2)   \
@@ -605,6 +827,9 @@ static const GemmCfg g_cfgs[] = {
 #undef X
 #define X(id, BM, BN, WM, WN, NS) {#BM "x" #BN "/" #WM "x" #WN "/s" #NS, BM, BN, 64 * WM * WN, GemmGeom<_Float16, BM, BN, WM, WN, NS>::LDS, GemmGeom<float, BM, BN, WM, WN, NS>::LDS},
     SRV_CFGS2(X)
+#undef X
+#define X(id, BN) {"halo16x16x" #BN, 256, BN, 512, Conv3Geom<BN>::LDS, 0u},
+    SRV_HCFGS(X)
 #undef X
 };
 int gemm_num_configs() { return (int)(sizeof(g_cfgs) / sizeof(g_cfgs[0])); }
@@ -675,6 +900,11 @@ static bool gemm_dispatch(const GemmArgs& a, bool half, int cfg, hipStream_t s, 
     case id * 2 + 1: return gemm_go<_Float16, BM, BN, WM, WN, NS>(a, s, query, err); \
     case id * 2: return gemm_go<float, BM, BN, WM, WN, NS>(a, s, query, err);
     SRV_CFGS2(X)
+#undef X
+#define X(id, BN)                                                  \
+    case id * 2 + 1: return conv3_go<BN>(a, true, s, query, err); \
+    case id * 2: err = "the halo form is f16 only"; return false;
+    SRV_HCFGS(X)
 #undef X
   }
   err = "no such tile configuration";

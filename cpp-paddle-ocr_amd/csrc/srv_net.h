@@ -66,6 +66,7 @@ class SrvNet {
     const float *bias = nullptr, *scale = nullptr, *shift = nullptr, *p0 = nullptr, *p1 = nullptr;
     float fbias = 0;
     int act = 0, res_tid = -1, res_up = 0;
+    int korder = 0;                // GemmArgs::korder of this op's weight image
   };
   struct Launch {
     std::string name;

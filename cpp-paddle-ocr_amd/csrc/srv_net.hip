@@ -216,6 +216,21 @@ bool SrvNet::prepare_op(Op& op, const WeightMap& W, std::string& err) {
         h_scale.clear();
         h_shift.clear();
       }
+      // f16 build, 3x3 stride-1 pad-1 convs on whole 64-channel tiles: K order (channel tile, tap, channel in tile) - GemmArgs::korder = 1.
+      // Both forms of such a conv (implicit GEMM, halo patch) then accumulate in the same order.  OCR_SRV_KORDER=0: the oracle's order (no halo form)
+      static const bool korder_on = [] { const char* e = getenv("OCR_SRV_KORDER"); return !(e && e[0] == '0'); }();
+      if (half_ && korder_on && op.kind == "conv" && op.geti("kh") == 3 && op.geti("kw") == 3 && op.geti("sh") == 1 && op.geti("sw") == 1 &&
+          op.geti("ph") == 1 && op.geti("pw") == 1 && cin_s % 64 == 0) {
+        op.korder = 1;
+        const int nct = cin_s / 64;
+        std::vector<float> perm(wnk.size());
+        for (int n = 0; n < op.ncols; ++n)
+          for (int tap = 0; tap < 9; ++tap)
+            for (int c = 0; c < cin_s; ++c)
+              perm[(size_t)n * K + (size_t)((c / 64) * 9 + tap) * 64 + (c % 64)] = wnk[(size_t)n * K + (size_t)tap * cin_s + c];
+        (void)nct;
+        wnk.swap(perm);
+      }
       int nkt = 0;
       if (half_) {
         auto img = weight_image<_Float16>(wnk, op.ncols, K, op.npad, nkt);
@@ -600,6 +615,7 @@ bool SrvNet::bind(int N, int H, int W, hipStream_t s, std::string& err) {
       }
       a.bias = op.bias; a.scale = op.scale; a.shift = op.shift;
       a.act = op.act;
+      a.korder = op.korder;
       if (op.res_tid >= 0) {
         const SrvTensor& rt = tensors_[op.res_tid];
         a.res = ptr(op.res_tid);

@@ -216,19 +216,17 @@ bool SrvNet::prepare_op(Op& op, const WeightMap& W, std::string& err) {
         h_scale.clear();
         h_shift.clear();
       }
-      // f16 build, 3x3 stride-1 pad-1 convs on whole 64-channel tiles: K order (channel tile, tap, channel in tile) - GemmArgs::korder = 1.
+      // f16 build, k x k convs on whole 64-channel tiles: K order (channel tile, tap, channel in tile) - GemmArgs::korder = 1.
       // Both forms of such a conv (implicit GEMM, halo patch) then accumulate in the same order.  OCR_SRV_KORDER=0: the oracle's order (no halo form)
       static const bool korder_on = [] { const char* e = getenv("OCR_SRV_KORDER"); return !(e && e[0] == '0'); }();
-      if (half_ && korder_on && op.kind == "conv" && op.geti("kh") == 3 && op.geti("kw") == 3 && op.geti("sh") == 1 && op.geti("sw") == 1 &&
-          op.geti("ph") == 1 && op.geti("pw") == 1 && cin_s % 64 == 0) {
-        op.korder = 1;
-        const int nct = cin_s / 64;
+      if (half_ && korder_on && op.kind == "conv" && op.geti("kh") * op.geti("kw") > 1 && cin_s % 64 == 0) {  // (any stride: the implicit-GEMM form gains
+        op.korder = 1;                                                                                     // from the locality alone; the halo form takes stride 1)
+        const int taps = op.geti("kh") * op.geti("kw");
         std::vector<float> perm(wnk.size());
         for (int n = 0; n < op.ncols; ++n)
-          for (int tap = 0; tap < 9; ++tap)
+          for (int tap = 0; tap < taps; ++tap)
             for (int c = 0; c < cin_s; ++c)
-              perm[(size_t)n * K + (size_t)((c / 64) * 9 + tap) * 64 + (c % 64)] = wnk[(size_t)n * K + (size_t)tap * cin_s + c];
-        (void)nct;
+              perm[(size_t)n * K + (size_t)((c / 64) * taps + tap) * 64 + (c % 64)] = wnk[(size_t)n * K + (size_t)tap * cin_s + c];
         wnk.swap(perm);
       }
       int nkt = 0;

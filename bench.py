@@ -503,7 +503,7 @@ def cfg5_cpu_baseline():
     from oracle import OracleNet, usable_cores
     rs = np.random.RandomState(5)
     d = OracleNet("srv_det")
-    n_img, n_lines = 4, 32
+    n_img, n_lines = 8, 64
     t0 = time.perf_counter()
     for _ in range(n_img):
         d.run(rs.randn(1, H, W, 3).astype(np.float32))
@@ -588,7 +588,7 @@ def main_cfg5(args):
         for k in ("ms", "flops", "bytes"):
             tot[k] += v[k] / rsteps
             pn[k] += v[k] / rsteps
-        if key.startswith(("conv", "deconv", "linear")):
+        if key.startswith(("conv", "deconv", "linear", "head_tail")):
             pn["conv_ms"] += v["ms"] / rsteps
             pn["conv_flops"] += v["flops"] / rsteps
     # every launch against its own binding roof (f16 matrix peak or HBM peak, whichever takes longer)

@@ -445,6 +445,12 @@ bool SrvNet::bind(int N, int H, int W, hipStream_t s, std::string& err) {
     if (op.res_tid >= 0) last_use[op.res_tid] = (int)oi;
   }
   last_use[out_tid_] = 1 << 30;
+  // a fused pair runs as ONE launch that writes the SECOND op's tensor: what the first op reads must outlive that tensor's allocation
+  // (and is released then - the arena loop below skips a fused head, with it the releases that fall on its index)
+  for (size_t oi = 0; oi + 1 < ops_.size(); ++oi)
+    if (ht_head[oi] || mlp_head[oi])
+      for (int t = 0; t <= ntensors_; ++t)
+        if (last_use[t] == (int)oi) last_use[t] = (int)oi + 1;
   {
     struct Blk { size_t off, size; };
     std::vector<Blk> free_list;

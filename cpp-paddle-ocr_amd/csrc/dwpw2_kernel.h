@@ -445,7 +445,7 @@ __global__ void __launch_bounds__(256, LB) dwpw2_kernel(const DwPwArgs a) {
     for (int k = 1; k < total; ++k) {
       FUSED(rb, k & 1);
       rb = rb + 1 == NB ? 0 : rb + 1;
-      DMA();  // item k+2
+      DMA();  // item k+2  (round 6: issued in FRONT of item k's taps instead - its buffer is free since the last barrier - the step measured the same, 1271-1290 against 1283-1290 img/s)
       ocr_wait_vm<C8S * NT + DPW>();
       (void)mma_end();
       __syncthreads();

@@ -427,6 +427,8 @@ def parse_args(argv=None):
                     help="the stages' precision parameter for EVERY leg of this run (exploration; the default line measures fp32 and "
                          "reports the opt-in fp16 mode under its own key)")
     ap.add_argument("--no-fp16", action="store_true", help="skip the fp16 leg of the default line")
+    ap.add_argument("--no-cfg5", action="store_true", help="skip the BASELINE configs[4] leg (server det + SVTR-large rec, fp16, batch 32; NOT a "
+                                                            "reference artifact) that the default line carries as an extra key")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-request latency calls (profiling runs)")
@@ -520,7 +522,7 @@ def cfg5_cpu_baseline():
                       "lines; networks only (pre/post-processing is < 1 %% of this)" % (n_img, t_det, n_lines, t_rec, t_det * n_img + t_rec)}
 
 
-def main_cfg5(args):
+def cfg5_line(args):
     """BASELINE configs[4]: "PP-OCRv4_server_det (ResNet50 backbone) + SVTR-large rec, fp16, batch=32" - NOT a reference
     artifact: hand-written plans from the public PaddleOCR definitions, seeded weights.  One step =
     one pass of the whole pipeline over 32 synthetic 960 x 960 images per GPU (the cfg2 generator, 32 lines each, the
@@ -634,7 +636,11 @@ def main_cfg5(args):
     }
     if not args.no_cpu_baseline:
         line["cpu_baseline"] = cfg5_cpu_baseline()
-    print(json.dumps(line))
+    return line
+
+
+def main_cfg5(args):
+    print(json.dumps(cfg5_line(args)))
 
 
 def main(argv=None):
@@ -960,6 +966,25 @@ def main(argv=None):
         fp16 = fp16_leg(mk_pipe, lambda p_: (lambda collect=False: p_.run_device(d_imgs, H, W, BATCH, d_probs, collect=collect)),
                         ref_words, batch, max(2, args.steps), sync)
 
+    # ---- BASELINE configs[4] (server det + SVTR-large rec, fp16, batch 32; hand-written plans, NOT a reference artifact): an extra
+    # key of the default line, so that the driver's record holds a number measured by the driver for it; `--config cfg5` prints the
+    # full line (roofline tables, CPU baseline).  Never `value`.
+    cfg5 = None
+    if not stub and cfg == "cfg2" and world == 1 and not args.no_cfg5 and args.precision == "fp32" and not under_profiler():
+        try:
+            import argparse as _ap
+            a5 = _ap.Namespace(**vars(args))
+            a5.steps, a5.warmup, a5.no_cpu_baseline, a5.gpus = max(2, min(args.steps, 6)), 1, True, 1
+            l5 = cfg5_line(a5)
+            r5 = l5["roofline"]
+            cfg5 = {"value": l5["value"], "unit": l5["unit"], "ms_per_step": l5["ms_per_step"], "steps": l5["steps"], "dtype": l5["dtype"],
+                    "reference_artifact": False, "global_batch": l5["config"]["global_batch"], "workload": l5["config"]["workload"],
+                    "roofline": {k: r5[k] for k in ("kernel", "ms_per_launch", "bound", "achieved", "peak", "unit", "frac", "traffic", "det_conv_stack", "step", "per_network_ms")},
+                    "what": "BASELINE configs[4] on this GPU, after the headline's timed region (its own inputs, handles and timed region); "
+                            "`python bench.py --config cfg5` prints the whole line"}
+        except Exception as e:  # (the default line must not die with its extra)
+            cfg5 = {"error": repr(e)[:400], "reference_artifact": False}
+
     # ---- result gather (after the timed region): every rank's words of one step as fixed-size records
     gather = None
     gcap = max(GATHER_CAP, batch * 80)
@@ -1068,6 +1093,8 @@ def main(argv=None):
             out["two_workers_per_gpu"] = two_workers
         if fp16:
             out["fp16"] = fp16
+        if cfg5:
+            out["cfg5"] = cfg5
         if args.precision != "fp32":
             out["precision_override"] = args.precision
         if gather:

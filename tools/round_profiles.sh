@@ -6,7 +6,7 @@ T=${1:-r5}
 O=gpurun_out/ev_$T
 mkdir -p $O
 # (gpurun_out/ does not travel to the box: this call makes its own bench line for the duration check of pmc_traffic.py)
-python bench.py --no-cpu-baseline --no-fp16 --no-two-workers --no-host-input --no-latency > $O/bench_cfg2_prof.json 2> $O/bench_cfg2_prof.err
+python bench.py --no-cpu-baseline --no-fp16 --no-cfg5 --no-two-workers --no-host-input --no-latency > $O/bench_cfg2_prof.json 2> $O/bench_cfg2_prof.err
 tools/run_profile.sh $T > $O/profile.log 2>&1
 python tools/prof_summary.py gpurun_out/prof_$T > $O/prof_summary.txt 2>&1
 python tools/pmc_traffic.py gpurun_out/prof_$T $O/pmc_traffic.json $O/bench_cfg2_prof.json dw_lds_kernel,dw_conv_kernel > $O/pmc_traffic.log 2>&1

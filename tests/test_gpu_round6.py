@@ -344,3 +344,26 @@ def test_server_nets_at_production_shapes_against_the_oracle(pkg, built):
     net.close()
     assert np.abs(got - want).max() <= 0.06 * np.abs(want).max(), float(np.abs(got - want).max())
     assert (got.argmax(-1) == want.argmax(-1)).mean() >= 0.90, float((got.argmax(-1) == want.argmax(-1)).mean())
+
+
+def test_server_fp16_results_do_not_depend_on_the_batch(pkg, built):
+    """A size-independent property of the f16 build at production shapes: a text line's logits and an image's probability map are the same
+    BITS whether the line / image runs alone, in a small batch or in a full one - every matrix product accumulates a row in one fixed
+    order whatever tile configuration the shape's tuning picked (test_every_tile_configuration_gives_the_same_bits), attention, LayerNorm
+    and the fused kernels work per line / per pixel.  (The f32 build has this by equalling the oracle.)"""
+    _srv_ready()
+    rs = np.random.RandomState(71)
+    x = rs.randn(96, 48, 320, 3).astype(np.float32)
+    net = pkg.SrvNet("rec", "fp16")
+    full = net.forward(x, keep_all=False)
+    some = net.forward(x[40:48], keep_all=False)
+    one = net.forward(x[95:96], keep_all=False)
+    net.close()
+    assert np.array_equal(full[40:48].view(np.uint32), some.view(np.uint32))
+    assert np.array_equal(full[95:96].view(np.uint32), one.view(np.uint32))
+    y = rs.randn(3, 480, 640, 3).astype(np.float32)
+    net = pkg.SrvNet("det", "fp16")
+    full = net.forward(y, keep_all=False)
+    one = net.forward(y[2:3], keep_all=False)
+    net.close()
+    assert np.array_equal(full[2:3].view(np.uint32), one.view(np.uint32))

@@ -1437,29 +1437,39 @@ __global__ void __launch_bounds__(64) attn_f_kernel(const float* __restrict__ qk
 
 // f16: one workgroup per (line, head); K and V of the pair in LDS ([T + 32][32] halfs each; K rows XOR-swizzled by
 // (row >> 2) & 3 for conflict-free ds_read_b128, V rows linear for ds_read_b64_tr_b16), a wave per tile of 32 queries of one grid row.
-template <int NWV>
-__global__ void __launch_bounds__(64 * NWV, 16 / NWV) attn_h_kernel(const _Float16* __restrict__ qkv, _Float16* __restrict__ out, int T, int heads, float scale_log2e,
-                                                          int gh, int gw, int lh, int lw) {
-  constexpr int HD = 32;
+// NH = heads per workgroup.  A head's K (V) row of a token is 64 bytes of the token's 3 D wide qkv row: fetched head by head, every
+// 128-byte line of the tensor is read by two workgroups (PMC: FETCH = 2.0 x the qkv tensor per launch - 1.51 GB in 0.40 ms, the
+// launch's real bound at stage 3).  NH = 2: a workgroup takes a PAIR of heads, its loads are whole lines, half of its waves work on each.
+template <int NWV, int NH>
+__global__ void __launch_bounds__(64 * NWV, NWV >= 16 ? 1 : 16 / NWV) attn_h_kernel(const _Float16* __restrict__ qkv, _Float16* __restrict__ out, int T, int heads,
+                                                                                   float scale_log2e, int gh, int gw, int lh, int lw) {
+  constexpr int HD = 32, WPH = NWV / NH;  // waves per head
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hl = wave_all / WPH, wave = wave_all - hl * WPH;  // this wave's head of the workgroup, its index among that head's waves
   const int r = lane & 31, h = lane >> 5;
-  const int n = blockIdx.x / heads, hh = blockIdx.x % heads;
+  const int hpb = heads / NH;
+  const int n = blockIdx.x / hpb, hh = (blockIdx.x % hpb) * NH + hl;
   const int D = heads * HD;
   const _Float16* base = qkv + (long)n * T * 3 * D + hh * HD;
-  unsigned char* sK = smem;
-  unsigned char* sV = smem + (size_t)(T + 32) * 64;
+  const size_t img = (size_t)(T + 32) * 64;
+  unsigned char* sK = smem + (size_t)hl * 2 * img;
+  unsigned char* sV = sK + img;
   // ---- K, V -> LDS (16-byte chunks; the 32 rows past T hold zeros: a masked key's probability is 0, and 0 x garbage must not be NaN)
-  for (int i = tid; i < (T + 32) * 4; i += 64 * NWV) {
-    const int t = i >> 2, c = i & 3;
-    h8v kv = {0, 0, 0, 0, 0, 0, 0, 0}, vv = kv;
-    if (t < T) {
-      kv = *(const h8v*)(base + (long)t * 3 * D + D + 8 * c);
-      vv = *(const h8v*)(base + (long)t * 3 * D + 2 * D + 8 * c);
+  {
+    const _Float16* base0 = qkv + (long)n * T * 3 * D + (blockIdx.x % hpb) * NH * HD;
+    for (int i = tid; i < (T + 32) * 4 * NH; i += 64 * NWV) {
+      const int t = i / (4 * NH), c8 = i % (4 * NH), hd2 = c8 >> 2, c = c8 & 3;  // (lanes of a token: consecutive 16-byte chunks of NH x 64 bytes)
+      h8v kv = {0, 0, 0, 0, 0, 0, 0, 0}, vv = kv;
+      if (t < T) {
+        kv = *(const h8v*)(base0 + (long)t * 3 * D + D + 8 * c8);
+        vv = *(const h8v*)(base0 + (long)t * 3 * D + 2 * D + 8 * c8);
+      }
+      unsigned char* k0 = smem + (size_t)hd2 * 2 * img;
+      *(h8v*)(k0 + t * 64 + ((c ^ ((t >> 2) & 3)) << 4)) = kv;
+      *(h8v*)(k0 + img + t * 64 + (c << 4)) = vv;
     }
-    *(h8v*)(sK + t * 64 + ((c ^ ((t >> 2) & 3)) << 4)) = kv;
-    *(h8v*)(sV + t * 64 + (c << 4)) = vv;
   }
   __syncthreads();
   const int hwy = lh >> 1, hwx = lw >> 1;
@@ -1474,7 +1484,7 @@ __global__ void __launch_bounds__(64 * NWV, 16 / NWV) attn_h_kernel(const _Float
   // supplies the address of row q, columns 4 p .. 4 p + 3
   const int trq = (lane & 15) >> 2, trp = lane & 3;
   const unsigned tr_off = (unsigned)((4 * h + trq) * 64 + (16 * ((lane >> 4) & 1) + 4 * trp) * 2);
-  for (int qt = wave; qt < nq; qt += NWV) {
+  for (int qt = wave; qt < nq; qt += WPH) {
     const int qrow = qt / segs, qseg = qt - qrow * segs;
     const int qy0 = pairs ? 2 * qrow : qrow, qxs = qseg << (pairs ? 4 : 5);
     const int qy = pairs ? qy0 + (r >> 4) : qy0, qx = qxs + (pairs ? r & 15 : r);
@@ -1619,13 +1629,27 @@ bool launch_attention(const void* qkv, void* out, int N, int T, int heads, int h
   if (lh <= 0) { gh = 1; gw = T; }
   const bool pairs = lh > 0 && lw / 2 <= 8;  // (the kernel's query tiling)
   const int nq = pairs ? ((gh + 1) / 2) * ((gw + 15) / 16) : gh * ((gw + 31) / 32);
-  static LdsAttrMemo memo8, memo4;
+  // heads in pairs (whole-line loads) where two heads' K and V fit beside another workgroup's: T = 240 (70 KB, 8 waves, two workgroups
+  // per CU) and T = 480 (131 KB: one workgroup of 16 waves); a 960-token line (123 KB per head) keeps one head per workgroup
+  static LdsAttrMemo memo8, memo4, memo8p, memo16p;
+  static const bool pair_on = [] { const char* e = getenv("OCR_SRV_ATTN_PAIR"); return !(e && e[0] == '0'); }();
+  if (pair_on && heads % 2 == 0 && 2 * lds <= 160 * 1024) {
+    const size_t lds2 = 2 * lds;
+    if (2 * lds2 <= 160 * 1024) {
+      if (lds2 > 64 * 1024 && !raise_dynamic_lds((const void*)attn_h_kernel<8, 2>, (int)lds2, memo8p)) { err = "attention: dynamic LDS attribute refused"; return false; }
+      hipLaunchKernelGGL((attn_h_kernel<8, 2>), dim3((unsigned)(N * heads / 2)), dim3(512), lds2, s, (const _Float16*)qkv, (_Float16*)out, T, heads, sl, gh, gw, lh, lw);
+    } else {
+      if (!raise_dynamic_lds((const void*)attn_h_kernel<16, 2>, (int)lds2, memo16p)) { err = "attention: dynamic LDS attribute refused"; return false; }
+      hipLaunchKernelGGL((attn_h_kernel<16, 2>), dim3((unsigned)(N * heads / 2)), dim3(1024), lds2, s, (const _Float16*)qkv, (_Float16*)out, T, heads, sl, gh, gw, lh, lw);
+    }
+    return true;
+  }
   if (nq >= 12) {
-    if (lds > 64 * 1024 && !raise_dynamic_lds((const void*)attn_h_kernel<8>, (int)lds, memo8)) { err = "attention: dynamic LDS attribute refused"; return false; }
-    hipLaunchKernelGGL(attn_h_kernel<8>, dim3((unsigned)(N * heads)), dim3(512), lds, s, (const _Float16*)qkv, (_Float16*)out, T, heads, sl, gh, gw, lh, lw);
+    if (lds > 64 * 1024 && !raise_dynamic_lds((const void*)attn_h_kernel<8, 1>, (int)lds, memo8)) { err = "attention: dynamic LDS attribute refused"; return false; }
+    hipLaunchKernelGGL((attn_h_kernel<8, 1>), dim3((unsigned)(N * heads)), dim3(512), lds, s, (const _Float16*)qkv, (_Float16*)out, T, heads, sl, gh, gw, lh, lw);
   } else {
-    if (lds > 64 * 1024 && !raise_dynamic_lds((const void*)attn_h_kernel<4>, (int)lds, memo4)) { err = "attention: dynamic LDS attribute refused"; return false; }
-    hipLaunchKernelGGL(attn_h_kernel<4>, dim3((unsigned)(N * heads)), dim3(256), lds, s, (const _Float16*)qkv, (_Float16*)out, T, heads, sl, gh, gw, lh, lw);
+    if (lds > 64 * 1024 && !raise_dynamic_lds((const void*)attn_h_kernel<4, 1>, (int)lds, memo4)) { err = "attention: dynamic LDS attribute refused"; return false; }
+    hipLaunchKernelGGL((attn_h_kernel<4, 1>), dim3((unsigned)(N * heads)), dim3(256), lds, s, (const _Float16*)qkv, (_Float16*)out, T, heads, sl, gh, gw, lh, lw);
   }
   return true;
 }

@@ -50,6 +50,9 @@ struct GemmArgs {
   int res_up = 0;
   int act = SACT_NONE;
   int out_f32 = 0;
+  int group_m = 0;           // tile order: 0 = the column tiles of a pixel tile are neighbours (the whole weight slab streams past each pixel tile);
+                             // G > 0 = pixel tiles in groups of G, a column tile's G pixel tiles neighbours, then the next column tile - the slab
+                             // streams once per GROUP while the group's G pixel panels stay in L2 (slabs that do not fit L2: the CTC head's 5 MB)
   int korder = 0;            // K order of a 3x3 stride-1 conv's weight image: 0 = (tap, channel) - the oracle's ascending chain, every f32 launch;
                              // 1 = (64-channel tile, tap, channel in tile) - the f16 build: a channel tile's nine taps are consecutive K tiles,
                              // so the halo form (srv_conv3_kernel) streams ONE input patch per channel tile; both forms accumulate in this order

@@ -195,8 +195,17 @@ __global__ void __launch_bounds__(64 * WM * WN) srv_gemm_kernel(const GemmArgs a
   // ---- tile of this workgroup: column (n) tiles of one pixel tile are neighbours (they share the X panel in L2)
   const unsigned nb_n = (unsigned)((a.Ncols + BN - 1) / BN);
   const unsigned bid = srv_xcd(blockIdx.x, gridDim.x);
-  const int n0 = (int)(bid % nb_n) * BN;
-  const long m0 = (long)(bid / nb_n) * BM;
+  unsigned tn = bid % nb_n, tm = bid / nb_n;
+  if (a.group_m > 0) {  // (wave-uniform)
+    const unsigned nb_m = (unsigned)((a.M + BM - 1) / BM), G = (unsigned)a.group_m;
+    const unsigned per = G * nb_n, grp = bid / per, first = grp * G;
+    const unsigned gsz = nb_m - first < G ? nb_m - first : G;
+    const unsigned in = bid - grp * per;
+    tm = first + in % gsz;
+    tn = in / gsz;
+  }
+  const int n0 = (int)tn * BN;
+  const long m0 = (long)tm * BM;
 
   // ---- buffer descriptors
   v4u rs_w, rs_x;

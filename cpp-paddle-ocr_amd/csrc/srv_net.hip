@@ -631,6 +631,14 @@ bool SrvNet::bind(int N, int H, int W, hipStream_t s, std::string& err) {
       a.bias = op.bias; a.scale = op.scale; a.shift = op.shift;
       a.act = op.act;
       a.korder = op.korder;
+      {
+        // tile order (GemmArgs::group_m): a weight slab beyond ~1.5 MB does not stay in an XCD's 4 MB L2 beside the pixel panels and the
+        // output stream - it would be fetched again for every pixel tile (PMC on the CTC head, 5 MB of weights: 1.77 GB fetched per launch
+        // against 68 MB of operands).  OCR_SRV_GROUP_M=0 / n overrides
+        static const int gm_env = [] { const char* e = getenv("OCR_SRV_GROUP_M"); return e && *e ? atoi(e) : -1; }();
+        const double slab = (double)op.ncols * (double)a.K * esz;
+        a.group_m = gm_env >= 0 ? gm_env : (slab > 1.5e6 ? 8 : 0);
+      }
       if (op.res_tid >= 0) {
         const SrvTensor& rt = tensors_[op.res_tid];
         a.res = ptr(op.res_tid);

@@ -50,6 +50,11 @@ struct GemmArgs {
   int res_up = 0;
   int act = SACT_NONE;
   int out_f32 = 0;
+  // CTC head (f32-output launches): instead of writing the logits, every workgroup leaves per output row ONE partial of its column
+  // tile - (max logit, sum of exp(logit - max), index of the first maximum) as 4 floats at ctc_part[(row * ctc_slots + n0 / 64) * 4] -
+  // which launch_ctc_reduce folds into the row's arg max and its softmax probability: the logits (2.2 GB per 1024 lines) never exist
+  float* ctc_part = nullptr;
+  int ctc_slots = 0;
   int group_m = 0;           // tile order: 0 = the column tiles of a pixel tile are neighbours (the whole weight slab streams past each pixel tile);
                              // G > 0 = pixel tiles in groups of G, a column tile's G pixel tiles neighbours, then the next column tile - the slab
                              // streams once per GROUP while the group's G pixel panels stay in L2 (slabs that do not fit L2: the CTC head's 5 MB)
@@ -58,6 +63,7 @@ struct GemmArgs {
                              // so the halo form (srv_conv3_kernel) streams ONE input patch per channel tile; both forms accumulate in this order
 };
 int gemm_num_configs();
+int gemm_config_bn(int cfg);  // column-tile width of a configuration (the CTC partials' slot step is bn / 64)
 const char* gemm_config_name(int cfg);
 // can tile configuration `cfg` run this problem? (shape divisibility, LDS attribute) - asked at bind time
 bool gemm_config_ok(const GemmArgs& a, bool half, int cfg);
@@ -94,6 +100,8 @@ void launch_deconv_to_map(const void* x, const float* w4 /* [4 taps][Cs] */, flo
 bool launch_head_tail(const void* x, const void* w1img, const float* b1, const float* w4, float bias2, float* prob, int N, int H, int W, hipStream_t s,
                       bool query, std::string& err);
 void launch_argmax_softmax(const float* logits, long rows, int C, int ld, int* amax, float* pmax, hipStream_t s);
+// folds the partials of a CTC-mode head launch (GemmArgs::ctc_part): slots 0, step, 2 step, .. < slots of every row
+void launch_ctc_reduce(const float* part, long rows, int slots, int step, int* amax, float* pmax, hipStream_t s);
 void launch_argmax_softmax(const float* logits, long rows, int C, int ld, int* amax, float* pmax, bool half, hipStream_t s);  // half: the one-pass form
 // copies a T tensor to f32 dropping the pad channels (parity taps)
 void launch_to_f32(const void* x, float* y, long pixels, int Cs, int C, bool half, hipStream_t s);

@@ -509,6 +509,47 @@ __global__ void __launch_bounds__(64 * WM * WN) srv_gemm_kernel(const GemmArgs a
   constexpr int CP = BN / 8;  // 8-channel chunks per pixel row of the tile
   const int ch = tid % CP;
   const int n = n0 + 8 * ch;
+  if (a.ctc_part) {
+    // ---- CTC head: the row's partial of this column tile instead of its logits.  The CP chunk threads of a row are consecutive
+    // lanes: each folds its eight logits (bias added; columns past Ncols do not exist), then log2(CP) exchanges fold the row
+    constexpr float L2E = 1.44269504088896341f;
+    float pb[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) pb[e] = a.bias && n + e < a.Ncols ? a.bias[n + e] : 0.f;
+    for (int p = tid / CP; p < BM; p += NT / CP) {
+      const long m = m0 + p;
+      if (m >= a.M) break;  // (the same for every chunk thread of the row)
+      const f4v lo = *(const f4v*)(tile + p * SP + 8 * ch), hi = *(const f4v*)(tile + p * SP + 8 * ch + 4);
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[e] = lo[e] + pb[e]; v[4 + e] = hi[e] + pb[4 + e]; }
+      float mx = -INFINITY;
+      int mi = 0x7fffffff;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        if (n + e >= a.Ncols) v[e] = -INFINITY;
+        if (v[e] > mx) { mx = v[e]; mi = n + e; }
+      }
+      float sum = 0.f;
+      if (mx != -INFINITY) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sum += __builtin_amdgcn_exp2f((v[e] - mx) * L2E);
+      }
+#pragma unroll
+      for (int o = 1; o < CP; o <<= 1) {
+        const float om = __shfl_xor(mx, o), os = __shfl_xor(sum, o);
+        const int oi = __shfl_xor(mi, o);
+        const float M2 = fmaxf(mx, om);
+        const float sa = mx == -INFINITY ? 0.f : sum * __builtin_amdgcn_exp2f((mx - M2) * L2E);
+        const float sb = om == -INFINITY ? 0.f : os * __builtin_amdgcn_exp2f((om - M2) * L2E);
+        if (om > mx || (om == mx && oi < mi)) mi = oi;
+        mx = M2;
+        sum = sa + sb;
+      }
+      if (ch == 0) *(f4v*)(a.ctc_part + ((size_t)m * (size_t)a.ctc_slots + (size_t)(n0 >> 6)) * 4) = f4v{mx, sum, __int_as_float(mi), 0.f};
+    }
+    return;
+  }
   const int ncols_store = a.deconv ? a.Ncols : a.Cs_out;
   if (n >= ncols_store) return;
   float pbias[8], pscale[8], pshift[8];
@@ -842,6 +883,7 @@ static const GemmCfg g_cfgs[] = {
 #undef X
 };
 int gemm_num_configs() { return (int)(sizeof(g_cfgs) / sizeof(g_cfgs[0])); }
+int gemm_config_bn(int cfg) { return cfg >= 0 && cfg < gemm_num_configs() ? g_cfgs[cfg].bn : 0; }
 const char* gemm_config_name(int cfg) { return cfg >= 0 && cfg < gemm_num_configs() ? g_cfgs[cfg].name : "?"; }
 
 template <typename T, int BM, int BN, int WM, int WN, int NS>
@@ -850,6 +892,7 @@ static bool gemm_go(const GemmArgs& a, hipStream_t s, bool query, std::string& e
   auto kern = srv_gemm_kernel<T, BM, BN, WM, WN, NS>;
   static LdsAttrMemo memo;
   if (G::BIG && !(sizeof(T) == 2 && !a.deconv && !a.out_f32 && !a.scale)) { err = "a big tile has the register epilogue only"; return false; }
+  if (a.ctc_part && !(a.out_f32 && !a.deconv && !a.res_up && !a.scale && a.act == SACT_NONE && a.ctc_slots >= (a.Ncols + 63) / 64)) { err = "CTC partials: a plain f32-output linear"; return false; }
   if (G::LDS > 64 * 1024 && !raise_dynamic_lds((const void*)kern, (int)G::LDS, memo)) { err = "dynamic LDS attribute refused"; return false; }
   if (query) return true;
   const long nb = ((a.M + BM - 1) / BM) * ((a.Ncols + BN - 1) / BN);
@@ -867,6 +910,7 @@ static bool pgemm_go(const GemmArgs& a, hipStream_t s, bool query, std::string& 
   auto kern = srv_pgemm_kernel<T, BM, BN, WM, WN, 3, OF32>;
   static LdsAttrMemo memo;
   if (!a.x1) { err = "the persistent form takes 1x1 problems"; return false; }
+  if (a.ctc_part) { err = "the persistent form has no CTC epilogue"; return false; }
   if (a.res_up && (OF32 || a.res_bytes >= 0xfffffff0ull)) { err = "residual"; return false; }
   if (a.y_bytes >= 0xfffffff0ull) { err = "output beyond the 4 GB a buffer descriptor spans"; return false; }
   if (G::LDS > 64 * 1024 && !raise_dynamic_lds((const void*)kern, (int)G::LDS, memo)) { err = "dynamic LDS attribute refused"; return false; }
@@ -1309,6 +1353,32 @@ bool launch_head_tail(const void* x, const void* w1img, const float* b1, const f
   const unsigned grid = (unsigned)std::min<long>(tiles, 1024);
   hipLaunchKernelGGL(head_tail_kernel, dim3(grid), dim3(256), LDS, s, (const _Float16*)x, (const _Float16*)w1img, b1, w4, bias2, prob, N, H, W, tiles);
   return true;
+}
+
+// ---- CTC tail of a head launch in partial mode: a thread per row folds the row's column-tile partials (ascending columns: the first maximum wins)
+__global__ void __launch_bounds__(256) ctc_reduce_kernel(const float* __restrict__ part, long rows, int slots, int step, int* __restrict__ amax,
+                                                         float* __restrict__ pmax) {
+  const long row = (long)blockIdx.x * 256 + threadIdx.x;
+  if (row >= rows) return;
+  constexpr float L2E = 1.44269504088896341f;
+  float mx = -INFINITY, sum = 0.f;
+  int mi = 0x7fffffff;
+  for (int sl = 0; sl < slots; sl += step) {
+    const f4v p4 = *(const f4v*)(part + ((size_t)row * (size_t)slots + (size_t)sl) * 4);
+    const float om = p4[0], os = p4[1];
+    const int oi = __float_as_int(p4[2]);
+    const float M2 = fmaxf(mx, om);
+    const float sa = mx == -INFINITY ? 0.f : sum * __builtin_amdgcn_exp2f((mx - M2) * L2E);
+    const float sb = om == -INFINITY ? 0.f : os * __builtin_amdgcn_exp2f((om - M2) * L2E);
+    if (om > mx || (om == mx && oi < mi)) mi = oi;
+    mx = M2;
+    sum = sa + sb;
+  }
+  amax[row] = mi;
+  pmax[row] = 1.0f / sum;
+}
+void launch_ctc_reduce(const float* part, long rows, int slots, int step, int* amax, float* pmax, hipStream_t s) {
+  hipLaunchKernelGGL(ctc_reduce_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, part, rows, slots, step, amax, pmax);
 }
 
 // ---- CTC tail: a wave per row; arg max = first maximum of the logits, its probability 1 / sum exp(x - max)

@@ -41,6 +41,12 @@ class SrvNet {
   // parity tap: tensor `tid` in logical NHWC f32 (pad channels dropped)
   bool fetch_logical(int tid, std::vector<float>& host, int dims[4], hipStream_t s, std::string& err);
   void set_keep_all(bool on) { if (on != keep_all_) { keep_all_ = on; bound_n_ = -1; } }
+  // CTC mode of the LAST linear (f32 logits), f16 build: it leaves per-row partials in the output tensor's slot instead of the logits
+  // (GemmArgs::ctc_part); the caller folds them with srv::launch_ctc_reduce(tensor_ptr(output_tid()), rows, ctc_slots(), ctc_step(), ..)
+  void set_ctc_partials(bool on) { if (on != ctc_) { ctc_ = on; bound_n_ = -1; } }
+  bool ctc_partials() const { return ctc_ && half_ && ctc_slots_ > 0; }
+  int ctc_slots() const { return ctc_slots_; }
+  int ctc_step() const { return ctc_step_; }
   void enable_timing(bool on) { timing_ = on; }
   const std::map<std::string, KernelTiming>& timings() const { return timings_; }
   void reset_timings() { timings_.clear(); }
@@ -82,7 +88,8 @@ class SrvNet {
 
   std::vector<Op> ops_;
   int ntensors_ = 0, out_tid_ = -1;
-  bool half_ = true, keep_all_ = false, timing_ = false;
+  bool half_ = true, keep_all_ = false, timing_ = false, ctc_ = false;
+  int ctc_slots_ = 0, ctc_step_ = 0;
   std::vector<void*> dev_allocs_;
   std::vector<SrvTensor> tensors_;
   std::vector<Launch> launches_;

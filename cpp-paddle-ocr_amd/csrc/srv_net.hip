@@ -366,6 +366,7 @@ int SrvNet::tune(const srv::GemmArgs& a, const std::string& key, hipStream_t s) 
 bool SrvNet::bind(int N, int H, int W, hipStream_t s, std::string& err) {
   launches_.clear();
   flops_ = bytes_ = 0;
+  ctc_slots_ = ctc_step_ = 0;
   const int pk = ntensors_;  // the packed input [N][H][W][8] T: an extra tensor behind the plan's
   tensors_.assign(ntensors_ + 1, SrvTensor());
   auto set = [&](int tid, int n, int h, int w, int c, bool f32 = false, int cs = -1) {
@@ -648,11 +649,18 @@ bool SrvNet::bind(int N, int H, int W, hipStream_t s, std::string& err) {
         if (!okshape || rt.cs != ot.cs || rt.n != ot.n || op.kind == "deconv") { err = "server plan: residual of op " + std::to_string(oi) + " has another shape"; return false; }
       }
       a.out_f32 = ot.f32 ? 1 : 0;
+      const bool ctc_here = ctc_ && half_ && !keep_all_ && o == out_tid_ && ot.f32 && op.kind == "linear" && op.res_tid < 0 && !op.scale && op.act == srv::SACT_NONE &&
+                            (size_t)((op.ncols + 63) / 64) * 16 <= (size_t)ot.cs * 4;  // (the partials of a row fit the row's logits slot)
+      if (ctc_here) {
+        a.ctc_part = (float*)ptr(o);
+        a.ctc_slots = (op.ncols + 63) / 64;
+      }
       snprintf(nm, sizeof nm, "%zu.%s%dx%d_%d_%d_s%d%s@%dx%dx%d", oi, op.kind.c_str(), a.KH, a.KW, in.c, op.geti("cout"), a.SH * 10 + a.SW,
                op.res_tid >= 0 ? "_res" : "", ot.n, ot.h, ot.w);
       const int cfg = tune(a, std::string(nm), s);
       if (cfg < 0) { err = std::string("no tile configuration runs ") + nm; return false; }
-      L.name = std::string(nm) + "[" + srv::gemm_config_name(cfg) + "]";
+      L.name = std::string(nm) + (ctc_here ? "_ctc" : "") + "[" + srv::gemm_config_name(cfg) + "]";
+      if (ctc_here) { ctc_slots_ = a.ctc_slots; ctc_step_ = std::max(1, srv::gemm_config_bn(cfg) / 64); }
       const double klog = (double)a.KH * a.KW * in.c;
       L.flops = 2.0 * (double)a.M * klog * (double)op.ncols;
       L.bytes = (double)in.bytes(half_) + (double)ot.bytes(half_) + (double)op.ncols * klog * esz + (op.res_tid >= 0 ? (double)tensors_[op.res_tid].bytes(half_) / (op.res_up == 2 ? 1.0 : 1.0) : 0.0);

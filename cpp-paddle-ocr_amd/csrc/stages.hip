@@ -442,6 +442,10 @@ bool RecStage::create(const RecConfig& cfg, std::string& err, int& code) {
     if (!load_server_model_dir(cfg.model_dir, "srv_rec", w, err)) return false;
     srv_.reset(new SrvNet());
     if (!srv_->load(embedded_plan("srv_rec"), w, cfg.precision == "fp16", err)) return false;
+    {  // the pipeline needs arg max and its probability, never the logits: the CTC head in partial mode (f16 build; OCR_SRV_CTC=0: logits + one pass over them)
+      static const bool ctc_on = [] { const char* e = getenv("OCR_SRV_CTC"); return !(e && e[0] == '0'); }();
+      srv_->set_ctc_partials(ctc_on);
+    }
   } else {
     if (!load_model_dir(cfg.model_dir, nullptr, "rec", w, err)) return false;
     if (!net_.load(embedded_plan("rec"), w, err, cfg.precision == "fp16")) return false;
@@ -616,8 +620,12 @@ int RecStage::run_lines(const std::vector<LineSrc>& lines, const std::vector<int
       if (ot.c != (int)labels_.size()) { err = "dictionary size does not match the CTC head"; return OCR_ERR_MODEL; }
       sl.T = ot.w;
       if (sl.T > Wt / 4 + 8) { err = "rec step buffer too small"; return OCR_ERR_CAPACITY; }
-      srv::launch_argmax_softmax((const float*)srv_->tensor_ptr(srv_->output_tid()), (long)sl.count * sl.T, ot.c, ot.cs, amax_.p + sl.step_off,
-                                 pmax_.p + sl.step_off, srv_->half(), stream_);
+      if (srv_->ctc_partials())  // the head left per-row partials instead of logits (srv_net.h): fold them
+        srv::launch_ctc_reduce((const float*)srv_->tensor_ptr(srv_->output_tid()), (long)sl.count * sl.T, srv_->ctc_slots(), srv_->ctc_step(),
+                               amax_.p + sl.step_off, pmax_.p + sl.step_off, stream_);
+      else
+        srv::launch_argmax_softmax((const float*)srv_->tensor_ptr(srv_->output_tid()), (long)sl.count * sl.T, ot.c, ot.cs, amax_.p + sl.step_off,
+                                   pmax_.p + sl.step_off, srv_->half(), stream_);
       launch_ctc(amax_.p + sl.step_off, pmax_.p + sl.step_off, sl.count, sl.T, max_len, ids_.p + (size_t)sl.first * max_len,
                  lens_.p + sl.first, scores_.p + sl.first, stream_);
     } else if (sl.ragged) {

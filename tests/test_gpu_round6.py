@@ -367,3 +367,47 @@ def test_server_fp16_results_do_not_depend_on_the_batch(pkg, built):
     one = net.forward(y[2:3], keep_all=False)
     net.close()
     assert np.array_equal(full[2:3].view(np.uint32), one.view(np.uint32))
+
+
+_CTC_CHILD = r"""
+import sys, os, json, numpy as np
+sys.path[:0] = [sys.argv[1], sys.argv[1] + "/tools"]
+import __graft_entry__ as ge
+pkg = ge.load_package()
+from synth_data import cfg2_sample
+n, hw, k = 3, 320, 8
+samples = [cfg2_sample(200 + i, hw, hw, k) for i in range(n)]
+srv = os.path.join(sys.argv[1], "models_server")
+pipe = pkg.Pipe(device=0, enable_cls=True, limit_side_len=hw, rec_batch_num=16, rec_img_h=48, rec_img_w=320, precision="fp16",
+                det_dir=os.path.join(srv, "det"), rec_dir=os.path.join(srv, "rec"))
+pipe.timing(True)
+got = pipe.run_device(pkg.DevArray(np.stack([s[0] for s in samples])), hw, hw, n, pkg.DevArray(np.stack([s[1] for s in samples])), collect=True)
+names = " ".join(pipe.timing_report())
+pipe.close()
+print("CTC", json.dumps({"ctc_launches": names.count("_ctc["), "words": [[(w["ids"].tolist(), float(w["confidence"])) for w in im] for im in got]}))
+"""
+
+
+def test_ctc_head_in_partial_mode_equals_logits_then_arg_max(pkg, built):
+    """The server recognizer's CTC head inside the pipeline (f16 build): every workgroup of the last linear leaves a per-row partial
+    (max, sum of exp, first arg max) of its column tile and a small kernel folds them - the 2.2 GB of logits per 1024 lines are never
+    written - against OCR_SRV_CTC=0 (logits, then one pass over them): the same id sequences, confidences to 2e-6 (sums in another order)."""
+    import json
+    import subprocess
+    import sys
+    _srv_ready()
+    res = {}
+    procs = {k: subprocess.Popen([sys.executable, "-c", _CTC_CHILD, ROOT], env=dict(os.environ, **env), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for k, env in (("partials", {}), ("logits", {"OCR_SRV_CTC": "0"}))}
+    for k, pr in procs.items():
+        so, se = pr.communicate(timeout=600)
+        assert pr.returncode == 0 and "CTC " in so, (k, so[-1500:], se[-1500:])
+        res[k] = json.loads(so[so.index("CTC ") + 4:])
+    assert res["partials"]["ctc_launches"] >= 1 and res["logits"]["ctc_launches"] == 0
+    a, b = res["partials"]["words"], res["logits"]["words"]
+    assert len(a) == len(b) and sum(len(im) for im in a) >= 12
+    for ia, ib in zip(a, b):
+        assert len(ia) == len(ib)
+        for (ids_a, c_a), (ids_b, c_b) in zip(ia, ib):
+            assert ids_a == ids_b
+            assert abs(c_a - c_b) <= 2e-6, (c_a, c_b)

@@ -53,6 +53,13 @@ struct GemmArgs {
   // CTC head (f32-output launches): instead of writing the logits, every workgroup leaves per output row ONE partial of its column
   // tile - (max logit, sum of exp(logit - max), index of the first maximum) as 4 floats at ctc_part[(row * ctc_slots + n0 / 64) * 4] -
   // which launch_ctc_reduce folds into the row's arg max and its softmax probability: the logits (2.2 GB per 1024 lines) never exist
+  // halo form only: the input is the CONCATENATION of cat_n 64-channel tensors, source j nearest-upsampled by 2^cat_sh[j] (the DB
+  // neck's `concat up=8,4,2,1` in front of the head conv): channel tile j of the K order (channel tile, tap) IS source j, so the
+  // patch of tile j is fetched from source j at (y >> sh, x >> sh) - the 256-channel concatenation is never written
+  const void* cat_x[4] = {nullptr, nullptr, nullptr, nullptr};
+  unsigned long long cat_bytes[4] = {0, 0, 0, 0};
+  int cat_sh[4] = {0, 0, 0, 0};
+  int cat_n = 0;
   float* ctc_part = nullptr;
   int ctc_slots = 0;
   int group_m = 0;           // tile order: 0 = the column tiles of a pixel tile are neighbours (the whole weight slab streams past each pixel tile);

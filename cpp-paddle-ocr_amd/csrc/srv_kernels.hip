@@ -674,6 +674,7 @@ __global__ void __launch_bounds__(512) srv_conv3_kernel(const GemmArgs a) {
   const int gq = (lane & 7) ^ ((4 * wave + (lane >> 4)) & 7);
   const int npp = wave < G::PINSTR - 5 * NW ? 6 : 5;  // pieces of this wave
   unsigned pvo[6];
+  int piy[6], pix[6];  // (concatenated input: the piece's image pixel, -1 = outside)
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
     const int q = 8 * (wave + NW * i) + (lane >> 3);
@@ -681,6 +682,8 @@ __global__ void __launch_bounds__(512) srv_conv3_kernel(const GemmArgs a) {
     const int iy = ty0 - 1 + py, ix = tx0 - 1 + px;
     const bool ok = q < 324 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
     pvo[i] = ok ? (unsigned)(((unsigned long long)((long)img * a.H + iy) * a.W + ix) * (unsigned)a.Cin * 2ull) + (unsigned)(gq * 16) : SRV_OOB;
+    piy[i] = ok ? iy : -1;
+    pix[i] = ix;
   }
   unsigned wvo[WI];
 #pragma unroll
@@ -689,9 +692,27 @@ __global__ void __launch_bounds__(512) srv_conv3_kernel(const GemmArgs a) {
   int issued = 0;
   auto issue_patch = [&](int c) __attribute__((always_inline)) {
     const unsigned dst = lds0 + (unsigned)(c & 1) * PBUF;
+    if (a.cat_n) {  // channel tile c = source c of the concatenation, at (y >> sh, x >> sh) of its own map
+      const int cc = c < 3 ? c : 3;
+      const unsigned long long xb = (unsigned long long)a.cat_x[cc];
+      v4u rs_c;
+      rs_c.x = __builtin_amdgcn_readfirstlane((unsigned)xb);
+      rs_c.y = __builtin_amdgcn_readfirstlane((unsigned)(xb >> 32));
+      rs_c.z = __builtin_amdgcn_readfirstlane((unsigned)a.cat_bytes[cc]);
+      rs_c.w = 0x00020000u;
+      const int sh = a.cat_sh[cc], hc = a.H >> sh, wc = a.W >> sh;
 #pragma unroll
-    for (int i = 0; i < 6; ++i)
-      if (i < npp) srv_dma16(dst + (unsigned)(wave + NW * i) * 1024u, pvo[i], rs_x, (unsigned)c * 128u);
+      for (int i = 0; i < 6; ++i)
+        if (i < npp) {
+          const unsigned off = piy[i] < 0 ? SRV_OOB
+                                          : (unsigned)(((unsigned long long)((long)img * hc + (piy[i] >> sh)) * wc + (pix[i] >> sh)) * 128ull) + (unsigned)(gq * 16);
+          srv_dma16(dst + (unsigned)(wave + NW * i) * 1024u, off, rs_c, 0u);
+        }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+        if (i < npp) srv_dma16(dst + (unsigned)(wave + NW * i) * 1024u, pvo[i], rs_x, (unsigned)c * 128u);
+    }
     issued += npp;
   };
   auto issue_w = [&](int st) __attribute__((always_inline)) {  // K tiles 3 st .. 3 st + 2 = (channel tile st / 3, kernel row st % 3, dx = 0 .. 2)
@@ -824,6 +845,11 @@ static bool conv3_go(const GemmArgs& a, bool half, hipStream_t s, bool query, st
   using G = Conv3Geom<BN>;
   if (!half || !a.korder || a.KH != 3 || a.KW != 3 || a.SH != 1 || a.SW != 1 || a.PH != 1 || a.PW != 1 || a.Cin % 64 || a.cin_shift != -1 || a.deconv ||
       a.out_f32 || a.scale || a.res_up || a.OH != a.H || a.OW != a.W) { err = "the halo form takes f16 3x3 stride-1 convs on whole channel tiles"; return false; }
+  if (a.cat_n) {
+    if (a.cat_n != a.Cin / 64 || a.cat_n > 4) { err = "concatenated input: one 64-channel source per channel tile"; return false; }
+    for (int j = 0; j < a.cat_n; ++j)
+      if (a.cat_bytes[j] >= 0xfffffff0ull || ((a.H >> a.cat_sh[j]) << a.cat_sh[j]) != a.H || ((a.W >> a.cat_sh[j]) << a.cat_sh[j]) != a.W) { err = "concatenated input: source shape"; return false; }
+  }
   static LdsAttrMemo memo;
   if (!raise_dynamic_lds((const void*)srv_conv3_kernel<BN>, (int)G::LDS, memo)) { err = "dynamic LDS attribute refused"; return false; }
   if (query) return true;
@@ -892,6 +918,7 @@ static bool gemm_go(const GemmArgs& a, hipStream_t s, bool query, std::string& e
   auto kern = srv_gemm_kernel<T, BM, BN, WM, WN, NS>;
   static LdsAttrMemo memo;
   if (G::BIG && !(sizeof(T) == 2 && !a.deconv && !a.out_f32 && !a.scale)) { err = "a big tile has the register epilogue only"; return false; }
+  if (a.cat_n) { err = "a concatenated input: the halo form only"; return false; }
   if (a.ctc_part && !(a.out_f32 && !a.deconv && !a.res_up && !a.scale && a.act == SACT_NONE && a.ctc_slots >= (a.Ncols + 63) / 64)) { err = "CTC partials: a plain f32-output linear"; return false; }
   if (G::LDS > 64 * 1024 && !raise_dynamic_lds((const void*)kern, (int)G::LDS, memo)) { err = "dynamic LDS attribute refused"; return false; }
   if (query) return true;
@@ -910,7 +937,7 @@ static bool pgemm_go(const GemmArgs& a, hipStream_t s, bool query, std::string& 
   auto kern = srv_pgemm_kernel<T, BM, BN, WM, WN, 3, OF32>;
   static LdsAttrMemo memo;
   if (!a.x1) { err = "the persistent form takes 1x1 problems"; return false; }
-  if (a.ctc_part) { err = "the persistent form has no CTC epilogue"; return false; }
+  if (a.ctc_part || a.cat_n) { err = "the persistent form has neither the CTC epilogue nor a concatenated input"; return false; }
   if (a.res_up && (OF32 || a.res_bytes >= 0xfffffff0ull)) { err = "residual"; return false; }
   if (a.y_bytes >= 0xfffffff0ull) { err = "output beyond the 4 GB a buffer descriptor spans"; return false; }
   if (G::LDS > 64 * 1024 && !raise_dynamic_lds((const void*)kern, (int)G::LDS, memo)) { err = "dynamic LDS attribute refused"; return false; }

@@ -407,7 +407,7 @@ bool SrvNet::bind(int N, int H, int W, hipStream_t s, std::string& err) {
   }
   // ---- SVTR's MLP pairs as one launch (f16 build, production mode; srv_mlp.h): `linear C -> 4C | gelu` whose only reader is
   // `linear 4C -> C | + the first linear's input`: the hidden tensor then never exists (no arena slot, no launch of its own)
-  std::vector<char> mlp_head(ops_.size(), 0), mlp_tail(ops_.size(), 0), ht_head(ops_.size(), 0), ht_tail(ops_.size(), 0);
+  std::vector<char> mlp_head(ops_.size(), 0), mlp_tail(ops_.size(), 0), ht_head(ops_.size(), 0), ht_tail(ops_.size(), 0), cat_head(ops_.size(), 0);
   {
     // OCR_SRV_MLP=0: never; =all: every width; default: C <= 256 (measured, tools/micro/srv_mlp_probe + tools/srv_bench.py: 1.46 ms
     // against 1.60 for the two launches at C = 192, 1.22 against 1.20 at C = 256 with 1.5 / 1.0 GB less HBM traffic per launch;
@@ -446,6 +446,19 @@ bool SrvNet::bind(int N, int H, int W, hipStream_t s, std::string& err) {
       ht_head[oi] = 1;
       ht_tail[oi + 1] = 1;
     }
+    // ---- the DB neck's `concat up=8,4,2,1` folded into the 3x3 conv that is its only reader (f16 build, production mode): with the
+    // K order (channel tile, tap) channel tile j of that conv IS source j, and the halo form fetches tile j's patch from source j at
+    // (y >> sh, x >> sh) (GemmArgs::cat_*) - the 256-channel tensor (0.94 GB at batch 32) is neither written nor read.  OCR_SRV_CAT=0: a concat launch
+    static const bool cat_on = [] { const char* e = getenv("OCR_SRV_CAT"); return !(e && e[0] == '0'); }();
+    for (size_t oi = 0; half_ && cat_on && !keep_all_ && oi + 1 < ops_.size(); ++oi) {
+      const Op &c = ops_[oi], &v = ops_[oi + 1];
+      if (c.kind != "concat" || v.kind != "conv" || !v.korder || v.geti("i") != c.geti("o") || readers[c.geti("o")] != 1) continue;
+      if (v.geti("kh") != 3 || v.geti("kw") != 3 || v.geti("sh") != 1 || v.geti("sw") != 1 || v.geti("ph") != 1 || v.geti("pw") != 1 || v.res_tid >= 0 || v.scale) continue;
+      const int ns = (int)c.ins.size();
+      bool ok = ns >= 1 && ns <= 4 && v.cin_s == 64 * ns;
+      for (int j = 0; ok && j < ns; ++j) ok = c.ups[j] >= 1 && (c.ups[j] & (c.ups[j] - 1)) == 0;  // (shapes are checked at bind: 64 channels each)
+      if (ok) cat_head[oi] = 1;
+    }
   }
   // ---- arena: every tensor a slot of its own (keep_all) or first-fit reuse by last reader
   std::vector<int> last_use(ntensors_ + 1, -1);
@@ -460,7 +473,7 @@ bool SrvNet::bind(int N, int H, int W, hipStream_t s, std::string& err) {
   // a fused pair runs as ONE launch that writes the SECOND op's tensor: what the first op reads must outlive that tensor's allocation
   // (and is released then - the arena loop below skips a fused head, with it the releases that fall on its index)
   for (size_t oi = 0; oi + 1 < ops_.size(); ++oi)
-    if (ht_head[oi] || mlp_head[oi])
+    if (ht_head[oi] || mlp_head[oi] || cat_head[oi])
       for (int t = 0; t <= ntensors_; ++t)
         if (last_use[t] == (int)oi) last_use[t] = (int)oi + 1;
   {
@@ -496,7 +509,7 @@ bool SrvNet::bind(int N, int H, int W, hipStream_t s, std::string& err) {
       const Op& op = ops_[oi];
       if (op.kind == "output") continue;
       const int o = op.geti("o");
-      if (mlp_head[oi] || ht_head[oi]) { tensors_[o].n = 0; continue; }  // the hidden tensor of a fused MLP / the head's 64-channel map: never written
+      if (mlp_head[oi] || ht_head[oi] || cat_head[oi]) { tensors_[o].n = 0; continue; }  // the hidden tensor of a fused MLP / the head's 64-channel map: never written
       tensors_[o].offset = alloc(tensors_[o].bytes(half_));
       if (keep_all_) continue;
       for (int t = 1; t <= ntensors_; ++t)
@@ -531,6 +544,7 @@ bool SrvNet::bind(int N, int H, int W, hipStream_t s, std::string& err) {
     const bool hf = half_;
     Launch L;
     char nm[160];
+    if (op.kind == "concat" && cat_head[oi]) continue;  // gathered by the conv behind it
     if (op.kind == "concat") {
       const void* src[4] = {nullptr, nullptr, nullptr, nullptr};
       int ups[4] = {1, 1, 1, 1};
@@ -555,7 +569,15 @@ bool SrvNet::bind(int N, int H, int W, hipStream_t s, std::string& err) {
     }
     if (mlp_tail[oi] || ht_tail[oi]) continue;  // launched with its head
     const int itid = op.geti("i") == 0 ? pk : op.geti("i");
-    const SrvTensor& in = tensors_[itid];
+    const bool cat_in = oi > 0 && cat_head[oi - 1] && ops_[oi - 1].geti("o") == itid;
+    SrvTensor in_cat;
+    if (cat_in) {  // (the concatenation has no tensor: its shape from its sources)
+      const Op& c = ops_[oi - 1];
+      const SrvTensor& sl = tensors_[c.ins.back()];
+      in_cat.n = sl.n; in_cat.h = sl.h * c.ups.back(); in_cat.w = sl.w * c.ups.back();
+      in_cat.c = in_cat.cs = 64 * (int)c.ins.size();
+    }
+    const SrvTensor& in = cat_in ? in_cat : tensors_[itid];
     if (ht_head[oi]) {
       const Op& d2 = ops_[oi + 1];
       const SrvTensor& yt = tensors_[d2.geti("o")];
@@ -597,8 +619,21 @@ bool SrvNet::bind(int N, int H, int W, hipStream_t s, std::string& err) {
     const bool gemm = (op.kind == "conv" || op.kind == "linear" || op.kind == "deconv") && op.ncols > 0;
     if (gemm) {
       srv::GemmArgs a;
-      a.x = ptr(itid);
-      a.x_bytes = in.bytes(half_);
+      a.x = cat_in ? ptr(ops_[oi - 1].ins[0]) : ptr(itid);
+      a.x_bytes = cat_in ? tensors_[ops_[oi - 1].ins[0]].bytes(half_) : in.bytes(half_);
+      if (cat_in) {
+        const Op& c = ops_[oi - 1];
+        a.cat_n = (int)c.ins.size();
+        for (int j = 0; j < a.cat_n; ++j) {
+          const SrvTensor& sj = tensors_[c.ins[j]];
+          if (sj.cs != 64 || sj.c != 64 || sj.n != in.n || sj.h * c.ups[j] != in.h || sj.w * c.ups[j] != in.w) { err = "server plan: folded concat: source shapes"; return false; }
+          a.cat_x[j] = ptr(c.ins[j]);
+          a.cat_bytes[j] = sj.bytes(half_);
+          int sh_ = 0;
+          while ((1 << sh_) < c.ups[j]) ++sh_;
+          a.cat_sh[j] = sh_;
+        }
+      }
       a.w = op.wimg;
       a.w_bytes = op.wimg_bytes;
       a.y = ptr(o);
@@ -657,13 +692,19 @@ bool SrvNet::bind(int N, int H, int W, hipStream_t s, std::string& err) {
       }
       snprintf(nm, sizeof nm, "%zu.%s%dx%d_%d_%d_s%d%s@%dx%dx%d", oi, op.kind.c_str(), a.KH, a.KW, in.c, op.geti("cout"), a.SH * 10 + a.SW,
                op.res_tid >= 0 ? "_res" : "", ot.n, ot.h, ot.w);
-      const int cfg = tune(a, std::string(nm), s);
-      if (cfg < 0) { err = std::string("no tile configuration runs ") + nm; return false; }
-      L.name = std::string(nm) + (ctc_here ? "_ctc" : "") + "[" + srv::gemm_config_name(cfg) + "]";
+      const std::string lname = std::string(nm) + (ctc_here ? "_ctc" : "") + (cat_in ? "_cat" : "");  // (also the tuning key: these forms have their own candidates)
+      const int cfg = tune(a, lname, s);
+      if (cfg < 0) { err = std::string("no tile configuration runs ") + lname; return false; }
+      L.name = lname + "[" + srv::gemm_config_name(cfg) + "]";
       if (ctc_here) { ctc_slots_ = a.ctc_slots; ctc_step_ = std::max(1, srv::gemm_config_bn(cfg) / 64); }
       const double klog = (double)a.KH * a.KW * in.c;
       L.flops = 2.0 * (double)a.M * klog * (double)op.ncols;
-      L.bytes = (double)in.bytes(half_) + (double)ot.bytes(half_) + (double)op.ncols * klog * esz + (op.res_tid >= 0 ? (double)tensors_[op.res_tid].bytes(half_) / (op.res_up == 2 ? 1.0 : 1.0) : 0.0);
+      double in_bytes = (double)in.bytes(half_);
+      if (cat_in) {  // (what is read: the sources at their own resolutions)
+        in_bytes = 0;
+        for (int j = 0; j < a.cat_n; ++j) in_bytes += (double)a.cat_bytes[j];
+      }
+      L.bytes = in_bytes + (double)ot.bytes(half_) + (double)op.ncols * klog * esz + (op.res_tid >= 0 ? (double)tensors_[op.res_tid].bytes(half_) / (op.res_up == 2 ? 1.0 : 1.0) : 0.0);
       L.fn = [a, hf, cfg](hipStream_t st, std::string& e) { return srv::launch_gemm(a, hf, cfg, st, e); };
       launches_.push_back(L);
       ++gi;

@@ -411,3 +411,35 @@ def test_ctc_head_in_partial_mode_equals_logits_then_arg_max(pkg, built):
         for (ids_a, c_a), (ids_b, c_b) in zip(ia, ib):
             assert ids_a == ids_b
             assert abs(c_a - c_b) <= 2e-6, (c_a, c_b)
+
+
+def test_concat_folded_into_the_head_conv_gives_the_same_bits(pkg, built):
+    """The DB neck's `concat up=8,4,2,1` folded into the 3 x 3 conv that reads it (halo form: channel tile j of the conv's K order is
+    source j, its patch comes from source j at (y >> sh, x >> sh)) against the materialised concatenation: production mode folds,
+    OCR_SRV_CAT=0 (a child process) launches the concat.  Same values in the same accumulation order: the probability maps are
+    bit-identical; the timing report shows one `_cat` launch and no concat.  An image that is not a multiple of the 16 x 16 tile."""
+    import hashlib
+    import subprocess
+    import sys
+    _srv_ready()
+    child = r"""
+import sys, hashlib, numpy as np
+sys.path[:0] = [sys.argv[1], sys.argv[1] + "/tools"]
+import __graft_entry__ as ge
+pkg = ge.load_package()
+x = np.random.RandomState(81).randn(2, 160, 224, 3).astype(np.float32)
+net = pkg.SrvNet("det", "fp16")
+y = net.forward(x, keep_all=False)
+net.timing(True)
+net.forward(x, keep_all=False)
+names = " ".join(net.timing_report())
+net.close()
+print("CAT", hashlib.sha1(np.ascontiguousarray(y).view(np.uint8)).hexdigest(), names.count("_cat["), names.count(".concat_"))
+"""
+    out = {}
+    for k, env in (("fold", {}), ("concat", {"OCR_SRV_CAT": "0", "OCR_SRV_CFG": "20"})):
+        pr = subprocess.run([sys.executable, "-c", child, ROOT], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert pr.returncode == 0 and "CAT " in pr.stdout, (k, pr.stdout[-1500:], pr.stderr[-1500:])
+        out[k] = pr.stdout[pr.stdout.index("CAT ") + 4:].split()
+    assert out["fold"][1:] == ["1", "0"] and out["concat"][1:] == ["0", "1"], out
+    assert out["fold"][0] == out["concat"][0], out

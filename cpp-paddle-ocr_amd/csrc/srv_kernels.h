@@ -82,6 +82,11 @@ bool launch_gemm(const GemmArgs& a, bool half, int cfg, hipStream_t s, std::stri
 bool launch_mlp(const void* x, unsigned long long x_bytes, const void* w1, unsigned long long w1_bytes, int w1_npad, const void* w2,
                 unsigned long long w2_bytes, int w2_npad, const float* b1, const float* b2, void* y, long M, int C, hipStream_t s, bool query,
                 std::string& err);
+// the same with the LayerNorm of its input absorbed (srv_mlp.h MlpArgs::ln_*): x = the raw sum, w1 = the image of diag(gamma) W1
+struct MlpLn { const float *g = nullptr, *b = nullptr, *s = nullptr, *c = nullptr; float eps = 0.f; };
+bool launch_mlp_ln(const void* x, unsigned long long x_bytes, const void* w1, unsigned long long w1_bytes, int w1_npad, const void* w2,
+                   unsigned long long w2_bytes, int w2_npad, const MlpLn& ln, const float* b2, void* y, long M, int C, hipStream_t s, bool query,
+                   std::string& err);
 
 // f32 [N][H][W][3] (the normalised image, what the pre-processing kernels write) -> T [N][H][W][8], channels 3..7 zero
 void launch_pack_input(const float* x, void* y, long pixels, bool half, hipStream_t s);

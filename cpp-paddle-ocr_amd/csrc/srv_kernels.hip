@@ -996,18 +996,38 @@ bool gemm_config_ok(const GemmArgs& a, bool half, int cfg) {
 }
 bool launch_gemm(const GemmArgs& a, bool half, int cfg, hipStream_t s, std::string& err) { return gemm_dispatch(a, half, cfg, s, false, err); }
 
+static bool mlp_go(const MlpArgs& a, unsigned long long x_bytes, unsigned long long w1_bytes, unsigned long long w2_bytes, long M, int C, hipStream_t s, bool query,
+                   std::string& err);
 bool launch_mlp(const void* x, unsigned long long x_bytes, const void* w1, unsigned long long w1_bytes, int w1_npad, const void* w2,
                 unsigned long long w2_bytes, int w2_npad, const float* b1, const float* b2, void* y, long M, int C, hipStream_t s, bool query,
                 std::string& err) {
-  if (x_bytes >= 0xfffffff0ull || w1_bytes >= 0xfffffff0ull || w2_bytes >= 0xfffffff0ull) { err = "tensor beyond the 4 GB a buffer descriptor spans"; return false; }
   MlpArgs a{x, x_bytes, w1, w1_bytes, w1_npad, w2, w2_bytes, w2_npad, b1, b2, y, M};
+  return mlp_go(a, x_bytes, w1_bytes, w2_bytes, M, C, s, query, err);
+}
+bool launch_mlp_ln(const void* x, unsigned long long x_bytes, const void* w1, unsigned long long w1_bytes, int w1_npad, const void* w2,
+                   unsigned long long w2_bytes, int w2_npad, const MlpLn& ln, const float* b2, void* y, long M, int C, hipStream_t s, bool query,
+                   std::string& err) {
+  MlpArgs a{x, x_bytes, w1, w1_bytes, w1_npad, w2, w2_bytes, w2_npad, nullptr, b2, y, M};
+  a.ln_g = ln.g; a.ln_b = ln.b; a.ln_s = ln.s; a.ln_c = ln.c; a.ln_eps = ln.eps;
+  if (!query && !(ln.g && ln.b && ln.s && ln.c)) { err = "fused MLP: absorbed LayerNorm without its vectors"; return false; }
+  return mlp_go(a, x_bytes, w1_bytes, w2_bytes, M, C, s, query, err);
+}
+static bool mlp_go(const MlpArgs& a, unsigned long long x_bytes, unsigned long long w1_bytes, unsigned long long w2_bytes, long M, int C, hipStream_t s, bool query,
+                   std::string& err) {
+  if (x_bytes >= 0xfffffff0ull || w1_bytes >= 0xfffffff0ull || w2_bytes >= 0xfffffff0ull) { err = "tensor beyond the 4 GB a buffer descriptor spans"; return false; }
   const unsigned nb = (unsigned)((M + 127) / 128);
   static LdsAttrMemo m192, m256, m512;
   switch (C) {
 #define SRV_MLP_CASE(CC, memo)                                                                                              \
     case CC:                                                                                                                \
-      if (!raise_dynamic_lds((const void*)srv_mlp_kernel<CC>, (int)MlpGeom<CC>::LDS, memo)) { err = "dynamic LDS attribute refused"; return false; } \
-      if (!query) hipLaunchKernelGGL(srv_mlp_kernel<CC>, dim3(nb), dim3(512), MlpGeom<CC>::LDS, s, a);                      \
+      if (a.ln_g) {                                                                                                         \
+        static LdsAttrMemo memo_ln;                                                                                         \
+        if (!raise_dynamic_lds((const void*)srv_mlp_kernel<CC, true>, (int)MlpGeom<CC>::LDS, memo_ln)) { err = "dynamic LDS attribute refused"; return false; } \
+        if (!query) hipLaunchKernelGGL((srv_mlp_kernel<CC, true>), dim3(nb), dim3(512), MlpGeom<CC>::LDS, s, a);            \
+        return true;                                                                                                        \
+      }                                                                                                                     \
+      if (!raise_dynamic_lds((const void*)srv_mlp_kernel<CC, false>, (int)MlpGeom<CC>::LDS, memo)) { err = "dynamic LDS attribute refused"; return false; } \
+      if (!query) hipLaunchKernelGGL((srv_mlp_kernel<CC, false>), dim3(nb), dim3(512), MlpGeom<CC>::LDS, s, a);             \
       return true;
     SRV_MLP_CASE(192, m192)
     SRV_MLP_CASE(256, m256)

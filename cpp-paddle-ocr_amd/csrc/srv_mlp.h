@@ -27,6 +27,15 @@ struct MlpArgs {
   const float* b2;      // [C]
   void* y;              // [M][C] f16
   long M;
+  // LayerNorm of the INPUT absorbed (SVTR's post-norm: x = LN(u) feeds this MLP and nothing else): x = the raw sum u, w1 = the image of
+  // diag(gamma) W1, and with a token's mean m and rstd r (found here, from the X tiles of the first hidden chunk as they pass through LDS)
+  //   LN(u) W1 + b1 = r (u W1') - r m s + c,   s = column sums of W1' (as rounded to f16), c = beta W1 + b1     (ln_s, ln_c: [4 C])
+  // the residual is LN(u) = (u - m) r gamma + beta on the fly.  ln_g == nullptr: x is the MLP's input as it is, b1 its bias.
+  const float* ln_g = nullptr;
+  const float* ln_b = nullptr;
+  const float* ln_s = nullptr;
+  const float* ln_c = nullptr;
+  float ln_eps = 0.f;
   unsigned long long* clocks = nullptr;  // development probe (-DSRV_MLP_CLOCKS): [blocks][8 waves][8] shader cycles per phase
 };
 
@@ -39,12 +48,12 @@ struct MlpGeom {
   static constexpr int ROWS2 = C / SPLIT;              // output rows per fc2 stage
   static constexpr int SPC = NKT1 + 2 * SPLIT;         // stages per chunk
   static constexpr int TN2 = C / 64;                   // 32-row output blocks per wave
-  static constexpr unsigned SLOT = 32768u, HBUF = NS * SLOT, BIAS = HBUF + 32768u, LDS = BIAS + 1024u;  // BIAS: the chunk's 128 fc1 biases, two slots
+  static constexpr unsigned SLOT = 32768u, HBUF = NS * SLOT, BIAS = HBUF + 32768u, LDS = BIAS + 2048u;  // BIAS: the chunk's 128 fc1 biases, two slots (+ 1 KB: the column sums s of the absorbed LayerNorm)
   static constexpr int W1I = HC / 8 / NW, XI = BM / 8 / NW, W2I = (ROWS2 / 8 + NW - 1) / NW;  // DMA instructions per wave per stage
   static_assert(C % 64 == 0 && ROWS2 * 128 <= (int)SLOT && (ROWS2 / 8) % NW == 0, "stage fits a ring slot, every wave issues equally");
 };
 
-template <int C>
+template <int C, bool LN>  // LN: the LayerNorm of the input absorbed (MlpArgs::ln_*) - its own instantiation: the plain form's loops carry no test of it
 __global__ void __launch_bounds__(512) srv_mlp_kernel(const MlpArgs a) {
   using G = MlpGeom<C>;
   constexpr int BM = G::BM, NW = G::NW, NKT1 = G::NKT1, SPLIT = G::SPLIT, ROWS2 = G::ROWS2, SPC = G::SPC, TN2 = G::TN2, NCH = G::NCH;
@@ -58,9 +67,14 @@ __global__ void __launch_bounds__(512) srv_mlp_kernel(const MlpArgs a) {
   const int wn = wave >> 2, wm = wave & 3;
   const long m0 = (long)blockIdx.x * BM;
 
-  v4u rs_x, rs_w1, rs_w2, rs_b1;
+  v4u rs_x, rs_w1, rs_w2, rs_b1, rs_s;
   {
-    const unsigned long long b1b = (unsigned long long)a.b1;
+    const unsigned long long sb = (unsigned long long)a.ln_s;
+    rs_s.x = __builtin_amdgcn_readfirstlane((unsigned)sb);
+    rs_s.y = __builtin_amdgcn_readfirstlane((unsigned)(sb >> 32));
+    rs_s.z = (unsigned)(4 * C * 4);
+    rs_s.w = 0x00020000u;
+    const unsigned long long b1b = (unsigned long long)(a.ln_g ? a.ln_c : a.b1);  // (absorbed LayerNorm: c carries b1)
     rs_b1.x = __builtin_amdgcn_readfirstlane((unsigned)b1b);
     rs_b1.y = __builtin_amdgcn_readfirstlane((unsigned)(b1b >> 32));
     rs_b1.z = (unsigned)(4 * C * 4);
@@ -95,6 +109,10 @@ __global__ void __launch_bounds__(512) srv_mlp_kernel(const MlpArgs a) {
       // epilogue they cost two exposed L2 round trips per chunk (stamps: 5200 of a chunk's 9900 cycles in the GELU epilogue)
       srv_dma16(lds0 + BIAS + (unsigned)(i_c & 1) * 512u, lane < 32 ? (unsigned)(i_c * 512 + lane * 16) : SRV_OOB, rs_b1, 0u);
       issued += 1;
+      if (LN) {
+        srv_dma16(lds0 + BIAS + 1024u + (unsigned)(i_c & 1) * 512u, lane < 32 ? (unsigned)(i_c * 512 + lane * 16) : SRV_OOB, rs_s, 0u);
+        issued += 1;
+      }
     }
     if (i_s < NKT1) {  // fc1: W1 tile (rows = the chunk's hidden units, K tile i_s) | X tile (K tile i_s)
       const unsigned wso = (unsigned)(((unsigned long long)i_s * (unsigned)a.w1_npad + (unsigned)(i_c * G::HC)) * 128ull);
@@ -115,6 +133,7 @@ __global__ void __launch_bounds__(512) srv_mlp_kernel(const MlpArgs a) {
   };
 
   const int swz = (r >> 1) & 7;
+  float ln_s1 = 0.f, ln_s2 = 0.f, ln_mean = 0.f, ln_rstd = 1.f;
   f16x acc1[2], acc2[TN2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -177,6 +196,21 @@ __global__ void __launch_bounds__(512) srv_mlp_kernel(const MlpArgs a) {
 #pragma unroll
           for (int i = 0; i < 2; ++i) acc1[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[s & 1][i], fb[s & 1], acc1[i], 0, 0, 0);
         }
+        if constexpr (LN) {
+          if (c_c == 0) {  // the token's row sums, from the X tile of each of the first chunk's K tiles (this half-wave's channels) - read
+                           // again behind the matrix instructions: four more LDS reads per stage of the FIRST chunk, nothing in the loop above
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+              const h8v xf = *(const h8v*)(sx + (unsigned)(((2 * s + h) ^ swz) * 16));
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                const float f = (float)xf[e];
+                ln_s1 += f;
+                ln_s2 = fmaf(f, f, ln_s2);
+              }
+            }
+          }
+        }
 #ifdef SRV_MLP_CLOCKS
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         const unsigned long long ka = __builtin_readcyclecounter();
@@ -189,16 +223,35 @@ __global__ void __launch_bounds__(512) srv_mlp_kernel(const MlpArgs a) {
           unsigned char* hrow = smem + HBUF + (unsigned)wn * 16384u + (unsigned)t * 128u;
           const int tsw = (t >> 1) & 7;
           const float* bl = (const float*)(smem + BIAS + (unsigned)(c_c & 1) * 512u) + wn * 64 + 4 * h;
+          if (LN && c_c == 0) {  // (LN: compile time) every K tile of the token's row has passed: mean and rstd (the other half-wave holds the other channels)
+            float a1 = ln_s1, b1_ = ln_s1, a2 = ln_s2, b2_ = ln_s2;
+            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\tv_permlane32_swap_b32 %2, %3\n\ts_nop 1" : "+v"(a1), "+v"(b1_), "+v"(a2), "+v"(b2_));
+            ln_mean = (a1 + b1_) * (1.0f / (float)C);
+            ln_rstd = 1.0f / sqrtf(fmaxf((a2 + b2_) * (1.0f / (float)C) - ln_mean * ln_mean, 0.f) + a.ln_eps);
+          }
+          const float ln_nmr = -ln_rstd * ln_mean;
 #pragma unroll
           for (int i = 0; i < 2; ++i) {
 #pragma unroll
             for (int q = 0; q < 4; q += 2) {
               const f4v b4 = *(const f4v*)(bl + i * 32 + 8 * q), b5 = *(const f4v*)(bl + i * 32 + 8 * q + 8);
               float v[8];
+              if (LN) {  // r (u W1') - r m s + c
+                const f4v s4 = *(const f4v*)(bl + 256 + i * 32 + 8 * q), s5 = *(const f4v*)(bl + 256 + i * 32 + 8 * q + 8);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  v[e] = fmaf(acc1[i][4 * q + e], ln_rstd, fmaf(ln_nmr, s4[e], b4[e]));
+                  v[4 + e] = fmaf(acc1[i][4 * q + 4 + e], ln_rstd, fmaf(ln_nmr, s5[e], b5[e]));
+                }
+              } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  v[e] = acc1[i][4 * q + e] + b4[e];
+                  v[4 + e] = acc1[i][4 * q + 4 + e] + b5[e];
+                }
+              }
 #pragma unroll
               for (int e = 0; e < 4; ++e) {
-                v[e] = acc1[i][4 * q + e] + b4[e];
-                v[4 + e] = acc1[i][4 * q + 4 + e] + b5[e];
                 acc1[i][4 * q + e] = 0.f;
                 acc1[i][4 * q + 4 + e] = 0.f;
               }
@@ -302,10 +355,21 @@ __global__ void __launch_bounds__(512) srv_mlp_kernel(const MlpArgs a) {
         float bb[8], v[8];
         ld8(a.b2 + n, bb);
         const h8v rv = *(const h8v*)cell;
+        if (LN) {  // the residual is LN(u), normalised here
+          float gg[8], be[8];
+          ld8(a.ln_g + n, gg);
+          ld8(a.ln_b + n, be);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float t = acc2[i][8 * c + e] + bb[e];
-          v[e] = t + (float)rv[e];
+          for (int e = 0; e < 8; ++e) {
+            const float t = acc2[i][8 * c + e] + bb[e];
+            v[e] = t + (((float)rv[e] - ln_mean) * ln_rstd * gg[e] + be[e]);
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float t = acc2[i][8 * c + e] + bb[e];
+            v[e] = t + (float)rv[e];
+          }
         }
         h8v hv;
 #pragma unroll
@@ -345,6 +409,13 @@ __global__ void __launch_bounds__(512) srv_mlp_kernel(const MlpArgs a) {
       float bb[8], rv[8], v[8];
       ld8(a.b2 + n, bb);
       ld8((const _Float16*)a.x + m * C + n, rv);
+      if (LN) {
+        float gg[8], be[8];
+        ld8(a.ln_g + n, gg);
+        ld8(a.ln_b + n, be);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) rv[e] = (rv[e] - ln_mean) * ln_rstd * gg[e] + be[e];
+      }
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float t = acc2[i][8 * c + e] + bb[e];

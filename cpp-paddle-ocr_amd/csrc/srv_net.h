@@ -72,6 +72,10 @@ class SrvNet {
     const float *bias = nullptr, *scale = nullptr, *shift = nullptr, *p0 = nullptr, *p1 = nullptr;
     float fbias = 0;
     int act = 0, res_tid = -1, res_up = 0;
+    // fc1 of an MLP behind an `ln` (f16 build): the image of diag(gamma) W1 and the vectors of MlpArgs::ln_* (srv_mlp.h)
+    const void* wimg_ln = nullptr;
+    size_t wimg_ln_bytes = 0;
+    const float *ln_s = nullptr, *ln_c = nullptr;
     int korder = 0;                // GemmArgs::korder of this op's weight image
   };
   struct Launch {
@@ -81,6 +85,7 @@ class SrvNet {
   };
   bool parse(const char* text, std::string& err);
   bool prepare_op(Op& op, const WeightMap& w, std::string& err);
+  bool prepare_ln_fold(Op& fc1, const Op& ln, const WeightMap& w, std::string& err);
   bool bind(int N, int H, int W, hipStream_t s, std::string& err);
   int tune(const srv::GemmArgs& a, const std::string& key, hipStream_t s);
   void* upload_bytes(const void* p, size_t n);

@@ -267,11 +267,48 @@ bool SrvNet::prepare_op(Op& op, const WeightMap& W, std::string& err) {
   return true;
 }
 
+// An `ln` whose result feeds `linear C -> 4C | bias | gelu` (an MLP's fc1): LN(u) W1 + b1 = r (u W1') - r m s + c with W1' = diag(gamma) W1,
+// s = the column sums of W1' AS ROUNDED TO f16 (what the matrix instructions multiply), c = beta W1 + b1 (srv_mlp.h MlpArgs::ln_*)
+bool SrvNet::prepare_ln_fold(Op& fc1, const Op& ln, const WeightMap& W, std::string& err) {
+  auto find = [&](const std::string& n) -> const HostTensor* { auto it = W.find(n); return it == W.end() ? nullptr : &it->second; };
+  const HostTensor *w = find(fc1.kv["w"]), *g = find(ln.kv.at("g")), *b = find(ln.kv.at("b")), *b1 = nullptr;
+  for (const Stage& st : fc1.ep)
+    if (st.kind == "bias") b1 = find(st.a0);
+  const int cin = fc1.geti("cin"), cout = fc1.geti("cout");
+  if (!w || !g || !b || !b1 || (int)w->numel() != cin * cout || (int)g->numel() != cin || (int)b->numel() != cin || (int)b1->numel() != cout || cin % 8) return true;  // (no fold: the pair runs unfused)
+  std::vector<float> wnk((size_t)cout * cin), sv(cout), cv(cout);
+  for (int o = 0; o < cout; ++o) {
+    double ss = 0, cc = b1->data[o];
+    for (int c = 0; c < cin; ++c) {
+      const float wv = w->data[(size_t)c * cout + o] * g->data[c];
+      wnk[(size_t)o * cin + c] = wv;
+      ss += (double)(float)(_Float16)wv;
+      cc += (double)w->data[(size_t)c * cout + o] * (double)b->data[c];
+    }
+    sv[o] = (float)ss;
+    cv[o] = (float)cc;
+  }
+  int nkt = 0;
+  auto img = weight_image<_Float16>(wnk, cout, cin, fc1.npad, nkt);
+  fc1.wimg_ln_bytes = img.size() * sizeof(_Float16);
+  fc1.wimg_ln = upload_bytes(img.data(), fc1.wimg_ln_bytes);
+  fc1.ln_s = upload_f32(sv);
+  fc1.ln_c = upload_f32(cv);
+  if (!fc1.wimg_ln || !fc1.ln_s || !fc1.ln_c) { err = "device allocation failed"; return false; }
+  return true;
+}
+
 bool SrvNet::load(const char* plan_text, const WeightMap& weights, bool half, std::string& err) {
   half_ = half;
   if (!parse(plan_text, err)) return false;
   for (Op& op : ops_)
     if (!prepare_op(op, weights, err)) return false;
+  for (size_t oi = 0; half_ && oi + 1 < ops_.size(); ++oi) {
+    const Op& l = ops_[oi];
+    Op& f1 = ops_[oi + 1];
+    if (l.kind == "ln" && f1.kind == "linear" && f1.act == srv::SACT_GELU && f1.bias && !f1.scale && f1.res_tid < 0 && f1.geti("i") == l.geti("o") &&
+        f1.geti("cout") == 4 * f1.geti("cin") && !prepare_ln_fold(f1, l, weights, err)) return false;
+  }
   return true;
 }
 
@@ -407,7 +444,7 @@ bool SrvNet::bind(int N, int H, int W, hipStream_t s, std::string& err) {
   }
   // ---- SVTR's MLP pairs as one launch (f16 build, production mode; srv_mlp.h): `linear C -> 4C | gelu` whose only reader is
   // `linear 4C -> C | + the first linear's input`: the hidden tensor then never exists (no arena slot, no launch of its own)
-  std::vector<char> mlp_head(ops_.size(), 0), mlp_tail(ops_.size(), 0), ht_head(ops_.size(), 0), ht_tail(ops_.size(), 0), cat_head(ops_.size(), 0);
+  std::vector<char> mlp_head(ops_.size(), 0), mlp_tail(ops_.size(), 0), ht_head(ops_.size(), 0), ht_tail(ops_.size(), 0), cat_head(ops_.size(), 0), ln_abs(ops_.size(), 0);
   {
     // OCR_SRV_MLP=0: never; =all: every width; default: C <= 256 (measured, tools/micro/srv_mlp_probe + tools/srv_bench.py: 1.46 ms
     // against 1.60 for the two launches at C = 192, 1.22 against 1.20 at C = 256 with 1.5 / 1.0 GB less HBM traffic per launch;
@@ -432,6 +469,14 @@ bool SrvNet::bind(int N, int H, int W, hipStream_t s, std::string& err) {
       if (!srv::launch_mlp(nullptr, 0, nullptr, 0, 0, nullptr, 0, 0, nullptr, nullptr, nullptr, 0, c, nullptr, true, e)) continue;
       mlp_head[oi] = 1;
       mlp_tail[oi + 1] = 1;
+    }
+    // ---- the LayerNorm IN FRONT of a fused MLP absorbed into it (srv_mlp.h MlpArgs::ln_*): `ln` read by exactly the pair - fc1's input and
+    // fc2's residual.  The normalised tensor is then never written and the LayerNorm launch is gone.  OCR_SRV_MLPLN=0: a launch of its own
+    static const bool mlpln_on = [] { const char* e = getenv("OCR_SRV_MLPLN"); return !(e && e[0] == '0'); }();
+    for (size_t oi = 0; half_ && mlpln_on && !keep_all_ && oi + 2 < ops_.size(); ++oi) {
+      const Op &l = ops_[oi], &f1 = ops_[oi + 1];
+      if (l.kind != "ln" || !mlp_head[oi + 1] || !f1.wimg_ln || f1.geti("i") != l.geti("o") || readers[l.geti("o")] != 2 || l.geti("o") == out_tid_) continue;
+      ln_abs[oi] = 1;
     }
     // ---- the DB head's two transposed convs as one launch (f16 build, production mode; srv_kernels.hip head_tail_kernel):
     // `deconv 64 -> 64 | bias | relu` (batch norm folded) whose only reader is `deconv 64 -> 1 | bias | sigmoid`.  OCR_SRV_HEAD=0: two launches
@@ -476,6 +521,11 @@ bool SrvNet::bind(int N, int H, int W, hipStream_t s, std::string& err) {
     if (ht_head[oi] || mlp_head[oi] || cat_head[oi])
       for (int t = 0; t <= ntensors_; ++t)
         if (last_use[t] == (int)oi) last_use[t] = (int)oi + 1;
+  for (size_t oi = 0; oi + 2 < ops_.size(); ++oi)
+    if (ln_abs[oi]) {  // (after the loop above: the raw sum is read by the launch that writes fc2's tensor)
+      const int u = ops_[oi].geti("i") == 0 ? ntensors_ : ops_[oi].geti("i");
+      last_use[u] = std::max(last_use[u], (int)oi + 2);
+    }
   {
     struct Blk { size_t off, size; };
     std::vector<Blk> free_list;
@@ -509,7 +559,7 @@ bool SrvNet::bind(int N, int H, int W, hipStream_t s, std::string& err) {
       const Op& op = ops_[oi];
       if (op.kind == "output") continue;
       const int o = op.geti("o");
-      if (mlp_head[oi] || ht_head[oi] || cat_head[oi]) { tensors_[o].n = 0; continue; }  // the hidden tensor of a fused MLP / the head's 64-channel map: never written
+      if (mlp_head[oi] || ht_head[oi] || cat_head[oi] || ln_abs[oi]) { tensors_[o].n = 0; continue; }  // the hidden tensor of a fused MLP / the head's 64-channel map: never written
       tensors_[o].offset = alloc(tensors_[o].bytes(half_));
       if (keep_all_) continue;
       for (int t = 1; t <= ntensors_; ++t)
@@ -567,7 +617,7 @@ bool SrvNet::bind(int N, int H, int W, hipStream_t s, std::string& err) {
       launches_.push_back(L);
       continue;
     }
-    if (mlp_tail[oi] || ht_tail[oi]) continue;  // launched with its head
+    if (mlp_tail[oi] || ht_tail[oi] || ln_abs[oi]) continue;  // launched with its head (an absorbed LayerNorm: inside the MLP behind it)
     const int itid = op.geti("i") == 0 ? pk : op.geti("i");
     const bool cat_in = oi > 0 && cat_head[oi - 1] && ops_[oi - 1].geti("o") == itid;
     SrvTensor in_cat;
@@ -598,21 +648,31 @@ bool SrvNet::bind(int N, int H, int W, hipStream_t s, std::string& err) {
     if (mlp_head[oi]) {
       const Op& f2 = ops_[oi + 1];
       const SrvTensor& yt = tensors_[f2.geti("o")];
-      const int c = in.c;
-      snprintf(nm, sizeof nm, "%zu.mlp_%d_%d_%d@%dx%dx%d", oi, c, 4 * c, c, yt.n, yt.h, yt.w);
+      const bool lnin = oi > 0 && ln_abs[oi - 1];  // its input's LayerNorm absorbed: it reads the raw sum
+      const int xtid = lnin ? (ops_[oi - 1].geti("i") == 0 ? pk : ops_[oi - 1].geti("i")) : itid;
+      const SrvTensor& xt = tensors_[xtid];
+      const int c = xt.c;
+      snprintf(nm, sizeof nm, "%zu.mlp%s_%d_%d_%d@%dx%dx%d", oi, lnin ? "_ln" : "", c, 4 * c, c, yt.n, yt.h, yt.w);
       L.name = nm;
-      const double M_ = (double)in.pixels();
+      const double M_ = (double)xt.pixels();
       L.flops = 2.0 * 2.0 * M_ * c * 4.0 * c;
-      L.bytes = (double)in.bytes(half_) + (double)yt.bytes(half_) + 2.0 * 4.0 * c * c * esz;
-      const void* xs = ptr(itid);
+      L.bytes = (double)xt.bytes(half_) + (double)yt.bytes(half_) + 2.0 * 4.0 * c * c * esz;
+      const void* xs = ptr(xtid);
       void* dst = ptr(f2.geti("o"));
-      const unsigned long long xb = in.bytes(half_);
-      const void *w1 = op.wimg, *w2 = f2.wimg;
-      const unsigned long long w1b = op.wimg_bytes, w2b = f2.wimg_bytes;
+      const unsigned long long xb = xt.bytes(half_);
+      const void *w1 = lnin ? op.wimg_ln : op.wimg, *w2 = f2.wimg;
+      const unsigned long long w1b = lnin ? op.wimg_ln_bytes : op.wimg_bytes, w2b = f2.wimg_bytes;
       const int n1 = op.npad, n2 = f2.npad;
       const float *b1 = op.bias, *b2 = f2.bias;
-      const long M = in.pixels();
-      L.fn = [=](hipStream_t st, std::string& e) { return srv::launch_mlp(xs, xb, w1, w1b, n1, w2, w2b, n2, b1, b2, dst, M, c, st, false, e); };
+      const long M = xt.pixels();
+      if (lnin) {
+        const Op& l = ops_[oi - 1];
+        srv::MlpLn ln;
+        ln.g = l.p0; ln.b = l.p1; ln.s = op.ln_s; ln.c = op.ln_c; ln.eps = l.getf("eps");
+        L.fn = [=](hipStream_t st, std::string& e) { return srv::launch_mlp_ln(xs, xb, w1, w1b, n1, w2, w2b, n2, ln, b2, dst, M, c, st, false, e); };
+      } else {
+        L.fn = [=](hipStream_t st, std::string& e) { return srv::launch_mlp(xs, xb, w1, w1b, n1, w2, w2b, n2, b1, b2, dst, M, c, st, false, e); };
+      }
       launches_.push_back(L);
       continue;
     }

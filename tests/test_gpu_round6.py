@@ -225,22 +225,55 @@ def test_pool_under_a_mixed_size_stream_on_eight_logical_devices(pkg, built):
         assert sum(js["requests_per_worker"]) == 120 and min(js["requests_per_worker"]) > 0, js["requests_per_worker"]
 
 
+_MLP_CHILD = r"""
+import sys, numpy as np
+sys.path[:0] = [sys.argv[1], sys.argv[1] + "/tools"]
+import __graft_entry__ as ge
+pkg = ge.load_package()
+x = np.random.RandomState(21).randn(3, 48, 320, 3).astype(np.float32)
+net = pkg.SrvNet("rec", "fp16")
+plain = net.forward(x, keep_all=True)
+net.timing(True)
+fused = net.forward(x, keep_all=False)
+names = list(net.timing_report())
+net.close()
+d = np.abs(plain - fused)
+print("MLP", sum(".mlp_" in n for n in names), sum(".mlp_ln_" in n for n in names), sum(".ln_" in n for n in names), sum("_768_192_" in n or "_1024_256_" in n for n in names),
+      int(np.array_equal(plain.view(np.uint32), fused.view(np.uint32))), float(d.max()), float(np.abs(plain).max()), float((plain.argmax(-1) == fused.argmax(-1)).mean()))
+"""
+
+
+def _mlp_child(env):
+    import subprocess
+    import sys
+    pr = subprocess.run([sys.executable, "-c", _MLP_CHILD, ROOT], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+    assert pr.returncode == 0 and "MLP " in pr.stdout, (pr.stdout[-1500:], pr.stderr[-1500:])
+    f = pr.stdout[pr.stdout.index("MLP ") + 4:].split()
+    return dict(mlp=int(f[0]), mlp_ln=int(f[1]), ln=int(f[2]), unfused=int(f[3]), same_bits=int(f[4]), dmax=float(f[5]), scale=float(f[6]), argmax=float(f[7]))
+
+
 def test_fused_mlp_equals_the_two_launches(pkg, built):
     """SVTR's MLP as one kernel (csrc/srv_mlp.h: the 4 C wide hidden tensor stays in LDS) against the two GEMM launches it
     replaces: production mode fuses, keep_all mode materialises every tensor - the recognizer's logits are bit-identical
     (hidden values rounded to f16 once either way, fc2 accumulating them in ascending k), and the timing report shows the
-    fused launches."""
+    fused launches.  (OCR_SRV_MLPLN=0, a child process: the LayerNorm in front of the MLP stays a launch of its own - absorbed, the
+    arithmetic is another one: the next test.)"""
     _srv_ready()
-    x = np.random.RandomState(21).randn(3, 48, 320, 3).astype(np.float32)
-    net = pkg.SrvNet("rec", "fp16")
-    plain = net.forward(x, keep_all=True)
-    net.timing(True)
-    fused = net.forward(x, keep_all=False)
-    names = list(net.timing_report())
-    assert sum(".mlp_" in n for n in names) == 12, names[:8]       # the 3 + 9 blocks of width 192 and 256 (512: two launches)
-    assert not any("_768_192_" in n or "_1024_256_" in n for n in names)
-    assert np.array_equal(plain.view(np.uint32), fused.view(np.uint32)), float(np.abs(plain - fused).max())
-    net.close()
+    r = _mlp_child({"OCR_SRV_MLPLN": "0"})
+    assert r["mlp"] == 12 and r["mlp_ln"] == 0 and r["unfused"] == 0, r  # the 3 + 9 blocks of width 192 and 256 (512: two launches)
+    assert r["same_bits"] == 1, r
+
+
+def test_layernorm_absorbed_into_the_fused_mlp(pkg, built):
+    """The LayerNorm in front of a fused MLP absorbed into it: LN(u) W1 + b1 = r (u W1') - r m s + c with the folded image W1' = diag(gamma) W1,
+    the token's mean and rstd found in the kernel from the tiles it streams anyway, the residual normalised on the fly - the
+    normalised tensor is never written, twelve LayerNorm launches are gone.  Another (equally valid) f16 arithmetic than LayerNorm-then-
+    MLP: against the keep_all run (every op a launch) the logits agree to 3 % of their scale, the arg max on >= 95 % of the steps."""
+    _srv_ready()
+    base, absorbed = _mlp_child({"OCR_SRV_MLPLN": "0"}), _mlp_child({})
+    assert absorbed["mlp_ln"] == 12 and absorbed["mlp"] == 12 and absorbed["ln"] == base["ln"] - 12, (base, absorbed)  # (".mlp_" also counts ".mlp_ln_")
+    print("absorbed LayerNorm: max |d| %.3g of |logit| <= %.3g, arg max equal on %.4f" % (absorbed["dmax"], absorbed["scale"], absorbed["argmax"]))
+    assert absorbed["dmax"] <= 0.03 * absorbed["scale"] and absorbed["argmax"] >= 0.95, absorbed
 
 
 _CFG_CHILD = r"""

@@ -33,16 +33,17 @@ int main(int argc, char** argv) {
   hipMemcpy(dx, hx.data(), hx.size() * 2, hipMemcpyHostToDevice);
   hipMemcpy(dw1, w1.data(), w1.size() * 2, hipMemcpyHostToDevice);
   hipMemcpy(dw2, w2.data(), w2.size() * 2, hipMemcpyHostToDevice);
-  MlpArgs a{dx, hx.size() * 2, dw1, w1.size() * 2, pad(H), dw2, w2.size() * 2, pad(C), b1, b2, dy, M, clk};
+  MlpArgs a{dx, hx.size() * 2, dw1, w1.size() * 2, pad(H), dw2, w2.size() * 2, pad(C), b1, b2, dy, M};
+  a.clocks = clk;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   auto go = [&] {
-    if (C == 192) hipLaunchKernelGGL(srv_mlp_kernel<192>, dim3(nb), dim3(512), MlpGeom<192>::LDS, 0, a);
-    else if (C == 256) hipLaunchKernelGGL(srv_mlp_kernel<256>, dim3(nb), dim3(512), MlpGeom<256>::LDS, 0, a);
-    else hipLaunchKernelGGL(srv_mlp_kernel<512>, dim3(nb), dim3(512), MlpGeom<512>::LDS, 0, a);
+    if (C == 192) hipLaunchKernelGGL((srv_mlp_kernel<192, false>), dim3(nb), dim3(512), MlpGeom<192>::LDS, 0, a);
+    else if (C == 256) hipLaunchKernelGGL((srv_mlp_kernel<256, false>), dim3(nb), dim3(512), MlpGeom<256>::LDS, 0, a);
+    else hipLaunchKernelGGL((srv_mlp_kernel<512, false>), dim3(nb), dim3(512), MlpGeom<512>::LDS, 0, a);
   };
-  hipFuncSetAttribute((const void*)srv_mlp_kernel<192>, hipFuncAttributeMaxDynamicSharedMemorySize, MlpGeom<192>::LDS);
-  hipFuncSetAttribute((const void*)srv_mlp_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, MlpGeom<256>::LDS);
-  hipFuncSetAttribute((const void*)srv_mlp_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, MlpGeom<512>::LDS);
+  hipFuncSetAttribute((const void*)srv_mlp_kernel<192, false>, hipFuncAttributeMaxDynamicSharedMemorySize, MlpGeom<192>::LDS);
+  hipFuncSetAttribute((const void*)srv_mlp_kernel<256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, MlpGeom<256>::LDS);
+  hipFuncSetAttribute((const void*)srv_mlp_kernel<512, false>, hipFuncAttributeMaxDynamicSharedMemorySize, MlpGeom<512>::LDS);
   go(); hipDeviceSynchronize();
   hipEventRecord(e0); for (int i = 0; i < 3; ++i) go(); hipEventRecord(e1); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 3;

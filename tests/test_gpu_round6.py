@@ -256,21 +256,21 @@ def test_fused_mlp_equals_the_two_launches(pkg, built):
     """SVTR's MLP as one kernel (csrc/srv_mlp.h: the 4 C wide hidden tensor stays in LDS) against the two GEMM launches it
     replaces: production mode fuses, keep_all mode materialises every tensor - the recognizer's logits are bit-identical
     (hidden values rounded to f16 once either way, fc2 accumulating them in ascending k), and the timing report shows the
-    fused launches.  (OCR_SRV_MLPLN=0, a child process: the LayerNorm in front of the MLP stays a launch of its own - absorbed, the
-    arithmetic is another one: the next test.)"""
+    fused launches.  (The default: the LayerNorm in front of the MLP is a launch of its own; absorbed - OCR_SRV_MLPLN=1 - the arithmetic
+    is another one: the next test.)"""
     _srv_ready()
-    r = _mlp_child({"OCR_SRV_MLPLN": "0"})
+    r = _mlp_child({})
     assert r["mlp"] == 12 and r["mlp_ln"] == 0 and r["unfused"] == 0, r  # the 3 + 9 blocks of width 192 and 256 (512: two launches)
     assert r["same_bits"] == 1, r
 
 
 def test_layernorm_absorbed_into_the_fused_mlp(pkg, built):
-    """The LayerNorm in front of a fused MLP absorbed into it: LN(u) W1 + b1 = r (u W1') - r m s + c with the folded image W1' = diag(gamma) W1,
+    """OCR_SRV_MLPLN=1 (opt-in): the LayerNorm in front of a fused MLP absorbed into it: LN(u) W1 + b1 = r (u W1') - r m s + c with the folded image W1' = diag(gamma) W1,
     the token's mean and rstd found in the kernel from the tiles it streams anyway, the residual normalised on the fly - the
     normalised tensor is never written, twelve LayerNorm launches are gone.  Another (equally valid) f16 arithmetic than LayerNorm-then-
     MLP: against the keep_all run (every op a launch) the logits agree to 3 % of their scale, the arg max on >= 95 % of the steps."""
     _srv_ready()
-    base, absorbed = _mlp_child({"OCR_SRV_MLPLN": "0"}), _mlp_child({})
+    base, absorbed = _mlp_child({}), _mlp_child({"OCR_SRV_MLPLN": "1"})
     assert absorbed["mlp_ln"] == 12 and absorbed["mlp"] == 12 and absorbed["ln"] == base["ln"] - 12, (base, absorbed)  # (".mlp_" also counts ".mlp_ln_")
     print("absorbed LayerNorm: max |d| %.3g of |logit| <= %.3g, arg max equal on %.4f" % (absorbed["dmax"], absorbed["scale"], absorbed["argmax"]))
     assert absorbed["dmax"] <= 0.03 * absorbed["scale"] and absorbed["argmax"] >= 0.95, absorbed

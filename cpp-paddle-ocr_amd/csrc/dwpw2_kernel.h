@@ -351,6 +351,8 @@ __global__ void __launch_bounds__(256, LB) dwpw2_kernel(const DwPwArgs a) {
   // the depthwise result of item k into operand ob, the fragments of item k into the registers item k-1 has used up
   constexpr int ROWS = (PR - 1) * SH + K, NS = ROWS * K, D = TD, RS = D + 1, NM = C8S * NT * 4, NST = NS + 1;
   auto FUSED = [&](int rb, int ob) __attribute__((always_inline)) {
+    // (markers for build.py's ISA check: between them exactly C8S * NT vector loads - the fragment refills the counted waits assume)
+    asm volatile("; OCR_DWPW2_FUSED_BEGIN %0" ::"n"(C8S * NT));
     const char* reg = s_reg + rb * BUF;
     const char* col[K];
 #pragma unroll
@@ -419,6 +421,7 @@ __global__ void __launch_bounds__(256, LB) dwpw2_kernel(const DwPwArgs a) {
       });
       __builtin_amdgcn_sched_barrier(0);
     });
+    asm volatile("; OCR_DWPW2_FUSED_END");
     advanceB();
   };
 

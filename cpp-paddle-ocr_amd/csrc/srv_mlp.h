@@ -321,16 +321,19 @@ __global__ void __launch_bounds__(512) srv_mlp_kernel(const MlpArgs a) {
   // lanes, through 8 KB of LDS per wave (the ring's memory, one barrier).  In 32-byte pieces straight from the accumulator layout
   // (the first form) the PMC passes counted 1.55 GB fetched and 0.51 GB written per launch at C = 256 against 0.50 GB of tensors.
   constexpr int CPR = 4 * TN2;                       // 16-byte chunks of a token's half row (C / 2 channels)
-  constexpr bool LINES = (CPR & (CPR - 1)) == 0;     // (C = 192: 12 chunks - the piecewise form below)
+  constexpr bool POW2 = (CPR & (CPR - 1)) == 0;      // (C = 192: 12 chunks per half row - lanes walk the block's 384 chunks linearly, cells unswizzled)
+  constexpr bool LINES = (32 * CPR) % 64 == 0;
   if constexpr (LINES) {
-    constexpr int RPI = 64 / CPR, NI = 32 / RPI;     // rows per instruction, instructions per 32-token block
+    constexpr int NI = 32 * CPR / 64;                // instructions per 32-token block: lane l of instruction t = chunk 64 t + l of the block, row-major
     constexpr int RPB = CPR >= 16 ? 1 : 16 / CPR;    // rows per 256 bytes of LDS: the XOR term changes every RPB rows
     __syncthreads();                                 // (every wave is through with the ring and the hidden image)
     unsigned char* const scr = smem + (unsigned)wave * (unsigned)(32 * CPR * 16);
-    auto cell_of = [&](int row, int k) { return scr + (unsigned)row * (unsigned)(CPR * 16) + (unsigned)((k ^ ((row / RPB) & (CPR - 1))) * 16); };
+    auto cell_of = [&](int row, int k) {
+      return scr + (unsigned)row * (unsigned)(CPR * 16) + (unsigned)((POW2 ? (k ^ ((row / RPB) & (CPR - 1))) : k) * 16);
+    };
 #pragma unroll
     for (int t = 0; t < NI; ++t) {
-      const int row = t * RPI + lane / CPR, kk = lane % CPR;
+      const int row = (64 * t + lane) / CPR, kk = (64 * t + lane) % CPR;
       const long ml = m0 + wm * 32 + row;
       *(h8v*)cell_of(row, kk) = ml < a.M ? *(const h8v*)((const _Float16*)a.x + ml * C + wn * (C / 2) + 8 * kk) : h8v{0, 0, 0, 0, 0, 0, 0, 0};
     }
@@ -379,7 +382,7 @@ __global__ void __launch_bounds__(512) srv_mlp_kernel(const MlpArgs a) {
     }
 #pragma unroll
     for (int t = 0; t < NI; ++t) {
-      const int row = t * RPI + lane / CPR, kk = lane % CPR;
+      const int row = (64 * t + lane) / CPR, kk = (64 * t + lane) % CPR;
       const long ml = m0 + wm * 32 + row;
       const h8v hv = *(const h8v*)cell_of(row, kk);
       if (ml < a.M) *(h8v*)((_Float16*)a.y + ml * C + wn * (C / 2) + 8 * kk) = hv;

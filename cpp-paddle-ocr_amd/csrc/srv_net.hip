@@ -350,9 +350,11 @@ int SrvNet::tune(const srv::GemmArgs& a, const std::string& key, hipStream_t s) 
   int best = -1;
   if (forced >= 0 && srv::gemm_config_ok(a, half_, forced)) best = forced;
   if (best < 0 && !do_tune) {
-    // shape heuristic: the big tile where there are enough of them to fill the chip, thinner ones for thin layers
-    const long tiles_big = ((a.M + 255) / 256) * ((a.Ncols + 127) / 128);
-    const int pref[] = {a.Ncols <= 64 ? (a.M >= 256 * 512 ? 2 : 3) : (tiles_big >= 512 ? 0 : 1), 1, 3};
+    // shape heuristic (what the timed choices of the two server networks look like): 256 x 256 tiles where the product is wide and there
+    // are enough of them to fill the chip, 128 x 128 for the middle, 128 x 64 for thin layers; forms with one candidate (the halo form
+    // behind a folded concat) fall through to the timing loop below
+    const long tiles_256 = ((a.M + 255) / 256) * ((a.Ncols + 255) / 256);
+    const int pref[] = {a.Ncols <= 64 ? 3 : (a.Ncols >= 512 && tiles_256 >= 256 ? 12 : 1), 1, 3};
     for (int c : pref)
       if (srv::gemm_config_ok(a, half_, c)) { best = c; break; }
   }

@@ -329,15 +329,23 @@ __global__ void __launch_bounds__(64 * WM * WN) srv_gemm_kernel(const GemmArgs a
         if constexpr (HALF) res_l[j][t] = n < a.Cs_out ? *(const h8v*)((const _Float16*)a.res + rp * a.Cs_out + n) : h8v{0, 0, 0, 0, 0, 0, 0, 0};
       }
   };
-  if (direct) {
+  const bool ctc_regs = HALF && a.ctc_part != nullptr;  // the CTC head's partials, from the registers (below)
+  if (direct || ctc_regs) {
 #pragma unroll
     for (int i = 0; i < TN; ++i)
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
         const int n = n0 + wn * TN * 32 + i * 32 + 8 * h + 16 * c;
-        if (a.bias) ld8(a.bias + n, pre_b[i][c]);
-      }
-    if (PRE_R && a.res_up) fetch_res();
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pre_b[i][c][e] = 0.f;
+        if (a.bias && n + 8 <= a.Ncols) ld8(a.bias + n, pre_b[i][c]);
+        else if (a.bias) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (n + e < a.Ncols) pre_b[i][c][e] = a.bias[n + e];
+        }
+    }
+    if (direct && PRE_R && a.res_up) fetch_res();
   }
   // prologue: NS - 1 stages in flight
 #pragma unroll
@@ -417,6 +425,87 @@ __global__ void __launch_bounds__(64 * WM * WN) srv_gemm_kernel(const GemmArgs a
   // read as chunks (pixel r, chunk 4 i + 2 c + h); the result overwrites its chunk and leaves as lines.  Wave-private: LDS
   // executes a wave's instructions in order, no barrier inside.
   if constexpr (HALF) {
+    if (ctc_regs) {
+      // ---- CTC head (GemmArgs::ctc_part): no logits leave the workgroup.  A lane folds the 16 TN logits it holds of its row (bias added;
+      // columns past Ncols do not exist) into (max, first arg max, sum of exp(x - max)), its half-wave partner adds the other half, the
+      // WN waves of a pixel row meet in LDS, and one lane per row writes the column tile's partial.  Big tiles (256 x 256) may run this:
+      // nothing is staged
+      constexpr float L2E = 1.44269504088896341f;
+      __syncthreads();
+      float* const part = (float*)smem;  // [wave][j][row r] x (max, sum, arg max, -)
+      auto fold = [&](float& mx, float& sum, int& mi, float om, float os, int oi) __attribute__((always_inline)) {
+        const float M2 = fmaxf(mx, om);
+        const float sa = mx == -INFINITY ? 0.f : sum * __builtin_amdgcn_exp2f((mx - M2) * L2E);
+        const float sb = om == -INFINITY ? 0.f : os * __builtin_amdgcn_exp2f((om - M2) * L2E);
+        if (om > mx || (om == mx && oi < mi)) mi = oi;
+        mx = M2;
+        sum = sa + sb;
+      };
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+        float mx = -INFINITY, sum = 0.f;
+        int mi = 0x7fffffff;
+        // (the eight swaps of the storing epilogue first: the prefetched bias vectors are laid out for its chunks - registers 8 c + e of
+        // block i = columns 32 i + 16 c + 8 h + e, ascending in (i, c, e))
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+          f16x& A = acc[i][j];
+          float a0 = A[0], a1 = A[1], a2 = A[2], a3 = A[3], a4 = A[4], a5 = A[5], a6 = A[6], a7 = A[7];
+          float b0 = A[8], b1 = A[9], b2 = A[10], b3 = A[11], b4 = A[12], b5 = A[13], b6 = A[14], b7 = A[15];
+          asm volatile(
+              "s_nop 1\n\tv_permlane32_swap_b32 %0, %4\n\tv_permlane32_swap_b32 %1, %5\n\tv_permlane32_swap_b32 %2, %6\n\tv_permlane32_swap_b32 %3, %7\n\t"
+              "v_permlane32_swap_b32 %8, %12\n\tv_permlane32_swap_b32 %9, %13\n\tv_permlane32_swap_b32 %10, %14\n\tv_permlane32_swap_b32 %11, %15\n\ts_nop 1"
+              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3),
+                "+v"(b4), "+v"(b5), "+v"(b6), "+v"(b7));
+          A[0] = a0; A[1] = a1; A[2] = a2; A[3] = a3; A[4] = a4; A[5] = a5; A[6] = a6; A[7] = a7;
+          A[8] = b0; A[9] = b1; A[10] = b2; A[11] = b3; A[12] = b4; A[13] = b5; A[14] = b6; A[15] = b7;
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            const int n = n0 + wn * TN * 32 + i * 32 + 8 * h + 16 * c;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float v = n + e < a.Ncols ? A[8 * c + e] + pre_b[i][c][e] : -INFINITY;
+              A[8 * c + e] = v;
+              if (v > mx) { mx = v; mi = n + e; }  // (ascending columns within the lane: the first maximum stays)
+            }
+          }
+        }
+        if (mx != -INFINITY) {
+#pragma unroll
+          for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) sum += __builtin_amdgcn_exp2f((acc[i][j][q] - mx) * L2E);
+        }
+        {
+          float am = mx, bm = mx, as = sum, bs = sum;
+          float ai = __int_as_float(mi), bi = ai;  // the other half-wave's lanes hold the same rows' other columns
+          asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\tv_permlane32_swap_b32 %2, %3\n\tv_permlane32_swap_b32 %4, %5\n\ts_nop 1"
+                       : "+v"(am), "+v"(bm), "+v"(as), "+v"(bs), "+v"(ai), "+v"(bi));
+          // after the swap a lane of half 0 holds (its own, the partner's) in (a, b), a lane of half 1 (the partner's, its own)
+          const float om = h ? am : bm, os = h ? as : bs;
+          const int oi = __float_as_int(h ? ai : bi);
+          fold(mx, sum, mi, om, os, oi);
+        }
+        if (h == 0) *(f4v*)(part + ((wave * TM + j) * 32 + r) * 4) = f4v{mx, sum, __int_as_float(mi), 0.f};
+      }
+      __syncthreads();
+      if (wn == 0 && h == 0) {
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+          const long m = m0 + wm * TM * 32 + j * 32 + r;
+          f4v p4 = *(const f4v*)(part + (((wm * WN) * TM + j) * 32 + r) * 4);
+          float mx = p4[0], sum = p4[1];
+          int mi = __float_as_int(p4[2]);
+#pragma unroll
+          for (int w2 = 1; w2 < WN; ++w2) {
+            p4 = *(const f4v*)(part + (((wm * WN + w2) * TM + j) * 32 + r) * 4);
+            fold(mx, sum, mi, p4[0], p4[1], __float_as_int(p4[2]));
+          }
+          if (m < a.M) *(f4v*)(a.ctc_part + ((size_t)m * (size_t)a.ctc_slots + (size_t)(n0 >> 6)) * 4) = f4v{mx, sum, __int_as_float(mi), 0.f};
+        }
+      }
+      return;
+    }
     if (direct) {
       __syncthreads();
       constexpr int RPB = TN >= 4 ? 1 : 4 / TN;                   // pixel rows per 256 bytes of LDS: the XOR term changes every RPB rows
@@ -509,47 +598,6 @@ __global__ void __launch_bounds__(64 * WM * WN) srv_gemm_kernel(const GemmArgs a
   constexpr int CP = BN / 8;  // 8-channel chunks per pixel row of the tile
   const int ch = tid % CP;
   const int n = n0 + 8 * ch;
-  if (a.ctc_part) {
-    // ---- CTC head: the row's partial of this column tile instead of its logits.  The CP chunk threads of a row are consecutive
-    // lanes: each folds its eight logits (bias added; columns past Ncols do not exist), then log2(CP) exchanges fold the row
-    constexpr float L2E = 1.44269504088896341f;
-    float pb[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) pb[e] = a.bias && n + e < a.Ncols ? a.bias[n + e] : 0.f;
-    for (int p = tid / CP; p < BM; p += NT / CP) {
-      const long m = m0 + p;
-      if (m >= a.M) break;  // (the same for every chunk thread of the row)
-      const f4v lo = *(const f4v*)(tile + p * SP + 8 * ch), hi = *(const f4v*)(tile + p * SP + 8 * ch + 4);
-      float v[8];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { v[e] = lo[e] + pb[e]; v[4 + e] = hi[e] + pb[4 + e]; }
-      float mx = -INFINITY;
-      int mi = 0x7fffffff;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        if (n + e >= a.Ncols) v[e] = -INFINITY;
-        if (v[e] > mx) { mx = v[e]; mi = n + e; }
-      }
-      float sum = 0.f;
-      if (mx != -INFINITY) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) sum += __builtin_amdgcn_exp2f((v[e] - mx) * L2E);
-      }
-#pragma unroll
-      for (int o = 1; o < CP; o <<= 1) {
-        const float om = __shfl_xor(mx, o), os = __shfl_xor(sum, o);
-        const int oi = __shfl_xor(mi, o);
-        const float M2 = fmaxf(mx, om);
-        const float sa = mx == -INFINITY ? 0.f : sum * __builtin_amdgcn_exp2f((mx - M2) * L2E);
-        const float sb = om == -INFINITY ? 0.f : os * __builtin_amdgcn_exp2f((om - M2) * L2E);
-        if (om > mx || (om == mx && oi < mi)) mi = oi;
-        mx = M2;
-        sum = sa + sb;
-      }
-      if (ch == 0) *(f4v*)(a.ctc_part + ((size_t)m * (size_t)a.ctc_slots + (size_t)(n0 >> 6)) * 4) = f4v{mx, sum, __int_as_float(mi), 0.f};
-    }
-    return;
-  }
   const int ncols_store = a.deconv ? a.Ncols : a.Cs_out;
   if (n >= ncols_store) return;
   float pbias[8], pscale[8], pshift[8];
@@ -917,7 +965,8 @@ static bool gemm_go(const GemmArgs& a, hipStream_t s, bool query, std::string& e
   using G = GemmGeom<T, BM, BN, WM, WN, NS>;
   auto kern = srv_gemm_kernel<T, BM, BN, WM, WN, NS>;
   static LdsAttrMemo memo;
-  if (G::BIG && !(sizeof(T) == 2 && !a.deconv && !a.out_f32 && !a.scale)) { err = "a big tile has the register epilogue only"; return false; }
+  if (G::BIG && !(sizeof(T) == 2 && !a.deconv && !a.scale && (!a.out_f32 || a.ctc_part))) { err = "a big tile has the register epilogues only"; return false; }
+  if (a.ctc_part && sizeof(T) != 2) { err = "CTC partials: f16 build"; return false; }
   if (a.cat_n) { err = "a concatenated input: the halo form only"; return false; }
   if (a.ctc_part && !(a.out_f32 && !a.deconv && !a.res_up && !a.scale && a.act == SACT_NONE && a.ctc_slots >= (a.Ncols + 63) / 64)) { err = "CTC partials: a plain f32-output linear"; return false; }
   if (G::LDS > 64 * 1024 && !raise_dynamic_lds((const void*)kern, (int)G::LDS, memo)) { err = "dynamic LDS attribute refused"; return false; }

@@ -172,12 +172,12 @@ struct GemmGeom {
   static constexpr int SP = BN + 4;  // epilogue tile: floats per pixel row (+4: consecutive pixels 16 bytes apart in the bank row)
   // BIG: a tile whose f32 epilogue image would not fit LDS (256 x 256) - such a configuration has the register epilogue only
   // (f16 build, no transposed conv, no f32 output, no scale / shift pair: gemm_go refuses the rest) and fetches its residual where it is used
-  static constexpr bool BIG = (unsigned)(BM * SP * 4) > 160u * 1024u;
+  static constexpr bool BIG = (unsigned)(BM * SP * 4) > 160u * 1024u || NT % (BN / 8) != 0;  // (or a 192-column tile: the staged form's thread -> chunk map needs NT % (BN / 8) == 0)
   static constexpr unsigned LDS = BIG ? NS * STG : ((NS * STG > (unsigned)(BM * SP * 4)) ? NS * STG : (unsigned)(BM * SP * 4));
   static_assert(BN % (32 * WN) == 0 && BM % (32 * WM) == 0, "wave tiles are whole 32 x 32 blocks");
   static_assert((BN / 8) % NW == 0 && (BM / 8) % NW == 0, "every wave issues the same number of DMA instructions per stage");
   static_assert(NW % 2 == 0, "the swizzle term of a lane's DMA rows must not depend on the instruction index");
-  static_assert(NT % (BN / 8) == 0, "a thread keeps its channel chunk over the rows of the store loop");
+  static_assert((32 * 4 * TN) % 64 == 0, "a 32-pixel block of a wave is a whole number of 64-chunk store instructions");
 };
 
 template <typename T, int BM, int BN, int WM, int WN, int NS>
@@ -308,7 +308,15 @@ __global__ void __launch_bounds__(64 * WM * WN) srv_gemm_kernel(const GemmArgs a
   const bool direct = HALF && !a.deconv && !a.out_f32 && !a.scale;
   constexpr bool PRE_R = !G::BIG;  // (a 256 x 256 tile's residual is 64 registers per lane: fetched when the K loop is over instead)
   // line layout of a wave's 32-pixel block (the epilogue below): CPR 16-byte chunks per pixel row, lane -> (row t RPI + lane / CPR, chunk lane % CPR)
-  constexpr int CPR = 4 * TN, RPI = 64 / CPR, NI = 32 / RPI;
+  // (lane l of instruction t = chunk 64 t + l of the block, row-major; CPR a power of two - 64 / CPR whole rows per instruction - or 12)
+  constexpr int CPR = 4 * TN, NI = 32 * CPR / 64;
+  constexpr bool CPOW2 = (CPR & (CPR - 1)) == 0;
+  constexpr int RPB = TN >= 4 ? 1 : (CPOW2 ? 4 / TN : 1);  // pixel rows per 256 bytes of LDS: the XOR term changes every RPB rows
+  auto l_row = [&](int t) __attribute__((always_inline)) { return (64 * t + lane) / CPR; };
+  auto l_chk = [&](int t) __attribute__((always_inline)) { return (64 * t + lane) % CPR; };
+  auto cell_off = [&](int row, int k) __attribute__((always_inline)) {  // a 16-byte cell of a wave's block image (unswizzled where CPR is 12)
+    return (unsigned)row * (unsigned)(CPR * 16) + (unsigned)((CPOW2 ? (k ^ ((row / RPB) & (CPR - 1))) : k) * 16);
+  };
   float pre_b[TN][2][8];
   h8v res_l[TM][NI];
   auto fetch_res = [&]() __attribute__((always_inline)) {
@@ -316,8 +324,8 @@ __global__ void __launch_bounds__(64 * WM * WN) srv_gemm_kernel(const GemmArgs a
     for (int j = 0; j < TM; ++j)
 #pragma unroll
       for (int t = 0; t < NI; ++t) {
-        const long m = m0 + wm * TM * 32 + j * 32 + t * RPI + lane / CPR;
-        const int n = n0 + wn * TN * 32 + 8 * (lane % CPR);
+        const long m = m0 + wm * TM * 32 + j * 32 + l_row(t);
+        const int n = n0 + wn * TN * 32 + 8 * l_chk(t);
         long rp = m < a.M ? m : a.M - 1;
         if (a.res_up == 2) {
           const int ohw = a.OH * a.OW;
@@ -508,7 +516,6 @@ __global__ void __launch_bounds__(64 * WM * WN) srv_gemm_kernel(const GemmArgs a
     }
     if (direct) {
       __syncthreads();
-      constexpr int RPB = TN >= 4 ? 1 : 4 / TN;                   // pixel rows per 256 bytes of LDS: the XOR term changes every RPB rows
       unsigned char* const scr = smem + (unsigned)wave * (unsigned)(32 * CPR * 16);
       if (!PRE_R && a.res_up) fetch_res();
 #pragma unroll
@@ -516,10 +523,7 @@ __global__ void __launch_bounds__(64 * WM * WN) srv_gemm_kernel(const GemmArgs a
         // the residual arrives the way the output leaves - whole lines (fetched before the K loop) - and takes the same block the other way round
         if (a.res_up) {
 #pragma unroll
-          for (int t = 0; t < NI; ++t) {
-            const int row = t * RPI + lane / CPR, kk = lane % CPR;
-            *(h8v*)(scr + (unsigned)row * (unsigned)(CPR * 16) + (unsigned)((kk ^ ((row / RPB) & (CPR - 1))) * 16)) = res_l[j][t];
-          }
+          for (int t = 0; t < NI; ++t) *(h8v*)(scr + cell_off(l_row(t), l_chk(t))) = res_l[j][t];
         }
 #pragma unroll
         for (int i = 0; i < TN; ++i) {
@@ -547,7 +551,7 @@ __global__ void __launch_bounds__(64 * WM * WN) srv_gemm_kernel(const GemmArgs a
               for (int e = 0; e < 8; ++e) v[e] = v[e] + pre_b[i][c][e];
             }
             const int k = 4 * i + 2 * c + h;
-            unsigned char* const cell = scr + (unsigned)r * (unsigned)(CPR * 16) + (unsigned)((k ^ ((r / RPB) & (CPR - 1))) * 16);
+            unsigned char* const cell = scr + cell_off(r, k);
             if (a.res_up) {
               const h8v rv = *(const h8v*)cell;
 #pragma unroll
@@ -567,8 +571,8 @@ __global__ void __launch_bounds__(64 * WM * WN) srv_gemm_kernel(const GemmArgs a
         }
 #pragma unroll
         for (int t = 0; t < NI; ++t) {
-          const int row = t * RPI + lane / CPR, kk = lane % CPR;
-          const h8v hv = *(const h8v*)(scr + (unsigned)row * (unsigned)(CPR * 16) + (unsigned)((kk ^ ((row / RPB) & (CPR - 1))) * 16));
+          const int row = l_row(t), kk = l_chk(t);
+          const h8v hv = *(const h8v*)(scr + cell_off(row, kk));
           const long m = m0 + wm * TM * 32 + j * 32 + row;
           const int n = n0 + wn * TN * 32 + 8 * kk;
 #ifdef SRV_PROBE_NOSTORE
@@ -939,6 +943,11 @@ struct GemmCfg { const char* name; int bm, bn, nt; unsigned lds_h, lds_f; };
 #define SRV_BCFGS(X)         \
   X(12, 256, 256, 2, 4, 2)   \
   X(13, 256, 256, 4, 2, 2)
+// 192-column tiles (f16 build, register epilogues only): SVTR's qkv widths are multiples of 192 (576, 768, 1536) - a 128-column tile
+// leaves the last column tile of 576 half empty, and these launches' time goes with their tile COUNT (ids follow the table's order)
+#define SRV_BCFGS2(X)        \
+  X(21, 128, 192, 2, 2, 2)   \
+  X(22, 256, 192, 4, 2, 2)
 static const GemmCfg g_cfgs[] = {
 #define X(id, BM, BN, WM, WN, NS) {#BM "x" #BN "/" #WM "x" #WN "/s" #NS, BM, BN, 64 * WM * WN, GemmGeom<_Float16, BM, BN, WM, WN, NS>::LDS, GemmGeom<float, BM, BN, WM, WN, NS>::LDS},
     SRV_CFGS(X)
@@ -954,6 +963,9 @@ static const GemmCfg g_cfgs[] = {
 #undef X
 #define X(id, BN) {"halo16x16x" #BN, 256, BN, 512, Conv3Geom<BN>::LDS, 0u},
     SRV_HCFGS(X)
+#undef X
+#define X(id, BM, BN, WM, WN, NS) {#BM "x" #BN "/" #WM "x" #WN "/s" #NS, BM, BN, 64 * WM * WN, GemmGeom<_Float16, BM, BN, WM, WN, NS>::LDS, GemmGeom<float, 128, 128, 2, 2, 2>::LDS},
+    SRV_BCFGS2(X)
 #undef X
 };
 int gemm_num_configs() { return (int)(sizeof(g_cfgs) / sizeof(g_cfgs[0])); }
@@ -1034,6 +1046,11 @@ static bool gemm_dispatch(const GemmArgs& a, bool half, int cfg, hipStream_t s, 
     case id * 2 + 1: return conv3_go<BN>(a, true, s, query, err); \
     case id * 2: err = "the halo form is f16 only"; return false;
     SRV_HCFGS(X)
+#undef X
+#define X(id, BM, BN, WM, WN, NS)                                                   \
+    case id * 2 + 1: return gemm_go<_Float16, BM, BN, WM, WN, NS>(a, s, query, err); \
+    case id * 2: return gemm_go<float, 128, 128, 2, 2, 2>(a, s, query, err);
+    SRV_BCFGS2(X)
 #undef X
   }
   err = "no such tile configuration";

@@ -306,7 +306,7 @@ def test_every_tile_configuration_gives_the_same_bits(pkg, built):
     _srv_ready()
     cfgs = [("", "", {}), ("0", "256x128/2x4", {}), ("4", "128x256/1x8", {}), ("6", "256x128/4x2", {}), ("9", "64x64/2x2", {}),
             ("12", "256x256/2x4", {}), ("13", "256x256/4x2", {}), ("14", "128x64/4x1", {}), ("15", "128x128/4x2", {}), ("16", "256x64/4x1", {}),
-            ("3", "128x64/2x2", {}), ("1", "128x128/2x2", {}), ("20", "halo16x16x64", {})]
+            ("3", "128x64/2x2", {}), ("1", "128x128/2x2", {}), ("20", "halo16x16x64", {}), ("21", "128x192/2x2", {}), ("22", "256x192/4x2", {})]
     pending, running, res = list(enumerate(cfgs)), [], {}
     while pending or running:
         while pending and len(running) < 4:

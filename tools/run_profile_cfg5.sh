@@ -43,7 +43,9 @@ try:
     bk, bms = bl["roofline"]["kernel"], bl["roofline"]["ms_per_launch"]
     import re
     m = re.search(r"\.mlp_(\d+)_", bk)
-    cands = [r for r in rows if (("srv_mlp_kernel<%s>" % m.group(1)) in r["Name"] if m else abs(float(r["AverageNs"]) / 1e6 - bms) <= 0.1 * bms)]
+    lnv = "true" if ".mlp_ln_" in bk else "false"
+    cands = [r for r in rows if ((("srv_mlp_kernel<%s>" % m.group(1)) in r["Name"] or ("srv_mlp_kernel<%s, %s>" % (m.group(1), lnv)) in r["Name"]) if m
+                                 else abs(float(r["AverageNs"]) / 1e6 - bms) <= 0.1 * bms)]
     if len(cands) == 1:
         r = cands[0]; nm = r["Name"][:120]
         f, w = fe.get(nm, [0, 1]), wr.get(nm, [0, 1])

@@ -42,7 +42,7 @@ try:
     bl = json.loads([l for l in open(O + "/bench_line.json") if l.startswith("{")][-1])
     bk, bms = bl["roofline"]["kernel"], bl["roofline"]["ms_per_launch"]
     import re
-    m = re.search(r"\.mlp_(\d+)_", bk)
+    m = re.search(r"\.mlp(?:_ln)?_(\d+)_", bk)
     lnv = "true" if ".mlp_ln_" in bk else "false"
     cands = [r for r in rows if ((("srv_mlp_kernel<%s>" % m.group(1)) in r["Name"] or ("srv_mlp_kernel<%s, %s>" % (m.group(1), lnv)) in r["Name"]) if m
                                  else abs(float(r["AverageNs"]) / 1e6 - bms) <= 0.1 * bms)]

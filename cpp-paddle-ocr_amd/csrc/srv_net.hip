@@ -339,16 +339,16 @@ int SrvNet::tune(const srv::GemmArgs& a, const std::string& key, hipStream_t s) 
   auto it = tuned_.find(key);
   if (it != tuned_.end()) return it->second;
   const std::string fkey = std::string(half_ ? "fp16 " : "fp32 ") + key;
-  {
+  static const bool do_tune = [] { const char* e = getenv("OCR_SRV_TUNE"); return !(e && e[0] == '0'); }();
+  static const int forced = [] { const char* e = getenv("OCR_SRV_CFG"); return e && *e ? atoi(e) : -1; }();
+  int best = -1;
+  if (forced >= 0 && srv::gemm_config_ok(a, half_, forced)) best = forced;  // (a forced configuration goes before the file's)
+  if (best < 0) {
     std::lock_guard<std::mutex> lk(g_tune_mu);
     auto& fc = tune_file_cache();
     auto fi = fc.find(fkey);
     if (fi != fc.end() && srv::gemm_config_ok(a, half_, fi->second)) { tuned_[key] = fi->second; return fi->second; }
   }
-  static const bool do_tune = [] { const char* e = getenv("OCR_SRV_TUNE"); return !(e && e[0] == '0'); }();
-  static const int forced = [] { const char* e = getenv("OCR_SRV_CFG"); return e && *e ? atoi(e) : -1; }();
-  int best = -1;
-  if (forced >= 0 && srv::gemm_config_ok(a, half_, forced)) best = forced;
   if (best < 0 && !do_tune) {
     // shape heuristic (what the timed choices of the two server networks look like): 256 x 256 tiles where the product is wide and there
     // are enough of them to fill the chip, 128 x 128 for the middle, 128 x 64 for thin layers; forms with one candidate (the halo form

@@ -11,6 +11,11 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tools")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (runs the HIP path through the C-ABI)")
+    # the server networks time their tile configurations per (layer, shape) at bind: one file for the whole run, so that the tests'
+    # many handles and child processes time a layer once (OCR_SRV_TUNE_FILE; every configuration gives the same bits)
+    if "OCR_SRV_TUNE_FILE" not in os.environ:
+        import tempfile
+        os.environ["OCR_SRV_TUNE_FILE"] = os.path.join(tempfile.gettempdir(), "ocr_srv_tune_%d.txt" % os.getpid())
 
 
 @pytest.fixture(scope="session")
